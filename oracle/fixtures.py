@@ -1,0 +1,78 @@
+"""Seed recipes shared by oracle/gen_golden.py (reference side) and tests (oracle / HIP side).
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Weights and inputs are functions of
+integer seeds only, independent of module construction order, so the reference, the
+oracle and the HIP path can all be fed bit-identical tensors without shipping them.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+CASES = OrderedDict([
+    # name: (trainer, nf, nb, n (dataloader batch), lr_size, fs, d_in_nc)
+    ('cfg1_sr_nf32_nb4_b2_64', dict(kind='sr', nf=32, nb=4, n=2, lr=64)),
+    ('sr_nf64_nb2_b2_32', dict(kind='sr', nf=64, nb=2, n=2, lr=32)),
+    ('sr_nf64_nb1_b1_24x40', dict(kind='sr', nf=64, nb=1, n=1, lr=(24, 40))),
+    ('dasr_wavelet_nf32_nb2_n2_32', dict(kind='dasr', nf=32, nb=2, n=2, lr=32, fs='wavelet', d_in_nc=9)),
+    ('dasr_gau9_nf64_nb1_n1_32', dict(kind='dasr', nf=64, nb=1, n=1, lr=32, fs='gau', d_in_nc=3)),
+])
+
+
+def seeded_state_dict(template_sd, seed, scale):
+    """kaiming-normal(fan_in)*scale weights / zero biases, one generator per key index."""
+    out = OrderedDict()
+    for i, (k, v) in enumerate(template_sd.items()):
+        if v.dim() == 4:
+            fan_in = v.shape[1] * v.shape[2] * v.shape[3]
+            g = torch.Generator().manual_seed(seed * 100003 + i)
+            out[k] = torch.randn(v.shape, generator=g) * (math.sqrt(2.0 / fan_in) * scale)
+        elif k.endswith('bias'):
+            g = torch.Generator().manual_seed(seed * 100003 + i)
+            out[k] = (torch.rand(v.shape, generator=g) - 0.5) * 0.02  # non-zero so bias paths are exercised
+        else:
+            out[k] = v.clone()
+    return out
+
+
+def make_opt(case):
+    c = CASES[case] if isinstance(case, str) else case
+    opt = {
+        'is_train': True, 'gpu_ids': None, 'scale': 4, 'chop': False, 'val_lpips': False,
+        'model': 'sr' if c['kind'] == 'sr' else 'DASR', 'multiweights': True,
+        'path': {'pretrain_model_G': None, 'pretrain_model_D_target': None, 'pretrain_model_D_source': None,
+                 'models': '/tmp/dasr_golden', 'training_state': '/tmp/dasr_golden'},
+        'network_G': {'which_model_G': 'RRDB_net', 'norm_type': None, 'mode': 'CNA', 'nf': c['nf'], 'nb': c['nb'],
+                      'in_nc': 3, 'out_nc': 3, 'gc': 32, 'scale': 4},
+        'train': {'lr_G': 1e-4, 'weight_decay_G': 0, 'beta1_G': 0.9, 'lr_scheme': 'MultiStepLR',
+                  'lr_steps': [2, 4], 'lr_gamma': 0.5, 'pixel_criterion': 'l1', 'pixel_weight': 1.0,
+                  'manual_seed': 0},
+    }
+    if c['kind'] == 'dasr':
+        opt['network_D'] = {'which_model_D': 'discriminator_patch', 'norm_type': 'Batch', 'act_type': 'leakyrelu',
+                            'mode': 'CNA', 'nf': 64, 'in_nc': c['d_in_nc'], 'n_layers': 2}
+        opt['train'].update({'lr_D': 1e-4, 'weight_decay_D': 0, 'beta1_D': 0.9, 'fs': c['fs'], 'fs_kernel_size': 9,
+                             'norm': True, 'sup_LL': True, 'pixel_LL_weight': 1, 'feature_criterion': 'l1',
+                             'feature_weight': 1, 'gan_type': 'vanilla', 'ragan': False, 'gan_H_target': 0.01,
+                             'gan_H_source': 0, 'G_update_inter': 1, 'D_update_inter': 1})
+    return opt
+
+
+def make_batch(case, seed=1234):
+    """Synthetic batch dict: torch.rand from Generator(seed)."""
+    c = CASES[case] if isinstance(case, str) else case
+    g = torch.Generator().manual_seed(seed)
+    n = c['n']
+    h, w = (c['lr'], c['lr']) if isinstance(c['lr'], int) else c['lr']
+    if c['kind'] == 'sr':
+        return {'LR': torch.rand(n, 3, h, w, generator=g), 'HR': torch.rand(n, 3, 4 * h, 4 * w, generator=g)}
+    return {'LR_fake': torch.rand(n, 3, h, w, generator=g), 'LR_real': torch.rand(n, 3, h, w, generator=g),
+            'HR': torch.rand(n, 3, 4 * h, 4 * w, generator=g), 'HR_unpair': torch.rand(n, 3, 4 * h, 4 * w, generator=g),
+            'fake_w': torch.rand(n, 1, h, w, generator=g)}
+
+
+def subsample(t, k=64):
+    """Deterministic k-element strided sub-sample of a tensor (flattened)."""
+    f = t.detach().flatten()
+    step = max(1, f.numel() // k)
+    return f[::step][:k].clone()
