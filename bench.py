@@ -1,0 +1,156 @@
+#!/usr/bin/env python
+"""Headline benchmark: SR train images/sec (4x, 128->512) of the SRN generator step on MI355X.
+
+Workload at N=1 (BASELINE.json configs[1]): RRDBNet nf=64 nb=23 (ESRGAN), batch 16 of 128x128 LR crops,
+generator-only L1 step (forward + backward + Adam + weight repack), synthetic torch.rand data
+(Generator seed 1234 + rank), kaiming x0.1 weights under torch.manual_seed(0).  With --gpus N the same
+per-GPU batch runs on every rank (weak scaling) with an RCCL all-reduce of the gradients.
+
+Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel (3x3 dense-block conv, Cout=32, bf16 MFMA)
+timed in isolation with HIP events on the launch stream; `cpu_baseline` = the oracle (fp32 PyTorch restatement
+of the reference step) timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TFLOP_PER_IMAGE_TRAIN = 1.762  # 3 x 587.43 GFLOP per 128x128 LR image (nf64/nb23)
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def make_opt(nf, nb):
+    return {'is_train': True, 'gpu_ids': [0], 'scale': 4, 'chop': False, 'val_lpips': False, 'model': 'sr', 'name': 'bench',
+            'path': {'pretrain_model_G': None, 'models': '/tmp', 'training_state': '/tmp'},
+            'network_G': {'which_model_G': 'RRDB_net', 'norm_type': None, 'mode': 'CNA', 'nf': nf, 'nb': nb, 'in_nc': 3,
+                          'out_nc': 3, 'gc': 32, 'scale': 4},
+            'train': {'lr_G': 2e-4, 'lr_scheme': 'MultiStepLR', 'lr_steps': [70000, 150000], 'lr_gamma': 0.5,
+                      'pixel_criterion': 'l1', 'pixel_weight': 1.0, 'manual_seed': 0}}
+
+
+def roofline_dominant_kernel(model, plan, reps=5):
+    """Time the Cout=32 dense-block conv kernel (conv1..conv4 of one RDB: Cin 64/96/128/160) in isolation."""
+    from dasr_amd.engine import OpList
+    from dasr_amd import _lib
+    convs = [o for o in plan.fwd.ops if o.op == _lib.OP_CONV and o.conv.prec == 1 and o.conv.cout == 32][:4]
+    ol = OpList()
+    for o in convs:
+        ol.add(o)
+    flops = sum(2.0 * o.conv.N * o.conv.Hout * o.conv.Wout * 9 * o.conv.cin * o.conv.cout for o in convs)
+    ol.run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ol.run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+            'kernel': 'conv_kernel<prec1,bf16,mt1,3x3,s1> (RDB conv1-4, Cout=32)', 'avg_launch_us': round(ms * 1e3 / len(convs), 1),
+            'flops_per_launch_avg': flops / len(convs)}
+
+
+def cpu_baseline(nf, nb, lr_size):
+    """oracle (port of the reference step) on the host cores, bounded sample: batch 1, 1 warm-up + 1 timed step."""
+    from oracle import nets, trainers
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    opt = make_opt(nf, nb)
+    torch.manual_seed(0)
+    t = trainers.SRTrainer(opt)
+    g = torch.Generator().manual_seed(1234)
+    data = {'LR': torch.rand(1, 3, lr_size, lr_size, generator=g), 'HR': torch.rand(1, 3, 4 * lr_size, 4 * lr_size, generator=g)}
+    t.feed_data(data)
+    t.optimize_parameters(1)
+    t0 = time.time()
+    t.optimize_parameters(2)
+    dt = time.time() - t0
+    return {'value': round(1.0 / dt, 4), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
+            'sample': 'oracle SRTrainer nf%d nb%d, batch 1 x %dx%d LR, 1 warm-up + 1 timed step (%.1f s), fp32 torch CPU' % (nf, nb, lr_size, lr_size, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=16, help='LR crops per GPU per step')
+    ap.add_argument('--lr-size', type=int, default=128)
+    ap.add_argument('--nf', type=int, default=64)
+    ap.add_argument('--nb', type=int, default=23)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    from dasr_amd import options
+    from dasr_amd.dist import DataParallelGroup
+    from dasr_amd.models import create_model
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dp = DataParallelGroup() if world > 1 else None
+    rank = dp.rank if dp else 0
+    if dp:
+        torch.cuda.set_device(dp.local_rank)
+    torch.manual_seed(0)
+    model = create_model(options.dict_to_nonedict(make_opt(a.nf, a.nb)))
+    if dp:
+        model.dp = dp
+        dp.broadcast_params(model.netG.params.flat)
+        model.netG.repack()
+    g = torch.Generator().manual_seed(1234 + rank)
+    data = {'LR': torch.rand(a.batch, 3, a.lr_size, a.lr_size, generator=g).cuda(),
+            'HR': torch.rand(a.batch, 3, 4 * a.lr_size, 4 * a.lr_size, generator=g).cuda()}
+    step = 0
+    for _ in range(a.warmup):
+        step += 1
+        model.update_learning_rate()
+        model.feed_data(data)
+        model.optimize_parameters(step)
+    torch.cuda.synchronize()
+    if dp:
+        dp.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step += 1
+        model.update_learning_rate()
+        model.feed_data(data)
+        model.optimize_parameters(step)
+    torch.cuda.synchronize()
+    if dp:
+        dp.barrier()
+    dt = time.perf_counter() - t0
+    if dp:
+        dt = dp.max_over_ranks(dt)
+    loss = model.get_current_log()['l_pix']
+    if rank != 0:
+        return
+    n_gpus = world
+    ips = a.batch * n_gpus * a.steps / dt
+    full = (a.nf == 64 and a.nb == 23 and a.lr_size == 128)
+    out = {'metric': 'SR train images/sec (4x, 128->512)', 'value': round(ips, 3), 'unit': 'images/s', 'n_gpus': n_gpus,
+           'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2), 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16 MFMA operands, fp32 accumulate / fp32 residual stream',
+           'data': 'synthetic (torch.rand, seed 1234+rank; kaiming x0.1 weights, seed 0)',
+           'config': {'workload': 'configs[1]: RRDBNet nf=%d nb=%d 4x SR, batch %d of %dx%d LR per GPU, generator-only L1 step '
+                                  '(fwd+bwd+Adam)' % (a.nf, a.nb, a.batch, a.lr_size, a.lr_size),
+                      'global_batch': a.batch * n_gpus, 'parallelism': 'dp%d' % n_gpus},
+           'final_loss': loss}
+    if full:
+        out['mfma_util_step'] = round(ips * TFLOP_PER_IMAGE_TRAIN / PEAK_BF16_TFLOPS, 4)
+    plan = model.netG.plan(a.batch, a.lr_size, a.lr_size)
+    out['roofline'] = roofline_dominant_kernel(model, plan)
+    if n_gpus == 1 and not a.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(a.nf, a.nb, a.lr_size)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,111 @@
+"""ctypes binding of libdasr_hip.so (include/dasr_hip.h).  Fails loudly when the library is missing:
+there is no CPU / PyTorch fallback on the product path."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libdasr_hip.so')
+
+c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class Tensor(C.Structure):
+    _fields_ = [('p', c_vp), ('n_stride', c_i64), ('cb_stride', c_i64)]
+
+
+class ConvParams(C.Structure):
+    _fields_ = [('inp', Tensor), ('in_f32', c_i32), ('Hin', c_i32), ('Win', c_i32), ('ups', c_i32), ('cin', c_i32),
+                ('w', c_vp), ('w_lo_off', c_i64), ('bias', c_vp),
+                ('cout', c_i32), ('Hout', c_i32), ('Wout', c_i32), ('N', c_i32),
+                ('kh', c_i32), ('stride', c_i32), ('pad', c_i32), ('prec', c_i32), ('mt', c_i32),
+                ('act', c_i32), ('slope', c_f32),
+                ('mask', Tensor), ('mask_f32', c_i32),
+                ('alpha', c_f32), ('res1', Tensor), ('beta1', c_f32), ('res2', Tensor), ('beta2', c_f32),
+                ('out_f32', Tensor), ('out_bf16', Tensor), ('gamma', c_f32)]
+
+
+class WgradPart(C.Structure):
+    _fields_ = [('g', Tensor), ('g_f32', c_i32), ('inp', Tensor), ('in_f32', c_i32), ('ups', c_i32), ('n_ctiles', c_i32),
+                ('g_planes', c_i32), ('in_planes', c_i32),
+                ('Hin', c_i32), ('Win', c_i32), ('Hout', c_i32), ('Wout', c_i32), ('N', c_i32),
+                ('kh', c_i32), ('stride', c_i32), ('pad', c_i32), ('want_bias', c_i32),
+                ('ws_off', c_i64), ('ws_bias_off', c_i64)]
+
+
+class WgradReducePart(C.Structure):
+    _fields_ = [('ws_off', c_i64), ('ws_bias_off', c_i64), ('nsplit', c_i32), ('ntaps', c_i32), ('oc0', c_i32), ('c0', c_i32),
+                ('cout', c_i32), ('cin', c_i32), ('n_ctiles', c_i32), ('dst_w_off', c_i64), ('dst_b_off', c_i64),
+                ('flip_io', c_i32)]
+
+
+class PackSeg(C.Structure):
+    _fields_ = [('src_off', c_i64), ('src_cout', c_i32), ('src_cin', c_i32), ('cin_start', c_i32), ('cin_len', c_i32),
+                ('src_c0', c_i32), ('transpose', c_i32)]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [('dst_off', c_i64), ('lo_off', c_i64), ('cout', c_i32), ('cin_pad', c_i32), ('ntaps', c_i32), ('mt', c_i32),
+                ('nseg', c_i32), ('seg', PackSeg * 5)]
+
+
+class Op(C.Structure):
+    _fields_ = [('op', c_i32), ('i', c_i32 * 8), ('f', c_f32 * 4), ('l', c_i64 * 4), ('p', c_vp * 4), ('t', Tensor * 5),
+                ('conv', ConvParams)]
+
+
+OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_DOWNSUM, OP_AXPBY, OP_FILL, OP_L1LOSS, OP_NCHW2B, OP_B2NCHW = range(1, 11)
+OP_BCE, OP_INORM_FWD, OP_INORM_BWD, OP_DWT_FWD, OP_DWT_BWD, OP_GAUSS, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_L1DIFF, OP_VGGNORM = range(11, 21)
+
+_SIGS = {
+    'dasr_conv': [C.POINTER(ConvParams), c_vp],
+    'dasr_conv_naive': [C.POINTER(ConvParams), c_vp, c_vp],
+    'dasr_wgrad': [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
+    'dasr_wgrad_set_mode': [c_i32],
+    'dasr_wgrad_reduce': [c_vp, c_i32, c_vp, c_vp, c_f32, c_vp],
+    'dasr_pack_weights': [c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp],
+    'dasr_nchw_to_blocked': [c_vp, c_i32, c_i32, c_i32, c_i32, Tensor, Tensor, c_vp],
+    'dasr_blocked_to_nchw': [Tensor, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
+    'dasr_l1_loss': [Tensor, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, Tensor, c_i32, c_vp],
+    'dasr_downsum2x': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_f32, Tensor, Tensor, c_vp],
+    'dasr_axpby': [Tensor, c_f32, Tensor, c_f32, c_i32, c_i32, c_i32, c_i32, Tensor, Tensor, c_f32, c_vp],
+    'dasr_adam': [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp],
+    'dasr_fill_f32': [c_vp, c_i64, c_f32, c_vp],
+    'dasr_run_ops': [c_vp, c_i32, c_vp],
+    'dasr_last_failed_op': [],
+    'dasr_abi_version': [],
+    'dasr_probe_tr16': [c_vp],
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class DasrHipError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    """Names every entry point include/dasr_hip.h declares (used by the CPU symbol test)."""
+    return sorted(_SIGS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DasrHipError('libdasr_hip.so is missing (%s): run `python -m dasr_amd.build` or __graft_entry__.build(); '
+                               'the DASR MI355X path has no fallback.' % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.argtypes = args
+            fn.restype = c_i32
+        if L.dasr_abi_version() != ABI_VERSION:
+            raise DasrHipError('libdasr_hip.so ABI %d != binding ABI %d; rebuild' % (L.dasr_abi_version(), ABI_VERSION))
+        _lib = L
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise DasrHipError('%s failed with code %d' % (what or 'dasr call', rc))

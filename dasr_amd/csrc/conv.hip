@@ -1,0 +1,365 @@
+// Implicit-GEMM convolution (forward / data-gradient) for gfx950.
+//
+// GEMM view: D[oc][pixel] = sum_{tap, c} W[oc][tap][c] * X[pixel + tap][c]
+//   A operand = packed weights (32 oc x 16 c per MFMA), B operand = activations (16 c x 32 pixels),
+//   v_mfma_f32_32x32x16_bf16, fp32 accumulate.  The output fragment then holds, per lane, one pixel
+//   and 4x4 consecutive output channels -> vector stores into the NC16HW16 layout.
+// Workgroup = 4 waves; spatial tile TH x TW output pixels; each wave owns NT n-tiles (32 pixels each)
+// and MT m-tiles (32 output channels each).  Input channels are consumed in chunks of 16 (one MFMA
+// k-step per tap): the (TH-1)*S+KH by (TW-1)*S+KH input halo tile of the chunk and the chunk's
+// weights are staged in LDS (im2col-free: the taps are just shifted LDS reads with immediate offsets).
+// prec 3 ("split bf16"): x = hi + lo with hi = bf16(x), lo = bf16(x - hi); hi*hi + hi*lo + lo*hi
+// gives ~2^-17 relative operand error with three bf16 MFMAs (16x faster than the f32 MFMA).
+#include "common.h"
+
+namespace {
+
+template <int PREC, bool IN_F32, int MT, int KH, int STRIDE, int NT_>
+struct Cfg {
+    static constexpr int NT = NT_;
+    static constexpr int RPT = STRIDE == 1 ? 1 : 2;    // output rows per n-tile
+    static constexpr int CPT = STRIDE == 1 ? 32 : 16;  // output cols per n-tile
+    static constexpr int TH = 4 * NT * RPT;
+    static constexpr int TW = CPT;
+    static constexpr int IH = (TH - 1) * STRIDE + KH;
+    static constexpr int IW = (TW - 1) * STRIDE + KH;
+    static constexpr int NTAPS = KH * KH;
+    static constexpr int PIXB = 48;  // 32 B of bf16 + 16 B pad: conflict-free ds_read_b128 (3 slots/pixel)
+    static constexpr int ACT_BYTES = IH * IW * PIXB;
+    static constexpr int W_BYTES = NTAPS * MT * 1024;
+    static constexpr int NARR = PREC == 3 ? 2 : 1;
+    static constexpr int LDS_BYTES = NARR * (ACT_BYTES + W_BYTES);
+    // staging pieces (16 B of global memory each)
+    static constexpr int PPP = IN_F32 ? 4 : 2;  // pieces per pixel
+    static constexpr int NPIECE = IH * IW * PPP;
+    static constexpr int AR = (NPIECE + 255) / 256;
+    static constexpr int WPIECE = NTAPS * MT * 64;
+    static constexpr int WR = (WPIECE + 255) / 256;
+};
+
+template <int PREC, bool IN_F32, int MT, int KH, int STRIDE, int NT>
+__global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) {
+    using C = Cfg<PREC, IN_F32, MT, KH, STRIDE, NT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* act_hi = smem;
+    char* act_lo = smem + C::ACT_BYTES;  // only PREC 3
+    char* w_hi = smem + C::NARR * C::ACT_BYTES;
+    char* w_lo = w_hi + C::W_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cout_tiles = (p.cout + 31) >> 5;
+    const int MG = (cout_tiles + MT - 1) / MT;
+    const int tiles_x = (p.Wout + C::TW - 1) / C::TW, tiles_y = (p.Hout + C::TH - 1) / C::TH;
+    int bid = blockIdx.x;
+    const int mg = bid % MG;
+    bid /= MG;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int n = bid / tiles_y;
+    const int oy0 = ty * C::TH, ox0 = tx * C::TW;
+    const int iy0 = oy0 * STRIDE - p.pad, ix0 = ox0 * STRIDE - p.pad;
+    const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
+    const int nchunks = p.cin >> 4;
+
+    // ---- per-thread staging offsets (independent of the chunk) ----
+    int goff[C::AR];  // element offset inside a plane, -1: zero fill
+    int loff[C::AR];  // LDS byte offset
+#pragma unroll
+    for (int r = 0; r < C::AR; ++r) {
+        const int q = tid + r * 256;
+        const int pix = q / C::PPP, piece = q - pix * C::PPP;
+        const int iy = pix / C::IW, ix = pix - iy * C::IW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        const bool ok = q < C::NPIECE && gy >= 0 && gy < HL && gx >= 0 && gx < WL;
+        const int sy = p.ups ? (gy >> 1) : gy, sx = p.ups ? (gx >> 1) : gx;
+        goff[r] = ok ? (sy * p.Win + sx) * 16 + piece * (IN_F32 ? 4 : 8) : -1;
+        loff[r] = q < C::NPIECE ? pix * C::PIXB + piece * (IN_F32 ? 8 : 16) : -1;
+    }
+    const char* in_base = (const char*)p.in.p + (size_t)n * p.in.n_stride * (IN_F32 ? 4 : 2);
+    const size_t in_cb_bytes = (size_t)p.in.cb_stride * (IN_F32 ? 4 : 2);
+    const bf16_t* wg = (const bf16_t*)p.w + (size_t)mg * nchunks * C::NTAPS * MT * 512;
+
+    u32x4 areg[C::AR];
+    u32x4 wreg[C::WR * C::NARR];
+
+    auto load_chunk = [&](int ck) {
+        const char* plane = in_base + ck * in_cb_bytes;
+#pragma unroll
+        for (int r = 0; r < C::AR; ++r) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (goff[r] >= 0) v = *(const u32x4*)(plane + (size_t)goff[r] * (IN_F32 ? 4 : 2));
+            areg[r] = v;
+        }
+        const bf16_t* wc = wg + (size_t)ck * C::NTAPS * MT * 512;
+#pragma unroll
+        for (int r = 0; r < C::WR; ++r) {
+            int q = tid + r * 256;
+            q = q < C::WPIECE ? q : C::WPIECE - 1;  // clamp (the store below is predicated)
+            wreg[r] = *(const u32x4*)(wc + (size_t)q * 8);
+            if constexpr (PREC == 3) wreg[C::WR + r] = *(const u32x4*)(wc + p.w_lo_off + (size_t)q * 8);
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int r = 0; r < C::AR; ++r) {
+            if (loff[r] >= 0) {
+                if constexpr (!IN_F32) {
+                    *(u32x4*)(act_hi + loff[r]) = areg[r];
+                } else {
+                    bf16x4 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bf16_t h, l;
+                        split_bf16(__uint_as_float(areg[r][j]), h, l);
+                        hi[j] = h;
+                        lo[j] = l;
+                    }
+                    *(bf16x4*)(act_hi + loff[r]) = hi;
+                    if constexpr (PREC == 3) *(bf16x4*)(act_lo + loff[r]) = lo;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < C::WR; ++r) {
+            const int q = tid + r * 256;
+            if (q < C::WPIECE) {
+                *(u32x4*)(w_hi + q * 16) = wreg[r];
+                if constexpr (PREC == 3) *(u32x4*)(w_lo + q * 16) = wreg[C::WR + r];
+            }
+        }
+    };
+
+    // ---- per-lane fragment addresses ----
+    const int nn = lane & 31, kh2 = lane >> 5;
+    int boff[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        int r, c;
+        if constexpr (STRIDE == 1) {
+            r = (wave * NT + nt);
+            c = nn;
+        } else {
+            r = (wave * NT + nt) * 2 + (nn >> 4);
+            c = nn & 15;
+        }
+        boff[nt] = ((r * STRIDE) * C::IW + c * STRIDE) * C::PIXB + kh2 * 16;
+    }
+    const int aoff = lane * 16;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[mi][nt][j] = 0.f;
+
+    load_chunk(0);
+    for (int ck = 0; ck < nchunks; ++ck) {
+        store_chunk();
+        __syncthreads();
+        if (ck + 1 < nchunks) load_chunk(ck + 1);
+#pragma unroll
+        for (int t = 0; t < C::NTAPS; ++t) {
+            const int ky = t / KH, kx = t - ky * KH;
+            const int toff = (ky * C::IW + kx) * C::PIXB;
+            bf16x8 a[MT], al[MT], b[NT], bl[NT];
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+                a[mi] = *(const bf16x8*)(w_hi + (t * MT + mi) * 1024 + aoff);
+                if constexpr (PREC == 3) al[mi] = *(const bf16x8*)(w_lo + (t * MT + mi) * 1024 + aoff);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                b[nt] = *(const bf16x8*)(act_hi + boff[nt] + toff);
+                if constexpr (PREC == 3) bl[nt] = *(const bf16x8*)(act_lo + boff[nt] + toff);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if constexpr (PREC == 3) {
+                        acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], b[nt], acc[mi][nt], 0, 0, 0);
+                        acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], bl[nt], acc[mi][nt], 0, 0, 0);
+                    }
+                    acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[nt], acc[mi][nt], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    const int cout_pad = (p.cout + 15) & ~15;
+    const float* bias = p.bias;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        int r, c;
+        if constexpr (STRIDE == 1) {
+            r = wave * NT + nt;
+            c = nn;
+        } else {
+            r = (wave * NT + nt) * 2 + (nn >> 4);
+            c = nn & 15;
+        }
+        const int oy = oy0 + r, ox = ox0 + c;
+        if (oy >= p.Hout || ox >= p.Wout) continue;
+        const size_t pixoff = ((size_t)oy * p.Wout + ox) * 16;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int oc = (mg * MT + mi) * 32 + 8 * g + 4 * kh2;
+                if (oc >= cout_pad) continue;
+                const int cb = oc >> 4, ci = oc & 15;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[mi][nt][4 * g + j];
+                if (bias) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (oc + j < p.cout) v[j] += bias[oc + j];
+                }
+                if (p.act) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
+                }
+                if (p.mask.p) {
+                    const size_t mo = (size_t)n * p.mask.n_stride + (size_t)cb * p.mask.cb_stride + pixoff + ci;
+                    float m[4];
+                    if (p.mask_f32) {
+                        const f32x4 mv = *(const f32x4*)((const float*)p.mask.p + mo);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) m[j] = mv[j];
+                    } else {
+                        const bf16x4 mv = *(const bf16x4*)((const bf16_t*)p.mask.p + mo);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) m[j] = (float)mv[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = m[j] > 0.f ? v[j] : v[j] * p.slope;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
+                if (p.res1.p) {
+                    const f32x4 rv = *(const f32x4*)((const float*)p.res1.p + (size_t)n * p.res1.n_stride +
+                                                     (size_t)cb * p.res1.cb_stride + pixoff + ci);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += p.beta1 * rv[j];
+                }
+                if (p.res2.p) {
+                    const f32x4 rv = *(const f32x4*)((const float*)p.res2.p + (size_t)n * p.res2.n_stride +
+                                                     (size_t)cb * p.res2.cb_stride + pixoff + ci);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += p.beta2 * rv[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (oc + j >= p.cout) v[j] = 0.f;  // padded channels of the last plane stay zero
+                if (p.out_f32.p) {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    *(f32x4*)((float*)p.out_f32.p + (size_t)n * p.out_f32.n_stride + (size_t)cb * p.out_f32.cb_stride +
+                              pixoff + ci) = o;
+                }
+                if (p.out_bf16.p) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(v[j] * p.gamma);
+                    *(bf16x4*)((bf16_t*)p.out_bf16.p + (size_t)n * p.out_bf16.n_stride +
+                               (size_t)cb * p.out_bf16.cb_stride + pixoff + ci) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int PREC, bool IN_F32, int MT, int KH, int STRIDE, int NT>
+int launch(const dasr_conv_params& p, hipStream_t s) {
+    using C = Cfg<PREC, IN_F32, MT, KH, STRIDE, NT>;
+    static bool attr_set = false;
+    auto kfn = conv_kernel<PREC, IN_F32, MT, KH, STRIDE, NT>;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        attr_set = true;
+    }
+    const int cout_tiles = (p.cout + 31) >> 5;
+    const int MG = (cout_tiles + MT - 1) / MT;
+    const int tiles_x = (p.Wout + C::TW - 1) / C::TW, tiles_y = (p.Hout + C::TH - 1) / C::TH;
+    const long long grid = (long long)MG * tiles_x * tiles_y * p.N;
+    if (grid <= 0 || grid > 0x7fffffffLL) return DASR_EINVAL;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(256), C::LDS_BYTES, s, p);
+    return (int)hipGetLastError();
+}
+
+// naive cross-check: one thread per (n, oc, oy, ox); fp32 direct convolution from the reference weight layout
+__global__ void conv_naive_kernel(const dasr_conv_params p, const float* w) {
+    const long long total = (long long)p.N * p.cout * p.Hout * p.Wout;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ox = i % p.Wout;
+    long long t = i / p.Wout;
+    const int oy = t % p.Hout;
+    t /= p.Hout;
+    const int oc = t % p.cout;
+    const int n = t / p.cout;
+    const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
+    float acc = 0.f;
+    for (int c = 0; c < p.cin; ++c)
+        for (int ky = 0; ky < p.kh; ++ky)
+            for (int kx = 0; kx < p.kh; ++kx) {
+                const int gy = oy * p.stride - p.pad + ky, gx = ox * p.stride - p.pad + kx;
+                if (gy < 0 || gy >= HL || gx < 0 || gx >= WL) continue;
+                const int sy = p.ups ? gy >> 1 : gy, sx = p.ups ? gx >> 1 : gx;
+                const size_t o = (size_t)n * p.in.n_stride + (size_t)(c >> 4) * p.in.cb_stride + ((size_t)sy * p.Win + sx) * 16 + (c & 15);
+                const float x = p.in_f32 ? ((const float*)p.in.p)[o] : (float)((const bf16_t*)p.in.p)[o];
+                acc += x * w[(((size_t)oc * p.cin + c) * p.kh + ky) * p.kh + kx];
+            }
+    if (p.bias) acc += p.bias[oc];
+    if (p.act) acc = acc > 0.f ? acc : acc * p.slope;
+    const size_t po = ((size_t)oy * p.Wout + ox) * 16 + (oc & 15);
+    if (p.mask.p) {
+        const size_t mo = (size_t)n * p.mask.n_stride + (size_t)(oc >> 4) * p.mask.cb_stride + po;
+        const float m = p.mask_f32 ? ((const float*)p.mask.p)[mo] : (float)((const bf16_t*)p.mask.p)[mo];
+        acc = m > 0.f ? acc : acc * p.slope;
+    }
+    acc *= p.alpha;
+    if (p.res1.p) acc += p.beta1 * ((const float*)p.res1.p)[(size_t)n * p.res1.n_stride + (size_t)(oc >> 4) * p.res1.cb_stride + po];
+    if (p.res2.p) acc += p.beta2 * ((const float*)p.res2.p)[(size_t)n * p.res2.n_stride + (size_t)(oc >> 4) * p.res2.cb_stride + po];
+    if (p.out_f32.p) ((float*)p.out_f32.p)[(size_t)n * p.out_f32.n_stride + (size_t)(oc >> 4) * p.out_f32.cb_stride + po] = acc;
+    if (p.out_bf16.p)
+        ((bf16_t*)p.out_bf16.p)[(size_t)n * p.out_bf16.n_stride + (size_t)(oc >> 4) * p.out_bf16.cb_stride + po] = (bf16_t)(acc * p.gamma);
+}
+
+}  // namespace
+
+extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
+    const dasr_conv_params& p = *pp;
+    hipStream_t s = as_stream(stream);
+    if (p.cin <= 0 || (p.cin & 15) || p.cout <= 0 || !p.w || !p.in.p) return DASR_EINVAL;
+    if (!(p.mt == 1 || p.mt == 2) || !(p.prec == 1 || p.prec == 3)) return DASR_EINVAL;
+    const int key = (p.prec == 3 ? 1000 : 0) + (p.in_f32 ? 100 : 0) + p.mt * 10 + (p.kh == 4 ? (p.stride == 2 ? 2 : 1) : 0);
+    if (p.kh == 3 && (p.stride != 1 || p.pad != 1)) return DASR_EINVAL;
+    if (p.kh == 4 && (p.pad != 1 || (p.stride != 1 && p.stride != 2))) return DASR_EINVAL;
+    if (p.kh != 3 && p.kh != 4) return DASR_EINVAL;
+    switch (key) {
+        // prec 1, bf16 input (RDB dense-block convs, fwd and dgrad)
+        case 10: return launch<1, false, 1, 3, 1, 4>(p, s);
+        case 20: return launch<1, false, 2, 3, 1, 4>(p, s);
+        // prec 1, f32 input (VGG perceptual branch)
+        case 110: return launch<1, true, 1, 3, 1, 4>(p, s);
+        case 120: return launch<1, true, 2, 3, 1, 4>(p, s);
+        // prec 3, f32 input (residual-stream convs of the generator, discriminator)
+        case 1110: return launch<3, true, 1, 3, 1, 4>(p, s);
+        case 1111: return launch<3, true, 1, 4, 1, 2>(p, s);
+        case 1112: return launch<3, true, 1, 4, 2, 1>(p, s);
+        default: return DASR_EINVAL;
+    }
+}
+
+extern "C" int dasr_conv_naive(const dasr_conv_params* pp, const float* w_ref, void* stream) {
+    const dasr_conv_params& p = *pp;
+    const long long total = (long long)p.N * p.cout * p.Hout * p.Wout;
+    if (total <= 0) return DASR_EINVAL;
+    hipLaunchKernelGGL(conv_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), p, w_ref);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,339 @@
+// Weight packing, HBM-bound elementwise kernels, fused Adam and the op-list executor (gfx950).
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// fp32 master weights -> bf16 MFMA A-fragment order [mgroup][chunk][tap][mt][lane][8] (+ lo plane)
+// ---------------------------------------------------------------------------------------------------
+__global__ void pack_kernel(const dasr_pack_desc* __restrict__ descs, int ndesc, long long total,
+                            const long long* __restrict__ prefix, const float* __restrict__ params, bf16_t* __restrict__ packed) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    int lo = 0, hi = ndesc - 1;  // find desc: prefix[d] <= gid < prefix[d+1]
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (prefix[mid] <= gid) lo = mid; else hi = mid - 1;
+    }
+    const dasr_pack_desc& D = descs[lo];
+    long long q = gid - prefix[lo];
+    const int lane = q & 63;
+    q >>= 6;
+    const int mi = q % D.mt;
+    q /= D.mt;
+    const int tap = q % D.ntaps;
+    q /= D.ntaps;
+    const int nchunks = D.cin_pad >> 4;
+    const int ck = q % nchunks;
+    const int mg = q / nchunks;
+    const int oc = (mg * D.mt + mi) * 32 + (lane & 31);
+    const int c0 = ck * 16 + 8 * (lane >> 5);
+    bf16x8 vh, vl;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int cin = c0 + e;
+        float v = 0.f;
+        if (oc < D.cout) {
+            for (int s = 0; s < D.nseg; ++s) {
+                const dasr_pack_seg& S = D.seg[s];
+                const int ci = cin - S.cin_start;
+                if (ci >= 0 && ci < S.cin_len) {
+                    if (!S.transpose) {
+                        v = params[S.src_off + ((long long)oc * S.src_cin + S.src_c0 + ci) * D.ntaps + tap];
+                    } else if (ci < S.src_cout) {
+                        v = params[S.src_off + ((long long)ci * S.src_cin + S.src_c0 + oc) * D.ntaps + (D.ntaps - 1 - tap)];
+                    }
+                }
+            }
+        }
+        bf16_t h, l;
+        split_bf16(v, h, l);
+        vh[e] = h;
+        vl[e] = l;
+    }
+    const long long o = D.dst_off + (gid - prefix[lo]) * 8;
+    *(bf16x8*)(packed + o) = vh;
+    if (D.lo_off) *(bf16x8*)(packed + o + D.lo_off) = vl;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void nchw_to_blocked_kernel(const float* __restrict__ src, int N, int C, int H, int W, dasr_tensor df, dasr_tensor db) {
+    const int ncb = (C + 15) >> 4;
+    const long long total = (long long)N * ncb * H * W;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x = i % W;
+    long long t = i / W;
+    const int y = t % H;
+    t /= H;
+    const int cb = t % ncb;
+    const int n = t / ncb;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int c = cb * 16 + j;
+        v[j] = c < C ? src[(((long long)n * C + c) * H + y) * W + x] : 0.f;
+    }
+    const size_t po = ((size_t)y * W + x) * 16;
+    if (df.p) {
+        float* d = (float*)df.p + (size_t)n * df.n_stride + (size_t)cb * df.cb_stride + po;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ((f32x4*)d)[j] = f32x4{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]};
+    }
+    if (db.p) {
+        bf16_t* d = (bf16_t*)db.p + (size_t)n * db.n_stride + (size_t)cb * db.cb_stride + po;
+        bf16x8 a, b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a[j] = (bf16_t)v[j];
+            b[j] = (bf16_t)v[8 + j];
+        }
+        ((bf16x8*)d)[0] = a;
+        ((bf16x8*)d)[1] = b;
+    }
+}
+
+__global__ void blocked_to_nchw_kernel(dasr_tensor s, int N, int C, int H, int W, float* __restrict__ dst) {
+    const long long total = (long long)N * C * H * W;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x = i % W;
+    long long t = i / W;
+    const int y = t % H;
+    t /= H;
+    const int c = t % C;
+    const int n = t / C;
+    dst[i] = ((const float*)s.p)[(size_t)n * s.n_stride + (size_t)(c >> 4) * s.cb_stride + ((size_t)y * W + x) * 16 + (c & 15)];
+}
+
+// one thread per pixel (plane 0 only: C <= 16)
+__global__ void l1_loss_kernel(dasr_tensor sr, const float* __restrict__ hr, const float* __restrict__ wm, int N, int C, int H, int W,
+                               float coef, float* loss_acc, dasr_tensor grad, int accumulate) {
+    const long long total = (long long)N * H * W;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float part = 0.f;
+    if (i < total) {
+        const int x = i % W;
+        long long t = i / W;
+        const int y = t % H;
+        const int n = t / H;
+        const size_t po = ((size_t)y * W + x) * 16;
+        const float* s = (const float*)sr.p + (size_t)n * sr.n_stride + po;
+        const float wgt = wm ? wm[((long long)n * H + y) * W + x] : 1.f;
+        float g[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) g[j] = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float d = s[c] - hr[(((long long)n * C + c) * H + y) * W + x];
+            part += wgt * fabsf(d);
+            g[c] = coef * wgt * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        }
+        if (grad.p) {
+            float* gp = (float*)grad.p + (size_t)n * grad.n_stride + po;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 o = {g[4 * j], g[4 * j + 1], g[4 * j + 2], g[4 * j + 3]};
+                if (accumulate) o += ((const f32x4*)gp)[j];
+                ((f32x4*)gp)[j] = o;
+            }
+        }
+    }
+    part = wave_sum(part);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_acc) atomicAdd(loss_acc, (red[0] + red[1] + red[2] + red[3]) * coef);
+}
+
+// thread per (n, cb, y, x) at the LOW resolution
+__global__ void downsum2x_kernel(dasr_tensor src, int N, int C, int H, int W, dasr_tensor mask, int mask_f32, float slope,
+                                 dasr_tensor df, dasr_tensor db) {
+    const int ncb = (C + 15) >> 4;
+    const long long total = (long long)N * ncb * H * W * 4;  // 4 threads per pixel, 4 channels each
+    const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= total) return;
+    const int q = gi & 3;
+    const long long i = gi >> 2;
+    const int x = i % W;
+    long long t = i / W;
+    const int y = t % H;
+    t /= H;
+    const int cb = t % ncb;
+    const int n = t / ncb;
+    const float* s = (const float*)src.p + (size_t)n * src.n_stride + (size_t)cb * src.cb_stride + q * 4;
+    const int W2 = 2 * W;
+    f32x4 a = *(const f32x4*)(s + ((size_t)(2 * y) * W2 + 2 * x) * 16);
+    a += *(const f32x4*)(s + ((size_t)(2 * y) * W2 + 2 * x + 1) * 16);
+    a += *(const f32x4*)(s + ((size_t)(2 * y + 1) * W2 + 2 * x) * 16);
+    a += *(const f32x4*)(s + ((size_t)(2 * y + 1) * W2 + 2 * x + 1) * 16);
+    const size_t po = ((size_t)y * W + x) * 16 + q * 4;
+    if (mask.p) {
+        const size_t mo = (size_t)n * mask.n_stride + (size_t)cb * mask.cb_stride + po;
+        float m[4];
+        if (mask_f32) {
+            const f32x4 mv = *(const f32x4*)((const float*)mask.p + mo);
+            for (int j = 0; j < 4; ++j) m[j] = mv[j];
+        } else {
+            const bf16x4 mv = *(const bf16x4*)((const bf16_t*)mask.p + mo);
+            for (int j = 0; j < 4; ++j) m[j] = (float)mv[j];
+        }
+        for (int j = 0; j < 4; ++j) a[j] = m[j] > 0.f ? a[j] : a[j] * slope;
+    }
+    if (df.p) *(f32x4*)((float*)df.p + (size_t)n * df.n_stride + (size_t)cb * df.cb_stride + po) = a;
+    if (db.p) {
+        bf16x4 o;
+        for (int j = 0; j < 4; ++j) o[j] = (bf16_t)a[j];
+        *(bf16x4*)((bf16_t*)db.p + (size_t)n * db.n_stride + (size_t)cb * db.cb_stride + po) = o;
+    }
+}
+
+__global__ void axpby_kernel(dasr_tensor x, float a, dasr_tensor z, float b, int N, int C, int H, int W, dasr_tensor of,
+                             dasr_tensor ob, float gamma) {
+    const int ncb = (C + 15) >> 4;
+    const long long per_plane = (long long)H * W * 4;  // f32x4 pieces
+    const long long total = (long long)N * ncb * per_plane;
+    const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= total) return;
+    const long long e = (gi % per_plane) * 4;
+    long long t = gi / per_plane;
+    const int cb = t % ncb;
+    const int n = t / ncb;
+    f32x4 v = *(const f32x4*)((const float*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + e) * a;
+    if (z.p) v += *(const f32x4*)((const float*)z.p + (size_t)n * z.n_stride + (size_t)cb * z.cb_stride + e) * b;
+    if (of.p) *(f32x4*)((float*)of.p + (size_t)n * of.n_stride + (size_t)cb * of.cb_stride + e) = v;
+    if (ob.p) {
+        bf16x4 o;
+        for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(v[j] * gamma);
+        *(bf16x4*)((bf16_t*)ob.p + (size_t)n * ob.n_stride + (size_t)cb * ob.cb_stride + e) = o;
+    }
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long long n, float step_size, float beta1, float beta2, float eps, float wd, float inv_sqrt_bc2) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+
+__global__ void fill_kernel(float* p, long long n, float v) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+inline unsigned blocks_for(long long total, int bs = 256) { return (unsigned)((total + bs - 1) / bs); }
+
+}  // namespace
+
+extern "C" int dasr_pack_weights(const dasr_pack_desc* descs_dev, int32_t ndesc, int64_t total_pieces, const int64_t* piece_prefix_dev,
+                                 const float* params_flat, void* packed, void* stream) {
+    if (ndesc <= 0 || total_pieces <= 0) return DASR_EINVAL;
+    hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(total_pieces)), dim3(256), 0, as_stream(stream), descs_dev, ndesc,
+                       (long long)total_pieces, (const long long*)piece_prefix_dev, params_flat, (bf16_t*)packed);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_nchw_to_blocked(const float* src, int32_t N, int32_t C, int32_t H, int32_t W, dasr_tensor dst_f32,
+                                    dasr_tensor dst_bf16, void* stream) {
+    const long long total = (long long)N * ((C + 15) / 16) * H * W;
+    if (total <= 0) return DASR_EINVAL;
+    hipLaunchKernelGGL(nchw_to_blocked_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), src, N, C, H, W, dst_f32, dst_bf16);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_blocked_to_nchw(dasr_tensor src, int32_t N, int32_t C, int32_t H, int32_t W, float* dst, void* stream) {
+    const long long total = (long long)N * C * H * W;
+    if (total <= 0) return DASR_EINVAL;
+    hipLaunchKernelGGL(blocked_to_nchw_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), src, N, C, H, W, dst);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_l1_loss(dasr_tensor sr, const float* hr_nchw, const float* weight_map, int32_t N, int32_t C, int32_t H, int32_t W,
+                            float coef, float* loss_acc, dasr_tensor grad, int32_t accumulate, void* stream) {
+    const long long total = (long long)N * H * W;
+    if (total <= 0 || C > 16) return DASR_EINVAL;
+    hipLaunchKernelGGL(l1_loss_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), sr, hr_nchw, weight_map, N, C, H, W, coef,
+                       loss_acc, grad, accumulate);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_downsum2x(dasr_tensor src, int32_t N, int32_t C, int32_t H, int32_t W, dasr_tensor mask, int32_t mask_f32,
+                              float slope, dasr_tensor dst_f32, dasr_tensor dst_bf16, void* stream) {
+    const long long total = (long long)N * ((C + 15) / 16) * H * W * 4;
+    if (total <= 0) return DASR_EINVAL;
+    hipLaunchKernelGGL(downsum2x_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), src, N, C, H, W, mask, mask_f32, slope,
+                       dst_f32, dst_bf16);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_axpby(dasr_tensor x, float a, dasr_tensor z, float b, int32_t N, int32_t C, int32_t H, int32_t W,
+                          dasr_tensor out_f32, dasr_tensor out_bf16, float gamma, void* stream) {
+    const long long total = (long long)N * ((C + 15) / 16) * H * W * 4;
+    if (total <= 0) return DASR_EINVAL;
+    hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), x, a, z, b, N, C, H, W, out_f32, out_bf16, gamma);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int32_t step, void* stream) {
+    if (n <= 0 || step <= 0) return DASR_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p, g, m, v, (long long)n, step_size, beta1, beta2, eps,
+                       weight_decay, inv_sqrt_bc2);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_fill_f32(float* p, int64_t n, float value, void* stream) {
+    if (n <= 0) return DASR_EINVAL;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p, (long long)n, value);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_abi_version(void) { return DASR_ABI_VERSION; }
+
+static int g_last_failed_op = -1;
+extern "C" int dasr_last_failed_op(void) { return g_last_failed_op; }
+
+extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream) {
+    for (int k = 0; k < n; ++k) {
+        const dasr_op& o = ops[k];
+        int rc = 0;
+        switch (o.op) {
+            case DASR_OP_CONV: rc = dasr_conv(&o.conv, stream); break;
+            case DASR_OP_WGRAD:
+                rc = dasr_wgrad((const dasr_wgrad_part*)o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], (float*)o.p[1], stream);
+                break;
+            case DASR_OP_WGRAD_REDUCE:
+                rc = dasr_wgrad_reduce((const dasr_wgrad_reduce_part*)o.p[0], o.i[0], (const float*)o.p[1], (float*)o.p[2], o.f[0], stream);
+                break;
+            case DASR_OP_PACK:
+                rc = dasr_pack_weights((const dasr_pack_desc*)o.p[0], o.i[0], o.l[0], (const int64_t*)o.p[1], (const float*)o.p[2], o.p[3], stream);
+                break;
+            case DASR_OP_DOWNSUM: rc = dasr_downsum2x(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1], o.i[4], o.f[0], o.t[2], o.t[3], stream); break;
+            case DASR_OP_AXPBY: rc = dasr_axpby(o.t[0], o.f[0], o.t[1], o.f[1], o.i[0], o.i[1], o.i[2], o.i[3], o.t[2], o.t[3], o.f[2], stream); break;
+            case DASR_OP_FILL: rc = dasr_fill_f32((float*)o.p[0], o.l[0], o.f[0], stream); break;
+            case DASR_OP_L1LOSS:
+                rc = dasr_l1_loss(o.t[0], (const float*)o.p[0], (const float*)o.p[1], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], (float*)o.p[2], o.t[1],
+                                  o.i[4], stream);
+                break;
+            case DASR_OP_NCHW2B: rc = dasr_nchw_to_blocked((const float*)o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[0], o.t[1], stream); break;
+            case DASR_OP_B2NCHW: rc = dasr_blocked_to_nchw(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], (float*)o.p[0], stream); break;
+            default: rc = DASR_EINVAL;
+        }
+        if (rc != 0) {
+            g_last_failed_op = k;
+            return rc;
+        }
+    }
+    return 0;
+}

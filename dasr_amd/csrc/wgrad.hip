@@ -1,0 +1,283 @@
+// Weight-gradient kernels for gfx950.
+//
+// dW[oc][c][tap] = sum_{n,y,x} G[n][oc][y][x] * X[n][c][y*S+ky-P][x*S+kx-P]
+// GEMM view per tap: D[oc][c] = sum_k A[oc][k] * B[k][c], k = output pixel.  Both operands are stored
+// pixel-major ([pixel][16 channels]) so the MFMA fragments (8 consecutive k per lane) are gathered with
+// the LDS transpose read ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group).
+// One workgroup (4 waves) = one "part" (32 oc x up to 64 cin x all taps of one conv) x one pixel split.
+// wave w: cin tile = w & 1, tap group = w >> 1.  Partial sums -> workspace; wgrad_reduce sums the splits
+// in a fixed order (deterministic) and scatters into the reference layout [cout][cin][kh][kw].
+#include "common.h"
+
+namespace {
+
+template <int KH, int STRIDE>
+struct WCfg {
+    static constexpr int NTAPS = KH * KH;
+    static constexpr int TPG = (NTAPS + 1) / 2;  // taps per wave
+    static constexpr int PH = 8, PW = 16;        // output-pixel tile (8 k-steps of 16 pixels)
+    static constexpr int IH = (PH - 1) * STRIDE + KH;
+    static constexpr int IW = (PW - 1) * STRIDE + KH;
+    static constexpr int GPLANE = PH * PW * 32 + 128;  // bytes; stride = 128 (mod 256): the two planes of a
+    static constexpr int IPLANE_RAW = IH * IW * 32;    // 32-lane half hit disjoint bank halves
+    static constexpr int IPLANE = IPLANE_RAW + ((IPLANE_RAW % 256) == 128 ? 0 : ((128 - (IPLANE_RAW % 256) + 256) % 256));
+    static constexpr int G_BYTES = 2 * GPLANE;
+    static constexpr int I_BYTES = 4 * IPLANE;
+    static constexpr int LDS_BYTES = G_BYTES + I_BYTES;
+};
+
+__device__ __forceinline__ bf16x8 frag_tr(const char* base, int off0, int off1) {
+    const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((DASR_LDS bf16x4*)(base + off0));
+    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((DASR_LDS bf16x4*)(base + off1));
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int KH, int STRIDE, bool USE_TR>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit,
+                                                       float* __restrict__ ws) {
+    using C = WCfg<KH, STRIDE>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* gl = smem;
+    char* il = smem + C::G_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int part_id = blockIdx.x / nsplit, split = blockIdx.x - part_id * nsplit;
+    const dasr_wgrad_part P = parts[part_id];
+    const int ct = wave & 1, tg = wave >> 1;
+    const bool active = ct < P.n_ctiles;
+    const int tiles_x = (P.Wout + C::PW - 1) / C::PW, tiles_y = (P.Hout + C::PH - 1) / C::PH;
+    const int ntiles = tiles_x * tiles_y * P.N;
+    const int HL = P.ups ? 2 * P.Hin : P.Hin, WL = P.ups ? 2 * P.Win : P.Win;
+    const int gsz = P.g_f32 ? 4 : 2, isz = P.in_f32 ? 4 : 2;
+
+    f32x16 acc[C::TPG];
+#pragma unroll
+    for (int t = 0; t < C::TPG; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+    float bsum = 0.f;
+
+    // fragment gather geometry
+    const int gg = lane >> 4, li = lane & 15;
+    const int fplane = gg & 1, khalf = gg >> 1;
+
+    for (int tile = split; tile < ntiles; tile += nsplit) {
+        int t2 = tile;
+        const int tx = t2 % tiles_x;
+        t2 /= tiles_x;
+        const int ty = t2 % tiles_y;
+        const int n = t2 / tiles_y;
+        const int oy0 = ty * C::PH, ox0 = tx * C::PW;
+        const int iy0 = oy0 * STRIDE - P.pad, ix0 = ox0 * STRIDE - P.pad;
+        __syncthreads();  // previous tile's reads are done
+        // ---- stage G tile: 2 planes x 128 pixels x 16 ch (bf16 in LDS) ----
+        {
+            const char* gb = (const char*)P.g.p + (size_t)n * P.g.n_stride * gsz;
+            const int psh = P.g_f32 ? 2 : 1;  // log2(16-byte global pieces per pixel-plane)
+            const int npiece = (2 * C::PH * C::PW) << psh;
+            for (int q = tid; q < npiece; q += 256) {
+                const int piece = q & ((1 << psh) - 1);
+                int r = q >> psh;
+                const int pix = r % (C::PH * C::PW);
+                const int pl = r / (C::PH * C::PW);
+                const int py = pix / C::PW, px = pix - py * C::PW;
+                const int oy = oy0 + py, ox = ox0 + px;
+                const bool ok = oy < P.Hout && ox < P.Wout && pl < P.g_planes;
+                const size_t eoff = (size_t)pl * P.g.cb_stride + ((size_t)oy * P.Wout + ox) * 16;
+                char* dst = gl + pl * C::GPLANE + pix * 32;
+                if (P.g_f32) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (ok) v = *(const f32x4*)(gb + (eoff + piece * 4) * 4);
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
+                    *(bf16x4*)(dst + piece * 8) = o;
+                } else {
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (ok) v = *(const u32x4*)(gb + (eoff + piece * 8) * 2);
+                    *(u32x4*)(dst + piece * 16) = v;
+                }
+            }
+        }
+        // ---- stage input halo tile: 2*n_ctiles planes x IH*IW pixels ----
+        {
+            const char* ib = (const char*)P.in.p + (size_t)n * P.in.n_stride * isz;
+            const int psh = P.in_f32 ? 2 : 1;
+            const int npiece = (2 * P.n_ctiles * C::IH * C::IW) << psh;
+            for (int q = tid; q < npiece; q += 256) {
+                const int piece = q & ((1 << psh) - 1);
+                int r = q >> psh;
+                const int pix = r % (C::IH * C::IW);
+                const int pl = r / (C::IH * C::IW);
+                const int iy = pix / C::IW, ix = pix - iy * C::IW;
+                const int gy = iy0 + iy, gx = ix0 + ix;
+                const bool ok = gy >= 0 && gy < HL && gx >= 0 && gx < WL && pl < P.in_planes;
+                const int sy = P.ups ? gy >> 1 : gy, sx = P.ups ? gx >> 1 : gx;
+                const size_t eoff = (size_t)pl * P.in.cb_stride + ((size_t)sy * P.Win + sx) * 16;
+                char* dst = il + pl * C::IPLANE + pix * 32;
+                if (P.in_f32) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (ok) v = *(const f32x4*)(ib + (eoff + piece * 4) * 4);
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
+                    *(bf16x4*)(dst + piece * 8) = o;
+                } else {
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (ok) v = *(const u32x4*)(ib + (eoff + piece * 8) * 2);
+                    *(u32x4*)(dst + piece * 16) = v;
+                }
+            }
+        }
+        __syncthreads();
+        if (!active) continue;
+        // ---- MFMA over the 8 pixel rows of the tile ----
+#pragma unroll 2
+        for (int r = 0; r < C::PH; ++r) {
+            bf16x8 a;
+            if constexpr (USE_TR) {
+                const int o0 = fplane * C::GPLANE + (r * C::PW + 8 * khalf + (li >> 2)) * 32 + (li & 3) * 8;
+                a = frag_tr(gl, o0, o0 + 4 * 32);
+            } else {
+                const char* b0 = gl + fplane * C::GPLANE + (r * C::PW + 8 * khalf) * 32 + li * 2;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = *(const bf16_t*)(b0 + j * 32);
+            }
+            if (P.want_bias && tg == 0 && ct == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum += (float)a[j];
+            }
+#pragma unroll
+            for (int t = 0; t < C::TPG; ++t) {
+                const int tap = tg * C::TPG + t;
+                if (tap < C::NTAPS) {  // uniform per wave
+                    const int ky = tap / KH, kx = tap - ky * KH;
+                    bf16x8 b;
+                    const int prow = (r * STRIDE + ky) * C::IW + kx;
+                    if constexpr (USE_TR) {
+                        const int o0 = (ct * 2 + fplane) * C::IPLANE + (prow + (8 * khalf + (li >> 2)) * STRIDE) * 32 + (li & 3) * 8;
+                        b = frag_tr(il, o0, o0 + 4 * STRIDE * 32);
+                    } else {
+                        const char* b0 = il + (ct * 2 + fplane) * C::IPLANE + (prow + 8 * khalf * STRIDE) * 32 + li * 2;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) b[j] = *(const bf16_t*)(b0 + j * STRIDE * 32);
+                    }
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- write partials: ws[part][split][tap][oc 32][cin 64] ----
+    if (active) {
+        float* w = ws + P.ws_off + (size_t)split * C::NTAPS * 32 * 64;
+        const int cin = ct * 32 + (lane & 31), h = lane >> 5;
+#pragma unroll
+        for (int t = 0; t < C::TPG; ++t) {
+            const int tap = tg * C::TPG + t;
+            if (tap < C::NTAPS) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int oc = (j & 3) + 8 * (j >> 2) + 4 * h;
+                    w[((size_t)tap * 32 + oc) * 64 + cin] = acc[t][j];
+                }
+            }
+        }
+        if (P.want_bias && tg == 0 && ct == 0) {
+            const float tot = bsum + __shfl_xor(bsum, 32, 64);
+            if (lane < 32) ws[P.ws_bias_off + (size_t)split * 32 + lane] = tot;
+        }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const dasr_wgrad_reduce_part* __restrict__ parts, int nparts, const float* __restrict__ ws,
+                                    float* __restrict__ grad, float scale) {
+    const int part_id = blockIdx.y;
+    const dasr_wgrad_reduce_part P = parts[part_id];
+    const int per = P.ntaps * 32 * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per + 32; i += gridDim.x * blockDim.x) {
+        if (i < per) {
+            const int cin = i & 63, oc = (i >> 6) & 31, tap = i >> 11;
+            if (cin >= 32 * P.n_ctiles) continue;
+            const int goc = P.oc0 + oc, gc = P.c0 + cin;
+            if (goc >= P.cout || gc >= P.cin) continue;
+            float s = 0.f;
+            for (int sp = 0; sp < P.nsplit; ++sp) s += ws[P.ws_off + (size_t)sp * per + i];
+            grad[P.dst_w_off + ((size_t)goc * P.cin + gc) * P.ntaps + tap] = s * scale;
+        } else if (P.dst_b_off >= 0) {
+            const int oc = i - per;
+            if (P.oc0 + oc < P.cout) {
+                float s = 0.f;
+                for (int sp = 0; sp < P.nsplit; ++sp) s += ws[P.ws_bias_off + (size_t)sp * 32 + oc];
+                grad[P.dst_b_off + P.oc0 + oc] = s * scale;
+            }
+        }
+    }
+}
+
+__global__ void probe_tr16_kernel(int* result) {
+    __shared__ __attribute__((aligned(16))) short lds[4 * 64];
+    const int l = threadIdx.x;
+    // 4 groups, each a 4 x 16 row-major matrix M[row][col] = 1000*group + 16*row + col
+    for (int i = l; i < 256; i += 64) lds[i] = (short)(1000 * (i >> 6) + (i & 63));
+    __syncthreads();
+    const int gg = l >> 4, li = l & 15;
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((DASR_LDS s16x4*)((char*)lds + gg * 128 + (li >> 2) * 32 + (li & 3) * 8));
+    int ok = 1;
+    for (int j = 0; j < 4; ++j) ok &= (v[j] == (short)(1000 * gg + 16 * j + li));
+    const unsigned long long m = __ballot(ok);
+    if (l == 0) *result = (m == ~0ull) ? 1 : 0;
+}
+
+template <int KH, int STRIDE, bool USE_TR>
+int launch_wgrad(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws, hipStream_t s) {
+    using C = WCfg<KH, STRIDE>;
+    auto kfn = wgrad_kernel<KH, STRIDE, USE_TR>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3(nparts * nsplit), dim3(256), C::LDS_BYTES, s, parts, nparts, nsplit, ws);
+    return (int)hipGetLastError();
+}
+
+int g_use_tr = -1;  // -1 unknown, 0 gather fallback, 1 transpose reads
+
+}  // namespace
+
+extern "C" int dasr_probe_tr16(void* stream) {
+    int* d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(int)));
+    hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, as_stream(stream), d);
+    int h = -1;
+    hipError_t e = hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, as_stream(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));
+    hipFree(d);
+    if (e != hipSuccess) return -(int)e;
+    g_use_tr = h;
+    return h;
+}
+
+extern "C" int dasr_wgrad_set_mode(int use_tr) {
+    g_use_tr = use_tr;
+    return 0;
+}
+
+extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int32_t nsplit, int32_t kh, int32_t stride,
+                          float* ws, void* stream) {
+    hipStream_t s = as_stream(stream);
+    if (nparts <= 0 || nsplit <= 0) return DASR_EINVAL;
+    if (g_use_tr < 0) return DASR_EINVAL;  // dasr_probe_tr16 must run once per process (outside graph capture)
+    const bool tr = g_use_tr == 1;
+    if (kh == 3 && stride == 1) return tr ? launch_wgrad<3, 1, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad<3, 1, false>(parts_dev, nparts, nsplit, ws, s);
+    if (kh == 4 && stride == 1) return tr ? launch_wgrad<4, 1, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad<4, 1, false>(parts_dev, nparts, nsplit, ws, s);
+    if (kh == 4 && stride == 2) return tr ? launch_wgrad<4, 2, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad<4, 2, false>(parts_dev, nparts, nsplit, ws, s);
+    return DASR_EINVAL;
+}
+
+extern "C" int dasr_wgrad_reduce(const dasr_wgrad_reduce_part* parts_dev, int32_t nparts, const float* ws, float* grad_flat,
+                                 float scale, void* stream) {
+    if (nparts <= 0) return DASR_EINVAL;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(36, nparts), dim3(256), 0, as_stream(stream), parts_dev, nparts, ws, grad_flat, scale);
+    return (int)hipGetLastError();
+}

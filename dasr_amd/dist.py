@@ -1,0 +1,88 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL all-reduce over xGMI.
+
+Reference mechanism being replaced: single-process nn.DataParallel (codes/SRN/models/networks.py:144-146,
+192-193: per-forward parameter broadcast + gather on GPU 0).  Here weights are replicated, every rank runs the
+same step on its shard of the minibatch, and the only exchange is a SUM all-reduce of the flat fp32 gradient
+buffer (the 1/world factor is folded into the wgrad reduction kernel, so no extra pass).  The buffer is reduced
+in a few contiguous buckets, issued on a side stream as soon as the backward segment that produces them has
+been enqueued, so the exchange overlaps the remaining wgrad/dgrad kernels.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class DataParallelGroup:
+    def __init__(self, backend=None):
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        self.backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if self.world > 1 and not dist.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29500')
+            if self.backend == 'nccl':
+                torch.cuda.set_device(self.local_rank)
+            dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+        self.comm_stream = torch.cuda.Stream() if (self.backend == 'nccl' and torch.cuda.is_available()) else None
+        self.pending = []
+
+    @property
+    def grad_scale(self):
+        """factor folded into the gradient reduction so that SUM over ranks == global-batch mean gradient"""
+        return 1.0 / self.world
+
+    def reduce_async(self, flat_slice):
+        """SUM all-reduce of a contiguous slice of the flat gradient buffer, overlapped with compute."""
+        if self.world == 1 or flat_slice.numel() == 0:
+            return
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM)
+            self.pending.append(flat_slice)
+        else:
+            dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM)
+
+    def wait(self):
+        if self.comm_stream is not None and self.pending:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            self.pending = []
+
+    def allreduce_mean(self, flat):
+        self.reduce_async(flat)
+        self.wait()
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier()
+
+    def max_over_ranks(self, value):
+        if self.world == 1:
+            return value
+        dev = 'cuda' if self.backend == 'nccl' else 'cpu'
+        t = torch.tensor([value], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def broadcast_params(self, flat):
+        if self.world > 1:
+            dist.broadcast(flat, src=0)
+
+
+def shard_minibatch(batch, rank, world):
+    """Rank r takes rows [r*n/world, (r+1)*n/world) of every batch tensor: the [fake;real] halves stay balanced
+    because the DASR trainer concatenates them per rank after sharding (DASR_model.py:170-171)."""
+    out = {}
+    for k, v in batch.items():
+        if torch.is_tensor(v):
+            n = v.shape[0]
+            assert n % world == 0, 'global batch %d not divisible by world size %d' % (n, world)
+            per = n // world
+            out[k] = v[rank * per:(rank + 1) * per]
+        else:
+            out[k] = v
+    return out

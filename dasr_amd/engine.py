@@ -1,0 +1,303 @@
+"""Host-side plan builder for the MI355X kernels: parameter store (reference state_dict layout),
+NC16HW16 activation buffers, packed-weight registry and recorded op lists that libdasr_hip.so executes.
+
+PyTorch is used only as the device allocator / stream owner; all arithmetic runs in the HIP library.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+from ._lib import Tensor, ConvParams, WgradPart, WgradReducePart, PackDesc, Op
+
+SLOPE = 0.2
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ceil_div(a, b):
+    return (a + b - 1) // b
+
+
+# --------------------------------------------------------------------------------------------------
+class BTensor:
+    """Blocked activation tensor T[n][cb][y][x][16] (bf16 or f32) living in a torch CUDA tensor."""
+
+    def __init__(self, N, C_, H, W, f32, device):
+        self.N, self.C, self.H, self.W, self.f32 = N, C_, H, W, f32
+        self.planes = ceil_div(C_, 16)
+        self.t = torch.zeros((N, self.planes, H, W, 16), dtype=torch.float32 if f32 else torch.bfloat16, device=device)
+        self.esz = 4 if f32 else 2
+
+    def view(self, c0=0):
+        """dasr_tensor starting at channel c0 (multiple of 16)."""
+        assert c0 % 16 == 0 and c0 // 16 < self.planes, (c0, self.planes)
+        cbs = self.H * self.W * 16
+        return Tensor(self.t.data_ptr() + (c0 // 16) * cbs * self.esz, self.planes * cbs, cbs)
+
+    def nchw(self, C_=None):
+        """Debug/IO helper: gather to a torch NCHW float tensor (torch indexing only, no arithmetic)."""
+        C_ = C_ or self.C
+        return self.t.permute(0, 1, 4, 2, 3).reshape(self.N, self.planes * 16, self.H, self.W)[:, :C_].float()
+
+
+NULL_T = Tensor(None, 0, 0)
+
+
+# --------------------------------------------------------------------------------------------------
+class ParamStore:
+    """Flat fp32 parameter / gradient / Adam-moment buffers with the reference's state_dict keys."""
+
+    def __init__(self, spec, device):
+        self.spec = OrderedDict()
+        off = 0
+        for k, shape in spec:
+            n = 1
+            for s in shape:
+                n *= s
+            self.spec[k] = (off, tuple(shape), n)
+            off += n
+        self.total = off
+        self.device = device
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        self.m = torch.zeros(off, dtype=torch.float32, device=device)
+        self.v = torch.zeros(off, dtype=torch.float32, device=device)
+
+    def off(self, k):
+        return self.spec[k][0]
+
+    def ptr(self, k, buf=None):
+        buf = self.flat if buf is None else buf
+        return buf.data_ptr() + 4 * self.spec[k][0]
+
+    def view(self, k, buf=None):
+        o, shape, n = self.spec[k]
+        return (self.flat if buf is None else buf)[o:o + n].view(shape)
+
+    def state_dict(self):
+        return OrderedDict((k, self.view(k).detach().clone().cpu()) for k in self.spec)
+
+    def grad_dict(self):
+        return OrderedDict((k, self.view(k, self.grad).detach().clone().cpu()) for k in self.spec)
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self.spec if k not in sd]
+        unexpected = [k for k in sd if k not in self.spec]
+        if strict and (missing or unexpected):
+            raise RuntimeError('Error(s) in loading state_dict: missing %s unexpected %s' % (missing, unexpected))
+        for k in self.spec:
+            if k in sd:
+                v = sd[k]
+                if tuple(v.shape) != self.spec[k][1]:
+                    raise RuntimeError('size mismatch for %s: %s vs %s' % (k, tuple(v.shape), self.spec[k][1]))
+                self.view(k).copy_(v.to(self.device, torch.float32))
+
+
+# --------------------------------------------------------------------------------------------------
+class PackedRef:
+    __slots__ = ('off', 'lo_off', 'cout', 'cin_pad', 'ntaps', 'mt', 'prec')
+
+
+class PackRegistry:
+    """bf16 MFMA-fragment-ordered weight copies, rebuilt from the fp32 masters by one kernel launch."""
+
+    def __init__(self, params):
+        self.params = params
+        self.descs = []
+        self.prefix = [0]
+        self.size = 0  # bf16 elements
+        self.buf = None
+
+    def add(self, cout, cin_pad, ntaps, mt, prec, segs):
+        assert cin_pad % 16 == 0 and len(segs) <= 5
+        mg = ceil_div(ceil_div(cout, 32), mt)
+        pieces = mg * (cin_pad // 16) * ntaps * mt * 64
+        r = PackedRef()
+        r.off, r.cout, r.cin_pad, r.ntaps, r.mt, r.prec = self.size, cout, cin_pad, ntaps, mt, prec
+        r.lo_off = pieces * 8 if prec == 3 else 0
+        d = PackDesc()
+        d.dst_off, d.lo_off, d.cout, d.cin_pad, d.ntaps, d.mt, d.nseg = self.size, r.lo_off, cout, cin_pad, ntaps, mt, len(segs)
+        for i, s in enumerate(segs):
+            sg = d.seg[i]
+            sg.src_off, sg.src_cout, sg.src_cin, sg.cin_start, sg.cin_len, sg.src_c0, sg.transpose = s
+        self.descs.append(d)
+        self.prefix.append(self.prefix[-1] + pieces)
+        self.size += pieces * 8 * (2 if prec == 3 else 1)
+        return r
+
+    def finalize(self):
+        dev = self.params.device
+        self.buf = torch.zeros(self.size, dtype=torch.bfloat16, device=dev)
+        arr = (PackDesc * len(self.descs))(*self.descs)
+        self.desc_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self.prefix_dev = torch.tensor(self.prefix, dtype=torch.int64, device=dev)
+
+    def ptr(self, ref):
+        return self.buf.data_ptr() + 2 * ref.off
+
+    def op(self):
+        o = Op()
+        o.op = _lib.OP_PACK
+        o.p[0], o.i[0], o.l[0] = self.desc_dev.data_ptr(), len(self.descs), self.prefix[-1]
+        o.p[1], o.p[2], o.p[3] = self.prefix_dev.data_ptr(), self.params.flat.data_ptr(), self.buf.data_ptr()
+        return o
+
+    def run(self):
+        ops = (Op * 1)(self.op())
+        _lib.check(_lib.lib().dasr_run_ops(C.cast(ops, C.c_void_p), 1, _stream()), 'pack')
+
+
+# --------------------------------------------------------------------------------------------------
+class OpList:
+    def __init__(self):
+        self.ops = []
+        self.keep = []  # device tables that must outlive the list
+        self._arr = None
+
+    def add(self, o):
+        self.ops.append(o)
+        self._arr = None
+
+    def extend(self, other):
+        self.ops.extend(other.ops)
+        self.keep.extend(other.keep)
+        self._arr = None
+
+    def run(self):
+        if not self.ops:
+            return
+        if self._arr is None:
+            self._arr = (Op * len(self.ops))(*self.ops)
+        L = _lib.lib()
+        rc = L.dasr_run_ops(C.cast(self._arr, C.c_void_p), len(self.ops), _stream())
+        if rc != 0:
+            k = L.dasr_last_failed_op()
+            raise _lib.DasrHipError('dasr_run_ops: op #%d (kind %d) failed with code %d' % (k, self.ops[k].op if 0 <= k < len(self.ops) else -1, rc))
+
+
+def conv_op(pack, ref, inp, in_f32, cin, Hin, Win, Hout, Wout, N, bias=None, kh=3, stride=1, pad=1, ups=0, act=0, slope=SLOPE,
+            mask=None, mask_f32=0, alpha=1.0, res1=None, beta1=0.0, res2=None, beta2=0.0, out_f32=None, out_bf16=None, gamma=1.0):
+    assert cin == ref.cin_pad, (cin, ref.cin_pad)
+    o = Op()
+    o.op = _lib.OP_CONV
+    p = o.conv
+    p.inp, p.in_f32, p.Hin, p.Win, p.ups, p.cin = inp, int(in_f32), Hin, Win, ups, cin
+    p.w, p.w_lo_off, p.bias = pack.ptr(ref), ref.lo_off, bias
+    p.cout, p.Hout, p.Wout, p.N = ref.cout, Hout, Wout, N
+    p.kh, p.stride, p.pad, p.prec, p.mt = kh, stride, pad, ref.prec, ref.mt
+    p.act, p.slope = act, slope
+    p.mask, p.mask_f32 = (mask if mask is not None else NULL_T), mask_f32
+    p.alpha = alpha
+    p.res1, p.beta1 = (res1 if res1 is not None else NULL_T), beta1
+    p.res2, p.beta2 = (res2 if res2 is not None else NULL_T), beta2
+    p.out_f32 = out_f32 if out_f32 is not None else NULL_T
+    p.out_bf16 = out_bf16 if out_bf16 is not None else NULL_T
+    p.gamma = gamma
+    return o
+
+
+class WgradGroup:
+    """Parts of one wgrad launch (same kernel size / stride) + the matching reduce table."""
+
+    def __init__(self, kh, stride):
+        self.kh, self.stride = kh, stride
+        self.parts = []  # (WgradPart, WgradReducePart)
+
+    def add_conv(self, g, g_f32, g_planes_total, inp, in_f32, in_planes_total, cout, cin, Hin, Win, Hout, Wout, N,
+                 dst_w_off, dst_b_off, pad=1, ups=0):
+        """g / inp are BTensor-like callables c0 -> dasr_tensor view."""
+        ntaps = self.kh * self.kh
+        cin_pad = ceil_div(cin, 16) * 16
+        for oc0 in range(0, cout, 32):
+            for c0 in range(0, cin_pad, 64):
+                wp, rp = WgradPart(), WgradReducePart()
+                wp.g, wp.g_f32 = g(oc0), int(g_f32)
+                wp.inp, wp.in_f32 = inp(c0), int(in_f32)
+                wp.ups = ups
+                wp.n_ctiles = min(2, ceil_div(cin_pad - c0, 32))
+                wp.g_planes = min(2, g_planes_total - oc0 // 16)
+                wp.in_planes = min(4, in_planes_total - c0 // 16)
+                wp.Hin, wp.Win, wp.Hout, wp.Wout, wp.N = Hin, Win, Hout, Wout, N
+                wp.kh, wp.stride, wp.pad = self.kh, self.stride, pad
+                wp.want_bias = 1 if (dst_b_off is not None and c0 == 0) else 0
+                rp.ntaps, rp.oc0, rp.c0, rp.cout, rp.cin, rp.n_ctiles = ntaps, oc0, c0, cout, cin, wp.n_ctiles
+                rp.dst_w_off = dst_w_off
+                rp.dst_b_off = dst_b_off if (dst_b_off is not None and c0 == 0) else -1
+                self.parts.append((wp, rp))
+
+    def finalize(self, workspace, device, target_wgs=512):
+        wp0 = self.parts[0][0]
+        ntiles = wp0.N * ceil_div(wp0.Hout, 8) * ceil_div(wp0.Wout, 16)
+        nparts = len(self.parts)
+        self.nsplit = max(1, min(ntiles, target_wgs // nparts))
+        ntaps = self.kh * self.kh
+        off = 0
+        for wp, rp in self.parts:
+            wp.ws_off = rp.ws_off = off
+            off += self.nsplit * ntaps * 2048
+            wp.ws_bias_off = rp.ws_bias_off = off
+            off += self.nsplit * 32
+            rp.nsplit = self.nsplit
+        self.ws_floats = off
+        self.workspace = workspace
+        workspace.reserve(off)
+        wa = (WgradPart * nparts)(*[p[0] for p in self.parts])
+        ra = (WgradReducePart * nparts)(*[p[1] for p in self.parts])
+        self.w_dev = torch.frombuffer(bytearray(bytes(wa)), dtype=torch.uint8).to(device)
+        self.r_dev = torch.frombuffer(bytearray(bytes(ra)), dtype=torch.uint8).to(device)
+
+    def ops(self, grad_ptr, scale=1.0):
+        """[wgrad, reduce] ops; the workspace pointer is patched in by Workspace.finalize()."""
+        a, b = Op(), Op()
+        a.op = _lib.OP_WGRAD
+        a.p[0], a.i[0], a.i[1], a.i[2], a.i[3] = self.w_dev.data_ptr(), len(self.parts), self.nsplit, self.kh, self.stride
+        b.op = _lib.OP_WGRAD_REDUCE
+        b.p[0], b.i[0], b.p[2], b.f[0] = self.r_dev.data_ptr(), len(self.parts), grad_ptr, scale
+        self.workspace.register(a, b)
+        return [a, b]
+
+
+class Workspace:
+    """Grow-only float workspace shared by all wgrad groups of a plan (launches are stream ordered)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.need = 0
+        self.buf = None
+        self.pending = []
+
+    def reserve(self, n):
+        self.need = max(self.need, n)
+
+    def register(self, *ops):
+        self.pending.extend(ops)
+
+    def finalize(self):
+        self.buf = torch.zeros(max(self.need, 1), dtype=torch.float32, device=self.device)
+        for o in self.pending:
+            o.p[1] = self.buf.data_ptr()
+        self.pending = []
+
+
+def ensure_runtime_ready():
+    """One-time device probe (selects the wgrad gather mode); must run outside graph capture."""
+    L = _lib.lib()
+    if not torch.cuda.is_available():
+        raise _lib.DasrHipError('dasr_amd needs a ROCm GPU (MI355X); there is no CPU path')
+    global _PROBED
+    if not _PROBED:
+        rc = L.dasr_probe_tr16(_stream())
+        if rc < 0:
+            raise _lib.DasrHipError('dasr_probe_tr16 failed: %d' % rc)
+        _PROBED = True
+        global TR16_OK
+        TR16_OK = rc
+    return TR16_OK
+
+
+_PROBED = False
+TR16_OK = None

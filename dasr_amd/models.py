@@ -1,0 +1,267 @@
+"""Trainer objects with the reference's duck-typed interface (codes/SRN/models/base_model.py:6-85,
+SR_model.py:18-173, DASR_model.py:24-460): update_learning_rate / feed_data / optimize_parameters /
+get_current_log / get_current_learning_rate / test / get_current_visuals / save / save_training_state /
+resume_training, and the same checkpoint files ({iter}_G.pth, {iter}_D_target.pth, {iter}.state).
+
+All arithmetic of the step runs in libdasr_hip.so; this file only sequences recorded op lists, keeps the
+learning-rate schedule, and (de)serialises checkpoints in the reference's torch formats.
+"""
+import bisect
+import ctypes as C
+import logging
+import os
+from collections import Counter, OrderedDict
+
+import torch
+
+from . import _lib
+from .engine import Op, OpList, NULL_T, ensure_runtime_ready, _stream
+from .init import kaiming_state_dict
+from .rrdbnet import RRDBNetHIP, rrdbnet_param_spec
+
+logger = logging.getLogger('base')
+
+
+def create_model(opt):
+    """codes/SRN/models/__init__.py:5-26; 'DASR_FS_ESRGAN_patchGAN' (shipped JSONs) aliases 'DASR'."""
+    model = opt['model']
+    if model == 'sr':
+        m = SRModel(opt)
+    elif model in ('DASR', 'DASR_FS_ESRGAN_patchGAN'):
+        from .dasr_model import DASR_Model
+        m = DASR_Model(opt)
+    else:
+        raise NotImplementedError('Model [{:s}] not recognized.'.format(model))
+    logger.info('Model [{:s}] is created.'.format(m.__class__.__name__))
+    return m
+
+
+class MultiStepLR:
+    """torch.optim.lr_scheduler.MultiStepLR semantics as the reference uses it (scheduler stepped at the
+    top of every iteration, DASR_model.py:146-149, base_model.py:35-37)."""
+
+    def __init__(self, base_lr, milestones, gamma):
+        self.base_lr, self.milestones, self.gamma = base_lr, sorted(int(m) for m in milestones), gamma
+        self.last_epoch = 0
+
+    def step(self):
+        self.last_epoch += 1
+
+    def get_lr(self):
+        return self.base_lr * self.gamma ** bisect.bisect_right(self.milestones, self.last_epoch)
+
+    def state_dict(self):
+        return {'milestones': Counter(self.milestones), 'gamma': self.gamma, 'base_lrs': [self.base_lr],
+                'last_epoch': self.last_epoch, '_step_count': self.last_epoch + 1, '_last_lr': [self.get_lr()]}
+
+    def load_state_dict(self, sd):
+        self.last_epoch = sd['last_epoch']
+        self.gamma = sd.get('gamma', self.gamma)
+        if 'milestones' in sd:
+            self.milestones = sorted(sd['milestones'].elements()) if isinstance(sd['milestones'], Counter) else sorted(sd['milestones'])
+        if 'base_lrs' in sd:
+            self.base_lr = sd['base_lrs'][0]
+
+
+class AdamHIP:
+    """torch.optim.Adam (eps 1e-8, no amsgrad, L2 weight decay) over a ParamStore's flat buffers."""
+
+    def __init__(self, params, lr, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8):
+        self.params, self.lr, self.betas, self.wd, self.eps = params, lr, betas, weight_decay, eps
+        self.step_count = 0
+
+    def step(self, lr):
+        self.step_count += 1
+        P = self.params
+        _lib.check(_lib.lib().dasr_adam(P.flat.data_ptr(), P.grad.data_ptr(), P.m.data_ptr(), P.v.data_ptr(), P.total, lr,
+                                        self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, _stream()), 'adam')
+
+    def state_dict(self, lr):
+        P = self.params
+        state = {}
+        for i, k in enumerate(P.spec):
+            if self.step_count > 0:
+                state[i] = {'step': torch.tensor(float(self.step_count)), 'exp_avg': P.view(k, P.m).detach().clone().cpu(),
+                            'exp_avg_sq': P.view(k, P.v).detach().clone().cpu()}
+        group = {'lr': lr, 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': self.wd, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'initial_lr': self.lr, 'params': list(range(len(P.spec)))}
+        return {'state': state, 'param_groups': [group]}
+
+    def load_state_dict(self, sd):
+        P = self.params
+        for i, k in enumerate(P.spec):
+            st = sd['state'].get(i)
+            if st is not None:
+                P.view(k, P.m).copy_(st['exp_avg'].to(P.device))
+                P.view(k, P.v).copy_(st['exp_avg_sq'].to(P.device))
+                self.step_count = int(float(st['step']))
+        g = sd['param_groups'][0]
+        self.betas, self.eps, self.wd = tuple(g['betas']), g['eps'], g['weight_decay']
+
+
+class BaseModel:
+    def __init__(self, opt):
+        self.opt = opt
+        if opt['gpu_ids'] is None:
+            raise _lib.DasrHipError('gpu_ids is null: the MI355X trainer has no CPU path (use the oracle for CPU runs)')
+        ensure_runtime_ready()
+        self.device = torch.device('cuda', torch.cuda.current_device())
+        self.is_train = opt['is_train']
+        self.schedulers = []
+        self.optimizers = []
+        # data-parallel group (one process per GPU, see dasr_amd/dist.py); None = single GPU
+        self.dp = None
+
+    def update_learning_rate(self):
+        for s in self.schedulers:
+            s.step()
+
+    def get_current_learning_rate(self):
+        return self.schedulers[0].get_lr()
+
+    def get_network_description(self, network):
+        n = network.params.total
+        s = '%s(%s)' % (network.__class__.__name__, ', '.join('%s%s' % (k, list(v[1])) for k, v in list(network.params.spec.items())[:4]) + ', ...')
+        return s, n
+
+    def save_network(self, network, network_label, iter_step):
+        """{iter}_{label}.pth = plain state_dict of CPU tensors (base_model.py:49-58)."""
+        path = os.path.join(self.opt['path']['models'], '{}_{}.pth'.format(iter_step, network_label))
+        torch.save(network.state_dict(), path)
+
+    def load_network(self, load_path, network, strict=True):
+        network.load_state_dict(torch.load(load_path, map_location='cpu'), strict=strict)
+
+    def save_training_state(self, epoch, iter_step):
+        """training_state/{iter}.state (base_model.py:65-74); optimizer/scheduler entries are torch-format dicts."""
+        state = {'epoch': epoch, 'iter': iter_step, 'schedulers': [s.state_dict() for s in self.schedulers],
+                 'optimizers': [o.state_dict(s.get_lr()) for o, s in zip(self.optimizers, self.schedulers)]}
+        torch.save(state, os.path.join(self.opt['path']['training_state'], '{}.state'.format(iter_step)))
+
+    def resume_training(self, resume_state, opt=None):
+        ro, rs = resume_state['optimizers'], resume_state['schedulers']
+        assert len(ro) == len(self.optimizers), 'Wrong lengths of optimizers'
+        assert len(rs) == len(self.schedulers), 'Wrong lengths of schedulers'
+        for i, o in enumerate(ro):
+            self.optimizers[i].load_state_dict(o)
+        for i, s in enumerate(rs):
+            self.schedulers[i].load_state_dict(s)
+
+
+def _define_G(opt, device):
+    """networks.py:83-147 restricted to the hot-path generator (RRDB_net, upconv)."""
+    g = opt['network_G']
+    which = g['which_model_G']
+    if which not in ('RRDB_net', 'RRDB_mask'):
+        raise NotImplementedError('Generator model [{:s}] not recognized'.format(which))
+    net = RRDBNetHIP(in_nc=g['in_nc'], out_nc=g['out_nc'], nf=g['nf'], nb=g['nb'], upscale=g['scale'], device=device)
+    if opt['is_train']:
+        logger.info('Initialization method [kaiming]')
+        net.load_state_dict(kaiming_state_dict(rrdbnet_param_spec(g['in_nc'], g['out_nc'], g['nf'], g['nb']), 0.1))
+    else:
+        net.repack()
+    return net
+
+
+class SRModel(BaseModel):
+    """Generator-only trainer (SR_model.py:18-173): l_pix_w * L1|L2(G(LR), HR), Adam(default betas), MultiStepLR."""
+
+    def __init__(self, opt):
+        super().__init__(opt)
+        t = opt['train']
+        self.scale = opt['scale']
+        self.netG = _define_G(opt, self.device)
+        self.load()
+        if self.is_train:
+            if t['pixel_criterion'] != 'l1':
+                raise NotImplementedError('Loss type [{:s}] is not recognized.'.format(str(t['pixel_criterion'])))
+            self.l_pix_w = t['pixel_weight']
+            wd = t['weight_decay_G'] if t['weight_decay_G'] else 0
+            self.optimizer_G = AdamHIP(self.netG.params, t['lr_G'], (0.9, 0.999), wd)
+            self.optimizers.append(self.optimizer_G)
+            if t['lr_scheme'] != 'MultiStepLR':
+                raise NotImplementedError('MultiStepLR learning rate scheme is enough.')
+            self.schedulers.append(MultiStepLR(t['lr_G'], t['lr_steps'], t['lr_gamma']))
+            self.log_dict = OrderedDict()
+            self.loss_acc = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self._step_ops = {}
+
+    def feed_data(self, data, need_HR=True):
+        self.var_L = data['LR'].to(self.device, non_blocking=True)
+        if 'HR' in data:
+            self.real_H = data['HR'].to(self.device, non_blocking=True)
+
+    def _ops_for(self, plan):
+        """loss op list for this plan: zero the loss accumulator, L1 forward+gradient into plan.g_sr."""
+        key = id(plan)
+        if key not in self._step_ops:
+            N, C_, H, W = self.real_H.shape
+            hr_buf = torch.zeros_like(self.real_H)
+            ops = OpList()
+            o = Op()
+            o.op = _lib.OP_FILL
+            o.p[0], o.l[0], o.f[0] = self.loss_acc.data_ptr(), 4, 0.0
+            ops.add(o)
+            o = Op()
+            o.op = _lib.OP_L1LOSS
+            o.t[0], o.p[0], o.p[1] = plan.sr.view(), hr_buf.data_ptr(), None
+            o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = N, C_, H, W, 0
+            o.f[0] = float(self.l_pix_w) / float(N * C_ * H * W)
+            o.p[2], o.t[1] = self.loss_acc.data_ptr(), plan.g_sr.view()
+            ops.add(o)
+            self._step_ops[key] = (ops, hr_buf)
+        return self._step_ops[key]
+
+    def optimize_parameters(self, step):
+        N, _, h, w = self.var_L.shape
+        plan = self.netG.plan(N, h, w)
+        loss_ops, hr_buf = self._ops_for(plan)
+        hr_buf.copy_(self.real_H)
+        plan.set_input(self.var_L)
+        plan.fwd.run()
+        loss_ops.run()
+        if self.dp is None or self.dp.world == 1:
+            plan.bwd.run()
+        else:
+            plan.set_grad_scale(self.dp.grad_scale)
+            g = self.netG.params.grad
+            for seg, (lo, hi) in plan.bwd_segments():
+                seg.run()
+                self.dp.reduce_async(g[lo:hi])
+            self.dp.wait()
+        self.optimizer_G.step(self.schedulers[0].get_lr())
+        self.netG.repack()
+        self.fake_H = plan.read_output()
+        self._l_pix_dev = self.loss_acc[0:1]
+        self.log_dict['l_pix'] = None  # materialised lazily by get_current_log (no per-step host sync)
+
+    def get_current_log(self):
+        if 'l_pix' in self.log_dict:
+            self.log_dict['l_pix'] = float(self._l_pix_dev.item())
+        return self.log_dict
+
+    def test(self):
+        N, _, h, w = self.var_L.shape
+        self.fake_H = self.netG.forward(self.var_L).clone()
+
+    def get_current_visuals(self, need_HR=True):
+        out = OrderedDict()
+        out['LR'] = self.var_L.detach()[0].float().cpu()
+        out['SR'] = self.fake_H.detach()[0].float().cpu()
+        if need_HR:
+            out['HR'] = self.real_H.detach()[0].float().cpu()
+        return out
+
+    def print_network(self):
+        s, n = self.get_network_description(self.netG)
+        logger.info('Network G structure: {}, with parameters: {:,d}'.format(self.netG.__class__.__name__, n))
+
+    def load(self):
+        p = self.opt['path']['pretrain_model_G']
+        if p is not None:
+            logger.info('Loading pretrained model for G [{:s}] ...'.format(p))
+            self.load_network(p, self.netG)
+
+    def save(self, iter_step):
+        self.save_network(self.netG, 'G', iter_step)

@@ -1,0 +1,340 @@
+"""RRDBNet generator (reference: codes/SRN/models/modules/architecture.py:174-205, block.py:254-309,854-861)
+as recorded op lists over the MI355X kernels.
+
+Numerics recipe ("recipe A"): the dense-block convs (92% of the FLOPs, damped by the
+0.2 residual scales) run with bf16 operands / fp32 accumulate; the six convs that sit on the residual
+stream (fea_conv, LR_conv, the two upconvs, HR_conv0/1) run in split-bf16 (prec 3, ~fp32) on fp32
+activations.  The residual stream itself is kept in fp32; dense-slab channels are stored in bf16.
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+from .engine import (BTensor, ParamStore, PackRegistry, OpList, WgradGroup, Workspace, conv_op, ceil_div, SLOPE, NULL_T)
+from ._lib import Op, Tensor
+
+GC = 32  # growth channels are hard-wired to 32 in the reference (architecture.py:183)
+
+
+def rrdbnet_param_spec(in_nc, out_nc, nf, nb):
+    """state_dict keys / shapes of the reference RRDBNet with upsample_mode='upconv' (SURVEY.md App. A)."""
+    spec = [('model.0.weight', (nf, in_nc, 3, 3)), ('model.0.bias', (nf,))]
+    for i in range(nb):
+        for r in (1, 2, 3):
+            for j in range(1, 6):
+                cin = nf + (j - 1) * GC
+                cout = GC if j < 5 else nf
+                p = 'model.1.sub.%d.RDB%d.conv%d.0.' % (i, r, j)
+                spec += [(p + 'weight', (cout, cin, 3, 3)), (p + 'bias', (cout,))]
+    spec += [('model.1.sub.%d.weight' % nb, (nf, nf, 3, 3)), ('model.1.sub.%d.bias' % nb, (nf,))]
+    for idx, co in ((3, nf), (6, nf), (8, nf), (10, out_nc)):
+        spec += [('model.%d.weight' % idx, (co, nf, 3, 3)), ('model.%d.bias' % idx, (co,))]
+    return spec
+
+
+class RRDBNetHIP:
+    def __init__(self, in_nc=3, out_nc=3, nf=64, nb=23, upscale=4, device='cuda', rdb_prec=1, stream_prec=3):
+        assert upscale == 4 and nf % 32 == 0 and in_nc <= 16 and out_nc <= 16
+        self.in_nc, self.out_nc, self.nf, self.nb = in_nc, out_nc, nf, nb
+        self.device = torch.device(device)
+        self.params = ParamStore(rrdbnet_param_spec(in_nc, out_nc, nf, nb), self.device)
+        self.rdb_prec, self.stream_prec = rdb_prec, stream_prec
+        self.pack = PackRegistry(self.params)
+        self._register_packs()
+        self.pack.finalize()
+        self.plans = {}
+
+    # ---- packed weights ----------------------------------------------------------------------------
+    def _seg_fwd(self, key, cout, cin):
+        return (self.params.off(key), cout, cin, 0, cin, 0, 0)
+
+    def _register_packs(self):
+        nf, P, sp = self.nf, self.params, self.stream_prec
+        mt_nf = 2 if (nf >= 64 and self.rdb_prec == 1) else 1
+        self.pk = {}
+        # stream convs, forward (prec 3 -> mt 1)
+        self.pk['fea'] = self.pack.add(nf, 16, 9, 1, sp, [(P.off('model.0.weight'), nf, self.in_nc, 0, self.in_nc, 0, 0)])
+        lr = 'model.1.sub.%d.weight' % self.nb
+        for name, key, cout in (('lr', lr, nf), ('up1', 'model.3.weight', nf), ('up2', 'model.6.weight', nf),
+                                ('hr0', 'model.8.weight', nf), ('hr1', 'model.10.weight', self.out_nc)):
+            self.pk[name] = self.pack.add(cout, nf, 9, 1, sp, [self._seg_fwd(key, cout, nf)])
+            # data-gradient: transposed + tap-flipped; packed cin = forward cout (padded to 16)
+            cin_b = ceil_div(cout, 16) * 16
+            self.pk[name + '_b'] = self.pack.add(nf, cin_b, 9, 1, sp, [(P.off(key), cout, nf, 0, cout, 0, 1)])
+        # dense blocks
+        for i in range(self.nb):
+            for r in (1, 2, 3):
+                pre = 'model.1.sub.%d.RDB%d.conv' % (i, r)
+                for j in range(1, 6):
+                    cin = nf + (j - 1) * GC
+                    cout = GC if j < 5 else nf
+                    self.pk[(i, r, j)] = self.pack.add(cout, cin, 9, mt_nf if j == 5 else 1, self.rdb_prec,
+                                                       [self._seg_fwd('%s%d.0.weight' % (pre, j), cout, cin)])
+                # backward convs: k = 4..1 produce g_k (32 ch), k = 0 produces g_x (nf ch).
+                # gslab' channel order: [g5 (nf) | g4 | g3 | g2 | g1]
+                for k in range(4, -1, -1):
+                    segs = []
+                    for j in range(5, k, -1):
+                        cout_j = GC if j < 5 else nf
+                        cin_j = nf + (j - 1) * GC
+                        start = 0 if j == 5 else nf + (4 - j) * GC
+                        src_c0 = 0 if k == 0 else nf + (k - 1) * GC
+                        segs.append((P.off('%s%d.0.weight' % (pre, j)), cout_j, cin_j, start, cout_j, src_c0, 1))
+                    cin_b = nf + (4 - k) * GC
+                    cout_b = nf if k == 0 else GC
+                    self.pk[(i, r, 'b', k)] = self.pack.add(cout_b, cin_b, 9, mt_nf if k == 0 else 1, self.rdb_prec, segs)
+
+    def repack(self):
+        self.pack.run()
+
+    # ---- plan ---------------------------------------------------------------------------------------
+    def plan(self, N, h, w):
+        key = (N, h, w)
+        if key not in self.plans:
+            self.plans[key] = _Plan(self, N, h, w)
+        return self.plans[key]
+
+    # convenience API used by the trainers / tests -------------------------------------------------------
+    def state_dict(self):
+        return self.params.state_dict()
+
+    def load_state_dict(self, sd, strict=True):
+        self.params.load_state_dict(sd, strict)
+        self.repack()
+
+    def forward(self, x):
+        """x: NCHW fp32 CUDA tensor -> SR NCHW fp32 CUDA tensor (keeps activations for backward)."""
+        N, _, h, w = x.shape
+        p = self.plan(N, h, w)
+        p.set_input(x)
+        p.fwd.run()
+        return p.read_output()
+
+
+class _Plan:
+    """Buffers + recorded forward / backward op lists for one (N, h, w)."""
+
+    def __init__(self, net, N, h, w):
+        self.net, self.N, self.h, self.w = net, N, h, w
+        dev, nf, nb = net.device, net.nf, net.nb
+        P, pack, pk = net.params, net.pack, net.pk
+        H2, W2, H4, W4 = 2 * h, 2 * w, 4 * h, 4 * w
+        sc = nf + 4 * GC  # dense-slab channels
+        B = lambda C_, H, W, f32: BTensor(N, C_, H, W, f32, dev)
+        self.x_nchw = torch.zeros((N, net.in_nc, h, w), dtype=torch.float32, device=dev)
+        self.sr_nchw = torch.zeros((N, net.out_nc, H4, W4), dtype=torch.float32, device=dev)
+        self.x_in = B(16, h, w, True)
+        self.fea = B(nf, h, w, True)
+        self.slabs = [B(sc, h, w, False) for _ in range(3 * nb)]
+        self.stream = [B(nf, h, w, True) for _ in range(4)]
+        self.t0 = B(nf, h, w, True)
+        self.u1 = B(nf, H2, W2, True)
+        self.u2 = B(nf, H4, W4, True)
+        self.h0 = B(nf, H4, W4, True)
+        self.sr = B(16, H4, W4, True)
+        # backward
+        self.g_sr = B(16, H4, W4, True)
+        self.g4a = B(nf, H4, W4, True)
+        self.g4b = B(nf, H4, W4, True)
+        self.g2a = B(nf, H2, W2, True)
+        self.g2b = B(nf, H2, W2, True)
+        self.g_t0 = B(nf, h, w, True)
+        self.gstream = [B(nf, h, w, True) for _ in range(4)]
+        self.gslab = [B(sc, h, w, False) for _ in range(2)]
+        self.g_fea = B(nf, h, w, True)
+        self.ws = Workspace(dev)
+        self._build_forward()
+        self._build_backward()
+        self.ws.finalize()
+
+    # ---- IO -----------------------------------------------------------------------------------------
+    def set_input(self, x):
+        self.x_nchw.copy_(x)
+
+    def read_output(self):
+        return self.sr_nchw
+
+    # ---- forward --------------------------------------------------------------------------------------
+    def _build_forward(self):
+        net, N, h, w = self.net, self.N, self.h, self.w
+        nf, nb, P, pack, pk = net.nf, net.nb, net.params, net.pack, net.pk
+        H2, W2, H4, W4 = 2 * h, 2 * w, 4 * h, 4 * w
+        ops = OpList()
+        o = Op()
+        o.op = _lib.OP_NCHW2B
+        o.p[0], o.i[0], o.i[1], o.i[2], o.i[3] = self.x_nchw.data_ptr(), N, net.in_nc, h, w
+        o.t[0], o.t[1] = self.x_in.view(), NULL_T
+        ops.add(o)
+        # fea_conv: fp32 stream + bf16 shadow into the first dense slab
+        ops.add(conv_op(pack, pk['fea'], self.x_in.view(), True, 16, h, w, h, w, N, bias=P.ptr('model.0.bias'),
+                        out_f32=self.fea.view(), out_bf16=self.slabs[0].view(0)))
+        X = self.fea  # fp32 input of the current RDB
+        free = list(self.stream)
+        self.rdb_in = []
+        for i in range(nb):
+            Xrrdb = X
+            for r in (1, 2, 3):
+                ridx = 3 * i + (r - 1)
+                S = self.slabs[ridx]
+                pre = 'model.1.sub.%d.RDB%d.conv' % (i, r)
+                for j in range(1, 5):
+                    cin = nf + (j - 1) * GC
+                    ops.add(conv_op(pack, pk[(i, r, j)], S.view(0), False, cin, h, w, h, w, N, bias=P.ptr('%s%d.0.bias' % (pre, j)),
+                                    act=1, out_bf16=S.view(cin)))
+                last = (ridx == 3 * nb - 1)
+                Y = next(b for b in free if b is not X and b is not Xrrdb)
+                nxt = None if last else self.slabs[ridx + 1].view(0)
+                if r < 3:
+                    ops.add(conv_op(pack, pk[(i, r, 5)], S.view(0), False, nf + 4 * GC, h, w, h, w, N, bias=P.ptr(pre + '5.0.bias'),
+                                    alpha=0.2, res1=X.view(), beta1=1.0, out_f32=Y.view(), out_bf16=nxt))
+                else:  # RDB3 + RRDB residual fused: 0.2*(0.2*c + x3) + x_rrdb
+                    ops.add(conv_op(pack, pk[(i, r, 5)], S.view(0), False, nf + 4 * GC, h, w, h, w, N, bias=P.ptr(pre + '5.0.bias'),
+                                    alpha=0.04, res1=X.view(), beta1=0.2, res2=Xrrdb.view(), beta2=1.0, out_f32=Y.view(), out_bf16=nxt))
+                X = Y
+        self.x_last = X
+        lrb = 'model.1.sub.%d.bias' % nb
+        ops.add(conv_op(pack, pk['lr'], X.view(), True, nf, h, w, h, w, N, bias=P.ptr(lrb), res1=self.fea.view(), beta1=1.0,
+                        out_f32=self.t0.view()))
+        ops.add(conv_op(pack, pk['up1'], self.t0.view(), True, nf, h, w, H2, W2, N, bias=P.ptr('model.3.bias'), ups=1, act=1,
+                        out_f32=self.u1.view()))
+        ops.add(conv_op(pack, pk['up2'], self.u1.view(), True, nf, H2, W2, H4, W4, N, bias=P.ptr('model.6.bias'), ups=1, act=1,
+                        out_f32=self.u2.view()))
+        ops.add(conv_op(pack, pk['hr0'], self.u2.view(), True, nf, H4, W4, H4, W4, N, bias=P.ptr('model.8.bias'), act=1,
+                        out_f32=self.h0.view()))
+        ops.add(conv_op(pack, pk['hr1'], self.h0.view(), True, nf, H4, W4, H4, W4, N, bias=P.ptr('model.10.bias'),
+                        out_f32=self.sr.view()))
+        o = Op()
+        o.op = _lib.OP_B2NCHW
+        o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.p[0] = self.sr.view(), N, net.out_nc, H4, W4, self.sr_nchw.data_ptr()
+        ops.add(o)
+        self.fwd = ops
+
+    # ---- backward (input: self.g_sr filled by a loss kernel) -----------------------------------------------
+    def _wg(self, ops, conv_key, g, g_f32, inp, in_f32, cout, cin, Hin, Win, Hout, Wout, ups=0, groups=None):
+        """single-conv wgrad group"""
+        P = self.net.params
+        grp = WgradGroup(3, 1)
+        grp.add_conv(g.view, g_f32, g.planes, inp.view, in_f32, inp.planes, cout, cin, Hin, Win, Hout, Wout, self.N,
+                     P.off(conv_key + 'weight'), P.off(conv_key + 'bias'), ups=ups)
+        grp.finalize(self.ws, self.net.device)
+        for o in grp.ops(P.grad.data_ptr()):
+            ops.add(o)
+        ops.keep.append(grp)
+
+    def _build_backward(self):
+        net, N, h, w = self.net, self.N, self.h, self.w
+        nf, nb, P, pack, pk = net.nf, net.nb, net.params, net.pack, net.pk
+        H2, W2, H4, W4 = 2 * h, 2 * w, 4 * h, 4 * w
+        ops = OpList()
+        g_h0, g_u2, g_up2 = self.g4a, self.g4b, self.g4a
+        # HR_conv1
+        self._wg(ops, 'model.10.', self.g_sr, True, self.h0, True, net.out_nc, nf, H4, W4, H4, W4)
+        ops.add(conv_op(pack, pk['hr1_b'], self.g_sr.view(), True, 16, H4, W4, H4, W4, N, mask=self.h0.view(), mask_f32=1,
+                        out_f32=g_h0.view()))
+        # HR_conv0
+        self._wg(ops, 'model.8.', g_h0, True, self.u2, True, nf, nf, H4, W4, H4, W4)
+        ops.add(conv_op(pack, pk['hr0_b'], g_h0.view(), True, nf, H4, W4, H4, W4, N, mask=self.u2.view(), mask_f32=1,
+                        out_f32=g_u2.view()))
+        # upconv2 (model.6): wgrad on the upsampled u1; dgrad at 4h x 4w then 2x2 sum (+ LeakyReLU' of u1)
+        self._wg(ops, 'model.6.', g_u2, True, self.u1, True, nf, nf, H2, W2, H4, W4, ups=1)
+        ops.add(conv_op(pack, pk['up2_b'], g_u2.view(), True, nf, H4, W4, H4, W4, N, out_f32=g_up2.view()))
+        g_u1 = self.g2a
+        o = Op()
+        o.op = _lib.OP_DOWNSUM
+        o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = g_up2.view(), N, nf, H2, W2
+        o.t[1], o.i[4], o.f[0], o.t[2], o.t[3] = self.u1.view(), 1, SLOPE, g_u1.view(), NULL_T
+        ops.add(o)
+        # upconv1 (model.3)
+        self._wg(ops, 'model.3.', g_u1, True, self.t0, True, nf, nf, h, w, H2, W2, ups=1)
+        g_up1 = self.g2b
+        ops.add(conv_op(pack, pk['up1_b'], g_u1.view(), True, nf, H2, W2, H2, W2, N, out_f32=g_up1.view()))
+        o = Op()
+        o.op = _lib.OP_DOWNSUM
+        o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = g_up1.view(), N, nf, h, w
+        o.t[1], o.i[4], o.f[0], o.t[2], o.t[3] = NULL_T, 0, SLOPE, self.g_t0.view(), NULL_T
+        ops.add(o)
+        # LR_conv (model.1.sub.nb): t0 = fea + LR_conv(x_last)
+        lrk = 'model.1.sub.%d.' % nb
+        self._wg(ops, lrk, self.g_t0, True, self.x_last, True, nf, nf, h, w, h, w)
+        self._marks = [(len(ops.ops), P.off(lrk + 'weight'))]
+        bucket_every = max(1, ceil_div(nb, 4))
+        free = list(self.gstream)
+        G = free[0]
+        gs_cur = 0
+        ops.add(conv_op(pack, pk['lr_b'], self.g_t0.view(), True, nf, h, w, h, w, N, out_f32=G.view(),
+                        out_bf16=self.gslab[gs_cur].view(0), gamma=0.04))
+        # RRDB chain, reversed
+        for i in range(nb - 1, -1, -1):
+            Grr = G  # grad wrt the RRDB output
+            Gout = None  # grad wrt the current RDB output (None: it is 0.2*Grr, folded into the epilogue)
+            for r in (3, 2, 1):
+                ridx = 3 * i + (r - 1)
+                S, Gs = self.slabs[ridx], self.gslab[gs_cur]
+                for k in range(4, 0, -1):
+                    cin_b = nf + (4 - k) * GC
+                    ops.add(conv_op(pack, pk[(i, r, 'b', k)], Gs.view(0), False, cin_b, h, w, h, w, N,
+                                    mask=S.view(nf + (k - 1) * GC), mask_f32=0, out_bf16=Gs.view(cin_b)))
+                # weight gradients of the 5 convs of this RDB in one launch
+                grp = WgradGroup(3, 1)
+                pre = 'model.1.sub.%d.RDB%d.conv' % (i, r)
+                for j in range(1, 6):
+                    cin = nf + (j - 1) * GC
+                    cout = GC if j < 5 else nf
+                    gc0 = 0 if j == 5 else nf + (4 - j) * GC
+                    grp.add_conv((lambda c0, gc0=gc0, Gs=Gs: Gs.view(gc0 + c0)), False, cout // 16, S.view, False, cin // 16,
+                                 cout, cin, h, w, h, w, N, P.off('%s%d.0.weight' % (pre, j)), P.off('%s%d.0.bias' % (pre, j)))
+                grp.finalize(self.ws, net.device)
+                for o in grp.ops(P.grad.data_ptr()):
+                    ops.add(o)
+                ops.keep.append(grp)
+                # g_x conv with the residual bookkeeping fused
+                Gin = next(b for b in free if b is not Grr and b is not Gout)
+                first = (ridx == 0)
+                nxt = None if first else self.gslab[1 - gs_cur].view(0)
+                if r == 3:
+                    ops.add(conv_op(pack, pk[(i, r, 'b', 0)], Gs.view(0), False, nf + 4 * GC, h, w, h, w, N,
+                                    res1=Grr.view(), beta1=0.2, out_f32=Gin.view(), out_bf16=nxt, gamma=0.2))
+                elif r == 2:
+                    ops.add(conv_op(pack, pk[(i, r, 'b', 0)], Gs.view(0), False, nf + 4 * GC, h, w, h, w, N,
+                                    res1=Gout.view(), beta1=1.0, out_f32=Gin.view(), out_bf16=nxt, gamma=0.2))
+                else:
+                    ops.add(conv_op(pack, pk[(i, r, 'b', 0)], Gs.view(0), False, nf + 4 * GC, h, w, h, w, N,
+                                    res1=Gout.view(), beta1=1.0, res2=Grr.view(), beta2=1.0, out_f32=Gin.view(), out_bf16=nxt, gamma=0.04))
+                Gout = Gin
+                gs_cur = 1 - gs_cur
+            G = Gout
+            if i > 0 and i % bucket_every == 0:
+                self._marks.append((len(ops.ops), P.off('model.1.sub.%d.RDB1.conv1.0.weight' % i)))
+        # ShortcutBlock: g_fea = g_chain + g_t0
+        o = Op()
+        o.op = _lib.OP_AXPBY
+        o.t[0], o.f[0], o.t[1], o.f[1] = G.view(), 1.0, self.g_t0.view(), 1.0
+        o.i[0], o.i[1], o.i[2], o.i[3] = N, nf, h, w
+        o.t[2], o.t[3], o.f[2] = self.g_fea.view(), NULL_T, 1.0
+        ops.add(o)
+        self._wg(ops, 'model.0.', self.g_fea, True, self.x_in, True, nf, net.in_nc, h, w, h, w)
+        self._marks.append((len(ops.ops), 0))
+        self.bwd = ops
+        self._segments = None
+
+    def set_grad_scale(self, scale):
+        """fold 1/world_size into the deterministic wgrad reduction (data-parallel mean gradient)"""
+        for o in self.bwd.ops:
+            if o.op == _lib.OP_WGRAD_REDUCE and o.f[0] != scale:
+                o.f[0] = scale
+                self.bwd._arr = None
+                self._segments = None
+
+    def bwd_segments(self):
+        """backward op list cut at gradient-bucket boundaries: [(OpList, (lo, hi) of the flat grad buffer that is
+        complete once the segment has run)], in execution order (the buffer fills from its end)."""
+        if self._segments is None:
+            segs, prev_idx, prev_hi = [], 0, self.net.params.total
+            for idx, lo in self._marks:
+                ol = OpList()
+                ol.ops = self.bwd.ops[prev_idx:idx]
+                segs.append((ol, (lo, prev_hi)))
+                prev_idx, prev_hi = idx, lo
+            self._segments = segs
+        return self._segments

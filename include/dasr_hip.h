@@ -1,0 +1,173 @@
+/*
+ * dasr_hip.h -- C ABI of libdasr_hip.so, the MI355X (gfx950) kernels behind the DASR SRN
+ * training step (ShuhangGu/DASR, codes/SRN).  Plain pointers and sizes only; no torch types.
+ *
+ * The reference has NO native/FFI layer: every op below replaces a stock
+ * PyTorch op that the reference reaches through nn.Module graphs.  The citation on each entry
+ * point names the reference construct whose arithmetic it takes over.
+ *
+ * Activation layout ("NC16HW16"): T[n][cb][y][x][16], 16 channels innermost, bf16 or f32.
+ * A dasr_tensor is a view: base pointer of plane cb=0 of the slice, element strides between
+ * images and between 16-channel planes.  H, W travel in the op parameters.
+ *
+ * All launchers are asynchronous on `stream` (a hipStream_t passed as void*), own no memory,
+ * and return 0 on success or a hipError_t / negative DASR_E* code.
+ */
+#ifndef DASR_HIP_H
+#define DASR_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DASR_ABI_VERSION 1
+#define DASR_EINVAL (-22)
+
+typedef struct {
+    void*   p;          /* base of plane 0 (device pointer) */
+    int64_t n_stride;   /* elements between images */
+    int64_t cb_stride;  /* elements between 16-channel planes */
+} dasr_tensor;
+
+/* ---- implicit-GEMM convolution, forward and data-gradient ------------------------------------
+ * Replaces nn.Conv2d fwd (+bias, +LeakyReLU/ReLU, + residual scale-add) of conv_block
+ * (codes/SRN/models/modules/block.py:130-156), the torch.cat of ResidualDenseBlock_5C
+ * (block.py:280-286: input = first cin/16 planes of a dense slab, output written into its own
+ * planes), nn.Upsample(nearest,2) of upconv_blcok (block.py:854-861, `ups`), the 4x4 convs of
+ * NLayerDiscriminator (architecture.py:983-1024) and VGG19 convs (architecture.py:1060-1088).
+ * The data-gradient of a stride-1 conv is the same op on flipped/transposed packed weights
+ * with `mask` = forward activation (LeakyReLU'/ReLU').
+ *   v = acc + bias[oc]; if act: v = v>0 ? v : slope*v; if mask.p: v *= (mask>0 ? 1 : slope)
+ *   v = alpha*v + beta1*res1 + beta2*res2;  out_f32 = v;  out_bf16 = bf16(gamma*v)
+ */
+typedef struct {
+    dasr_tensor in;  int32_t in_f32;  int32_t Hin, Win;  int32_t ups;  int32_t cin; /* cin % 16 == 0 */
+    const void* w;   int64_t w_lo_off;      /* packed bf16 weights (dasr_pack_weights); lo plane offset (elements) for prec 3 */
+    const float* bias;                      /* [cout] or NULL */
+    int32_t cout, Hout, Wout, N;
+    int32_t kh, stride, pad;                /* 3/1/1 or 4/2/1 or 4/1/1 */
+    int32_t prec;                           /* 1: bf16 operands; 3: split-bf16 (hi*hi+hi*lo+lo*hi), ~fp32 */
+    int32_t mt;                             /* 32-oc tiles per workgroup (1 or 2); must match the packing */
+    int32_t act;  float slope;
+    dasr_tensor mask;  int32_t mask_f32;
+    float alpha;  dasr_tensor res1;  float beta1;  dasr_tensor res2;  float beta2;
+    dasr_tensor out_f32;  dasr_tensor out_bf16;  float gamma;
+} dasr_conv_params;
+
+int dasr_conv(const dasr_conv_params* p, void* stream);
+
+/* ---- weight gradient ---------------------------------------------------------------------------
+ * Replaces autograd's convolution_backward (weight, bias) for the convs above.  One launch covers
+ * a list of `parts` (each: one 32-oc tile x up to two 32-cin tiles x all taps of one conv) times
+ * `nsplit` pixel splits; partial sums go to a workspace, dasr_wgrad_reduce sums them
+ * deterministically into the flat gradient buffer in the reference layout [cout][cin][kh][kw].
+ */
+typedef struct {
+    dasr_tensor g;   int32_t g_f32;         /* output-gradient, planes starting at this part's oc tile */
+    dasr_tensor in;  int32_t in_f32;        /* layer input, planes starting at this part's first cin tile */
+    int32_t ups;                            /* input is nearest-x2 upsampled on the fly */
+    int32_t n_ctiles;                       /* 1 or 2 valid 32-cin tiles */
+    int32_t g_planes, in_planes;            /* 16-ch planes that really exist (g: 1..2, in: 1..4); the rest reads as zero */
+    int32_t Hin, Win, Hout, Wout, N;
+    int32_t kh, stride, pad;
+    int32_t want_bias;                      /* this part also accumulates sum_p g[oc] */
+    int64_t ws_off;                         /* float offset into workspace: [nsplit][ntaps][32][64] (+ bias [nsplit][32]) */
+    int64_t ws_bias_off;
+} dasr_wgrad_part;
+
+int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int32_t nsplit, int32_t kh, int32_t stride, float* ws,
+               void* stream);
+/* 1: use ds_read_b64_tr_b16 gathers, 0: scalar LDS gathers.  dasr_probe_tr16 sets it from the device. */
+int dasr_wgrad_set_mode(int32_t use_tr);
+
+typedef struct {
+    int64_t ws_off;  int64_t ws_bias_off;  int32_t nsplit;  int32_t ntaps;
+    int32_t oc0, c0;                        /* tile origin inside the conv */
+    int32_t cout, cin, n_ctiles;            /* real (unpadded) sizes of the conv */
+    int64_t dst_w_off;  int64_t dst_b_off;  /* float offsets into the flat grad buffer; dst_b_off < 0: no bias */
+    int32_t flip_io;                        /* reserved */
+} dasr_wgrad_reduce_part;
+
+int dasr_wgrad_reduce(const dasr_wgrad_reduce_part* parts_dev, int32_t nparts, const float* ws, float* grad_flat,
+                      float scale, void* stream);
+
+/* ---- weight packing ------------------------------------------------------------------------------
+ * fp32 master weights (reference layout [cout][cin][kh][kw], nn.Conv2d) -> bf16 MFMA-fragment order
+ * [mgroup][chunk][tap][mt][lane][8] (+ lo plane for prec 3).  A packed conv is assembled from up to
+ * 5 source segments so that the dense-block data-gradient (transposed, tap-flipped, concatenated
+ * over the later convs of the block) is just another packed conv.
+ */
+typedef struct {
+    int64_t src_off;      /* float offset of the source conv weight in the flat param buffer */
+    int32_t src_cout, src_cin;
+    int32_t cin_start, cin_len;   /* range of packed input channels fed by this segment */
+    int32_t src_c0;       /* fwd: source cin offset; bwd: source cin (= packed oc) offset */
+    int32_t transpose;    /* 0: W[oc][src_c0+ci][t];  1: W[ci][src_c0+oc][ntaps-1-t] */
+} dasr_pack_seg;
+
+typedef struct {
+    int64_t dst_off;      /* bf16 element offset of the hi plane; lo plane at dst_off + lo_off */
+    int64_t lo_off;       /* 0 when prec 1 */
+    int32_t cout, cin_pad, ntaps, mt, nseg;
+    dasr_pack_seg seg[5];
+} dasr_pack_desc;
+
+/* piece_prefix_dev[ndesc+1]: cumulative count of 16-byte output pieces (= mgroups*chunks*ntaps*mt*64 per desc) */
+int dasr_pack_weights(const dasr_pack_desc* descs_dev, int32_t ndesc, int64_t total_pieces, const int64_t* piece_prefix_dev,
+                      const float* params_flat, void* packed, void* stream);
+
+/* ---- elementwise / reductions --------------------------------------------------------------------*/
+/* NCHW f32 [N][C][H][W] (reference tensor layout at the trainer boundary) <-> NC16HW16 f32 (+ optional bf16 copy) */
+int dasr_nchw_to_blocked(const float* src, int32_t N, int32_t C, int32_t H, int32_t W, dasr_tensor dst_f32,
+                         dasr_tensor dst_bf16, void* stream);
+int dasr_blocked_to_nchw(dasr_tensor src, int32_t N, int32_t C, int32_t H, int32_t W, float* dst, void* stream);
+
+/* L1 pixel loss of SRModel (codes/SRN/models/SR_model.py:80) / DASR_Model (DASR_model.py:212-222):
+ *   loss_acc[0] += coef * sum wm*|sr - hr|,   grad (blocked f32, zero beyond C) (+)= coef * wm * sign(sr - hr)
+ * coef = weight / element count is computed by the caller; `weight_map` (NCHW [N][1][H][W]) is the optional
+ * domain-distance map of the multiweights pixel loss (DASR_model.py:213-215). */
+int dasr_l1_loss(dasr_tensor sr, const float* hr_nchw, const float* weight_map, int32_t N, int32_t C, int32_t H, int32_t W,
+                 float coef, float* loss_acc, dasr_tensor grad, int32_t accumulate, void* stream);
+
+/* backward of nn.Upsample(nearest,2) (block.py:857): dst[y][x] = sum of the 2x2 block of src (Hs=2H, Ws=2W);
+ * optional LeakyReLU' mask (mask>0 ? 1 : slope) from the forward activation at the low resolution. */
+int dasr_downsum2x(dasr_tensor src, int32_t N, int32_t C, int32_t H, int32_t W, dasr_tensor mask, int32_t mask_f32,
+                   float slope, dasr_tensor dst_f32, dasr_tensor dst_bf16, void* stream);
+
+/* out = a*x + b*z (z optional) over blocked f32 tensors, optional bf16 copy scaled by gamma
+ * (ShortcutBlock / RRDB residual bookkeeping, block.py:97-105,305-309) */
+int dasr_axpby(dasr_tensor x, float a, dasr_tensor z, float b, int32_t N, int32_t C, int32_t H, int32_t W,
+               dasr_tensor out_f32, dasr_tensor out_bf16, float gamma, void* stream);
+
+/* torch.optim.Adam step (DASR_model.py:129-143; SR_model.py:50-51) on flat fp32 buffers:
+ * g += wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps) */
+int dasr_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+              float weight_decay, int32_t step, void* stream);
+
+int dasr_fill_f32(float* p, int64_t n, float value, void* stream);
+
+/* ---- executor: run a recorded list of ops in one call (keeps the host out of the step) ----------*/
+enum { DASR_OP_CONV = 1, DASR_OP_WGRAD = 2, DASR_OP_WGRAD_REDUCE = 3, DASR_OP_PACK = 4, DASR_OP_DOWNSUM = 5,
+       DASR_OP_AXPBY = 6, DASR_OP_FILL = 7, DASR_OP_L1LOSS = 8, DASR_OP_NCHW2B = 9, DASR_OP_B2NCHW = 10 };
+
+typedef struct {
+    int32_t op;  int32_t i[8];  float f[4];  int64_t l[4];  void* p[4];  dasr_tensor t[5];
+    dasr_conv_params conv;
+} dasr_op;
+
+int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream);
+int dasr_last_failed_op(void);   /* index of the op that made dasr_run_ops return non-zero */
+
+/* ---- diagnostics ----------------------------------------------------------------------------------*/
+int dasr_abi_version(void);
+/* 1 if ds_read_b64_tr_b16 has the lane mapping the wgrad kernel assumes on this device, 0 if not, <0 on error.
+ * Must be called once per process before dasr_wgrad (it also selects the wgrad gather mode). */
+int dasr_probe_tr16(void* stream);
+/* naive fp32 direct convolution (one thread per output), used by tests as an on-device cross-check */
+int dasr_conv_naive(const dasr_conv_params* p, const float* w_ref /* [cout][cin][kh][kw] */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,270 @@
+"""GPU parity tests of the individual HIP kernels against plain fp32 PyTorch-CPU math (the same ops the
+oracle is built from), called through the C ABI (ctypes).  Run on the MI355X box with `-m gpu`."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from dasr_amd import engine
+    engine.ensure_runtime_ready()
+    return torch.device('cuda')
+
+
+def to_blocked(x, f32, dev):
+    """NCHW cpu tensor -> BTensor on device (layout plumbing only)."""
+    from dasr_amd.engine import BTensor
+    N, Cc, H, W = x.shape
+    b = BTensor(N, Cc, H, W, f32, dev)
+    xp = torch.zeros(N, b.planes * 16, H, W)
+    xp[:, :Cc] = x
+    b.t.copy_(xp.view(N, b.planes, 16, H, W).permute(0, 1, 3, 4, 2).to(b.t.dtype))
+    return b
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def bf16r(x):
+    return x.to(torch.bfloat16).float()
+
+
+def make_conv(cout, cin, kh, mt, prec, dev, seed, transpose_src=None):
+    from dasr_amd.engine import ParamStore, PackRegistry
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(cout, cin, kh, kh, generator=g) * math.sqrt(2.0 / (cin * kh * kh))
+    b = torch.randn(cout, generator=g) * 0.1
+    P = ParamStore([('w', (cout, cin, kh, kh)), ('b', (cout,))], dev)
+    P.load_state_dict({'w': w, 'b': b})
+    pack = PackRegistry(P)
+    cin_pad = (cin + 15) // 16 * 16
+    ref = pack.add(cout, cin_pad, kh * kh, mt, prec, [(0, cout, cin, 0, cin, 0, 0)])
+    pack.finalize()
+    pack.run()
+    return w, b, P, pack, ref
+
+
+CONV_CASES = [
+    # name, prec, in_f32, mt, kh, stride, cin, cout, H, W, ups
+    ('rdb_c32', 1, False, 1, 3, 1, 64, 32, 24, 40, 0),
+    ('rdb_c64', 1, False, 2, 3, 1, 96, 64, 20, 36, 0),
+    ('rdb_wide', 1, False, 1, 3, 1, 160, 32, 16, 32, 0),
+    ('stream', 3, True, 1, 3, 1, 64, 64, 18, 34, 0),
+    ('stream_ups', 3, True, 1, 3, 1, 32, 32, 9, 17, 1),
+    ('stream_c3', 3, True, 1, 3, 1, 16, 64, 16, 32, 0),
+    ('stream_out3', 3, True, 1, 3, 1, 64, 3, 20, 20, 0),
+    ('vgg_like', 1, True, 2, 3, 1, 64, 128, 16, 16, 0),
+    ('d_k4s2', 3, True, 1, 4, 2, 16, 64, 32, 48, 0),
+    ('d_k4s1', 3, True, 1, 4, 1, 64, 32, 17, 21, 0),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_forward_matches_torch(case):
+    dev = _gpu()
+    from dasr_amd import _lib
+    from dasr_amd.engine import BTensor, OpList, conv_op
+    name, prec, in_f32, mt, kh, stride, cin, cout, H, W, ups = case
+    N = 2
+    real_cin = 3 if name == 'stream_c3' else cin
+    w, b, P, pack, ref = make_conv(cout, real_cin, kh, mt, prec, dev, 11)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, real_cin, H, W, generator=g)
+    HL, WL = (2 * H, 2 * W) if ups else (H, W)
+    Ho = (HL + 2 - kh) // stride + 1
+    Wo = (WL + 2 - kh) // stride + 1
+    res = torch.randn(N, cout, Ho, Wo, generator=g)
+    msk = torch.randn(N, cout, Ho, Wo, generator=g)
+    xin = x if in_f32 else bf16r(x)
+    xb = to_blocked(xin, in_f32, dev)
+    rb = to_blocked(res, True, dev)
+    mb = to_blocked(bf16r(msk), False, dev)
+    of = BTensor(N, cout, Ho, Wo, True, dev)
+    ob = BTensor(N, cout, Ho, Wo, False, dev)
+    ops = OpList()
+    ops.add(conv_op(pack, ref, xb.view(), in_f32, (real_cin + 15) // 16 * 16, H, W, Ho, Wo, N, bias=P.ptr('b'), kh=kh, stride=stride,
+                    pad=1, ups=ups, act=1, mask=mb.view(), mask_f32=0, alpha=0.2, res1=rb.view(), beta1=1.0,
+                    out_f32=of.view(), out_bf16=ob.view(), gamma=0.5))
+    ops.run()
+    torch.cuda.synchronize()
+    # fp32 reference (operands rounded exactly as the kernel rounds them for prec 1)
+    xr = xin if prec == 3 else bf16r(xin)
+    wr = w if prec == 3 else bf16r(w)
+    if ups:
+        xr = F.interpolate(xr, scale_factor=2, mode='nearest')
+    y = F.conv2d(xr.double(), wr.double(), b.double(), stride=stride, padding=1)
+    y = F.leaky_relu(y, 0.2)
+    y = torch.where(bf16r(msk).double() > 0, y, y * 0.2)
+    y = (0.2 * y + res.double()).float()
+    got = of.nchw().cpu()
+    tol = 2e-5 if prec == 3 else 2e-5  # operands pre-rounded -> only accumulation-order differences remain
+    assert rel(got, y) < tol, (name, rel(got, y))
+    got_b = ob.nchw().cpu()
+    assert rel(got_b, bf16r(y * 0.5)) < 5e-3
+    # padded channels of the last plane must be exactly zero
+    if cout % 16:
+        pad_part = of.t[:, -1, :, :, cout % 16:]
+        assert float(pad_part.abs().max()) == 0.0
+
+
+def test_conv_prec3_is_fp32_grade():
+    """split-bf16 must be ~fp32 accurate on un-rounded operands (this is what the residual stream relies on)."""
+    dev = _gpu()
+    from dasr_amd.engine import BTensor, OpList, conv_op
+    N, cin, cout, H, W = 1, 64, 64, 32, 32
+    w, b, P, pack, ref = make_conv(cout, cin, 3, 1, 3, dev, 3)
+    x = torch.randn(N, cin, H, W, generator=torch.Generator().manual_seed(1))
+    xb = to_blocked(x, True, dev)
+    of = BTensor(N, cout, H, W, True, dev)
+    ops = OpList()
+    ops.add(conv_op(pack, ref, xb.view(), True, cin, H, W, H, W, N, bias=P.ptr('b'), out_f32=of.view()))
+    ops.run()
+    y = F.conv2d(x.double(), w.double(), b.double(), padding=1).float()
+    assert rel(of.nchw().cpu(), y) < 3e-5
+
+
+def test_naive_conv_crosscheck():
+    dev = _gpu()
+    from dasr_amd import _lib
+    from dasr_amd.engine import BTensor, OpList, conv_op, _stream
+    N, cin, cout, H, W = 1, 32, 32, 16, 32
+    w, b, P, pack, ref = make_conv(cout, cin, 3, 1, 3, dev, 4)
+    x = torch.randn(N, cin, H, W, generator=torch.Generator().manual_seed(2))
+    xb = to_blocked(x, True, dev)
+    o1, o2 = BTensor(N, cout, H, W, True, dev), BTensor(N, cout, H, W, True, dev)
+    op = conv_op(pack, ref, xb.view(), True, cin, H, W, H, W, N, bias=P.ptr('b'), act=1, out_f32=o1.view())
+    _lib.check(_lib.lib().dasr_conv(C.byref(op.conv), _stream()))
+    op2 = conv_op(pack, ref, xb.view(), True, cin, H, W, H, W, N, bias=P.ptr('b'), act=1, out_f32=o2.view())
+    _lib.check(_lib.lib().dasr_conv_naive(C.byref(op2.conv), P.ptr('w'), _stream()))
+    torch.cuda.synchronize()
+    assert rel(o1.t.float().cpu(), o2.t.float().cpu()) < 3e-5
+
+
+WG_CASES = [
+    # name, kh, stride, cin, cout, H, W (input), ups, f32
+    ('rdb', 3, 1, 96, 32, 24, 40, 0, False),
+    ('rdb64', 3, 1, 192, 64, 16, 16, 0, False),
+    ('stream_f32', 3, 1, 64, 64, 20, 28, 0, True),
+    ('ups_f32', 3, 1, 64, 64, 9, 13, 1, True),
+    ('cin3', 3, 1, 3, 64, 16, 24, 0, True),
+    ('cout3', 3, 1, 64, 3, 16, 24, 0, True),
+    ('k4s2', 4, 2, 16, 64, 32, 40, 0, True),
+    ('k4s1', 4, 1, 64, 32, 15, 18, 0, True),
+]
+
+
+@pytest.mark.parametrize('case', WG_CASES, ids=[c[0] for c in WG_CASES])
+def test_wgrad_matches_torch(case):
+    dev = _gpu()
+    from dasr_amd.engine import ParamStore, WgradGroup, Workspace, OpList
+    name, kh, stride, cin, cout, H, W, ups, f32 = case
+    N = 2
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(N, cin, H, W, generator=g)
+    HL, WL = (2 * H, 2 * W) if ups else (H, W)
+    Ho = (HL + 2 - kh) // stride + 1
+    Wo = (WL + 2 - kh) // stride + 1
+    gy = torch.randn(N, cout, Ho, Wo, generator=g)
+    xq, gq = bf16r(x), bf16r(gy)  # the kernel rounds both operands to bf16
+    xb = to_blocked(x if f32 else xq, f32, dev)
+    gb = to_blocked(gy if f32 else gq, f32, dev)
+    P = ParamStore([('weight', (cout, cin, kh, kh)), ('bias', (cout,))], dev)
+    ws = Workspace(dev)
+    grp = WgradGroup(kh, stride)
+    grp.add_conv(gb.view, f32, gb.planes, xb.view, f32, xb.planes, cout, cin, H, W, Ho, Wo, N, P.off('weight'), P.off('bias'), ups=ups)
+    grp.finalize(ws, dev, target_wgs=24)
+    ops = OpList()
+    for o in grp.ops(P.grad.data_ptr()):
+        ops.add(o)
+    ws.finalize()
+    ops.run()
+    torch.cuda.synchronize()
+    xx = xq.double().requires_grad_(False)
+    if ups:
+        xx = F.interpolate(xx, scale_factor=2, mode='nearest')
+    wt = torch.zeros(cout, cin, kh, kh, dtype=torch.double, requires_grad=True)
+    y = F.conv2d(xx, wt, None, stride=stride, padding=1)
+    (y * gq.double()).sum().backward()
+    dw = wt.grad.float()
+    db = gq.double().sum(dim=(0, 2, 3)).float()
+    assert rel(P.view('weight', P.grad).cpu(), dw) < 2e-5, name
+    assert rel(P.view('bias', P.grad).cpu(), db) < 2e-5, name
+
+
+def test_pack_backward_is_transposed_flipped():
+    """dgrad through the conv kernel with a transposed/flipped pack == autograd input gradient."""
+    dev = _gpu()
+    from dasr_amd.engine import ParamStore, PackRegistry, BTensor, OpList, conv_op
+    N, cin, cout, H, W = 1, 64, 32, 16, 32
+    g = torch.Generator().manual_seed(21)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    P = ParamStore([('w', (cout, cin, 3, 3))], dev)
+    P.load_state_dict({'w': w})
+    pack = PackRegistry(P)
+    refb = pack.add(cin, cout, 9, 1, 3, [(0, cout, cin, 0, cout, 0, 1)])
+    pack.finalize()
+    pack.run()
+    gy = torch.randn(N, cout, H, W, generator=g)
+    gb = to_blocked(gy, True, dev)
+    of = BTensor(N, cin, H, W, True, dev)
+    ops = OpList()
+    ops.add(conv_op(pack, refb, gb.view(), True, cout, H, W, H, W, N, out_f32=of.view()))
+    ops.run()
+    x = torch.zeros(N, cin, H, W, dtype=torch.double, requires_grad=True)
+    (F.conv2d(x, w.double(), padding=1) * gy.double()).sum().backward()
+    assert rel(of.nchw().cpu(), x.grad.float()) < 3e-5
+
+
+def test_elementwise_and_adam():
+    dev = _gpu()
+    from dasr_amd import _lib
+    from dasr_amd.engine import BTensor, _stream, NULL_T
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    # nchw <-> blocked round trip
+    x = torch.rand(2, 3, 10, 14, generator=g)
+    xd = x.to(dev)
+    b = BTensor(2, 16, 10, 14, True, dev)
+    _lib.check(L.dasr_nchw_to_blocked(xd.data_ptr(), 2, 3, 10, 14, b.view(), NULL_T, _stream()))
+    back = torch.zeros_like(xd)
+    _lib.check(L.dasr_blocked_to_nchw(b.view(), 2, 3, 10, 14, back.data_ptr(), _stream()))
+    assert torch.equal(back.cpu(), x)
+    assert float(b.t[:, :, :, :, 3:].abs().max()) == 0.0
+    # L1 loss + gradient
+    hr = torch.rand(2, 3, 10, 14, generator=g)
+    hrd = hr.to(dev)
+    acc = torch.zeros(4, device=dev)
+    gr = BTensor(2, 16, 10, 14, True, dev)
+    coef = 1.0 / x.numel()
+    _lib.check(L.dasr_l1_loss(b.view(), hrd.data_ptr(), None, 2, 3, 10, 14, coef, acc.data_ptr(), gr.view(), 0, _stream()))
+    assert abs(float(acc[0]) - float((x - hr).abs().mean())) < 1e-6
+    assert torch.allclose(gr.nchw(3).cpu(), torch.sign(x - hr) * coef, atol=1e-9)
+    # 2x2 down-sum with LeakyReLU' mask
+    s = torch.randn(1, 32, 8, 12, generator=g)
+    m = torch.randn(1, 32, 4, 6, generator=g)
+    sb, mb = to_blocked(s, True, dev), to_blocked(m, True, dev)
+    db = BTensor(1, 32, 4, 6, True, dev)
+    _lib.check(L.dasr_downsum2x(sb.view(), 1, 32, 4, 6, mb.view(), 1, 0.2, db.view(), NULL_T, _stream()))
+    want = F.avg_pool2d(s, 2) * 4
+    want = torch.where(m > 0, want, want * 0.2)
+    assert torch.allclose(db.nchw().cpu(), want, atol=1e-5)
+    # Adam vs torch.optim.Adam, 3 steps, with weight decay
+    p0 = torch.randn(1000, generator=g)
+    grads = [torch.randn(1000, generator=g) for _ in range(3)]
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
+    pd, md, vd = p0.to(dev), torch.zeros(1000, device=dev), torch.zeros(1000, device=dev)
+    for i, gg in enumerate(grads):
+        pt.grad = gg.clone()
+        opt.step()
+        gd = gg.to(dev)
+        _lib.check(L.dasr_adam(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), 1000, 1e-3, 0.9, 0.999, 1e-8, 0.01, i + 1, _stream()))
+    assert torch.allclose(pd.cpu(), pt.detach(), rtol=1e-5, atol=1e-7)

@@ -1,0 +1,144 @@
+"""CPU tests: C-ABI library loads and exports every declared symbol; host logic (options, schedule, init,
+sharding, gloo all-reduce of gradient buckets)."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_and_exports_all_declared_symbols():
+    from dasr_amd import build, _lib
+    lib = build.build()
+    assert os.path.exists(lib)
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, 'include', 'dasr_hip.h')).read()
+    declared = set(re.findall(r'^\s*int\s+(dasr_\w+)\s*\(', hdr, flags=re.M))
+    assert declared, 'no declarations parsed'
+    for name in declared:
+        assert hasattr(L, name), name
+    assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
+    assert L.dasr_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_sizes_match_header_layout():
+    """compile a tiny C program against include/dasr_hip.h and compare sizeof with the ctypes mirrors"""
+    import ctypes
+    from dasr_amd import _lib
+    src = r'''#include <stdio.h>
+#include "dasr_hip.h"
+int main(){printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(dasr_tensor), sizeof(dasr_conv_params), sizeof(dasr_wgrad_part),
+ sizeof(dasr_wgrad_reduce_part), sizeof(dasr_pack_seg), sizeof(dasr_pack_desc), sizeof(dasr_op)); return 0;}'''
+    import tempfile
+    d = tempfile.mkdtemp()
+    open(os.path.join(d, 't.c'), 'w').write(src)
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), os.path.join(d, 't.c'), '-o', os.path.join(d, 't')])
+    sizes = [int(x) for x in subprocess.check_output([os.path.join(d, 't')]).split()]
+    mine = [ctypes.sizeof(c) for c in (_lib.Tensor, _lib.ConvParams, _lib.WgradPart, _lib.WgradReducePart, _lib.PackSeg,
+                                       _lib.PackDesc, _lib.Op)]
+    assert sizes == mine, (sizes, mine)
+
+
+def test_options_parse_and_nonedict(tmp_path):
+    from dasr_amd import options
+    p = tmp_path / 'o.json'
+    p.write_text('''{
+  "name": "debug_x" // comment
+  , "model": "DASR_FS_ESRGAN_patchGAN", "scale": 4, "gpu_ids": [0]
+  , "datasets": {"train": {"name": "a", "mode": "LRHR", "dataroot_HR": "~/hr", "dataroot_LR": "~/x.lmdb", "batch_size": 2}}
+  , "path": {"root": "/tmp/dasr_opt_test", "pretrain_model_G": null}
+  , "network_G": {"which_model_G": "RRDB_net", "nf": 64, "nb": 23, "in_nc": 3, "out_nc": 3}
+  , "train": {"lr_G": 1e-4, "val_freq": 5000}, "logger": {"print_freq": 200, "save_checkpoint_freq": 5000}
+}''')
+    opt = options.dict_to_nonedict(options.parse(str(p)))
+    assert opt['is_train'] and opt['network_G']['scale'] == 4
+    assert opt['datasets']['train']['data_type'] == 'lmdb' and opt['datasets']['train']['phase'] == 'train'
+    assert opt['path']['models'].endswith('experiments/debug_x/models')
+    assert opt['train']['val_freq'] == 8 and opt['logger']['print_freq'] == 2  # debug mode
+    assert opt['nonexistent'] is None and opt['train']['nope'] is None
+    assert os.environ['CUDA_VISIBLE_DEVICES'] == '0'
+    assert 'lr_G' in options.dict2str(opt)
+
+
+def test_multistep_lr_matches_torch():
+    from dasr_amd.models import MultiStepLR
+    p = torch.nn.Parameter(torch.zeros(1))
+    o = torch.optim.Adam([p], lr=1e-3)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        ts = torch.optim.lr_scheduler.MultiStepLR(o, [2, 4, 7], 0.5)
+        mine = MultiStepLR(1e-3, [2, 4, 7], 0.5)
+        for _ in range(10):
+            ts.step()
+            mine.step()
+            assert abs(o.param_groups[0]['lr'] - mine.get_lr()) < 1e-15
+    sd = mine.state_dict()
+    m2 = MultiStepLR(1e-3, [2, 4, 7], 0.5)
+    m2.load_state_dict(sd)
+    assert m2.get_lr() == mine.get_lr()
+
+
+def test_reference_init_is_reproduced(golden_dir):
+    from dasr_amd.init import kaiming_state_dict
+    from dasr_amd.rrdbnet import rrdbnet_param_spec
+    from oracle import nets
+    ref = np.load(os.path.join(golden_dir, 'misc_modules.npz'))
+    torch.manual_seed(5)
+    sd = kaiming_state_dict(rrdbnet_param_spec(3, 3, 32, 1), 0.1)
+    d = np.array([nets.tensor_digest(v) for v in sd.values()])
+    np.testing.assert_array_equal(d, ref['init_digest'])
+
+
+def test_param_spec_matches_reference_keys(golden_dir):
+    from dasr_amd.rrdbnet import rrdbnet_param_spec
+    ref = np.load(os.path.join(golden_dir, 'cfg1_sr_nf32_nb4_b2_64.npz'))
+    assert [k for k, _ in rrdbnet_param_spec(3, 3, 32, 4)] == list(ref['state_keys'])
+    n = sum(int(np.prod(s)) for _, s in rrdbnet_param_spec(3, 3, 64, 23))
+    assert n == 16697987
+
+
+def test_shard_minibatch():
+    from dasr_amd.dist import shard_minibatch
+    b = {'LR': torch.arange(8).view(8, 1), 'p': ['x']}
+    s = shard_minibatch(b, 1, 4)
+    assert s['LR'].flatten().tolist() == [2, 3] and s['p'] == ['x']
+
+
+def _dp_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from dasr_amd.dist import DataParallelGroup
+    dp = DataParallelGroup(backend='gloo')
+    g = torch.Generator().manual_seed(100 + rank)
+    grad = torch.randn(1000, generator=g) * dp.grad_scale  # the wgrad reduction pre-scales by 1/world
+    for lo, hi in ((600, 1000), (250, 600), (0, 250)):     # buckets complete from the end of the buffer
+        dp.reduce_async(grad[lo:hi])
+    dp.wait()
+    m = dp.max_over_ranks(float(rank))
+    torch.save({'grad': grad, 'max': m}, out % rank)
+    dp.barrier()
+
+
+def test_gloo_world2_bucketed_allreduce(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29511 + (os.getpid() % 200)
+    out = str(tmp_path / 'r%d.pt')
+    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out % 0), torch.load(out % 1)
+    want = (torch.randn(1000, generator=torch.Generator().manual_seed(100)) + torch.randn(1000, generator=torch.Generator().manual_seed(101))) / 2
+    assert torch.allclose(r0['grad'], want, atol=1e-6) and torch.equal(r0['grad'], r1['grad'])
+    assert r0['max'] == 1.0 and r1['max'] == 1.0
+
+
+def test_product_path_does_not_import_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, 'dasr_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                txt = open(os.path.join(root, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', txt, flags=re.M), f
