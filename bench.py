@@ -18,6 +18,13 @@ import time
 
 import torch
 
+
+def log(msg):
+    sys.stderr.write('[bench %.1fs] %s\n' % (time.time() - T0, msg))
+    sys.stderr.flush()
+
+
+T0 = time.time()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -59,23 +66,50 @@ def roofline_dominant_kernel(model, plan, reps=5):
             'flops_per_launch_avg': flops / len(convs)}
 
 
-def cpu_baseline(nf, nb, lr_size):
-    """oracle (port of the reference step) on the host cores, bounded sample: batch 1, 1 warm-up + 1 timed step."""
-    from oracle import nets, trainers
-    threads = os.cpu_count() or 1
+def _usable_cores():
+    """host cores this process may really use: affinity mask, capped by the cgroup CPU quota if there is one"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = max(1, min(n, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return n
+
+
+def _cpu_baseline_worker(nf, nb, lr_size, threads):
+    from oracle import trainers
     torch.set_num_threads(threads)
     opt = make_opt(nf, nb)
     torch.manual_seed(0)
     t = trainers.SRTrainer(opt)
     g = torch.Generator().manual_seed(1234)
+    small = {'LR': torch.rand(1, 3, 32, 32, generator=g), 'HR': torch.rand(1, 3, 128, 128, generator=g)}
     data = {'LR': torch.rand(1, 3, lr_size, lr_size, generator=g), 'HR': torch.rand(1, 3, 4 * lr_size, 4 * lr_size, generator=g)}
+    t.feed_data(small)
+    t.optimize_parameters(1)  # warm-up (thread pools, allocator) on a small crop
     t.feed_data(data)
-    t.optimize_parameters(1)
     t0 = time.time()
     t.optimize_parameters(2)
-    dt = time.time() - t0
+    print(json.dumps({'dt': time.time() - t0}))
+
+
+def cpu_baseline(nf, nb, lr_size, timeout=150):
+    """oracle (port of the reference step) on the host cores, bounded sample: batch 1, small warm-up + 1 timed step.
+    Runs in a subprocess with a timeout so a slow/oversubscribed host cannot stall the GPU benchmark."""
+    import subprocess
+    threads = min(int(os.environ.get('DASR_CPU_THREADS', '64')), _usable_cores())
+    code = 'import sys; sys.path.insert(0, %r); import bench; bench._cpu_baseline_worker(%d, %d, %d, %d)' % (ROOT, nf, nb, lr_size, threads)
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='')
+    try:
+        out = subprocess.run([sys.executable, '-c', code], capture_output=True, timeout=timeout, env=env, text=True)
+        dt = json.loads(out.stdout.strip().splitlines()[-1])['dt']
+    except Exception as e:  # timeout or failure: report, do not fail the GPU measurement
+        return {'value': None, 'unit': 'images/s', 'cores': threads, 'kind': 'port', 'sample': 'cpu baseline did not finish: %r' % (e,)}
     return {'value': round(1.0 / dt, 4), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
-            'sample': 'oracle SRTrainer nf%d nb%d, batch 1 x %dx%d LR, 1 warm-up + 1 timed step (%.1f s), fp32 torch CPU' % (nf, nb, lr_size, lr_size, dt)}
+            'sample': 'oracle SRTrainer nf%d nb%d, batch 1 x %dx%d LR, small warm-up + 1 timed step (%.1f s), fp32 torch CPU, %d threads'
+                      % (nf, nb, lr_size, lr_size, dt, threads)}
 
 
 def main():
@@ -108,6 +142,7 @@ def main():
     g = torch.Generator().manual_seed(1234 + rank)
     data = {'LR': torch.rand(a.batch, 3, a.lr_size, a.lr_size, generator=g).cuda(),
             'HR': torch.rand(a.batch, 3, 4 * a.lr_size, 4 * a.lr_size, generator=g).cuda()}
+    log('model built')
     step = 0
     for _ in range(a.warmup):
         step += 1
@@ -115,6 +150,7 @@ def main():
         model.feed_data(data)
         model.optimize_parameters(step)
     torch.cuda.synchronize()
+    log('warm-up done')
     if dp:
         dp.barrier()
     t0 = time.perf_counter()
@@ -130,6 +166,7 @@ def main():
     if dp:
         dt = dp.max_over_ranks(dt)
     loss = model.get_current_log()['l_pix']
+    log('timed steps done: %.1f ms/step' % (dt / a.steps * 1e3))
     if rank != 0:
         return
     n_gpus = world
@@ -147,6 +184,7 @@ def main():
         out['mfma_util_step'] = round(ips * TFLOP_PER_IMAGE_TRAIN / PEAK_BF16_TFLOPS, 4)
     plan = model.netG.plan(a.batch, a.lr_size, a.lr_size)
     out['roofline'] = roofline_dominant_kernel(model, plan)
+    log('roofline done')
     if n_gpus == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(a.nf, a.nb, a.lr_size)
     print(json.dumps(out))

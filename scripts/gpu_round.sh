@@ -9,7 +9,9 @@ timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider ${PYTEST_ARGS:
 echo "pytest exit $?" >> gpurun_out/pytest.log
 tail -40 gpurun_out/pytest.log
 if [ "${RUN_BENCH:-1}" = "1" ]; then
-  timeout 900 python bench.py --steps ${BENCH_STEPS:-4} --warmup 1 ${BENCH_ARGS:-} > gpurun_out/bench.log 2>&1
+  timeout 200 python bench.py --steps 2 --warmup 1 --nb 2 --batch 2 --no-cpu-baseline > gpurun_out/bench_small.log 2>&1
+  echo "bench_small exit $?" >> gpurun_out/bench_small.log; tail -4 gpurun_out/bench_small.log
+  timeout ${BENCH_TIMEOUT:-420} python bench.py --steps ${BENCH_STEPS:-4} --warmup 1 ${BENCH_ARGS:-} > gpurun_out/bench.log 2>&1
   echo "bench exit $?" >> gpurun_out/bench.log
   tail -5 gpurun_out/bench.log
 fi

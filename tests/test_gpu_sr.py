@@ -35,8 +35,12 @@ def _oracle_run(case, steps=2):
     t = trainers.SRTrainer(opt, netG=netG)
     batch = fixtures.make_batch(case)
     taps = {}
-    hs = [netG.model[0].register_forward_hook(lambda m, i, o: taps.setdefault('fea', o.detach().clone())),
-          netG.model[1].register_forward_hook(lambda m, i, o: taps.setdefault('trunk', o.detach().clone()))]
+    def hook(name):
+        def f(m, i, o):  # must return None (a returned tensor would replace the module output)
+            taps.setdefault(name, o.detach().clone())
+        return f
+
+    hs = [netG.model[0].register_forward_hook(hook('fea')), netG.model[1].register_forward_hook(hook('trunk'))]
     out = {'sd0': sd0, 'batch': batch, 'logs': []}
     for step in range(1, steps + 1):
         t.update_learning_rate()
@@ -94,7 +98,9 @@ def test_sr_step_matches_oracle_and_reference_fixture(case, golden_dir):
     # the weights tightly
     sdN = m.netG.state_dict()
     for k, v in sdN.items():
-        assert torch.allclose(v, want['sdN'][k], atol=2.5e-4), k  # |update| <= 2*lr = 2e-4 per step pair
+        d = (v - want['sdN'][k]).abs()
+        assert float(d.max()) <= 3.2e-4, k  # Adam normalises: a sign flip of a ~0 gradient moves a weight by 2*lr
+        assert float((d > 2e-5).float().mean()) < 0.02, (k, float((d > 2e-5).float().mean()))
 
 
 def test_checkpoint_layout_roundtrip(tmp_path):
