@@ -1,0 +1,545 @@
+// HBM-bound kernels of the DASR GAN step (gfx950): InstanceNorm+LeakyReLU fwd/bwd, BCE-with-logits,
+// Haar DWT fwd/adjoint, depthwise gaussian / box low-pass (+ frequency split), 2x2 max-pool fwd/bwd,
+// L1 between feature maps, VGG input normalisation, bilinear x4 of the domain-distance map.
+// All tensors are NC16HW16 (see dasr_hip.h); one 16-channel pixel = 64 B (f32) / 32 B (bf16).
+#include "common.h"
+
+namespace {
+
+inline unsigned nblk(long long total, int bs = 256) { return (unsigned)((total + bs - 1) / bs); }
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// InstanceNorm2d(affine=False, eps) + LeakyReLU, one workgroup per (n, 16-channel plane).
+// thread t: channel quad q = t & 3, pixel lane = t >> 2 (64 pixel lanes); sums reduced per quad.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 quad_reduce(f32x4 v, f32x4* red) {
+    // reduce over the 64 threads that share (threadIdx.x & 3): xor-shuffle over lane bits 2..5, then LDS over 4 waves
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += __shfl_xor(v[j], o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) < 4) red[(threadIdx.x >> 6) * 4 + (threadIdx.x & 3)] = v;
+    __syncthreads();
+    const int q = threadIdx.x & 3;
+    return red[q] + red[4 + q] + red[8 + q] + red[12 + q];
+}
+
+__global__ __launch_bounds__(256) void inorm_lrelu_fwd_kernel(dasr_tensor x, int C, int H, int W, float eps, float slope,
+                                                              dasr_tensor y, float* __restrict__ stats /* [N][Cpad][2] mean, rstd */) {
+    __shared__ f32x4 red[16];
+    const int ncb = (C + 15) >> 4;
+    const int n = blockIdx.x / ncb, cb = blockIdx.x - n * ncb;
+    const int q = threadIdx.x & 3, pl = threadIdx.x >> 2;
+    const float* xp = (const float*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + q * 4;
+    float* yp = (float*)y.p + (size_t)n * y.n_stride + (size_t)cb * y.cb_stride + q * 4;
+    const int HW = H * W;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int p = pl; p < HW; p += 64) s += *(const f32x4*)(xp + (size_t)p * 16);
+    const f32x4 mean = quad_reduce(s, red) * (1.f / HW);
+    f32x4 s2 = {0.f, 0.f, 0.f, 0.f};
+    for (int p = pl; p < HW; p += 64) {
+        const f32x4 d = *(const f32x4*)(xp + (size_t)p * 16) - mean;
+        s2 += d * d;
+    }
+    const f32x4 var = quad_reduce(s2, red) * (1.f / HW);  // biased variance (nn.InstanceNorm2d)
+    f32x4 rstd;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rstd[j] = 1.f / sqrtf(var[j] + eps);
+    for (int p = pl; p < HW; p += 64) {
+        f32x4 v = (*(const f32x4*)(xp + (size_t)p * 16) - mean) * rstd;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+        *(f32x4*)(yp + (size_t)p * 16) = v;
+    }
+    if (pl == 0 && stats) {
+        float* st = stats + ((size_t)n * ncb * 16 + cb * 16 + q * 4) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            st[2 * j] = mean[j];
+            st[2 * j + 1] = rstd[j];
+        }
+    }
+}
+
+// backward: a = lrelu(xhat) is the saved forward output; ga = dL/da.  gy = ga * lrelu'(a);
+// gx = rstd * (gy - mean(gy) - xhat * mean(gy * xhat)),  xhat = a > 0 ? a : a / slope.
+__global__ __launch_bounds__(256) void inorm_lrelu_bwd_kernel(dasr_tensor a, dasr_tensor ga, int C, int H, int W, float slope,
+                                                              const float* __restrict__ stats, dasr_tensor gx) {
+    __shared__ f32x4 red[16];
+    const int ncb = (C + 15) >> 4;
+    const int n = blockIdx.x / ncb, cb = blockIdx.x - n * ncb;
+    const int q = threadIdx.x & 3, pl = threadIdx.x >> 2;
+    const float* ap = (const float*)a.p + (size_t)n * a.n_stride + (size_t)cb * a.cb_stride + q * 4;
+    const float* gp = (const float*)ga.p + (size_t)n * ga.n_stride + (size_t)cb * ga.cb_stride + q * 4;
+    float* op = (float*)gx.p + (size_t)n * gx.n_stride + (size_t)cb * gx.cb_stride + q * 4;
+    const int HW = H * W;
+    const float inv_slope = 1.f / slope;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    for (int p = pl; p < HW; p += 64) {
+        const f32x4 av = *(const f32x4*)(ap + (size_t)p * 16);
+        f32x4 g = *(const f32x4*)(gp + (size_t)p * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool pos = av[j] > 0.f;
+            const float xh = pos ? av[j] : av[j] * inv_slope;
+            const float gy = pos ? g[j] : g[j] * slope;
+            s1[j] += gy;
+            s2[j] += gy * xh;
+        }
+    }
+    const f32x4 m1 = quad_reduce(s1, red) * (1.f / HW);
+    const f32x4 m2 = quad_reduce(s2, red) * (1.f / HW);
+    f32x4 rstd;
+    const float* st = stats + ((size_t)n * ncb * 16 + cb * 16 + q * 4) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rstd[j] = st[2 * j + 1];
+    for (int p = pl; p < HW; p += 64) {
+        const f32x4 av = *(const f32x4*)(ap + (size_t)p * 16);
+        const f32x4 g = *(const f32x4*)(gp + (size_t)p * 16);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool pos = av[j] > 0.f;
+            const float xh = pos ? av[j] : av[j] * inv_slope;
+            const float gy = pos ? g[j] : g[j] * slope;
+            o[j] = rstd[j] * (gy - m1[j] - xh * m2[j]);
+        }
+        *(f32x4*)(op + (size_t)p * 16) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// BCEWithLogits(x, t) mean over C real channels (GANLoss 'vanilla', loss.py:8-40):
+// loss_acc[0] += coef * sum(max(x,0) - x t + log1p(exp(-|x|))); loss_acc[1] += coef_mean * sum(x) (disc score);
+// grad = gcoef * (sigmoid(x) - t) (zero on padded channels)
+// ---------------------------------------------------------------------------------------------------
+__global__ void bce_logits_kernel(dasr_tensor x, int N, int C, int H, int W, float target, float coef, float gcoef, float* loss_acc,
+                                  float* score_acc, float score_coef, dasr_tensor grad) {
+    __shared__ float red[4];
+    const long long total = (long long)N * H * W;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float l = 0.f, sc = 0.f;
+    if (i < total) {
+        const int n = i / ((long long)H * W);
+        const long long p = i - (long long)n * H * W;
+        const float* xp = (const float*)x.p + (size_t)n * x.n_stride + (size_t)p * 16;
+        float g[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) g[j] = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float v = xp[c];
+            l += fmaxf(v, 0.f) - v * target + log1pf(expf(-fabsf(v)));
+            sc += v;
+            g[c] = gcoef * (1.f / (1.f + expf(-v)) - target);
+        }
+        if (grad.p) {
+            float* gp = (float*)grad.p + (size_t)n * grad.n_stride + (size_t)p * 16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ((f32x4*)gp)[j] = f32x4{g[4 * j], g[4 * j + 1], g[4 * j + 2], g[4 * j + 3]};
+        }
+    }
+    const float tl = block_sum_256(l, red);
+    const float ts = block_sum_256(sc, red);
+    if (threadIdx.x == 0) {
+        if (loss_acc) atomicAdd(loss_acc, tl * coef);
+        if (score_acc) atomicAdd(score_acc, ts * score_coef);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Haar DWT level 1 on C (<=5) channels of plane 0: LL -> ll plane (C ch), [LH|HL|HH] -> hc plane (3C ch).
+// Convention (oracle/nets.py::HaarDWT): block [[a,b],[c,d]]: LL=(a+b+c+d)/2, LH=(a+b-c-d)/2, HL=(a-b+c-d)/2, HH=(a-b-c+d)/2
+// norm: LL*0.5, Hc*0.5+0.5 (DASR_model.py:442-452).  Thread per output pixel.
+// ---------------------------------------------------------------------------------------------------
+__global__ void dwt_fwd_kernel(dasr_tensor x, int N, int C, int H2, int W2, int norm, dasr_tensor ll, dasr_tensor hc) {
+    const long long total = (long long)N * H2 * W2;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int xx = i % W2;
+    long long t = i / W2;
+    const int yy = t % H2;
+    const int n = t / H2;
+    const int W = 2 * W2;
+    const float* xp = (const float*)x.p + (size_t)n * x.n_stride;
+    const float* pa = xp + ((size_t)(2 * yy) * W + 2 * xx) * 16;
+    const float* pc = pa + (size_t)W * 16;
+    float L[16], Hh[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) L[j] = Hh[j] = 0.f;
+    const float s = norm ? 0.5f : 1.f, off = norm ? 0.5f : 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float a = pa[c], b = pa[16 + c], cc = pc[c], d = pc[16 + c];
+        L[c] = (a + b + cc + d) * 0.5f * s;
+        Hh[c] = (a + b - cc - d) * 0.5f * s + off;
+        Hh[C + c] = (a - b + cc - d) * 0.5f * s + off;
+        Hh[2 * C + c] = (a - b - cc + d) * 0.5f * s + off;
+    }
+    const size_t po = ((size_t)yy * W2 + xx) * 16;
+    if (ll.p) {
+        float* o = (float*)ll.p + (size_t)n * ll.n_stride + po;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ((f32x4*)o)[j] = f32x4{L[4 * j], L[4 * j + 1], L[4 * j + 2], L[4 * j + 3]};
+    }
+    if (hc.p) {
+        float* o = (float*)hc.p + (size_t)n * hc.n_stride + po;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ((f32x4*)o)[j] = f32x4{Hh[4 * j], Hh[4 * j + 1], Hh[4 * j + 2], Hh[4 * j + 3]};
+    }
+}
+
+// adjoint: gx (+)= DWT^T (gll, ghc); gll / ghc may be null (treated as zero)
+__global__ void dwt_bwd_kernel(dasr_tensor gll, dasr_tensor ghc, int N, int C, int H2, int W2, int norm, dasr_tensor gx, int accumulate) {
+    const long long total = (long long)N * H2 * W2;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int xx = i % W2;
+    long long t = i / W2;
+    const int yy = t % H2;
+    const int n = t / H2;
+    const int W = 2 * W2;
+    const size_t po = ((size_t)yy * W2 + xx) * 16;
+    const float* gl = gll.p ? (const float*)gll.p + (size_t)n * gll.n_stride + po : nullptr;
+    const float* gh = ghc.p ? (const float*)ghc.p + (size_t)n * ghc.n_stride + po : nullptr;
+    float* pa = (float*)gx.p + (size_t)n * gx.n_stride + ((size_t)(2 * yy) * W + 2 * xx) * 16;
+    float* pc = pa + (size_t)W * 16;
+    const float s = (norm ? 0.5f : 1.f) * 0.5f;
+    float A[16], B[16], Cc[16], D[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) A[j] = B[j] = Cc[j] = D[j] = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float l = gl ? gl[c] : 0.f;
+        const float lh = gh ? gh[c] : 0.f, hl = gh ? gh[C + c] : 0.f, hh = gh ? gh[2 * C + c] : 0.f;
+        A[c] = s * (l + lh + hl + hh);
+        B[c] = s * (l + lh - hl - hh);
+        Cc[c] = s * (l - lh + hl - hh);
+        D[c] = s * (l - lh - hl + hh);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 va = {A[4 * j], A[4 * j + 1], A[4 * j + 2], A[4 * j + 3]}, vb = {B[4 * j], B[4 * j + 1], B[4 * j + 2], B[4 * j + 3]};
+        f32x4 vc = {Cc[4 * j], Cc[4 * j + 1], Cc[4 * j + 2], Cc[4 * j + 3]}, vd = {D[4 * j], D[4 * j + 1], D[4 * j + 2], D[4 * j + 3]};
+        if (accumulate) {
+            va += ((f32x4*)pa)[j];
+            vb += ((f32x4*)(pa + 16))[j];
+            vc += ((f32x4*)pc)[j];
+            vd += ((f32x4*)(pc + 16))[j];
+        }
+        ((f32x4*)pa)[j] = va;
+        ((f32x4*)(pa + 16))[j] = vb;
+        ((f32x4*)pc)[j] = vc;
+        ((f32x4*)(pc + 16))[j] = vd;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Depthwise k x k low-pass with zero padding (k-1)/2 on C (<=4) channels of plane 0, weights w[k*k]
+// (GaussianFilter / AvgPool2d(count_include_pad=True) of FilterLow, architecture.py:1177-1224).
+//   mode 0: out_low = low(x)                  ; out_high = a_h * (x - low(x)) + b_h
+//   mode 1 (adjoint): out_low(=gx) (+)= low(g_low) + a_h * (g_high - low(g_high))   (the kernel is symmetric)
+// Thread per pixel; the window is read through L1/L2 (3-4 floats per tap).
+// ---------------------------------------------------------------------------------------------------
+__global__ void lowpass_kernel(dasr_tensor x, dasr_tensor x2, const float* __restrict__ w, int k, int N, int C, int H, int W, int mode,
+                               float a_h, float b_h, dasr_tensor out_low, dasr_tensor out_high, int accumulate) {
+    const long long total = (long long)N * H * W;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int xx = i % W;
+    long long t = i / W;
+    const int yy = t % H;
+    const int n = t / H;
+    const int r = (k - 1) / 2;
+    const float* xp = x.p ? (const float*)x.p + (size_t)n * x.n_stride : nullptr;
+    const float* x2p = x2.p ? (const float*)x2.p + (size_t)n * x2.n_stride : nullptr;
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, lo2 = {0.f, 0.f, 0.f, 0.f};
+    for (int ky = 0; ky < k; ++ky) {
+        const int sy = yy + ky - r;
+        if (sy < 0 || sy >= H) continue;
+        for (int kx = 0; kx < k; ++kx) {
+            const int sx = xx + kx - r;
+            if (sx < 0 || sx >= W) continue;
+            const float wt = w[ky * k + kx];
+            const size_t o = ((size_t)sy * W + sx) * 16;
+            if (xp) lo += *(const f32x4*)(xp + o) * wt;
+            if (x2p) lo2 += *(const f32x4*)(x2p + o) * wt;
+        }
+    }
+    const size_t po = ((size_t)yy * W + xx) * 16;
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    auto maskc = [&](f32x4 v) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j >= C) v[j] = 0.f;
+        return v;
+    };
+    if (mode == 0) {
+        const f32x4 c = *(const f32x4*)(xp + po);
+        if (out_low.p) {
+            float* o = (float*)out_low.p + (size_t)n * out_low.n_stride + po;
+            ((f32x4*)o)[0] = maskc(lo);
+            ((f32x4*)o)[1] = z; ((f32x4*)o)[2] = z; ((f32x4*)o)[3] = z;
+        }
+        if (out_high.p) {
+            float* o = (float*)out_high.p + (size_t)n * out_high.n_stride + po;
+            f32x4 hv = (c - lo) * a_h + b_h;
+            ((f32x4*)o)[0] = maskc(hv);
+            ((f32x4*)o)[1] = z; ((f32x4*)o)[2] = z; ((f32x4*)o)[3] = z;
+        }
+    } else {
+        // x = g_low (may be null), x2 = g_high (may be null)
+        f32x4 g = lo;
+        if (x2p) g += (*(const f32x4*)(x2p + po) - lo2) * a_h;
+        float* o = (float*)out_low.p + (size_t)n * out_low.n_stride + po;
+        g = maskc(g);
+        if (accumulate) g += ((f32x4*)o)[0];
+        ((f32x4*)o)[0] = g;
+        if (!accumulate) { ((f32x4*)o)[1] = z; ((f32x4*)o)[2] = z; ((f32x4*)o)[3] = z; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// MaxPool2d(2,2) forward / backward (first maximum in scan order wins, like ATen), f32 or bf16 tensors
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool_fwd_kernel(dasr_tensor x, int N, int C, int Ho, int Wo, dasr_tensor y) {
+    const int ncb = (C + 15) >> 4;
+    const long long total = (long long)N * ncb * Ho * Wo * 4;
+    const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= total) return;
+    const int q = gi & 3;
+    long long i = gi >> 2;
+    const int xx = i % Wo; i /= Wo;
+    const int yy = i % Ho; i /= Ho;
+    const int cb = i % ncb;
+    const int n = i / ncb;
+    const int W = 2 * Wo;
+    const T* xp = (const T*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + q * 4;
+    T* yp = (T*)y.p + (size_t)n * y.n_stride + (size_t)cb * y.cb_stride + ((size_t)yy * Wo + xx) * 16 + q * 4;
+    float m[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = -3.4e38f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const T* s = xp + ((size_t)(2 * yy + (d >> 1)) * W + 2 * xx + (d & 1)) * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], (float)s[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) yp[j] = (T)m[j];
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(dasr_tensor x, dasr_tensor gy, int N, int C, int Ho, int Wo, dasr_tensor gx) {
+    const int ncb = (C + 15) >> 4;
+    const long long total = (long long)N * ncb * Ho * Wo * 4;
+    const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= total) return;
+    const int q = gi & 3;
+    long long i = gi >> 2;
+    const int xx = i % Wo; i /= Wo;
+    const int yy = i % Ho; i /= Ho;
+    const int cb = i % ncb;
+    const int n = i / ncb;
+    const int W = 2 * Wo;
+    const T* xp = (const T*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + q * 4;
+    const T* gp = (const T*)gy.p + (size_t)n * gy.n_stride + (size_t)cb * gy.cb_stride + ((size_t)yy * Wo + xx) * 16 + q * 4;
+    T* op = (T*)gx.p + (size_t)n * gx.n_stride + (size_t)cb * gx.cb_stride + q * 4;
+    float m[4];
+    int am[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { m[j] = -3.4e38f; am[j] = 0; }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const T* s = xp + ((size_t)(2 * yy + (d >> 1)) * W + 2 * xx + (d & 1)) * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = (float)s[j];
+            if (v > m[j]) { m[j] = v; am[j] = d; }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        T* o = op + ((size_t)(2 * yy + (d >> 1)) * W + 2 * xx + (d & 1)) * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = am[j] == d ? gp[j] : (T)0.f;
+    }
+}
+
+// L1 between two blocked tensors over all C channels: loss_acc += coef*sum|a-b|; ga = gcoef*sign(a-b)
+template <typename T>
+__global__ void l1_diff_kernel(dasr_tensor a, dasr_tensor b, int N, int C, int H, int W, float coef, float gcoef, float* loss_acc, dasr_tensor ga) {
+    __shared__ float red[4];
+    const int ncb = (C + 15) >> 4;
+    const long long per = (long long)H * W * 4;
+    const long long total = (long long)N * ncb * per;
+    const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float l = 0.f;
+    if (gi < total) {
+        const long long e = (gi % per) * 4;
+        long long t = gi / per;
+        const int cb = t % ncb;
+        const int n = t / ncb;
+        const T* ap = (const T*)a.p + (size_t)n * a.n_stride + (size_t)cb * a.cb_stride + e;
+        const T* bp = (const T*)b.p + (size_t)n * b.n_stride + (size_t)cb * b.cb_stride + e;
+        const int c0 = cb * 16 + (int)(e & 15);
+        float g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = (c0 + j < C) ? (float)ap[j] - (float)bp[j] : 0.f;
+            l += fabsf(d);
+            g[j] = gcoef * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        }
+        if (ga.p) {
+            T* gp = (T*)ga.p + (size_t)n * ga.n_stride + (size_t)cb * ga.cb_stride + e;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gp[j] = (T)g[j];
+        }
+    }
+    const float tl = block_sum_256(l, red);
+    if (threadIdx.x == 0 && loss_acc) atomicAdd(loss_acc, tl * coef);
+}
+
+// y[c] = x[c] * sc[c] + sh[c] on C (<=4) channels of plane 0 (VGG input normalisation and its adjoint);
+// optional accumulate into y (used for dL/dSR += dL/dnorm / std)
+template <typename TO>
+__global__ void affine4_kernel(dasr_tensor x, int N, int C, int H, int W, f32x4 sc, f32x4 sh, dasr_tensor y, int accumulate) {
+    const long long total = (long long)N * H * W;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int n = i / ((long long)H * W);
+    const long long p = i - (long long)n * H * W;
+    f32x4 v = *(const f32x4*)((const float*)x.p + (size_t)n * x.n_stride + (size_t)p * 16) * sc + sh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j >= C) v[j] = 0.f;
+    TO* o = (TO*)y.p + (size_t)n * y.n_stride + (size_t)p * 16;
+    if (accumulate) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (TO)((float)o[j] + v[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[j] = (TO)(j < 4 ? v[j] : 0.f);
+    }
+}
+
+// F.interpolate(mode='bilinear', align_corners=False) of an NCHW [N][1][h][w] map by an integer factor
+__global__ void bilinear_up_kernel(const float* __restrict__ src, int N, int h, int w, int f, float* __restrict__ dst) {
+    const int H = h * f, W = w * f;
+    const long long total = (long long)N * H * W;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x = i % W;
+    long long t = i / W;
+    const int y = t % H;
+    const int n = t / H;
+    const float inv = 1.f / f;
+    float sy = (y + 0.5f) * inv - 0.5f, sx = (x + 0.5f) * inv - 0.5f;
+    sy = sy < 0.f ? 0.f : sy;
+    sx = sx < 0.f ? 0.f : sx;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
+    const float ly = sy - y0, lx = sx - x0;
+    const float* s = src + (size_t)n * h * w;
+    dst[i] = (1.f - ly) * ((1.f - lx) * s[y0 * w + x0] + lx * s[y0 * w + x1]) + ly * ((1.f - lx) * s[y1 * w + x0] + lx * s[y1 * w + x1]);
+}
+
+}  // namespace
+
+extern "C" int dasr_inorm_lrelu_fwd(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, float eps, float slope, dasr_tensor y,
+                                    float* stats, void* stream) {
+    if (N <= 0 || C <= 0) return DASR_EINVAL;
+    hipLaunchKernelGGL(inorm_lrelu_fwd_kernel, dim3(N * ((C + 15) / 16)), dim3(256), 0, as_stream(stream), x, C, H, W, eps, slope, y, stats);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_inorm_lrelu_bwd(dasr_tensor a, dasr_tensor ga, int32_t N, int32_t C, int32_t H, int32_t W, float slope,
+                                    const float* stats, dasr_tensor gx, void* stream) {
+    if (N <= 0 || C <= 0) return DASR_EINVAL;
+    hipLaunchKernelGGL(inorm_lrelu_bwd_kernel, dim3(N * ((C + 15) / 16)), dim3(256), 0, as_stream(stream), a, ga, C, H, W, slope, stats, gx);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_bce_logits(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, float target, float coef, float gcoef,
+                               float* loss_acc, float* score_acc, float score_coef, dasr_tensor grad, void* stream) {
+    const long long total = (long long)N * H * W;
+    if (total <= 0 || C > 16) return DASR_EINVAL;
+    hipLaunchKernelGGL(bce_logits_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, target, coef, gcoef, loss_acc,
+                       score_acc, score_coef, grad);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_dwt_fwd(dasr_tensor x, int32_t N, int32_t C, int32_t H2, int32_t W2, int32_t norm, dasr_tensor ll, dasr_tensor hc,
+                            void* stream) {
+    const long long total = (long long)N * H2 * W2;
+    if (total <= 0 || C > 5) return DASR_EINVAL;
+    hipLaunchKernelGGL(dwt_fwd_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H2, W2, norm, ll, hc);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_dwt_bwd(dasr_tensor gll, dasr_tensor ghc, int32_t N, int32_t C, int32_t H2, int32_t W2, int32_t norm, dasr_tensor gx,
+                            int32_t accumulate, void* stream) {
+    const long long total = (long long)N * H2 * W2;
+    if (total <= 0 || C > 5) return DASR_EINVAL;
+    hipLaunchKernelGGL(dwt_bwd_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), gll, ghc, N, C, H2, W2, norm, gx, accumulate);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_lowpass(dasr_tensor x, dasr_tensor x2, const float* w, int32_t k, int32_t N, int32_t C, int32_t H, int32_t W,
+                            int32_t mode, float a_h, float b_h, dasr_tensor out_low, dasr_tensor out_high, int32_t accumulate, void* stream) {
+    const long long total = (long long)N * H * W;
+    if (total <= 0 || C > 4 || !(k & 1)) return DASR_EINVAL;
+    hipLaunchKernelGGL(lowpass_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, x2, w, k, N, C, H, W, mode, a_h, b_h, out_low,
+                       out_high, accumulate);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_maxpool2(dasr_tensor x, int32_t is_f32, int32_t N, int32_t C, int32_t Ho, int32_t Wo, dasr_tensor y, void* stream) {
+    const long long total = (long long)N * ((C + 15) / 16) * Ho * Wo * 4;
+    if (total <= 0) return DASR_EINVAL;
+    if (is_f32) hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
+    else hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_maxpool2_bwd(dasr_tensor x, dasr_tensor gy, int32_t is_f32, int32_t N, int32_t C, int32_t Ho, int32_t Wo, dasr_tensor gx,
+                                 void* stream) {
+    const long long total = (long long)N * ((C + 15) / 16) * Ho * Wo * 4;
+    if (total <= 0) return DASR_EINVAL;
+    if (is_f32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx);
+    else hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_l1_diff(dasr_tensor a, dasr_tensor b, int32_t is_f32, int32_t N, int32_t C, int32_t H, int32_t W, float coef, float gcoef,
+                            float* loss_acc, dasr_tensor ga, void* stream) {
+    const long long total = (long long)N * ((C + 15) / 16) * H * W * 4;
+    if (total <= 0) return DASR_EINVAL;
+    if (is_f32) hipLaunchKernelGGL(l1_diff_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), a, b, N, C, H, W, coef, gcoef, loss_acc, ga);
+    else hipLaunchKernelGGL(l1_diff_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), a, b, N, C, H, W, coef, gcoef, loss_acc, ga);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_affine4(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, const float* scale4, const float* shift4, dasr_tensor y,
+                            int32_t y_f32, int32_t accumulate, void* stream) {
+    const long long total = (long long)N * H * W;
+    if (total <= 0 || C > 4) return DASR_EINVAL;
+    const f32x4 sc = {scale4[0], scale4[1], scale4[2], scale4[3]}, sh = {shift4[0], shift4[1], shift4[2], shift4[3]};
+    if (y_f32) hipLaunchKernelGGL(affine4_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, sc, sh, y, accumulate);
+    else hipLaunchKernelGGL(affine4_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, sc, sh, y, accumulate);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_bilinear_up(const float* src, int32_t N, int32_t h, int32_t w, int32_t factor, float* dst, void* stream) {
+    const long long total = (long long)N * h * w * factor * factor;
+    if (total <= 0) return DASR_EINVAL;
+    hipLaunchKernelGGL(bilinear_up_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), src, N, h, w, factor, dst);
+    return (int)hipGetLastError();
+}

@@ -253,6 +253,9 @@ class SRModel(BaseModel):
             out['HR'] = self.real_H.detach()[0].float().cpu()
         return out
 
+    def networks(self):
+        return [self.netG]
+
     def print_network(self):
         s, n = self.get_network_description(self.netG)
         logger.info('Network G structure: {}, with parameters: {:,d}'.format(self.netG.__class__.__name__, n))

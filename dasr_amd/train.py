@@ -1,0 +1,148 @@
+"""`python -m dasr_amd.train -opt X.json` -- the SRN training driver (reference: codes/SRN/train.py:20-245).
+
+Same loop order as the reference: update_learning_rate -> feed_data -> optimize_parameters, log every
+logger.print_freq, checkpoint every logger.save_checkpoint_freq (model.save + save_training_state), final
+model.save('latest').  Data: the reference's cv2/lmdb datasets are CPU-side IO and out of the hot-path scope
+(SURVEY.md section 8, row 10); this driver accepts any iterable of batch dicts with the reference's keys and ships a
+synthetic dataset (`datasets.train.mode: "synthetic"`) used by the benchmark and the tests.  Under
+torch.distributed.run every rank takes its shard of each batch (dasr_amd.dist.shard_minibatch).
+"""
+import argparse
+import logging
+import math
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from . import options as option
+from .dist import DataParallelGroup, shard_minibatch
+from .models import create_model
+
+
+class SyntheticDataset:
+    """Fixed-seed random crops with the reference batch-dict keys."""
+
+    def __init__(self, ds_opt, scale, model):
+        self.n = int(ds_opt['batch_size'])
+        hr = int(ds_opt['HR_size'] or 128)
+        self.h = hr // scale
+        self.scale = scale
+        self.len = int(ds_opt.get('n_batches') or 1000)
+        self.dasr = model not in ('sr',)
+        self.seed = int(ds_opt.get('seed') or 1234)
+
+    def __len__(self):
+        return self.len
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed)
+        n, h, H = self.n, self.h, self.h * self.scale
+        for _ in range(self.len):
+            if self.dasr:
+                yield {'LR_fake': torch.rand(n, 3, h, h, generator=g), 'LR_real': torch.rand(n, 3, h, h, generator=g),
+                       'HR': torch.rand(n, 3, H, H, generator=g), 'HR_unpair': torch.rand(n, 3, H, H, generator=g),
+                       'fake_w': torch.rand(n, 1, h, h, generator=g)}
+            else:
+                yield {'LR': torch.rand(n, 3, h, h, generator=g), 'HR': torch.rand(n, 3, H, H, generator=g)}
+
+
+def create_dataset(ds_opt, opt):
+    mode = ds_opt['mode']
+    if mode == 'synthetic':
+        return SyntheticDataset(ds_opt, opt['scale'], opt['model'])
+    raise NotImplementedError('Dataset [{:s}] is not recognized (the cv2/lmdb loaders of the reference stay on its side of '
+                              'the boundary; feed their batch dicts to the trainer object).'.format(str(mode)))
+
+
+def setup_logger(name, root, phase, level=logging.INFO, screen=False):
+    lg = logging.getLogger(name)
+    fmt = logging.Formatter('%(asctime)s.%(msecs)03d - %(levelname)s: %(message)s', datefmt='%y-%m-%d %H:%M:%S')
+    os.makedirs(root, exist_ok=True)
+    fh = logging.FileHandler(os.path.join(root, phase + '_{}.log'.format(time.strftime('%y%m%d-%H%M%S'))), mode='w')
+    fh.setFormatter(fmt)
+    lg.setLevel(level)
+    lg.addHandler(fh)
+    if screen:
+        sh = logging.StreamHandler()
+        sh.setFormatter(fmt)
+        lg.addHandler(sh)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('-opt', type=str, required=True, help='Path to option JSON file.')
+    opt = option.dict_to_nonedict(option.parse(ap.parse_args(argv).opt, is_train=True))
+    dp = DataParallelGroup() if int(os.environ.get('WORLD_SIZE', '1')) > 1 else None
+    rank = dp.rank if dp else 0
+    if dp:
+        torch.cuda.set_device(dp.local_rank)
+    resume_state = None
+    if opt['path']['resume_state']:
+        resume_state = torch.load(opt['path']['resume_state'], weights_only=False)
+    elif rank == 0:
+        root = opt['path']['experiments_root']
+        if os.path.exists(root):
+            os.rename(root, root + '_archived_' + time.strftime('%y%m%d-%H%M%S'))
+        for k, p in opt['path'].items():
+            if k != 'experiments_root' and 'pretrain_model' not in k and 'resume' not in k and p:
+                os.makedirs(p, exist_ok=True)
+    if dp:
+        dp.barrier()
+    setup_logger('base', opt['path']['log'], 'train_rank%d' % rank if dp else 'train', screen=(rank == 0))
+    logger = logging.getLogger('base')
+    if resume_state:
+        logger.info('Resuming training from epoch: {}, iter: {}.'.format(resume_state['epoch'], resume_state['iter']))
+        option.check_resume(opt)
+    logger.info(option.dict2str(opt))
+    seed = opt['train']['manual_seed']
+    if seed is None:
+        seed = random.randint(1, 10000)
+    logger.info('Random seed: {}'.format(seed))
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+    train_set = create_dataset(opt['datasets']['train'], opt)
+    total_iters = int(opt['train']['niter'])
+    total_epochs = int(math.ceil(total_iters / max(1, len(train_set))))
+    model = create_model(opt)
+    if dp:
+        model.dp = dp
+        for net in model.networks():
+            dp.broadcast_params(net.params.flat)
+            net.repack()
+    current_step, start_epoch = 0, 0
+    if resume_state:
+        start_epoch, current_step = resume_state['epoch'], resume_state['iter']
+        model.resume_training(resume_state, opt['train'])
+    logger.info('Start training from epoch: {:d}, iter: {:d}'.format(start_epoch, current_step))
+    for epoch in range(start_epoch, total_epochs):
+        for batch in train_set:
+            current_step += 1
+            if current_step > total_iters:
+                break
+            model.update_learning_rate()
+            if dp:
+                batch = shard_minibatch(batch, dp.rank, dp.world)
+            model.feed_data(batch, True)
+            model.optimize_parameters(current_step)
+            if current_step % opt['logger']['print_freq'] == 0 and rank == 0:
+                msg = '<epoch:{:3d}, iter:{:8,d}, lr:{:.3e}> '.format(epoch, current_step, model.get_current_learning_rate())
+                for k, v in model.get_current_log().items():
+                    msg += '{:s}: {:.4e} '.format(k, v)
+                logger.info(msg)
+            if current_step % opt['logger']['save_checkpoint_freq'] == 0 and rank == 0:
+                logger.info('Saving models and training states.')
+                model.save(current_step)
+                model.save_training_state(epoch, current_step)
+    if rank == 0:
+        logger.info('Saving the final model.')
+        model.save('latest')
+        logger.info('End of training.')
+
+
+if __name__ == '__main__':
+    main()
