@@ -112,6 +112,76 @@ def cpu_baseline(nf, nb, lr_size, timeout=150):
                       % (nf, nb, lr_size, lr_size, dt, threads)}
 
 
+def sweep(model, data, a):
+    """interleaved A/B of the kernel variants: isolated dense-conv microbench + whole-step time"""
+    from dasr_amd import _lib
+    from dasr_amd.engine import OpList
+    L = _lib.lib()
+    step = [0]
+
+    def run_steps(n):
+        for _ in range(n):
+            step[0] += 1
+            model.update_learning_rate()
+            model.feed_data(data)
+            model.optimize_parameters(step[0])
+        torch.cuda.synchronize()
+
+    run_steps(2)
+    plan = model.netG.plan(a.batch, a.lr_size, a.lr_size)
+
+    def time_ops(ops, reps=10):
+        ol = OpList()
+        for o in ops:
+            ol.add(o)
+        ol.run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ol.run()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    c32 = [o for o in plan.fwd.ops if o.op == _lib.OP_CONV and o.conv.prec == 1 and o.conv.cout == 32][:4]
+    c64 = [o for o in plan.fwd.ops if o.op == _lib.OP_CONV and o.conv.prec == 1 and o.conv.cout == 64][:1]
+    cst = [o for o in plan.fwd.ops if o.op == _lib.OP_CONV and o.conv.prec == 3 and o.conv.Hout == 4 * a.lr_size and o.conv.cout == 64][:1]
+    wg = [o for o in plan.bwd.ops if o.op in (_lib.OP_WGRAD, _lib.OP_WGRAD_REDUCE)]
+    wg_rdb = wg[-4:-2]  # an RDB group (wgrad + reduce) near the end of the backward list
+    fl = lambda ops: sum(2.0 * o.conv.N * o.conv.Hout * o.conv.Wout * 9 * o.conv.cin * o.conv.cout for o in ops)
+    res = {}
+    for rnd in range(2):
+        for v in (0, 1, 2, 3):
+            L.dasr_set_tuning(1, v)
+            ms = time_ops(c32)
+            res.setdefault(('rdb32', v), []).append(fl(c32) / ms / 1e9)
+        L.dasr_set_tuning(1, 0)
+        for v in (0, 1, 2):
+            L.dasr_set_tuning(2, v)
+            ms = time_ops(c64)
+            res.setdefault(('rdb64', v), []).append(fl(c64) / ms / 1e9)
+        L.dasr_set_tuning(2, 0)
+        for v in (0, 1):
+            L.dasr_set_tuning(3, v)
+            ms = time_ops(cst)
+            res.setdefault(('stream', v), []).append(fl(cst) / ms / 1e9)
+        L.dasr_set_tuning(3, 0)
+        ms = time_ops(wg_rdb[:1])
+        res.setdefault(('wgrad_rdb', 0), []).append(2.0 * a.batch * a.lr_size * a.lr_size * 239616 / ms / 1e9)
+        ms = time_ops(wg_rdb[1:])
+        res.setdefault(('wgrad_reduce_us', 0), []).append(ms * 1e3)
+    for k, v in res.items():
+        log('sweep %-16s variant %d : %s (TFLOP/s algorithmic; stream = 1/3 of MFMA rate)' % (k[0], k[1], ' '.join('%.0f' % x for x in v)))
+    for combo in ((0, 0, 0), (1, 0, 0), (2, 0, 0), (3, 0, 0), (1, 1, 1), (2, 2, 1), (0, 0, 1)):
+        for k, v in zip((1, 2, 3), combo):
+            L.dasr_set_tuning(k, v)
+        run_steps(1)
+        t0 = time.perf_counter()
+        run_steps(3)
+        log('sweep step time, tuning %s: %.2f ms/step' % (combo, (time.perf_counter() - t0) / 3 * 1e3))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -122,12 +192,18 @@ def main():
     ap.add_argument('--nf', type=int, default=64)
     ap.add_argument('--nb', type=int, default=23)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--tune', type=str, default='', help='kernel variant knobs, e.g. 1=1,2=0 (dasr_set_tuning key=value)')
+    ap.add_argument('--sweep', action='store_true', help='A/B the conv kernel variants (stderr table), then exit')
     a = ap.parse_args()
 
     from dasr_amd import options
     from dasr_amd.dist import DataParallelGroup
     from dasr_amd.models import create_model
 
+    from dasr_amd import _lib
+    for kv in [x for x in a.tune.split(',') if x]:
+        k, v = kv.split('=')
+        _lib.check(_lib.lib().dasr_set_tuning(int(k), int(v)), 'set_tuning')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     dp = DataParallelGroup() if world > 1 else None
     rank = dp.rank if dp else 0
@@ -143,6 +219,8 @@ def main():
     data = {'LR': torch.rand(a.batch, 3, a.lr_size, a.lr_size, generator=g).cuda(),
             'HR': torch.rand(a.batch, 3, 4 * a.lr_size, 4 * a.lr_size, generator=g).cuda()}
     log('model built')
+    if a.sweep:
+        return sweep(model, data, a)
     step = 0
     for _ in range(a.warmup):
         step += 1

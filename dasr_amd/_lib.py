@@ -59,7 +59,8 @@ OP_BCE, OP_INORM_FWD, OP_INORM_BWD, OP_DWT_FWD, OP_DWT_BWD, OP_GAUSS, OP_MAXPOOL
 _SIGS = {
     'dasr_conv': [C.POINTER(ConvParams), c_vp],
     'dasr_conv_naive': [C.POINTER(ConvParams), c_vp, c_vp],
-    'dasr_wgrad': [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
+    'dasr_set_tuning': [c_i32, c_i32],
+    'dasr_wgrad': [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
     'dasr_wgrad_set_mode': [c_i32],
     'dasr_wgrad_reduce': [c_vp, c_i32, c_vp, c_vp, c_f32, c_vp],
     'dasr_pack_weights': [c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp],

@@ -14,7 +14,7 @@
 
 namespace {
 
-template <int PREC, bool IN_F32, int MT, int KH, int STRIDE, int NT_>
+template <int PREC, bool IN_F32, int MT, int KH, int STRIDE, int NT_, int KS = 1, bool DBUF = false>
 struct Cfg {
     static constexpr int NT = NT_;
     static constexpr int RPT = STRIDE == 1 ? 1 : 2;    // output rows per n-tile
@@ -24,27 +24,27 @@ struct Cfg {
     static constexpr int IH = (TH - 1) * STRIDE + KH;
     static constexpr int IW = (TW - 1) * STRIDE + KH;
     static constexpr int NTAPS = KH * KH;
-    static constexpr int PIXB = 48;  // 32 B of bf16 + 16 B pad: conflict-free ds_read_b128 (3 slots/pixel)
+    static constexpr int PIXB = KS == 1 ? 48 : 80;  // 32*KS B of bf16 + 16 B pad: conflict-free ds_read_b128 (3 or 5 slots/pixel)
     static constexpr int ACT_BYTES = IH * IW * PIXB;
-    static constexpr int W_BYTES = NTAPS * MT * 1024;
+    static constexpr int W_BYTES = KS * NTAPS * MT * 1024;
     static constexpr int NARR = PREC == 3 ? 2 : 1;
-    static constexpr int LDS_BYTES = NARR * (ACT_BYTES + W_BYTES);
+    static constexpr int BUF_BYTES = NARR * (ACT_BYTES + W_BYTES);
+    static constexpr int LDS_BYTES = (DBUF ? 2 : 1) * BUF_BYTES;
     // staging pieces (16 B of global memory each)
-    static constexpr int PPP = IN_F32 ? 4 : 2;  // pieces per pixel
+    static constexpr int PPP16 = IN_F32 ? 4 : 2;  // pieces per pixel per 16-channel plane
+    static constexpr int PPP = PPP16 * KS;        // pieces per pixel
     static constexpr int NPIECE = IH * IW * PPP;
     static constexpr int AR = (NPIECE + 255) / 256;
-    static constexpr int WPIECE = NTAPS * MT * 64;
+    static constexpr int WPIECE = KS * NTAPS * MT * 64;
     static constexpr int WR = (WPIECE + 255) / 256;
 };
 
-template <int PREC, bool IN_F32, int MT, int KH, int STRIDE, int NT>
+template <int PREC, bool IN_F32, int MT, int KH, int STRIDE, int NT, int KS, bool DBUF>
 __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) {
-    using C = Cfg<PREC, IN_F32, MT, KH, STRIDE, NT>;
+    using C = Cfg<PREC, IN_F32, MT, KH, STRIDE, NT, KS, DBUF>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* act_hi = smem;
-    char* act_lo = smem + C::ACT_BYTES;  // only PREC 3
-    char* w_hi = smem + C::NARR * C::ACT_BYTES;
-    char* w_lo = w_hi + C::W_BYTES;
+    // buffer b: [act_hi | act_lo (prec 3) | w_hi | w_lo (prec 3)]
+    constexpr int ACT_LO = C::ACT_BYTES, W_HI = C::NARR * C::ACT_BYTES, W_LO = W_HI + C::W_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cout_tiles = (p.cout + 31) >> 5;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
     const int oy0 = ty * C::TH, ox0 = tx * C::TW;
     const int iy0 = oy0 * STRIDE - p.pad, ix0 = ox0 * STRIDE - p.pad;
     const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
-    const int nchunks = p.cin >> 4;
+    const int nchunks = p.cin / (16 * KS);
 
     // ---- per-thread staging offsets (independent of the chunk) ----
     int goff[C::AR];  // element offset inside a plane, -1: zero fill
@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
         const int gy = iy0 + iy, gx = ix0 + ix;
         const bool ok = q < C::NPIECE && gy >= 0 && gy < HL && gx >= 0 && gx < WL;
         const int sy = p.ups ? (gy >> 1) : gy, sx = p.ups ? (gx >> 1) : gx;
-        goff[r] = ok ? (sy * p.Win + sx) * 16 + piece * (IN_F32 ? 4 : 8) : -1;
+        const int pl = piece / C::PPP16, pp = piece - pl * C::PPP16;
+        goff[r] = ok ? pl * (int)p.in.cb_stride + (sy * p.Win + sx) * 16 + pp * (IN_F32 ? 4 : 8) : -1;
         loff[r] = q < C::NPIECE ? pix * C::PIXB + piece * (IN_F32 ? 8 : 16) : -1;
     }
     const char* in_base = (const char*)p.in.p + (size_t)n * p.in.n_stride * (IN_F32 ? 4 : 2);
@@ -84,14 +85,14 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
     u32x4 wreg[C::WR * C::NARR];
 
     auto load_chunk = [&](int ck) {
-        const char* plane = in_base + ck * in_cb_bytes;
+        const char* plane = in_base + (size_t)ck * KS * in_cb_bytes;
 #pragma unroll
         for (int r = 0; r < C::AR; ++r) {
             u32x4 v = {0u, 0u, 0u, 0u};
             if (goff[r] >= 0) v = *(const u32x4*)(plane + (size_t)goff[r] * (IN_F32 ? 4 : 2));
             areg[r] = v;
         }
-        const bf16_t* wc = wg + (size_t)ck * C::NTAPS * MT * 512;
+        const bf16_t* wc = wg + (size_t)ck * KS * C::NTAPS * MT * 512;
 #pragma unroll
         for (int r = 0; r < C::WR; ++r) {
             int q = tid + r * 256;
@@ -100,7 +101,11 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
             if constexpr (PREC == 3) wreg[C::WR + r] = *(const u32x4*)(wc + p.w_lo_off + (size_t)q * 8);
         }
     };
-    auto store_chunk = [&]() {
+    auto store_chunk = [&](char* buf) {
+        char* act_hi = buf;
+        char* act_lo = buf + ACT_LO;
+        char* w_hi = buf + W_HI;
+        char* w_lo = buf + W_LO;
 #pragma unroll
         for (int r = 0; r < C::AR; ++r) {
             if (loff[r] >= 0) {
@@ -155,38 +160,64 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[mi][nt][j] = 0.f;
 
-    load_chunk(0);
-    for (int ck = 0; ck < nchunks; ++ck) {
-        store_chunk();
-        __syncthreads();
-        if (ck + 1 < nchunks) load_chunk(ck + 1);
+    auto compute = [&](const char* buf) {
+        const char* act_hi = buf;
+        const char* act_lo = buf + ACT_LO;
+        const char* w_hi = buf + W_HI;
+        const char* w_lo = buf + W_LO;
 #pragma unroll
-        for (int t = 0; t < C::NTAPS; ++t) {
-            const int ky = t / KH, kx = t - ky * KH;
-            const int toff = (ky * C::IW + kx) * C::PIXB;
-            bf16x8 a[MT], al[MT], b[NT], bl[NT];
+        for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
-                a[mi] = *(const bf16x8*)(w_hi + (t * MT + mi) * 1024 + aoff);
-                if constexpr (PREC == 3) al[mi] = *(const bf16x8*)(w_lo + (t * MT + mi) * 1024 + aoff);
-            }
+            for (int t = 0; t < C::NTAPS; ++t) {
+                const int ky = t / KH, kx = t - ky * KH;
+                const int toff = (ky * C::IW + kx) * C::PIXB + ks * 32;
+                bf16x8 a[MT], al[MT], b[NT], bl[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                b[nt] = *(const bf16x8*)(act_hi + boff[nt] + toff);
-                if constexpr (PREC == 3) bl[nt] = *(const bf16x8*)(act_lo + boff[nt] + toff);
-            }
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
+                for (int mi = 0; mi < MT; ++mi) {
+                    a[mi] = *(const bf16x8*)(w_hi + ((ks * C::NTAPS + t) * MT + mi) * 1024 + aoff);
+                    if constexpr (PREC == 3) al[mi] = *(const bf16x8*)(w_lo + ((ks * C::NTAPS + t) * MT + mi) * 1024 + aoff);
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    if constexpr (PREC == 3) {
-                        acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], b[nt], acc[mi][nt], 0, 0, 0);
-                        acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], bl[nt], acc[mi][nt], 0, 0, 0);
-                    }
-                    acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[nt], acc[mi][nt], 0, 0, 0);
+                    b[nt] = *(const bf16x8*)(act_hi + boff[nt] + toff);
+                    if constexpr (PREC == 3) bl[nt] = *(const bf16x8*)(act_lo + boff[nt] + toff);
                 }
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if constexpr (PREC == 3) {
+                            acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], b[nt], acc[mi][nt], 0, 0, 0);
+                            acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], bl[nt], acc[mi][nt], 0, 0, 0);
+                        }
+                        acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[nt], acc[mi][nt], 0, 0, 0);
+                    }
+            }
         }
+    };
+
+    load_chunk(0);
+    if constexpr (DBUF) {
+        // one barrier per chunk: chunk ck+1 is fetched to registers before, and written to the other LDS
+        // buffer after, the MFMAs of chunk ck
+        store_chunk(smem);
         __syncthreads();
+        for (int ck = 0; ck < nchunks; ++ck) {
+            char* cur = smem + (ck & 1) * C::BUF_BYTES;
+            char* nxt = smem + ((ck + 1) & 1) * C::BUF_BYTES;
+            if (ck + 1 < nchunks) load_chunk(ck + 1);
+            compute(cur);
+            if (ck + 1 < nchunks) store_chunk(nxt);
+            __syncthreads();
+        }
+    } else {
+        for (int ck = 0; ck < nchunks; ++ck) {
+            store_chunk(smem);
+            __syncthreads();
+            if (ck + 1 < nchunks) load_chunk(ck + 1);
+            compute(smem);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue ----
@@ -273,11 +304,12 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
     }
 }
 
-template <int PREC, bool IN_F32, int MT, int KH, int STRIDE, int NT>
+template <int PREC, bool IN_F32, int MT, int KH, int STRIDE, int NT, int KS = 1, bool DBUF = false>
 int launch(const dasr_conv_params& p, hipStream_t s) {
-    using C = Cfg<PREC, IN_F32, MT, KH, STRIDE, NT>;
+    using C = Cfg<PREC, IN_F32, MT, KH, STRIDE, NT, KS, DBUF>;
     static bool attr_set = false;
-    auto kfn = conv_kernel<PREC, IN_F32, MT, KH, STRIDE, NT>;
+    auto kfn = conv_kernel<PREC, IN_F32, MT, KH, STRIDE, NT, KS, DBUF>;
+    if (p.cin % (16 * KS)) return DASR_EINVAL;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         attr_set = true;
@@ -330,7 +362,19 @@ __global__ void conv_naive_kernel(const dasr_conv_params p, const float* w) {
         ((bf16_t*)p.out_bf16.p)[(size_t)n * p.out_bf16.n_stride + (size_t)(oc >> 4) * p.out_bf16.cb_stride + po] = (bf16_t)(acc * p.gamma);
 }
 
+// kernel-variant selection (A/B-able from the host: dasr_set_tuning)
+int g_tune_rdb32 = 0, g_tune_rdb64 = 0, g_tune_stream = 0;
+
 }  // namespace
+
+extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
+    switch (key) {
+        case 1: g_tune_rdb32 = value; return 0;   // Cout=32 dense conv: 0 single-buffer CK16, 1 double-buffer CK16, 2 single CK32, 3 double CK32
+        case 2: g_tune_rdb64 = value; return 0;   // Cout=64 dense conv: 0 single CK16, 1 double CK16, 2 single CK32
+        case 3: g_tune_stream = value; return 0;  // split-bf16 stream conv: 0 single, 1 double
+        default: return DASR_EINVAL;
+    }
+}
 
 extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
     const dasr_conv_params& p = *pp;
@@ -343,13 +387,28 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
     if (p.kh != 3 && p.kh != 4) return DASR_EINVAL;
     switch (key) {
         // prec 1, bf16 input (RDB dense-block convs, fwd and dgrad)
-        case 10: return launch<1, false, 1, 3, 1, 4>(p, s);
-        case 20: return launch<1, false, 2, 3, 1, 4>(p, s);
+        case 10:
+            switch (g_tune_rdb32) {
+                case 1: return launch<1, false, 1, 3, 1, 4, 1, true>(p, s);
+                case 2: if (p.cin % 32 == 0) return launch<1, false, 1, 3, 1, 4, 2, false>(p, s); break;
+                case 3: if (p.cin % 32 == 0) return launch<1, false, 1, 3, 1, 4, 2, true>(p, s); break;
+                default: break;
+            }
+            return launch<1, false, 1, 3, 1, 4>(p, s);
+        case 20:
+            switch (g_tune_rdb64) {
+                case 1: return launch<1, false, 2, 3, 1, 4, 1, true>(p, s);
+                case 2: if (p.cin % 32 == 0) return launch<1, false, 2, 3, 1, 4, 2, false>(p, s); break;
+                default: break;
+            }
+            return launch<1, false, 2, 3, 1, 4>(p, s);
         // prec 1, f32 input (VGG perceptual branch)
         case 110: return launch<1, true, 1, 3, 1, 4>(p, s);
         case 120: return launch<1, true, 2, 3, 1, 4>(p, s);
         // prec 3, f32 input (residual-stream convs of the generator, discriminator)
-        case 1110: return launch<3, true, 1, 3, 1, 4>(p, s);
+        case 1110:
+            if (g_tune_stream == 1) return launch<3, true, 1, 3, 1, 4, 1, true>(p, s);
+            return launch<3, true, 1, 3, 1, 4>(p, s);
         case 1111: return launch<3, true, 1, 4, 1, 2>(p, s);
         case 1112: return launch<3, true, 1, 4, 2, 1>(p, s);
         default: return DASR_EINVAL;

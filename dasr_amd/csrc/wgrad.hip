@@ -15,7 +15,7 @@ template <int KH, int STRIDE>
 struct WCfg {
     static constexpr int NTAPS = KH * KH;
     static constexpr int TPG = (NTAPS + 1) / 2;  // taps per wave
-    static constexpr int PH = 8, PW = 16;        // output-pixel tile (8 k-steps of 16 pixels)
+    static constexpr int PH = KH == 3 ? 8 : (STRIDE == 2 ? 2 : 4), PW = 16;  // output-pixel tile (PH k-steps of 16 pixels)
     static constexpr int IH = (PH - 1) * STRIDE + KH;
     static constexpr int IW = (PW - 1) * STRIDE + KH;
     static constexpr int GPLANE = PH * PW * 32 + 128;  // bytes; stride = 128 (mod 256): the two planes of a
@@ -32,7 +32,43 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* base, int off0, int off1) 
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int KH, int STRIDE, bool USE_TR>
+// Staging helpers: one "piece" = 16 B of LDS payload (8 bf16 channels of one pixel).  For f32 sources a piece is
+// assembled from two 16 B global loads (8 floats) and rounded to bf16 on the way.
+template <bool F32>
+struct StageReg {
+    u32x4 a, b;  // b only used when F32
+};
+
+template <bool F32>
+__device__ __forceinline__ void stage_load(StageReg<F32>& r, const char* base, size_t eoff, bool ok) {
+    r.a = u32x4{0u, 0u, 0u, 0u};
+    if constexpr (F32) r.b = u32x4{0u, 0u, 0u, 0u};
+    if (ok) {
+        if constexpr (F32) {
+            r.a = *(const u32x4*)(base + eoff * 4);
+            r.b = *(const u32x4*)(base + eoff * 4 + 16);
+        } else {
+            r.a = *(const u32x4*)(base + eoff * 2);
+        }
+    }
+}
+
+template <bool F32>
+__device__ __forceinline__ void stage_store(const StageReg<F32>& r, char* dst) {
+    if constexpr (F32) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = (bf16_t)__uint_as_float(r.a[j]);
+            o[4 + j] = (bf16_t)__uint_as_float(r.b[j]);
+        }
+        *(bf16x8*)dst = o;
+    } else {
+        *(u32x4*)dst = r.a;
+    }
+}
+
+template <int KH, int STRIDE, bool USE_TR, bool F32>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit,
                                                        float* __restrict__ ws) {
     using C = WCfg<KH, STRIDE>;
@@ -47,7 +83,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __
     const int tiles_x = (P.Wout + C::PW - 1) / C::PW, tiles_y = (P.Hout + C::PH - 1) / C::PH;
     const int ntiles = tiles_x * tiles_y * P.N;
     const int HL = P.ups ? 2 * P.Hin : P.Hin, WL = P.ups ? 2 * P.Win : P.Win;
-    const int gsz = P.g_f32 ? 4 : 2, isz = P.in_f32 ? 4 : 2;
+    constexpr int ESZ = F32 ? 4 : 2;
+    constexpr int GPIX = C::PH * C::PW, IPIX = C::IH * C::IW;
+    constexpr int GPIECES = 2 * GPIX * 2;          // 2 planes x pixels x 2 halves (8 channels each)
+    constexpr int GR = (GPIECES + 255) / 256;
+    constexpr int IPIECES_MAX = 4 * IPIX * 2;
+    constexpr int IR = (IPIECES_MAX + 255) / 256;
+    const int ipieces = 2 * P.n_ctiles * IPIX * 2;
 
     f32x16 acc[C::TPG];
 #pragma unroll
@@ -55,12 +97,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
     float bsum = 0.f;
-
-    // fragment gather geometry
     const int gg = lane >> 4, li = lane & 15;
     const int fplane = gg & 1, khalf = gg >> 1;
 
-    for (int tile = split; tile < ntiles; tile += nsplit) {
+    StageReg<F32> greg[GR], ireg[IR];
+
+    auto prefetch = [&](int tile) {
         int t2 = tile;
         const int tx = t2 % tiles_x;
         t2 /= tiles_x;
@@ -68,69 +110,54 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __
         const int n = t2 / tiles_y;
         const int oy0 = ty * C::PH, ox0 = tx * C::PW;
         const int iy0 = oy0 * STRIDE - P.pad, ix0 = ox0 * STRIDE - P.pad;
-        __syncthreads();  // previous tile's reads are done
-        // ---- stage G tile: 2 planes x 128 pixels x 16 ch (bf16 in LDS) ----
-        {
-            const char* gb = (const char*)P.g.p + (size_t)n * P.g.n_stride * gsz;
-            const int psh = P.g_f32 ? 2 : 1;  // log2(16-byte global pieces per pixel-plane)
-            const int npiece = (2 * C::PH * C::PW) << psh;
-            for (int q = tid; q < npiece; q += 256) {
-                const int piece = q & ((1 << psh) - 1);
-                int r = q >> psh;
-                const int pix = r % (C::PH * C::PW);
-                const int pl = r / (C::PH * C::PW);
-                const int py = pix / C::PW, px = pix - py * C::PW;
-                const int oy = oy0 + py, ox = ox0 + px;
-                const bool ok = oy < P.Hout && ox < P.Wout && pl < P.g_planes;
-                const size_t eoff = (size_t)pl * P.g.cb_stride + ((size_t)oy * P.Wout + ox) * 16;
-                char* dst = gl + pl * C::GPLANE + pix * 32;
-                if (P.g_f32) {
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (ok) v = *(const f32x4*)(gb + (eoff + piece * 4) * 4);
-                    bf16x4 o;
+        const char* gb = (const char*)P.g.p + (size_t)n * P.g.n_stride * ESZ;
+        const char* ib = (const char*)P.in.p + (size_t)n * P.in.n_stride * ESZ;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
-                    *(bf16x4*)(dst + piece * 8) = o;
-                } else {
-                    u32x4 v = {0u, 0u, 0u, 0u};
-                    if (ok) v = *(const u32x4*)(gb + (eoff + piece * 8) * 2);
-                    *(u32x4*)(dst + piece * 16) = v;
-                }
+        for (int r = 0; r < GR; ++r) {
+            const int q = tid + r * 256;
+            const int half = q & 1, pix = (q >> 1) % GPIX, pl = (q >> 1) / GPIX;
+            const int py = pix / C::PW, px = pix - py * C::PW;
+            const int oy = oy0 + py, ox = ox0 + px;
+            const bool ok = q < GPIECES && oy < P.Hout && ox < P.Wout && pl < P.g_planes;
+            stage_load<F32>(greg[r], gb, (size_t)pl * P.g.cb_stride + ((size_t)oy * P.Wout + ox) * 16 + half * 8, ok);
+        }
+#pragma unroll
+        for (int r = 0; r < IR; ++r) {
+            const int q = tid + r * 256;
+            const int half = q & 1, pix = (q >> 1) % IPIX, pl = (q >> 1) / IPIX;
+            const int iy = pix / C::IW, ix = pix - iy * C::IW;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            const bool ok = q < ipieces && gy >= 0 && gy < HL && gx >= 0 && gx < WL && pl < P.in_planes;
+            const int sy = P.ups ? gy >> 1 : gy, sx = P.ups ? gx >> 1 : gx;
+            stage_load<F32>(ireg[r], ib, (size_t)pl * P.in.cb_stride + ((size_t)sy * P.Win + sx) * 16 + half * 8, ok);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int r = 0; r < GR; ++r) {
+            const int q = tid + r * 256;
+            if (q < GPIECES) {
+                const int half = q & 1, pix = (q >> 1) % GPIX, pl = (q >> 1) / GPIX;
+                stage_store<F32>(greg[r], gl + pl * C::GPLANE + pix * 32 + half * 16);
             }
         }
-        // ---- stage input halo tile: 2*n_ctiles planes x IH*IW pixels ----
-        {
-            const char* ib = (const char*)P.in.p + (size_t)n * P.in.n_stride * isz;
-            const int psh = P.in_f32 ? 2 : 1;
-            const int npiece = (2 * P.n_ctiles * C::IH * C::IW) << psh;
-            for (int q = tid; q < npiece; q += 256) {
-                const int piece = q & ((1 << psh) - 1);
-                int r = q >> psh;
-                const int pix = r % (C::IH * C::IW);
-                const int pl = r / (C::IH * C::IW);
-                const int iy = pix / C::IW, ix = pix - iy * C::IW;
-                const int gy = iy0 + iy, gx = ix0 + ix;
-                const bool ok = gy >= 0 && gy < HL && gx >= 0 && gx < WL && pl < P.in_planes;
-                const int sy = P.ups ? gy >> 1 : gy, sx = P.ups ? gx >> 1 : gx;
-                const size_t eoff = (size_t)pl * P.in.cb_stride + ((size_t)sy * P.Win + sx) * 16;
-                char* dst = il + pl * C::IPLANE + pix * 32;
-                if (P.in_f32) {
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (ok) v = *(const f32x4*)(ib + (eoff + piece * 4) * 4);
-                    bf16x4 o;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
-                    *(bf16x4*)(dst + piece * 8) = o;
-                } else {
-                    u32x4 v = {0u, 0u, 0u, 0u};
-                    if (ok) v = *(const u32x4*)(ib + (eoff + piece * 8) * 2);
-                    *(u32x4*)(dst + piece * 16) = v;
-                }
+        for (int r = 0; r < IR; ++r) {
+            const int q = tid + r * 256;
+            if (q < ipieces) {
+                const int half = q & 1, pix = (q >> 1) % IPIX, pl = (q >> 1) / IPIX;
+                stage_store<F32>(ireg[r], il + pl * C::IPLANE + pix * 32 + half * 16);
             }
         }
+    };
+
+    if (split < ntiles) prefetch(split);
+    for (int tile = split; tile < ntiles; tile += nsplit) {
+        __syncthreads();  // previous tile's LDS reads are done
+        commit();
         __syncthreads();
+        if (tile + nsplit < ntiles) prefetch(tile + nsplit);  // global loads fly under the MFMAs below
         if (!active) continue;
-        // ---- MFMA over the 8 pixel rows of the tile ----
 #pragma unroll 2
         for (int r = 0; r < C::PH; ++r) {
             bf16x8 a;
@@ -200,9 +227,17 @@ __global__ void wgrad_reduce_kernel(const dasr_wgrad_reduce_part* __restrict__ p
             if (cin >= 32 * P.n_ctiles) continue;
             const int goc = P.oc0 + oc, gc = P.c0 + cin;
             if (goc >= P.cout || gc >= P.cin) continue;
-            float s = 0.f;
-            for (int sp = 0; sp < P.nsplit; ++sp) s += ws[P.ws_off + (size_t)sp * per + i];
-            grad[P.dst_w_off + ((size_t)goc * P.cin + gc) * P.ntaps + tap] = s * scale;
+            const float* src = ws + P.ws_off + i;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int sp = 0;
+            for (; sp + 4 <= P.nsplit; sp += 4) {  // fixed order -> deterministic; 4 loads in flight
+                s0 += src[(size_t)sp * per];
+                s1 += src[(size_t)(sp + 1) * per];
+                s2 += src[(size_t)(sp + 2) * per];
+                s3 += src[(size_t)(sp + 3) * per];
+            }
+            for (; sp < P.nsplit; ++sp) s0 += src[(size_t)sp * per];
+            grad[P.dst_w_off + ((size_t)goc * P.cin + gc) * P.ntaps + tap] = ((s0 + s1) + (s2 + s3)) * scale;
         } else if (P.dst_b_off >= 0) {
             const int oc = i - per;
             if (P.oc0 + oc < P.cout) {
@@ -228,10 +263,10 @@ __global__ void probe_tr16_kernel(int* result) {
     if (l == 0) *result = (m == ~0ull) ? 1 : 0;
 }
 
-template <int KH, int STRIDE, bool USE_TR>
+template <int KH, int STRIDE, bool USE_TR, bool F32>
 int launch_wgrad(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws, hipStream_t s) {
     using C = WCfg<KH, STRIDE>;
-    auto kfn = wgrad_kernel<KH, STRIDE, USE_TR>;
+    auto kfn = wgrad_kernel<KH, STRIDE, USE_TR, F32>;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
@@ -263,15 +298,23 @@ extern "C" int dasr_wgrad_set_mode(int use_tr) {
     return 0;
 }
 
-extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int32_t nsplit, int32_t kh, int32_t stride,
+namespace {
+template <int KH, int STRIDE>
+int dispatch_wgrad(const dasr_wgrad_part* parts, int nparts, int nsplit, bool tr, bool f32, float* ws, hipStream_t s) {
+    if (tr) return f32 ? launch_wgrad<KH, STRIDE, true, true>(parts, nparts, nsplit, ws, s) : launch_wgrad<KH, STRIDE, true, false>(parts, nparts, nsplit, ws, s);
+    return f32 ? launch_wgrad<KH, STRIDE, false, true>(parts, nparts, nsplit, ws, s) : launch_wgrad<KH, STRIDE, false, false>(parts, nparts, nsplit, ws, s);
+}
+}  // namespace
+
+extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int32_t nsplit, int32_t kh, int32_t stride, int32_t f32,
                           float* ws, void* stream) {
     hipStream_t s = as_stream(stream);
     if (nparts <= 0 || nsplit <= 0) return DASR_EINVAL;
     if (g_use_tr < 0) return DASR_EINVAL;  // dasr_probe_tr16 must run once per process (outside graph capture)
     const bool tr = g_use_tr == 1;
-    if (kh == 3 && stride == 1) return tr ? launch_wgrad<3, 1, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad<3, 1, false>(parts_dev, nparts, nsplit, ws, s);
-    if (kh == 4 && stride == 1) return tr ? launch_wgrad<4, 1, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad<4, 1, false>(parts_dev, nparts, nsplit, ws, s);
-    if (kh == 4 && stride == 2) return tr ? launch_wgrad<4, 2, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad<4, 2, false>(parts_dev, nparts, nsplit, ws, s);
+    if (kh == 3 && stride == 1) return dispatch_wgrad<3, 1>(parts_dev, nparts, nsplit, tr, f32 != 0, ws, s);
+    if (kh == 4 && stride == 1) return dispatch_wgrad<4, 1>(parts_dev, nparts, nsplit, tr, f32 != 0, ws, s);
+    if (kh == 4 && stride == 2) return dispatch_wgrad<4, 2>(parts_dev, nparts, nsplit, tr, f32 != 0, ws, s);
     return DASR_EINVAL;
 }
 

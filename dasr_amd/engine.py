@@ -229,11 +229,14 @@ class WgradGroup:
                 rp.dst_b_off = dst_b_off if (dst_b_off is not None and c0 == 0) else -1
                 self.parts.append((wp, rp))
 
-    def finalize(self, workspace, device, target_wgs=512):
+    def finalize(self, workspace, device, target_wgs=768):
         wp0 = self.parts[0][0]
-        ntiles = wp0.N * ceil_div(wp0.Hout, 8) * ceil_div(wp0.Wout, 16)
+        ph = 8 if self.kh == 3 else (2 if self.stride == 2 else 4)  # WCfg::PH in wgrad.hip
+        ntiles = wp0.N * ceil_div(wp0.Hout, ph) * ceil_div(wp0.Wout, 16)
         nparts = len(self.parts)
         self.nsplit = max(1, min(ntiles, target_wgs // nparts))
+        if self.nsplit >= 16:
+            self.nsplit -= self.nsplit % 8  # same pixel split -> same XCD (block id % 8) for every part: shared L2 lines
         ntaps = self.kh * self.kh
         off = 0
         for wp, rp in self.parts:
@@ -255,6 +258,9 @@ class WgradGroup:
         a, b = Op(), Op()
         a.op = _lib.OP_WGRAD
         a.p[0], a.i[0], a.i[1], a.i[2], a.i[3] = self.w_dev.data_ptr(), len(self.parts), self.nsplit, self.kh, self.stride
+        f32s = set((p[0].g_f32, p[0].in_f32) for p in self.parts)
+        assert f32s in ({(0, 0)}, {(1, 1)}), 'a wgrad group must be all-bf16 or all-f32'
+        a.i[4] = self.parts[0][0].g_f32
         b.op = _lib.OP_WGRAD_REDUCE
         b.p[0], b.i[0], b.p[2], b.f[0] = self.r_dev.data_ptr(), len(self.parts), grad_ptr, scale
         self.workspace.register(a, b)

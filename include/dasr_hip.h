@@ -56,6 +56,8 @@ typedef struct {
 } dasr_conv_params;
 
 int dasr_conv(const dasr_conv_params* p, void* stream);
+/* kernel-variant knobs (LDS double buffering / 32-channel chunks); see conv.hip.  Defaults are the tuned choice. */
+int dasr_set_tuning(int32_t key, int32_t value);
 
 /* ---- weight gradient ---------------------------------------------------------------------------
  * Replaces autograd's convolution_backward (weight, bias) for the convs above.  One launch covers
@@ -76,8 +78,9 @@ typedef struct {
     int64_t ws_bias_off;
 } dasr_wgrad_part;
 
-int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int32_t nsplit, int32_t kh, int32_t stride, float* ws,
-               void* stream);
+/* f32: g and in tensors of ALL parts are f32 (rounded to bf16 while staging) instead of bf16 */
+int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int32_t nsplit, int32_t kh, int32_t stride, int32_t f32,
+               float* ws, void* stream);
 /* 1: use ds_read_b64_tr_b16 gathers, 0: scalar LDS gathers.  dasr_probe_tr16 sets it from the device. */
 int dasr_wgrad_set_mode(int32_t use_tr);
 
