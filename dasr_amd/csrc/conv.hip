@@ -39,12 +39,24 @@ struct Cfg {
     static constexpr int WR = (WPIECE + 255) / 256;
 };
 
+// All global traffic goes through raw buffer loads/stores: an out-of-range offset (OOB) reads as zero / drops the
+// store, so halo padding, partial tiles and padded channels need no divergent branches (exec-masked branches around
+// loads make hipcc drain vmcnt and serialise the pipeline).
+constexpr unsigned OOB = 0x80000000u;
+constexpr int RSRC_FLAGS = 0x00020000;
+constexpr int RSRC_RANGE = 0x7fffffff;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, RSRC_RANGE, RSRC_FLAGS);
+}
+
 template <int PREC, bool IN_F32, int MT, int KH, int STRIDE, int NT, int KS, bool DBUF>
-__global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) {
+__global__ __launch_bounds__(256, (MT == 1 && PREC == 1 && !IN_F32) ? 3 : 2) void conv_kernel(const dasr_conv_params p) {
     using C = Cfg<PREC, IN_F32, MT, KH, STRIDE, NT, KS, DBUF>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // buffer b: [act_hi | act_lo (prec 3) | w_hi | w_lo (prec 3)]
+    // buffer b: [act_hi | act_lo (prec 3) | w_hi | w_lo (prec 3)]; one 16 B dummy slot after the buffers
     constexpr int ACT_LO = C::ACT_BYTES, W_HI = C::NARR * C::ACT_BYTES, W_LO = W_HI + C::W_BYTES;
+    constexpr int DUMMY = C::LDS_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cout_tiles = (p.cout + 31) >> 5;
@@ -61,10 +73,11 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
     const int iy0 = oy0 * STRIDE - p.pad, ix0 = ox0 * STRIDE - p.pad;
     const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
     const int nchunks = p.cin / (16 * KS);
+    constexpr int ESZ = IN_F32 ? 4 : 2;
 
     // ---- per-thread staging offsets (independent of the chunk) ----
-    int goff[C::AR];  // element offset inside a plane, -1: zero fill
-    int loff[C::AR];  // LDS byte offset
+    unsigned goff[C::AR];  // byte offset inside the image, OOB: zero fill
+    int loff[C::AR];       // LDS byte offset (dummy slot for the tail)
 #pragma unroll
     for (int r = 0; r < C::AR; ++r) {
         const int q = tid + r * 256;
@@ -74,64 +87,59 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
         const bool ok = q < C::NPIECE && gy >= 0 && gy < HL && gx >= 0 && gx < WL;
         const int sy = p.ups ? (gy >> 1) : gy, sx = p.ups ? (gx >> 1) : gx;
         const int pl = piece / C::PPP16, pp = piece - pl * C::PPP16;
-        goff[r] = ok ? pl * (int)p.in.cb_stride + (sy * p.Win + sx) * 16 + pp * (IN_F32 ? 4 : 8) : -1;
-        loff[r] = q < C::NPIECE ? pix * C::PIXB + piece * (IN_F32 ? 8 : 16) : -1;
+        goff[r] = ok ? (unsigned)((pl * (int)p.in.cb_stride + (sy * p.Win + sx) * 16 + pp * (IN_F32 ? 4 : 8)) * ESZ) : OOB;
+        loff[r] = q < C::NPIECE ? pix * C::PIXB + piece * (IN_F32 ? 8 : 16) : DUMMY;
     }
-    const char* in_base = (const char*)p.in.p + (size_t)n * p.in.n_stride * (IN_F32 ? 4 : 2);
-    const size_t in_cb_bytes = (size_t)p.in.cb_stride * (IN_F32 ? 4 : 2);
-    const bf16_t* wg = (const bf16_t*)p.w + (size_t)mg * nchunks * C::NTAPS * MT * 512;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc((const char*)p.in.p + (size_t)n * p.in.n_stride * ESZ);
+    const unsigned in_chunk_bytes = (unsigned)(p.in.cb_stride * KS * ESZ);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const bf16_t*)p.w + (size_t)mg * nchunks * KS * C::NTAPS * MT * 512);
+    const unsigned w_chunk_bytes = KS * C::NTAPS * MT * 1024;
+    const unsigned w_lo_bytes = (unsigned)(p.w_lo_off * 2);
+    unsigned woff[C::WR];
+    int wloff[C::WR];
+#pragma unroll
+    for (int r = 0; r < C::WR; ++r) {
+        const int q = tid + r * 256;
+        woff[r] = q < C::WPIECE ? (unsigned)q * 16u : OOB;
+        wloff[r] = q < C::WPIECE ? q * 16 : DUMMY - W_HI;
+    }
 
     u32x4 areg[C::AR];
     u32x4 wreg[C::WR * C::NARR];
 
     auto load_chunk = [&](int ck) {
-        const char* plane = in_base + (size_t)ck * KS * in_cb_bytes;
+        const unsigned so = (unsigned)ck * in_chunk_bytes;
 #pragma unroll
-        for (int r = 0; r < C::AR; ++r) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (goff[r] >= 0) v = *(const u32x4*)(plane + (size_t)goff[r] * (IN_F32 ? 4 : 2));
-            areg[r] = v;
-        }
-        const bf16_t* wc = wg + (size_t)ck * KS * C::NTAPS * MT * 512;
+        for (int r = 0; r < C::AR; ++r) areg[r] = __builtin_amdgcn_raw_buffer_load_b128(rin, goff[r], so, 0);
+        const unsigned wo = (unsigned)ck * w_chunk_bytes;
 #pragma unroll
         for (int r = 0; r < C::WR; ++r) {
-            int q = tid + r * 256;
-            q = q < C::WPIECE ? q : C::WPIECE - 1;  // clamp (the store below is predicated)
-            wreg[r] = *(const u32x4*)(wc + (size_t)q * 8);
-            if constexpr (PREC == 3) wreg[C::WR + r] = *(const u32x4*)(wc + p.w_lo_off + (size_t)q * 8);
+            wreg[r] = __builtin_amdgcn_raw_buffer_load_b128(rw, woff[r], wo, 0);
+            if constexpr (PREC == 3) wreg[C::WR + r] = __builtin_amdgcn_raw_buffer_load_b128(rw, woff[r], wo + w_lo_bytes, 0);
         }
     };
     auto store_chunk = [&](char* buf) {
-        char* act_hi = buf;
-        char* act_lo = buf + ACT_LO;
-        char* w_hi = buf + W_HI;
-        char* w_lo = buf + W_LO;
 #pragma unroll
         for (int r = 0; r < C::AR; ++r) {
-            if (loff[r] >= 0) {
-                if constexpr (!IN_F32) {
-                    *(u32x4*)(act_hi + loff[r]) = areg[r];
-                } else {
-                    bf16x4 hi, lo;
+            if constexpr (!IN_F32) {
+                *(u32x4*)(buf + loff[r]) = areg[r];
+            } else {
+                bf16x4 hi, lo;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        bf16_t h, l;
-                        split_bf16(__uint_as_float(areg[r][j]), h, l);
-                        hi[j] = h;
-                        lo[j] = l;
-                    }
-                    *(bf16x4*)(act_hi + loff[r]) = hi;
-                    if constexpr (PREC == 3) *(bf16x4*)(act_lo + loff[r]) = lo;
+                for (int j = 0; j < 4; ++j) {
+                    bf16_t h, l;
+                    split_bf16(__uint_as_float(areg[r][j]), h, l);
+                    hi[j] = h;
+                    lo[j] = l;
                 }
+                *(bf16x4*)(buf + loff[r]) = hi;
+                if constexpr (PREC == 3) *(bf16x4*)(buf + (loff[r] == DUMMY ? DUMMY : ACT_LO + loff[r])) = lo;
             }
         }
 #pragma unroll
         for (int r = 0; r < C::WR; ++r) {
-            const int q = tid + r * 256;
-            if (q < C::WPIECE) {
-                *(u32x4*)(w_hi + q * 16) = wreg[r];
-                if constexpr (PREC == 3) *(u32x4*)(w_lo + q * 16) = wreg[C::WR + r];
-            }
+            *(u32x4*)(buf + W_HI + wloff[r]) = wreg[r];
+            if constexpr (PREC == 3) *(u32x4*)(buf + (wloff[r] == DUMMY - W_HI ? DUMMY : W_LO + wloff[r])) = wreg[C::WR + r];
         }
     };
 
@@ -220,9 +228,36 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
         }
     }
 
-    // ---- epilogue ----
+    // ---- epilogue: straight-line code.  Absent tensors are read/written at OOB offsets (loads return 0, stores are
+    // dropped) and neutral coefficients make the arithmetic a no-op, so there is not a single branch: all loads of a
+    // (tile, m-tile) group are in flight together.  The mask tensor has the input's dtype (bf16 slabs / f32 stream).
     const int cout_pad = (p.cout + 15) & ~15;
-    const float* bias = p.bias;
+    constexpr int MSZ = IN_F32 ? 4 : 2;
+    const bool has_mask = p.mask.p != nullptr, has_r1 = p.res1.p != nullptr, has_r2 = p.res2.p != nullptr;
+    const bool has_f32 = p.out_f32.p != nullptr, has_bf16 = p.out_bf16.p != nullptr;
+    const float act_slope = p.act ? p.slope : 1.f, mask_slope = has_mask ? p.slope : 1.f;
+    const float beta1 = has_r1 ? p.beta1 : 0.f, beta2 = has_r2 ? p.beta2 : 0.f;
+    const __amdgpu_buffer_rsrc_t rmask = make_rsrc((const char*)p.mask.p + (size_t)n * p.mask.n_stride * MSZ);
+    const __amdgpu_buffer_rsrc_t rr1 = make_rsrc((const float*)p.res1.p + (size_t)n * p.res1.n_stride);
+    const __amdgpu_buffer_rsrc_t rr2 = make_rsrc((const float*)p.res2.p + (size_t)n * p.res2.n_stride);
+    const __amdgpu_buffer_rsrc_t rof = make_rsrc((float*)p.out_f32.p + (size_t)n * p.out_f32.n_stride);
+    const __amdgpu_buffer_rsrc_t rob = make_rsrc((bf16_t*)p.out_bf16.p + (size_t)n * p.out_bf16.n_stride);
+    const __amdgpu_buffer_rsrc_t rbias = make_rsrc(p.bias);
+    const unsigned mask_cb = (unsigned)p.mask.cb_stride, r1_cb = (unsigned)p.res1.cb_stride, r2_cb = (unsigned)p.res2.cb_stride;
+    const unsigned of_cb = (unsigned)p.out_f32.cb_stride, ob_cb = (unsigned)p.out_bf16.cb_stride;
+    // bias: 4 consecutive channels per (mi, g); per-element OOB so cout = 3 or 1 stay in range
+    float bia[MT][4][4];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int oc = (mg * MT + mi) * 32 + 8 * g + 4 * kh2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned bo = (p.bias && oc + j < p.cout) ? (unsigned)(oc + j) * 4u : OOB;
+                bia[mi][g][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rbias, bo, 0, 0));
+            }
+        }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         int r, c;
@@ -234,72 +269,51 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
             c = nn & 15;
         }
         const int oy = oy0 + r, ox = ox0 + c;
-        if (oy >= p.Hout || ox >= p.Wout) continue;
-        const size_t pixoff = ((size_t)oy * p.Wout + ox) * 16;
+        const bool pv = oy < p.Hout && ox < p.Wout;
+        const unsigned pixel = (unsigned)(oy * p.Wout + ox) * 16u;
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
+            u32x4 mk[4], r1v[4], r2v[4];
+            unsigned eo[4], cbv[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int oc = (mg * MT + mi) * 32 + 8 * g + 4 * kh2;
-                if (oc >= cout_pad) continue;
-                const int cb = oc >> 4, ci = oc & 15;
+                const bool cv = pv && oc < cout_pad;
+                cbv[g] = (unsigned)(oc >> 4);
+                eo[g] = pixel + (unsigned)(oc & 15);
+                const unsigned mo = (cv && has_mask) ? (cbv[g] * mask_cb + eo[g]) * MSZ : OOB;
+                if constexpr (IN_F32) {
+                    mk[g] = __builtin_amdgcn_raw_buffer_load_b128(rmask, mo, 0, 0);
+                } else {
+                    const u32x2 t2 = __builtin_amdgcn_raw_buffer_load_b64(rmask, mo, 0, 0);
+                    mk[g] = u32x4{t2[0] << 16, t2[0] & 0xffff0000u, t2[1] << 16, t2[1] & 0xffff0000u};
+                }
+                r1v[g] = __builtin_amdgcn_raw_buffer_load_b128(rr1, (cv && has_r1) ? (cbv[g] * r1_cb + eo[g]) * 4u : OOB, 0, 0);
+                r2v[g] = __builtin_amdgcn_raw_buffer_load_b128(rr2, (cv && has_r2) ? (cbv[g] * r2_cb + eo[g]) * 4u : OOB, 0, 0);
+                if (!cv) eo[g] = OOB;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int oc = (mg * MT + mi) * 32 + 8 * g + 4 * kh2;
                 float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = acc[mi][nt][4 * g + j];
-                if (bias) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (oc + j < p.cout) v[j] += bias[oc + j];
+                for (int j = 0; j < 4; ++j) {
+                    float t = acc[mi][nt][4 * g + j] + bia[mi][g][j];
+                    t = fmaxf(t, 0.f) + act_slope * fminf(t, 0.f);
+                    t *= __uint_as_float(mk[g][j]) > 0.f ? 1.f : mask_slope;
+                    t = p.alpha * t + beta1 * __uint_as_float(r1v[g][j]) + beta2 * __uint_as_float(r2v[g][j]);
+                    v[j] = (oc + j < p.cout) ? t : 0.f;  // padded channels of the last plane stay zero
                 }
-                if (p.act) {
+                const unsigned e = eo[g];
+                const u32x4 o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(o, rof, (e != OOB && has_f32) ? (cbv[g] * of_cb + e) * 4u : OOB, 0, 0);
+                bf16x4 ob;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * p.slope;
-                }
-                if (p.mask.p) {
-                    const size_t mo = (size_t)n * p.mask.n_stride + (size_t)cb * p.mask.cb_stride + pixoff + ci;
-                    float m[4];
-                    if (p.mask_f32) {
-                        const f32x4 mv = *(const f32x4*)((const float*)p.mask.p + mo);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) m[j] = mv[j];
-                    } else {
-                        const bf16x4 mv = *(const bf16x4*)((const bf16_t*)p.mask.p + mo);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) m[j] = (float)mv[j];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = m[j] > 0.f ? v[j] : v[j] * p.slope;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
-                if (p.res1.p) {
-                    const f32x4 rv = *(const f32x4*)((const float*)p.res1.p + (size_t)n * p.res1.n_stride +
-                                                     (size_t)cb * p.res1.cb_stride + pixoff + ci);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += p.beta1 * rv[j];
-                }
-                if (p.res2.p) {
-                    const f32x4 rv = *(const f32x4*)((const float*)p.res2.p + (size_t)n * p.res2.n_stride +
-                                                     (size_t)cb * p.res2.cb_stride + pixoff + ci);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += p.beta2 * rv[j];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (oc + j >= p.cout) v[j] = 0.f;  // padded channels of the last plane stay zero
-                if (p.out_f32.p) {
-                    f32x4 o = {v[0], v[1], v[2], v[3]};
-                    *(f32x4*)((float*)p.out_f32.p + (size_t)n * p.out_f32.n_stride + (size_t)cb * p.out_f32.cb_stride +
-                              pixoff + ci) = o;
-                }
-                if (p.out_bf16.p) {
-                    bf16x4 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(v[j] * p.gamma);
-                    *(bf16x4*)((bf16_t*)p.out_bf16.p + (size_t)n * p.out_bf16.n_stride +
-                               (size_t)cb * p.out_bf16.cb_stride + pixoff + ci) = o;
-                }
+                for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)(v[j] * p.gamma);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), rob,
+                                                     (e != OOB && has_bf16) ? (cbv[g] * ob_cb + e) * 2u : OOB, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);  // keep the next group's loads from being hoisted over this one (VGPR pressure)
         }
     }
 }
@@ -311,7 +325,7 @@ int launch(const dasr_conv_params& p, hipStream_t s) {
     auto kfn = conv_kernel<PREC, IN_F32, MT, KH, STRIDE, NT, KS, DBUF>;
     if (p.cin % (16 * KS)) return DASR_EINVAL;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + 16));
         attr_set = true;
     }
     const int cout_tiles = (p.cout + 31) >> 5;
@@ -319,7 +333,7 @@ int launch(const dasr_conv_params& p, hipStream_t s) {
     const int tiles_x = (p.Wout + C::TW - 1) / C::TW, tiles_y = (p.Hout + C::TH - 1) / C::TH;
     const long long grid = (long long)MG * tiles_x * tiles_y * p.N;
     if (grid <= 0 || grid > 0x7fffffffLL) return DASR_EINVAL;
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(256), C::LDS_BYTES, s, p);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(256), C::LDS_BYTES + 16, s, p);
     return (int)hipGetLastError();
 }
 
@@ -385,6 +399,7 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
     if (p.kh == 3 && (p.stride != 1 || p.pad != 1)) return DASR_EINVAL;
     if (p.kh == 4 && (p.pad != 1 || (p.stride != 1 && p.stride != 2))) return DASR_EINVAL;
     if (p.kh != 3 && p.kh != 4) return DASR_EINVAL;
+    if (p.mask.p && (p.mask_f32 != 0) != (p.in_f32 != 0)) return DASR_EINVAL;  // mask dtype is tied to the input dtype
     switch (key) {
         // prec 1, bf16 input (RDB dense-block convs, fwd and dgrad)
         case 10:

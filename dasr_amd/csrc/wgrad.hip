@@ -39,17 +39,20 @@ struct StageReg {
     u32x4 a, b;  // b only used when F32
 };
 
+// branch-free staging loads: an out-of-range buffer offset reads as zero (halo / partial tiles / missing planes)
+constexpr unsigned OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff, 0x00020000);
+}
+
 template <bool F32>
-__device__ __forceinline__ void stage_load(StageReg<F32>& r, const char* base, size_t eoff, bool ok) {
-    r.a = u32x4{0u, 0u, 0u, 0u};
-    if constexpr (F32) r.b = u32x4{0u, 0u, 0u, 0u};
-    if (ok) {
-        if constexpr (F32) {
-            r.a = *(const u32x4*)(base + eoff * 4);
-            r.b = *(const u32x4*)(base + eoff * 4 + 16);
-        } else {
-            r.a = *(const u32x4*)(base + eoff * 2);
-        }
+__device__ __forceinline__ void stage_load(StageReg<F32>& r, __amdgpu_buffer_rsrc_t rs, unsigned eoff, bool ok) {
+    if constexpr (F32) {
+        const unsigned o = ok ? eoff * 4u : OOB;
+        r.a = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0);
+        r.b = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 16, 0);
+    } else {
+        r.a = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? eoff * 2u : OOB, 0, 0);
     }
 }
 
@@ -110,8 +113,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __
         const int n = t2 / tiles_y;
         const int oy0 = ty * C::PH, ox0 = tx * C::PW;
         const int iy0 = oy0 * STRIDE - P.pad, ix0 = ox0 * STRIDE - P.pad;
-        const char* gb = (const char*)P.g.p + (size_t)n * P.g.n_stride * ESZ;
-        const char* ib = (const char*)P.in.p + (size_t)n * P.in.n_stride * ESZ;
+        const __amdgpu_buffer_rsrc_t gb = make_rsrc((const char*)P.g.p + (size_t)n * P.g.n_stride * ESZ);
+        const __amdgpu_buffer_rsrc_t ib = make_rsrc((const char*)P.in.p + (size_t)n * P.in.n_stride * ESZ);
 #pragma unroll
         for (int r = 0; r < GR; ++r) {
             const int q = tid + r * 256;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __
             const int py = pix / C::PW, px = pix - py * C::PW;
             const int oy = oy0 + py, ox = ox0 + px;
             const bool ok = q < GPIECES && oy < P.Hout && ox < P.Wout && pl < P.g_planes;
-            stage_load<F32>(greg[r], gb, (size_t)pl * P.g.cb_stride + ((size_t)oy * P.Wout + ox) * 16 + half * 8, ok);
+            stage_load<F32>(greg[r], gb, (unsigned)(pl * (int)P.g.cb_stride + (oy * P.Wout + ox) * 16 + half * 8), ok);
         }
 #pragma unroll
         for (int r = 0; r < IR; ++r) {
@@ -129,25 +132,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __
             const int gy = iy0 + iy, gx = ix0 + ix;
             const bool ok = q < ipieces && gy >= 0 && gy < HL && gx >= 0 && gx < WL && pl < P.in_planes;
             const int sy = P.ups ? gy >> 1 : gy, sx = P.ups ? gx >> 1 : gx;
-            stage_load<F32>(ireg[r], ib, (size_t)pl * P.in.cb_stride + ((size_t)sy * P.Win + sx) * 16 + half * 8, ok);
+            stage_load<F32>(ireg[r], ib, (unsigned)(pl * (int)P.in.cb_stride + (sy * P.Win + sx) * 16 + half * 8), ok);
         }
     };
+    char* const dummy = smem + C::LDS_BYTES;  // 16 B slot that swallows the tail threads' stores (no divergent branch)
     auto commit = [&]() {
 #pragma unroll
         for (int r = 0; r < GR; ++r) {
             const int q = tid + r * 256;
-            if (q < GPIECES) {
-                const int half = q & 1, pix = (q >> 1) % GPIX, pl = (q >> 1) / GPIX;
-                stage_store<F32>(greg[r], gl + pl * C::GPLANE + pix * 32 + half * 16);
-            }
+            const int half = q & 1, pix = (q >> 1) % GPIX, pl = (q >> 1) / GPIX;
+            stage_store<F32>(greg[r], q < GPIECES ? gl + pl * C::GPLANE + pix * 32 + half * 16 : dummy);
         }
 #pragma unroll
         for (int r = 0; r < IR; ++r) {
             const int q = tid + r * 256;
-            if (q < ipieces) {
-                const int half = q & 1, pix = (q >> 1) % IPIX, pl = (q >> 1) / IPIX;
-                stage_store<F32>(ireg[r], il + pl * C::IPLANE + pix * 32 + half * 16);
-            }
+            const int half = q & 1, pix = (q >> 1) % IPIX, pl = (q >> 1) / IPIX;
+            stage_store<F32>(ireg[r], q < ipieces ? il + pl * C::IPLANE + pix * 32 + half * 16 : dummy);
         }
     };
 
@@ -269,10 +269,10 @@ int launch_wgrad(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws
     auto kfn = wgrad_kernel<KH, STRIDE, USE_TR, F32>;
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + 16));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kfn, dim3(nparts * nsplit), dim3(256), C::LDS_BYTES, s, parts, nparts, nsplit, ws);
+    hipLaunchKernelGGL(kfn, dim3(nparts * nsplit), dim3(256), C::LDS_BYTES + 16, s, parts, nparts, nsplit, ws);
     return (int)hipGetLastError();
 }
 

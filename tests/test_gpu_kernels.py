@@ -86,12 +86,12 @@ def test_conv_forward_matches_torch(case):
     xin = x if in_f32 else bf16r(x)
     xb = to_blocked(xin, in_f32, dev)
     rb = to_blocked(res, True, dev)
-    mb = to_blocked(bf16r(msk), False, dev)
+    mb = to_blocked(bf16r(msk), in_f32, dev)  # the mask tensor has the input's dtype (bf16 slabs / f32 stream)
     of = BTensor(N, cout, Ho, Wo, True, dev)
     ob = BTensor(N, cout, Ho, Wo, False, dev)
     ops = OpList()
     ops.add(conv_op(pack, ref, xb.view(), in_f32, (real_cin + 15) // 16 * 16, H, W, Ho, Wo, N, bias=P.ptr('b'), kh=kh, stride=stride,
-                    pad=1, ups=ups, act=1, mask=mb.view(), mask_f32=0, alpha=0.2, res1=rb.view(), beta1=1.0,
+                    pad=1, ups=ups, act=1, mask=mb.view(), mask_f32=int(in_f32), alpha=0.2, res1=rb.view(), beta1=1.0,
                     out_f32=of.view(), out_bf16=ob.view(), gamma=0.5))
     ops.run()
     torch.cuda.synchronize()
