@@ -21,7 +21,7 @@ class ConvParams(C.Structure):
                 ('act', c_i32), ('slope', c_f32),
                 ('mask', Tensor), ('mask_f32', c_i32),
                 ('alpha', c_f32), ('res1', Tensor), ('beta1', c_f32), ('res2', Tensor), ('beta2', c_f32),
-                ('out_f32', Tensor), ('out_bf16', Tensor), ('gamma', c_f32)]
+                ('out_f32', Tensor), ('out_bf16', Tensor), ('gamma', c_f32), ('xcd_remap', c_i32)]
 
 
 class WgradPart(C.Structure):

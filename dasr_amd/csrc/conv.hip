@@ -63,6 +63,12 @@ __global__ __launch_bounds__(256, (MT == 1 && PREC == 1 && !IN_F32) ? 3 : 2) voi
     const int MG = (cout_tiles + MT - 1) / MT;
     const int tiles_x = (p.Wout + C::TW - 1) / C::TW, tiles_y = (p.Hout + C::TH - 1) / C::TH;
     int bid = blockIdx.x;
+    {   // XCD-aware remap: workgroup b runs on XCD b % 8 (private L2).  Give each XCD a contiguous range of tiles so
+        // that neighbouring tiles (which share halo rows/columns) hit the same L2.  Bijective when the grid is a
+        // multiple of 8; otherwise keep the natural order.
+        const int total = gridDim.x;
+        if (p.xcd_remap && (total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);
+    }
     const int mg = bid % MG;
     bid /= MG;
     const int tx = bid % tiles_x;
@@ -377,7 +383,7 @@ __global__ void conv_naive_kernel(const dasr_conv_params p, const float* w) {
 }
 
 // kernel-variant selection (A/B-able from the host: dasr_set_tuning)
-int g_tune_rdb32 = 0, g_tune_rdb64 = 0, g_tune_stream = 0;
+int g_tune_rdb32 = 0, g_tune_rdb64 = 0, g_tune_stream = 0, g_tune_xcd = 1;
 
 }  // namespace
 
@@ -386,12 +392,14 @@ extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
         case 1: g_tune_rdb32 = value; return 0;   // Cout=32 dense conv: 0 single-buffer CK16, 1 double-buffer CK16, 2 single CK32, 3 double CK32
         case 2: g_tune_rdb64 = value; return 0;   // Cout=64 dense conv: 0 single CK16, 1 double CK16, 2 single CK32
         case 3: g_tune_stream = value; return 0;  // split-bf16 stream conv: 0 single, 1 double
+        case 4: g_tune_xcd = value; return 0;     // XCD-aware tile order on/off
         default: return DASR_EINVAL;
     }
 }
 
 extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
-    const dasr_conv_params& p = *pp;
+    dasr_conv_params p = *pp;
+    p.xcd_remap = g_tune_xcd;
     hipStream_t s = as_stream(stream);
     if (p.cin <= 0 || (p.cin & 15) || p.cout <= 0 || !p.w || !p.in.p) return DASR_EINVAL;
     if (!(p.mt == 1 || p.mt == 2) || !(p.prec == 1 || p.prec == 3)) return DASR_EINVAL;
@@ -407,6 +415,9 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                 case 1: return launch<1, false, 1, 3, 1, 4, 1, true>(p, s);
                 case 2: if (p.cin % 32 == 0) return launch<1, false, 1, 3, 1, 4, 2, false>(p, s); break;
                 case 3: if (p.cin % 32 == 0) return launch<1, false, 1, 3, 1, 4, 2, true>(p, s); break;
+                case 4: return launch<1, false, 1, 3, 1, 2>(p, s);          // 8x32 tiles: 2x the workgroups
+                case 5: return launch<1, false, 1, 3, 1, 2, 1, true>(p, s);
+                case 6: return launch<1, false, 1, 3, 1, 1>(p, s);          // 4x32 tiles
                 default: break;
             }
             return launch<1, false, 1, 3, 1, 4>(p, s);
@@ -414,6 +425,8 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
             switch (g_tune_rdb64) {
                 case 1: return launch<1, false, 2, 3, 1, 4, 1, true>(p, s);
                 case 2: if (p.cin % 32 == 0) return launch<1, false, 2, 3, 1, 4, 2, false>(p, s); break;
+                case 4: return launch<1, false, 2, 3, 1, 2>(p, s);
+                case 5: return launch<1, false, 2, 3, 1, 2, 1, true>(p, s);
                 default: break;
             }
             return launch<1, false, 2, 3, 1, 4>(p, s);
@@ -423,6 +436,7 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
         // prec 3, f32 input (residual-stream convs of the generator, discriminator)
         case 1110:
             if (g_tune_stream == 1) return launch<3, true, 1, 3, 1, 4, 1, true>(p, s);
+            if (g_tune_stream == 4) return launch<3, true, 1, 3, 1, 2>(p, s);
             return launch<3, true, 1, 3, 1, 4>(p, s);
         case 1111: return launch<3, true, 1, 4, 1, 2>(p, s);
         case 1112: return launch<3, true, 1, 4, 2, 1>(p, s);

@@ -53,6 +53,7 @@ typedef struct {
     dasr_tensor mask;  int32_t mask_f32;
     float alpha;  dasr_tensor res1;  float beta1;  dasr_tensor res2;  float beta2;
     dasr_tensor out_f32;  dasr_tensor out_bf16;  float gamma;
+    int32_t xcd_remap;                      /* set by the library (XCD-aware tile order); callers leave it 0 */
 } dasr_conv_params;
 
 int dasr_conv(const dasr_conv_params* p, void* stream);
