@@ -21,7 +21,8 @@ class ConvParams(C.Structure):
                 ('act', c_i32), ('slope', c_f32),
                 ('mask', Tensor), ('mask_f32', c_i32),
                 ('alpha', c_f32), ('res1', Tensor), ('beta1', c_f32), ('res2', Tensor), ('beta2', c_f32),
-                ('out_f32', Tensor), ('out_bf16', Tensor), ('gamma', c_f32), ('xcd_remap', c_i32)]
+                ('out_f32', Tensor), ('out_bf16', Tensor), ('gamma', c_f32), ('xcd_remap', c_i32),
+                ('pad_x', c_i32), ('out_stride', c_i32), ('out_oy', c_i32), ('out_ox', c_i32), ('out_W', c_i32)]
 
 
 class WgradPart(C.Structure):
@@ -45,7 +46,7 @@ class PackSeg(C.Structure):
 
 class PackDesc(C.Structure):
     _fields_ = [('dst_off', c_i64), ('lo_off', c_i64), ('cout', c_i32), ('cin_pad', c_i32), ('ntaps', c_i32), ('mt', c_i32),
-                ('nseg', c_i32), ('seg', PackSeg * 5)]
+                ('nseg', c_i32), ('src_ntaps', c_i32), ('tapmap', C.c_int8 * 16), ('seg', PackSeg * 5)]
 
 
 class Op(C.Structure):
@@ -54,7 +55,8 @@ class Op(C.Structure):
 
 
 OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_DOWNSUM, OP_AXPBY, OP_FILL, OP_L1LOSS, OP_NCHW2B, OP_B2NCHW = range(1, 11)
-OP_BCE, OP_INORM_FWD, OP_INORM_BWD, OP_DWT_FWD, OP_DWT_BWD, OP_GAUSS, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_L1DIFF, OP_VGGNORM = range(11, 21)
+(OP_INORM_FWD, OP_INORM_BWD, OP_BCE, OP_DWT_FWD, OP_DWT_BWD, OP_LOWPASS, OP_MAXPOOL, OP_MAXPOOL_BWD, OP_L1DIFF, OP_AFFINE4,
+ OP_BILINEAR) = range(11, 22)
 
 _SIGS = {
     'dasr_conv': [C.POINTER(ConvParams), c_vp],
@@ -71,6 +73,17 @@ _SIGS = {
     'dasr_axpby': [Tensor, c_f32, Tensor, c_f32, c_i32, c_i32, c_i32, c_i32, Tensor, Tensor, c_f32, c_vp],
     'dasr_adam': [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp],
     'dasr_fill_f32': [c_vp, c_i64, c_f32, c_vp],
+    'dasr_inorm_lrelu_fwd': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, Tensor, c_vp, c_vp],
+    'dasr_inorm_lrelu_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, Tensor, c_vp],
+    'dasr_bce_logits': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp, c_f32, Tensor, c_vp],
+    'dasr_dwt_fwd': [Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, Tensor, c_vp],
+    'dasr_dwt_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_vp],
+    'dasr_lowpass': [Tensor, Tensor, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, Tensor, Tensor, c_i32, c_vp],
+    'dasr_maxpool2': [Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, c_vp],
+    'dasr_maxpool2_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_vp],
+    'dasr_l1_diff': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, Tensor, c_vp],
+    'dasr_affine4': [Tensor, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, Tensor, c_i32, c_i32, c_vp],
+    'dasr_bilinear_up': [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
     'dasr_run_ops': [c_vp, c_i32, c_vp],
     'dasr_last_failed_op': [],
     'dasr_abi_version': [],

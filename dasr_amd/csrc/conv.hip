@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, (MT == 1 && PREC == 1 && !IN_F32) ? 3 : 2) voi
     const int ty = bid % tiles_y;
     const int n = bid / tiles_y;
     const int oy0 = ty * C::TH, ox0 = tx * C::TW;
-    const int iy0 = oy0 * STRIDE - p.pad, ix0 = ox0 * STRIDE - p.pad;
+    const int iy0 = oy0 * STRIDE - p.pad, ix0 = ox0 * STRIDE - (p.pad_x >= 0 ? p.pad_x : p.pad);
     const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
     const int nchunks = p.cin / (16 * KS);
     constexpr int ESZ = IN_F32 ? 4 : 2;
@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256, (MT == 1 && PREC == 1 && !IN_F32) ? 3 : 2) voi
     // dropped) and neutral coefficients make the arithmetic a no-op, so there is not a single branch: all loads of a
     // (tile, m-tile) group are in flight together.  The mask tensor has the input's dtype (bf16 slabs / f32 stream).
     const int cout_pad = (p.cout + 15) & ~15;
+    const int ostr = p.out_stride > 1 ? p.out_stride : 1, owid = p.out_W > 0 ? p.out_W : p.Wout;  // strided sub-grid output (stride-2 dgrad)
     constexpr int MSZ = IN_F32 ? 4 : 2;
     const bool has_mask = p.mask.p != nullptr, has_r1 = p.res1.p != nullptr, has_r2 = p.res2.p != nullptr;
     const bool has_f32 = p.out_f32.p != nullptr, has_bf16 = p.out_bf16.p != nullptr;
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256, (MT == 1 && PREC == 1 && !IN_F32) ? 3 : 2) voi
         }
         const int oy = oy0 + r, ox = ox0 + c;
         const bool pv = oy < p.Hout && ox < p.Wout;
-        const unsigned pixel = (unsigned)(oy * p.Wout + ox) * 16u;
+        const unsigned pixel = (unsigned)((oy * ostr + p.out_oy) * owid + ox * ostr + p.out_ox) * 16u;
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
             u32x4 mk[4], r1v[4], r2v[4];
@@ -359,7 +360,7 @@ __global__ void conv_naive_kernel(const dasr_conv_params p, const float* w) {
     for (int c = 0; c < p.cin; ++c)
         for (int ky = 0; ky < p.kh; ++ky)
             for (int kx = 0; kx < p.kh; ++kx) {
-                const int gy = oy * p.stride - p.pad + ky, gx = ox * p.stride - p.pad + kx;
+                const int gy = oy * p.stride - p.pad + ky, gx = ox * p.stride - (p.pad_x >= 0 ? p.pad_x : p.pad) + kx;
                 if (gy < 0 || gy >= HL || gx < 0 || gx >= WL) continue;
                 const int sy = p.ups ? gy >> 1 : gy, sx = p.ups ? gx >> 1 : gx;
                 const size_t o = (size_t)n * p.in.n_stride + (size_t)(c >> 4) * p.in.cb_stride + ((size_t)sy * p.Win + sx) * 16 + (c & 15);
@@ -400,13 +401,15 @@ extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
 extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
     dasr_conv_params p = *pp;
     p.xcd_remap = g_tune_xcd;
+    if (p.pad_x == 0 && p.out_stride == 0 && p.kh != 2) p.pad_x = -1;  // zero-initialised extension fields = "same as pad"
     hipStream_t s = as_stream(stream);
     if (p.cin <= 0 || (p.cin & 15) || p.cout <= 0 || !p.w || !p.in.p) return DASR_EINVAL;
     if (!(p.mt == 1 || p.mt == 2) || !(p.prec == 1 || p.prec == 3)) return DASR_EINVAL;
-    const int key = (p.prec == 3 ? 1000 : 0) + (p.in_f32 ? 100 : 0) + p.mt * 10 + (p.kh == 4 ? (p.stride == 2 ? 2 : 1) : 0);
+    const int key = (p.prec == 3 ? 1000 : 0) + (p.in_f32 ? 100 : 0) + p.mt * 10 + (p.kh == 4 ? (p.stride == 2 ? 2 : 1) : (p.kh == 2 ? 3 : 0));
     if (p.kh == 3 && (p.stride != 1 || p.pad != 1)) return DASR_EINVAL;
-    if (p.kh == 4 && (p.pad != 1 || (p.stride != 1 && p.stride != 2))) return DASR_EINVAL;
-    if (p.kh != 3 && p.kh != 4) return DASR_EINVAL;
+    if (p.kh == 4 && ((p.stride != 1 && p.stride != 2) || p.pad < 0 || p.pad > 3)) return DASR_EINVAL;
+    if (p.kh == 2 && (p.stride != 1 || p.pad < 0 || p.pad > 1)) return DASR_EINVAL;
+    if (p.kh != 3 && p.kh != 4 && p.kh != 2) return DASR_EINVAL;
     if (p.mask.p && (p.mask_f32 != 0) != (p.in_f32 != 0)) return DASR_EINVAL;  // mask dtype is tied to the input dtype
     switch (key) {
         // prec 1, bf16 input (RDB dense-block convs, fwd and dgrad)
@@ -440,6 +443,7 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
             return launch<3, true, 1, 3, 1, 4>(p, s);
         case 1111: return launch<3, true, 1, 4, 1, 2>(p, s);
         case 1112: return launch<3, true, 1, 4, 2, 1>(p, s);
+        case 1113: return launch<3, true, 1, 2, 1, 4>(p, s);  // 2x2 parity sub-convs of the stride-2 data-gradient
         default: return DASR_EINVAL;
     }
 }

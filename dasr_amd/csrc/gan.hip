@@ -337,7 +337,7 @@ __global__ void maxpool_fwd_kernel(dasr_tensor x, int N, int C, int Ho, int Wo, 
 }
 
 template <typename T>
-__global__ void maxpool_bwd_kernel(dasr_tensor x, dasr_tensor gy, int N, int C, int Ho, int Wo, dasr_tensor gx) {
+__global__ void maxpool_bwd_kernel(dasr_tensor x, dasr_tensor gy, int N, int C, int Ho, int Wo, dasr_tensor gx, int relu_mask) {
     const int ncb = (C + 15) >> 4;
     const long long total = (long long)N * ncb * Ho * Wo * 4;
     const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -369,7 +369,7 @@ __global__ void maxpool_bwd_kernel(dasr_tensor x, dasr_tensor gy, int N, int C, 
     for (int d = 0; d < 4; ++d) {
         T* o = op + ((size_t)(2 * yy + (d >> 1)) * W + 2 * xx + (d & 1)) * 16;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = am[j] == d ? gp[j] : (T)0.f;
+        for (int j = 0; j < 4; ++j) o[j] = (am[j] == d && !(relu_mask && m[j] <= 0.f)) ? gp[j] : (T)0.f;
     }
 }
 
@@ -510,11 +510,11 @@ extern "C" int dasr_maxpool2(dasr_tensor x, int32_t is_f32, int32_t N, int32_t C
 }
 
 extern "C" int dasr_maxpool2_bwd(dasr_tensor x, dasr_tensor gy, int32_t is_f32, int32_t N, int32_t C, int32_t Ho, int32_t Wo, dasr_tensor gx,
-                                 void* stream) {
+                                 int32_t relu_mask, void* stream) {
     const long long total = (long long)N * ((C + 15) / 16) * Ho * Wo * 4;
     if (total <= 0) return DASR_EINVAL;
-    if (is_f32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx);
-    else hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx);
+    if (is_f32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
+    else hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
     return (int)hipGetLastError();
 }
 

@@ -38,10 +38,12 @@ __global__ void pack_kernel(const dasr_pack_desc* __restrict__ descs, int ndesc,
                 const dasr_pack_seg& S = D.seg[s];
                 const int ci = cin - S.cin_start;
                 if (ci >= 0 && ci < S.cin_len) {
-                    if (!S.transpose) {
-                        v = params[S.src_off + ((long long)oc * S.src_cin + S.src_c0 + ci) * D.ntaps + tap];
+                    const int st = D.tapmap[tap];
+                    if (st < 0) {
+                    } else if (!S.transpose) {
+                        v = params[S.src_off + ((long long)oc * S.src_cin + S.src_c0 + ci) * D.src_ntaps + st];
                     } else if (ci < S.src_cout) {
-                        v = params[S.src_off + ((long long)ci * S.src_cin + S.src_c0 + oc) * D.ntaps + (D.ntaps - 1 - tap)];
+                        v = params[S.src_off + ((long long)ci * S.src_cin + S.src_c0 + oc) * D.src_ntaps + st];
                     }
                 }
             }
@@ -328,6 +330,23 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream) {
                 break;
             case DASR_OP_NCHW2B: rc = dasr_nchw_to_blocked((const float*)o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[0], o.t[1], stream); break;
             case DASR_OP_B2NCHW: rc = dasr_blocked_to_nchw(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], (float*)o.p[0], stream); break;
+            case DASR_OP_INORM_FWD: rc = dasr_inorm_lrelu_fwd(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.f[1], o.t[1], (float*)o.p[0], stream); break;
+            case DASR_OP_INORM_BWD: rc = dasr_inorm_lrelu_bwd(o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], (const float*)o.p[0], o.t[2], stream); break;
+            case DASR_OP_BCE:
+                rc = dasr_bce_logits(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.f[1], o.f[2], (float*)o.p[0], (float*)o.p[1], o.f[3], o.t[1], stream);
+                break;
+            case DASR_OP_DWT_FWD: rc = dasr_dwt_fwd(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[1], o.t[2], stream); break;
+            case DASR_OP_DWT_BWD: rc = dasr_dwt_bwd(o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[2], o.i[5], stream); break;
+            case DASR_OP_LOWPASS:
+                rc = dasr_lowpass(o.t[0], o.t[1], (const float*)o.p[0], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], o.i[5], o.f[0], o.f[1], o.t[2], o.t[3], o.i[6], stream);
+                break;
+            case DASR_OP_MAXPOOL: rc = dasr_maxpool2(o.t[0], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1], stream); break;
+            case DASR_OP_MAXPOOL_BWD: rc = dasr_maxpool2_bwd(o.t[0], o.t[1], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], o.t[2], o.i[5], stream); break;
+            case DASR_OP_L1DIFF:
+                rc = dasr_l1_diff(o.t[0], o.t[1], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.f[1], (float*)o.p[0], o.t[2], stream);
+                break;
+            case DASR_OP_AFFINE4: rc = dasr_affine4(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], &o.f[0], (const float*)o.l, o.t[1], o.i[4], o.i[5], stream); break;
+            case DASR_OP_BILINEAR: rc = dasr_bilinear_up((const float*)o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], (float*)o.p[1], stream); break;
             default: rc = DASR_EINVAL;
         }
         if (rc != 0) {

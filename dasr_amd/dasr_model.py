@@ -1,0 +1,403 @@
+"""DASR_Model: the SRN GAN training step (reference: codes/SRN/models/DASR_model.py:24-460) on the MI355X kernels.
+
+Step (DASR_model.py:192-330), n = dataloader batch per rank, the generator sees 2n crops (first n = fake-LR "source"
+samples with HR pairs and a domain-distance map, last n = real-LR "target" samples):
+    fake_H = G([LR_fake; LR_real]);  (LL, Hf) = fs(fake_H), fs([HR; HR_unpair])
+    L_G = w_pix * [w_pix * mean(W |fake_s - HR_s|)] + w_LL * L1(LL_s) + w_fea * L1(F(fake_s), F(HR_s)) + w_gan * BCE(D(Hf_t(fake)), 1)
+    L_D = 0.5 * [BCE(D(Hf_t(real)), 1) + BCE(D(Hf_t(fake)), 0)]
+Reference quirks kept on purpose: double pixel weight with `multiweights`, gc ignored, scheduler
+stepped before the optimizer, FilterHigh normalised twice under `norm`.  D(Hf_t(fake)) is evaluated once and shared by
+the G and the D loss (same weights, same input in the reference too); the reference's discarded D weight-gradients of
+the G step are not computed.
+"""
+import ctypes as C
+import logging
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+from .engine import BTensor, Op, OpList, NULL_T, Tensor, _stream
+from .gan_nets import NLayerDiscriminatorHIP, VGGFeatureHIP, VGG_MEAN, VGG_STD, nlayer_d_spec
+from .init import kaiming_state_dict
+from .models import BaseModel, AdamHIP, MultiStepLR, _define_G
+
+logger = logging.getLogger('base')
+
+A_PIX, A_LL, A_FEA, A_GAN, A_DREAL, A_DFAKE, A_SREAL, A_SFAKE = range(8)
+
+
+def _op(kind):
+    o = Op()
+    o.op = kind
+    return o
+
+
+def _nview(bt, n0):
+    """view of images [n0:] of a blocked tensor"""
+    v = bt.view()
+    return Tensor(v.p + n0 * v.n_stride * bt.esz, v.n_stride, v.cb_stride)
+
+
+def gaussian_kernel2d(k):
+    """GaussianFilter weights (architecture.py:1177-1199)"""
+    mean, var = (k - 1) / 2.0, (k / 6.0) ** 2.0
+    ax = torch.arange(k, dtype=torch.float32)
+    xx = ax.repeat(k).view(k, k)
+    g = torch.exp(-((xx - mean) ** 2 + (xx.t() - mean) ** 2) / (2 * var))
+    return g / g.sum()
+
+
+def vgg_random_state_dict(spec, seed):
+    """torchvision's VGG init rule (kaiming_normal fan_out / relu, zero bias) from one seeded generator; used when no
+    pretrained VGG19 file is supplied (`path.pretrain_model_F`): the weights cannot be downloaded offline."""
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+    for k, shape in spec:
+        if k.endswith('weight'):
+            sd[k] = torch.randn(shape, generator=g) * math.sqrt(2.0 / (shape[0] * 9))
+        else:
+            sd[k] = torch.zeros(shape)
+    return sd
+
+
+class DASR_Model(BaseModel):
+    def __init__(self, opt):
+        super().__init__(opt)
+        t = opt['train']
+        self.scale = opt['scale']
+        self.multiweights = opt['multiweights']
+        if opt['adaptive_weights']:
+            raise NotImplementedError('adaptive_weights (DASR_Adaptive_Model) is outside the hot path')
+        if t['gan_type'] != 'vanilla':
+            raise NotImplementedError('GAN type [{:s}] is not found'.format(str(t['gan_type'])))
+        if t['ragan']:
+            raise NotImplementedError('ragan=True couples samples across the batch; not on the data-parallel hot path')
+        self.l_gan_H_target_w = t['gan_H_target'] or 0
+        if (t['gan_H_source'] or 0) > 0:
+            raise NotImplementedError('gan_H_source > 0 (BatchNorm source discriminator) is a "next" row (SURVEY 8(f4))')
+        self.netG = _define_G(opt, self.device)
+        self.netD_target = None
+        if self.is_train and self.l_gan_H_target_w > 0:
+            d = opt['network_D']
+            if d['which_model_D'] != 'discriminator_patch':
+                raise NotImplementedError('Discriminator model [{:s}] not recognized'.format(str(d['which_model_D'])))
+            self.netD_target = NLayerDiscriminatorHIP(d['in_nc'], 64, d['n_layers'], device=self.device)  # networks.py:184-185
+            spec, _ = nlayer_d_spec(d['in_nc'], 64, d['n_layers'])
+            self.netD_target.load_state_dict(kaiming_state_dict(spec, 1))  # init_weights(kaiming, scale=1), networks.py:191
+        self.load()
+        self.norm = bool(t['norm'])
+        self.fs = t['fs']
+        if self.fs == 'wavelet':
+            pass
+        elif self.fs in ('gau', 'avgpool'):
+            k = t['fs_kernel_size']
+            w = gaussian_kernel2d(k) if self.fs == 'gau' else torch.full((k, k), 1.0 / (k * k))  # count_include_pad=True
+            self.fs_k, self.fs_w = k, w.contiguous().to(self.device)
+        else:
+            raise NotImplementedError('FS type [{:s}] not recognized.'.format(str(self.fs)))
+        if self.is_train:
+            self.l_pix_w = t['pixel_weight'] or 0
+            if self.l_pix_w > 0 and t['pixel_criterion'] != 'l1':
+                raise NotImplementedError('Loss type [{:s}] not recognized.'.format(str(t['pixel_criterion'])))
+            self.l_pix_LL_w = t['pixel_LL_weight'] or 0
+            self.sup_LL = bool(t['sup_LL']) and self.l_pix_w > 0
+            self.l_fea_w = t['feature_weight'] or 0
+            self.netF = None
+            if self.l_fea_w > 0:
+                if t['feature_criterion'] != 'l1':
+                    raise NotImplementedError('Loss type [{:s}] not recognized (LPIPS needs pretrained AlexNet).'.format(str(t['feature_criterion'])))
+                self.netF = VGGFeatureHIP(34, device=self.device)
+                pf = opt['path']['pretrain_model_F']
+                if pf:
+                    self.netF.load_state_dict(torch.load(pf, map_location='cpu'), strict=False)
+                else:
+                    logger.warning('no path.pretrain_model_F: VGG19-54 uses seeded random weights (torchvision init rule)')
+                    self.netF.load_state_dict(vgg_random_state_dict(self.netF.spec, int(t['vgg_seed'] or 77)))
+            self.G_update_inter = t['G_update_inter'] or 1
+            self.D_update_inter = t['D_update_inter'] or 1
+            wd_G = t['weight_decay_G'] or 0
+            self.optimizer_G = AdamHIP(self.netG.params, t['lr_G'], (t['beta1_G'], 0.999), wd_G)
+            self.optimizers.append(self.optimizer_G)
+            if self.netD_target is not None:
+                wd_D = t['weight_decay_D'] or 0
+                self.optimizer_D_target = AdamHIP(self.netD_target.params, t['lr_D'], (t['beta1_D'], 0.999), wd_D)
+                self.optimizers.append(self.optimizer_D_target)
+            if t['lr_scheme'] != 'MultiStepLR':
+                raise NotImplementedError('MultiStepLR learning rate scheme is enough.')
+            for o in self.optimizers:
+                self.schedulers.append(MultiStepLR(o.lr, t['lr_steps'], t['lr_gamma']))
+            self.log_dict = OrderedDict()
+            self.acc = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self._plans = {}
+
+    def networks(self):
+        return [self.netG] + ([self.netD_target] if self.netD_target is not None else [])
+
+    # ---- data (DASR_model.py:161-187) --------------------------------------------------------------------------
+    def feed_data(self, data, istrain=True):
+        dev = self.device
+        if istrain and 'HR' in data:
+            self.var_L = torch.cat([data['LR_fake'], data['LR_real']], 0).to(dev, non_blocking=True)
+            self.var_H = torch.cat([data['HR'], data['HR_unpair']], 0).to(dev, non_blocking=True).contiguous()
+            self.fake_w = data['fake_w'].to(dev, non_blocking=True).contiguous()
+        else:
+            self.var_L = data['LR'].to(dev)
+            self.needHR = 'HR' in data
+            if self.needHR:
+                self.var_H = data['HR'].to(dev)
+
+    # ---- plan ----------------------------------------------------------------------------------------------------
+    def _plan(self, n, h, w):
+        k = (n, h, w)
+        if k not in self._plans:
+            self._plans[k] = _StepPlan(self, n, h, w)
+        return self._plans[k]
+
+    def optimize_parameters(self, step):
+        N2, _, h, w = self.var_L.shape
+        n = N2 // 2
+        P = self._plan(n, h, w)
+        do_g = step % self.G_update_inter == 0
+        do_d = step % self.D_update_inter == 0 and self.netD_target is not None
+        P.hr_nchw.copy_(self.var_H)
+        P.fake_w.copy_(self.fake_w)
+        P.g.set_input(self.var_L)
+        P.fwd.run()                       # G forward, frequency separation, D forward, VGG forward, all losses + loss gradients
+        scale = 1.0
+        if self.dp is not None and self.dp.world > 1:
+            scale = self.dp.grad_scale
+            P.g.set_grad_scale(scale)
+            P.set_d_grad_scale(scale)
+        if do_g:
+            P.g_loss_bwd.run()            # D / VGG / fs data-gradients into dL/dSR
+            gG = self.netG.params.grad
+            if scale == 1.0:
+                P.g.bwd.run()
+            else:
+                for seg, (lo, hi) in P.g.bwd_segments():
+                    seg.run()
+                    self.dp.reduce_async(gG[lo:hi])
+                self.dp.wait()
+            self.optimizer_G.step(self.schedulers[0].get_lr())
+            self.netG.repack()
+        if do_d:
+            P.d_step.run()                # BCE(real,1), BCE(fake,0), D backward with weight gradients
+            if scale != 1.0:
+                self.dp.allreduce_mean(self.netD_target.params.grad)
+            self.optimizer_D_target.step(self.schedulers[1].get_lr())
+            self.netD_target.repack()
+        self.fake_H = P.g.read_output()
+        self._acc_snapshot = (self.acc, do_g, do_d)
+        self._pix_div = getattr(P, 'pix_log_div', 1.0)
+
+    def get_current_log(self):
+        """one device->host sync, only when the caller logs (the reference syncs 5-9 times every step, App. C-8)"""
+        if getattr(self, '_acc_snapshot', None) is not None:
+            acc, do_g, do_d = self._acc_snapshot
+            a = acc.tolist()
+            if do_g:
+                if self.l_pix_w > 0:
+                    self.log_dict['loss/l_g_pix'] = a[A_PIX] / self._pix_div
+                    if self.sup_LL:
+                        self.log_dict['loss/l_g_LL_pix'] = a[A_LL]
+                if self.netF is not None:
+                    self.log_dict['loss/l_g_fea'] = a[A_FEA]
+                if self.netD_target is not None:
+                    self.log_dict['loss/l_g_gan_target_Hf'] = a[A_GAN]
+            if do_d:
+                self.log_dict['loss/l_d_target_total'] = a[A_DREAL] + a[A_DFAKE]
+                self.log_dict['disc_Score/D_real_target_H'] = a[A_SREAL]
+                self.log_dict['disc_Score/D_fake_target_H'] = a[A_SFAKE]
+            self._acc_snapshot = None
+        return self.log_dict
+
+    def test(self, tsamples=False):
+        self.fake_H = self.netG.forward(self.var_L).clone()
+
+    def get_current_visuals(self, need_HR=True, tsamples=False):
+        out = OrderedDict()
+        out['LR'] = self.var_L.detach()[0].float().cpu()
+        out['SR'] = self.fake_H.detach().float().cpu() if tsamples else self.fake_H.detach()[0].float().cpu()
+        if need_HR and getattr(self, 'var_H', None) is not None:
+            out['HR'] = self.var_H.detach()[0].float().cpu()
+        return out
+
+    def load(self):
+        pg = self.opt['path']['pretrain_model_G']
+        if pg is not None:
+            logger.info('Loading pretrained model for G [{:s}] ...'.format(pg))
+            self.load_network(pg, self.netG)
+        pd = self.opt['path']['pretrain_model_D_target']
+        if self.opt['is_train'] and pd is not None and self.netD_target is not None:
+            logger.info('Loading pretrained model for D_target [{:s}] ...'.format(pd))
+            self.load_network(pd, self.netD_target)
+
+    def save(self, iter_step):
+        self.save_network(self.netG, 'G', iter_step)
+        if self.netD_target is not None:
+            self.save_network(self.netD_target, 'D_target', iter_step)
+
+
+class _StepPlan:
+    """All buffers and op lists of one DASR step for (n, h, w)."""
+
+    def __init__(self, m, n, h, w):
+        self.m = m
+        dev = m.device
+        N2, H, W = 2 * n, 4 * h, 4 * w
+        self.g = m.netG.plan(N2, h, w)
+        g = self.g
+        self.hr_nchw = torch.zeros((N2, 3, H, W), dtype=torch.float32, device=dev)
+        self.hr_b = BTensor(N2, 16, H, W, True, dev)
+        self.fake_w = torch.zeros((n, 1, h, w), dtype=torch.float32, device=dev)
+        self.wmap = torch.zeros((n, 1, H, W), dtype=torch.float32, device=dev)
+        acc = m.acc.data_ptr()
+        wavelet = m.fs == 'wavelet'
+        Hd, Wd = (H // 2, W // 2) if wavelet else (H, W)
+        fwd, gl = OpList(), OpList()
+
+        def add(ol, o):
+            ol.add(o)
+            return o
+
+        # ---- forward -------------------------------------------------------------------------------------------
+        fwd.extend(g.fwd)
+        o = add(fwd, _op(_lib.OP_FILL))
+        o.p[0], o.l[0], o.f[0] = acc, 8, 0.0
+        o = add(fwd, _op(_lib.OP_NCHW2B))
+        o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[0], o.t[1] = self.hr_nchw.data_ptr(), N2, 3, H, W, self.hr_b.view(), NULL_T
+        o = add(fwd, _op(_lib.OP_BILINEAR))  # ddm -> HR size (DASR_model.py:173-174)
+        o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.p[1] = self.fake_w.data_ptr(), n, h, w, 4, self.wmap.data_ptr()
+        o = add(fwd, _op(_lib.OP_FILL))      # dL/dSR accumulates contributions of every loss term
+        o.p[0], o.l[0], o.f[0] = g.g_sr.t.data_ptr(), g.g_sr.t.numel(), 0.0
+        # pixel loss on the source half
+        if m.l_pix_w > 0:
+            o = add(fwd, _op(_lib.OP_L1LOSS))
+            cnt = float(n * 3 * H * W)
+            o.t[0], o.p[0] = g.sr.view(), self.hr_nchw.data_ptr()
+            o.p[1] = self.wmap.data_ptr() if m.multiweights else None
+            o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = n, 3, H, W, 1
+            # multiweights: l_g_pix = w * mean(W|d|) and total += w * l_g_pix  (DASR_model.py:213-218)
+            self.pix_log_div = 1.0
+            if m.multiweights:
+                o.f[0] = float(m.l_pix_w) * float(m.l_pix_w) / cnt
+                self.pix_log_div = float(m.l_pix_w)
+            else:
+                o.f[0] = float(m.l_pix_w) / cnt
+                self.pix_log_div = float(m.l_pix_w)
+            o.p[2], o.t[1] = acc + 4 * A_PIX, g.g_sr.view()
+        # frequency separation
+        D = m.netD_target
+        self.d = D.plan(N2, Hd, Wd) if D is not None else None
+        d = self.d
+        self.fake_low = BTensor(n, 16, Hd, Wd, True, dev)
+        self.real_low = BTensor(n, 16, Hd, Wd, True, dev)
+        self.g_low = BTensor(n, 16, Hd, Wd, True, dev)
+        dx_fake = d.x.view() if d is not None else NULL_T
+        dx_real = _nview(d.x, n) if d is not None else NULL_T
+        if wavelet:
+            for src, n0, ll, hc in ((g.sr, 0, self.fake_low.view(), NULL_T), (g.sr, n, NULL_T, dx_fake),
+                                    (self.hr_b, 0, self.real_low.view(), NULL_T), (self.hr_b, n, NULL_T, dx_real)):
+                if ll.p is None and hc.p is None:
+                    continue
+                o = add(fwd, _op(_lib.OP_DWT_FWD))
+                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[1], o.t[2] = _nview(src, n0), n, 3, Hd, Wd, int(m.norm), ll, hc
+        else:
+            a_h, b_h = (0.25, 0.75) if m.norm else (0.5, 0.5)  # FilterHigh normalises, filter_func normalises again (App. C-11)
+            self.ab = (a_h, b_h)
+            for src, n0, lo, hi in ((g.sr, 0, self.fake_low.view(), NULL_T), (g.sr, n, NULL_T, dx_fake),
+                                    (self.hr_b, 0, self.real_low.view(), NULL_T), (self.hr_b, n, NULL_T, dx_real)):
+                if lo.p is None and hi.p is None:
+                    continue
+                o = add(fwd, _op(_lib.OP_LOWPASS))
+                o.t[0], o.t[1], o.p[0], o.i[4] = _nview(src, n0), NULL_T, m.fs_w.data_ptr(), m.fs_k
+                o.i[0], o.i[1], o.i[2], o.i[3], o.i[5], o.i[6] = n, 3, H, W, 0, 0
+                o.f[0], o.f[1], o.t[2], o.t[3] = a_h, b_h, lo, hi
+        # LL loss (source half)
+        if m.sup_LL:
+            o = add(fwd, _op(_lib.OP_L1DIFF))
+            cnt = float(n * 3 * Hd * Wd)
+            o.t[0], o.t[1], o.i[4] = self.fake_low.view(), self.real_low.view(), 1
+            o.i[0], o.i[1], o.i[2], o.i[3] = n, 3, Hd, Wd
+            o.f[0], o.f[1], o.p[0], o.t[2] = 1.0 / cnt, float(m.l_pix_LL_w) / cnt, acc + 4 * A_LL, self.g_low.view()
+        # VGG feature loss (source half): batch [fake_s; real_s]
+        self.v = None
+        if m.netF is not None:
+            self.v = m.netF.plan(N2, n, H, W)
+            v = self.v
+            sc = [1.0 / s for s in VGG_STD] + [0.0]
+            sh = [-mu / s for mu, s in zip(VGG_MEAN, VGG_STD)] + [0.0]
+            for src, dst in ((g.sr.view(), v.x.view()), (self.hr_b.view(), _nview(v.x, n))):
+                o = add(fwd, _op(_lib.OP_AFFINE4))
+                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1], o.i[4], o.i[5] = src, n, 3, H, W, dst, 1, 0
+                for j in range(4):
+                    o.f[j] = sc[j]
+                C.memmove(C.addressof(o.l), (C.c_float * 4)(*sh), 16)
+            fwd.extend(v.fwd)
+            o = add(fwd, _op(_lib.OP_L1DIFF))
+            f = v.feat
+            cnt = float(n * f.C * f.H * f.W)
+            o.t[0], o.t[1], o.i[4] = f.view(), _nview(f, n), 1
+            o.i[0], o.i[1], o.i[2], o.i[3] = n, f.C, f.H, f.W
+            o.f[0], o.f[1], o.p[0], o.t[2] = 1.0 / cnt, float(m.l_fea_w) / cnt, acc + 4 * A_FEA, v.g_feat.view()
+        # discriminator forward on [fake_t; real_t] and the generator's GAN loss
+        if d is not None:
+            fwd.extend(d.fwd)
+            lg = d.logits
+            cnt = float(n * 1 * lg.H * lg.W)
+            o = add(fwd, _op(_lib.OP_BCE))
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = lg.view(), n, 1, lg.H, lg.W
+            o.f[0], o.f[1], o.f[2], o.p[0], o.p[1], o.f[3], o.t[1] = 1.0, 1.0 / cnt, float(m.l_gan_H_target_w) / cnt, acc + 4 * A_GAN, None, 0.0, d.g_logits.view()
+        self.fwd = fwd
+
+        # ---- generator-loss backward: everything that lands in dL/dSR ----------------------------------------------------
+        if self.v is not None:
+            v = self.v
+            gl.extend(v.bwd)
+            o = add(gl, _op(_lib.OP_AFFINE4))  # adjoint of the input normalisation, accumulated into dL/dSR (source half)
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1], o.i[4], o.i[5] = v.gx.view(), n, 3, H, W, g.g_sr.view(), 1, 1
+            for j in range(4):
+                o.f[j] = ([1.0 / s for s in VGG_STD] + [0.0])[j]
+            C.memmove(C.addressof(o.l), (C.c_float * 4)(0.0, 0.0, 0.0, 0.0), 16)
+        if d is not None:
+            gl.extend(d.bwd_data_ops(n))
+        g_hi_t = d.gx.view() if d is not None else NULL_T
+        g_lo_s = self.g_low.view() if m.sup_LL else NULL_T
+        if wavelet:
+            for n0, gll, ghc in ((0, g_lo_s, NULL_T), (n, NULL_T, g_hi_t)):
+                if gll.p is None and ghc.p is None:
+                    continue
+                o = add(gl, _op(_lib.OP_DWT_BWD))
+                o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[2], o.i[5] = gll, ghc, n, 3, Hd, Wd, int(m.norm), _nview(g.g_sr, n0), 1
+        else:
+            for n0, glo, ghi in ((0, g_lo_s, NULL_T), (n, NULL_T, g_hi_t)):
+                if glo.p is None and ghi.p is None:
+                    continue
+                o = add(gl, _op(_lib.OP_LOWPASS))
+                o.t[0], o.t[1], o.p[0], o.i[4] = glo, ghi, m.fs_w.data_ptr(), m.fs_k
+                o.i[0], o.i[1], o.i[2], o.i[3], o.i[5], o.i[6] = n, 3, H, W, 1, 1
+                o.f[0], o.f[1], o.t[2], o.t[3] = self.ab[0], 0.0, _nview(g.g_sr, n0), NULL_T
+        self.g_loss_bwd = gl
+
+        # ---- discriminator step: BCE(real, 1), BCE(fake, 0), backward with weight gradients -----------------------------------
+        ds = OpList()
+        if d is not None:
+            lg = d.logits
+            cnt = float(n * lg.H * lg.W)
+            for n0, target, a_loss, a_score in ((n, 1.0, A_DREAL, A_SREAL), (0, 0.0, A_DFAKE, A_SFAKE)):
+                o = add(ds, _op(_lib.OP_BCE))
+                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = _nview(lg, n0), n, 1, lg.H, lg.W
+                o.f[0], o.f[1], o.f[2] = target, 0.5 / cnt, 0.5 / cnt
+                o.p[0], o.p[1], o.f[3], o.t[1] = acc + 4 * a_loss, acc + 4 * a_score, 1.0 / cnt, _nview(d.g_logits, n0)
+            ds.extend(d.bwd_full)
+        self.d_step = ds
+
+    def set_d_grad_scale(self, scale):
+        if self.d is None:
+            return
+        for o in self.d_step.ops:
+            if o.op == _lib.OP_WGRAD_REDUCE and o.f[0] != scale:
+                o.f[0] = scale
+                self.d_step._arr = None

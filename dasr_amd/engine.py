@@ -112,7 +112,9 @@ class PackRegistry:
         self.size = 0  # bf16 elements
         self.buf = None
 
-    def add(self, cout, cin_pad, ntaps, mt, prec, segs):
+    def add(self, cout, cin_pad, ntaps, mt, prec, segs, tapmap=None, src_ntaps=None):
+        """tapmap: packed tap -> source tap.  Default: identity for forward segments, reversed (tap flip) when the
+        segments are transposed (stride-1 data-gradient)."""
         assert cin_pad % 16 == 0 and len(segs) <= 5
         mg = ceil_div(ceil_div(cout, 32), mt)
         pieces = mg * (cin_pad // 16) * ntaps * mt * 64
@@ -121,6 +123,12 @@ class PackRegistry:
         r.lo_off = pieces * 8 if prec == 3 else 0
         d = PackDesc()
         d.dst_off, d.lo_off, d.cout, d.cin_pad, d.ntaps, d.mt, d.nseg = self.size, r.lo_off, cout, cin_pad, ntaps, mt, len(segs)
+        d.src_ntaps = src_ntaps or ntaps
+        if tapmap is None:
+            tr = bool(segs and segs[0][6])
+            tapmap = [ntaps - 1 - t for t in range(ntaps)] if tr else list(range(ntaps))
+        for t in range(16):
+            d.tapmap[t] = tapmap[t] if t < len(tapmap) else -1
         for i, s in enumerate(segs):
             sg = d.seg[i]
             sg.src_off, sg.src_cout, sg.src_cin, sg.cin_start, sg.cin_len, sg.src_c0, sg.transpose = s
@@ -180,7 +188,8 @@ class OpList:
 
 
 def conv_op(pack, ref, inp, in_f32, cin, Hin, Win, Hout, Wout, N, bias=None, kh=3, stride=1, pad=1, ups=0, act=0, slope=SLOPE,
-            mask=None, mask_f32=0, alpha=1.0, res1=None, beta1=0.0, res2=None, beta2=0.0, out_f32=None, out_bf16=None, gamma=1.0):
+            mask=None, mask_f32=0, alpha=1.0, res1=None, beta1=0.0, res2=None, beta2=0.0, out_f32=None, out_bf16=None, gamma=1.0,
+            pad_x=-1, out_stride=1, out_oy=0, out_ox=0, out_W=0):
     assert cin == ref.cin_pad, (cin, ref.cin_pad)
     o = Op()
     o.op = _lib.OP_CONV
@@ -197,6 +206,7 @@ def conv_op(pack, ref, inp, in_f32, cin, Hin, Win, Hout, Wout, N, bias=None, kh=
     p.out_f32 = out_f32 if out_f32 is not None else NULL_T
     p.out_bf16 = out_bf16 if out_bf16 is not None else NULL_T
     p.gamma = gamma
+    p.pad_x, p.out_stride, p.out_oy, p.out_ox, p.out_W = pad_x, out_stride, out_oy, out_ox, out_W
     return o
 
 

@@ -1,0 +1,311 @@
+"""Patch discriminator and VGG19-54 feature extractor as recorded op lists over the MI355X kernels.
+
+NLayerDiscriminatorHIP : codes/SRN/models/modules/architecture.py:983-1024 (built by networks.py:184-185: ndf stays 64)
+VGGFeatureHIP          : codes/SRN/models/modules/architecture.py:1060-1088 (vgg19.features[:35], input norm, frozen)
+
+Both run in split-bf16 (prec 3, ~fp32) on fp32 activations: together they are <10 % of the step's FLOPs and they sit
+between the losses and the generator gradient, where the 1e-2 gradient tolerance is decided.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .engine import (BTensor, ParamStore, PackRegistry, OpList, WgradGroup, Workspace, conv_op, ceil_div, NULL_T)
+from ._lib import Op, Tensor
+
+SLOPE = 0.2
+IN_EPS = 1e-5
+
+
+def _op(kind):
+    o = Op()
+    o.op = kind
+    return o
+
+
+def nlayer_d_spec(input_nc, ndf=64, n_layers=2):
+    """[(key, shape)] and layer descriptions of the reference nn.Sequential."""
+    spec = [('model.0.weight', (ndf, input_nc, 4, 4)), ('model.0.bias', (ndf,))]
+    layers = [dict(key='model.0.', cin=input_nc, cout=ndf, stride=2, bias=True, norm=False)]
+    mult, idx = 1, 2
+    for n in range(1, n_layers):
+        prev, mult = mult, min(2 ** n, 8)
+        spec.append(('model.%d.weight' % idx, (ndf * mult, ndf * prev, 4, 4)))
+        layers.append(dict(key='model.%d.' % idx, cin=ndf * prev, cout=ndf * mult, stride=2, bias=False, norm=True))
+        idx += 3
+    prev, mult = mult, min(2 ** n_layers, 8)
+    spec.append(('model.%d.weight' % idx, (ndf * mult, ndf * prev, 4, 4)))
+    layers.append(dict(key='model.%d.' % idx, cin=ndf * prev, cout=ndf * mult, stride=1, bias=False, norm=True))
+    idx += 3
+    spec += [('model.%d.weight' % idx, (1, ndf * mult, 4, 4)), ('model.%d.bias' % idx, (1,))]
+    layers.append(dict(key='model.%d.' % idx, cin=ndf * mult, cout=1, stride=1, bias=True, norm=False, last=True))
+    return spec, layers
+
+
+# stride-2 4x4 data-gradient = four 2x2 sub-convolutions, one per parity (py, px) of the input pixel:
+# packed tap a (0/1) along one axis -> source tap k and zero-padding of the sub-conv (see DESIGN.md / conv.hip)
+_PARITY_TAPS = {0: (3, 1), 1: (2, 0)}  # parity -> (k for a=0, k for a=1)
+_PARITY_PAD = {0: 1, 1: 0}
+
+
+class NLayerDiscriminatorHIP:
+    def __init__(self, input_nc, ndf=64, n_layers=2, device='cuda'):
+        self.input_nc, self.device = input_nc, torch.device(device)
+        self.spec, self.layers = nlayer_d_spec(input_nc, ndf, n_layers)
+        self.params = ParamStore(self.spec, self.device)
+        self.pack = PackRegistry(self.params)
+        P = self.params
+        for L in self.layers:
+            cin_pad = ceil_div(L['cin'], 16) * 16
+            w = P.off(L['key'] + 'weight')
+            L['cin_pad'] = cin_pad
+            L['fwd'] = self.pack.add(L['cout'], cin_pad, 16, 1, 3, [(w, L['cout'], L['cin'], 0, L['cin'], 0, 0)])
+            cb = ceil_div(L['cout'], 16) * 16
+            if L['stride'] == 1:
+                L['bwd'] = self.pack.add(L['cin'], cb, 16, 1, 3, [(w, L['cout'], L['cin'], 0, L['cout'], 0, 1)])
+            else:
+                L['bwd'] = {}
+                for py in (0, 1):
+                    for px in (0, 1):
+                        tm = [_PARITY_TAPS[py][a] * 4 + _PARITY_TAPS[px][b] for a in (0, 1) for b in (0, 1)]
+                        L['bwd'][(py, px)] = self.pack.add(L['cin'], cb, 4, 1, 3, [(w, L['cout'], L['cin'], 0, L['cout'], 0, 1)],
+                                                           tapmap=tm, src_ntaps=16)
+        self.pack.finalize()
+        self.plans = {}
+
+    def repack(self):
+        self.pack.run()
+
+    def state_dict(self):
+        return self.params.state_dict()
+
+    def load_state_dict(self, sd, strict=True):
+        self.params.load_state_dict(sd, strict)
+        self.repack()
+
+    def plan(self, N, H, W):
+        k = (N, H, W)
+        if k not in self.plans:
+            self.plans[k] = _DPlan(self, N, H, W)
+        return self.plans[k]
+
+
+class _DPlan:
+    """Forward on N images; data-gradient of the first `n_g` images (generator step, no weight gradients);
+    full backward with weight gradients on all N images (discriminator step)."""
+
+    def __init__(self, net, N, H, W):
+        self.net, self.N = net, N
+        dev, P, pack = net.device, net.params, net.pack
+        self.x = BTensor(N, 16, H, W, True, dev)       # D input (3 or 9 real channels)
+        self.gx = BTensor(N, 16, H, W, True, dev)      # dL/d input
+        self.acts, self.zs, self.stats, self.dims = [], [], [], [(H, W)]
+        h, w = H, W
+        for L in net.layers:
+            ho = (h + 2 - 4) // L['stride'] + 1
+            wo = (w + 2 - 4) // L['stride'] + 1
+            self.dims.append((ho, wo))
+            z = BTensor(N, max(L['cout'], 16), ho, wo, True, dev) if L['norm'] else None
+            a = BTensor(N, max(L['cout'], 16), ho, wo, True, dev)
+            self.zs.append(z)
+            self.acts.append(a)
+            self.stats.append(torch.zeros(N * ceil_div(L['cout'], 16) * 16 * 2, dtype=torch.float32, device=dev) if L['norm'] else None)
+            h, w = ho, wo
+        self.logits = self.acts[-1]
+        self.g_logits = BTensor(N, 16, h, w, True, dev)
+        # gradient buffers: ga[i] = dL/d acts[i], gz[i] = dL/d (conv output of layer i)
+        self.ga = [BTensor(N, a.C, a.H, a.W, True, dev) for a in self.acts[:-1]]
+        self.gz = [BTensor(N, a.C, a.H, a.W, True, dev) for a in self.acts[:-1]] + [self.g_logits]
+        self.ws = Workspace(dev)
+        self.fwd = self._build_fwd(N)
+        self.bwd_full = self._build_bwd(N, wgrad=True, input_grad=False)
+        self.bwd_data = {}
+        self.ws.finalize()
+
+    def view_n(self, bt, n0=0):
+        v = bt.view()
+        return Tensor(v.p + n0 * v.n_stride * bt.esz, v.n_stride, v.cb_stride)
+
+    def _build_fwd(self, N):
+        net, P, pack = self.net, self.net.params, self.net.pack
+        ops = OpList()
+        src = self.x
+        for i, L in enumerate(net.layers):
+            (hi, wi), (ho, wo) = self.dims[i], self.dims[i + 1]
+            bias = P.ptr(L['key'] + 'bias') if L['bias'] else None
+            if L['norm']:
+                ops.add(conv_op(pack, L['fwd'], src.view(), True, L['cin_pad'], hi, wi, ho, wo, N, bias=bias, kh=4, stride=L['stride'],
+                                out_f32=self.zs[i].view()))
+                o = _op(_lib.OP_INORM_FWD)
+                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = self.zs[i].view(), N, L['cout'], ho, wo
+                o.f[0], o.f[1], o.t[1], o.p[0] = IN_EPS, SLOPE, self.acts[i].view(), self.stats[i].data_ptr()
+                ops.add(o)
+            else:
+                ops.add(conv_op(pack, L['fwd'], src.view(), True, L['cin_pad'], hi, wi, ho, wo, N, bias=bias, kh=4, stride=L['stride'],
+                                act=0 if L.get('last') else 1, slope=SLOPE, out_f32=self.acts[i].view()))
+            src = self.acts[i]
+        return ops
+
+    def _dgrad_ops(self, ops, i, N, g_in, out, mask):
+        """dL/d(input of layer i) from g_in = dL/d(conv output of layer i); optional LeakyReLU' mask of the input"""
+        net, pack = self.net, self.net.pack
+        L = net.layers[i]
+        (hi, wi), (ho, wo) = self.dims[i], self.dims[i + 1]
+        cb = ceil_div(L['cout'], 16) * 16
+        m = mask.view() if mask is not None else None
+        if L['stride'] == 1:
+            ops.add(conv_op(pack, L['bwd'], g_in.view(), True, cb, ho, wo, hi, wi, N, kh=4, stride=1, pad=2, mask=m, mask_f32=1,
+                            slope=SLOPE, out_f32=out.view()))
+        else:
+            for (py, px), ref in L['bwd'].items():
+                hs, wsub = (hi - py + 1) // 2, (wi - px + 1) // 2
+                ops.add(conv_op(pack, ref, g_in.view(), True, cb, ho, wo, hs, wsub, N, kh=2, stride=1, pad=_PARITY_PAD[py],
+                                pad_x=_PARITY_PAD[px], mask=m, mask_f32=1, slope=SLOPE, out_f32=out.view(), out_stride=2, out_oy=py,
+                                out_ox=px, out_W=wi))
+
+    def _build_bwd(self, N, wgrad, input_grad):
+        """input: self.g_logits.  N may be a prefix of the batch (views start at image 0)."""
+        net, P = self.net, self.net.params
+        ops = OpList()
+        nl = len(net.layers)
+        for i in range(nl - 1, -1, -1):
+            L = net.layers[i]
+            (hi, wi), (ho, wo) = self.dims[i], self.dims[i + 1]
+            gz = self.gz[i]
+            if L['norm']:  # dL/da -> dL/dz through InstanceNorm + LeakyReLU
+                o = _op(_lib.OP_INORM_BWD)
+                o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3] = self.acts[i].view(), self.ga[i].view(), N, L['cout'], ho, wo
+                o.f[0], o.p[0], o.t[2] = SLOPE, self.stats[i].data_ptr(), gz.view()
+                ops.add(o)
+            inp = self.x if i == 0 else self.acts[i - 1]
+            if wgrad:
+                grp = WgradGroup(4, L['stride'])
+                grp.add_conv(gz.view, True, gz.planes, inp.view, True, inp.planes, L['cout'], L['cin'], hi, wi, ho, wo, N,
+                             P.off(L['key'] + 'weight'), P.off(L['key'] + 'bias') if L['bias'] else None)
+                grp.finalize(self.ws, net.device)
+                for o in grp.ops(P.grad.data_ptr()):
+                    ops.add(o)
+                ops.keep.append(grp)
+            if i > 0:
+                prev = net.layers[i - 1]
+                if prev['norm']:
+                    self._dgrad_ops(ops, i, N, gz, self.ga[i - 1], None)        # IN backward applies the LeakyReLU'
+                else:
+                    self._dgrad_ops(ops, i, N, gz, self.gz[i - 1], self.acts[i - 1])  # plain conv+LeakyReLU layer
+            elif input_grad:
+                self._dgrad_ops(ops, 0, N, gz, self.gx, None)
+        return ops
+
+    def bwd_data_ops(self, n):
+        """data-gradient only (generator step) for the first n images"""
+        if n not in self.bwd_data:
+            ws_before = self.ws.need
+            self.bwd_data[n] = self._build_bwd(n, wgrad=False, input_grad=True)
+            assert self.ws.need == ws_before
+        return self.bwd_data[n]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M']
+VGG_MEAN, VGG_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def vgg19_spec(feature_layer=34):
+    """torchvision vgg19.features[: feature_layer + 1] as [(kind, idx, cin, cout, relu)]"""
+    layers, spec, idx, c = [], [], 0, 3
+    for v in VGG19_CFG:
+        if idx > feature_layer:
+            break
+        if v == 'M':
+            layers.append(('pool', idx, c, c, False))
+            idx += 1
+        else:
+            relu = (idx + 1) <= feature_layer
+            layers.append(('conv', idx, c, v, relu))
+            spec += [('features.%d.weight' % idx, (v, c, 3, 3)), ('features.%d.bias' % idx, (v,))]
+            c = v
+            idx += 2
+    return spec, layers
+
+
+class VGGFeatureHIP:
+    """Frozen feature extractor: forward on N images, data-gradient w.r.t. the first n_g inputs."""
+
+    def __init__(self, feature_layer=34, device='cuda'):
+        self.device = torch.device(device)
+        self.spec, self.layers = vgg19_spec(feature_layer)
+        self.params = ParamStore(self.spec, self.device)
+        self.pack = PackRegistry(self.params)
+        P = self.params
+        self.pk = {}
+        for kind, idx, cin, cout, relu in self.layers:
+            if kind != 'conv':
+                continue
+            w = P.off('features.%d.weight' % idx)
+            cin_pad = ceil_div(cin, 16) * 16
+            self.pk[idx] = self.pack.add(cout, cin_pad, 9, 1, 3, [(w, cout, cin, 0, cin, 0, 0)])
+            self.pk[(idx, 'b')] = self.pack.add(cin, cout, 9, 1, 3, [(w, cout, cin, 0, cout, 0, 1)])
+        self.pack.finalize()
+        self.plans = {}
+
+    def load_state_dict(self, sd, strict=True):
+        self.params.load_state_dict(sd, strict)
+        self.pack.run()
+
+    def state_dict(self):
+        return self.params.state_dict()
+
+    def plan(self, N, n_g, H, W):
+        k = (N, n_g, H, W)
+        if k not in self.plans:
+            self.plans[k] = _VGGPlan(self, N, n_g, H, W)
+        return self.plans[k]
+
+
+class _VGGPlan:
+    def __init__(self, net, N, n_g, H, W):
+        self.net, self.N, self.n_g = net, N, n_g
+        dev, P, pack = net.device, net.params, net.pack
+        self.x = BTensor(N, 16, H, W, True, dev)  # normalised input
+        self.outs = []
+        h, w = H, W
+        fwd = OpList()
+        src = self.x
+        for kind, idx, cin, cout, relu in net.layers:
+            if kind == 'conv':
+                out = BTensor(N, cout, h, w, True, dev)
+                fwd.add(conv_op(pack, net.pk[idx], src.view(), True, ceil_div(cin, 16) * 16, h, w, h, w, N,
+                                bias=P.ptr('features.%d.bias' % idx), act=1 if relu else 0, slope=0.0, out_f32=out.view()))
+            else:
+                h, w = h // 2, w // 2
+                out = BTensor(N, cout, h, w, True, dev)
+                o = _op(_lib.OP_MAXPOOL)
+                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[1] = src.view(), N, cout, h, w, 1, out.view()
+                fwd.add(o)
+            self.outs.append(out)
+            src = out
+        self.feat = src
+        self.fwd = fwd
+        # data gradient for the first n_g images.  Gradients handed between layers are w.r.t. PRE-activation values:
+        # a dgrad conv's epilogue applies the ReLU' of the layer that produced its input; a pool's backward applies the
+        # ReLU' of the conv feeding the pool (every VGG pool follows a ReLU).
+        n = n_g
+        self.g_feat = BTensor(N, self.feat.C, self.feat.H, self.feat.W, True, dev)
+        self.gx = BTensor(N, 16, H, W, True, dev)
+        bwd = OpList()
+        g = self.g_feat
+        for li in range(len(net.layers) - 1, -1, -1):
+            kind, idx, cin, cout, relu = net.layers[li]
+            inp = self.x if li == 0 else self.outs[li - 1]
+            gin = self.gx if li == 0 else BTensor(N, inp.C, inp.H, inp.W, True, dev)
+            if kind == 'conv':
+                prev_relu = li > 0 and net.layers[li - 1][0] == 'conv' and net.layers[li - 1][4]
+                bwd.add(conv_op(pack, net.pk[(idx, 'b')], g.view(), True, cout, inp.H, inp.W, inp.H, inp.W, n,
+                                mask=inp.view() if prev_relu else None, mask_f32=1, slope=0.0, out_f32=gin.view()))
+            else:
+                o = _op(_lib.OP_MAXPOOL_BWD)
+                o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.t[2] = inp.view(), g.view(), n, cout, g.H, g.W, 1, 1, gin.view()
+                bwd.add(o)
+            g = gin
+        self.bwd = bwd

@@ -54,6 +54,10 @@ typedef struct {
     float alpha;  dasr_tensor res1;  float beta1;  dasr_tensor res2;  float beta2;
     dasr_tensor out_f32;  dasr_tensor out_bf16;  float gamma;
     int32_t xcd_remap;                      /* set by the library (XCD-aware tile order); callers leave it 0 */
+    /* extensions used by the stride-2 data-gradient (four 2x2 parity sub-convolutions writing interleaved sub-grids):
+     * pad_x < 0: same as pad; out_stride 0/1: dense output, 2: output pixel (oy,ox) lands at (2*oy+out_oy, 2*ox+out_ox)
+     * of a tensor of width out_W (mask / res / out tensors are all indexed at that full-resolution position). */
+    int32_t pad_x, out_stride, out_oy, out_ox, out_W;
 } dasr_conv_params;
 
 int dasr_conv(const dasr_conv_params* p, void* stream);
@@ -107,13 +111,15 @@ typedef struct {
     int32_t src_cout, src_cin;
     int32_t cin_start, cin_len;   /* range of packed input channels fed by this segment */
     int32_t src_c0;       /* fwd: source cin offset; bwd: source cin (= packed oc) offset */
-    int32_t transpose;    /* 0: W[oc][src_c0+ci][t];  1: W[ci][src_c0+oc][ntaps-1-t] */
+    int32_t transpose;    /* 0: W[oc][src_c0+ci][tapmap[t]];  1: W[ci][src_c0+oc][tapmap[t]] */
 } dasr_pack_seg;
 
 typedef struct {
     int64_t dst_off;      /* bf16 element offset of the hi plane; lo plane at dst_off + lo_off */
     int64_t lo_off;       /* 0 when prec 1 */
     int32_t cout, cin_pad, ntaps, mt, nseg;
+    int32_t src_ntaps;    /* taps of the source weight (kh*kw of the nn.Conv2d) */
+    int8_t  tapmap[16];   /* packed tap -> source tap (identity: forward; reversed: stride-1 dgrad; parity subset: stride-2 dgrad) */
     dasr_pack_seg seg[5];
 } dasr_pack_desc;
 
@@ -151,9 +157,49 @@ int dasr_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr,
 
 int dasr_fill_f32(float* p, int64_t n, float value, void* stream);
 
+
+/* ---- GAN-step kernels (csrc/gan.hip) ---------------------------------------------------------------------*/
+/* nn.InstanceNorm2d(affine=False, eps) + LeakyReLU of NLayerDiscriminator (architecture.py:1003-1015), fused;
+ * stats[N][Cpad][2] = (mean, rstd).  Backward takes the saved forward output a and dL/da, returns dL/dx. */
+int dasr_inorm_lrelu_fwd(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, float eps, float slope, dasr_tensor y,
+                         float* stats, void* stream);
+int dasr_inorm_lrelu_bwd(dasr_tensor a, dasr_tensor ga, int32_t N, int32_t C, int32_t H, int32_t W, float slope,
+                         const float* stats, dasr_tensor gx, void* stream);
+/* GANLoss('vanilla') = BCEWithLogitsLoss vs a constant target (loss.py:8-40): loss_acc += coef*sum(bce),
+ * score_acc += score_coef*sum(x) (the disc_Score log), grad = gcoef*(sigmoid(x)-target) */
+int dasr_bce_logits(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, float target, float coef, float gcoef,
+                    float* loss_acc, float* score_acc, float score_coef, dasr_tensor grad, void* stream);
+/* Haar DWT level 1 as used by DASR_Model.wavelet_s (DASR_model.py:442-452): LL (C ch) and [LH|HL|HH] (3C ch), optional
+ * norm (LL*0.5, Hc*0.5+0.5); and its adjoint (accumulating into gx).  H2, W2 = output size. */
+int dasr_dwt_fwd(dasr_tensor x, int32_t N, int32_t C, int32_t H2, int32_t W2, int32_t norm, dasr_tensor ll, dasr_tensor hc, void* stream);
+int dasr_dwt_bwd(dasr_tensor gll, dasr_tensor ghc, int32_t N, int32_t C, int32_t H2, int32_t W2, int32_t norm, dasr_tensor gx,
+                 int32_t accumulate, void* stream);
+/* depthwise k x k low-pass (GaussianFilter / AvgPool2d of FilterLow/FilterHigh, architecture.py:1177-1243), zero pad.
+ * mode 0: out_low = low(x), out_high = a_h*(x - low(x)) + b_h.  mode 1 (adjoint): out_low (+)= low(x) + a_h*(x2 - low(x2))
+ * with x = dL/dlow, x2 = dL/dhigh (either may be null). */
+int dasr_lowpass(dasr_tensor x, dasr_tensor x2, const float* w, int32_t k, int32_t N, int32_t C, int32_t H, int32_t W,
+                 int32_t mode, float a_h, float b_h, dasr_tensor out_low, dasr_tensor out_high, int32_t accumulate, void* stream);
+/* nn.MaxPool2d(2,2) of the VGG19 feature stack, forward and backward (Ho, Wo = pooled size) */
+int dasr_maxpool2(dasr_tensor x, int32_t is_f32, int32_t N, int32_t C, int32_t Ho, int32_t Wo, dasr_tensor y, void* stream);
+/* relu_mask: also zero the gradient where the pooled maximum is <= 0 (the ReLU' of the conv feeding the pool) */
+int dasr_maxpool2_bwd(dasr_tensor x, dasr_tensor gy, int32_t is_f32, int32_t N, int32_t C, int32_t Ho, int32_t Wo, dasr_tensor gx,
+                      int32_t relu_mask, void* stream);
+/* L1 between two blocked tensors (feature loss DASR_model.py:224-229; LL loss :220-222): loss_acc += coef*sum|a-b|,
+ * ga = gcoef*sign(a-b) */
+int dasr_l1_diff(dasr_tensor a, dasr_tensor b, int32_t is_f32, int32_t N, int32_t C, int32_t H, int32_t W, float coef, float gcoef,
+                 float* loss_acc, dasr_tensor ga, void* stream);
+/* per-channel affine on <=4 channels (VGG input normalisation architecture.py:1086-1087 and its adjoint) */
+int dasr_affine4(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, const float* scale4, const float* shift4, dasr_tensor y,
+                 int32_t y_f32, int32_t accumulate, void* stream);
+/* F.interpolate(bilinear, align_corners=False) of the domain-distance map (DASR_model.py:173-174), NCHW [N][1][h][w] */
+int dasr_bilinear_up(const float* src, int32_t N, int32_t h, int32_t w, int32_t factor, float* dst, void* stream);
+
 /* ---- executor: run a recorded list of ops in one call (keeps the host out of the step) ----------*/
 enum { DASR_OP_CONV = 1, DASR_OP_WGRAD = 2, DASR_OP_WGRAD_REDUCE = 3, DASR_OP_PACK = 4, DASR_OP_DOWNSUM = 5,
-       DASR_OP_AXPBY = 6, DASR_OP_FILL = 7, DASR_OP_L1LOSS = 8, DASR_OP_NCHW2B = 9, DASR_OP_B2NCHW = 10 };
+       DASR_OP_AXPBY = 6, DASR_OP_FILL = 7, DASR_OP_L1LOSS = 8, DASR_OP_NCHW2B = 9, DASR_OP_B2NCHW = 10,
+       DASR_OP_INORM_FWD = 11, DASR_OP_INORM_BWD = 12, DASR_OP_BCE = 13, DASR_OP_DWT_FWD = 14, DASR_OP_DWT_BWD = 15,
+       DASR_OP_LOWPASS = 16, DASR_OP_MAXPOOL = 17, DASR_OP_MAXPOOL_BWD = 18, DASR_OP_L1DIFF = 19, DASR_OP_AFFINE4 = 20,
+       DASR_OP_BILINEAR = 21 };
 
 typedef struct {
     int32_t op;  int32_t i[8];  float f[4];  int64_t l[4];  void* p[4];  dasr_tensor t[5];
