@@ -136,12 +136,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __
         }
     };
     char* const dummy = smem + C::LDS_BYTES;  // 16 B slot that swallows the tail threads' stores (no divergent branch)
+    // f32 gradients: the bias gradient (sum over pixels, heavy cancellation) is accumulated from the UNROUNDED values
+    // while staging; thread t always stages the same 8 channels (plane, half) in round r.
+    float bacc[GR][8];
+#pragma unroll
+    for (int r = 0; r < GR; ++r)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bacc[r][j] = 0.f;
     auto commit = [&]() {
 #pragma unroll
         for (int r = 0; r < GR; ++r) {
             const int q = tid + r * 256;
             const int half = q & 1, pix = (q >> 1) % GPIX, pl = (q >> 1) / GPIX;
             stage_store<F32>(greg[r], q < GPIECES ? gl + pl * C::GPLANE + pix * 32 + half * 16 : dummy);
+            if constexpr (F32) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bacc[r][j] += __uint_as_float(greg[r].a[j]);
+                    bacc[r][4 + j] += __uint_as_float(greg[r].b[j]);
+                }
+            }
         }
 #pragma unroll
         for (int r = 0; r < IR; ++r) {
@@ -169,9 +183,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __
 #pragma unroll
                 for (int j = 0; j < 8; ++j) a[j] = *(const bf16_t*)(b0 + j * 32);
             }
-            if (P.want_bias && tg == 0 && ct == 0) {
+            if constexpr (!F32) {
+                if (P.want_bias && tg == 0 && ct == 0) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bsum += (float)a[j];
+                    for (int j = 0; j < 8; ++j) bsum += (float)a[j];
+                }
             }
 #pragma unroll
             for (int t = 0; t < C::TPG; ++t) {
@@ -209,9 +225,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __
                 }
             }
         }
-        if (P.want_bias && tg == 0 && ct == 0) {
-            const float tot = bsum + __shfl_xor(bsum, 32, 64);
-            if (lane < 32) ws[P.ws_bias_off + (size_t)split * 32 + lane] = tot;
+        if constexpr (!F32) {
+            if (P.want_bias && tg == 0 && ct == 0) {
+                const float tot = bsum + __shfl_xor(bsum, 32, 64);
+                if (lane < 32) ws[P.ws_bias_off + (size_t)split * 32 + lane] = tot;
+            }
+        }
+    }
+    if constexpr (F32) {
+        if (P.want_bias) {  // uniform: deterministic fixed-order reduction of the per-thread fp32 partials through LDS
+            __syncthreads();
+            float* red = (float*)smem;  // [256][GR*8]
+#pragma unroll
+            for (int r = 0; r < GR; ++r)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[tid * (GR * 8) + r * 8 + j] = (tid + r * 256 < GPIECES) ? bacc[r][j] : 0.f;
+            __syncthreads();
+            if (tid < 32) {
+                const int pl = tid >> 4, half = (tid >> 3) & 1, j = tid & 7;
+                float tot = 0.f;
+                for (int t = 0; t < 256; ++t) {
+#pragma unroll
+                    for (int r = 0; r < GR; ++r) {
+                        const int q = t + r * 256;
+                        if (q < GPIECES && (q & 1) == half && (q >> 1) / GPIX == pl) tot += red[t * (GR * 8) + r * 8 + j];
+                    }
+                }
+                ws[P.ws_bias_off + (size_t)split * 32 + tid] = tot;
+            }
         }
     }
 }

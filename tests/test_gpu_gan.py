@@ -85,7 +85,8 @@ def test_bce_dwt_lowpass_pool_misc():
     gl, gh = torch.randn(2, 3, 8, 12, generator=g), torch.randn(2, 9, 8, 12, generator=g)
     (rl * gl).sum().backward(retain_graph=True)
     (rh * gh).sum().backward()
-    _lib.check(L.dasr_dwt_bwd(to_blocked(gl, dev).view(), to_blocked(gh, dev).view(), 2, 3, 8, 12, 1, gx.view(), 0, _stream()))
+    glb, ghb = to_blocked(gl, dev), to_blocked(gh, dev)  # keep the buffers alive: a dasr_tensor is a raw pointer
+    _lib.check(L.dasr_dwt_bwd(glb.view(), ghb.view(), 2, 3, 8, 12, 1, gx.view(), 0, _stream()))
     assert rel(gx.nchw(3).cpu(), ir.grad) < 1e-6
     # gaussian low/high split and its adjoint
     for k in (5, 9):
@@ -101,7 +102,8 @@ def test_bce_dwt_lowpass_pool_misc():
         assert rel(lo.nchw(3).cpu(), rlo.detach()) < 1e-5 and rel(hi.nchw(3).cpu(), rhi.detach()) < 1e-5
         g1, g2 = torch.randn(2, 3, 20, 28, generator=g), torch.randn(2, 3, 20, 28, generator=g)
         ((rlo * g1).sum() + (rhi * g2).sum()).backward()
-        _lib.check(L.dasr_lowpass(to_blocked(g1, dev).view(), to_blocked(g2, dev).view(), wd.data_ptr(), k, 2, 3, 20, 28, 1, 0.25, 0.0, gxx.view(), NULL_T, 0, _stream()))
+        g1b, g2b = to_blocked(g1, dev), to_blocked(g2, dev)
+        _lib.check(L.dasr_lowpass(g1b.view(), g2b.view(), wd.data_ptr(), k, 2, 3, 20, 28, 1, 0.25, 0.0, gxx.view(), NULL_T, 0, _stream()))
         assert rel(gxx.nchw(3).cpu(), ir.grad) < 1e-5
     # max-pool forward / backward (with the ReLU' of the producer)
     a = F.relu(torch.randn(2, 32, 12, 16, generator=g))
@@ -116,18 +118,21 @@ def test_bce_dwt_lowpass_pool_misc():
     pr.backward(gp)
     _lib.check(L.dasr_maxpool2(ab2.view(), 1, 2, 32, 6, 8, pb.view(), _stream()))
     assert torch.equal(pb.nchw().cpu(), pr.detach())
-    _lib.check(L.dasr_maxpool2_bwd(ab2.view(), to_blocked(gp, dev).view(), 1, 2, 32, 6, 8, gab.view(), 1, _stream()))
+    gpb = to_blocked(gp, dev)
+    _lib.check(L.dasr_maxpool2_bwd(ab2.view(), gpb.view(), 1, 2, 32, 6, 8, gab.view(), 1, _stream()))
     assert rel(gab.nchw().cpu(), pre.grad) < 1e-6
     # bilinear x4 of the ddm
     wm = torch.rand(2, 1, 7, 9, generator=g)
     dst = torch.zeros(2, 1, 28, 36, device=dev)
-    _lib.check(L.dasr_bilinear_up(wm.to(dev).data_ptr(), 2, 7, 9, 4, dst.data_ptr(), _stream()))
+    wmd = wm.to(dev)
+    _lib.check(L.dasr_bilinear_up(wmd.data_ptr(), 2, 7, 9, 4, dst.data_ptr(), _stream()))
     assert torch.allclose(dst.cpu(), F.interpolate(wm, size=(28, 36), mode='bilinear', align_corners=False), atol=1e-6)
     # L1 between feature maps + VGG affine
     fa, fb = torch.randn(2, 40, 5, 6, generator=g), torch.randn(2, 40, 5, 6, generator=g)
     ga = BTensor(2, 40, 5, 6, True, dev)
     acc.zero_()
-    _lib.check(L.dasr_l1_diff(to_blocked(fa, dev).view(), to_blocked(fb, dev).view(), 1, 2, 40, 5, 6, 1.0 / fa.numel(), 2.0 / fa.numel(), acc.data_ptr(), ga.view(), _stream()))
+    fab, fbb = to_blocked(fa, dev), to_blocked(fb, dev)
+    _lib.check(L.dasr_l1_diff(fab.view(), fbb.view(), 1, 2, 40, 5, 6, 1.0 / fa.numel(), 2.0 / fa.numel(), acc.data_ptr(), ga.view(), _stream()))
     assert abs(float(acc[0]) - float((fa - fb).abs().mean())) < 1e-6
     assert rel(ga.nchw().cpu(), 2.0 * torch.sign(fa - fb) / fa.numel()) < 1e-6
 
@@ -225,8 +230,10 @@ def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir):
         for k in keys:
             ref_v, gold_v = t.log[k], float(gold['logs'][step - 1][keys.index(k)])
             tol = 2e-3 if step == 1 else 2e-2  # step 2 sees weights moved by a sign-normalised Adam update
-            assert abs(log[k] - ref_v) <= tol * max(1e-3, abs(ref_v)) + 1e-5, (step, k, log[k], ref_v)
-            assert abs(log[k] - gold_v) <= tol * max(1e-3, abs(gold_v)) + 1e-5, (step, k, log[k], gold_v)
+            # disc_Score = mean of logits of magnitude ~0.1-1 that nearly cancels: absolute tolerance on that scale
+            atol = (2e-4 if step == 1 else 2e-3) if k.startswith('disc_Score') else 1e-5
+            assert abs(log[k] - ref_v) <= tol * max(1e-3, abs(ref_v)) + atol, (step, k, log[k], ref_v)
+            assert abs(log[k] - gold_v) <= tol * max(1e-3, abs(gold_v)) + atol, (step, k, log[k], gold_v)
         if step == 1:
             assert rel(m.fake_H.cpu(), t.fake_H.detach()) < ACT_TOL
             gd = m.netG.params.grad_dict()
