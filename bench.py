@@ -32,6 +32,19 @@ TFLOP_PER_IMAGE_TRAIN = 1.762  # 3 x 587.43 GFLOP per 128x128 LR
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
+def make_dasr_opt(nf, nb, fs):
+    o = make_opt(nf, nb)
+    o.update(model='DASR', multiweights=True)
+    o['path'].update(pretrain_model_D_target=None, pretrain_model_D_source=None)
+    o['network_D'] = {'which_model_D': 'discriminator_patch', 'norm_type': 'Batch', 'act_type': 'leakyrelu', 'mode': 'CNA', 'nf': 64,
+                      'in_nc': 9 if fs == 'wavelet' else 3, 'n_layers': 2}
+    o['train'].update({'lr_G': 1e-4, 'weight_decay_G': 0, 'beta1_G': 0.9, 'lr_D': 1e-4, 'weight_decay_D': 0, 'beta1_D': 0.9, 'fs': fs,
+                       'fs_kernel_size': 9, 'norm': True, 'sup_LL': True, 'pixel_LL_weight': 1, 'feature_criterion': 'l1',
+                       'feature_weight': 1, 'gan_type': 'vanilla', 'ragan': False, 'gan_H_target': 0.01, 'gan_H_source': 0,
+                       'G_update_inter': 1, 'D_update_inter': 1})
+    return o
+
+
 def make_opt(nf, nb):
     return {'is_train': True, 'gpu_ids': [0], 'scale': 4, 'chop': False, 'val_lpips': False, 'model': 'sr', 'name': 'bench',
             'path': {'pretrain_model_G': None, 'models': '/tmp', 'training_state': '/tmp'},
@@ -41,29 +54,45 @@ def make_opt(nf, nb):
                       'pixel_criterion': 'l1', 'pixel_weight': 1.0, 'manual_seed': 0}}
 
 
-def roofline_dominant_kernel(model, plan, reps=5):
-    """Time the Cout=32 dense-block conv kernel (conv1..conv4 of one RDB: Cin 64/96/128/160) in isolation."""
+def roofline_dominant_kernel(model, plans, reps=5):
+    """Time the Cout=32 dense-block conv kernel (conv1..conv4 of one RDB: Cin 64/96/128/160) the way the step runs it:
+    one launch sequence per concurrently processed sub-batch, each on its own stream, bracketed by HIP events."""
     from dasr_amd.engine import OpList
     from dasr_amd import _lib
-    convs = [o for o in plan.fwd.ops if o.op == _lib.OP_CONV and o.conv.prec == 1 and o.conv.cout == 32][:4]
-    ol = OpList()
-    for o in convs:
-        ol.add(o)
-    flops = sum(2.0 * o.conv.N * o.conv.Hout * o.conv.Wout * 9 * o.conv.cin * o.conv.cout for o in convs)
-    ol.run()
+    ols, flops = [], 0.0
+    for plan in plans:
+        convs = [o for o in plan.fwd.ops if o.op == _lib.OP_CONV and o.conv.prec == 1 and o.conv.cout == 32][:4]
+        ol = OpList()
+        for o in convs:
+            ol.add(o)
+        flops += sum(2.0 * o.conv.N * o.conv.Hout * o.conv.Wout * 9 * o.conv.cin * o.conv.cout for o in convs)
+        ols.append(ol)
+    streams = [torch.cuda.current_stream()] if len(plans) == 1 else [torch.cuda.Stream() for _ in plans]
+    cur = torch.cuda.current_stream()
+
+    def run_all(n):
+        for st, ol in zip(streams, ols):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                for _ in range(n):
+                    ol.run()
+        for st in streams:
+            cur.wait_stream(st)
+
+    run_all(1)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        ol.run()
+    run_all(reps)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     achieved = flops / (ms * 1e-3) / 1e12
+    nl = 4 * len(plans)
     return {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
-            'kernel': 'conv_kernel<prec1,bf16,mt1,3x3,s1> (RDB conv1-4, Cout=32)', 'avg_launch_us': round(ms * 1e3 / len(convs), 1),
-            'flops_per_launch_avg': flops / len(convs)}
+            'kernel': 'conv_kernel<prec1,bf16,mt1,3x3,s1> (RDB conv1-4, Cout=32), %d concurrent sub-batch stream(s)' % len(plans),
+            'avg_launch_us': round(ms * 1e3 / nl * len(plans), 1), 'flops_per_launch_avg': flops / nl}
 
 
 def _usable_cores():
@@ -128,7 +157,7 @@ def sweep(model, data, a):
         torch.cuda.synchronize()
 
     run_steps(2)
-    plan = model.netG.plan(a.batch, a.lr_size, a.lr_size)
+    plan = (getattr(model, '_out_plans', None) or [model.netG.plan(a.batch, a.lr_size, a.lr_size)])[0]
 
     def time_ops(ops, reps=10):
         ol = OpList()
@@ -172,7 +201,7 @@ def sweep(model, data, a):
             res.setdefault(('stream', v), []).append(fl(cst) / ms / 1e9)
         L.dasr_set_tuning(3, 0)
         ms = time_ops(wg_rdb[:1])
-        res.setdefault(('wgrad_rdb', 0), []).append(2.0 * a.batch * a.lr_size * a.lr_size * 239616 / ms / 1e9)
+        res.setdefault(('wgrad_rdb', 0), []).append(2.0 * plan.N * a.lr_size * a.lr_size * 239616 / ms / 1e9)
         ms = time_ops(wg_rdb[1:])
         res.setdefault(('wgrad_reduce_us', 0), []).append(ms * 1e3)
     for k, v in res.items():
@@ -198,6 +227,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--tune', type=str, default='', help='kernel variant knobs, e.g. 1=1,2=0 (dasr_set_tuning key=value)')
     ap.add_argument('--sweep', action='store_true', help='A/B the conv kernel variants (stderr table), then exit')
+    ap.add_argument('--model', type=str, default='sr', choices=['sr', 'dasr'],
+                    help="sr: configs[1] generator-only step (the headline line); dasr: configs[2] full GAN step (batch = G crops per GPU)")
+    ap.add_argument('--fs', type=str, default='wavelet', choices=['wavelet', 'gau'])
     a = ap.parse_args()
 
     from dasr_amd import options
@@ -214,14 +246,22 @@ def main():
     if dp:
         torch.cuda.set_device(dp.local_rank)
     torch.manual_seed(0)
-    model = create_model(options.dict_to_nonedict(make_opt(a.nf, a.nb)))
+    dasr = a.model == 'dasr'
+    model = create_model(options.dict_to_nonedict(make_dasr_opt(a.nf, a.nb, a.fs) if dasr else make_opt(a.nf, a.nb)))
     if dp:
         model.dp = dp
-        dp.broadcast_params(model.netG.params.flat)
-        model.netG.repack()
+        for net in model.networks():
+            dp.broadcast_params(net.params.flat)
+            net.repack()
     g = torch.Generator().manual_seed(1234 + rank)
-    data = {'LR': torch.rand(a.batch, 3, a.lr_size, a.lr_size, generator=g).cuda(),
-            'HR': torch.rand(a.batch, 3, 4 * a.lr_size, 4 * a.lr_size, generator=g).cuda()}
+    if dasr:
+        n, s = a.batch // 2, a.lr_size
+        data = {'LR_fake': torch.rand(n, 3, s, s, generator=g).cuda(), 'LR_real': torch.rand(n, 3, s, s, generator=g).cuda(),
+                'HR': torch.rand(n, 3, 4 * s, 4 * s, generator=g).cuda(), 'HR_unpair': torch.rand(n, 3, 4 * s, 4 * s, generator=g).cuda(),
+                'fake_w': torch.rand(n, 1, s, s, generator=g).cuda()}
+    else:
+        data = {'LR': torch.rand(a.batch, 3, a.lr_size, a.lr_size, generator=g).cuda(),
+                'HR': torch.rand(a.batch, 3, 4 * a.lr_size, 4 * a.lr_size, generator=g).cuda()}
     log('model built')
     if a.sweep:
         return sweep(model, data, a)
@@ -247,7 +287,8 @@ def main():
     dt = time.perf_counter() - t0
     if dp:
         dt = dp.max_over_ranks(dt)
-    loss = model.get_current_log()['l_pix']
+    logd = model.get_current_log()
+    loss = logd.get('l_pix', logd.get('loss/l_g_pix'))
     log('timed steps done: %.1f ms/step' % (dt / a.steps * 1e3))
     if rank != 0:
         return
@@ -258,16 +299,19 @@ def main():
            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2), 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16 MFMA operands, fp32 accumulate / fp32 residual stream',
            'data': 'synthetic (torch.rand, seed 1234+rank; kaiming x0.1 weights, seed 0)',
-           'config': {'workload': 'configs[1]: RRDBNet nf=%d nb=%d 4x SR, batch %d of %dx%d LR per GPU, generator-only L1 step '
-                                  '(fwd+bwd+Adam)' % (a.nf, a.nb, a.batch, a.lr_size, a.lr_size),
+           'config': {'workload': ('configs[2]: full SRN GAN step (RRDBNet nf=%d nb=%d + NLayer patch-D + VGG19-54 perceptual, fs=%s), %d G crops of '
+                                   '%dx%d LR per GPU (n=%d source + %d target)' % (a.nf, a.nb, a.fs, a.batch, a.lr_size, a.lr_size, a.batch // 2, a.batch // 2))
+                      if dasr else
+                      'configs[1]: RRDBNet nf=%d nb=%d 4x SR, batch %d of %dx%d LR per GPU, generator-only L1 step '
+                      '(fwd+bwd+Adam)' % (a.nf, a.nb, a.batch, a.lr_size, a.lr_size),
                       'global_batch': a.batch * n_gpus, 'parallelism': 'dp%d' % n_gpus},
            'final_loss': loss}
-    if full:
+    if full and not dasr:
         out['mfma_util_step'] = round(ips * TFLOP_PER_IMAGE_TRAIN / PEAK_BF16_TFLOPS, 4)
-    plan = model.netG.plan(a.batch, a.lr_size, a.lr_size)
-    out['roofline'] = roofline_dominant_kernel(model, plan)
+    plans = getattr(model, '_out_plans', None) or [model.netG.plan(a.batch, a.lr_size, a.lr_size)]
+    out['roofline'] = roofline_dominant_kernel(model, plans)
     log('roofline done')
-    if n_gpus == 1 and not a.no_cpu_baseline:
+    if n_gpus == 1 and not a.no_cpu_baseline and not dasr:
         out['cpu_baseline'] = cpu_baseline(a.nf, a.nb, a.lr_size)
     print(json.dumps(out))
 

@@ -73,6 +73,7 @@ _SIGS = {
     'dasr_axpby': [Tensor, c_f32, Tensor, c_f32, c_i32, c_i32, c_i32, c_i32, Tensor, Tensor, c_f32, c_vp],
     'dasr_adam': [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp],
     'dasr_fill_f32': [c_vp, c_i64, c_f32, c_vp],
+    'dasr_add_flat': [c_vp, c_vp, c_i64, c_vp],
     'dasr_inorm_lrelu_fwd': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, Tensor, c_vp, c_vp],
     'dasr_inorm_lrelu_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, Tensor, c_vp],
     'dasr_bce_logits': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp, c_f32, Tensor, c_vp],

@@ -225,6 +225,10 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+__global__ void add_flat_kernel(float* __restrict__ y, const float* __restrict__ x, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] += x[i];
+}
+
 __global__ void fill_kernel(float* p, long long n, float v) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -298,6 +302,13 @@ extern "C" int dasr_fill_f32(float* p, int64_t n, float value, void* stream) {
     if (n <= 0) return DASR_EINVAL;
     const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p, (long long)n, value);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_add_flat(float* y, const float* x, int64_t n, void* stream) {
+    if (n <= 0) return DASR_EINVAL;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(add_flat_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), y, x, (long long)n);
     return (int)hipGetLastError();
 }
 

@@ -175,16 +175,31 @@ class OpList:
         self.keep.extend(other.keep)
         self._arr = None
 
-    def run(self):
+    def run(self, lo=0, hi=None):
+        """enqueue ops[lo:hi] on the current stream"""
         if not self.ops:
             return
         if self._arr is None:
             self._arr = (Op * len(self.ops))(*self.ops)
+        hi = len(self.ops) if hi is None else min(hi, len(self.ops))
+        if hi <= lo:
+            return
         L = _lib.lib()
-        rc = L.dasr_run_ops(C.cast(self._arr, C.c_void_p), len(self.ops), _stream())
+        rc = L.dasr_run_ops(C.c_void_p(C.addressof(self._arr) + lo * C.sizeof(Op)), hi - lo, _stream())
         if rc != 0:
-            k = L.dasr_last_failed_op()
+            k = L.dasr_last_failed_op() + lo
             raise _lib.DasrHipError('dasr_run_ops: op #%d (kind %d) failed with code %d' % (k, self.ops[k].op if 0 <= k < len(self.ops) else -1, rc))
+
+
+def run_interleaved(lists, streams, chunk=48):
+    """Enqueue several op lists on their own streams, alternating in chunks so that every hardware queue gets work
+    early (the host enqueues ~250k launches/s; a whole 1200-op list first would leave the other stream idle for ms)."""
+    n = max(len(l.ops) for l in lists)
+    for lo in range(0, n, chunk):
+        for l, st in zip(lists, streams):
+            if lo < len(l.ops):
+                with torch.cuda.stream(st):
+                    l.run(lo, lo + chunk)
 
 
 def conv_op(pack, ref, inp, in_f32, cin, Hin, Win, Hout, Wout, N, bias=None, kh=3, stride=1, pad=1, ups=0, act=0, slope=SLOPE,

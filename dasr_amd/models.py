@@ -15,7 +15,7 @@ from collections import Counter, OrderedDict
 import torch
 
 from . import _lib
-from .engine import Op, OpList, NULL_T, ensure_runtime_ready, _stream
+from .engine import Op, OpList, NULL_T, ensure_runtime_ready, _stream, run_interleaved
 from .init import kaiming_state_dict
 from .rrdbnet import RRDBNetHIP, rrdbnet_param_spec
 
@@ -192,49 +192,102 @@ class SRModel(BaseModel):
         if 'HR' in data:
             self.real_H = data['HR'].to(self.device, non_blocking=True)
 
-    def _ops_for(self, plan):
-        """loss op list for this plan: zero the loss accumulator, L1 forward+gradient into plan.g_sr."""
+    def _ops_for(self, plan, n_total):
+        """loss op list for this plan: L1 forward+gradient into plan.g_sr (mean over the WHOLE batch of n_total crops)"""
         key = id(plan)
         if key not in self._step_ops:
-            N, C_, H, W = self.real_H.shape
-            hr_buf = torch.zeros_like(self.real_H)
+            N, C_, H, W = plan.N, self.real_H.shape[1], self.real_H.shape[2], self.real_H.shape[3]
+            hr_buf = torch.zeros((N, C_, H, W), dtype=torch.float32, device=self.device)
             ops = OpList()
-            o = Op()
-            o.op = _lib.OP_FILL
-            o.p[0], o.l[0], o.f[0] = self.loss_acc.data_ptr(), 4, 0.0
-            ops.add(o)
             o = Op()
             o.op = _lib.OP_L1LOSS
             o.t[0], o.p[0], o.p[1] = plan.sr.view(), hr_buf.data_ptr(), None
             o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = N, C_, H, W, 0
-            o.f[0] = float(self.l_pix_w) / float(N * C_ * H * W)
+            o.f[0] = float(self.l_pix_w) / float(n_total * C_ * H * W)
             o.p[2], o.t[1] = self.loss_acc.data_ptr(), plan.g_sr.view()
             ops.add(o)
             self._step_ops[key] = (ops, hr_buf)
         return self._step_ops[key]
 
+    def _sub_plans(self, N, h, w):
+        """Sub-batches processed concurrently on separate HIP streams: at batch 16 one launch has only 512 workgroups
+        (2 per CU) and ~35 % of every kernel is ramp / first-load / epilogue latency; two independent half-batches
+        fill those gaps with each other's main loops.  DASR_STREAMS=1 disables it."""
+        k = max(1, int(os.environ.get('DASR_STREAMS', '2')))
+        if k == 1 or N % k or N // k < 4:
+            return [self.netG.plan(N, h, w)]
+        return [self.netG.plan(N // k, h, w, replica=i) for i in range(k)]
+
     def optimize_parameters(self, step):
         N, _, h, w = self.var_L.shape
-        plan = self.netG.plan(N, h, w)
-        loss_ops, hr_buf = self._ops_for(plan)
-        hr_buf.copy_(self.real_H)
-        plan.set_input(self.var_L)
-        plan.fwd.run()
-        loss_ops.run()
-        if self.dp is None or self.dp.world == 1:
-            plan.bwd.run()
+        plans = self._sub_plans(N, h, w)
+        L = _lib.lib()
+        _lib.check(L.dasr_fill_f32(self.loss_acc.data_ptr(), 4, 0.0, _stream()), 'fill')
+        dp_on = self.dp is not None and self.dp.world > 1
+        if len(plans) == 1:
+            plan = plans[0]
+            loss_ops, hr_buf = self._ops_for(plan, N)
+            hr_buf.copy_(self.real_H)
+            plan.set_input(self.var_L)
+            plan.fwd.run()
+            loss_ops.run()
+            if not dp_on:
+                plan.bwd.run()
+            else:
+                plan.set_grad_scale(self.dp.grad_scale)
+                g = self.netG.params.grad
+                for seg, (lo, hi) in plan.bwd_segments():
+                    seg.run()
+                    self.dp.reduce_async(g[lo:hi])
+                self.dp.wait()
         else:
-            plan.set_grad_scale(self.dp.grad_scale)
+            if not hasattr(self, '_streams'):
+                self._streams = [torch.cuda.Stream() for _ in plans]
+            cur = torch.cuda.current_stream()
+            per = N // len(plans)
+            steps = []
+            for i, (plan, st) in enumerate(zip(plans, self._streams)):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    loss_ops, hr_buf = self._ops_for(plan, N)
+                    hr_buf.copy_(self.real_H[i * per:(i + 1) * per])
+                    plan.set_input(self.var_L[i * per:(i + 1) * per])
+                    if dp_on:
+                        plan.set_grad_scale(self.dp.grad_scale)
+                if not hasattr(plan, 'whole_step'):
+                    ws = OpList()
+                    ws.extend(plan.fwd)
+                    ws.extend(loss_ops)
+                    ws.extend(plan.bwd)
+                    plan.whole_step = ws
+                if dp_on:
+                    plan.whole_step._arr = None  # grad scale may have been patched
+                steps.append(plan.whole_step)
+            run_interleaved(steps, self._streams)
+            for st in self._streams:
+                cur.wait_stream(st)
             g = self.netG.params.grad
-            for seg, (lo, hi) in plan.bwd_segments():
-                seg.run()
-                self.dp.reduce_async(g[lo:hi])
-            self.dp.wait()
+            for plan in plans[1:]:
+                _lib.check(L.dasr_add_flat(g.data_ptr(), plan.grad.data_ptr(), g.numel(), _stream()), 'add_flat')
+            if dp_on:
+                self.dp.allreduce_mean(g)
         self.optimizer_G.step(self.schedulers[0].get_lr())
         self.netG.repack()
-        self.fake_H = plan.read_output()
+        self._out_plans = plans
+        self._fake_H = None
         self._l_pix_dev = self.loss_acc[0:1]
         self.log_dict['l_pix'] = None  # materialised lazily by get_current_log (no per-step host sync)
+
+    @property
+    def fake_H(self):
+        if getattr(self, '_fake_H', None) is not None:
+            return self._fake_H
+        ps = self._out_plans
+        return ps[0].read_output() if len(ps) == 1 else torch.cat([p.read_output() for p in ps], 0)
+
+    @fake_H.setter
+    def fake_H(self, v):
+        self._fake_H = v
 
     def get_current_log(self):
         if 'l_pix' in self.log_dict:
@@ -242,7 +295,6 @@ class SRModel(BaseModel):
         return self.log_dict
 
     def test(self):
-        N, _, h, w = self.var_L.shape
         self.fake_H = self.netG.forward(self.var_L).clone()
 
     def get_current_visuals(self, need_HR=True):

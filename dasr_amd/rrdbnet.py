@@ -89,10 +89,12 @@ class RRDBNetHIP:
         self.pack.run()
 
     # ---- plan ---------------------------------------------------------------------------------------
-    def plan(self, N, h, w):
-        key = (N, h, w)
+    def plan(self, N, h, w, replica=0):
+        """replica > 0: an independent set of buffers for a sub-batch processed concurrently on another stream; its
+        weight gradients go to a private flat buffer (plan.grad) that the trainer adds to params.grad."""
+        key = (N, h, w, replica)
         if key not in self.plans:
-            self.plans[key] = _Plan(self, N, h, w)
+            self.plans[key] = _Plan(self, N, h, w, replica)
         return self.plans[key]
 
     # convenience API used by the trainers / tests -------------------------------------------------------
@@ -115,9 +117,10 @@ class RRDBNetHIP:
 class _Plan:
     """Buffers + recorded forward / backward op lists for one (N, h, w)."""
 
-    def __init__(self, net, N, h, w):
+    def __init__(self, net, N, h, w, replica=0):
         self.net, self.N, self.h, self.w = net, N, h, w
         dev, nf, nb = net.device, net.nf, net.nb
+        self.grad = net.params.grad if replica == 0 else torch.zeros_like(net.params.grad)
         P, pack, pk = net.params, net.pack, net.pk
         H2, W2, H4, W4 = 2 * h, 2 * w, 4 * h, 4 * w
         sc = nf + 4 * GC  # dense-slab channels
@@ -218,7 +221,7 @@ class _Plan:
         grp.add_conv(g.view, g_f32, g.planes, inp.view, in_f32, inp.planes, cout, cin, Hin, Win, Hout, Wout, self.N,
                      P.off(conv_key + 'weight'), P.off(conv_key + 'bias'), ups=ups)
         grp.finalize(self.ws, self.net.device)
-        for o in grp.ops(P.grad.data_ptr()):
+        for o in grp.ops(self.grad.data_ptr()):
             ops.add(o)
         ops.keep.append(grp)
 
@@ -285,7 +288,7 @@ class _Plan:
                     grp.add_conv((lambda c0, gc0=gc0, Gs=Gs: Gs.view(gc0 + c0)), False, cout // 16, S.view, False, cin // 16,
                                  cout, cin, h, w, h, w, N, P.off('%s%d.0.weight' % (pre, j)), P.off('%s%d.0.bias' % (pre, j)))
                 grp.finalize(self.ws, net.device)
-                for o in grp.ops(P.grad.data_ptr()):
+                for o in grp.ops(self.grad.data_ptr()):
                     ops.add(o)
                 ops.keep.append(grp)
                 # g_x conv with the residual bookkeeping fused

@@ -156,6 +156,8 @@ int dasr_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr,
               float weight_decay, int32_t step, void* stream);
 
 int dasr_fill_f32(float* p, int64_t n, float value, void* stream);
+/* y += x over flat fp32 buffers (sum of the gradient buffers of concurrently processed sub-batches) */
+int dasr_add_flat(float* y, const float* x, int64_t n, void* stream);
 
 
 /* ---- GAN-step kernels (csrc/gan.hip) ---------------------------------------------------------------------*/
