@@ -36,7 +36,7 @@ class WgradPart(C.Structure):
 class WgradReducePart(C.Structure):
     _fields_ = [('ws_off', c_i64), ('ws_bias_off', c_i64), ('nsplit', c_i32), ('ntaps', c_i32), ('oc0', c_i32), ('c0', c_i32),
                 ('cout', c_i32), ('cin', c_i32), ('n_ctiles', c_i32), ('dst_w_off', c_i64), ('dst_b_off', c_i64),
-                ('flip_io', c_i32)]
+                ('flip_io', c_i32), ('split_stride', c_i64), ('tap_stride', c_i64), ('bias_stride', c_i64)]
 
 
 class PackSeg(C.Structure):

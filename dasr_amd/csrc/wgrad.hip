@@ -257,33 +257,228 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// wgrad v3 (3x3, stride 1): one workgroup = 6 waves = one 64-channel INPUT block x up to three 32-oc tiles of the
+// gradient slab x all 9 taps.  wave w: oc tile = w >> 1, cin tile = w & 1, 9 accumulators.  Compared with the
+// 4-wave kernel above this halves the bytes staged per MFMA (the input block is shared by three oc tiles instead of
+// one): the dense-block wgrad is bound by L2/HBM traffic, not by MFMA issue.
+// workspace per part: [split][tap][ot 3][oc 32][cin 64]; bias: [split][96]
+// ---------------------------------------------------------------------------------------------------------------
+struct W3 {
+    static constexpr int NTAPS = 9, PH = 8, PW = 16, IH = 10, IW = 18;
+    static constexpr int GPIX = PH * PW, IPIX = IH * IW;
+    static constexpr int GPLANE = GPIX * 32 + 128;
+    static constexpr int IPLANE = IPIX * 32;  // 5760 = 128 (mod 256)
+    static constexpr int G_BYTES = 6 * GPLANE, I_BYTES = 4 * IPLANE;
+    static constexpr int LDS_BYTES = G_BYTES + I_BYTES;
+    static constexpr int NT = 384;
+    static constexpr int GPIECES = 6 * GPIX * 2, IPIECES = 4 * IPIX * 2;
+    static constexpr int GR = (GPIECES + NT - 1) / NT, IR = (IPIECES + NT - 1) / NT;
+};
+
+template <bool USE_TR, bool F32>
+__global__ __launch_bounds__(384, 2) void wgrad3_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit,
+                                                        float* __restrict__ ws) {
+    using C = W3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* gl = smem;
+    char* il = smem + C::G_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int part_id = blockIdx.x / nsplit, split = blockIdx.x - part_id * nsplit;
+    const dasr_wgrad_part P = parts[part_id];
+    const int ot = wave >> 1, ct = wave & 1;
+    const int n_ot = (P.g_planes + 1) >> 1;  // oc tiles present in this part (planes are 16 channels)
+    const bool active = ct < P.n_ctiles && ot < n_ot;
+    const int tiles_x = (P.Wout + C::PW - 1) / C::PW, tiles_y = (P.Hout + C::PH - 1) / C::PH;
+    const int ntiles = tiles_x * tiles_y * P.N;
+    const int HL = P.ups ? 2 * P.Hin : P.Hin, WL = P.ups ? 2 * P.Win : P.Win;
+    constexpr int ESZ = F32 ? 4 : 2;
+    const int gpieces = P.g_planes * C::GPIX * 2, ipieces = 2 * P.n_ctiles * C::IPIX * 2;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+    float bsum = 0.f;
+    const int gg = lane >> 4, li = lane & 15;
+    const int fplane = gg & 1, khalf = gg >> 1;
+    StageReg<F32> greg[C::GR], ireg[C::IR];
+    float bacc[F32 ? C::GR : 1][8];
+    if constexpr (F32) {
+#pragma unroll
+        for (int r = 0; r < C::GR; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bacc[r][j] = 0.f;
+    }
+    char* const dummy = smem + C::LDS_BYTES;
+
+    auto prefetch = [&](int tile) {
+        int t2 = tile;
+        const int tx = t2 % tiles_x;
+        t2 /= tiles_x;
+        const int ty = t2 % tiles_y;
+        const int n = t2 / tiles_y;
+        const int oy0 = ty * C::PH, ox0 = tx * C::PW;
+        const int iy0 = oy0 - P.pad, ix0 = ox0 - P.pad;
+        const __amdgpu_buffer_rsrc_t gb = make_rsrc((const char*)P.g.p + (size_t)n * P.g.n_stride * ESZ);
+        const __amdgpu_buffer_rsrc_t ib = make_rsrc((const char*)P.in.p + (size_t)n * P.in.n_stride * ESZ);
+#pragma unroll
+        for (int r = 0; r < C::GR; ++r) {
+            const int q = tid + r * C::NT;
+            const int half = q & 1, pix = (q >> 1) % C::GPIX, pl = (q >> 1) / C::GPIX;
+            const int py = pix / C::PW, px = pix - py * C::PW;
+            const int oy = oy0 + py, ox = ox0 + px;
+            const bool ok = q < gpieces && oy < P.Hout && ox < P.Wout;
+            stage_load<F32>(greg[r], gb, (unsigned)(pl * (int)P.g.cb_stride + (oy * P.Wout + ox) * 16 + half * 8), ok);
+        }
+#pragma unroll
+        for (int r = 0; r < C::IR; ++r) {
+            const int q = tid + r * C::NT;
+            const int half = q & 1, pix = (q >> 1) % C::IPIX, pl = (q >> 1) / C::IPIX;
+            const int iy = pix / C::IW, ix = pix - iy * C::IW;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            const bool ok = q < ipieces && gy >= 0 && gy < HL && gx >= 0 && gx < WL && pl < P.in_planes;
+            const int sy = P.ups ? gy >> 1 : gy, sx = P.ups ? gx >> 1 : gx;
+            stage_load<F32>(ireg[r], ib, (unsigned)(pl * (int)P.in.cb_stride + (sy * P.Win + sx) * 16 + half * 8), ok);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int r = 0; r < C::GR; ++r) {
+            const int q = tid + r * C::NT;
+            const int half = q & 1, pix = (q >> 1) % C::GPIX, pl = (q >> 1) / C::GPIX;
+            stage_store<F32>(greg[r], q < gpieces ? gl + pl * C::GPLANE + pix * 32 + half * 16 : dummy);
+            if constexpr (F32) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bacc[r][j] += __uint_as_float(greg[r].a[j]);
+                    bacc[r][4 + j] += __uint_as_float(greg[r].b[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < C::IR; ++r) {
+            const int q = tid + r * C::NT;
+            const int half = q & 1, pix = (q >> 1) % C::IPIX, pl = (q >> 1) / C::IPIX;
+            stage_store<F32>(ireg[r], q < ipieces ? il + pl * C::IPLANE + pix * 32 + half * 16 : dummy);
+        }
+    };
+
+    if (split < ntiles) prefetch(split);
+    for (int tile = split; tile < ntiles; tile += nsplit) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (tile + nsplit < ntiles) prefetch(tile + nsplit);
+        if (!active) continue;
+#pragma unroll 2
+        for (int r = 0; r < C::PH; ++r) {
+            bf16x8 a;
+            const int gplane = ot * 2 + fplane;
+            if constexpr (USE_TR) {
+                const int o0 = gplane * C::GPLANE + (r * C::PW + 8 * khalf + (li >> 2)) * 32 + (li & 3) * 8;
+                a = frag_tr(gl, o0, o0 + 4 * 32);
+            } else {
+                const char* b0 = gl + gplane * C::GPLANE + (r * C::PW + 8 * khalf) * 32 + li * 2;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = *(const bf16_t*)(b0 + j * 32);
+            }
+            if constexpr (!F32) {
+                if (P.want_bias && ct == 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum += (float)a[j];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ky = t / 3, kx = t - ky * 3;
+                bf16x8 b;
+                const int prow = (r + ky) * C::IW + kx;
+                if constexpr (USE_TR) {
+                    const int o0 = (ct * 2 + fplane) * C::IPLANE + (prow + 8 * khalf + (li >> 2)) * 32 + (li & 3) * 8;
+                    b = frag_tr(il, o0, o0 + 4 * 32);
+                } else {
+                    const char* b0 = il + (ct * 2 + fplane) * C::IPLANE + (prow + 8 * khalf) * 32 + li * 2;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) b[j] = *(const bf16_t*)(b0 + j * 32);
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    if (active) {
+        float* w = ws + P.ws_off + (size_t)split * 9 * 3 * 2048 + (size_t)ot * 2048;
+        const int cin = ct * 32 + (lane & 31), h = lane >> 5;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int oc = (j & 3) + 8 * (j >> 2) + 4 * h;
+                w[(size_t)t * 3 * 2048 + oc * 64 + cin] = acc[t][j];
+            }
+        if constexpr (!F32) {
+            if (P.want_bias && ct == 0) {
+                const float tot = bsum + __shfl_xor(bsum, 32, 64);
+                if (lane < 32) ws[P.ws_bias_off + (size_t)split * 96 + ot * 32 + lane] = tot;
+            }
+        }
+    }
+    if constexpr (F32) {
+        if (P.want_bias) {
+            __syncthreads();
+            float* red = (float*)smem;  // [384][GR*8] floats = 49 KB <= LDS_BYTES
+#pragma unroll
+            for (int r = 0; r < C::GR; ++r)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[tid * (C::GR * 8) + r * 8 + j] = (tid + r * C::NT < gpieces) ? bacc[r][j] : 0.f;
+            __syncthreads();
+            if (tid < 96) {
+                const int pl = tid >> 4, half = (tid >> 3) & 1, j = tid & 7;
+                float tot = 0.f;
+                for (int t = 0; t < C::NT; ++t) {
+#pragma unroll
+                    for (int r = 0; r < C::GR; ++r) {
+                        const int q = t + r * C::NT;
+                        if (q < gpieces && (q & 1) == half && (q >> 1) / C::GPIX == pl) tot += red[t * (C::GR * 8) + r * 8 + j];
+                    }
+                }
+                ws[P.ws_bias_off + (size_t)split * 96 + tid] = tot;
+            }
+        }
+    }
+}
+
 __global__ void wgrad_reduce_kernel(const dasr_wgrad_reduce_part* __restrict__ parts, int nparts, const float* __restrict__ ws,
                                     float* __restrict__ grad, float scale) {
     const int part_id = blockIdx.y;
     const dasr_wgrad_reduce_part P = parts[part_id];
     const int per = P.ntaps * 32 * 64;
+    const long long sstride = P.split_stride > 0 ? P.split_stride : per, tstride = P.tap_stride > 0 ? P.tap_stride : 2048;
+    const long long bstride = P.bias_stride > 0 ? P.bias_stride : 32;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per + 32; i += gridDim.x * blockDim.x) {
         if (i < per) {
             const int cin = i & 63, oc = (i >> 6) & 31, tap = i >> 11;
             if (cin >= 32 * P.n_ctiles) continue;
             const int goc = P.oc0 + oc, gc = P.c0 + cin;
             if (goc >= P.cout || gc >= P.cin) continue;
-            const float* src = ws + P.ws_off + i;
+            const float* src = ws + P.ws_off + (long long)tap * tstride + (i & 2047);
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
             int sp = 0;
             for (; sp + 4 <= P.nsplit; sp += 4) {  // fixed order -> deterministic; 4 loads in flight
-                s0 += src[(size_t)sp * per];
-                s1 += src[(size_t)(sp + 1) * per];
-                s2 += src[(size_t)(sp + 2) * per];
-                s3 += src[(size_t)(sp + 3) * per];
+                s0 += src[(size_t)sp * sstride];
+                s1 += src[(size_t)(sp + 1) * sstride];
+                s2 += src[(size_t)(sp + 2) * sstride];
+                s3 += src[(size_t)(sp + 3) * sstride];
             }
-            for (; sp < P.nsplit; ++sp) s0 += src[(size_t)sp * per];
+            for (; sp < P.nsplit; ++sp) s0 += src[(size_t)sp * sstride];
             grad[P.dst_w_off + ((size_t)goc * P.cin + gc) * P.ntaps + tap] = ((s0 + s1) + (s2 + s3)) * scale;
         } else if (P.dst_b_off >= 0) {
             const int oc = i - per;
             if (P.oc0 + oc < P.cout) {
                 float s = 0.f;
-                for (int sp = 0; sp < P.nsplit; ++sp) s += ws[P.ws_bias_off + (size_t)sp * 32 + oc];
+                for (int sp = 0; sp < P.nsplit; ++sp) s += ws[P.ws_bias_off + (size_t)sp * bstride + oc];
                 grad[P.dst_b_off + P.oc0 + oc] = s * scale;
             }
         }
@@ -314,6 +509,18 @@ int launch_wgrad(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws
         attr_set = true;
     }
     hipLaunchKernelGGL(kfn, dim3(nparts * nsplit), dim3(256), C::LDS_BYTES + 16, s, parts, nparts, nsplit, ws);
+    return (int)hipGetLastError();
+}
+
+template <bool USE_TR, bool F32>
+int launch_wgrad3(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws, hipStream_t s) {
+    auto kfn = wgrad3_kernel<USE_TR, F32>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, W3::LDS_BYTES + 16));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3(nparts * nsplit), dim3(W3::NT), W3::LDS_BYTES + 16, s, parts, nparts, nsplit, ws);
     return (int)hipGetLastError();
 }
 
@@ -353,6 +560,10 @@ extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int3
     if (nparts <= 0 || nsplit <= 0) return DASR_EINVAL;
     if (g_use_tr < 0) return DASR_EINVAL;  // dasr_probe_tr16 must run once per process (outside graph capture)
     const bool tr = g_use_tr == 1;
+    if (kh == 33) {  // v3 layout: 6-wave workgroups, 3 oc tiles x 64 cin per part (3x3 stride 1 only)
+        if (tr) return f32 ? launch_wgrad3<true, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3<true, false>(parts_dev, nparts, nsplit, ws, s);
+        return f32 ? launch_wgrad3<false, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3<false, false>(parts_dev, nparts, nsplit, ws, s);
+    }
     if (kh == 3 && stride == 1) return dispatch_wgrad<3, 1>(parts_dev, nparts, nsplit, tr, f32 != 0, ws, s);
     if (kh == 4 && stride == 1) return dispatch_wgrad<4, 1>(parts_dev, nparts, nsplit, tr, f32 != 0, ws, s);
     if (kh == 4 && stride == 2) return dispatch_wgrad<4, 2>(parts_dev, nparts, nsplit, tr, f32 != 0, ws, s);

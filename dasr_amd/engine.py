@@ -292,6 +292,66 @@ class WgradGroup:
         return [a, b]
 
 
+class WgradGroup3:
+    """Parts of one 6-wave 3x3 wgrad launch (csrc/wgrad.hip, wgrad3_kernel): a part = one 64-channel input block x up
+    to three consecutive 32-oc tiles of a gradient tensor; every (part, oc tile) has its own reduce descriptor."""
+
+    kh, stride = 3, 1
+
+    def __init__(self):
+        self.parts = []   # (WgradPart, [(ot, dict)])
+
+    def add_block(self, g_view, g_planes, in_view, in_planes, n_ctiles, Hin, Win, Hout, Wout, N, tiles, want_bias, f32=False, ups=0):
+        """tiles: per oc tile of the part: dict(dst_w_off, dst_b_off|None, cout, cin, oc0, c0, n_ctiles) or None (unused tile)"""
+        assert 1 <= len(tiles) <= 3 and g_planes <= 6
+        wp = WgradPart()
+        wp.g, wp.g_f32, wp.inp, wp.in_f32 = g_view, int(f32), in_view, int(f32)
+        wp.ups, wp.n_ctiles, wp.g_planes, wp.in_planes = ups, n_ctiles, g_planes, in_planes
+        wp.Hin, wp.Win, wp.Hout, wp.Wout, wp.N = Hin, Win, Hout, Wout, N
+        wp.kh, wp.stride, wp.pad, wp.want_bias = 3, 1, 1, int(bool(want_bias))
+        self.parts.append((wp, [(i, t) for i, t in enumerate(tiles) if t is not None]))
+
+    def finalize(self, workspace, device, target_wgs=256):
+        wp0 = self.parts[0][0]
+        ntiles = wp0.N * ceil_div(wp0.Hout, 8) * ceil_div(wp0.Wout, 16)
+        nparts = len(self.parts)
+        self.nsplit = max(1, min(ntiles, target_wgs // nparts))
+        if self.nsplit >= 16:
+            self.nsplit -= self.nsplit % 8
+        off, red = 0, []
+        for wp, tiles in self.parts:
+            wp.ws_off = off
+            off += self.nsplit * 9 * 3 * 2048
+            wp.ws_bias_off = off
+            off += self.nsplit * 96
+            for ot, t in tiles:
+                rp = WgradReducePart()
+                rp.ws_off, rp.ws_bias_off = wp.ws_off + ot * 2048, wp.ws_bias_off + ot * 32
+                rp.nsplit, rp.ntaps, rp.oc0, rp.c0 = self.nsplit, 9, t['oc0'], t['c0']
+                rp.cout, rp.cin, rp.n_ctiles = t['cout'], t['cin'], t['n_ctiles']
+                rp.dst_w_off = t['dst_w_off']
+                rp.dst_b_off = t['dst_b_off'] if t.get('dst_b_off') is not None else -1
+                rp.split_stride, rp.tap_stride, rp.bias_stride = 9 * 3 * 2048, 3 * 2048, 96
+                red.append(rp)
+        self.n_red = len(red)
+        self.ws_floats = off
+        self.workspace = workspace
+        workspace.reserve(off)
+        wa = (WgradPart * nparts)(*[p[0] for p in self.parts])
+        ra = (WgradReducePart * len(red))(*red)
+        self.w_dev = torch.frombuffer(bytearray(bytes(wa)), dtype=torch.uint8).to(device)
+        self.r_dev = torch.frombuffer(bytearray(bytes(ra)), dtype=torch.uint8).to(device)
+
+    def ops(self, grad_ptr, scale=1.0):
+        a, b = Op(), Op()
+        a.op = _lib.OP_WGRAD
+        a.p[0], a.i[0], a.i[1], a.i[2], a.i[3], a.i[4] = self.w_dev.data_ptr(), len(self.parts), self.nsplit, 33, 1, self.parts[0][0].g_f32
+        b.op = _lib.OP_WGRAD_REDUCE
+        b.p[0], b.i[0], b.p[2], b.f[0] = self.r_dev.data_ptr(), self.n_red, grad_ptr, scale
+        self.workspace.register(a, b)
+        return [a, b]
+
+
 class Workspace:
     """Grow-only float workspace shared by all wgrad groups of a plan (launches are stream ordered)."""
 

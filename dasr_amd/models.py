@@ -216,6 +216,7 @@ class SRModel(BaseModel):
         k = max(1, int(os.environ.get('DASR_STREAMS', '2')))
         if k == 1 or N % k or N // k < 4:
             return [self.netG.plan(N, h, w)]
+        self.netG.concurrent_replicas = k  # the 1-WG/CU wgrad launches of the replicas must fit on the chip together
         return [self.netG.plan(N // k, h, w, replica=i) for i in range(k)]
 
     def optimize_parameters(self, step):

@@ -6,12 +6,13 @@ Numerics recipe ("recipe A"): the dense-block convs (92% of the F
 stream (fea_conv, LR_conv, the two upconvs, HR_conv0/1) run in split-bf16 (prec 3, ~fp32) on fp32
 activations.  The residual stream itself is kept in fp32; dense-slab channels are stored in bf16.
 """
+import os
 from collections import OrderedDict
 
 import torch
 
 from . import _lib
-from .engine import (BTensor, ParamStore, PackRegistry, OpList, WgradGroup, Workspace, conv_op, ceil_div, SLOPE, NULL_T)
+from .engine import (BTensor, ParamStore, PackRegistry, OpList, WgradGroup, WgradGroup3, Workspace, conv_op, ceil_div, SLOPE, NULL_T)
 from ._lib import Op, Tensor
 
 GC = 32  # growth channels are hard-wired to 32 in the reference (architecture.py:183)
@@ -278,16 +279,29 @@ class _Plan:
                     cin_b = nf + (4 - k) * GC
                     ops.add(conv_op(pack, pk[(i, r, 'b', k)], Gs.view(0), False, cin_b, h, w, h, w, N,
                                     mask=S.view(nf + (k - 1) * GC), mask_f32=0, out_bf16=Gs.view(cin_b)))
-                # weight gradients of the 5 convs of this RDB in one launch
-                grp = WgradGroup(3, 1)
+                # weight gradients of the 5 convs of this RDB in one launch: one part per 64-channel block of the
+                # forward slab x up to three 32-oc tiles of gslab' (= every conv that consumes those channels)
                 pre = 'model.1.sub.%d.RDB%d.conv' % (i, r)
-                for j in range(1, 6):
-                    cin = nf + (j - 1) * GC
-                    cout = GC if j < 5 else nf
-                    gc0 = 0 if j == 5 else nf + (4 - j) * GC
-                    grp.add_conv((lambda c0, gc0=gc0, Gs=Gs: Gs.view(gc0 + c0)), False, cout // 16, S.view, False, cin // 16,
-                                 cout, cin, h, w, h, w, N, P.off('%s%d.0.weight' % (pre, j)), P.off('%s%d.0.bias' % (pre, j)))
-                grp.finalize(self.ws, net.device)
+                gt = []  # gslab' oc tiles in order: conv5 (nf/32 tiles), conv4, conv3, conv2, conv1
+                for j in (5, 4, 3, 2, 1):
+                    cout_j = nf if j == 5 else GC
+                    for oc0 in range(0, cout_j, 32):
+                        gt.append(dict(j=j, oc0=oc0, cout=cout_j, cin=nf + (j - 1) * GC))
+                grp = WgradGroup3()
+                for c0 in range(0, nf + 4 * GC, 64):
+                    need = [t for t in gt if t['cin'] > c0]
+                    blk_ch = min(64, nf + 4 * GC - c0)
+                    for k0 in range(0, len(need), 3):
+                        sub = need[k0:k0 + 3]
+                        tiles = []
+                        for t in sub:
+                            wkey = '%s%d.0.' % (pre, t['j'])
+                            tiles.append(dict(dst_w_off=P.off(wkey + 'weight'), dst_b_off=P.off(wkey + 'bias') if c0 == 0 else None,
+                                              cout=t['cout'], cin=t['cin'], oc0=t['oc0'], c0=c0,
+                                              n_ctiles=min(2, ceil_div(min(t['cin'] - c0, 64), 32))))
+                        grp.add_block(Gs.view(32 * k0), 2 * len(sub), S.view(c0), blk_ch // 16, ceil_div(blk_ch, 32),
+                                      h, w, h, w, N, tiles, want_bias=(c0 == 0))
+                grp.finalize(self.ws, net.device, target_wgs=int(os.environ.get('DASR_WG3_TARGET', str(256 // max(1, getattr(net, 'concurrent_replicas', 1))))))
                 for o in grp.ops(self.grad.data_ptr()):
                     ops.add(o)
                 ops.keep.append(grp)

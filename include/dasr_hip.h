@@ -83,7 +83,9 @@ typedef struct {
     int64_t ws_bias_off;
 } dasr_wgrad_part;
 
-/* f32: g and in tensors of ALL parts are f32 (rounded to bf16 while staging) instead of bf16 */
+/* f32: g and in tensors of ALL parts are f32 (rounded to bf16 while staging) instead of bf16.
+ * kh = 33 selects the 6-wave 3x3 kernel: a part is one 64-channel input block x up to three 32-oc tiles
+ * (g_planes = 2/4/6), workspace [split][tap][3][32][64], bias [split][96]. */
 int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int32_t nsplit, int32_t kh, int32_t stride, int32_t f32,
                float* ws, void* stream);
 /* 1: use ds_read_b64_tr_b16 gathers, 0: scalar LDS gathers.  dasr_probe_tr16 sets it from the device. */
@@ -95,6 +97,8 @@ typedef struct {
     int32_t cout, cin, n_ctiles;            /* real (unpadded) sizes of the conv */
     int64_t dst_w_off;  int64_t dst_b_off;  /* float offsets into the flat grad buffer; dst_b_off < 0: no bias */
     int32_t flip_io;                        /* reserved */
+    /* workspace strides (floats); 0 = the 4-wave layout [split][tap][32][64] / bias [split][32] */
+    int64_t split_stride, tap_stride, bias_stride;
 } dasr_wgrad_reduce_part;
 
 int dasr_wgrad_reduce(const dasr_wgrad_reduce_part* parts_dev, int32_t nparts, const float* ws, float* grad_flat,
