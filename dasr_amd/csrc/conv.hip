@@ -421,6 +421,7 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                 case 4: return launch<1, false, 1, 3, 1, 2>(p, s);          // 8x32 tiles: 2x the workgroups
                 case 5: return launch<1, false, 1, 3, 1, 2, 1, true>(p, s);
                 case 6: return launch<1, false, 1, 3, 1, 1>(p, s);          // 4x32 tiles
+                case 7: return launch<1, false, 1, 3, 1, 8>(p, s);          // 32x32 tiles: -20 % bytes per pixel, half the workgroups
                 default: break;
             }
             return launch<1, false, 1, 3, 1, 4>(p, s);

@@ -450,38 +450,50 @@ __global__ __launch_bounds__(384, 2) void wgrad3_kernel(const dasr_wgrad_part* _
     }
 }
 
-__global__ void wgrad_reduce_kernel(const dasr_wgrad_reduce_part* __restrict__ parts, int nparts, const float* __restrict__ ws,
-                                    float* __restrict__ grad, float scale) {
+// deterministic split reduction: block = 64 consecutive elements x 4 split lanes (fixed summation tree)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const dasr_wgrad_reduce_part* __restrict__ parts, int nparts,
+                                                           const float* __restrict__ ws, float* __restrict__ grad, float scale) {
+    __shared__ float red[256];
     const int part_id = blockIdx.y;
     const dasr_wgrad_reduce_part P = parts[part_id];
     const int per = P.ntaps * 32 * 64;
     const long long sstride = P.split_stride > 0 ? P.split_stride : per, tstride = P.tap_stride > 0 ? P.tap_stride : 2048;
     const long long bstride = P.bias_stride > 0 ? P.bias_stride : 32;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per + 32; i += gridDim.x * blockDim.x) {
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int nblk = (per + 32 + 63) / 64;
+    for (int b = blockIdx.x; b < nblk; b += gridDim.x) {  // uniform per block
+        const int i = b * 64 + e;
+        float s = 0.f;
+        bool valid = false;
+        long long dst = 0;
         if (i < per) {
             const int cin = i & 63, oc = (i >> 6) & 31, tap = i >> 11;
-            if (cin >= 32 * P.n_ctiles) continue;
             const int goc = P.oc0 + oc, gc = P.c0 + cin;
-            if (goc >= P.cout || gc >= P.cin) continue;
-            const float* src = ws + P.ws_off + (long long)tap * tstride + (i & 2047);
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            int sp = 0;
-            for (; sp + 4 <= P.nsplit; sp += 4) {  // fixed order -> deterministic; 4 loads in flight
-                s0 += src[(size_t)sp * sstride];
-                s1 += src[(size_t)(sp + 1) * sstride];
-                s2 += src[(size_t)(sp + 2) * sstride];
-                s3 += src[(size_t)(sp + 3) * sstride];
+            valid = cin < 32 * P.n_ctiles && goc < P.cout && gc < P.cin;
+            if (valid) {
+                const float* src = ws + P.ws_off + (long long)tap * tstride + (i & 2047);
+                float s0 = 0.f, s1 = 0.f;
+                int sp = sl;
+                for (; sp + 4 < P.nsplit; sp += 8) {
+                    s0 += src[(size_t)sp * sstride];
+                    s1 += src[(size_t)(sp + 4) * sstride];
+                }
+                if (sp < P.nsplit) s0 += src[(size_t)sp * sstride];
+                s = s0 + s1;
+                dst = P.dst_w_off + ((long long)goc * P.cin + gc) * P.ntaps + tap;
             }
-            for (; sp < P.nsplit; ++sp) s0 += src[(size_t)sp * sstride];
-            grad[P.dst_w_off + ((size_t)goc * P.cin + gc) * P.ntaps + tap] = ((s0 + s1) + (s2 + s3)) * scale;
-        } else if (P.dst_b_off >= 0) {
+        } else if (i < per + 32 && P.dst_b_off >= 0) {
             const int oc = i - per;
-            if (P.oc0 + oc < P.cout) {
-                float s = 0.f;
-                for (int sp = 0; sp < P.nsplit; ++sp) s += ws[P.ws_bias_off + (size_t)sp * bstride + oc];
-                grad[P.dst_b_off + P.oc0 + oc] = s * scale;
+            valid = P.oc0 + oc < P.cout;
+            if (valid) {
+                for (int sp = sl; sp < P.nsplit; sp += 4) s += ws[P.ws_bias_off + (size_t)sp * bstride + oc];
+                dst = P.dst_b_off + P.oc0 + oc;
             }
         }
+        __syncthreads();
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (sl == 0 && valid) grad[dst] = ((red[e] + red[64 + e]) + (red[128 + e] + red[192 + e])) * scale;
     }
 }
 
@@ -573,6 +585,6 @@ extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int3
 extern "C" int dasr_wgrad_reduce(const dasr_wgrad_reduce_part* parts_dev, int32_t nparts, const float* ws, float* grad_flat,
                                  float scale, void* stream) {
     if (nparts <= 0) return DASR_EINVAL;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(36, nparts), dim3(256), 0, as_stream(stream), parts_dev, nparts, ws, grad_flat, scale);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(145, nparts), dim3(256), 0, as_stream(stream), parts_dev, nparts, ws, grad_flat, scale);
     return (int)hipGetLastError();
 }
