@@ -54,45 +54,56 @@ def make_opt(nf, nb):
                       'pixel_criterion': 'l1', 'pixel_weight': 1.0, 'manual_seed': 0}}
 
 
-def roofline_dominant_kernel(model, plans, reps=5):
+def roofline_dominant_kernel(model, plans, reps=25):
     """Time the Cout=32 dense-block conv kernel (conv1..conv4 of one RDB: Cin 64/96/128/160) the way the step runs it:
-    one launch sequence per concurrently processed sub-batch, each on its own stream, bracketed by HIP events."""
+    one launch sequence per concurrently processed sub-batch, each on its own stream, bracketed by HIP events on the
+    launching stream.  `achieved` is the rate the chip sustains on this kernel = (concurrent launches x algorithmic
+    FLOPs per launch) / average launch duration; with 2 sub-batch streams two launches are in flight at any time, so
+    `avg_launch_us` is what rocprofv3 reports per launch (profiles/) and achieved = launches_concurrent * flops / it."""
     from dasr_amd.engine import OpList
     from dasr_amd import _lib
     ols, flops = [], 0.0
     for plan in plans:
         convs = [o for o in plan.fwd.ops if o.op == _lib.OP_CONV and o.conv.prec == 1 and o.conv.cout == 32][:4]
         ol = OpList()
-        for o in convs:
-            ol.add(o)
+        for _ in range(reps):       # one executor call per stream: the measurement is GPU-bound, not host-launch-bound
+            for o in convs:
+                ol.add(o)
         flops += sum(2.0 * o.conv.N * o.conv.Hout * o.conv.Wout * 9 * o.conv.cin * o.conv.cout for o in convs)
         ols.append(ol)
     streams = [torch.cuda.current_stream()] if len(plans) == 1 else [torch.cuda.Stream() for _ in plans]
     cur = torch.cuda.current_stream()
 
-    def run_all(n):
+    def run_all():
         for st, ol in zip(streams, ols):
             st.wait_stream(cur)
             with torch.cuda.stream(st):
-                for _ in range(n):
-                    ol.run()
+                ol.run()
         for st in streams:
             cur.wait_stream(st)
 
-    run_all(1)
+    run_all()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    run_all(reps)
+    run_all()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    ms = e0.elapsed_time(e1) / reps           # one pass of the 4 convs on every stream
     achieved = flops / (ms * 1e-3) / 1e12
-    nl = 4 * len(plans)
+    k = len(plans)
+    traffic = None
+    try:  # HBM bytes per launch from the committed PMC pass (bench.py cannot collect counters itself), scaled to this launch shape
+        pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_dominant_kernel.json')))
+        per_img = (pm['fetch_size_kb_raw'] * pm['fetch_correction_gfx950'] + pm['write_size_kb']) * 1024.0 / pm['images_per_launch']
+        traffic = round(per_img * plans[0].N)
+    except Exception:
+        pass
     return {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': None,
-            'kernel': 'conv_kernel<prec1,bf16,mt1,3x3,s1> (RDB conv1-4, Cout=32), %d concurrent sub-batch stream(s)' % len(plans),
-            'avg_launch_us': round(ms * 1e3 / nl * len(plans), 1), 'flops_per_launch_avg': flops / nl}
+            'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+            'kernel': 'conv_kernel<1,false,1,3,1,4,1,false> (dense-block conv1-4, Cout=32, bf16 MFMA)',
+            'launches_concurrent': k, 'avg_launch_us': round(ms * 1e3 / 4, 1), 'flops_per_launch': flops / (4 * k),
+            'note': 'achieved = launches_concurrent * flops_per_launch / avg_launch_us (sub-batch streams overlap launches)'}
 
 
 def _usable_cores():
