@@ -1,0 +1,109 @@
+"""Generate tests/golden/dsn_*.npz by running the REFERENCE DSN modules (codes/DSN/model.py, loss.py), imported from
+/root/reference in a process of their own (DSN and SRN both define top-level `model`/`utils`/`loss` modules).
+TEST INFRASTRUCTURE (see oracle/__init__.py).   python -m oracle.gen_golden_dsn
+The reference training loop cannot run on torch >= 1.5 (stale-graph update order); the fixture pins the
+modules and the losses, with both gradients taken from the pre-update graph (the semantics oracle/dsn.py fixes)."""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import fixtures, nets, dsn
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+REF = '/root/reference/codes'
+
+DSN_CASES = {
+    'dsn_gau5_inst_b2_128': dict(filter='gau', k=5, norm='Instance', n=2, crop=128),
+    'dsn_wavelet_inst_b2_128': dict(filter='wavelet', k=5, norm='Instance', n=2, crop=128),
+    'dsn_avg5_inst_b1_160': dict(filter='avg_pool', k=5, norm='Instance', n=1, crop=160),
+}
+
+
+def dsn_state(template_sd, seed, scale):
+    sd = fixtures.seeded_state_dict({k: v for k, v in template_sd.items() if 'gaussian_filter' not in k and 'num_batches' not in k}, seed, scale)
+    out = {}
+    for k, v in template_sd.items():
+        out[k] = sd[k] if k in sd else v.clone()
+    return out
+
+
+def dsn_batch(c, seed=4321):
+    g = torch.Generator().manual_seed(seed)
+    n, s = c['n'], c['crop']
+    return (torch.rand(n, 3, s, s, generator=g), torch.rand(n, 3, s // 4, s // 4, generator=g), torch.rand(n, 3, s // 4, s // 4, generator=g))
+
+
+def collect(G, D, color_filter, per_net, c, w=(1.0, 0.005, 0.01)):
+    hr, bic, real = dsn_batch(c)
+    fake = G(hr)
+    rt, ft = D(real), D(fake)
+    d_loss = -torch.log(rt + 1e-8).mean() - torch.log(1 - ft + 1e-8).mean()
+    tex = torch.mean(-torch.log(ft + 1e-8))
+    col = torch.nn.functional.l1_loss(color_filter(fake), color_filter(bic))
+    per = torch.nn.functional.mse_loss(per_net(fake), per_net(bic))
+    g_loss = w[0] * col + w[1] * tex + w[2] * per
+    dp = [p for p in D.parameters() if p.requires_grad]
+    gd = torch.autograd.grad(d_loss, dp, retain_graph=True)
+    gg = torch.autograd.grad(g_loss, list(G.parameters()))
+    return {'fake_sub': fixtures.subsample(fake).numpy(), 'real_tex_sub': fixtures.subsample(rt).detach().numpy(),
+            'fake_tex_sub': fixtures.subsample(ft).detach().numpy(),
+            'losses': np.array([d_loss.item(), tex.item(), col.item(), per.item(), g_loss.item()]),
+            'gradG_norm': np.array([float(x.double().norm()) for x in gg]), 'gradD_norm': np.array([float(x.double().norm()) for x in gd]),
+            'G_keys': np.array(list(G.state_dict().keys())), 'D_keys': np.array(list(D.state_dict().keys()))}
+
+
+def main():
+    from .ref_import import _mod
+    class DWTForward(nn.Module):
+        def __init__(self, J=1, mode='reflect', wave='haar'):
+            super().__init__()
+            self.h = nets.HaarDWT()
+        def forward(self, x):
+            ll, hc = self.h(x)
+            c = hc.shape[1] // 3
+            return ll, [torch.stack((hc[:, :c], hc[:, c:2 * c], hc[:, 2 * c:]), 2)]
+        def cuda(self):
+            return self
+    _mod('pytorch_wavelets', DWTForward=DWTForward)
+    tv = _mod('torchvision')
+    class _V(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.features = dsn.vgg16_features31(78)
+    tv.models = _mod('torchvision.models')
+    _mod('torchvision.models.vgg', vgg16=lambda pretrained=False: types.SimpleNamespace(features=list(dsn.vgg16_features31(78)) + [nn.Identity()] * 0),
+         vgg19=lambda pretrained=False: None)
+    sk = _mod('skimage'); _mod('skimage.measure', compare_ssim=None); _mod('skimage.color'); _mod('skimage.transform')
+    _mod('IPython', embed=lambda *a, **k: None)
+    _mod('cv2')
+    sys.path[:0] = [os.path.join(REF, 'DSN'), REF]
+    import model as rmodel
+    import loss as rloss
+    os.makedirs(OUT, exist_ok=True)
+    for name, c in DSN_CASES.items():
+        torch.manual_seed(0)
+        G = rmodel.De_resnet(n_res_blocks=8, scale=4)
+        D = rmodel.Discriminator(kernel_size=c['k'], D_arch='FSD', norm_layer=c['norm'], filter_type=c['filter'], cs='cat')
+        G.load_state_dict(dsn_state(G.state_dict(), 21, 0.5))
+        D.load_state_dict(dsn_state(D.state_dict(), 22, 1.0))
+        _cuda = nn.Module.cuda
+        nn.Module.cuda = lambda self, *a, **k: self   # loss.py:63-64 moves the colour filter to the GPU unconditionally
+        try:
+            gl = rloss.GeneratorLoss(kernel_size=c['k'], per_type='VGG', filter=c['filter'], w_col=1, w_tex=0.005, w_per=0.01)
+        finally:
+            nn.Module.cuda = _cuda
+        if c['filter'] == 'wavelet':
+            cf = lambda x: nets.HaarDWT()(x)[0] * 0.5   # reference filter_wavelet_LL calls .cuda(); same arithmetic
+        else:
+            cf = gl.color_filter
+        fx = collect(G, D, cf, gl.perceptual_loss.loss_network, c)
+        np.savez_compressed(os.path.join(OUT, name + '.npz'), **fx)
+        print(name, fx['losses'])
+
+
+if __name__ == '__main__':
+    main()
