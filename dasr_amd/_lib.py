@@ -22,7 +22,7 @@ class ConvParams(C.Structure):
                 ('mask', Tensor), ('mask_f32', c_i32),
                 ('alpha', c_f32), ('res1', Tensor), ('beta1', c_f32), ('res2', Tensor), ('beta2', c_f32),
                 ('out_f32', Tensor), ('out_bf16', Tensor), ('gamma', c_f32), ('xcd_remap', c_i32),
-                ('pad_x', c_i32), ('out_stride', c_i32), ('out_oy', c_i32), ('out_ox', c_i32), ('out_W', c_i32)]
+                ('pad_x', c_i32), ('out_stride', c_i32), ('out_oy', c_i32), ('out_ox', c_i32), ('out_W', c_i32), ('slope_ptr', c_vp)]
 
 
 class WgradPart(C.Structure):
@@ -30,13 +30,14 @@ class WgradPart(C.Structure):
                 ('g_planes', c_i32), ('in_planes', c_i32),
                 ('Hin', c_i32), ('Win', c_i32), ('Hout', c_i32), ('Wout', c_i32), ('N', c_i32),
                 ('kh', c_i32), ('stride', c_i32), ('pad', c_i32), ('want_bias', c_i32),
-                ('ws_off', c_i64), ('ws_bias_off', c_i64)]
+                ('ws_off', c_i64), ('ws_bias_off', c_i64), ('tap0', c_i32)]
 
 
 class WgradReducePart(C.Structure):
     _fields_ = [('ws_off', c_i64), ('ws_bias_off', c_i64), ('nsplit', c_i32), ('ntaps', c_i32), ('oc0', c_i32), ('c0', c_i32),
                 ('cout', c_i32), ('cin', c_i32), ('n_ctiles', c_i32), ('dst_w_off', c_i64), ('dst_b_off', c_i64),
-                ('flip_io', c_i32), ('split_stride', c_i64), ('tap_stride', c_i64), ('bias_stride', c_i64)]
+                ('flip_io', c_i32), ('split_stride', c_i64), ('tap_stride', c_i64), ('bias_stride', c_i64),
+                ('tap0', c_i32), ('ntaps_total', c_i32)]
 
 
 class PackSeg(C.Structure):
@@ -46,7 +47,7 @@ class PackSeg(C.Structure):
 
 class PackDesc(C.Structure):
     _fields_ = [('dst_off', c_i64), ('lo_off', c_i64), ('cout', c_i32), ('cin_pad', c_i32), ('ntaps', c_i32), ('mt', c_i32),
-                ('nseg', c_i32), ('src_ntaps', c_i32), ('tapmap', C.c_int8 * 16), ('seg', PackSeg * 5)]
+                ('nseg', c_i32), ('src_ntaps', c_i32), ('tapmap', C.c_int8 * 32), ('seg', PackSeg * 5)]
 
 
 class Op(C.Structure):
@@ -56,7 +57,7 @@ class Op(C.Structure):
 
 OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_DOWNSUM, OP_AXPBY, OP_FILL, OP_L1LOSS, OP_NCHW2B, OP_B2NCHW = range(1, 11)
 (OP_INORM_FWD, OP_INORM_BWD, OP_BCE, OP_DWT_FWD, OP_DWT_BWD, OP_LOWPASS, OP_MAXPOOL, OP_MAXPOOL_BWD, OP_L1DIFF, OP_AFFINE4,
- OP_BILINEAR) = range(11, 22)
+ OP_BILINEAR, OP_LOGLOSS, OP_SIGMOID_BWD, OP_PRELU_GRAD, OP_LOWPASS_VALID, OP_ADD_FLAT) = range(11, 27)
 
 _SIGS = {
     'dasr_conv': [C.POINTER(ConvParams), c_vp],
@@ -70,7 +71,7 @@ _SIGS = {
     'dasr_blocked_to_nchw': [Tensor, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
     'dasr_l1_loss': [Tensor, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, Tensor, c_i32, c_vp],
     'dasr_downsum2x': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_f32, Tensor, Tensor, c_vp],
-    'dasr_axpby': [Tensor, c_f32, Tensor, c_f32, c_i32, c_i32, c_i32, c_i32, Tensor, Tensor, c_f32, c_vp],
+    'dasr_axpby': [Tensor, c_f32, Tensor, c_f32, c_i32, c_i32, c_i32, c_i32, Tensor, Tensor, c_f32, Tensor, c_f32, c_vp, c_vp],
     'dasr_adam': [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp],
     'dasr_fill_f32': [c_vp, c_i64, c_f32, c_vp],
     'dasr_add_flat': [c_vp, c_vp, c_i64, c_vp],
@@ -85,6 +86,10 @@ _SIGS = {
     'dasr_l1_diff': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, Tensor, c_vp],
     'dasr_affine4': [Tensor, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, Tensor, c_i32, c_i32, c_vp],
     'dasr_bilinear_up': [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
+    'dasr_logloss': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp, c_f32, Tensor, c_i32, c_vp],
+    'dasr_sigmoid_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_vp],
+    'dasr_prelu_grad': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_vp],
+    'dasr_lowpass_valid': [Tensor, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_vp],
     'dasr_run_ops': [c_vp, c_i32, c_vp],
     'dasr_last_failed_op': [],
     'dasr_abi_version': [],

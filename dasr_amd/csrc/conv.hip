@@ -242,7 +242,9 @@ __global__ __launch_bounds__(256, (MT == 1 && PREC == 1 && !IN_F32) ? 3 : 2) voi
     constexpr int MSZ = IN_F32 ? 4 : 2;
     const bool has_mask = p.mask.p != nullptr, has_r1 = p.res1.p != nullptr, has_r2 = p.res2.p != nullptr;
     const bool has_f32 = p.out_f32.p != nullptr, has_bf16 = p.out_bf16.p != nullptr;
-    const float act_slope = p.act ? p.slope : 1.f, mask_slope = has_mask ? p.slope : 1.f;
+    const float slope = p.slope_ptr ? *p.slope_ptr : p.slope;  // PReLU: the (learned) slope lives in the parameter buffer
+    const float act_slope = p.act == 1 ? slope : 1.f, mask_slope = has_mask ? slope : 1.f;
+    const bool act_sigmoid = p.act == 2;
     const float beta1 = has_r1 ? p.beta1 : 0.f, beta2 = has_r2 ? p.beta2 : 0.f;
     const __amdgpu_buffer_rsrc_t rmask = make_rsrc((const char*)p.mask.p + (size_t)n * p.mask.n_stride * MSZ);
     const __amdgpu_buffer_rsrc_t rr1 = make_rsrc((const float*)p.res1.p + (size_t)n * p.res1.n_stride);
@@ -307,6 +309,7 @@ __global__ __launch_bounds__(256, (MT == 1 && PREC == 1 && !IN_F32) ? 3 : 2) voi
                 for (int j = 0; j < 4; ++j) {
                     float t = acc[mi][nt][4 * g + j] + bia[mi][g][j];
                     t = fmaxf(t, 0.f) + act_slope * fminf(t, 0.f);
+                    if (act_sigmoid) t = 1.f / (1.f + __expf(-t));
                     t *= __uint_as_float(mk[g][j]) > 0.f ? 1.f : mask_slope;
                     t = p.alpha * t + beta1 * __uint_as_float(r1v[g][j]) + beta2 * __uint_as_float(r2v[g][j]);
                     v[j] = (oc + j < p.cout) ? t : 0.f;  // padded channels of the last plane stay zero
@@ -368,12 +371,14 @@ __global__ void conv_naive_kernel(const dasr_conv_params p, const float* w) {
                 acc += x * w[(((size_t)oc * p.cin + c) * p.kh + ky) * p.kh + kx];
             }
     if (p.bias) acc += p.bias[oc];
-    if (p.act) acc = acc > 0.f ? acc : acc * p.slope;
+    const float nslope = p.slope_ptr ? *p.slope_ptr : p.slope;
+    if (p.act == 1) acc = acc > 0.f ? acc : acc * nslope;
+    if (p.act == 2) acc = 1.f / (1.f + expf(-acc));
     const size_t po = ((size_t)oy * p.Wout + ox) * 16 + (oc & 15);
     if (p.mask.p) {
         const size_t mo = (size_t)n * p.mask.n_stride + (size_t)(oc >> 4) * p.mask.cb_stride + po;
         const float m = p.mask_f32 ? ((const float*)p.mask.p)[mo] : (float)((const bf16_t*)p.mask.p)[mo];
-        acc = m > 0.f ? acc : acc * p.slope;
+        acc = m > 0.f ? acc : acc * nslope;
     }
     acc *= p.alpha;
     if (p.res1.p) acc += p.beta1 * ((const float*)p.res1.p)[(size_t)n * p.res1.n_stride + (size_t)(oc >> 4) * p.res1.cb_stride + po];
@@ -401,15 +406,23 @@ extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
 extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
     dasr_conv_params p = *pp;
     p.xcd_remap = g_tune_xcd;
-    if (p.pad_x == 0 && p.out_stride == 0 && p.kh != 2) p.pad_x = -1;  // zero-initialised extension fields = "same as pad"
+    if (p.pad_x == 0 && p.out_stride == 0 && p.kh != 2 && p.kh != 1) p.pad_x = -1;  // zero-initialised extension fields = "same as pad"
     hipStream_t s = as_stream(stream);
     if (p.cin <= 0 || (p.cin & 15) || p.cout <= 0 || !p.w || !p.in.p) return DASR_EINVAL;
     if (!(p.mt == 1 || p.mt == 2) || !(p.prec == 1 || p.prec == 3)) return DASR_EINVAL;
-    const int key = (p.prec == 3 ? 1000 : 0) + (p.in_f32 ? 100 : 0) + p.mt * 10 + (p.kh == 4 ? (p.stride == 2 ? 2 : 1) : (p.kh == 2 ? 3 : 0));
-    if (p.kh == 3 && (p.stride != 1 || p.pad != 1)) return DASR_EINVAL;
+    int kcode = 0;
+    if (p.kh == 4) kcode = p.stride == 2 ? 2 : 1;
+    else if (p.kh == 2) kcode = 3;
+    else if (p.kh == 5) kcode = 4;
+    else if (p.kh == 1) kcode = 5;
+    else if (p.kh == 3 && p.stride == 2) kcode = 6;
+    const int key = (p.prec == 3 ? 1000 : 0) + (p.in_f32 ? 100 : 0) + p.mt * 10 + kcode;
+    if (p.kh == 3 && ((p.stride != 1 && p.stride != 2) || p.pad != 1)) return DASR_EINVAL;
+    if (p.kh == 5 && (p.stride != 1 || p.pad != 2)) return DASR_EINVAL;
+    if (p.kh == 1 && (p.stride != 1 || p.pad != 0)) return DASR_EINVAL;
     if (p.kh == 4 && ((p.stride != 1 && p.stride != 2) || p.pad < 0 || p.pad > 3)) return DASR_EINVAL;
     if (p.kh == 2 && (p.stride != 1 || p.pad < 0 || p.pad > 1)) return DASR_EINVAL;
-    if (p.kh != 3 && p.kh != 4 && p.kh != 2) return DASR_EINVAL;
+    if (p.kh < 1 || p.kh > 5) return DASR_EINVAL;
     if (p.mask.p && (p.mask_f32 != 0) != (p.in_f32 != 0)) return DASR_EINVAL;  // mask dtype is tied to the input dtype
     switch (key) {
         // prec 1, bf16 input (RDB dense-block convs, fwd and dgrad)
@@ -445,6 +458,9 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
         case 1111: return launch<3, true, 1, 4, 1, 2>(p, s);
         case 1112: return launch<3, true, 1, 4, 2, 1>(p, s);
         case 1113: return launch<3, true, 1, 2, 1, 4>(p, s);  // 2x2 parity sub-convs of the stride-2 data-gradient
+        case 1114: return launch<3, true, 1, 5, 1, 2>(p, s);  // DSN FSD discriminator 5x5
+        case 1115: return launch<3, true, 1, 1, 1, 4>(p, s);  // 1x1 head
+        case 1116: return launch<3, true, 1, 3, 2, 1>(p, s);  // De_resnet down-sampling convs
         default: return DASR_EINVAL;
     }
 }

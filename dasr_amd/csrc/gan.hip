@@ -247,8 +247,15 @@ __global__ void dwt_bwd_kernel(dasr_tensor gll, dasr_tensor ghc, int N, int C, i
 //   mode 1 (adjoint): out_low(=gx) (+)= low(g_low) + a_h * (g_high - low(g_high))   (the kernel is symmetric)
 // Thread per pixel; the window is read through L1/L2 (3-4 floats per tap).
 // ---------------------------------------------------------------------------------------------------
-__global__ void lowpass_kernel(dasr_tensor x, dasr_tensor x2, const float* __restrict__ w, int k, int N, int C, int H, int W, int mode,
+__device__ __forceinline__ float valid_frac(int y, int x, int H, int W, int k, int r) {
+    // fraction of the k x k window centred at (y, x) that lies inside the image (uniform kernel: = sum of used weights)
+    const int ny = min(y + r, H - 1) - max(y - r, 0) + 1, nx = min(x + r, W - 1) - max(x - r, 0) + 1;
+    return (float)(ny * nx) / (float)(k * k);
+}
+
+__global__ void lowpass_kernel(dasr_tensor x, dasr_tensor x2, const float* __restrict__ w, int k, int N, int C, int H, int W, int mode_,
                                float a_h, float b_h, dasr_tensor out_low, dasr_tensor out_high, int accumulate) {
+    const int mode = mode_ & 1, norm_valid = (mode_ >> 1) & 1;  // norm_valid: AvgPool2d(count_include_pad=False)
     const long long total = (long long)N * H * W;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -266,11 +273,16 @@ __global__ void lowpass_kernel(dasr_tensor x, dasr_tensor x2, const float* __res
         for (int kx = 0; kx < k; ++kx) {
             const int sx = xx + kx - r;
             if (sx < 0 || sx >= W) continue;
-            const float wt = w[ky * k + kx];
+            float wt = w[ky * k + kx];
+            if (norm_valid && mode == 1) wt /= valid_frac(sy, sx, H, W, k, r);  // adjoint: the normaliser belongs to the OUTPUT pixel
             const size_t o = ((size_t)sy * W + sx) * 16;
             if (xp) lo += *(const f32x4*)(xp + o) * wt;
             if (x2p) lo2 += *(const f32x4*)(x2p + o) * wt;
         }
+    }
+    if (norm_valid && mode == 0) {
+        const float inv = 1.f / valid_frac(yy, xx, H, W, k, r);
+        lo *= inv;
     }
     const size_t po = ((size_t)yy * W + xx) * 16;
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -375,7 +387,8 @@ __global__ void maxpool_bwd_kernel(dasr_tensor x, dasr_tensor gy, int N, int C, 
 
 // L1 between two blocked tensors over all C channels: loss_acc += coef*sum|a-b|; ga = gcoef*sign(a-b)
 template <typename T>
-__global__ void l1_diff_kernel(dasr_tensor a, dasr_tensor b, int N, int C, int H, int W, float coef, float gcoef, float* loss_acc, dasr_tensor ga) {
+__global__ void l1_diff_kernel(dasr_tensor a, dasr_tensor b, int N, int C, int H, int W, float coef, float gcoef, float* loss_acc, dasr_tensor ga,
+                               int squared) {
     __shared__ float red[4];
     const int ncb = (C + 15) >> 4;
     const long long per = (long long)H * W * 4;
@@ -394,8 +407,8 @@ __global__ void l1_diff_kernel(dasr_tensor a, dasr_tensor b, int N, int C, int H
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float d = (c0 + j < C) ? (float)ap[j] - (float)bp[j] : 0.f;
-            l += fabsf(d);
-            g[j] = gcoef * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+            l += squared ? d * d : fabsf(d);
+            g[j] = squared ? gcoef * 2.f * d : gcoef * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
         }
         if (ga.p) {
             T* gp = (T*)ga.p + (size_t)n * ga.n_stride + (size_t)cb * ga.cb_stride + e;
@@ -449,6 +462,139 @@ __global__ void bilinear_up_kernel(const float* __restrict__ src, int N, int h, 
     const float ly = sy - y0, lx = sx - x0;
     const float* s = src + (size_t)n * h * w;
     dst[i] = (1.f - ly) * ((1.f - lx) * s[y0 * w + x0] + lx * s[y0 * w + x1]) + ly * ((1.f - lx) * s[y1 * w + x0] + lx * s[y1 * w + x1]);
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// DSN kernels (codes/DSN): -log losses on sigmoid(logits), sigmoid backward, PReLU slope gradient,
+// "valid" (un-padded) low-pass of the colour loss and its adjoint.
+// ---------------------------------------------------------------------------------------------------
+// mode 0: l = -log(p + eps); mode 1: l = -log(1 - p + eps), p = sigmoid(x) on channel 0.
+// loss_acc += coef*sum(l); score_acc += score_coef*sum(p); grad (+)= gcoef * dl/dx
+__global__ void logloss_kernel(dasr_tensor x, int N, int H, int W, int mode, float eps, float coef, float gcoef, float* loss_acc,
+                               float* score_acc, float score_coef, dasr_tensor grad, int accumulate) {
+    __shared__ float red[4];
+    const long long total = (long long)N * H * W;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float l = 0.f, sc = 0.f;
+    if (i < total) {
+        const int n = i / ((long long)H * W);
+        const long long pix = i - (long long)n * H * W;
+        const float v = ((const float*)x.p)[(size_t)n * x.n_stride + (size_t)pix * 16];
+        const float p = 1.f / (1.f + expf(-v));
+        sc = p;
+        const float dp = p * (1.f - p);
+        float g;
+        if (mode == 0) {
+            l = -logf(p + eps);
+            g = -dp / (p + eps);
+        } else {
+            l = -logf(1.f - p + eps);
+            g = dp / (1.f - p + eps);
+        }
+        if (grad.p) {
+            float* gp = (float*)grad.p + (size_t)n * grad.n_stride + (size_t)pix * 16;
+            f32x4 o = {gcoef * g, 0.f, 0.f, 0.f};
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            if (accumulate) o += ((f32x4*)gp)[0];
+            ((f32x4*)gp)[0] = o;
+            if (!accumulate) { ((f32x4*)gp)[1] = z; ((f32x4*)gp)[2] = z; ((f32x4*)gp)[3] = z; }
+        }
+    }
+    const float tl = block_sum_256(l, red);
+    const float ts = block_sum_256(sc, red);
+    if (threadIdx.x == 0) {
+        if (loss_acc) atomicAdd(loss_acc, tl * coef);
+        if (score_acc) atomicAdd(score_acc, ts * score_coef);
+    }
+}
+
+// gz = g * y * (1 - y) on C (<= 4) channels of plane 0 (y = sigmoid output of the generator, model.py:55)
+__global__ void sigmoid_bwd_kernel(dasr_tensor y, dasr_tensor g, int N, int C, int H, int W, dasr_tensor gz) {
+    const long long total = (long long)N * H * W;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int n = i / ((long long)H * W);
+    const long long p = i - (long long)n * H * W;
+    const f32x4 yv = *(const f32x4*)((const float*)y.p + (size_t)n * y.n_stride + (size_t)p * 16);
+    const f32x4 gv = *(const f32x4*)((const float*)g.p + (size_t)n * g.n_stride + (size_t)p * 16);
+    f32x4 o = gv * yv * (1.f - yv);
+    for (int j = 0; j < 4; ++j)
+        if (j >= C) o[j] = 0.f;
+    float* op = (float*)gz.p + (size_t)n * gz.n_stride + (size_t)p * 16;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    ((f32x4*)op)[0] = o; ((f32x4*)op)[1] = z; ((f32x4*)op)[2] = z; ((f32x4*)op)[3] = z;
+}
+
+// nn.PReLU() with one shared slope a: y = x > 0 ? x : a x.  Given y and gx = dL/dx (already masked by PReLU'),
+// dL/da = sum_{y <= 0} (gx / a) * (y / a).  Two deterministic stages: per-block partials, then one block.
+__global__ void prelu_grad_partial_kernel(dasr_tensor y, dasr_tensor gx, int N, int C, int H, int W, float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int ncb = (C + 15) >> 4;
+    const long long per = (long long)H * W * 4;
+    const long long total = (long long)N * ncb * per;
+    float s = 0.f;
+    for (long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += (long long)gridDim.x * blockDim.x) {
+        const long long e = (gi % per) * 4;
+        long long t = gi / per;
+        const int cb = t % ncb;
+        const int n = t / ncb;
+        const f32x4 yv = *(const f32x4*)((const float*)y.p + (size_t)n * y.n_stride + (size_t)cb * y.cb_stride + e);
+        const f32x4 gv = *(const f32x4*)((const float*)gx.p + (size_t)n * gx.n_stride + (size_t)cb * gx.cb_stride + e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (yv[j] <= 0.f) s += gv[j] * yv[j];
+    }
+    const float tot = block_sum_256(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ void prelu_grad_final_kernel(const float* __restrict__ partial, int nblocks, const float* __restrict__ slope, float* __restrict__ dst,
+                                        float scale) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < nblocks; ++i) s += partial[i];
+        const float a = *slope;
+        *dst = scale * s / (a * a);
+    }
+}
+
+// un-padded ("valid") depthwise k x k low-pass on C (<= 4) channels: out is (H-k+1) x (W-k+1) (FilterLow(padding=False),
+// codes/DSN/loss.py:52-56).  mode 0 forward; mode 1 adjoint (gx (+)= sum_q w * g_low[q]).
+__global__ void lowpass_valid_kernel(dasr_tensor x, const float* __restrict__ w, int k, int N, int C, int H, int W, int mode, dasr_tensor out,
+                                     int accumulate) {
+    const int Ho = H - k + 1, Wo = W - k + 1;
+    const int OH = mode == 0 ? Ho : H, OW = mode == 0 ? Wo : W;
+    const long long total = (long long)N * OH * OW;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int xx = i % OW;
+    long long t = i / OW;
+    const int yy = t % OH;
+    const int n = t / OH;
+    const float* xp = (const float*)x.p + (size_t)n * x.n_stride;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (mode == 0) {
+        for (int ky = 0; ky < k; ++ky)
+            for (int kx = 0; kx < k; ++kx) acc += *(const f32x4*)(xp + ((size_t)(yy + ky) * W + xx + kx) * 16) * w[ky * k + kx];
+    } else {  // x = g_low with dims Ho x Wo; output pixel (yy, xx) of the full image
+        for (int ky = 0; ky < k; ++ky) {
+            const int qy = yy - ky;
+            if (qy < 0 || qy >= Ho) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int qx = xx - kx;
+                if (qx < 0 || qx >= Wo) continue;
+                acc += *(const f32x4*)(xp + ((size_t)qy * Wo + qx) * 16) * w[ky * k + kx];
+            }
+        }
+    }
+    for (int j = 0; j < 4; ++j)
+        if (j >= C) acc[j] = 0.f;
+    float* op = (float*)out.p + (size_t)n * out.n_stride + ((size_t)yy * OW + xx) * 16;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (accumulate) acc += ((f32x4*)op)[0];
+    ((f32x4*)op)[0] = acc;
+    if (!accumulate) { ((f32x4*)op)[1] = z; ((f32x4*)op)[2] = z; ((f32x4*)op)[3] = z; }
 }
 
 }  // namespace
@@ -520,10 +666,12 @@ extern "C" int dasr_maxpool2_bwd(dasr_tensor x, dasr_tensor gy, int32_t is_f32, 
 
 extern "C" int dasr_l1_diff(dasr_tensor a, dasr_tensor b, int32_t is_f32, int32_t N, int32_t C, int32_t H, int32_t W, float coef, float gcoef,
                             float* loss_acc, dasr_tensor ga, void* stream) {
+    const int squared = is_f32 >> 1;  // bit 1 of the dtype flag selects the squared (MSE) form
+    is_f32 &= 1;
     const long long total = (long long)N * ((C + 15) / 16) * H * W * 4;
     if (total <= 0) return DASR_EINVAL;
-    if (is_f32) hipLaunchKernelGGL(l1_diff_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), a, b, N, C, H, W, coef, gcoef, loss_acc, ga);
-    else hipLaunchKernelGGL(l1_diff_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), a, b, N, C, H, W, coef, gcoef, loss_acc, ga);
+    if (is_f32) hipLaunchKernelGGL(l1_diff_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), a, b, N, C, H, W, coef, gcoef, loss_acc, ga, squared);
+    else hipLaunchKernelGGL(l1_diff_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), a, b, N, C, H, W, coef, gcoef, loss_acc, ga, squared);
     return (int)hipGetLastError();
 }
 
@@ -541,5 +689,37 @@ extern "C" int dasr_bilinear_up(const float* src, int32_t N, int32_t h, int32_t 
     const long long total = (long long)N * h * w * factor * factor;
     if (total <= 0) return DASR_EINVAL;
     hipLaunchKernelGGL(bilinear_up_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), src, N, h, w, factor, dst);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_logloss(dasr_tensor x, int32_t N, int32_t H, int32_t W, int32_t mode, float eps, float coef, float gcoef, float* loss_acc,
+                            float* score_acc, float score_coef, dasr_tensor grad, int32_t accumulate, void* stream) {
+    const long long total = (long long)N * H * W;
+    if (total <= 0) return DASR_EINVAL;
+    hipLaunchKernelGGL(logloss_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, H, W, mode, eps, coef, gcoef, loss_acc, score_acc,
+                       score_coef, grad, accumulate);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_sigmoid_bwd(dasr_tensor y, dasr_tensor g, int32_t N, int32_t C, int32_t H, int32_t W, dasr_tensor gz, void* stream) {
+    const long long total = (long long)N * H * W;
+    if (total <= 0 || C > 4) return DASR_EINVAL;
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), y, g, N, C, H, W, gz);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_prelu_grad(dasr_tensor y, dasr_tensor gx, int32_t N, int32_t C, int32_t H, int32_t W, const float* slope, float* scratch256,
+                               float* dst, float scale, void* stream) {
+    if ((long long)N * C * H * W <= 0) return DASR_EINVAL;
+    hipLaunchKernelGGL(prelu_grad_partial_kernel, dim3(256), dim3(256), 0, as_stream(stream), y, gx, N, C, H, W, scratch256);
+    hipLaunchKernelGGL(prelu_grad_final_kernel, dim3(1), dim3(64), 0, as_stream(stream), scratch256, 256, slope, dst, scale);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_lowpass_valid(dasr_tensor x, const float* w, int32_t k, int32_t N, int32_t C, int32_t H, int32_t W, int32_t mode,
+                                  dasr_tensor out, int32_t accumulate, void* stream) {
+    const long long total = (long long)N * (mode == 0 ? (H - k + 1) * (long long)(W - k + 1) : (long long)H * W);
+    if (total <= 0 || C > 4 || H < k || W < k) return DASR_EINVAL;
+    hipLaunchKernelGGL(lowpass_valid_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, w, k, N, C, H, W, mode, out, accumulate);
     return (int)hipGetLastError();
 }

@@ -190,7 +190,7 @@ __global__ void downsum2x_kernel(dasr_tensor src, int N, int C, int H, int W, da
 }
 
 __global__ void axpby_kernel(dasr_tensor x, float a, dasr_tensor z, float b, int N, int C, int H, int W, dasr_tensor of,
-                             dasr_tensor ob, float gamma) {
+                             dasr_tensor ob, float gamma, dasr_tensor mask, float slope, const float* slope_ptr) {
     const int ncb = (C + 15) >> 4;
     const long long per_plane = (long long)H * W * 4;  // f32x4 pieces
     const long long total = (long long)N * ncb * per_plane;
@@ -202,6 +202,11 @@ __global__ void axpby_kernel(dasr_tensor x, float a, dasr_tensor z, float b, int
     const int n = t / ncb;
     f32x4 v = *(const f32x4*)((const float*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + e) * a;
     if (z.p) v += *(const f32x4*)((const float*)z.p + (size_t)n * z.n_stride + (size_t)cb * z.cb_stride + e) * b;
+    if (mask.p) {  // (Leaky/P)ReLU' of the f32 activation `mask`, applied after the sum
+        const float sl = slope_ptr ? *slope_ptr : slope;
+        const f32x4 mv = *(const f32x4*)((const float*)mask.p + (size_t)n * mask.n_stride + (size_t)cb * mask.cb_stride + e);
+        for (int j = 0; j < 4; ++j) v[j] = mv[j] > 0.f ? v[j] : v[j] * sl;
+    }
     if (of.p) *(f32x4*)((float*)of.p + (size_t)n * of.n_stride + (size_t)cb * of.cb_stride + e) = v;
     if (ob.p) {
         bf16x4 o;
@@ -279,10 +284,11 @@ extern "C" int dasr_downsum2x(dasr_tensor src, int32_t N, int32_t C, int32_t H, 
 }
 
 extern "C" int dasr_axpby(dasr_tensor x, float a, dasr_tensor z, float b, int32_t N, int32_t C, int32_t H, int32_t W,
-                          dasr_tensor out_f32, dasr_tensor out_bf16, float gamma, void* stream) {
+                          dasr_tensor out_f32, dasr_tensor out_bf16, float gamma, dasr_tensor mask, float slope, const float* slope_ptr,
+                          void* stream) {
     const long long total = (long long)N * ((C + 15) / 16) * H * W * 4;
     if (total <= 0) return DASR_EINVAL;
-    hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), x, a, z, b, N, C, H, W, out_f32, out_bf16, gamma);
+    hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), x, a, z, b, N, C, H, W, out_f32, out_bf16, gamma, mask, slope, slope_ptr);
     return (int)hipGetLastError();
 }
 
@@ -333,7 +339,7 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream) {
                 rc = dasr_pack_weights((const dasr_pack_desc*)o.p[0], o.i[0], o.l[0], (const int64_t*)o.p[1], (const float*)o.p[2], o.p[3], stream);
                 break;
             case DASR_OP_DOWNSUM: rc = dasr_downsum2x(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1], o.i[4], o.f[0], o.t[2], o.t[3], stream); break;
-            case DASR_OP_AXPBY: rc = dasr_axpby(o.t[0], o.f[0], o.t[1], o.f[1], o.i[0], o.i[1], o.i[2], o.i[3], o.t[2], o.t[3], o.f[2], stream); break;
+            case DASR_OP_AXPBY: rc = dasr_axpby(o.t[0], o.f[0], o.t[1], o.f[1], o.i[0], o.i[1], o.i[2], o.i[3], o.t[2], o.t[3], o.f[2], o.t[4], o.f[3], (const float*)o.p[0], stream); break;
             case DASR_OP_FILL: rc = dasr_fill_f32((float*)o.p[0], o.l[0], o.f[0], stream); break;
             case DASR_OP_L1LOSS:
                 rc = dasr_l1_loss(o.t[0], (const float*)o.p[0], (const float*)o.p[1], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], (float*)o.p[2], o.t[1],
@@ -358,6 +364,15 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream) {
                 break;
             case DASR_OP_AFFINE4: rc = dasr_affine4(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], &o.f[0], (const float*)o.l, o.t[1], o.i[4], o.i[5], stream); break;
             case DASR_OP_BILINEAR: rc = dasr_bilinear_up((const float*)o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], (float*)o.p[1], stream); break;
+            case DASR_OP_LOGLOSS:
+                rc = dasr_logloss(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.f[1], o.f[2], (float*)o.p[0], (float*)o.p[1], o.f[3], o.t[1], o.i[4], stream);
+                break;
+            case DASR_OP_SIGMOID_BWD: rc = dasr_sigmoid_bwd(o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.t[2], stream); break;
+            case DASR_OP_PRELU_GRAD:
+                rc = dasr_prelu_grad(o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], (const float*)o.p[0], (float*)o.p[1], (float*)o.p[2], o.f[0], stream);
+                break;
+            case DASR_OP_LOWPASS_VALID: rc = dasr_lowpass_valid(o.t[0], (const float*)o.p[0], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], o.i[5], o.t[1], o.i[6], stream); break;
+            case DASR_OP_ADD_FLAT: rc = dasr_add_flat((float*)o.p[0], (const float*)o.p[1], o.l[0], stream); break;
             default: rc = DASR_EINVAL;
         }
         if (rc != 0) {

@@ -14,8 +14,9 @@ namespace {
 template <int KH, int STRIDE>
 struct WCfg {
     static constexpr int NTAPS = KH * KH;
-    static constexpr int TPG = (NTAPS + 1) / 2;  // taps per wave
-    static constexpr int PH = KH == 3 ? 8 : (STRIDE == 2 ? 2 : 4), PW = 16;  // output-pixel tile (PH k-steps of 16 pixels)
+    static constexpr int TAPS_PER_PART = NTAPS <= 16 ? NTAPS : 10;  // 5x5: three parts of 10 / 10 / 5 taps
+    static constexpr int TPG = (TAPS_PER_PART + 1) / 2;             // taps per wave
+    static constexpr int PH = STRIDE == 2 ? 2 : ((KH == 3 || KH == 1) ? 8 : 4), PW = 16;  // output-pixel tile (PH k-steps of 16 pixels)
     static constexpr int IH = (PH - 1) * STRIDE + KH;
     static constexpr int IW = (PW - 1) * STRIDE + KH;
     static constexpr int GPLANE = PH * PW * 32 + 128;  // bytes; stride = 128 (mod 256): the two planes of a
@@ -191,8 +192,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __
             }
 #pragma unroll
             for (int t = 0; t < C::TPG; ++t) {
-                const int tap = tg * C::TPG + t;
-                if (tap < C::NTAPS) {  // uniform per wave
+                const int tl = tg * C::TPG + t;
+                const int tap = P.tap0 + tl;
+                if (tl < C::TAPS_PER_PART && tap < C::NTAPS) {  // uniform per wave
                     const int ky = tap / KH, kx = tap - ky * KH;
                     bf16x8 b;
                     const int prow = (r * STRIDE + ky) * C::IW + kx;
@@ -212,16 +214,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __
 
     // ---- write partials: ws[part][split][tap][oc 32][cin 64] ----
     if (active) {
-        float* w = ws + P.ws_off + (size_t)split * C::NTAPS * 32 * 64;
+        float* w = ws + P.ws_off + (size_t)split * C::TAPS_PER_PART * 32 * 64;
         const int cin = ct * 32 + (lane & 31), h = lane >> 5;
 #pragma unroll
         for (int t = 0; t < C::TPG; ++t) {
-            const int tap = tg * C::TPG + t;
-            if (tap < C::NTAPS) {
+            const int tl = tg * C::TPG + t;
+            if (tl < C::TAPS_PER_PART && P.tap0 + tl < C::NTAPS) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const int oc = (j & 3) + 8 * (j >> 2) + 4 * h;
-                    w[((size_t)tap * 32 + oc) * 64 + cin] = acc[t][j];
+                    w[((size_t)tl * 32 + oc) * 64 + cin] = acc[t][j];
                 }
             }
         }
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const dasr_wgrad_redu
         if (i < per) {
             const int cin = i & 63, oc = (i >> 6) & 31, tap = i >> 11;
             const int goc = P.oc0 + oc, gc = P.c0 + cin;
-            valid = cin < 32 * P.n_ctiles && goc < P.cout && gc < P.cin;
+            valid = cin < 32 * P.n_ctiles && goc < P.cout && gc < P.cin && P.tap0 + tap < (P.ntaps_total > 0 ? P.ntaps_total : P.ntaps);
             if (valid) {
                 const float* src = ws + P.ws_off + (long long)tap * tstride + (i & 2047);
                 float s0 = 0.f, s1 = 0.f;
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const dasr_wgrad_redu
                 }
                 if (sp < P.nsplit) s0 += src[(size_t)sp * sstride];
                 s = s0 + s1;
-                dst = P.dst_w_off + ((long long)goc * P.cin + gc) * P.ntaps + tap;
+                dst = P.dst_w_off + ((long long)goc * P.cin + gc) * (P.ntaps_total > 0 ? P.ntaps_total : P.ntaps) + P.tap0 + tap;
             }
         } else if (i < per + 32 && P.dst_b_off >= 0) {
             const int oc = i - per;
@@ -579,6 +581,9 @@ extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int3
     if (kh == 3 && stride == 1) return dispatch_wgrad<3, 1>(parts_dev, nparts, nsplit, tr, f32 != 0, ws, s);
     if (kh == 4 && stride == 1) return dispatch_wgrad<4, 1>(parts_dev, nparts, nsplit, tr, f32 != 0, ws, s);
     if (kh == 4 && stride == 2) return dispatch_wgrad<4, 2>(parts_dev, nparts, nsplit, tr, f32 != 0, ws, s);
+    if (kh == 5 && stride == 1) return dispatch_wgrad<5, 1>(parts_dev, nparts, nsplit, tr, f32 != 0, ws, s);
+    if (kh == 1 && stride == 1) return dispatch_wgrad<1, 1>(parts_dev, nparts, nsplit, tr, f32 != 0, ws, s);
+    if (kh == 3 && stride == 2) return dispatch_wgrad<3, 2>(parts_dev, nparts, nsplit, tr, f32 != 0, ws, s);
     return DASR_EINVAL;
 }
 

@@ -1,0 +1,491 @@
+"""DSN training iteration (second hot path) on the MI355X kernels.
+
+De_resnet generator        codes/DSN/model.py:25-55, ResidualBlock :213-224
+FSD discriminator + filter codes/DSN/model.py:60-118, 173-210, 227-293
+losses                     codes/DSN/loss.py:11-41, 44-107
+iteration / optimisers     codes/DSN/train.py:204-285, 152-157;  checkpoint .tar layout train.py:357-376
+
+Update order: both gradients are taken from the same pre-update graph, then D steps, then G steps (the reference's
+`d_loss.backward(retain_graph=True); optimizer_d.step(); g_loss.backward()` only ran under torch 1.1 -- SURVEY 8(c)).
+Perceptual term: per_type 'VGG' = MSE between vgg16.features[:31] of fake and of the bicubic LR (loss.py:119-130), the
+weights coming from `vgg_state` / `vgg_path` or, offline, from a seeded random init; LPIPS (pretrained AlexNet package)
+is not available offline -> NotImplementedError.
+nn.PReLU slopes are read from the parameter buffer at run time; their derivative masks use the sign of the layer
+output, which equals the sign of the pre-activation while the slope stays positive (init 0.25).
+Everything runs in split-bf16 (prec 3) on fp32 activations.
+"""
+import ctypes as C
+import logging
+import os
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+from .engine import (BTensor, ParamStore, PackRegistry, OpList, WgradGroup, Workspace, conv_op, ceil_div, NULL_T, Op, Tensor,
+                     ensure_runtime_ready, _stream)
+from .gan_nets import NLayerDiscriminatorHIP, VGGFeatureHIP, VGG16_CFG, fsd_spec
+from .models import AdamHIP
+from .dasr_model import gaussian_kernel2d, vgg_random_state_dict, _nview
+
+logger = logging.getLogger('base')
+EPS = 1e-8
+
+
+def _op(kind):
+    o = Op()
+    o.op = kind
+    return o
+
+
+def deresnet_spec(n_res_blocks=8):
+    spec = [('block_input.0.weight', (64, 3, 3, 3)), ('block_input.0.bias', (64,)), ('block_input.1.weight', (1,))]
+    for k in range(n_res_blocks):
+        p = 'res_blocks.%d.' % k
+        spec += [(p + 'conv1.weight', (64, 64, 3, 3)), (p + 'conv1.bias', (64,)), (p + 'prelu.weight', (1,)),
+                 (p + 'conv2.weight', (64, 64, 3, 3)), (p + 'conv2.bias', (64,))]
+    spec += [('down_sample.0.weight', (64, 64, 3, 3)), ('down_sample.0.bias', (64,)), ('down_sample.1.weight', (1,)),
+             ('down_sample.2.weight', (64, 64, 3, 3)), ('down_sample.2.bias', (64,)), ('down_sample.3.weight', (1,)),
+             ('block_output.weight', (3, 64, 3, 3)), ('block_output.bias', (3,))]
+    return spec
+
+
+def default_init_state(spec):
+    """nn.Conv2d / nn.PReLU default initialisation in construction order (codes/DSN/train.py:77 seeds torch with 0)"""
+    import math
+    from torch.nn import init
+    sd = OrderedDict()
+    i = 0
+    while i < len(spec):
+        k, shape = spec[i]
+        if len(shape) == 1 and k.endswith('.weight'):  # PReLU
+            sd[k] = torch.full(shape, 0.25)
+            i += 1
+            continue
+        if 'gaussian_filter' in k:  # bias-free depthwise conv: its default init draws from the RNG before being overwritten
+            init.kaiming_uniform_(torch.empty(shape), a=math.sqrt(5))
+            sd[k] = gaussian_kernel2d(shape[-1]).view(1, 1, shape[-1], shape[-1]).repeat(shape[0], 1, 1, 1)
+            i += 1
+            continue
+        w = torch.empty(shape)
+        init.kaiming_uniform_(w, a=math.sqrt(5))
+        sd[k] = w
+        fan_in = shape[1] * shape[2] * shape[3]
+        b = torch.empty(spec[i + 1][1])
+        init.uniform_(b, -1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
+        sd[spec[i + 1][0]] = b
+        i += 2
+    return sd
+
+
+# stride-2 3x3 (pad 1) data-gradient as 2-tap parity sub-convs: parity -> (source tap for a=0, a=1), -1 = no tap
+_P3_TAPS = {0: (1, -1), 1: (2, 0)}
+
+
+class DeResnetHIP:
+    def __init__(self, n_res_blocks=8, device='cuda'):
+        self.nb, self.device = n_res_blocks, torch.device(device)
+        self.spec = deresnet_spec(n_res_blocks)
+        self.params = ParamStore(self.spec, self.device)
+        self.pack = PackRegistry(self.params)
+        P = self.params
+        self.pk = {}
+
+        def fb(name, key, cout, cin, stride=1):
+            w = P.off(key + 'weight')
+            self.pk[name] = self.pack.add(cout, ceil_div(cin, 16) * 16, 9, 1, 3, [(w, cout, cin, 0, cin, 0, 0)])
+            cb = ceil_div(cout, 16) * 16
+            if stride == 1:
+                self.pk[name + '_b'] = self.pack.add(cin, cb, 9, 1, 3, [(w, cout, cin, 0, cout, 0, 1)])
+            else:
+                for py in (0, 1):
+                    for px in (0, 1):
+                        tm = [(-1 if (_P3_TAPS[py][a] < 0 or _P3_TAPS[px][b] < 0) else _P3_TAPS[py][a] * 3 + _P3_TAPS[px][b])
+                              for a in (0, 1) for b in (0, 1)]
+                        self.pk[(name + '_b', py, px)] = self.pack.add(cin, cb, 4, 1, 3, [(w, cout, cin, 0, cout, 0, 1)], tapmap=tm, src_ntaps=9)
+
+        fb('in', 'block_input.0.', 64, 3)
+        for k in range(n_res_blocks):
+            fb('r%d_1' % k, 'res_blocks.%d.conv1.' % k, 64, 64)
+            fb('r%d_2' % k, 'res_blocks.%d.conv2.' % k, 64, 64)
+        fb('d0', 'down_sample.0.', 64, 64, 2)
+        fb('d2', 'down_sample.2.', 64, 64, 2)
+        fb('out', 'block_output.', 3, 64)
+        self.pack.finalize()
+        self.plans = {}
+
+    def repack(self):
+        self.pack.run()
+
+    def state_dict(self):
+        return self.params.state_dict()
+
+    def load_state_dict(self, sd, strict=True):
+        self.params.load_state_dict(sd, strict)
+        self.repack()
+
+    def plan(self, N, H, W):
+        k = (N, H, W)
+        if k not in self.plans:
+            self.plans[k] = _GPlan(self, N, H, W)
+        return self.plans[k]
+
+
+class _GPlan:
+    def __init__(self, net, N, H, W):
+        assert H % 4 == 0 and W % 4 == 0
+        self.net, self.N = net, N
+        dev, P, pack, pk, nb = net.device, net.params, net.pack, net.pk, net.nb
+        H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
+        B = lambda C_, h, w: BTensor(N, C_, h, w, True, dev)
+        self.x_nchw = torch.zeros((N, 3, H, W), dtype=torch.float32, device=dev)
+        self.fake_nchw = torch.zeros((N, 3, H4, W4), dtype=torch.float32, device=dev)
+        self.x_in = B(16, H, W)
+        self.s = [B(64, H, W) for _ in range(nb + 1)]
+        self.h = [B(64, H, W) for _ in range(nb)]
+        self.d1, self.d2, self.fake = B(64, H2, W2), B(64, H4, W4), B(16, H4, W4)
+        self.g_fake, self.gz_out = B(16, H4, W4), B(16, H4, W4)
+        self.g_d2, self.g_d1 = B(64, H4, W4), B(64, H2, W2)
+        self.g_s = [B(64, H, W) for _ in range(2)]
+        self.g_h = B(64, H, W)
+        self.scratch = torch.zeros(256, dtype=torch.float32, device=dev)
+        self.ws = Workspace(dev)
+        sp = lambda key: P.ptr(key)
+        # ---- forward ----
+        f = OpList()
+        o = _op(_lib.OP_NCHW2B)
+        o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[0], o.t[1] = self.x_nchw.data_ptr(), N, 3, H, W, self.x_in.view(), NULL_T
+        f.add(o)
+        f.add(conv_op(pack, pk['in'], self.x_in.view(), True, 16, H, W, H, W, N, bias=sp('block_input.0.bias'), act=1,
+                      slope_ptr=sp('block_input.1.weight'), out_f32=self.s[0].view()))
+        for k in range(nb):
+            pre = 'res_blocks.%d.' % k
+            f.add(conv_op(pack, pk['r%d_1' % k], self.s[k].view(), True, 64, H, W, H, W, N, bias=sp(pre + 'conv1.bias'), act=1,
+                          slope_ptr=sp(pre + 'prelu.weight'), out_f32=self.h[k].view()))
+            f.add(conv_op(pack, pk['r%d_2' % k], self.h[k].view(), True, 64, H, W, H, W, N, bias=sp(pre + 'conv2.bias'),
+                          res1=self.s[k].view(), beta1=1.0, out_f32=self.s[k + 1].view()))
+        f.add(conv_op(pack, pk['d0'], self.s[nb].view(), True, 64, H, W, H2, W2, N, bias=sp('down_sample.0.bias'), stride=2, act=1,
+                      slope_ptr=sp('down_sample.1.weight'), out_f32=self.d1.view()))
+        f.add(conv_op(pack, pk['d2'], self.d1.view(), True, 64, H2, W2, H4, W4, N, bias=sp('down_sample.2.bias'), stride=2, act=1,
+                      slope_ptr=sp('down_sample.3.weight'), out_f32=self.d2.view()))
+        f.add(conv_op(pack, pk['out'], self.d2.view(), True, 64, H4, W4, H4, W4, N, bias=sp('block_output.bias'), act=2,
+                      out_f32=self.fake.view()))
+        o = _op(_lib.OP_B2NCHW)
+        o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.p[0] = self.fake.view(), N, 3, H4, W4, self.fake_nchw.data_ptr()
+        f.add(o)
+        self.fwd = f
+        # ---- backward (input: g_fake = dL/d fake) ----
+        b = OpList()
+        G = P.grad.data_ptr()
+
+        def wg(key, g, inp, cout, cin, hi, wi, ho, wo, stride=1):
+            grp = WgradGroup(3, stride)
+            grp.add_conv(g.view, True, g.planes, inp.view, True, inp.planes, cout, cin, hi, wi, ho, wo, N, P.off(key + 'weight'), P.off(key + 'bias'))
+            grp.finalize(self.ws, dev)
+            for op in grp.ops(G):
+                b.add(op)
+            b.keep.append(grp)
+
+        def prelu_grad(key, y, gx, h, w):
+            o = _op(_lib.OP_PRELU_GRAD)
+            o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3] = y.view(), gx.view(), N, 64, h, w
+            o.p[0], o.p[1], o.p[2], o.f[0] = sp(key), self.scratch.data_ptr(), P.ptr(key, P.grad), 1.0
+            b.add(o)
+            self._prelu_ops.append(o)
+
+        def dgrad_s2(name, g, out, mask, slope_key, hi, wi, ho, wo):
+            for py in (0, 1):
+                for px in (0, 1):
+                    hs, wsub = (hi - py + 1) // 2, (wi - px + 1) // 2
+                    b.add(conv_op(pack, pk[(name + '_b', py, px)], g.view(), True, 64, ho, wo, hs, wsub, N, kh=2, stride=1, pad=0, pad_x=0,
+                                  mask=mask.view() if mask is not None else None, mask_f32=1,
+                                  slope_ptr=sp(slope_key) if slope_key else None, out_f32=out.view(), out_stride=2, out_oy=py, out_ox=px,
+                                  out_W=wi))
+
+        self._prelu_ops = []
+        o = _op(_lib.OP_SIGMOID_BWD)
+        o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.t[2] = self.fake.view(), self.g_fake.view(), N, 3, H4, W4, self.gz_out.view()
+        b.add(o)
+        wg('block_output.', self.gz_out, self.d2, 3, 64, H4, W4, H4, W4)
+        b.add(conv_op(pack, pk['out_b'], self.gz_out.view(), True, 16, H4, W4, H4, W4, N, mask=self.d2.view(), mask_f32=1,
+                      slope_ptr=sp('down_sample.3.weight'), out_f32=self.g_d2.view()))
+        prelu_grad('down_sample.3.weight', self.d2, self.g_d2, H4, W4)
+        wg('down_sample.2.', self.g_d2, self.d1, 64, 64, H2, W2, H4, W4, stride=2)
+        dgrad_s2('d2', self.g_d2, self.g_d1, self.d1, 'down_sample.1.weight', H2, W2, H4, W4)
+        prelu_grad('down_sample.1.weight', self.d1, self.g_d1, H2, W2)
+        wg('down_sample.0.', self.g_d1, self.s[nb], 64, 64, H, W, H2, W2, stride=2)
+        gs = self.g_s[0]
+        dgrad_s2('d0', self.g_d1, gs, None, None, H, W, H2, W2)
+        for k in range(nb - 1, -1, -1):
+            pre = 'res_blocks.%d.' % k
+            wg(pre + 'conv2.', gs, self.h[k], 64, 64, H, W, H, W)
+            b.add(conv_op(pack, pk['r%d_2_b' % k], gs.view(), True, 64, H, W, H, W, N, mask=self.h[k].view(), mask_f32=1,
+                          slope_ptr=sp(pre + 'prelu.weight'), out_f32=self.g_h.view()))
+            prelu_grad(pre + 'prelu.weight', self.h[k], self.g_h, H, W)
+            wg(pre + 'conv1.', self.g_h, self.s[k], 64, 64, H, W, H, W)
+            nxt = self.g_s[1] if gs is self.g_s[0] else self.g_s[0]
+            b.add(conv_op(pack, pk['r%d_1_b' % k], self.g_h.view(), True, 64, H, W, H, W, N, res1=gs.view(), beta1=1.0, out_f32=nxt.view()))
+            gs = nxt
+        # s[0] = PReLU(conv_in(x)): apply PReLU' to dL/ds0, then the input conv's weight gradient
+        o = _op(_lib.OP_AXPBY)
+        o.t[0], o.f[0], o.t[1], o.f[1] = gs.view(), 1.0, NULL_T, 0.0
+        o.i[0], o.i[1], o.i[2], o.i[3] = N, 64, H, W
+        o.t[2], o.t[3], o.f[2], o.t[4], o.f[3], o.p[0] = self.g_h.view(), NULL_T, 1.0, self.s[0].view(), 0.25, sp('block_input.1.weight')
+        b.add(o)
+        prelu_grad('block_input.1.weight', self.s[0], self.g_h, H, W)
+        wg('block_input.0.', self.g_h, self.x_in, 64, 3, H, W, H, W)
+        self.bwd = b
+        self.ws.finalize()
+
+    def set_grad_scale(self, scale):
+        for o in self.bwd.ops:
+            if o.op == _lib.OP_WGRAD_REDUCE:
+                o.f[0] = scale
+        for o in self._prelu_ops:
+            o.f[0] = scale
+        self.bwd._arr = None
+
+
+class DSNModel:
+    """iteration(hr, bicubic_lr, real_lr) / end_epoch() / save(path) / load(path)"""
+
+    def __init__(self, opt=None, device=None, **kw):
+        o = dict(n_res_blocks=8, kernel_size=5, filter='gau', norm_layer='Instance', discriminator='FSD', learning_rate=1e-4,
+                 adam_beta_1=0.5, w_col=1.0, w_tex=0.005, w_per=0.01, per_type='VGG', vgg_path=None, vgg_seed=78, num_epochs=400,
+                 num_decay_epochs=150, upscale_factor=4)
+        o.update(opt or {})
+        o.update(kw)
+        self.opt = o
+        ensure_runtime_ready()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        if o['upscale_factor'] != 4 or o['discriminator'].lower() != 'fsd' or o['norm_layer'] != 'Instance':
+            raise NotImplementedError('DSN on MI355X: De_resnet x4 + FSD discriminator with Instance norm')
+        self.netF = None
+        if o['w_per'] > 0:
+            if o['per_type'] != 'VGG':
+                raise NotImplementedError('perceptual type [%s]: LPIPS needs its pretrained package (offline); use per_type=VGG or w_per=0' % o['per_type'])
+            self.netF = VGGFeatureHIP(30, device=self.device, cfg=VGG16_CFG)
+            if o['vgg_path']:
+                sd = torch.load(o['vgg_path'], map_location='cpu')
+                self.netF.load_state_dict({k: v for k, v in sd.items() if k in self.netF.params.spec})
+            else:
+                logger.warning('no vgg_path: VGG16 perceptual net uses seeded random weights (torchvision init rule)')
+                self.netF.load_state_dict(vgg_random_state_dict(self.netF.spec, int(o['vgg_seed'])))
+        self.filter = o['filter'].lower()
+        if self.filter not in ('gau', 'avg_pool', 'wavelet'):
+            raise NotImplementedError('Frequency Separation type [{:s}] not recognized'.format(o['filter']))
+        self.k = o['kernel_size']
+        self.netG = DeResnetHIP(o['n_res_blocks'], device=self.device)
+        nc = 9 if self.filter == 'wavelet' else 3
+        self.netD = NLayerDiscriminatorHIP(nc, device=self.device, spec_layers=fsd_spec(nc, self.k if self.filter == 'gau' else None))
+        # default nn init, G first then D (codes/DSN/train.py:124-135 under torch.manual_seed(0))
+        self.netG.load_state_dict(default_init_state(self.netG.spec))
+        self.netD.load_state_dict(default_init_state(self.netD.spec))
+        if self.filter != 'wavelet':
+            w = gaussian_kernel2d(self.k) if self.filter == 'gau' else torch.full((self.k, self.k), 1.0 / (self.k * self.k))
+            self.fw = w.contiguous().to(self.device)
+        self.opt_g = AdamHIP(self.netG.params, o['learning_rate'], (o['adam_beta_1'], 0.999), 0.0)
+        self.opt_d = AdamHIP(self.netD.params, o['learning_rate'], (o['adam_beta_1'], 0.999), 0.0)
+        self.epoch, self.iteration_count = 0, 0
+        self.acc = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self.log = OrderedDict()
+        self.dp = None
+        self._plans = {}
+
+    def networks(self):
+        return [self.netG, self.netD]
+
+    def lr(self):
+        """LambdaLR rule of train.py:154-157 (schedulers stepped once per epoch)"""
+        o = self.opt
+        start = o['num_epochs'] - o['num_decay_epochs']
+        e = self.epoch
+        f = 1.0 if e < start else 1.0 - max(0.0, float(e - start) / o['num_decay_epochs'])
+        return o['learning_rate'] * f
+
+    def end_epoch(self):
+        self.epoch += 1
+
+    def _plan(self, N, H, W):
+        k = (N, H, W)
+        if k not in self._plans:
+            self._plans[k] = _DSNPlan(self, N, H, W)
+        return self._plans[k]
+
+    def iteration(self, hr, bicubic_lr, real_lr):
+        N, _, H, W = hr.shape
+        P = self._plan(N, H, W)
+        P.g.x_nchw.copy_(hr)
+        P.bic_nchw.copy_(bicubic_lr)
+        P.real_nchw.copy_(real_lr)
+        scale = self.dp.grad_scale if (self.dp is not None and self.dp.world > 1) else 1.0
+        if scale != P.scale:
+            P.set_grad_scale(scale)
+        P.fwd.run()     # G, front ends, D on [fake; real], all losses and loss gradients
+        P.d_bwd.run()   # D weight gradients (pre-update graph)
+        P.g_bwd.run()   # texture gradient through D's data path, colour adjoint, G backward
+        if scale != 1.0:
+            self.dp.allreduce_mean(self.netD.params.grad)
+            self.dp.allreduce_mean(self.netG.params.grad)
+        lr = self.lr()
+        self.opt_d.step(lr)
+        self.netD.repack()
+        self.opt_g.step(lr)
+        self.netG.repack()
+        self.iteration_count += 1
+        self.fake = P.g.fake_nchw
+        self._pending = True
+
+    def get_current_log(self):
+        if getattr(self, '_pending', False):
+            a = self.acc.tolist()
+            o = self.opt
+            self.log.update({'loss/d_tex_loss': a[0] + a[1], 'loss/g_tex_loss': a[2], 'loss/color_loss': a[3], 'loss/perceptual_loss': a[6],
+                             'loss/g_overall_loss': o['w_col'] * a[3] + o['w_tex'] * a[2] + o['w_per'] * a[6], 'disc_score/real': a[4],
+                             'disc_score/fake': a[5]})
+            self._pending = False
+        return self.log
+
+    # ---- checkpoint (.tar dict of codes/DSN/train.py:357-376) ----
+    def save(self, path):
+        o = self.opt
+        torch.save({'epoch': self.epoch, 'iteration': self.iteration_count, 'fs_type': o['filter'], 'fs_kernel_size': o['kernel_size'],
+                    'D_type': o['discriminator'], 'model_g_state_dict': self.netG.state_dict(), 'models_d_state_dict': self.netD.state_dict(),
+                    'optimizer_g_state_dict': self.opt_g.state_dict(self.lr()), 'optimizer_d_state_dict': self.opt_d.state_dict(self.lr()),
+                    'scheduler_g_state_dict': {'last_epoch': self.epoch}, 'scheduler_d_state_dict': {'last_epoch': self.epoch}}, path)
+
+    def load(self, path):
+        ck = torch.load(path, map_location='cpu', weights_only=False)
+        self.netG.load_state_dict(ck['model_g_state_dict'])
+        self.netD.load_state_dict(ck['models_d_state_dict'])
+        self.opt_g.load_state_dict(ck['optimizer_g_state_dict'])
+        self.opt_d.load_state_dict(ck['optimizer_d_state_dict'])
+        self.epoch, self.iteration_count = ck['epoch'], ck['iteration']
+
+
+class _DSNPlan:
+    def __init__(self, m, N, H, W):
+        dev = m.device
+        self.m, self.N, self.scale = m, N, 1.0
+        h, w = H // 4, W // 4
+        self.g = m.netG.plan(N, H, W)
+        g = self.g
+        wav = m.filter == 'wavelet'
+        hd, wd = (h // 2, w // 2) if wav else (h, w)
+        self.d = m.netD.plan(2 * N, hd, wd)   # [fake; real]
+        d = self.d
+        self.bic_nchw = torch.zeros((N, 3, h, w), dtype=torch.float32, device=dev)
+        self.real_nchw = torch.zeros((N, 3, h, w), dtype=torch.float32, device=dev)
+        self.bic_b, self.real_b = BTensor(N, 16, h, w, True, dev), BTensor(N, 16, h, w, True, dev)
+        k = m.k
+        hc, wc = (hd, wd) if wav else (h - k + 1, w - k + 1)
+        self.col_f, self.col_b, self.g_col = (BTensor(N, 16, hc, wc, True, dev) for _ in range(3))
+        acc = m.acc.data_ptr()
+        o_ = m.opt
+        f = OpList()
+        f.extend(g.fwd)
+        o = _op(_lib.OP_FILL)
+        o.p[0], o.l[0], o.f[0] = acc, 8, 0.0
+        f.add(o)
+        for src, dst in ((self.bic_nchw, self.bic_b), (self.real_nchw, self.real_b)):
+            o = _op(_lib.OP_NCHW2B)
+            o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[0], o.t[1] = src.data_ptr(), N, 3, h, w, dst.view(), NULL_T
+            f.add(o)
+        # discriminator front end on fake -> d.x[:N], real -> d.x[N:]
+        norm_valid = 2 if m.filter == 'avg_pool' else 0
+        for src, n0 in ((g.fake, 0), (self.real_b, N)):
+            if wav:
+                o = _op(_lib.OP_DWT_FWD)
+                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[1], o.t[2] = src.view(), N, 3, hd, wd, 1, NULL_T, _nview(d.x, n0)
+            else:
+                o = _op(_lib.OP_LOWPASS)
+                o.t[0], o.t[1], o.p[0], o.i[4] = src.view(), NULL_T, m.fw.data_ptr(), k
+                o.i[0], o.i[1], o.i[2], o.i[3], o.i[5], o.i[6] = N, 3, h, w, 0 | norm_valid, 0
+                o.f[0], o.f[1], o.t[2], o.t[3] = 0.5, 0.5, NULL_T, _nview(d.x, n0)
+            f.add(o)
+        f.extend(d.fwd)
+        lg = d.logits
+        cnt = float(N * lg.H * lg.W)
+        # discriminator loss: -log(real) - log(1 - fake)   (acc[0], acc[1]); scores acc[4] (real), acc[5] (fake)
+        for n0, mode, a_loss, a_score in ((N, 0, 0, 4), (0, 1, 1, 5)):
+            o = _op(_lib.OP_LOGLOSS)
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = _nview(lg, n0), N, lg.H, lg.W, mode, 0
+            o.f[0], o.f[1], o.f[2], o.f[3] = EPS, 1.0 / cnt, 1.0 / cnt, 1.0 / cnt
+            o.p[0], o.p[1], o.t[1] = acc + 4 * a_loss, acc + 4 * a_score, _nview(d.g_logits, n0)
+            f.add(o)
+        # colour loss: L1 between the low-pass of fake and of the bicubic LR (acc[3])
+        for src, dst in ((g.fake, self.col_f), (self.bic_b, self.col_b)):
+            if wav:
+                o = _op(_lib.OP_DWT_FWD)
+                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[1], o.t[2] = src.view(), N, 3, hd, wd, 1, dst.view(), NULL_T
+            else:
+                o = _op(_lib.OP_LOWPASS_VALID)
+                o.t[0], o.p[0], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], o.i[5], o.t[1], o.i[6] = src.view(), m.fw.data_ptr(), k, N, 3, h, w, 0, dst.view(), 0
+            f.add(o)
+        o = _op(_lib.OP_L1DIFF)
+        ccnt = float(N * 3 * hc * wc)
+        o.t[0], o.t[1], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3] = self.col_f.view(), self.col_b.view(), 1, N, 3, hc, wc
+        o.f[0], o.f[1], o.p[0], o.t[2] = 1.0 / ccnt, float(o_['w_col']) / ccnt, acc + 4 * 3, self.g_col.view()
+        f.add(o)
+        self.v = None
+        if m.netF is not None:   # perceptual: MSE(vgg16(fake), vgg16(bicubic)) -> acc[6], gradient into v.g_feat[:N]
+            self.v = m.netF.plan(2 * N, N, h, w)
+            v = self.v
+            for src, n0 in ((g.fake, 0), (self.bic_b, N)):
+                o = _op(_lib.OP_AXPBY)
+                o.t[0], o.f[0], o.t[1], o.f[1] = src.view(), 1.0, NULL_T, 0.0
+                o.i[0], o.i[1], o.i[2], o.i[3] = N, 16, h, w
+                o.t[2], o.t[3], o.f[2], o.t[4] = _nview(v.x, n0), NULL_T, 1.0, NULL_T
+                f.add(o)
+            f.extend(v.fwd)
+            ft = v.feat
+            o = _op(_lib.OP_L1DIFF)
+            fcnt = float(N * ft.C * ft.H * ft.W)
+            o.t[0], o.t[1], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3] = ft.view(), _nview(ft, N), 1 | 2, N, ft.C, ft.H, ft.W
+            o.f[0], o.f[1], o.p[0], o.t[2] = 1.0 / fcnt, float(o_['w_per']) / fcnt, acc + 4 * 6, v.g_feat.view()
+            f.add(o)
+        self.fwd = f
+        # D weight gradients from the pre-update graph
+        self.d_bwd = d.bwd_full
+        # generator: texture loss gradient through D's data path (+ colour adjoint) -> g_fake -> G backward
+        gb = OpList()
+        o = _op(_lib.OP_LOGLOSS)   # -log(fake_tex) on the fake half: value -> acc[2], gradient -> g_logits[:N]
+        o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = lg.view(), N, lg.H, lg.W, 0, 0
+        o.f[0], o.f[1], o.f[2], o.f[3] = EPS, 1.0 / cnt, float(o_['w_tex']) / cnt, 0.0
+        o.p[0], o.p[1], o.t[1] = acc + 4 * 2, None, d.g_logits.view()
+        gb.add(o)
+        gb.extend(d.bwd_data_ops(N))
+        o = _op(_lib.OP_FILL)
+        o.p[0], o.l[0], o.f[0] = g.g_fake.t.data_ptr(), g.g_fake.t.numel(), 0.0
+        gb.add(o)
+        if wav:
+            o = _op(_lib.OP_DWT_BWD)
+            o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[2], o.i[5] = self.g_col.view(), d.gx.view(), N, 3, hd, wd, 1, g.g_fake.view(), 1
+            gb.add(o)
+        else:
+            o = _op(_lib.OP_LOWPASS)   # adjoint of the high-pass front end
+            o.t[0], o.t[1], o.p[0], o.i[4] = NULL_T, d.gx.view(), m.fw.data_ptr(), k
+            o.i[0], o.i[1], o.i[2], o.i[3], o.i[5], o.i[6] = N, 3, h, w, 1 | norm_valid, 1
+            o.f[0], o.f[1], o.t[2], o.t[3] = 0.5, 0.0, g.g_fake.view(), NULL_T
+            gb.add(o)
+            o = _op(_lib.OP_LOWPASS_VALID)
+            o.t[0], o.p[0], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], o.i[5], o.t[1], o.i[6] = self.g_col.view(), m.fw.data_ptr(), k, N, 3, h, w, 1, g.g_fake.view(), 1
+            gb.add(o)
+        if self.v is not None:
+            gb.extend(self.v.bwd)
+            o = _op(_lib.OP_AXPBY)
+            o.t[0], o.f[0], o.t[1], o.f[1] = g.g_fake.view(), 1.0, self.v.gx.view(), 1.0
+            o.i[0], o.i[1], o.i[2], o.i[3] = N, 16, h, w
+            o.t[2], o.t[3], o.f[2], o.t[4] = g.g_fake.view(), NULL_T, 1.0, NULL_T
+            gb.add(o)
+        gb.extend(g.bwd)
+        self.g_bwd = gb
+
+    def set_grad_scale(self, scale):
+        self.scale = scale
+        self.g.set_grad_scale(scale)
+        for ol in (self.d_bwd, self.g_bwd):
+            for o in ol.ops:
+                if o.op == _lib.OP_WGRAD_REDUCE:
+                    o.f[0] = scale
+            ol._arr = None

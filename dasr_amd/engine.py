@@ -115,7 +115,7 @@ class PackRegistry:
     def add(self, cout, cin_pad, ntaps, mt, prec, segs, tapmap=None, src_ntaps=None):
         """tapmap: packed tap -> source tap.  Default: identity for forward segments, reversed (tap flip) when the
         segments are transposed (stride-1 data-gradient)."""
-        assert cin_pad % 16 == 0 and len(segs) <= 5
+        assert cin_pad % 16 == 0 and len(segs) <= 5 and ntaps <= 32
         mg = ceil_div(ceil_div(cout, 32), mt)
         pieces = mg * (cin_pad // 16) * ntaps * mt * 64
         r = PackedRef()
@@ -127,7 +127,7 @@ class PackRegistry:
         if tapmap is None:
             tr = bool(segs and segs[0][6])
             tapmap = [ntaps - 1 - t for t in range(ntaps)] if tr else list(range(ntaps))
-        for t in range(16):
+        for t in range(32):
             d.tapmap[t] = tapmap[t] if t < len(tapmap) else -1
         for i, s in enumerate(segs):
             sg = d.seg[i]
@@ -204,7 +204,7 @@ def run_interleaved(lists, streams, chunk=48):
 
 def conv_op(pack, ref, inp, in_f32, cin, Hin, Win, Hout, Wout, N, bias=None, kh=3, stride=1, pad=1, ups=0, act=0, slope=SLOPE,
             mask=None, mask_f32=0, alpha=1.0, res1=None, beta1=0.0, res2=None, beta2=0.0, out_f32=None, out_bf16=None, gamma=1.0,
-            pad_x=-1, out_stride=1, out_oy=0, out_ox=0, out_W=0):
+            pad_x=-1, out_stride=1, out_oy=0, out_ox=0, out_W=0, slope_ptr=None):
     assert cin == ref.cin_pad, (cin, ref.cin_pad)
     o = Op()
     o.op = _lib.OP_CONV
@@ -222,6 +222,7 @@ def conv_op(pack, ref, inp, in_f32, cin, Hin, Win, Hout, Wout, N, bias=None, kh=
     p.out_bf16 = out_bf16 if out_bf16 is not None else NULL_T
     p.gamma = gamma
     p.pad_x, p.out_stride, p.out_oy, p.out_ox, p.out_W = pad_x, out_stride, out_oy, out_ox, out_W
+    p.slope_ptr = slope_ptr
     return o
 
 
@@ -233,30 +234,36 @@ class WgradGroup:
         self.parts = []  # (WgradPart, WgradReducePart)
 
     def add_conv(self, g, g_f32, g_planes_total, inp, in_f32, in_planes_total, cout, cin, Hin, Win, Hout, Wout, N,
-                 dst_w_off, dst_b_off, pad=1, ups=0):
+                 dst_w_off, dst_b_off, pad=None, ups=0):
         """g / inp are BTensor-like callables c0 -> dasr_tensor view."""
         ntaps = self.kh * self.kh
+        tpp = ntaps if ntaps <= 16 else 10  # WCfg::TAPS_PER_PART
+        self.tpp = tpp
+        pad = (self.kh - 1) // 2 if pad is None else pad
         cin_pad = ceil_div(cin, 16) * 16
         for oc0 in range(0, cout, 32):
             for c0 in range(0, cin_pad, 64):
-                wp, rp = WgradPart(), WgradReducePart()
-                wp.g, wp.g_f32 = g(oc0), int(g_f32)
-                wp.inp, wp.in_f32 = inp(c0), int(in_f32)
-                wp.ups = ups
-                wp.n_ctiles = min(2, ceil_div(cin_pad - c0, 32))
-                wp.g_planes = min(2, g_planes_total - oc0 // 16)
-                wp.in_planes = min(4, in_planes_total - c0 // 16)
-                wp.Hin, wp.Win, wp.Hout, wp.Wout, wp.N = Hin, Win, Hout, Wout, N
-                wp.kh, wp.stride, wp.pad = self.kh, self.stride, pad
-                wp.want_bias = 1 if (dst_b_off is not None and c0 == 0) else 0
-                rp.ntaps, rp.oc0, rp.c0, rp.cout, rp.cin, rp.n_ctiles = ntaps, oc0, c0, cout, cin, wp.n_ctiles
-                rp.dst_w_off = dst_w_off
-                rp.dst_b_off = dst_b_off if (dst_b_off is not None and c0 == 0) else -1
-                self.parts.append((wp, rp))
+                for tap0 in range(0, ntaps, tpp):
+                    wp, rp = WgradPart(), WgradReducePart()
+                    wp.g, wp.g_f32 = g(oc0), int(g_f32)
+                    wp.inp, wp.in_f32 = inp(c0), int(in_f32)
+                    wp.ups = ups
+                    wp.n_ctiles = min(2, ceil_div(cin_pad - c0, 32))
+                    wp.g_planes = min(2, g_planes_total - oc0 // 16)
+                    wp.in_planes = min(4, in_planes_total - c0 // 16)
+                    wp.Hin, wp.Win, wp.Hout, wp.Wout, wp.N = Hin, Win, Hout, Wout, N
+                    wp.kh, wp.stride, wp.pad, wp.tap0 = self.kh, self.stride, pad, tap0
+                    first = dst_b_off is not None and c0 == 0 and tap0 == 0
+                    wp.want_bias = 1 if first else 0
+                    rp.ntaps, rp.oc0, rp.c0, rp.cout, rp.cin, rp.n_ctiles = min(tpp, ntaps - tap0), oc0, c0, cout, cin, wp.n_ctiles
+                    rp.tap0, rp.ntaps_total = tap0, ntaps
+                    rp.dst_w_off = dst_w_off
+                    rp.dst_b_off = dst_b_off if first else -1
+                    self.parts.append((wp, rp))
 
     def finalize(self, workspace, device, target_wgs=768):
         wp0 = self.parts[0][0]
-        ph = 8 if self.kh == 3 else (2 if self.stride == 2 else 4)  # WCfg::PH in wgrad.hip
+        ph = 2 if self.stride == 2 else (8 if self.kh in (3, 1) else 4)  # WCfg::PH in wgrad.hip
         ntiles = wp0.N * ceil_div(wp0.Hout, ph) * ceil_div(wp0.Wout, 16)
         nparts = len(self.parts)
         self.nsplit = max(1, min(ntiles, target_wgs // nparts))
@@ -266,10 +273,11 @@ class WgradGroup:
         off = 0
         for wp, rp in self.parts:
             wp.ws_off = rp.ws_off = off
-            off += self.nsplit * ntaps * 2048
+            off += self.nsplit * self.tpp * 2048
             wp.ws_bias_off = rp.ws_bias_off = off
             off += self.nsplit * 32
             rp.nsplit = self.nsplit
+            rp.split_stride, rp.tap_stride, rp.bias_stride = self.tpp * 2048, 2048, 32
         self.ws_floats = off
         self.workspace = workspace
         workspace.reserve(off)

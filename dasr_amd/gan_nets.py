@@ -27,19 +27,34 @@ def _op(kind):
 def nlayer_d_spec(input_nc, ndf=64, n_layers=2):
     """[(key, shape)] and layer descriptions of the reference nn.Sequential."""
     spec = [('model.0.weight', (ndf, input_nc, 4, 4)), ('model.0.bias', (ndf,))]
-    layers = [dict(key='model.0.', cin=input_nc, cout=ndf, stride=2, bias=True, norm=False)]
+    layers = [dict(key='model.0.', cin=input_nc, cout=ndf, stride=2, bias=True, norm=False, kh=4, pad=1)]
     mult, idx = 1, 2
     for n in range(1, n_layers):
         prev, mult = mult, min(2 ** n, 8)
         spec.append(('model.%d.weight' % idx, (ndf * mult, ndf * prev, 4, 4)))
-        layers.append(dict(key='model.%d.' % idx, cin=ndf * prev, cout=ndf * mult, stride=2, bias=False, norm=True))
+        layers.append(dict(key='model.%d.' % idx, cin=ndf * prev, cout=ndf * mult, stride=2, bias=False, norm=True, kh=4, pad=1))
         idx += 3
     prev, mult = mult, min(2 ** n_layers, 8)
     spec.append(('model.%d.weight' % idx, (ndf * mult, ndf * prev, 4, 4)))
-    layers.append(dict(key='model.%d.' % idx, cin=ndf * prev, cout=ndf * mult, stride=1, bias=False, norm=True))
+    layers.append(dict(key='model.%d.' % idx, cin=ndf * prev, cout=ndf * mult, stride=1, bias=False, norm=True, kh=4, pad=1))
     idx += 3
     spec += [('model.%d.weight' % idx, (1, ndf * mult, 4, 4)), ('model.%d.bias' % idx, (1,))]
-    layers.append(dict(key='model.%d.' % idx, cin=ndf * mult, cout=1, stride=1, bias=True, norm=False, last=True))
+    layers.append(dict(key='model.%d.' % idx, cin=ndf * mult, cout=1, stride=1, bias=True, norm=False, last=True, kh=4, pad=1))
+    return spec, layers
+
+
+def fsd_spec(input_nc, gaussian_k=None):
+    """DSN DiscriminatorBasic (codes/DSN/model.py:173-210, Instance norm): 5x5 convs (all with bias) and a 1x1 head.
+    gaussian_k: the frozen depthwise gaussian of the 'gau' front end is part of the reference state_dict."""
+    spec = []
+    if gaussian_k:
+        spec.append(('filter.filter_low.filter.gaussian_filter.weight', (3, 1, gaussian_k, gaussian_k)))
+    layers = []
+    for idx, cin, cout, kh, norm, last in ((0, input_nc, 64, 5, False, False), (2, 64, 128, 5, True, False), (5, 128, 256, 5, True, False),
+                                           (8, 256, 1, 1, False, True)):
+        key = 'net.net.%d.' % idx
+        spec += [(key + 'weight', (cout, cin, kh, kh)), (key + 'bias', (cout,))]
+        layers.append(dict(key=key, cin=cin, cout=cout, stride=1, bias=True, norm=norm, last=last, kh=kh, pad=(kh - 1) // 2))
     return spec, layers
 
 
@@ -50,9 +65,9 @@ _PARITY_PAD = {0: 1, 1: 0}
 
 
 class NLayerDiscriminatorHIP:
-    def __init__(self, input_nc, ndf=64, n_layers=2, device='cuda'):
+    def __init__(self, input_nc, ndf=64, n_layers=2, device='cuda', spec_layers=None):
         self.input_nc, self.device = input_nc, torch.device(device)
-        self.spec, self.layers = nlayer_d_spec(input_nc, ndf, n_layers)
+        self.spec, self.layers = spec_layers if spec_layers is not None else nlayer_d_spec(input_nc, ndf, n_layers)
         self.params = ParamStore(self.spec, self.device)
         self.pack = PackRegistry(self.params)
         P = self.params
@@ -60,10 +75,11 @@ class NLayerDiscriminatorHIP:
             cin_pad = ceil_div(L['cin'], 16) * 16
             w = P.off(L['key'] + 'weight')
             L['cin_pad'] = cin_pad
-            L['fwd'] = self.pack.add(L['cout'], cin_pad, 16, 1, 3, [(w, L['cout'], L['cin'], 0, L['cin'], 0, 0)])
+            nt = L['kh'] * L['kh']
+            L['fwd'] = self.pack.add(L['cout'], cin_pad, nt, 1, 3, [(w, L['cout'], L['cin'], 0, L['cin'], 0, 0)])
             cb = ceil_div(L['cout'], 16) * 16
             if L['stride'] == 1:
-                L['bwd'] = self.pack.add(L['cin'], cb, 16, 1, 3, [(w, L['cout'], L['cin'], 0, L['cout'], 0, 1)])
+                L['bwd'] = self.pack.add(L['cin'], cb, nt, 1, 3, [(w, L['cout'], L['cin'], 0, L['cout'], 0, 1)])
             else:
                 L['bwd'] = {}
                 for py in (0, 1):
@@ -103,8 +119,8 @@ class _DPlan:
         self.acts, self.zs, self.stats, self.dims = [], [], [], [(H, W)]
         h, w = H, W
         for L in net.layers:
-            ho = (h + 2 - 4) // L['stride'] + 1
-            wo = (w + 2 - 4) // L['stride'] + 1
+            ho = (h + 2 * L['pad'] - L['kh']) // L['stride'] + 1
+            wo = (w + 2 * L['pad'] - L['kh']) // L['stride'] + 1
             self.dims.append((ho, wo))
             z = BTensor(N, max(L['cout'], 16), ho, wo, True, dev) if L['norm'] else None
             a = BTensor(N, max(L['cout'], 16), ho, wo, True, dev)
@@ -135,15 +151,15 @@ class _DPlan:
             (hi, wi), (ho, wo) = self.dims[i], self.dims[i + 1]
             bias = P.ptr(L['key'] + 'bias') if L['bias'] else None
             if L['norm']:
-                ops.add(conv_op(pack, L['fwd'], src.view(), True, L['cin_pad'], hi, wi, ho, wo, N, bias=bias, kh=4, stride=L['stride'],
-                                out_f32=self.zs[i].view()))
+                ops.add(conv_op(pack, L['fwd'], src.view(), True, L['cin_pad'], hi, wi, ho, wo, N, bias=bias, kh=L['kh'], stride=L['stride'],
+                                pad=L['pad'], out_f32=self.zs[i].view()))
                 o = _op(_lib.OP_INORM_FWD)
                 o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = self.zs[i].view(), N, L['cout'], ho, wo
                 o.f[0], o.f[1], o.t[1], o.p[0] = IN_EPS, SLOPE, self.acts[i].view(), self.stats[i].data_ptr()
                 ops.add(o)
             else:
-                ops.add(conv_op(pack, L['fwd'], src.view(), True, L['cin_pad'], hi, wi, ho, wo, N, bias=bias, kh=4, stride=L['stride'],
-                                act=0 if L.get('last') else 1, slope=SLOPE, out_f32=self.acts[i].view()))
+                ops.add(conv_op(pack, L['fwd'], src.view(), True, L['cin_pad'], hi, wi, ho, wo, N, bias=bias, kh=L['kh'], stride=L['stride'],
+                                pad=L['pad'], act=0 if L.get('last') else 1, slope=SLOPE, out_f32=self.acts[i].view()))
             src = self.acts[i]
         return ops
 
@@ -155,8 +171,8 @@ class _DPlan:
         cb = ceil_div(L['cout'], 16) * 16
         m = mask.view() if mask is not None else None
         if L['stride'] == 1:
-            ops.add(conv_op(pack, L['bwd'], g_in.view(), True, cb, ho, wo, hi, wi, N, kh=4, stride=1, pad=2, mask=m, mask_f32=1,
-                            slope=SLOPE, out_f32=out.view()))
+            ops.add(conv_op(pack, L['bwd'], g_in.view(), True, cb, ho, wo, hi, wi, N, kh=L['kh'], stride=1, pad=L['kh'] - 1 - L['pad'], mask=m,
+                            mask_f32=1, slope=SLOPE, out_f32=out.view()))
         else:
             for (py, px), ref in L['bwd'].items():
                 hs, wsub = (hi - py + 1) // 2, (wi - px + 1) // 2
@@ -180,9 +196,9 @@ class _DPlan:
                 ops.add(o)
             inp = self.x if i == 0 else self.acts[i - 1]
             if wgrad:
-                grp = WgradGroup(4, L['stride'])
+                grp = WgradGroup(L['kh'], L['stride'])
                 grp.add_conv(gz.view, True, gz.planes, inp.view, True, inp.planes, L['cout'], L['cin'], hi, wi, ho, wo, N,
-                             P.off(L['key'] + 'weight'), P.off(L['key'] + 'bias') if L['bias'] else None)
+                             P.off(L['key'] + 'weight'), P.off(L['key'] + 'bias') if L['bias'] else None, pad=L['pad'])
                 grp.finalize(self.ws, net.device)
                 for o in grp.ops(P.grad.data_ptr()):
                     ops.add(o)
@@ -211,10 +227,13 @@ VGG19_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512,
 VGG_MEAN, VGG_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
 
-def vgg19_spec(feature_layer=34):
-    """torchvision vgg19.features[: feature_layer + 1] as [(kind, idx, cin, cout, relu)]"""
+VGG16_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
+
+
+def vgg19_spec(feature_layer=34, cfg=None):
+    """torchvision vgg19 (or `cfg`) .features[: feature_layer + 1] as [(kind, idx, cin, cout, relu)]"""
     layers, spec, idx, c = [], [], 0, 3
-    for v in VGG19_CFG:
+    for v in (cfg or VGG19_CFG):
         if idx > feature_layer:
             break
         if v == 'M':
@@ -232,9 +251,9 @@ def vgg19_spec(feature_layer=34):
 class VGGFeatureHIP:
     """Frozen feature extractor: forward on N images, data-gradient w.r.t. the first n_g inputs."""
 
-    def __init__(self, feature_layer=34, device='cuda'):
+    def __init__(self, feature_layer=34, device='cuda', cfg=None):
         self.device = torch.device(device)
-        self.spec, self.layers = vgg19_spec(feature_layer)
+        self.spec, self.layers = vgg19_spec(feature_layer, cfg)
         self.params = ParamStore(self.spec, self.device)
         self.pack = PackRegistry(self.params)
         P = self.params

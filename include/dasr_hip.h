@@ -58,6 +58,9 @@ typedef struct {
      * pad_x < 0: same as pad; out_stride 0/1: dense output, 2: output pixel (oy,ox) lands at (2*oy+out_oy, 2*ox+out_ox)
      * of a tensor of width out_W (mask / res / out tensors are all indexed at that full-resolution position). */
     int32_t pad_x, out_stride, out_oy, out_ox, out_W;
+    /* act: 0 none, 1 (Leaky/P)ReLU with `slope`, 2 sigmoid.  slope_ptr != NULL: slope read from device memory
+     * (nn.PReLU's learned parameter, codes/DSN/model.py:29,215), used for `act` and for the `mask` derivative. */
+    const float* slope_ptr;
 } dasr_conv_params;
 
 int dasr_conv(const dasr_conv_params* p, void* stream);
@@ -79,8 +82,9 @@ typedef struct {
     int32_t Hin, Win, Hout, Wout, N;
     int32_t kh, stride, pad;
     int32_t want_bias;                      /* this part also accumulates sum_p g[oc] */
-    int64_t ws_off;                         /* float offset into workspace: [nsplit][ntaps][32][64] (+ bias [nsplit][32]) */
+    int64_t ws_off;                         /* float offset into workspace: [nsplit][taps of the part][32][64] (+ bias [nsplit][32]) */
     int64_t ws_bias_off;
+    int32_t tap0;                           /* first tap of this part (5x5 kernels are split into parts of <= 10 taps) */
 } dasr_wgrad_part;
 
 /* f32: g and in tensors of ALL parts are f32 (rounded to bf16 while staging) instead of bf16.
@@ -99,6 +103,7 @@ typedef struct {
     int32_t flip_io;                        /* reserved */
     /* workspace strides (floats); 0 = the 4-wave layout [split][tap][32][64] / bias [split][32] */
     int64_t split_stride, tap_stride, bias_stride;
+    int32_t tap0, ntaps_total;              /* part covers taps [tap0, tap0+ntaps) of a kernel with ntaps_total taps (0: = ntaps) */
 } dasr_wgrad_reduce_part;
 
 int dasr_wgrad_reduce(const dasr_wgrad_reduce_part* parts_dev, int32_t nparts, const float* ws, float* grad_flat,
@@ -123,7 +128,7 @@ typedef struct {
     int64_t lo_off;       /* 0 when prec 1 */
     int32_t cout, cin_pad, ntaps, mt, nseg;
     int32_t src_ntaps;    /* taps of the source weight (kh*kw of the nn.Conv2d) */
-    int8_t  tapmap[16];   /* packed tap -> source tap (identity: forward; reversed: stride-1 dgrad; parity subset: stride-2 dgrad) */
+    int8_t  tapmap[32];   /* packed tap -> source tap (identity: forward; reversed: stride-1 dgrad; parity subset: stride-2 dgrad) */
     dasr_pack_seg seg[5];
 } dasr_pack_desc;
 
@@ -152,7 +157,8 @@ int dasr_downsum2x(dasr_tensor src, int32_t N, int32_t C, int32_t H, int32_t W, 
 /* out = a*x + b*z (z optional) over blocked f32 tensors, optional bf16 copy scaled by gamma
  * (ShortcutBlock / RRDB residual bookkeeping, block.py:97-105,305-309) */
 int dasr_axpby(dasr_tensor x, float a, dasr_tensor z, float b, int32_t N, int32_t C, int32_t H, int32_t W,
-               dasr_tensor out_f32, dasr_tensor out_bf16, float gamma, void* stream);
+               dasr_tensor out_f32, dasr_tensor out_bf16, float gamma, dasr_tensor mask /* optional (P)ReLU' mask, f32 */, float slope,
+               const float* slope_ptr, void* stream);
 
 /* torch.optim.Adam step (DASR_model.py:129-143; SR_model.py:50-51) on flat fp32 buffers:
  * g += wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps) */
@@ -181,6 +187,7 @@ int dasr_dwt_fwd(dasr_tensor x, int32_t N, int32_t C, int32_t H2, int32_t W2, in
 int dasr_dwt_bwd(dasr_tensor gll, dasr_tensor ghc, int32_t N, int32_t C, int32_t H2, int32_t W2, int32_t norm, dasr_tensor gx,
                  int32_t accumulate, void* stream);
 /* depthwise k x k low-pass (GaussianFilter / AvgPool2d of FilterLow/FilterHigh, architecture.py:1177-1243), zero pad.
+ * mode bit 1 set: normalise by the in-image fraction of the window (AvgPool2d(count_include_pad=False), model.py:69-74).
  * mode 0: out_low = low(x), out_high = a_h*(x - low(x)) + b_h.  mode 1 (adjoint): out_low (+)= low(x) + a_h*(x2 - low(x2))
  * with x = dL/dlow, x2 = dL/dhigh (either may be null). */
 int dasr_lowpass(dasr_tensor x, dasr_tensor x2, const float* w, int32_t k, int32_t N, int32_t C, int32_t H, int32_t W,
@@ -191,7 +198,7 @@ int dasr_maxpool2(dasr_tensor x, int32_t is_f32, int32_t N, int32_t C, int32_t H
 int dasr_maxpool2_bwd(dasr_tensor x, dasr_tensor gy, int32_t is_f32, int32_t N, int32_t C, int32_t Ho, int32_t Wo, dasr_tensor gx,
                       int32_t relu_mask, void* stream);
 /* L1 between two blocked tensors (feature loss DASR_model.py:224-229; LL loss :220-222): loss_acc += coef*sum|a-b|,
- * ga = gcoef*sign(a-b) */
+ * ga = gcoef*sign(a-b).  is_f32 bit 1 set: squared form (MSE of the DSN VGG16 perceptual loss, loss.py:119-130). */
 int dasr_l1_diff(dasr_tensor a, dasr_tensor b, int32_t is_f32, int32_t N, int32_t C, int32_t H, int32_t W, float coef, float gcoef,
                  float* loss_acc, dasr_tensor ga, void* stream);
 /* per-channel affine on <=4 channels (VGG input normalisation architecture.py:1086-1087 and its adjoint) */
@@ -200,12 +207,29 @@ int dasr_affine4(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, cons
 /* F.interpolate(bilinear, align_corners=False) of the domain-distance map (DASR_model.py:173-174), NCHW [N][1][h][w] */
 int dasr_bilinear_up(const float* src, int32_t N, int32_t h, int32_t w, int32_t factor, float* dst, void* stream);
 
+/* ---- DSN (codes/DSN) kernels ---------------------------------------------------------------------------------*/
+/* -log losses of codes/DSN/loss.py:11-41 on p = sigmoid(logit) (model.py:104-105): mode 0: -log(p+eps), mode 1:
+ * -log(1-p+eps); loss_acc += coef*sum, score_acc += score_coef*sum(p), grad (+)= gcoef * d/dlogit */
+int dasr_logloss(dasr_tensor x, int32_t N, int32_t H, int32_t W, int32_t mode, float eps, float coef, float gcoef, float* loss_acc,
+                 float* score_acc, float score_coef, dasr_tensor grad, int32_t accumulate, void* stream);
+/* backward of the generator's output sigmoid (model.py:55) */
+int dasr_sigmoid_bwd(dasr_tensor y, dasr_tensor g, int32_t N, int32_t C, int32_t H, int32_t W, dasr_tensor gz, void* stream);
+/* gradient of nn.PReLU()'s single slope (model.py:29,215) from the layer output y and dL/dx; deterministic two-stage sum;
+ * scratch256: 256 floats */
+int dasr_prelu_grad(dasr_tensor y, dasr_tensor gx, int32_t N, int32_t C, int32_t H, int32_t W, const float* slope, float* scratch256,
+                    float* dst, float scale, void* stream);
+/* un-padded low-pass of the colour loss (FilterLow(padding=False), loss.py:52-56): mode 0 forward (H-k+1 x W-k+1 out),
+ * mode 1 adjoint */
+int dasr_lowpass_valid(dasr_tensor x, const float* w, int32_t k, int32_t N, int32_t C, int32_t H, int32_t W, int32_t mode,
+                       dasr_tensor out, int32_t accumulate, void* stream);
+
 /* ---- executor: run a recorded list of ops in one call (keeps the host out of the step) ----------*/
 enum { DASR_OP_CONV = 1, DASR_OP_WGRAD = 2, DASR_OP_WGRAD_REDUCE = 3, DASR_OP_PACK = 4, DASR_OP_DOWNSUM = 5,
        DASR_OP_AXPBY = 6, DASR_OP_FILL = 7, DASR_OP_L1LOSS = 8, DASR_OP_NCHW2B = 9, DASR_OP_B2NCHW = 10,
        DASR_OP_INORM_FWD = 11, DASR_OP_INORM_BWD = 12, DASR_OP_BCE = 13, DASR_OP_DWT_FWD = 14, DASR_OP_DWT_BWD = 15,
        DASR_OP_LOWPASS = 16, DASR_OP_MAXPOOL = 17, DASR_OP_MAXPOOL_BWD = 18, DASR_OP_L1DIFF = 19, DASR_OP_AFFINE4 = 20,
-       DASR_OP_BILINEAR = 21 };
+       DASR_OP_BILINEAR = 21, DASR_OP_LOGLOSS = 22, DASR_OP_SIGMOID_BWD = 23, DASR_OP_PRELU_GRAD = 24, DASR_OP_LOWPASS_VALID = 25,
+       DASR_OP_ADD_FLAT = 26 };
 
 typedef struct {
     int32_t op;  int32_t i[8];  float f[4];  int64_t l[4];  void* p[4];  dasr_tensor t[5];
