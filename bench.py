@@ -225,6 +225,55 @@ def sweep(model, data, a):
         log('sweep step time, tuning %s: %.2f ms/step' % (combo, (time.perf_counter() - t0) / 3 * 1e3))
 
 
+def bench_dsn(a):
+    """second hot path: one DSN iteration = G fwd, D fwd on [fake; real], losses, D wgrad, G bwd, 2x Adam"""
+    from dasr_amd.dist import DataParallelGroup
+    from dasr_amd.dsn_model import DSNModel
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dp = DataParallelGroup() if world > 1 else None
+    rank = dp.rank if dp else 0
+    if dp:
+        torch.cuda.set_device(dp.local_rank)
+    torch.manual_seed(0)
+    m = DSNModel(dict(filter=a.fs, w_per=0.01, per_type='VGG'))
+    if dp:
+        m.dp = dp
+        for net in m.networks():
+            dp.broadcast_params(net.params.flat)
+            net.repack()
+    b = a.batch if a.batch != 16 else 8
+    c = 4 * a.lr_size if a.lr_size != 128 else 256
+    g = torch.Generator().manual_seed(1234 + rank)
+    hr, bic, real = (torch.rand(b, 3, c, c, generator=g).cuda(), torch.rand(b, 3, c // 4, c // 4, generator=g).cuda(),
+                     torch.rand(b, 3, c // 4, c // 4, generator=g).cuda())
+    for _ in range(a.warmup):
+        m.iteration(hr, bic, real)
+    torch.cuda.synchronize()
+    if dp:
+        dp.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        m.iteration(hr, bic, real)
+    torch.cuda.synchronize()
+    if dp:
+        dp.barrier()
+    dt = time.perf_counter() - t0
+    if dp:
+        dt = dp.max_over_ranks(dt)
+    if rank != 0:
+        return
+    # De_resnet: 39.5 GMAC fwd per 256 crop (SURVEY 8(a) a19), x3 for fwd+dgrad+wgrad
+    tf = 3 * 2 * 39.5e-3 * (c / 256.0) ** 2
+    ips = b * world * a.steps / dt
+    print(json.dumps({'metric': 'DSN train crops/sec (De_resnet + FSD, %dx%d HR crops)' % (c, c), 'value': round(ips, 2), 'unit': 'images/s',
+                      'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2), 'higher_is_better': True,
+                      'scaling': 'weak', 'vs_baseline': None, 'dtype': 'split-bf16 MFMA operands (~fp32), fp32 accumulate',
+                      'data': 'synthetic (torch.rand, seed 1234+rank; default nn init, seed 0; VGG16 seeded random)',
+                      'config': {'workload': 'configs[4]: DSN iteration, De_resnet(8 blocks) + FSD discriminator (%s filter) + colour/texture/VGG16 losses, '
+                                             'batch %d of %dx%d crops per GPU' % (a.fs, b, c, c), 'global_batch': b * world, 'parallelism': 'dp%d' % world},
+                      'generator_tflops': round(ips * tf, 1), 'log': m.get_current_log()}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -237,10 +286,13 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--tune', type=str, default='', help='kernel variant knobs, e.g. 1=1,2=0 (dasr_set_tuning key=value)')
     ap.add_argument('--sweep', action='store_true', help='A/B the conv kernel variants (stderr table), then exit')
-    ap.add_argument('--model', type=str, default='sr', choices=['sr', 'dasr'],
-                    help="sr: configs[1] generator-only step (the headline line); dasr: configs[2] full GAN step (batch = G crops per GPU)")
-    ap.add_argument('--fs', type=str, default='wavelet', choices=['wavelet', 'gau'])
+    ap.add_argument('--model', type=str, default='sr', choices=['sr', 'dasr', 'dsn'],
+                    help="sr: configs[1] generator-only step (the headline line); dasr: configs[2] full GAN step (batch = G crops per GPU); "
+                         "dsn: configs[4] DSN iteration (De_resnet + FSD discriminator, --batch HR crops of 4*lr-size per GPU)")
+    ap.add_argument('--fs', type=str, default='wavelet', choices=['wavelet', 'gau', 'avg_pool'])
     a = ap.parse_args()
+    if a.model == 'dsn':
+        return bench_dsn(a)
 
     from dasr_amd import options
     from dasr_amd.dist import DataParallelGroup

@@ -352,7 +352,12 @@ class DSNModel:
         torch.save({'epoch': self.epoch, 'iteration': self.iteration_count, 'fs_type': o['filter'], 'fs_kernel_size': o['kernel_size'],
                     'D_type': o['discriminator'], 'model_g_state_dict': self.netG.state_dict(), 'models_d_state_dict': self.netD.state_dict(),
                     'optimizer_g_state_dict': self.opt_g.state_dict(self.lr()), 'optimizer_d_state_dict': self.opt_d.state_dict(self.lr()),
-                    'scheduler_g_state_dict': {'last_epoch': self.epoch}, 'scheduler_d_state_dict': {'last_epoch': self.epoch}}, path)
+                    'scheduler_g_state_dict': self._sched_state(), 'scheduler_d_state_dict': self._sched_state()}, path)
+
+    def _sched_state(self):
+        """torch.optim.lr_scheduler.LambdaLR.state_dict() layout (the lambda itself is not picklable and is stored as None)"""
+        return {'base_lrs': [self.opt['learning_rate']], 'last_epoch': self.epoch, 'verbose': False, '_step_count': self.epoch + 1,
+                '_get_lr_called_within_step': False, '_last_lr': [self.lr()], 'lr_lambdas': [None]}
 
     def load(self, path):
         ck = torch.load(path, map_location='cpu', weights_only=False)

@@ -1,0 +1,149 @@
+"""`python -m dasr_amd.dsn_train [flags]` -- the DSN training driver (reference: codes/DSN/train.py:24-376).
+
+Same flags and defaults as the reference's argparse block (train.py:24-72) and the same loop: per iteration one
+DSNModel.iteration(hr, bicubic_lr, real_lr); schedulers step once per epoch (train.py:287-288); every
+`save_model_interval` epochs the `.tar` checkpoint dict of train.py:357-376 is written to
+<save_path>/checkpoints/iteration_<n>.tar and last_iteration.tar.  Accepted-but-unsupported choices fail the way the
+reference does for unknown strings (NotImplementedError): --generator DSGAN, --discriminator nld_s1/nld_s2, --ragan,
+--wgan, --norm_layer Batch, --per_type LPIPS (pretrained AlexNet package, offline).  Data: the PIL/torchvision loaders
+(data_loader.py) stay on the reference's side of the boundary; any iterable of (hr, bicubic_lr, real_lr) tuples works, and
+`--dataset synthetic` ships fixed-seed random crops for benchmarks and tests.
+"""
+import argparse
+import json
+import logging
+import os
+
+import torch
+
+from .dist import DataParallelGroup
+from .dsn_model import DSNModel
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description='Train Downscaling Models')
+    p.add_argument('--upscale_factor', default=4, type=int, choices=[4])
+    p.add_argument('--crop_size', default=256, type=int)
+    p.add_argument('--crop_size_val', default=256, type=int)
+    p.add_argument('--batch_size', default=4, type=int)
+    p.add_argument('--num_workers', default=6, type=int)
+    p.add_argument('--num_epochs', default=400, type=int)
+    p.add_argument('--num_decay_epochs', default=150, type=int)
+    p.add_argument('--learning_rate', default=0.0001, type=float)
+    p.add_argument('--adam_beta_1', default=0.5, type=float)
+    p.add_argument('--val_interval', default=5, type=int)
+    p.add_argument('--val_img_interval', default=5, type=int)
+    p.add_argument('--save_model_interval', default=5, type=int)
+    p.add_argument('--artifacts', default='tdsr', type=str)
+    p.add_argument('--dataset', default='synthetic', type=str)
+    p.add_argument('--flips', dest='flips', action='store_true')
+    p.add_argument('--rotations', dest='rotations', action='store_true')
+    p.add_argument('--num_res_blocks', default=8, type=int)
+    p.add_argument('--ragan', dest='ragan', action='store_true')
+    p.add_argument('--wgan', dest='wgan', action='store_true')
+    p.add_argument('--no_highpass', dest='highpass', action='store_false')
+    p.add_argument('--kernel_size', default=5, type=int)
+    p.add_argument('--no_per_loss', dest='use_per_loss', action='store_false')
+    p.add_argument('--lpips_rot_flip', dest='lpips_rot_flip', action='store_true')
+    p.add_argument('--per_type', default='VGG', type=str)
+    p.add_argument('--disc_freq', default=1, type=int)
+    p.add_argument('--gen_freq', default=1, type=int)
+    p.add_argument('--w_col', default=1, type=float)
+    p.add_argument('--w_tex', default=0.005, type=float)
+    p.add_argument('--w_per', default=0.01, type=float)
+    p.add_argument('--checkpoint', default=None, type=str)
+    p.add_argument('--save_path', default=None, type=str)
+    p.add_argument('--generator', default='DeResnet', type=str)
+    p.add_argument('--discriminator', default='FSD', type=str)
+    p.add_argument('--filter', default='gau', type=str)
+    p.add_argument('--cat_or_sum', default='cat', type=str)
+    p.add_argument('--norm_layer', default='Instance', type=str)
+    p.add_argument('--no_saving', dest='saving', action='store_false')
+    p.add_argument('--debug', dest='debug', action='store_true')
+    # additions of this build
+    p.add_argument('--iters_per_epoch', default=100, type=int, help='synthetic dataset: iterations per epoch')
+    p.add_argument('--vgg_path', default=None, type=str, help='torchvision vgg16 state_dict for --per_type VGG')
+    return p
+
+
+def check_supported(o):
+    if o.generator != 'DeResnet':
+        raise NotImplementedError('Generator model [{:s}] not recognized'.format(o.generator))
+    if o.discriminator.lower() != 'fsd':
+        raise NotImplementedError('Discriminator architecture [{:s}] not recognized'.format(o.discriminator))
+    if o.ragan or o.wgan or not o.highpass or o.cat_or_sum != 'cat' or o.norm_layer != 'Instance':
+        raise NotImplementedError('DSN on MI355X covers the default path: DCGAN loss, high-pass front end, wavelet bands cat, Instance norm')
+    if o.disc_freq != 1 or o.gen_freq != 1:
+        raise NotImplementedError('disc_freq / gen_freq other than 1')
+
+
+class SyntheticCrops:
+    """(hr [b,3,c,c], bicubic_lr [b,3,c/4,c/4], real_lr [b,3,c/4,c/4]) in [0,1] (data_loader.py:50-54)"""
+
+    def __init__(self, batch, crop, n, seed=1234):
+        self.b, self.c, self.n, self.seed = batch, crop, n, seed
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed)
+        b, c = self.b, self.c
+        for _ in range(self.n):
+            yield torch.rand(b, 3, c, c, generator=g), torch.rand(b, 3, c // 4, c // 4, generator=g), torch.rand(b, 3, c // 4, c // 4, generator=g)
+
+
+def main(argv=None, loader=None):
+    o = build_parser().parse_args(argv)
+    check_supported(o)
+    logging.basicConfig(level=logging.INFO, format='%(asctime)s %(message)s')
+    log = logging.getLogger('base')
+    torch.manual_seed(0)  # train.py:76
+    dp = DataParallelGroup() if int(os.environ.get('WORLD_SIZE', '1')) > 1 else None
+    rank = dp.rank if dp else 0
+    if dp:
+        torch.cuda.set_device(dp.local_rank)
+    if o.debug:
+        o.num_epochs, o.iters_per_epoch = min(o.num_epochs, 2), min(o.iters_per_epoch, 3)
+    opt = dict(n_res_blocks=o.num_res_blocks, kernel_size=o.kernel_size, filter=o.filter, norm_layer=o.norm_layer, discriminator=o.discriminator,
+               learning_rate=o.learning_rate, adam_beta_1=o.adam_beta_1, w_col=o.w_col, w_tex=o.w_tex, w_per=o.w_per if o.use_per_loss else 0.0,
+               per_type=o.per_type, vgg_path=o.vgg_path, num_epochs=o.num_epochs, num_decay_epochs=o.num_decay_epochs,
+               upscale_factor=o.upscale_factor)
+    model = DSNModel(opt)
+    if dp:
+        model.dp = dp
+        for net in model.networks():
+            dp.broadcast_params(net.params.flat)
+            net.repack()
+    start_epoch = 1
+    if o.checkpoint:
+        model.load(o.checkpoint)
+        start_epoch = model.epoch + 1
+        log.info('Continuing training at epoch %d' % start_epoch)
+    if loader is None:
+        if o.dataset != 'synthetic':
+            raise NotImplementedError('dataset [%s]: pass a loader of (hr, bicubic_lr, real_lr) batches; only "synthetic" is built in' % o.dataset)
+        per_rank = o.batch_size // (dp.world if dp else 1)
+        loader = SyntheticCrops(per_rank, o.crop_size, o.iters_per_epoch, seed=1234 + rank)
+    save_path = o.save_path or os.path.join('experiments', 'dsn_' + o.filter)
+    if o.saving and rank == 0:
+        os.makedirs(os.path.join(save_path, 'checkpoints'), exist_ok=True)
+        with open(os.path.join(save_path, 'commandline_args.txt'), 'w') as f:
+            json.dump(o.__dict__, f, indent=2)
+    dev = model.device
+    for epoch in range(start_epoch, o.num_epochs + 1):
+        for hr, bic, real in loader:
+            model.iteration(hr.to(dev, non_blocking=True), bic.to(dev, non_blocking=True), real.to(dev, non_blocking=True))
+        model.end_epoch()
+        if rank == 0:
+            lg = model.get_current_log()
+            log.info('[%d/%d] iter %d lr %.3e ' % (epoch, o.num_epochs, model.iteration_count, model.lr()) +
+                     ' '.join('%s: %.4e' % kv for kv in lg.items()))
+            if o.saving and epoch % o.save_model_interval == 0:
+                model.save(os.path.join(save_path, 'checkpoints', 'iteration_{}.tar'.format(model.iteration_count)))
+                model.save(os.path.join(save_path, 'checkpoints', 'last_iteration.tar'))
+    return model
+
+
+if __name__ == '__main__':
+    main()

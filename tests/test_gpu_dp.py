@@ -67,3 +67,52 @@ def test_two_rank_step_equals_full_batch_step(case, tmp_path):
             d = (r0[net][k] - v).abs().max().item()
             assert d <= 3.2e-4, (net, k, d)                      # Adam: sign flips of ~0 gradients move a weight by 2*lr
             assert ((r0[net][k] - v).abs() > 2e-5).float().mean().item() < 0.02, (net, k)
+
+
+def _dsn_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch
+    from dasr_amd.dist import DataParallelGroup
+    from dasr_amd.dsn_model import DSNModel
+    from oracle.gen_golden_dsn import dsn_state, dsn_batch
+    torch.cuda.set_device(0)
+    dp = DataParallelGroup(backend='gloo') if world > 1 else None
+    torch.manual_seed(0)
+    m = DSNModel(dict(filter='wavelet', w_per=0.01, vgg_seed=78))
+    m.netG.load_state_dict(dsn_state(m.netG.state_dict(), 21, 0.5))
+    m.netD.load_state_dict(dsn_state(m.netD.state_dict(), 22, 1.0))
+    if dp:
+        m.dp = dp
+        for net in m.networks():
+            dp.broadcast_params(net.params.flat)
+            net.repack()
+    hr, bic, real = dsn_batch(dict(n=2, crop=128))  # VGG16's five pools need >= 32 px LR
+    if dp:
+        hr, bic, real = (t[rank:rank + 1] for t in (hr, bic, real))
+    for _ in range(2):
+        m.iteration(hr.cuda(), bic.cuda(), real.cuda())
+    torch.cuda.synchronize()
+    torch.save({'G': m.netG.state_dict(), 'D': m.netD.state_dict()}, out % (world, rank))
+    if dp:
+        dp.barrier()
+
+
+def test_dsn_two_rank_iteration_equals_full_batch(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'dsn_w%d_r%d.pt')
+    port = 29911 + (os.getpid() % 300)
+    mp.spawn(_dsn_worker, args=(1, port, out), nprocs=1, join=True)
+    mp.spawn(_dsn_worker, args=(2, port + 1, out), nprocs=2, join=True)
+    full = torch.load(out % (1, 0))
+    r0, r1 = torch.load(out % (2, 0)), torch.load(out % (2, 1))
+    for net in ('G', 'D'):
+        for k, v in full[net].items():
+            assert torch.equal(r0[net][k], r1[net][k]), (net, k)
+            if k in ('net.net.2.bias', 'net.net.5.bias'):
+                continue  # bias in front of an InstanceNorm: true gradient 0, Adam turns the rounding noise into +-lr steps (no effect on D)
+            d = (r0[net][k] - v).abs().max().item()
+            assert d <= 4.2e-4, (net, k, d)   # two Adam steps at lr 1e-4: a flipped ~0 gradient moves a weight by <= 2*lr per step
+            if v.numel() > 64:
+                assert ((r0[net][k] - v).abs() > 2e-5).float().mean().item() < 0.03, (net, k)

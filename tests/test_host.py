@@ -142,3 +142,48 @@ def test_product_path_does_not_import_oracle():
             if f.endswith('.py'):
                 txt = open(os.path.join(root, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle', txt, flags=re.M), f
+
+
+# ---- DSN host side (codes/DSN) -------------------------------------------------------------------------------------
+def test_dsn_default_init_replays_reference_rng_and_key_order(golden_dir):
+    """nn.Conv2d / nn.PReLU default init in construction order under torch.manual_seed(0) (codes/DSN/train.py:76,127-135);
+    key order against the fixtures made from the reference modules"""
+    import numpy as np
+    from dasr_amd import dsn_model as M
+    from dasr_amd.gan_nets import fsd_spec
+    from oracle import dsn
+    for filt, case in (('gau', 'dsn_gau5_inst_b2_128'), ('wavelet', 'dsn_wavelet_inst_b2_128'), ('avg_pool', 'dsn_avg5_inst_b1_160')):
+        gold = np.load(os.path.join(golden_dir, case + '.npz'))
+        torch.manual_seed(0)
+        G, D = dsn.DeResnet(), dsn.Discriminator(5, 'Instance', filt)
+        torch.manual_seed(0)
+        nc = 9 if filt == 'wavelet' else 3
+        g_spec, d_spec = M.deresnet_spec(8), fsd_spec(nc, 5 if filt == 'gau' else None)[0]
+        a, b = M.default_init_state(g_spec), M.default_init_state(d_spec)
+        assert [k for k, _ in g_spec] == list(gold['G_keys']) and [k for k, _ in d_spec] == list(gold['D_keys'])
+        assert all(torch.equal(a[k], v) for k, v in G.state_dict().items())
+        assert all(torch.equal(b[k], v) for k, v in D.state_dict().items())
+    assert sum(v.numel() for v in a.values()) == 668238  # SURVEY.md 8(a) a19
+
+
+def test_dsn_cli_flags_and_lr_rule():
+    from dasr_amd import dsn_train, dsn_model
+    o = dsn_train.build_parser().parse_args([])
+    assert (o.batch_size, o.num_epochs, o.num_decay_epochs, o.learning_rate, o.adam_beta_1) == (4, 400, 150, 1e-4, 0.5)
+    assert (o.w_col, o.w_tex, o.w_per, o.kernel_size, o.filter, o.discriminator, o.generator) == (1, 0.005, 0.01, 5, 'gau', 'FSD', 'DeResnet')
+    dsn_train.check_supported(o)
+    for bad in (['--generator', 'DSGAN'], ['--discriminator', 'nld_s1'], ['--ragan'], ['--wgan'], ['--norm_layer', 'Batch']):
+        with pytest.raises(NotImplementedError):
+            dsn_train.check_supported(dsn_train.build_parser().parse_args(bad))
+    # LambdaLR rule of train.py:154-157 against torch's scheduler
+    m = dsn_model.DSNModel.__new__(dsn_model.DSNModel)
+    m.opt = dict(num_epochs=10, num_decay_epochs=4, learning_rate=2e-4)
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=2e-4)
+    rule = lambda e: 1.0 if e < 6 else 1.0 - max(0.0, float(e - 6) / 4)
+    sch = torch.optim.lr_scheduler.LambdaLR(opt, rule)
+    for e in range(10):
+        m.epoch = e
+        assert abs(m.lr() - opt.param_groups[0]['lr']) < 1e-12
+        opt.step()
+        sch.step()
