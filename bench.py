@@ -192,15 +192,14 @@ def sweep(model, data, a):
     fl = lambda ops: sum(2.0 * o.conv.N * o.conv.Hout * o.conv.Wout * 9 * o.conv.cin * o.conv.cout for o in ops)
     res = {}
     for rnd in range(2):
-        for v in (0, 7):
+        for v in (0, 8, 9):
             L.dasr_set_tuning(1, v)
             ms = time_ops(c32)
             res.setdefault(('rdb32', v), []).append(fl(c32) / ms / 1e9)
         L.dasr_set_tuning(1, 0)
         L.dasr_set_tuning(4, 1)
-        for v in (0, 10):
-            L.dasr_set_tuning(4, 0 if v == 10 else 1)
-            L.dasr_set_tuning(2, 0)
+        for v in (0, 8, 9):
+            L.dasr_set_tuning(2, v)
             ms = time_ops(c64)
             res.setdefault(('rdb64', v), []).append(fl(c64) / ms / 1e9)
         L.dasr_set_tuning(2, 0)
@@ -216,7 +215,7 @@ def sweep(model, data, a):
         res.setdefault(('wgrad_reduce_us', 0), []).append(ms * 1e3)
     for k, v in res.items():
         log('sweep %-16s variant %d : %s (TFLOP/s algorithmic; stream = 1/3 of MFMA rate)' % (k[0], k[1], ' '.join('%.0f' % x for x in v)))
-    for combo in ((0, 0, 0, 1), (7, 0, 0, 1), (0, 0, 0, 1), (7, 0, 0, 1)):
+    for combo in ((0, 0, 0, 1), (8, 8, 0, 1), (9, 9, 0, 1), (0, 0, 0, 1), (8, 8, 0, 1), (9, 9, 0, 1)):
         for k, v in zip((1, 2, 3, 4), combo):
             L.dasr_set_tuning(k, v)
         run_steps(1)

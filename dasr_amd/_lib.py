@@ -115,7 +115,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise DasrHipError('libdasr_hip.so is missing (%s): run `python -m dasr_amd.build` or __graft_entry__.build(); '
                                'the DASR MI355X path has no fallback.' % LIB_PATH)
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(os.environ.get('DASR_HIP_LIB') or LIB_PATH)  # DASR_HIP_LIB: instrumented build for scripts/ (same ABI)
         for name, args in _SIGS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export it
             fn.argtypes = args

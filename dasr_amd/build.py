@@ -18,8 +18,13 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
+def build(force=False, verbose=False, trace=False):
+    """trace=True: instrumented copy (libdasr_hip_trace.so, -DDASR_TRACE: per-workgroup s_memtime stamps in conv_kernel) for
+    scripts/micro_conv.py; never loaded by the product path unless DASR_HIP_LIB points at it."""
+    global LIB
+    if trace:
+        LIB = os.path.join(HERE, 'libdasr_hip_trace.so')
+    if not force and not trace and not _stale():
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
@@ -29,8 +34,8 @@ def build(force=False, verbose=False):
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):
             continue
-        obj = os.path.join(HERE, 'build', src.replace('.hip', '.o'))
-        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', path, '-o', obj]
+        obj = os.path.join(HERE, 'build', src.replace('.hip', '_trace.o' if trace else '.o'))
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', path, '-o', obj] + (['-DDASR_TRACE'] if trace else [])
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
     for cmd, p in procs:
@@ -45,4 +50,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    print(build(force='--force' in sys.argv, verbose=True, trace='--trace' in sys.argv))

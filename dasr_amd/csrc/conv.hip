@@ -46,12 +46,196 @@ constexpr unsigned OOB = 0x80000000u;
 constexpr int RSRC_FLAGS = 0x00020000;
 constexpr int RSRC_RANGE = 0x7fffffff;
 
+#ifdef DASR_TRACE
+__device__ unsigned long long* g_trace = nullptr;  // [grid][16]: s_memrealtime at entry, then s_memtime stamps
+#define TRACE_STAMP(k)                                                                         \
+    do {                                                                                       \
+        if (g_trace && threadIdx.x == 0) g_trace[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define TRACE_STAMP(k) do {} while (0)
+#endif
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, RSRC_RANGE, RSRC_FLAGS);
 }
 
-template <int PREC, bool IN_F32, int MT, int KH, int STRIDE, int NT, int KS, bool DBUF>
-__global__ __launch_bounds__(256, (MT == 1 && PREC == 1 && !IN_F32) ? 3 : 2) void conv_kernel(const dasr_conv_params p) {
+// ---------------------------------------------------------------------------------------------------
+// Epilogue shared by the conv kernels: acc (MFMA D layout: lane -> pixel nn = lane & 31 of an n-tile row, channels
+// 8g + 4*(lane >> 5) + j of the m-tile) -> bias / activation / mask / scaled residual adds -> fp32 and/or bf16 stores.
+// ---------------------------------------------------------------------------------------------------
+template <bool IN_F32, int MT, int NT, int STRIDE, int EPI>
+__device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 (&acc)[MT][NT], char* smem, float bias_reg, int tid, int mg, int n,
+                                              int oy0, int ox0) {
+    const int lane = tid & 63, wave = tid >> 6, nn = lane & 31, kh2 = lane >> 5;
+    (void)lane;
+    // ---- epilogue.  EPI != 0: the set of optional terms is a compile-time constant (the hot dense-block cases, chosen by
+    // the host from the call's arguments), the code is straight-line; EPI == 0: every term is selected by a wave-uniform
+    // branch on a kernel argument.  Only per-lane conditions (partial tiles) use out-of-range offsets.  The bias of the
+    // m-group was fetched by the first 32*MT threads at kernel start and is handed round through LDS (free after the loop).
+    constexpr bool G = EPI == 0;
+    const bool has_bias = G ? p.bias != nullptr : bool(EPI & 1);
+    const bool act_lrelu = G ? p.act == 1 : bool(EPI & 2);
+    const bool act_sigmoid = G ? p.act == 2 : false;
+    const bool has_mask = G ? p.mask.p != nullptr : bool(EPI & 4);
+    const bool has_r1 = G ? p.res1.p != nullptr : bool(EPI & 8);
+    const bool has_r2 = G ? p.res2.p != nullptr : bool(EPI & 16);
+    const bool has_f32 = G ? p.out_f32.p != nullptr : bool(EPI & 32);
+    const bool has_bf16 = G ? p.out_bf16.p != nullptr : bool(EPI & 64);
+    const bool scaled = G ? true : bool(EPI & 128);   // alpha / gamma may differ from 1
+    const bool chan_tail = G ? true : false;          // cout not a multiple of 32 (specialised variants require it)
+    const int ostr = p.out_stride > 1 ? p.out_stride : 1, owid = p.out_W > 0 ? p.out_W : p.Wout;  // strided sub-grid output (stride-2 dgrad)
+    constexpr int MSZ = IN_F32 ? 4 : 2;
+    const float slope = (G && p.slope_ptr) ? *p.slope_ptr : p.slope;  // PReLU: the (learned) slope lives in the parameter buffer
+    const __amdgpu_buffer_rsrc_t rmask = make_rsrc((const char*)p.mask.p + (size_t)n * p.mask.n_stride * MSZ);
+    const __amdgpu_buffer_rsrc_t rr1 = make_rsrc((const float*)p.res1.p + (size_t)n * p.res1.n_stride);
+    const __amdgpu_buffer_rsrc_t rr2 = make_rsrc((const float*)p.res2.p + (size_t)n * p.res2.n_stride);
+    const __amdgpu_buffer_rsrc_t rof = make_rsrc((float*)p.out_f32.p + (size_t)n * p.out_f32.n_stride);
+    const __amdgpu_buffer_rsrc_t rob = make_rsrc((bf16_t*)p.out_bf16.p + (size_t)n * p.out_bf16.n_stride);
+    const unsigned mask_cb = (unsigned)p.mask.cb_stride, r1_cb = (unsigned)p.res1.cb_stride, r2_cb = (unsigned)p.res2.cb_stride;
+    const unsigned of_cb = (unsigned)p.out_f32.cb_stride, ob_cb = (unsigned)p.out_bf16.cb_stride;
+    f32x4 bia[MT][4];
+    if (has_bias) {
+        float* bl = (float*)smem;
+        if (tid < 32 * MT) bl[tid] = bias_reg;
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bia[mi][g] = *(const f32x4*)(bl + mi * 32 + 8 * g + 4 * kh2);
+    }
+    TRACE_STAMP(5);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        int r, c;
+        if constexpr (STRIDE == 1) {
+            r = wave * NT + nt;
+            c = nn;
+        } else {
+            r = (wave * NT + nt) * 2 + (nn >> 4);
+            c = nn & 15;
+        }
+        const int oy = oy0 + r, ox = ox0 + c;
+        const bool pv = oy < p.Hout && ox < p.Wout;
+        const unsigned pixel = (unsigned)((oy * ostr + p.out_oy) * owid + ox * ostr + p.out_ox) * 16u;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            u32x4 mk[4], r1v[4], r2v[4];
+            unsigned eo[4], cbv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int oc = (mg * MT + mi) * 32 + 8 * g + 4 * kh2;
+                const bool cv = chan_tail ? (pv && oc < ((p.cout + 15) & ~15)) : pv;
+                cbv[g] = (unsigned)(oc >> 4);
+                eo[g] = cv ? pixel + (unsigned)(oc & 15) : OOB;
+            }
+            if (has_mask) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned mo = eo[g] != OOB ? (cbv[g] * mask_cb + eo[g]) * MSZ : OOB;
+                    if constexpr (IN_F32) {
+                        mk[g] = __builtin_amdgcn_raw_buffer_load_b128(rmask, mo, 0, 0);
+                    } else {
+                        const u32x2 t2 = __builtin_amdgcn_raw_buffer_load_b64(rmask, mo, 0, 0);
+                        mk[g] = u32x4{t2[0] << 16, t2[0] & 0xffff0000u, t2[1] << 16, t2[1] & 0xffff0000u};
+                    }
+                }
+            }
+            if (has_r1) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) r1v[g] = __builtin_amdgcn_raw_buffer_load_b128(rr1, eo[g] != OOB ? (cbv[g] * r1_cb + eo[g]) * 4u : OOB, 0, 0);
+            }
+            if (has_r2) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) r2v[g] = __builtin_amdgcn_raw_buffer_load_b128(rr2, eo[g] != OOB ? (cbv[g] * r2_cb + eo[g]) * 4u : OOB, 0, 0);
+            }
+            // arithmetic in passes: the VALU work of an absent term is skipped, not multiplied by a neutral coefficient
+            // (64 outputs per lane: every op per element is 64 VALU instructions per wave; exp/rcp are quarter rate)
+            float v[4][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[g][j] = acc[mi][nt][4 * g + j];
+            if (has_bias) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[g][j] += bia[mi][g][j];
+            }
+            if (act_lrelu) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[g][j] = fmaxf(v[g][j], 0.f) + slope * fminf(v[g][j], 0.f);
+            } else if (act_sigmoid) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[g][j] = __frcp_rn(1.f + __expf(-v[g][j]));
+            }
+            if (has_mask) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[g][j] *= __uint_as_float(mk[g][j]) > 0.f ? 1.f : slope;
+            }
+            if (scaled && p.alpha != 1.f) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[g][j] *= p.alpha;
+            }
+            if (has_r1) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[g][j] += p.beta1 * __uint_as_float(r1v[g][j]);
+            }
+            if (has_r2) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[g][j] += p.beta2 * __uint_as_float(r2v[g][j]);
+            }
+            if (chan_tail && (mg * MT + mi) * 32 + 32 > p.cout) {  // last, partial m-tile: padded channels of the last plane stay zero
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if ((mg * MT + mi) * 32 + 8 * g + 4 * kh2 + j >= p.cout) v[g][j] = 0.f;
+            }
+            if (has_f32) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const u32x4 o = {__float_as_uint(v[g][0]), __float_as_uint(v[g][1]), __float_as_uint(v[g][2]), __float_as_uint(v[g][3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rof, eo[g] != OOB ? (cbv[g] * of_cb + eo[g]) * 4u : OOB, 0, 0);
+                }
+            }
+            if (has_bf16) {
+                const bool gm = scaled && p.gamma != 1.f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 ob;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)(gm ? v[g][j] * p.gamma : v[g][j]);
+#ifdef DASR_TRACE
+                    if (p.xcd_remap & 2) {  // timing experiment only: lane-linear (fully contiguous) store addresses, wrong layout
+                        const unsigned lin = ((((unsigned)blockIdx.x * 4 + wave) * NT + nt) * 4 + g) * 512u + (unsigned)lane * 8u;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), make_rsrc(p.out_bf16.p), lin, 0, 0);
+                        continue;
+                    }
+#endif
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), rob, eo[g] != OOB ? (cbv[g] * ob_cb + eo[g]) * 2u : OOB, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+template <int PREC, bool IN_F32, int MT, int KH, int STRIDE, int NT, int KS, bool DBUF, int MODE, int EPI>
+__global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) {
+    constexpr bool RU = MODE == 1, PIPE = MODE == 2;  // PIPE requires DBUF (two LDS buffers)
+    static_assert(!PIPE || (DBUF && PREC == 1 && !IN_F32), "pipelined main loop: bf16 dense-block convs, double-buffered LDS");
     using C = Cfg<PREC, IN_F32, MT, KH, STRIDE, NT, KS, DBUF>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // buffer b: [act_hi | act_lo (prec 3) | w_hi | w_lo (prec 3)]; one 16 B dummy slot after the buffers
@@ -59,6 +243,10 @@ __global__ __launch_bounds__(256, (MT == 1 && PREC == 1 && !IN_F32) ? 3 : 2) voi
     constexpr int DUMMY = C::LDS_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef DASR_TRACE
+    if (g_trace && threadIdx.x == 0) g_trace[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+#endif
+    TRACE_STAMP(0);
     const int cout_tiles = (p.cout + 31) >> 5;
     const int MG = (cout_tiles + MT - 1) / MT;
     const int tiles_x = (p.Wout + C::TW - 1) / C::TW, tiles_y = (p.Hout + C::TH - 1) / C::TH;
@@ -80,6 +268,13 @@ __global__ __launch_bounds__(256, (MT == 1 && PREC == 1 && !IN_F32) ? 3 : 2) voi
     const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
     const int nchunks = p.cin / (16 * KS);
     constexpr int ESZ = IN_F32 ? 4 : 2;
+    // bias of this m-group: one value per thread of the first 32*MT, consumed in the epilogue (latency hidden by the main loop)
+    float bias_reg = 0.f;
+    {
+        const int oc = mg * MT * 32 + tid;
+        const unsigned bo = (p.bias && tid < 32 * MT && oc < p.cout) ? (unsigned)oc * 4u : OOB;
+        bias_reg = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(p.bias), bo, 0, 0));
+    }
 
     // ---- per-thread staging offsets (independent of the chunk) ----
     unsigned goff[C::AR];  // byte offset inside the image, OOB: zero fill
@@ -112,6 +307,19 @@ __global__ __launch_bounds__(256, (MT == 1 && PREC == 1 && !IN_F32) ? 3 : 2) voi
 
     u32x4 areg[C::AR];
     u32x4 wreg[C::WR * C::NARR];
+    u32x4 areg2[PIPE ? C::AR : 1], wreg2[PIPE ? C::WR : 1];  // second staging set of the pipelined main loop
+    auto load_set = [&](int ck, u32x4* ar, u32x4* wr) {
+        const unsigned so = (unsigned)ck * in_chunk_bytes, wo = (unsigned)ck * w_chunk_bytes;
+#pragma unroll
+        for (int r = 0; r < C::AR; ++r) ar[r] = __builtin_amdgcn_raw_buffer_load_b128(rin, goff[r], so, 0);
+#pragma unroll
+        for (int r = 0; r < C::WR; ++r) wr[r] = __builtin_amdgcn_raw_buffer_load_b128(rw, woff[r], wo, 0);
+    };
+    // one 16-byte piece of a staged chunk -> LDS (bf16 input): piece i < AR: activations, else weights
+    auto store_piece = [&](char* buf, const u32x4* ar, const u32x4* wr, int i) {
+        if (i < C::AR) *(u32x4*)(buf + loff[i]) = ar[i];
+        else *(u32x4*)(buf + W_HI + wloff[i - C::AR]) = wr[i - C::AR];
+    };
 
     auto load_chunk = [&](int ck) {
         const unsigned so = (unsigned)ck * in_chunk_bytes;
@@ -179,6 +387,63 @@ __global__ __launch_bounds__(256, (MT == 1 && PREC == 1 && !IN_F32) ? 3 : 2) voi
         const char* act_lo = buf + ACT_LO;
         const char* w_hi = buf + W_HI;
         const char* w_lo = buf + W_LO;
+        if constexpr (RU) {
+            // row reuse (3x3 stride 1, bf16): a wave's NT output rows need NT+2 input rows per kx; each row fragment is read from LDS
+            // once and feeds the MFMAs of the three ky taps -> 3*(NT+2+3*MT) instead of 9*(NT+MT) ds_read_b128 per chunk
+            static_assert(!RU || (KH == 3 && STRIDE == 1 && PREC == 1), "row reuse: 3x3 stride-1 bf16 only");
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    bf16x8 brow[NT + 2], a[3][MT];
+#pragma unroll
+                    for (int rr = 0; rr < NT + 2; ++rr) brow[rr] = *(const bf16x8*)(act_hi + boff[0] + (rr * C::IW + kx) * C::PIXB + ks * 32);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int mi = 0; mi < MT; ++mi)
+                            a[ky][mi] = *(const bf16x8*)(w_hi + ((ks * 9 + ky * 3 + kx) * MT + mi) * 1024 + aoff);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ky][mi], brow[nt + ky], acc[mi][nt], 0, 0, 0);
+                }
+            }
+            return;
+        }
+        if constexpr (PIPE) return;  // (PIPE uses compute_store below)
+        if constexpr (PREC == 1 && !IN_F32) {
+            // software pipeline over taps: the fragments of tap t+1 are requested from LDS before the MFMAs of tap t are issued
+            // (two register sets), so an MFMA never waits on a ds_read issued just ahead of it (hipcc's own schedule reads
+            // just-in-time: lgkmcnt(1) before every MFMA pair, ~130 cycles per MFMA instead of 32)
+            constexpr int TOT = KS * C::NTAPS;
+            bf16x8 fa[2][MT], fb[2][NT];
+            auto ldfrag = [&](int idx, int set) {
+                const int ks = idx / C::NTAPS, t = idx - ks * C::NTAPS;
+                const int ky = t / KH, kx = t - ky * KH;
+                const int toff = (ky * C::IW + kx) * C::PIXB + ks * 32;
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) fa[set][mi] = *(const bf16x8*)(w_hi + ((ks * C::NTAPS + t) * MT + mi) * 1024 + aoff);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) fb[set][nt] = *(const bf16x8*)(act_hi + boff[nt] + toff);
+            };
+            ldfrag(0, 0);
+#pragma unroll
+            for (int idx = 0; idx < TOT; ++idx) {
+                if (idx + 1 < TOT) ldfrag(idx + 1, (idx + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[idx & 1][mi], fb[idx & 1][nt], acc[mi][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -210,7 +475,64 @@ __global__ __launch_bounds__(256, (MT == 1 && PREC == 1 && !IN_F32) ? 3 : 2) voi
         }
     };
 
+    // pipelined main loop: MFMAs of tap t | LDS fragment reads of tap t+1 | ds_write of one staged piece of chunk k+1, all in one
+    // instruction stream; global loads run two chunks ahead (two register sets), so neither their latency nor the LDS fill is exposed:
+    // one barrier per chunk
+    auto compute_store = [&](const char* buf, char* nbuf, const u32x4* ar, const u32x4* wr) {
+        constexpr int TOT = KS * C::NTAPS, NP = C::AR + C::WR;
+        const char* act_hi = buf;
+        const char* w_hi = buf + W_HI;
+        bf16x8 fa[2][MT], fb[2][NT];
+        auto ldfrag = [&](int idx, int set) {
+            const int ks = idx / C::NTAPS, t = idx - ks * C::NTAPS;
+            const int ky = t / KH, kx = t - ky * KH;
+            const int toff = (ky * C::IW + kx) * C::PIXB + ks * 32;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) fa[set][mi] = *(const bf16x8*)(w_hi + ((ks * C::NTAPS + t) * MT + mi) * 1024 + aoff);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) fb[set][nt] = *(const bf16x8*)(act_hi + boff[nt] + toff);
+        };
+        ldfrag(0, 0);
+#pragma unroll
+        for (int idx = 0; idx < TOT; ++idx) {
+            if (idx + 1 < TOT) ldfrag(idx + 1, (idx + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[idx & 1][mi], fb[idx & 1][nt], acc[mi][nt], 0, 0, 0);
+            // the NP staged pieces of the next chunk are spread over the taps
+#pragma unroll
+            for (int i = idx * NP / TOT; i < (idx + 1) * NP / TOT; ++i) store_piece(nbuf, ar, wr, i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if constexpr (PIPE) {
+        load_set(0, areg, wreg);
+        if (nchunks > 1) load_set(1, areg2, wreg2);
+        TRACE_STAMP(1);
+#pragma unroll
+        for (int i = 0; i < C::AR + C::WR; ++i) store_piece(smem, areg, wreg, i);
+        __syncthreads();
+        TRACE_STAMP(2);
+        char* b0 = smem;
+        char* b1 = smem + C::BUF_BYTES;
+        for (int ck = 0; ck < nchunks; ck += 2) {
+            // even chunk: compute b0, fill b1 from set 2 (chunk ck+1), fetch chunk ck+2 into set 1
+            if (ck + 2 < nchunks) load_set(ck + 2, areg, wreg);
+            compute_store(b0, b1, areg2, wreg2);
+            __syncthreads();
+            if (ck + 1 >= nchunks) break;
+            if (ck + 3 < nchunks) load_set(ck + 3, areg2, wreg2);
+            compute_store(b1, b0, areg, wreg);
+            __syncthreads();
+        }
+        TRACE_STAMP(3);
+    } else {
     load_chunk(0);
+    TRACE_STAMP(1);
     if constexpr (DBUF) {
         // one barrier per chunk: chunk ck+1 is fetched to registers before, and written to the other LDS
         // buffer after, the MFMAs of chunk ck
@@ -226,113 +548,40 @@ __global__ __launch_bounds__(256, (MT == 1 && PREC == 1 && !IN_F32) ? 3 : 2) voi
         }
     } else {
         for (int ck = 0; ck < nchunks; ++ck) {
+            if (ck == 2) TRACE_STAMP(8);
             store_chunk(smem);
+            if (ck == 2) TRACE_STAMP(9);
             __syncthreads();
+            if (ck == 0) TRACE_STAMP(2);
+            if (ck == 2) TRACE_STAMP(10);
             if (ck + 1 < nchunks) load_chunk(ck + 1);
+            if (ck == 2) TRACE_STAMP(11);
             compute(smem);
+            if (ck == 0) TRACE_STAMP(3);
+            if (ck == 2) TRACE_STAMP(12);
             __syncthreads();
+            if (ck == 2) TRACE_STAMP(13);
         }
     }
+    }
+    TRACE_STAMP(4);
 
-    // ---- epilogue: straight-line code.  Absent tensors are read/written at OOB offsets (loads return 0, stores are
-    // dropped) and neutral coefficients make the arithmetic a no-op, so there is not a single branch: all loads of a
-    // (tile, m-tile) group are in flight together.  The mask tensor has the input's dtype (bf16 slabs / f32 stream).
-    const int cout_pad = (p.cout + 15) & ~15;
-    const int ostr = p.out_stride > 1 ? p.out_stride : 1, owid = p.out_W > 0 ? p.out_W : p.Wout;  // strided sub-grid output (stride-2 dgrad)
-    constexpr int MSZ = IN_F32 ? 4 : 2;
-    const bool has_mask = p.mask.p != nullptr, has_r1 = p.res1.p != nullptr, has_r2 = p.res2.p != nullptr;
-    const bool has_f32 = p.out_f32.p != nullptr, has_bf16 = p.out_bf16.p != nullptr;
-    const float slope = p.slope_ptr ? *p.slope_ptr : p.slope;  // PReLU: the (learned) slope lives in the parameter buffer
-    const float act_slope = p.act == 1 ? slope : 1.f, mask_slope = has_mask ? slope : 1.f;
-    const bool act_sigmoid = p.act == 2;
-    const float beta1 = has_r1 ? p.beta1 : 0.f, beta2 = has_r2 ? p.beta2 : 0.f;
-    const __amdgpu_buffer_rsrc_t rmask = make_rsrc((const char*)p.mask.p + (size_t)n * p.mask.n_stride * MSZ);
-    const __amdgpu_buffer_rsrc_t rr1 = make_rsrc((const float*)p.res1.p + (size_t)n * p.res1.n_stride);
-    const __amdgpu_buffer_rsrc_t rr2 = make_rsrc((const float*)p.res2.p + (size_t)n * p.res2.n_stride);
-    const __amdgpu_buffer_rsrc_t rof = make_rsrc((float*)p.out_f32.p + (size_t)n * p.out_f32.n_stride);
-    const __amdgpu_buffer_rsrc_t rob = make_rsrc((bf16_t*)p.out_bf16.p + (size_t)n * p.out_bf16.n_stride);
-    const __amdgpu_buffer_rsrc_t rbias = make_rsrc(p.bias);
-    const unsigned mask_cb = (unsigned)p.mask.cb_stride, r1_cb = (unsigned)p.res1.cb_stride, r2_cb = (unsigned)p.res2.cb_stride;
-    const unsigned of_cb = (unsigned)p.out_f32.cb_stride, ob_cb = (unsigned)p.out_bf16.cb_stride;
-    // bias: 4 consecutive channels per (mi, g); per-element OOB so cout = 3 or 1 stay in range
-    float bia[MT][4][4];
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int oc = (mg * MT + mi) * 32 + 8 * g + 4 * kh2;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned bo = (p.bias && oc + j < p.cout) ? (unsigned)(oc + j) * 4u : OOB;
-                bia[mi][g][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rbias, bo, 0, 0));
-            }
-        }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        int r, c;
-        if constexpr (STRIDE == 1) {
-            r = wave * NT + nt;
-            c = nn;
-        } else {
-            r = (wave * NT + nt) * 2 + (nn >> 4);
-            c = nn & 15;
-        }
-        const int oy = oy0 + r, ox = ox0 + c;
-        const bool pv = oy < p.Hout && ox < p.Wout;
-        const unsigned pixel = (unsigned)((oy * ostr + p.out_oy) * owid + ox * ostr + p.out_ox) * 16u;
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            u32x4 mk[4], r1v[4], r2v[4];
-            unsigned eo[4], cbv[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int oc = (mg * MT + mi) * 32 + 8 * g + 4 * kh2;
-                const bool cv = pv && oc < cout_pad;
-                cbv[g] = (unsigned)(oc >> 4);
-                eo[g] = pixel + (unsigned)(oc & 15);
-                const unsigned mo = (cv && has_mask) ? (cbv[g] * mask_cb + eo[g]) * MSZ : OOB;
-                if constexpr (IN_F32) {
-                    mk[g] = __builtin_amdgcn_raw_buffer_load_b128(rmask, mo, 0, 0);
-                } else {
-                    const u32x2 t2 = __builtin_amdgcn_raw_buffer_load_b64(rmask, mo, 0, 0);
-                    mk[g] = u32x4{t2[0] << 16, t2[0] & 0xffff0000u, t2[1] << 16, t2[1] & 0xffff0000u};
-                }
-                r1v[g] = __builtin_amdgcn_raw_buffer_load_b128(rr1, (cv && has_r1) ? (cbv[g] * r1_cb + eo[g]) * 4u : OOB, 0, 0);
-                r2v[g] = __builtin_amdgcn_raw_buffer_load_b128(rr2, (cv && has_r2) ? (cbv[g] * r2_cb + eo[g]) * 4u : OOB, 0, 0);
-                if (!cv) eo[g] = OOB;
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int oc = (mg * MT + mi) * 32 + 8 * g + 4 * kh2;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float t = acc[mi][nt][4 * g + j] + bia[mi][g][j];
-                    t = fmaxf(t, 0.f) + act_slope * fminf(t, 0.f);
-                    if (act_sigmoid) t = 1.f / (1.f + __expf(-t));
-                    t *= __uint_as_float(mk[g][j]) > 0.f ? 1.f : mask_slope;
-                    t = p.alpha * t + beta1 * __uint_as_float(r1v[g][j]) + beta2 * __uint_as_float(r2v[g][j]);
-                    v[j] = (oc + j < p.cout) ? t : 0.f;  // padded channels of the last plane stay zero
-                }
-                const unsigned e = eo[g];
-                const u32x4 o = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-                __builtin_amdgcn_raw_buffer_store_b128(o, rof, (e != OOB && has_f32) ? (cbv[g] * of_cb + e) * 4u : OOB, 0, 0);
-                bf16x4 ob;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)(v[j] * p.gamma);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), rob,
-                                                     (e != OOB && has_bf16) ? (cbv[g] * ob_cb + e) * 2u : OOB, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);  // keep the next group's loads from being hoisted over this one (VGPR pressure)
-        }
-    }
+    conv_epilogue<IN_F32, MT, NT, STRIDE, EPI>(p, acc, smem, bias_reg, tid, mg, n, oy0, ox0);
+    TRACE_STAMP(6);  // all stores issued
+#ifdef DASR_TRACE
+    __builtin_amdgcn_s_waitcnt(0);  // stamp 7 = all stores retired (vmcnt/expcnt/lgkmcnt 0)
+#endif
+    TRACE_STAMP(7);
+#ifdef DASR_TRACE
+    if (g_trace && threadIdx.x == 0) g_trace[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
-template <int PREC, bool IN_F32, int MT, int KH, int STRIDE, int NT, int KS = 1, bool DBUF = false>
+template <int PREC, bool IN_F32, int MT, int KH, int STRIDE, int NT, int KS = 1, bool DBUF = false, int MODE = 0, int EPI = 0>
 int launch(const dasr_conv_params& p, hipStream_t s) {
     using C = Cfg<PREC, IN_F32, MT, KH, STRIDE, NT, KS, DBUF>;
     static bool attr_set = false;
-    auto kfn = conv_kernel<PREC, IN_F32, MT, KH, STRIDE, NT, KS, DBUF>;
+    auto kfn = conv_kernel<PREC, IN_F32, MT, KH, STRIDE, NT, KS, DBUF, MODE, EPI>;
     if (p.cin % (16 * KS)) return DASR_EINVAL;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + 16));
@@ -388,10 +637,25 @@ __global__ void conv_naive_kernel(const dasr_conv_params p, const float* w) {
         ((bf16_t*)p.out_bf16.p)[(size_t)n * p.out_bf16.n_stride + (size_t)(oc >> 4) * p.out_bf16.cb_stride + po] = (bf16_t)(acc * p.gamma);
 }
 
+// compile-time epilogue variant of the hot dense-block cases (bit set: see conv_kernel's epilogue); 0 = generic
+int classify_epi(const dasr_conv_params& p) {
+    if ((p.cout & 31) || p.slope_ptr || p.act == 2 || p.out_stride > 1) return 0;
+    int e = (p.bias ? 1 : 0) | (p.act == 1 ? 2 : 0) | (p.mask.p ? 4 : 0) | (p.res1.p ? 8 : 0) | (p.res2.p ? 16 : 0) | (p.out_f32.p ? 32 : 0) |
+            (p.out_bf16.p ? 64 : 0);
+    if (p.res1.p || p.alpha != 1.f || p.gamma != 1.f) e |= 128;
+    return e;
+}
+
 // kernel-variant selection (A/B-able from the host: dasr_set_tuning)
-int g_tune_rdb32 = 0, g_tune_rdb64 = 0, g_tune_stream = 0, g_tune_xcd = 1;
+int g_tune_rdb32 = 0, g_tune_rdb64 = 0, g_tune_stream = 0, g_tune_xcd = 1, g_tune_epi = 1;
 
 }  // namespace
+
+#ifdef DASR_TRACE
+extern "C" int dasr_debug_set_trace(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(buf));
+}
+#endif
 
 extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
     switch (key) {
@@ -399,13 +663,14 @@ extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
         case 2: g_tune_rdb64 = value; return 0;   // Cout=64 dense conv: 0 single CK16, 1 double CK16, 2 single CK32
         case 3: g_tune_stream = value; return 0;  // split-bf16 stream conv: 0 single, 1 double
         case 4: g_tune_xcd = value; return 0;     // XCD-aware tile order on/off
+        case 5: g_tune_epi = value; return 0;     // compile-time specialised epilogues on/off
         default: return DASR_EINVAL;
     }
 }
 
 extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
     dasr_conv_params p = *pp;
-    p.xcd_remap = g_tune_xcd;
+    p.xcd_remap = g_tune_xcd;  // bit 1 (trace builds): contiguous-store timing experiment
     if (p.pad_x == 0 && p.out_stride == 0 && p.kh != 2 && p.kh != 1) p.pad_x = -1;  // zero-initialised extension fields = "same as pad"
     hipStream_t s = as_stream(stream);
     if (p.cin <= 0 || (p.cin & 15) || p.cout <= 0 || !p.w || !p.in.p) return DASR_EINVAL;
@@ -435,6 +700,15 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                 case 5: return launch<1, false, 1, 3, 1, 2, 1, true>(p, s);
                 case 6: return launch<1, false, 1, 3, 1, 1>(p, s);          // 4x32 tiles
                 case 7: return launch<1, false, 1, 3, 1, 8>(p, s);          // 32x32 tiles: -20 % bytes per pixel, half the workgroups
+                case 8: return launch<1, false, 1, 3, 1, 4, 1, false, 1>(p, s);  // row reuse of B fragments across ky
+                case 9: return launch<1, false, 1, 3, 1, 4, 1, true, 1>(p, s);
+                case 10: return launch<1, false, 1, 3, 1, 4, 1, true, 2>(p, s);  // pipelined: prefetch distance 2, ds_write inside the MFMA stream
+                case 11: return launch<1, false, 1, 3, 1, 2, 1, true, 2>(p, s);
+                default: break;
+            }
+            switch (g_tune_epi ? classify_epi(p) : 0) {
+                case 67: return launch<1, false, 1, 3, 1, 4, 1, false, 0, 67>(p, s);  // bias + LeakyReLU -> bf16 slab planes (forward conv1-4)
+                case 68: return launch<1, false, 1, 3, 1, 4, 1, false, 0, 68>(p, s);  // LeakyReLU' mask -> bf16 gslab planes (data gradient)
                 default: break;
             }
             return launch<1, false, 1, 3, 1, 4>(p, s);
@@ -444,6 +718,17 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                 case 2: if (p.cin % 32 == 0) return launch<1, false, 2, 3, 1, 4, 2, false>(p, s); break;
                 case 4: return launch<1, false, 2, 3, 1, 2>(p, s);
                 case 5: return launch<1, false, 2, 3, 1, 2, 1, true>(p, s);
+                case 8: return launch<1, false, 2, 3, 1, 4, 1, false, 1>(p, s);
+                case 9: return launch<1, false, 2, 3, 1, 4, 1, true, 1>(p, s);
+                case 10: return launch<1, false, 2, 3, 1, 4, 1, true, 2>(p, s);
+                case 11: return launch<1, false, 2, 3, 1, 2, 1, true, 2>(p, s);
+                default: break;
+            }
+            switch (g_tune_epi ? classify_epi(p) : 0) {
+                case 233: return launch<1, false, 2, 3, 1, 4, 1, false, 0, 233>(p, s);  // conv5: bias, alpha, one residual -> fp32 stream + bf16 shadow
+                case 249: return launch<1, false, 2, 3, 1, 4, 1, false, 0, 249>(p, s);  // conv5 of RDB3: two residuals (RRDB skip fused)
+                case 232: return launch<1, false, 2, 3, 1, 4, 1, false, 0, 232>(p, s);  // data gradient w.r.t. the RDB input
+                case 248: return launch<1, false, 2, 3, 1, 4, 1, false, 0, 248>(p, s);
                 default: break;
             }
             return launch<1, false, 2, 3, 1, 4>(p, s);

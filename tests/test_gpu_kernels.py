@@ -115,6 +115,21 @@ def test_conv_forward_matches_torch(case):
         assert float(pad_part.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('variant', [1, 4, 5, 8, 9, 10, 11])
+@pytest.mark.parametrize('case', CONV_CASES[:3], ids=[c[0] for c in CONV_CASES[:3]])
+def test_conv_tuning_variants_match_torch(case, variant):
+    """the A/B-able variants of the dense-block conv (dasr_set_tuning keys 1, 2: double buffering, tile heights, row reuse)"""
+    _gpu()
+    from dasr_amd import _lib
+    L = _lib.lib()
+    key = 2 if case[3] == 2 else 1
+    _lib.check(L.dasr_set_tuning(key, variant))
+    try:
+        test_conv_forward_matches_torch(case)
+    finally:
+        _lib.check(L.dasr_set_tuning(key, 0))
+
+
 def test_conv_prec3_is_fp32_grade():
     """split-bf16 must be ~fp32 accurate on un-rounded operands (this is what the residual stream relies on)."""
     dev = _gpu()
