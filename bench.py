@@ -192,17 +192,17 @@ def sweep(model, data, a):
     fl = lambda ops: sum(2.0 * o.conv.N * o.conv.Hout * o.conv.Wout * 9 * o.conv.cin * o.conv.cout for o in ops)
     res = {}
     for rnd in range(2):
-        for v in (0, 8, 9):
+        for v in (0, 12):
             L.dasr_set_tuning(1, v)
             ms = time_ops(c32)
             res.setdefault(('rdb32', v), []).append(fl(c32) / ms / 1e9)
-        L.dasr_set_tuning(1, 0)
+        L.dasr_set_tuning(1, 12)
         L.dasr_set_tuning(4, 1)
-        for v in (0, 8, 9):
+        for v in (0, 12):
             L.dasr_set_tuning(2, v)
             ms = time_ops(c64)
             res.setdefault(('rdb64', v), []).append(fl(c64) / ms / 1e9)
-        L.dasr_set_tuning(2, 0)
+        L.dasr_set_tuning(2, 12)
         L.dasr_set_tuning(4, 1)
         for v in (0, 4):
             L.dasr_set_tuning(3, v)
@@ -213,9 +213,27 @@ def sweep(model, data, a):
         res.setdefault(('wgrad_rdb', 0), []).append(2.0 * plan.N * a.lr_size * a.lr_size * 239616 / ms / 1e9)
         ms = time_ops(wg_rdb[1:])
         res.setdefault(('wgrad_reduce_us', 0), []).append(ms * 1e3)
+    if os.environ.get('DASR_HIP_LIB'):  # instrumented build: phase stamps of one RDB wgrad launch
+        import ctypes
+        import numpy as np
+        grid = wg_rdb[0].i[0] * wg_rdb[0].i[1]
+        buf = torch.zeros(grid * 16 + 64, dtype=torch.int64, device='cuda')
+        L.dasr_debug_set_wtrace.argtypes = [ctypes.c_void_p]
+        L.dasr_debug_set_wtrace(buf.data_ptr())
+        time_ops(wg_rdb[:1], reps=1)
+        L.dasr_debug_set_wtrace(None)
+        t = buf[:grid * 16].view(grid, 16).cpu().numpy().astype(np.float64)
+        t = t[t[:, 0] > 0]
+        wall = (t[:, 14] - t[:, 15]) * 10.0
+        log('wgrad3 trace: %d workgroups (parts %d x splits %d); wall p50 %.0f ns, span %.0f ns, clock %.2f GHz' % (
+            len(t), wg_rdb[0].i[0], wg_rdb[0].i[1], np.percentile(wall, 50), (t[:, 14].max() - t[:, 15].min()) * 10.0, np.median((t[:, 9] - t[:, 0]) / wall)))
+        for i, nm in enumerate(['entry->first prefetch issued', 'first prefetch -> tile 2 top (2 tiles)', 'tile2: barrier 1', 'tile2: commit (ds_write)', 'tile2: barrier 2',
+                                'tile2: prefetch issue', 'tile2: compute 72 MFMA', 'tiles 3.. (rest of loop)', 'result store']):
+            d = t[:, i + 1] - t[:, i]
+            log('  %-40s cycles p10 %8.0f p50 %8.0f p90 %8.0f' % (nm, np.percentile(d, 10), np.percentile(d, 50), np.percentile(d, 90)))
     for k, v in res.items():
         log('sweep %-16s variant %d : %s (TFLOP/s algorithmic; stream = 1/3 of MFMA rate)' % (k[0], k[1], ' '.join('%.0f' % x for x in v)))
-    for combo in ((0, 0, 0, 1), (8, 8, 0, 1), (9, 9, 0, 1), (0, 0, 0, 1), (8, 8, 0, 1), (9, 9, 0, 1)):
+    for combo in ((0, 0, 0, 1), (12, 12, 0, 1), (12, 0, 0, 1), (0, 0, 0, 1), (12, 12, 0, 1), (12, 0, 0, 1)):
         for k, v in zip((1, 2, 3, 4), combo):
             L.dasr_set_tuning(k, v)
         run_steps(1)

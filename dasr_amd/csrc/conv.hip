@@ -116,7 +116,7 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
             c = nn & 15;
         }
         const int oy = oy0 + r, ox = ox0 + c;
-        const bool pv = oy < p.Hout && ox < p.Wout;
+        const bool pv = (oy < p.Hout) & (ox < p.Wout);
         const unsigned pixel = (unsigned)((oy * ostr + p.out_oy) * owid + ox * ostr + p.out_ox) * 16u;
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
@@ -125,7 +125,7 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int oc = (mg * MT + mi) * 32 + 8 * g + 4 * kh2;
-                const bool cv = chan_tail ? (pv && oc < ((p.cout + 15) & ~15)) : pv;
+                const bool cv = chan_tail ? (pv & (oc < ((p.cout + 15) & ~15))) : pv;
                 cbv[g] = (unsigned)(oc >> 4);
                 eo[g] = cv ? pixel + (unsigned)(oc & 15) : OOB;
             }
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
     float bias_reg = 0.f;
     {
         const int oc = mg * MT * 32 + tid;
-        const unsigned bo = (p.bias && tid < 32 * MT && oc < p.cout) ? (unsigned)oc * 4u : OOB;
+        const unsigned bo = ((p.bias != nullptr) & (tid < 32 * MT) & (oc < p.cout)) ? (unsigned)oc * 4u : OOB;
         bias_reg = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(p.bias), bo, 0, 0));
     }
 
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
         const int pix = q / C::PPP, piece = q - pix * C::PPP;
         const int iy = pix / C::IW, ix = pix - iy * C::IW;
         const int gy = iy0 + iy, gx = ix0 + ix;
-        const bool ok = q < C::NPIECE && gy >= 0 && gy < HL && gx >= 0 && gx < WL;
+        const bool ok = (q < C::NPIECE) & (gy >= 0) & (gy < HL) & (gx >= 0) & (gx < WL);  // bitwise: keeps the prologue one basic block
         const int sy = p.ups ? (gy >> 1) : gy, sx = p.ups ? (gx >> 1) : gx;
         const int pl = piece / C::PPP16, pp = piece - pl * C::PPP16;
         goff[r] = ok ? (unsigned)((pl * (int)p.in.cb_stride + (sy * p.Win + sx) * 16 + pp * (IN_F32 ? 4 : 8)) * ESZ) : OOB;
@@ -577,6 +577,192 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Dense-block convolution, second generation ("glds"): 3x3 / stride 1 / pad 1, bf16 activations and weights, Cout tiles of 32*MT.
+// Differences from conv_kernel:
+//  * global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`): no staging registers, no ds_write, no VGPR round trip; the chunk
+//    k+1 lands in the other LDS buffer while chunk k is multiplied; one barrier per chunk.
+//  * DMA writes 64 lanes x 16 B contiguously, so pixels cannot be padded apart; instead the two 16-byte halves (channels 0-7 /
+//    8-15) of pixel p are stored at 16-byte slot 2p + (h ^ bit3(p)): a ds_read_b128 lane group then covers 16 distinct slots of
+//    the 256-byte bank row for any tile offset (pixels p and p+8 / p+24 share bank positions and differ in bit 3).  Each lane
+//    chooses WHICH global 16 bytes it fetches so that the linear DMA placement realises that layout.
+//  * B fragments are reused across the three ky taps (a wave's 4 output rows need 6 input rows per kx): 18 + 9*MT ds_read_b128
+//    per chunk instead of 36 + 9*MT, prefetched one (kx, ky) step ahead of the MFMAs.
+// Tile 16 x 32 output pixels, 4 waves, wave w owns rows 4w..4w+3 (4 n-tiles of 32 pixels) x MT m-tiles.
+// ---------------------------------------------------------------------------------------------------
+template <int MT>
+struct GCfg {
+    static constexpr int NT = 4, TH = 16, TW = 32, IH = 18, IW = 34, NPIX = IH * IW;
+    static constexpr int AR = (NPIX * 2 + 255) / 256;          // activation DMA pieces per thread (16 B each)
+    static constexpr int ACT_BYTES = AR * 256 * 16;            // 20480 >= 612 * 32
+    static constexpr int WPIECE = 9 * MT * 64;                 // 16-byte pieces of a chunk's weights
+    static constexpr int WR = (WPIECE + 255) / 256;
+    static constexpr int W_BYTES = WPIECE * 16;
+    static constexpr int BUF_BYTES = ACT_BYTES + W_BYTES;
+    static constexpr int LDS_BYTES = 2 * BUF_BYTES;
+};
+
+// one 16-byte-per-lane DMA piece of chunk ck: piece i < AR activations, else weights; the LDS base is wave-uniform.
+// (A free function, not a lambda: hipcc drops the host-side kernel handle when this builtin sits in a lambda of a __global__ template.)
+template <int MT>
+__device__ __forceinline__ void glds_dma_piece(int i, int ck, char* buf, __amdgpu_buffer_rsrc_t rin, __amdgpu_buffer_rsrc_t rw, const unsigned* goff,
+                                               unsigned in_chunk_bytes, int wave, int tid) {
+    using C = GCfg<MT>;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    if (i < C::AR) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(buf + (i * 256 + wave * 64) * 16), 16, goff[i], (unsigned)ck * in_chunk_bytes, 0, 0);
+    } else {
+        const int r = i - C::AR;
+        if (r * 256 + wave * 64 < C::WPIECE)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(buf + C::ACT_BYTES + (r * 256 + wave * 64) * 16), 16, (unsigned)(tid + r * 256) * 16u,
+                                                     (unsigned)ck * (9u * MT * 1024u), 0, 0);
+    }
+}
+
+template <int MT, int EPI>
+__global__ __launch_bounds__(256, 2) void conv_glds_kernel(const dasr_conv_params p) {
+    using C = GCfg<MT>;
+    constexpr int NT = C::NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef DASR_TRACE
+    if (g_trace && threadIdx.x == 0) g_trace[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+#endif
+    TRACE_STAMP(0);
+    const int cout_tiles = (p.cout + 31) >> 5;
+    const int MG = (cout_tiles + MT - 1) / MT;
+    const int tiles_x = (p.Wout + C::TW - 1) / C::TW, tiles_y = (p.Hout + C::TH - 1) / C::TH;
+    int bid = blockIdx.x;
+    {
+        const int total = gridDim.x;
+        if (p.xcd_remap && (total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);
+    }
+    const int mg = bid % MG;
+    bid /= MG;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int n = bid / tiles_y;
+    const int oy0 = ty * C::TH, ox0 = tx * C::TW;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int nchunks = p.cin >> 4;
+    float bias_reg = 0.f;
+    {
+        const int oc = mg * MT * 32 + tid;
+        const unsigned bo = ((p.bias != nullptr) & (tid < 32 * MT) & (oc < p.cout)) ? (unsigned)oc * 4u : OOB;
+        bias_reg = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(p.bias), bo, 0, 0));
+    }
+    // ---- DMA source offsets: piece q = tid + 256 r -> LDS slot q -> pixel p = q >> 1, stored half hs = q & 1 holds channel half hs ^ bit3(p)
+    unsigned goff[C::AR];
+#pragma unroll
+    for (int r = 0; r < C::AR; ++r) {
+        const int q = tid + r * 256;
+        const int pp = q >> 1, h = (q & 1) ^ ((pp >> 3) & 1);
+        const int iy = pp / C::IW, ix = pp - iy * C::IW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        const bool ok = (pp < C::NPIX) & (gy >= 0) & (gy < p.Hin) & (gx >= 0) & (gx < p.Win);  // bitwise: keeps the prologue one basic block
+        goff[r] = ok ? (unsigned)(((gy * p.Win + gx) * 16 + 8 * h) * 2) : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc((const bf16_t*)p.in.p + (size_t)n * p.in.n_stride);
+    const unsigned in_chunk_bytes = (unsigned)(p.in.cb_stride * 2);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const bf16_t*)p.w + (size_t)mg * nchunks * 9 * MT * 512);
+    constexpr int NP = C::AR + C::WR;
+    // ---- fragment read addresses: row rr (0..5) of this wave's 6 input rows, column shift kx; lane (nn, kh2)
+    const int nn = lane & 31, kh2 = lane >> 5;
+    int baddr[6][3];
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int pp = (wave * NT + rr) * C::IW + nn + kx;
+            baddr[rr][kx] = ((pp << 1) + (kh2 ^ ((pp >> 3) & 1))) << 4;
+        }
+    const int aoff = C::ACT_BYTES + lane * 16;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[mi][nt][j] = 0.f;
+
+    // chunk 0
+#pragma unroll
+    for (int i = 0; i < NP; ++i) glds_dma_piece<MT>(i, 0, smem, rin, rw, goff, in_chunk_bytes, wave, tid);
+    TRACE_STAMP(1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's DMA pieces have landed
+    __syncthreads();
+    TRACE_STAMP(2);
+
+    for (int ck = 0; ck < nchunks; ++ck) {
+        const char* buf = smem + (ck & 1) * C::BUF_BYTES;
+        char* nbuf = smem + ((ck + 1) & 1) * C::BUF_BYTES;
+        const bool more = ck + 1 < nchunks;
+        bf16x8 fb[2][6], fa[2][MT];
+        // step s = kx * 3 + ky; B rows of phase kx live in fb[kx & 1], A of step s in fa[s & 1]
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) fb[0][rr] = *(const bf16x8*)(buf + baddr[rr][0]);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) fa[0][mi] = *(const bf16x8*)(buf + aoff + (0 * MT + mi) * 1024);
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            const int kx = s / 3, ky = s - kx * 3;
+            if (s + 1 < 9) {
+                const int kx1 = (s + 1) / 3, ky1 = (s + 1) - kx1 * 3;
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) fa[(s + 1) & 1][mi] = *(const bf16x8*)(buf + aoff + ((ky1 * 3 + kx1) * MT + mi) * 1024);
+                if (ky == 1 && kx < 2) {  // rows of the next phase, requested one step before they are needed
+#pragma unroll
+                    for (int rr = 0; rr < 6; ++rr) fb[(kx + 1) & 1][rr] = *(const bf16x8*)(buf + baddr[rr][kx + 1]);
+                }
+            }
+            if (more && s < 4) {  // all pieces of the next chunk are requested in the first steps: they have the rest of the chunk to land
+#pragma unroll
+                for (int i = s * NP / 4; i < (s + 1) * NP / 4; ++i) glds_dma_piece<MT>(i, ck + 1, nbuf, rin, rw, goff, in_chunk_bytes, wave, tid);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][mi], fb[kx & 1][nt + ky], acc[mi][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+    }
+    TRACE_STAMP(4);
+    conv_epilogue<false, MT, NT, 1, EPI>(p, acc, smem, bias_reg, tid, mg, n, oy0, ox0);
+    TRACE_STAMP(6);
+#ifdef DASR_TRACE
+    __builtin_amdgcn_s_waitcnt(0);
+#endif
+    TRACE_STAMP(7);
+#ifdef DASR_TRACE
+    if (g_trace && threadIdx.x == 0) g_trace[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+template <int MT, int EPI = 0>
+int launch_glds(const dasr_conv_params& p, hipStream_t s) {
+    using C = GCfg<MT>;
+    static bool attr_set = false;
+    auto kfn = conv_glds_kernel<MT, EPI>;
+    if ((p.cin & 15) || p.kh != 3 || p.stride != 1 || p.pad != 1 || p.ups || p.in_f32 || p.prec != 1 || (p.pad_x >= 0 && p.pad_x != 1)) return DASR_EINVAL;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        attr_set = true;
+    }
+    const int cout_tiles = (p.cout + 31) >> 5;
+    const int MG = (cout_tiles + MT - 1) / MT;
+    const int tiles_x = (p.Wout + C::TW - 1) / C::TW, tiles_y = (p.Hout + C::TH - 1) / C::TH;
+    const long long grid = (long long)MG * tiles_x * tiles_y * p.N;
+    if (grid <= 0 || grid > 0x7fffffffLL) return DASR_EINVAL;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(256), C::LDS_BYTES, s, p);
+    return (int)hipGetLastError();
+}
+
 template <int PREC, bool IN_F32, int MT, int KH, int STRIDE, int NT, int KS = 1, bool DBUF = false, int MODE = 0, int EPI = 0>
 int launch(const dasr_conv_params& p, hipStream_t s) {
     using C = Cfg<PREC, IN_F32, MT, KH, STRIDE, NT, KS, DBUF>;
@@ -647,7 +833,7 @@ int classify_epi(const dasr_conv_params& p) {
 }
 
 // kernel-variant selection (A/B-able from the host: dasr_set_tuning)
-int g_tune_rdb32 = 0, g_tune_rdb64 = 0, g_tune_stream = 0, g_tune_xcd = 1, g_tune_epi = 1;
+int g_tune_rdb32 = 12, g_tune_rdb64 = 12, g_tune_stream = 0, g_tune_xcd = 1, g_tune_epi = 1;
 
 }  // namespace
 
@@ -704,6 +890,12 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                 case 9: return launch<1, false, 1, 3, 1, 4, 1, true, 1>(p, s);
                 case 10: return launch<1, false, 1, 3, 1, 4, 1, true, 2>(p, s);  // pipelined: prefetch distance 2, ds_write inside the MFMA stream
                 case 11: return launch<1, false, 1, 3, 1, 2, 1, true, 2>(p, s);
+                case 12:
+                    switch (g_tune_epi ? classify_epi(p) : 0) {
+                        case 67: return launch_glds<1, 67>(p, s);
+                        case 68: return launch_glds<1, 68>(p, s);
+                        default: return launch_glds<1, 0>(p, s);
+                    }
                 default: break;
             }
             switch (g_tune_epi ? classify_epi(p) : 0) {
@@ -722,6 +914,14 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                 case 9: return launch<1, false, 2, 3, 1, 4, 1, true, 1>(p, s);
                 case 10: return launch<1, false, 2, 3, 1, 4, 1, true, 2>(p, s);
                 case 11: return launch<1, false, 2, 3, 1, 2, 1, true, 2>(p, s);
+                case 12:
+                    switch (g_tune_epi ? classify_epi(p) : 0) {
+                        case 233: return launch_glds<2, 233>(p, s);
+                        case 249: return launch_glds<2, 249>(p, s);
+                        case 232: return launch_glds<2, 232>(p, s);
+                        case 248: return launch_glds<2, 248>(p, s);
+                        default: return launch_glds<2, 0>(p, s);
+                    }
                 default: break;
             }
             switch (g_tune_epi ? classify_epi(p) : 0) {

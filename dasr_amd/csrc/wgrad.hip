@@ -8,6 +8,7 @@
 // wave w: cin tile = w & 1, tap group = w >> 1.  Partial sums -> workspace; wgrad_reduce sums the splits
 // in a fixed order (deterministic) and scatters into the reference layout [cout][cin][kh][kw].
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -26,6 +27,16 @@ struct WCfg {
     static constexpr int I_BYTES = 4 * IPLANE;
     static constexpr int LDS_BYTES = G_BYTES + I_BYTES;
 };
+
+#ifdef DASR_TRACE
+__device__ unsigned long long* g_wtrace = nullptr;  // [grid][16] s_memtime stamps of wave 0 (slot 15/14: s_memrealtime entry/exit)
+#define WTRACE(k)                                                                                        \
+    do {                                                                                                 \
+        if (g_wtrace && threadIdx.x == 0) g_wtrace[(size_t)blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define WTRACE(k) do {} while (0)
+#endif
 
 __device__ __forceinline__ bf16x8 frag_tr(const char* base, int off0, int off1) {
     const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((DASR_LDS bf16x4*)(base + off0));
@@ -273,13 +284,18 @@ struct W3 {
     static constexpr int IPLANE = IPIX * 32;  // 5760 = 128 (mod 256)
     static constexpr int G_BYTES = 6 * GPLANE, I_BYTES = 4 * IPLANE;
     static constexpr int LDS_BYTES = G_BYTES + I_BYTES;
-    static constexpr int NT = 384;
+    static constexpr int NT = 768;  // 12 waves: (oc tile, cin tile) pair = wave % 6, tap half = wave / 6 -> 3 waves per SIMD
     static constexpr int GPIECES = 6 * GPIX * 2, IPIECES = 4 * IPIX * 2;
     static constexpr int GR = (GPIECES + NT - 1) / NT, IR = (IPIECES + NT - 1) / NT;
 };
 
+// One workgroup = one part (64 input channels x up to three 32-oc tiles of one gradient tensor) x one pixel split.
+// Wave w: pair = w % 6 -> (oc tile ot = pair / 2, cin tile ct = pair % 2); taps 0..4 (w < 6) or 5..8 (w >= 6) of that pair's
+// 3x3 weight gradient, one 32x32 accumulator per tap.  Per 8x16-pixel tile: G and the X halo tile are staged into LDS by all
+// 768 threads (register prefetch one tile ahead; per-thread piece geometry is computed once), then per pixel row r and tap:
+// A = G^T fragment [oc][16 pixels], B = X fragment [16 pixels shifted by the tap][cin], both gathered with ds_read_b64_tr_b16.
 template <bool USE_TR, bool F32>
-__global__ __launch_bounds__(384, 2) void wgrad3_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit,
+__global__ __launch_bounds__(768, 1) void wgrad3_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit,
                                                         float* __restrict__ ws) {
     using C = W3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -288,7 +304,8 @@ __global__ __launch_bounds__(384, 2) void wgrad3_kernel(const dasr_wgrad_part* _
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int part_id = blockIdx.x / nsplit, split = blockIdx.x - part_id * nsplit;
     const dasr_wgrad_part P = parts[part_id];
-    const int ot = wave >> 1, ct = wave & 1;
+    const int pair = wave % 6, th = wave / 6;
+    const int ot = pair >> 1, ct = pair & 1;
     const int n_ot = (P.g_planes + 1) >> 1;  // oc tiles present in this part (planes are 16 channels)
     const bool active = ct < P.n_ctiles && ot < n_ot;
     const int tiles_x = (P.Wout + C::PW - 1) / C::PW, tiles_y = (P.Hout + C::PH - 1) / C::PH;
@@ -296,10 +313,14 @@ __global__ __launch_bounds__(384, 2) void wgrad3_kernel(const dasr_wgrad_part* _
     const int HL = P.ups ? 2 * P.Hin : P.Hin, WL = P.ups ? 2 * P.Win : P.Win;
     constexpr int ESZ = F32 ? 4 : 2;
     const int gpieces = P.g_planes * C::GPIX * 2, ipieces = 2 * P.n_ctiles * C::IPIX * 2;
+#ifdef DASR_TRACE
+    if (g_wtrace && threadIdx.x == 0) g_wtrace[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+#endif
+    WTRACE(0);
 
-    f32x16 acc[9];
+    f32x16 acc[5];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 5; ++t)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
     float bsum = 0.f;
@@ -315,6 +336,32 @@ __global__ __launch_bounds__(384, 2) void wgrad3_kernel(const dasr_wgrad_part* _
     }
     char* const dummy = smem + C::LDS_BYTES;
 
+    // per-thread piece geometry (tile independent): pixel coordinates inside the tile, element offset relative to the tile origin,
+    // LDS destination
+    int gpy[C::GR], gpx[C::GR], geo[C::GR], ipy[C::IR], ipx[C::IR], ipl[C::IR], ihalf[C::IR];
+    char* gdst[C::GR];
+    char* idst[C::IR];
+#pragma unroll
+    for (int r = 0; r < C::GR; ++r) {
+        const int q = tid + r * C::NT;
+        const int half = q & 1, pix = (q >> 1) % C::GPIX, pl = (q >> 1) / C::GPIX;
+        gpy[r] = q < gpieces ? pix / C::PW : 0x40000000;  // out-of-range piece: never valid
+        gpx[r] = pix % C::PW;
+        geo[r] = pl * (int)P.g.cb_stride + (gpy[r] * P.Wout + gpx[r]) * 16 + half * 8;
+        gdst[r] = q < gpieces ? gl + pl * C::GPLANE + pix * 32 + half * 16 : dummy;
+    }
+#pragma unroll
+    for (int r = 0; r < C::IR; ++r) {
+        const int q = tid + r * C::NT;
+        const int pix = (q >> 1) % C::IPIX, pl = (q >> 1) / C::IPIX;
+        ihalf[r] = q & 1;
+        ipl[r] = pl;
+        const bool ok = (q < ipieces) & (pl < P.in_planes);
+        ipy[r] = ok ? pix / C::IW : 0x40000000;
+        ipx[r] = pix % C::IW;
+        idst[r] = q < ipieces ? il + pl * C::IPLANE + pix * 32 + (q & 1) * 16 : dummy;
+    }
+
     auto prefetch = [&](int tile) {
         int t2 = tile;
         const int tx = t2 % tiles_x;
@@ -325,32 +372,24 @@ __global__ __launch_bounds__(384, 2) void wgrad3_kernel(const dasr_wgrad_part* _
         const int iy0 = oy0 - P.pad, ix0 = ox0 - P.pad;
         const __amdgpu_buffer_rsrc_t gb = make_rsrc((const char*)P.g.p + (size_t)n * P.g.n_stride * ESZ);
         const __amdgpu_buffer_rsrc_t ib = make_rsrc((const char*)P.in.p + (size_t)n * P.in.n_stride * ESZ);
+        const int gorg = (oy0 * P.Wout + ox0) * 16;
 #pragma unroll
         for (int r = 0; r < C::GR; ++r) {
-            const int q = tid + r * C::NT;
-            const int half = q & 1, pix = (q >> 1) % C::GPIX, pl = (q >> 1) / C::GPIX;
-            const int py = pix / C::PW, px = pix - py * C::PW;
-            const int oy = oy0 + py, ox = ox0 + px;
-            const bool ok = q < gpieces && oy < P.Hout && ox < P.Wout;
-            stage_load<F32>(greg[r], gb, (unsigned)(pl * (int)P.g.cb_stride + (oy * P.Wout + ox) * 16 + half * 8), ok);
+            const bool ok = (oy0 + gpy[r] < P.Hout) & (ox0 + gpx[r] < P.Wout);
+            stage_load<F32>(greg[r], gb, (unsigned)(gorg + geo[r]), ok);
         }
 #pragma unroll
         for (int r = 0; r < C::IR; ++r) {
-            const int q = tid + r * C::NT;
-            const int half = q & 1, pix = (q >> 1) % C::IPIX, pl = (q >> 1) / C::IPIX;
-            const int iy = pix / C::IW, ix = pix - iy * C::IW;
-            const int gy = iy0 + iy, gx = ix0 + ix;
-            const bool ok = q < ipieces && gy >= 0 && gy < HL && gx >= 0 && gx < WL && pl < P.in_planes;
+            const int gy = iy0 + ipy[r], gx = ix0 + ipx[r];
+            const bool ok = (gy >= 0) & (gy < HL) & (gx >= 0) & (gx < WL);
             const int sy = P.ups ? gy >> 1 : gy, sx = P.ups ? gx >> 1 : gx;
-            stage_load<F32>(ireg[r], ib, (unsigned)(pl * (int)P.in.cb_stride + (sy * P.Win + sx) * 16 + half * 8), ok);
+            stage_load<F32>(ireg[r], ib, (unsigned)(ipl[r] * (int)P.in.cb_stride + (sy * P.Win + sx) * 16 + ihalf[r] * 8), ok);
         }
     };
     auto commit = [&]() {
 #pragma unroll
         for (int r = 0; r < C::GR; ++r) {
-            const int q = tid + r * C::NT;
-            const int half = q & 1, pix = (q >> 1) % C::GPIX, pl = (q >> 1) / C::GPIX;
-            stage_store<F32>(greg[r], q < gpieces ? gl + pl * C::GPLANE + pix * 32 + half * 16 : dummy);
+            stage_store<F32>(greg[r], gdst[r]);
             if constexpr (F32) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -360,68 +399,108 @@ __global__ __launch_bounds__(384, 2) void wgrad3_kernel(const dasr_wgrad_part* _
             }
         }
 #pragma unroll
-        for (int r = 0; r < C::IR; ++r) {
-            const int q = tid + r * C::NT;
-            const int half = q & 1, pix = (q >> 1) % C::IPIX, pl = (q >> 1) / C::IPIX;
-            stage_store<F32>(ireg[r], q < ipieces ? il + pl * C::IPLANE + pix * 32 + half * 16 : dummy);
+        for (int r = 0; r < C::IR; ++r) stage_store<F32>(ireg[r], idst[r]);
+    };
+
+    const int gbase = (ot * 2 + fplane) * C::GPLANE + (8 * khalf + (li >> 2)) * 32 + (li & 3) * 8;
+    const int ibase = (ct * 2 + fplane) * C::IPLANE + (8 * khalf + (li >> 2)) * 32 + (li & 3) * 8;
+    // one tile of MFMAs for the tap range [T0, T0 + NA): flat software pipeline, fragments of step i+1 requested before MFMA i
+    auto compute = [&](auto t0c, auto nac) {
+        constexpr int T0 = decltype(t0c)::value, NA = decltype(nac)::value;
+        if constexpr (USE_TR) {
+            bf16x8 a[2], b[2];
+            a[0] = frag_tr(gl, gbase, gbase + 4 * 32);
+            {
+                constexpr int ky = T0 / 3, kx = T0 - ky * 3;
+                const int o = ibase + (ky * C::IW + kx) * 32;
+                b[0] = frag_tr(il, o, o + 4 * 32);
+            }
+#pragma unroll
+            for (int i = 0; i < C::PH * NA; ++i) {
+                const int r = i / NA, t = T0 + (i - r * NA);
+                if (i + 1 < C::PH * NA) {
+                    const int r1 = (i + 1) / NA, t1 = T0 + ((i + 1) - r1 * NA);
+                    const int ky1 = t1 / 3, kx1 = t1 - ky1 * 3;
+                    const int o1 = ibase + ((r1 + ky1) * C::IW + kx1) * 32;
+                    b[(i + 1) & 1] = frag_tr(il, o1, o1 + 4 * 32);
+                    if (t1 == T0) {
+                        const int g1 = gbase + r1 * C::PW * 32;
+                        a[r1 & 1] = frag_tr(gl, g1, g1 + 4 * 32);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[t - T0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r & 1], b[i & 1], acc[t - T0], 0, 0, 0);
+                if constexpr (!F32 && T0 == 0) {
+                    if (t == 2 && P.want_bias && ct == 0) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) bsum += (float)a[r & 1][j];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll 2
+            for (int r = 0; r < C::PH; ++r) {
+                bf16x8 a;
+                const char* b0 = gl + (ot * 2 + fplane) * C::GPLANE + (r * C::PW + 8 * khalf) * 32 + li * 2;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = *(const bf16_t*)(b0 + j * 32);
+                if constexpr (!F32 && T0 == 0) {
+                    if (P.want_bias && ct == 0) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) bsum += (float)a[j];
+                    }
+                }
+#pragma unroll
+                for (int t = T0; t < T0 + NA; ++t) {
+                    const int ky = t / 3, kx = t - ky * 3;
+                    bf16x8 b;
+                    const int prow = (r + ky) * C::IW + kx;
+                    const char* b1 = il + (ct * 2 + fplane) * C::IPLANE + (prow + 8 * khalf) * 32 + li * 2;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) b[j] = *(const bf16_t*)(b1 + j * 32);
+                    acc[t - T0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t - T0], 0, 0, 0);
+                }
+            }
         }
     };
 
     if (split < ntiles) prefetch(split);
-    for (int tile = split; tile < ntiles; tile += nsplit) {
+    WTRACE(1);
+    int it = 0;
+    for (int tile = split; tile < ntiles; tile += nsplit, ++it) {
+        if (it == 2) WTRACE(2);
         __syncthreads();
+        if (it == 2) WTRACE(3);
         commit();
+        if (it == 2) WTRACE(4);
         __syncthreads();
+        if (it == 2) WTRACE(5);
         if (tile + nsplit < ntiles) prefetch(tile + nsplit);
+        if (it == 2) WTRACE(6);
         if (!active) continue;
-#pragma unroll 2
-        for (int r = 0; r < C::PH; ++r) {
-            bf16x8 a;
-            const int gplane = ot * 2 + fplane;
-            if constexpr (USE_TR) {
-                const int o0 = gplane * C::GPLANE + (r * C::PW + 8 * khalf + (li >> 2)) * 32 + (li & 3) * 8;
-                a = frag_tr(gl, o0, o0 + 4 * 32);
-            } else {
-                const char* b0 = gl + gplane * C::GPLANE + (r * C::PW + 8 * khalf) * 32 + li * 2;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) a[j] = *(const bf16_t*)(b0 + j * 32);
-            }
-            if constexpr (!F32) {
-                if (P.want_bias && ct == 0) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) bsum += (float)a[j];
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int ky = t / 3, kx = t - ky * 3;
-                bf16x8 b;
-                const int prow = (r + ky) * C::IW + kx;
-                if constexpr (USE_TR) {
-                    const int o0 = (ct * 2 + fplane) * C::IPLANE + (prow + 8 * khalf + (li >> 2)) * 32 + (li & 3) * 8;
-                    b = frag_tr(il, o0, o0 + 4 * 32);
-                } else {
-                    const char* b0 = il + (ct * 2 + fplane) * C::IPLANE + (prow + 8 * khalf) * 32 + li * 2;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) b[j] = *(const bf16_t*)(b0 + j * 32);
-                }
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
-            }
-        }
+        if (th == 0) compute(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+        else compute(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
+        if (it == 2) WTRACE(7);
     }
 
+    WTRACE(8);
     if (active) {
         float* w = ws + P.ws_off + (size_t)split * 9 * 3 * 2048 + (size_t)ot * 2048;
         const int cin = ct * 32 + (lane & 31), h = lane >> 5;
+        const int t0 = th * 5, na = th ? 4 : 5;
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < 5; ++t) {
+            if (t < na) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int oc = (j & 3) + 8 * (j >> 2) + 4 * h;
-                w[(size_t)t * 3 * 2048 + oc * 64 + cin] = acc[t][j];
+                for (int j = 0; j < 16; ++j) {
+                    const int oc = (j & 3) + 8 * (j >> 2) + 4 * h;
+                    w[(size_t)(t0 + t) * 3 * 2048 + oc * 64 + cin] = acc[t][j];
+                }
             }
+        }
         if constexpr (!F32) {
-            if (P.want_bias && ct == 0) {
+            if (P.want_bias && ct == 0 && th == 0) {
                 const float tot = bsum + __shfl_xor(bsum, 32, 64);
                 if (lane < 32) ws[P.ws_bias_off + (size_t)split * 96 + ot * 32 + lane] = tot;
             }
@@ -430,7 +509,7 @@ __global__ __launch_bounds__(384, 2) void wgrad3_kernel(const dasr_wgrad_part* _
     if constexpr (F32) {
         if (P.want_bias) {
             __syncthreads();
-            float* red = (float*)smem;  // [384][GR*8] floats = 49 KB <= LDS_BYTES
+            float* red = (float*)smem;  // [768][GR*8] floats = 49 KB <= LDS_BYTES
 #pragma unroll
             for (int r = 0; r < C::GR; ++r)
 #pragma unroll
@@ -450,6 +529,10 @@ __global__ __launch_bounds__(384, 2) void wgrad3_kernel(const dasr_wgrad_part* _
             }
         }
     }
+    WTRACE(9);
+#ifdef DASR_TRACE
+    if (g_wtrace && threadIdx.x == 0) g_wtrace[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // deterministic split reduction: block = 64 consecutive elements x 4 split lanes (fixed summation tree)
@@ -554,6 +637,10 @@ extern "C" int dasr_probe_tr16(void* stream) {
     g_use_tr = h;
     return h;
 }
+
+#ifdef DASR_TRACE
+extern "C" int dasr_debug_set_wtrace(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_wtrace), &buf, sizeof(buf)); }
+#endif
 
 extern "C" int dasr_wgrad_set_mode(int use_tr) {
     g_use_tr = use_tr;

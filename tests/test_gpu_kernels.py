@@ -115,10 +115,11 @@ def test_conv_forward_matches_torch(case):
         assert float(pad_part.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('variant', [1, 4, 5, 8, 9, 10, 11])
+@pytest.mark.parametrize('variant', [0, 1, 4, 5, 8, 9, 10, 11])
 @pytest.mark.parametrize('case', CONV_CASES[:3], ids=[c[0] for c in CONV_CASES[:3]])
 def test_conv_tuning_variants_match_torch(case, variant):
-    """the A/B-able variants of the dense-block conv (dasr_set_tuning keys 1, 2: double buffering, tile heights, row reuse)"""
+    """the A/B-able variants of the dense-block conv (dasr_set_tuning keys 1, 2; default 12 = LDS-DMA kernel, 0 = first-generation
+    kernel, others: double buffering, tile heights, row reuse, register-staged pipeline)"""
     _gpu()
     from dasr_amd import _lib
     L = _lib.lib()
@@ -127,7 +128,7 @@ def test_conv_tuning_variants_match_torch(case, variant):
     try:
         test_conv_forward_matches_torch(case)
     finally:
-        _lib.check(L.dasr_set_tuning(key, 0))
+        _lib.check(L.dasr_set_tuning(key, 12))
 
 
 def test_conv_prec3_is_fp32_grade():
