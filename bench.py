@@ -101,7 +101,7 @@ def roofline_dominant_kernel(model, plans, reps=25):
         pass
     return {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
-            'kernel': 'conv_kernel<1,false,1,3,1,4,1,false> (dense-block conv1-4, Cout=32, bf16 MFMA)',
+            'kernel': 'conv_glds_kernel<1,67> (dense-block conv1-4 forward, Cout=32, bf16 MFMA, LDS-DMA staging; <1,68> is its data-gradient twin)',
             'launches_concurrent': k, 'avg_launch_us': round(ms * 1e3 / 4, 1), 'flops_per_launch': flops / (4 * k),
             'note': 'achieved = launches_concurrent * flops_per_launch / avg_launch_us (sub-batch streams overlap launches)'}
 
@@ -233,7 +233,14 @@ def sweep(model, data, a):
             log('  %-40s cycles p10 %8.0f p50 %8.0f p90 %8.0f' % (nm, np.percentile(d, 10), np.percentile(d, 50), np.percentile(d, 90)))
     for k, v in res.items():
         log('sweep %-16s variant %d : %s (TFLOP/s algorithmic; stream = 1/3 of MFMA rate)' % (k[0], k[1], ' '.join('%.0f' % x for x in v)))
-    for combo in ((0, 0, 0, 1), (12, 12, 0, 1), (12, 0, 0, 1), (0, 0, 0, 1), (12, 12, 0, 1), (12, 0, 0, 1)):
+    for wm in (1, 3, 1, 3):  # wgrad3: register-staged kernel (1) vs LDS-DMA kernel (3 = bit 1 set)
+        L.dasr_wgrad_set_mode(wm)
+        run_steps(1)
+        t0 = time.perf_counter()
+        run_steps(3)
+        log('sweep step time, wgrad mode %d: %.2f ms/step' % (wm, (time.perf_counter() - t0) / 3 * 1e3))
+    L.dasr_wgrad_set_mode(1)
+    for combo in ((0, 0, 0, 1), (12, 12, 0, 1), (0, 0, 0, 1), (12, 12, 0, 1)):
         for k, v in zip((1, 2, 3, 4), combo):
             L.dasr_set_tuning(k, v)
         run_steps(1)

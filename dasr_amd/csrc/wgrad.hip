@@ -535,6 +535,206 @@ __global__ __launch_bounds__(768, 1) void wgrad3_kernel(const dasr_wgrad_part* _
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------
+// wgrad3 with LDS-DMA staging (bf16 tensors, transpose reads): same decomposition as wgrad3_kernel, but the G tile and the X
+// halo tile of the NEXT pixel tile are written straight into the other LDS buffer by `buffer_load_dwordx4 ... lds` while the
+// current tile is multiplied: no staging registers, no ds_write, one barrier per tile.  48 one-KiB DMA instructions per tile
+// (6 G planes x 4, 4 X planes x 6), four per wave; each lane's source address is tile origin + a per-lane constant.
+// ---------------------------------------------------------------------------------------------------
+struct W3G {
+    static constexpr int PH = 8, PW = 16, IH = 10, IW = 18, GPIX = PH * PW, IPIX = IH * IW;
+    static constexpr int GPLANE = GPIX * 32 + 128;           // 4 DMA instructions per plane
+    static constexpr int IPLANE = 6 * 1024 + 128;            // 6 DMA instructions per plane (180 pixels = 5.6 KiB), = 128 (mod 256)
+    static constexpr int G_BYTES = 6 * GPLANE, I_BYTES = 4 * IPLANE;
+    static constexpr int BUF_BYTES = G_BYTES + I_BYTES;
+    static constexpr int LDS_BYTES = 2 * BUF_BYTES;
+    static constexpr int NT = 768;
+};
+
+// per-lane geometry of one of the wave's four DMA instructions (j = wave + 12 k), tile independent
+struct W3GPiece {
+    int dy, dx;   // pixel position inside the tile (G) / halo tile (X); dy huge = never valid
+    int rel;      // element offset of the lane's 8 channels relative to the tile origin pixel
+    int lds;      // LDS byte offset of the instruction inside a buffer (wave uniform)
+};
+
+__device__ __forceinline__ W3GPiece w3g_piece(const dasr_wgrad_part& P, int j, int lane) {
+    using C = W3G;
+    W3GPiece g;
+    if (j < 24) {
+        const int pl = j >> 2, sub = j & 3;
+        const int q = sub * 64 + lane, pix = q >> 1, half = q & 1;
+        g.dy = pl < P.g_planes ? (pix >> 4) : 0x40000000;
+        g.dx = pix & 15;
+        g.rel = pl * (int)P.g.cb_stride + half * 8;
+        g.lds = pl * C::GPLANE + sub * 1024;
+    } else {
+        const int jj = j - 24, pl = jj / 6, sub = jj - pl * 6;
+        const int q = sub * 64 + lane, pix = q >> 1, half = q & 1;
+        const int iy = pix / C::IW;
+        g.dy = ((pix < C::IPIX) & (pl < P.in_planes) & (pl < 2 * P.n_ctiles)) ? iy : 0x40000000;
+        g.dx = pix - iy * C::IW;
+        g.rel = pl * (int)P.in.cb_stride + half * 8;
+        g.lds = C::G_BYTES + pl * C::IPLANE + sub * 1024;
+    }
+    return g;
+}
+
+struct W3GTile {
+    __amdgpu_buffer_rsrc_t gb, ib;
+    int oy0, ox0;
+};
+
+__device__ __forceinline__ W3GTile w3g_tile(const dasr_wgrad_part& P, int tile, int tiles_x, int tiles_y) {
+    W3GTile T;
+    int t2 = tile;
+    const int tx = t2 % tiles_x;
+    t2 /= tiles_x;
+    const int ty = t2 % tiles_y;
+    const int n = t2 / tiles_y;
+    T.oy0 = ty * W3G::PH;
+    T.ox0 = tx * W3G::PW;
+    T.gb = make_rsrc((const bf16_t*)P.g.p + (size_t)n * P.g.n_stride);
+    T.ib = make_rsrc((const bf16_t*)P.in.p + (size_t)n * P.in.n_stride);
+    return T;
+}
+
+// the wave's k-th 1-KiB DMA instruction (j = wave + 12 k) of pixel tile T into `buf`
+__device__ __forceinline__ void w3g_dma(const dasr_wgrad_part& P, const W3GTile& T, const W3GPiece& pc, int j, char* buf, int HL, int WL) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    if (j < 24) {
+        const int oy = T.oy0 + pc.dy, ox = T.ox0 + pc.dx;
+        const bool ok = (oy < P.Hout) & (ox < P.Wout);
+        const unsigned off = ok ? (unsigned)((pc.rel + (oy * P.Wout + ox) * 16) * 2) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(T.gb, (lds_ptr)(buf + pc.lds), 16, off, 0, 0, 0);
+    } else {
+        const int gy = T.oy0 - P.pad + pc.dy, gx = T.ox0 - P.pad + pc.dx;
+        const bool ok = (gy >= 0) & (gy < HL) & (gx >= 0) & (gx < WL);
+        const int sy = P.ups ? gy >> 1 : gy, sx = P.ups ? gx >> 1 : gx;
+        const unsigned off = ok ? (unsigned)((pc.rel + (sy * P.Win + sx) * 16) * 2) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(T.ib, (lds_ptr)(buf + pc.lds), 16, off, 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(768, 1) void wgrad3_glds_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit, float* __restrict__ ws) {
+    using C = W3G;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int part_id = blockIdx.x / nsplit, split = blockIdx.x - part_id * nsplit;
+    const dasr_wgrad_part P = parts[part_id];
+    const int pair = wave % 6, th = wave / 6;
+    const int ot = pair >> 1, ct = pair & 1;
+    const int n_ot = (P.g_planes + 1) >> 1;
+    const bool active = ct < P.n_ctiles && ot < n_ot;
+    const int tiles_x = (P.Wout + C::PW - 1) / C::PW, tiles_y = (P.Hout + C::PH - 1) / C::PH;
+    const int ntiles = tiles_x * tiles_y * P.N;
+    const int HL = P.ups ? 2 * P.Hin : P.Hin, WL = P.ups ? 2 * P.Win : P.Win;
+#ifdef DASR_TRACE
+    if (g_wtrace && threadIdx.x == 0) g_wtrace[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+#endif
+    WTRACE(0);
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+    float bsum = 0.f;
+    const int gg = lane >> 4, li = lane & 15;
+    const int fplane = gg & 1, khalf = gg >> 1;
+    const int gbase = (ot * 2 + fplane) * C::GPLANE + (8 * khalf + (li >> 2)) * 32 + (li & 3) * 8;
+    const int ibase = C::G_BYTES + (ct * 2 + fplane) * C::IPLANE + (8 * khalf + (li >> 2)) * 32 + (li & 3) * 8;
+
+    W3GPiece pc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        pc[k] = w3g_piece(P, wave + 12 * k, lane);
+        pc[k].lds = __builtin_amdgcn_readfirstlane(pc[k].lds);
+    }
+    // taps of this wave: th = 0 -> 0..4, th = 1 -> 5..8 (the fifth slot repeats tap 8's address and its MFMA is skipped): one code
+    // path for both halves (two specialised copies cost 60 VGPRs and spilled)
+    int tb[5];
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+        const int t = th ? (a < 4 ? 5 + a : 8) : a;
+        tb[a] = ibase + ((t / 3) * C::IW + (t % 3)) * 32;
+    }
+    auto compute = [&](const char* buf, char* nbuf, const W3GTile& T, bool more) {
+        bf16x8 a[2], b[2];
+        a[0] = frag_tr(buf, gbase, gbase + 4 * 32);
+        b[0] = frag_tr(buf, tb[0], tb[0] + 4 * 32);
+#pragma unroll
+        for (int i = 0; i < C::PH * 5; ++i) {
+            const int r = i / 5, t = i - r * 5;
+            if (i + 1 < C::PH * 5) {
+                const int r1 = (i + 1) / 5, t1 = (i + 1) - r1 * 5;
+                const int o1 = tb[t1] + r1 * C::IW * 32;
+                b[(i + 1) & 1] = frag_tr(buf, o1, o1 + 4 * 32);
+                if (t1 == 0) {
+                    const int g1 = gbase + r1 * C::PW * 32;
+                    a[r1 & 1] = frag_tr(buf, g1, g1 + 4 * 32);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t < 4 || th == 0) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r & 1], b[i & 1], acc[t], 0, 0, 0);
+            if (t == 2 && P.want_bias && ct == 0 && th == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum += (float)a[r & 1][j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if (split < ntiles) {
+        const W3GTile T0 = w3g_tile(P, split, tiles_x, tiles_y);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w3g_dma(P, T0, pc[k], wave + 12 * k, smem, HL, WL);
+    }
+    WTRACE(1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    int it = 0;
+    for (int tile = split; tile < ntiles; tile += nsplit, ++it) {
+        char* buf = smem + (it & 1) * C::BUF_BYTES;
+        char* nbuf = smem + ((it + 1) & 1) * C::BUF_BYTES;
+        if (it == 2) WTRACE(2);
+        const bool more = tile + nsplit < ntiles;
+        const W3GTile T = w3g_tile(P, more ? tile + nsplit : tile, tiles_x, tiles_y);
+        if (it == 2) WTRACE(6);
+        if (more) {  // the next tile's pieces are requested up front (issuing them between the MFMAs stalled the stream: measured slower)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w3g_dma(P, T, pc[k], wave + 12 * k, nbuf, HL, WL);
+        }
+        if (active) compute(buf, nbuf, T, more);
+        if (it == 2) WTRACE(7);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+    }
+    WTRACE(8);
+    if (active) {
+        float* w = ws + P.ws_off + (size_t)split * 9 * 3 * 2048 + (size_t)ot * 2048;
+        const int cin = ct * 32 + (lane & 31), h = lane >> 5;
+        const int t0 = th * 5, na = th ? 4 : 5;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            if (t < na) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int oc = (j & 3) + 8 * (j >> 2) + 4 * h;
+                    w[(size_t)(t0 + t) * 3 * 2048 + oc * 64 + cin] = acc[t][j];
+                }
+            }
+        }
+        if (P.want_bias && ct == 0 && th == 0) {
+            const float tot = bsum + __shfl_xor(bsum, 32, 64);
+            if (lane < 32) ws[P.ws_bias_off + (size_t)split * 96 + ot * 32 + lane] = tot;
+        }
+    }
+    WTRACE(9);
+#ifdef DASR_TRACE
+    if (g_wtrace && threadIdx.x == 0) g_wtrace[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
 // deterministic split reduction: block = 64 consecutive elements x 4 split lanes (fixed summation tree)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const dasr_wgrad_reduce_part* __restrict__ parts, int nparts,
                                                            const float* __restrict__ ws, float* __restrict__ grad, float scale) {
@@ -621,7 +821,18 @@ int launch_wgrad3(const dasr_wgrad_part* parts, int nparts, int nsplit, float* w
     return (int)hipGetLastError();
 }
 
+int launch_wgrad3_glds(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)wgrad3_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W3G::LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad3_glds_kernel, dim3(nparts * nsplit), dim3(W3G::NT), W3G::LDS_BYTES, s, parts, nparts, nsplit, ws);
+    return (int)hipGetLastError();
+}
+
 int g_use_tr = -1;  // -1 unknown, 0 gather fallback, 1 transpose reads
+int g_wgrad3_glds = 0;  // LDS-DMA wgrad3: faster alone (490 vs 470 TFLOP/s) but its 101 KB of LDS keeps the other sub-batch stream off the CU: -2.5 % on the step
 
 }  // namespace
 
@@ -643,6 +854,8 @@ extern "C" int dasr_debug_set_wtrace(void* buf) { return (int)hipMemcpyToSymbol(
 #endif
 
 extern "C" int dasr_wgrad_set_mode(int use_tr) {
+    g_wgrad3_glds = (use_tr & 2) ? 1 : 0;  // bit 1: LDS-DMA wgrad3 instead of the register-staged one (A/B)
+    use_tr &= 1;
     g_use_tr = use_tr;
     return 0;
 }
@@ -662,6 +875,7 @@ extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int3
     if (g_use_tr < 0) return DASR_EINVAL;  // dasr_probe_tr16 must run once per process (outside graph capture)
     const bool tr = g_use_tr == 1;
     if (kh == 33) {  // v3 layout: 6-wave workgroups, 3 oc tiles x 64 cin per part (3x3 stride 1 only)
+        if (tr && !f32 && g_wgrad3_glds) return launch_wgrad3_glds(parts_dev, nparts, nsplit, ws, s);
         if (tr) return f32 ? launch_wgrad3<true, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3<true, false>(parts_dev, nparts, nsplit, ws, s);
         return f32 ? launch_wgrad3<false, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3<false, false>(parts_dev, nparts, nsplit, ws, s);
     }
