@@ -105,8 +105,14 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
             for (int g = 0; g < 4; ++g) bia[mi][g] = *(const f32x4*)(bl + mi * 32 + 8 * g + 4 * kh2);
     }
     TRACE_STAMP(5);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+    // groups (nt, mi) of 32 pixels x 32 channels.  With a compile-time term set the optional-tensor loads of group g+1 are issued
+    // before the arithmetic and stores of group g (two register sets), so only the first group's load latency is exposed;
+    // the 64-channel kernel with two residuals has no registers left for that and loads just in time.
+    constexpr int NG = NT * MT;
+    constexpr bool PIPE_EPI = !G && !(MT == 2 && (EPI & 16)) && (EPI & (4 | 8 | 16));
+    u32x4 mk[2][4], r1v[2][4], r2v[2][4];
+    auto group_addr = [&](int gi, unsigned (&eo)[4], unsigned (&cbv)[4]) {
+        const int nt = gi / MT, mi = gi - nt * MT;
         int r, c;
         if constexpr (STRIDE == 1) {
             r = wave * NT + nt;
@@ -119,36 +125,50 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
         const bool pv = (oy < p.Hout) & (ox < p.Wout);
         const unsigned pixel = (unsigned)((oy * ostr + p.out_oy) * owid + ox * ostr + p.out_ox) * 16u;
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            u32x4 mk[4], r1v[4], r2v[4];
-            unsigned eo[4], cbv[4];
+        for (int g = 0; g < 4; ++g) {
+            const int oc = (mg * MT + mi) * 32 + 8 * g + 4 * kh2;
+            const bool cv = chan_tail ? (pv & (oc < ((p.cout + 15) & ~15))) : pv;
+            cbv[g] = (unsigned)(oc >> 4);
+            eo[g] = cv ? pixel + (unsigned)(oc & 15) : OOB;
+        }
+    };
+    auto issue_loads = [&](int gi, int slot) {
+        unsigned eo[4], cbv[4];
+        group_addr(gi, eo, cbv);
+        if (has_mask) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int oc = (mg * MT + mi) * 32 + 8 * g + 4 * kh2;
-                const bool cv = chan_tail ? (pv & (oc < ((p.cout + 15) & ~15))) : pv;
-                cbv[g] = (unsigned)(oc >> 4);
-                eo[g] = cv ? pixel + (unsigned)(oc & 15) : OOB;
-            }
-            if (has_mask) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const unsigned mo = eo[g] != OOB ? (cbv[g] * mask_cb + eo[g]) * MSZ : OOB;
-                    if constexpr (IN_F32) {
-                        mk[g] = __builtin_amdgcn_raw_buffer_load_b128(rmask, mo, 0, 0);
-                    } else {
-                        const u32x2 t2 = __builtin_amdgcn_raw_buffer_load_b64(rmask, mo, 0, 0);
-                        mk[g] = u32x4{t2[0] << 16, t2[0] & 0xffff0000u, t2[1] << 16, t2[1] & 0xffff0000u};
-                    }
+                const unsigned mo = eo[g] != OOB ? (cbv[g] * mask_cb + eo[g]) * MSZ : OOB;
+                if constexpr (IN_F32) {
+                    mk[slot][g] = __builtin_amdgcn_raw_buffer_load_b128(rmask, mo, 0, 0);
+                } else {
+                    const u32x2 t2 = __builtin_amdgcn_raw_buffer_load_b64(rmask, mo, 0, 0);
+                    mk[slot][g] = u32x4{t2[0], t2[1], 0u, 0u};  // unpacked after the wait
                 }
             }
-            if (has_r1) {
+        }
+        if (has_r1) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) r1v[g] = __builtin_amdgcn_raw_buffer_load_b128(rr1, eo[g] != OOB ? (cbv[g] * r1_cb + eo[g]) * 4u : OOB, 0, 0);
-            }
-            if (has_r2) {
+            for (int g = 0; g < 4; ++g) r1v[slot][g] = __builtin_amdgcn_raw_buffer_load_b128(rr1, eo[g] != OOB ? (cbv[g] * r1_cb + eo[g]) * 4u : OOB, 0, 0);
+        }
+        if (has_r2) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) r2v[g] = __builtin_amdgcn_raw_buffer_load_b128(rr2, eo[g] != OOB ? (cbv[g] * r2_cb + eo[g]) * 4u : OOB, 0, 0);
-            }
+            for (int g = 0; g < 4; ++g) r2v[slot][g] = __builtin_amdgcn_raw_buffer_load_b128(rr2, eo[g] != OOB ? (cbv[g] * r2_cb + eo[g]) * 4u : OOB, 0, 0);
+        }
+    };
+    if constexpr (PIPE_EPI) issue_loads(0, 0);
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+        const int nt = gi / MT, mi = gi - nt * MT;
+        const int slot = PIPE_EPI ? (gi & 1) : 0;
+        if constexpr (PIPE_EPI) {
+            if (gi + 1 < NG) issue_loads(gi + 1, (gi + 1) & 1);
+        } else {
+            issue_loads(gi, 0);
+        }
+        {
+            unsigned eo[4], cbv[4];
+            group_addr(gi, eo, cbv);
             // arithmetic in passes: the VALU work of an absent term is skipped, not multiplied by a neutral coefficient
             // (64 outputs per lane: every op per element is 64 VALU instructions per wave; exp/rcp are quarter rate)
             float v[4][4];
@@ -177,7 +197,12 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[g][j] *= __uint_as_float(mk[g][j]) > 0.f ? 1.f : slope;
+                    for (int j = 0; j < 4; ++j) {
+                        unsigned mbits;
+                        if constexpr (IN_F32) mbits = mk[slot][g][j];
+                        else mbits = (j & 1) ? (mk[slot][g][j >> 1] & 0xffff0000u) : (mk[slot][g][j >> 1] << 16);
+                        v[g][j] *= __uint_as_float(mbits) > 0.f ? 1.f : slope;
+                    }
             }
             if (scaled && p.alpha != 1.f) {
 #pragma unroll
@@ -189,13 +214,13 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[g][j] += p.beta1 * __uint_as_float(r1v[g][j]);
+                    for (int j = 0; j < 4; ++j) v[g][j] += p.beta1 * __uint_as_float(r1v[slot][g][j]);
             }
             if (has_r2) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[g][j] += p.beta2 * __uint_as_float(r2v[g][j]);
+                    for (int j = 0; j < 4; ++j) v[g][j] += p.beta2 * __uint_as_float(r2v[slot][g][j]);
             }
             if (chan_tail && (mg * MT + mi) * 32 + 32 > p.cout) {  // last, partial m-tile: padded channels of the last plane stay zero
 #pragma unroll

@@ -11,6 +11,7 @@ ap.add_argument('--n', type=int, default=16); ap.add_argument('--hw', type=int, 
 ap.add_argument('--reps', type=int, default=40); ap.add_argument('--tune', type=str, default='')
 ap.add_argument('--streams', type=int, default=1)
 ap.add_argument('--noout', type=int, default=0)
+ap.add_argument('--mode', type=str, default='fwd', help='fwd: bias+lrelu->bf16 | dgrad: mask->bf16 | conv5: bias, alpha, res1 -> f32+bf16')
 ap.add_argument('--alias', type=int, default=0, help='1: all images alias image 0 on the input, 2: also on the output (cache-resident working set)')
 a = ap.parse_args()
 engine.ensure_runtime_ready()
@@ -29,7 +30,9 @@ lists = []
 for s in range(a.streams):
     n = a.n // a.streams
     x = BTensor(n, a.cin, a.hw, a.hw, False, dev); x.t.normal_()
-    y = BTensor(n, a.cout, a.hw, a.hw, False, dev)
+    y = BTensor(n, a.cout, a.hw, a.hw, False, dev); y.t.normal_()
+    ym = BTensor(n, a.cout, a.hw, a.hw, False, dev)
+    rf = BTensor(n, a.cout, a.hw, a.hw, True, dev); of = BTensor(n, a.cout, a.hw, a.hw, True, dev)
     ol = OpList()
     for _ in range(a.reps):
         xv, yv = x.view(), y.view()
@@ -37,8 +40,13 @@ for s in range(a.streams):
             xv.n_stride = 0
         if a.alias >= 2:
             yv.n_stride = 0
-        ol.add(conv_op(pack, ref, xv, False, a.cin, a.hw, a.hw, a.hw, a.hw, n, bias=P.ptr('b'), act=1, out_bf16=None if a.noout else yv, out_f32=None))
-    ol.keep += [x, y]
+        if a.mode == 'dgrad':
+            ol.add(conv_op(pack, ref, xv, False, a.cin, a.hw, a.hw, a.hw, a.hw, n, mask=yv, mask_f32=0, out_bf16=ym.view()))
+        elif a.mode == 'conv5':
+            ol.add(conv_op(pack, ref, xv, False, a.cin, a.hw, a.hw, a.hw, a.hw, n, bias=P.ptr('b'), alpha=0.2, res1=rf.view(), beta1=1.0, out_f32=of.view(), out_bf16=yv))
+        else:
+            ol.add(conv_op(pack, ref, xv, False, a.cin, a.hw, a.hw, a.hw, a.hw, n, bias=P.ptr('b'), act=1, out_bf16=None if a.noout else yv, out_f32=None))
+    ol.keep += [x, y, ym, rf, of]
     lists.append(ol)
 streams = [torch.cuda.Stream() for _ in lists]
 def run():
@@ -51,7 +59,7 @@ t0 = time.perf_counter()
 run(); torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 fl = 2.0 * a.n * a.hw * a.hw * 9 * a.cin * a.cout * a.reps
-print('alias %d ' % a.alias + 'cin %d cout %d N %d streams %d tune [%s]: %.1f us/launch-set, %.0f TFLOP/s' % (a.cin, a.cout, a.n, a.streams, a.tune, dt / a.reps * 1e6, fl / dt / 1e12))
+print('%s alias %d ' % (a.mode, a.alias) + 'cin %d cout %d N %d streams %d tune [%s]: %.1f us/launch-set, %.0f TFLOP/s' % (a.cin, a.cout, a.n, a.streams, a.tune, dt / a.reps * 1e6, fl / dt / 1e12))
 
 if os.environ.get('DASR_HIP_LIB'):
     import ctypes, numpy as np
