@@ -870,8 +870,9 @@ extern "C" int dasr_debug_set_trace(void* buf) {
 
 extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
     switch (key) {
-        case 1: g_tune_rdb32 = value; return 0;   // Cout=32 dense conv: 0 single-buffer CK16, 1 double-buffer CK16, 2 single CK32, 3 double CK32
-        case 2: g_tune_rdb64 = value; return 0;   // Cout=64 dense conv: 0 single CK16, 1 double CK16, 2 single CK32
+        case 1: g_tune_rdb32 = value; return 0;   // Cout=32 dense conv: 12 LDS-DMA kernel (default); first-generation kernel: 0 single LDS buffer, 1 double,
+                                                   // 4/5 8x32 tiles, 6 4x32 tiles, 8/9 row reuse, 10/11 register-staged pipeline
+        case 2: g_tune_rdb64 = value; return 0;   // Cout=64 dense conv: same codes as key 1
         case 3: g_tune_stream = value; return 0;  // split-bf16 stream conv: 0 single, 1 double
         case 4: g_tune_xcd = value; return 0;     // XCD-aware tile order on/off
         case 5: g_tune_epi = value; return 0;     // compile-time specialised epilogues on/off
@@ -905,12 +906,9 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
         case 10:
             switch (g_tune_rdb32) {
                 case 1: return launch<1, false, 1, 3, 1, 4, 1, true>(p, s);
-                case 2: if (p.cin % 32 == 0) return launch<1, false, 1, 3, 1, 4, 2, false>(p, s); break;
-                case 3: if (p.cin % 32 == 0) return launch<1, false, 1, 3, 1, 4, 2, true>(p, s); break;
                 case 4: return launch<1, false, 1, 3, 1, 2>(p, s);          // 8x32 tiles: 2x the workgroups
                 case 5: return launch<1, false, 1, 3, 1, 2, 1, true>(p, s);
                 case 6: return launch<1, false, 1, 3, 1, 1>(p, s);          // 4x32 tiles
-                case 7: return launch<1, false, 1, 3, 1, 8>(p, s);          // 32x32 tiles: -20 % bytes per pixel, half the workgroups
                 case 8: return launch<1, false, 1, 3, 1, 4, 1, false, 1>(p, s);  // row reuse of B fragments across ky
                 case 9: return launch<1, false, 1, 3, 1, 4, 1, true, 1>(p, s);
                 case 10: return launch<1, false, 1, 3, 1, 4, 1, true, 2>(p, s);  // pipelined: prefetch distance 2, ds_write inside the MFMA stream
@@ -932,7 +930,6 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
         case 20:
             switch (g_tune_rdb64) {
                 case 1: return launch<1, false, 2, 3, 1, 4, 1, true>(p, s);
-                case 2: if (p.cin % 32 == 0) return launch<1, false, 2, 3, 1, 4, 2, false>(p, s); break;
                 case 4: return launch<1, false, 2, 3, 1, 2>(p, s);
                 case 5: return launch<1, false, 2, 3, 1, 2, 1, true>(p, s);
                 case 8: return launch<1, false, 2, 3, 1, 4, 1, false, 1>(p, s);

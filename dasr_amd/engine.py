@@ -395,6 +395,9 @@ def ensure_runtime_ready():
         _PROBED = True
         global TR16_OK
         TR16_OK = rc
+        import os
+        if rc == 1 and os.environ.get('DASR_WGRAD_GLDS', '') in ('0', '1'):  # A/B: LDS-DMA (1) vs register-staged (0) dense-block wgrad
+            L.dasr_wgrad_set_mode(1 | (2 if os.environ['DASR_WGRAD_GLDS'] == '1' else 0))
     return TR16_OK
 
 

@@ -251,8 +251,12 @@ def vgg19_spec(feature_layer=34, cfg=None):
 class VGGFeatureHIP:
     """Frozen feature extractor: forward on N images, data-gradient w.r.t. the first n_g inputs."""
 
-    def __init__(self, feature_layer=34, device='cuda', cfg=None):
+    def __init__(self, feature_layer=34, device='cuda', cfg=None, prec=None):
+        """prec 3: split-bf16 operands (~fp32); prec 1: plain bf16 operands, fp32 accumulation (3x fewer MFMAs).  Default from
+        DASR_VGG_PREC, else 3."""
+        import os
         self.device = torch.device(device)
+        self.prec = int(prec if prec is not None else os.environ.get('DASR_VGG_PREC', '3'))
         self.spec, self.layers = vgg19_spec(feature_layer, cfg)
         self.params = ParamStore(self.spec, self.device)
         self.pack = PackRegistry(self.params)
@@ -263,8 +267,10 @@ class VGGFeatureHIP:
                 continue
             w = P.off('features.%d.weight' % idx)
             cin_pad = ceil_div(cin, 16) * 16
-            self.pk[idx] = self.pack.add(cout, cin_pad, 9, 1, 3, [(w, cout, cin, 0, cin, 0, 0)])
-            self.pk[(idx, 'b')] = self.pack.add(cin, cout, 9, 1, 3, [(w, cout, cin, 0, cout, 0, 1)])
+            mt_f = 2 if (self.prec == 1 and cout % 64 == 0) else 1
+            mt_b = 2 if (self.prec == 1 and cin % 64 == 0) else 1
+            self.pk[idx] = self.pack.add(cout, cin_pad, 9, mt_f, self.prec, [(w, cout, cin, 0, cin, 0, 0)])
+            self.pk[(idx, 'b')] = self.pack.add(cin, cout, 9, mt_b, self.prec, [(w, cout, cin, 0, cout, 0, 1)])
         self.pack.finalize()
         self.plans = {}
 

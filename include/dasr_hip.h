@@ -64,7 +64,11 @@ typedef struct {
 } dasr_conv_params;
 
 int dasr_conv(const dasr_conv_params* p, void* stream);
-/* kernel-variant knobs (LDS double buffering / 32-channel chunks); see conv.hip.  Defaults are the tuned choice. */
+/* kernel-variant knobs for A/B runs (bench.py --sweep / --tune); defaults are the tuned choice.
+ * key 1 / 2: dense-block conv with Cout = 32 / 64: 12 = LDS-DMA kernel (default), 0 = first-generation register-staged kernel,
+ *            1 double-buffered LDS, 4/5 8x32 tiles, 6 4x32 tiles, 8/9 row reuse, 10/11 register-staged pipeline;
+ * key 3: split-bf16 stream conv (0 single / 1 double LDS buffer, 4 8x32 tiles); key 4: XCD-aware tile order on/off;
+ * key 5: compile-time specialised epilogues on/off. */
 int dasr_set_tuning(int32_t key, int32_t value);
 
 /* ---- weight gradient ---------------------------------------------------------------------------
@@ -92,7 +96,8 @@ typedef struct {
  * (g_planes = 2/4/6), workspace [split][tap][3][32][64], bias [split][96]. */
 int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int32_t nsplit, int32_t kh, int32_t stride, int32_t f32,
                float* ws, void* stream);
-/* 1: use ds_read_b64_tr_b16 gathers, 0: scalar LDS gathers.  dasr_probe_tr16 sets it from the device. */
+/* bit 0: 1 = ds_read_b64_tr_b16 gathers, 0 = scalar LDS gathers (dasr_probe_tr16 sets it from the device);
+ * bit 1: dense-block wgrad staged by LDS-DMA instead of registers (A/B; default off). */
 int dasr_wgrad_set_mode(int32_t use_tr);
 
 typedef struct {
