@@ -214,7 +214,14 @@ class DASR_Model(BaseModel):
         return self.log_dict
 
     def test(self, tsamples=False):
-        self.fake_H = self.netG.forward(self.var_L).clone()
+        """inference on var_L (DASR_model.py:333-345; `chop`: quadrant inference, utils/util.py:87-147)"""
+        if not tsamples and self.opt['val_lpips']:
+            raise NotImplementedError('val_lpips needs the pretrained LPIPS package (offline)')
+        if self.opt['chop']:
+            from .util import forward_chop
+            self.fake_H = forward_chop(self.var_L, self.opt['scale'], lambda x: self.netG.forward(x).clone(), min_size=320000)
+        else:
+            self.fake_H = self.netG.forward(self.var_L).clone()
 
     def get_current_visuals(self, need_HR=True, tsamples=False):
         out = OrderedDict()

@@ -296,7 +296,14 @@ class SRModel(BaseModel):
         return self.log_dict
 
     def test(self):
-        self.fake_H = self.netG.forward(self.var_L).clone()
+        """inference on var_L (SR_model.py:87-93; `chop`: quadrant inference of DASR_model.py:333-339 / util.py:87-147)"""
+        if self.opt['val_lpips']:
+            raise NotImplementedError('val_lpips needs the pretrained LPIPS package (offline)')
+        if self.opt['chop']:
+            from .util import forward_chop
+            self.fake_H = forward_chop(self.var_L, self.opt['scale'], lambda x: self.netG.forward(x).clone(), min_size=320000)
+        else:
+            self.fake_H = self.netG.forward(self.var_L).clone()
 
     def get_current_visuals(self, need_HR=True):
         out = OrderedDict()

@@ -22,6 +22,29 @@ from .dist import DataParallelGroup, shard_minibatch
 from .models import create_model
 
 
+class SyntheticValDataset:
+    """LR/HR validation pairs (batch 1, reference keys incl. the *_path strings): HR = smooth random image, LR = 4x4 box average"""
+
+    def __init__(self, ds_opt, scale):
+        self.n = int(ds_opt.get('n_images') or 4)
+        self.h = int(ds_opt.get('LR_size') or 32)
+        self.scale = scale
+        self.seed = int(ds_opt.get('seed') or 4321)
+        self.opt = ds_opt
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed)
+        s, h = self.scale, self.h
+        for i in range(self.n):
+            base = torch.rand(1, 3, h // 4 + 2, h // 4 + 2, generator=g)
+            hr = torch.nn.functional.interpolate(base, size=(h * s, h * s), mode='bilinear', align_corners=False).clamp(0, 1)
+            lr = torch.nn.functional.avg_pool2d(hr, s)
+            yield {'LR': lr, 'HR': hr, 'LR_path': ['synthetic/val_%03d.png' % i], 'HR_path': ['synthetic/val_%03d.png' % i]}
+
+
 class SyntheticDataset:
     """Fixed-seed random crops with the reference batch-dict keys."""
 
@@ -52,9 +75,35 @@ class SyntheticDataset:
 def create_dataset(ds_opt, opt):
     mode = ds_opt['mode']
     if mode == 'synthetic':
+        if ds_opt.get('phase') in ('val', 'test'):
+            return SyntheticValDataset(ds_opt, opt['scale'])
         return SyntheticDataset(ds_opt, opt['scale'], opt['model'])
     raise NotImplementedError('Dataset [{:s}] is not recognized (the cv2/lmdb loaders of the reference stay on its side of '
                               'the boundary; feed their batch dicts to the trainer object).'.format(str(mode)))
+
+
+def validate(model, val_set, opt, current_step, logger):
+    """validation pass of codes/SRN/train.py:174-235: test() per image, SR image saved, PSNR on the `scale`-pixel-cropped uint8 images"""
+    from . import util
+    avg_psnr, idx = 0.0, 0
+    for val_data in val_set:
+        idx += 1
+        img_name = os.path.splitext(os.path.basename(val_data['LR_path'][0]))[0]
+        img_dir = os.path.join(opt['path']['val_images'], img_name)
+        util.mkdir(img_dir)
+        model.feed_data(val_data, False)
+        model.test()
+        visuals = model.get_current_visuals()
+        sr_img = util.tensor2img(visuals['SR'])
+        logger.info('{}'.format(val_data['HR_path'][0].split('/')[-1]))
+        util.save_img(sr_img, os.path.join(img_dir, '{:s}_{:d}.png'.format(img_name, current_step)))
+        if 'HR' in visuals:
+            gt_img = util.tensor2img(visuals['HR'])
+            c = opt['scale']
+            avg_psnr += util.calculate_psnr((sr_img / 255.)[c:-c, c:-c, :] * 255, (gt_img / 255.)[c:-c, c:-c, :] * 255)
+    avg_psnr = avg_psnr / max(idx, 1)
+    logger.info('# Validation # PSNR: {:.4e}'.format(avg_psnr))
+    return avg_psnr
 
 
 def setup_logger(name, root, phase, level=logging.INFO, screen=False):
@@ -106,6 +155,9 @@ def main(argv=None):
     torch.manual_seed(seed)
 
     train_set = create_dataset(opt['datasets']['train'], opt)
+    val_set = create_dataset(opt['datasets']['val'], opt) if opt['datasets'].get('val') else None
+    if rank == 0:
+        setup_logger('val', opt['path']['log'], 'val')
     total_iters = int(opt['train']['niter'])
     total_epochs = int(math.ceil(total_iters / max(1, len(train_set))))
     model = create_model(opt)
@@ -134,6 +186,9 @@ def main(argv=None):
                 for k, v in model.get_current_log().items():
                     msg += '{:s}: {:.4e} '.format(k, v)
                 logger.info(msg)
+            if val_set is not None and opt['train']['val_freq'] and current_step % opt['train']['val_freq'] == 0 and rank == 0:
+                avg_psnr = validate(model, val_set, opt, current_step, logger)
+                logging.getLogger('val').info('<epoch:{:3d}, iter:{:8,d}> psnr: {:.4e}'.format(epoch, current_step, avg_psnr))
             if current_step % opt['logger']['save_checkpoint_freq'] == 0 and rank == 0:
                 logger.info('Saving models and training states.')
                 model.save(current_step)

@@ -1,0 +1,91 @@
+"""GPU: validation / inference path: test() with and without quadrant inference against the oracle net, the
+validation pass of the training driver and the evaluation CLI on synthetic LR/HR pairs."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from dasr_amd import engine
+    engine.ensure_runtime_ready()
+    return torch.device('cuda')
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def _json_opt(tmp_path, name, is_train, extra=None):
+    opt = {
+        'name': name, 'use_tb_logger': False, 'model': 'sr', 'scale': 4, 'gpu_ids': [0], 'chop': False, 'val_lpips': False,
+        'datasets': {},
+        'path': {'root': str(tmp_path), 'pretrain_model_G': None},
+        'network_G': {'which_model_G': 'RRDB_net', 'norm_type': None, 'mode': 'CNA', 'nf': 32, 'nb': 1, 'in_nc': 3, 'out_nc': 3, 'gc': 32},
+    }
+    if is_train:
+        opt['datasets'] = {'train': {'name': 'syn', 'mode': 'synthetic', 'batch_size': 4, 'HR_size': 64, 'n_batches': 8},
+                           'val': {'name': 'synval', 'mode': 'synthetic', 'n_images': 2, 'LR_size': 24}}
+        opt['train'] = {'lr_G': 2e-4, 'weight_decay_G': 0, 'beta1_G': 0.9, 'lr_scheme': 'MultiStepLR', 'lr_steps': [100], 'lr_gamma': 0.5,
+                        'pixel_criterion': 'l1', 'pixel_weight': 1.0, 'manual_seed': 0, 'niter': 4, 'val_freq': 2}
+        opt['logger'] = {'print_freq': 2, 'save_checkpoint_freq': 4}
+    else:
+        opt['datasets'] = {'test_1': {'name': 'synset', 'mode': 'synthetic', 'n_images': 3, 'LR_size': 64}}  # > 2 * shave (20) for the chop run
+    opt.update(extra or {})
+    p = tmp_path / (name + '.json')
+    p.write_text(json.dumps(opt))
+    return str(p)
+
+
+@pytest.mark.parametrize('chop', [False, True])
+def test_inference_matches_oracle(chop):
+    dev = _gpu()
+    from oracle import fixtures, nets, util_ref
+    from dasr_amd import options
+    from dasr_amd.models import create_model
+    opt = fixtures.make_opt('sr_nf64_nb1_b1_24x40')
+    opt['gpu_ids'] = [0]
+    opt['chop'] = chop
+    m = create_model(options.dict_to_nonedict(opt))
+    net = nets.RRDBNet(3, 3, 64, 1, 4)
+    sd = fixtures.seeded_state_dict(net.state_dict(), 3, 0.1)
+    net.load_state_dict(sd)
+    m.netG.load_state_dict(sd)
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(1, 3, 52, 44, generator=g)
+    m.feed_data({'LR': x, 'HR': torch.rand(1, 3, 208, 176, generator=g)}, False)
+    m.test()
+    with torch.no_grad():
+        want = util_ref.forward_chop(x, 4, net, shave=20, min_size=320000) if chop else net(x)
+    got = m.fake_H.cpu()
+    assert tuple(got.shape) == tuple(want.shape)
+    assert rel(got, want) < 1e-3, rel(got, want)
+    vis = m.get_current_visuals()
+    assert set(vis) >= {'LR', 'SR', 'HR'} and tuple(vis['SR'].shape) == (3, 208, 176)
+
+
+def test_training_driver_validates_and_eval_cli_reports_metrics(tmp_path):
+    _gpu()
+    from dasr_amd import train, test as dtest
+    train.main(['-opt', _json_opt(tmp_path, 'f1_train', True)])
+    root = tmp_path / 'experiments' / 'f1_train'
+    logs = [f for f in os.listdir(root) if f.startswith('val_')]
+    assert logs and 'psnr:' in (root / logs[0]).read_text()
+    imgs = list((root / 'val_images').rglob('*.png'))
+    assert len(imgs) == 4  # 2 images x 2 validation passes
+    g_path = root / 'models' / 'latest_G.pth'
+    assert g_path.exists()
+    summary = dtest.main(['-opt', _json_opt(tmp_path, 'f1_test', False, {'path': {'root': str(tmp_path), 'pretrain_model_G': str(g_path)}})])
+    s = summary['synset']
+    assert all(np.isfinite(s[k]) for k in ('psnr', 'ssim', 'psnr_y', 'ssim_y')) and 5 < s['psnr'] < 60 and 0 < s['ssim'] <= 1
+    out = list((tmp_path / 'results' / 'f1_test' / 'synset' / 'imgs').glob('*.png'))
+    assert len(out) == 3
+    # same images through the quadrant path: PSNR within a small margin of the plain forward
+    s2 = dtest.main(['-opt', _json_opt(tmp_path, 'f1_test_chop', False, {'chop': True, 'path': {'root': str(tmp_path), 'pretrain_model_G': str(g_path)}})])
+    assert abs(s2['synset']['psnr'] - s['psnr']) < 1.0
