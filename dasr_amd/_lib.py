@@ -57,7 +57,7 @@ class Op(C.Structure):
 
 OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_DOWNSUM, OP_AXPBY, OP_FILL, OP_L1LOSS, OP_NCHW2B, OP_B2NCHW = range(1, 11)
 (OP_INORM_FWD, OP_INORM_BWD, OP_BCE, OP_DWT_FWD, OP_DWT_BWD, OP_LOWPASS, OP_MAXPOOL, OP_MAXPOOL_BWD, OP_L1DIFF, OP_AFFINE4,
- OP_BILINEAR, OP_LOGLOSS, OP_SIGMOID_BWD, OP_PRELU_GRAD, OP_LOWPASS_VALID, OP_ADD_FLAT) = range(11, 27)
+ OP_BILINEAR, OP_LOGLOSS, OP_SIGMOID_BWD, OP_PRELU_GRAD, OP_LOWPASS_VALID, OP_ADD_FLAT, OP_SIGMOID_FWD) = range(11, 28)
 
 _SIGS = {
     'dasr_conv': [C.POINTER(ConvParams), c_vp],
@@ -88,6 +88,7 @@ _SIGS = {
     'dasr_bilinear_up': [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
     'dasr_logloss': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp, c_f32, Tensor, c_i32, c_vp],
     'dasr_sigmoid_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_vp],
+    'dasr_sigmoid_fwd': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_vp],
     'dasr_prelu_grad': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_vp],
     'dasr_lowpass_valid': [Tensor, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_vp],
     'dasr_run_ops': [c_vp, c_i32, c_vp],

@@ -526,6 +526,21 @@ __global__ void sigmoid_bwd_kernel(dasr_tensor y, dasr_tensor g, int N, int C, i
     ((f32x4*)op)[0] = o; ((f32x4*)op)[1] = z; ((f32x4*)op)[2] = z; ((f32x4*)op)[3] = z;
 }
 
+// y = sigmoid(x) on C (<= 4) channels of plane 0 (the FSD discriminator's output map at inference, codes/DSN/model.py:104-106)
+__global__ void sigmoid_fwd_kernel(dasr_tensor x, int N, int C, int H, int W, dasr_tensor y) {
+    const long long total = (long long)N * H * W;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int n = i / ((long long)H * W);
+    const long long p = i - (long long)n * H * W;
+    const f32x4 v = *(const f32x4*)((const float*)x.p + (size_t)n * x.n_stride + (size_t)p * 16);
+    f32x4 o;
+    for (int j = 0; j < 4; ++j) o[j] = j < C ? 1.f / (1.f + expf(-v[j])) : 0.f;
+    float* op = (float*)y.p + (size_t)n * y.n_stride + (size_t)p * 16;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    ((f32x4*)op)[0] = o; ((f32x4*)op)[1] = z; ((f32x4*)op)[2] = z; ((f32x4*)op)[3] = z;
+}
+
 // nn.PReLU() with one shared slope a: y = x > 0 ? x : a x.  Given y and gx = dL/dx (already masked by PReLU'),
 // dL/da = sum_{y <= 0} (gx / a) * (y / a).  Two deterministic stages: per-block partials, then one block.
 __global__ void prelu_grad_partial_kernel(dasr_tensor y, dasr_tensor gx, int N, int C, int H, int W, float* __restrict__ partial) {
@@ -705,6 +720,13 @@ extern "C" int dasr_sigmoid_bwd(dasr_tensor y, dasr_tensor g, int32_t N, int32_t
     const long long total = (long long)N * H * W;
     if (total <= 0 || C > 4) return DASR_EINVAL;
     hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), y, g, N, C, H, W, gz);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_sigmoid_fwd(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, dasr_tensor y, void* stream) {
+    const long long total = (long long)N * H * W;
+    if (total <= 0 || C > 4) return DASR_EINVAL;
+    hipLaunchKernelGGL(sigmoid_fwd_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, y);
     return (int)hipGetLastError();
 }
 

@@ -373,6 +373,7 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream) {
                 break;
             case DASR_OP_LOWPASS_VALID: rc = dasr_lowpass_valid(o.t[0], (const float*)o.p[0], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], o.i[5], o.t[1], o.i[6], stream); break;
             case DASR_OP_ADD_FLAT: rc = dasr_add_flat((float*)o.p[0], (const float*)o.p[1], o.l[0], stream); break;
+            case DASR_OP_SIGMOID_FWD: rc = dasr_sigmoid_fwd(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1], stream); break;
             default: rc = DASR_EINVAL;
         }
         if (rc != 0) {

@@ -336,6 +336,36 @@ class DSNModel:
         self.fake = P.g.fake_nchw
         self._pending = True
 
+    # ---- inference: fake LR, discriminator map and domain-distance map (codes/DSN/create_dataset_modified.py:14-24,147-164) ----
+    def translate(self, img):
+        """img [n,3,H,W] in [0,1] -> (fake_lr [n,3,H/4,W/4], D_out [n,1,h',w'], ddm [n,1,h',w']).  D_out = sigmoid(D(fake)) with the
+        frequency-separation front end (h' = h/2 for the wavelet filter); ddm = every D_out value spread over its receptive field
+        (four [5,1,2] layers as the reference's table has it: 17x17) and divided by the coverage count = a count-normalised 17x17 box
+        average (receptive_cal.py:34-60)."""
+        n, _, H, W = img.shape
+        k = ('inf', n, H, W)
+        if k not in self._plans:
+            self._plans[k] = _InferPlan(self, n, H, W)
+        P = self._plans[k]
+        P.g.x_nchw.copy_(img)
+        P.ops.run()
+        return P.g.fake_nchw, P.dout.nchw(1), P.ddm.nchw(1)
+
+    def ddm_of(self, lr):
+        """lr [n,3,h,w] in [0,1] (an LR image of either domain) -> (D_out, ddm) as in translate(), without the generator
+        (create_dataset_modified.py:170-176, --including_source_ddm)"""
+        n, _, h, w = lr.shape
+        if self.filter == 'wavelet':
+            h, w = h // 2 * 2, w // 2 * 2
+            lr = lr[..., :h, :w]
+        k = ('ddm', n, h, w)
+        if k not in self._plans:
+            self._plans[k] = _InferPlan(self, n, h, w, with_g=False)
+        P = self._plans[k]
+        P.lr_nchw.copy_(lr)
+        P.ops.run()
+        return P.dout.nchw(1), P.ddm.nchw(1)
+
     def get_current_log(self):
         if getattr(self, '_pending', False):
             a = self.acc.tolist()
@@ -494,3 +524,51 @@ class _DSNPlan:
                 if o.op == _lib.OP_WGRAD_REDUCE:
                     o.f[0] = scale
             ol._arr = None
+
+
+DDM_RF = 17  # receptive field of the reference's conv table [[5,1,2]] * 4 for FSD (create_dataset_modified.py:120-121)
+
+
+class _InferPlan:
+    """with_g: (H, W) is the HR input of the generator and the discriminator sees G's output; else (H, W) is an LR image fed to D"""
+
+    def __init__(self, m, N, H, W, with_g=True):
+        dev = m.device
+        h, w = (H // 4, W // 4) if with_g else (H, W)
+        wav = m.filter == 'wavelet'
+        hd, wd = (h // 2, w // 2) if wav else (h, w)
+        self.d = m.netD.plan(N, hd, wd)
+        d = self.d
+        self.dout, self.ddm = BTensor(N, 16, hd, wd, True, dev), BTensor(N, 16, hd, wd, True, dev)
+        self.box = torch.full((DDM_RF * DDM_RF,), 1.0 / (DDM_RF * DDM_RF), dtype=torch.float32, device=dev)
+        ops = OpList()
+        if with_g:
+            self.g = m.netG.plan(N, H, W)
+            ops.extend(self.g.fwd)
+            src = self.g.fake
+        else:
+            self.lr_nchw = torch.zeros((N, 3, h, w), dtype=torch.float32, device=dev)
+            src = BTensor(N, 16, h, w, True, dev)
+            o = _op(_lib.OP_NCHW2B)
+            o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[0], o.t[1] = self.lr_nchw.data_ptr(), N, 3, h, w, src.view(), NULL_T
+            ops.add(o)
+            self.src = src
+        if wav:
+            o = _op(_lib.OP_DWT_FWD)
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[1], o.t[2] = src.view(), N, 3, hd, wd, 1, NULL_T, d.x.view()
+        else:
+            o = _op(_lib.OP_LOWPASS)
+            o.t[0], o.t[1], o.p[0], o.i[4] = src.view(), NULL_T, m.fw.data_ptr(), m.k
+            o.i[0], o.i[1], o.i[2], o.i[3], o.i[5], o.i[6] = N, 3, h, w, 0 | (2 if m.filter == 'avg_pool' else 0), 0
+            o.f[0], o.f[1], o.t[2], o.t[3] = 0.5, 0.5, NULL_T, d.x.view()
+        ops.add(o)
+        ops.extend(d.fwd)
+        o = _op(_lib.OP_SIGMOID_FWD)
+        o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1] = d.logits.view(), N, 1, hd, wd, self.dout.view()
+        ops.add(o)
+        o = _op(_lib.OP_LOWPASS)   # count-normalised box average = spread over the receptive field / coverage count
+        o.t[0], o.t[1], o.p[0], o.i[4] = self.dout.view(), NULL_T, self.box.data_ptr(), DDM_RF
+        o.i[0], o.i[1], o.i[2], o.i[3], o.i[5], o.i[6] = N, 1, hd, wd, 0 | 2, 0
+        o.f[0], o.f[1], o.t[2], o.t[3] = 0.0, 0.0, self.ddm.view(), NULL_T
+        ops.add(o)
+        self.ops = ops

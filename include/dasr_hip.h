@@ -219,6 +219,9 @@ int dasr_logloss(dasr_tensor x, int32_t N, int32_t H, int32_t W, int32_t mode, f
                  float* score_acc, float score_coef, dasr_tensor grad, int32_t accumulate, void* stream);
 /* backward of the generator's output sigmoid (model.py:55) */
 int dasr_sigmoid_bwd(dasr_tensor y, dasr_tensor g, int32_t N, int32_t C, int32_t H, int32_t W, dasr_tensor gz, void* stream);
+/* y = sigmoid(x) on C (<= 4) channels of plane 0: the discriminator's output map at inference (codes/DSN/model.py:104-106,
+ * consumed by create_dataset_modified.py:14-24) */
+int dasr_sigmoid_fwd(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, dasr_tensor y, void* stream);
 /* gradient of nn.PReLU()'s single slope (model.py:29,215) from the layer output y and dL/dx; deterministic two-stage sum;
  * scratch256: 256 floats */
 int dasr_prelu_grad(dasr_tensor y, dasr_tensor gx, int32_t N, int32_t C, int32_t H, int32_t W, const float* slope, float* scratch256,
@@ -234,7 +237,7 @@ enum { DASR_OP_CONV = 1, DASR_OP_WGRAD = 2, DASR_OP_WGRAD_REDUCE = 3, DASR_OP_PA
        DASR_OP_INORM_FWD = 11, DASR_OP_INORM_BWD = 12, DASR_OP_BCE = 13, DASR_OP_DWT_FWD = 14, DASR_OP_DWT_BWD = 15,
        DASR_OP_LOWPASS = 16, DASR_OP_MAXPOOL = 17, DASR_OP_MAXPOOL_BWD = 18, DASR_OP_L1DIFF = 19, DASR_OP_AFFINE4 = 20,
        DASR_OP_BILINEAR = 21, DASR_OP_LOGLOSS = 22, DASR_OP_SIGMOID_BWD = 23, DASR_OP_PRELU_GRAD = 24, DASR_OP_LOWPASS_VALID = 25,
-       DASR_OP_ADD_FLAT = 26 };
+       DASR_OP_ADD_FLAT = 26, DASR_OP_SIGMOID_FWD = 27 };
 
 typedef struct {
     int32_t op;  int32_t i[8];  float f[4];  int64_t l[4];  void* p[4];  dasr_tensor t[5];

@@ -1,0 +1,33 @@
+"""tests/golden/dsn_ddm.npz from the reference's codes/DSN/receptive_cal.py + the handler of create_dataset_modified.py
+(python -m oracle.gen_golden_dsn_dataset).  TEST INFRASTRUCTURE.  receptive_cal.py is numpy-only and imported as is; the handler is
+the 10-line function at create_dataset_modified.py:14-24, which cannot be imported without running the script, so its two shape
+rules are applied here around the imported getWeights / receptive_cal."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+
+
+def main():
+    sys.path.insert(0, '/root/reference/codes/DSN')
+    import receptive_cal as rc
+    out = {}
+    rs = np.random.RandomState(3)
+    convnet = [[5, 1, 2]] * 4
+    for name, (h, w), fs in (('gau_23x31', (23, 31), 'gau'), ('wav_40x36', (40, 36), 'wavelet'), ('avg_12x9', (12, 9), 'avg_pool')):
+        hh, ww = (h // 2, w // 2) if fs == 'wavelet' else (h, w)
+        d_out = rs.rand(1, 1, hh, ww)  # the reference broadcasts patch[:, :, i, j] against a window: batch 1 only
+        ddm = torch.zeros((1, 1, hh, ww))
+        lh, lw = rc.receptive_cal(ddm.shape[2], convnet), rc.receptive_cal(ddm.shape[3], convnet)
+        out[name + '_dout'] = d_out
+        out[name + '_ddm'] = np.asarray(rc.getWeights(d_out, ddm, lh, lw))
+        out[name + '_layers'] = np.array([lh, lw], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'dsn_ddm.npz'), **out)
+    print({k: v.shape for k, v in out.items()})
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,32 @@
+"""CPU: domain-distance-map restatement (oracle/dsn_dataset.py) against the fixture produced by the reference's receptive_cal.py
+(SURVEY.md 8(f2)), and its closed form used on the GPU (count-normalised 17x17 box average)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+@pytest.mark.parametrize('name,fs,hw', [('gau_23x31', 'gau', (23, 31)), ('wav_40x36', 'wavelet', (40, 36)), ('avg_12x9', 'avg_pool', (12, 9))])
+def test_ddm_matches_reference(name, fs, hw, golden_dir):
+    from oracle import dsn_dataset as dd
+    gold = np.load(os.path.join(golden_dir, 'dsn_ddm.npz'))
+    d_out = gold[name + '_dout']
+    got = dd.domain_distance_map(d_out, (1, 3) + hw, fs)
+    np.testing.assert_allclose(got, gold[name + '_ddm'], rtol=1e-12, atol=0)
+    h, w = d_out.shape[2:]
+    np.testing.assert_allclose(np.array([dd.receptive(h, dd.CONVNETS['FSD']), dd.receptive(w, dd.CONVNETS['FSD'])], dtype=np.float64),
+                               gold[name + '_layers'])
+    # closed form: AvgPool2d(17, 1, 8, count_include_pad=False) of the discriminator map
+    box = F.avg_pool2d(torch.from_numpy(d_out), 17, 1, 8, count_include_pad=False).numpy()
+    np.testing.assert_allclose(box, gold[name + '_ddm'], rtol=1e-10, atol=1e-12)
+
+
+def test_cli_flags_and_unsupported_choices():
+    from dasr_amd import dsn_create_dataset as cd
+    o = cd.build_parser().parse_args([])
+    assert (o.generator, o.discriminator, o.kernel_size, o.filter, o.name, o.upscale_factor) == ('DeResnet', 'FSD', 5, 'gau', '0603_DSN_LRs', 4)
+    for bad in (['--generator', 'DSGAN', '--checkpoint', 'x'], ['--discriminator', 'nld_s2', '--checkpoint', 'x'], ['--wgan', '--checkpoint', 'x']):
+        with pytest.raises(NotImplementedError):
+            cd.main(bad)

@@ -275,3 +275,57 @@ def test_dsn_checkpoint_roundtrip(tmp_path):
         assert torch.equal(v, m2.netG.state_dict()[k]), k
     for k, v in m.netD.state_dict().items():
         assert torch.equal(v, m2.netD.state_dict()[k]), k
+
+
+@pytest.mark.parametrize('filt', ['gau', 'wavelet', 'avg_pool'])
+def test_dsn_translate_and_domain_distance_map(filt):
+    """dataset-generation inference: fake LR, discriminator map and ddm against the oracle nets + the restated
+    receptive-field spreading"""
+    dev = _gpu()
+    from dasr_amd.dsn_model import DSNModel
+    from oracle import dsn, dsn_dataset
+    from oracle.gen_golden_dsn import dsn_state
+    G, D = dsn.DeResnet(), dsn.Discriminator(5, 'Instance', filt)
+    sdG, sdD = dsn_state(G.state_dict(), 21, 0.5), dsn_state(D.state_dict(), 22, 1.0)
+    G.load_state_dict(sdG)
+    D.load_state_dict(sdD)
+    m = DSNModel(dict(filter=filt, w_per=0.0), device=dev)
+    m.netG.load_state_dict(sdG)
+    m.netD.load_state_dict(sdD)
+    g = torch.Generator().manual_seed(31)
+    img = torch.rand(1, 3, 104, 88, generator=g)
+    fake, d_out, ddm = m.translate(img.to(dev))
+    rf, rd, rddm = dsn_dataset.translate(G, D, img, filt)
+    assert rel(fake.cpu(), rf) < ACT_TOL
+    assert tuple(d_out.shape) == tuple(rd.shape)
+    assert rel(d_out.cpu(), torch.from_numpy(rd)) < ACT_TOL
+    assert rel(ddm.cpu().double(), torch.from_numpy(rddm)) < ACT_TOL
+    # discriminator map of a given LR image (source-domain ddm)
+    lr = torch.rand(1, 3, 27, 34, generator=g)
+    d2, ddm2 = m.ddm_of(lr.to(dev))
+    lr_c = lr[..., :26, :34] if filt == 'wavelet' else lr
+    with torch.no_grad():
+        rd2 = D(lr_c).numpy()
+    assert rel(d2.cpu(), torch.from_numpy(rd2)) < ACT_TOL
+    assert rel(ddm2.cpu().double(), torch.from_numpy(dsn_dataset.domain_distance_map(rd2, lr_c.shape, filt))) < ACT_TOL
+
+
+def test_dsn_dataset_cli_end_to_end(tmp_path):
+    _gpu()
+    from dasr_amd import dsn_train, dsn_create_dataset
+    save = str(tmp_path / 'dsn')
+    dsn_train.main(['--debug', '--batch_size', '2', '--crop_size', '128', '--filter', 'wavelet', '--save_path', save, '--save_model_interval', '1',
+                    '--no_per_loss'])
+    ck = os.path.join(save, 'checkpoints', 'last_iteration.tar')
+    assert os.path.exists(ck)
+    out, n = dsn_create_dataset.main(['--checkpoint', ck, '--filter', 'wavelet', '--name', 'gen', '--out_root', str(tmp_path / 'res'),
+                                      '--including_source_ddm', '--n_synthetic', '2'])
+    assert n == 2 and os.path.exists(os.path.join(out, 'gen.tar'))
+    pngs = sorted(os.listdir(os.path.join(out, 'imgs_from_target')))
+    assert pngs == ['target_000.png', 'target_001.png']
+    from PIL import Image
+    assert Image.open(os.path.join(out, 'imgs_from_target', pngs[0])).size == (48, 40)   # 192x160 HR / 4
+    ddm = np.load(os.path.join(out, 'ddm_target', 'target_000.npy'))
+    assert ddm.dtype == np.float64 and ddm.shape == (1, 1, 20, 24) and 0 < ddm.min() and ddm.max() < 1
+    dds = np.load(os.path.join(out, 'ddm_source', 'source_001.npy'))
+    assert dds.shape == (1, 1, 20, 24)
