@@ -724,6 +724,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const dasr_conv_param
         const char* buf = smem + (ck & 1) * C::BUF_BYTES;
         char* nbuf = smem + ((ck + 1) & 1) * C::BUF_BYTES;
         const bool more = ck + 1 < nchunks;
+        if (ck == 2) TRACE_STAMP(8);
         bf16x8 fb[2][6], fa[2][MT];
         // step s = kx * 3 + ky; B rows of phase kx live in fb[kx & 1], A of step s in fa[s & 1]
 #pragma unroll
@@ -754,8 +755,11 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const dasr_conv_param
                     acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][mi], fb[kx & 1][nt + ky], acc[mi][nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (ck == 2) TRACE_STAMP(9);
         __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (ck == 2) TRACE_STAMP(10);
         __syncthreads();
+        if (ck == 2) TRACE_STAMP(11);
     }
     TRACE_STAMP(4);
     conv_epilogue<false, MT, NT, 1, EPI>(p, acc, smem, bias_reg, tid, mg, n, oy0, ox0);

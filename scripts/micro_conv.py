@@ -80,9 +80,11 @@ if os.environ.get('DASR_HIP_LIB'):
     for i, nm in enumerate(names):
         d = t[:, i + 1] - t[:, i]
         print('  %-30s cycles p10 %7.0f p50 %7.0f p90 %7.0f' % (nm, np.percentile(d, 10), np.percentile(d, 50), np.percentile(d, 90)))
-    for i, nm in zip(range(8, 13), ['chunk2: store_chunk (vmcnt wait + ds_write)', 'chunk2: barrier 1', 'chunk2: issue loads', 'chunk2: compute', 'chunk2: barrier 2']):
+    glds = t[:, 12].max() == 0
+    for i, nm in zip(range(8, 13), ['chunk2: reads + MFMAs + DMA issue', 'chunk2: wait for own DMA (vmcnt 0)', 'chunk2: barrier', '-', '-'] if glds else
+                     ['chunk2: store_chunk (vmcnt wait + ds_write)', 'chunk2: barrier 1', 'chunk2: issue loads', 'chunk2: compute', 'chunk2: barrier 2']):
         d = t[:, i + 1] - t[:, i]
-        if t[:, i].min() > 0:
+        if t[:, i].min() > 0 and t[:, i + 1].min() > 0:
             print('  %-44s cycles p10 %7.0f p50 %7.0f p90 %7.0f' % (nm, np.percentile(d, 10), np.percentile(d, 50), np.percentile(d, 90)))
     wall = (t[:, 14] - t[:, 15]) * 10.0
     cyc = t[:, 7] - t[:, 0]
