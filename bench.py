@@ -240,7 +240,7 @@ def sweep(model, data, a):
         run_steps(3)
         log('sweep step time, wgrad mode %d: %.2f ms/step' % (wm, (time.perf_counter() - t0) / 3 * 1e3))
     L.dasr_wgrad_set_mode(1)
-    for combo in ((0, 0, 0, 1), (12, 12, 0, 1), (0, 0, 0, 1), (12, 12, 0, 1)):
+    for combo in ((12, 12, 0, 1), (13, 13, 0, 1), (0, 0, 0, 1), (12, 12, 0, 1), (13, 13, 0, 1), (0, 0, 0, 1)):
         for k, v in zip((1, 2, 3, 4), combo):
             L.dasr_set_tuning(k, v)
         run_steps(1)

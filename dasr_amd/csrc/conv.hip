@@ -615,13 +615,13 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
 //    per chunk instead of 36 + 9*MT, prefetched one (kx, ky) step ahead of the MFMAs.
 // Tile 16 x 32 output pixels, 4 waves, wave w owns rows 4w..4w+3 (4 n-tiles of 32 pixels) x MT m-tiles.
 // ---------------------------------------------------------------------------------------------------
-template <int MT>
+template <int MT, int NW = 4>
 struct GCfg {
-    static constexpr int NT = 4, TH = 16, TW = 32, IH = 18, IW = 34, NPIX = IH * IW;
-    static constexpr int AR = (NPIX * 2 + 255) / 256;          // activation DMA pieces per thread (16 B each)
-    static constexpr int ACT_BYTES = AR * 256 * 16;            // 20480 >= 612 * 32
+    static constexpr int NT = 4, NTH = NW * 64, TH = 4 * NW, TW = 32, IH = TH + 2, IW = 34, NPIX = IH * IW;
+    static constexpr int AR = (NPIX * 2 + NTH - 1) / NTH;      // activation DMA pieces per thread (16 B each)
+    static constexpr int ACT_BYTES = AR * NTH * 16;            // >= NPIX * 32
     static constexpr int WPIECE = 9 * MT * 64;                 // 16-byte pieces of a chunk's weights
-    static constexpr int WR = (WPIECE + 255) / 256;
+    static constexpr int WR = (WPIECE + NTH - 1) / NTH;
     static constexpr int W_BYTES = WPIECE * 16;
     static constexpr int BUF_BYTES = ACT_BYTES + W_BYTES;
     static constexpr int LDS_BYTES = 2 * BUF_BYTES;
@@ -629,24 +629,24 @@ struct GCfg {
 
 // one 16-byte-per-lane DMA piece of chunk ck: piece i < AR activations, else weights; the LDS base is wave-uniform.
 // (A free function, not a lambda: hipcc drops the host-side kernel handle when this builtin sits in a lambda of a __global__ template.)
-template <int MT>
+template <int MT, int NW>
 __device__ __forceinline__ void glds_dma_piece(int i, int ck, char* buf, __amdgpu_buffer_rsrc_t rin, __amdgpu_buffer_rsrc_t rw, const unsigned* goff,
                                                unsigned in_chunk_bytes, int wave, int tid) {
-    using C = GCfg<MT>;
+    using C = GCfg<MT, NW>;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     if (i < C::AR) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(buf + (i * 256 + wave * 64) * 16), 16, goff[i], (unsigned)ck * in_chunk_bytes, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(buf + (i * C::NTH + wave * 64) * 16), 16, goff[i], (unsigned)ck * in_chunk_bytes, 0, 0);
     } else {
         const int r = i - C::AR;
-        if (r * 256 + wave * 64 < C::WPIECE)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(buf + C::ACT_BYTES + (r * 256 + wave * 64) * 16), 16, (unsigned)(tid + r * 256) * 16u,
+        if (r * C::NTH + wave * 64 < C::WPIECE)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(buf + C::ACT_BYTES + (r * C::NTH + wave * 64) * 16), 16, (unsigned)(tid + r * C::NTH) * 16u,
                                                      (unsigned)ck * (9u * MT * 1024u), 0, 0);
     }
 }
 
-template <int MT, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_glds_kernel(const dasr_conv_params p) {
-    using C = GCfg<MT>;
+template <int MT, int EPI, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(const dasr_conv_params p) {
+    using C = GCfg<MT, NW>;
     constexpr int NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const dasr_conv_param
     unsigned goff[C::AR];
 #pragma unroll
     for (int r = 0; r < C::AR; ++r) {
-        const int q = tid + r * 256;
+        const int q = tid + r * C::NTH;
         const int pp = q >> 1, h = (q & 1) ^ ((pp >> 3) & 1);
         const int iy = pp / C::IW, ix = pp - iy * C::IW;
         const int gy = iy0 + iy, gx = ix0 + ix;
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const dasr_conv_param
 
     // chunk 0
 #pragma unroll
-    for (int i = 0; i < NP; ++i) glds_dma_piece<MT>(i, 0, smem, rin, rw, goff, in_chunk_bytes, wave, tid);
+    for (int i = 0; i < NP; ++i) glds_dma_piece<MT, NW>(i, 0, smem, rin, rw, goff, in_chunk_bytes, wave, tid);
     TRACE_STAMP(1);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's DMA pieces have landed
     __syncthreads();
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const dasr_conv_param
             }
             if (more && s < 4) {  // all pieces of the next chunk are requested in the first steps: they have the rest of the chunk to land
 #pragma unroll
-                for (int i = s * NP / 4; i < (s + 1) * NP / 4; ++i) glds_dma_piece<MT>(i, ck + 1, nbuf, rin, rw, goff, in_chunk_bytes, wave, tid);
+                for (int i = s * NP / 4; i < (s + 1) * NP / 4; ++i) glds_dma_piece<MT, NW>(i, ck + 1, nbuf, rin, rw, goff, in_chunk_bytes, wave, tid);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -773,11 +773,11 @@ __global__ __launch_bounds__(256, 2) void conv_glds_kernel(const dasr_conv_param
 #endif
 }
 
-template <int MT, int EPI = 0>
+template <int MT, int EPI = 0, int NW = 4>
 int launch_glds(const dasr_conv_params& p, hipStream_t s) {
-    using C = GCfg<MT>;
+    using C = GCfg<MT, NW>;
     static bool attr_set = false;
-    auto kfn = conv_glds_kernel<MT, EPI>;
+    auto kfn = conv_glds_kernel<MT, EPI, NW>;
     if ((p.cin & 15) || p.kh != 3 || p.stride != 1 || p.pad != 1 || p.ups || p.in_f32 || p.prec != 1 || (p.pad_x >= 0 && p.pad_x != 1)) return DASR_EINVAL;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
@@ -788,7 +788,7 @@ int launch_glds(const dasr_conv_params& p, hipStream_t s) {
     const int tiles_x = (p.Wout + C::TW - 1) / C::TW, tiles_y = (p.Hout + C::TH - 1) / C::TH;
     const long long grid = (long long)MG * tiles_x * tiles_y * p.N;
     if (grid <= 0 || grid > 0x7fffffffLL) return DASR_EINVAL;
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(256), C::LDS_BYTES, s, p);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(C::NTH), C::LDS_BYTES, s, p);
     return (int)hipGetLastError();
 }
 
@@ -874,7 +874,7 @@ extern "C" int dasr_debug_set_trace(void* buf) {
 
 extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
     switch (key) {
-        case 1: g_tune_rdb32 = value; return 0;   // Cout=32 dense conv: 12 LDS-DMA kernel (default); first-generation kernel: 0 single LDS buffer, 1 double,
+        case 1: g_tune_rdb32 = value; return 0;   // Cout=32 dense conv: 12 LDS-DMA kernel (default), 13 its 8-wave 32x32-tile form; first-generation kernel: 0 single LDS buffer, 1 double,
                                                    // 4/5 8x32 tiles, 6 4x32 tiles, 8/9 row reuse, 10/11 register-staged pipeline
         case 2: g_tune_rdb64 = value; return 0;   // Cout=64 dense conv: same codes as key 1
         case 3: g_tune_stream = value; return 0;  // split-bf16 stream conv: 0 single, 1 double
@@ -923,6 +923,12 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                         case 68: return launch_glds<1, 68>(p, s);
                         default: return launch_glds<1, 0>(p, s);
                     }
+                case 13:  // 8 waves, 32x32-pixel tile: -20 % DMA bytes per MFMA (weights and halo amortised over twice the pixels)
+                    switch (g_tune_epi ? classify_epi(p) : 0) {
+                        case 67: return launch_glds<1, 67, 8>(p, s);
+                        case 68: return launch_glds<1, 68, 8>(p, s);
+                        default: return launch_glds<1, 0, 8>(p, s);
+                    }
                 default: break;
             }
             switch (g_tune_epi ? classify_epi(p) : 0) {
@@ -947,6 +953,14 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                         case 232: return launch_glds<2, 232>(p, s);
                         case 248: return launch_glds<2, 248>(p, s);
                         default: return launch_glds<2, 0>(p, s);
+                    }
+                case 13:
+                    switch (g_tune_epi ? classify_epi(p) : 0) {
+                        case 233: return launch_glds<2, 233, 8>(p, s);
+                        case 249: return launch_glds<2, 249, 8>(p, s);
+                        case 232: return launch_glds<2, 232, 8>(p, s);
+                        case 248: return launch_glds<2, 248, 8>(p, s);
+                        default: return launch_glds<2, 0, 8>(p, s);
                     }
                 default: break;
             }

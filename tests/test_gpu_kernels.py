@@ -115,7 +115,7 @@ def test_conv_forward_matches_torch(case):
         assert float(pad_part.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('variant', [0, 1, 4, 5, 8, 9, 10, 11])
+@pytest.mark.parametrize('variant', [0, 1, 4, 5, 8, 9, 10, 11, 13])
 @pytest.mark.parametrize('case', CONV_CASES[:3], ids=[c[0] for c in CONV_CASES[:3]])
 def test_conv_tuning_variants_match_torch(case, variant):
     """the A/B-able variants of the dense-block conv (dasr_set_tuning keys 1, 2; default 12 = LDS-DMA kernel, 0 = first-generation
