@@ -50,6 +50,10 @@ class PackDesc(C.Structure):
                 ('nseg', c_i32), ('src_ntaps', c_i32), ('tapmap', C.c_int8 * 32), ('seg', PackSeg * 5)]
 
 
+class CropDesc(C.Structure):
+    _fields_ = [('src', c_vp), ('C', c_i32), ('H', c_i32), ('W', c_i32), ('vH', c_i32), ('vW', c_i32), ('y0', c_i32), ('x0', c_i32), ('flags', c_i32)]
+
+
 class Op(C.Structure):
     _fields_ = [('op', c_i32), ('i', c_i32 * 8), ('f', c_f32 * 4), ('l', c_i64 * 4), ('p', c_vp * 4), ('t', Tensor * 5),
                 ('conv', ConvParams)]
@@ -89,6 +93,7 @@ _SIGS = {
     'dasr_logloss': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp, c_f32, Tensor, c_i32, c_vp],
     'dasr_sigmoid_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_vp],
     'dasr_sigmoid_fwd': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_vp],
+    'dasr_gather_crops': [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
     'dasr_prelu_grad': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_vp],
     'dasr_lowpass_valid': [Tensor, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_vp],
     'dasr_run_ops': [c_vp, c_i32, c_vp],

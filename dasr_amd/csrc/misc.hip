@@ -318,6 +318,50 @@ extern "C" int dasr_add_flat(float* y, const float* x, int64_t n, void* stream) 
     return (int)hipGetLastError();
 }
 
+// batch assembly on resident images: crop (+ optional bilinear resize of the source, cv2.INTER_LINEAR convention: half-pixel
+// centres, edge clamp) + hflip / vflip / transpose; one thread per output element
+__global__ void gather_crops_kernel(const dasr_crop_desc* __restrict__ descs, int n, int C, int size, float* __restrict__ dst) {
+    const long long total = (long long)n * C * size * size;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x = i % size;
+    long long t = i / size;
+    const int y = t % size;
+    t /= size;
+    const int c = t % C;
+    const int k = t / C;
+    const dasr_crop_desc D = descs[k];
+    int ci = y, cj = x;
+    if (D.flags & 4) { ci = x; cj = y; }           // transpose was applied last: undo first
+    if (D.flags & 2) ci = size - 1 - ci;           // vflip
+    if (D.flags & 1) cj = size - 1 - cj;           // hflip
+    const int vy = D.y0 + ci, vx = D.x0 + cj;
+    float v = 0.f;
+    if (c < D.C && vy >= 0 && vy < D.vH && vx >= 0 && vx < D.vW) {
+        const float* s = D.src + (size_t)c * D.H * D.W;
+        if (D.vH == D.H && D.vW == D.W) {
+            v = s[(size_t)vy * D.W + vx];
+        } else {
+            float fy = ((float)vy + 0.5f) * ((float)D.H / (float)D.vH) - 0.5f, fx = ((float)vx + 0.5f) * ((float)D.W / (float)D.vW) - 0.5f;
+            int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+            const float wy = fy - (float)y0, wx = fx - (float)x0;
+            const int y1 = min(max(y0 + 1, 0), D.H - 1), x1 = min(max(x0 + 1, 0), D.W - 1);
+            y0 = min(max(y0, 0), D.H - 1);
+            x0 = min(max(x0, 0), D.W - 1);
+            v = (1.f - wy) * ((1.f - wx) * s[(size_t)y0 * D.W + x0] + wx * s[(size_t)y0 * D.W + x1]) +
+                wy * ((1.f - wx) * s[(size_t)y1 * D.W + x0] + wx * s[(size_t)y1 * D.W + x1]);
+        }
+    }
+    dst[i] = v;
+}
+
+extern "C" int dasr_gather_crops(const dasr_crop_desc* descs_dev, int32_t n, int32_t C, int32_t size, float* dst, void* stream) {
+    const long long total = (long long)n * C * size * size;
+    if (total <= 0 || !descs_dev || !dst) return DASR_EINVAL;
+    hipLaunchKernelGGL(gather_crops_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), descs_dev, n, C, size, dst);
+    return (int)hipGetLastError();
+}
+
 extern "C" int dasr_abi_version(void) { return DASR_ABI_VERSION; }
 
 static int g_last_failed_op = -1;

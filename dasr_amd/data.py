@@ -1,0 +1,119 @@
+"""Device-side input pipeline for the DASR unpaired dataset.
+
+Reference: codes/SRN/data/LRHR_wavelet_unpairEq_fake_w_dataset.py:50-166 (`__getitem__`), data/util.py:78-128 (read_img, augment),
+DataLoader collation.  The reference decodes four images per sample on CPU workers, resizes the domain-distance map with
+cv2.INTER_LINEAR, crops, flips / transposes with numpy and ships the batch over PCIe.  Here every image (and every ddm array) is
+uploaded ONCE as a CHW fp32 RGB tensor; a batch is n descriptors (image, crop origin, flags) and five `dasr_gather_crops`
+launches that write the five batch tensors of the reference's dict directly in HBM.  Random draws are made on the host in the
+reference's order (np.random for the unpaired indices, `random` for the crop origins and the three augmentation coins), so with
+equal seeds and num_workers=0 the batches coincide.  Image decoding (PIL) stays on the host and happens once per file.
+"""
+import ctypes as C
+import os
+import random
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import _stream, ensure_runtime_ready
+
+IMG_EXTENSIONS = ('.jpg', '.JPG', '.jpeg', '.JPEG', '.png', '.PNG', '.ppm', '.PPM', '.bmp', '.BMP')
+
+
+def image_paths(root):
+    """sorted image (and .npy) files under root (data/util.py:24-38)"""
+    out = []
+    for dirpath, _, fnames in sorted(os.walk(root)):
+        for f in sorted(fnames):
+            if f.endswith(IMG_EXTENSIONS) or f.endswith('.npy'):
+                out.append(os.path.join(dirpath, f))
+    return sorted(out)
+
+
+def load_image(path):
+    """file -> CHW fp32 RGB in [0,1] (read_img gives HWC BGR; the dataset flips to RGB at the end: same values)"""
+    if path.endswith('.npy'):
+        a = np.load(path)
+        return torch.from_numpy(np.ascontiguousarray(a[0] if a.ndim == 4 else a)).float()
+    from PIL import Image
+    a = np.asarray(Image.open(path).convert('RGB'), dtype=np.float32) / 255.0
+    return torch.from_numpy(a).permute(2, 0, 1).contiguous()
+
+
+class DeviceUnpairedDataset:
+    """Iterable of batch dicts {'LR_fake','LR_real','HR','HR_unpair','fake_w'} (CUDA tensors) built on the device.
+
+    images: dict with lists of CHW fp32 tensors 'fake_LR', 'real_LR', 'HR' and 'fake_w' ([1,h',w'] domain-distance maps, any size)
+    -- or None to read `dataroot_*` folders of `ds_opt` (PNG / .npy files)."""
+
+    def __init__(self, ds_opt, scale=4, images=None, device=None, shuffle=None, drop_last=True):
+        ensure_runtime_ready()
+        self.opt, self.scale = ds_opt, scale
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.n = int(ds_opt['batch_size'])
+        self.hr_size = int(ds_opt['HR_size'])
+        self.use_flip, self.use_rot = bool(ds_opt.get('use_flip')), bool(ds_opt.get('use_rot'))
+        self.shuffle = bool(ds_opt.get('use_shuffle')) if shuffle is None else shuffle
+        if images is None:
+            images = {k: [load_image(p) for p in image_paths(ds_opt[r])] for k, r in
+                      (('fake_LR', 'dataroot_fake_LR'), ('real_LR', 'dataroot_real_LR'), ('HR', 'dataroot_HR'), ('fake_w', 'dataroot_fake_weights'))}
+        self.img = {k: [t.to(self.device, torch.float32).contiguous() for t in v] for k, v in images.items()}
+        assert self.img['HR'], 'Error: HR path is empty.'
+        assert len(self.img['fake_LR']) == len(self.img['HR']) == len(self.img['fake_w'])
+        self.drop_last = drop_last
+
+    def __len__(self):
+        m = len(self.img['fake_LR'])
+        return m // self.n if self.drop_last else (m + self.n - 1) // self.n
+
+    def sample(self, index):
+        """descriptor of one sample; consumes the RNGs exactly like the reference's __getitem__ (train phase)"""
+        s, HRs = self.scale, self.hr_size
+        LRs = HRs // s
+        index_real = np.random.randint(0, len(self.img['real_LR']))
+        index_unpair = np.random.randint(0, len(self.img['HR']))
+        lf, lr_, hr, hu, fw = (self.img['fake_LR'][index], self.img['real_LR'][index_real], self.img['HR'][index], self.img['HR'][index_unpair],
+                               self.img['fake_w'][index])
+        H, W = lf.shape[1:]
+        Hr, Wr = lr_.shape[1:]
+        y_f, x_f = random.randint(0, max(0, H - LRs)), random.randint(0, max(0, W - LRs))
+        y_r, x_r = random.randint(0, max(0, Hr - LRs)), random.randint(0, max(0, Wr - LRs))
+        Hu, Wu = hu.shape[1:]
+        y_u, x_u = random.randint(0, max(0, Hu - HRs)), random.randint(0, max(0, Wu - HRs))
+        hflip = self.use_flip and random.random() < 0.5
+        vflip = self.use_rot and random.random() < 0.5
+        rot90 = self.use_rot and random.random() < 0.5
+        flags = int(hflip) | (int(vflip) << 1) | (int(rot90) << 2)
+        return {'LR_fake': (lf, None, y_f, x_f), 'LR_real': (lr_, None, y_r, x_r), 'HR': (hr, None, y_f * s, x_f * s), 'HR_unpair': (hu, None, y_u, x_u),
+                'fake_w': (fw, (H, W), y_f, x_f), 'flags': flags}
+
+    def batch(self, indices):
+        samples = [self.sample(i) for i in indices]
+        out = {}
+        L = _lib.lib()
+        for key, size in (('LR_fake', self.hr_size // self.scale), ('LR_real', self.hr_size // self.scale), ('HR', self.hr_size), ('HR_unpair', self.hr_size),
+                          ('fake_w', self.hr_size // self.scale)):
+            Cc = 1 if key == 'fake_w' else 3
+            descs = (_lib.CropDesc * len(samples))()
+            for d, smp in zip(descs, samples):
+                t, virt, y0, x0 = smp[key]
+                d.src, d.C, d.H, d.W = t.data_ptr(), t.shape[0], t.shape[1], t.shape[2]
+                d.vH, d.vW = virt if virt is not None else (t.shape[1], t.shape[2])
+                d.y0, d.x0, d.flags = y0, x0, smp['flags']
+            dd = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.device)
+            dst = torch.empty((len(samples), Cc, size, size), dtype=torch.float32, device=self.device)
+            _lib.check(L.dasr_gather_crops(dd.data_ptr(), len(samples), Cc, size, dst.data_ptr(), _stream()), 'gather_crops')
+            out[key] = dst
+            out.setdefault('_keep', []).append(dd)
+        return out
+
+    def __iter__(self):
+        m = len(self.img['fake_LR'])
+        order = list(range(m))
+        if self.shuffle:
+            order = torch.randperm(m).tolist()   # DataLoader(shuffle=True): RandomSampler draws from torch's global generator
+        for b in range(len(self)):
+            idx = order[b * self.n:(b + 1) * self.n]
+            if idx:
+                yield self.batch(idx)

@@ -78,6 +78,10 @@ def create_dataset(ds_opt, opt):
         if ds_opt.get('phase') in ('val', 'test'):
             return SyntheticValDataset(ds_opt, opt['scale'])
         return SyntheticDataset(ds_opt, opt['scale'], opt['model'])
+    if mode == 'LRHR_wavelet_unpair_fake_weights_EQ' and ds_opt.get('phase', 'train') == 'train':
+        # the DASR training set (data/__init__.py:35-36): images resident in HBM, batches assembled by dasr_gather_crops
+        from .data import DeviceUnpairedDataset
+        return DeviceUnpairedDataset(ds_opt, opt['scale'])
     raise NotImplementedError('Dataset [{:s}] is not recognized (the cv2/lmdb loaders of the reference stay on its side of '
                               'the boundary; feed their batch dicts to the trainer object).'.format(str(mode)))
 

@@ -231,6 +231,20 @@ int dasr_prelu_grad(dasr_tensor y, dasr_tensor gx, int32_t N, int32_t C, int32_t
 int dasr_lowpass_valid(dasr_tensor x, const float* w, int32_t k, int32_t N, int32_t C, int32_t H, int32_t W, int32_t mode,
                        dasr_tensor out, int32_t accumulate, void* stream);
 
+/* ---- device-side input pipeline -----------------------------------------------------
+ * Batch assembly of codes/SRN/data/LRHR_wavelet_unpairEq_fake_w_dataset.py:50-166 + data/util.py:116-128 on resident images:
+ * sample k of the batch = size x size crop at (y0, x0) of image `src` (CHW fp32, RGB) -- first resized bilinearly to vH x vW when
+ * that differs from H x W (cv2.resize(..., INTER_LINEAR) of the domain-distance map to the LR size) -- then horizontal flip,
+ * vertical flip, transpose, in that order (util.augment).  dst is [n][C][size][size] fp32. */
+typedef struct {
+    const float* src;
+    int32_t C, H, W;      /* source image */
+    int32_t vH, vW;       /* size it is resized to before cropping (== H, W: no resize) */
+    int32_t y0, x0;       /* crop origin */
+    int32_t flags;        /* bit 0 hflip, bit 1 vflip, bit 2 transpose */
+} dasr_crop_desc;
+int dasr_gather_crops(const dasr_crop_desc* descs_dev, int32_t n, int32_t C, int32_t size, float* dst, void* stream);
+
 /* ---- executor: run a recorded list of ops in one call (keeps the host out of the step) ----------*/
 enum { DASR_OP_CONV = 1, DASR_OP_WGRAD = 2, DASR_OP_WGRAD_REDUCE = 3, DASR_OP_PACK = 4, DASR_OP_DOWNSUM = 5,
        DASR_OP_AXPBY = 6, DASR_OP_FILL = 7, DASR_OP_L1LOSS = 8, DASR_OP_NCHW2B = 9, DASR_OP_B2NCHW = 10,

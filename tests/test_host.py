@@ -33,15 +33,15 @@ def test_struct_sizes_match_header_layout():
     from dasr_amd import _lib
     src = r'''#include <stdio.h>
 #include "dasr_hip.h"
-int main(){printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(dasr_tensor), sizeof(dasr_conv_params), sizeof(dasr_wgrad_part),
- sizeof(dasr_wgrad_reduce_part), sizeof(dasr_pack_seg), sizeof(dasr_pack_desc), sizeof(dasr_op)); return 0;}'''
+int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(dasr_tensor), sizeof(dasr_conv_params), sizeof(dasr_wgrad_part),
+ sizeof(dasr_wgrad_reduce_part), sizeof(dasr_pack_seg), sizeof(dasr_pack_desc), sizeof(dasr_op), sizeof(dasr_crop_desc)); return 0;}'''
     import tempfile
     d = tempfile.mkdtemp()
     open(os.path.join(d, 't.c'), 'w').write(src)
     subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), os.path.join(d, 't.c'), '-o', os.path.join(d, 't')])
     sizes = [int(x) for x in subprocess.check_output([os.path.join(d, 't')]).split()]
     mine = [ctypes.sizeof(c) for c in (_lib.Tensor, _lib.ConvParams, _lib.WgradPart, _lib.WgradReducePart, _lib.PackSeg,
-                                       _lib.PackDesc, _lib.Op)]
+                                       _lib.PackDesc, _lib.Op, _lib.CropDesc)]
     assert sizes == mine, (sizes, mine)
 
 
