@@ -75,7 +75,7 @@ def test_training_driver_validates_and_eval_cli_reports_metrics(tmp_path):
     from dasr_amd import train, test as dtest
     train.main(['-opt', _json_opt(tmp_path, 'f1_train', True)])
     root = tmp_path / 'experiments' / 'f1_train'
-    logs = [f for f in os.listdir(root) if f.startswith('val_')]
+    logs = [f for f in os.listdir(root) if f.startswith('val_') and f.endswith('.log')]
     assert logs and 'psnr:' in (root / logs[0]).read_text()
     imgs = list((root / 'val_images').rglob('*.png'))
     assert len(imgs) == 4  # 2 images x 2 validation passes
