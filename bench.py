@@ -233,7 +233,7 @@ def sweep(model, data, a):
             log('  %-40s cycles p10 %8.0f p50 %8.0f p90 %8.0f' % (nm, np.percentile(d, 10), np.percentile(d, 50), np.percentile(d, 90)))
     for k, v in res.items():
         log('sweep %-16s variant %d : %s (TFLOP/s algorithmic; stream = 1/3 of MFMA rate)' % (k[0], k[1], ' '.join('%.0f' % x for x in v)))
-    for wm in (1, 3, 1, 3):  # wgrad3: register-staged kernel (1) vs LDS-DMA kernel (3 = bit 1 set)
+    for wm in (1, 5, 1, 5):  # wgrad3 staging requests: staggered inside the MFMA stream (1) vs all up front (5 = bit 2 set)
         L.dasr_wgrad_set_mode(wm)
         run_steps(1)
         t0 = time.perf_counter()

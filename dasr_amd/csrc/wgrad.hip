@@ -295,9 +295,11 @@ struct W3 {
 // 768 threads (register prefetch one tile ahead; per-thread piece geometry is computed once), then per pixel row r and tap:
 // A = G^T fragment [oc][16 pixels], B = X fragment [16 pixels shifted by the tap][cin], both gathered with ds_read_b64_tr_b16.
 template <bool USE_TR, bool F32>
-__global__ __launch_bounds__(768, 1) void wgrad3_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit,
+__global__ __launch_bounds__(768, 1) void wgrad3_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit_flags,
                                                         float* __restrict__ ws) {
     using C = W3;
+    const int nsplit = nsplit_flags & 0xffffff;
+    const bool g_stagger_flag = (nsplit_flags >> 24) & 1;  // A/B: staggered in-compute prefetch issue
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* gl = smem;
     char* il = smem + C::G_BYTES;
@@ -405,7 +407,9 @@ __global__ __launch_bounds__(768, 1) void wgrad3_kernel(const dasr_wgrad_part* _
     const int gbase = (ot * 2 + fplane) * C::GPLANE + (8 * khalf + (li >> 2)) * 32 + (li & 3) * 8;
     const int ibase = (ct * 2 + fplane) * C::IPLANE + (8 * khalf + (li >> 2)) * 32 + (li & 3) * 8;
     // one tile of MFMAs for the tap range [T0, T0 + NA): flat software pipeline, fragments of step i+1 requested before MFMA i
-    auto compute = [&](auto t0c, auto nac) {
+    // next_tile >= 0: this wave requests the next tile's staging loads at MFMA step 5 * (pair index), so the twelve waves' requests
+    // are spread over the compute phase instead of hitting the texture path together before it
+    auto compute = [&](auto t0c, auto nac, int next_tile) {
         constexpr int T0 = decltype(t0c)::value, NA = decltype(nac)::value;
         if constexpr (USE_TR) {
             bf16x8 a[2], b[2];
@@ -415,9 +419,13 @@ __global__ __launch_bounds__(768, 1) void wgrad3_kernel(const dasr_wgrad_part* _
                 const int o = ibase + (ky * C::IW + kx) * 32;
                 b[0] = frag_tr(il, o, o + 4 * 32);
             }
+            const int pf_step = next_tile >= 0 ? 5 * pair : -1;
 #pragma unroll
             for (int i = 0; i < C::PH * NA; ++i) {
                 const int r = i / NA, t = T0 + (i - r * NA);
+                if (i % 5 == 0 && i <= 25) {
+                    if (i == pf_step) prefetch(next_tile);
+                }
                 if (i + 1 < C::PH * NA) {
                     const int r1 = (i + 1) / NA, t1 = T0 + ((i + 1) - r1 * NA);
                     const int ky1 = t1 / 3, kx1 = t1 - ky1 * 3;
@@ -476,11 +484,13 @@ __global__ __launch_bounds__(768, 1) void wgrad3_kernel(const dasr_wgrad_part* _
         if (it == 2) WTRACE(4);
         __syncthreads();
         if (it == 2) WTRACE(5);
-        if (tile + nsplit < ntiles) prefetch(tile + nsplit);
+        const int next_tile = tile + nsplit < ntiles ? tile + nsplit : -1;
+        const bool stagger = USE_TR && active && g_stagger_flag;
+        if (next_tile >= 0 && !stagger) prefetch(next_tile);
         if (it == 2) WTRACE(6);
         if (!active) continue;
-        if (th == 0) compute(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
-        else compute(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
+        if (th == 0) compute(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{}, stagger ? next_tile : -1);
+        else compute(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{}, stagger ? next_tile : -1);
         if (it == 2) WTRACE(7);
     }
 
@@ -809,6 +819,7 @@ int launch_wgrad(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws
     return (int)hipGetLastError();
 }
 
+extern int g_wgrad3_stagger;
 template <bool USE_TR, bool F32>
 int launch_wgrad3(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws, hipStream_t s) {
     auto kfn = wgrad3_kernel<USE_TR, F32>;
@@ -817,7 +828,7 @@ int launch_wgrad3(const dasr_wgrad_part* parts, int nparts, int nsplit, float* w
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, W3::LDS_BYTES + 16));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kfn, dim3(nparts * nsplit), dim3(W3::NT), W3::LDS_BYTES + 16, s, parts, nparts, nsplit, ws);
+    hipLaunchKernelGGL(kfn, dim3(nparts * nsplit), dim3(W3::NT), W3::LDS_BYTES + 16, s, parts, nparts, nsplit | (g_wgrad3_stagger << 24), ws);
     return (int)hipGetLastError();
 }
 
@@ -832,6 +843,7 @@ int launch_wgrad3_glds(const dasr_wgrad_part* parts, int nparts, int nsplit, flo
 }
 
 int g_use_tr = -1;  // -1 unknown, 0 gather fallback, 1 transpose reads
+int g_wgrad3_stagger = 1;
 int g_wgrad3_glds = 0;  // LDS-DMA wgrad3: faster alone (490 vs 470 TFLOP/s) but its 101 KB of LDS keeps the other sub-batch stream off the CU: -2.5 % on the step
 
 }  // namespace
@@ -854,6 +866,7 @@ extern "C" int dasr_debug_set_wtrace(void* buf) { return (int)hipMemcpyToSymbol(
 #endif
 
 extern "C" int dasr_wgrad_set_mode(int use_tr) {
+    g_wgrad3_stagger = (use_tr & 4) ? 0 : 1;  // bit 2: all waves request the next tile before computing (A/B)
     g_wgrad3_glds = (use_tr & 2) ? 1 : 0;  // bit 1: LDS-DMA wgrad3 instead of the register-staged one (A/B)
     use_tr &= 1;
     g_use_tr = use_tr;
