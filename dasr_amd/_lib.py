@@ -22,7 +22,8 @@ class ConvParams(C.Structure):
                 ('mask', Tensor), ('mask_f32', c_i32),
                 ('alpha', c_f32), ('res1', Tensor), ('beta1', c_f32), ('res2', Tensor), ('beta2', c_f32),
                 ('out_f32', Tensor), ('out_bf16', Tensor), ('gamma', c_f32), ('xcd_remap', c_i32),
-                ('pad_x', c_i32), ('out_stride', c_i32), ('out_oy', c_i32), ('out_ox', c_i32), ('out_W', c_i32), ('slope_ptr', c_vp)]
+                ('pad_x', c_i32), ('out_stride', c_i32), ('out_oy', c_i32), ('out_ox', c_i32), ('out_W', c_i32), ('slope_ptr', c_vp),
+                ('in_stride', c_i32), ('in_oy', c_i32), ('in_ox', c_i32), ('in_W', c_i32)]
 
 
 class WgradPart(C.Structure):
@@ -47,7 +48,7 @@ class PackSeg(C.Structure):
 
 class PackDesc(C.Structure):
     _fields_ = [('dst_off', c_i64), ('lo_off', c_i64), ('cout', c_i32), ('cin_pad', c_i32), ('ntaps', c_i32), ('mt', c_i32),
-                ('nseg', c_i32), ('src_ntaps', c_i32), ('tapmap', C.c_int8 * 32), ('seg', PackSeg * 5)]
+                ('nseg', c_i32), ('src_ntaps', c_i32), ('tapmap', C.c_int8 * 32), ('tapmask', C.c_uint16 * 16), ('seg', PackSeg * 5)]
 
 
 class CropDesc(C.Structure):
@@ -102,7 +103,7 @@ _SIGS = {
     'dasr_probe_tr16': [c_vp],
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 

@@ -313,7 +313,8 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
         const bool ok = (q < C::NPIECE) & (gy >= 0) & (gy < HL) & (gx >= 0) & (gx < WL);  // bitwise: keeps the prologue one basic block
         const int sy = p.ups ? (gy >> 1) : gy, sx = p.ups ? (gx >> 1) : gx;
         const int pl = piece / C::PPP16, pp = piece - pl * C::PPP16;
-        goff[r] = ok ? (unsigned)((pl * (int)p.in.cb_stride + (sy * p.Win + sx) * 16 + pp * (IN_F32 ? 4 : 8)) * ESZ) : OOB;
+        const int spix = p.in_stride > 1 ? (sy * p.in_stride + p.in_oy) * p.in_W + sx * p.in_stride + p.in_ox : sy * p.Win + sx;
+        goff[r] = ok ? (unsigned)((pl * (int)p.in.cb_stride + spix * 16 + pp * (IN_F32 ? 4 : 8)) * ESZ) : OOB;
         loff[r] = q < C::NPIECE ? pix * C::PIXB + piece * (IN_F32 ? 8 : 16) : DUMMY;
     }
     const __amdgpu_buffer_rsrc_t rin = make_rsrc((const char*)p.in.p + (size_t)n * p.in.n_stride * ESZ);
@@ -778,7 +779,8 @@ int launch_glds(const dasr_conv_params& p, hipStream_t s) {
     using C = GCfg<MT, NW>;
     static bool attr_set = false;
     auto kfn = conv_glds_kernel<MT, EPI, NW>;
-    if ((p.cin & 15) || p.kh != 3 || p.stride != 1 || p.pad != 1 || p.ups || p.in_f32 || p.prec != 1 || (p.pad_x >= 0 && p.pad_x != 1)) return DASR_EINVAL;
+    if ((p.cin & 15) || p.kh != 3 || p.stride != 1 || p.pad != 1 || p.ups || p.in_f32 || p.prec != 1 || (p.pad_x >= 0 && p.pad_x != 1) || p.in_stride > 1)
+        return DASR_EINVAL;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         attr_set = true;
@@ -830,7 +832,8 @@ __global__ void conv_naive_kernel(const dasr_conv_params p, const float* w) {
                 const int gy = oy * p.stride - p.pad + ky, gx = ox * p.stride - (p.pad_x >= 0 ? p.pad_x : p.pad) + kx;
                 if (gy < 0 || gy >= HL || gx < 0 || gx >= WL) continue;
                 const int sy = p.ups ? gy >> 1 : gy, sx = p.ups ? gx >> 1 : gx;
-                const size_t o = (size_t)n * p.in.n_stride + (size_t)(c >> 4) * p.in.cb_stride + ((size_t)sy * p.Win + sx) * 16 + (c & 15);
+                const size_t spix = p.in_stride > 1 ? ((size_t)sy * p.in_stride + p.in_oy) * p.in_W + (size_t)sx * p.in_stride + p.in_ox : (size_t)sy * p.Win + sx;
+                const size_t o = (size_t)n * p.in.n_stride + (size_t)(c >> 4) * p.in.cb_stride + spix * 16 + (c & 15);
                 const float x = p.in_f32 ? ((const float*)p.in.p)[o] : (float)((const bf16_t*)p.in.p)[o];
                 acc += x * w[(((size_t)oc * p.cin + c) * p.kh + ky) * p.kh + kx];
             }

@@ -39,11 +39,17 @@ __global__ void pack_kernel(const dasr_pack_desc* __restrict__ descs, int ndesc,
                 const int ci = cin - S.cin_start;
                 if (ci >= 0 && ci < S.cin_len) {
                     const int st = D.tapmap[tap];
-                    if (st < 0) {
-                    } else if (!S.transpose) {
-                        v = params[S.src_off + ((long long)oc * S.src_cin + S.src_c0 + ci) * D.src_ntaps + st];
-                    } else if (ci < S.src_cout) {
-                        v = params[S.src_off + ((long long)ci * S.src_cin + S.src_c0 + oc) * D.src_ntaps + st];
+                    const unsigned msk = tap < 16 ? D.tapmask[tap] : 0u;
+                    const bool okc = !S.transpose || ci < S.src_cout;
+                    const long long base = !S.transpose ? S.src_off + ((long long)oc * S.src_cin + S.src_c0 + ci) * D.src_ntaps
+                                                        : S.src_off + ((long long)ci * S.src_cin + S.src_c0 + oc) * D.src_ntaps;
+                    if (msk && okc) {  // sum of source taps (fixed order: deterministic)
+                        float acc = 0.f;
+                        for (int k = 0; k < D.src_ntaps && k < 16; ++k)
+                            if (msk & (1u << k)) acc += params[base + k];
+                        v = acc;
+                    } else if (st >= 0 && okc) {
+                        v = params[base + st];
                     }
                 }
             }

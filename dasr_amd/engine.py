@@ -112,7 +112,7 @@ class PackRegistry:
         self.size = 0  # bf16 elements
         self.buf = None
 
-    def add(self, cout, cin_pad, ntaps, mt, prec, segs, tapmap=None, src_ntaps=None):
+    def add(self, cout, cin_pad, ntaps, mt, prec, segs, tapmap=None, src_ntaps=None, tapmasks=None):
         """tapmap: packed tap -> source tap.  Default: identity for forward segments, reversed (tap flip) when the
         segments are transposed (stride-1 data-gradient)."""
         assert cin_pad % 16 == 0 and len(segs) <= 5 and ntaps <= 32
@@ -129,6 +129,8 @@ class PackRegistry:
             tapmap = [ntaps - 1 - t for t in range(ntaps)] if tr else list(range(ntaps))
         for t in range(32):
             d.tapmap[t] = tapmap[t] if t < len(tapmap) else -1
+        for t in range(16):  # packed tap = sum of the source taps in the bit mask (sub-pixel upconv)
+            d.tapmask[t] = tapmasks[t] if (tapmasks is not None and t < len(tapmasks)) else 0
         for i, s in enumerate(segs):
             sg = d.seg[i]
             sg.src_off, sg.src_cout, sg.src_cin, sg.cin_start, sg.cin_len, sg.src_c0, sg.transpose = s
@@ -204,7 +206,7 @@ def run_interleaved(lists, streams, chunk=48):
 
 def conv_op(pack, ref, inp, in_f32, cin, Hin, Win, Hout, Wout, N, bias=None, kh=3, stride=1, pad=1, ups=0, act=0, slope=SLOPE,
             mask=None, mask_f32=0, alpha=1.0, res1=None, beta1=0.0, res2=None, beta2=0.0, out_f32=None, out_bf16=None, gamma=1.0,
-            pad_x=-1, out_stride=1, out_oy=0, out_ox=0, out_W=0, slope_ptr=None):
+            pad_x=-1, out_stride=1, out_oy=0, out_ox=0, out_W=0, slope_ptr=None, in_stride=1, in_oy=0, in_ox=0, in_W=0):
     assert cin == ref.cin_pad, (cin, ref.cin_pad)
     o = Op()
     o.op = _lib.OP_CONV
@@ -223,6 +225,7 @@ def conv_op(pack, ref, inp, in_f32, cin, Hin, Win, Hout, Wout, N, bias=None, kh=
     p.gamma = gamma
     p.pad_x, p.out_stride, p.out_oy, p.out_ox, p.out_W = pad_x, out_stride, out_oy, out_ox, out_W
     p.slope_ptr = slope_ptr
+    p.in_stride, p.in_oy, p.in_ox, p.in_W = in_stride, in_oy, in_ox, in_W
     return o
 
 

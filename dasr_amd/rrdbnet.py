@@ -63,6 +63,21 @@ class RRDBNetHIP:
             # data-gradient: transposed + tap-flipped; packed cin = forward cout (padded to 16)
             cin_b = ceil_div(cout, 16) * 16
             self.pk[name + '_b'] = self.pack.add(nf, cin_b, 9, 1, sp, [(P.off(key), cout, nf, 0, cout, 0, 1)])
+        # sub-pixel form of nearest-x2 + 3x3 (upconv_blcok, block.py:854-861): output parity (py, px) is a 2x2 convolution of the
+        # LOW-resolution input whose taps are sums of the 3x3 taps that land on the same source pixel -- 16 instead of 36 MACs per
+        # input pixel, channel pair and 2x2 output block.  Row taps per parity: py=0 reads rows (i-1, i) with (w0, w1+w2), py=1 rows
+        # (i, i+1) with (w0+w1, w2); same along x.  The data gradient is the transpose: per parity a 2x2 conv of that parity's
+        # sub-grid of the output gradient with the tap order reversed, summed over the four parities.
+        self.subpixel = os.environ.get('DASR_SUBPIXEL', '1') == '1'
+        rows = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}   # parity -> source taps of packed tap a = 0, 1
+        for name, key in (('up1', 'model.3.weight'), ('up2', 'model.6.weight')):
+            for py in (0, 1):
+                for px in (0, 1):
+                    fw = [sum(1 << (ky * 3 + kx) for ky in rows[py][a] for kx in rows[px][b]) for a in (0, 1) for b in (0, 1)]
+                    bw = [sum(1 << (ky * 3 + kx) for ky in rows[py][1 - a] for kx in rows[px][1 - b]) for a in (0, 1) for b in (0, 1)]
+                    self.pk[(name, py, px)] = self.pack.add(nf, nf, 4, 1, sp, [self._seg_fwd(key, nf, nf)], tapmap=[0, 0, 0, 0], src_ntaps=9, tapmasks=fw)
+                    self.pk[(name + '_b', py, px)] = self.pack.add(nf, nf, 4, 1, sp, [(P.off(key), nf, nf, 0, nf, 0, 1)], tapmap=[0, 0, 0, 0], src_ntaps=9,
+                                                                   tapmasks=bw)
         # dense blocks
         for i in range(self.nb):
             for r in (1, 2, 3):
@@ -200,10 +215,14 @@ class _Plan:
         lrb = 'model.1.sub.%d.bias' % nb
         ops.add(conv_op(pack, pk['lr'], X.view(), True, nf, h, w, h, w, N, bias=P.ptr(lrb), res1=self.fea.view(), beta1=1.0,
                         out_f32=self.t0.view()))
-        ops.add(conv_op(pack, pk['up1'], self.t0.view(), True, nf, h, w, H2, W2, N, bias=P.ptr('model.3.bias'), ups=1, act=1,
-                        out_f32=self.u1.view()))
-        ops.add(conv_op(pack, pk['up2'], self.u1.view(), True, nf, H2, W2, H4, W4, N, bias=P.ptr('model.6.bias'), ups=1, act=1,
-                        out_f32=self.u2.view()))
+        for name, bkey, src, dst, hi, wi in (('up1', 'model.3.bias', self.t0, self.u1, h, w), ('up2', 'model.6.bias', self.u1, self.u2, H2, W2)):
+            if not net.subpixel:
+                ops.add(conv_op(pack, pk[name], src.view(), True, nf, hi, wi, 2 * hi, 2 * wi, N, bias=P.ptr(bkey), ups=1, act=1, out_f32=dst.view()))
+                continue
+            for py in (0, 1):
+                for px in (0, 1):
+                    ops.add(conv_op(pack, pk[(name, py, px)], src.view(), True, nf, hi, wi, hi, wi, N, bias=P.ptr(bkey), kh=2, stride=1, pad=1 - py,
+                                    pad_x=1 - px, act=1, out_f32=dst.view(), out_stride=2, out_oy=py, out_ox=px, out_W=2 * wi))
         ops.add(conv_op(pack, pk['hr0'], self.u2.view(), True, nf, H4, W4, H4, W4, N, bias=P.ptr('model.8.bias'), act=1,
                         out_f32=self.h0.view()))
         ops.add(conv_op(pack, pk['hr1'], self.h0.view(), True, nf, H4, W4, H4, W4, N, bias=P.ptr('model.10.bias'),
@@ -226,6 +245,20 @@ class _Plan:
             ops.add(o)
         ops.keep.append(grp)
 
+    def _subpixel_dgrad(self, ops, name, g_hi, g_lo, hl, wl, mask):
+        """g_lo[hl x wl] = (mask') * sum over output parities of the transposed 2x2 conv of g_hi's parity sub-grid (g_hi: 2hl x 2wl).
+        Forward parity (py, px) read input rows i - (1 - py) + a; the transpose reads sub-grid rows m + (1 - py) - a = m - pad' + a' with
+        a' = 1 - a (tap order reversed in the pack) and pad' = py."""
+        net, pack, pk, N = self.net, self.net.pack, self.net.pk, self.N
+        first = True
+        for py in (0, 1):
+            for px in (0, 1):
+                ops.add(conv_op(pack, pk[(name, py, px)], g_hi.view(), True, net.nf, hl, wl, hl, wl, N, kh=2, stride=1, pad=py, pad_x=px,
+                                mask=mask.view() if mask is not None else None, mask_f32=1, slope=SLOPE,
+                                res1=None if first else g_lo.view(), beta1=0.0 if first else 1.0, out_f32=g_lo.view(),
+                                in_stride=2, in_oy=py, in_ox=px, in_W=2 * wl))
+                first = False
+
     def _build_backward(self):
         net, N, h, w = self.net, self.N, self.h, self.w
         nf, nb, P, pack, pk = net.nf, net.nb, net.params, net.pack, net.pk
@@ -242,22 +275,28 @@ class _Plan:
                         out_f32=g_u2.view()))
         # upconv2 (model.6): wgrad on the upsampled u1; dgrad at 4h x 4w then 2x2 sum (+ LeakyReLU' of u1)
         self._wg(ops, 'model.6.', g_u2, True, self.u1, True, nf, nf, H2, W2, H4, W4, ups=1)
-        ops.add(conv_op(pack, pk['up2_b'], g_u2.view(), True, nf, H4, W4, H4, W4, N, out_f32=g_up2.view()))
         g_u1 = self.g2a
-        o = Op()
-        o.op = _lib.OP_DOWNSUM
-        o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = g_up2.view(), N, nf, H2, W2
-        o.t[1], o.i[4], o.f[0], o.t[2], o.t[3] = self.u1.view(), 1, SLOPE, g_u1.view(), NULL_T
-        ops.add(o)
+        if net.subpixel:   # four parity sub-grids of g_u2 -> low-res gradient, LeakyReLU' of u1 applied to every (linear) partial
+            self._subpixel_dgrad(ops, 'up2_b', g_u2, g_u1, H2, W2, mask=self.u1)
+        else:
+            ops.add(conv_op(pack, pk['up2_b'], g_u2.view(), True, nf, H4, W4, H4, W4, N, out_f32=g_up2.view()))
+            o = Op()
+            o.op = _lib.OP_DOWNSUM
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = g_up2.view(), N, nf, H2, W2
+            o.t[1], o.i[4], o.f[0], o.t[2], o.t[3] = self.u1.view(), 1, SLOPE, g_u1.view(), NULL_T
+            ops.add(o)
         # upconv1 (model.3)
         self._wg(ops, 'model.3.', g_u1, True, self.t0, True, nf, nf, h, w, H2, W2, ups=1)
-        g_up1 = self.g2b
-        ops.add(conv_op(pack, pk['up1_b'], g_u1.view(), True, nf, H2, W2, H2, W2, N, out_f32=g_up1.view()))
-        o = Op()
-        o.op = _lib.OP_DOWNSUM
-        o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = g_up1.view(), N, nf, h, w
-        o.t[1], o.i[4], o.f[0], o.t[2], o.t[3] = NULL_T, 0, SLOPE, self.g_t0.view(), NULL_T
-        ops.add(o)
+        if net.subpixel:
+            self._subpixel_dgrad(ops, 'up1_b', g_u1, self.g_t0, h, w, mask=None)
+        else:
+            g_up1 = self.g2b
+            ops.add(conv_op(pack, pk['up1_b'], g_u1.view(), True, nf, H2, W2, H2, W2, N, out_f32=g_up1.view()))
+            o = Op()
+            o.op = _lib.OP_DOWNSUM
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = g_up1.view(), N, nf, h, w
+            o.t[1], o.i[4], o.f[0], o.t[2], o.t[3] = NULL_T, 0, SLOPE, self.g_t0.view(), NULL_T
+            ops.add(o)
         # LR_conv (model.1.sub.nb): t0 = fea + LR_conv(x_last)
         lrk = 'model.1.sub.%d.' % nb
         self._wg(ops, lrk, self.g_t0, True, self.x_last, True, nf, nf, h, w, h, w)

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DASR_ABI_VERSION 1
+#define DASR_ABI_VERSION 2
 #define DASR_EINVAL (-22)
 
 typedef struct {
@@ -61,6 +61,10 @@ typedef struct {
     /* act: 0 none, 1 (Leaky/P)ReLU with `slope`, 2 sigmoid.  slope_ptr != NULL: slope read from device memory
      * (nn.PReLU's learned parameter, codes/DSN/model.py:29,215), used for `act` and for the `mask` derivative. */
     const float* slope_ptr;
+    /* strided INPUT view (sub-pixel data-gradient of nearest-x2 + 3x3: the parity sub-grids of the gradient are read in place):
+     * in_stride 0/1: dense; 2: input pixel (y,x) of the Hin x Win grid lives at (2*y+in_oy, 2*x+in_ox) of a tensor of width in_W.
+     * conv_kernel variants only (not the LDS-DMA dense-block kernel). */
+    int32_t in_stride, in_oy, in_ox, in_W;
 } dasr_conv_params;
 
 int dasr_conv(const dasr_conv_params* p, void* stream);
@@ -134,6 +138,7 @@ typedef struct {
     int32_t cout, cin_pad, ntaps, mt, nseg;
     int32_t src_ntaps;    /* taps of the source weight (kh*kw of the nn.Conv2d) */
     int8_t  tapmap[32];   /* packed tap -> source tap (identity: forward; reversed: stride-1 dgrad; parity subset: stride-2 dgrad) */
+    uint16_t tapmask[16]; /* non-zero: packed tap t (< 16) = SUM of the source taps whose bits are set (sub-pixel form of nearest-x2 + 3x3) */
     dasr_pack_seg seg[5];
 } dasr_pack_desc;
 
