@@ -1,12 +1,8 @@
 #!/bin/bash
-# SQ counters of the isolated dense conv (one pass, 8 SQ slots) -> gpurun_out/pmc_micro/
+# SQ counters of the isolated dense conv (batch 16, Cin 160 -> 32) -> gpurun_out/pmc_micro/ ; two passes of 8 SQ slots each
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out; export TMPDIR=/tmp; exec < /dev/null
-ARGS="${MICRO_ARGS:---cin 160 --cout 32 --n 16 --reps 20}"
-for t in "" "1=8" ; do timeout 60 python scripts/micro_conv.py $ARGS --tune "$t"; done
-timeout 60 python scripts/micro_conv.py $ARGS --streams 2
-timeout 60 python scripts/micro_conv.py --cin 64 --cout 32 --n 16 --reps 40
-timeout 60 python scripts/micro_conv.py --cin 192 --cout 64 --n 16 --reps 20
+ARGS="${MICRO_ARGS:---cin 160 --cout 32 --n 16}"
 rm -rf gpurun_out/pmc_micro
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT" "SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAVES GRBM_GUI_ACTIVE"; do
@@ -15,4 +11,3 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_I
   echo "pmc pass $i exit $?"
 done
 find gpurun_out/pmc_micro -name "*kernel_trace*" -delete
-find gpurun_out/pmc_micro -type f | head
