@@ -693,6 +693,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
     const unsigned in_chunk_bytes = (unsigned)(p.in.cb_stride * 2);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc((const bf16_t*)p.w + (size_t)mg * nchunks * 9 * MT * 512);
     constexpr int NP = C::AR + C::WR;
+    // chunk 0 is requested before the fragment addresses and accumulators are set up: the DMA round trip overlaps that ALU work
+#pragma unroll
+    for (int i = 0; i < NP; ++i) glds_dma_piece<MT, NW>(i, 0, smem, rin, rw, goff, in_chunk_bytes, wave, tid);
+    TRACE_STAMP(1);
     // ---- fragment read addresses: row rr (0..5) of this wave's 6 input rows, column shift kx; lane (nn, kh2)
     const int nn = lane & 31, kh2 = lane >> 5;
     int baddr[6][3];
@@ -713,10 +717,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[mi][nt][j] = 0.f;
 
-    // chunk 0
-#pragma unroll
-    for (int i = 0; i < NP; ++i) glds_dma_piece<MT, NW>(i, 0, smem, rin, rw, goff, in_chunk_bytes, wave, tid);
-    TRACE_STAMP(1);
+
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's DMA pieces have landed
     __syncthreads();
     TRACE_STAMP(2);
