@@ -866,7 +866,7 @@ int classify_epi(const dasr_conv_params& p) {
 }
 
 // kernel-variant selection (A/B-able from the host: dasr_set_tuning)
-int g_tune_rdb32 = 12, g_tune_rdb64 = 12, g_tune_stream = 0, g_tune_xcd = 1, g_tune_epi = 1;
+int g_tune_rdb32 = 12, g_tune_rdb64 = 13, g_tune_stream = 0, g_tune_xcd = 1, g_tune_epi = 1;  // Cout=64: 13 = 8-wave form for launches of <= 256 four-wave workgroups (worth 1-2 % of the step under two sub-batch streams)
 
 }  // namespace
 
@@ -958,7 +958,16 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                         case 248: return launch_glds<2, 248>(p, s);
                         default: return launch_glds<2, 0>(p, s);
                     }
-                case 13:
+                case 13:  // auto: the 8-wave form when the 4-wave grid would not exceed one workgroup per CU (sub-batch launches), else 4 waves
+                    if ((long long)p.N * ((p.Hout + 15) / 16) * ((p.Wout + 31) / 32) * ((p.cout + 63) / 64) > 256) {
+                        switch (g_tune_epi ? classify_epi(p) : 0) {
+                            case 233: return launch_glds<2, 233>(p, s);
+                            case 249: return launch_glds<2, 249>(p, s);
+                            case 232: return launch_glds<2, 232>(p, s);
+                            case 248: return launch_glds<2, 248>(p, s);
+                            default: return launch_glds<2, 0>(p, s);
+                        }
+                    }
                     switch (g_tune_epi ? classify_epi(p) : 0) {
                         case 233: return launch_glds<2, 233, 8>(p, s);
                         case 249: return launch_glds<2, 249, 8>(p, s);

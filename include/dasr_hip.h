@@ -69,7 +69,7 @@ typedef struct {
 
 int dasr_conv(const dasr_conv_params* p, void* stream);
 /* kernel-variant knobs for A/B runs (bench.py --sweep / --tune); defaults are the tuned choice.
- * key 1 / 2: dense-block conv with Cout = 32 / 64: 12 = LDS-DMA kernel (default), 13 = its 8-wave 32x32-tile form, 0 = first-generation register-staged kernel,
+ * key 1 / 2: dense-block conv with Cout = 32 / 64: 12 = LDS-DMA kernel (default for Cout 32), 13 = its 8-wave 32x32-tile form (Cout 64 default: chosen per launch when the 4-wave grid has <= 256 workgroups), 0 = first-generation register-staged kernel,
  *            1 double-buffered LDS, 4/5 8x32 tiles, 6 4x32 tiles, 8/9 row reuse, 10/11 register-staged pipeline;
  * key 3: split-bf16 stream conv (0 single / 1 double LDS buffer, 4 8x32 tiles); key 4: XCD-aware tile order on/off;
  * key 5: compile-time specialised epilogues on/off. */
