@@ -193,9 +193,11 @@ class OpList:
             raise _lib.DasrHipError('dasr_run_ops: op #%d (kind %d) failed with code %d' % (k, self.ops[k].op if 0 <= k < len(self.ops) else -1, rc))
 
 
-def run_interleaved(lists, streams, chunk=48):
+def run_interleaved(lists, streams, chunk=None):
     """Enqueue several op lists on their own streams, alternating in chunks so that every hardware queue gets work
     early (the host enqueues ~250k launches/s; a whole 1200-op list first would leave the other stream idle for ms)."""
+    import os
+    chunk = chunk or int(os.environ.get('DASR_ENQ_CHUNK', '48'))
     n = max(len(l.ops) for l in lists)
     for lo in range(0, n, chunk):
         for l, st in zip(lists, streams):
