@@ -470,6 +470,42 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
             }
             return;
         }
+        if constexpr (PREC == 3 && NT <= 2) {
+            // same tap-level pipeline for the split-bf16 path where the register budget allows two fragment sets (8x32 tiles)
+            constexpr int TOT = KS * C::NTAPS;
+            bf16x8 fa[2][MT], fal[2][MT], fb[2][NT], fbl[2][NT];
+            auto ldfrag = [&](int idx, int set) {
+                const int ks = idx / C::NTAPS, t = idx - ks * C::NTAPS;
+                const int ky = t / KH, kx = t - ky * KH;
+                const int toff = (ky * C::IW + kx) * C::PIXB + ks * 32;
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    fa[set][mi] = *(const bf16x8*)(w_hi + ((ks * C::NTAPS + t) * MT + mi) * 1024 + aoff);
+                    fal[set][mi] = *(const bf16x8*)(w_lo + ((ks * C::NTAPS + t) * MT + mi) * 1024 + aoff);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    fb[set][nt] = *(const bf16x8*)(act_hi + boff[nt] + toff);
+                    fbl[set][nt] = *(const bf16x8*)(act_lo + boff[nt] + toff);
+                }
+            };
+            ldfrag(0, 0);
+#pragma unroll
+            for (int idx = 0; idx < TOT; ++idx) {
+                if (idx + 1 < TOT) ldfrag(idx + 1, (idx + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[idx & 1][mi], fb[idx & 1][nt], acc[mi][nt], 0, 0, 0);
+                        acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[idx & 1][mi], fbl[idx & 1][nt], acc[mi][nt], 0, 0, 0);
+                        acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[idx & 1][mi], fb[idx & 1][nt], acc[mi][nt], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
