@@ -62,7 +62,8 @@ class Op(C.Structure):
 
 OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_DOWNSUM, OP_AXPBY, OP_FILL, OP_L1LOSS, OP_NCHW2B, OP_B2NCHW = range(1, 11)
 (OP_INORM_FWD, OP_INORM_BWD, OP_BCE, OP_DWT_FWD, OP_DWT_BWD, OP_LOWPASS, OP_MAXPOOL, OP_MAXPOOL_BWD, OP_L1DIFF, OP_AFFINE4,
- OP_BILINEAR, OP_LOGLOSS, OP_SIGMOID_BWD, OP_PRELU_GRAD, OP_LOWPASS_VALID, OP_ADD_FLAT, OP_SIGMOID_FWD) = range(11, 28)
+ OP_BILINEAR, OP_LOGLOSS, OP_SIGMOID_BWD, OP_PRELU_GRAD, OP_LOWPASS_VALID, OP_ADD_FLAT, OP_SIGMOID_FWD, OP_EVENT_RECORD, OP_STREAM_WAIT,
+ OP_SET_STREAM) = range(11, 31)
 
 _SIGS = {
     'dasr_conv': [C.POINTER(ConvParams), c_vp],
@@ -95,6 +96,8 @@ _SIGS = {
     'dasr_sigmoid_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_vp],
     'dasr_sigmoid_fwd': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_vp],
     'dasr_gather_crops': [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp],
+    'dasr_event_create': [],
+    'dasr_event_destroy': [c_vp],
     'dasr_prelu_grad': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_vp],
     'dasr_lowpass_valid': [Tensor, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_vp],
     'dasr_run_ops': [c_vp, c_i32, c_vp],
@@ -126,7 +129,7 @@ def lib():
         for name, args in _SIGS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export it
             fn.argtypes = args
-            fn.restype = c_i32
+            fn.restype = c_vp if name == 'dasr_event_create' else c_i32
         if L.dasr_abi_version() != ABI_VERSION:
             raise DasrHipError('libdasr_hip.so ABI %d != binding ABI %d; rebuild' % (L.dasr_abi_version(), ABI_VERSION))
         _lib = L

@@ -368,12 +368,21 @@ extern "C" int dasr_gather_crops(const dasr_crop_desc* descs_dev, int32_t n, int
     return (int)hipGetLastError();
 }
 
+extern "C" void* dasr_event_create(void) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return (void*)e;
+}
+
+extern "C" int dasr_event_destroy(void* ev) { return ev ? (int)hipEventDestroy((hipEvent_t)ev) : 0; }
+
 extern "C" int dasr_abi_version(void) { return DASR_ABI_VERSION; }
 
 static int g_last_failed_op = -1;
 extern "C" int dasr_last_failed_op(void) { return g_last_failed_op; }
 
-extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream) {
+extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream0) {
+    void* stream = stream0;  // DASR_OP_SET_STREAM redirects the following ops
     for (int k = 0; k < n; ++k) {
         const dasr_op& o = ops[k];
         int rc = 0;
@@ -424,6 +433,9 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream) {
             case DASR_OP_LOWPASS_VALID: rc = dasr_lowpass_valid(o.t[0], (const float*)o.p[0], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], o.i[5], o.t[1], o.i[6], stream); break;
             case DASR_OP_ADD_FLAT: rc = dasr_add_flat((float*)o.p[0], (const float*)o.p[1], o.l[0], stream); break;
             case DASR_OP_SIGMOID_FWD: rc = dasr_sigmoid_fwd(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1], stream); break;
+            case DASR_OP_EVENT_RECORD: rc = (int)hipEventRecord((hipEvent_t)o.p[0], as_stream(stream)); break;
+            case DASR_OP_STREAM_WAIT: rc = (int)hipStreamWaitEvent(as_stream(stream), (hipEvent_t)o.p[0], 0); break;
+            case DASR_OP_SET_STREAM: stream = o.p[0] ? o.p[0] : stream0; break;
             default: rc = DASR_EINVAL;
         }
         if (rc != 0) {

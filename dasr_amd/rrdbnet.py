@@ -130,6 +130,13 @@ class RRDBNetHIP:
         return p.read_output()
 
 
+def _sched(kind, handle):
+    o = Op()
+    o.op = kind
+    o.p[0] = handle
+    return o
+
+
 class _Plan:
     """Buffers + recorded forward / backward op lists for one (N, h, w)."""
 
@@ -160,12 +167,21 @@ class _Plan:
         self.g2b = B(nf, H2, W2, True)
         self.g_t0 = B(nf, h, w, True)
         self.gstream = [B(nf, h, w, True) for _ in range(4)]
-        self.gslab = [B(sc, h, w, False) for _ in range(2)]
+        # RDB weight gradients are off the data-gradient chain's critical path; DASR_WG_SIDE=1 moves them to a side stream of the plan
+        # (events recorded / awaited by scheduling ops inside the op list, four gradient slabs instead of two for slack).  Correct
+        # (same tests green) but SLOWER on MI355X: 46.8 vs 38.6 ms/step -- the 1-workgroup-per-CU wgrad launches take CUs from the
+        # serial data-gradient chain of their own sub-batch; kept off, as an experiment switch
+        self.side_stream = torch.cuda.Stream() if (dev.type == 'cuda' and getattr(net, 'concurrent_replicas', 1) > 1 and
+                                                   os.environ.get('DASR_WG_SIDE', '0') == '1') else None
+        self.n_gslab = 4 if self.side_stream is not None else 2
+        self.gslab = [B(sc, h, w, False) for _ in range(self.n_gslab)]
+        self.ws_side = Workspace(dev)
         self.g_fea = B(nf, h, w, True)
         self.ws = Workspace(dev)
         self._build_forward()
         self._build_backward()
         self.ws.finalize()
+        self.ws_side.finalize()
 
     # ---- IO -----------------------------------------------------------------------------------------
     def set_input(self, x):
@@ -259,6 +275,14 @@ class _Plan:
                                 in_stride=2, in_oy=py, in_ox=px, in_W=2 * wl))
                 first = False
 
+    def _event(self):
+        ev = _lib.lib().dasr_event_create()
+        if not ev:
+            raise _lib.DasrHipError('hipEventCreate failed')
+        self._events = getattr(self, '_events', [])
+        self._events.append(ev)
+        return ev
+
     def _build_backward(self):
         net, N, h, w = self.net, self.N, self.h, self.w
         nf, nb, P, pack, pk = net.nf, net.nb, net.params, net.pack, net.pk
@@ -307,6 +331,7 @@ class _Plan:
         gs_cur = 0
         ops.add(conv_op(pack, pk['lr_b'], self.g_t0.view(), True, nf, h, w, h, w, N, out_f32=G.view(),
                         out_bf16=self.gslab[gs_cur].view(0), gamma=0.04))
+        done_events = []
         # RRDB chain, reversed
         for i in range(nb - 1, -1, -1):
             Grr = G  # grad wrt the RRDB output
@@ -340,14 +365,29 @@ class _Plan:
                                               n_ctiles=min(2, ceil_div(min(t['cin'] - c0, 64), 32))))
                         grp.add_block(Gs.view(32 * k0), 2 * len(sub), S.view(c0), blk_ch // 16, ceil_div(blk_ch, 32),
                                       h, w, h, w, N, tiles, want_bias=(c0 == 0))
-                grp.finalize(self.ws, net.device, target_wgs=int(os.environ.get('DASR_WG3_TARGET', str(256 // max(1, getattr(net, 'concurrent_replicas', 1))))))
+                side = self.side_stream is not None
+                grp.finalize(self.ws_side if side else self.ws, net.device,
+                             target_wgs=int(os.environ.get('DASR_WG3_TARGET', str(256 // max(1, getattr(net, 'concurrent_replicas', 1))))))
+                if side:   # main: record "g1..g5 of this RDB complete"; side: wait, wgrad + reduce, record "slab free"
+                    e_ready, e_done = self._event(), self._event()
+                    ops.add(_sched(_lib.OP_EVENT_RECORD, e_ready))
+                    ops.add(_sched(_lib.OP_SET_STREAM, self.side_stream.cuda_stream))
+                    ops.add(_sched(_lib.OP_STREAM_WAIT, e_ready))
                 for o in grp.ops(self.grad.data_ptr()):
                     ops.add(o)
                 ops.keep.append(grp)
+                if side:
+                    ops.add(_sched(_lib.OP_EVENT_RECORD, e_done))
+                    ops.add(_sched(_lib.OP_SET_STREAM, None))
+                    done_events.append(e_done)
+                    # the g_x conv below writes g5 of the next RDB into the slab that the wgrad of (n_gslab - 1) RDBs ago read
+                    q = len(done_events) - 1
+                    if q - (self.n_gslab - 1) >= 0:
+                        ops.add(_sched(_lib.OP_STREAM_WAIT, done_events[q - (self.n_gslab - 1)]))
                 # g_x conv with the residual bookkeeping fused
                 Gin = next(b for b in free if b is not Grr and b is not Gout)
                 first = (ridx == 0)
-                nxt = None if first else self.gslab[1 - gs_cur].view(0)
+                nxt = None if first else self.gslab[(gs_cur + 1) % self.n_gslab].view(0)
                 if r == 3:
                     ops.add(conv_op(pack, pk[(i, r, 'b', 0)], Gs.view(0), False, nf + 4 * GC, h, w, h, w, N,
                                     res1=Grr.view(), beta1=0.2, out_f32=Gin.view(), out_bf16=nxt, gamma=0.2))
@@ -358,10 +398,12 @@ class _Plan:
                     ops.add(conv_op(pack, pk[(i, r, 'b', 0)], Gs.view(0), False, nf + 4 * GC, h, w, h, w, N,
                                     res1=Gout.view(), beta1=1.0, res2=Grr.view(), beta2=1.0, out_f32=Gin.view(), out_bf16=nxt, gamma=0.04))
                 Gout = Gin
-                gs_cur = 1 - gs_cur
+                gs_cur = (gs_cur + 1) % self.n_gslab
             G = Gout
             if i > 0 and i % bucket_every == 0:
                 self._marks.append((len(ops.ops), P.off('model.1.sub.%d.RDB1.conv1.0.weight' % i)))
+        if done_events:   # the side stream is in order: its last event covers every weight gradient of the chain
+            ops.add(_sched(_lib.OP_STREAM_WAIT, done_events[-1]))
         # ShortcutBlock: g_fea = g_chain + g_t0
         o = Op()
         o.op = _lib.OP_AXPBY

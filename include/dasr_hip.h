@@ -256,7 +256,9 @@ enum { DASR_OP_CONV = 1, DASR_OP_WGRAD = 2, DASR_OP_WGRAD_REDUCE = 3, DASR_OP_PA
        DASR_OP_INORM_FWD = 11, DASR_OP_INORM_BWD = 12, DASR_OP_BCE = 13, DASR_OP_DWT_FWD = 14, DASR_OP_DWT_BWD = 15,
        DASR_OP_LOWPASS = 16, DASR_OP_MAXPOOL = 17, DASR_OP_MAXPOOL_BWD = 18, DASR_OP_L1DIFF = 19, DASR_OP_AFFINE4 = 20,
        DASR_OP_BILINEAR = 21, DASR_OP_LOGLOSS = 22, DASR_OP_SIGMOID_BWD = 23, DASR_OP_PRELU_GRAD = 24, DASR_OP_LOWPASS_VALID = 25,
-       DASR_OP_ADD_FLAT = 26, DASR_OP_SIGMOID_FWD = 27 };
+       DASR_OP_ADD_FLAT = 26, DASR_OP_SIGMOID_FWD = 27,
+       /* scheduling ops: p[0] = event from dasr_event_create / a hipStream_t (NULL: back to the stream dasr_run_ops was called with) */
+       DASR_OP_EVENT_RECORD = 28, DASR_OP_STREAM_WAIT = 29, DASR_OP_SET_STREAM = 30 };
 
 typedef struct {
     int32_t op;  int32_t i[8];  float f[4];  int64_t l[4];  void* p[4];  dasr_tensor t[5];
@@ -264,6 +266,10 @@ typedef struct {
 } dasr_op;
 
 int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream);
+/* events for the scheduling ops (hipEventDisableTiming); independent work of one list can be moved to a second stream this way
+ * (the dense-block weight gradients are not on the data-gradient chain's critical path) */
+void* dasr_event_create(void);
+int dasr_event_destroy(void* ev);
 int dasr_last_failed_op(void);   /* index of the op that made dasr_run_ops return non-zero */
 
 /* ---- diagnostics ----------------------------------------------------------------------------------*/

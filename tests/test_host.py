@@ -19,7 +19,7 @@ def test_library_builds_and_exports_all_declared_symbols():
     assert os.path.exists(lib)
     L = _lib.lib()
     hdr = open(os.path.join(ROOT, 'include', 'dasr_hip.h')).read()
-    declared = set(re.findall(r'^\s*int\s+(dasr_\w+)\s*\(', hdr, flags=re.M))
+    declared = set(re.findall(r'^\s*(?:int|void\*)\s+(dasr_\w+)\s*\(', hdr, flags=re.M))
     assert declared, 'no declarations parsed'
     for name in declared:
         assert hasattr(L, name), name
