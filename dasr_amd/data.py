@@ -117,3 +117,65 @@ class DeviceUnpairedDataset:
             idx = order[b * self.n:(b + 1) * self.n]
             if idx:
                 yield self.batch(idx)
+
+
+class DevicePairedDataset:
+    """`mode: "LRHR"` with LR files given (codes/SRN/data/LRHR_dataset.py:44-126, train phase): {'LR','HR'} batches assembled on the
+    device.  Per sample the reference draws random.randint twice (crop origin in the LR image) and then util.augment's coins.
+    (On-the-fly LR generation by MATLAB-style imresize and the too-small-image resize stay on the reference's side.)"""
+
+    def __init__(self, ds_opt, scale=4, images=None, device=None, shuffle=None, drop_last=True):
+        ensure_runtime_ready()
+        self.opt, self.scale = ds_opt, scale
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.n, self.hr_size = int(ds_opt['batch_size']), int(ds_opt['HR_size'])
+        self.use_flip, self.use_rot = bool(ds_opt.get('use_flip')), bool(ds_opt.get('use_rot'))
+        self.shuffle = bool(ds_opt.get('use_shuffle')) if shuffle is None else shuffle
+        if images is None:
+            if not ds_opt.get('dataroot_LR'):
+                raise NotImplementedError('LRHR without dataroot_LR: LR images are made by imresize on the host in the reference; provide LR files')
+            images = {'LR': [load_image(p) for p in image_paths(ds_opt['dataroot_LR'])], 'HR': [load_image(p) for p in image_paths(ds_opt['dataroot_HR'])]}
+        self.img = {k: [t.to(self.device, torch.float32).contiguous() for t in v] for k, v in images.items()}
+        assert self.img['HR'], 'Error: HR path is empty.'
+        assert len(self.img['LR']) == len(self.img['HR']), 'HR and LR datasets have different number of images - {}, {}.'.format(
+            len(self.img['LR']), len(self.img['HR']))
+        self.drop_last = drop_last
+
+    def __len__(self):
+        m = len(self.img['HR'])
+        return m // self.n if self.drop_last else (m + self.n - 1) // self.n
+
+    def batch(self, indices):
+        s, HRs = self.scale, self.hr_size
+        LRs = HRs // s
+        L = _lib.lib()
+        descs = {'LR': (_lib.CropDesc * len(indices))(), 'HR': (_lib.CropDesc * len(indices))()}
+        for k, idx in enumerate(indices):
+            lr, hr = self.img['LR'][idx], self.img['HR'][idx]
+            if hr.shape[1] < HRs or hr.shape[2] < HRs:
+                raise NotImplementedError('HR image smaller than HR_size (the reference resizes it and re-derives LR by imresize on the host)')
+            y0, x0 = random.randint(0, max(0, lr.shape[1] - LRs)), random.randint(0, max(0, lr.shape[2] - LRs))
+            hflip = self.use_flip and random.random() < 0.5
+            vflip = self.use_rot and random.random() < 0.5
+            rot90 = self.use_rot and random.random() < 0.5
+            flags = int(hflip) | (int(vflip) << 1) | (int(rot90) << 2)
+            for key, t, yy, xx in (('LR', lr, y0, x0), ('HR', hr, y0 * s, x0 * s)):
+                d = descs[key][k]
+                d.src, d.C, d.H, d.W, d.vH, d.vW = t.data_ptr(), t.shape[0], t.shape[1], t.shape[2], t.shape[1], t.shape[2]
+                d.y0, d.x0, d.flags = yy, xx, flags
+        out = {'_keep': []}
+        for key, size in (('LR', LRs), ('HR', HRs)):
+            dd = torch.frombuffer(bytearray(bytes(descs[key])), dtype=torch.uint8).to(self.device)
+            dst = torch.empty((len(indices), 3, size, size), dtype=torch.float32, device=self.device)
+            _lib.check(L.dasr_gather_crops(dd.data_ptr(), len(indices), 3, size, dst.data_ptr(), _stream()), 'gather_crops')
+            out[key] = dst
+            out['_keep'].append(dd)
+        return out
+
+    def __iter__(self):
+        m = len(self.img['HR'])
+        order = torch.randperm(m).tolist() if self.shuffle else list(range(m))
+        for b in range(len(self)):
+            idx = order[b * self.n:(b + 1) * self.n]
+            if idx:
+                yield self.batch(idx)

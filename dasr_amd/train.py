@@ -82,6 +82,9 @@ def create_dataset(ds_opt, opt):
         # the DASR training set (data/__init__.py:35-36): images resident in HBM, batches assembled by dasr_gather_crops
         from .data import DeviceUnpairedDataset
         return DeviceUnpairedDataset(ds_opt, opt['scale'])
+    if mode == 'LRHR' and ds_opt.get('phase', 'train') == 'train' and ds_opt.get('dataroot_LR'):
+        from .data import DevicePairedDataset
+        return DevicePairedDataset(ds_opt, opt['scale'])
     raise NotImplementedError('Dataset [{:s}] is not recognized (the cv2/lmdb loaders of the reference stay on its side of '
                               'the boundary; feed their batch dicts to the trainer object).'.format(str(mode)))
 

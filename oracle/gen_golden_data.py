@@ -78,6 +78,17 @@ def main():
             out['c%d_seeds' % case] = np.array([s1, s2])
     finally:
         np.load = np_load
+    # paired LRHR dataset (codes/SRN/data/LRHR_dataset.py), LR files given
+    import data.LRHR_dataset as DL
+    DL.util.read_img = dutil.read_img
+    dl = DL.LRHRDataset.__new__(DL.LRHRDataset)
+    dl.opt = {'scale': 4, 'HR_size': 32, 'phase': 'train', 'color': None, 'use_flip': True, 'use_rot': True}
+    dl.LR_env = dl.HR_env = None
+    dl.paths_LR, dl.paths_HR, dl.random_scale_list = ds.paths_fake_LR, ds.paths_HR, [1]
+    random.seed(31)
+    items = [dl[i] for i in (2, 0, 4)]
+    out['p_LR'] = torch.stack([it['LR'] for it in items]).numpy()
+    out['p_HR'] = torch.stack([it['HR'] for it in items]).numpy()
     np.savez_compressed(os.path.join(OUT, 'data_pipeline.npz'), **out)
     print({k: v.shape for k, v in out.items()})
 

@@ -26,6 +26,13 @@ def test_device_batches_equal_reference_dataset(golden_dir):
         for key in ('LR_fake', 'LR_real', 'HR', 'HR_unpair'):
             assert torch.equal(b[key].cpu(), torch.from_numpy(gold['c%d_%s' % (case, key)])), (case, key)   # pure data movement: bit exact
         np.testing.assert_allclose(b['fake_w'].cpu().numpy(), gold['c%d_fake_w' % case], rtol=0, atol=2e-6)   # fp32 bilinear of a float64 map
+    # paired LRHR mode
+    from dasr_amd.data import DevicePairedDataset
+    dp = DevicePairedDataset({'batch_size': 3, 'HR_size': 32, 'use_flip': True, 'use_rot': True, 'use_shuffle': False}, scale=4,
+                             images={'LR': imgs['fake_LR'], 'HR': imgs['HR']})
+    random.seed(31)
+    b = dp.batch([2, 0, 4])
+    assert torch.equal(b['LR'].cpu(), torch.from_numpy(gold['p_LR'])) and torch.equal(b['HR'].cpu(), torch.from_numpy(gold['p_HR']))
     # iterator protocol / shapes / device
     batches = list(DeviceUnpairedDataset({'batch_size': 2, 'HR_size': 32, 'use_flip': False, 'use_rot': False, 'use_shuffle': True}, scale=4, images=imgs))
     assert len(batches) == 2 and batches[0]['HR'].is_cuda and tuple(batches[0]['fake_w'].shape) == (2, 1, 8, 8)
