@@ -3,16 +3,25 @@
 
 Workload at N=1 (BASELINE.json configs[1]): RRDBNet nf=64 nb=23 (ESRGAN), batch 16 of 128x128 LR crops,
 generator-only L1 step (forward + backward + Adam + weight repack), synthetic torch.rand data
-(Generator seed 1234 + rank), kaiming x0.1 weights under torch.manual_seed(0).  With --gpus N the same
-per-GPU batch runs on every rank (weak scaling) with an RCCL all-reduce of the gradients.
+(Generator seed 1234 + rank), kaiming x0.1 weights under torch.manual_seed(0).
 
-Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel (3x3 dense-block conv, Cout=32, bf16 MFMA)
-timed in isolation with HIP events on the launch stream; `cpu_baseline` = the oracle (fp32 PyTorch restatement
-of the reference step) timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+`python bench.py --gpus N` launches N ranks itself (re-exec under torch.distributed.run, one process per GPU, RCCL) when
+it was not already started by a launcher; every rank runs the same per-GPU batch (weak scaling) and the gradients are
+all-reduced over RCCL, overlapped with the backward kernels.  `n_gpus` is the size of the process group, not the flag.
+
+Prints ONE JSON line (rank 0):
+  * `roofline`: per-kernel rows measured live in one extra PRODUCTION step after the timed region: every launch of that step
+    carries its own start/stop events on its launch stream (hipExtLaunchKernel: the dispatch's begin/end timestamps, the very
+    numbers `rocprofv3 --kernel-trace --stats` prints, see profiles/), `achieved` = algorithmic FLOPs per launch / average
+    launch duration; the headline row is the kernel with the largest total time.
+  * `cpu_baseline`: the oracle (fp32 PyTorch restatement of the reference step) on this box's host cores, 1 warm-up + 3 timed
+    steps of the bench workload at batch 1 (and configs[0] exactly), rank 0 at N=1 only.
+  * `secondary`: driver-visible numbers for configs[2] (full GAN step) and configs[4] (DSN iteration) on the same box.
 """
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -29,7 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 TFLOP_PER_IMAGE_TRAIN = 1.762  # 3 x 587.43 GFLOP per 128x128 LR image (nf64/nb23)
-PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak at 2.4 GHz (MI355X_MICROARCH.md)
 
 
 def make_dasr_opt(nf, nb, fs):
@@ -54,58 +63,92 @@ def make_opt(nf, nb):
                       'pixel_criterion': 'l1', 'pixel_weight': 1.0, 'manual_seed': 0}}
 
 
-def roofline_dominant_kernel(model, plans, reps=25):
-    """Time the Cout=32 dense-block conv kernel (conv1..conv4 of one RDB: Cin 64/96/128/160) the way the step runs it:
-    one launch sequence per concurrently processed sub-batch, each on its own stream, bracketed by HIP events on the
-    launching stream.  `achieved` is the rate the chip sustains on this kernel = (concurrent launches x algorithmic
-    FLOPs per launch) / average launch duration; with 2 sub-batch streams two launches are in flight at any time, so
-    `avg_launch_us` is what rocprofv3 reports per launch (profiles/) and achieved = launches_concurrent * flops / it."""
-    from dasr_amd.engine import OpList
+# ---------------------------------------------------------------------------------------------------------------------------
+# roofline: per-kernel durations of one production step
+# ---------------------------------------------------------------------------------------------------------------------------
+_KNAME = {'launch_glds': 'conv_glds_kernel', 'launch': 'conv_kernel', 'launch_wgrad': 'wgrad_kernel', 'launch_wgrad3': 'wgrad3_kernel'}
+
+
+def kernel_name(tag):
+    """launcher tag (__PRETTY_FUNCTION__ of the launch template, or the kernel's own name) -> the kernel name rocprofv3 prints"""
+    m = re.search(r'::(\w+)\(.*\)\s*\[(.*)\]\s*$', tag)
+    if not m:
+        return tag
+    vals = [kv.split('=')[1].strip() for kv in m.group(2).split(',')]
+    return '%s<%s>' % (_KNAME.get(m.group(1), m.group(1)), ', '.join(vals))
+
+
+def profiled_steps(run_step, nsteps=1, capacity=16384):
+    """run `nsteps` production steps inside a profiling session of the library; returns per-launch records + wall time"""
+    import ctypes as C
     from dasr_amd import _lib
-    ols, flops = [], 0.0
-    for plan in plans:
-        convs = [o for o in plan.fwd.ops if o.op == _lib.OP_CONV and o.conv.prec == 1 and o.conv.cout == 32][:4]
-        ol = OpList()
-        for _ in range(reps):       # one executor call per stream: the measurement is GPU-bound, not host-launch-bound
-            for o in convs:
-                ol.add(o)
-        flops += sum(2.0 * o.conv.N * o.conv.Hout * o.conv.Wout * 9 * o.conv.cin * o.conv.cout for o in convs)
-        ols.append(ol)
-    streams = [torch.cuda.current_stream()] if len(plans) == 1 else [torch.cuda.Stream() for _ in plans]
-    cur = torch.cuda.current_stream()
-
-    def run_all():
-        for st, ol in zip(streams, ols):
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                ol.run()
-        for st in streams:
-            cur.wait_stream(st)
-
-    run_all()
+    L = _lib.lib()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    run_all()
-    e1.record()
+    _lib.check(L.dasr_prof_begin(capacity), 'prof_begin')
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        run_step()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps           # one pass of the 4 convs on every stream
-    achieved = flops / (ms * 1e-3) / 1e12
-    k = len(plans)
-    traffic = None
-    try:  # HBM bytes per launch from the committed PMC pass (bench.py cannot collect counters itself), scaled to this launch shape
-        pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_dominant_kernel.json')))
-        per_img = (pm['fetch_size_kb_raw'] * pm['fetch_correction_gfx950'] + pm['write_size_kb']) * 1024.0 / pm['images_per_launch']
-        traffic = round(per_img * plans[0].N)
+    wall = time.perf_counter() - t0
+    us, fl, by = (C.c_float * capacity)(), (C.c_double * capacity)(), (C.c_double * capacity)()
+    op, tg = (C.c_int32 * capacity)(), (C.c_char_p * capacity)()
+    n = L.dasr_prof_end(capacity, us, fl, by, op, tg)
+    if n < 0:
+        raise RuntimeError('dasr_prof_end: %d' % n)
+    recs = [(tg[i].decode(), us[i], fl[i]) for i in range(n)]
+    return recs, wall, n >= capacity
+
+
+def roofline_from_step(run_step, peak_measured, streams, nsteps=1):
+    recs, wall, truncated = profiled_steps(run_step, nsteps)
+    rows = {}
+    for tag, us, fl in recs:
+        r = rows.setdefault(tag, {'launches': 0, 'total_us': 0.0, 'flops': 0.0})
+        r['launches'] += 1
+        r['total_us'] += us
+        r['flops'] += fl
+    ksum = sum(r['total_us'] for r in rows.values())
+    out = []
+    for tag, r in sorted(rows.items(), key=lambda kv: -kv[1]['total_us']):
+        if r['flops'] <= 0:
+            continue
+        avg = r['total_us'] / r['launches']
+        fpl = r['flops'] / r['launches']
+        ach = fpl / avg / 1e6  # TFLOP/s
+        out.append({'kernel': kernel_name(tag), 'launches_per_step': r['launches'] // nsteps, 'avg_launch_us': round(avg, 2),
+                    'flops_per_launch': fpl, 'achieved': round(ach, 1), 'frac': round(ach / PEAK_BF16_TFLOPS, 4),
+                    'share_of_kernel_time': round(r['total_us'] / ksum, 4)})
+    other = sum(r['total_us'] for r in rows.values() if r['flops'] <= 0)
+    head = dict(out[0]) if out else {}
+    overlap = ksum / (wall * 1e6) if wall > 0 else None
+    traffic, tsrc = None, None
+    try:  # HBM bytes per launch of the headline kernel: from the committed PMC passes (rocprofv3 --pmc cannot run inside bench.py)
+        pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+        ent = pm['kernels'].get(head.get('kernel'))
+        if ent:
+            traffic = int((ent['fetch_size_kb_raw'] * pm['fetch_correction_gfx950'] + ent['write_size_kb']) * 1024.0)
+            tsrc = pm['source']
     except Exception:
         pass
-    return {'bound': 'mfma', 'achieved': round(achieved, 1), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(achieved / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
-            'kernel': 'conv_glds_kernel<1,67> (dense-block conv1-4 forward, Cout=32, bf16 MFMA, LDS-DMA staging; <1,68> is its data-gradient twin)',
-            'launches_concurrent': k, 'avg_launch_us': round(ms * 1e3 / 4, 1), 'flops_per_launch': flops / (4 * k),
-            'note': 'achieved = launches_concurrent * flops_per_launch / avg_launch_us (sub-batch streams overlap launches)'}
+    roof = {'bound': 'mfma', 'achieved': head.get('achieved'), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': head.get('frac'),
+            'traffic': traffic, 'traffic_source': tsrc, 'kernel': head.get('kernel'), 'avg_launch_us': head.get('avg_launch_us'),
+            'flops_per_launch': head.get('flops_per_launch'),
+            'peak_at_observed_clock': round(peak_measured, 1) if peak_measured else None,
+            'frac_of_peak_at_observed_clock': round(head['achieved'] / peak_measured, 4) if (peak_measured and head) else None,
+            'streams': streams, 'kernel_time_over_wall': round(overlap, 3) if overlap else None,
+            'non_mfma_kernel_time_share': round(other / ksum, 4) if ksum else None,
+            'method': 'one extra production step after the timed region; every launch has its own start/stop events on its launch stream '
+                      '(hipExtLaunchKernel = the dispatch timestamps rocprofv3 --kernel-trace reports); achieved = algorithmic FLOPs per launch / '
+                      'average launch duration; headline = kernel with the largest total time; with streams > 1 launches of the sub-batch '
+                      'streams overlap (kernel_time_over_wall = sum of launch durations / step wall time), so the chip-level rate of a kernel '
+                      'is up to that factor above its per-launch rate',
+            'per_kernel': out[:8], 'truncated': truncated}
+    return roof
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle = port of the reference step) in a bounded subprocess
+# ---------------------------------------------------------------------------------------------------------------------------
 def _usable_cores():
     """host cores this process may really use: affinity mask, capped by the cgroup CPU quota if there is one"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -119,43 +162,60 @@ def _usable_cores():
 
 
 def _cpu_baseline_worker(nf, nb, lr_size, threads):
+    """SURVEY 8(d) protocol: 1 warm-up + 3 timed steps; the bench workload at batch 1, then configs[0] exactly (nf32 nb4, batch 2, 64x64)"""
     from oracle import trainers
     torch.set_num_threads(threads)
-    opt = make_opt(nf, nb)
-    torch.manual_seed(0)
-    t = trainers.SRTrainer(opt)
-    g = torch.Generator().manual_seed(1234)
-    small = {'LR': torch.rand(1, 3, 32, 32, generator=g), 'HR': torch.rand(1, 3, 128, 128, generator=g)}
-    data = {'LR': torch.rand(1, 3, lr_size, lr_size, generator=g), 'HR': torch.rand(1, 3, 4 * lr_size, 4 * lr_size, generator=g)}
-    t.feed_data(small)
-    t.optimize_parameters(1)  # warm-up (thread pools, allocator) on a small crop
-    t.feed_data(data)
-    t0 = time.time()
-    t.optimize_parameters(2)
-    print(json.dumps({'dt': time.time() - t0}))
+    res = {}
+    for name, (nf_, nb_, b, s) in (('bench', (nf, nb, 1, lr_size)), ('cfg0', (32, 4, 2, 64))):
+        torch.manual_seed(0)
+        t = trainers.SRTrainer(make_opt(nf_, nb_))
+        g = torch.Generator().manual_seed(1234)
+        data = {'LR': torch.rand(b, 3, s, s, generator=g), 'HR': torch.rand(b, 3, 4 * s, 4 * s, generator=g)}
+        times = []
+        for i in range(4):
+            t.feed_data(data)
+            t0 = time.time()
+            t.optimize_parameters(i + 1)
+            times.append(time.time() - t0)
+        res[name] = {'batch': b, 'lr': s, 'warmup_s': times[0], 'timed_s': times[1:]}
+        print(json.dumps(res))
+        sys.stdout.flush()
 
 
-def cpu_baseline(nf, nb, lr_size, timeout=150):
-    """oracle (port of the reference step) on the host cores, bounded sample: batch 1, small warm-up + 1 timed step.
-    Runs in a subprocess with a timeout so a slow/oversubscribed host cannot stall the GPU benchmark."""
+def cpu_baseline(nf, nb, lr_size, timeout=240):
     import subprocess
     threads = min(int(os.environ.get('DASR_CPU_THREADS', '64')), _usable_cores())
     code = 'import sys; sys.path.insert(0, %r); import bench; bench._cpu_baseline_worker(%d, %d, %d, %d)' % (ROOT, nf, nb, lr_size, threads)
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
     try:
         out = subprocess.run([sys.executable, '-c', code], capture_output=True, timeout=timeout, env=env, text=True)
-        dt = json.loads(out.stdout.strip().splitlines()[-1])['dt']
-    except Exception as e:  # timeout or failure: report, do not fail the GPU measurement
+    except subprocess.TimeoutExpired as e:
+        out = e
+    try:
+        res = json.loads((out.stdout or '').strip().splitlines()[-1])
+        r = res['bench']
+    except Exception as e:  # timeout before the first result or failure: report, do not fail the GPU measurement
         return {'value': None, 'unit': 'images/s', 'cores': threads, 'kind': 'port', 'sample': 'cpu baseline did not finish: %r' % (e,)}
-    return {'value': round(1.0 / dt, 4), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
-            'sample': 'oracle SRTrainer nf%d nb%d, batch 1 x %dx%d LR, small warm-up + 1 timed step (%.1f s), fp32 torch CPU, %d threads'
-                      % (nf, nb, lr_size, lr_size, dt, threads)}
+    mean = sum(r['timed_s']) / len(r['timed_s'])
+    d = {'value': round(r['batch'] / mean, 4), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
+         'sample': 'oracle SRTrainer nf%d nb%d, batch 1 x %dx%d LR (linear in the batch: the bench batch is this step repeated), 1 warm-up + %d timed '
+                   'steps (%s s), fp32 torch CPU, %d threads' % (nf, nb, lr_size, lr_size, len(r['timed_s']),
+                                                                 ' '.join('%.2f' % x for x in r['timed_s']), threads),
+         'step_s': [round(x, 3) for x in r['timed_s']]}
+    if 'cfg0' in res:
+        c = res['cfg0']
+        m0 = sum(c['timed_s']) / len(c['timed_s'])
+        d['configs0'] = {'value': round(c['batch'] / m0, 3), 'unit': 'images/s',
+                         'sample': 'configs[0] exactly: nf32 nb4, batch 2 x 64x64 LR, 1 warm-up + 3 timed steps (%s s)' % ' '.join('%.2f' % x for x in c['timed_s'])}
+    return d
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
 def sweep(model, data, a):
-    """interleaved A/B of the kernel variants: isolated dense-conv microbench + whole-step time"""
+    """interleaved A/B of kernel variants on the whole step (dasr_set_tuning keys, see include/dasr_hip.h)"""
     from dasr_amd import _lib
-    from dasr_amd.engine import OpList
     L = _lib.lib()
     step = [0]
 
@@ -168,96 +228,63 @@ def sweep(model, data, a):
         torch.cuda.synchronize()
 
     run_steps(2)
-    plan = (getattr(model, '_out_plans', None) or [model.netG.plan(a.batch, a.lr_size, a.lr_size)])[0]
-
-    def time_ops(ops, reps=10):
-        ol = OpList()
-        for o in ops:
-            ol.add(o)
-        ol.run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            ol.run()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
-
-    c32 = [o for o in plan.fwd.ops if o.op == _lib.OP_CONV and o.conv.prec == 1 and o.conv.cout == 32][:4]
-    c64 = [o for o in plan.fwd.ops if o.op == _lib.OP_CONV and o.conv.prec == 1 and o.conv.cout == 64][:1]
-    cst = [o for o in plan.fwd.ops if o.op == _lib.OP_CONV and o.conv.prec == 3 and o.conv.Hout == 4 * a.lr_size and o.conv.cout == 64][:1]
-    wg = [o for o in plan.bwd.ops if o.op in (_lib.OP_WGRAD, _lib.OP_WGRAD_REDUCE)]
-    wg_rdb = wg[-4:-2]  # an RDB group (wgrad + reduce) near the end of the backward list
-    fl = lambda ops: sum(2.0 * o.conv.N * o.conv.Hout * o.conv.Wout * 9 * o.conv.cin * o.conv.cout for o in ops)
-    res = {}
-    for rnd in range(2):
-        for v in (0, 12):
-            L.dasr_set_tuning(1, v)
-            ms = time_ops(c32)
-            res.setdefault(('rdb32', v), []).append(fl(c32) / ms / 1e9)
-        L.dasr_set_tuning(1, 12)
-        L.dasr_set_tuning(4, 1)
-        for v in (0, 12):
-            L.dasr_set_tuning(2, v)
-            ms = time_ops(c64)
-            res.setdefault(('rdb64', v), []).append(fl(c64) / ms / 1e9)
-        L.dasr_set_tuning(2, 12)
-        L.dasr_set_tuning(4, 1)
-        for v in (0, 4):
-            L.dasr_set_tuning(3, v)
-            ms = time_ops(cst)
-            res.setdefault(('stream', v), []).append(fl(cst) / ms / 1e9)
-        L.dasr_set_tuning(3, 0)
-        ms = time_ops(wg_rdb[:1])
-        res.setdefault(('wgrad_rdb', 0), []).append(2.0 * plan.N * a.lr_size * a.lr_size * 239616 / ms / 1e9)
-        ms = time_ops(wg_rdb[1:])
-        res.setdefault(('wgrad_reduce_us', 0), []).append(ms * 1e3)
-    if os.environ.get('DASR_HIP_LIB'):  # instrumented build: phase stamps of one RDB wgrad launch
-        import ctypes
-        import numpy as np
-        grid = wg_rdb[0].i[0] * wg_rdb[0].i[1]
-        buf = torch.zeros(grid * 16 + 64, dtype=torch.int64, device='cuda')
-        L.dasr_debug_set_wtrace.argtypes = [ctypes.c_void_p]
-        L.dasr_debug_set_wtrace(buf.data_ptr())
-        time_ops(wg_rdb[:1], reps=1)
-        L.dasr_debug_set_wtrace(None)
-        t = buf[:grid * 16].view(grid, 16).cpu().numpy().astype(np.float64)
-        t = t[t[:, 0] > 0]
-        wall = (t[:, 14] - t[:, 15]) * 10.0
-        log('wgrad3 trace: %d workgroups (parts %d x splits %d); wall p50 %.0f ns, span %.0f ns, clock %.2f GHz' % (
-            len(t), wg_rdb[0].i[0], wg_rdb[0].i[1], np.percentile(wall, 50), (t[:, 14].max() - t[:, 15].min()) * 10.0, np.median((t[:, 9] - t[:, 0]) / wall)))
-        for i, nm in enumerate(['entry->first prefetch issued', 'first prefetch -> tile 2 top (2 tiles)', 'tile2: barrier 1', 'tile2: commit (ds_write)', 'tile2: barrier 2',
-                                'tile2: prefetch issue', 'tile2: compute 72 MFMA', 'tiles 3.. (rest of loop)', 'result store']):
-            d = t[:, i + 1] - t[:, i]
-            log('  %-40s cycles p10 %8.0f p50 %8.0f p90 %8.0f' % (nm, np.percentile(d, 10), np.percentile(d, 50), np.percentile(d, 90)))
-    for k, v in res.items():
-        log('sweep %-16s variant %d : %s (TFLOP/s algorithmic; stream = 1/3 of MFMA rate)' % (k[0], k[1], ' '.join('%.0f' % x for x in v)))
-    for wm in (1, 5, 1, 5):  # wgrad3 staging requests: staggered inside the MFMA stream (1) vs all up front (5 = bit 2 set)
-        L.dasr_wgrad_set_mode(wm)
-        run_steps(1)
-        t0 = time.perf_counter()
-        run_steps(3)
-        log('sweep step time, wgrad mode %d: %.2f ms/step' % (wm, (time.perf_counter() - t0) / 3 * 1e3))
-    L.dasr_wgrad_set_mode(1)
-    for combo in ((12, 12, 0, 1), (13, 13, 0, 1), (0, 0, 0, 1), (12, 12, 0, 1), (13, 13, 0, 1), (0, 0, 0, 1)):
-        for k, v in zip((1, 2, 3, 4), combo):
-            L.dasr_set_tuning(k, v)
-        run_steps(1)
-        t0 = time.perf_counter()
-        run_steps(3)
-        log('sweep step time, tuning %s: %.2f ms/step' % (combo, (time.perf_counter() - t0) / 3 * 1e3))
+    combos = [[tuple(int(x) for x in kv.split('=')) for kv in c.split(';') if kv] for c in (a.sweep_combos or '6=0,6=1').split(',')]
+    for rnd in range(a.sweep_rounds):
+        for combo in combos:
+            for k, v in combo:
+                _lib.check(L.dasr_set_tuning(k, v), 'set_tuning %d' % k)
+            run_steps(1)
+            t0 = time.perf_counter()
+            run_steps(3)
+            log('sweep step time, tuning %s: %.2f ms/step' % (combo, (time.perf_counter() - t0) / 3 * 1e3))
 
 
-def bench_dsn(a):
-    """second hot path (SURVEY.md 8(a) a19-a22): one DSN iteration = G fwd, D fwd on [fake; real], losses, D wgrad, G bwd, 2x Adam"""
-    from dasr_amd.dist import DataParallelGroup
-    from dasr_amd.dsn_model import DSNModel
+def setup_dist(a):
+    """one process per GPU.  Started by a launcher (WORLD_SIZE set): join its group.  Started directly with --gpus N > 1: re-exec
+    under torch.distributed.run so that `python bench.py --gpus N` really measures N GPUs."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        import socket
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log('launching %d ranks: %s' % (a.gpus, ' '.join(cmd)))
+        os.execv(sys.executable, cmd)
+    if world != a.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (a.gpus, world))
+    from dasr_amd.dist import DataParallelGroup
     dp = DataParallelGroup() if world > 1 else None
-    rank = dp.rank if dp else 0
     if dp:
         torch.cuda.set_device(dp.local_rank)
+        import torch.distributed as dist
+        assert dist.get_world_size() == a.gpus
+    return dp
+
+
+def timed_loop(step_fn, a, dp):
+    for _ in range(a.warmup):
+        step_fn()
+    torch.cuda.synchronize()
+    if dp:
+        dp.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step_fn()
+    torch.cuda.synchronize()
+    if dp:
+        dp.barrier()
+    dt = time.perf_counter() - t0
+    return dp.max_over_ranks(dt) if dp else dt
+
+
+def bench_dsn(a, dp, as_secondary=False):
+    """second hot path (SURVEY.md 8(a) a19-a22): one DSN iteration = G fwd, D fwd on [fake; real], losses, D wgrad, G bwd, 2x Adam"""
+    from dasr_amd.dsn_model import DSNModel
+    world = dp.world if dp else 1
+    rank = dp.rank if dp else 0
     torch.manual_seed(0)
     m = DSNModel(dict(filter=a.fs, w_per=0.01, per_type='VGG'))
     if dp:
@@ -265,37 +292,94 @@ def bench_dsn(a):
         for net in m.networks():
             dp.broadcast_params(net.params.flat)
             net.repack()
-    b = a.batch if a.batch != 16 else 8
-    c = 4 * a.lr_size if a.lr_size != 128 else 256
+    b = 8 if (as_secondary or a.batch == 16) else a.batch
+    c = 256 if (as_secondary or a.lr_size == 128) else 4 * a.lr_size
     g = torch.Generator().manual_seed(1234 + rank)
     hr, bic, real = (torch.rand(b, 3, c, c, generator=g).cuda(), torch.rand(b, 3, c // 4, c // 4, generator=g).cuda(),
                      torch.rand(b, 3, c // 4, c // 4, generator=g).cuda())
-    for _ in range(a.warmup):
-        m.iteration(hr, bic, real)
-    torch.cuda.synchronize()
-    if dp:
-        dp.barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        m.iteration(hr, bic, real)
-    torch.cuda.synchronize()
-    if dp:
-        dp.barrier()
-    dt = time.perf_counter() - t0
-    if dp:
-        dt = dp.max_over_ranks(dt)
-    if rank != 0:
-        return
+    dt = timed_loop(lambda: m.iteration(hr, bic, real), a, dp)
     # De_resnet: 39.5 GMAC fwd per 256 crop, x3 for fwd+dgrad+wgrad
     tf = 3 * 2 * 39.5e-3 * (c / 256.0) ** 2
     ips = b * world * a.steps / dt
-    print(json.dumps({'metric': 'DSN train crops/sec (De_resnet + FSD, %dx%d HR crops)' % (c, c), 'value': round(ips, 2), 'unit': 'images/s',
-                      'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2), 'higher_is_better': True,
-                      'scaling': 'weak', 'vs_baseline': None, 'dtype': 'split-bf16 MFMA operands (~fp32), fp32 accumulate',
-                      'data': 'synthetic (torch.rand, seed 1234+rank; default nn init, seed 0; VGG16 seeded random)',
-                      'config': {'workload': 'configs[4]: DSN iteration, De_resnet(8 blocks) + FSD discriminator (%s filter) + colour/texture/VGG16 losses, '
-                                             'batch %d of %dx%d crops per GPU' % (a.fs, b, c, c), 'global_batch': b * world, 'parallelism': 'dp%d' % world},
-                      'generator_tflops': round(ips * tf, 1), 'log': m.get_current_log()}))
+    out = {'metric': 'DSN train crops/sec (De_resnet + FSD, %dx%d HR crops)' % (c, c), 'value': round(ips, 2), 'unit': 'images/s',
+           'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2), 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': m.dtype_note if hasattr(m, 'dtype_note') else 'split-bf16 MFMA operands (~fp32), fp32 accumulate',
+           'data': 'synthetic (torch.rand, seed 1234+rank; default nn init, seed 0; VGG16 seeded random)',
+           'config': {'workload': 'configs[4]: DSN iteration, De_resnet(8 blocks) + FSD discriminator (%s filter) + colour/texture/VGG16 losses, '
+                                  'batch %d of %dx%d crops per GPU' % (a.fs, b, c, c), 'global_batch': b * world, 'parallelism': 'dp%d' % world},
+           'generator_tflops': round(ips * tf, 1)}
+    if not as_secondary:
+        out['log'] = m.get_current_log()
+    return out
+
+
+def bench_srn(a, dp, dasr, as_secondary=False):
+    from dasr_amd import options, _lib
+    from dasr_amd.models import create_model
+    world = dp.world if dp else 1
+    rank = dp.rank if dp else 0
+    torch.manual_seed(0)
+    batch = (32 if dasr else 16) if as_secondary else a.batch
+    model = create_model(options.dict_to_nonedict(make_dasr_opt(a.nf, a.nb, a.fs) if dasr else make_opt(a.nf, a.nb)))
+    if dp:
+        model.dp = dp
+        for net in model.networks():
+            dp.broadcast_params(net.params.flat)
+            net.repack()
+    g = torch.Generator().manual_seed(1234 + rank)
+    s = a.lr_size
+    if dasr:
+        n = batch // 2
+        data = {'LR_fake': torch.rand(n, 3, s, s, generator=g).cuda(), 'LR_real': torch.rand(n, 3, s, s, generator=g).cuda(),
+                'HR': torch.rand(n, 3, 4 * s, 4 * s, generator=g).cuda(), 'HR_unpair': torch.rand(n, 3, 4 * s, 4 * s, generator=g).cuda(),
+                'fake_w': torch.rand(n, 1, s, s, generator=g).cuda()}
+    else:
+        data = {'LR': torch.rand(batch, 3, s, s, generator=g).cuda(), 'HR': torch.rand(batch, 3, 4 * s, 4 * s, generator=g).cuda()}
+    log('model built (%s)' % ('dasr' if dasr else 'sr'))
+    if a.sweep:
+        sweep(model, data, a)
+        return None
+    step = [0]
+
+    def one_step():
+        step[0] += 1
+        model.update_learning_rate()
+        model.feed_data(data)
+        model.optimize_parameters(step[0])
+
+    dt = timed_loop(one_step, a, dp)
+    logd = model.get_current_log()
+    loss = logd.get('l_pix', logd.get('loss/l_g_pix'))
+    log('timed steps done: %.2f ms/step' % (dt / a.steps * 1e3))
+    ips = batch * world * a.steps / dt
+    full = (a.nf == 64 and a.nb == 23 and s == 128)
+    out = {'metric': 'SR train images/sec (4x, 128->512)', 'value': round(ips, 3), 'unit': 'images/s', 'n_gpus': world,
+           'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2), 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16 MFMA operands, fp32 accumulate / fp32 residual stream',
+           'data': 'synthetic (torch.rand, seed 1234+rank; kaiming x0.1 weights, seed 0)',
+           'config': {'workload': ('configs[2]: full SRN GAN step (RRDBNet nf=%d nb=%d + NLayer patch-D + VGG19-54 perceptual, fs=%s), %d G crops of '
+                                   '%dx%d LR per GPU (n=%d source + %d target)' % (a.nf, a.nb, a.fs, batch, s, s, batch // 2, batch // 2))
+                      if dasr else
+                      'configs[1]: RRDBNet nf=%d nb=%d 4x SR, batch %d of %dx%d LR per GPU, generator-only L1 step '
+                      '(fwd+bwd+Adam)' % (a.nf, a.nb, batch, s, s),
+                      'global_batch': batch * world, 'parallelism': 'dp%d' % world},
+           'final_loss': loss}
+    if dasr:
+        out['metric'] = 'SRN GAN train G-images/sec (4x, 128->512)'
+    if full and not dasr:
+        out['mfma_util_step'] = round(ips * TFLOP_PER_IMAGE_TRAIN / world / PEAK_BF16_TFLOPS, 4)
+    if rank == 0 and not as_secondary:
+        import ctypes as C
+        pk = C.c_float(0.0)
+        peak_measured = pk.value if _lib.lib().dasr_probe_mfma_peak(20000, C.byref(pk), None) == 0 else None
+        streams = len(getattr(model, '_out_plans', None) or [0])
+        out['roofline'] = roofline_from_step(one_step, peak_measured, streams)
+        log('roofline done')
+    elif not as_secondary:
+        one_step()  # the other ranks take part in the profiled step's collectives
+    del model
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -308,96 +392,46 @@ def main():
     ap.add_argument('--nf', type=int, default=64)
     ap.add_argument('--nb', type=int, default=23)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the configs[2] / configs[4] secondary measurements')
     ap.add_argument('--tune', type=str, default='', help='kernel variant knobs, e.g. 1=1,2=0 (dasr_set_tuning key=value)')
-    ap.add_argument('--sweep', action='store_true', help='A/B the conv kernel variants (stderr table), then exit')
+    ap.add_argument('--sweep', action='store_true', help='A/B kernel variants on the whole step (stderr table), then exit')
+    ap.add_argument('--sweep-combos', type=str, default='', help="tuning combos, e.g. '6=0,6=1;1=13' (dasr_set_tuning key=value; ';' joins, ',' separates combos)")
+    ap.add_argument('--sweep-rounds', type=int, default=3)
     ap.add_argument('--model', type=str, default='sr', choices=['sr', 'dasr', 'dsn'],
                     help="sr: configs[1] generator-only step (the headline line); dasr: configs[2] full GAN step (batch = G crops per GPU); "
                          "dsn: configs[4] DSN iteration (De_resnet + FSD discriminator, --batch HR crops of 4*lr-size per GPU)")
     ap.add_argument('--fs', type=str, default='wavelet', choices=['wavelet', 'gau', 'avg_pool'])
     a = ap.parse_args()
-    if a.model == 'dsn':
-        return bench_dsn(a)
-
-    from dasr_amd import options
-    from dasr_amd.dist import DataParallelGroup
-    from dasr_amd.models import create_model
+    dp = setup_dist(a)
+    rank = dp.rank if dp else 0
 
     from dasr_amd import _lib
     for kv in [x for x in a.tune.split(',') if x]:
         k, v = kv.split('=')
         _lib.check(_lib.lib().dasr_set_tuning(int(k), int(v)), 'set_tuning')
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    dp = DataParallelGroup() if world > 1 else None
-    rank = dp.rank if dp else 0
-    if dp:
-        torch.cuda.set_device(dp.local_rank)
-    torch.manual_seed(0)
-    dasr = a.model == 'dasr'
-    model = create_model(options.dict_to_nonedict(make_dasr_opt(a.nf, a.nb, a.fs) if dasr else make_opt(a.nf, a.nb)))
-    if dp:
-        model.dp = dp
-        for net in model.networks():
-            dp.broadcast_params(net.params.flat)
-            net.repack()
-    g = torch.Generator().manual_seed(1234 + rank)
-    if dasr:
-        n, s = a.batch // 2, a.lr_size
-        data = {'LR_fake': torch.rand(n, 3, s, s, generator=g).cuda(), 'LR_real': torch.rand(n, 3, s, s, generator=g).cuda(),
-                'HR': torch.rand(n, 3, 4 * s, 4 * s, generator=g).cuda(), 'HR_unpair': torch.rand(n, 3, 4 * s, 4 * s, generator=g).cuda(),
-                'fake_w': torch.rand(n, 1, s, s, generator=g).cuda()}
+
+    if a.model == 'dsn':
+        out = bench_dsn(a, dp)
     else:
-        data = {'LR': torch.rand(a.batch, 3, a.lr_size, a.lr_size, generator=g).cuda(),
-                'HR': torch.rand(a.batch, 3, 4 * a.lr_size, 4 * a.lr_size, generator=g).cuda()}
-    log('model built')
-    if a.sweep:
-        return sweep(model, data, a)
-    step = 0
-    for _ in range(a.warmup):
-        step += 1
-        model.update_learning_rate()
-        model.feed_data(data)
-        model.optimize_parameters(step)
-    torch.cuda.synchronize()
-    log('warm-up done')
-    if dp:
-        dp.barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step += 1
-        model.update_learning_rate()
-        model.feed_data(data)
-        model.optimize_parameters(step)
-    torch.cuda.synchronize()
-    if dp:
-        dp.barrier()
-    dt = time.perf_counter() - t0
-    if dp:
-        dt = dp.max_over_ranks(dt)
-    logd = model.get_current_log()
-    loss = logd.get('l_pix', logd.get('loss/l_g_pix'))
-    log('timed steps done: %.1f ms/step' % (dt / a.steps * 1e3))
+        out = bench_srn(a, dp, a.model == 'dasr')
+    if out is None:
+        return
+    default_workload = a.model == 'sr' and a.nf == 64 and a.nb == 23 and a.lr_size == 128 and a.batch == 16
+    if default_workload and not a.no_secondary:
+        # driver-visible numbers for the other GPU configs of BASELINE.json, measured in the same process (fewer steps)
+        sec = argparse.Namespace(**vars(a))
+        sec.steps, sec.warmup = max(2, a.steps // 2), 1
+        out['secondary'] = []
+        for fn in (lambda: bench_srn(sec, dp, True, as_secondary=True), lambda: bench_dsn(sec, dp, as_secondary=True)):
+            try:
+                r = fn()
+                out['secondary'].append({k: r[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'dtype', 'config')})
+            except Exception as e:  # a secondary measurement must not take the headline line down
+                out['secondary'].append({'error': repr(e)})
+        log('secondary done')
     if rank != 0:
         return
-    n_gpus = world
-    ips = a.batch * n_gpus * a.steps / dt
-    full = (a.nf == 64 and a.nb == 23 and a.lr_size == 128)
-    out = {'metric': 'SR train images/sec (4x, 128->512)', 'value': round(ips, 3), 'unit': 'images/s', 'n_gpus': n_gpus,
-           'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2), 'higher_is_better': True,
-           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16 MFMA operands, fp32 accumulate / fp32 residual stream',
-           'data': 'synthetic (torch.rand, seed 1234+rank; kaiming x0.1 weights, seed 0)',
-           'config': {'workload': ('configs[2]: full SRN GAN step (RRDBNet nf=%d nb=%d + NLayer patch-D + VGG19-54 perceptual, fs=%s), %d G crops of '
-                                   '%dx%d LR per GPU (n=%d source + %d target)' % (a.nf, a.nb, a.fs, a.batch, a.lr_size, a.lr_size, a.batch // 2, a.batch // 2))
-                      if dasr else
-                      'configs[1]: RRDBNet nf=%d nb=%d 4x SR, batch %d of %dx%d LR per GPU, generator-only L1 step '
-                      '(fwd+bwd+Adam)' % (a.nf, a.nb, a.batch, a.lr_size, a.lr_size),
-                      'global_batch': a.batch * n_gpus, 'parallelism': 'dp%d' % n_gpus},
-           'final_loss': loss}
-    if full and not dasr:
-        out['mfma_util_step'] = round(ips * TFLOP_PER_IMAGE_TRAIN / PEAK_BF16_TFLOPS, 4)
-    plans = getattr(model, '_out_plans', None) or [model.netG.plan(a.batch, a.lr_size, a.lr_size)]
-    out['roofline'] = roofline_dominant_kernel(model, plans)
-    log('roofline done')
-    if n_gpus == 1 and not a.no_cpu_baseline and not dasr:
+    if out['n_gpus'] == 1 and not a.no_cpu_baseline and a.model == 'sr':
         out['cpu_baseline'] = cpu_baseline(a.nf, a.nb, a.lr_size)
     print(json.dumps(out))
 

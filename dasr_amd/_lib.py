@@ -57,7 +57,7 @@ class CropDesc(C.Structure):
 
 class Op(C.Structure):
     _fields_ = [('op', c_i32), ('i', c_i32 * 8), ('f', c_f32 * 4), ('l', c_i64 * 4), ('p', c_vp * 4), ('t', Tensor * 5),
-                ('conv', ConvParams)]
+                ('conv', ConvParams), ('flops', C.c_double), ('bytes', C.c_double)]
 
 
 OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_DOWNSUM, OP_AXPBY, OP_FILL, OP_L1LOSS, OP_NCHW2B, OP_B2NCHW = range(1, 11)
@@ -104,9 +104,12 @@ _SIGS = {
     'dasr_last_failed_op': [],
     'dasr_abi_version': [],
     'dasr_probe_tr16': [c_vp],
+    'dasr_probe_mfma_peak': [c_i32, c_vp, c_vp],
+    'dasr_prof_begin': [c_i32],
+    'dasr_prof_end': [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 

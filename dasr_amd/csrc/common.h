@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels (CDNA4, wave64).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "../../include/dasr_hip.h"
 
@@ -38,3 +39,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+
+// Every kernel launch of the library goes through DASR_LAUNCH.  While a profiling session is open (dasr_prof_begin, used by
+// bench.py for the `roofline` block) the launch carries its own start/stop events (hipExtLaunchKernelGGL: the dispatch's own
+// begin/end timestamps, the same ones rocprofv3 --kernel-trace reports); otherwise it is a plain launch.
+bool dasr_prof_slot(const char* tag, hipEvent_t* e0, hipEvent_t* e1);  // misc.hip
+#define DASR_LAUNCH_TAG(tag, kfn, grid, block, lds, s, ...)                                         \
+    do {                                                                                            \
+        hipEvent_t _e0 = nullptr, _e1 = nullptr;                                                    \
+        if (dasr_prof_slot(tag, &_e0, &_e1)) hipExtLaunchKernelGGL(kfn, grid, block, lds, s, _e0, _e1, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kfn, grid, block, lds, s, __VA_ARGS__);                             \
+    } while (0)
+#define DASR_LAUNCH(kfn, ...) DASR_LAUNCH_TAG(#kfn, kfn, __VA_ARGS__)

@@ -708,6 +708,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
     const int oy0 = ty * C::TH, ox0 = tx * C::TW;
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
     const int nchunks = p.cin >> 4;
+    // chunk-order rotation: the workgroups that run side by side on one XCD (consecutive blockIdx >> 3) start at different 16-channel
+    // chunks, so at any moment they pull DIFFERENT weight blocks / activation planes through the L2 instead of all hammering the same
+    // 9 KB of weights (same few L2 channels) at the same time.  fp32 accumulation order changes per workgroup, deterministically.
+    const int rot = (p.xcd_remap & 4) ? (int)((blockIdx.x >> 3) % (unsigned)nchunks) : 0;
     float bias_reg = 0.f;
     {
         const int oc = mg * MT * 32 + tid;
@@ -731,7 +735,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
     constexpr int NP = C::AR + C::WR;
     // chunk 0 is requested before the fragment addresses and accumulators are set up: the DMA round trip overlaps that ALU work
 #pragma unroll
-    for (int i = 0; i < NP; ++i) glds_dma_piece<MT, NW>(i, 0, smem, rin, rw, goff, in_chunk_bytes, wave, tid);
+    for (int i = 0; i < NP; ++i) glds_dma_piece<MT, NW>(i, rot, smem, rin, rw, goff, in_chunk_bytes, wave, tid);
     TRACE_STAMP(1);
     // ---- fragment read addresses: row rr (0..5) of this wave's 6 input rows, column shift kx; lane (nn, kh2)
     const int nn = lane & 31, kh2 = lane >> 5;
@@ -762,6 +766,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
         const char* buf = smem + (ck & 1) * C::BUF_BYTES;
         char* nbuf = smem + ((ck + 1) & 1) * C::BUF_BYTES;
         const bool more = ck + 1 < nchunks;
+        const int ckn = ck + 1 + rot < nchunks ? ck + 1 + rot : ck + 1 + rot - nchunks;  // global index of the next chunk
         if (ck == 2) TRACE_STAMP(8);
         bf16x8 fb[2][6], fa[2][MT];
         // step s = kx * 3 + ky; B rows of phase kx live in fb[kx & 1], A of step s in fa[s & 1]
@@ -783,7 +788,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
             }
             if (more && s < 4) {  // all pieces of the next chunk are requested in the first steps: they have the rest of the chunk to land
 #pragma unroll
-                for (int i = s * NP / 4; i < (s + 1) * NP / 4; ++i) glds_dma_piece<MT, NW>(i, ck + 1, nbuf, rin, rw, goff, in_chunk_bytes, wave, tid);
+                for (int i = s * NP / 4; i < (s + 1) * NP / 4; ++i) glds_dma_piece<MT, NW>(i, ckn, nbuf, rin, rw, goff, in_chunk_bytes, wave, tid);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -827,7 +832,7 @@ int launch_glds(const dasr_conv_params& p, hipStream_t s) {
     const int tiles_x = (p.Wout + C::TW - 1) / C::TW, tiles_y = (p.Hout + C::TH - 1) / C::TH;
     const long long grid = (long long)MG * tiles_x * tiles_y * p.N;
     if (grid <= 0 || grid > 0x7fffffffLL) return DASR_EINVAL;
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(C::NTH), C::LDS_BYTES, s, p);
+    DASR_LAUNCH_TAG(__PRETTY_FUNCTION__, kfn, dim3((unsigned)grid), dim3(C::NTH), C::LDS_BYTES, s, p);
     return (int)hipGetLastError();
 }
 
@@ -846,7 +851,7 @@ int launch(const dasr_conv_params& p, hipStream_t s) {
     const int tiles_x = (p.Wout + C::TW - 1) / C::TW, tiles_y = (p.Hout + C::TH - 1) / C::TH;
     const long long grid = (long long)MG * tiles_x * tiles_y * p.N;
     if (grid <= 0 || grid > 0x7fffffffLL) return DASR_EINVAL;
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(256), C::LDS_BYTES + 16, s, p);
+    DASR_LAUNCH_TAG(__PRETTY_FUNCTION__, kfn, dim3((unsigned)grid), dim3(256), C::LDS_BYTES + 16, s, p);
     return (int)hipGetLastError();
 }
 
@@ -902,6 +907,7 @@ int classify_epi(const dasr_conv_params& p) {
 }
 
 // kernel-variant selection (A/B-able from the host: dasr_set_tuning)
+int g_tune_rot = 0;  // chunk-order rotation of the LDS-DMA dense-block conv (A/B)
 int g_tune_rdb32 = 12, g_tune_rdb64 = 13, g_tune_stream = 0, g_tune_xcd = 1, g_tune_epi = 1;  // Cout=64: 13 = 8-wave form for launches of <= 256 four-wave workgroups (worth 1-2 % of the step under two sub-batch streams)
 
 }  // namespace
@@ -920,13 +926,14 @@ extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
         case 3: g_tune_stream = value; return 0;  // split-bf16 stream conv: 0 single, 1 double
         case 4: g_tune_xcd = value; return 0;     // XCD-aware tile order on/off
         case 5: g_tune_epi = value; return 0;     // compile-time specialised epilogues on/off
+        case 6: g_tune_rot = value; return 0;     // LDS-DMA dense conv: per-workgroup chunk-order rotation on/off
         default: return DASR_EINVAL;
     }
 }
 
 extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
     dasr_conv_params p = *pp;
-    p.xcd_remap = g_tune_xcd;  // bit 1 (trace builds): contiguous-store timing experiment
+    p.xcd_remap = g_tune_xcd | (g_tune_rot ? 4 : 0);  // bit 1 (trace builds): contiguous-store timing experiment; bit 2: chunk rotation
     if (p.pad_x == 0 && p.out_stride == 0 && p.kh != 2 && p.kh != 1) p.pad_x = -1;  // zero-initialised extension fields = "same as pad"
     hipStream_t s = as_stream(stream);
     if (p.cin <= 0 || (p.cin & 15) || p.cout <= 0 || !p.w || !p.in.p) return DASR_EINVAL;
@@ -1043,6 +1050,6 @@ extern "C" int dasr_conv_naive(const dasr_conv_params* pp, const float* w_ref, v
     const dasr_conv_params& p = *pp;
     const long long total = (long long)p.N * p.cout * p.Hout * p.Wout;
     if (total <= 0) return DASR_EINVAL;
-    hipLaunchKernelGGL(conv_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), p, w_ref);
+    DASR_LAUNCH(conv_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), p, w_ref);
     return (int)hipGetLastError();
 }

@@ -617,14 +617,14 @@ __global__ void lowpass_valid_kernel(dasr_tensor x, const float* __restrict__ w,
 extern "C" int dasr_inorm_lrelu_fwd(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, float eps, float slope, dasr_tensor y,
                                     float* stats, void* stream) {
     if (N <= 0 || C <= 0) return DASR_EINVAL;
-    hipLaunchKernelGGL(inorm_lrelu_fwd_kernel, dim3(N * ((C + 15) / 16)), dim3(256), 0, as_stream(stream), x, C, H, W, eps, slope, y, stats);
+    DASR_LAUNCH(inorm_lrelu_fwd_kernel, dim3(N * ((C + 15) / 16)), dim3(256), 0, as_stream(stream), x, C, H, W, eps, slope, y, stats);
     return (int)hipGetLastError();
 }
 
 extern "C" int dasr_inorm_lrelu_bwd(dasr_tensor a, dasr_tensor ga, int32_t N, int32_t C, int32_t H, int32_t W, float slope,
                                     const float* stats, dasr_tensor gx, void* stream) {
     if (N <= 0 || C <= 0) return DASR_EINVAL;
-    hipLaunchKernelGGL(inorm_lrelu_bwd_kernel, dim3(N * ((C + 15) / 16)), dim3(256), 0, as_stream(stream), a, ga, C, H, W, slope, stats, gx);
+    DASR_LAUNCH(inorm_lrelu_bwd_kernel, dim3(N * ((C + 15) / 16)), dim3(256), 0, as_stream(stream), a, ga, C, H, W, slope, stats, gx);
     return (int)hipGetLastError();
 }
 
@@ -632,7 +632,7 @@ extern "C" int dasr_bce_logits(dasr_tensor x, int32_t N, int32_t C, int32_t H, i
                                float* loss_acc, float* score_acc, float score_coef, dasr_tensor grad, void* stream) {
     const long long total = (long long)N * H * W;
     if (total <= 0 || C > 16) return DASR_EINVAL;
-    hipLaunchKernelGGL(bce_logits_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, target, coef, gcoef, loss_acc,
+    DASR_LAUNCH(bce_logits_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, target, coef, gcoef, loss_acc,
                        score_acc, score_coef, grad);
     return (int)hipGetLastError();
 }
@@ -641,7 +641,7 @@ extern "C" int dasr_dwt_fwd(dasr_tensor x, int32_t N, int32_t C, int32_t H2, int
                             void* stream) {
     const long long total = (long long)N * H2 * W2;
     if (total <= 0 || C > 5) return DASR_EINVAL;
-    hipLaunchKernelGGL(dwt_fwd_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H2, W2, norm, ll, hc);
+    DASR_LAUNCH(dwt_fwd_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H2, W2, norm, ll, hc);
     return (int)hipGetLastError();
 }
 
@@ -649,7 +649,7 @@ extern "C" int dasr_dwt_bwd(dasr_tensor gll, dasr_tensor ghc, int32_t N, int32_t
                             int32_t accumulate, void* stream) {
     const long long total = (long long)N * H2 * W2;
     if (total <= 0 || C > 5) return DASR_EINVAL;
-    hipLaunchKernelGGL(dwt_bwd_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), gll, ghc, N, C, H2, W2, norm, gx, accumulate);
+    DASR_LAUNCH(dwt_bwd_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), gll, ghc, N, C, H2, W2, norm, gx, accumulate);
     return (int)hipGetLastError();
 }
 
@@ -657,7 +657,7 @@ extern "C" int dasr_lowpass(dasr_tensor x, dasr_tensor x2, const float* w, int32
                             int32_t mode, float a_h, float b_h, dasr_tensor out_low, dasr_tensor out_high, int32_t accumulate, void* stream) {
     const long long total = (long long)N * H * W;
     if (total <= 0 || C > 4 || !(k & 1)) return DASR_EINVAL;
-    hipLaunchKernelGGL(lowpass_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, x2, w, k, N, C, H, W, mode, a_h, b_h, out_low,
+    DASR_LAUNCH(lowpass_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, x2, w, k, N, C, H, W, mode, a_h, b_h, out_low,
                        out_high, accumulate);
     return (int)hipGetLastError();
 }
@@ -665,8 +665,8 @@ extern "C" int dasr_lowpass(dasr_tensor x, dasr_tensor x2, const float* w, int32
 extern "C" int dasr_maxpool2(dasr_tensor x, int32_t is_f32, int32_t N, int32_t C, int32_t Ho, int32_t Wo, dasr_tensor y, void* stream) {
     const long long total = (long long)N * ((C + 15) / 16) * Ho * Wo * 4;
     if (total <= 0) return DASR_EINVAL;
-    if (is_f32) hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
-    else hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
+    if (is_f32) DASR_LAUNCH(maxpool_fwd_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
+    else DASR_LAUNCH(maxpool_fwd_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
     return (int)hipGetLastError();
 }
 
@@ -674,8 +674,8 @@ extern "C" int dasr_maxpool2_bwd(dasr_tensor x, dasr_tensor gy, int32_t is_f32, 
                                  int32_t relu_mask, void* stream) {
     const long long total = (long long)N * ((C + 15) / 16) * Ho * Wo * 4;
     if (total <= 0) return DASR_EINVAL;
-    if (is_f32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
-    else hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
+    if (is_f32) DASR_LAUNCH(maxpool_bwd_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
+    else DASR_LAUNCH(maxpool_bwd_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
     return (int)hipGetLastError();
 }
 
@@ -685,8 +685,8 @@ extern "C" int dasr_l1_diff(dasr_tensor a, dasr_tensor b, int32_t is_f32, int32_
     is_f32 &= 1;
     const long long total = (long long)N * ((C + 15) / 16) * H * W * 4;
     if (total <= 0) return DASR_EINVAL;
-    if (is_f32) hipLaunchKernelGGL(l1_diff_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), a, b, N, C, H, W, coef, gcoef, loss_acc, ga, squared);
-    else hipLaunchKernelGGL(l1_diff_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), a, b, N, C, H, W, coef, gcoef, loss_acc, ga, squared);
+    if (is_f32) DASR_LAUNCH(l1_diff_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), a, b, N, C, H, W, coef, gcoef, loss_acc, ga, squared);
+    else DASR_LAUNCH(l1_diff_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), a, b, N, C, H, W, coef, gcoef, loss_acc, ga, squared);
     return (int)hipGetLastError();
 }
 
@@ -695,15 +695,15 @@ extern "C" int dasr_affine4(dasr_tensor x, int32_t N, int32_t C, int32_t H, int3
     const long long total = (long long)N * H * W;
     if (total <= 0 || C > 4) return DASR_EINVAL;
     const f32x4 sc = {scale4[0], scale4[1], scale4[2], scale4[3]}, sh = {shift4[0], shift4[1], shift4[2], shift4[3]};
-    if (y_f32) hipLaunchKernelGGL(affine4_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, sc, sh, y, accumulate);
-    else hipLaunchKernelGGL(affine4_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, sc, sh, y, accumulate);
+    if (y_f32) DASR_LAUNCH(affine4_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, sc, sh, y, accumulate);
+    else DASR_LAUNCH(affine4_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, sc, sh, y, accumulate);
     return (int)hipGetLastError();
 }
 
 extern "C" int dasr_bilinear_up(const float* src, int32_t N, int32_t h, int32_t w, int32_t factor, float* dst, void* stream) {
     const long long total = (long long)N * h * w * factor * factor;
     if (total <= 0) return DASR_EINVAL;
-    hipLaunchKernelGGL(bilinear_up_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), src, N, h, w, factor, dst);
+    DASR_LAUNCH(bilinear_up_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), src, N, h, w, factor, dst);
     return (int)hipGetLastError();
 }
 
@@ -711,7 +711,7 @@ extern "C" int dasr_logloss(dasr_tensor x, int32_t N, int32_t H, int32_t W, int3
                             float* score_acc, float score_coef, dasr_tensor grad, int32_t accumulate, void* stream) {
     const long long total = (long long)N * H * W;
     if (total <= 0) return DASR_EINVAL;
-    hipLaunchKernelGGL(logloss_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, H, W, mode, eps, coef, gcoef, loss_acc, score_acc,
+    DASR_LAUNCH(logloss_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, H, W, mode, eps, coef, gcoef, loss_acc, score_acc,
                        score_coef, grad, accumulate);
     return (int)hipGetLastError();
 }
@@ -719,22 +719,22 @@ extern "C" int dasr_logloss(dasr_tensor x, int32_t N, int32_t H, int32_t W, int3
 extern "C" int dasr_sigmoid_bwd(dasr_tensor y, dasr_tensor g, int32_t N, int32_t C, int32_t H, int32_t W, dasr_tensor gz, void* stream) {
     const long long total = (long long)N * H * W;
     if (total <= 0 || C > 4) return DASR_EINVAL;
-    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), y, g, N, C, H, W, gz);
+    DASR_LAUNCH(sigmoid_bwd_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), y, g, N, C, H, W, gz);
     return (int)hipGetLastError();
 }
 
 extern "C" int dasr_sigmoid_fwd(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, dasr_tensor y, void* stream) {
     const long long total = (long long)N * H * W;
     if (total <= 0 || C > 4) return DASR_EINVAL;
-    hipLaunchKernelGGL(sigmoid_fwd_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, y);
+    DASR_LAUNCH(sigmoid_fwd_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, y);
     return (int)hipGetLastError();
 }
 
 extern "C" int dasr_prelu_grad(dasr_tensor y, dasr_tensor gx, int32_t N, int32_t C, int32_t H, int32_t W, const float* slope, float* scratch256,
                                float* dst, float scale, void* stream) {
     if ((long long)N * C * H * W <= 0) return DASR_EINVAL;
-    hipLaunchKernelGGL(prelu_grad_partial_kernel, dim3(256), dim3(256), 0, as_stream(stream), y, gx, N, C, H, W, scratch256);
-    hipLaunchKernelGGL(prelu_grad_final_kernel, dim3(1), dim3(64), 0, as_stream(stream), scratch256, 256, slope, dst, scale);
+    DASR_LAUNCH(prelu_grad_partial_kernel, dim3(256), dim3(256), 0, as_stream(stream), y, gx, N, C, H, W, scratch256);
+    DASR_LAUNCH(prelu_grad_final_kernel, dim3(1), dim3(64), 0, as_stream(stream), scratch256, 256, slope, dst, scale);
     return (int)hipGetLastError();
 }
 
@@ -742,6 +742,6 @@ extern "C" int dasr_lowpass_valid(dasr_tensor x, const float* w, int32_t k, int3
                                   dasr_tensor out, int32_t accumulate, void* stream) {
     const long long total = (long long)N * (mode == 0 ? (H - k + 1) * (long long)(W - k + 1) : (long long)H * W);
     if (total <= 0 || C > 4 || H < k || W < k) return DASR_EINVAL;
-    hipLaunchKernelGGL(lowpass_valid_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, w, k, N, C, H, W, mode, out, accumulate);
+    DASR_LAUNCH(lowpass_valid_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, w, k, N, C, H, W, mode, out, accumulate);
     return (int)hipGetLastError();
 }

@@ -251,7 +251,7 @@ inline unsigned blocks_for(long long total, int bs = 256) { return (unsigned)((t
 extern "C" int dasr_pack_weights(const dasr_pack_desc* descs_dev, int32_t ndesc, int64_t total_pieces, const int64_t* piece_prefix_dev,
                                  const float* params_flat, void* packed, void* stream) {
     if (ndesc <= 0 || total_pieces <= 0) return DASR_EINVAL;
-    hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(total_pieces)), dim3(256), 0, as_stream(stream), descs_dev, ndesc,
+    DASR_LAUNCH(pack_kernel, dim3(blocks_for(total_pieces)), dim3(256), 0, as_stream(stream), descs_dev, ndesc,
                        (long long)total_pieces, (const long long*)piece_prefix_dev, params_flat, (bf16_t*)packed);
     return (int)hipGetLastError();
 }
@@ -260,14 +260,14 @@ extern "C" int dasr_nchw_to_blocked(const float* src, int32_t N, int32_t C, int3
                                     dasr_tensor dst_bf16, void* stream) {
     const long long total = (long long)N * ((C + 15) / 16) * H * W;
     if (total <= 0) return DASR_EINVAL;
-    hipLaunchKernelGGL(nchw_to_blocked_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), src, N, C, H, W, dst_f32, dst_bf16);
+    DASR_LAUNCH(nchw_to_blocked_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), src, N, C, H, W, dst_f32, dst_bf16);
     return (int)hipGetLastError();
 }
 
 extern "C" int dasr_blocked_to_nchw(dasr_tensor src, int32_t N, int32_t C, int32_t H, int32_t W, float* dst, void* stream) {
     const long long total = (long long)N * C * H * W;
     if (total <= 0) return DASR_EINVAL;
-    hipLaunchKernelGGL(blocked_to_nchw_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), src, N, C, H, W, dst);
+    DASR_LAUNCH(blocked_to_nchw_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), src, N, C, H, W, dst);
     return (int)hipGetLastError();
 }
 
@@ -275,7 +275,7 @@ extern "C" int dasr_l1_loss(dasr_tensor sr, const float* hr_nchw, const float* w
                             float coef, float* loss_acc, dasr_tensor grad, int32_t accumulate, void* stream) {
     const long long total = (long long)N * H * W;
     if (total <= 0 || C > 16) return DASR_EINVAL;
-    hipLaunchKernelGGL(l1_loss_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), sr, hr_nchw, weight_map, N, C, H, W, coef,
+    DASR_LAUNCH(l1_loss_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), sr, hr_nchw, weight_map, N, C, H, W, coef,
                        loss_acc, grad, accumulate);
     return (int)hipGetLastError();
 }
@@ -284,7 +284,7 @@ extern "C" int dasr_downsum2x(dasr_tensor src, int32_t N, int32_t C, int32_t H, 
                               float slope, dasr_tensor dst_f32, dasr_tensor dst_bf16, void* stream) {
     const long long total = (long long)N * ((C + 15) / 16) * H * W * 4;
     if (total <= 0) return DASR_EINVAL;
-    hipLaunchKernelGGL(downsum2x_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), src, N, C, H, W, mask, mask_f32, slope,
+    DASR_LAUNCH(downsum2x_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), src, N, C, H, W, mask, mask_f32, slope,
                        dst_f32, dst_bf16);
     return (int)hipGetLastError();
 }
@@ -294,7 +294,7 @@ extern "C" int dasr_axpby(dasr_tensor x, float a, dasr_tensor z, float b, int32_
                           void* stream) {
     const long long total = (long long)N * ((C + 15) / 16) * H * W * 4;
     if (total <= 0) return DASR_EINVAL;
-    hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), x, a, z, b, N, C, H, W, out_f32, out_bf16, gamma, mask, slope, slope_ptr);
+    DASR_LAUNCH(axpby_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), x, a, z, b, N, C, H, W, out_f32, out_bf16, gamma, mask, slope, slope_ptr);
     return (int)hipGetLastError();
 }
 
@@ -305,7 +305,7 @@ extern "C" int dasr_adam(float* p, const float* g, float* m, float* v, int64_t n
     const float step_size = (float)((double)lr / bc1);
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p, g, m, v, (long long)n, step_size, beta1, beta2, eps,
+    DASR_LAUNCH(adam_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p, g, m, v, (long long)n, step_size, beta1, beta2, eps,
                        weight_decay, inv_sqrt_bc2);
     return (int)hipGetLastError();
 }
@@ -313,14 +313,14 @@ extern "C" int dasr_adam(float* p, const float* g, float* m, float* v, int64_t n
 extern "C" int dasr_fill_f32(float* p, int64_t n, float value, void* stream) {
     if (n <= 0) return DASR_EINVAL;
     const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p, (long long)n, value);
+    DASR_LAUNCH(fill_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p, (long long)n, value);
     return (int)hipGetLastError();
 }
 
 extern "C" int dasr_add_flat(float* y, const float* x, int64_t n, void* stream) {
     if (n <= 0) return DASR_EINVAL;
     const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(add_flat_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), y, x, (long long)n);
+    DASR_LAUNCH(add_flat_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), y, x, (long long)n);
     return (int)hipGetLastError();
 }
 
@@ -364,7 +364,7 @@ __global__ void gather_crops_kernel(const dasr_crop_desc* __restrict__ descs, in
 extern "C" int dasr_gather_crops(const dasr_crop_desc* descs_dev, int32_t n, int32_t C, int32_t size, float* dst, void* stream) {
     const long long total = (long long)n * C * size * size;
     if (total <= 0 || !descs_dev || !dst) return DASR_EINVAL;
-    hipLaunchKernelGGL(gather_crops_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), descs_dev, n, C, size, dst);
+    DASR_LAUNCH(gather_crops_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), descs_dev, n, C, size, dst);
     return (int)hipGetLastError();
 }
 
@@ -381,11 +381,117 @@ extern "C" int dasr_abi_version(void) { return DASR_ABI_VERSION; }
 static int g_last_failed_op = -1;
 extern "C" int dasr_last_failed_op(void) { return g_last_failed_op; }
 
+// ---- profiling session (see DASR_LAUNCH in common.h) ------------------------------------------------------------------------
+namespace {
+struct ProfRec {
+    hipEvent_t e0, e1;
+    const char* tag;
+    double flops, bytes;
+    int op;
+};
+ProfRec* g_prof = nullptr;
+int g_prof_cap = 0, g_prof_n = 0;
+bool g_prof_on = false;
+double g_prof_flops = 0.0, g_prof_bytes = 0.0;  // algorithmic work of the op being dispatched (consumed by its first launch)
+int g_prof_op = 0;
+}  // namespace
+
+bool dasr_prof_slot(const char* tag, hipEvent_t* e0, hipEvent_t* e1) {
+    if (!g_prof_on || g_prof_n >= g_prof_cap) return false;
+    ProfRec& r = g_prof[g_prof_n++];
+    r.tag = tag;
+    r.flops = g_prof_flops;
+    r.bytes = g_prof_bytes;
+    r.op = g_prof_op;
+    g_prof_flops = g_prof_bytes = 0.0;
+    *e0 = r.e0;
+    *e1 = r.e1;
+    return true;
+}
+
+// MFMA-only micro-benchmark: every SIMD of the chip issues back-to-back v_mfma_f32_32x32x16_bf16 on four independent accumulators.
+// What it sustains is the dense bf16 peak of THIS box at the clock the power state allows (spec: 2.5 PFLOP/s at 2.4 GHz).
+__global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, float* sink) {
+    bf16x8 a, b;
+    for (int j = 0; j < 8; ++j) {
+        a[j] = (bf16_t)(0.001f * (float)((threadIdx.x * 7 + j * 13) % 31 - 15));
+        b[j] = (bf16_t)(0.002f * (float)((threadIdx.x * 5 + j * 11) % 29 - 14));
+    }
+    f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
+    }
+    float t = 0.f;
+    for (int j = 0; j < 16; ++j) t += c0[j] + c1[j] + c2[j] + c3[j];
+    if (t == 12345.678f) sink[0] = t;  // keeps the chain live
+}
+
+extern "C" int dasr_probe_mfma_peak(int32_t iters, float* tflops_out, void* stream) {
+    if (iters <= 0 || !tflops_out) return DASR_EINVAL;
+    float* sink = nullptr;
+    HIP_TRY(hipMalloc(&sink, 16));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    const int blocks = 256 * 2;  // 2 workgroups of 4 waves per CU: 2 waves per SIMD
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), iters / 8 + 1, sink);  // warm-up (clock ramp)
+    hipExtLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), e0, e1, 0, iters, sink);
+    hipError_t e = hipStreamSynchronize(as_stream(stream));
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    if (e != hipSuccess) return (int)e;
+    const double flops = (double)blocks * 4.0 * (double)iters * 4.0 * 2.0 * 32 * 32 * 16;
+    *tflops_out = (float)(flops / ((double)ms * 1e-3) / 1e12);
+    return 0;
+}
+
+extern "C" int dasr_prof_begin(int32_t capacity) {
+    if (capacity <= 0) return DASR_EINVAL;
+    if (capacity > g_prof_cap) {
+        ProfRec* np = (ProfRec*)realloc(g_prof, sizeof(ProfRec) * (size_t)capacity);
+        if (!np) return DASR_EINVAL;
+        g_prof = np;
+        for (int i = g_prof_cap; i < capacity; ++i) {
+            HIP_TRY(hipEventCreate(&g_prof[i].e0));
+            HIP_TRY(hipEventCreate(&g_prof[i].e1));
+            g_prof_cap = i + 1;
+        }
+    }
+    g_prof_n = 0;
+    g_prof_on = true;
+    return 0;
+}
+
+extern "C" int dasr_prof_end(int32_t max_out, float* us_out, double* flops_out, double* bytes_out, int32_t* op_out, const char** tag_out) {
+    g_prof_on = false;
+    HIP_TRY(hipDeviceSynchronize());
+    const int n = g_prof_n < max_out ? g_prof_n : max_out;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, g_prof[i].e0, g_prof[i].e1));
+        us_out[i] = ms * 1e3f;
+        flops_out[i] = g_prof[i].flops;
+        bytes_out[i] = g_prof[i].bytes;
+        op_out[i] = g_prof[i].op;
+        tag_out[i] = g_prof[i].tag;
+    }
+    return n;
+}
+
 extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream0) {
     void* stream = stream0;  // DASR_OP_SET_STREAM redirects the following ops
     for (int k = 0; k < n; ++k) {
         const dasr_op& o = ops[k];
         int rc = 0;
+        g_prof_flops = o.flops;
+        g_prof_bytes = o.bytes;
+        g_prof_op = o.op;
         switch (o.op) {
             case DASR_OP_CONV: rc = dasr_conv(&o.conv, stream); break;
             case DASR_OP_WGRAD:

@@ -815,7 +815,7 @@ int launch_wgrad(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + 16));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kfn, dim3(nparts * nsplit), dim3(256), C::LDS_BYTES + 16, s, parts, nparts, nsplit, ws);
+    DASR_LAUNCH_TAG(__PRETTY_FUNCTION__, kfn, dim3(nparts * nsplit), dim3(256), C::LDS_BYTES + 16, s, parts, nparts, nsplit, ws);
     return (int)hipGetLastError();
 }
 
@@ -828,7 +828,7 @@ int launch_wgrad3(const dasr_wgrad_part* parts, int nparts, int nsplit, float* w
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, W3::LDS_BYTES + 16));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kfn, dim3(nparts * nsplit), dim3(W3::NT), W3::LDS_BYTES + 16, s, parts, nparts, nsplit | (g_wgrad3_stagger << 24), ws);
+    DASR_LAUNCH_TAG(__PRETTY_FUNCTION__, kfn, dim3(nparts * nsplit), dim3(W3::NT), W3::LDS_BYTES + 16, s, parts, nparts, nsplit | (g_wgrad3_stagger << 24), ws);
     return (int)hipGetLastError();
 }
 
@@ -838,7 +838,7 @@ int launch_wgrad3_glds(const dasr_wgrad_part* parts, int nparts, int nsplit, flo
         HIP_TRY(hipFuncSetAttribute((const void*)wgrad3_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W3G::LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(wgrad3_glds_kernel, dim3(nparts * nsplit), dim3(W3G::NT), W3G::LDS_BYTES, s, parts, nparts, nsplit, ws);
+    DASR_LAUNCH(wgrad3_glds_kernel, dim3(nparts * nsplit), dim3(W3G::NT), W3G::LDS_BYTES, s, parts, nparts, nsplit, ws);
     return (int)hipGetLastError();
 }
 
@@ -851,7 +851,7 @@ int g_wgrad3_glds = 0;  // LDS-DMA wgrad3: faster alone (490 vs 470 TFLOP/s) but
 extern "C" int dasr_probe_tr16(void* stream) {
     int* d = nullptr;
     HIP_TRY(hipMalloc(&d, sizeof(int)));
-    hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, as_stream(stream), d);
+    DASR_LAUNCH(probe_tr16_kernel, dim3(1), dim3(64), 0, as_stream(stream), d);
     int h = -1;
     hipError_t e = hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, as_stream(stream));
     if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));
@@ -904,6 +904,6 @@ extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int3
 extern "C" int dasr_wgrad_reduce(const dasr_wgrad_reduce_part* parts_dev, int32_t nparts, const float* ws, float* grad_flat,
                                  float scale, void* stream) {
     if (nparts <= 0) return DASR_EINVAL;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(145, nparts), dim3(256), 0, as_stream(stream), parts_dev, nparts, ws, grad_flat, scale);
+    DASR_LAUNCH(wgrad_reduce_kernel, dim3(145, nparts), dim3(256), 0, as_stream(stream), parts_dev, nparts, ws, grad_flat, scale);
     return (int)hipGetLastError();
 }

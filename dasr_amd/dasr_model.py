@@ -166,14 +166,15 @@ class DASR_Model(BaseModel):
         P.g.set_input(self.var_L)
         P.fwd.run()                       # G forward, frequency separation, D forward, VGG forward, all losses + loss gradients
         scale = 1.0
-        if self.dp is not None and self.dp.world > 1:
+        dp_on = self.dp is not None and self.dp.active
+        if dp_on:
             scale = self.dp.grad_scale
             P.g.set_grad_scale(scale)
             P.set_d_grad_scale(scale)
         if do_g:
             P.g_loss_bwd.run()            # D / VGG / fs data-gradients into dL/dSR
             gG = self.netG.params.grad
-            if scale == 1.0:
+            if not dp_on:
                 P.g.bwd.run()
             else:
                 for seg, (lo, hi) in P.g.bwd_segments():
@@ -184,7 +185,7 @@ class DASR_Model(BaseModel):
             self.netG.repack()
         if do_d:
             P.d_step.run()                # BCE(real,1), BCE(fake,0), D backward with weight gradients
-            if scale != 1.0:
+            if dp_on:
                 self.dp.allreduce_mean(self.netD_target.params.grad)
             self.optimizer_D_target.step(self.schedulers[1].get_lr())
             self.netD_target.repack()

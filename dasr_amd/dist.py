@@ -14,12 +14,15 @@ import torch.distributed as dist
 
 
 class DataParallelGroup:
-    def __init__(self, backend=None):
+    def __init__(self, backend=None, force=False):
+        """force: build the process group and run the exchange code even with a single rank (exercises the RCCL / communication-
+        stream plumbing on a one-GPU box; RCCL refuses two ranks on one device)"""
         self.world = int(os.environ.get('WORLD_SIZE', '1'))
         self.rank = int(os.environ.get('RANK', '0'))
         self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
         self.backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
-        if self.world > 1 and not dist.is_initialized():
+        self.force = bool(force)
+        if (self.world > 1 or force) and not dist.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
             if self.backend == 'nccl':
@@ -29,13 +32,22 @@ class DataParallelGroup:
         self.pending = []
 
     @property
+    def active(self):
+        return self.world > 1 or self.force
+
+    def all_reduce_here(self, flat_slice):
+        """SUM all-reduce enqueued on the CURRENT stream (the caller has switched to the communication stream)"""
+        if self.active and flat_slice.numel():
+            dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM)
+
+    @property
     def grad_scale(self):
         """factor folded into the gradient reduction so that SUM over ranks == global-batch mean gradient"""
         return 1.0 / self.world
 
     def reduce_async(self, flat_slice):
         """SUM all-reduce of a contiguous slice of the flat gradient buffer, overlapped with compute."""
-        if self.world == 1 or flat_slice.numel() == 0:
+        if not self.active or flat_slice.numel() == 0:
             return
         if self.comm_stream is not None:
             ev = torch.cuda.Event()
@@ -57,11 +69,11 @@ class DataParallelGroup:
         self.wait()
 
     def barrier(self):
-        if self.world > 1:
+        if self.active:
             dist.barrier()
 
     def max_over_ranks(self, value):
-        if self.world == 1:
+        if not self.active:
             return value
         dev = 'cuda' if self.backend == 'nccl' else 'cpu'
         t = torch.tensor([value], dtype=torch.float64, device=dev)
@@ -69,7 +81,7 @@ class DataParallelGroup:
         return float(t.item())
 
     def broadcast_params(self, flat):
-        if self.world > 1:
+        if self.active:
             dist.broadcast(flat, src=0)
 
 

@@ -318,13 +318,13 @@ class DSNModel:
         P.g.x_nchw.copy_(hr)
         P.bic_nchw.copy_(bicubic_lr)
         P.real_nchw.copy_(real_lr)
-        scale = self.dp.grad_scale if (self.dp is not None and self.dp.world > 1) else 1.0
+        scale = self.dp.grad_scale if (self.dp is not None and self.dp.active) else 1.0
         if scale != P.scale:
             P.set_grad_scale(scale)
         P.fwd.run()     # G, front ends, D on [fake; real], all losses and loss gradients
         P.d_bwd.run()   # D weight gradients (pre-update graph)
         P.g_bwd.run()   # texture gradient through D's data path, colour adjoint, G backward
-        if scale != 1.0:
+        if self.dp is not None and self.dp.active:
             self.dp.allreduce_mean(self.netD.params.grad)
             self.dp.allreduce_mean(self.netG.params.grad)
         lr = self.lr()

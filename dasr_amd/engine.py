@@ -177,6 +177,22 @@ class OpList:
         self.keep.extend(other.keep)
         self._arr = None
 
+    def safe_cuts(self, chunk):
+        """[0, c1, c2, ..., len]: chunk boundaries of about `chunk` ops at which no stream redirect (OP_SET_STREAM) is open"""
+        key = ('cuts', chunk, len(self.ops))
+        if getattr(self, '_cuts_key', None) != key:
+            cuts, redirected, last = [0], False, 0
+            for i, o in enumerate(self.ops):
+                if o.op == _lib.OP_SET_STREAM:
+                    redirected = bool(o.p[0])
+                if i + 1 - last >= chunk and not redirected:
+                    cuts.append(i + 1)
+                    last = i + 1
+            if cuts[-1] != len(self.ops):
+                cuts.append(len(self.ops))
+            self._cuts, self._cuts_key = cuts, key
+        return self._cuts
+
     def run(self, lo=0, hi=None):
         """enqueue ops[lo:hi] on the current stream"""
         if not self.ops:
@@ -198,20 +214,24 @@ def run_interleaved(lists, streams, chunk=None):
     early (the host enqueues ~250k launches/s; a whole 1200-op list first would leave the other stream idle for ms)."""
     import os
     chunk = chunk or int(os.environ.get('DASR_ENQ_CHUNK', '48'))
-    n = max(len(l.ops) for l in lists)
-    for lo in range(0, n, chunk):
-        for l, st in zip(lists, streams):
-            if lo < len(l.ops):
+    # dasr_run_ops forgets a DASR_OP_SET_STREAM redirect when it returns, so a list is only cut where it is back on its own stream
+    cuts = [l.safe_cuts(chunk) for l in lists]
+    for k in range(max(len(c) for c in cuts) - 1):
+        for l, st, c in zip(lists, streams, cuts):
+            if k + 1 < len(c):
                 with torch.cuda.stream(st):
-                    l.run(lo, lo + chunk)
+                    l.run(c[k], c[k + 1])
 
 
 def conv_op(pack, ref, inp, in_f32, cin, Hin, Win, Hout, Wout, N, bias=None, kh=3, stride=1, pad=1, ups=0, act=0, slope=SLOPE,
             mask=None, mask_f32=0, alpha=1.0, res1=None, beta1=0.0, res2=None, beta2=0.0, out_f32=None, out_bf16=None, gamma=1.0,
-            pad_x=-1, out_stride=1, out_oy=0, out_ox=0, out_W=0, slope_ptr=None, in_stride=1, in_oy=0, in_ox=0, in_W=0):
+            pad_x=-1, out_stride=1, out_oy=0, out_ox=0, out_W=0, slope_ptr=None, in_stride=1, in_oy=0, in_ox=0, in_W=0, flops=None):
+    """flops: algorithmic FLOPs of the reference op this launch stands for (default: 2 * outputs * taps * cin * cout of the launch
+    itself; the sub-pixel upconv launches pass a quarter of the reference's 3x3 conv on the up-sampled grid instead)."""
     assert cin == ref.cin_pad, (cin, ref.cin_pad)
     o = Op()
     o.op = _lib.OP_CONV
+    o.flops = float(flops) if flops is not None else 2.0 * N * Hout * Wout * kh * kh * cin * ref.cout
     p = o.conv
     p.inp, p.in_f32, p.Hin, p.Win, p.ups, p.cin = inp, int(in_f32), Hin, Win, ups, cin
     p.w, p.w_lo_off, p.bias = pack.ptr(ref), ref.lo_off, bias
@@ -244,6 +264,7 @@ class WgradGroup:
         ntaps = self.kh * self.kh
         tpp = ntaps if ntaps <= 16 else 10  # WCfg::TAPS_PER_PART
         self.tpp = tpp
+        self.flops = getattr(self, 'flops', 0.0) + 2.0 * N * Hout * Wout * ntaps * cin * cout
         pad = (self.kh - 1) // 2 if pad is None else pad
         cin_pad = ceil_div(cin, 16) * 16
         for oc0 in range(0, cout, 32):
@@ -299,6 +320,7 @@ class WgradGroup:
         f32s = set((p[0].g_f32, p[0].in_f32) for p in self.parts)
         assert f32s in ({(0, 0)}, {(1, 1)}), 'a wgrad group must be all-bf16 or all-f32'
         a.i[4] = self.parts[0][0].g_f32
+        a.flops = float(getattr(self, 'flops', 0.0))
         b.op = _lib.OP_WGRAD_REDUCE
         b.p[0], b.i[0], b.p[2], b.f[0] = self.r_dev.data_ptr(), len(self.parts), grad_ptr, scale
         self.workspace.register(a, b)
@@ -359,6 +381,7 @@ class WgradGroup3:
         a, b = Op(), Op()
         a.op = _lib.OP_WGRAD
         a.p[0], a.i[0], a.i[1], a.i[2], a.i[3], a.i[4] = self.w_dev.data_ptr(), len(self.parts), self.nsplit, 33, 1, self.parts[0][0].g_f32
+        a.flops = float(getattr(self, 'flops', 0.0))
         b.op = _lib.OP_WGRAD_REDUCE
         b.p[0], b.i[0], b.p[2], b.f[0] = self.r_dev.data_ptr(), self.n_red, grad_ptr, scale
         self.workspace.register(a, b)

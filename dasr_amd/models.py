@@ -219,12 +219,56 @@ class SRModel(BaseModel):
         self.netG.concurrent_replicas = k  # the 1-WG/CU wgrad launches of the replicas must fit on the chip together
         return [self.netG.plan(N // k, h, w, replica=i) for i in range(k)]
 
+    @staticmethod
+    def _whole_step(plan, loss_ops):
+        """forward + loss + backward of one sub-batch replica as ONE recorded list; an event is recorded on the replica's stream at
+        every gradient-bucket boundary of the backward list (plan.buckets: [(event, lo, hi)] in completion order)"""
+        if not hasattr(plan, 'whole_step'):
+            from .rrdbnet import _sched
+            ws = OpList()
+            ws.extend(plan.fwd)
+            ws.extend(loss_ops)
+            plan.buckets, prev, prev_hi = [], 0, plan.net.params.total
+            for idx, lo in plan._marks:
+                ws.ops.extend(plan.bwd.ops[prev:idx])
+                ev = plan._event()
+                ws.ops.append(_sched(_lib.OP_EVENT_RECORD, ev))
+                plan.buckets.append((ev, lo, prev_hi))
+                prev, prev_hi = idx, lo
+            ws.ops.extend(plan.bwd.ops[prev:])
+            ws.keep.extend(plan.bwd.keep)
+            ws._arr = None
+            plan.whole_step = ws
+        return plan.whole_step
+
+    def _bucket_ops(self, plans):
+        """per gradient bucket: op list for the communication stream = wait for every replica's boundary event, then add the private
+        gradient slices of replicas 1.. into params.grad[lo:hi]"""
+        key = tuple(id(p.whole_step) for p in plans)
+        if getattr(self, '_bucket_key', None) != key:
+            from .rrdbnet import _sched
+            g, out = self.netG.params.grad, []
+            for k in range(len(plans[0].buckets)):
+                _, lo, hi = plans[0].buckets[k]
+                ol = OpList()
+                for p in plans:
+                    ol.add(_sched(_lib.OP_STREAM_WAIT, p.buckets[k][0]))
+                for p in plans[1:]:
+                    o = Op()
+                    o.op = _lib.OP_ADD_FLAT
+                    o.p[0], o.p[1], o.l[0] = g.data_ptr() + 4 * lo, p.grad.data_ptr() + 4 * lo, hi - lo
+                    if hi > lo:
+                        ol.add(o)
+                out.append((ol, lo, hi))
+            self._bucket_list, self._bucket_key = out, key
+        return self._bucket_list
+
     def optimize_parameters(self, step):
         N, _, h, w = self.var_L.shape
         plans = self._sub_plans(N, h, w)
         L = _lib.lib()
         _lib.check(L.dasr_fill_f32(self.loss_acc.data_ptr(), 4, 0.0, _stream()), 'fill')
-        dp_on = self.dp is not None and self.dp.world > 1
+        dp_on = self.dp is not None and self.dp.active
         if len(plans) == 1:
             plan = plans[0]
             loss_ops, hr_buf = self._ops_for(plan, N)
@@ -253,25 +297,30 @@ class SRModel(BaseModel):
                     loss_ops, hr_buf = self._ops_for(plan, N)
                     hr_buf.copy_(self.real_H[i * per:(i + 1) * per])
                     plan.set_input(self.var_L[i * per:(i + 1) * per])
-                    if dp_on:
-                        plan.set_grad_scale(self.dp.grad_scale)
-                if not hasattr(plan, 'whole_step'):
-                    ws = OpList()
-                    ws.extend(plan.fwd)
-                    ws.extend(loss_ops)
-                    ws.extend(plan.bwd)
-                    plan.whole_step = ws
-                if dp_on:
-                    plan.whole_step._arr = None  # grad scale may have been patched
-                steps.append(plan.whole_step)
+                    if dp_on and plan.set_grad_scale(self.dp.grad_scale) and hasattr(plan, 'whole_step'):
+                        del plan.whole_step  # the recorded list holds copies of the patched reduce ops
+                steps.append(self._whole_step(plan, loss_ops))
             run_interleaved(steps, self._streams)
-            for st in self._streams:
-                cur.wait_stream(st)
             g = self.netG.params.grad
-            for plan in plans[1:]:
-                _lib.check(L.dasr_add_flat(g.data_ptr(), plan.grad.data_ptr(), g.numel(), _stream()), 'add_flat')
-            if dp_on:
-                self.dp.allreduce_mean(g)
+            comm = self.dp.comm_stream if dp_on else None
+            if comm is not None:
+                # bucket k of the flat gradient buffer is summed over the sub-batch replicas and all-reduced over the ranks on the
+                # communication stream as soon as BOTH replica streams have passed its boundary event: the exchange overlaps the
+                # remaining data-gradient / weight-gradient kernels (reference mechanism replaced: networks.py:144-146)
+                for k, (bops, lo, hi) in enumerate(self._bucket_ops(plans)):
+                    with torch.cuda.stream(comm):
+                        bops.run()
+                        self.dp.all_reduce_here(g[lo:hi])
+                for st in self._streams:
+                    cur.wait_stream(st)
+                cur.wait_stream(comm)
+            else:
+                for st in self._streams:
+                    cur.wait_stream(st)
+                for plan in plans[1:]:
+                    _lib.check(L.dasr_add_flat(g.data_ptr(), plan.grad.data_ptr(), g.numel(), _stream()), 'add_flat')
+                if dp_on:
+                    self.dp.allreduce_mean(g)
         self.optimizer_G.step(self.schedulers[0].get_lr())
         self.netG.repack()
         self._out_plans = plans

@@ -53,11 +53,17 @@ def parse(opt_path, is_train=True):
         opt['path']['results_root'] = root
         opt['path']['log'] = root
     opt['network_G']['scale'] = scale
+    # codes/SRN/options/options.py:68-71 exports CUDA_VISIBLE_DEVICES = gpu_ids for its single-process nn.DataParallel.  HIP honours
+    # that variable too, so under one-process-per-GPU launch (torch.distributed.run sets WORLD_SIZE / LOCAL_RANK) it would hide every
+    # device but the listed ones from EVERY rank (the shipped JSONs say gpu_ids [0]: rank 1's set_device(1) would fail).  Rule:
+    # a launcher-managed process never touches *_VISIBLE_DEVICES (rank r uses device LOCAL_RANK); a stand-alone process keeps the
+    # reference's behaviour.
     gpu_list = ','.join(str(x) for x in (opt.get('gpu_ids') or []))
-    os.environ['CUDA_VISIBLE_DEVICES'] = gpu_list
-    if os.environ.get('DASR_SET_VISIBLE_DEVICES') == '1':
-        os.environ['HIP_VISIBLE_DEVICES'] = gpu_list
-    print('export CUDA_VISIBLE_DEVICES=' + gpu_list)
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 or 'LOCAL_RANK' in os.environ:
+        print('distributed launch: device = LOCAL_RANK, CUDA_VISIBLE_DEVICES left as is (gpu_ids %s ignored)' % gpu_list)
+    else:
+        os.environ['CUDA_VISIBLE_DEVICES'] = gpu_list
+        print('export CUDA_VISIBLE_DEVICES=' + gpu_list)
     return opt
 
 

@@ -227,6 +227,15 @@ class _Plan:
                     ops.add(conv_op(pack, pk[(i, r, 5)], S.view(0), False, nf + 4 * GC, h, w, h, w, N, bias=P.ptr(pre + '5.0.bias'),
                                     alpha=0.04, res1=X.view(), beta1=0.2, res2=Xrrdb.view(), beta2=1.0, out_f32=Y.view(), out_bf16=nxt))
                 X = Y
+            if i in getattr(net, 'debug_taps', ()):   # tests: fp32 copy of this RRDB's output (the stream buffers rotate)
+                self.taps = getattr(self, 'taps', {})
+                self.taps[i] = BTensor(N, nf, h, w, True, net.device)
+                o = Op()
+                o.op = _lib.OP_AXPBY
+                o.t[0], o.f[0], o.t[1], o.f[1] = X.view(), 1.0, NULL_T, 0.0
+                o.i[0], o.i[1], o.i[2], o.i[3] = N, nf, h, w
+                o.t[2], o.t[3], o.f[2] = self.taps[i].view(), NULL_T, 1.0
+                ops.add(o)
         self.x_last = X
         lrb = 'model.1.sub.%d.bias' % nb
         ops.add(conv_op(pack, pk['lr'], X.view(), True, nf, h, w, h, w, N, bias=P.ptr(lrb), res1=self.fea.view(), beta1=1.0,
@@ -238,7 +247,8 @@ class _Plan:
             for py in (0, 1):
                 for px in (0, 1):
                     ops.add(conv_op(pack, pk[(name, py, px)], src.view(), True, nf, hi, wi, hi, wi, N, bias=P.ptr(bkey), kh=2, stride=1, pad=1 - py,
-                                    pad_x=1 - px, act=1, out_f32=dst.view(), out_stride=2, out_oy=py, out_ox=px, out_W=2 * wi))
+                                    pad_x=1 - px, act=1, out_f32=dst.view(), out_stride=2, out_oy=py, out_ox=px, out_W=2 * wi,
+                                    flops=2.0 * N * hi * wi * 9 * nf * nf))
         ops.add(conv_op(pack, pk['hr0'], self.u2.view(), True, nf, H4, W4, H4, W4, N, bias=P.ptr('model.8.bias'), act=1,
                         out_f32=self.h0.view()))
         ops.add(conv_op(pack, pk['hr1'], self.h0.view(), True, nf, H4, W4, H4, W4, N, bias=P.ptr('model.10.bias'),
@@ -272,7 +282,7 @@ class _Plan:
                 ops.add(conv_op(pack, pk[(name, py, px)], g_hi.view(), True, net.nf, hl, wl, hl, wl, N, kh=2, stride=1, pad=py, pad_x=px,
                                 mask=mask.view() if mask is not None else None, mask_f32=1, slope=SLOPE,
                                 res1=None if first else g_lo.view(), beta1=0.0 if first else 1.0, out_f32=g_lo.view(),
-                                in_stride=2, in_oy=py, in_ox=px, in_W=2 * wl))
+                                in_stride=2, in_oy=py, in_ox=px, in_W=2 * wl, flops=2.0 * N * hl * wl * 9 * net.nf * net.nf))
                 first = False
 
     def _event(self):
@@ -365,6 +375,7 @@ class _Plan:
                                               n_ctiles=min(2, ceil_div(min(t['cin'] - c0, 64), 32))))
                         grp.add_block(Gs.view(32 * k0), 2 * len(sub), S.view(c0), blk_ch // 16, ceil_div(blk_ch, 32),
                                       h, w, h, w, N, tiles, want_bias=(c0 == 0))
+                grp.flops = 2.0 * N * h * w * 9 * sum((nf + (j - 1) * GC) * (GC if j < 5 else nf) for j in range(1, 6))
                 side = self.side_stream is not None
                 grp.finalize(self.ws_side if side else self.ws, net.device,
                              target_wgs=int(os.environ.get('DASR_WG3_TARGET', str(256 // max(1, getattr(net, 'concurrent_replicas', 1))))))
@@ -417,12 +428,16 @@ class _Plan:
         self._segments = None
 
     def set_grad_scale(self, scale):
-        """fold 1/world_size into the deterministic wgrad reduction (data-parallel mean gradient)"""
+        """fold 1/world_size into the deterministic wgrad reduction (data-parallel mean gradient); True if anything changed"""
+        changed = False
         for o in self.bwd.ops:
             if o.op == _lib.OP_WGRAD_REDUCE and o.f[0] != scale:
                 o.f[0] = scale
-                self.bwd._arr = None
-                self._segments = None
+                changed = True
+        if changed:
+            self.bwd._arr = None
+            self._segments = None
+        return changed
 
     def bwd_segments(self):
         """backward op list cut at gradient-bucket boundaries: [(OpList, (lo, hi) of the flat grad buffer that is

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DASR_ABI_VERSION 2
+#define DASR_ABI_VERSION 3
 #define DASR_EINVAL (-22)
 
 typedef struct {
@@ -263,6 +263,7 @@ enum { DASR_OP_CONV = 1, DASR_OP_WGRAD = 2, DASR_OP_WGRAD_REDUCE = 3, DASR_OP_PA
 typedef struct {
     int32_t op;  int32_t i[8];  float f[4];  int64_t l[4];  void* p[4];  dasr_tensor t[5];
     dasr_conv_params conv;
+    double flops, bytes;   /* algorithmic work of the op (set by the plan builder; only read by the profiling session below) */
 } dasr_op;
 
 int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream);
@@ -271,6 +272,19 @@ int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream);
 void* dasr_event_create(void);
 int dasr_event_destroy(void* ev);
 int dasr_last_failed_op(void);   /* index of the op that made dasr_run_ops return non-zero */
+
+/* ---- profiling session (bench.py `roofline`) -----------------------------------------------------------
+ * Between dasr_prof_begin and dasr_prof_end every kernel launch of the library (up to `capacity`) carries its own start/stop
+ * events on its launch stream (hipExtLaunchKernel: the dispatch's begin/end timestamps, what rocprofv3 --kernel-trace prints).
+ * dasr_prof_end synchronises the device and returns, per launch in issue order: duration in microseconds, the algorithmic
+ * flops / bytes of the op it belongs to (dasr_op.flops / .bytes, attributed to the op's first launch), the op kind and a
+ * static string naming the kernel variant.  Returns the number of records written (<= max_out) or a negative error. */
+int dasr_prof_begin(int32_t capacity);
+int dasr_prof_end(int32_t max_out, float* us_out, double* flops_out, double* bytes_out, int32_t* op_out, const char** tag_out);
+
+/* MFMA-only micro-benchmark (every SIMD issuing back-to-back v_mfma_f32_32x32x16_bf16): the dense bf16 rate this box sustains at
+ * the clock its power state allows, in TFLOP/s; `iters` MFMA quads per wave (e.g. 20000 ~ 1.5 ms).  Synchronises the stream. */
+int dasr_probe_mfma_peak(int32_t iters, float* tflops_out, void* stream);
 
 /* ---- diagnostics ----------------------------------------------------------------------------------*/
 int dasr_abi_version(void);

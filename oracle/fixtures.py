@@ -16,6 +16,9 @@ CASES = OrderedDict([
     ('sr_nf64_nb1_b1_24x40', dict(kind='sr', nf=64, nb=1, n=1, lr=(24, 40))),
     ('dasr_wavelet_nf32_nb2_n2_32', dict(kind='dasr', nf=32, nb=2, n=2, lr=32, fs='wavelet', d_in_nc=9)),
     ('dasr_gau9_nf64_nb1_n1_32', dict(kind='dasr', nf=64, nb=1, n=1, lr=32, fs='gau', d_in_nc=3)),
+    # round 2: the production schedule (batch >= 8 -> two sub-batch streams) and the full ESRGAN depth
+    ('sr_nf64_nb2_b8_32', dict(kind='sr', nf=64, nb=2, n=8, lr=32)),
+    ('sr_nf64_nb23_b2_32', dict(kind='sr', nf=64, nb=23, n=2, lr=32)),
 ])
 
 

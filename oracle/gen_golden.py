@@ -127,11 +127,13 @@ def main():
         sys.exit('reference tree missing; fixtures can only be generated in the build container')
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    for case in fixtures.CASES:
+    only = [a for a in sys.argv[1:] if a in fixtures.CASES]   # `python -m oracle.gen_golden CASE...`: just these (plus nothing else)
+    for case in (only or fixtures.CASES):
         fx = run_reference(case)
         np.savez_compressed(os.path.join(OUT, case + '.npz'), **fx)
         print(case, 'logs', fx['logs'][0])
-    np.savez_compressed(os.path.join(OUT, 'misc_modules.npz'), **misc_reference())
+    if not only:
+        np.savez_compressed(os.path.join(OUT, 'misc_modules.npz'), **misc_reference())
     print('written to', OUT)
 
 

@@ -23,7 +23,7 @@ def _worker(rank, world, port, case, out, streams):
     opt = fixtures.make_opt(case)
     opt['gpu_ids'] = [0]
     m = create_model(options.dict_to_nonedict(opt))
-    kind = fixtures.CASES[case]['kind']
+    kind = (fixtures.CASES[case] if isinstance(case, str) else case)['kind']
     from oracle import nets
     sd = fixtures.seeded_state_dict(m.netG.state_dict(), 1, 0.1)
     m.netG.load_state_dict(sd)
@@ -50,15 +50,21 @@ def _worker(rank, world, port, case, out, streams):
         dp.barrier()
 
 
-@pytest.mark.parametrize('case', ['sr_nf64_nb2_b2_32', 'dasr_wavelet_nf32_nb2_n2_32'])
-def test_two_rank_step_equals_full_batch_step(case, tmp_path):
+B16 = dict(kind='sr', nf=64, nb=2, n=16, lr=32)   # 8 crops per rank -> two sub-batch replicas of 4 under DASR_STREAMS=2
+
+
+@pytest.mark.parametrize('case,streams', [('sr_nf64_nb2_b2_32', 1), ('dasr_wavelet_nf32_nb2_n2_32', 1), (B16, 1), (B16, 2)],
+                         ids=['sr_b2-1stream', 'dasr_n2-1stream', 'sr_b16-1stream', 'sr_b16-2streams'])
+def test_two_rank_step_equals_full_batch_step(case, streams, tmp_path, margins):
+    """streams = 2: the DP x two-sub-batch-stream combination (replica gradient buffers summed, then reduced over the ranks);
+    the single-process side runs the same DASR_STREAMS so that both schedules are compared like for like"""
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     import torch.multiprocessing as mp
     out = str(tmp_path / 'w%d_r%d.pt')
     port = 29611 + (os.getpid() % 300)
-    mp.spawn(_worker, args=(1, port, case, out, 1), nprocs=1, join=True)
-    mp.spawn(_worker, args=(2, port + 1, case, out, 1), nprocs=2, join=True)
+    mp.spawn(_worker, args=(1, port, case, out, streams), nprocs=1, join=True)
+    mp.spawn(_worker, args=(2, port + 1, case, out, streams), nprocs=2, join=True)
     full = torch.load(out % (1, 0))
     r0, r1 = torch.load(out % (2, 0)), torch.load(out % (2, 1))
     for net in [k for k in ('G', 'D') if k in full]:
@@ -67,6 +73,55 @@ def test_two_rank_step_equals_full_batch_step(case, tmp_path):
             d = (r0[net][k] - v).abs().max().item()
             assert d <= 3.2e-4, (net, k, d)                      # Adam: sign flips of ~0 gradients move a weight by 2*lr
             assert ((r0[net][k] - v).abs() > 2e-5).float().mean().item() < 0.02, (net, k)
+    dmax = max((r0[n_][k] - v).abs().max().item() for n_ in full if n_ in ('G', 'D') for k, v in full[n_].items())
+    margins('DP 2 ranks vs full batch (%s, %d streams): max |dw| after 2 Adam steps %.2e (bound 3.2e-4)' % (
+        case if isinstance(case, str) else 'sr_nf64_nb2_b16_32', streams, dmax))
+
+
+def _rccl_worker(rank, port, out, streams, use_dp):
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DASR_STREAMS=str(streams))
+    import torch
+    from oracle import fixtures
+    from dasr_amd import options
+    from dasr_amd.dist import DataParallelGroup
+    from dasr_amd.models import create_model
+    torch.cuda.set_device(0)
+    opt = fixtures.make_opt(B16)
+    opt['gpu_ids'] = [0]
+    m = create_model(options.dict_to_nonedict(opt))
+    m.netG.load_state_dict(fixtures.seeded_state_dict(m.netG.state_dict(), 1, 0.1))
+    if use_dp:
+        m.dp = DataParallelGroup(backend='nccl', force=True)   # a real RCCL communicator of one rank
+        assert m.dp.comm_stream is not None
+        m.dp.broadcast_params(m.netG.params.flat)
+    batch = fixtures.make_batch(B16)
+    for step in (1, 2):
+        m.update_learning_rate()
+        m.feed_data(batch)
+        m.optimize_parameters(step)
+    torch.cuda.synchronize()
+    torch.save({'G': m.netG.state_dict(), 'l_pix': m.get_current_log()['l_pix']}, out % int(use_dp))
+    if use_dp:
+        m.dp.barrier()
+        assert m.dp.max_over_ranks(1.5) == 1.5
+
+
+@pytest.mark.parametrize('streams', [1, 2])
+def test_rccl_exchange_path_single_rank(streams, tmp_path):
+    """The RCCL code path (backend 'nccl': communication stream, bucket events, all-reduce enqueued behind the boundary events of
+    both replica streams) executed for real on this one-GPU box with a communicator of ONE rank (RCCL refuses two ranks on one
+    device).  The exchange is the identity, so the step must reproduce the no-DP step bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'rccl_%d.pt')
+    port = 29411 + (os.getpid() % 300) + streams
+    mp.spawn(_rccl_worker, args=(port, out, streams, False), nprocs=1, join=True)
+    mp.spawn(_rccl_worker, args=(port, out, streams, True), nprocs=1, join=True)
+    a, b = torch.load(out % 0), torch.load(out % 1)
+    assert a['l_pix'] == b['l_pix']
+    for k, v in a['G'].items():
+        assert torch.equal(v, b['G'][k]), k
 
 
 def _dsn_worker(rank, world, port, out):

@@ -1,0 +1,189 @@
+"""Full-size checks of the configs[2] (full SRN GAN step, 32 G-crops @128x128 -> 512x512) and configs[4] (DSN, 256x256 crops)
+kernels at their real spatial sizes, where the CPU oracle would take minutes.  Size-independent properties for the MFMA kernels
+(the operator is linear in x and in W):
+  * adjointness:   <conv_W(x), g> == <x, dgrad_W(g)>   (stride-2 4x4: the data-gradient is four 2x2 parity sub-convolutions)
+  * wgrad pairing: <conv_W'(x), g> == <W', wgrad(x, g)> for a random direction W'
+  * linearity:     conv(2 x) == 2 conv(x)
+and direct fp64 restatements with plain tensor arithmetic on the device for the HBM-bound kernels (InstanceNorm + LeakyReLU over
+16 384-element planes, Haar DWT at 512x512 and its adjoint).
+Shapes: VGG19 conv1_2 / HR_conv0 64->64 @512^2 (architecture.py:1060-1088, :174-205); patch-D conv 4x4 s2 9->64 @256^2 and 64->128
+@128^2 (architecture.py:983-1024); InstanceNorm over 128 ch @128^2 (gaussian fs: 16 129..16 384 elements per plane); De_resnet
+64->64 @256^2 (codes/DSN/model.py:25-55); FSD 5x5 64->128 @64^2 (codes/DSN/model.py:173-210)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from dasr_amd import engine
+    engine.ensure_runtime_ready()
+    return torch.device('cuda')
+
+
+def _dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+CASES = [
+    # id, cin, cout, kh, stride, pad, N, H, W (input size)
+    ('vgg_conv1_2_hr_conv0_512', 64, 64, 3, 1, 1, 2, 512, 512),
+    ('dsn_resblock_256', 64, 64, 3, 1, 1, 4, 256, 256),
+    ('patchD_k4s2_9to64_256', 9, 64, 4, 2, 1, 4, 256, 256),
+    ('patchD_k4s2_64to128_128', 64, 128, 4, 2, 1, 4, 128, 128),
+    ('patchD_k4s1_128to256_64', 128, 256, 4, 1, 1, 2, 64, 64),
+    ('fsd_k5_64to128_64', 64, 128, 5, 1, 2, 8, 64, 64),
+    ('dsn_down_k3s2_256', 64, 64, 3, 2, 1, 4, 256, 256),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_split_bf16_conv_adjoint_wgrad_linearity_fullsize(case, margins):
+    dev = _gpu()
+    from dasr_amd.engine import BTensor, ParamStore, PackRegistry, OpList, WgradGroup, Workspace, conv_op, ceil_div
+    from dasr_amd.gan_nets import _PARITY_TAPS, _PARITY_PAD
+    name, cin, cout, kh, stride, pad, N, H, W = case
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kh) // stride + 1
+    g = torch.Generator(device='cuda').manual_seed(1)
+    P = ParamStore([('w', (cout, cin, kh, kh)), ('w2', (cout, cin, kh, kh)), ('b', (cout,))], dev)
+    P.view('w').copy_(torch.randn(cout, cin, kh, kh, device=dev, generator=g) * 0.05)
+    P.view('w2').copy_(torch.randn(cout, cin, kh, kh, device=dev, generator=g) * 0.05)
+    pack = PackRegistry(P)
+    cin_pad, cb = ceil_div(cin, 16) * 16, ceil_div(cout, 16) * 16
+    nt = kh * kh
+    fw = pack.add(cout, cin_pad, nt, 1, 3, [(P.off('w'), cout, cin, 0, cin, 0, 0)])
+    fw2 = pack.add(cout, cin_pad, nt, 1, 3, [(P.off('w2'), cout, cin, 0, cin, 0, 0)])
+    if stride == 1:
+        bw = pack.add(cin, cb, nt, 1, 3, [(P.off('w'), cout, cin, 0, cout, 0, 1)])
+    elif kh == 4:
+        bw = {(py, px): pack.add(cin, cb, 4, 1, 3, [(P.off('w'), cout, cin, 0, cout, 0, 1)],
+                                 tapmap=[_PARITY_TAPS[py][a] * 4 + _PARITY_TAPS[px][b] for a in (0, 1) for b in (0, 1)], src_ntaps=16)
+              for py in (0, 1) for px in (0, 1)}
+    else:
+        bw = None   # 3x3 stride 2 (De_resnet down-sampling): forward + weight gradient only here (its dgrad is covered in test_gpu_dsn)
+    pack.finalize()
+    pack.run()
+    x, gy = BTensor(N, cin_pad, H, W, True, dev), BTensor(N, cb, Ho, Wo, True, dev)
+    x.t.copy_(torch.randn(x.t.shape, device=dev, generator=g))
+    gy.t.copy_(torch.randn(gy.t.shape, device=dev, generator=g))
+    if cin_pad != cin:   # padded input channels must be zero (the layout contract)
+        x.t.view(N, -1, H, W, 16)[:, -1, :, :, cin % 16:] = 0
+    if cb != cout:
+        gy.t.view(N, -1, Ho, Wo, 16)[:, -1, :, :, cout % 16:] = 0
+    y, y2, ya = (BTensor(N, cb, Ho, Wo, True, dev) for _ in range(3))
+    gx = BTensor(N, cin_pad, H, W, True, dev)
+    ops = OpList()
+    ops.add(conv_op(pack, fw, x.view(), True, cin_pad, H, W, Ho, Wo, N, kh=kh, stride=stride, pad=pad, out_f32=y.view()))
+    ops.add(conv_op(pack, fw2, x.view(), True, cin_pad, H, W, Ho, Wo, N, kh=kh, stride=stride, pad=pad, out_f32=y2.view()))
+    if stride == 1:
+        ops.add(conv_op(pack, bw, gy.view(), True, cb, Ho, Wo, H, W, N, kh=kh, stride=1, pad=kh - 1 - pad, out_f32=gx.view()))
+    elif bw is not None:
+        for (py, px), ref in bw.items():
+            ops.add(conv_op(pack, ref, gy.view(), True, cb, Ho, Wo, (H - py + 1) // 2, (W - px + 1) // 2, N, kh=2, stride=1, pad=_PARITY_PAD[py],
+                            pad_x=_PARITY_PAD[px], out_f32=gx.view(), out_stride=2, out_oy=py, out_ox=px, out_W=W))
+    ws = Workspace(dev)
+    grp = WgradGroup(kh, stride)
+    grp.add_conv(gy.view, True, gy.planes, x.view, True, x.planes, cout, cin, H, W, Ho, Wo, N, P.off('w'), P.off('b'), pad=pad)
+    grp.finalize(ws, dev)
+    for o in grp.ops(P.grad.data_ptr()):
+        ops.add(o)
+    ws.finalize()
+    ops.run()
+    torch.cuda.synchronize()
+    msg = name
+    if bw is not None:
+        # split-bf16 forward and data-gradient are both ~fp32.  <y, g> of independent random tensors is ~ |y||g| / sqrt(n): the tolerance is
+        # a fraction of THAT, so that a wrong tap or a wrong border row (which only moves the sum by its share of the pixels) is seen
+        def adjoint_err():
+            lhs, rhs = _dot(y.t, gy.t), _dot(x.t, gx.t)
+            typ = float(y.t.double().norm() * gy.t.double().norm()) / float(gy.t.numel()) ** 0.5
+            return abs(lhs - rhs) / typ
+        e_all = adjoint_err()
+        # second direction: g supported on a 3-pixel frame of the image only -> only halo / partial-tile code paths contribute
+        frame = torch.zeros((1, 1, Ho, Wo, 1), device=dev)
+        frame[:, :, :3], frame[:, :, -3:], frame[:, :, :, :3], frame[:, :, :, -3:] = 1, 1, 1, 1
+        gy.t.mul_(frame)
+        ops.run()
+        torch.cuda.synchronize()
+        e_frame = adjoint_err()
+        msg += ': adjoint err / typical |<y,g>|: %.1e all pixels, %.1e border frame (tol 3e-3)' % (e_all, e_frame)
+        assert e_all <= 3e-3 and e_frame <= 3e-3, (e_all, e_frame)
+    # <conv_{w2}(x), g> == <w2, dW>: the weight gradient rounds x and g to bf16 while staging (documented), the forward does not
+    lhs2, rhs2 = _dot(y2.t, gy.t), _dot(P.view('w2'), P.view('w', P.grad))
+    scale2 = float(y2.t.double().norm() * gy.t.double().norm())
+    msg += '; wgrad pairing err / (|y||g|) = %.2e (tol 5e-3)' % (abs(lhs2 - rhs2) / scale2)
+    assert abs(lhs2 - rhs2) <= 5e-3 * scale2, (lhs2, rhs2, scale2)
+    bsum = gy.nchw(cout).sum(dim=(0, 2, 3))
+    assert torch.allclose(P.view('b', P.grad), bsum, rtol=1e-4, atol=1e-3 * float(bsum.abs().max()) + 1e-3)
+    margins(msg)
+    # linearity in x
+    x.t.mul_(2)
+    ops2 = OpList()
+    ops2.add(conv_op(pack, fw, x.view(), True, cin_pad, H, W, Ho, Wo, N, kh=kh, stride=stride, pad=pad, out_f32=ya.view()))
+    ops2.run()
+    torch.cuda.synchronize()
+    assert float((ya.t - 2 * y.t).abs().max()) <= 1e-5 * float(y.t.abs().max())
+
+
+@pytest.mark.parametrize('C_,H,W', [(128, 128, 128), (128, 127, 127), (256, 63, 63)])
+def test_instance_norm_lrelu_fullsize(C_, H, W, margins):
+    """InstanceNorm2d(affine=False, eps 1e-5) + LeakyReLU(0.2) forward and backward on planes of up to 16 384 elements (the patch
+    discriminator under the gaussian frequency split, architecture.py:1003-1015) against an fp64 restatement on the device"""
+    dev = _gpu()
+    import ctypes as C
+    from dasr_amd import _lib
+    from dasr_amd.engine import BTensor, _stream
+    L = _lib.lib()
+    N = 4
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x, y, ga, gx = (BTensor(N, C_, H, W, True, dev) for _ in range(4))
+    x.t.copy_(torch.randn(x.t.shape, device=dev, generator=g) * 3 + 1)
+    ga.t.copy_(torch.randn(ga.t.shape, device=dev, generator=g))
+    stats = torch.zeros(N * C_ * 2, dtype=torch.float32, device=dev)
+    _lib.check(L.dasr_inorm_lrelu_fwd(x.view(), N, C_, H, W, 1e-5, 0.2, y.view(), stats.data_ptr(), _stream()))
+    _lib.check(L.dasr_inorm_lrelu_bwd(y.view(), ga.view(), N, C_, H, W, 0.2, stats.data_ptr(), gx.view(), _stream()))
+    torch.cuda.synchronize()
+    xd = x.nchw().double().requires_grad_(True)
+    mu = xd.mean(dim=(2, 3), keepdim=True)
+    var = ((xd - mu) ** 2).mean(dim=(2, 3), keepdim=True)
+    z = (xd - mu) / torch.sqrt(var + 1e-5)
+    ref = torch.where(z > 0, z, 0.2 * z)
+    ref.backward(ga.nchw().double())
+    e_f = float((y.nchw().double() - ref.detach()).norm() / ref.detach().norm())
+    e_b = float((gx.nchw().double() - xd.grad).norm() / xd.grad.norm())
+    margins('instance norm + lrelu %dx%dx%d: fwd rel err %.2e, bwd rel err %.2e (tol 1e-5 / 1e-4)' % (C_, H, W, e_f, e_b))
+    assert e_f < 1e-5 and e_b < 1e-4
+
+
+def test_haar_dwt_fullsize(margins):
+    """Haar level-1 DWT of 512x512 images (DASR_model.py:442-452) and its adjoint: direct restatement + dot-product test"""
+    dev = _gpu()
+    from dasr_amd import _lib
+    from dasr_amd.engine import BTensor, _stream, NULL_T
+    L = _lib.lib()
+    N, H2, W2 = 4, 256, 256
+    g = torch.Generator(device='cuda').manual_seed(6)
+    x, gx = BTensor(N, 16, 2 * H2, 2 * W2, True, dev), BTensor(N, 16, 2 * H2, 2 * W2, True, dev)
+    ll, hc, gll, ghc = BTensor(N, 16, H2, W2, True, dev), BTensor(N, 16, H2, W2, True, dev), BTensor(N, 16, H2, W2, True, dev), BTensor(N, 16, H2, W2, True, dev)
+    x.t[..., :3] = torch.rand((N, 1, 2 * H2, 2 * W2, 3), device=dev, generator=g)
+    gll.t[..., :3] = torch.randn((N, 1, H2, W2, 3), device=dev, generator=g)
+    ghc.t[..., :9] = torch.randn((N, 1, H2, W2, 9), device=dev, generator=g)
+    for norm in (0, 1):
+        _lib.check(L.dasr_dwt_fwd(x.view(), N, 3, H2, W2, norm, ll.view(), hc.view(), _stream()))
+        _lib.check(L.dasr_dwt_bwd(gll.view(), ghc.view(), N, 3, H2, W2, norm, gx.view(), 0, _stream()))
+        torch.cuda.synchronize()
+        xi = x.nchw(3).double()
+        a, b, c, d = xi[:, :, 0::2, 0::2], xi[:, :, 0::2, 1::2], xi[:, :, 1::2, 0::2], xi[:, :, 1::2, 1::2]
+        LL, LH, HL, HH = (a + b + c + d) / 2, (a + b - c - d) / 2, (a - b + c - d) / 2, (a - b - c + d) / 2   # oracle/nets.py::HaarDWT
+        Hc = torch.cat([LH, HL, HH], 1)
+        if norm:
+            LL, Hc = LL * 0.5, Hc * 0.5 + 0.5
+        assert float((ll.nchw(3).double() - LL).abs().max()) < 1e-6 and float((hc.nchw(9).double() - Hc).abs().max()) < 1e-6
+        # adjoint of the LINEAR part (the +0.5 offset of the normalised high band has no gradient)
+        lin_ll, lin_hc = ll.nchw(3).double(), hc.nchw(9).double() - (0.5 if norm else 0.0)
+        lhs = _dot(lin_ll, gll.nchw(3)) + _dot(lin_hc, ghc.nchw(9))
+        rhs = _dot(x.nchw(3), gx.nchw(3))
+        margins('haar dwt 512x512 norm=%d: adjoint rel err %.2e (tol 1e-6)' % (norm, abs(lhs - rhs) / max(abs(lhs), 1.0)))
+        assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), abs(rhs), 1.0)

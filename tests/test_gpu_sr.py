@@ -25,6 +25,9 @@ def rel(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
 
 
+TAP_RRDBS = (0, 11, 22)   # RRDB outputs compared at full depth (nb = 23)
+
+
 def _oracle_run(case, steps=2):
     from oracle import fixtures, nets, trainers
     c = fixtures.CASES[case]
@@ -41,6 +44,7 @@ def _oracle_run(case, steps=2):
         return f
 
     hs = [netG.model[0].register_forward_hook(hook('fea')), netG.model[1].register_forward_hook(hook('trunk'))]
+    hs += [netG.model[1].sub[i].register_forward_hook(hook('rrdb%d' % i)) for i in TAP_RRDBS if i < c['nb']]
     out = {'sd0': sd0, 'batch': batch, 'logs': []}
     for step in range(1, steps + 1):
         t.update_learning_rate()
@@ -57,8 +61,11 @@ def _oracle_run(case, steps=2):
     return out
 
 
-@pytest.mark.parametrize('case', ['sr_nf64_nb1_b1_24x40', 'sr_nf64_nb2_b2_32', 'cfg1_sr_nf32_nb4_b2_64'])
-def test_sr_step_matches_oracle_and_reference_fixture(case, golden_dir):
+# sr_nf64_nb2_b8_32: batch 8 -> the PRODUCTION schedule (two sub-batch replicas on two streams, run_interleaved, private replica
+# gradient buffer + add_flat; SR_model.py:77-85 is the reference step).  sr_nf64_nb23_b2_32: the full ESRGAN depth
+# (architecture.py:174-205), RRDB outputs 0 / 11 / 22 tapped in fp32.
+@pytest.mark.parametrize('case', ['sr_nf64_nb1_b1_24x40', 'sr_nf64_nb2_b2_32', 'cfg1_sr_nf32_nb4_b2_64', 'sr_nf64_nb2_b8_32', 'sr_nf64_nb23_b2_32'])
+def test_sr_step_matches_oracle_and_reference_fixture(case, golden_dir, margins):
     dev = _gpu()
     torch.set_num_threads(8)
     from oracle import fixtures
@@ -69,6 +76,7 @@ def test_sr_step_matches_oracle_and_reference_fixture(case, golden_dir):
     opt['gpu_ids'] = [0]
     m = create_model(options.dict_to_nonedict(opt))
     m.netG.load_state_dict(want['sd0'])
+    m.netG.debug_taps = tuple(i for i in TAP_RRDBS if i < fixtures.CASES[case]['nb'])
     gold = np.load(os.path.join(golden_dir, case + '.npz'))
     logs = []
     for step in (1, 2):
@@ -77,30 +85,44 @@ def test_sr_step_matches_oracle_and_reference_fixture(case, golden_dir):
         m.optimize_parameters(step)
         logs.append(m.get_current_log()['l_pix'])
         if step == 1:
-            plan = m.netG.plan(*want['batch']['LR'].shape[0:1], *want['batch']['LR'].shape[2:])
+            plans = m._out_plans
+            assert len(plans) == (2 if fixtures.CASES[case]['n'] >= 8 else 1)   # batch >= 8: the two-stream schedule really ran
+            cat = lambda f: torch.cat([f(p).cpu() for p in plans], 0)
             # activations
-            assert rel(plan.fea.nchw().cpu(), want['taps']['fea']) < ACT_TOL
-            assert rel(plan.t0.nchw().cpu(), want['taps']['trunk']) < ACT_TOL
-            assert rel(m.fake_H.cpu(), want['sr']) < ACT_TOL
+            errs = {'fea': rel(cat(lambda p: p.fea.nchw()), want['taps']['fea']), 'trunk': rel(cat(lambda p: p.t0.nchw()), want['taps']['trunk']),
+                    'sr': rel(m.fake_H.cpu(), want['sr'])}
+            for i in m.netG.debug_taps:
+                errs['rrdb%d' % i] = rel(cat(lambda p: p.taps[i].nchw()), want['taps']['rrdb%d' % i])
+            margins('%s activations: %s (tol %.0e)' % (case, ' '.join('%s %.2e' % kv for kv in errs.items()), ACT_TOL))
+            for k, e in errs.items():
+                assert e < ACT_TOL, (k, e)
             # gradients, per parameter tensor
             gd = m.netG.params.grad_dict()
-            worst = 0.0
+            worst, wk = 0.0, None
             for (k, gv), gw in zip(gd.items(), want['grads']):
                 r = rel(gv, gw)
-                worst = max(worst, r)
-                assert r < GRAD_TOL, (k, r)
-            print('%s: worst grad rel err %.2e' % (case, worst))
+                if r > worst:
+                    worst, wk = r, k
+            margins('%s gradients: worst normwise rel err %.2e at %s (tol %.0e, %d tensors)' % (case, worst, wk, GRAD_TOL, len(gd)))
+            assert worst < GRAD_TOL, (wk, worst)
             # against the REFERENCE's own numbers
             np.testing.assert_allclose(np.array([float(g.double().norm()) for g in gd.values()]), gold['gradG_norm'], rtol=GRAD_TOL)
+            for i in m.netG.debug_taps:
+                got_n = float(cat(lambda p: p.taps[i].nchw()).double().norm())
+                np.testing.assert_allclose(got_n, float(gold['tap_norm/trunk_%d' % i]), rtol=ACT_TOL)
     np.testing.assert_allclose(logs, want['logs'], rtol=1e-4)
     np.testing.assert_allclose(logs, gold['logs'][:, 0], rtol=1e-4)
-    # weights after 2 Adam steps: Adam normalises the update, so compare the *update* direction loosely and
-    # the weights tightly
+    # weights after 2 Adam steps: Adam normalises the update (a sign flip of a ~0 gradient moves a weight by 2*lr), so the bound is
+    # absolute; the worst observed values are logged so the margin stays visible
     sdN = m.netG.state_dict()
+    dmax, frac = 0.0, 0.0
     for k, v in sdN.items():
         d = (v - want['sdN'][k]).abs()
-        assert float(d.max()) <= 3.2e-4, k  # Adam normalises: a sign flip of a ~0 gradient moves a weight by 2*lr
+        dmax, frac = max(dmax, float(d.max())), max(frac, float((d > 2e-5).float().mean()))
+        assert float(d.max()) <= 3.2e-4, k
         assert float((d > 2e-5).float().mean()) < 0.02, (k, float((d > 2e-5).float().mean()))
+    margins('%s weights after 2 Adam steps: max |dw| %.2e (bound 3.2e-4 = 2 steps x 2 lr... lr 1e-4), worst fraction of elements off by > 2e-5: %.4f (bound 0.02)'
+            % (case, dmax, frac))
 
 
 def test_checkpoint_layout_roundtrip(tmp_path):
