@@ -66,7 +66,7 @@ def make_opt(nf, nb):
 # ---------------------------------------------------------------------------------------------------------------------------
 # roofline: per-kernel durations of one production step
 # ---------------------------------------------------------------------------------------------------------------------------
-_KNAME = {'launch_glds': 'conv_glds_kernel', 'launch': 'conv_kernel', 'launch_wgrad': 'wgrad_kernel', 'launch_wgrad3': 'wgrad3_kernel'}
+_KNAME = {'launch_glds': 'conv_glds_kernel', 'launch_ring3': 'conv_ring3_kernel', 'launch': 'conv_kernel', 'launch_wgrad': 'wgrad_kernel', 'launch_wgrad3': 'wgrad3_kernel'}
 
 
 def kernel_name(tag):

@@ -23,7 +23,7 @@ class ConvParams(C.Structure):
                 ('alpha', c_f32), ('res1', Tensor), ('beta1', c_f32), ('res2', Tensor), ('beta2', c_f32),
                 ('out_f32', Tensor), ('out_bf16', Tensor), ('gamma', c_f32), ('xcd_remap', c_i32),
                 ('pad_x', c_i32), ('out_stride', c_i32), ('out_oy', c_i32), ('out_ox', c_i32), ('out_W', c_i32), ('slope_ptr', c_vp),
-                ('in_stride', c_i32), ('in_oy', c_i32), ('in_ox', c_i32), ('in_W', c_i32)]
+                ('in_stride', c_i32), ('in_oy', c_i32), ('in_ox', c_i32), ('in_W', c_i32), ('in_scale', c_f32)]
 
 
 class WgradPart(C.Structure):
@@ -31,7 +31,7 @@ class WgradPart(C.Structure):
                 ('g_planes', c_i32), ('in_planes', c_i32),
                 ('Hin', c_i32), ('Win', c_i32), ('Hout', c_i32), ('Wout', c_i32), ('N', c_i32),
                 ('kh', c_i32), ('stride', c_i32), ('pad', c_i32), ('want_bias', c_i32),
-                ('ws_off', c_i64), ('ws_bias_off', c_i64), ('tap0', c_i32)]
+                ('ws_off', c_i64), ('ws_bias_off', c_i64), ('tap0', c_i32), ('g_scale', c_f32)]
 
 
 class WgradReducePart(C.Structure):
@@ -48,7 +48,7 @@ class PackSeg(C.Structure):
 
 class PackDesc(C.Structure):
     _fields_ = [('dst_off', c_i64), ('lo_off', c_i64), ('cout', c_i32), ('cin_pad', c_i32), ('ntaps', c_i32), ('mt', c_i32),
-                ('nseg', c_i32), ('src_ntaps', c_i32), ('tapmap', C.c_int8 * 32), ('tapmask', C.c_uint16 * 16), ('seg', PackSeg * 5)]
+                ('nseg', c_i32), ('src_ntaps', c_i32), ('fmt', c_i32), ('tapmap', C.c_int8 * 32), ('tapmask', C.c_uint16 * 16), ('seg', PackSeg * 5)]
 
 
 class CropDesc(C.Structure):
@@ -109,7 +109,7 @@ _SIGS = {
     'dasr_prof_end': [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 
@@ -135,6 +135,10 @@ def lib():
             fn.restype = c_vp if name == 'dasr_event_create' else c_i32
         if L.dasr_abi_version() != ABI_VERSION:
             raise DasrHipError('libdasr_hip.so ABI %d != binding ABI %d; rebuild' % (L.dasr_abi_version(), ABI_VERSION))
+        for kv in [x for x in os.environ.get('DASR_TUNE', '').split(',') if x]:   # A/B of kernel variants without code changes: DASR_TUNE="1=14,2=12"
+            k, v = kv.split('=')
+            if L.dasr_set_tuning(int(k), int(v)) != 0:
+                raise DasrHipError('DASR_TUNE: bad tuning key/value %r' % kv)
         _lib = L
     return _lib
 

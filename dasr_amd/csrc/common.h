@@ -9,6 +9,9 @@ typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -30,6 +33,13 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float v) { return (bf16_t)v; }
 __device__ __forceinline__ void split_bf16(float v, bf16_t& hi, bf16_t& lo) {
     hi = (bf16_t)v;
     lo = (bf16_t)(v - (float)hi);
+}
+
+// one MFMA k-step (32 x 32 x 16) on 16-bit operand fragments held as bf16x8 bit patterns: F16 selects the f16 instruction
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

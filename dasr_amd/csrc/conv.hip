@@ -11,6 +11,7 @@
 // prec 3 ("split bf16"): x = hi + lo with hi = bf16(x), lo = bf16(x - hi); hi*hi + hi*lo + lo*hi
 // gives ~2^-17 relative operand error with three bf16 MFMAs (16x faster than the f32 MFMA).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -109,6 +110,9 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
     // before the arithmetic and stores of group g (two register sets), so only the first group's load latency is exposed;
     // the 64-channel kernel with two residuals has no registers left for that and loads just in time.
     constexpr int NG = NT * MT;
+    // bf16 tensors of the specialised variants move 16 bytes per lane (v_permlane32_swap pairs the two half-waves' 4-channel groups):
+    // half the VMEM instructions of the epilogue, each covering one contiguous KiB (the store tail is issue-bound, not bandwidth-bound)
+    constexpr bool WIDE16 = !G && !IN_F32;
     constexpr bool PIPE_EPI = !G && !(MT == 2 && (EPI & 16)) && (EPI & (4 | 8 | 16));
     u32x4 mk[2][4], r1v[2][4], r2v[2][4];
     auto group_addr = [&](int gi, unsigned (&eo)[4], unsigned (&cbv)[4]) {
@@ -136,14 +140,24 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
         unsigned eo[4], cbv[4];
         group_addr(gi, eo, cbv);
         if (has_mask) {
+            if constexpr (WIDE16) {
+                // one 16-byte load per lane and 16-channel plane: lanes 0-31 fetch channels 0-7, lanes 32-63 channels 8-15 of their pixel
+                // (a fully contiguous KiB per instruction); the half-wave exchange back to the MFMA D layout happens after the wait
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const unsigned mo = eo[g] != OOB ? (cbv[g] * mask_cb + eo[g]) * MSZ : OOB;
-                if constexpr (IN_F32) {
-                    mk[slot][g] = __builtin_amdgcn_raw_buffer_load_b128(rmask, mo, 0, 0);
-                } else {
-                    const u32x2 t2 = __builtin_amdgcn_raw_buffer_load_b64(rmask, mo, 0, 0);
-                    mk[slot][g] = u32x4{t2[0], t2[1], 0u, 0u};  // unpacked after the wait
+                for (int pr = 0; pr < 2; ++pr) {
+                    const unsigned mo = eo[2 * pr] != OOB ? (cbv[2 * pr] * mask_cb + eo[2 * pr] + 4u * kh2) * 2u : OOB;
+                    mk[slot][2 * pr] = __builtin_amdgcn_raw_buffer_load_b128(rmask, mo, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned mo = eo[g] != OOB ? (cbv[g] * mask_cb + eo[g]) * MSZ : OOB;
+                    if constexpr (IN_F32) {
+                        mk[slot][g] = __builtin_amdgcn_raw_buffer_load_b128(rmask, mo, 0, 0);
+                    } else {
+                        const u32x2 t2 = __builtin_amdgcn_raw_buffer_load_b64(rmask, mo, 0, 0);
+                        mk[slot][g] = u32x4{t2[0], t2[1], 0u, 0u};  // unpacked after the wait
+                    }
                 }
             }
         }
@@ -194,6 +208,16 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                     for (int j = 0; j < 4; ++j) v[g][j] = __frcp_rn(1.f + __expf(-v[g][j]));
             }
             if (has_mask) {
+                if constexpr (WIDE16) {   // wide piece {w0 w1 | w2 w3} -> this lane's two 4-channel groups of the plane
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const u32x4 w = mk[slot][2 * pr];
+                        const auto r0 = __builtin_amdgcn_permlane32_swap(w[0], w[2], false, false);
+                        const auto r1 = __builtin_amdgcn_permlane32_swap(w[1], w[3], false, false);
+                        mk[slot][2 * pr] = u32x4{r0[0], r1[0], 0u, 0u};
+                        mk[slot][2 * pr + 1] = u32x4{r0[1], r1[1], 0u, 0u};
+                    }
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -236,7 +260,23 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                     __builtin_amdgcn_raw_buffer_store_b128(o, rof, eo[g] != OOB ? (cbv[g] * of_cb + eo[g]) * 4u : OOB, 0, 0);
                 }
             }
-            if (has_bf16) {
+            if (has_bf16 && WIDE16) {
+                const bool gm = scaled && p.gamma != 1.f;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    bf16x4 oa, ob;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        oa[j] = (bf16_t)(gm ? v[2 * pr][j] * p.gamma : v[2 * pr][j]);
+                        ob[j] = (bf16_t)(gm ? v[2 * pr + 1][j] * p.gamma : v[2 * pr + 1][j]);
+                    }
+                    const u32x2 a = __builtin_bit_cast(u32x2, oa), b = __builtin_bit_cast(u32x2, ob);
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+                    const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};   // lanes 0-31: channels 0-7 of the plane, lanes 32-63: channels 8-15
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rob, eo[2 * pr] != OOB ? (cbv[2 * pr] * ob_cb + eo[2 * pr] + 4u * kh2) * 2u : OOB, 0, 0);
+                }
+            } else if (has_bf16) {
                 const bool gm = scaled && p.gamma != 1.f;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -293,6 +333,8 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
     const int HL = p.ups ? 2 * p.Hin : p.Hin, WL = p.ups ? 2 * p.Win : p.Win;
     const int nchunks = p.cin / (16 * KS);
     constexpr int ESZ = IN_F32 ? 4 : 2;
+    static_assert(PREC != 2 || IN_F32, "prec 2 (f16 operands) converts an f32 input while staging");
+    const float in_sc = (PREC == 2 && p.in_scale != 0.f) ? p.in_scale : 1.f;
     // bias of this m-group: one value per thread of the first 32*MT, consumed in the epilogue (latency hidden by the main loop)
     float bias_reg = 0.f;
     {
@@ -368,7 +410,12 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     bf16_t h, l;
-                    split_bf16(__uint_as_float(areg[r][j]), h, l);
+                    if constexpr (PREC == 2) {   // one rounding to f16 (11-bit mantissa) of the pre-scaled value
+                        h = __builtin_bit_cast(bf16_t, (f16_t)(__uint_as_float(areg[r][j]) * in_sc));
+                        l = h;
+                    } else {
+                        split_bf16(__uint_as_float(areg[r][j]), h, l);
+                    }
                     hi[j] = h;
                     lo[j] = l;
                 }
@@ -435,13 +482,13 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
                         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ky][mi], brow[nt + ky], acc[mi][nt], 0, 0, 0);
+                                acc[mi][nt] = mfma16<PREC == 2>(a[ky][mi], brow[nt + ky], acc[mi][nt]);
                 }
             }
             return;
         }
         if constexpr (PIPE) return;  // (PIPE uses compute_store below)
-        if constexpr (PREC == 1 && !IN_F32) {
+        if constexpr ((PREC == 1 && !IN_F32) || (PREC == 2 && MT == 1)) {
             // software pipeline over taps: the fragments of tap t+1 are requested from LDS before the MFMAs of tap t are issued
             // (two register sets), so an MFMA never waits on a ds_read issued just ahead of it (hipcc's own schedule reads
             // just-in-time: lgkmcnt(1) before every MFMA pair, ~130 cycles per MFMA instead of 32)
@@ -465,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
                 for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[idx & 1][mi], fb[idx & 1][nt], acc[mi][nt], 0, 0, 0);
+                        acc[mi][nt] = mfma16<PREC == 2>(fa[idx & 1][mi], fb[idx & 1][nt], acc[mi][nt]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             return;
@@ -498,9 +545,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
                 for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[idx & 1][mi], fb[idx & 1][nt], acc[mi][nt], 0, 0, 0);
-                        acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[idx & 1][mi], fbl[idx & 1][nt], acc[mi][nt], 0, 0, 0);
-                        acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[idx & 1][mi], fb[idx & 1][nt], acc[mi][nt], 0, 0, 0);
+                        acc[mi][nt] = mfma16<PREC == 2>(fal[idx & 1][mi], fb[idx & 1][nt], acc[mi][nt]);
+                        acc[mi][nt] = mfma16<PREC == 2>(fa[idx & 1][mi], fbl[idx & 1][nt], acc[mi][nt]);
+                        acc[mi][nt] = mfma16<PREC == 2>(fa[idx & 1][mi], fb[idx & 1][nt], acc[mi][nt]);
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -528,10 +575,10 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         if constexpr (PREC == 3) {
-                            acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], b[nt], acc[mi][nt], 0, 0, 0);
-                            acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], bl[nt], acc[mi][nt], 0, 0, 0);
+                            acc[mi][nt] = mfma16<PREC == 2>(al[mi], b[nt], acc[mi][nt]);
+                            acc[mi][nt] = mfma16<PREC == 2>(a[mi], bl[nt], acc[mi][nt]);
                         }
-                        acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[nt], acc[mi][nt], 0, 0, 0);
+                        acc[mi][nt] = mfma16<PREC == 2>(a[mi], b[nt], acc[mi][nt]);
                     }
             }
         }
@@ -563,7 +610,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
             for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[idx & 1][mi], fb[idx & 1][nt], acc[mi][nt], 0, 0, 0);
+                    acc[mi][nt] = mfma16<PREC == 2>(fa[idx & 1][mi], fb[idx & 1][nt], acc[mi][nt]);
             // the NP staged pieces of the next chunk are spread over the taps
 #pragma unroll
             for (int i = idx * NP / TOT; i < (idx + 1) * NP / TOT; ++i) store_piece(nbuf, ar, wr, i);
@@ -627,6 +674,15 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
     }
     }
     TRACE_STAMP(4);
+    if constexpr (PREC == 2) {
+        if (in_sc != 1.f) {   // undo the operand pre-scaling (exact: power of two)
+            const float inv = 1.f / in_sc;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mi][nt] *= inv;
+        }
+    }
 
     conv_epilogue<IN_F32, MT, NT, STRIDE, EPI>(p, acc, smem, bias_reg, tid, mg, n, oy0, ox0);
     TRACE_STAMP(6);  // all stores issued
@@ -681,7 +737,9 @@ __device__ __forceinline__ void glds_dma_piece(int i, int ck, char* buf, __amdgp
     }
 }
 
-template <int MT, int EPI, int NW>
+// ABL (micro-benchmarks only, results are wrong): bit 0 no DMA inside the main loop, bit 1 no fragment reads inside the main loop
+// (stale registers), bit 2 no vmcnt wait / barrier per chunk, bit 3 no MFMAs: what each component costs per chunk (guide: ablate, don't guess)
+template <int MT, int EPI, int NW, int ABL = 0>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(const dasr_conv_params p) {
     using C = GCfg<MT, NW>;
     constexpr int NT = C::NT;
@@ -691,13 +749,24 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
     if (g_trace && threadIdx.x == 0) g_trace[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memrealtime();
 #endif
     TRACE_STAMP(0);
-    const int cout_tiles = (p.cout + 31) >> 5;
+    // every kernel argument the prologue needs, fetched in ONE scalar-memory batch (hipcc otherwise sinks each s_load next to its first
+    // use: three dependent ~0.4 us round trips before the first DMA could be issued); the empty asm pins the batch here
+    int a_cout = p.cout, a_Wout = p.Wout, a_Hout = p.Hout, a_remap = p.xcd_remap, a_cin = p.cin, a_Hin = p.Hin, a_Win = p.Win;
+    const void* a_bias = p.bias;
+    const void* a_in = p.in.p;
+    const void* a_w = p.w;
+    long long a_nstr = p.in.n_stride, a_cbstr = p.in.cb_stride;
+    asm volatile("" : "+s"(a_cout), "+s"(a_Wout), "+s"(a_Hout), "+s"(a_remap), "+s"(a_cin), "+s"(a_Hin), "+s"(a_Win), "+s"(a_bias), "+s"(a_in), "+s"(a_w),
+                 "+s"(a_nstr), "+s"(a_cbstr));
+    const int cout_tiles = (a_cout + 31) >> 5;
     const int MG = (cout_tiles + MT - 1) / MT;
-    const int tiles_x = (p.Wout + C::TW - 1) / C::TW, tiles_y = (p.Hout + C::TH - 1) / C::TH;
+    const int tiles_x = (a_Wout + C::TW - 1) / C::TW, tiles_y = (a_Hout + C::TH - 1) / C::TH;
     int bid = blockIdx.x;
-    {
+    {   // XCD-aware tile order as a select, not a branch: the whole prologue stays ONE basic block, so hipcc batches every kernel-argument
+        // load into a single scalar-memory round trip at the top (three serialised round trips of ~0.4 us each before)
         const int total = gridDim.x;
-        if (p.xcd_remap && (total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);
+        const int remapped = (bid & 7) * (total >> 3) + (bid >> 3);
+        bid = ((a_remap & 1) && (total & 7) == 0) ? remapped : bid;
     }
     const int mg = bid % MG;
     bid /= MG;
@@ -707,16 +776,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
     const int n = bid / tiles_y;
     const int oy0 = ty * C::TH, ox0 = tx * C::TW;
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
-    const int nchunks = p.cin >> 4;
-    // chunk-order rotation: the workgroups that run side by side on one XCD (consecutive blockIdx >> 3) start at different 16-channel
-    // chunks, so at any moment they pull DIFFERENT weight blocks / activation planes through the L2 instead of all hammering the same
-    // 9 KB of weights (same few L2 channels) at the same time.  fp32 accumulation order changes per workgroup, deterministically.
-    const int rot = (p.xcd_remap & 4) ? (int)((blockIdx.x >> 3) % (unsigned)nchunks) : 0;
+    const int nchunks = a_cin >> 4;
+    constexpr int rot = 0;   // (per-workgroup chunk-order rotation was tried against L2 hot-spotting of the shared weight blocks: no effect)
     float bias_reg = 0.f;
     {
         const int oc = mg * MT * 32 + tid;
-        const unsigned bo = ((p.bias != nullptr) & (tid < 32 * MT) & (oc < p.cout)) ? (unsigned)oc * 4u : OOB;
-        bias_reg = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(p.bias), bo, 0, 0));
+        const unsigned bo = ((a_bias != nullptr) & (tid < 32 * MT) & (oc < a_cout)) ? (unsigned)oc * 4u : OOB;
+        bias_reg = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(a_bias), bo, 0, 0));
     }
     // ---- DMA source offsets: piece q = tid + 256 r -> LDS slot q -> pixel p = q >> 1, stored half hs = q & 1 holds channel half hs ^ bit3(p)
     unsigned goff[C::AR];
@@ -726,12 +792,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
         const int pp = q >> 1, h = (q & 1) ^ ((pp >> 3) & 1);
         const int iy = pp / C::IW, ix = pp - iy * C::IW;
         const int gy = iy0 + iy, gx = ix0 + ix;
-        const bool ok = (pp < C::NPIX) & (gy >= 0) & (gy < p.Hin) & (gx >= 0) & (gx < p.Win);  // bitwise: keeps the prologue one basic block
-        goff[r] = ok ? (unsigned)(((gy * p.Win + gx) * 16 + 8 * h) * 2) : OOB;
+        const bool ok = (pp < C::NPIX) & (gy >= 0) & (gy < a_Hin) & (gx >= 0) & (gx < a_Win);  // bitwise: keeps the prologue one basic block
+        goff[r] = ok ? (unsigned)(((gy * a_Win + gx) * 16 + 8 * h) * 2) : OOB;
     }
-    const __amdgpu_buffer_rsrc_t rin = make_rsrc((const bf16_t*)p.in.p + (size_t)n * p.in.n_stride);
-    const unsigned in_chunk_bytes = (unsigned)(p.in.cb_stride * 2);
-    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const bf16_t*)p.w + (size_t)mg * nchunks * 9 * MT * 512);
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc((const bf16_t*)a_in + (size_t)n * a_nstr);
+    const unsigned in_chunk_bytes = (unsigned)(a_cbstr * 2);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const bf16_t*)a_w + (size_t)mg * nchunks * 9 * MT * 512);
     constexpr int NP = C::AR + C::WR;
     // chunk 0 is requested before the fragment addresses and accumulators are set up: the DMA round trip overlaps that ALU work
 #pragma unroll
@@ -762,22 +828,25 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
     __syncthreads();
     TRACE_STAMP(2);
 
+    bf16x8 fb[2][6], fa[2][MT];
     for (int ck = 0; ck < nchunks; ++ck) {
         const char* buf = smem + (ck & 1) * C::BUF_BYTES;
         char* nbuf = smem + ((ck + 1) & 1) * C::BUF_BYTES;
         const bool more = ck + 1 < nchunks;
         const int ckn = ck + 1 + rot < nchunks ? ck + 1 + rot : ck + 1 + rot - nchunks;  // global index of the next chunk
         if (ck == 2) TRACE_STAMP(8);
-        bf16x8 fb[2][6], fa[2][MT];
         // step s = kx * 3 + ky; B rows of phase kx live in fb[kx & 1], A of step s in fa[s & 1]
+        const bool rd = !(ABL & 2) || ck == 0;   // ablation: fragments are read in the first chunk only
+        if (rd) {
 #pragma unroll
-        for (int rr = 0; rr < 6; ++rr) fb[0][rr] = *(const bf16x8*)(buf + baddr[rr][0]);
+            for (int rr = 0; rr < 6; ++rr) fb[0][rr] = *(const bf16x8*)(buf + baddr[rr][0]);
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) fa[0][mi] = *(const bf16x8*)(buf + aoff + (0 * MT + mi) * 1024);
+            for (int mi = 0; mi < MT; ++mi) fa[0][mi] = *(const bf16x8*)(buf + aoff + (0 * MT + mi) * 1024);
+        }
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
             const int kx = s / 3, ky = s - kx * 3;
-            if (s + 1 < 9) {
+            if (s + 1 < 9 && rd) {
                 const int kx1 = (s + 1) / 3, ky1 = (s + 1) - kx1 * 3;
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) fa[(s + 1) & 1][mi] = *(const bf16x8*)(buf + aoff + ((ky1 * 3 + kx1) * MT + mi) * 1024);
@@ -786,22 +855,31 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
                     for (int rr = 0; rr < 6; ++rr) fb[(kx + 1) & 1][rr] = *(const bf16x8*)(buf + baddr[rr][kx + 1]);
                 }
             }
-            if (more && s < 4) {  // all pieces of the next chunk are requested in the first steps: they have the rest of the chunk to land
+            if (more && s < 4 && !(ABL & 1)) {  // all pieces of the next chunk are requested in the first steps: they have the rest of the chunk to land
 #pragma unroll
                 for (int i = s * NP / 4; i < (s + 1) * NP / 4; ++i) glds_dma_piece<MT, NW>(i, ckn, nbuf, rin, rw, goff, in_chunk_bytes, wave, tid);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(ABL & 8)) {
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
+                for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][mi], fb[kx & 1][nt + ky], acc[mi][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][mi], fb[kx & 1][nt + ky], acc[mi][nt], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) asm volatile("" ::"v"(fa[s & 1][mi]));
+#pragma unroll
+                for (int rr = 0; rr < 6; ++rr) asm volatile("" ::"v"(fb[kx & 1][rr]));
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (ck == 2) TRACE_STAMP(9);
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        if (ck == 2) TRACE_STAMP(10);
-        __syncthreads();
+        if constexpr (!(ABL & 4)) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            if (ck == 2) TRACE_STAMP(10);
+            __syncthreads();
+        }
         if (ck == 2) TRACE_STAMP(11);
     }
     TRACE_STAMP(4);
@@ -816,11 +894,170 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
 #endif
 }
 
-template <int MT, int EPI = 0, int NW = 4>
+// ---------------------------------------------------------------------------------------------------
+// Dense-block convolution, third generation ("ring3"): Cout = 32 (MT = 1), 8 waves, 32 x 32 output pixels per workgroup, one workgroup
+// per CU.  Same LDS image, fragment reuse and epilogue as conv_glds_kernel; what changes is the staging pipeline:
+//  * THREE chunk buffers in a ring (3 x 48 KiB).  The DMA of chunk k+2 is issued while chunk k is multiplied, and the top of chunk k
+//    waits only for chunk k's own pieces with a COUNTED vmcnt (the six pieces of chunk k+1 stay in flight across the barrier), so the
+//    memory pipe is never drained inside the main loop and a chunk's transfer has two chunk times to land instead of a fraction of one.
+//  * a chunk is exactly 48 DMA instructions of 1 KiB: 37 activation (34 x 34 halo tile x 16 ch), 9 weight, 2 padding; wave w issues
+//    slots w, w+8, ..., w+40, i.e. every wave has the same six instructions per chunk in flight (uniform vmcnt arithmetic).
+//  * raw s_barrier (a __syncthreads() would drain vmcnt while LDS-DMA is pending).
+// 160 B of DMA per MFMA instead of 200 (halo and weights amortised over twice the pixels of the 4-wave tile).
+// ---------------------------------------------------------------------------------------------------
+struct G3 {
+    static constexpr int NW = 8, NTH = 512, NT = 4, TH = 32, TW = 32, IH = 34, IW = 34, NPIX = IH * IW;
+    static constexpr int ACT_SLOTS = 37, W_SLOTS = 9, SLOTS = 48, PPW = 6;   // 1 KiB DMA instructions per chunk / per wave
+    static constexpr int BUF_BYTES = SLOTS * 1024, W_OFF = ACT_SLOTS * 1024, LDS_BYTES = 3 * BUF_BYTES;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void conv_ring3_kernel(const dasr_conv_params p) {
+    using C = G3;
+    constexpr int NT = C::NT, MT = 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (p.Wout + C::TW - 1) / C::TW, tiles_y = (p.Hout + C::TH - 1) / C::TH;
+    int bid = blockIdx.x;
+    {
+        const int total = gridDim.x;
+        if ((p.xcd_remap & 1) && (total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);
+    }
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int n = bid / tiles_y;
+    const int oy0 = ty * C::TH, ox0 = tx * C::TW;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int nchunks = p.cin >> 4;
+    float bias_reg = 0.f;
+    {
+        const unsigned bo = ((p.bias != nullptr) & (tid < 32) & (tid < p.cout)) ? (unsigned)tid * 4u : OOB;
+        bias_reg = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(p.bias), bo, 0, 0));
+    }
+    // ---- the wave's six DMA slots: global byte offset of this lane's 16 bytes (chunk-independent part)
+    unsigned goff[C::PPW];
+#pragma unroll
+    for (int i = 0; i < C::PPW; ++i) {
+        const int s = wave + 8 * i;
+        if (s < C::ACT_SLOTS) {  // piece q -> pixel pp = q >> 1, stored half q & 1 holds channel half (q & 1) ^ bit3(pp)
+            const int q = s * 64 + lane;
+            const int pp = q >> 1, h = (q & 1) ^ ((pp >> 3) & 1);
+            const int iy = pp / C::IW, ix = pp - iy * C::IW;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            const bool ok = (pp < C::NPIX) & (gy >= 0) & (gy < p.Hin) & (gx >= 0) & (gx < p.Win);
+            goff[i] = ok ? (unsigned)(((gy * p.Win + gx) * 16 + 8 * h) * 2) : OOB;
+        } else if (s < C::ACT_SLOTS + C::W_SLOTS) {
+            goff[i] = (unsigned)(((s - C::ACT_SLOTS) * 64 + lane) * 16);
+        } else {
+            goff[i] = OOB;  // padding slot: zero fill of an unused KiB, keeps the per-wave instruction count uniform
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc((const bf16_t*)p.in.p + (size_t)n * p.in.n_stride);
+    const unsigned in_chunk_bytes = (unsigned)(p.in.cb_stride * 2);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc((const bf16_t*)p.w);
+    // per-slot descriptor and chunk stride, chosen once (wave-uniform scalar selects, no branches in the main loop)
+    __amdgpu_buffer_rsrc_t rs[C::PPW];
+    unsigned cstride[C::PPW];
+#pragma unroll
+    for (int i = 0; i < C::PPW; ++i) {
+        const bool isw = wave + 8 * i >= C::ACT_SLOTS;
+        rs[i] = isw ? rw : rin;
+        cstride[i] = isw ? 9216u : in_chunk_bytes;
+    }
+    auto dma = [&](int i, int ck, char* buf) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[i], (lds_ptr)(buf + (wave + 8 * i) * 1024), 16, goff[i], (unsigned)ck * cstride[i], 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < C::PPW; ++i) dma(i, 0, smem);
+    if (nchunks > 1) {
+#pragma unroll
+        for (int i = 0; i < C::PPW; ++i) dma(i, 1, smem + C::BUF_BYTES);
+    }
+    // ---- fragment read addresses (same swizzled image as conv_glds_kernel)
+    const int nn = lane & 31, kh2 = lane >> 5;
+    int baddr[6][3];
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int pp = (wave * NT + rr) * C::IW + nn + kx;
+            baddr[rr][kx] = ((pp << 1) + (kh2 ^ ((pp >> 3) & 1))) << 4;
+        }
+    const int aoff = C::W_OFF + lane * 16;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[0][nt][j] = 0.f;
+
+    int bsel = 0;  // ring position of chunk ck
+    for (int ck = 0; ck < nchunks; ++ck) {
+        // chunk ck's pieces (this wave's) have landed once at most the six pieces of chunk ck+1 are outstanding
+        if (ck + 1 < nchunks) __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+        __builtin_amdgcn_s_barrier();   // every wave's pieces of chunk ck are in LDS; every wave is done reading chunk ck-1
+        const char* buf = smem + bsel * C::BUF_BYTES;
+        const int nsel = bsel == 0 ? 2 : bsel - 1;   // (bsel + 2) % 3: the buffer chunk ck-1 was read from
+        char* nbuf = smem + nsel * C::BUF_BYTES;
+        auto body = [&](auto more_c) {   // two straight-line copies: with / without the DMA of chunk ck+2
+            constexpr bool MORE = decltype(more_c)::value;
+            bf16x8 fb[2][6], fa[2][MT];
+#pragma unroll
+            for (int rr = 0; rr < 6; ++rr) fb[0][rr] = *(const bf16x8*)(buf + baddr[rr][0]);
+            fa[0][0] = *(const bf16x8*)(buf + aoff);
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                const int kx = s / 3, ky = s - kx * 3;
+                if (s + 1 < 9) {
+                    const int kx1 = (s + 1) / 3, ky1 = (s + 1) - kx1 * 3;
+                    fa[(s + 1) & 1][0] = *(const bf16x8*)(buf + aoff + (ky1 * 3 + kx1) * 1024);
+                    if (ky == 1 && kx < 2) {
+#pragma unroll
+                        for (int rr = 0; rr < 6; ++rr) fb[(kx + 1) & 1][rr] = *(const bf16x8*)(buf + baddr[rr][kx + 1]);
+                    }
+                }
+                if (MORE && s >= 1 && s <= C::PPW) dma(s - 1, ck + 2, nbuf);   // one piece per step, behind the first step's fragment reads
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][0], fb[kx & 1][nt + ky], acc[0][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (ck + 2 < nchunks) body(std::true_type{});
+        else body(std::false_type{});
+        bsel = bsel == 2 ? 0 : bsel + 1;
+    }
+    __builtin_amdgcn_s_barrier();   // all fragment reads done before the epilogue reuses LDS for the bias
+    conv_epilogue<false, MT, NT, 1, EPI>(p, acc, smem, bias_reg, tid, 0, n, oy0, ox0);
+}
+
+template <int EPI = 0>
+int launch_ring3(const dasr_conv_params& p, hipStream_t s) {
+    using C = G3;
+    static bool attr_set = false;
+    auto kfn = conv_ring3_kernel<EPI>;
+    if ((p.cin & 15) || p.kh != 3 || p.stride != 1 || p.pad != 1 || p.ups || p.in_f32 || p.prec != 1 || (p.pad_x >= 0 && p.pad_x != 1) || p.in_stride > 1 ||
+        p.cout > 32 || p.mt != 1)
+        return DASR_EINVAL;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        attr_set = true;
+    }
+    const int tiles_x = (p.Wout + C::TW - 1) / C::TW, tiles_y = (p.Hout + C::TH - 1) / C::TH;
+    const long long grid = (long long)tiles_x * tiles_y * p.N;
+    if (grid <= 0 || grid > 0x7fffffffLL) return DASR_EINVAL;
+    DASR_LAUNCH_TAG(__PRETTY_FUNCTION__, kfn, dim3((unsigned)grid), dim3(C::NTH), C::LDS_BYTES, s, p);
+    return (int)hipGetLastError();
+}
+
+template <int MT, int EPI = 0, int NW = 4, int ABL = 0>
 int launch_glds(const dasr_conv_params& p, hipStream_t s) {
     using C = GCfg<MT, NW>;
     static bool attr_set = false;
-    auto kfn = conv_glds_kernel<MT, EPI, NW>;
+    auto kfn = conv_glds_kernel<MT, EPI, NW, ABL>;
     if ((p.cin & 15) || p.kh != 3 || p.stride != 1 || p.pad != 1 || p.ups || p.in_f32 || p.prec != 1 || (p.pad_x >= 0 && p.pad_x != 1) || p.in_stride > 1)
         return DASR_EINVAL;
     if (!attr_set) {
@@ -933,18 +1170,19 @@ extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
 
 extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
     dasr_conv_params p = *pp;
-    p.xcd_remap = g_tune_xcd | (g_tune_rot ? 4 : 0);  // bit 1 (trace builds): contiguous-store timing experiment; bit 2: chunk rotation
+    p.xcd_remap = g_tune_xcd;  // bit 1 (trace builds): contiguous-store timing experiment
     if (p.pad_x == 0 && p.out_stride == 0 && p.kh != 2 && p.kh != 1) p.pad_x = -1;  // zero-initialised extension fields = "same as pad"
     hipStream_t s = as_stream(stream);
     if (p.cin <= 0 || (p.cin & 15) || p.cout <= 0 || !p.w || !p.in.p) return DASR_EINVAL;
-    if (!(p.mt == 1 || p.mt == 2) || !(p.prec == 1 || p.prec == 3)) return DASR_EINVAL;
+    if (!(p.mt == 1 || p.mt == 2) || !(p.prec == 1 || p.prec == 2 || p.prec == 3)) return DASR_EINVAL;
+    if (p.prec == 2 && !p.in_f32) return DASR_EINVAL;
     int kcode = 0;
     if (p.kh == 4) kcode = p.stride == 2 ? 2 : 1;
     else if (p.kh == 2) kcode = 3;
     else if (p.kh == 5) kcode = 4;
     else if (p.kh == 1) kcode = 5;
     else if (p.kh == 3 && p.stride == 2) kcode = 6;
-    const int key = (p.prec == 3 ? 1000 : 0) + (p.in_f32 ? 100 : 0) + p.mt * 10 + kcode;
+    const int key = (p.prec == 3 ? 1000 : p.prec == 2 ? 2000 : 0) + (p.in_f32 ? 100 : 0) + p.mt * 10 + kcode;
     if (p.kh == 3 && ((p.stride != 1 && p.stride != 2) || p.pad != 1)) return DASR_EINVAL;
     if (p.kh == 5 && (p.stride != 1 || p.pad != 2)) return DASR_EINVAL;
     if (p.kh == 1 && (p.stride != 1 || p.pad != 0)) return DASR_EINVAL;
@@ -964,11 +1202,26 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                 case 9: return launch<1, false, 1, 3, 1, 4, 1, true, 1>(p, s);
                 case 10: return launch<1, false, 1, 3, 1, 4, 1, true, 2>(p, s);  // pipelined: prefetch distance 2, ds_write inside the MFMA stream
                 case 11: return launch<1, false, 1, 3, 1, 2, 1, true, 2>(p, s);
+                case 100: return launch_glds<1, 67, 4, 0>(p, s);   // ablation series (scripts/micro_conv.py --mode fwd): wrong results, timing only
+                case 101: return launch_glds<1, 67, 4, 1>(p, s);
+                case 102: return launch_glds<1, 67, 4, 2>(p, s);
+                case 103: return launch_glds<1, 67, 4, 3>(p, s);
+                case 104: return launch_glds<1, 67, 4, 4>(p, s);
+                case 107: return launch_glds<1, 67, 4, 7>(p, s);
+                case 108: return launch_glds<1, 67, 4, 8>(p, s);
+                case 112: return launch_glds<1, 67, 4, 12>(p, s);
+                case 115: return launch_glds<1, 67, 4, 15>(p, s);
                 case 12:
                     switch (g_tune_epi ? classify_epi(p) : 0) {
                         case 67: return launch_glds<1, 67>(p, s);
                         case 68: return launch_glds<1, 68>(p, s);
                         default: return launch_glds<1, 0>(p, s);
+                    }
+                case 14:  // 8 waves, 32x32 tile, three-buffer ring with counted vmcnt (no drain inside the main loop)
+                    switch (g_tune_epi ? classify_epi(p) : 0) {
+                        case 67: return launch_ring3<67>(p, s);
+                        case 68: return launch_ring3<68>(p, s);
+                        default: return launch_ring3<0>(p, s);
                     }
                 case 13:  // 8 waves, 32x32-pixel tile: -20 % DMA bytes per MFMA (weights and halo amortised over twice the pixels)
                     switch (g_tune_epi ? classify_epi(p) : 0) {
@@ -1042,6 +1295,16 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
         case 1114: return launch<3, true, 1, 5, 1, 2>(p, s);  // DSN FSD discriminator 5x5
         case 1115: return launch<3, true, 1, 1, 1, 4>(p, s);  // 1x1 head
         case 1116: return launch<3, true, 1, 3, 2, 1>(p, s);  // De_resnet down-sampling convs
+        // prec 2: f16 operands, ONE MFMA pass on f32 activations (HR tail of the generator; VGG / discriminators / DSN when selected)
+        case 2110: return launch<2, true, 1, 3, 1, 4>(p, s);
+        case 2120: return launch<2, true, 2, 3, 1, 4>(p, s);
+        case 2111: return launch<2, true, 1, 4, 1, 2>(p, s);
+        case 2112: return launch<2, true, 1, 4, 2, 1>(p, s);
+        case 2113: return launch<2, true, 1, 2, 1, 4>(p, s);
+        case 2123: return launch<2, true, 2, 2, 1, 4>(p, s);
+        case 2114: return launch<2, true, 1, 5, 1, 2>(p, s);
+        case 2115: return launch<2, true, 1, 1, 1, 4>(p, s);
+        case 2116: return launch<2, true, 1, 3, 2, 1>(p, s);
         default: return DASR_EINVAL;
     }
 }

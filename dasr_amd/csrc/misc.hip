@@ -56,6 +56,7 @@ __global__ void pack_kernel(const dasr_pack_desc* __restrict__ descs, int ndesc,
         }
         bf16_t h, l;
         split_bf16(v, h, l);
+        if (D.fmt == 1) h = __builtin_bit_cast(bf16_t, (f16_t)v);   // f16 bit pattern (prec 2 convs)
         vh[e] = h;
         vl[e] = l;
     }
@@ -498,7 +499,8 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream0) {
                 rc = dasr_wgrad((const dasr_wgrad_part*)o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], (float*)o.p[1], stream);
                 break;
             case DASR_OP_WGRAD_REDUCE:
-                rc = dasr_wgrad_reduce((const dasr_wgrad_reduce_part*)o.p[0], o.i[0], (const float*)o.p[1], (float*)o.p[2], o.f[0], stream);
+                rc = dasr_wgrad_reduce((const dasr_wgrad_reduce_part*)o.p[0], o.i[0], (const float*)o.p[1], (float*)o.p[2],
+                                       o.f[1] != 0.f ? o.f[0] * o.f[1] : o.f[0], stream);   // f[1]: inverse of the f16 operand pre-scale
                 break;
             case DASR_OP_PACK:
                 rc = dasr_pack_weights((const dasr_pack_desc*)o.p[0], o.i[0], o.l[0], (const int64_t*)o.p[1], (const float*)o.p[2], o.p[3], stream);

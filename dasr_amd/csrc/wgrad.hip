@@ -68,9 +68,18 @@ __device__ __forceinline__ void stage_load(StageReg<F32>& r, __amdgpu_buffer_rsr
     }
 }
 
-template <bool F32>
-__device__ __forceinline__ void stage_store(const StageReg<F32>& r, char* dst) {
-    if constexpr (F32) {
+// F16: the f32 values are multiplied by `scale` (a power of two) and rounded to f16 instead of bf16
+template <bool F32, bool F16 = false>
+__device__ __forceinline__ void stage_store(const StageReg<F32>& r, char* dst, float scale = 1.f) {
+    if constexpr (F32 && F16) {
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = (f16_t)(__uint_as_float(r.a[j]) * scale);
+            o[4 + j] = (f16_t)(__uint_as_float(r.b[j]) * scale);
+        }
+        *(f16x8*)dst = o;
+    } else if constexpr (F32) {
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -83,9 +92,10 @@ __device__ __forceinline__ void stage_store(const StageReg<F32>& r, char* dst) {
     }
 }
 
-template <int KH, int STRIDE, bool USE_TR, bool F32>
+template <int KH, int STRIDE, bool USE_TR, bool F32, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit,
                                                        float* __restrict__ ws) {
+    static_assert(!F16 || F32, "f16 staging converts f32 tensors");
     using C = WCfg<KH, STRIDE>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* gl = smem;
@@ -105,6 +115,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __
     constexpr int IPIECES_MAX = 4 * IPIX * 2;
     constexpr int IR = (IPIECES_MAX + 255) / 256;
     const int ipieces = 2 * P.n_ctiles * IPIX * 2;
+    const float gsc = (F16 && P.g_scale != 0.f) ? P.g_scale : 1.f;
 
     f32x16 acc[C::TPG];
 #pragma unroll
@@ -160,12 +171,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __
         for (int r = 0; r < GR; ++r) {
             const int q = tid + r * 256;
             const int half = q & 1, pix = (q >> 1) % GPIX, pl = (q >> 1) / GPIX;
-            stage_store<F32>(greg[r], q < GPIECES ? gl + pl * C::GPLANE + pix * 32 + half * 16 : dummy);
-            if constexpr (F32) {
+            stage_store<F32, F16>(greg[r], q < GPIECES ? gl + pl * C::GPLANE + pix * 32 + half * 16 : dummy, gsc);
+            if constexpr (F32) {   // (scaled like the staged values: the caller's reduce scale undoes g_scale for weights and bias alike)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    bacc[r][j] += __uint_as_float(greg[r].a[j]);
-                    bacc[r][4 + j] += __uint_as_float(greg[r].b[j]);
+                    bacc[r][j] += __uint_as_float(greg[r].a[j]) * gsc;
+                    bacc[r][4 + j] += __uint_as_float(greg[r].b[j]) * gsc;
                 }
             }
         }
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __
         for (int r = 0; r < IR; ++r) {
             const int q = tid + r * 256;
             const int half = q & 1, pix = (q >> 1) % IPIX, pl = (q >> 1) / IPIX;
-            stage_store<F32>(ireg[r], q < ipieces ? il + pl * C::IPLANE + pix * 32 + half * 16 : dummy);
+            stage_store<F32, F16>(ireg[r], q < ipieces ? il + pl * C::IPLANE + pix * 32 + half * 16 : dummy);
         }
     };
 
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __
 #pragma unroll
                         for (int j = 0; j < 8; ++j) b[j] = *(const bf16_t*)(b0 + j * STRIDE * 32);
                     }
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+                    acc[t] = mfma16<F16>(a, b, acc[t]);
                 }
             }
         }
@@ -806,10 +817,10 @@ __global__ void probe_tr16_kernel(int* result) {
     if (l == 0) *result = (m == ~0ull) ? 1 : 0;
 }
 
-template <int KH, int STRIDE, bool USE_TR, bool F32>
+template <int KH, int STRIDE, bool USE_TR, bool F32, bool F16 = false>
 int launch_wgrad(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws, hipStream_t s) {
     using C = WCfg<KH, STRIDE>;
-    auto kfn = wgrad_kernel<KH, STRIDE, USE_TR, F32>;
+    auto kfn = wgrad_kernel<KH, STRIDE, USE_TR, F32, F16>;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + 16));
@@ -875,7 +886,11 @@ extern "C" int dasr_wgrad_set_mode(int use_tr) {
 
 namespace {
 template <int KH, int STRIDE>
-int dispatch_wgrad(const dasr_wgrad_part* parts, int nparts, int nsplit, bool tr, bool f32, float* ws, hipStream_t s) {
+int dispatch_wgrad(const dasr_wgrad_part* parts, int nparts, int nsplit, bool tr, int f32, float* ws, hipStream_t s) {
+    if (f32 & 2) {   // f32 tensors rounded to f16 (pre-scaled gradient), f16 MFMA
+        if (tr) return launch_wgrad<KH, STRIDE, true, true, true>(parts, nparts, nsplit, ws, s);
+        return launch_wgrad<KH, STRIDE, false, true, true>(parts, nparts, nsplit, ws, s);
+    }
     if (tr) return f32 ? launch_wgrad<KH, STRIDE, true, true>(parts, nparts, nsplit, ws, s) : launch_wgrad<KH, STRIDE, true, false>(parts, nparts, nsplit, ws, s);
     return f32 ? launch_wgrad<KH, STRIDE, false, true>(parts, nparts, nsplit, ws, s) : launch_wgrad<KH, STRIDE, false, false>(parts, nparts, nsplit, ws, s);
 }
@@ -892,12 +907,12 @@ extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int3
         if (tr) return f32 ? launch_wgrad3<true, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3<true, false>(parts_dev, nparts, nsplit, ws, s);
         return f32 ? launch_wgrad3<false, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3<false, false>(parts_dev, nparts, nsplit, ws, s);
     }
-    if (kh == 3 && stride == 1) return dispatch_wgrad<3, 1>(parts_dev, nparts, nsplit, tr, f32 != 0, ws, s);
-    if (kh == 4 && stride == 1) return dispatch_wgrad<4, 1>(parts_dev, nparts, nsplit, tr, f32 != 0, ws, s);
-    if (kh == 4 && stride == 2) return dispatch_wgrad<4, 2>(parts_dev, nparts, nsplit, tr, f32 != 0, ws, s);
-    if (kh == 5 && stride == 1) return dispatch_wgrad<5, 1>(parts_dev, nparts, nsplit, tr, f32 != 0, ws, s);
-    if (kh == 1 && stride == 1) return dispatch_wgrad<1, 1>(parts_dev, nparts, nsplit, tr, f32 != 0, ws, s);
-    if (kh == 3 && stride == 2) return dispatch_wgrad<3, 2>(parts_dev, nparts, nsplit, tr, f32 != 0, ws, s);
+    if (kh == 3 && stride == 1) return dispatch_wgrad<3, 1>(parts_dev, nparts, nsplit, tr, f32, ws, s);
+    if (kh == 4 && stride == 1) return dispatch_wgrad<4, 1>(parts_dev, nparts, nsplit, tr, f32, ws, s);
+    if (kh == 4 && stride == 2) return dispatch_wgrad<4, 2>(parts_dev, nparts, nsplit, tr, f32, ws, s);
+    if (kh == 5 && stride == 1) return dispatch_wgrad<5, 1>(parts_dev, nparts, nsplit, tr, f32, ws, s);
+    if (kh == 1 && stride == 1) return dispatch_wgrad<1, 1>(parts_dev, nparts, nsplit, tr, f32, ws, s);
+    if (kh == 3 && stride == 2) return dispatch_wgrad<3, 2>(parts_dev, nparts, nsplit, tr, f32, ws, s);
     return DASR_EINVAL;
 }
 

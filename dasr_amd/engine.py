@@ -122,6 +122,7 @@ class PackRegistry:
         r.off, r.cout, r.cin_pad, r.ntaps, r.mt, r.prec = self.size, cout, cin_pad, ntaps, mt, prec
         r.lo_off = pieces * 8 if prec == 3 else 0
         d = PackDesc()
+        d.fmt = 1 if prec == 2 else 0   # prec 2: f16 operands (one MFMA pass); 1 / 3: bf16 hi (+ lo) planes
         d.dst_off, d.lo_off, d.cout, d.cin_pad, d.ntaps, d.mt, d.nseg = self.size, r.lo_off, cout, cin_pad, ntaps, mt, len(segs)
         d.src_ntaps = src_ntaps or ntaps
         if tapmap is None:
@@ -225,7 +226,7 @@ def run_interleaved(lists, streams, chunk=None):
 
 def conv_op(pack, ref, inp, in_f32, cin, Hin, Win, Hout, Wout, N, bias=None, kh=3, stride=1, pad=1, ups=0, act=0, slope=SLOPE,
             mask=None, mask_f32=0, alpha=1.0, res1=None, beta1=0.0, res2=None, beta2=0.0, out_f32=None, out_bf16=None, gamma=1.0,
-            pad_x=-1, out_stride=1, out_oy=0, out_ox=0, out_W=0, slope_ptr=None, in_stride=1, in_oy=0, in_ox=0, in_W=0, flops=None):
+            pad_x=-1, out_stride=1, out_oy=0, out_ox=0, out_W=0, slope_ptr=None, in_stride=1, in_oy=0, in_ox=0, in_W=0, flops=None, in_scale=0.0):
     """flops: algorithmic FLOPs of the reference op this launch stands for (default: 2 * outputs * taps * cin * cout of the launch
     itself; the sub-pixel upconv launches pass a quarter of the reference's 3x3 conv on the up-sampled grid instead)."""
     assert cin == ref.cin_pad, (cin, ref.cin_pad)
@@ -248,6 +249,7 @@ def conv_op(pack, ref, inp, in_f32, cin, Hin, Win, Hout, Wout, N, bias=None, kh=
     p.pad_x, p.out_stride, p.out_oy, p.out_ox, p.out_W = pad_x, out_stride, out_oy, out_ox, out_W
     p.slope_ptr = slope_ptr
     p.in_stride, p.in_oy, p.in_ox, p.in_W = in_stride, in_oy, in_ox, in_W
+    p.in_scale = in_scale if ref.prec == 2 else 0.0   # power-of-two pre-scale of a gradient input before its f16 rounding
     return o
 
 
@@ -259,8 +261,12 @@ class WgradGroup:
         self.parts = []  # (WgradPart, WgradReducePart)
 
     def add_conv(self, g, g_f32, g_planes_total, inp, in_f32, in_planes_total, cout, cin, Hin, Win, Hout, Wout, N,
-                 dst_w_off, dst_b_off, pad=None, ups=0):
-        """g / inp are BTensor-like callables c0 -> dasr_tensor view."""
+                 dst_w_off, dst_b_off, pad=None, ups=0, f16=False, g_scale=0.0):
+        """g / inp are BTensor-like callables c0 -> dasr_tensor view.  f16: the f32 tensors are rounded to f16 (g pre-scaled by the
+        power of two g_scale) instead of bf16 while staging; the reduce op undoes the scale."""
+        assert not f16 or (g_f32 and in_f32)
+        self.f16 = bool(f16) or getattr(self, 'f16', False)
+        self.g_scale = float(g_scale) if f16 and g_scale else getattr(self, 'g_scale', 0.0)
         ntaps = self.kh * self.kh
         tpp = ntaps if ntaps <= 16 else 10  # WCfg::TAPS_PER_PART
         self.tpp = tpp
@@ -281,6 +287,7 @@ class WgradGroup:
                     wp.kh, wp.stride, wp.pad, wp.tap0 = self.kh, self.stride, pad, tap0
                     first = dst_b_off is not None and c0 == 0 and tap0 == 0
                     wp.want_bias = 1 if first else 0
+                    wp.g_scale = float(g_scale) if f16 else 0.0
                     rp.ntaps, rp.oc0, rp.c0, rp.cout, rp.cin, rp.n_ctiles = min(tpp, ntaps - tap0), oc0, c0, cout, cin, wp.n_ctiles
                     rp.tap0, rp.ntaps_total = tap0, ntaps
                     rp.dst_w_off = dst_w_off
@@ -319,10 +326,12 @@ class WgradGroup:
         a.p[0], a.i[0], a.i[1], a.i[2], a.i[3] = self.w_dev.data_ptr(), len(self.parts), self.nsplit, self.kh, self.stride
         f32s = set((p[0].g_f32, p[0].in_f32) for p in self.parts)
         assert f32s in ({(0, 0)}, {(1, 1)}), 'a wgrad group must be all-bf16 or all-f32'
-        a.i[4] = self.parts[0][0].g_f32
+        a.i[4] = self.parts[0][0].g_f32 | (2 if getattr(self, 'f16', False) else 0)
         a.flops = float(getattr(self, 'flops', 0.0))
         b.op = _lib.OP_WGRAD_REDUCE
         b.p[0], b.i[0], b.p[2], b.f[0] = self.r_dev.data_ptr(), len(self.parts), grad_ptr, scale
+        gs = getattr(self, 'g_scale', 0.0)
+        b.f[1] = 1.0 / gs if gs else 0.0   # second factor of the reduce scale (f[0] stays the data-parallel 1/world): undoes the f16 pre-scale
         self.workspace.register(a, b)
         return [a, b]
 

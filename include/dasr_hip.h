@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DASR_ABI_VERSION 3
+#define DASR_ABI_VERSION 4
 #define DASR_EINVAL (-22)
 
 typedef struct {
@@ -47,7 +47,7 @@ typedef struct {
     const float* bias;                      /* [cout] or NULL */
     int32_t cout, Hout, Wout, N;
     int32_t kh, stride, pad;                /* 3/1/1 or 4/2/1 or 4/1/1 */
-    int32_t prec;                           /* 1: bf16 operands; 3: split-bf16 (hi*hi+hi*lo+lo*hi), ~fp32 */
+    int32_t prec;                           /* 1: bf16 operands; 2: f16 operands, one MFMA pass (f32 input, see in_scale); 3: split-bf16 (hi*hi+hi*lo+lo*hi), ~fp32 */
     int32_t mt;                             /* 32-oc tiles per workgroup (1 or 2); must match the packing */
     int32_t act;  float slope;
     dasr_tensor mask;  int32_t mask_f32;
@@ -65,6 +65,9 @@ typedef struct {
      * in_stride 0/1: dense; 2: input pixel (y,x) of the Hin x Win grid lives at (2*y+in_oy, 2*x+in_ox) of a tensor of width in_W.
      * conv_kernel variants only (not the LDS-DMA dense-block kernel). */
     int32_t in_stride, in_oy, in_ox, in_W;
+    /* prec 2: the f32 input is multiplied by in_scale (a power of two; 0 = 1) before it is rounded to f16, and the accumulator by
+     * 1/in_scale before the epilogue: keeps tiny loss gradients (1e-8..1e-5) inside f16's normal range, exact otherwise. */
+    float in_scale;
 } dasr_conv_params;
 
 int dasr_conv(const dasr_conv_params* p, void* stream);
@@ -93,9 +96,12 @@ typedef struct {
     int64_t ws_off;                         /* float offset into workspace: [nsplit][taps of the part][32][64] (+ bias [nsplit][32]) */
     int64_t ws_bias_off;
     int32_t tap0;                           /* first tap of this part (5x5 kernels are split into parts of <= 10 taps) */
+    float g_scale;                          /* f16 staging (f32 & 2): g is multiplied by g_scale (power of two, 0 = 1) before rounding; the caller folds
+                                             * 1/g_scale into dasr_wgrad_reduce's scale */
 } dasr_wgrad_part;
 
-/* f32: g and in tensors of ALL parts are f32 (rounded to bf16 while staging) instead of bf16.
+/* f32 bit 0: g and in tensors of ALL parts are f32 (rounded while staging) instead of bf16; bit 1: ... rounded to f16 (11-bit mantissa,
+ * g pre-scaled by part.g_scale) and multiplied with v_mfma_f32_32x32x16_f16 instead of bf16.
  * kh = 33 selects the 6-wave 3x3 kernel: a part is one 64-channel input block x up to three 32-oc tiles
  * (g_planes = 2/4/6), workspace [split][tap][3][32][64], bias [split][96]. */
 int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int32_t nsplit, int32_t kh, int32_t stride, int32_t f32,
@@ -137,6 +143,7 @@ typedef struct {
     int64_t lo_off;       /* 0 when prec 1 */
     int32_t cout, cin_pad, ntaps, mt, nseg;
     int32_t src_ntaps;    /* taps of the source weight (kh*kw of the nn.Conv2d) */
+    int32_t fmt;          /* 0: bf16 (hi plane, + lo plane when lo_off != 0); 1: f16 (prec 2 convs) */
     int8_t  tapmap[32];   /* packed tap -> source tap (identity: forward; reversed: stride-1 dgrad; parity subset: stride-2 dgrad) */
     uint16_t tapmask[16]; /* non-zero: packed tap t (< 16) = SUM of the source taps whose bits are set (sub-pixel form of nearest-x2 + 3x3) */
     dasr_pack_seg seg[5];

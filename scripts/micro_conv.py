@@ -11,6 +11,7 @@ ap.add_argument('--n', type=int, default=16); ap.add_argument('--hw', type=int, 
 ap.add_argument('--reps', type=int, default=40); ap.add_argument('--tune', type=str, default='')
 ap.add_argument('--streams', type=int, default=1)
 ap.add_argument('--noout', type=int, default=0)
+ap.add_argument('--zero', type=int, default=0, help='1: zero-filled activations and weights (DVFS: how much of the time is clock, not cycles)')
 ap.add_argument('--mode', type=str, default='fwd', help='fwd: bias+lrelu->bf16 | dgrad: mask->bf16 | conv5: bias, alpha, res1 -> f32+bf16')
 ap.add_argument('--alias', type=int, default=0, help='1: all images alias image 0 on the input, 2: also on the output (cache-resident working set)')
 a = ap.parse_args()
@@ -22,14 +23,17 @@ for kv in [x for x in a.tune.split(',') if x]:
     _lib.check(L.dasr_set_tuning(int(k), int(v)))
 mt = 2 if a.cout == 64 else 1
 P = ParamStore([('w', (a.cout, a.cin, 3, 3)), ('b', (a.cout,))], dev)
-P.flat.normal_(0, math.sqrt(2.0 / (9 * a.cin)))
+if not a.zero:
+    P.flat.normal_(0, math.sqrt(2.0 / (9 * a.cin)))
 pack = PackRegistry(P)
 ref = pack.add(a.cout, a.cin, 9, mt, 1, [(0, a.cout, a.cin, 0, a.cin, 0, 0)])
 pack.finalize(); pack.run()
 lists = []
 for s in range(a.streams):
     n = a.n // a.streams
-    x = BTensor(n, a.cin, a.hw, a.hw, False, dev); x.t.normal_()
+    x = BTensor(n, a.cin, a.hw, a.hw, False, dev)
+    if not a.zero:
+        x.t.normal_()
     y = BTensor(n, a.cout, a.hw, a.hw, False, dev); y.t.normal_()
     ym = BTensor(n, a.cout, a.hw, a.hw, False, dev)
     rf = BTensor(n, a.cout, a.hw, a.hw, True, dev); of = BTensor(n, a.cout, a.hw, a.hw, True, dev)
@@ -59,7 +63,7 @@ t0 = time.perf_counter()
 run(); torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 fl = 2.0 * a.n * a.hw * a.hw * 9 * a.cin * a.cout * a.reps
-print('%s alias %d ' % (a.mode, a.alias) + 'cin %d cout %d N %d streams %d tune [%s]: %.1f us/launch-set, %.0f TFLOP/s' % (a.cin, a.cout, a.n, a.streams, a.tune, dt / a.reps * 1e6, fl / dt / 1e12))
+print('%s alias %d zero %d ' % (a.mode, a.alias, a.zero) + 'cin %d cout %d N %d streams %d tune [%s]: %.1f us/launch-set, %.0f TFLOP/s' % (a.cin, a.cout, a.n, a.streams, a.tune, dt / a.reps * 1e6, fl / dt / 1e12))
 
 if os.environ.get('DASR_HIP_LIB'):
     import ctypes, numpy as np

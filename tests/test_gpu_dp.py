@@ -119,7 +119,7 @@ def test_rccl_exchange_path_single_rank(streams, tmp_path):
     mp.spawn(_rccl_worker, args=(port, out, streams, False), nprocs=1, join=True)
     mp.spawn(_rccl_worker, args=(port, out, streams, True), nprocs=1, join=True)
     a, b = torch.load(out % 0), torch.load(out % 1)
-    assert a['l_pix'] == b['l_pix']
+    assert abs(a['l_pix'] - b['l_pix']) <= 1e-6 * abs(a['l_pix'])   # the logged loss is an atomic sum (order varies from run to run); the weights are not
     for k, v in a['G'].items():
         assert torch.equal(v, b['G'][k]), k
 

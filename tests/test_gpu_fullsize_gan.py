@@ -152,9 +152,12 @@ def test_instance_norm_lrelu_fullsize(C_, H, W, margins):
     ref = torch.where(z > 0, z, 0.2 * z)
     ref.backward(ga.nchw().double())
     e_f = float((y.nchw().double() - ref.detach()).norm() / ref.detach().norm())
-    e_b = float((gx.nchw().double() - xd.grad).norm() / xd.grad.norm())
-    margins('instance norm + lrelu %dx%dx%d: fwd rel err %.2e, bwd rel err %.2e (tol 1e-5 / 1e-4)' % (C_, H, W, e_f, e_b))
-    assert e_f < 1e-5 and e_b < 1e-4
+    # an element whose normalised value is within fp32 round-off of the LeakyReLU kink may land on the other side in fp32 (derivative 1 vs
+    # 0.2: ONE such element among 8 M moves the normwise error to ~2e-4); those elements are left out of the comparison
+    keep = (z.detach().abs() > 1e-5).double()
+    e_b = float(((gx.nchw().double() - xd.grad) * keep).norm() / xd.grad.norm())
+    margins('instance norm + lrelu %dx%dx%d: fwd rel err %.2e, bwd rel err %.2e away from the kink (tol 1e-5 / 1e-5; %d elements at the kink)' % (C_, H, W, e_f, e_b, int((1 - keep).sum())))
+    assert e_f < 1e-5 and e_b < 1e-5
 
 
 def test_haar_dwt_fullsize(margins):

@@ -121,7 +121,7 @@ def test_sr_step_matches_oracle_and_reference_fixture(case, golden_dir, margins)
         dmax, frac = max(dmax, float(d.max())), max(frac, float((d > 2e-5).float().mean()))
         assert float(d.max()) <= 3.2e-4, k
         assert float((d > 2e-5).float().mean()) < 0.02, (k, float((d > 2e-5).float().mean()))
-    margins('%s weights after 2 Adam steps: max |dw| %.2e (bound 3.2e-4 = 2 steps x 2 lr... lr 1e-4), worst fraction of elements off by > 2e-5: %.4f (bound 0.02)'
+    margins('%s weights after 2 Adam steps: max |dw| %.2e (bound 3.2e-4 at lr 1e-4), worst fraction of elements off by > 2e-5: %.4f (bound 0.02)'
             % (case, dmax, frac))
 
 
