@@ -23,7 +23,7 @@ class ConvParams(C.Structure):
                 ('alpha', c_f32), ('res1', Tensor), ('beta1', c_f32), ('res2', Tensor), ('beta2', c_f32),
                 ('out_f32', Tensor), ('out_bf16', Tensor), ('gamma', c_f32), ('xcd_remap', c_i32),
                 ('pad_x', c_i32), ('out_stride', c_i32), ('out_oy', c_i32), ('out_ox', c_i32), ('out_W', c_i32), ('slope_ptr', c_vp),
-                ('in_stride', c_i32), ('in_oy', c_i32), ('in_ox', c_i32), ('in_W', c_i32), ('in_scale', c_f32)]
+                ('in_stride', c_i32), ('in_oy', c_i32), ('in_ox', c_i32), ('in_W', c_i32), ('in_scale', c_f32), ('out16_f16', c_i32)]
 
 
 class WgradPart(C.Structure):
@@ -64,6 +64,7 @@ OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_DOWNSUM, OP_AXPBY, OP_FILL, OP_L
 (OP_INORM_FWD, OP_INORM_BWD, OP_BCE, OP_DWT_FWD, OP_DWT_BWD, OP_LOWPASS, OP_MAXPOOL, OP_MAXPOOL_BWD, OP_L1DIFF, OP_AFFINE4,
  OP_BILINEAR, OP_LOGLOSS, OP_SIGMOID_BWD, OP_PRELU_GRAD, OP_LOWPASS_VALID, OP_ADD_FLAT, OP_SIGMOID_FWD, OP_EVENT_RECORD, OP_STREAM_WAIT,
  OP_SET_STREAM) = range(11, 31)
+OP_CVT_F16, OP_DOWNSUM_F16 = 31, 32
 
 _SIGS = {
     'dasr_conv': [C.POINTER(ConvParams), c_vp],
@@ -76,6 +77,8 @@ _SIGS = {
     'dasr_nchw_to_blocked': [c_vp, c_i32, c_i32, c_i32, c_i32, Tensor, Tensor, c_vp],
     'dasr_blocked_to_nchw': [Tensor, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
     'dasr_l1_loss': [Tensor, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, Tensor, c_i32, c_vp],
+    'dasr_cvt_f16': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, Tensor, c_vp],
+    'dasr_downsum2x_f16': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_f32, c_f32, Tensor, Tensor, c_vp],
     'dasr_downsum2x': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_f32, Tensor, Tensor, c_vp],
     'dasr_axpby': [Tensor, c_f32, Tensor, c_f32, c_i32, c_i32, c_i32, c_i32, Tensor, Tensor, c_f32, Tensor, c_f32, c_vp, c_vp],
     'dasr_adam': [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp],

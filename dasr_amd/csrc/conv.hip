@@ -84,6 +84,7 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
     const bool has_f32 = G ? p.out_f32.p != nullptr : bool(EPI & 32);
     const bool has_bf16 = G ? p.out_bf16.p != nullptr : bool(EPI & 64);
     const bool scaled = G ? true : bool(EPI & 128);   // alpha / gamma may differ from 1
+    const bool f16out = p.out16_f16 != 0;             // the 16-bit output tensor holds f16 (HR tail, f16 storage) instead of bf16: wave-uniform
     const bool chan_tail = G ? true : false;          // cout not a multiple of 32 (specialised variants require it)
     const int ostr = p.out_stride > 1 ? p.out_stride : 1, owid = p.out_W > 0 ? p.out_W : p.Wout;  // strided sub-grid output (stride-2 dgrad)
     constexpr int MSZ = IN_F32 ? 4 : 2;
@@ -267,8 +268,9 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                     bf16x4 oa, ob;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        oa[j] = (bf16_t)(gm ? v[2 * pr][j] * p.gamma : v[2 * pr][j]);
-                        ob[j] = (bf16_t)(gm ? v[2 * pr + 1][j] * p.gamma : v[2 * pr + 1][j]);
+                        const float va = gm ? v[2 * pr][j] * p.gamma : v[2 * pr][j], vb = gm ? v[2 * pr + 1][j] * p.gamma : v[2 * pr + 1][j];
+                        oa[j] = f16out ? __builtin_bit_cast(bf16_t, (f16_t)va) : (bf16_t)va;
+                        ob[j] = f16out ? __builtin_bit_cast(bf16_t, (f16_t)vb) : (bf16_t)vb;
                     }
                     const u32x2 a = __builtin_bit_cast(u32x2, oa), b = __builtin_bit_cast(u32x2, ob);
                     const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
@@ -282,7 +284,10 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                 for (int g = 0; g < 4; ++g) {
                     bf16x4 ob;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) ob[j] = (bf16_t)(gm ? v[g][j] * p.gamma : v[g][j]);
+                    for (int j = 0; j < 4; ++j) {
+                        const float vv = gm ? v[g][j] * p.gamma : v[g][j];
+                        ob[j] = f16out ? __builtin_bit_cast(bf16_t, (f16_t)vv) : (bf16_t)vv;
+                    }
 #ifdef DASR_TRACE
                     if (p.xcd_remap & 2) {  // timing experiment only: lane-linear (fully contiguous) store addresses, wrong layout
                         const unsigned lin = ((((unsigned)blockIdx.x * 4 + wave) * NT + nt) * 4 + g) * 512u + (unsigned)lane * 8u;
@@ -739,7 +744,10 @@ __device__ __forceinline__ void glds_dma_piece(int i, int ck, char* buf, __amdgp
 
 // ABL (micro-benchmarks only, results are wrong): bit 0 no DMA inside the main loop, bit 1 no fragment reads inside the main loop
 // (stale registers), bit 2 no vmcnt wait / barrier per chunk, bit 3 no MFMAs: what each component costs per chunk (guide: ablate, don't guess)
-template <int MT, int EPI, int NW, int ABL = 0>
+// F16: the 16-bit activations and packed weights are f16 (HR tail of the generator in f16 storage): v_mfma_f32_32x32x16_f16.
+// p.ups: nearest x2 up-sampling folded into the DMA source addresses (upconv_blcok, block.py:854-861): each lane fetches the 16 bytes of
+// low-resolution pixel (y >> 1, x >> 1); the four duplicates come from L2.
+template <int MT, int EPI, int NW, int ABL = 0, bool F16 = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(const dasr_conv_params p) {
     using C = GCfg<MT, NW>;
     constexpr int NT = C::NT;
@@ -751,7 +759,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
     TRACE_STAMP(0);
     // every kernel argument the prologue needs, fetched in ONE scalar-memory batch (hipcc otherwise sinks each s_load next to its first
     // use: three dependent ~0.4 us round trips before the first DMA could be issued); the empty asm pins the batch here
-    int a_cout = p.cout, a_Wout = p.Wout, a_Hout = p.Hout, a_remap = p.xcd_remap, a_cin = p.cin, a_Hin = p.Hin, a_Win = p.Win;
+    int a_cout = p.cout, a_Wout = p.Wout, a_Hout = p.Hout, a_remap = p.xcd_remap | (p.ups << 8), a_cin = p.cin, a_Hin = p.Hin, a_Win = p.Win;
     const void* a_bias = p.bias;
     const void* a_in = p.in.p;
     const void* a_w = p.w;
@@ -792,8 +800,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
         const int pp = q >> 1, h = (q & 1) ^ ((pp >> 3) & 1);
         const int iy = pp / C::IW, ix = pp - iy * C::IW;
         const int gy = iy0 + iy, gx = ix0 + ix;
-        const bool ok = (pp < C::NPIX) & (gy >= 0) & (gy < a_Hin) & (gx >= 0) & (gx < a_Win);  // bitwise: keeps the prologue one basic block
-        goff[r] = ok ? (unsigned)(((gy * a_Win + gx) * 16 + 8 * h) * 2) : OOB;
+        const int us = (a_remap >> 8) & 1;   // nearest x2: the conv runs on the (2 Hin) x (2 Win) grid, the source pixel is (gy >> 1, gx >> 1)
+        const bool ok = (pp < C::NPIX) & (gy >= 0) & (gy < (a_Hin << us)) & (gx >= 0) & (gx < (a_Win << us));  // bitwise: keeps the prologue one basic block
+        goff[r] = ok ? (unsigned)((((gy >> us) * a_Win + (gx >> us)) * 16 + 8 * h) * 2) : OOB;
     }
     const __amdgpu_buffer_rsrc_t rin = make_rsrc((const bf16_t*)a_in + (size_t)n * a_nstr);
     const unsigned in_chunk_bytes = (unsigned)(a_cbstr * 2);
@@ -865,7 +874,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
                 for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[mi][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s & 1][mi], fb[kx & 1][nt + ky], acc[mi][nt], 0, 0, 0);
+                        acc[mi][nt] = mfma16<F16>(fa[s & 1][mi], fb[kx & 1][nt + ky], acc[mi][nt]);
             } else {
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) asm volatile("" ::"v"(fa[s & 1][mi]));
@@ -1053,12 +1062,12 @@ int launch_ring3(const dasr_conv_params& p, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-template <int MT, int EPI = 0, int NW = 4, int ABL = 0>
+template <int MT, int EPI = 0, int NW = 4, int ABL = 0, bool F16 = false>
 int launch_glds(const dasr_conv_params& p, hipStream_t s) {
     using C = GCfg<MT, NW>;
     static bool attr_set = false;
-    auto kfn = conv_glds_kernel<MT, EPI, NW, ABL>;
-    if ((p.cin & 15) || p.kh != 3 || p.stride != 1 || p.pad != 1 || p.ups || p.in_f32 || p.prec != 1 || (p.pad_x >= 0 && p.pad_x != 1) || p.in_stride > 1)
+    auto kfn = conv_glds_kernel<MT, EPI, NW, ABL, F16>;
+    if ((p.cin & 15) || p.kh != 3 || p.stride != 1 || p.pad != 1 || p.in_f32 || p.prec != (F16 ? 2 : 1) || (p.pad_x >= 0 && p.pad_x != 1) || p.in_stride > 1)
         return DASR_EINVAL;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
@@ -1175,7 +1184,7 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
     hipStream_t s = as_stream(stream);
     if (p.cin <= 0 || (p.cin & 15) || p.cout <= 0 || !p.w || !p.in.p) return DASR_EINVAL;
     if (!(p.mt == 1 || p.mt == 2) || !(p.prec == 1 || p.prec == 2 || p.prec == 3)) return DASR_EINVAL;
-    if (p.prec == 2 && !p.in_f32) return DASR_EINVAL;
+    if (p.prec == 2 && !p.in_f32 && (p.kh != 3 || p.stride != 1)) return DASR_EINVAL;   // f16 tensors: dense 3x3 kernel only
     int kcode = 0;
     if (p.kh == 4) kcode = p.stride == 2 ? 2 : 1;
     else if (p.kh == 2) kcode = 3;
@@ -1190,6 +1199,7 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
     if (p.kh == 2 && (p.stride != 1 || p.pad < 0 || p.pad > 1)) return DASR_EINVAL;
     if (p.kh < 1 || p.kh > 5) return DASR_EINVAL;
     if (p.mask.p && (p.mask_f32 != 0) != (p.in_f32 != 0)) return DASR_EINVAL;  // mask dtype is tied to the input dtype
+    if (p.ups && !p.in_f32 && p.prec != 2) return DASR_EINVAL;
     switch (key) {
         // prec 1, bf16 input (RDB dense-block convs, fwd and dgrad)
         case 10:
@@ -1295,6 +1305,21 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
         case 1114: return launch<3, true, 1, 5, 1, 2>(p, s);  // DSN FSD discriminator 5x5
         case 1115: return launch<3, true, 1, 1, 1, 4>(p, s);  // 1x1 head
         case 1116: return launch<3, true, 1, 3, 2, 1>(p, s);  // De_resnet down-sampling convs
+        // prec 2 on f16 TENSORS (HR tail in f16 storage): the LDS-DMA dense-conv kernel with the f16 MFMA
+        case 2010:
+            switch (g_tune_epi ? classify_epi(p) : 0) {
+                case 67: return launch_glds<1, 67, 4, 0, true>(p, s);
+                case 68: return launch_glds<1, 68, 4, 0, true>(p, s);
+                case 64: return launch_glds<1, 64, 4, 0, true>(p, s);
+                default: return launch_glds<1, 0, 4, 0, true>(p, s);
+            }
+        case 2020:
+            switch (g_tune_epi ? classify_epi(p) : 0) {
+                case 67: return launch_glds<2, 67, 4, 0, true>(p, s);
+                case 68: return launch_glds<2, 68, 4, 0, true>(p, s);
+                case 64: return launch_glds<2, 64, 4, 0, true>(p, s);
+                default: return launch_glds<2, 0, 4, 0, true>(p, s);
+            }
         // prec 2: f16 operands, ONE MFMA pass on f32 activations (HR tail of the generator; VGG / discriminators / DSN when selected)
         case 2110: return launch<2, true, 1, 3, 1, 4>(p, s);
         case 2120: return launch<2, true, 2, 3, 1, 4>(p, s);

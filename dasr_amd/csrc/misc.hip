@@ -290,6 +290,74 @@ extern "C" int dasr_downsum2x(dasr_tensor src, int32_t N, int32_t C, int32_t H, 
     return (int)hipGetLastError();
 }
 
+// ---- f16-storage helpers of the generator's HR tail ---------------------------------------------------------------------------
+// y16 = f16(scale * x) over a blocked f32 tensor (dL/dSR -> pre-scaled f16 gradient)
+__global__ void cvt_f16_kernel(dasr_tensor x, int N, int C, int H, int W, float scale, dasr_tensor y) {
+    const int ncb = (C + 15) >> 4;
+    const long long per_plane = (long long)H * W * 4, total = (long long)N * ncb * per_plane;
+    const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= total) return;
+    const long long e = (gi % per_plane) * 4;
+    long long t = gi / per_plane;
+    const int cb = t % ncb, n = t / ncb;
+    const f32x4 v = *(const f32x4*)((const float*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + e);
+    f16x4 o;
+    for (int j = 0; j < 4; ++j) o[j] = (f16_t)(v[j] * scale);
+    *(f16x4*)((f16_t*)y.p + (size_t)n * y.n_stride + (size_t)cb * y.cb_stride + e) = o;
+}
+
+// backward of nn.Upsample(nearest, 2) on f16 tensors: dst[y][x] = out_scale * (LeakyReLU' mask) * sum of the 2x2 block of src;
+// dst is f16 (df.p == NULL) or f32.  thread per (n, cb, y, x, 4-channel quad) at the LOW resolution
+__global__ void downsum2x_f16_kernel(dasr_tensor src, int N, int C, int H, int W, dasr_tensor mask, float slope, float out_scale, dasr_tensor df,
+                                     dasr_tensor dh) {
+    const int ncb = (C + 15) >> 4;
+    const long long total = (long long)N * ncb * H * W * 4;
+    const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= total) return;
+    const int q = gi & 3;
+    const long long i = gi >> 2;
+    const int x = i % W;
+    long long t = i / W;
+    const int y = t % H;
+    t /= H;
+    const int cb = t % ncb, n = t / ncb;
+    const f16_t* s = (const f16_t*)src.p + (size_t)n * src.n_stride + (size_t)cb * src.cb_stride + q * 4;
+    const int W2 = 2 * W;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx) {
+            const f16x4 v = *(const f16x4*)(s + ((size_t)(2 * y + dy) * W2 + 2 * x + dx) * 16);
+            for (int j = 0; j < 4; ++j) a[j] += (float)v[j];
+        }
+    const size_t po = ((size_t)y * W + x) * 16 + q * 4;
+    if (mask.p) {
+        const f16x4 mv = *(const f16x4*)((const f16_t*)mask.p + (size_t)n * mask.n_stride + (size_t)cb * mask.cb_stride + po);
+        for (int j = 0; j < 4; ++j) a[j] = (float)mv[j] > 0.f ? a[j] : a[j] * slope;
+    }
+    for (int j = 0; j < 4; ++j) a[j] *= out_scale;
+    if (df.p) *(f32x4*)((float*)df.p + (size_t)n * df.n_stride + (size_t)cb * df.cb_stride + po) = f32x4{a[0], a[1], a[2], a[3]};
+    if (dh.p) {
+        f16x4 o;
+        for (int j = 0; j < 4; ++j) o[j] = (f16_t)a[j];
+        *(f16x4*)((f16_t*)dh.p + (size_t)n * dh.n_stride + (size_t)cb * dh.cb_stride + po) = o;
+    }
+}
+
+extern "C" int dasr_cvt_f16(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, float scale, dasr_tensor y, void* stream) {
+    const long long total = (long long)N * ((C + 15) / 16) * H * W * 4;
+    if (total <= 0 || !x.p || !y.p) return DASR_EINVAL;
+    DASR_LAUNCH(cvt_f16_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, scale, y);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_downsum2x_f16(dasr_tensor src, int32_t N, int32_t C, int32_t H, int32_t W, dasr_tensor mask, float slope, float out_scale,
+                                  dasr_tensor dst_f32, dasr_tensor dst_f16, void* stream) {
+    const long long total = (long long)N * ((C + 15) / 16) * H * W * 4;
+    if (total <= 0 || !src.p) return DASR_EINVAL;
+    DASR_LAUNCH(downsum2x_f16_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), src, N, C, H, W, mask, slope, out_scale, dst_f32, dst_f16);
+    return (int)hipGetLastError();
+}
+
 extern "C" int dasr_axpby(dasr_tensor x, float a, dasr_tensor z, float b, int32_t N, int32_t C, int32_t H, int32_t W,
                           dasr_tensor out_f32, dasr_tensor out_bf16, float gamma, dasr_tensor mask, float slope, const float* slope_ptr,
                           void* stream) {
@@ -544,6 +612,8 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream0) {
             case DASR_OP_EVENT_RECORD: rc = (int)hipEventRecord((hipEvent_t)o.p[0], as_stream(stream)); break;
             case DASR_OP_STREAM_WAIT: rc = (int)hipStreamWaitEvent(as_stream(stream), (hipEvent_t)o.p[0], 0); break;
             case DASR_OP_SET_STREAM: stream = o.p[0] ? o.p[0] : stream0; break;
+            case DASR_OP_CVT_F16: rc = dasr_cvt_f16(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1], stream); break;
+            case DASR_OP_DOWNSUM_F16: rc = dasr_downsum2x_f16(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1], o.f[0], o.f[1], o.t[2], o.t[3], stream); break;
             default: rc = DASR_EINVAL;
         }
         if (rc != 0) {

@@ -38,6 +38,12 @@ __device__ unsigned long long* g_wtrace = nullptr;  // [grid][16] s_memtime stam
 #define WTRACE(k) do {} while (0)
 #endif
 
+template <bool F16>
+__device__ __forceinline__ float frag_f32(bf16x8 a, int j) {
+    if constexpr (F16) return (float)__builtin_bit_cast(f16x8, a)[j];
+    else return (float)a[j];
+}
+
 __device__ __forceinline__ bf16x8 frag_tr(const char* base, int off0, int off1) {
     const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((DASR_LDS bf16x4*)(base + off0));
     const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((DASR_LDS bf16x4*)(base + off1));
@@ -305,9 +311,11 @@ struct W3 {
 // 3x3 weight gradient, one 32x32 accumulator per tap.  Per 8x16-pixel tile: G and the X halo tile are staged into LDS by all
 // 768 threads (register prefetch one tile ahead; per-thread piece geometry is computed once), then per pixel row r and tap:
 // A = G^T fragment [oc][16 pixels], B = X fragment [16 pixels shifted by the tap][cin], both gathered with ds_read_b64_tr_b16.
-template <bool USE_TR, bool F32>
+// F16: the 16-bit tensors hold f16 (HR tail of the generator in f16 storage, gradients pre-scaled by a power of two): f16 MFMA
+template <bool USE_TR, bool F32, bool F16 = false>
 __global__ __launch_bounds__(768, 1) void wgrad3_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit_flags,
                                                         float* __restrict__ ws) {
+    static_assert(!F16 || !F32, "wgrad3 F16: 16-bit f16 tensors");
     using C = W3;
     const int nsplit = nsplit_flags & 0xffffff;
     const bool g_stagger_flag = (nsplit_flags >> 24) & 1;  // A/B: staggered in-compute prefetch issue
@@ -448,11 +456,11 @@ __global__ __launch_bounds__(768, 1) void wgrad3_kernel(const dasr_wgrad_part* _
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                acc[t - T0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[r & 1], b[i & 1], acc[t - T0], 0, 0, 0);
+                acc[t - T0] = mfma16<F16>(a[r & 1], b[i & 1], acc[t - T0]);
                 if constexpr (!F32 && T0 == 0) {
                     if (t == 2 && P.want_bias && ct == 0) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) bsum += (float)a[r & 1][j];
+                        for (int j = 0; j < 8; ++j) bsum += frag_f32<F16>(a[r & 1], j);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -467,7 +475,7 @@ __global__ __launch_bounds__(768, 1) void wgrad3_kernel(const dasr_wgrad_part* _
                 if constexpr (!F32 && T0 == 0) {
                     if (P.want_bias && ct == 0) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) bsum += (float)a[j];
+                        for (int j = 0; j < 8; ++j) bsum += frag_f32<F16>(a, j);
                     }
                 }
 #pragma unroll
@@ -478,7 +486,7 @@ __global__ __launch_bounds__(768, 1) void wgrad3_kernel(const dasr_wgrad_part* _
                     const char* b1 = il + (ct * 2 + fplane) * C::IPLANE + (prow + 8 * khalf) * 32 + li * 2;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) b[j] = *(const bf16_t*)(b1 + j * 32);
-                    acc[t - T0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t - T0], 0, 0, 0);
+                    acc[t - T0] = mfma16<F16>(a, b, acc[t - T0]);
                 }
             }
         }
@@ -831,9 +839,9 @@ int launch_wgrad(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws
 }
 
 extern int g_wgrad3_stagger;
-template <bool USE_TR, bool F32>
+template <bool USE_TR, bool F32, bool F16 = false>
 int launch_wgrad3(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws, hipStream_t s) {
-    auto kfn = wgrad3_kernel<USE_TR, F32>;
+    auto kfn = wgrad3_kernel<USE_TR, F32, F16>;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, W3::LDS_BYTES + 16));
@@ -903,6 +911,7 @@ extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int3
     if (g_use_tr < 0) return DASR_EINVAL;  // dasr_probe_tr16 must run once per process (outside graph capture)
     const bool tr = g_use_tr == 1;
     if (kh == 33) {  // v3 layout: 6-wave workgroups, 3 oc tiles x 64 cin per part (3x3 stride 1 only)
+        if (f32 == 2) return tr ? launch_wgrad3<true, false, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3<false, false, true>(parts_dev, nparts, nsplit, ws, s);
         if (tr && !f32 && g_wgrad3_glds) return launch_wgrad3_glds(parts_dev, nparts, nsplit, ws, s);
         if (tr) return f32 ? launch_wgrad3<true, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3<true, false>(parts_dev, nparts, nsplit, ws, s);
         return f32 ? launch_wgrad3<false, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3<false, false>(parts_dev, nparts, nsplit, ws, s);

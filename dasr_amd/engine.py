@@ -26,10 +26,11 @@ def ceil_div(a, b):
 class BTensor:
     """Blocked activation tensor T[n][cb][y][x][16] (bf16 or f32) living in a torch CUDA tensor."""
 
-    def __init__(self, N, C_, H, W, f32, device):
+    def __init__(self, N, C_, H, W, f32, device, f16=False):
+        """f16 (with f32 False): the 16-bit elements are IEEE half instead of bfloat16 (HR tail of the generator)"""
         self.N, self.C, self.H, self.W, self.f32 = N, C_, H, W, f32
         self.planes = ceil_div(C_, 16)
-        self.t = torch.zeros((N, self.planes, H, W, 16), dtype=torch.float32 if f32 else torch.bfloat16, device=device)
+        self.t = torch.zeros((N, self.planes, H, W, 16), dtype=torch.float32 if f32 else (torch.float16 if f16 else torch.bfloat16), device=device)
         self.esz = 4 if f32 else 2
 
     def view(self, c0=0):
@@ -226,7 +227,7 @@ def run_interleaved(lists, streams, chunk=None):
 
 def conv_op(pack, ref, inp, in_f32, cin, Hin, Win, Hout, Wout, N, bias=None, kh=3, stride=1, pad=1, ups=0, act=0, slope=SLOPE,
             mask=None, mask_f32=0, alpha=1.0, res1=None, beta1=0.0, res2=None, beta2=0.0, out_f32=None, out_bf16=None, gamma=1.0,
-            pad_x=-1, out_stride=1, out_oy=0, out_ox=0, out_W=0, slope_ptr=None, in_stride=1, in_oy=0, in_ox=0, in_W=0, flops=None, in_scale=0.0):
+            pad_x=-1, out_stride=1, out_oy=0, out_ox=0, out_W=0, slope_ptr=None, in_stride=1, in_oy=0, in_ox=0, in_W=0, flops=None, in_scale=0.0, out16_f16=0):
     """flops: algorithmic FLOPs of the reference op this launch stands for (default: 2 * outputs * taps * cin * cout of the launch
     itself; the sub-pixel upconv launches pass a quarter of the reference's 3x3 conv on the up-sampled grid instead)."""
     assert cin == ref.cin_pad, (cin, ref.cin_pad)
@@ -249,7 +250,8 @@ def conv_op(pack, ref, inp, in_f32, cin, Hin, Win, Hout, Wout, N, bias=None, kh=
     p.pad_x, p.out_stride, p.out_oy, p.out_ox, p.out_W = pad_x, out_stride, out_oy, out_ox, out_W
     p.slope_ptr = slope_ptr
     p.in_stride, p.in_oy, p.in_ox, p.in_W = in_stride, in_oy, in_ox, in_W
-    p.in_scale = in_scale if ref.prec == 2 else 0.0   # power-of-two pre-scale of a gradient input before its f16 rounding
+    p.in_scale = in_scale if (ref.prec == 2 and in_f32) else 0.0   # power-of-two pre-scale of an f32 gradient input before its f16 rounding
+    p.out16_f16 = int(out16_f16)
     return o
 
 
@@ -389,10 +391,13 @@ class WgradGroup3:
     def ops(self, grad_ptr, scale=1.0):
         a, b = Op(), Op()
         a.op = _lib.OP_WGRAD
-        a.p[0], a.i[0], a.i[1], a.i[2], a.i[3], a.i[4] = self.w_dev.data_ptr(), len(self.parts), self.nsplit, 33, 1, self.parts[0][0].g_f32
+        f16 = getattr(self, 'f16', False)   # 16-bit f16 tensors (gradient pre-scaled by g_scale): f16 MFMA, reduce scale x 1 / g_scale
+        a.p[0], a.i[0], a.i[1], a.i[2], a.i[3], a.i[4] = self.w_dev.data_ptr(), len(self.parts), self.nsplit, 33, 1, (2 if f16 else self.parts[0][0].g_f32)
         a.flops = float(getattr(self, 'flops', 0.0))
         b.op = _lib.OP_WGRAD_REDUCE
         b.p[0], b.i[0], b.p[2], b.f[0] = self.r_dev.data_ptr(), self.n_red, grad_ptr, scale
+        gs = getattr(self, 'g_scale', 0.0)
+        b.f[1] = 1.0 / gs if (f16 and gs) else 0.0
         self.workspace.register(a, b)
         return [a, b]
 

@@ -42,6 +42,10 @@ class RRDBNetHIP:
         self.params = ParamStore(rrdbnet_param_spec(in_nc, out_nc, nf, nb), self.device)
         self.rdb_prec, self.stream_prec = rdb_prec, stream_prec
         self.hr_prec = int(os.environ.get('DASR_HR_PREC', '2')) if stream_prec == 3 else stream_prec
+        # f16 STORAGE of the HR tail (u1, u2, h0 and their gradients live in HBM as f16): the consumers then run on the LDS-DMA dense-conv
+        # kernel / the 12-wave wgrad kernel with the f16 MFMA instead of the register-staged f32-input kernels (3x faster there), and the
+        # HR tensors cost half the bytes.  DASR_HR_STORE=f32 keeps f32 tensors (f16 rounding while staging)
+        self.hr_f16s = self.hr_prec == 2 and os.environ.get('DASR_HR_STORE', 'f16') == 'f16'
         self.pack = PackRegistry(self.params)
         self._register_packs()
         self.pack.finalize()
@@ -67,18 +71,27 @@ class RRDBNetHIP:
         for name, key, cout in (('lr', lr, nf), ('up1', 'model.3.weight', nf), ('up2', 'model.6.weight', nf),
                                 ('hr0', 'model.8.weight', nf), ('hr1', 'model.10.weight', self.out_nc)):
             pr = sp if name == 'lr' else hp
+            if self.hr_f16s and name != 'lr':
+                continue   # f16 storage: the HR-tail packs are registered below (direct 3x3 forms on 16-bit tensors)
             self.pk[name] = self.pack.add(cout, nf, 9, hmt if (pr == 2 and cout % 64 == 0) else 1, pr, [self._seg_fwd(key, cout, nf)])
             # data-gradient: transposed + tap-flipped; packed cin = forward cout (padded to 16)
             cin_b = ceil_div(cout, 16) * 16
             self.pk[name + '_b'] = self.pack.add(nf, cin_b, 9, hmt if pr == 2 else 1, pr, [(P.off(key), cout, nf, 0, cout, 0, 1)])
+        if self.hr_f16s:   # direct 3x3 forms on 16-bit tensors (nearest x2 folded into the DMA addresses of the dense-conv kernel)
+            mtH = 2 if nf % 64 == 0 else 1
+            for name, key in (('up1', 'model.3.weight'), ('up2', 'model.6.weight'), ('hr0', 'model.8.weight')):
+                self.pk[name] = self.pack.add(nf, nf, 9, mtH, 2, [self._seg_fwd(key, nf, nf)])
+                self.pk[name + '_b'] = self.pack.add(nf, nf, 9, mtH, 2, [(P.off(key), nf, nf, 0, nf, 0, 1)])
+            self.pk['hr1'] = self.pack.add(self.out_nc, nf, 9, 1, 2, [self._seg_fwd('model.10.weight', self.out_nc, nf)])
+            self.pk['hr1_b'] = self.pack.add(nf, 16, 9, mtH, 2, [(P.off('model.10.weight'), self.out_nc, nf, 0, self.out_nc, 0, 1)])
         # sub-pixel form of nearest-x2 + 3x3 (upconv_blcok, block.py:854-861): output parity (py, px) is a 2x2 convolution of the
         # LOW-resolution input whose taps are sums of the 3x3 taps that land on the same source pixel -- 16 instead of 36 MACs per
         # input pixel, channel pair and 2x2 output block.  Row taps per parity: py=0 reads rows (i-1, i) with (w0, w1+w2), py=1 rows
         # (i, i+1) with (w0+w1, w2); same along x.  The data gradient is the transpose: per parity a 2x2 conv of that parity's
         # sub-grid of the output gradient with the tap order reversed, summed over the four parities.
-        self.subpixel = os.environ.get('DASR_SUBPIXEL', '1') == '1'
+        self.subpixel = os.environ.get('DASR_SUBPIXEL', '1') == '1' and not self.hr_f16s
         rows = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}   # parity -> source taps of packed tap a = 0, 1
-        for name, key in (('up1', 'model.3.weight'), ('up2', 'model.6.weight')):
+        for name, key in (() if self.hr_f16s else (('up1', 'model.3.weight'), ('up2', 'model.6.weight'))):
             for py in (0, 1):
                 for px in (0, 1):
                     fw = [sum(1 << (ky * 3 + kx) for ky in rows[py][a] for kx in rows[px][b]) for a in (0, 1) for b in (0, 1)]
@@ -167,16 +180,20 @@ class _Plan:
         self.slabs = [B(sc, h, w, False) for _ in range(3 * nb)]
         self.stream = [B(nf, h, w, True) for _ in range(4)]
         self.t0 = B(nf, h, w, True)
-        self.u1 = B(nf, H2, W2, True)
-        self.u2 = B(nf, H4, W4, True)
-        self.h0 = B(nf, H4, W4, True)
+        hs = net.hr_f16s
+        Bh = (lambda C_, H, W: BTensor(N, C_, H, W, False, dev, f16=True)) if hs else (lambda C_, H, W: B(C_, H, W, True))
+        self.t0h = Bh(nf, h, w) if hs else None   # f16 shadow of the trunk output (input of upconv1)
+        self.u1 = Bh(nf, H2, W2)
+        self.u2 = Bh(nf, H4, W4)
+        self.h0 = Bh(nf, H4, W4)
         self.sr = B(16, H4, W4, True)
         # backward
         self.g_sr = B(16, H4, W4, True)
-        self.g4a = B(nf, H4, W4, True)
-        self.g4b = B(nf, H4, W4, True)
-        self.g2a = B(nf, H2, W2, True)
-        self.g2b = B(nf, H2, W2, True)
+        self.g_sr16 = Bh(16, H4, W4) if hs else None   # dL/dSR, pre-scaled by gscale, f16
+        self.g4a = Bh(nf, H4, W4)
+        self.g4b = Bh(nf, H4, W4)
+        self.g2a = Bh(nf, H2, W2)
+        self.g2b = Bh(nf, H2, W2)
         self.g_t0 = B(nf, h, w, True)
         self.gstream = [B(nf, h, w, True) for _ in range(4)]
         # RDB weight gradients are off the data-gradient chain's critical path; DASR_WG_SIDE=1 moves them to a side stream of the plan
@@ -250,6 +267,21 @@ class _Plan:
                 ops.add(o)
         self.x_last = X
         lrb = 'model.1.sub.%d.bias' % nb
+        if net.hr_f16s:
+            ops.add(conv_op(pack, pk['lr'], X.view(), True, nf, h, w, h, w, N, bias=P.ptr(lrb), res1=self.fea.view(), beta1=1.0,
+                            out_f32=self.t0.view(), out_bf16=self.t0h.view(), out16_f16=1))
+            for name, bkey, src, dst, hi, wi in (('up1', 'model.3.bias', self.t0h, self.u1, h, w), ('up2', 'model.6.bias', self.u1, self.u2, H2, W2)):
+                ops.add(conv_op(pack, pk[name], src.view(), False, nf, hi, wi, 2 * hi, 2 * wi, N, bias=P.ptr(bkey), ups=1, act=1, out_bf16=dst.view(),
+                                out16_f16=1))
+            ops.add(conv_op(pack, pk['hr0'], self.u2.view(), False, nf, H4, W4, H4, W4, N, bias=P.ptr('model.8.bias'), act=1, out_bf16=self.h0.view(),
+                            out16_f16=1))
+            ops.add(conv_op(pack, pk['hr1'], self.h0.view(), False, nf, H4, W4, H4, W4, N, bias=P.ptr('model.10.bias'), out_f32=self.sr.view()))
+            o = Op()
+            o.op = _lib.OP_B2NCHW
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.p[0] = self.sr.view(), N, net.out_nc, H4, W4, self.sr_nchw.data_ptr()
+            ops.add(o)
+            self.fwd = ops
+            return
         ops.add(conv_op(pack, pk['lr'], X.view(), True, nf, h, w, h, w, N, bias=P.ptr(lrb), res1=self.fea.view(), beta1=1.0,
                         out_f32=self.t0.view()))
         for name, bkey, src, dst, hi, wi in (('up1', 'model.3.bias', self.t0, self.u1, h, w), ('up2', 'model.6.bias', self.u1, self.u2, H2, W2)):
@@ -313,6 +345,74 @@ class _Plan:
         g_h0, g_u2, g_up2 = self.g4a, self.g4b, self.g4a
         f16 = net.hr_prec == 2
         gs = self.gscale
+        if net.hr_f16s:
+            self._build_backward_tail_f16(ops)
+        else:
+            self._build_backward_tail_f32(ops, f16, gs)
+        self._build_backward_trunk(ops)
+
+    def _wg3(self, ops, conv_key, g, inp, cout, cin, Hin, Win, Hout, Wout, ups=0):
+        """weight gradient of one 3x3 conv on f16 tensors (g pre-scaled by gscale) with the 12-wave kernel: one part per 64-channel block of
+        the input x up to three 32-oc tiles"""
+        P, N = self.net.params, self.N
+        grp = WgradGroup3()
+        octs = list(range(0, cout, 32))
+        for c0 in range(0, cin, 64):
+            blk = min(64, cin - c0)
+            for k0 in range(0, len(octs), 3):
+                sub = octs[k0:k0 + 3]
+                tiles = [dict(dst_w_off=P.off(conv_key + 'weight'), dst_b_off=P.off(conv_key + 'bias') if c0 == 0 else None, cout=cout, cin=cin,
+                              oc0=oc0, c0=c0, n_ctiles=min(2, ceil_div(blk, 32))) for oc0 in sub]
+                grp.add_block(g.view(sub[0]), min(2 * len(sub), g.planes - sub[0] // 16), inp.view(c0), ceil_div(blk, 16), ceil_div(blk, 32),
+                              Hin, Win, Hout, Wout, N, tiles, want_bias=(c0 == 0), ups=ups)
+        grp.f16, grp.g_scale = True, self.gscale
+        grp.flops = 2.0 * N * Hout * Wout * 9 * cin * cout
+        grp.finalize(self.ws, self.net.device, target_wgs=int(os.environ.get('DASR_WG3_TARGET', str(256 // max(1, getattr(self.net, 'concurrent_replicas', 1))))))
+        for o in grp.ops(self.grad.data_ptr()):
+            ops.add(o)
+        ops.keep.append(grp)
+
+    def _build_backward_tail_f16(self, ops):
+        """HR tail in f16 storage: every gradient tensor holds gscale * dL/d(.) in f16; the last 2x2 down-sum hands dL/d(trunk output) back in
+        f32, un-scaled"""
+        net, N, h, w = self.net, self.N, self.h, self.w
+        nf, pack, pk, gs = net.nf, net.pack, net.pk, self.gscale
+        H2, W2, H4, W4 = 2 * h, 2 * w, 4 * h, 4 * w
+        g_h0, g_u2, g_up2, g_u1, g_up1 = self.g4a, self.g4b, self.g4a, self.g2a, self.g2b
+
+        def downsum(src, hl, wl, mask, dst_f32, dst_f16, out_scale):
+            o = Op()
+            o.op = _lib.OP_DOWNSUM_F16
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = src.view(), N, nf, hl, wl
+            o.t[1], o.f[0], o.f[1] = (mask.view() if mask is not None else NULL_T), SLOPE, out_scale
+            o.t[2], o.t[3] = (dst_f32.view() if dst_f32 is not None else NULL_T), (dst_f16.view() if dst_f16 is not None else NULL_T)
+            ops.add(o)
+
+        o = Op()
+        o.op = _lib.OP_CVT_F16
+        o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1] = self.g_sr.view(), N, net.out_nc, H4, W4, gs, self.g_sr16.view()
+        ops.add(o)
+        # HR_conv1
+        self._wg3(ops, 'model.10.', self.g_sr16, self.h0, net.out_nc, nf, H4, W4, H4, W4)
+        ops.add(conv_op(pack, pk['hr1_b'], self.g_sr16.view(), False, 16, H4, W4, H4, W4, N, mask=self.h0.view(), mask_f32=0, out_bf16=g_h0.view(),
+                        out16_f16=1))
+        # HR_conv0
+        self._wg3(ops, 'model.8.', g_h0, self.u2, nf, nf, H4, W4, H4, W4)
+        ops.add(conv_op(pack, pk['hr0_b'], g_h0.view(), False, nf, H4, W4, H4, W4, N, mask=self.u2.view(), mask_f32=0, out_bf16=g_u2.view(), out16_f16=1))
+        # upconv2: weight gradient on the up-sampled u1; data gradient on the 4h x 4w grid, then the 2x2 sum with LeakyReLU'(u1)
+        self._wg3(ops, 'model.6.', g_u2, self.u1, nf, nf, H2, W2, H4, W4, ups=1)
+        ops.add(conv_op(pack, pk['up2_b'], g_u2.view(), False, nf, H4, W4, H4, W4, N, out_bf16=g_up2.view(), out16_f16=1))
+        downsum(g_up2, H2, W2, self.u1, None, g_u1, 1.0)
+        # upconv1: its input is the (linear) trunk output: no mask; the sum leaves the f16 / scaled domain
+        self._wg3(ops, 'model.3.', g_u1, self.t0h, nf, nf, h, w, H2, W2, ups=1)
+        ops.add(conv_op(pack, pk['up1_b'], g_u1.view(), False, nf, H2, W2, H2, W2, N, out_bf16=g_up1.view(), out16_f16=1))
+        downsum(g_up1, h, w, None, self.g_t0, None, 1.0 / gs)
+
+    def _build_backward_tail_f32(self, ops, f16, gs):
+        net, N, h, w = self.net, self.N, self.h, self.w
+        nf, nb, P, pack, pk = net.nf, net.nb, net.params, net.pack, net.pk
+        H2, W2, H4, W4 = 2 * h, 2 * w, 4 * h, 4 * w
+        g_h0, g_u2, g_up2 = self.g4a, self.g4b, self.g4a
         # HR_conv1
         self._wg(ops, 'model.10.', self.g_sr, True, self.h0, True, net.out_nc, nf, H4, W4, H4, W4, f16=f16)
         ops.add(conv_op(pack, pk['hr1_b'], self.g_sr.view(), True, 16, H4, W4, H4, W4, N, mask=self.h0.view(), mask_f32=1,
@@ -345,6 +445,10 @@ class _Plan:
             o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = g_up1.view(), N, nf, h, w
             o.t[1], o.i[4], o.f[0], o.t[2], o.t[3] = NULL_T, 0, SLOPE, self.g_t0.view(), NULL_T
             ops.add(o)
+
+    def _build_backward_trunk(self, ops):
+        net, N, h, w = self.net, self.N, self.h, self.w
+        nf, nb, P, pack, pk = net.nf, net.nb, net.params, net.pack, net.pk
         # LR_conv (model.1.sub.nb): t0 = fea + LR_conv(x_last)
         lrk = 'model.1.sub.%d.' % nb
         self._wg(ops, lrk, self.g_t0, True, self.x_last, True, nf, nf, h, w, h, w)

@@ -68,6 +68,9 @@ typedef struct {
     /* prec 2: the f32 input is multiplied by in_scale (a power of two; 0 = 1) before it is rounded to f16, and the accumulator by
      * 1/in_scale before the epilogue: keeps tiny loss gradients (1e-8..1e-5) inside f16's normal range, exact otherwise. */
     float in_scale;
+    /* non-zero: the 16-bit output tensor (`out_bf16`) is written as f16 instead of bf16 (activations of the generator's HR tail are
+     * kept in f16: 11-bit mantissa, one MFMA pass in the consuming conv, prec 2 with in_f32 = 0) */
+    int32_t out16_f16;
 } dasr_conv_params;
 
 int dasr_conv(const dasr_conv_params* p, void* stream);
@@ -171,6 +174,12 @@ int dasr_l1_loss(dasr_tensor sr, const float* hr_nchw, const float* weight_map, 
 int dasr_downsum2x(dasr_tensor src, int32_t N, int32_t C, int32_t H, int32_t W, dasr_tensor mask, int32_t mask_f32,
                    float slope, dasr_tensor dst_f32, dasr_tensor dst_bf16, void* stream);
 
+/* f16 storage of the generator's HR tail: y (f16, blocked) = f16(scale * x) of a blocked f32 tensor (dL/dSR -> pre-scaled f16 gradient), and
+ * the backward of nn.Upsample(nearest,2) on f16 tensors: dst = out_scale * mask' * (2x2 block sum of src); dst_f32 and/or dst_f16 */
+int dasr_cvt_f16(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, float scale, dasr_tensor y, void* stream);
+int dasr_downsum2x_f16(dasr_tensor src, int32_t N, int32_t C, int32_t H, int32_t W, dasr_tensor mask /* f16, optional */, float slope,
+                       float out_scale, dasr_tensor dst_f32, dasr_tensor dst_f16, void* stream);
+
 /* out = a*x + b*z (z optional) over blocked f32 tensors, optional bf16 copy scaled by gamma
  * (ShortcutBlock / RRDB residual bookkeeping, block.py:97-105,305-309) */
 int dasr_axpby(dasr_tensor x, float a, dasr_tensor z, float b, int32_t N, int32_t C, int32_t H, int32_t W,
@@ -265,7 +274,8 @@ enum { DASR_OP_CONV = 1, DASR_OP_WGRAD = 2, DASR_OP_WGRAD_REDUCE = 3, DASR_OP_PA
        DASR_OP_BILINEAR = 21, DASR_OP_LOGLOSS = 22, DASR_OP_SIGMOID_BWD = 23, DASR_OP_PRELU_GRAD = 24, DASR_OP_LOWPASS_VALID = 25,
        DASR_OP_ADD_FLAT = 26, DASR_OP_SIGMOID_FWD = 27,
        /* scheduling ops: p[0] = event from dasr_event_create / a hipStream_t (NULL: back to the stream dasr_run_ops was called with) */
-       DASR_OP_EVENT_RECORD = 28, DASR_OP_STREAM_WAIT = 29, DASR_OP_SET_STREAM = 30 };
+       DASR_OP_EVENT_RECORD = 28, DASR_OP_STREAM_WAIT = 29, DASR_OP_SET_STREAM = 30,
+       DASR_OP_CVT_F16 = 31, DASR_OP_DOWNSUM_F16 = 32 };
 
 typedef struct {
     int32_t op;  int32_t i[8];  float f[4];  int64_t l[4];  void* p[4];  dasr_tensor t[5];
