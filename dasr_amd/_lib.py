@@ -64,7 +64,7 @@ OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_DOWNSUM, OP_AXPBY, OP_FILL, OP_L
 (OP_INORM_FWD, OP_INORM_BWD, OP_BCE, OP_DWT_FWD, OP_DWT_BWD, OP_LOWPASS, OP_MAXPOOL, OP_MAXPOOL_BWD, OP_L1DIFF, OP_AFFINE4,
  OP_BILINEAR, OP_LOGLOSS, OP_SIGMOID_BWD, OP_PRELU_GRAD, OP_LOWPASS_VALID, OP_ADD_FLAT, OP_SIGMOID_FWD, OP_EVENT_RECORD, OP_STREAM_WAIT,
  OP_SET_STREAM) = range(11, 31)
-OP_CVT_F16, OP_DOWNSUM_F16 = 31, 32
+OP_CVT_F16, OP_DOWNSUM_F16, OP_PIXSHUF, OP_PIXUNSHUF = 31, 32, 33, 34
 
 _SIGS = {
     'dasr_conv': [C.POINTER(ConvParams), c_vp],
@@ -77,6 +77,8 @@ _SIGS = {
     'dasr_nchw_to_blocked': [c_vp, c_i32, c_i32, c_i32, c_i32, Tensor, Tensor, c_vp],
     'dasr_blocked_to_nchw': [Tensor, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
     'dasr_l1_loss': [Tensor, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, Tensor, c_i32, c_vp],
+    'dasr_pixel_shuffle_f16': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_vp],
+    'dasr_pixel_unshuffle_f16': [Tensor, Tensor, c_f32, c_i32, c_i32, c_i32, c_i32, Tensor, c_vp],
     'dasr_cvt_f16': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, Tensor, c_vp],
     'dasr_downsum2x_f16': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_f32, c_f32, Tensor, Tensor, c_vp],
     'dasr_downsum2x': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_f32, Tensor, Tensor, c_vp],
@@ -108,6 +110,11 @@ _SIGS = {
     'dasr_abi_version': [],
     'dasr_probe_tr16': [c_vp],
     'dasr_probe_mfma_peak': [c_i32, c_vp, c_vp],
+    'dasr_rccl_unique_id': [c_vp],
+    'dasr_rccl_init': [c_vp, c_i32, c_i32, c_vp],
+    'dasr_allreduce': [c_vp, c_vp, c_i64, c_vp],
+    'dasr_broadcast': [c_vp, c_vp, c_i64, c_i32, c_vp],
+    'dasr_rccl_destroy': [c_vp],
     'dasr_prof_begin': [c_i32],
     'dasr_prof_end': [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
 }

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libdasr_hip.so')
-SOURCES = ['conv.hip', 'wgrad.hip', 'misc.hip', 'gan.hip']
+SOURCES = ['conv.hip', 'wgrad.hip', 'misc.hip', 'gan.hip', 'rccl.hip']
 
 
 def _stale():
@@ -44,7 +44,7 @@ def build(force=False, verbose=False, trace=False):
             sys.stderr.write(out.decode())
         if p.returncode != 0:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl']
     subprocess.check_call(cmd)
     return LIB
 

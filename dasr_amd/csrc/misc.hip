@@ -343,6 +343,75 @@ __global__ void downsum2x_f16_kernel(dasr_tensor src, int N, int C, int H, int W
     }
 }
 
+// nn.PixelShuffle(2) of pixelshuffle_block (block.py:838-851) on f16 tensors: dst[n][c][2y+dy][2x+dx] = src[n][4c + 2dy + dx][y][x].
+// One thread per (n, 16-channel input plane p, y, x): the plane holds output channels 4p..4p+3 for the four (dy, dx).
+__global__ void pixel_shuffle_f16_kernel(dasr_tensor src, int N, int C4, int H, int W, dasr_tensor dst) {
+    const int ncb = C4 >> 4;
+    const long long total = (long long)N * ncb * H * W;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x = i % W;
+    long long t = i / W;
+    const int y = t % H;
+    t /= H;
+    const int p = t % ncb, n = t / ncb;
+    const f16_t* s = (const f16_t*)src.p + (size_t)n * src.n_stride + (size_t)p * src.cb_stride + ((size_t)y * W + x) * 16;
+    const f16x8 lo = *(const f16x8*)s, hi = *(const f16x8*)(s + 8);
+    f16_t v[16];
+    for (int j = 0; j < 8; ++j) { v[j] = lo[j]; v[8 + j] = hi[j]; }
+    f16_t* d = (f16_t*)dst.p + (size_t)n * dst.n_stride + (size_t)(p >> 2) * dst.cb_stride + 4 * (p & 3);
+    const int W2 = 2 * W;
+    for (int k = 0; k < 4; ++k) {   // k = 2 dy + dx; channels 4p + cc take src channel 4 cc + k of the plane
+        const f16x4 o = {v[k], v[4 + k], v[8 + k], v[12 + k]};
+        *(f16x4*)(d + ((size_t)(2 * y + (k >> 1)) * W2 + 2 * x + (k & 1)) * 16) = o;
+    }
+}
+
+// its adjoint with the LeakyReLU' of the (already activated) shuffle input folded in: gdst[n][4c+k][y][x] = m * gsrc[n][c][2y+dy][2x+dx],
+// m = mask > 0 ? 1 : slope
+__global__ void pixel_unshuffle_f16_kernel(dasr_tensor gsrc, dasr_tensor mask, float slope, int N, int C4, int H, int W, dasr_tensor gdst) {
+    const int ncb = C4 >> 4;
+    const long long total = (long long)N * ncb * H * W;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int x = i % W;
+    long long t = i / W;
+    const int y = t % H;
+    t /= H;
+    const int p = t % ncb, n = t / ncb;
+    const f16_t* g = (const f16_t*)gsrc.p + (size_t)n * gsrc.n_stride + (size_t)(p >> 2) * gsrc.cb_stride + 4 * (p & 3);
+    const int W2 = 2 * W;
+    f16_t v[16];
+    for (int k = 0; k < 4; ++k) {
+        const f16x4 q = *(const f16x4*)(g + ((size_t)(2 * y + (k >> 1)) * W2 + 2 * x + (k & 1)) * 16);
+        for (int cc = 0; cc < 4; ++cc) v[4 * cc + k] = q[cc];
+    }
+    const size_t po = (size_t)n * gdst.n_stride + (size_t)p * gdst.cb_stride + ((size_t)y * W + x) * 16;
+    if (mask.p) {
+        const f16_t* m = (const f16_t*)mask.p + (size_t)n * mask.n_stride + (size_t)p * mask.cb_stride + ((size_t)y * W + x) * 16;
+        for (int j = 0; j < 16; ++j) v[j] = (float)m[j] > 0.f ? v[j] : (f16_t)((float)v[j] * slope);
+    }
+    f16x8 lo, hi;
+    for (int j = 0; j < 8; ++j) { lo[j] = v[j]; hi[j] = v[8 + j]; }
+    *(f16x8*)((f16_t*)gdst.p + po) = lo;
+    *(f16x8*)((f16_t*)gdst.p + po + 8) = hi;
+}
+
+extern "C" int dasr_pixel_shuffle_f16(dasr_tensor src, int32_t N, int32_t C4, int32_t H, int32_t W, dasr_tensor dst, void* stream) {
+    const long long total = (long long)N * (C4 / 16) * H * W;
+    if (total <= 0 || (C4 & 63) || !src.p || !dst.p) return DASR_EINVAL;
+    DASR_LAUNCH(pixel_shuffle_f16_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), src, N, C4, H, W, dst);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_pixel_unshuffle_f16(dasr_tensor gsrc, dasr_tensor mask, float slope, int32_t N, int32_t C4, int32_t H, int32_t W, dasr_tensor gdst,
+                                        void* stream) {
+    const long long total = (long long)N * (C4 / 16) * H * W;
+    if (total <= 0 || (C4 & 63) || !gsrc.p || !gdst.p) return DASR_EINVAL;
+    DASR_LAUNCH(pixel_unshuffle_f16_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), gsrc, mask, slope, N, C4, H, W, gdst);
+    return (int)hipGetLastError();
+}
+
 extern "C" int dasr_cvt_f16(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, float scale, dasr_tensor y, void* stream) {
     const long long total = (long long)N * ((C + 15) / 16) * H * W * 4;
     if (total <= 0 || !x.p || !y.p) return DASR_EINVAL;
@@ -612,6 +681,8 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream0) {
             case DASR_OP_EVENT_RECORD: rc = (int)hipEventRecord((hipEvent_t)o.p[0], as_stream(stream)); break;
             case DASR_OP_STREAM_WAIT: rc = (int)hipStreamWaitEvent(as_stream(stream), (hipEvent_t)o.p[0], 0); break;
             case DASR_OP_SET_STREAM: stream = o.p[0] ? o.p[0] : stream0; break;
+            case DASR_OP_PIXSHUF: rc = dasr_pixel_shuffle_f16(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1], stream); break;
+            case DASR_OP_PIXUNSHUF: rc = dasr_pixel_unshuffle_f16(o.t[0], o.t[1], o.f[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[2], stream); break;
             case DASR_OP_CVT_F16: rc = dasr_cvt_f16(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1], stream); break;
             case DASR_OP_DOWNSUM_F16: rc = dasr_downsum2x_f16(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1], o.f[0], o.f[1], o.t[2], o.t[3], stream); break;
             default: rc = DASR_EINVAL;

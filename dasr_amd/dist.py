@@ -30,6 +30,27 @@ class DataParallelGroup:
             dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
         self.comm_stream = torch.cuda.Stream() if (self.backend == 'nccl' and torch.cuda.is_available()) else None
         self.pending = []
+        # DASR_RCCL_NATIVE=1: the exchange goes through the library's own RCCL communicator (include/dasr_hip.h: dasr_rccl_init /
+        # dasr_allreduce -- plain pointers, a stream, no torch types) instead of torch.distributed's RCCL front end; the 128-byte unique
+        # id travels through the torch.distributed store.  Default: torch's front end (same RCCL underneath).
+        self.native = None
+        if self.backend == 'nccl' and self.active and os.environ.get('DASR_RCCL_NATIVE', '0') == '1':
+            self._init_native()
+
+    def _init_native(self):
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        ident = [None]
+        if self.rank == 0:
+            buf = C.create_string_buffer(128)
+            _lib.check(L.dasr_rccl_unique_id(buf), 'dasr_rccl_unique_id')
+            ident = [buf.raw]
+        if self.world > 1:
+            dist.broadcast_object_list(ident, src=0)
+        comm = C.c_void_p()
+        _lib.check(L.dasr_rccl_init(ident[0], self.rank, self.world, C.byref(comm)), 'dasr_rccl_init')
+        self.native = comm
 
     @property
     def active(self):
@@ -38,7 +59,12 @@ class DataParallelGroup:
     def all_reduce_here(self, flat_slice):
         """SUM all-reduce enqueued on the CURRENT stream (the caller has switched to the communication stream)"""
         if self.active and flat_slice.numel():
-            dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM)
+            if self.native is not None:
+                from . import _lib
+                _lib.check(_lib.lib().dasr_allreduce(self.native, flat_slice.data_ptr(), flat_slice.numel(), torch.cuda.current_stream().cuda_stream),
+                           'dasr_allreduce')
+            else:
+                dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM)
 
     @property
     def grad_scale(self):
@@ -54,7 +80,7 @@ class DataParallelGroup:
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM)
+                self.all_reduce_here(flat_slice)
             self.pending.append(flat_slice)
         else:
             dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM)

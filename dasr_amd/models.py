@@ -155,10 +155,13 @@ def _define_G(opt, device):
     which = g['which_model_G']
     if which not in ('RRDB_net', 'RRDB_mask'):
         raise NotImplementedError('Generator model [{:s}] not recognized'.format(which))
-    net = RRDBNetHIP(in_nc=g['in_nc'], out_nc=g['out_nc'], nf=g['nf'], nb=g['nb'], upscale=g['scale'], device=device)
+    # `upsample_mode` is an extension of the option surface: the reference's define_G hard-wires 'upconv' (networks.py:96-99) although
+    # its RRDBNet also implements 'pixelshuffle' (architecture.py:186-191); absent / null = the reference's behaviour
+    um = g['upsample_mode'] or 'upconv'
+    net = RRDBNetHIP(in_nc=g['in_nc'], out_nc=g['out_nc'], nf=g['nf'], nb=g['nb'], upscale=g['scale'], device=device, upsample_mode=um)
     if opt['is_train']:
         logger.info('Initialization method [kaiming]')
-        net.load_state_dict(kaiming_state_dict(rrdbnet_param_spec(g['in_nc'], g['out_nc'], g['nf'], g['nb']), 0.1))
+        net.load_state_dict(kaiming_state_dict(rrdbnet_param_spec(g['in_nc'], g['out_nc'], g['nf'], g['nb'], um), 0.1))
     else:
         net.repack()
     return net

@@ -18,8 +18,10 @@ from ._lib import Op, Tensor
 GC = 32  # growth channels are hard-wired to 32 in the reference (architecture.py:183)
 
 
-def rrdbnet_param_spec(in_nc, out_nc, nf, nb):
-    """state_dict keys / shapes of the reference RRDBNet with upsample_mode='upconv' (SURVEY.md App. A)."""
+def rrdbnet_param_spec(in_nc, out_nc, nf, nb, upsample_mode='upconv'):
+    """state_dict keys / shapes of the reference RRDBNet.  upsample_mode 'upconv' (what define_G selects,
+    networks.py:96-99): nearest x2 -> conv nf->nf -> LeakyReLU at model.{2,3,4} / {5,6,7}; 'pixelshuffle' (block.py:838-851): conv nf->4nf
+    -> PixelShuffle(2) -> LeakyReLU, convs at model.2 / model.5 (checkpoints of the two modes are not interchangeable)."""
     spec = [('model.0.weight', (nf, in_nc, 3, 3)), ('model.0.bias', (nf,))]
     for i in range(nb):
         for r in (1, 2, 3):
@@ -29,23 +31,29 @@ def rrdbnet_param_spec(in_nc, out_nc, nf, nb):
                 p = 'model.1.sub.%d.RDB%d.conv%d.0.' % (i, r, j)
                 spec += [(p + 'weight', (cout, cin, 3, 3)), (p + 'bias', (cout,))]
     spec += [('model.1.sub.%d.weight' % nb, (nf, nf, 3, 3)), ('model.1.sub.%d.bias' % nb, (nf,))]
-    for idx, co in ((3, nf), (6, nf), (8, nf), (10, out_nc)):
+    ups = ((3, nf), (6, nf)) if upsample_mode == 'upconv' else ((2, 4 * nf), (5, 4 * nf))
+    for idx, co in ups + ((8, nf), (10, out_nc)):
         spec += [('model.%d.weight' % idx, (co, nf, 3, 3)), ('model.%d.bias' % idx, (co,))]
     return spec
 
 
 class RRDBNetHIP:
-    def __init__(self, in_nc=3, out_nc=3, nf=64, nb=23, upscale=4, device='cuda', rdb_prec=1, stream_prec=3):
+    def __init__(self, in_nc=3, out_nc=3, nf=64, nb=23, upscale=4, device='cuda', rdb_prec=1, stream_prec=3, upsample_mode='upconv'):
         assert upscale == 4 and nf % 32 == 0 and in_nc <= 16 and out_nc <= 16
-        self.in_nc, self.out_nc, self.nf, self.nb = in_nc, out_nc, nf, nb
+        if upsample_mode not in ('upconv', 'pixelshuffle'):
+            raise NotImplementedError('upsample mode [{:s}] is not found'.format(str(upsample_mode)))   # architecture.py:190
+        self.in_nc, self.out_nc, self.nf, self.nb, self.upsample_mode = in_nc, out_nc, nf, nb, upsample_mode
         self.device = torch.device(device)
-        self.params = ParamStore(rrdbnet_param_spec(in_nc, out_nc, nf, nb), self.device)
+        self.params = ParamStore(rrdbnet_param_spec(in_nc, out_nc, nf, nb, upsample_mode), self.device)
         self.rdb_prec, self.stream_prec = rdb_prec, stream_prec
         self.hr_prec = int(os.environ.get('DASR_HR_PREC', '2')) if stream_prec == 3 else stream_prec
         # f16 STORAGE of the HR tail (u1, u2, h0 and their gradients live in HBM as f16): the consumers then run on the LDS-DMA dense-conv
         # kernel / the 12-wave wgrad kernel with the f16 MFMA instead of the register-staged f32-input kernels (3x faster there), and the
         # HR tensors cost half the bytes.  DASR_HR_STORE=f32 keeps f32 tensors (f16 rounding while staging)
         self.hr_f16s = self.hr_prec == 2 and os.environ.get('DASR_HR_STORE', 'f16') == 'f16'
+        self.ps = upsample_mode == 'pixelshuffle'
+        if self.ps and not self.hr_f16s:
+            raise NotImplementedError('the PixelShuffle upsampler is built on the f16-storage HR tail (unset DASR_HR_PREC / DASR_HR_STORE)')
         self.pack = PackRegistry(self.params)
         self._register_packs()
         self.pack.finalize()
@@ -70,6 +78,8 @@ class RRDBNetHIP:
         lr = 'model.1.sub.%d.weight' % self.nb
         for name, key, cout in (('lr', lr, nf), ('up1', 'model.3.weight', nf), ('up2', 'model.6.weight', nf),
                                 ('hr0', 'model.8.weight', nf), ('hr1', 'model.10.weight', self.out_nc)):
+            if self.ps and name in ('up1', 'up2'):
+                continue
             pr = sp if name == 'lr' else hp
             if self.hr_f16s and name != 'lr':
                 continue   # f16 storage: the HR-tail packs are registered below (direct 3x3 forms on 16-bit tensors)
@@ -79,9 +89,10 @@ class RRDBNetHIP:
             self.pk[name + '_b'] = self.pack.add(nf, cin_b, 9, hmt if pr == 2 else 1, pr, [(P.off(key), cout, nf, 0, cout, 0, 1)])
         if self.hr_f16s:   # direct 3x3 forms on 16-bit tensors (nearest x2 folded into the DMA addresses of the dense-conv kernel)
             mtH = 2 if nf % 64 == 0 else 1
-            for name, key in (('up1', 'model.3.weight'), ('up2', 'model.6.weight'), ('hr0', 'model.8.weight')):
-                self.pk[name] = self.pack.add(nf, nf, 9, mtH, 2, [self._seg_fwd(key, nf, nf)])
-                self.pk[name + '_b'] = self.pack.add(nf, nf, 9, mtH, 2, [(P.off(key), nf, nf, 0, nf, 0, 1)])
+            ups = (('up1', 'model.2.weight', 4 * nf), ('up2', 'model.5.weight', 4 * nf)) if self.ps else (('up1', 'model.3.weight', nf), ('up2', 'model.6.weight', nf))
+            for name, key, co in ups + (('hr0', 'model.8.weight', nf),):
+                self.pk[name] = self.pack.add(co, nf, 9, mtH, 2, [self._seg_fwd(key, co, nf)])
+                self.pk[name + '_b'] = self.pack.add(nf, co, 9, mtH, 2, [(P.off(key), co, nf, 0, co, 0, 1)])
             self.pk['hr1'] = self.pack.add(self.out_nc, nf, 9, 1, 2, [self._seg_fwd('model.10.weight', self.out_nc, nf)])
             self.pk['hr1_b'] = self.pack.add(nf, 16, 9, mtH, 2, [(P.off('model.10.weight'), self.out_nc, nf, 0, self.out_nc, 0, 1)])
         # sub-pixel form of nearest-x2 + 3x3 (upconv_blcok, block.py:854-861): output parity (py, px) is a 2x2 convolution of the
@@ -185,6 +196,9 @@ class _Plan:
         self.t0h = Bh(nf, h, w) if hs else None   # f16 shadow of the trunk output (input of upconv1)
         self.u1 = Bh(nf, H2, W2)
         self.u2 = Bh(nf, H4, W4)
+        if net.ps:   # conv outputs before the shuffle (already activated) and their gradients
+            self.ps1, self.ps2 = Bh(4 * nf, h, w), Bh(4 * nf, H2, W2)
+            self.g_ps1, self.g_ps2 = Bh(4 * nf, h, w), Bh(4 * nf, H2, W2)
         self.h0 = Bh(nf, H4, W4)
         self.sr = B(16, H4, W4, True)
         # backward
@@ -270,7 +284,14 @@ class _Plan:
         if net.hr_f16s:
             ops.add(conv_op(pack, pk['lr'], X.view(), True, nf, h, w, h, w, N, bias=P.ptr(lrb), res1=self.fea.view(), beta1=1.0,
                             out_f32=self.t0.view(), out_bf16=self.t0h.view(), out16_f16=1))
-            for name, bkey, src, dst, hi, wi in (('up1', 'model.3.bias', self.t0h, self.u1, h, w), ('up2', 'model.6.bias', self.u1, self.u2, H2, W2)):
+            if net.ps:   # pixelshuffle_block (block.py:838-851): conv nf -> 4 nf, PixelShuffle(2), LeakyReLU (applied before the shuffle: it is elementwise)
+                for name, bkey, src, pre, dst, hi, wi in (('up1', 'model.2.bias', self.t0h, self.ps1, self.u1, h, w), ('up2', 'model.5.bias', self.u1, self.ps2, self.u2, H2, W2)):
+                    ops.add(conv_op(pack, pk[name], src.view(), False, nf, hi, wi, hi, wi, N, bias=P.ptr(bkey), act=1, out_bf16=pre.view(), out16_f16=1))
+                    o = Op()
+                    o.op = _lib.OP_PIXSHUF
+                    o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1] = pre.view(), N, 4 * nf, hi, wi, dst.view()
+                    ops.add(o)
+            for name, bkey, src, dst, hi, wi in (() if net.ps else (('up1', 'model.3.bias', self.t0h, self.u1, h, w), ('up2', 'model.6.bias', self.u1, self.u2, H2, W2))):
                 ops.add(conv_op(pack, pk[name], src.view(), False, nf, hi, wi, 2 * hi, 2 * wi, N, bias=P.ptr(bkey), ups=1, act=1, out_bf16=dst.view(),
                                 out16_f16=1))
             ops.add(conv_op(pack, pk['hr0'], self.u2.view(), False, nf, H4, W4, H4, W4, N, bias=P.ptr('model.8.bias'), act=1, out_bf16=self.h0.view(),
@@ -399,6 +420,20 @@ class _Plan:
         # HR_conv0
         self._wg3(ops, 'model.8.', g_h0, self.u2, nf, nf, H4, W4, H4, W4)
         ops.add(conv_op(pack, pk['hr0_b'], g_h0.view(), False, nf, H4, W4, H4, W4, N, mask=self.u2.view(), mask_f32=0, out_bf16=g_u2.view(), out16_f16=1))
+        if net.ps:
+            # PixelShuffle upsamplers: un-shuffle the gradient (+ LeakyReLU' of the activated conv output), then a plain conv nf -> 4 nf backward
+            for key, name, g_hi, pre, g_pre, src, g_lo, hl, wl, last in (('model.5.', 'up2', g_u2, self.ps2, self.g_ps2, self.u1, g_u1, H2, W2, False),
+                                                                          ('model.2.', 'up1', g_u1, self.ps1, self.g_ps1, self.t0h, None, h, w, True)):
+                o = Op()
+                o.op = _lib.OP_PIXUNSHUF
+                o.t[0], o.t[1], o.f[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[2] = g_hi.view(), pre.view(), SLOPE, N, 4 * nf, hl, wl, g_pre.view()
+                ops.add(o)
+                self._wg3(ops, key, g_pre, src, 4 * nf, nf, hl, wl, hl, wl)
+                if last:   # dL/d(trunk output) leaves the f16 / scaled domain
+                    ops.add(conv_op(pack, pk[name + '_b'], g_pre.view(), False, 4 * nf, hl, wl, hl, wl, N, alpha=1.0 / gs, out_f32=self.g_t0.view()))
+                else:
+                    ops.add(conv_op(pack, pk[name + '_b'], g_pre.view(), False, 4 * nf, hl, wl, hl, wl, N, out_bf16=g_lo.view(), out16_f16=1))
+            return
         # upconv2: weight gradient on the up-sampled u1; data gradient on the 4h x 4w grid, then the 2x2 sum with LeakyReLU'(u1)
         self._wg3(ops, 'model.6.', g_u2, self.u1, nf, nf, H2, W2, H4, W4, ups=1)
         ops.add(conv_op(pack, pk['up2_b'], g_u2.view(), False, nf, H4, W4, H4, W4, N, out_bf16=g_up2.view(), out16_f16=1))

@@ -180,6 +180,12 @@ int dasr_cvt_f16(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, floa
 int dasr_downsum2x_f16(dasr_tensor src, int32_t N, int32_t C, int32_t H, int32_t W, dasr_tensor mask /* f16, optional */, float slope,
                        float out_scale, dasr_tensor dst_f32, dasr_tensor dst_f16, void* stream);
 
+/* nn.PixelShuffle(2) of pixelshuffle_block (codes/SRN/models/modules/block.py:838-851) on f16 blocked tensors: src has C4 = 4 C channels at H x W,
+ * dst C channels at 2H x 2W, dst[c][2y+dy][2x+dx] = src[4c+2dy+dx][y][x]; and its adjoint with the LeakyReLU' of the (activated) src as mask */
+int dasr_pixel_shuffle_f16(dasr_tensor src, int32_t N, int32_t C4, int32_t H, int32_t W, dasr_tensor dst, void* stream);
+int dasr_pixel_unshuffle_f16(dasr_tensor gsrc, dasr_tensor mask /* f16 [C4 @ HxW], optional */, float slope, int32_t N, int32_t C4, int32_t H,
+                             int32_t W, dasr_tensor gdst, void* stream);
+
 /* out = a*x + b*z (z optional) over blocked f32 tensors, optional bf16 copy scaled by gamma
  * (ShortcutBlock / RRDB residual bookkeeping, block.py:97-105,305-309) */
 int dasr_axpby(dasr_tensor x, float a, dasr_tensor z, float b, int32_t N, int32_t C, int32_t H, int32_t W,
@@ -275,7 +281,7 @@ enum { DASR_OP_CONV = 1, DASR_OP_WGRAD = 2, DASR_OP_WGRAD_REDUCE = 3, DASR_OP_PA
        DASR_OP_ADD_FLAT = 26, DASR_OP_SIGMOID_FWD = 27,
        /* scheduling ops: p[0] = event from dasr_event_create / a hipStream_t (NULL: back to the stream dasr_run_ops was called with) */
        DASR_OP_EVENT_RECORD = 28, DASR_OP_STREAM_WAIT = 29, DASR_OP_SET_STREAM = 30,
-       DASR_OP_CVT_F16 = 31, DASR_OP_DOWNSUM_F16 = 32 };
+       DASR_OP_CVT_F16 = 31, DASR_OP_DOWNSUM_F16 = 32, DASR_OP_PIXSHUF = 33, DASR_OP_PIXUNSHUF = 34 };
 
 typedef struct {
     int32_t op;  int32_t i[8];  float f[4];  int64_t l[4];  void* p[4];  dasr_tensor t[5];
@@ -289,6 +295,17 @@ int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream);
 void* dasr_event_create(void);
 int dasr_event_destroy(void* ev);
 int dasr_last_failed_op(void);   /* index of the op that made dasr_run_ops return non-zero */
+
+/* ---- RCCL gradient exchange (csrc/rccl.hip) ------------------------------------------------------------------------------
+ * Replaces the single-process nn.DataParallel of the reference (codes/SRN/models/networks.py:144-146,192-193): one process per GPU,
+ * replicated weights, SUM all-reduce of the flat fp32 gradient buffer over xGMI (the 1/world factor is folded into dasr_wgrad_reduce).
+ * Rank 0 creates a 128-byte id (dasr_rccl_unique_id) and hands it to the other ranks through any side channel; every rank then calls
+ * dasr_rccl_init (collective).  dasr_allreduce / dasr_broadcast are in place, asynchronous on `stream`; return an ncclResult_t. */
+int dasr_rccl_unique_id(void* id128);
+int dasr_rccl_init(const void* id128, int32_t rank, int32_t world, void** comm_out);
+int dasr_allreduce(void* comm, float* buf, int64_t count, void* stream);
+int dasr_broadcast(void* comm, float* buf, int64_t count, int32_t root, void* stream);
+int dasr_rccl_destroy(void* comm);
 
 /* ---- profiling session (bench.py `roofline`) -----------------------------------------------------------
  * Between dasr_prof_begin and dasr_prof_end every kernel launch of the library (up to `capacity`) carries its own start/stop

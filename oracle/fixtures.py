@@ -19,6 +19,9 @@ CASES = OrderedDict([
     # round 2: the production schedule (batch >= 8 -> two sub-batch streams) and the full ESRGAN depth
     ('sr_nf64_nb2_b8_32', dict(kind='sr', nf=64, nb=2, n=8, lr=32)),
     ('sr_nf64_nb23_b2_32', dict(kind='sr', nf=64, nb=23, n=2, lr=32)),
+    # PixelShuffle upsampler (architecture.py:186-191, block.py:838-851; the reference's define_G never selects it: the generator of
+    # the fixture is the reference's RRDBNet(upsample_mode='pixelshuffle') put behind its SRModel)
+    ('sr_ps_nf64_nb1_b2_32', dict(kind='sr', nf=64, nb=1, n=2, lr=32, upsample_mode='pixelshuffle')),
 ])
 
 
@@ -46,7 +49,7 @@ def make_opt(case):
         'path': {'pretrain_model_G': None, 'pretrain_model_D_target': None, 'pretrain_model_D_source': None,
                  'models': '/tmp/dasr_golden', 'training_state': '/tmp/dasr_golden'},
         'network_G': {'which_model_G': 'RRDB_net', 'norm_type': None, 'mode': 'CNA', 'nf': c['nf'], 'nb': c['nb'],
-                      'in_nc': 3, 'out_nc': 3, 'gc': 32, 'scale': 4},
+                      'in_nc': 3, 'out_nc': 3, 'gc': 32, 'scale': 4, 'upsample_mode': c.get('upsample_mode')},
         'train': {'lr_G': 1e-4, 'weight_decay_G': 0, 'beta1_G': 0.9, 'lr_scheme': 'MultiStepLR',
                   'lr_steps': [2, 4], 'lr_gamma': 0.5, 'pixel_criterion': 'l1', 'pixel_weight': 1.0,
                   'manual_seed': 0},

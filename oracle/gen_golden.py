@@ -65,7 +65,18 @@ def run_reference(case):
     c = fixtures.CASES[case]
     opt = option.dict_to_nonedict(fixtures.make_opt(case))
     torch.manual_seed(0)
-    m = (SRModel if c['kind'] == 'sr' else DASR_Model)(opt)
+    orig_define_G = networks.define_G
+    if c.get('upsample_mode', 'upconv') != 'upconv':
+        # the reference's define_G hard-wires 'upconv'; its own RRDBNet class implements the other mode: hand THAT class to its trainer
+        def define_G(o):
+            g = o['network_G']
+            return arch.RRDBNet(in_nc=g['in_nc'], out_nc=g['out_nc'], nf=g['nf'], nb=g['nb'], gc=g['gc'], upscale=g['scale'], norm_type=g['norm_type'],
+                                act_type='leakyrelu', mode=g['mode'], upsample_mode=c['upsample_mode'])
+        networks.define_G = define_G
+    try:
+        m = (SRModel if c['kind'] == 'sr' else DASR_Model)(opt)
+    finally:
+        networks.define_G = orig_define_G
     m.netG.load_state_dict(fixtures.seeded_state_dict(m.netG.state_dict(), 1, 0.1))
     netD = None
     if c['kind'] == 'dasr':
@@ -81,7 +92,7 @@ def run_oracle(case):
     from . import trainers
     c = fixtures.CASES[case]
     opt = fixtures.make_opt(case)
-    netG = nets.RRDBNet(3, 3, c['nf'], c['nb'], 4)
+    netG = nets.RRDBNet(3, 3, c['nf'], c['nb'], 4, upsample_mode=c.get('upsample_mode', 'upconv'))
     netG.load_state_dict(fixtures.seeded_state_dict(netG.state_dict(), 1, 0.1))
     if c['kind'] == 'sr':
         t = trainers.SRTrainer(opt, netG=netG)

@@ -78,8 +78,9 @@ def test_two_rank_step_equals_full_batch_step(case, streams, tmp_path, margins):
         case if isinstance(case, str) else 'sr_nf64_nb2_b16_32', streams, dmax))
 
 
-def _rccl_worker(rank, port, out, streams, use_dp):
-    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DASR_STREAMS=str(streams))
+def _rccl_worker(rank, port, out, streams, use_dp, native=0):
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DASR_STREAMS=str(streams),
+                      DASR_RCCL_NATIVE=str(native))
     import torch
     from oracle import fixtures
     from dasr_amd import options
@@ -92,7 +93,7 @@ def _rccl_worker(rank, port, out, streams, use_dp):
     m.netG.load_state_dict(fixtures.seeded_state_dict(m.netG.state_dict(), 1, 0.1))
     if use_dp:
         m.dp = DataParallelGroup(backend='nccl', force=True)   # a real RCCL communicator of one rank
-        assert m.dp.comm_stream is not None
+        assert m.dp.comm_stream is not None and (m.dp.native is not None) == bool(native)
         m.dp.broadcast_params(m.netG.params.flat)
     batch = fixtures.make_batch(B16)
     for step in (1, 2):
@@ -106,8 +107,8 @@ def _rccl_worker(rank, port, out, streams, use_dp):
         assert m.dp.max_over_ranks(1.5) == 1.5
 
 
-@pytest.mark.parametrize('streams', [1, 2])
-def test_rccl_exchange_path_single_rank(streams, tmp_path):
+@pytest.mark.parametrize('streams,native', [(1, 0), (2, 0), (2, 1)], ids=['1stream-torch', '2streams-torch', '2streams-c_abi'])
+def test_rccl_exchange_path_single_rank(streams, native, tmp_path):
     """The RCCL code path (backend 'nccl': communication stream, bucket events, all-reduce enqueued behind the boundary events of
     both replica streams) executed for real on this one-GPU box with a communicator of ONE rank (RCCL refuses two ranks on one
     device).  The exchange is the identity, so the step must reproduce the no-DP step bit for bit."""
@@ -117,7 +118,7 @@ def test_rccl_exchange_path_single_rank(streams, tmp_path):
     out = str(tmp_path / 'rccl_%d.pt')
     port = 29411 + (os.getpid() % 300) + streams
     mp.spawn(_rccl_worker, args=(port, out, streams, False), nprocs=1, join=True)
-    mp.spawn(_rccl_worker, args=(port, out, streams, True), nprocs=1, join=True)
+    mp.spawn(_rccl_worker, args=(port, out, streams, True, native), nprocs=1, join=True)
     a, b = torch.load(out % 0), torch.load(out % 1)
     assert abs(a['l_pix'] - b['l_pix']) <= 1e-6 * abs(a['l_pix'])   # the logged loss is an atomic sum (order varies from run to run); the weights are not
     for k, v in a['G'].items():

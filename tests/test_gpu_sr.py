@@ -32,7 +32,7 @@ def _oracle_run(case, steps=2):
     from oracle import fixtures, nets, trainers
     c = fixtures.CASES[case]
     opt = fixtures.make_opt(case)
-    netG = nets.RRDBNet(3, 3, c['nf'], c['nb'], 4)
+    netG = nets.RRDBNet(3, 3, c['nf'], c['nb'], 4, upsample_mode=c.get('upsample_mode', 'upconv'))
     sd0 = fixtures.seeded_state_dict(netG.state_dict(), 1, 0.1)
     netG.load_state_dict(sd0)
     t = trainers.SRTrainer(opt, netG=netG)
@@ -64,7 +64,9 @@ def _oracle_run(case, steps=2):
 # sr_nf64_nb2_b8_32: batch 8 -> the PRODUCTION schedule (two sub-batch replicas on two streams, run_interleaved, private replica
 # gradient buffer + add_flat; SR_model.py:77-85 is the reference step).  sr_nf64_nb23_b2_32: the full ESRGAN depth
 # (architecture.py:174-205), RRDB outputs 0 / 11 / 22 tapped in fp32.
-@pytest.mark.parametrize('case', ['sr_nf64_nb1_b1_24x40', 'sr_nf64_nb2_b2_32', 'cfg1_sr_nf32_nb4_b2_64', 'sr_nf64_nb2_b8_32', 'sr_nf64_nb23_b2_32'])
+# sr_ps_nf64_nb1_b2_32: the PixelShuffle upsampler (block.py:838-851) instead of nearest + conv.
+@pytest.mark.parametrize('case', ['sr_nf64_nb1_b1_24x40', 'sr_nf64_nb2_b2_32', 'cfg1_sr_nf32_nb4_b2_64', 'sr_nf64_nb2_b8_32', 'sr_nf64_nb23_b2_32',
+                                  'sr_ps_nf64_nb1_b2_32'])
 def test_sr_step_matches_oracle_and_reference_fixture(case, golden_dir, margins):
     dev = _gpu()
     torch.set_num_threads(8)
