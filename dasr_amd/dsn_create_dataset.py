@@ -77,7 +77,7 @@ def main(argv=None):
         raise NotImplementedError('Generator model [{:s}] not recognized'.format(o.generator))
     if o.discriminator != 'FSD':
         raise NotImplementedError('Please specified conv_net of discriminator.')
-    if o.wgan or not o.highpass or o.cat_or_sum != 'cat' or o.norm_layer != 'Instance':
+    if o.wgan or not o.highpass or o.cat_or_sum != 'cat' or o.norm_layer not in ('Instance', 'Batch'):
         raise NotImplementedError('DSN on MI355X covers the default path: DCGAN loss, high-pass front end, wavelet bands cat, Instance norm')
     if o.checkpoint is None:
         print('Use --checkpoint to define the model parameters used')

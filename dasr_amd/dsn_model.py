@@ -258,8 +258,10 @@ class DSNModel:
         self.opt = o
         ensure_runtime_ready()
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
-        if o['upscale_factor'] != 4 or o['discriminator'].lower() != 'fsd' or o['norm_layer'] != 'Instance':
-            raise NotImplementedError('DSN on MI355X: De_resnet x4 + FSD discriminator with Instance norm')
+        if o['upscale_factor'] != 4 or o['discriminator'].lower() != 'fsd' or o['norm_layer'] not in ('Instance', 'Batch'):
+            raise NotImplementedError('DSN on MI355X: De_resnet x4 + FSD discriminator with Instance (training + inference) or Batch (inference) norm')
+        # norm_layer 'Batch': inference only (translate / ddm_of): BatchNorm in eval mode is folded into the convs at load time
+        self.bn_eval = o['norm_layer'] == 'Batch'
         self.netF = None
         if o['w_per'] > 0:
             if o['per_type'] != 'VGG':
@@ -277,7 +279,8 @@ class DSNModel:
         self.k = o['kernel_size']
         self.netG = DeResnetHIP(o['n_res_blocks'], device=self.device)
         nc = 9 if self.filter == 'wavelet' else 3
-        self.netD = NLayerDiscriminatorHIP(nc, device=self.device, spec_layers=fsd_spec(nc, self.k if self.filter == 'gau' else None))
+        self.netD = NLayerDiscriminatorHIP(nc, device=self.device, spec_layers=fsd_spec(nc, self.k if self.filter == 'gau' else None,
+                                                                                        norm='BatchEval' if self.bn_eval else 'Instance'))
         # default nn init, G first then D (codes/DSN/train.py:124-135 under torch.manual_seed(0))
         self.netG.load_state_dict(default_init_state(self.netG.spec))
         self.netD.load_state_dict(default_init_state(self.netD.spec))
@@ -312,7 +315,17 @@ class DSNModel:
             self._plans[k] = _DSNPlan(self, N, H, W)
         return self._plans[k]
 
+    def load_discriminator_state(self, sd):
+        """state_dict of the reference Discriminator (codes/DSN/model.py:60-118).  FSD-Batch dicts are folded (eval-mode BatchNorm -> conv)"""
+        from .gan_nets import fold_batchnorm_fsd
+        if self.bn_eval:
+            self.bn_state = {k: v.clone() for k, v in sd.items()}   # kept for save(): the reference layout with the BN buffers
+            sd = fold_batchnorm_fsd(sd)
+        self.netD.load_state_dict(sd)
+
     def iteration(self, hr, bicubic_lr, real_lr):
+        if self.bn_eval:
+            raise NotImplementedError('training with a BatchNorm discriminator (batch statistics across ranks) is not on the hot path; norm_layer=Instance')
         N, _, H, W = hr.shape
         P = self._plan(N, H, W)
         P.g.x_nchw.copy_(hr)
@@ -392,9 +405,10 @@ class DSNModel:
     def load(self, path):
         ck = torch.load(path, map_location='cpu', weights_only=False)
         self.netG.load_state_dict(ck['model_g_state_dict'])
-        self.netD.load_state_dict(ck['models_d_state_dict'])
-        self.opt_g.load_state_dict(ck['optimizer_g_state_dict'])
-        self.opt_d.load_state_dict(ck['optimizer_d_state_dict'])
+        self.load_discriminator_state(ck['models_d_state_dict'])
+        if not self.bn_eval:
+            self.opt_g.load_state_dict(ck['optimizer_g_state_dict'])
+            self.opt_d.load_state_dict(ck['optimizer_d_state_dict'])
         self.epoch, self.iteration_count = ck['epoch'], ck['iteration']
 
 

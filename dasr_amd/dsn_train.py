@@ -35,7 +35,7 @@ def build_parser():
     p.add_argument('--val_img_interval', default=5, type=int)
     p.add_argument('--save_model_interval', default=5, type=int)
     p.add_argument('--artifacts', default='tdsr', type=str)
-    p.add_argument('--dataset', default='synthetic', type=str)
+    p.add_argument('--dataset', default='df2k', type=str)   # reference default (train.py:38); only 'synthetic' is built in: anything else needs a loader
     p.add_argument('--flips', dest='flips', action='store_true')
     p.add_argument('--rotations', dest='rotations', action='store_true')
     p.add_argument('--num_res_blocks', default=8, type=int)
@@ -45,7 +45,7 @@ def build_parser():
     p.add_argument('--kernel_size', default=5, type=int)
     p.add_argument('--no_per_loss', dest='use_per_loss', action='store_false')
     p.add_argument('--lpips_rot_flip', dest='lpips_rot_flip', action='store_true')
-    p.add_argument('--per_type', default='VGG', type=str)
+    p.add_argument('--per_type', default='LPIPS', type=str)   # reference default (train.py:54); LPIPS needs the pretrained AlexNet package -> raises, pass VGG
     p.add_argument('--disc_freq', default=1, type=int)
     p.add_argument('--gen_freq', default=1, type=int)
     p.add_argument('--w_col', default=1, type=float)

@@ -43,14 +43,33 @@ def nlayer_d_spec(input_nc, ndf=64, n_layers=2):
     return spec, layers
 
 
-def fsd_spec(input_nc, gaussian_k=None):
-    """DSN DiscriminatorBasic (codes/DSN/model.py:173-210, Instance norm): 5x5 convs (all with bias) and a 1x1 head.
+def fold_batchnorm_fsd(sd, eps=1e-5):
+    """FSD-Batch state_dict (codes/DSN/model.py:176-189: Conv, BatchNorm2d at net.net.3 / net.net.6) -> the equivalent conv-only state_dict of
+    the network in eval() mode: BN(z) = (z - mean) / sqrt(var + eps) * gamma + beta is a per-channel affine map of the conv output, folded
+    into the conv's weight and bias (host-side, float64, once per load).  Used for inference with BN discriminators (dataset generation,
+    create_dataset_modified.py:147-164); training a BN discriminator needs cross-rank batch statistics and is not on the hot path."""
+    out = {}
+    for k, v in sd.items():
+        if k.split('.')[-1] in ('running_mean', 'running_var', 'num_batches_tracked') or k.startswith(('net.net.3.', 'net.net.6.')):
+            continue
+        out[k] = v.clone()
+    for conv, bn in (('net.net.2.', 'net.net.3.'), ('net.net.5.', 'net.net.6.')):
+        s = sd[bn + 'weight'].double() / torch.sqrt(sd[bn + 'running_var'].double() + eps)
+        out[conv + 'weight'] = (sd[conv + 'weight'].double() * s.view(-1, 1, 1, 1)).float()
+        out[conv + 'bias'] = ((sd[conv + 'bias'].double() - sd[bn + 'running_mean'].double()) * s + sd[bn + 'bias'].double()).float()
+    return out
+
+
+def fsd_spec(input_nc, gaussian_k=None, norm='Instance'):
+    """DSN DiscriminatorBasic (codes/DSN/model.py:173-210): 5x5 convs (all with bias) and a 1x1 head.  norm 'Instance': InstanceNorm after
+    the 2nd / 3rd conv; 'BatchEval': BatchNorm in eval mode, folded into those convs (fold_batchnorm_fsd), i.e. no norm op at all.
     gaussian_k: the frozen depthwise gaussian of the 'gau' front end is part of the reference state_dict."""
     spec = []
     if gaussian_k:
         spec.append(('filter.filter_low.filter.gaussian_filter.weight', (3, 1, gaussian_k, gaussian_k)))
     layers = []
-    for idx, cin, cout, kh, norm, last in ((0, input_nc, 64, 5, False, False), (2, 64, 128, 5, True, False), (5, 128, 256, 5, True, False),
+    inorm = norm == 'Instance'
+    for idx, cin, cout, kh, norm, last in ((0, input_nc, 64, 5, False, False), (2, 64, 128, 5, inorm, False), (5, 128, 256, 5, inorm, False),
                                            (8, 256, 1, 1, False, True)):
         key = 'net.net.%d.' % idx
         spec += [(key + 'weight', (cout, cin, kh, kh)), (key + 'bias', (cout,))]

@@ -153,10 +153,21 @@ class RRDBNetHIP:
         self.params.load_state_dict(sd, strict)
         self.repack()
 
+    INFER_CACHE = 2   # forward-only plans kept (validation / test images come in many sizes; a plan of a big image is GBs)
+
     def forward(self, x):
-        """x: NCHW fp32 CUDA tensor -> SR NCHW fp32 CUDA tensor (keeps activations for backward)."""
+        """Inference: x NCHW fp32 CUDA tensor -> SR NCHW fp32 CUDA tensor.  Uses a FORWARD-ONLY plan (two dense slabs reused by all RDBs,
+        no gradient buffers, no wgrad workspace: the reference frees activations under no_grad too, SR_model.py:87-93) from a small LRU
+        cache, so evaluating many differently sized images does not accumulate training-sized plans."""
         N, _, h, w = x.shape
-        p = self.plan(N, h, w)
+        key = (N, h, w)
+        cache = self.__dict__.setdefault('infer_plans', OrderedDict())
+        p = cache.pop(key, None)
+        if p is None:
+            while len(cache) >= self.INFER_CACHE:
+                cache.popitem(last=False)
+            p = _Plan(self, N, h, w, inference=True)
+        cache[key] = p
         p.set_input(x)
         p.fwd.run()
         return p.read_output()
@@ -172,10 +183,11 @@ def _sched(kind, handle):
 class _Plan:
     """Buffers + recorded forward / backward op lists for one (N, h, w)."""
 
-    def __init__(self, net, N, h, w, replica=0):
+    def __init__(self, net, N, h, w, replica=0, inference=False):
         self.net, self.N, self.h, self.w = net, N, h, w
         dev, nf, nb = net.device, net.nf, net.nb
-        self.grad = net.params.grad if replica == 0 else torch.zeros_like(net.params.grad)
+        self.inference = inference
+        self.grad = net.params.grad if (replica == 0 or inference) else torch.zeros_like(net.params.grad)
         # power-of-two pre-scale of the HR-tail gradients before their f16 rounding (prec 2): dL/dSR of a mean loss is ~1 / (N 3 H W) ~ 1e-7,
         # far below f16's normal range; scaled to ~2^-3.  Exact (power of two), undone in the conv epilogue / the wgrad reduction.
         import math
@@ -188,7 +200,11 @@ class _Plan:
         self.sr_nchw = torch.zeros((N, net.out_nc, H4, W4), dtype=torch.float32, device=dev)
         self.x_in = B(16, h, w, True)
         self.fea = B(nf, h, w, True)
-        self.slabs = [B(sc, h, w, False) for _ in range(3 * nb)]
+        if inference:   # nothing is kept for a backward pass: two slabs alternate through the 3 nb dense blocks
+            ab = [B(sc, h, w, False), B(sc, h, w, False)]
+            self.slabs = [ab[i & 1] for i in range(3 * nb)]
+        else:
+            self.slabs = [B(sc, h, w, False) for _ in range(3 * nb)]
         self.stream = [B(nf, h, w, True) for _ in range(4)]
         self.t0 = B(nf, h, w, True)
         hs = net.hr_f16s
@@ -198,9 +214,13 @@ class _Plan:
         self.u2 = Bh(nf, H4, W4)
         if net.ps:   # conv outputs before the shuffle (already activated) and their gradients
             self.ps1, self.ps2 = Bh(4 * nf, h, w), Bh(4 * nf, H2, W2)
-            self.g_ps1, self.g_ps2 = Bh(4 * nf, h, w), Bh(4 * nf, H2, W2)
+            if not inference:
+                self.g_ps1, self.g_ps2 = Bh(4 * nf, h, w), Bh(4 * nf, H2, W2)
         self.h0 = Bh(nf, H4, W4)
         self.sr = B(16, H4, W4, True)
+        if inference:
+            self._build_forward()
+            return
         # backward
         self.g_sr = B(16, H4, W4, True)
         self.g_sr16 = Bh(16, H4, W4) if hs else None   # dL/dSR, pre-scaled by gscale, f16
@@ -422,11 +442,13 @@ class _Plan:
         ops.add(conv_op(pack, pk['hr0_b'], g_h0.view(), False, nf, H4, W4, H4, W4, N, mask=self.u2.view(), mask_f32=0, out_bf16=g_u2.view(), out16_f16=1))
         if net.ps:
             # PixelShuffle upsamplers: un-shuffle the gradient (+ LeakyReLU' of the activated conv output), then a plain conv nf -> 4 nf backward
-            for key, name, g_hi, pre, g_pre, src, g_lo, hl, wl, last in (('model.5.', 'up2', g_u2, self.ps2, self.g_ps2, self.u1, g_u1, H2, W2, False),
+            # (g_u2 already carries the LeakyReLU' of u2: HR_conv0's data-gradient applied it as its mask; g_u1 comes out of a plain conv)
+            for key, name, g_hi, pre, g_pre, src, g_lo, hl, wl, last in (('model.5.', 'up2', g_u2, None, self.g_ps2, self.u1, g_u1, H2, W2, False),
                                                                           ('model.2.', 'up1', g_u1, self.ps1, self.g_ps1, self.t0h, None, h, w, True)):
                 o = Op()
                 o.op = _lib.OP_PIXUNSHUF
-                o.t[0], o.t[1], o.f[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[2] = g_hi.view(), pre.view(), SLOPE, N, 4 * nf, hl, wl, g_pre.view()
+                o.t[0], o.t[1], o.f[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[2] = (g_hi.view(), pre.view() if pre is not None else NULL_T, SLOPE, N, 4 * nf,
+                                                                                  hl, wl, g_pre.view())
                 ops.add(o)
                 self._wg3(ops, key, g_pre, src, 4 * nf, nf, hl, wl, hl, wl)
                 if last:   # dL/d(trunk output) leaves the f16 / scaled domain

@@ -103,6 +103,20 @@ def main():
         fx = collect(G, D, cf, gl.perceptual_loss.loss_network, c)
         np.savez_compressed(os.path.join(OUT, name + '.npz'), **fx)
         print(name, fx['losses'])
+    # real-weights known-answer test: the only weights file the reference ships, codes/DSN/test.tar = state_dict of
+    # Discriminator(D_arch='FSD', norm_layer='Batch', filter_type='gau', kernel_size=5) (model.py:60-118,173-189).  The fixture carries the
+    # weights (a data file of the reference) and the eval-mode output of the reference module on a seeded input.
+    sd = torch.load(os.path.join(REF, 'DSN', 'test.tar'), map_location='cpu', weights_only=False)
+    D = rmodel.Discriminator(kernel_size=5, D_arch='FSD', norm_layer='Batch', filter_type='gau', cs='cat')
+    D.load_state_dict(sd)
+    D.eval()
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(97))
+    with torch.no_grad():
+        y = D(x)
+    fx = {'w/' + k: v.numpy() for k, v in sd.items()}
+    fx['out'] = y.numpy()
+    np.savez_compressed(os.path.join(OUT, 'dsn_fsd_batch_test_tar.npz'), **fx)
+    print('dsn_fsd_batch_test_tar', tuple(y.shape), float(y.mean()))
 
 
 if __name__ == '__main__':

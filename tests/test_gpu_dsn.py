@@ -315,7 +315,7 @@ def test_dsn_dataset_cli_end_to_end(tmp_path):
     from dasr_amd import dsn_train, dsn_create_dataset
     save = str(tmp_path / 'dsn')
     dsn_train.main(['--debug', '--batch_size', '2', '--crop_size', '128', '--filter', 'wavelet', '--save_path', save, '--save_model_interval', '1',
-                    '--no_per_loss'])
+                    '--no_per_loss', '--dataset', 'synthetic'])
     ck = os.path.join(save, 'checkpoints', 'last_iteration.tar')
     assert os.path.exists(ck)
     out, n = dsn_create_dataset.main(['--checkpoint', ck, '--filter', 'wavelet', '--name', 'gen', '--out_root', str(tmp_path / 'res'),
@@ -329,3 +329,26 @@ def test_dsn_dataset_cli_end_to_end(tmp_path):
     assert ddm.dtype == np.float64 and ddm.shape == (1, 1, 20, 24) and 0 < ddm.min() and ddm.max() < 1
     dds = np.load(os.path.join(out, 'ddm_source', 'source_001.npy'))
     assert dds.shape == (1, 1, 20, 24)
+
+
+def test_fsd_batch_discriminator_matches_reference_test_tar(golden_dir, margins):
+    """Real-weights known-answer test: the FSD-Batch discriminator (codes/DSN/model.py:60-118,173-189) with the weights of the reference's
+    codes/DSN/test.tar, BatchNorm in eval mode folded into the convs, on the HIP inference path (DSNModel.ddm_of, what
+    create_dataset_modified.py:147-164 runs) against the output of the reference module itself (tests/golden/dsn_fsd_batch_test_tar.npz)."""
+    _gpu()
+    import numpy as np
+    from dasr_amd.dsn_model import DSNModel
+    fx = np.load(os.path.join(golden_dir, 'dsn_fsd_batch_test_tar.npz'))
+    sd = {k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith('w/')}
+    m = DSNModel(dict(filter='gau', kernel_size=5, norm_layer='Batch', w_per=0.0))
+    m.load_discriminator_state(sd)
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(97))
+    dout, ddm = m.ddm_of(x.cuda())
+    torch.cuda.synchronize()
+    want = torch.from_numpy(fx['out'])
+    e = rel(dout.cpu(), want)
+    margins('FSD-Batch discriminator with the reference test.tar weights: D_out rel err %.2e (tol 1e-3), max abs %.2e' % (
+        e, float((dout.cpu() - want).abs().max())))
+    assert dout.shape == want.shape and e < 1e-3
+    with pytest.raises(NotImplementedError):
+        m.iteration(torch.rand(1, 3, 128, 128).cuda(), torch.rand(1, 3, 32, 32).cuda(), torch.rand(1, 3, 32, 32).cuda())

@@ -66,6 +66,23 @@ def test_options_parse_and_nonedict(tmp_path):
     assert 'lr_G' in options.dict2str(opt)
 
 
+def test_options_parse_leaves_visible_devices_alone_under_a_launcher(tmp_path, monkeypatch):
+    """one process per GPU: rank r uses device LOCAL_RANK; gpu_ids [0] of the shipped JSONs must not hide the other devices"""
+    from dasr_amd import options
+    p = tmp_path / 'o.json'
+    p.write_text('{"name": "x", "model": "sr", "scale": 4, "gpu_ids": [0], "datasets": {}, "path": {"root": "/tmp/dasr_opt_test"}, '
+                 '"network_G": {"which_model_G": "RRDB_net"}, "train": {}, "logger": {}}')
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    monkeypatch.setenv('LOCAL_RANK', '1')
+    monkeypatch.setenv('CUDA_VISIBLE_DEVICES', '0,1,2,3')
+    options.parse(str(p))
+    assert os.environ['CUDA_VISIBLE_DEVICES'] == '0,1,2,3'
+    monkeypatch.delenv('WORLD_SIZE')
+    monkeypatch.delenv('LOCAL_RANK')
+    options.parse(str(p))
+    assert os.environ['CUDA_VISIBLE_DEVICES'] == '0'
+
+
 def test_multistep_lr_matches_torch():
     from dasr_amd.models import MultiStepLR
     p = torch.nn.Parameter(torch.zeros(1))
@@ -171,6 +188,7 @@ def test_dsn_cli_flags_and_lr_rule():
     o = dsn_train.build_parser().parse_args([])
     assert (o.batch_size, o.num_epochs, o.num_decay_epochs, o.learning_rate, o.adam_beta_1) == (4, 400, 150, 1e-4, 0.5)
     assert (o.w_col, o.w_tex, o.w_per, o.kernel_size, o.filter, o.discriminator, o.generator) == (1, 0.005, 0.01, 5, 'gau', 'FSD', 'DeResnet')
+    assert (o.dataset, o.per_type) == ('df2k', 'LPIPS')   # the reference's defaults (codes/DSN/train.py:38,54); both fail loudly offline
     dsn_train.check_supported(o)
     for bad in (['--generator', 'DSGAN'], ['--discriminator', 'nld_s1'], ['--ragan'], ['--wgan'], ['--norm_layer', 'Batch']):
         with pytest.raises(NotImplementedError):

@@ -39,3 +39,19 @@ def test_dsn_trainer_runs_two_iterations():
     t.iteration(hr, bic, real)
     t.end_epoch()
     assert all(np.isfinite(v) for v in t.log.values()) and t.log != l0
+
+
+def test_oracle_fsd_batch_reproduces_reference_test_tar(golden_dir):
+    """real-weights KAT: the oracle Discriminator (FSD, BatchNorm, gaussian k=5) in eval mode with the weights of the reference's
+    codes/DSN/test.tar reproduces the reference module's output"""
+    import numpy as np
+    fx = np.load(os.path.join(golden_dir, 'dsn_fsd_batch_test_tar.npz'))
+    sd = {k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith('w/')}
+    D = dsn.Discriminator(kernel_size=5, norm_layer='Batch', filter_type='gau')
+    missing = D.load_state_dict(sd, strict=False)
+    assert not [k for k in missing.missing_keys if 'gaussian' not in k] and not [k for k in missing.unexpected_keys if 'gaussian' not in k]
+    D.eval()
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(97))
+    with torch.no_grad():
+        y = D(x)
+    np.testing.assert_allclose(y.numpy(), fx['out'], rtol=1e-5, atol=1e-6)
