@@ -665,7 +665,8 @@ extern "C" int dasr_lowpass(dasr_tensor x, dasr_tensor x2, const float* w, int32
 extern "C" int dasr_maxpool2(dasr_tensor x, int32_t is_f32, int32_t N, int32_t C, int32_t Ho, int32_t Wo, dasr_tensor y, void* stream) {
     const long long total = (long long)N * ((C + 15) / 16) * Ho * Wo * 4;
     if (total <= 0) return DASR_EINVAL;
-    if (is_f32) DASR_LAUNCH(maxpool_fwd_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
+    if (is_f32 == 2) DASR_LAUNCH(maxpool_fwd_kernel<f16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
+    else if (is_f32) DASR_LAUNCH(maxpool_fwd_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
     else DASR_LAUNCH(maxpool_fwd_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
     return (int)hipGetLastError();
 }
@@ -674,7 +675,8 @@ extern "C" int dasr_maxpool2_bwd(dasr_tensor x, dasr_tensor gy, int32_t is_f32, 
                                  int32_t relu_mask, void* stream) {
     const long long total = (long long)N * ((C + 15) / 16) * Ho * Wo * 4;
     if (total <= 0) return DASR_EINVAL;
-    if (is_f32) DASR_LAUNCH(maxpool_bwd_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
+    if (is_f32 == 2) DASR_LAUNCH(maxpool_bwd_kernel<f16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
+    else if (is_f32) DASR_LAUNCH(maxpool_bwd_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
     else DASR_LAUNCH(maxpool_bwd_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
     return (int)hipGetLastError();
 }
@@ -695,7 +697,8 @@ extern "C" int dasr_affine4(dasr_tensor x, int32_t N, int32_t C, int32_t H, int3
     const long long total = (long long)N * H * W;
     if (total <= 0 || C > 4) return DASR_EINVAL;
     const f32x4 sc = {scale4[0], scale4[1], scale4[2], scale4[3]}, sh = {shift4[0], shift4[1], shift4[2], shift4[3]};
-    if (y_f32) DASR_LAUNCH(affine4_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, sc, sh, y, accumulate);
+    if (y_f32 == 2) DASR_LAUNCH(affine4_kernel<f16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, sc, sh, y, accumulate);
+    else if (y_f32) DASR_LAUNCH(affine4_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, sc, sh, y, accumulate);
     else DASR_LAUNCH(affine4_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, sc, sh, y, accumulate);
     return (int)hipGetLastError();
 }

@@ -339,7 +339,7 @@ class _StepPlan:
             sh = [-mu / s for mu, s in zip(VGG_MEAN, VGG_STD)] + [0.0]
             for src, dst in ((g.sr.view(), v.x.view()), (self.hr_b.view(), _nview(v.x, n))):
                 o = add(fwd, _op(_lib.OP_AFFINE4))
-                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1], o.i[4], o.i[5] = src, n, 3, H, W, dst, 1, 0
+                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1], o.i[4], o.i[5] = src, n, 3, H, W, dst, v.x_flag, 0
                 for j in range(4):
                     o.f[j] = sc[j]
                 C.memmove(C.addressof(o.l), (C.c_float * 4)(*sh), 16)

@@ -481,11 +481,7 @@ class _DSNPlan:
             self.v = m.netF.plan(2 * N, N, h, w)
             v = self.v
             for src, n0 in ((g.fake, 0), (self.bic_b, N)):
-                o = _op(_lib.OP_AXPBY)
-                o.t[0], o.f[0], o.t[1], o.f[1] = src.view(), 1.0, NULL_T, 0.0
-                o.i[0], o.i[1], o.i[2], o.i[3] = N, 16, h, w
-                o.t[2], o.t[3], o.f[2], o.t[4] = _nview(v.x, n0), NULL_T, 1.0, NULL_T
-                f.add(o)
+                f.add(v.input_copy_op(src.view(), n0, N, h, w))
             f.extend(v.fwd)
             ft = v.feat
             o = _op(_lib.OP_L1DIFF)

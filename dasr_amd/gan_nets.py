@@ -271,11 +271,16 @@ class VGGFeatureHIP:
     """Frozen feature extractor: forward on N images, data-gradient w.r.t. the first n_g inputs."""
 
     def __init__(self, feature_layer=34, device='cuda', cfg=None, prec=None):
-        """prec 3: split-bf16 operands (~fp32); prec 1: plain bf16 operands, fp32 accumulation (3x fewer MFMAs).  Default from
-        DASR_VGG_PREC, else 3."""
+        """prec 3 (default): split-bf16 operands on f32 tensors (~fp32, 3 MFMA passes).  prec 2: activations and gradients stored in f16
+        (11-bit mantissa; gradients pre-scaled by a power of two), one f16 MFMA pass on the LDS-DMA dense-conv kernel: the full GAN step
+        drops from 101 to 84 ms, but over the 16 un-damped layers the operand rounding adds up to 1.0e-3 on the features, and max-pool's
+        arg-max routing turns 11-bit ties into an 11 % normwise error of dL/dx (1.2-1.6e-2 on the generator gradient of the full step) with
+        the seeded-random VGG of the fixtures -- outside the 1e-3 / 1e-2 tolerances, so it is an opt-in (DASR_VGG_PREC=2), not the
+        default.  prec 1: plain bf16 operands on f32 tensors (8x coarser than f16)."""
         import os
         self.device = torch.device(device)
         self.prec = int(prec if prec is not None else os.environ.get('DASR_VGG_PREC', '3'))
+        self.f16s = self.prec == 2
         self.spec, self.layers = vgg19_spec(feature_layer, cfg)
         self.params = ParamStore(self.spec, self.device)
         self.pack = PackRegistry(self.params)
@@ -286,8 +291,8 @@ class VGGFeatureHIP:
                 continue
             w = P.off('features.%d.weight' % idx)
             cin_pad = ceil_div(cin, 16) * 16
-            mt_f = 2 if (self.prec == 1 and cout % 64 == 0) else 1
-            mt_b = 2 if (self.prec == 1 and cin % 64 == 0) else 1
+            mt_f = 2 if (self.prec in (1, 2) and cout % 64 == 0) else 1
+            mt_b = 2 if (self.prec in (1, 2) and cin % 64 == 0) else 1
             self.pk[idx] = self.pack.add(cout, cin_pad, 9, mt_f, self.prec, [(w, cout, cin, 0, cin, 0, 0)])
             self.pk[(idx, 'b')] = self.pack.add(cin, cout, 9, mt_b, self.prec, [(w, cout, cin, 0, cout, 0, 1)])
         self.pack.finalize()
@@ -311,6 +316,9 @@ class _VGGPlan:
     def __init__(self, net, N, n_g, H, W):
         self.net, self.N, self.n_g = net, N, n_g
         dev, P, pack = net.device, net.params, net.pack
+        if net.f16s:
+            return self._init_f16(N, n_g, H, W)
+        self.x_flag = 1                           # dtype code of x for dasr_affine4 (1 f32, 2 f16)
         self.x = BTensor(N, 16, H, W, True, dev)  # normalised input
         self.outs = []
         h, w = H, W
@@ -350,6 +358,86 @@ class _VGGPlan:
             else:
                 o = _op(_lib.OP_MAXPOOL_BWD)
                 o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.t[2] = inp.view(), g.view(), n, cout, g.H, g.W, 1, 1, gin.view()
+                bwd.add(o)
+            g = gin
+        self.bwd = bwd
+
+    def input_copy_op(self, src_view, n0, n, H, W):
+        """op that writes `n` images of a blocked f32 tensor (<= 16 channels) into x[n0 : n0 + n] (DSN: no input normalisation)"""
+        dst = Tensor(self.x.view().p + n0 * self.x.view().n_stride * self.x.esz, self.x.view().n_stride, self.x.view().cb_stride)
+        o = _op(_lib.OP_CVT_F16 if self.net.f16s else _lib.OP_AXPBY)
+        if self.net.f16s:
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1] = src_view, n, 16, H, W, 1.0, dst
+        else:
+            o.t[0], o.f[0], o.t[1], o.f[1] = src_view, 1.0, NULL_T, 0.0
+            o.i[0], o.i[1], o.i[2], o.i[3] = n, 16, H, W
+            o.t[2], o.t[3], o.f[2], o.t[4] = dst, NULL_T, 1.0, NULL_T
+        return o
+
+    def _init_f16(self, N, n_g, H, W):
+        """f16 storage: every activation up to the last conv (and, backward, every gradient below it, pre-scaled by gscale) is an f16 tensor;
+        convs run on the LDS-DMA dense-conv kernel with the f16 MFMA.  The last conv writes f32, a pool behind it (vgg16.features[:31]) runs
+        in f32: the feature map and dL/dx are f32 like in the other modes."""
+        import math
+        net = self.net
+        dev, P, pack = net.device, net.params, net.pack
+        Bh = lambda C_, h, w: BTensor(N, C_, h, w, False, dev, f16=True)
+        Bf = lambda C_, h, w: BTensor(N, C_, h, w, True, dev)
+        self.x_flag = 2
+        self.x = Bh(16, H, W)
+        self.outs = []
+        h, w = H, W
+        fwd = OpList()
+        src = self.x
+        nl = len(net.layers)
+        lc = max(i for i, L in enumerate(net.layers) if L[0] == 'conv')   # last conv: the hand-off to f32
+        for li, (kind, idx, cin, cout, relu) in enumerate(net.layers):
+            if kind == 'conv':
+                out = Bf(cout, h, w) if li == lc else Bh(cout, h, w)
+                fwd.add(conv_op(pack, net.pk[idx], src.view(), False, ceil_div(cin, 16) * 16, h, w, h, w, N, bias=P.ptr('features.%d.bias' % idx),
+                                act=1 if relu else 0, slope=0.0, out_f32=out.view() if li == lc else None, out_bf16=None if li == lc else out.view(),
+                                out16_f16=0 if li == lc else 1))
+            else:
+                h, w = h // 2, w // 2
+                out = Bf(cout, h, w) if li > lc else Bh(cout, h, w)
+                o = _op(_lib.OP_MAXPOOL)
+                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[1] = src.view(), N, cout, h, w, (1 if li > lc else 2), out.view()
+                fwd.add(o)
+            self.outs.append(out)
+            src = out
+        self.feat = src
+        self.fwd = fwd
+        n = n_g
+        self.g_feat = Bf(self.feat.C, self.feat.H, self.feat.W)
+        self.gx = Bf(16, H, W)
+        # dL/dfeat of a mean loss over n_g x C x h x w elements is ~1 / count: scaled to ~2^-3 before its f16 rounding (exact power of two)
+        cnt = max(1, n_g * self.feat.C * self.feat.H * self.feat.W)
+        self.gscale = float(2.0 ** max(0, int(math.floor(math.log2(cnt))) - 3))
+        bwd = OpList()
+        g = self.g_feat
+        for li in range(nl - 1, -1, -1):
+            kind, idx, cin, cout, relu = net.layers[li]
+            inp = self.x if li == 0 else self.outs[li - 1]
+            if kind == 'conv':
+                if li == lc:   # f32 gradient of the last conv's output -> pre-scaled f16
+                    g16 = Bh(g.C, g.H, g.W)
+                    o = _op(_lib.OP_CVT_F16)
+                    o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1] = g.view(), n, g.C, g.H, g.W, self.gscale, g16.view()
+                    bwd.add(o)
+                    g = g16
+                prev_relu = li > 0 and net.layers[li - 1][0] == 'conv' and net.layers[li - 1][4]
+                if li == 0:   # dL/d(normalised input): f32, un-scaled
+                    bwd.add(conv_op(pack, net.pk[(idx, 'b')], g.view(), False, cout, inp.H, inp.W, inp.H, inp.W, n, alpha=1.0 / self.gscale,
+                                    out_f32=self.gx.view()))
+                    break
+                gin = Bh(inp.C, inp.H, inp.W)
+                bwd.add(conv_op(pack, net.pk[(idx, 'b')], g.view(), False, cout, inp.H, inp.W, inp.H, inp.W, n,
+                                mask=inp.view() if prev_relu else None, mask_f32=0, slope=0.0, out_bf16=gin.view(), out16_f16=1))
+            else:
+                f32 = li > lc
+                gin = Bf(inp.C, inp.H, inp.W) if f32 else Bh(inp.C, inp.H, inp.W)
+                o = _op(_lib.OP_MAXPOOL_BWD)
+                o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.t[2] = inp.view(), g.view(), n, cout, g.H, g.W, (1 if f32 else 2), 1, gin.view()
                 bwd.add(o)
             g = gin
         self.bwd = bwd

@@ -224,7 +224,7 @@ int dasr_dwt_bwd(dasr_tensor gll, dasr_tensor ghc, int32_t N, int32_t C, int32_t
  * with x = dL/dlow, x2 = dL/dhigh (either may be null). */
 int dasr_lowpass(dasr_tensor x, dasr_tensor x2, const float* w, int32_t k, int32_t N, int32_t C, int32_t H, int32_t W,
                  int32_t mode, float a_h, float b_h, dasr_tensor out_low, dasr_tensor out_high, int32_t accumulate, void* stream);
-/* nn.MaxPool2d(2,2) of the VGG19 feature stack, forward and backward (Ho, Wo = pooled size) */
+/* nn.MaxPool2d(2,2) of the VGG19 feature stack, forward and backward (Ho, Wo = pooled size); is_f32: 0 bf16, 1 f32, 2 f16 tensors */
 int dasr_maxpool2(dasr_tensor x, int32_t is_f32, int32_t N, int32_t C, int32_t Ho, int32_t Wo, dasr_tensor y, void* stream);
 /* relu_mask: also zero the gradient where the pooled maximum is <= 0 (the ReLU' of the conv feeding the pool) */
 int dasr_maxpool2_bwd(dasr_tensor x, dasr_tensor gy, int32_t is_f32, int32_t N, int32_t C, int32_t Ho, int32_t Wo, dasr_tensor gx,
@@ -233,7 +233,7 @@ int dasr_maxpool2_bwd(dasr_tensor x, dasr_tensor gy, int32_t is_f32, int32_t N, 
  * ga = gcoef*sign(a-b).  is_f32 bit 1 set: squared form (MSE of the DSN VGG16 perceptual loss, loss.py:119-130). */
 int dasr_l1_diff(dasr_tensor a, dasr_tensor b, int32_t is_f32, int32_t N, int32_t C, int32_t H, int32_t W, float coef, float gcoef,
                  float* loss_acc, dasr_tensor ga, void* stream);
-/* per-channel affine on <=4 channels (VGG input normalisation architecture.py:1086-1087 and its adjoint) */
+/* per-channel affine on <=4 channels (VGG input normalisation architecture.py:1086-1087 and its adjoint); y_f32: 0 bf16, 1 f32, 2 f16 output */
 int dasr_affine4(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, const float* scale4, const float* shift4, dasr_tensor y,
                  int32_t y_f32, int32_t accumulate, void* stream);
 /* F.interpolate(bilinear, align_corners=False) of the domain-distance map (DASR_model.py:173-174), NCHW [N][1][h][w] */

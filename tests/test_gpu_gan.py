@@ -172,28 +172,38 @@ def test_discriminator_forward_backward(nc, hw):
     assert rel(p.gx.nchw(nc).cpu()[:2], xr.grad[:2]) < GRAD_TOL
 
 
-def test_vgg_forward_and_input_gradient():
+# prec 3: the default (split-bf16, ~fp32).  prec 2: the opt-in f16-storage path (one MFMA pass): operand rounding of 2^-12 over 16 un-damped
+# layers lands AT the activation tolerance, and the gradient is far outside its tolerance: max-pool routes the gradient to the arg-max of each
+# 2x2 window, and values rounded to 11 bits tie or swap order in ~1e-3 of the windows (normwise error ~ sqrt of that fraction; even the
+# ~fp32 path shows 6.5e-3 from this mechanism).  The path is checked against its own documented bounds so that it stays correct; it is
+# NOT what the trainers use by default.
+@pytest.mark.parametrize('prec,act_tol,grad_tol', [(3, ACT_TOL, GRAD_TOL), (2, 2.5e-3, 0.2)], ids=['split_bf16', 'f16_storage_optin'])
+def test_vgg_forward_and_input_gradient(prec, act_tol, grad_tol, margins):
     dev = _gpu()
     from dasr_amd.gan_nets import VGGFeatureHIP
     from oracle import nets
     ref = nets.VGGFeatureExtractor(34, seed=77)
-    V = VGGFeatureHIP(34, device=dev)
+    V = VGGFeatureHIP(34, device=dev, prec=prec)
     V.load_state_dict({k: v for k, v in ref.state_dict().items() if k.startswith('features')})
     g = torch.Generator().manual_seed(3)
     x = torch.rand(2, 3, 64, 64, generator=g)
     xn = ((x - ref.mean) / ref.std)
     p = V.plan(2, 1, 64, 64)
-    p.x.t.copy_(to_blocked(xn, dev).t)
+    p.x.t.copy_(to_blocked(xn, dev).t.to(p.x.t.dtype))
     p.fwd.run()
     xr = x.clone().requires_grad_(True)
     f = ref(xr)
-    assert rel(p.feat.nchw().cpu(), f.detach()) < ACT_TOL
-    gf = torch.randn(f.shape, generator=g)
+    e_f = rel(p.feat.nchw().cpu(), f.detach())
+    # dL/dfeat at the magnitude a mean feature loss produces (~1 / element count): the f16 path pre-scales gradients by a power of two
+    # chosen for that magnitude (a unit-scale random gradient would overflow f16 in the middle of the stack)
+    gf = torch.randn(f.shape, generator=g) / f[:1].numel()
     p.g_feat.t.copy_(to_blocked(gf, dev).t)
     (f[:1] * gf[:1]).sum().backward()
     p.bwd.run()
     got = p.gx.nchw(3).cpu()[:1] / ref.std  # adjoint of the input normalisation
-    assert rel(got, xr.grad[:1]) < GRAD_TOL
+    e_g = rel(got, xr.grad[:1])
+    margins('VGG19-54 prec %d: feature rel err %.2e (tol %.1e), input-gradient rel err %.2e (tol %.1e)' % (prec, e_f, act_tol, e_g, grad_tol))
+    assert e_f < act_tol and e_g < grad_tol
 
 
 @pytest.mark.parametrize('case', ['dasr_wavelet_nf32_nb2_n2_32', 'dasr_gau9_nf64_nb1_n1_32'])
