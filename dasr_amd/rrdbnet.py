@@ -230,21 +230,17 @@ class _Plan:
         self.g2b = Bh(nf, H2, W2)
         self.g_t0 = B(nf, h, w, True)
         self.gstream = [B(nf, h, w, True) for _ in range(4)]
-        # RDB weight gradients are off the data-gradient chain's critical path; DASR_WG_SIDE=1 moves them to a side stream of the plan
-        # (events recorded / awaited by scheduling ops inside the op list, four gradient slabs instead of two for slack).  Correct
-        # (same tests green) but SLOWER on MI355X: 46.8 vs 38.6 ms/step -- the 1-workgroup-per-CU wgrad launches take CUs from the
-        # serial data-gradient chain of their own sub-batch; kept off, as an experiment switch
-        self.side_stream = torch.cuda.Stream() if (dev.type == 'cuda' and getattr(net, 'concurrent_replicas', 1) > 1 and
-                                                   os.environ.get('DASR_WG_SIDE', '0') == '1') else None
-        self.n_gslab = 4 if self.side_stream is not None else 2
+        # weight gradients of `wg_batch` consecutive RDBs share one launch (see _build_backward_trunk): wg_batch + 1 gradient slabs rotate.
+        # (A side stream for the RDB weight gradients was tried in round 1 and was slower -- they take CUs from the serial data-gradient
+        # chain of their own sub-batch -- and has been removed.)
+        self.wg_batch = max(1, int(os.environ.get('DASR_WG_BATCH', '3')))
+        self.n_gslab = self.wg_batch + 1
         self.gslab = [B(sc, h, w, False) for _ in range(self.n_gslab)]
-        self.ws_side = Workspace(dev)
         self.g_fea = B(nf, h, w, True)
         self.ws = Workspace(dev)
         self._build_forward()
         self._build_backward()
         self.ws.finalize()
-        self.ws_side.finalize()
 
     # ---- IO -----------------------------------------------------------------------------------------
     def set_input(self, x):
@@ -516,8 +512,23 @@ class _Plan:
         gs_cur = 0
         ops.add(conv_op(pack, pk['lr_b'], self.g_t0.view(), True, nf, h, w, h, w, N, out_f32=G.view(),
                         out_bf16=self.gslab[gs_cur].view(0), gamma=0.04))
-        done_events = []
-        # RRDB chain, reversed
+        # RRDB chain, reversed.  The weight gradients of `wgb` consecutive RDBs (default: the three of an RRDB) go into ONE launch: the
+        # split count per part drops by that factor, and with it the fp32 partial-sum traffic (49 MB written + read per RDB at 48 splits),
+        # the reduce work and two thirds of the launches.  Needs wgb + 1 gradient slabs in the ring.
+        wgb = self.wg_batch
+        grp, n_in_grp = None, 0
+
+        def flush_wgrad():
+            nonlocal grp, n_in_grp
+            if grp is None:
+                return
+            grp.finalize(self.ws, net.device,
+                         target_wgs=int(os.environ.get('DASR_WG3_TARGET', str(256 // max(1, getattr(net, 'concurrent_replicas', 1))))))
+            for o in grp.ops(self.grad.data_ptr()):
+                ops.add(o)
+            ops.keep.append(grp)
+            grp, n_in_grp = None, 0
+
         for i in range(nb - 1, -1, -1):
             Grr = G  # grad wrt the RRDB output
             Gout = None  # grad wrt the current RDB output (None: it is 0.2*Grr, folded into the epilogue)
@@ -528,15 +539,17 @@ class _Plan:
                     cin_b = nf + (4 - k) * GC
                     ops.add(conv_op(pack, pk[(i, r, 'b', k)], Gs.view(0), False, cin_b, h, w, h, w, N,
                                     mask=S.view(nf + (k - 1) * GC), mask_f32=0, out_bf16=Gs.view(cin_b)))
-                # weight gradients of the 5 convs of this RDB in one launch: one part per 64-channel block of the
-                # forward slab x up to three 32-oc tiles of gslab' (= every conv that consumes those channels)
+                # weight gradients of the 5 convs of this RDB: one part per 64-channel block of the forward slab x up to three
+                # 32-oc tiles of gslab' (= every conv that consumes those channels)
                 pre = 'model.1.sub.%d.RDB%d.conv' % (i, r)
                 gt = []  # gslab' oc tiles in order: conv5 (nf/32 tiles), conv4, conv3, conv2, conv1
                 for j in (5, 4, 3, 2, 1):
                     cout_j = nf if j == 5 else GC
                     for oc0 in range(0, cout_j, 32):
                         gt.append(dict(j=j, oc0=oc0, cout=cout_j, cin=nf + (j - 1) * GC))
-                grp = WgradGroup3()
+                if grp is None:
+                    grp = WgradGroup3()
+                    grp.flops = 0.0
                 for c0 in range(0, nf + 4 * GC, 64):
                     need = [t for t in gt if t['cin'] > c0]
                     blk_ch = min(64, nf + 4 * GC - c0)
@@ -550,26 +563,8 @@ class _Plan:
                                               n_ctiles=min(2, ceil_div(min(t['cin'] - c0, 64), 32))))
                         grp.add_block(Gs.view(32 * k0), 2 * len(sub), S.view(c0), blk_ch // 16, ceil_div(blk_ch, 32),
                                       h, w, h, w, N, tiles, want_bias=(c0 == 0))
-                grp.flops = 2.0 * N * h * w * 9 * sum((nf + (j - 1) * GC) * (GC if j < 5 else nf) for j in range(1, 6))
-                side = self.side_stream is not None
-                grp.finalize(self.ws_side if side else self.ws, net.device,
-                             target_wgs=int(os.environ.get('DASR_WG3_TARGET', str(256 // max(1, getattr(net, 'concurrent_replicas', 1))))))
-                if side:   # main: record "g1..g5 of this RDB complete"; side: wait, wgrad + reduce, record "slab free"
-                    e_ready, e_done = self._event(), self._event()
-                    ops.add(_sched(_lib.OP_EVENT_RECORD, e_ready))
-                    ops.add(_sched(_lib.OP_SET_STREAM, self.side_stream.cuda_stream))
-                    ops.add(_sched(_lib.OP_STREAM_WAIT, e_ready))
-                for o in grp.ops(self.grad.data_ptr()):
-                    ops.add(o)
-                ops.keep.append(grp)
-                if side:
-                    ops.add(_sched(_lib.OP_EVENT_RECORD, e_done))
-                    ops.add(_sched(_lib.OP_SET_STREAM, None))
-                    done_events.append(e_done)
-                    # the g_x conv below writes g5 of the next RDB into the slab that the wgrad of (n_gslab - 1) RDBs ago read
-                    q = len(done_events) - 1
-                    if q - (self.n_gslab - 1) >= 0:
-                        ops.add(_sched(_lib.OP_STREAM_WAIT, done_events[q - (self.n_gslab - 1)]))
+                grp.flops += 2.0 * N * h * w * 9 * sum((nf + (j - 1) * GC) * (GC if j < 5 else nf) for j in range(1, 6))
+                n_in_grp += 1
                 # g_x conv with the residual bookkeeping fused
                 Gin = next(b for b in free if b is not Grr and b is not Gout)
                 first = (ridx == 0)
@@ -585,11 +580,13 @@ class _Plan:
                                     res1=Gout.view(), beta1=1.0, res2=Grr.view(), beta2=1.0, out_f32=Gin.view(), out_bf16=nxt, gamma=0.04))
                 Gout = Gin
                 gs_cur = (gs_cur + 1) % self.n_gslab
+                if n_in_grp >= wgb:
+                    flush_wgrad()
             G = Gout
             if i > 0 and i % bucket_every == 0:
+                flush_wgrad()   # a gradient bucket is complete only when its weight gradients have been reduced
                 self._marks.append((len(ops.ops), P.off('model.1.sub.%d.RDB1.conv1.0.weight' % i)))
-        if done_events:   # the side stream is in order: its last event covers every weight gradient of the chain
-            ops.add(_sched(_lib.OP_STREAM_WAIT, done_events[-1]))
+        flush_wgrad()
         # ShortcutBlock: g_fea = g_chain + g_t0
         o = Op()
         o.op = _lib.OP_AXPBY
