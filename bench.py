@@ -239,6 +239,13 @@ def sweep(model, data, a):
             log('sweep step time, tuning %s: %.2f ms/step' % (combo, (time.perf_counter() - t0) / 3 * 1e3))
 
 
+_STREAMS0 = os.environ.get('DASR_STREAMS', '2')
+
+
+def streams_default():
+    return max(1, int(_STREAMS0))
+
+
 def setup_dist(a):
     """one process per GPU.  Started by a launcher (WORLD_SIZE set): join its group.  Started directly with --gpus N > 1: re-exec
     under torch.distributed.run so that `python bench.py --gpus N` really measures N GPUs."""
@@ -377,6 +384,28 @@ def bench_srn(a, dp, dasr, as_secondary=False):
         log('roofline done')
     elif not as_secondary:
         one_step()  # the other ranks take part in the profiled step's collectives
+    if not as_secondary and not dasr and streams_default() > 1 and not a.no_secondary:
+        # (skipped with --no-secondary = the rocprofv3 / PMC runs, so profiles/*.csv hold launches of the production schedule only)
+        # the same step with ONE stream (every launch covers the whole per-GPU batch and has the chip to itself): the per-launch rates of
+        # the kernels without the overlap of the sub-batch streams.  Not the production schedule: reported beside it, never as `value`.
+        os.environ['DASR_STREAMS'] = '1'
+        try:
+            one_step()
+            one_step()
+            if rank == 0:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                one_step()
+                torch.cuda.synchronize()
+                ms1 = (time.perf_counter() - t0) * 1e3
+                r1 = roofline_from_step(one_step, None, 1)
+                out['roofline']['single_stream'] = {'ms_per_step': round(ms1, 2), 'per_kernel': r1['per_kernel'],
+                                                    'note': 'DASR_STREAMS=1: batch-%d launches, no overlap between launches' % batch}
+            else:
+                one_step()
+                one_step()
+        finally:
+            os.environ['DASR_STREAMS'] = str(streams_default())
     del model
     torch.cuda.empty_cache()
     return out

@@ -218,6 +218,8 @@ class SRModel(BaseModel):
         fill those gaps with each other's main loops.  DASR_STREAMS=1 disables it."""
         k = max(1, int(os.environ.get('DASR_STREAMS', '2')))
         if k == 1 or N % k or N // k < 4:
+            if (N, h, w, 0) not in self.netG.plans:
+                self.netG.concurrent_replicas = 1   # a plan built now has the chip to itself (wgrad split count)
             return [self.netG.plan(N, h, w)]
         self.netG.concurrent_replicas = k  # the 1-WG/CU wgrad launches of the replicas must fit on the chip together
         return [self.netG.plan(N // k, h, w, replica=i) for i in range(k)]
