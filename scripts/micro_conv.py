@@ -40,9 +40,9 @@ for s in range(a.streams):
     ol = OpList()
     for _ in range(a.reps):
         xv, yv = x.view(), y.view()
-        if a.alias >= 1:
+        if a.alias in (1, 2):
             xv.n_stride = 0
-        if a.alias >= 2:
+        if a.alias >= 2:   # 3: only the mask / output tensor aliases image 0
             yv.n_stride = 0
         if a.mode == 'dgrad':
             ol.add(conv_op(pack, ref, xv, False, a.cin, a.hw, a.hw, a.hw, a.hw, n, mask=yv, mask_f32=0, out_bf16=ym.view()))
