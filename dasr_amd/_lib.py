@@ -65,6 +65,7 @@ OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_DOWNSUM, OP_AXPBY, OP_FILL, OP_L
  OP_BILINEAR, OP_LOGLOSS, OP_SIGMOID_BWD, OP_PRELU_GRAD, OP_LOWPASS_VALID, OP_ADD_FLAT, OP_SIGMOID_FWD, OP_EVENT_RECORD, OP_STREAM_WAIT,
  OP_SET_STREAM) = range(11, 31)
 OP_CVT_F16, OP_DOWNSUM_F16, OP_PIXSHUF, OP_PIXUNSHUF = 31, 32, 33, 34
+OP_LPIPS_S2D, OP_MAXPOOL3, OP_MAXPOOL3_BWD, OP_LPIPS_HEAD = 35, 36, 37, 38
 
 _SIGS = {
     'dasr_conv': [C.POINTER(ConvParams), c_vp],
@@ -115,11 +116,15 @@ _SIGS = {
     'dasr_allreduce': [c_vp, c_vp, c_i64, c_vp],
     'dasr_broadcast': [c_vp, c_vp, c_i64, c_i32, c_vp],
     'dasr_rccl_destroy': [c_vp],
+    'dasr_lpips_s2d': [Tensor, c_i32, c_i32, c_i32, c_vp, c_vp, Tensor, c_i32, c_vp],
+    'dasr_maxpool3s2': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_vp],
+    'dasr_maxpool3s2_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_i32, c_vp],
+    'dasr_lpips_head': [Tensor, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_f32, c_f32, c_f32, c_vp, Tensor, c_i32, c_vp],
     'dasr_prof_begin': [c_i32],
     'dasr_prof_end': [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

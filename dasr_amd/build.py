@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libdasr_hip.so')
-SOURCES = ['conv.hip', 'wgrad.hip', 'misc.hip', 'gan.hip', 'rccl.hip']
+SOURCES = ['conv.hip', 'wgrad.hip', 'misc.hip', 'gan.hip', 'lpips.hip', 'rccl.hip']
 
 
 def _stale():

@@ -1192,7 +1192,8 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
     else if (p.kh == 1) kcode = 5;
     else if (p.kh == 3 && p.stride == 2) kcode = 6;
     const int key = (p.prec == 3 ? 1000 : p.prec == 2 ? 2000 : 0) + (p.in_f32 ? 100 : 0) + p.mt * 10 + kcode;
-    if (p.kh == 3 && ((p.stride != 1 && p.stride != 2) || p.pad != 1)) return DASR_EINVAL;
+    // 3x3: pad 1; the register-staged f32-tensor stride-1 kernel also runs pad 0 / 2 (LPIPS conv1 on the space-to-depth grid and its adjoint)
+    if (p.kh == 3 && ((p.stride != 1 && p.stride != 2) || (p.pad != 1 && !(p.pad >= 0 && p.pad <= 2 && p.stride == 1 && p.in_f32)))) return DASR_EINVAL;
     if (p.kh == 5 && (p.stride != 1 || p.pad != 2)) return DASR_EINVAL;
     if (p.kh == 1 && (p.stride != 1 || p.pad != 0)) return DASR_EINVAL;
     if (p.kh == 4 && ((p.stride != 1 && p.stride != 2) || p.pad < 0 || p.pad > 3)) return DASR_EINVAL;

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DASR_ABI_VERSION 4
+#define DASR_ABI_VERSION 5
 #define DASR_EINVAL (-22)
 
 typedef struct {
@@ -46,7 +46,7 @@ typedef struct {
     const void* w;   int64_t w_lo_off;      /* packed bf16 weights (dasr_pack_weights); lo plane offset (elements) for prec 3 */
     const float* bias;                      /* [cout] or NULL */
     int32_t cout, Hout, Wout, N;
-    int32_t kh, stride, pad;                /* 3/1/1 or 4/2/1 or 4/1/1 */
+    int32_t kh, stride, pad;                /* 3/1/1 or 4/2/1 or 4/1/1; the f32-tensor 3x3 stride-1 conv also takes pad 0 / 2 (LPIPS conv1 and its adjoint) */
     int32_t prec;                           /* 1: bf16 operands; 2: f16 operands, one MFMA pass (f32 input, see in_scale); 3: split-bf16 (hi*hi+hi*lo+lo*hi), ~fp32 */
     int32_t mt;                             /* 32-oc tiles per workgroup (1 or 2); must match the packing */
     int32_t act;  float slope;
@@ -239,6 +239,25 @@ int dasr_affine4(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, cons
 /* F.interpolate(bilinear, align_corners=False) of the domain-distance map (DASR_model.py:173-174), NCHW [N][1][h][w] */
 int dasr_bilinear_up(const float* src, int32_t N, int32_t h, int32_t w, int32_t factor, float* dst, void* stream);
 
+/* ---- LPIPS(alex) perceptual loss (csrc/lpips.hip) ----------------------------------------------------------------------
+ * feature_criterion "LPIPS" of the shipped DASR configs: PerceptualLossLPIPS codes/SRN/models/modules/loss.py:66-72 -> PNetLin.forward
+ * codes/PerceptualSimilarity/models/networks_basic.py:64-92 on the AlexNet slices of pretrained_networks.py:57-95.  The convs run on
+ * dasr_conv (prec 3); these are the layers around them, all on blocked f32 tensors. */
+/* mode 0: ScalingLayer (networks_basic.py:94-101, with the 2x-1 of models/util.py:36-38 folded into scale4/shift4) + 4x4 space-to-depth of
+ * the 3-channel image (plane 0 of x) zero-padded by 2: y[c][Y][X][4*by+bx] = scale4[c]*x[c][4Y+by-2][4X+bx-2] + shift4[c], 3 planes of
+ * (H+4)/4 x (W+4)/4 -- the 11x11/s4/p2 conv becomes 3x3/s1/p0 on 48 channels.  mode 1: adjoint, ACCUMULATED into channels 0..2 of x. */
+int dasr_lpips_s2d(dasr_tensor x, int32_t N, int32_t H, int32_t W, const float* scale4, const float* shift4, dasr_tensor y, int32_t mode,
+                   void* stream);
+/* nn.MaxPool2d(3, 2) of torchvision alexnet.features[2] / [5] on H x W inputs (output (H-3)/2+1), and its backward: gather form, first
+ * maximum in scan order wins (ATen); relu_mask: zero where x <= 0; accumulate: gx += (the head gradient of that layer is already there) */
+int dasr_maxpool3s2(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, dasr_tensor y, void* stream);
+int dasr_maxpool3s2_bwd(dasr_tensor x, dasr_tensor gy, int32_t N, int32_t C, int32_t H, int32_t W, dasr_tensor gx, int32_t relu_mask,
+                        int32_t accumulate, void* stream);
+/* one LPIPS layer: images n < N of f are compared with images n + pair_off; u = f0/(|f0|_2+eps), v likewise (normalize_tensor),
+ * loss_acc += coef * sum_pixels sum_c lin[c] (u_c-v_c)^2;  g0 (optional) = gcoef * d(sum)/df0, zeroed where f0 <= 0 when relu_mask */
+int dasr_lpips_head(dasr_tensor f, int64_t pair_off, int32_t N, int32_t C, int32_t H, int32_t W, const float* lin, float eps, float coef,
+                    float gcoef, float* loss_acc, dasr_tensor g0, int32_t relu_mask, void* stream);
+
 /* ---- DSN (codes/DSN) kernels ---------------------------------------------------------------------------------*/
 /* -log losses of codes/DSN/loss.py:11-41 on p = sigmoid(logit) (model.py:104-105): mode 0: -log(p+eps), mode 1:
  * -log(1-p+eps); loss_acc += coef*sum, score_acc += score_coef*sum(p), grad (+)= gcoef * d/dlogit */
@@ -281,7 +300,8 @@ enum { DASR_OP_CONV = 1, DASR_OP_WGRAD = 2, DASR_OP_WGRAD_REDUCE = 3, DASR_OP_PA
        DASR_OP_ADD_FLAT = 26, DASR_OP_SIGMOID_FWD = 27,
        /* scheduling ops: p[0] = event from dasr_event_create / a hipStream_t (NULL: back to the stream dasr_run_ops was called with) */
        DASR_OP_EVENT_RECORD = 28, DASR_OP_STREAM_WAIT = 29, DASR_OP_SET_STREAM = 30,
-       DASR_OP_CVT_F16 = 31, DASR_OP_DOWNSUM_F16 = 32, DASR_OP_PIXSHUF = 33, DASR_OP_PIXUNSHUF = 34 };
+       DASR_OP_CVT_F16 = 31, DASR_OP_DOWNSUM_F16 = 32, DASR_OP_PIXSHUF = 33, DASR_OP_PIXUNSHUF = 34,
+       DASR_OP_LPIPS_S2D = 35, DASR_OP_MAXPOOL3 = 36, DASR_OP_MAXPOOL3_BWD = 37, DASR_OP_LPIPS_HEAD = 38 };
 
 typedef struct {
     int32_t op;  int32_t i[8];  float f[4];  int64_t l[4];  void* p[4];  dasr_tensor t[5];
