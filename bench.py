@@ -41,14 +41,14 @@ TFLOP_PER_IMAGE_TRAIN = 1.762  # 3 x 587.43 GFLOP per 128x128 LR
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak at 2.4 GHz (MI355X_MICROARCH.md)
 
 
-def make_dasr_opt(nf, nb, fs):
+def make_dasr_opt(nf, nb, fs, fea='l1'):
     o = make_opt(nf, nb)
     o.update(model='DASR', multiweights=True)
     o['path'].update(pretrain_model_D_target=None, pretrain_model_D_source=None)
     o['network_D'] = {'which_model_D': 'discriminator_patch', 'norm_type': 'Batch', 'act_type': 'leakyrelu', 'mode': 'CNA', 'nf': 64,
                       'in_nc': 9 if fs == 'wavelet' else 3, 'n_layers': 2}
     o['train'].update({'lr_G': 1e-4, 'weight_decay_G': 0, 'beta1_G': 0.9, 'lr_D': 1e-4, 'weight_decay_D': 0, 'beta1_D': 0.9, 'fs': fs,
-                       'fs_kernel_size': 9, 'norm': True, 'sup_LL': True, 'pixel_LL_weight': 1, 'feature_criterion': 'l1',
+                       'fs_kernel_size': 9, 'norm': True, 'sup_LL': True, 'pixel_LL_weight': 1, 'feature_criterion': fea,
                        'feature_weight': 1, 'gan_type': 'vanilla', 'ragan': False, 'gan_H_target': 0.01, 'gan_H_source': 0,
                        'G_update_inter': 1, 'D_update_inter': 1})
     return o
@@ -293,7 +293,7 @@ def bench_dsn(a, dp, as_secondary=False):
     world = dp.world if dp else 1
     rank = dp.rank if dp else 0
     torch.manual_seed(0)
-    m = DSNModel(dict(filter=a.fs, w_per=0.01, per_type='VGG'))
+    m = DSNModel(dict(filter=a.fs, w_per=0.01, per_type=a.per_type))
     if dp:
         m.dp = dp
         for net in m.networks():
@@ -311,9 +311,9 @@ def bench_dsn(a, dp, as_secondary=False):
     out = {'metric': 'DSN train crops/sec (De_resnet + FSD, %dx%d HR crops)' % (c, c), 'value': round(ips, 2), 'unit': 'images/s',
            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2), 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None, 'dtype': m.dtype_note if hasattr(m, 'dtype_note') else 'split-bf16 MFMA operands (~fp32), fp32 accumulate',
-           'data': 'synthetic (torch.rand, seed 1234+rank; default nn init, seed 0; VGG16 seeded random)',
-           'config': {'workload': 'configs[4]: DSN iteration, De_resnet(8 blocks) + FSD discriminator (%s filter) + colour/texture/VGG16 losses, '
-                                  'batch %d of %dx%d crops per GPU' % (a.fs, b, c, c), 'global_batch': b * world, 'parallelism': 'dp%d' % world},
+           'data': 'synthetic (torch.rand, seed 1234+rank; default nn init, seed 0; perceptual net seeded random)',
+           'config': {'workload': 'configs[4]: DSN iteration, De_resnet(8 blocks) + FSD discriminator (%s filter) + colour/texture/%s losses, '
+                                  'batch %d of %dx%d crops per GPU' % (a.fs, 'LPIPS(alex)' if a.per_type == 'LPIPS' else 'VGG16', b, c, c), 'global_batch': b * world, 'parallelism': 'dp%d' % world},
            'generator_tflops': round(ips * tf, 1)}
     if not as_secondary:
         out['log'] = m.get_current_log()
@@ -327,7 +327,7 @@ def bench_srn(a, dp, dasr, as_secondary=False):
     rank = dp.rank if dp else 0
     torch.manual_seed(0)
     batch = (32 if dasr else 16) if as_secondary else a.batch
-    model = create_model(options.dict_to_nonedict(make_dasr_opt(a.nf, a.nb, a.fs) if dasr else make_opt(a.nf, a.nb)))
+    model = create_model(options.dict_to_nonedict(make_dasr_opt(a.nf, a.nb, a.fs, a.fea) if dasr else make_opt(a.nf, a.nb)))
     if dp:
         model.dp = dp
         for net in model.networks():
@@ -364,8 +364,9 @@ def bench_srn(a, dp, dasr, as_secondary=False):
            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2), 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16 MFMA operands, fp32 accumulate / fp32 residual stream',
            'data': 'synthetic (torch.rand, seed 1234+rank; kaiming x0.1 weights, seed 0)',
-           'config': {'workload': ('configs[2]: full SRN GAN step (RRDBNet nf=%d nb=%d + NLayer patch-D + VGG19-54 perceptual, fs=%s), %d G crops of '
-                                   '%dx%d LR per GPU (n=%d source + %d target)' % (a.nf, a.nb, a.fs, batch, s, s, batch // 2, batch // 2))
+           'config': {'workload': ('configs[2]: full SRN GAN step (RRDBNet nf=%d nb=%d + NLayer patch-D + %s perceptual, fs=%s), %d G crops of '
+                                   '%dx%d LR per GPU (n=%d source + %d target)' % (a.nf, a.nb, 'LPIPS(alex)' if a.fea == 'LPIPS' else 'VGG19-54', a.fs, batch,
+                                                                                  s, s, batch // 2, batch // 2))
                       if dasr else
                       'configs[1]: RRDBNet nf=%d nb=%d 4x SR, batch %d of %dx%d LR per GPU, generator-only L1 step '
                       '(fwd+bwd+Adam)' % (a.nf, a.nb, batch, s, s),
@@ -430,6 +431,8 @@ def main():
                     help="sr: configs[1] generator-only step (the headline line); dasr: configs[2] full GAN step (batch = G crops per GPU); "
                          "dsn: configs[4] DSN iteration (De_resnet + FSD discriminator, --batch HR crops of 4*lr-size per GPU)")
     ap.add_argument('--fs', type=str, default='wavelet', choices=['wavelet', 'gau', 'avg_pool'])
+    ap.add_argument('--fea', type=str, default='l1', choices=['l1', 'LPIPS'], help="--model dasr: feature_criterion (l1 = VGG19-54 features, BASELINE configs[2]; LPIPS = the shipped train_DASR.json criterion)")
+    ap.add_argument('--per-type', dest='per_type', type=str, default='VGG', choices=['VGG', 'LPIPS'], help='--model dsn: perceptual term')
     a = ap.parse_args()
     dp = setup_dist(a)
     rank = dp.rank if dp else 0
@@ -449,9 +452,12 @@ def main():
     if default_workload and not a.no_secondary:
         # driver-visible numbers for the other GPU configs of BASELINE.json, measured in the same process (fewer steps)
         sec = argparse.Namespace(**vars(a))
-        sec.steps, sec.warmup = max(2, a.steps // 2), 1
+        sec.steps, sec.warmup = max(2, a.steps // 2), 2
         out['secondary'] = []
-        for fn in (lambda: bench_srn(sec, dp, True, as_secondary=True), lambda: bench_dsn(sec, dp, as_secondary=True)):
+        sec_l = argparse.Namespace(**vars(sec))
+        sec_l.fea, sec_l.per_type = 'LPIPS', 'LPIPS'   # the criteria the reference's shipped configs / CLI defaults select
+        for fn in (lambda: bench_srn(sec, dp, True, as_secondary=True), lambda: bench_dsn(sec, dp, as_secondary=True),
+                   lambda: bench_srn(sec_l, dp, True, as_secondary=True), lambda: bench_dsn(sec_l, dp, as_secondary=True)):
             try:
                 r = fn()
                 out['secondary'].append({k: r[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'dtype', 'config')})

@@ -21,6 +21,7 @@ from . import _lib
 from .engine import BTensor, Op, OpList, NULL_T, Tensor, _stream
 from .gan_nets import NLayerDiscriminatorHIP, VGGFeatureHIP, VGG_MEAN, VGG_STD, nlayer_d_spec
 from .init import kaiming_state_dict
+from .lpips import load_lpips, lpips_metric
 from .models import BaseModel, AdamHIP, MultiStepLR, _define_G
 
 logger = logging.getLogger('base')
@@ -105,16 +106,20 @@ class DASR_Model(BaseModel):
             self.sup_LL = bool(t['sup_LL']) and self.l_pix_w > 0
             self.l_fea_w = t['feature_weight'] or 0
             self.netF = None
+            self.l_fea_type = t['feature_criterion']
             if self.l_fea_w > 0:
-                if t['feature_criterion'] != 'l1':
-                    raise NotImplementedError('Loss type [{:s}] not recognized (LPIPS needs pretrained AlexNet).'.format(str(t['feature_criterion'])))
-                self.netF = VGGFeatureHIP(34, device=self.device)
-                pf = opt['path']['pretrain_model_F']
-                if pf:
-                    self.netF.load_state_dict(torch.load(pf, map_location='cpu'), strict=False)
+                if self.l_fea_type == 'l1':                                  # VGG19-54 feature L1 (DASR_model.py:93-94,105-106)
+                    self.netF = VGGFeatureHIP(34, device=self.device)
+                    pf = opt['path']['pretrain_model_F']
+                    if pf:
+                        self.netF.load_state_dict(torch.load(pf, map_location='cpu'), strict=False)
+                    else:
+                        logger.warning('no path.pretrain_model_F: VGG19-54 uses seeded random weights (torchvision init rule)')
+                        self.netF.load_state_dict(vgg_random_state_dict(self.netF.spec, int(t['vgg_seed'] or 77)))
+                elif self.l_fea_type == 'LPIPS':                             # PerceptualLoss() = LPIPS(alex) (DASR_model.py:97-98)
+                    self.netF = load_lpips(opt, self.device, int(t['vgg_seed'] or 77))
                 else:
-                    logger.warning('no path.pretrain_model_F: VGG19-54 uses seeded random weights (torchvision init rule)')
-                    self.netF.load_state_dict(vgg_random_state_dict(self.netF.spec, int(t['vgg_seed'] or 77)))
+                    raise NotImplementedError('Loss type [{:s}] not recognized.'.format(str(self.l_fea_type)))
             self.G_update_inter = t['G_update_inter'] or 1
             self.D_update_inter = t['D_update_inter'] or 1
             wd_G = t['weight_decay_G'] or 0
@@ -130,6 +135,9 @@ class DASR_Model(BaseModel):
                 self.schedulers.append(MultiStepLR(o.lr, t['lr_steps'], t['lr_gamma']))
             self.log_dict = OrderedDict()
             self.acc = torch.zeros(8, dtype=torch.float32, device=self.device)
+        if opt['val_lpips']:   # validation metric (DASR_model.py:158-159): shares the training criterion's network when that is LPIPS
+            own = getattr(self, 'netF', None) if getattr(self, 'l_fea_type', None) == 'LPIPS' else None
+            self.cri_fea_lpips = own or load_lpips(opt, self.device)
         self._plans = {}
 
     def networks(self):
@@ -216,18 +224,20 @@ class DASR_Model(BaseModel):
 
     def test(self, tsamples=False):
         """inference on var_L (DASR_model.py:333-345; `chop`: quadrant inference, utils/util.py:87-147)"""
-        if not tsamples and self.opt['val_lpips']:
-            raise NotImplementedError('val_lpips needs the pretrained LPIPS package (offline)')
         if self.opt['chop']:
             from .util import forward_chop
             self.fake_H = forward_chop(self.var_L, self.opt['scale'], lambda x: self.netG.forward(x).clone(), min_size=320000)
         else:
             self.fake_H = self.netG.forward(self.var_L).clone()
+        if not tsamples and self.opt['val_lpips']:
+            self.LPIPS = lpips_metric(self.cri_fea_lpips, self.fake_H, self.var_H)   # DASR_model.py:340-344
 
     def get_current_visuals(self, need_HR=True, tsamples=False):
         out = OrderedDict()
         out['LR'] = self.var_L.detach()[0].float().cpu()
         out['SR'] = self.fake_H.detach().float().cpu() if tsamples else self.fake_H.detach()[0].float().cpu()
+        if not tsamples and self.opt['val_lpips']:
+            out['LPIPS'] = self.LPIPS.detach().float().cpu()
         if need_HR and getattr(self, 'var_H', None) is not None:
             out['HR'] = self.var_H.detach()[0].float().cpu()
         return out
@@ -332,7 +342,15 @@ class _StepPlan:
             o.f[0], o.f[1], o.p[0], o.t[2] = 1.0 / cnt, float(m.l_pix_LL_w) / cnt, acc + 4 * A_LL, self.g_low.view()
         # VGG feature loss (source half): batch [fake_s; real_s]
         self.v = None
-        if m.netF is not None:
+        lpips = m.netF is not None and m.l_fea_type == 'LPIPS'
+        if lpips:                                # LPIPS(fake_s, real_s).mean() (DASR_model.py:231-233): loss and head gradients in the forward list
+            self.v = m.netF.plan(N2, n, H, W)
+            fwd.add(self.v.input_op(g.sr.view(), 0, n))
+            fwd.add(self.v.input_op(self.hr_b.view(), n, n))
+            fwd.extend(self.v.fwd)
+            for o in self.v.head_ops(acc + 4 * A_FEA, float(m.l_fea_w)):
+                fwd.add(o)
+        elif m.netF is not None:
             self.v = m.netF.plan(N2, n, H, W)
             v = self.v
             sc = [1.0 / s for s in VGG_STD] + [0.0]
@@ -361,7 +379,10 @@ class _StepPlan:
         self.fwd = fwd
 
         # ---- generator-loss backward: everything that lands in dL/dSR ----------------------------------------------------
-        if self.v is not None:
+        if lpips:
+            gl.extend(self.v.bwd)
+            gl.add(self.v.adjoint_op(g.g_sr.view()))   # accumulated into dL/dSR (source half = first n images)
+        elif self.v is not None:
             v = self.v
             gl.extend(v.bwd)
             o = add(gl, _op(_lib.OP_AFFINE4))  # adjoint of the input normalisation, accumulated into dL/dSR (source half)

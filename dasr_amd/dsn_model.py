@@ -8,8 +8,8 @@ iteration / optimisers     codes/DSN/train.py:204-285, 152-157;  checkpoint .tar
 Update order: both gradients are taken from the same pre-update graph, then D steps, then G steps (the reference's
 `d_loss.backward(retain_graph=True); optimizer_d.step(); g_loss.backward()` only ran under torch 1.1 -- SURVEY 8(c)).
 Perceptual term: per_type 'VGG' = MSE between vgg16.features[:31] of fake and of the bicubic LR (loss.py:119-130), the
-weights coming from `vgg_state` / `vgg_path` or, offline, from a seeded random init; LPIPS (pretrained AlexNet package)
-is not available offline -> NotImplementedError.
+weights coming from `vgg_state` / `vgg_path` or, offline, from a seeded random init; per_type 'LPIPS' (the reference default) =
+LPIPS(alex)(fake, bicubic LR).mean() (loss.py:68-69,84,108-114; dasr_amd/lpips.py), weights from `lpips_alexnet` / `lpips_lin` or seeded.
 nn.PReLU slopes are read from the parameter buffer at run time; their derivative masks use the sign of the layer
 output, which equals the sign of the pre-activation while the slope stays positive (init 0.25).
 Everything runs in split-bf16 (prec 3) on fp32 activations.
@@ -264,15 +264,19 @@ class DSNModel:
         self.bn_eval = o['norm_layer'] == 'Batch'
         self.netF = None
         if o['w_per'] > 0:
-            if o['per_type'] != 'VGG':
-                raise NotImplementedError('perceptual type [%s]: LPIPS needs its pretrained package (offline); use per_type=VGG or w_per=0' % o['per_type'])
-            self.netF = VGGFeatureHIP(30, device=self.device, cfg=VGG16_CFG)
-            if o['vgg_path']:
-                sd = torch.load(o['vgg_path'], map_location='cpu')
-                self.netF.load_state_dict({k: v for k, v in sd.items() if k in self.netF.params.spec})
+            if o['per_type'] == 'LPIPS':      # PerceptualLoss() = LPIPS(alex) on the LR-size images (loss.py:68-69,84,108-114)
+                from .lpips import load_lpips
+                self.netF = load_lpips({'path': {'lpips_alexnet': o.get('lpips_alexnet'), 'lpips_lin': o.get('lpips_lin')}}, self.device, int(o['vgg_seed']))
+            elif o['per_type'] == 'VGG':
+                self.netF = VGGFeatureHIP(30, device=self.device, cfg=VGG16_CFG)
+                if o['vgg_path']:
+                    sd = torch.load(o['vgg_path'], map_location='cpu')
+                    self.netF.load_state_dict({k: v for k, v in sd.items() if k in self.netF.params.spec})
+                else:
+                    logger.warning('no vgg_path: VGG16 perceptual net uses seeded random weights (torchvision init rule)')
+                    self.netF.load_state_dict(vgg_random_state_dict(self.netF.spec, int(o['vgg_seed'])))
             else:
-                logger.warning('no vgg_path: VGG16 perceptual net uses seeded random weights (torchvision init rule)')
-                self.netF.load_state_dict(vgg_random_state_dict(self.netF.spec, int(o['vgg_seed'])))
+                raise NotImplementedError('{} is not recognized'.format(o['per_type']))
         self.filter = o['filter'].lower()
         if self.filter not in ('gau', 'avg_pool', 'wavelet'):
             raise NotImplementedError('Frequency Separation type [{:s}] not recognized'.format(o['filter']))
@@ -477,7 +481,15 @@ class _DSNPlan:
         o.f[0], o.f[1], o.p[0], o.t[2] = 1.0 / ccnt, float(o_['w_col']) / ccnt, acc + 4 * 3, self.g_col.view()
         f.add(o)
         self.v = None
-        if m.netF is not None:   # perceptual: MSE(vgg16(fake), vgg16(bicubic)) -> acc[6], gradient into v.g_feat[:N]
+        lpips = m.netF is not None and o_['per_type'] == 'LPIPS'
+        if lpips:                # perceptual: LPIPS(fake, bicubic).mean() -> acc[6]; head gradients (weight w_per) in the forward list
+            self.v = m.netF.plan(2 * N, N, h, w)
+            f.add(self.v.input_op(g.fake.view(), 0, N))
+            f.add(self.v.input_op(self.bic_b.view(), N, N))
+            f.extend(self.v.fwd)
+            for o in self.v.head_ops(acc + 4 * 6, float(o_['w_per'])):
+                f.add(o)
+        elif m.netF is not None:   # perceptual: MSE(vgg16(fake), vgg16(bicubic)) -> acc[6], gradient into v.g_feat[:N]
             self.v = m.netF.plan(2 * N, N, h, w)
             v = self.v
             for src, n0 in ((g.fake, 0), (self.bic_b, N)):
@@ -516,7 +528,10 @@ class _DSNPlan:
             o = _op(_lib.OP_LOWPASS_VALID)
             o.t[0], o.p[0], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], o.i[5], o.t[1], o.i[6] = self.g_col.view(), m.fw.data_ptr(), k, N, 3, h, w, 1, g.g_fake.view(), 1
             gb.add(o)
-        if self.v is not None:
+        if lpips:
+            gb.extend(self.v.bwd)
+            gb.add(self.v.adjoint_op(g.g_fake.view()))
+        elif self.v is not None:
             gb.extend(self.v.bwd)
             o = _op(_lib.OP_AXPBY)
             o.t[0], o.f[0], o.t[1], o.f[1] = g.g_fake.view(), 1.0, self.v.gx.view(), 1.0

@@ -5,7 +5,8 @@ DSNModel.iteration(hr, bicubic_lr, real_lr); schedulers step once per epoch (tra
 `save_model_interval` epochs the `.tar` checkpoint dict of train.py:357-376 is written to
 <save_path>/checkpoints/iteration_<n>.tar and last_iteration.tar.  Accepted-but-unsupported choices fail the way the
 reference does for unknown strings (NotImplementedError): --generator DSGAN, --discriminator nld_s1/nld_s2, --ragan,
---wgan, --norm_layer Batch, --per_type LPIPS (pretrained AlexNet package, offline).  Data: the PIL/torchvision loaders
+--wgan, --norm_layer Batch, --lpips_rot_flip.  --per_type LPIPS (the reference default) runs LPIPS(alex) with weights from --lpips_alexnet /
+--lpips_lin (seeded and logged when absent: they cannot be downloaded offline).  Data: the PIL/torchvision loaders
 (data_loader.py) stay on the reference's side of the boundary; any iterable of (hr, bicubic_lr, real_lr) tuples works, and
 `--dataset synthetic` ships fixed-seed random crops for benchmarks and tests.
 """
@@ -45,7 +46,7 @@ def build_parser():
     p.add_argument('--kernel_size', default=5, type=int)
     p.add_argument('--no_per_loss', dest='use_per_loss', action='store_false')
     p.add_argument('--lpips_rot_flip', dest='lpips_rot_flip', action='store_true')
-    p.add_argument('--per_type', default='LPIPS', type=str)   # reference default (train.py:54); LPIPS needs the pretrained AlexNet package -> raises, pass VGG
+    p.add_argument('--per_type', default='LPIPS', type=str)   # reference default (train.py:54)
     p.add_argument('--disc_freq', default=1, type=int)
     p.add_argument('--gen_freq', default=1, type=int)
     p.add_argument('--w_col', default=1, type=float)
@@ -63,6 +64,8 @@ def build_parser():
     # additions of this build
     p.add_argument('--iters_per_epoch', default=100, type=int, help='synthetic dataset: iterations per epoch')
     p.add_argument('--vgg_path', default=None, type=str, help='torchvision vgg16 state_dict for --per_type VGG')
+    p.add_argument('--lpips_alexnet', default=None, type=str, help='torchvision alexnet state_dict for --per_type LPIPS')
+    p.add_argument('--lpips_lin', default=None, type=str, help="the reference's codes/PerceptualSimilarity/models/weights/v0.1/alex.pth")
     return p
 
 
@@ -71,6 +74,8 @@ def check_supported(o):
         raise NotImplementedError('Generator model [{:s}] not recognized'.format(o.generator))
     if o.discriminator.lower() != 'fsd':
         raise NotImplementedError('Discriminator architecture [{:s}] not recognized'.format(o.discriminator))
+    if o.lpips_rot_flip:
+        raise NotImplementedError('--lpips_rot_flip (random rotations / flips in front of LPIPS, loss.py:97-110) is not on the MI355X path')
     if o.ragan or o.wgan or not o.highpass or o.cat_or_sum != 'cat' or o.norm_layer != 'Instance':
         raise NotImplementedError('DSN on MI355X covers the default path: DCGAN loss, high-pass front end, wavelet bands cat, Instance norm')
     if o.disc_freq != 1 or o.gen_freq != 1:
@@ -107,7 +112,7 @@ def main(argv=None, loader=None):
         o.num_epochs, o.iters_per_epoch = min(o.num_epochs, 2), min(o.iters_per_epoch, 3)
     opt = dict(n_res_blocks=o.num_res_blocks, kernel_size=o.kernel_size, filter=o.filter, norm_layer=o.norm_layer, discriminator=o.discriminator,
                learning_rate=o.learning_rate, adam_beta_1=o.adam_beta_1, w_col=o.w_col, w_tex=o.w_tex, w_per=o.w_per if o.use_per_loss else 0.0,
-               per_type=o.per_type, vgg_path=o.vgg_path, num_epochs=o.num_epochs, num_decay_epochs=o.num_decay_epochs,
+               per_type=o.per_type, vgg_path=o.vgg_path, lpips_alexnet=o.lpips_alexnet, lpips_lin=o.lpips_lin, num_epochs=o.num_epochs, num_decay_epochs=o.num_decay_epochs,
                upscale_factor=o.upscale_factor)
     model = DSNModel(opt)
     if dp:

@@ -17,6 +17,7 @@ Weights: `load_state_dict` takes torchvision's alexnet keys (`features.{0,3,6,8,
 (`lin{0..4}.model.1.weight`, codes/PerceptualSimilarity/models/weights/v0.1/alex.pth).  Neither can be downloaded here: without files the
 caller seeds them (`lpips_random_state_dict`) and says so in the log."""
 import ctypes as C
+import logging
 import math
 from collections import OrderedDict
 
@@ -70,6 +71,36 @@ def conv1_to_s2d(w):
     wp = torch.zeros((cout, 3, 12, 12), dtype=w.dtype)
     wp[:, :, :11, :11] = w
     return wp.view(cout, 3, 3, 4, 3, 4).permute(0, 1, 3, 5, 2, 4).reshape(cout, 48, 3, 3).contiguous()
+
+
+logger = logging.getLogger('base')
+
+
+def load_lpips(opt, device, seed=77):
+    """LPIPS(alex) with weights from files when given: path.lpips_alexnet = torchvision's alexnet state_dict (features.*), path.lpips_lin =
+    the reference's codes/PerceptualSimilarity/models/weights/v0.1/alex.pth (lin*.model.1.weight).  The reference downloads / reads both
+    itself (pretrained_networks.py:60, dist_model.py:74-80); offline they cannot be fetched, so what is missing is seeded and logged."""
+    net = LPIPSAlexHIP(device=device)
+    sd = lpips_random_state_dict(seed)
+    pf, pl = opt['path']['lpips_alexnet'], opt['path']['lpips_lin']
+    if pf:
+        src = torch.load(pf, map_location='cpu')
+        sd.update({k: v for k, v in src.items() if k.startswith('features.') and k in sd})
+    else:
+        logger.warning('no path.lpips_alexnet: the LPIPS AlexNet backbone uses seeded random weights')
+    if pl:
+        src = torch.load(pl, map_location='cpu')
+        sd.update({k: v for k, v in src.items() if k.startswith('lin') and k in sd})
+    else:
+        logger.warning('no path.lpips_lin: the LPIPS linear heads use seeded random non-negative weights')
+    net.load_state_dict(sd)
+    return net
+
+
+def lpips_metric(net, fake, real):
+    """validation LPIPS of the reference: on the 8-bit images (tensor2img -> im2tensor, DASR_model.py:340-344 / SR_model.py:95-99), first image of the batch"""
+    q = lambda t: (t[:1].detach().float().clamp(0, 1) * 255.0).round() / 255.0
+    return net.distance(q(fake), q(real))
 
 
 class LPIPSAlexHIP:
@@ -126,6 +157,43 @@ class LPIPSAlexHIP:
         if k not in self.plans:
             self.plans[k] = _LPIPSPlan(self, N, n, H, W)
         return self.plans[k]
+
+    def distance(self, a, b):
+        """LPIPS distance of two image batches [n][3][H][W] in [0, 1] (device tensors), mean over the batch: the validation metric
+        (DASR_model.py:340-344 / SR_model.py:95-99: `cri_fea_lpips(im2tensor(fake), im2tensor(real))`, whose im2tensor maps uint8 to
+        [-1, 1]: the caller passes the 8-bit-quantised images / 255).  Plans of the last two image sizes are kept."""
+        n, c, H, W = a.shape
+        if c != 3 or tuple(b.shape) != tuple(a.shape) or H % 4 or W % 4:
+            raise ValueError('LPIPS distance: two [n,3,H,W] batches with H, W multiples of 4, got %s / %s' % (tuple(a.shape), tuple(b.shape)))
+        key = ('val', n, H, W)
+        lru = self.__dict__.setdefault('_val_lru', OrderedDict())
+        if key in lru:
+            lru.move_to_end(key)
+        else:
+            p = _LPIPSPlan(self, 2 * n, n, H, W)
+            img = BTensor(2 * n, 16, H, W, True, self.device)
+            nchw = torch.zeros((2 * n, 3, H, W), dtype=torch.float32, device=self.device)
+            acc = torch.zeros(1, dtype=torch.float32, device=self.device)
+            ops = OpList()
+            o = _op(_lib.OP_FILL)
+            o.p[0], o.l[0], o.f[0] = acc.data_ptr(), 1, 0.0
+            ops.add(o)
+            o = _op(_lib.OP_NCHW2B)
+            o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[0], o.t[1] = nchw.data_ptr(), 2 * n, 3, H, W, img.view(), NULL_T
+            ops.add(o)
+            ops.add(p.input_op(img.view(), 0, 2 * n))
+            ops.extend(p.fwd)
+            for o in p.head_ops(acc.data_ptr(), 0.0):
+                ops.add(o)
+            ops.keep += [p, img, nchw, acc]
+            lru[key] = (ops, nchw, acc)
+            while len(lru) > 2:
+                lru.popitem(last=False)
+        ops, nchw, acc = lru[key]
+        nchw[:n].copy_(a)
+        nchw[n:].copy_(b)
+        ops.run()
+        return acc[0].clone()
 
 
 class _LPIPSPlan:

@@ -351,18 +351,23 @@ class SRModel(BaseModel):
 
     def test(self):
         """inference on var_L (SR_model.py:87-93; `chop`: quadrant inference of DASR_model.py:333-339 / util.py:87-147)"""
-        if self.opt['val_lpips']:
-            raise NotImplementedError('val_lpips needs the pretrained LPIPS package (offline)')
         if self.opt['chop']:
             from .util import forward_chop
             self.fake_H = forward_chop(self.var_L, self.opt['scale'], lambda x: self.netG.forward(x).clone(), min_size=320000)
         else:
             self.fake_H = self.netG.forward(self.var_L).clone()
+        if self.opt['val_lpips']:    # SR_model.py:95-99
+            from .lpips import load_lpips, lpips_metric
+            if getattr(self, 'cri_fea_lpips', None) is None:
+                self.cri_fea_lpips = load_lpips(self.opt, self.device)
+            self.LPIPS = lpips_metric(self.cri_fea_lpips, self.fake_H, self.real_H)
 
     def get_current_visuals(self, need_HR=True):
         out = OrderedDict()
         out['LR'] = self.var_L.detach()[0].float().cpu()
         out['SR'] = self.fake_H.detach()[0].float().cpu()
+        if self.opt['val_lpips']:
+            out['LPIPS'] = self.LPIPS.detach().float().cpu()
         if need_HR:
             out['HR'] = self.real_H.detach()[0].float().cpu()
         return out

@@ -2,9 +2,9 @@
 
 For every dataset of the option file: feed_data -> test() -> get_current_visuals -> SR image saved under
 <results_root>/<dataset name>/imgs, and, when HR is present, PSNR / SSIM on the `scale`-pixel-cropped uint8 images in RGB and on the
-Y channel, per image and averaged (same log lines as the reference).  `chop: true` runs the quadrant inference.  LPIPS
-(`val_lpips`) and `save_RealorFake` need the pretrained LPIPS package / the discriminator visual, not available here:
-NotImplementedError.  Datasets: `mode: "synthetic"` ships seeded LR/HR pairs; any iterable of the reference's batch dicts works
+Y channel, per image and averaged (same log lines as the reference).  `chop: true` runs the quadrant inference.  `val_lpips: true` adds the
+LPIPS(alex) distance of the 8-bit images (test.py:88-128; weights from `path.lpips_alexnet` / `path.lpips_lin`, seeded when absent).
+`save_RealorFake` needs the discriminator visual, not available here: NotImplementedError.  Datasets: `mode: "synthetic"` ships seeded LR/HR pairs; any iterable of the reference's batch dicts works
 through `main(loaders=...)`.
 """
 import argparse
@@ -20,7 +20,7 @@ from .train import create_dataset, setup_logger
 
 
 def evaluate(model, loader, opt, dataset_dir, logger, scale):
-    res = OrderedDict((k, []) for k in ('psnr', 'ssim', 'psnr_y', 'ssim_y'))
+    res = OrderedDict((k, []) for k in ('psnr', 'ssim', 'psnr_y', 'ssim_y', 'lpips'))
     for data in loader:
         need_HR = 'HR' in data
         model.feed_data(data, False)
@@ -40,13 +40,19 @@ def evaluate(model, loader, opt, dataset_dir, logger, scale):
         psnr, ssim = util.calculate_psnr(csr * 255, cgt * 255), util.calculate_ssim(csr * 255, cgt * 255)
         res['psnr'].append(psnr)
         res['ssim'].append(ssim)
+        lpips = float(visuals['LPIPS']) if opt['val_lpips'] else None      # test.py:88-100
+        if lpips is not None:
+            res['lpips'].append(lpips)
         if gt_img.shape[2] == 3:
             sr_y, gt_y = util.bgr2ycbcr(sr_img, only_y=True), util.bgr2ycbcr(gt_img, only_y=True)
             psnr_y = util.calculate_psnr(sr_y[c:-c, c:-c] * 255, gt_y[c:-c, c:-c] * 255)
             ssim_y = util.calculate_ssim(sr_y[c:-c, c:-c] * 255, gt_y[c:-c, c:-c] * 255)
             res['psnr_y'].append(psnr_y)
             res['ssim_y'].append(ssim_y)
-            logger.info('{:20s} - PSNR: {:.6f} dB; SSIM: {:.6f}; PSNR_Y: {:.6f} dB; SSIM_Y: {:.6f};.'.format(img_name, psnr, ssim, psnr_y, ssim_y))
+            if lpips is not None:
+                logger.info('{:20s} - PSNR: {:.6f} dB; SSIM: {:.6f}; PSNR_Y: {:.6f} dB; SSIM_Y: {:.6f}; LPIPS: {:.3f}.'.format(img_name, psnr, ssim, psnr_y, ssim_y, lpips))
+            else:
+                logger.info('{:20s} - PSNR: {:.6f} dB; SSIM: {:.6f}; PSNR_Y: {:.6f} dB; SSIM_Y: {:.6f};.'.format(img_name, psnr, ssim, psnr_y, ssim_y))
         else:
             logger.info('{:20s} - PSNR: {:.6f} dB; SSIM: {:.6f}.'.format(img_name, psnr, ssim))
     return res
@@ -60,8 +66,8 @@ def main(argv=None, loaders=None):
         if key != 'pretrain_model_G' and path:
             util.mkdir(path)
     opt = option.dict_to_nonedict(opt)
-    if opt['val_lpips'] or opt['save_RealorFake']:
-        raise NotImplementedError('val_lpips / save_RealorFake are not available on the MI355X path')
+    if opt['save_RealorFake']:
+        raise NotImplementedError('save_RealorFake (discriminator visual) is not available on the MI355X path')
     setup_logger('base', opt['path']['log'], 'test', screen=True)
     logger = logging.getLogger('base')
     logger.info(option.dict2str(opt))
@@ -80,8 +86,13 @@ def main(argv=None, loaders=None):
         res = evaluate(model, loader, opt, dataset_dir, logger, opt['scale'])
         if res['psnr']:
             ave_psnr, ave_ssim = sum(res['psnr']) / len(res['psnr']), sum(res['ssim']) / len(res['ssim'])
-            logger.info('----Average PSNR/SSIM/LPIPS results for {}----\n\tPSNR: {:.6f} dB; SSIM: {:.6f}\n'.format(name, ave_psnr, ave_ssim))
             summary[name] = {'psnr': ave_psnr, 'ssim': ave_ssim}
+            if res['lpips']:
+                summary[name]['lpips'] = sum(res['lpips']) / len(res['lpips'])
+                logger.info('----Average PSNR/SSIM/LPIPS results for {}----\n\tPSNR: {:.6f} dB; SSIM: {:.6f}; LPIPS: {:.3f}\n'.format(
+                    name, ave_psnr, ave_ssim, summary[name]['lpips']))
+            else:
+                logger.info('----Average PSNR/SSIM/LPIPS results for {}----\n\tPSNR: {:.6f} dB; SSIM: {:.6f}\n'.format(name, ave_psnr, ave_ssim))
             if res['psnr_y']:
                 ay, asy = sum(res['psnr_y']) / len(res['psnr_y']), sum(res['ssim_y']) / len(res['ssim_y'])
                 logger.info('----Y channel, average PSNR/SSIM----\n\tPSNR_Y: {:.6f} dB; SSIM_Y: {:.6f}\n'.format(ay, asy))

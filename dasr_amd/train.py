@@ -92,7 +92,7 @@ def create_dataset(ds_opt, opt):
 def validate(model, val_set, opt, current_step, logger):
     """validation pass of codes/SRN/train.py:174-235: test() per image, SR image saved, PSNR on the `scale`-pixel-cropped uint8 images"""
     from . import util
-    avg_psnr, idx = 0.0, 0
+    avg_psnr, avg_lpips, idx = 0.0, 0.0, 0
     for val_data in val_set:
         idx += 1
         img_name = os.path.splitext(os.path.basename(val_data['LR_path'][0]))[0]
@@ -102,7 +102,11 @@ def validate(model, val_set, opt, current_step, logger):
         model.test()
         visuals = model.get_current_visuals()
         sr_img = util.tensor2img(visuals['SR'])
-        logger.info('{}'.format(val_data['HR_path'][0].split('/')[-1]))
+        log_info = '{}'.format(val_data['HR_path'][0].split('/')[-1])
+        if opt['val_lpips']:      # train.py:194-197
+            avg_lpips += float(visuals['LPIPS'])
+            log_info += '         LPIPS:{:.3f}'.format(float(visuals['LPIPS']))
+        logger.info(log_info)
         util.save_img(sr_img, os.path.join(img_dir, '{:s}_{:d}.png'.format(img_name, current_step)))
         if 'HR' in visuals:
             gt_img = util.tensor2img(visuals['HR'])
@@ -110,6 +114,8 @@ def validate(model, val_set, opt, current_step, logger):
             avg_psnr += util.calculate_psnr((sr_img / 255.)[c:-c, c:-c, :] * 255, (gt_img / 255.)[c:-c, c:-c, :] * 255)
     avg_psnr = avg_psnr / max(idx, 1)
     logger.info('# Validation # PSNR: {:.4e}'.format(avg_psnr))
+    if opt['val_lpips']:
+        return avg_psnr, avg_lpips / max(idx, 1)
     return avg_psnr
 
 
@@ -194,8 +200,11 @@ def main(argv=None):
                     msg += '{:s}: {:.4e} '.format(k, v)
                 logger.info(msg)
             if val_set is not None and opt['train']['val_freq'] and current_step % opt['train']['val_freq'] == 0 and rank == 0:
-                avg_psnr = validate(model, val_set, opt, current_step, logger)
-                logging.getLogger('val').info('<epoch:{:3d}, iter:{:8,d}> psnr: {:.4e}'.format(epoch, current_step, avg_psnr))
+                res = validate(model, val_set, opt, current_step, logger)
+                if opt['val_lpips']:   # train.py:226-228
+                    logging.getLogger('val').info('<epoch:{:3d}, iter:{:8,d}> psnr: {:.4e}, LPIPS: {:.4f}'.format(epoch, current_step, res[0], res[1]))
+                else:
+                    logging.getLogger('val').info('<epoch:{:3d}, iter:{:8,d}> psnr: {:.4e}'.format(epoch, current_step, res))
             if current_step % opt['logger']['save_checkpoint_freq'] == 0 and rank == 0:
                 logger.info('Saving models and training states.')
                 model.save(current_step)

@@ -144,7 +144,7 @@ class DSNTrainer:
     """one training iteration of codes/DSN/train.py:204-285 (non-ragan, non-wgan, DeResnet)"""
 
     def __init__(self, netG=None, netD=None, lr=1e-4, beta1=0.5, w_col=1.0, w_tex=0.005, w_per=0.01, per_type='VGG',
-                 kernel_size=5, filter_type='gau', norm_layer='Instance', vgg_seed=78, num_epochs=400, num_decay_epochs=150):
+                 kernel_size=5, filter_type='gau', norm_layer='Instance', vgg_seed=78, num_epochs=400, num_decay_epochs=150, netF=None):
         self.G = netG if netG is not None else DeResnet()
         self.D = netD if netD is not None else Discriminator(kernel_size, norm_layer, filter_type)
         self.w_col, self.w_tex, self.w_per = w_col, w_tex, w_per
@@ -155,7 +155,11 @@ class DSNTrainer:
             dwt = nets.HaarDWT()
             self.color_filter = lambda x: dwt(x)[0] * 0.5
         self.per = None
-        if w_per > 0:
+        self.lpips = None
+        if w_per > 0 and per_type == 'LPIPS':   # loss.py:68-69: PerceptualLoss() -> LPIPS(alex)(x, y, normalize=True).mean()
+            from . import lpips as _lp
+            self.lpips = netF if netF is not None else _lp.PerceptualLossLPIPS(_lp.LPIPSAlex(seed=vgg_seed))
+        elif w_per > 0:
             assert per_type == 'VGG'
             self.per = vgg16_features31(vgg_seed)
         self.opt_g = torch.optim.Adam(self.G.parameters(), lr=lr, betas=(beta1, 0.999))
@@ -174,6 +178,9 @@ class DSNTrainer:
         col = F.l1_loss(self.color_filter(fake), self.color_filter(bicubic_lr))
         g_loss = self.w_col * col + self.w_tex * tex
         per = torch.zeros(())
+        if self.lpips is not None:
+            per = self.lpips(fake, bicubic_lr)
+            g_loss = g_loss + self.w_per * per
         if self.per is not None:
             per = F.mse_loss(self.per(fake), self.per(bicubic_lr))
             g_loss = g_loss + self.w_per * per

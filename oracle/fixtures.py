@@ -22,6 +22,9 @@ CASES = OrderedDict([
     # PixelShuffle upsampler (architecture.py:186-191, block.py:838-851; the reference's define_G never selects it: the generator of
     # the fixture is the reference's RRDBNet(upsample_mode='pixelshuffle') put behind its SRModel)
     ('sr_ps_nf64_nb1_b2_32', dict(kind='sr', nf=64, nb=1, n=2, lr=32, upsample_mode='pixelshuffle')),
+    # feature_criterion LPIPS (what the shipped train_DASR*.json use): the reference's PerceptualLossLPIPS with its real linear heads on a
+    # seeded stand-in AlexNet (oracle/ref_import.py), behind its DASR_Model
+    ('dasr_lpips_wavelet_nf32_nb2_n2_32', dict(kind='dasr', nf=32, nb=2, n=2, lr=32, fs='wavelet', d_in_nc=9, fea='LPIPS')),
 ])
 
 
@@ -58,7 +61,7 @@ def make_opt(case):
         opt['network_D'] = {'which_model_D': 'discriminator_patch', 'norm_type': 'Batch', 'act_type': 'leakyrelu',
                             'mode': 'CNA', 'nf': 64, 'in_nc': c['d_in_nc'], 'n_layers': 2}
         opt['train'].update({'lr_D': 1e-4, 'weight_decay_D': 0, 'beta1_D': 0.9, 'fs': c['fs'], 'fs_kernel_size': 9,
-                             'norm': True, 'sup_LL': True, 'pixel_LL_weight': 1, 'feature_criterion': 'l1',
+                             'norm': True, 'sup_LL': True, 'pixel_LL_weight': 1, 'feature_criterion': c.get('fea', 'l1'),
                              'feature_weight': 1, 'gan_type': 'vanilla', 'ragan': False, 'gan_H_target': 0.01,
                              'gan_H_source': 0, 'G_update_inter': 1, 'D_update_inter': 1})
     return opt

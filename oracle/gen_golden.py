@@ -99,7 +99,11 @@ def run_oracle(case):
         return collect(case, netG, None, t.update_learning_rate, t.feed_data, t.optimize_parameters, lambda: t.log)
     netD = nets.NLayerDiscriminator(c['d_in_nc'], n_layers=2)
     netD.load_state_dict(fixtures.seeded_state_dict(netD.state_dict(), 2, 1.0))
-    t = trainers.DASRTrainer(opt, netG=netG, netD=netD, vgg_seed=77)
+    netF = None
+    if c.get('fea') == 'LPIPS':
+        from . import lpips
+        netF = lpips.golden_criterion(77)[0]
+    t = trainers.DASRTrainer(opt, netG=netG, netD=netD, netF=netF, vgg_seed=77)
     return collect(case, netG, netD, t.update_learning_rate, t.feed_data, t.optimize_parameters, lambda: t.log)
 
 

@@ -20,6 +20,9 @@ DSN_CASES = {
     'dsn_gau5_inst_b2_128': dict(filter='gau', k=5, norm='Instance', n=2, crop=128),
     'dsn_wavelet_inst_b2_128': dict(filter='wavelet', k=5, norm='Instance', n=2, crop=128),
     'dsn_avg5_inst_b1_160': dict(filter='avg_pool', k=5, norm='Instance', n=1, crop=160),
+    # --per_type LPIPS (the reference default): its GeneratorLoss builds PerceptualLoss() = LPIPS(alex) with the real linear heads on the
+    # stand-in AlexNet(seed 78); 64 x 64 LR images
+    'dsn_gau5_inst_b1_256_lpips': dict(filter='gau', k=5, norm='Instance', n=1, crop=256, per='LPIPS'),
 }
 
 
@@ -44,7 +47,7 @@ def collect(G, D, color_filter, per_net, c, w=(1.0, 0.005, 0.01)):
     d_loss = -torch.log(rt + 1e-8).mean() - torch.log(1 - ft + 1e-8).mean()
     tex = torch.mean(-torch.log(ft + 1e-8))
     col = torch.nn.functional.l1_loss(color_filter(fake), color_filter(bic))
-    per = torch.nn.functional.mse_loss(per_net(fake), per_net(bic))
+    per = per_net(fake, bic) if c.get('per') == 'LPIPS' else torch.nn.functional.mse_loss(per_net(fake), per_net(bic))
     g_loss = w[0] * col + w[1] * tex + w[2] * per
     dp = [p for p in D.parameters() if p.requires_grad]
     gd = torch.autograd.grad(d_loss, dp, retain_graph=True)
@@ -74,7 +77,12 @@ def main():
         def __init__(self):
             super().__init__()
             self.features = dsn.vgg16_features31(78)
-    tv.models = _mod('torchvision.models')
+    class _Alex(nn.Module):
+        def __init__(self):
+            super().__init__()
+            from . import lpips
+            self.features = lpips.alexnet_init_(lpips.alexnet_features(), 78)
+    tv.models = _mod('torchvision.models', alexnet=lambda pretrained=False: _Alex())
     _mod('torchvision.models.vgg', vgg16=lambda pretrained=False: types.SimpleNamespace(features=list(dsn.vgg16_features31(78)) + [nn.Identity()] * 0),
          vgg19=lambda pretrained=False: None)
     sk = _mod('skimage'); _mod('skimage.measure', compare_ssim=None); _mod('skimage.color'); _mod('skimage.transform')
@@ -84,7 +92,10 @@ def main():
     import model as rmodel
     import loss as rloss
     os.makedirs(OUT, exist_ok=True)
+    only = [a for a in sys.argv[1:] if a in DSN_CASES]
     for name, c in DSN_CASES.items():
+        if only and name not in only:
+            continue
         torch.manual_seed(0)
         G = rmodel.De_resnet(n_res_blocks=8, scale=4)
         D = rmodel.Discriminator(kernel_size=c['k'], D_arch='FSD', norm_layer=c['norm'], filter_type=c['filter'], cs='cat')
@@ -93,16 +104,18 @@ def main():
         _cuda = nn.Module.cuda
         nn.Module.cuda = lambda self, *a, **k: self   # loss.py:63-64 moves the colour filter to the GPU unconditionally
         try:
-            gl = rloss.GeneratorLoss(kernel_size=c['k'], per_type='VGG', filter=c['filter'], w_col=1, w_tex=0.005, w_per=0.01)
+            gl = rloss.GeneratorLoss(kernel_size=c['k'], per_type=c.get('per', 'VGG'), filter=c['filter'], w_col=1, w_tex=0.005, w_per=0.01)
         finally:
             nn.Module.cuda = _cuda
         if c['filter'] == 'wavelet':
             cf = lambda x: nets.HaarDWT()(x)[0] * 0.5   # reference filter_wavelet_LL calls .cuda(); same arithmetic
         else:
             cf = gl.color_filter
-        fx = collect(G, D, cf, gl.perceptual_loss.loss_network, c)
+        fx = collect(G, D, cf, gl.perceptual_loss if c.get('per') == 'LPIPS' else gl.perceptual_loss.loss_network, c)
         np.savez_compressed(os.path.join(OUT, name + '.npz'), **fx)
         print(name, fx['losses'])
+    if only:
+        return
     # real-weights known-answer test: the only weights file the reference ships, codes/DSN/test.tar = state_dict of
     # Discriminator(D_arch='FSD', norm_layer='Batch', filter_type='gau', kernel_size=5) (model.py:60-118,173-189).  The fixture carries the
     # weights (a data file of the reference) and the eval-mode output of the reference module on a seeded input.

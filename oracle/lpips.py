@@ -93,3 +93,21 @@ class PerceptualLossLPIPS(nn.Module):
 
     def forward(self, x, y):
         return self.net(2 * y - 1, 2 * x - 1).mean()
+
+
+def golden_lin(golden_dir=None):
+    """the reference's linear heads (weights/v0.1/alex.pth), held as data in tests/golden/lpips_alex.npz"""
+    import os
+    import numpy as np
+    golden_dir = golden_dir or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+    g = np.load(os.path.join(golden_dir, 'lpips_alex.npz'))
+    return [torch.from_numpy(g['lin%d' % i]) for i in range(5)]
+
+
+def golden_criterion(seed, golden_dir=None):
+    """what the reference builds for `feature_criterion: LPIPS` under oracle.ref_import's stand-in AlexNet(seed): (criterion, state_dict in
+    the key layout the product loads: torchvision alexnet `features.*` + `lin*.model.1.weight`)"""
+    feats, lin = alexnet_init_(alexnet_features(), seed), golden_lin(golden_dir)
+    sd = {'features.' + k: v.clone() for k, v in feats.state_dict().items()}
+    sd.update({'lin%d.model.1.weight' % i: w.reshape(1, -1, 1, 1).clone() for i, w in enumerate(lin)})
+    return PerceptualLossLPIPS(LPIPSAlex(feats, lin)), sd

@@ -10,6 +10,8 @@ Third-party packages the reference imports but this image lacks are replaced by
   cv2, skimage, IPython           -> empty modules (never called on the hot path)
   torchvision.models.vgg19        -> cfg-'E' VGG19 built by oracle.nets (random init;
                                      pretrained weights need a download)
+  torchvision.models.alexnet      -> the AlexNet feature stack restated in oracle.lpips (seeded;
+                                     LPIPS backbone, same reason)
   torchvision.utils.make_grid     -> unused placeholder
   pytorch_wavelets.DWTForward     -> oracle.nets.HaarDWT wrapped in the (LL, [Hc5d]) API
                                      (PARITY UNPINNED: sub-band order/sign convention)
@@ -44,6 +46,12 @@ def install_stubs(vgg_seed=77):
             self.features = nets.vgg19_features()
             nets.vgg_init_(self.features, vgg_seed)
 
+    class _Alex(nn.Module):   # LPIPS backbone (pretrained_networks.py:60): architecture restated in oracle.lpips, seeded weights
+        def __init__(self):
+            super().__init__()
+            from . import lpips
+            self.features = lpips.alexnet_init_(lpips.alexnet_features(), vgg_seed)
+
     class DWTForward(nn.Module):
         def __init__(self, J=1, mode='reflect', wave='haar'):
             super().__init__()
@@ -64,7 +72,7 @@ def install_stubs(vgg_seed=77):
     tv = _mod('torchvision')
     tv.utils = _mod('torchvision.utils', make_grid=lambda *a, **k: None)
     tv.models = _mod('torchvision.models', vgg19=lambda pretrained=False: _VGG(),
-                     vgg19_bn=lambda pretrained=False: None)
+                     vgg19_bn=lambda pretrained=False: None, alexnet=lambda pretrained=False: _Alex())
     tv.transforms = _mod('torchvision.transforms')
     _mod('pytorch_wavelets', DWTForward=DWTForward, DWTInverse=DWTInverse)
     sk = _mod('skimage')

@@ -78,7 +78,11 @@ class DASRTrainer:
         self.cri_pix = (F.l1_loss if t['pixel_criterion'] == 'l1' else F.mse_loss) if self.l_pix_w > 0 else None
         self.l_fea_w = _opt(t, 'feature_weight', 0)
         self.cri_fea = None
-        if self.l_fea_w > 0:
+        self.lpips = None
+        if self.l_fea_w > 0 and t['feature_criterion'] == 'LPIPS':      # DASR_model.py:97-98,231-233: PerceptualLoss() on the images
+            from . import lpips as _lp
+            self.lpips = netF if netF is not None else _lp.PerceptualLossLPIPS(_lp.LPIPSAlex(seed=vgg_seed))
+        elif self.l_fea_w > 0:
             self.cri_fea = F.l1_loss if t['feature_criterion'] == 'l1' else F.mse_loss
             self.netF = netF if netF is not None else nets.VGGFeatureExtractor(34, seed=vgg_seed)
             self.netF.eval()
@@ -141,6 +145,10 @@ class DASRTrainer:
                     l_ll = self.cri_pix(fake_LL[:n], real_LL[:n])
                     tot = tot + self.l_pix_LL_w * l_ll
                     self.log['loss/l_g_LL_pix'] = l_ll.item()
+            if self.lpips is not None:
+                l_fea = self.lpips(fake_src, real_src)
+                tot = tot + self.l_fea_w * l_fea
+                self.log['loss/l_g_fea'] = l_fea.item()
             if self.cri_fea is not None:
                 real_fea = self.netF(real_src).detach()
                 fake_fea = self.netF(fake_src)

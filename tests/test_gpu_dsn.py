@@ -208,7 +208,7 @@ def test_deresnet_forward_backward():
     print('De_resnet worst grad rel err %.2e' % worst)
 
 
-@pytest.mark.parametrize('case', ['dsn_gau5_inst_b2_128', 'dsn_wavelet_inst_b2_128', 'dsn_avg5_inst_b1_160'])
+@pytest.mark.parametrize('case', ['dsn_gau5_inst_b2_128', 'dsn_wavelet_inst_b2_128', 'dsn_avg5_inst_b1_160', 'dsn_gau5_inst_b1_256_lpips'])
 def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir):
     dev = _gpu()
     torch.set_num_threads(8)
@@ -221,12 +221,16 @@ def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir):
     sdG, sdD = dsn_state(G.state_dict(), 21, 0.5), dsn_state(D.state_dict(), 22, 1.0)
     G.load_state_dict(sdG)
     D.load_state_dict(sdD)
-    t = dsn.DSNTrainer(G, D, kernel_size=c['k'], filter_type=c['filter'], norm_layer=c['norm'], vgg_seed=78, w_per=0.01)
-    m = DSNModel(dict(filter=c['filter'], kernel_size=c['k'], norm_layer=c['norm'], w_per=0.01, vgg_seed=78), device=dev)
+    crit, sdF = None, None
+    if c.get('per') == 'LPIPS':     # --per_type LPIPS (reference default): real linear heads + the fixture's stand-in AlexNet
+        from oracle import lpips
+        crit, sdF = lpips.golden_criterion(78, golden_dir)
+    t = dsn.DSNTrainer(G, D, kernel_size=c['k'], filter_type=c['filter'], norm_layer=c['norm'], vgg_seed=78, w_per=0.01, per_type=c.get('per', 'VGG'), netF=crit)
+    m = DSNModel(dict(filter=c['filter'], kernel_size=c['k'], norm_layer=c['norm'], w_per=0.01, vgg_seed=78, per_type=c.get('per', 'VGG')), device=dev)
     assert list(m.netG.params.spec) == list(gold['G_keys']) and list(m.netD.params.spec) == list(gold['D_keys'])
     m.netG.load_state_dict(sdG)
     m.netD.load_state_dict(sdD)
-    m.netF.load_state_dict({'features.' + k: v for k, v in t.per.state_dict().items()})
+    m.netF.load_state_dict(sdF if sdF is not None else {'features.' + k: v for k, v in t.per.state_dict().items()})
     hr, bic, real = dsn_batch(c)
     from oracle import fixtures
     for step in (1, 2):

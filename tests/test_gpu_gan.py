@@ -206,7 +206,7 @@ def test_vgg_forward_and_input_gradient(prec, act_tol, grad_tol, margins):
     assert e_f < act_tol and e_g < grad_tol
 
 
-@pytest.mark.parametrize('case', ['dasr_wavelet_nf32_nb2_n2_32', 'dasr_gau9_nf64_nb1_n1_32'])
+@pytest.mark.parametrize('case', ['dasr_wavelet_nf32_nb2_n2_32', 'dasr_gau9_nf64_nb1_n1_32', 'dasr_lpips_wavelet_nf32_nb2_n2_32'])
 def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir):
     dev = _gpu()
     torch.set_num_threads(8)
@@ -221,7 +221,11 @@ def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir):
     netD = nets.NLayerDiscriminator(c['d_in_nc'], n_layers=2)
     sdD = fixtures.seeded_state_dict(netD.state_dict(), 2, 1.0)
     netD.load_state_dict(sdD)
-    t = trainers.DASRTrainer(opt, netG=netG, netD=netD, vgg_seed=77)
+    crit, sdF = None, None
+    if c.get('fea') == 'LPIPS':     # feature_criterion LPIPS: the reference's linear heads + the seeded stand-in AlexNet of the fixture
+        from oracle import lpips
+        crit, sdF = lpips.golden_criterion(77, golden_dir)
+    t = trainers.DASRTrainer(opt, netG=netG, netD=netD, netF=crit, vgg_seed=77)
     batch = fixtures.make_batch(case)
     opt2 = fixtures.make_opt(case)
     opt2['gpu_ids'] = [0]
@@ -229,7 +233,7 @@ def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir):
     m = create_model(options.dict_to_nonedict(opt2))
     m.netG.load_state_dict(sdG)
     m.netD_target.load_state_dict(sdD)
-    m.netF.load_state_dict({k: v for k, v in t.netF.state_dict().items() if k.startswith('features')})
+    m.netF.load_state_dict(sdF if sdF is not None else {k: v for k, v in t.netF.state_dict().items() if k.startswith('features')})
     gold = np.load(os.path.join(golden_dir, case + '.npz'))
     keys = list(gold['log_keys'])
     for step in (1, 2):

@@ -187,3 +187,27 @@ def test_lpips_at_training_size_is_zero_for_identical_pairs_and_deterministic(go
     l2, g2, _ = _run(net, x, y, dev, 0.5)
     assert l1 > 0 and torch.isfinite(g1).all() and float(g1.abs().max()) > 0
     assert torch.equal(g1, g2) and abs(l1 - l2) <= 1e-6 * l1     # the loss sum uses atomics; the gradient is order-free
+
+
+def test_val_lpips_metric_in_sr_model_matches_oracle(golden_dir):
+    """`val_lpips: true` (SR_model.py:95-99): LPIPS of the 8-bit SR and HR images after test(), reported through get_current_visuals()"""
+    dev = _gpu()
+    from oracle import fixtures, lpips
+    from dasr_amd import options
+    from dasr_amd.models import create_model
+    opt = fixtures.make_opt(dict(kind='sr', nf=32, nb=1, n=1, lr=16))
+    opt['gpu_ids'], opt['val_lpips'], opt['is_train'] = [0], True, False
+    m = create_model(options.dict_to_nonedict(opt))
+    m.netG.load_state_dict(fixtures.seeded_state_dict(m.netG.state_dict(), 1, 0.1))
+    crit, sd = lpips.golden_criterion(77, golden_dir)
+    from dasr_amd.lpips import LPIPSAlexHIP
+    m.cri_fea_lpips = LPIPSAlexHIP(device=dev)
+    m.cri_fea_lpips.load_state_dict(sd)
+    g = torch.Generator().manual_seed(8)
+    data = {'LR': torch.rand(1, 3, 16, 20, generator=g), 'HR': torch.rand(1, 3, 64, 80, generator=g)}
+    m.feed_data(data)
+    m.test()
+    vis = m.get_current_visuals()
+    q = lambda t: (t.float().clamp(0, 1) * 255.0).round() / 255.0
+    want = float(crit(q(vis['SR'][None]), q(data['HR'])))
+    assert abs(float(vis['LPIPS']) - want) < 1e-3 * want, (float(vis['LPIPS']), want)

@@ -21,8 +21,12 @@ def test_dsn_oracle_matches_reference_fixture(case, golden_dir):
     assert list(D.state_dict().keys()) == list(ref['D_keys'])
     G.load_state_dict(dsn_state(G.state_dict(), 21, 0.5))
     D.load_state_dict(dsn_state(D.state_dict(), 22, 1.0))
-    t = dsn.DSNTrainer(G, D, kernel_size=c['k'], filter_type=c['filter'], norm_layer=c['norm'], vgg_seed=78)
-    got = collect(G, D, t.color_filter, t.per, c)
+    crit = None
+    if c.get('per') == 'LPIPS':
+        from oracle import lpips
+        crit = lpips.golden_criterion(78, golden_dir)[0]
+    t = dsn.DSNTrainer(G, D, kernel_size=c['k'], filter_type=c['filter'], norm_layer=c['norm'], vgg_seed=78, per_type=c.get('per', 'VGG'), netF=crit)
+    got = collect(G, D, t.color_filter, t.lpips if crit is not None else t.per, c)
     for k in ('fake_sub', 'real_tex_sub', 'fake_tex_sub', 'losses'):
         np.testing.assert_allclose(got[k], ref[k], rtol=2e-5, atol=1e-7, err_msg=k)
     np.testing.assert_allclose(got['gradG_norm'], ref['gradG_norm'], rtol=1e-3, atol=1e-10)
