@@ -27,6 +27,8 @@ from .models import BaseModel, AdamHIP, MultiStepLR, _define_G
 logger = logging.getLogger('base')
 
 A_PIX, A_LL, A_FEA, A_GAN, A_DREAL, A_DFAKE, A_SREAL, A_SFAKE = range(8)
+A_GAN_SRC, A_DREAL_SRC, A_DFAKE_SRC, A_SREAL_SRC, A_SFAKE_SRC = range(8, 13)   # source-domain discriminator (gan_H_source > 0)
+N_ACC = 16
 
 
 def _op(kind):
@@ -76,8 +78,7 @@ class DASR_Model(BaseModel):
         if t['ragan']:
             raise NotImplementedError('ragan=True couples samples across the batch; not on the data-parallel hot path')
         self.l_gan_H_target_w = t['gan_H_target'] or 0
-        if (t['gan_H_source'] or 0) > 0:
-            raise NotImplementedError('gan_H_source > 0 (BatchNorm source discriminator) is a "next" row (SURVEY 8(f4))')
+        self.l_gan_H_source_w = (t['gan_H_source'] or 0) if self.is_train else 0
         self.netG = _define_G(opt, self.device)
         self.netD_target = None
         if self.is_train and self.l_gan_H_target_w > 0:
@@ -87,6 +88,15 @@ class DASR_Model(BaseModel):
             self.netD_target = NLayerDiscriminatorHIP(d['in_nc'], 64, d['n_layers'], device=self.device)  # networks.py:184-185
             spec, _ = nlayer_d_spec(d['in_nc'], 64, d['n_layers'])
             self.netD_target.load_state_dict(kaiming_state_dict(spec, 1))  # init_weights(kaiming, scale=1), networks.py:191
+        self.netD_source = None
+        if self.is_train and self.l_gan_H_source_w > 0:   # DASR_model.py:45-47 -> define_pairD (networks.py:196-227)
+            d = opt['network_D']
+            if d['which_model_pairD'] != 'discriminator_patch':
+                # discriminator_vgg_128 (BatchNorm in training mode: batch statistics across the data-parallel ranks) is not on this path
+                raise NotImplementedError('Discriminator model [{:s}] not recognized'.format(str(d['which_model_pairD'])))
+            self.netD_source = NLayerDiscriminatorHIP(d['in_nc'], d['nf'], d['n_layers'], device=self.device)  # networks.py:217-218: nf IS passed here
+            spec, _ = nlayer_d_spec(d['in_nc'], d['nf'], d['n_layers'])
+            self.netD_source.load_state_dict(kaiming_state_dict(spec, 1))
         self.load()
         self.norm = bool(t['norm'])
         self.fs = t['fs']
@@ -129,19 +139,25 @@ class DASR_Model(BaseModel):
                 wd_D = t['weight_decay_D'] or 0
                 self.optimizer_D_target = AdamHIP(self.netD_target.params, t['lr_D'], (t['beta1_D'], 0.999), wd_D)
                 self.optimizers.append(self.optimizer_D_target)
+            if self.netD_source is not None:   # DASR_model.py:139-143
+                self.optimizer_D_source = AdamHIP(self.netD_source.params, t['lr_D'], (t['beta1_D'], 0.999), t['weight_decay_D'] or 0)
+                self.optimizers.append(self.optimizer_D_source)
             if t['lr_scheme'] != 'MultiStepLR':
                 raise NotImplementedError('MultiStepLR learning rate scheme is enough.')
             for o in self.optimizers:
                 self.schedulers.append(MultiStepLR(o.lr, t['lr_steps'], t['lr_gamma']))
             self.log_dict = OrderedDict()
-            self.acc = torch.zeros(8, dtype=torch.float32, device=self.device)
+            self.acc = torch.zeros(N_ACC, dtype=torch.float32, device=self.device)
         if opt['val_lpips']:   # validation metric (DASR_model.py:158-159): shares the training criterion's network when that is LPIPS
             own = getattr(self, 'netF', None) if getattr(self, 'l_fea_type', None) == 'LPIPS' else None
             self.cri_fea_lpips = own or load_lpips(opt, self.device)
         self._plans = {}
 
     def networks(self):
-        return [self.netG] + ([self.netD_target] if self.netD_target is not None else [])
+        return [self.netG] + [d for d in (self.netD_target, self.netD_source) if d is not None]
+
+    def _lr_of(self, optimizer):
+        return self.schedulers[self.optimizers.index(optimizer)].get_lr()
 
     # ---- data (DASR_model.py:161-187) --------------------------------------------------------------------------
     def feed_data(self, data, istrain=True):
@@ -169,6 +185,7 @@ class DASR_Model(BaseModel):
         P = self._plan(n, h, w)
         do_g = step % self.G_update_inter == 0
         do_d = step % self.D_update_inter == 0 and self.netD_target is not None
+        do_ds = step % self.D_update_inter == 0 and self.netD_source is not None
         P.hr_nchw.copy_(self.var_H)
         P.fake_w.copy_(self.fake_w)
         P.g.set_input(self.var_L)
@@ -195,16 +212,22 @@ class DASR_Model(BaseModel):
             P.d_step.run()                # BCE(real,1), BCE(fake,0), D backward with weight gradients
             if dp_on:
                 self.dp.allreduce_mean(self.netD_target.params.grad)
-            self.optimizer_D_target.step(self.schedulers[1].get_lr())
+            self.optimizer_D_target.step(self._lr_of(self.optimizer_D_target))
             self.netD_target.repack()
+        if do_ds:                         # source domain (DASR_model.py:287-303)
+            P.ds_step.run()
+            if dp_on:
+                self.dp.allreduce_mean(self.netD_source.params.grad)
+            self.optimizer_D_source.step(self._lr_of(self.optimizer_D_source))
+            self.netD_source.repack()
         self.fake_H = P.g.read_output()
-        self._acc_snapshot = (self.acc, do_g, do_d)
+        self._acc_snapshot = (self.acc, do_g, do_d, do_ds)
         self._pix_div = getattr(P, 'pix_log_div', 1.0)
 
     def get_current_log(self):
         """one device->host sync, only when the caller logs (the reference syncs 5-9 times every step, App. C-8)"""
         if getattr(self, '_acc_snapshot', None) is not None:
-            acc, do_g, do_d = self._acc_snapshot
+            acc, do_g, do_d, do_ds = self._acc_snapshot
             a = acc.tolist()
             if do_g:
                 if self.l_pix_w > 0:
@@ -215,10 +238,16 @@ class DASR_Model(BaseModel):
                     self.log_dict['loss/l_g_fea'] = a[A_FEA]
                 if self.netD_target is not None:
                     self.log_dict['loss/l_g_gan_target_Hf'] = a[A_GAN]
+                if self.netD_source is not None:
+                    self.log_dict['loss/l_g_gan_source_H'] = a[A_GAN_SRC]   # the reference logs the WEIGHTED value here (DASR_model.py:258,316)
             if do_d:
                 self.log_dict['loss/l_d_target_total'] = a[A_DREAL] + a[A_DFAKE]
                 self.log_dict['disc_Score/D_real_target_H'] = a[A_SREAL]
                 self.log_dict['disc_Score/D_fake_target_H'] = a[A_SFAKE]
+            if do_ds:
+                self.log_dict['loss/l_d_total'] = a[A_DREAL_SRC] + a[A_DFAKE_SRC]
+                self.log_dict['disc_Score/D_real_source_H'] = a[A_SREAL_SRC]
+                self.log_dict['disc_Score/D_fake_source_H'] = a[A_SFAKE_SRC]
             self._acc_snapshot = None
         return self.log_dict
 
@@ -251,11 +280,17 @@ class DASR_Model(BaseModel):
         if self.opt['is_train'] and pd is not None and self.netD_target is not None:
             logger.info('Loading pretrained model for D_target [{:s}] ...'.format(pd))
             self.load_network(pd, self.netD_target)
+        ps = self.opt['path']['pretrain_model_D_source']
+        if self.opt['is_train'] and ps is not None and self.netD_source is not None:
+            logger.info('Loading pretrained model for D_source [{:s}] ...'.format(ps))
+            self.load_network(ps, self.netD_source)
 
     def save(self, iter_step):
         self.save_network(self.netG, 'G', iter_step)
         if self.netD_target is not None:
             self.save_network(self.netD_target, 'D_target', iter_step)
+        if self.netD_source is not None:
+            self.save_network(self.netD_source, 'D_source', iter_step)
 
 
 class _StepPlan:
@@ -283,7 +318,7 @@ class _StepPlan:
         # ---- forward -------------------------------------------------------------------------------------------
         fwd.extend(g.fwd)
         o = add(fwd, _op(_lib.OP_FILL))
-        o.p[0], o.l[0], o.f[0] = acc, 8, 0.0
+        o.p[0], o.l[0], o.f[0] = acc, N_ACC, 0.0
         o = add(fwd, _op(_lib.OP_NCHW2B))
         o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[0], o.t[1] = self.hr_nchw.data_ptr(), N2, 3, H, W, self.hr_b.view(), NULL_T
         o = add(fwd, _op(_lib.OP_BILINEAR))  # ddm -> HR size (DASR_model.py:173-174)
@@ -315,9 +350,14 @@ class _StepPlan:
         self.g_low = BTensor(n, 16, Hd, Wd, True, dev)
         dx_fake = d.x.view() if d is not None else NULL_T
         dx_real = _nview(d.x, n) if d is not None else NULL_T
+        Ds = m.netD_source                     # source-domain discriminator on the high frequencies of [fake_s ; real_s] (DASR_model.py:250-259)
+        self.ds = Ds.plan(N2, Hd, Wd) if Ds is not None else None
+        ds = self.ds
+        sx_fake = ds.x.view() if ds is not None else NULL_T
+        sx_real = _nview(ds.x, n) if ds is not None else NULL_T
         if wavelet:
-            for src, n0, ll, hc in ((g.sr, 0, self.fake_low.view(), NULL_T), (g.sr, n, NULL_T, dx_fake),
-                                    (self.hr_b, 0, self.real_low.view(), NULL_T), (self.hr_b, n, NULL_T, dx_real)):
+            for src, n0, ll, hc in ((g.sr, 0, self.fake_low.view(), sx_fake), (g.sr, n, NULL_T, dx_fake),
+                                    (self.hr_b, 0, self.real_low.view(), sx_real), (self.hr_b, n, NULL_T, dx_real)):
                 if ll.p is None and hc.p is None:
                     continue
                 o = add(fwd, _op(_lib.OP_DWT_FWD))
@@ -325,8 +365,8 @@ class _StepPlan:
         else:
             a_h, b_h = (0.25, 0.75) if m.norm else (0.5, 0.5)  # FilterHigh normalises, filter_func normalises again (App. C-11)
             self.ab = (a_h, b_h)
-            for src, n0, lo, hi in ((g.sr, 0, self.fake_low.view(), NULL_T), (g.sr, n, NULL_T, dx_fake),
-                                    (self.hr_b, 0, self.real_low.view(), NULL_T), (self.hr_b, n, NULL_T, dx_real)):
+            for src, n0, lo, hi in ((g.sr, 0, self.fake_low.view(), sx_fake), (g.sr, n, NULL_T, dx_fake),
+                                    (self.hr_b, 0, self.real_low.view(), sx_real), (self.hr_b, n, NULL_T, dx_real)):
                 if lo.p is None and hi.p is None:
                     continue
                 o = add(fwd, _op(_lib.OP_LOWPASS))
@@ -376,6 +416,14 @@ class _StepPlan:
             o = add(fwd, _op(_lib.OP_BCE))
             o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = lg.view(), n, 1, lg.H, lg.W
             o.f[0], o.f[1], o.f[2], o.p[0], o.p[1], o.f[3], o.t[1] = 1.0, 1.0 / cnt, float(m.l_gan_H_target_w) / cnt, acc + 4 * A_GAN, None, 0.0, d.g_logits.view()
+        if ds is not None:   # l_g_gan_source_Hf = w_src * BCE(D_s(fake_s), 1): value logged WITH the weight (DASR_model.py:258,316)
+            fwd.extend(ds.fwd)
+            lg = ds.logits
+            cnt = float(n * 1 * lg.H * lg.W)
+            o = add(fwd, _op(_lib.OP_BCE))
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = lg.view(), n, 1, lg.H, lg.W
+            o.f[0], o.f[1], o.f[2], o.p[0], o.p[1], o.f[3], o.t[1] = 1.0, float(m.l_gan_H_source_w) / cnt, float(m.l_gan_H_source_w) / cnt, \
+                acc + 4 * A_GAN_SRC, None, 0.0, ds.g_logits.view()
         self.fwd = fwd
 
         # ---- generator-loss backward: everything that lands in dL/dSR ----------------------------------------------------
@@ -392,16 +440,19 @@ class _StepPlan:
             C.memmove(C.addressof(o.l), (C.c_float * 4)(0.0, 0.0, 0.0, 0.0), 16)
         if d is not None:
             gl.extend(d.bwd_data_ops(n))
+        if ds is not None:
+            gl.extend(ds.bwd_data_ops(n))
         g_hi_t = d.gx.view() if d is not None else NULL_T
+        g_hi_s = ds.gx.view() if ds is not None else NULL_T
         g_lo_s = self.g_low.view() if m.sup_LL else NULL_T
         if wavelet:
-            for n0, gll, ghc in ((0, g_lo_s, NULL_T), (n, NULL_T, g_hi_t)):
+            for n0, gll, ghc in ((0, g_lo_s, g_hi_s), (n, NULL_T, g_hi_t)):
                 if gll.p is None and ghc.p is None:
                     continue
                 o = add(gl, _op(_lib.OP_DWT_BWD))
                 o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[2], o.i[5] = gll, ghc, n, 3, Hd, Wd, int(m.norm), _nview(g.g_sr, n0), 1
         else:
-            for n0, glo, ghi in ((0, g_lo_s, NULL_T), (n, NULL_T, g_hi_t)):
+            for n0, glo, ghi in ((0, g_lo_s, g_hi_s), (n, NULL_T, g_hi_t)):
                 if glo.p is None and ghi.p is None:
                     continue
                 o = add(gl, _op(_lib.OP_LOWPASS))
@@ -411,22 +462,33 @@ class _StepPlan:
         self.g_loss_bwd = gl
 
         # ---- discriminator step: BCE(real, 1), BCE(fake, 0), backward with weight gradients -----------------------------------
-        ds = OpList()
+        dstep = OpList()
         if d is not None:
             lg = d.logits
             cnt = float(n * lg.H * lg.W)
             for n0, target, a_loss, a_score in ((n, 1.0, A_DREAL, A_SREAL), (0, 0.0, A_DFAKE, A_SFAKE)):
-                o = add(ds, _op(_lib.OP_BCE))
+                o = add(dstep, _op(_lib.OP_BCE))
                 o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = _nview(lg, n0), n, 1, lg.H, lg.W
                 o.f[0], o.f[1], o.f[2] = target, 0.5 / cnt, 0.5 / cnt
                 o.p[0], o.p[1], o.f[3], o.t[1] = acc + 4 * a_loss, acc + 4 * a_score, 1.0 / cnt, _nview(d.g_logits, n0)
-            ds.extend(d.bwd_full)
-        self.d_step = ds
+            dstep.extend(d.bwd_full)
+        self.d_step = dstep
+        # ---- source-domain discriminator step (DASR_model.py:287-303): the same on [fake_s ; real_s] ------------------------------------
+        sstep = OpList()
+        if self.ds is not None:
+            lg = self.ds.logits
+            cnt = float(n * lg.H * lg.W)
+            for n0, target, a_loss, a_score in ((n, 1.0, A_DREAL_SRC, A_SREAL_SRC), (0, 0.0, A_DFAKE_SRC, A_SFAKE_SRC)):
+                o = add(sstep, _op(_lib.OP_BCE))
+                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = _nview(lg, n0), n, 1, lg.H, lg.W
+                o.f[0], o.f[1], o.f[2] = target, 0.5 / cnt, 0.5 / cnt
+                o.p[0], o.p[1], o.f[3], o.t[1] = acc + 4 * a_loss, acc + 4 * a_score, 1.0 / cnt, _nview(self.ds.g_logits, n0)
+            sstep.extend(self.ds.bwd_full)
+        self.ds_step = sstep
 
     def set_d_grad_scale(self, scale):
-        if self.d is None:
-            return
-        for o in self.d_step.ops:
-            if o.op == _lib.OP_WGRAD_REDUCE and o.f[0] != scale:
-                o.f[0] = scale
-                self.d_step._arr = None
+        for ol in (self.d_step, self.ds_step):
+            for o in ol.ops:
+                if o.op == _lib.OP_WGRAD_REDUCE and o.f[0] != scale:
+                    o.f[0] = scale
+                    ol._arr = None

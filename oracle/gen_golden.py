@@ -16,7 +16,7 @@ from . import fixtures, nets, ref_import
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
 
 
-def collect(case, netG, netD, update_lr, feed, step_fn, get_log, steps=2):
+def collect(case, netG, netD, update_lr, feed, step_fn, get_log, steps=2, netD2=None):
     """Drive a trainer for `steps` steps and return the fixture dict (numpy)."""
     out = {}
     taps = {}
@@ -50,12 +50,16 @@ def collect(case, netG, netD, update_lr, feed, step_fn, get_log, steps=2):
             out['gradG_sub'] = np.concatenate([fixtures.subsample(p.grad, 4).numpy() for p in netG.parameters()])
             if netD is not None:
                 out['gradD_norm'] = np.array([float(p.grad.double().norm()) for p in netD.parameters()])
+            if netD2 is not None:
+                out['gradD2_norm'] = np.array([float(p.grad.double().norm()) for p in netD2.parameters()])
     keys = sorted(logs[0].keys())
     out['log_keys'] = np.array(keys)
     out['logs'] = np.array([[l[k] for k in keys] for l in logs], dtype=np.float64)
     out['wN_digest'] = np.array([nets.tensor_digest(v) for v in netG.state_dict().values()])
     if netD is not None:
         out['dN_digest'] = np.array([nets.tensor_digest(v) for v in netD.state_dict().values()])
+    if netD2 is not None:
+        out['d2N_digest'] = np.array([nets.tensor_digest(v) for v in netD2.state_dict().values()])
     out['state_keys'] = np.array(list(netG.state_dict().keys()))
     return out
 
@@ -78,14 +82,17 @@ def run_reference(case):
     finally:
         networks.define_G = orig_define_G
     m.netG.load_state_dict(fixtures.seeded_state_dict(m.netG.state_dict(), 1, 0.1))
-    netD = None
+    netD = netD2 = None
     if c['kind'] == 'dasr':
         netD = m.netD_target
         netD.load_state_dict(fixtures.seeded_state_dict(netD.state_dict(), 2, 1.0))
+        if c.get('gan_src', 0) > 0:
+            netD2 = m.netD_source
+            netD2.load_state_dict(fixtures.seeded_state_dict(netD2.state_dict(), 3, 1.0))
         feed = lambda b: m.feed_data(b, True)
     else:
         feed = lambda b: m.feed_data(b)
-    return collect(case, m.netG, netD, m.update_learning_rate, feed, m.optimize_parameters, m.get_current_log)
+    return collect(case, m.netG, netD, m.update_learning_rate, feed, m.optimize_parameters, m.get_current_log, netD2=netD2)
 
 
 def run_oracle(case):
@@ -103,8 +110,12 @@ def run_oracle(case):
     if c.get('fea') == 'LPIPS':
         from . import lpips
         netF = lpips.golden_criterion(77)[0]
-    t = trainers.DASRTrainer(opt, netG=netG, netD=netD, netF=netF, vgg_seed=77)
-    return collect(case, netG, netD, t.update_learning_rate, t.feed_data, t.optimize_parameters, lambda: t.log)
+    netD2 = None
+    if c.get('gan_src', 0) > 0:
+        netD2 = nets.NLayerDiscriminator(c['d_in_nc'], 64, n_layers=2)
+        netD2.load_state_dict(fixtures.seeded_state_dict(netD2.state_dict(), 3, 1.0))
+    t = trainers.DASRTrainer(opt, netG=netG, netD=netD, netF=netF, vgg_seed=77, netD_source=netD2)
+    return collect(case, netG, netD, t.update_learning_rate, t.feed_data, t.optimize_parameters, lambda: t.log, netD2=netD2)
 
 
 def misc_reference():

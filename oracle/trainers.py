@@ -50,11 +50,12 @@ class SRTrainer:
 
 
 class DASRTrainer:
-    def __init__(self, opt, netG=None, netD=None, netF=None, vgg_seed=77):
+    def __init__(self, opt, netG=None, netD=None, netF=None, vgg_seed=77, netD_source=None):
         t = opt['train']
         g, d = opt['network_G'], opt['network_D']
         self.multiweights = opt.get('multiweights')
         self.l_gan_w = t['gan_H_target']
+        self.l_gan_src_w = _opt(t, 'gan_H_source', 0)
         self.netG = netG if netG is not None else nets.RRDBNet(g['in_nc'], g['out_nc'], g['nf'], g['nb'], opt['scale'])
         if netG is None:
             nets.init_kaiming_(self.netG, 0.1)
@@ -95,6 +96,17 @@ class DASRTrainer:
             self.opt_D = torch.optim.Adam(self.netD.parameters(), lr=t['lr_D'], weight_decay=_opt(t, 'weight_decay_D', 0),
                                           betas=(t['beta1_D'], 0.999))
             self.optimizers.append(self.opt_D)
+        self.netD_src = None
+        if self.l_gan_src_w > 0:   # DASR_model.py:45-47,139-143; define_pairD 'discriminator_patch' passes nf as ndf (networks.py:217-218)
+            if d.get('which_model_pairD') != 'discriminator_patch':
+                raise NotImplementedError('Discriminator model [{:s}] not recognized'.format(str(d.get('which_model_pairD'))))
+            self.netD_src = netD_source
+            if self.netD_src is None:
+                self.netD_src = nets.NLayerDiscriminator(d['in_nc'], d['nf'], d['n_layers'])
+                nets.init_kaiming_(self.netD_src, 1)
+            self.opt_D_src = torch.optim.Adam(self.netD_src.parameters(), lr=t['lr_D'], weight_decay=_opt(t, 'weight_decay_D', 0),
+                                              betas=(t['beta1_D'], 0.999))
+            self.optimizers.append(self.opt_D_src)
         self.scheds = [torch.optim.lr_scheduler.MultiStepLR(o, t['lr_steps'], t['lr_gamma']) for o in self.optimizers]
         self.log = OrderedDict()
 
@@ -160,6 +172,10 @@ class DASRTrainer:
                 l_gan = self._bce(pred, 1.0)
                 tot = tot + self.l_gan_w * l_gan
                 self.log['loss/l_g_gan_target_Hf'] = l_gan.item()
+            if self.l_gan_src_w > 0:   # DASR_model.py:250-259,316: the WEIGHTED value is what is added and logged
+                l_src = self.l_gan_src_w * self._bce(self.netD_src(fake_Hc[:n]), 1.0)
+                tot = tot + l_src
+                self.log['loss/l_g_gan_source_H'] = l_src.item()
             self.opt_G.zero_grad()
             tot.backward()
             self.opt_G.step()
@@ -173,3 +189,13 @@ class DASRTrainer:
             self.log['loss/l_d_target_total'] = l_d.item()
             self.log['disc_Score/D_real_target_H'] = pr.detach().mean().item()
             self.log['disc_Score/D_fake_target_H'] = pf.detach().mean().item()
+        if step % self.D_int == 0 and self.l_gan_src_w > 0:   # DASR_model.py:287-303,327-330
+            pr = self.netD_src(real_Hc[:n].detach())
+            pf = self.netD_src(fake_Hc[:n].detach())
+            l_d = (self._bce(pf, 0.0) + self._bce(pr, 1.0)) / 2
+            self.opt_D_src.zero_grad()
+            l_d.backward()
+            self.opt_D_src.step()
+            self.log['loss/l_d_total'] = l_d.item()
+            self.log['disc_Score/D_real_source_H'] = pr.detach().mean().item()
+            self.log['disc_Score/D_fake_source_H'] = pf.detach().mean().item()

@@ -206,7 +206,8 @@ def test_vgg_forward_and_input_gradient(prec, act_tol, grad_tol, margins):
     assert e_f < act_tol and e_g < grad_tol
 
 
-@pytest.mark.parametrize('case', ['dasr_wavelet_nf32_nb2_n2_32', 'dasr_gau9_nf64_nb1_n1_32', 'dasr_lpips_wavelet_nf32_nb2_n2_32'])
+@pytest.mark.parametrize('case', ['dasr_wavelet_nf32_nb2_n2_32', 'dasr_gau9_nf64_nb1_n1_32', 'dasr_lpips_wavelet_nf32_nb2_n2_32',
+                                  'dasr_srcD_wavelet_nf32_nb2_n2_32'])
 def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir):
     dev = _gpu()
     torch.set_num_threads(8)
@@ -225,7 +226,12 @@ def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir):
     if c.get('fea') == 'LPIPS':     # feature_criterion LPIPS: the reference's linear heads + the seeded stand-in AlexNet of the fixture
         from oracle import lpips
         crit, sdF = lpips.golden_criterion(77, golden_dir)
-    t = trainers.DASRTrainer(opt, netG=netG, netD=netD, netF=crit, vgg_seed=77)
+    netD2 = sdD2 = None
+    if c.get('gan_src', 0) > 0:     # source-domain patch discriminator (define_pairD passes nf = 64 as ndf)
+        netD2 = nets.NLayerDiscriminator(c['d_in_nc'], 64, n_layers=2)
+        sdD2 = fixtures.seeded_state_dict(netD2.state_dict(), 3, 1.0)
+        netD2.load_state_dict(sdD2)
+    t = trainers.DASRTrainer(opt, netG=netG, netD=netD, netF=crit, vgg_seed=77, netD_source=netD2)
     batch = fixtures.make_batch(case)
     opt2 = fixtures.make_opt(case)
     opt2['gpu_ids'] = [0]
@@ -233,6 +239,8 @@ def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir):
     m = create_model(options.dict_to_nonedict(opt2))
     m.netG.load_state_dict(sdG)
     m.netD_target.load_state_dict(sdD)
+    if sdD2 is not None:
+        m.netD_source.load_state_dict(sdD2)
     m.netF.load_state_dict(sdF if sdF is not None else {k: v for k, v in t.netF.state_dict().items() if k.startswith('features')})
     gold = np.load(os.path.join(golden_dir, case + '.npz'))
     keys = list(gold['log_keys'])
@@ -260,6 +268,11 @@ def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir):
             for (k, gv), pr in zip(dd.items(), netD.parameters()):
                 r = rel(gv, pr.grad)
                 assert r < GRAD_TOL, ('D', k, r)
+            if netD2 is not None:
+                d2 = m.netD_source.params.grad_dict()
+                for (k, gv), pr in zip(d2.items(), netD2.parameters()):
+                    assert rel(gv, pr.grad) < GRAD_TOL, ('D_source', k, rel(gv, pr.grad))
+                np.testing.assert_allclose(np.array([float(v.double().norm()) for v in d2.values()]), gold['gradD2_norm'], rtol=GRAD_TOL)
             np.testing.assert_allclose(np.array([float(v.double().norm()) for v in gd.values()]), gold['gradG_norm'], rtol=GRAD_TOL)
             np.testing.assert_allclose(np.array([float(v.double().norm()) for v in dd.values()]), gold['gradD_norm'], rtol=GRAD_TOL)
             print('%s: worst G grad rel err %.2e' % (case, worst))

@@ -30,6 +30,9 @@ def test_oracle_matches_reference_fixture(case, golden_dir):
     if 'dN_digest' in ref.files:
         np.testing.assert_allclose(got['gradD_norm'], ref['gradD_norm'], rtol=1e-4, atol=1e-9)
         np.testing.assert_allclose(got['dN_digest'], ref['dN_digest'], rtol=1e-5, atol=1e-6)
+    if 'd2N_digest' in ref.files:   # source-domain discriminator
+        np.testing.assert_allclose(got['gradD2_norm'], ref['gradD2_norm'], rtol=1e-4, atol=1e-9)
+        np.testing.assert_allclose(got['d2N_digest'], ref['d2N_digest'], rtol=1e-5, atol=1e-6)
 
 
 def test_oracle_modules_match_reference(golden_dir):
