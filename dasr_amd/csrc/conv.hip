@@ -65,7 +65,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
 // Epilogue shared by the conv kernels: acc (MFMA D layout: lane -> pixel nn = lane & 31 of an n-tile row, channels
 // 8g + 4*(lane >> 5) + j of the m-tile) -> bias / activation / mask / scaled residual adds -> fp32 and/or bf16 stores.
 // ---------------------------------------------------------------------------------------------------
-template <bool IN_F32, int MT, int NT, int STRIDE, int EPI>
+// F16OUT: -1 = the 16-bit output format is a run-time (wave-uniform) choice; 0 / 1 = bf16 / f16 fixed at compile time (the dense-block LDS-DMA
+// kernels: the run-time form converted every element to BOTH formats and selected: 224 of the 628 VALU instructions of the Cout=32 epilogue)
+template <bool IN_F32, int MT, int NT, int STRIDE, int EPI, int F16OUT = -1>
 __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 (&acc)[MT][NT], char* smem, float bias_reg, int tid, int mg, int n,
                                               int oy0, int ox0) {
     const int lane = tid & 63, wave = tid >> 6, nn = lane & 31, kh2 = lane >> 5;
@@ -84,7 +86,7 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
     const bool has_f32 = G ? p.out_f32.p != nullptr : bool(EPI & 32);
     const bool has_bf16 = G ? p.out_bf16.p != nullptr : bool(EPI & 64);
     const bool scaled = G ? true : bool(EPI & 128);   // alpha / gamma may differ from 1
-    const bool f16out = p.out16_f16 != 0;             // the 16-bit output tensor holds f16 (HR tail, f16 storage) instead of bf16: wave-uniform
+    const bool f16out = F16OUT < 0 ? p.out16_f16 != 0 : F16OUT != 0;   // the 16-bit output tensor holds f16 (HR tail, f16 storage) instead of bf16: wave-uniform
     const bool chan_tail = G ? true : false;          // cout not a multiple of 32 (specialised variants require it)
     const int ostr = p.out_stride > 1 ? p.out_stride : 1, owid = p.out_W > 0 ? p.out_W : p.Wout;  // strided sub-grid output (stride-2 dgrad)
     constexpr int MSZ = IN_F32 ? 4 : 2;
@@ -197,7 +199,12 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[g][j] += bia[mi][g][j];
             }
-            if (act_lrelu) {
+            if (act_lrelu && !G) {   // specialised variants (classify_epi: slope in [0, 1]): LeakyReLU = max(v, slope * v), two VALU ops per element, not three
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[g][j] = fmaxf(v[g][j], slope * v[g][j]);
+            } else if (act_lrelu) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -223,10 +230,15 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        unsigned mbits;
-                        if constexpr (IN_F32) mbits = mk[slot][g][j];
-                        else mbits = (j & 1) ? (mk[slot][g][j >> 1] & 0xffff0000u) : (mk[slot][g][j >> 1] << 16);
-                        v[g][j] *= __uint_as_float(mbits) > 0.f ? 1.f : slope;
+                        if constexpr (IN_F32) {
+                            v[g][j] *= __uint_as_float(mk[slot][g][j]) > 0.f ? 1.f : slope;
+                        } else {
+                            // 16-bit mask (bf16 or f16 forward activation): positive <=> its bit pattern is a positive int16 (no unpacking to f32);
+                            // select between v and slope * v (packed multiply): 2.5 VALU ops per element instead of 3.5
+                            const unsigned wd = mk[slot][g][j >> 1];
+                            const short hbits = (j & 1) ? (short)(wd >> 16) : (short)(wd & 0xffffu);
+                            v[g][j] = hbits > 0 ? v[g][j] : slope * v[g][j];
+                        }
                     }
             }
             if (scaled && p.alpha != 1.f) {
@@ -892,7 +904,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
         if (ck == 2) TRACE_STAMP(11);
     }
     TRACE_STAMP(4);
-    conv_epilogue<false, MT, NT, 1, EPI>(p, acc, smem, bias_reg, tid, mg, n, oy0, ox0);
+    conv_epilogue<false, MT, NT, 1, EPI, F16 ? 1 : 0>(p, acc, smem, bias_reg, tid, mg, n, oy0, ox0);
     TRACE_STAMP(6);
 #ifdef DASR_TRACE
     __builtin_amdgcn_s_waitcnt(0);
@@ -1069,6 +1081,7 @@ int launch_glds(const dasr_conv_params& p, hipStream_t s) {
     auto kfn = conv_glds_kernel<MT, EPI, NW, ABL, F16>;
     if ((p.cin & 15) || p.kh != 3 || p.stride != 1 || p.pad != 1 || p.in_f32 || p.prec != (F16 ? 2 : 1) || (p.pad_x >= 0 && p.pad_x != 1) || p.in_stride > 1)
         return DASR_EINVAL;
+    if (p.out_bf16.p && (p.out16_f16 != 0) != F16) return DASR_EINVAL;   // the 16-bit output format of this kernel is its operand format (compile time)
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         attr_set = true;
@@ -1146,6 +1159,7 @@ __global__ void conv_naive_kernel(const dasr_conv_params p, const float* w) {
 // compile-time epilogue variant of the hot dense-block cases (bit set: see conv_kernel's epilogue); 0 = generic
 int classify_epi(const dasr_conv_params& p) {
     if ((p.cout & 31) || p.slope_ptr || p.act == 2 || p.out_stride > 1) return 0;
+    if (p.act == 1 && !(p.slope >= 0.f && p.slope <= 1.f)) return 0;   // the specialised epilogues use max(v, slope * v)
     int e = (p.bias ? 1 : 0) | (p.act == 1 ? 2 : 0) | (p.mask.p ? 4 : 0) | (p.res1.p ? 8 : 0) | (p.res2.p ? 16 : 0) | (p.out_f32.p ? 32 : 0) |
             (p.out_bf16.p ? 64 : 0);
     if (p.res1.p || p.alpha != 1.f || p.gamma != 1.f) e |= 128;
