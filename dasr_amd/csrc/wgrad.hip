@@ -764,50 +764,61 @@ __global__ __launch_bounds__(768, 1) void wgrad3_glds_kernel(const dasr_wgrad_pa
 #endif
 }
 
-// deterministic split reduction: block = 64 consecutive elements x 4 split lanes (fixed summation tree)
+// deterministic split reduction.  One workgroup = one output channel x 16 input channels of one part; thread (split lane sl = t >> 4, cin =
+// t & 15) sums splits sl, sl + 16, ... of every tap (two accumulators, fixed order), the 16 lane sums meet in LDS and are added in a fixed
+// tree, and the reference layout [cout][cin][kh][kw] is written as ONE contiguous run of 16 * ntaps floats per workgroup (the first version
+// stored 4 bytes per lane 36 bytes apart: 8x write amplification, ~1 TB/s, 8 % of the DSN iteration).  128 workgroups per part: enough
+// parallelism both for the many-parts / 16-splits launches of the RRDB trunk and the 2-parts / 128-splits launches of the DSN generator.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const dasr_wgrad_reduce_part* __restrict__ parts, int nparts,
                                                            const float* __restrict__ ws, float* __restrict__ grad, float scale) {
-    __shared__ float red[256];
-    const int part_id = blockIdx.y;
-    const dasr_wgrad_reduce_part P = parts[part_id];
+    __shared__ float red[16 * 16 * 17];
+    const dasr_wgrad_reduce_part P = parts[blockIdx.y];
+    const int oc = blockIdx.x >> 2, cg = blockIdx.x & 3, goc = P.oc0 + oc;
+    if (goc >= P.cout) return;   // uniform per block
     const int per = P.ntaps * 32 * 64;
     const long long sstride = P.split_stride > 0 ? P.split_stride : per, tstride = P.tap_stride > 0 ? P.tap_stride : 2048;
     const long long bstride = P.bias_stride > 0 ? P.bias_stride : 32;
-    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int nblk = (per + 32 + 63) / 64;
-    for (int b = blockIdx.x; b < nblk; b += gridDim.x) {  // uniform per block
-        const int i = b * 64 + e;
-        float s = 0.f;
-        bool valid = false;
-        long long dst = 0;
-        if (i < per) {
-            const int cin = i & 63, oc = (i >> 6) & 31, tap = i >> 11;
-            const int goc = P.oc0 + oc, gc = P.c0 + cin;
-            valid = cin < 32 * P.n_ctiles && goc < P.cout && gc < P.cin && P.tap0 + tap < (P.ntaps_total > 0 ? P.ntaps_total : P.ntaps);
-            if (valid) {
-                const float* src = ws + P.ws_off + (long long)tap * tstride + (i & 2047);
-                float s0 = 0.f, s1 = 0.f;
+    const int NT = P.ntaps_total > 0 ? P.ntaps_total : P.ntaps;
+    const int ntaps = min(P.ntaps, NT - P.tap0);                        // taps of this part that exist in the kernel window
+    const int n_c = min(min(32 * P.n_ctiles, P.cin - P.c0), 64) - cg * 16;   // valid input channels of this 16-channel group (may be <= 0)
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    if (n_c > 0) {
+        const float* src = ws + P.ws_off + oc * 64 + cg * 16 + cl;
+        for (int tap = 0; tap < ntaps; ++tap) {
+            float a0 = 0.f, a1 = 0.f;
+            if (cl < n_c) {
                 int sp = sl;
-                for (; sp + 4 < P.nsplit; sp += 8) {
-                    s0 += src[(size_t)sp * sstride];
-                    s1 += src[(size_t)(sp + 4) * sstride];
+                for (; sp + 16 < P.nsplit; sp += 32) {
+                    a0 += src[(size_t)sp * sstride + (long long)tap * tstride];
+                    a1 += src[(size_t)(sp + 16) * sstride + (long long)tap * tstride];
                 }
-                if (sp < P.nsplit) s0 += src[(size_t)sp * sstride];
-                s = s0 + s1;
-                dst = P.dst_w_off + ((long long)goc * P.cin + gc) * (P.ntaps_total > 0 ? P.ntaps_total : P.ntaps) + P.tap0 + tap;
+                if (sp < P.nsplit) a0 += src[(size_t)sp * sstride + (long long)tap * tstride];
             }
-        } else if (i < per + 32 && P.dst_b_off >= 0) {
-            const int oc = i - per;
-            valid = P.oc0 + oc < P.cout;
-            if (valid) {
-                for (int sp = sl; sp < P.nsplit; sp += 4) s += ws[P.ws_bias_off + (size_t)sp * bstride + oc];
-                dst = P.dst_b_off + P.oc0 + oc;
-            }
+            red[(sl * 16 + cl) * 17 + tap] = a0 + a1;
         }
-        __syncthreads();
-        red[threadIdx.x] = s;
-        __syncthreads();
-        if (sl == 0 && valid) grad[dst] = ((red[e] + red[64 + e]) + (red[128 + e] + red[192 + e])) * scale;
+    }
+    __syncthreads();
+    if (n_c > 0) {
+        float* dst = grad + P.dst_w_off + ((long long)goc * P.cin + P.c0 + cg * 16) * NT + P.tap0;
+        const int nvalid = (n_c < 16 ? n_c : 16) * ntaps;
+        for (int o = threadIdx.x; o < nvalid; o += 256) {
+            const int c = o / ntaps, tap = o - c * ntaps;
+            const float* r = red + c * 17 + tap;
+            float q[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) q[k] = r[k * 16 * 17];
+            const float tot = (((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]))) +
+                              (((q[8] + q[9]) + (q[10] + q[11])) + ((q[12] + q[13]) + (q[14] + q[15])));
+            // the whole kernel window: [cin][tap] is contiguous in the destination; a tap range of a larger window (5x5 in parts of 10 taps): runs
+            dst[ntaps == NT ? (long long)o : (long long)c * NT + tap] = tot * scale;
+        }
+    }
+    if (cg == 0 && P.dst_b_off >= 0 && threadIdx.x < 64) {   // bias of this output channel: lane l sums splits l, l + 64, ...; fixed xor tree
+        float b = 0.f;
+        for (int sp = threadIdx.x; sp < P.nsplit; sp += 64) b += ws[P.ws_bias_off + (size_t)sp * bstride + oc];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) b += __shfl_xor(b, o, 64);
+        if (threadIdx.x == 0) grad[P.dst_b_off + goc] = b * scale;
     }
 }
 
@@ -928,6 +939,6 @@ extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int3
 extern "C" int dasr_wgrad_reduce(const dasr_wgrad_reduce_part* parts_dev, int32_t nparts, const float* ws, float* grad_flat,
                                  float scale, void* stream) {
     if (nparts <= 0) return DASR_EINVAL;
-    DASR_LAUNCH(wgrad_reduce_kernel, dim3(145, nparts), dim3(256), 0, as_stream(stream), parts_dev, nparts, ws, grad_flat, scale);
+    DASR_LAUNCH(wgrad_reduce_kernel, dim3(128, nparts), dim3(256), 0, as_stream(stream), parts_dev, nparts, ws, grad_flat, scale);
     return (int)hipGetLastError();
 }
