@@ -564,13 +564,15 @@ __global__ void prelu_grad_partial_kernel(dasr_tensor y, dasr_tensor gx, int N, 
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
-__global__ void prelu_grad_final_kernel(const float* __restrict__ partial, int nblocks, const float* __restrict__ slope, float* __restrict__ dst,
-                                        float scale) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float s = 0.f;
-        for (int i = 0; i < nblocks; ++i) s += partial[i];
+__global__ __launch_bounds__(256) void prelu_grad_final_kernel(const float* __restrict__ partial, int nblocks, const float* __restrict__ slope,
+                                                               float* __restrict__ dst, float scale) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];   // fixed order per thread, fixed tree across threads: deterministic
+    const float tot = block_sum_256(s, red);
+    if (threadIdx.x == 0) {
         const float a = *slope;
-        *dst = scale * s / (a * a);
+        *dst = scale * tot / (a * a);
     }
 }
 
@@ -736,8 +738,11 @@ extern "C" int dasr_sigmoid_fwd(dasr_tensor x, int32_t N, int32_t C, int32_t H, 
 extern "C" int dasr_prelu_grad(dasr_tensor y, dasr_tensor gx, int32_t N, int32_t C, int32_t H, int32_t W, const float* slope, float* scratch256,
                                float* dst, float scale, void* stream) {
     if ((long long)N * C * H * W <= 0) return DASR_EINVAL;
-    DASR_LAUNCH(prelu_grad_partial_kernel, dim3(256), dim3(256), 0, as_stream(stream), y, gx, N, C, H, W, scratch256);
-    DASR_LAUNCH(prelu_grad_final_kernel, dim3(1), dim3(64), 0, as_stream(stream), scratch256, 256, slope, dst, scale);
+    // 1024 workgroups (4 per CU: the streaming read of two tensors needs the occupancy), one partial each; `scratch256` holds 1024 floats
+    const long long vec = (long long)N * ((C + 15) / 16) * H * W * 4;
+    const int nb = (int)(vec < 1024LL * 256 ? (vec + 255) / 256 : 1024);
+    DASR_LAUNCH(prelu_grad_partial_kernel, dim3(nb), dim3(256), 0, as_stream(stream), y, gx, N, C, H, W, scratch256);
+    DASR_LAUNCH(prelu_grad_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), scratch256, nb, slope, dst, scale);
     return (int)hipGetLastError();
 }
 

@@ -784,17 +784,25 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const dasr_wgrad_redu
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
     if (n_c > 0) {
         const float* src = ws + P.ws_off + oc * 64 + cg * 16 + cl;
-        for (int tap = 0; tap < ntaps; ++tap) {
-            float a0 = 0.f, a1 = 0.f;
+        for (int tap0 = 0; tap0 < ntaps; tap0 += 3) {      // three taps x eight splits = 24 independent loads in flight per thread: the
+            float a[3] = {0.f, 0.f, 0.f};                    // few-parts / many-splits launches (DSN: 2 parts x 128 splits) are latency-bound
             if (cl < n_c) {
-                int sp = sl;
-                for (; sp + 16 < P.nsplit; sp += 32) {
-                    a0 += src[(size_t)sp * sstride + (long long)tap * tstride];
-                    a1 += src[(size_t)(sp + 16) * sstride + (long long)tap * tstride];
+                for (int sp = sl; sp < P.nsplit; sp += 16 * 8) {
+                    float q[3][8];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            q[t][k] = (tap0 + t < ntaps && sp + 16 * k < P.nsplit) ? src[(size_t)(sp + 16 * k) * sstride + (long long)(tap0 + t) * tstride] : 0.f;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) a[t] += q[t][k];   // ascending split order, whatever the unrolling
                 }
-                if (sp < P.nsplit) a0 += src[(size_t)sp * sstride + (long long)tap * tstride];
             }
-            red[(sl * 16 + cl) * 17 + tap] = a0 + a1;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                if (tap0 + t < ntaps) red[(sl * 16 + cl) * 17 + tap0 + t] = a[t];
         }
     }
     __syncthreads();

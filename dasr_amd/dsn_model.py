@@ -148,7 +148,7 @@ class _GPlan:
         self.g_d2, self.g_d1 = B(64, H4, W4), B(64, H2, W2)
         self.g_s = [B(64, H, W) for _ in range(2)]
         self.g_h = B(64, H, W)
-        self.scratch = torch.zeros(256, dtype=torch.float32, device=dev)
+        self.scratch = torch.zeros(1024, dtype=torch.float32, device=dev)
         self.ws = Workspace(dev)
         sp = lambda key: P.ptr(key)
         # ---- forward ----

@@ -269,7 +269,7 @@ int dasr_sigmoid_bwd(dasr_tensor y, dasr_tensor g, int32_t N, int32_t C, int32_t
  * consumed by create_dataset_modified.py:14-24) */
 int dasr_sigmoid_fwd(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, dasr_tensor y, void* stream);
 /* gradient of nn.PReLU()'s single slope (model.py:29,215) from the layer output y and dL/dx; deterministic two-stage sum;
- * scratch256: 256 floats */
+ * scratch256: 1024 floats (one partial per workgroup of the first stage; the name is historical) */
 int dasr_prelu_grad(dasr_tensor y, dasr_tensor gx, int32_t N, int32_t C, int32_t H, int32_t W, const float* slope, float* scratch256,
                     float* dst, float scale, void* stream);
 /* un-padded low-pass of the colour loss (FilterLow(padding=False), loss.py:52-56): mode 0 forward (H-k+1 x W-k+1 out),

@@ -146,7 +146,7 @@ def test_logloss_sigmoid_prelu_lowpass_valid():
     yv.backward(gpost)
     gpre = gpost * torch.where(pre > 0, torch.ones(()), a.detach())
     yb, gb = to_blocked(yv.detach(), dev), to_blocked(gpre, dev)
-    scratch = torch.zeros(256, device=dev)
+    scratch = torch.zeros(1024, device=dev)
     out = torch.zeros(2, device=dev)
     sl = a.detach().to(dev)
     _lib.check(L.dasr_prelu_grad(yb.view(), gb.view(), 2, 64, 10, 12, sl.data_ptr(), scratch.data_ptr(), out.data_ptr(), 0.5, _stream()))
