@@ -130,6 +130,12 @@ def roofline_from_step(run_step, peak_measured, streams, nsteps=1):
             tsrc = pm['source']
     except Exception:
         pass
+    busy = None
+    try:  # MFMA-pipe busy fraction from the committed SQ counter passes (the rocprof definition of "MFMA utilisation"), single-stream launches
+        pb = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_mfma_busy.json')))
+        busy = {'kernel': pb['kernels'].get(head.get('kernel')), 'rrdb_trunk_time_weighted': pb['rrdb_trunk_time_weighted'], 'source': pb['source']}
+    except Exception:
+        pass
     roof = {'bound': 'mfma', 'achieved': head.get('achieved'), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': head.get('frac'),
             'traffic': traffic, 'traffic_source': tsrc, 'kernel': head.get('kernel'), 'avg_launch_us': head.get('avg_launch_us'),
             'flops_per_launch': head.get('flops_per_launch'),
@@ -142,7 +148,7 @@ def roofline_from_step(run_step, peak_measured, streams, nsteps=1):
                       'average launch duration; headline = kernel with the largest total time; with streams > 1 launches of the sub-batch '
                       'streams overlap (kernel_time_over_wall = sum of launch durations / step wall time), so the chip-level rate of a kernel '
                       'is up to that factor above its per-launch rate',
-            'per_kernel': out[:8], 'truncated': truncated}
+            'mfma_busy_pmc': busy, 'per_kernel': out[:8], 'truncated': truncated}
     return roof
 
 
