@@ -65,11 +65,40 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
 // Epilogue shared by the conv kernels: acc (MFMA D layout: lane -> pixel nn = lane & 31 of an n-tile row, channels
 // 8g + 4*(lane >> 5) + j of the m-tile) -> bias / activation / mask / scaled residual adds -> fp32 and/or bf16 stores.
 // ---------------------------------------------------------------------------------------------------
+// mask planes of a workgroup's output tile fetched during the LAST chunk of the main loop (dgrad convs whose only epilogue input is the
+// LeakyReLU' mask): no LDS-DMA is in flight then (nothing left to prefetch), so the loads neither queue behind nor delay a chunk, and the
+// round trip (2-4 us under load, the whole difference between the dgrad and the forward launch) overlaps the last 36 MFMAs per wave.
+template <int NG>
+struct MaskPre {
+    u32x4 v[NG][2];
+};
+
+template <int MT, int NT>
+__device__ __forceinline__ void mask_prefetch(const dasr_conv_params& p, MaskPre<NT * MT>& m, int tid, int mg, int n, int oy0, int ox0) {
+    const int lane = tid & 63, wave = tid >> 6, nn = lane & 31, kh2 = lane >> 5;
+    const int ostr = p.out_stride > 1 ? p.out_stride : 1, owid = p.out_W > 0 ? p.out_W : p.Wout;
+    const __amdgpu_buffer_rsrc_t rmask = make_rsrc((const char*)p.mask.p + (size_t)n * p.mask.n_stride * 2);
+    const unsigned mask_cb = (unsigned)p.mask.cb_stride;
+#pragma unroll
+    for (int gi = 0; gi < NT * MT; ++gi) {
+        const int nt = gi / MT, mi = gi - nt * MT;
+        const int oy = oy0 + wave * NT + nt, ox = ox0 + nn;
+        const unsigned oob = ((oy < p.Hout) & (ox < p.Wout)) ? 0u : OOB;   // arithmetic, not a branch: the loads stay unconditional
+        const unsigned pixel = (unsigned)((oy * ostr + p.out_oy) * owid + ox * ostr + p.out_ox) * 16u;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int oc = (mg * MT + mi) * 32 + 16 * pr;
+            const unsigned mo = (((unsigned)(oc >> 4) * mask_cb + pixel + 8u * kh2) * 2u) | oob;
+            m.v[gi][pr] = __builtin_amdgcn_raw_buffer_load_b128(rmask, mo, 0, 0);
+        }
+    }
+}
+
 // F16OUT: -1 = the 16-bit output format is a run-time (wave-uniform) choice; 0 / 1 = bf16 / f16 fixed at compile time (the dense-block LDS-DMA
 // kernels: the run-time form converted every element to BOTH formats and selected: 224 of the 628 VALU instructions of the Cout=32 epilogue)
-template <bool IN_F32, int MT, int NT, int STRIDE, int EPI, int F16OUT = -1>
+template <bool IN_F32, int MT, int NT, int STRIDE, int EPI, int F16OUT = -1, bool PRE = false>
 __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 (&acc)[MT][NT], char* smem, float bias_reg, int tid, int mg, int n,
-                                              int oy0, int ox0) {
+                                              int oy0, int ox0, const MaskPre<NT * MT>* pre = nullptr) {
     const int lane = tid & 63, wave = tid >> 6, nn = lane & 31, kh2 = lane >> 5;
     (void)lane;
     // ---- epilogue.  EPI != 0: the set of optional terms is a compile-time constant (the hot dense-block cases, chosen by
@@ -142,7 +171,7 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
     auto issue_loads = [&](int gi, int slot) {
         unsigned eo[4], cbv[4];
         group_addr(gi, eo, cbv);
-        if (has_mask) {
+        if (has_mask && !PRE) {
             if constexpr (WIDE16) {
                 // one 16-byte load per lane and 16-channel plane: lanes 0-31 fetch channels 0-7, lanes 32-63 channels 8-15 of their pixel
                 // (a fully contiguous KiB per instruction); the half-wave exchange back to the MFMA D layout happens after the wait
@@ -219,7 +248,8 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                 if constexpr (WIDE16) {   // wide piece {w0 w1 | w2 w3} -> this lane's two 4-channel groups of the plane
 #pragma unroll
                     for (int pr = 0; pr < 2; ++pr) {
-                        const u32x4 w = mk[slot][2 * pr];
+                        u32x4 w = mk[slot][2 * pr];
+                        if constexpr (PRE) w = pre->v[gi][pr];
                         const auto r0 = __builtin_amdgcn_permlane32_swap(w[0], w[2], false, false);
                         const auto r1 = __builtin_amdgcn_permlane32_swap(w[1], w[3], false, false);
                         mk[slot][2 * pr] = u32x4{r0[0], r1[0], 0u, 0u};
@@ -849,11 +879,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
     __syncthreads();
     TRACE_STAMP(2);
 
+    constexpr bool PRE = EPI == 68 && MT == 1 && !ABL;
+    MaskPre<NT * MT> mpre;
     bf16x8 fb[2][6], fa[2][MT];
     for (int ck = 0; ck < nchunks; ++ck) {
         const char* buf = smem + (ck & 1) * C::BUF_BYTES;
         char* nbuf = smem + ((ck + 1) & 1) * C::BUF_BYTES;
         const bool more = ck + 1 < nchunks;
+        if constexpr (PRE) {
+            if (!more) mask_prefetch<MT, NT>(p, mpre, tid, mg, n, oy0, ox0);   // last chunk: the memory pipe is idle, the epilogue finds the mask in registers
+        }
         const int ckn = ck + 1 + rot < nchunks ? ck + 1 + rot : ck + 1 + rot - nchunks;  // global index of the next chunk
         if (ck == 2) TRACE_STAMP(8);
         // step s = kx * 3 + ky; B rows of phase kx live in fb[kx & 1], A of step s in fa[s & 1]
@@ -904,7 +939,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
         if (ck == 2) TRACE_STAMP(11);
     }
     TRACE_STAMP(4);
-    conv_epilogue<false, MT, NT, 1, EPI, F16 ? 1 : 0>(p, acc, smem, bias_reg, tid, mg, n, oy0, ox0);
+    conv_epilogue<false, MT, NT, 1, EPI, F16 ? 1 : 0, PRE>(p, acc, smem, bias_reg, tid, mg, n, oy0, ox0, &mpre);
     TRACE_STAMP(6);
 #ifdef DASR_TRACE
     __builtin_amdgcn_s_waitcnt(0);
