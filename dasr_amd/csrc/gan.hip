@@ -156,6 +156,73 @@ __global__ void bce_logits_kernel(dasr_tensor x, int N, int C, int H, int W, flo
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Relativistic average GAN terms (`ragan: true`, DASR_model.py:240-244,273-275): a, b = logit maps [N][1][H][W] of the two halves,
+//   L = coef * sum_{n,p} [ bce(a - mean_n(b), ta) + bce(b - mean_n(a), tb) ],   mean over the GLOBAL batch (n_glob samples) per pixel.
+// One thread per pixel, three stages so that a data-parallel run can all-reduce the two tiny per-pixel sums in between:
+//   stage 0: sums[0:HW] = sum_n a, sums[HW:2HW] = sum_n b                                      (-> all-reduce SUM)
+//   stage 1: za = a - sums_b / n_glob, zb = b - sums_a / n_glob; loss / score accumulation of the local samples;
+//            part[0:HW] = sum_n (sigmoid(za) - ta), part[HW:2HW] = sum_n (sigmoid(zb) - tb)    (-> all-reduce SUM)
+//   stage 2: ga = gcoef * ((sigmoid(za) - ta) - part_b / n_glob), gb = gcoef * ((sigmoid(zb) - tb) - part_a / n_glob)   (either may be null)
+// ---------------------------------------------------------------------------------------------------
+__global__ void ragan_kernel(dasr_tensor a, dasr_tensor b, int N, int H, int W, int stage, float inv_nglob, float ta, float tb, float coef, float gcoef,
+                             float* __restrict__ sums, float* __restrict__ part, float* loss_acc, float* score_a, float* score_b, float score_coef,
+                             dasr_tensor ga, dasr_tensor gb) {
+    __shared__ float red[4];
+    const int HW = H * W;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    float l = 0.f, sca = 0.f, scb = 0.f;
+    if (p < HW) {
+        const float* ap = (const float*)a.p + (size_t)p * 16;
+        const float* bp = (const float*)b.p + (size_t)p * 16;
+        if (stage == 0) {
+            float sa = 0.f, sb = 0.f;
+            for (int n = 0; n < N; ++n) { sa += ap[(size_t)n * a.n_stride]; sb += bp[(size_t)n * b.n_stride]; }
+            sums[p] = sa;
+            sums[HW + p] = sb;
+        } else {
+            const float ma = sums[p] * inv_nglob, mb = sums[HW + p] * inv_nglob;
+            if (stage == 1) {
+                float qa = 0.f, qb = 0.f;
+                for (int n = 0; n < N; ++n) {
+                    const float av = ap[(size_t)n * a.n_stride], bv = bp[(size_t)n * b.n_stride];
+                    const float za = av - mb, zb = bv - ma;
+                    l += fmaxf(za, 0.f) - za * ta + log1pf(expf(-fabsf(za))) + fmaxf(zb, 0.f) - zb * tb + log1pf(expf(-fabsf(zb)));
+                    qa += 1.f / (1.f + expf(-za)) - ta;
+                    qb += 1.f / (1.f + expf(-zb)) - tb;
+                    sca += av;
+                    scb += bv;
+                }
+                part[p] = qa;
+                part[HW + p] = qb;
+            } else {
+                const float ca = part[p] * inv_nglob, cb = part[HW + p] * inv_nglob;
+                for (int n = 0; n < N; ++n) {
+                    const float za = ap[(size_t)n * a.n_stride] - mb, zb = bp[(size_t)n * b.n_stride] - ma;
+                    if (ga.p) {
+                        f32x4* g = (f32x4*)((float*)ga.p + (size_t)n * ga.n_stride + (size_t)p * 16);
+                        g[0] = f32x4{gcoef * ((1.f / (1.f + expf(-za)) - ta) - cb), 0.f, 0.f, 0.f};
+                        g[1] = g[2] = g[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    if (gb.p) {
+                        f32x4* g = (f32x4*)((float*)gb.p + (size_t)n * gb.n_stride + (size_t)p * 16);
+                        g[0] = f32x4{gcoef * ((1.f / (1.f + expf(-zb)) - tb) - ca), 0.f, 0.f, 0.f};
+                        g[1] = g[2] = g[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
+        }
+    }
+    if (stage == 1) {
+        const float tl = block_sum_256(l, red), t1 = block_sum_256(sca, red), t2 = block_sum_256(scb, red);
+        if (threadIdx.x == 0) {
+            if (loss_acc) atomicAdd(loss_acc, tl * coef);
+            if (score_a) atomicAdd(score_a, t1 * score_coef);
+            if (score_b) atomicAdd(score_b, t2 * score_coef);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Haar DWT level 1 on C (<=5) channels of plane 0: LL -> ll plane (C ch), [LH|HL|HH] -> hc plane (3C ch).
 // Convention (oracle/nets.py::HaarDWT): block [[a,b],[c,d]]: LL=(a+b+c+d)/2, LH=(a+b-c-d)/2, HL=(a-b+c-d)/2, HH=(a-b-c+d)/2
 // norm: LL*0.5, Hc*0.5+0.5 (DASR_model.py:442-452).  Thread per output pixel.
@@ -636,6 +703,15 @@ extern "C" int dasr_bce_logits(dasr_tensor x, int32_t N, int32_t C, int32_t H, i
     if (total <= 0 || C > 16) return DASR_EINVAL;
     DASR_LAUNCH(bce_logits_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, target, coef, gcoef, loss_acc,
                        score_acc, score_coef, grad);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_ragan(dasr_tensor a, dasr_tensor b, int32_t N, int32_t H, int32_t W, int32_t stage, int32_t n_glob, float ta, float tb, float coef,
+                          float gcoef, float* sums, float* part, float* loss_acc, float* score_a, float* score_b, float score_coef, dasr_tensor ga,
+                          dasr_tensor gb, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0 || n_glob < N || stage < 0 || stage > 2 || !a.p || !b.p || !sums || (stage > 0 && !part)) return DASR_EINVAL;
+    DASR_LAUNCH(ragan_kernel, dim3(nblk((long long)H * W)), dim3(256), 0, as_stream(stream), a, b, N, H, W, stage, 1.f / (float)n_glob, ta, tb, coef, gcoef,
+                sums, part, loss_acc, score_a, score_b, score_coef, ga, gb);
     return (int)hipGetLastError();
 }
 

@@ -75,8 +75,7 @@ class DASR_Model(BaseModel):
             raise NotImplementedError('adaptive_weights (DASR_Adaptive_Model) is outside the hot path')
         if t['gan_type'] != 'vanilla':
             raise NotImplementedError('GAN type [{:s}] is not found'.format(str(t['gan_type'])))
-        if t['ragan']:
-            raise NotImplementedError('ragan=True couples samples across the batch; not on the data-parallel hot path')
+        self.ragan = bool(t['ragan'])   # relativistic average GAN: per-pixel batch means of the logits (all-reduced across data-parallel ranks)
         self.l_gan_H_target_w = t['gan_H_target'] or 0
         self.l_gan_H_source_w = (t['gan_H_source'] or 0) if self.is_train else 0
         self.netG = _define_G(opt, self.device)
@@ -197,6 +196,8 @@ class DASR_Model(BaseModel):
             P.g.set_grad_scale(scale)
             P.set_d_grad_scale(scale)
         if do_g:
+            if self.ragan:
+                self._run_ragan(P.rg, P, dp_on)   # relativistic GAN terms of the generator loss (value + dL/dlogits of the fake halves)
             P.g_loss_bwd.run()            # D / VGG / fs data-gradients into dL/dSR
             gG = self.netG.params.grad
             if not dp_on:
@@ -209,12 +210,16 @@ class DASR_Model(BaseModel):
             self.optimizer_G.step(self.schedulers[0].get_lr())
             self.netG.repack()
         if do_d:
+            if self.ragan:
+                self._run_ragan(P.rd, P, dp_on)
             P.d_step.run()                # BCE(real,1), BCE(fake,0), D backward with weight gradients
             if dp_on:
                 self.dp.allreduce_mean(self.netD_target.params.grad)
             self.optimizer_D_target.step(self._lr_of(self.optimizer_D_target))
             self.netD_target.repack()
         if do_ds:                         # source domain (DASR_model.py:287-303)
+            if self.ragan:
+                self._run_ragan(P.rs, P, dp_on)
             P.ds_step.run()
             if dp_on:
                 self.dp.allreduce_mean(self.netD_source.params.grad)
@@ -223,6 +228,17 @@ class DASR_Model(BaseModel):
         self.fake_H = P.g.read_output()
         self._acc_snapshot = (self.acc, do_g, do_d, do_ds)
         self._pix_div = getattr(P, 'pix_log_div', 1.0)
+
+    def _run_ragan(self, lists, P, dp_on):
+        """stage 0 -> (all-reduce of the per-pixel logit sums) -> stage 1 -> (all-reduce of the per-pixel sigmoid sums) -> stage 2: the batch
+        means of the relativistic loss are means over the GLOBAL batch, as in the reference's single-process nn.DataParallel"""
+        for stage in range(3):
+            if not lists[stage].ops:
+                return
+            lists[stage].run()
+            if dp_on and stage < 2:
+                for sums, part in P.r_bufs:
+                    self.dp.all_reduce_here(sums if stage == 0 else part)
 
     def get_current_log(self):
         """one device->host sync, only when the caller logs (the reference syncs 5-9 times every step, App. C-8)"""
@@ -291,6 +307,21 @@ class DASR_Model(BaseModel):
             self.save_network(self.netD_target, 'D_target', iter_step)
         if self.netD_source is not None:
             self.save_network(self.netD_source, 'D_source', iter_step)
+
+
+def _ragan_ops(lists, a, b, n, H, W, n_glob, ta, tb, coef, gcoef, sums, part, p_loss, p_sa, p_sb, score_coef, ga, gb):
+    """the three dasr_ragan stages of one relativistic loss, appended to lists[0..2] (include/dasr_hip.h)"""
+    import struct
+    for stage in range(3):
+        o = _op(_lib.OP_RAGAN)
+        o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = a, b, n, H, W, stage, n_glob
+        o.f[0], o.f[1], o.f[2], o.f[3] = ta, tb, coef, gcoef
+        o.p[0], o.p[1], o.p[2], o.p[3] = sums.data_ptr(), part.data_ptr(), p_loss, p_sa
+        o.l[0] = p_sb or 0
+        o.l[1] = struct.unpack('<I', struct.pack('<f', score_coef))[0]
+        o.t[2], o.t[3] = ga, gb
+        lists[stage].add(o)
+    lists[0].keep += [sums, part]
 
 
 class _StepPlan:
@@ -413,17 +444,46 @@ class _StepPlan:
             fwd.extend(d.fwd)
             lg = d.logits
             cnt = float(n * 1 * lg.H * lg.W)
-            o = add(fwd, _op(_lib.OP_BCE))
-            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = lg.view(), n, 1, lg.H, lg.W
-            o.f[0], o.f[1], o.f[2], o.p[0], o.p[1], o.f[3], o.t[1] = 1.0, 1.0 / cnt, float(m.l_gan_H_target_w) / cnt, acc + 4 * A_GAN, None, 0.0, d.g_logits.view()
+            if not m.ragan:
+                o = add(fwd, _op(_lib.OP_BCE))
+                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = lg.view(), n, 1, lg.H, lg.W
+                o.f[0], o.f[1], o.f[2], o.p[0], o.p[1], o.f[3], o.t[1] = 1.0, 1.0 / cnt, float(m.l_gan_H_target_w) / cnt, acc + 4 * A_GAN, None, 0.0, d.g_logits.view()
         if ds is not None:   # l_g_gan_source_Hf = w_src * BCE(D_s(fake_s), 1): value logged WITH the weight (DASR_model.py:258,316)
             fwd.extend(ds.fwd)
             lg = ds.logits
             cnt = float(n * 1 * lg.H * lg.W)
-            o = add(fwd, _op(_lib.OP_BCE))
-            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = lg.view(), n, 1, lg.H, lg.W
-            o.f[0], o.f[1], o.f[2], o.p[0], o.p[1], o.f[3], o.t[1] = 1.0, float(m.l_gan_H_source_w) / cnt, float(m.l_gan_H_source_w) / cnt, \
-                acc + 4 * A_GAN_SRC, None, 0.0, ds.g_logits.view()
+            if not m.ragan:
+                o = add(fwd, _op(_lib.OP_BCE))
+                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = lg.view(), n, 1, lg.H, lg.W
+                o.f[0], o.f[1], o.f[2], o.p[0], o.p[1], o.f[3], o.t[1] = 1.0, float(m.l_gan_H_source_w) / cnt, float(m.l_gan_H_source_w) / cnt, \
+                    acc + 4 * A_GAN_SRC, None, 0.0, ds.g_logits.view()
+        # relativistic average form (`ragan`, DASR_model.py:240-244,252-256): three stages per loss, the per-pixel batch sums are all-reduced between
+        # them under data parallelism (DASR_Model._run_ragan).  Weights: target w * (..)/2 enters the total times w AGAIN (w^2 on the gradient, w on
+        # the logged value); source w * (..)/2 is added as is.
+        self.rg = [OpList(), OpList(), OpList()]
+        self.rd = [OpList(), OpList(), OpList()]
+        self.rs = [OpList(), OpList(), OpList()]
+        self.r_bufs = []
+        if m.ragan:
+            world = m.dp.world if (getattr(m, 'dp', None) is not None and m.dp.active) else 1
+            for D_, slot_g, w_log, w_grad, lists_d, slots_d in (
+                    (d, A_GAN, m.l_gan_H_target_w, m.l_gan_H_target_w * m.l_gan_H_target_w, self.rd, (A_DREAL, A_SREAL, A_SFAKE)),
+                    (ds, A_GAN_SRC, m.l_gan_H_source_w, m.l_gan_H_source_w, self.rs, (A_DREAL_SRC, A_SREAL_SRC, A_SFAKE_SRC))):
+                if D_ is None:
+                    continue
+                lg = D_.logits
+                hw = lg.H * lg.W
+                cnt = float(n * hw)
+                sums, part = torch.zeros(2 * hw, dtype=torch.float32, device=dev), torch.zeros(2 * hw, dtype=torch.float32, device=dev)
+                self.r_bufs.append((sums, part))
+                fake, real = lg.view(), _nview(lg, n)
+                g_fake, g_real = D_.g_logits.view(), _nview(D_.g_logits, n)
+                # generator: a = fake (target 1, gradient), b = real (target 0, detached)
+                _ragan_ops(self.rg, fake, real, n, lg.H, lg.W, n * world, 1.0, 0.0, 0.5 * float(w_log) / cnt, 0.5 * float(w_grad) / cnt, sums, part,
+                           acc + 4 * slot_g, None, None, 0.0, g_fake, NULL_T)
+                # discriminator: a = real (target 1), b = fake (target 0), both carry gradient; the whole loss goes to the "real" slot
+                _ragan_ops(lists_d, real, fake, n, lg.H, lg.W, n * world, 1.0, 0.0, 0.5 / cnt, 0.5 / cnt, sums, part,
+                           acc + 4 * slots_d[0], acc + 4 * slots_d[1], acc + 4 * slots_d[2], 1.0 / cnt, g_real, g_fake)
         self.fwd = fwd
 
         # ---- generator-loss backward: everything that lands in dL/dSR ----------------------------------------------------
@@ -466,7 +526,7 @@ class _StepPlan:
         if d is not None:
             lg = d.logits
             cnt = float(n * lg.H * lg.W)
-            for n0, target, a_loss, a_score in ((n, 1.0, A_DREAL, A_SREAL), (0, 0.0, A_DFAKE, A_SFAKE)):
+            for n0, target, a_loss, a_score in (() if m.ragan else ((n, 1.0, A_DREAL, A_SREAL), (0, 0.0, A_DFAKE, A_SFAKE))):
                 o = add(dstep, _op(_lib.OP_BCE))
                 o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = _nview(lg, n0), n, 1, lg.H, lg.W
                 o.f[0], o.f[1], o.f[2] = target, 0.5 / cnt, 0.5 / cnt
@@ -478,7 +538,7 @@ class _StepPlan:
         if self.ds is not None:
             lg = self.ds.logits
             cnt = float(n * lg.H * lg.W)
-            for n0, target, a_loss, a_score in ((n, 1.0, A_DREAL_SRC, A_SREAL_SRC), (0, 0.0, A_DFAKE_SRC, A_SFAKE_SRC)):
+            for n0, target, a_loss, a_score in (() if m.ragan else ((n, 1.0, A_DREAL_SRC, A_SREAL_SRC), (0, 0.0, A_DFAKE_SRC, A_SFAKE_SRC))):
                 o = add(sstep, _op(_lib.OP_BCE))
                 o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = _nview(lg, n0), n, 1, lg.H, lg.W
                 o.f[0], o.f[1], o.f[2] = target, 0.5 / cnt, 0.5 / cnt

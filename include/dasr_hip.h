@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DASR_ABI_VERSION 5
+#define DASR_ABI_VERSION 6
 #define DASR_EINVAL (-22)
 
 typedef struct {
@@ -213,6 +213,14 @@ int dasr_inorm_lrelu_bwd(dasr_tensor a, dasr_tensor ga, int32_t N, int32_t C, in
  * score_acc += score_coef*sum(x) (the disc_Score log), grad = gcoef*(sigmoid(x)-target) */
 int dasr_bce_logits(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, float target, float coef, float gcoef,
                     float* loss_acc, float* score_acc, float score_coef, dasr_tensor grad, void* stream);
+/* relativistic average GAN loss (`ragan: true`, DASR_model.py:240-244,273-275): a, b = logit maps [N][1][H][W] of the two halves,
+ *   L = coef * sum_{n,p} [ bce(a - mean_n(b), ta) + bce(b - mean_n(a), tb) ],  means per pixel over the GLOBAL batch (n_glob >= N samples).
+ * Three stages so that data-parallel ranks can all-reduce (SUM) the two tiny per-pixel buffers in between (2*H*W floats each):
+ *   stage 0: sums = [sum_n a ; sum_n b];   stage 1: loss_acc += coef * local loss, score_a/b += score_coef * sum a / b,
+ *   part = [sum_n (sigmoid(za) - ta) ; sum_n (sigmoid(zb) - tb)];   stage 2: ga / gb (optional) = gcoef * d(sum)/da, /db incl. the mean terms */
+int dasr_ragan(dasr_tensor a, dasr_tensor b, int32_t N, int32_t H, int32_t W, int32_t stage, int32_t n_glob, float ta, float tb, float coef,
+               float gcoef, float* sums, float* part, float* loss_acc, float* score_a, float* score_b, float score_coef, dasr_tensor ga,
+               dasr_tensor gb, void* stream);
 /* Haar DWT level 1 as used by DASR_Model.wavelet_s (DASR_model.py:442-452): LL (C ch) and [LH|HL|HH] (3C ch), optional
  * norm (LL*0.5, Hc*0.5+0.5); and its adjoint (accumulating into gx).  H2, W2 = output size. */
 int dasr_dwt_fwd(dasr_tensor x, int32_t N, int32_t C, int32_t H2, int32_t W2, int32_t norm, dasr_tensor ll, dasr_tensor hc, void* stream);
@@ -301,7 +309,7 @@ enum { DASR_OP_CONV = 1, DASR_OP_WGRAD = 2, DASR_OP_WGRAD_REDUCE = 3, DASR_OP_PA
        /* scheduling ops: p[0] = event from dasr_event_create / a hipStream_t (NULL: back to the stream dasr_run_ops was called with) */
        DASR_OP_EVENT_RECORD = 28, DASR_OP_STREAM_WAIT = 29, DASR_OP_SET_STREAM = 30,
        DASR_OP_CVT_F16 = 31, DASR_OP_DOWNSUM_F16 = 32, DASR_OP_PIXSHUF = 33, DASR_OP_PIXUNSHUF = 34,
-       DASR_OP_LPIPS_S2D = 35, DASR_OP_MAXPOOL3 = 36, DASR_OP_MAXPOOL3_BWD = 37, DASR_OP_LPIPS_HEAD = 38 };
+       DASR_OP_LPIPS_S2D = 35, DASR_OP_MAXPOOL3 = 36, DASR_OP_MAXPOOL3_BWD = 37, DASR_OP_LPIPS_HEAD = 38, DASR_OP_RAGAN = 39 };
 
 typedef struct {
     int32_t op;  int32_t i[8];  float f[4];  int64_t l[4];  void* p[4];  dasr_tensor t[5];

@@ -27,6 +27,8 @@ CASES = OrderedDict([
     ('dasr_lpips_wavelet_nf32_nb2_n2_32', dict(kind='dasr', nf=32, nb=2, n=2, lr=32, fs='wavelet', d_in_nc=9, fea='LPIPS')),
     # source-domain discriminator (gan_H_source > 0, which_model_pairD 'discriminator_patch' as in the shipped aim2019 JSON): DASR_model.py:250-259,287-303
     ('dasr_srcD_wavelet_nf32_nb2_n2_32', dict(kind='dasr', nf=32, nb=2, n=2, lr=32, fs='wavelet', d_in_nc=9, gan_src=0.02)),
+    # relativistic average GAN (`ragan: true`, DASR_model.py:240-244,252-256,273-275,291-293) on both discriminators, n = 3 so that the batch means matter
+    ('dasr_ragan_wavelet_nf32_nb1_n3_32', dict(kind='dasr', nf=32, nb=1, n=3, lr=32, fs='wavelet', d_in_nc=9, gan_src=0.02, ragan=True)),
 ])
 
 
@@ -64,7 +66,7 @@ def make_opt(case):
                             'act_type': 'leakyrelu', 'mode': 'CNA', 'nf': 64, 'in_nc': c['d_in_nc'], 'n_layers': 2}
         opt['train'].update({'lr_D': 1e-4, 'weight_decay_D': 0, 'beta1_D': 0.9, 'fs': c['fs'], 'fs_kernel_size': 9,
                              'norm': True, 'sup_LL': True, 'pixel_LL_weight': 1, 'feature_criterion': c.get('fea', 'l1'),
-                             'feature_weight': 1, 'gan_type': 'vanilla', 'ragan': False, 'gan_H_target': 0.01,
+                             'feature_weight': 1, 'gan_type': 'vanilla', 'ragan': bool(c.get('ragan', False)), 'gan_H_target': 0.01,
                              'gan_H_source': c.get('gan_src', 0), 'G_update_inter': 1, 'D_update_inter': 1})
     return opt
 

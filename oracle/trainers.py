@@ -56,6 +56,7 @@ class DASRTrainer:
         self.multiweights = opt.get('multiweights')
         self.l_gan_w = t['gan_H_target']
         self.l_gan_src_w = _opt(t, 'gan_H_source', 0)
+        self.ragan = bool(t.get('ragan'))
         self.netG = netG if netG is not None else nets.RRDBNet(g['in_nc'], g['out_nc'], g['nf'], g['nb'], opt['scale'])
         if netG is None:
             nets.init_kaiming_(self.netG, 0.1)
@@ -169,11 +170,20 @@ class DASRTrainer:
                 self.log['loss/l_g_fea'] = l_fea.item()
             if self.l_gan_w > 0:
                 pred = self.netD(fake_Hc[n:])
-                l_gan = self._bce(pred, 1.0)
+                if self.ragan:   # DASR_model.py:240-244: relativistic average form; note the weight enters twice (here and in the total)
+                    pr = self.netD(real_Hc[n:]).detach()
+                    l_gan = self.l_gan_w * (self._bce(pred - pr.mean(0, keepdim=True), 1.0) + self._bce(pr - pred.mean(0, keepdim=True), 0.0)) / 2
+                else:
+                    l_gan = self._bce(pred, 1.0)
                 tot = tot + self.l_gan_w * l_gan
                 self.log['loss/l_g_gan_target_Hf'] = l_gan.item()
             if self.l_gan_src_w > 0:   # DASR_model.py:250-259,316: the WEIGHTED value is what is added and logged
-                l_src = self.l_gan_src_w * self._bce(self.netD_src(fake_Hc[:n]), 1.0)
+                ps = self.netD_src(fake_Hc[:n])
+                if self.ragan:   # DASR_model.py:252-256
+                    pr = self.netD_src(real_Hc[:n]).detach()
+                    l_src = self.l_gan_src_w * (self._bce(ps - pr.mean(0, keepdim=True), 1.0) + self._bce(pr - ps.mean(0, keepdim=True), 0.0)) / 2
+                else:
+                    l_src = self.l_gan_src_w * self._bce(ps, 1.0)
                 tot = tot + l_src
                 self.log['loss/l_g_gan_source_H'] = l_src.item()
             self.opt_G.zero_grad()
@@ -182,7 +192,10 @@ class DASRTrainer:
         if step % self.D_int == 0 and self.l_gan_w > 0:
             pr = self.netD(real_Hc[n:].detach())
             pf = self.netD(fake_Hc[n:].detach())
-            l_d = (self._bce(pr, 1.0) + self._bce(pf, 0.0)) / 2
+            if self.ragan:   # DASR_model.py:273-275
+                l_d = (self._bce(pr - pf.mean(0, keepdim=True), 1.0) + self._bce(pf - pr.mean(0, keepdim=True), 0.0)) / 2
+            else:
+                l_d = (self._bce(pr, 1.0) + self._bce(pf, 0.0)) / 2
             self.opt_D.zero_grad()
             l_d.backward()
             self.opt_D.step()
@@ -192,7 +205,10 @@ class DASRTrainer:
         if step % self.D_int == 0 and self.l_gan_src_w > 0:   # DASR_model.py:287-303,327-330
             pr = self.netD_src(real_Hc[:n].detach())
             pf = self.netD_src(fake_Hc[:n].detach())
-            l_d = (self._bce(pf, 0.0) + self._bce(pr, 1.0)) / 2
+            if self.ragan:   # DASR_model.py:291-293
+                l_d = (self._bce(pf - pr.mean(0, keepdim=True), 0.0) + self._bce(pr - pf.mean(0, keepdim=True), 1.0)) / 2
+            else:
+                l_d = (self._bce(pf, 0.0) + self._bce(pr, 1.0)) / 2
             self.opt_D_src.zero_grad()
             l_d.backward()
             self.opt_D_src.step()

@@ -29,6 +29,8 @@ def _worker(rank, world, port, case, out, streams):
     m.netG.load_state_dict(sd)
     if kind == 'dasr':
         m.netD_target.load_state_dict(fixtures.seeded_state_dict(m.netD_target.state_dict(), 2, 1.0))
+        if m.netD_source is not None:
+            m.netD_source.load_state_dict(fixtures.seeded_state_dict(m.netD_source.state_dict(), 3, 1.0))
     if dp:
         m.dp = dp
         for net in m.networks():
@@ -45,16 +47,21 @@ def _worker(rank, world, port, case, out, streams):
     res = {'G': m.netG.state_dict(), 'log': dict(m.get_current_log())}
     if kind == 'dasr':
         res['D'] = m.netD_target.state_dict()
+        if m.netD_source is not None:
+            res['D2'] = m.netD_source.state_dict()
     torch.save(res, out % (world, rank))
     if dp:
         dp.barrier()
 
 
 B16 = dict(kind='sr', nf=64, nb=2, n=16, lr=32)   # 8 crops per rank -> two sub-batch replicas of 4 under DASR_STREAMS=2
+# relativistic GAN + source-domain discriminator, 2 + 2 samples: the per-pixel batch means of the logits must be GLOBAL means (two tiny
+# all-reduces per loss evaluation), or the two-rank step would differ from the full-batch step
+RAGAN4 = dict(kind='dasr', nf=32, nb=1, n=4, lr=32, fs='wavelet', d_in_nc=9, gan_src=0.02, ragan=True)
 
 
-@pytest.mark.parametrize('case,streams', [('sr_nf64_nb2_b2_32', 1), ('dasr_wavelet_nf32_nb2_n2_32', 1), (B16, 1), (B16, 2)],
-                         ids=['sr_b2-1stream', 'dasr_n2-1stream', 'sr_b16-1stream', 'sr_b16-2streams'])
+@pytest.mark.parametrize('case,streams', [('sr_nf64_nb2_b2_32', 1), ('dasr_wavelet_nf32_nb2_n2_32', 1), (B16, 1), (B16, 2), (RAGAN4, 1)],
+                         ids=['sr_b2-1stream', 'dasr_n2-1stream', 'sr_b16-1stream', 'sr_b16-2streams', 'dasr_ragan_srcD_n4'])
 def test_two_rank_step_equals_full_batch_step(case, streams, tmp_path, margins):
     """streams = 2: the DP x two-sub-batch-stream combination (replica gradient buffers summed, then reduced over the ranks);
     the single-process side runs the same DASR_STREAMS so that both schedules are compared like for like"""
@@ -67,15 +74,18 @@ def test_two_rank_step_equals_full_batch_step(case, streams, tmp_path, margins):
     mp.spawn(_worker, args=(2, port + 1, case, out, streams), nprocs=2, join=True)
     full = torch.load(out % (1, 0))
     r0, r1 = torch.load(out % (2, 0)), torch.load(out % (2, 1))
-    for net in [k for k in ('G', 'D') if k in full]:
+    for net in [k for k in ('G', 'D', 'D2') if k in full]:
         for k, v in full[net].items():
             assert torch.equal(r0[net][k], r1[net][k]), (net, k)  # replicas stay bit-identical
+            if isinstance(case, dict) and case.get('ragan') and k == 'model.8.bias':
+                continue   # relativistic loss: the true gradient of the last bias is 0, Adam turns its rounding noise into +-lr steps
             d = (r0[net][k] - v).abs().max().item()
             assert d <= 3.2e-4, (net, k, d)                      # Adam: sign flips of ~0 gradients move a weight by 2*lr
             assert ((r0[net][k] - v).abs() > 2e-5).float().mean().item() < 0.02, (net, k)
-    dmax = max((r0[n_][k] - v).abs().max().item() for n_ in full if n_ in ('G', 'D') for k, v in full[n_].items())
+    dmax = max((r0[n_][k] - v).abs().max().item() for n_ in full if n_ in ('G', 'D', 'D2') for k, v in full[n_].items()
+               if not (isinstance(case, dict) and case.get('ragan') and k == 'model.8.bias'))
     margins('DP 2 ranks vs full batch (%s, %d streams): max |dw| after 2 Adam steps %.2e (bound 3.2e-4)' % (
-        case if isinstance(case, str) else 'sr_nf64_nb2_b16_32', streams, dmax))
+        case if isinstance(case, str) else ('sr_nf64_nb2_b16_32' if case['kind'] == 'sr' else 'dasr_ragan_srcD_n4'), streams, dmax))
 
 
 def _rccl_worker(rank, port, out, streams, use_dp, native=0):
