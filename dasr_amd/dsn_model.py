@@ -24,7 +24,7 @@ import torch
 from . import _lib
 from .engine import (BTensor, ParamStore, PackRegistry, OpList, WgradGroup, Workspace, conv_op, ceil_div, NULL_T, Op, Tensor,
                      ensure_runtime_ready, _stream)
-from .gan_nets import NLayerDiscriminatorHIP, VGGFeatureHIP, VGG16_CFG, fsd_spec
+from .gan_nets import NLayerDiscriminatorHIP, VGGFeatureHIP, VGG16_CFG, fsd_spec, dsn_nld_spec
 from .models import AdamHIP
 from .dasr_model import gaussian_kernel2d, vgg_random_state_dict, _nview
 
@@ -258,8 +258,11 @@ class DSNModel:
         self.opt = o
         ensure_runtime_ready()
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
-        if o['upscale_factor'] != 4 or o['discriminator'].lower() != 'fsd' or o['norm_layer'] not in ('Instance', 'Batch'):
-            raise NotImplementedError('DSN on MI355X: De_resnet x4 + FSD discriminator with Instance (training + inference) or Batch (inference) norm')
+        self.d_arch = o['discriminator'].lower()
+        if self.d_arch not in ('fsd', 'nld_s1', 'nld_s2'):
+            raise NotImplementedError('Discriminator architecture [{:s}] not recognized'.format(o['discriminator']))
+        if o['upscale_factor'] != 4 or o['norm_layer'] not in ('Instance', 'Batch') or (self.d_arch != 'fsd' and o['norm_layer'] != 'Instance'):
+            raise NotImplementedError('DSN on MI355X: De_resnet x4 + FSD / nld_s1 / nld_s2 discriminator with Instance norm (FSD also Batch norm at inference)')
         # norm_layer 'Batch': inference only (translate / ddm_of): BatchNorm in eval mode is folded into the convs at load time
         self.bn_eval = o['norm_layer'] == 'Batch'
         self.netF = None
@@ -283,8 +286,12 @@ class DSNModel:
         self.k = o['kernel_size']
         self.netG = DeResnetHIP(o['n_res_blocks'], device=self.device)
         nc = 9 if self.filter == 'wavelet' else 3
-        self.netD = NLayerDiscriminatorHIP(nc, device=self.device, spec_layers=fsd_spec(nc, self.k if self.filter == 'gau' else None,
-                                                                                        norm='BatchEval' if self.bn_eval else 'Instance'))
+        gk = self.k if self.filter == 'gau' else None
+        if self.d_arch == 'fsd':
+            spec_layers = fsd_spec(nc, gk, norm='BatchEval' if self.bn_eval else 'Instance')
+        else:   # codes/DSN/model.py:84-89: NLayerDiscriminator(n_layers=2) with stride 1 / 2
+            spec_layers = dsn_nld_spec(nc, 1 if self.d_arch == 'nld_s1' else 2, gk)
+        self.netD = NLayerDiscriminatorHIP(nc, device=self.device, spec_layers=spec_layers)
         # default nn init, G first then D (codes/DSN/train.py:124-135 under torch.manual_seed(0))
         self.netG.load_state_dict(default_init_state(self.netG.spec))
         self.netD.load_state_dict(default_init_state(self.netD.spec))
@@ -558,6 +565,8 @@ class _InferPlan:
     """with_g: (H, W) is the HR input of the generator and the discriminator sees G's output; else (H, W) is an LR image fed to D"""
 
     def __init__(self, m, N, H, W, with_g=True):
+        if m.d_arch != 'fsd':
+            raise NotImplementedError('domain-distance maps (create_dataset_modified.py:108-121) are built for the FSD discriminator only')
         dev = m.device
         h, w = (H // 4, W // 4) if with_g else (H, W)
         wav = m.filter == 'wavelet'

@@ -4,7 +4,7 @@ Same flags and defaults as the reference's argparse block (train.py:24-72) and t
 DSNModel.iteration(hr, bicubic_lr, real_lr); schedulers step once per epoch (train.py:287-288); every
 `save_model_interval` epochs the `.tar` checkpoint dict of train.py:357-376 is written to
 <save_path>/checkpoints/iteration_<n>.tar and last_iteration.tar.  Accepted-but-unsupported choices fail the way the
-reference does for unknown strings (NotImplementedError): --generator DSGAN, --discriminator nld_s1/nld_s2, --ragan,
+reference does for unknown strings (NotImplementedError): --generator DSGAN, --ragan,
 --wgan, --norm_layer Batch, --lpips_rot_flip.  --per_type LPIPS (the reference default) runs LPIPS(alex) with weights from --lpips_alexnet /
 --lpips_lin (seeded and logged when absent: they cannot be downloaded offline).  Data: the PIL/torchvision loaders
 (data_loader.py) stay on the reference's side of the boundary; any iterable of (hr, bicubic_lr, real_lr) tuples works, and
@@ -72,7 +72,7 @@ def build_parser():
 def check_supported(o):
     if o.generator != 'DeResnet':
         raise NotImplementedError('Generator model [{:s}] not recognized'.format(o.generator))
-    if o.discriminator.lower() != 'fsd':
+    if o.discriminator.lower() not in ('fsd', 'nld_s1', 'nld_s2'):
         raise NotImplementedError('Discriminator architecture [{:s}] not recognized'.format(o.discriminator))
     if o.lpips_rot_flip:
         raise NotImplementedError('--lpips_rot_flip (random rotations / flips in front of LPIPS, loss.py:97-110) is not on the MI355X path')

@@ -77,6 +77,21 @@ def fsd_spec(input_nc, gaussian_k=None, norm='Instance'):
     return spec, layers
 
 
+def dsn_nld_spec(input_nc, stride, gaussian_k=None, ndf=64):
+    """DSN `--discriminator nld_s1 / nld_s2` (codes/DSN/model.py:84-89,121-170): NLayerDiscriminator(n_layers=2, kw=4, padw=1) with stride 1 or 2
+    in its first two convs; with InstanceNorm `use_bias` is True, so the normalised convs DO carry a bias (it cancels in the norm: zero gradient)"""
+    spec = []
+    if gaussian_k:
+        spec.append(('filter.filter_low.filter.gaussian_filter.weight', (3, 1, gaussian_k, gaussian_k)))
+    layers = []
+    for idx, cin, cout, st, norm, last in ((0, input_nc, ndf, stride, False, False), (2, ndf, 2 * ndf, stride, True, False),
+                                           (5, 2 * ndf, 4 * ndf, 1, True, False), (8, 4 * ndf, 1, 1, False, True)):
+        key = 'net.model.%d.' % idx
+        spec += [(key + 'weight', (cout, cin, 4, 4)), (key + 'bias', (cout,))]
+        layers.append(dict(key=key, cin=cin, cout=cout, stride=st, bias=True, norm=norm, last=last, kh=4, pad=1))
+    return spec, layers
+
+
 # stride-2 4x4 data-gradient = four 2x2 sub-convolutions, one per parity (py, px) of the input pixel:
 # packed tap a (0/1) along one axis -> source tap k and zero-padding of the sub-conv (see DESIGN.md / conv.hip)
 _PARITY_TAPS = {0: (3, 1), 1: (2, 0)}  # parity -> (k for a=0, k for a=1)

@@ -100,10 +100,24 @@ class DiscriminatorBasic(nn.Module):
         return self.net(x)
 
 
-class Discriminator(nn.Module):
-    """Discriminator(D_arch='FSD') with the frequency-separation front end (model.py:60-118); output = sigmoid"""
+class NLayerDiscriminatorDSN(nn.Module):
+    """codes/DSN/model.py:121-170 with n_layers=2, kw=4, padw=1: `use_bias` is True under InstanceNorm; stride 1 (nld_s1) or 2 (nld_s2)"""
 
-    def __init__(self, kernel_size=5, norm_layer='Instance', filter_type='gau'):
+    def __init__(self, input_nc, ndf=64, stride=2):
+        super().__init__()
+        self.model = nn.Sequential(nn.Conv2d(input_nc, ndf, 4, stride, 1), nn.LeakyReLU(0.2),
+                                   nn.Conv2d(ndf, 2 * ndf, 4, stride, 1), nn.InstanceNorm2d(2 * ndf), nn.LeakyReLU(0.2),
+                                   nn.Conv2d(2 * ndf, 4 * ndf, 4, 1, 1), nn.InstanceNorm2d(4 * ndf), nn.LeakyReLU(0.2),
+                                   nn.Conv2d(4 * ndf, 1, 4, 1, 1))
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class Discriminator(nn.Module):
+    """Discriminator(D_arch='FSD' | 'nld_s1' | 'nld_s2') with the frequency-separation front end (model.py:60-118); output = sigmoid"""
+
+    def __init__(self, kernel_size=5, norm_layer='Instance', filter_type='gau', D_arch='FSD'):
         super().__init__()
         self.filter_type = filter_type.lower()
         nc = 3
@@ -114,7 +128,13 @@ class Discriminator(nn.Module):
             nc = 9
         else:
             raise NotImplementedError('Frequency Separation type [{:s}] not recognized'.format(filter_type))
-        self.net = DiscriminatorBasic(nc, norm_layer)
+        if D_arch.lower() == 'fsd':
+            self.net = DiscriminatorBasic(nc, norm_layer)
+        elif D_arch.lower() in ('nld_s1', 'nld_s2'):
+            assert norm_layer == 'Instance'
+            self.net = NLayerDiscriminatorDSN(nc, 64, 1 if D_arch.lower() == 'nld_s1' else 2)
+        else:
+            raise NotImplementedError('Discriminator architecture [{:s}] not recognized'.format(D_arch))
 
     def front(self, x):
         if self.filter_type == 'wavelet':

@@ -23,6 +23,9 @@ DSN_CASES = {
     # --per_type LPIPS (the reference default): its GeneratorLoss builds PerceptualLoss() = LPIPS(alex) with the real linear heads on the
     # stand-in AlexNet(seed 78); 64 x 64 LR images
     'dsn_gau5_inst_b1_256_lpips': dict(filter='gau', k=5, norm='Instance', n=1, crop=256, per='LPIPS'),
+    # --discriminator nld_s1 / nld_s2 (model.py:84-89,121-170): 4x4 convs, stride 1 / 2 in the first two
+    'dsn_wavelet_nld_s2_b2_128': dict(filter='wavelet', k=5, norm='Instance', n=2, crop=128, arch='nld_s2'),
+    'dsn_gau5_nld_s1_b1_128': dict(filter='gau', k=5, norm='Instance', n=1, crop=128, arch='nld_s1'),
 }
 
 
@@ -98,7 +101,7 @@ def main():
             continue
         torch.manual_seed(0)
         G = rmodel.De_resnet(n_res_blocks=8, scale=4)
-        D = rmodel.Discriminator(kernel_size=c['k'], D_arch='FSD', norm_layer=c['norm'], filter_type=c['filter'], cs='cat')
+        D = rmodel.Discriminator(kernel_size=c['k'], D_arch=c.get('arch', 'FSD'), norm_layer=c['norm'], filter_type=c['filter'], cs='cat')
         G.load_state_dict(dsn_state(G.state_dict(), 21, 0.5))
         D.load_state_dict(dsn_state(D.state_dict(), 22, 1.0))
         _cuda = nn.Module.cuda
