@@ -38,15 +38,18 @@ def _op(kind):
     return o
 
 
-def deresnet_spec(n_res_blocks=8):
+def deresnet_spec(n_res_blocks=8, scale=4):
+    """scale 4: De_resnet (codes/DSN/model.py:25-57); scale 1: `Generator` (--generator DSGAN, model.py:7-22): the same net without the two
+    stride-2 convs, applied to the bicubic LR image"""
     spec = [('block_input.0.weight', (64, 3, 3, 3)), ('block_input.0.bias', (64,)), ('block_input.1.weight', (1,))]
     for k in range(n_res_blocks):
         p = 'res_blocks.%d.' % k
         spec += [(p + 'conv1.weight', (64, 64, 3, 3)), (p + 'conv1.bias', (64,)), (p + 'prelu.weight', (1,)),
                  (p + 'conv2.weight', (64, 64, 3, 3)), (p + 'conv2.bias', (64,))]
-    spec += [('down_sample.0.weight', (64, 64, 3, 3)), ('down_sample.0.bias', (64,)), ('down_sample.1.weight', (1,)),
-             ('down_sample.2.weight', (64, 64, 3, 3)), ('down_sample.2.bias', (64,)), ('down_sample.3.weight', (1,)),
-             ('block_output.weight', (3, 64, 3, 3)), ('block_output.bias', (3,))]
+    if scale == 4:
+        spec += [('down_sample.0.weight', (64, 64, 3, 3)), ('down_sample.0.bias', (64,)), ('down_sample.1.weight', (1,)),
+                 ('down_sample.2.weight', (64, 64, 3, 3)), ('down_sample.2.bias', (64,)), ('down_sample.3.weight', (1,))]
+    spec += [('block_output.weight', (3, 64, 3, 3)), ('block_output.bias', (3,))]
     return spec
 
 
@@ -83,9 +86,10 @@ _P3_TAPS = {0: (1, -1), 1: (2, 0)}
 
 
 class DeResnetHIP:
-    def __init__(self, n_res_blocks=8, device='cuda'):
-        self.nb, self.device = n_res_blocks, torch.device(device)
-        self.spec = deresnet_spec(n_res_blocks)
+    def __init__(self, n_res_blocks=8, device='cuda', scale=4):
+        assert scale in (1, 4)
+        self.nb, self.device, self.scale = n_res_blocks, torch.device(device), scale
+        self.spec = deresnet_spec(n_res_blocks, scale)
         self.params = ParamStore(self.spec, self.device)
         self.pack = PackRegistry(self.params)
         P = self.params
@@ -108,8 +112,9 @@ class DeResnetHIP:
         for k in range(n_res_blocks):
             fb('r%d_1' % k, 'res_blocks.%d.conv1.' % k, 64, 64)
             fb('r%d_2' % k, 'res_blocks.%d.conv2.' % k, 64, 64)
-        fb('d0', 'down_sample.0.', 64, 64, 2)
-        fb('d2', 'down_sample.2.', 64, 64, 2)
+        if scale == 4:
+            fb('d0', 'down_sample.0.', 64, 64, 2)
+            fb('d2', 'down_sample.2.', 64, 64, 2)
         fb('out', 'block_output.', 3, 64)
         self.pack.finalize()
         self.plans = {}
@@ -136,16 +141,19 @@ class _GPlan:
         assert H % 4 == 0 and W % 4 == 0
         self.net, self.N = net, N
         dev, P, pack, pk, nb = net.device, net.params, net.pack, net.pk, net.nb
-        H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
+        down = net.scale == 4
+        H2, W2, H4, W4 = (H // 2, W // 2, H // 4, W // 4) if down else (H, W, H, W)
         B = lambda C_, h, w: BTensor(N, C_, h, w, True, dev)
         self.x_nchw = torch.zeros((N, 3, H, W), dtype=torch.float32, device=dev)
         self.fake_nchw = torch.zeros((N, 3, H4, W4), dtype=torch.float32, device=dev)
         self.x_in = B(16, H, W)
         self.s = [B(64, H, W) for _ in range(nb + 1)]
         self.h = [B(64, H, W) for _ in range(nb)]
-        self.d1, self.d2, self.fake = B(64, H2, W2), B(64, H4, W4), B(16, H4, W4)
+        self.fake = B(16, H4, W4)
         self.g_fake, self.gz_out = B(16, H4, W4), B(16, H4, W4)
-        self.g_d2, self.g_d1 = B(64, H4, W4), B(64, H2, W2)
+        if down:
+            self.d1, self.d2 = B(64, H2, W2), B(64, H4, W4)
+            self.g_d2, self.g_d1 = B(64, H4, W4), B(64, H2, W2)
         self.g_s = [B(64, H, W) for _ in range(2)]
         self.g_h = B(64, H, W)
         self.scratch = torch.zeros(1024, dtype=torch.float32, device=dev)
@@ -164,11 +172,13 @@ class _GPlan:
                           slope_ptr=sp(pre + 'prelu.weight'), out_f32=self.h[k].view()))
             f.add(conv_op(pack, pk['r%d_2' % k], self.h[k].view(), True, 64, H, W, H, W, N, bias=sp(pre + 'conv2.bias'),
                           res1=self.s[k].view(), beta1=1.0, out_f32=self.s[k + 1].view()))
-        f.add(conv_op(pack, pk['d0'], self.s[nb].view(), True, 64, H, W, H2, W2, N, bias=sp('down_sample.0.bias'), stride=2, act=1,
-                      slope_ptr=sp('down_sample.1.weight'), out_f32=self.d1.view()))
-        f.add(conv_op(pack, pk['d2'], self.d1.view(), True, 64, H2, W2, H4, W4, N, bias=sp('down_sample.2.bias'), stride=2, act=1,
-                      slope_ptr=sp('down_sample.3.weight'), out_f32=self.d2.view()))
-        f.add(conv_op(pack, pk['out'], self.d2.view(), True, 64, H4, W4, H4, W4, N, bias=sp('block_output.bias'), act=2,
+        if down:
+            f.add(conv_op(pack, pk['d0'], self.s[nb].view(), True, 64, H, W, H2, W2, N, bias=sp('down_sample.0.bias'), stride=2, act=1,
+                          slope_ptr=sp('down_sample.1.weight'), out_f32=self.d1.view()))
+            f.add(conv_op(pack, pk['d2'], self.d1.view(), True, 64, H2, W2, H4, W4, N, bias=sp('down_sample.2.bias'), stride=2, act=1,
+                          slope_ptr=sp('down_sample.3.weight'), out_f32=self.d2.view()))
+        last = self.d2 if down else self.s[nb]
+        f.add(conv_op(pack, pk['out'], last.view(), True, 64, H4, W4, H4, W4, N, bias=sp('block_output.bias'), act=2,
                       out_f32=self.fake.view()))
         o = _op(_lib.OP_B2NCHW)
         o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.p[0] = self.fake.view(), N, 3, H4, W4, self.fake_nchw.data_ptr()
@@ -206,16 +216,19 @@ class _GPlan:
         o = _op(_lib.OP_SIGMOID_BWD)
         o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.t[2] = self.fake.view(), self.g_fake.view(), N, 3, H4, W4, self.gz_out.view()
         b.add(o)
-        wg('block_output.', self.gz_out, self.d2, 3, 64, H4, W4, H4, W4)
-        b.add(conv_op(pack, pk['out_b'], self.gz_out.view(), True, 16, H4, W4, H4, W4, N, mask=self.d2.view(), mask_f32=1,
-                      slope_ptr=sp('down_sample.3.weight'), out_f32=self.g_d2.view()))
-        prelu_grad('down_sample.3.weight', self.d2, self.g_d2, H4, W4)
-        wg('down_sample.2.', self.g_d2, self.d1, 64, 64, H2, W2, H4, W4, stride=2)
-        dgrad_s2('d2', self.g_d2, self.g_d1, self.d1, 'down_sample.1.weight', H2, W2, H4, W4)
-        prelu_grad('down_sample.1.weight', self.d1, self.g_d1, H2, W2)
-        wg('down_sample.0.', self.g_d1, self.s[nb], 64, 64, H, W, H2, W2, stride=2)
+        wg('block_output.', self.gz_out, last, 3, 64, H4, W4, H4, W4)
         gs = self.g_s[0]
-        dgrad_s2('d0', self.g_d1, gs, None, None, H, W, H2, W2)
+        if down:
+            b.add(conv_op(pack, pk['out_b'], self.gz_out.view(), True, 16, H4, W4, H4, W4, N, mask=self.d2.view(), mask_f32=1,
+                          slope_ptr=sp('down_sample.3.weight'), out_f32=self.g_d2.view()))
+            prelu_grad('down_sample.3.weight', self.d2, self.g_d2, H4, W4)
+            wg('down_sample.2.', self.g_d2, self.d1, 64, 64, H2, W2, H4, W4, stride=2)
+            dgrad_s2('d2', self.g_d2, self.g_d1, self.d1, 'down_sample.1.weight', H2, W2, H4, W4)
+            prelu_grad('down_sample.1.weight', self.d1, self.g_d1, H2, W2)
+            wg('down_sample.0.', self.g_d1, self.s[nb], 64, 64, H, W, H2, W2, stride=2)
+            dgrad_s2('d0', self.g_d1, gs, None, None, H, W, H2, W2)
+        else:   # Generator (DSGAN): the output conv reads the residual stream directly (no activation in between)
+            b.add(conv_op(pack, pk['out_b'], self.gz_out.view(), True, 16, H, W, H, W, N, out_f32=gs.view()))
         for k in range(nb - 1, -1, -1):
             pre = 'res_blocks.%d.' % k
             wg(pre + 'conv2.', gs, self.h[k], 64, 64, H, W, H, W)
@@ -250,7 +263,7 @@ class DSNModel:
     """iteration(hr, bicubic_lr, real_lr) / end_epoch() / save(path) / load(path)"""
 
     def __init__(self, opt=None, device=None, **kw):
-        o = dict(n_res_blocks=8, kernel_size=5, filter='gau', norm_layer='Instance', discriminator='FSD', learning_rate=1e-4,
+        o = dict(n_res_blocks=8, kernel_size=5, filter='gau', norm_layer='Instance', discriminator='FSD', generator='DeResnet', learning_rate=1e-4,
                  adam_beta_1=0.5, w_col=1.0, w_tex=0.005, w_per=0.01, per_type='VGG', vgg_path=None, vgg_seed=78, num_epochs=400,
                  num_decay_epochs=150, upscale_factor=4)
         o.update(opt or {})
@@ -284,7 +297,9 @@ class DSNModel:
         if self.filter not in ('gau', 'avg_pool', 'wavelet'):
             raise NotImplementedError('Frequency Separation type [{:s}] not recognized'.format(o['filter']))
         self.k = o['kernel_size']
-        self.netG = DeResnetHIP(o['n_res_blocks'], device=self.device)
+        if o['generator'].lower() not in ('deresnet', 'dsgan'):   # codes/DSN/train.py:124-129
+            raise NotImplementedError('Generator model [{:s}] not recognized'.format(o['generator']))
+        self.netG = DeResnetHIP(o['n_res_blocks'], device=self.device, scale=4 if o['generator'].lower() == 'deresnet' else 1)
         nc = 9 if self.filter == 'wavelet' else 3
         gk = self.k if self.filter == 'gau' else None
         if self.d_arch == 'fsd':
@@ -339,7 +354,7 @@ class DSNModel:
             raise NotImplementedError('training with a BatchNorm discriminator (batch statistics across ranks) is not on the hot path; norm_layer=Instance')
         N, _, H, W = hr.shape
         P = self._plan(N, H, W)
-        P.g.x_nchw.copy_(hr)
+        P.g.x_nchw.copy_(hr if self.netG.scale == 4 else bicubic_lr)
         P.bic_nchw.copy_(bicubic_lr)
         P.real_nchw.copy_(real_lr)
         scale = self.dp.grad_scale if (self.dp is not None and self.dp.active) else 1.0
@@ -428,7 +443,8 @@ class _DSNPlan:
         dev = m.device
         self.m, self.N, self.scale = m, N, 1.0
         h, w = H // 4, W // 4
-        self.g = m.netG.plan(N, H, W)
+        # De_resnet maps the HR crop to LR size; the DSGAN Generator maps the bicubic LR image to an LR image (codes/DSN/train.py:213-217)
+        self.g = m.netG.plan(N, H, W) if m.netG.scale == 4 else m.netG.plan(N, h, w)
         g = self.g
         wav = m.filter == 'wavelet'
         hd, wd = (h // 2, w // 2) if wav else (h, w)
@@ -565,8 +581,8 @@ class _InferPlan:
     """with_g: (H, W) is the HR input of the generator and the discriminator sees G's output; else (H, W) is an LR image fed to D"""
 
     def __init__(self, m, N, H, W, with_g=True):
-        if m.d_arch != 'fsd':
-            raise NotImplementedError('domain-distance maps (create_dataset_modified.py:108-121) are built for the FSD discriminator only')
+        if m.d_arch != 'fsd' or (with_g and m.netG.scale != 4):
+            raise NotImplementedError('dataset generation (create_dataset_modified.py:108-164) is built for De_resnet + the FSD discriminator only')
         dev = m.device
         h, w = (H // 4, W // 4) if with_g else (H, W)
         wav = m.filter == 'wavelet'

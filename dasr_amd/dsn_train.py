@@ -4,7 +4,7 @@ Same flags and defaults as the reference's argparse block (train.py:24-72) and t
 DSNModel.iteration(hr, bicubic_lr, real_lr); schedulers step once per epoch (train.py:287-288); every
 `save_model_interval` epochs the `.tar` checkpoint dict of train.py:357-376 is written to
 <save_path>/checkpoints/iteration_<n>.tar and last_iteration.tar.  Accepted-but-unsupported choices fail the way the
-reference does for unknown strings (NotImplementedError): --generator DSGAN, --ragan,
+reference does for unknown strings (NotImplementedError): --ragan,
 --wgan, --norm_layer Batch, --lpips_rot_flip.  --per_type LPIPS (the reference default) runs LPIPS(alex) with weights from --lpips_alexnet /
 --lpips_lin (seeded and logged when absent: they cannot be downloaded offline).  Data: the PIL/torchvision loaders
 (data_loader.py) stay on the reference's side of the boundary; any iterable of (hr, bicubic_lr, real_lr) tuples works, and
@@ -70,7 +70,7 @@ def build_parser():
 
 
 def check_supported(o):
-    if o.generator != 'DeResnet':
+    if o.generator not in ('DeResnet', 'DSGAN'):
         raise NotImplementedError('Generator model [{:s}] not recognized'.format(o.generator))
     if o.discriminator.lower() not in ('fsd', 'nld_s1', 'nld_s2'):
         raise NotImplementedError('Discriminator architecture [{:s}] not recognized'.format(o.discriminator))
@@ -112,7 +112,7 @@ def main(argv=None, loader=None):
         o.num_epochs, o.iters_per_epoch = min(o.num_epochs, 2), min(o.iters_per_epoch, 3)
     opt = dict(n_res_blocks=o.num_res_blocks, kernel_size=o.kernel_size, filter=o.filter, norm_layer=o.norm_layer, discriminator=o.discriminator,
                learning_rate=o.learning_rate, adam_beta_1=o.adam_beta_1, w_col=o.w_col, w_tex=o.w_tex, w_per=o.w_per if o.use_per_loss else 0.0,
-               per_type=o.per_type, vgg_path=o.vgg_path, lpips_alexnet=o.lpips_alexnet, lpips_lin=o.lpips_lin, num_epochs=o.num_epochs, num_decay_epochs=o.num_decay_epochs,
+               per_type=o.per_type, generator=o.generator, vgg_path=o.vgg_path, lpips_alexnet=o.lpips_alexnet, lpips_lin=o.lpips_lin, num_epochs=o.num_epochs, num_decay_epochs=o.num_decay_epochs,
                upscale_factor=o.upscale_factor)
     model = DSNModel(opt)
     if dp:

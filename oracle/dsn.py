@@ -55,6 +55,22 @@ class DeResnet(nn.Module):
         return torch.sigmoid(self.block_output(self.down_sample(b)))
 
 
+class GeneratorDSGAN(nn.Module):
+    """`Generator` (--generator DSGAN, codes/DSN/model.py:7-22): De_resnet without the stride-2 convs, applied to the bicubic LR image"""
+
+    def __init__(self, n_res_blocks=8):
+        super().__init__()
+        self.block_input = nn.Sequential(nn.Conv2d(3, 64, 3, padding=1), nn.PReLU())
+        self.res_blocks = nn.ModuleList([ResidualBlock(64) for _ in range(n_res_blocks)])
+        self.block_output = nn.Conv2d(64, 3, 3, padding=1)
+
+    def forward(self, x):
+        b = self.block_input(x)
+        for r in self.res_blocks:
+            b = r(b)
+        return torch.sigmoid(self.block_output(b))
+
+
 class _GaussConv(nn.Module):
     def __init__(self, k, pad):
         super().__init__()
@@ -191,7 +207,7 @@ class DSNTrainer:
         self.log = OrderedDict()
 
     def iteration(self, hr, bicubic_lr, real_lr):
-        fake = self.G(hr)
+        fake = self.G(bicubic_lr if isinstance(self.G, GeneratorDSGAN) else hr)   # codes/DSN/train.py:213-217
         real_tex, fake_tex = self.D(real_lr), self.D(fake)
         d_loss = -torch.log(real_tex + 1e-8).mean() - torch.log(1 - fake_tex + 1e-8).mean()
         tex = torch.mean(-torch.log(fake_tex + 1e-8))

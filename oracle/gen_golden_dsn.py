@@ -26,6 +26,8 @@ DSN_CASES = {
     # --discriminator nld_s1 / nld_s2 (model.py:84-89,121-170): 4x4 convs, stride 1 / 2 in the first two
     'dsn_wavelet_nld_s2_b2_128': dict(filter='wavelet', k=5, norm='Instance', n=2, crop=128, arch='nld_s2'),
     'dsn_gau5_nld_s1_b1_128': dict(filter='gau', k=5, norm='Instance', n=1, crop=128, arch='nld_s1'),
+    # --generator DSGAN (model.py:7-22, train.py:213-215): the generator runs on the bicubic LR image
+    'dsn_dsgan_gau5_inst_b2_128': dict(filter='gau', k=5, norm='Instance', n=2, crop=128, gen='DSGAN'),
 }
 
 
@@ -45,7 +47,7 @@ def dsn_batch(c, seed=4321):
 
 def collect(G, D, color_filter, per_net, c, w=(1.0, 0.005, 0.01)):
     hr, bic, real = dsn_batch(c)
-    fake = G(hr)
+    fake = G(bic if c.get('gen') == 'DSGAN' else hr)
     rt, ft = D(real), D(fake)
     d_loss = -torch.log(rt + 1e-8).mean() - torch.log(1 - ft + 1e-8).mean()
     tex = torch.mean(-torch.log(ft + 1e-8))
@@ -100,7 +102,7 @@ def main():
         if only and name not in only:
             continue
         torch.manual_seed(0)
-        G = rmodel.De_resnet(n_res_blocks=8, scale=4)
+        G = rmodel.Generator(n_res_blocks=8) if c.get('gen') == 'DSGAN' else rmodel.De_resnet(n_res_blocks=8, scale=4)
         D = rmodel.Discriminator(kernel_size=c['k'], D_arch=c.get('arch', 'FSD'), norm_layer=c['norm'], filter_type=c['filter'], cs='cat')
         G.load_state_dict(dsn_state(G.state_dict(), 21, 0.5))
         D.load_state_dict(dsn_state(D.state_dict(), 22, 1.0))

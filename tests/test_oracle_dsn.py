@@ -15,7 +15,7 @@ def test_dsn_oracle_matches_reference_fixture(case, golden_dir):
     torch.set_num_threads(8)
     c = DSN_CASES[case]
     ref = np.load(os.path.join(golden_dir, case + '.npz'))
-    G = dsn.DeResnet()
+    G = dsn.GeneratorDSGAN() if c.get('gen') == 'DSGAN' else dsn.DeResnet()
     D = dsn.Discriminator(c['k'], c['norm'], c['filter'], D_arch=c.get('arch', 'FSD'))
     assert list(G.state_dict().keys()) == list(ref['G_keys'])
     assert list(D.state_dict().keys()) == list(ref['D_keys'])
