@@ -66,6 +66,7 @@ OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_DOWNSUM, OP_AXPBY, OP_FILL, OP_L
  OP_SET_STREAM) = range(11, 31)
 OP_CVT_F16, OP_DOWNSUM_F16, OP_PIXSHUF, OP_PIXUNSHUF = 31, 32, 33, 34
 OP_LPIPS_S2D, OP_MAXPOOL3, OP_MAXPOOL3_BWD, OP_LPIPS_HEAD, OP_RAGAN = 35, 36, 37, 38, 39
+OP_BNORM_FWD, OP_BNORM_BWD, OP_BNORM_RUNNING = 40, 41, 42
 
 _SIGS = {
     'dasr_conv': [C.POINTER(ConvParams), c_vp],
@@ -116,6 +117,9 @@ _SIGS = {
     'dasr_allreduce': [c_vp, c_vp, c_i64, c_vp],
     'dasr_broadcast': [c_vp, c_vp, c_i64, c_i32, c_vp],
     'dasr_rccl_destroy': [c_vp],
+    'dasr_bnorm_lrelu_fwd': [Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, Tensor, c_vp, c_vp],
+    'dasr_bnorm_lrelu_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, Tensor, c_vp, c_vp, c_f32, c_vp],
+    'dasr_bnorm_running': [c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp],
     'dasr_ragan': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, Tensor, Tensor, c_vp],
     'dasr_lpips_s2d': [Tensor, c_i32, c_i32, c_i32, c_vp, c_vp, Tensor, c_i32, c_vp],
     'dasr_maxpool3s2': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_vp],
@@ -125,7 +129,7 @@ _SIGS = {
     'dasr_prof_end': [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 

@@ -35,6 +35,14 @@ __device__ __forceinline__ void split_bf16(float v, bf16_t& hi, bf16_t& lo) {
     lo = (bf16_t)(v - (float)hi);
 }
 
+// f16 hi + lo pair of a (pre-scaled) fp32 value: 22 mantissa bits where the bf16 pair has 16 (values below 2^-14 fall into f16's subnormal
+// range: absolute error 2^-25; callers pre-scale tiny gradients by a power of two)
+__device__ __forceinline__ void split_f16(float v, bf16_t& hi, bf16_t& lo) {
+    const f16_t h = (f16_t)v;
+    hi = __builtin_bit_cast(bf16_t, h);
+    lo = __builtin_bit_cast(bf16_t, (f16_t)(v - (float)h));
+}
+
 // one MFMA k-step (32 x 32 x 16) on 16-bit operand fragments held as bf16x8 bit patterns: F16 selects the f16 instruction
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {

@@ -28,7 +28,7 @@ struct Cfg {
     static constexpr int PIXB = KS == 1 ? 48 : 80;  // 32*KS B of bf16 + 16 B pad: conflict-free ds_read_b128 (3 or 5 slots/pixel)
     static constexpr int ACT_BYTES = IH * IW * PIXB;
     static constexpr int W_BYTES = KS * NTAPS * MT * 1024;
-    static constexpr int NARR = PREC == 3 ? 2 : 1;
+    static constexpr int NARR = PREC >= 3 ? 2 : 1;
     static constexpr int BUF_BYTES = NARR * (ACT_BYTES + W_BYTES);
     static constexpr int LDS_BYTES = (DBUF ? 2 : 1) * BUF_BYTES;
     // staging pieces (16 B of global memory each)
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
     const int nchunks = p.cin / (16 * KS);
     constexpr int ESZ = IN_F32 ? 4 : 2;
     static_assert(PREC != 2 || IN_F32, "prec 2 (f16 operands) converts an f32 input while staging");
-    const float in_sc = (PREC == 2 && p.in_scale != 0.f) ? p.in_scale : 1.f;
+    const float in_sc = ((PREC == 2 || PREC == 4) && p.in_scale != 0.f) ? p.in_scale : 1.f;
     // bias of this m-group: one value per thread of the first 32*MT, consumed in the epilogue (latency hidden by the main loop)
     float bias_reg = 0.f;
     {
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
 #pragma unroll
         for (int r = 0; r < C::WR; ++r) {
             wreg[r] = __builtin_amdgcn_raw_buffer_load_b128(rw, woff[r], wo, 0);
-            if constexpr (PREC == 3) wreg[C::WR + r] = __builtin_amdgcn_raw_buffer_load_b128(rw, woff[r], wo + w_lo_bytes, 0);
+            if constexpr (PREC >= 3) wreg[C::WR + r] = __builtin_amdgcn_raw_buffer_load_b128(rw, woff[r], wo + w_lo_bytes, 0);
         }
     };
     auto store_chunk = [&](char* buf) {
@@ -460,6 +460,8 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
                     if constexpr (PREC == 2) {   // one rounding to f16 (11-bit mantissa) of the pre-scaled value
                         h = __builtin_bit_cast(bf16_t, (f16_t)(__uint_as_float(areg[r][j]) * in_sc));
                         l = h;
+                    } else if constexpr (PREC == 4) {   // f16 hi + lo of the pre-scaled value (22 mantissa bits)
+                        split_f16(__uint_as_float(areg[r][j]) * in_sc, h, l);
                     } else {
                         split_bf16(__uint_as_float(areg[r][j]), h, l);
                     }
@@ -467,13 +469,13 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
                     lo[j] = l;
                 }
                 *(bf16x4*)(buf + loff[r]) = hi;
-                if constexpr (PREC == 3) *(bf16x4*)(buf + (loff[r] == DUMMY ? DUMMY : ACT_LO + loff[r])) = lo;
+                if constexpr (PREC >= 3) *(bf16x4*)(buf + (loff[r] == DUMMY ? DUMMY : ACT_LO + loff[r])) = lo;
             }
         }
 #pragma unroll
         for (int r = 0; r < C::WR; ++r) {
             *(u32x4*)(buf + W_HI + wloff[r]) = wreg[r];
-            if constexpr (PREC == 3) *(u32x4*)(buf + (wloff[r] == DUMMY - W_HI ? DUMMY : W_LO + wloff[r])) = wreg[C::WR + r];
+            if constexpr (PREC >= 3) *(u32x4*)(buf + (wloff[r] == DUMMY - W_HI ? DUMMY : W_LO + wloff[r])) = wreg[C::WR + r];
         }
     };
 
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
                         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                acc[mi][nt] = mfma16<PREC == 2>(a[ky][mi], brow[nt + ky], acc[mi][nt]);
+                                acc[mi][nt] = mfma16<PREC == 2 || PREC == 4>(a[ky][mi], brow[nt + ky], acc[mi][nt]);
                 }
             }
             return;
@@ -559,12 +561,12 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
                 for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[mi][nt] = mfma16<PREC == 2>(fa[idx & 1][mi], fb[idx & 1][nt], acc[mi][nt]);
+                        acc[mi][nt] = mfma16<PREC == 2 || PREC == 4>(fa[idx & 1][mi], fb[idx & 1][nt], acc[mi][nt]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             return;
         }
-        if constexpr (PREC == 3 && NT <= 2) {
+        if constexpr (PREC >= 3 && NT <= 2) {
             // same tap-level pipeline for the split-bf16 path where the register budget allows two fragment sets (8x32 tiles)
             constexpr int TOT = KS * C::NTAPS;
             bf16x8 fa[2][MT], fal[2][MT], fb[2][NT], fbl[2][NT];
@@ -592,9 +594,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
                 for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        acc[mi][nt] = mfma16<PREC == 2>(fal[idx & 1][mi], fb[idx & 1][nt], acc[mi][nt]);
-                        acc[mi][nt] = mfma16<PREC == 2>(fa[idx & 1][mi], fbl[idx & 1][nt], acc[mi][nt]);
-                        acc[mi][nt] = mfma16<PREC == 2>(fa[idx & 1][mi], fb[idx & 1][nt], acc[mi][nt]);
+                        acc[mi][nt] = mfma16<PREC == 2 || PREC == 4>(fal[idx & 1][mi], fb[idx & 1][nt], acc[mi][nt]);
+                        acc[mi][nt] = mfma16<PREC == 2 || PREC == 4>(fa[idx & 1][mi], fbl[idx & 1][nt], acc[mi][nt]);
+                        acc[mi][nt] = mfma16<PREC == 2 || PREC == 4>(fa[idx & 1][mi], fb[idx & 1][nt], acc[mi][nt]);
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -610,22 +612,22 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) {
                     a[mi] = *(const bf16x8*)(w_hi + ((ks * C::NTAPS + t) * MT + mi) * 1024 + aoff);
-                    if constexpr (PREC == 3) al[mi] = *(const bf16x8*)(w_lo + ((ks * C::NTAPS + t) * MT + mi) * 1024 + aoff);
+                    if constexpr (PREC >= 3) al[mi] = *(const bf16x8*)(w_lo + ((ks * C::NTAPS + t) * MT + mi) * 1024 + aoff);
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     b[nt] = *(const bf16x8*)(act_hi + boff[nt] + toff);
-                    if constexpr (PREC == 3) bl[nt] = *(const bf16x8*)(act_lo + boff[nt] + toff);
+                    if constexpr (PREC >= 3) bl[nt] = *(const bf16x8*)(act_lo + boff[nt] + toff);
                 }
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        if constexpr (PREC == 3) {
-                            acc[mi][nt] = mfma16<PREC == 2>(al[mi], b[nt], acc[mi][nt]);
-                            acc[mi][nt] = mfma16<PREC == 2>(a[mi], bl[nt], acc[mi][nt]);
+                        if constexpr (PREC >= 3) {
+                            acc[mi][nt] = mfma16<PREC == 2 || PREC == 4>(al[mi], b[nt], acc[mi][nt]);
+                            acc[mi][nt] = mfma16<PREC == 2 || PREC == 4>(a[mi], bl[nt], acc[mi][nt]);
                         }
-                        acc[mi][nt] = mfma16<PREC == 2>(a[mi], b[nt], acc[mi][nt]);
+                        acc[mi][nt] = mfma16<PREC == 2 || PREC == 4>(a[mi], b[nt], acc[mi][nt]);
                     }
             }
         }
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
             for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mi][nt] = mfma16<PREC == 2>(fa[idx & 1][mi], fb[idx & 1][nt], acc[mi][nt]);
+                    acc[mi][nt] = mfma16<PREC == 2 || PREC == 4>(fa[idx & 1][mi], fb[idx & 1][nt], acc[mi][nt]);
             // the NP staged pieces of the next chunk are spread over the taps
 #pragma unroll
             for (int i = idx * NP / TOT; i < (idx + 1) * NP / TOT; ++i) store_piece(nbuf, ar, wr, i);
@@ -721,7 +723,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
     }
     }
     TRACE_STAMP(4);
-    if constexpr (PREC == 2) {
+    if constexpr (PREC == 2 || PREC == 4) {
         if (in_sc != 1.f) {   // undo the operand pre-scaling (exact: power of two)
             const float inv = 1.f / in_sc;
 #pragma unroll
@@ -1232,7 +1234,8 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
     if (p.pad_x == 0 && p.out_stride == 0 && p.kh != 2 && p.kh != 1) p.pad_x = -1;  // zero-initialised extension fields = "same as pad"
     hipStream_t s = as_stream(stream);
     if (p.cin <= 0 || (p.cin & 15) || p.cout <= 0 || !p.w || !p.in.p) return DASR_EINVAL;
-    if (!(p.mt == 1 || p.mt == 2) || !(p.prec == 1 || p.prec == 2 || p.prec == 3)) return DASR_EINVAL;
+    if (!(p.mt == 1 || p.mt == 2) || !(p.prec >= 1 && p.prec <= 4)) return DASR_EINVAL;
+    if (p.prec == 4 && (!p.in_f32 || p.mt != 1)) return DASR_EINVAL;   // split-f16: f32 tensors, 32-oc workgroups
     if (p.prec == 2 && !p.in_f32 && (p.kh != 3 || p.stride != 1)) return DASR_EINVAL;   // f16 tensors: dense 3x3 kernel only
     int kcode = 0;
     if (p.kh == 4) kcode = p.stride == 2 ? 2 : 1;
@@ -1240,7 +1243,7 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
     else if (p.kh == 5) kcode = 4;
     else if (p.kh == 1) kcode = 5;
     else if (p.kh == 3 && p.stride == 2) kcode = 6;
-    const int key = (p.prec == 3 ? 1000 : p.prec == 2 ? 2000 : 0) + (p.in_f32 ? 100 : 0) + p.mt * 10 + kcode;
+    const int key = (p.prec == 4 ? 3000 : p.prec == 3 ? 1000 : p.prec == 2 ? 2000 : 0) + (p.in_f32 ? 100 : 0) + p.mt * 10 + kcode;
     // 3x3: pad 1; the register-staged f32-tensor stride-1 kernel also runs pad 0 / 2 (LPIPS conv1 on the space-to-depth grid and its adjoint)
     if (p.kh == 3 && ((p.stride != 1 && p.stride != 2) || (p.pad != 1 && !(p.pad >= 0 && p.pad <= 2 && p.stride == 1 && p.in_f32)))) return DASR_EINVAL;
     if (p.kh == 5 && (p.stride != 1 || p.pad != 2)) return DASR_EINVAL;
@@ -1370,6 +1373,12 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                 case 64: return launch_glds<2, 64, 4, 0, true>(p, s);
                 default: return launch_glds<2, 0, 4, 0, true>(p, s);
             }
+        // prec 4: split-f16 (hi*hi + hi*lo + lo*hi on f16 pairs, 22-bit operands): the BatchNorm discriminator, where 16 bits are not enough
+        case 3110: return launch<4, true, 1, 3, 1, 4>(p, s);
+        case 3111: return launch<4, true, 1, 4, 1, 2>(p, s);
+        case 3112: return launch<4, true, 1, 4, 2, 1>(p, s);
+        case 3113: return launch<4, true, 1, 2, 1, 4>(p, s);
+        case 3115: return launch<4, true, 1, 1, 1, 4>(p, s);
         // prec 2: f16 operands, ONE MFMA pass on f32 activations (HR tail of the generator; VGG / discriminators / DSN when selected)
         case 2110: return launch<2, true, 1, 3, 1, 4>(p, s);
         case 2120: return launch<2, true, 2, 3, 1, 4>(p, s);

@@ -118,6 +118,134 @@ __global__ __launch_bounds__(256) void inorm_lrelu_bwd_kernel(dasr_tensor a, das
 }
 
 // ---------------------------------------------------------------------------------------------------
+// BatchNorm2d in TRAINING mode (batch statistics, affine) + LeakyReLU, as in Discriminator_VGG_128 (architecture.py:442-495).
+// The batch is processed in GROUPS of `group` consecutive images with their own statistics: the reference calls the discriminator
+// separately on the fake and on the real half (DASR_model.py:251,288-289), here both halves go through one launch.
+// One workgroup per 16-channel plane; thread t: channel quad q = t & 3, pixel lane t >> 2; fixed-order reductions (deterministic).
+// stats[g][Cpad][3] = (mean, rstd, biased variance).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bnorm_lrelu_fwd_kernel(dasr_tensor x, int N, int C, int H, int W, int group, float eps, float slope,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, dasr_tensor y,
+                                                              float* __restrict__ stats) {
+    __shared__ f32x4 red[16];
+    const int cb = blockIdx.x, q = threadIdx.x & 3, pl = threadIdx.x >> 2, HW = H * W, cpad = ((C + 15) >> 4) * 16;
+    const int c0 = cb * 16 + q * 4;
+    f32x4 gm = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (c0 + j < C) { gm[j] = gamma[c0 + j]; bt[j] = beta[c0 + j]; }
+    for (int g = 0; g * group < N; ++g) {
+        const int n0 = g * group, n1 = min(N, n0 + group);
+        const float inv = 1.f / (float)((n1 - n0) * HW);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int n = n0; n < n1; ++n) {
+            const float* xp = (const float*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + q * 4;
+            for (int p = pl; p < HW; p += 64) s += *(const f32x4*)(xp + (size_t)p * 16);
+        }
+        const f32x4 mean = quad_reduce(s, red) * inv;
+        f32x4 s2 = {0.f, 0.f, 0.f, 0.f};
+        for (int n = n0; n < n1; ++n) {
+            const float* xp = (const float*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + q * 4;
+            for (int p = pl; p < HW; p += 64) {
+                const f32x4 d = *(const f32x4*)(xp + (size_t)p * 16) - mean;
+                s2 += d * d;
+            }
+        }
+        const f32x4 var = quad_reduce(s2, red) * inv;
+        f32x4 rstd;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rstd[j] = 1.f / sqrtf(var[j] + eps);
+        for (int n = n0; n < n1; ++n) {
+            const float* xp = (const float*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + q * 4;
+            float* yp = (float*)y.p + (size_t)n * y.n_stride + (size_t)cb * y.cb_stride + q * 4;
+            for (int p = pl; p < HW; p += 64) {
+                f32x4 v = (*(const f32x4*)(xp + (size_t)p * 16) - mean) * rstd * gm + bt;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+                *(f32x4*)(yp + (size_t)p * 16) = v;
+            }
+        }
+        if (pl == 0) {
+            float* st = stats + ((size_t)g * cpad + c0) * 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { st[3 * j] = mean[j]; st[3 * j + 1] = rstd[j]; st[3 * j + 2] = var[j]; }
+        }
+    }
+}
+
+// backward: z = xhat * gamma + beta (recomputed from the saved conv output x and the statistics), gz = ga * lrelu'(z);
+// per group: gx = gamma * rstd * (gz - mean(gz) - xhat * mean(gz * xhat));  dgamma = sum over ALL groups of sum(gz * xhat), dbeta = sum gz
+// (written, scaled by pscale, when the pointers are given: the discriminator step; the generator step only needs gx of the fake group).
+__global__ __launch_bounds__(256) void bnorm_lrelu_bwd_kernel(dasr_tensor x, dasr_tensor ga, int N, int C, int H, int W, int group, float slope,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ stats, dasr_tensor gx, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float pscale) {
+    __shared__ f32x4 red[16];
+    const int cb = blockIdx.x, q = threadIdx.x & 3, pl = threadIdx.x >> 2, HW = H * W, cpad = ((C + 15) >> 4) * 16;
+    const int c0 = cb * 16 + q * 4;
+    f32x4 gm = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f}, dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (c0 + j < C) { gm[j] = gamma[c0 + j]; bt[j] = beta[c0 + j]; }
+    for (int g = 0; g * group < N; ++g) {
+        const int n0 = g * group, n1 = min(N, n0 + group);
+        const float inv = 1.f / (float)((n1 - n0) * HW);
+        const float* st = stats + ((size_t)g * cpad + c0) * 3;
+        f32x4 mean, rstd;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mean[j] = st[3 * j]; rstd[j] = st[3 * j + 1]; }
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        for (int n = n0; n < n1; ++n) {
+            const float* xp = (const float*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + q * 4;
+            const float* gp = (const float*)ga.p + (size_t)n * ga.n_stride + (size_t)cb * ga.cb_stride + q * 4;
+            for (int p = pl; p < HW; p += 64) {
+                const f32x4 xh = (*(const f32x4*)(xp + (size_t)p * 16) - mean) * rstd;
+                const f32x4 z = xh * gm + bt;
+                f32x4 gz = *(const f32x4*)(gp + (size_t)p * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gz[j] = z[j] > 0.f ? gz[j] : gz[j] * slope;
+                s1 += gz;
+                s2 += gz * xh;
+            }
+        }
+        const f32x4 t1 = quad_reduce(s1, red), t2 = quad_reduce(s2, red);
+        db += t1;
+        dg += t2;
+        const f32x4 m1 = t1 * inv, m2 = t2 * inv;
+        for (int n = n0; n < n1; ++n) {
+            const float* xp = (const float*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + q * 4;
+            const float* gp = (const float*)ga.p + (size_t)n * ga.n_stride + (size_t)cb * ga.cb_stride + q * 4;
+            float* op = (float*)gx.p + (size_t)n * gx.n_stride + (size_t)cb * gx.cb_stride + q * 4;
+            for (int p = pl; p < HW; p += 64) {
+                const f32x4 xh = (*(const f32x4*)(xp + (size_t)p * 16) - mean) * rstd;
+                const f32x4 z = xh * gm + bt;
+                f32x4 gz = *(const f32x4*)(gp + (size_t)p * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gz[j] = z[j] > 0.f ? gz[j] : gz[j] * slope;
+                *(f32x4*)(op + (size_t)p * 16) = gm * rstd * (gz - m1 - xh * m2);
+            }
+        }
+    }
+    if (pl == 0 && dgamma) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c0 + j < C) { dgamma[c0 + j] = dg[j] * pscale; dbeta[c0 + j] = db[j] * pscale; }
+    }
+}
+
+// running statistics of nn.BatchNorm2d after one training-mode forward on group g (momentum 0.1, UNBIASED variance, num_batches_tracked + 1)
+__global__ void bnorm_running_kernel(const float* __restrict__ stats, int g, int C, int count, float momentum, float* __restrict__ rmean,
+                                     float* __restrict__ rvar, float* __restrict__ nbt) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, cpad = ((C + 15) >> 4) * 16;
+    if (c < C) {
+        const float* st = stats + ((size_t)g * cpad + c) * 3;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * st[0];
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * st[2] * ((float)count / (float)(count > 1 ? count - 1 : 1));
+    }
+    if (c == 0 && nbt) nbt[0] += 1.f;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // BCEWithLogits(x, t) mean over C real channels (GANLoss 'vanilla', loss.py:8-40):
 // loss_acc[0] += coef * sum(max(x,0) - x t + log1p(exp(-|x|))); loss_acc[1] += coef_mean * sum(x) (disc score);
 // grad = gcoef * (sigmoid(x) - t) (zero on padded channels)
@@ -694,6 +822,30 @@ extern "C" int dasr_inorm_lrelu_bwd(dasr_tensor a, dasr_tensor ga, int32_t N, in
                                     const float* stats, dasr_tensor gx, void* stream) {
     if (N <= 0 || C <= 0) return DASR_EINVAL;
     DASR_LAUNCH(inorm_lrelu_bwd_kernel, dim3(N * ((C + 15) / 16)), dim3(256), 0, as_stream(stream), a, ga, C, H, W, slope, stats, gx);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_bnorm_lrelu_fwd(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, int32_t group, float eps, float slope, const float* gamma,
+                                    const float* beta, dasr_tensor y, float* stats, void* stream) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || group <= 0 || !gamma || !beta || !stats) return DASR_EINVAL;
+    DASR_LAUNCH(bnorm_lrelu_fwd_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), x, N, C, H, W, group, eps, slope, gamma, beta, y, stats);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_bnorm_lrelu_bwd(dasr_tensor x, dasr_tensor ga, int32_t N, int32_t C, int32_t H, int32_t W, int32_t group, float slope,
+                                    const float* gamma, const float* beta, const float* stats, dasr_tensor gx, float* dgamma, float* dbeta,
+                                    float pscale, void* stream) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || group <= 0 || !gamma || !beta || !stats || (dgamma != nullptr) != (dbeta != nullptr)) return DASR_EINVAL;
+    DASR_LAUNCH(bnorm_lrelu_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), x, ga, N, C, H, W, group, slope, gamma, beta, stats, gx,
+                dgamma, dbeta, pscale);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_bnorm_running(const float* stats, int32_t g, int32_t C, int32_t count, float momentum, float* running_mean, float* running_var,
+                                  float* num_batches_tracked, void* stream) {
+    if (!stats || g < 0 || C <= 0 || count <= 0 || !running_mean || !running_var) return DASR_EINVAL;
+    DASR_LAUNCH(bnorm_running_kernel, dim3(nblk(C)), dim3(256), 0, as_stream(stream), stats, g, C, count, momentum, running_mean, running_var,
+                num_batches_tracked);
     return (int)hipGetLastError();
 }
 

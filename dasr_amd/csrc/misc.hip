@@ -57,6 +57,7 @@ __global__ void pack_kernel(const dasr_pack_desc* __restrict__ descs, int ndesc,
         bf16_t h, l;
         split_bf16(v, h, l);
         if (D.fmt == 1) h = __builtin_bit_cast(bf16_t, (f16_t)v);   // f16 bit pattern (prec 2 convs)
+        if (D.fmt == 2) split_f16(v, h, l);                           // f16 hi + lo planes (prec 4 convs)
         vh[e] = h;
         vl[e] = l;
     }
@@ -685,6 +686,17 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream0) {
             case DASR_OP_PIXUNSHUF: rc = dasr_pixel_unshuffle_f16(o.t[0], o.t[1], o.f[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[2], stream); break;
             case DASR_OP_CVT_F16: rc = dasr_cvt_f16(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1], stream); break;
             case DASR_OP_DOWNSUM_F16: rc = dasr_downsum2x_f16(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1], o.f[0], o.f[1], o.t[2], o.t[3], stream); break;
+            case DASR_OP_BNORM_FWD:
+                rc = dasr_bnorm_lrelu_fwd(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.f[0], o.f[1], (const float*)o.p[0], (const float*)o.p[1], o.t[1],
+                                          (float*)o.p[2], stream);
+                break;
+            case DASR_OP_BNORM_BWD:
+                rc = dasr_bnorm_lrelu_bwd(o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.f[0], (const float*)o.p[0], (const float*)o.p[1],
+                                          (const float*)o.p[2], o.t[2], (float*)o.p[3], (float*)o.l[0], o.f[1], stream);
+                break;
+            case DASR_OP_BNORM_RUNNING:
+                rc = dasr_bnorm_running((const float*)o.p[0], o.i[0], o.i[1], o.i[2], o.f[0], (float*)o.p[1], (float*)o.p[2], (float*)o.p[3], stream);
+                break;
             case DASR_OP_RAGAN:
                 rc = dasr_ragan(o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.f[0], o.f[1], o.f[2], o.f[3], (float*)o.p[0], (float*)o.p[1],
                                 (float*)o.p[2], (float*)o.p[3], (float*)o.l[0], *(const float*)&o.l[1], o.t[2], o.t[3], stream);

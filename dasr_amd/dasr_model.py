@@ -19,7 +19,8 @@ import torch
 
 from . import _lib
 from .engine import BTensor, Op, OpList, NULL_T, Tensor, _stream
-from .gan_nets import NLayerDiscriminatorHIP, VGGFeatureHIP, VGG_MEAN, VGG_STD, nlayer_d_spec
+from .gan_nets import (NLayerDiscriminatorHIP, DiscriminatorVGG128HIP, VGGFeatureHIP, VGG_MEAN, VGG_STD, nlayer_d_spec, vgg128_spec,
+                       vgg128_init_state_dict)
 from .init import kaiming_state_dict
 from .lpips import load_lpips, lpips_metric
 from .models import BaseModel, AdamHIP, MultiStepLR, _define_G
@@ -90,12 +91,16 @@ class DASR_Model(BaseModel):
         self.netD_source = None
         if self.is_train and self.l_gan_H_source_w > 0:   # DASR_model.py:45-47 -> define_pairD (networks.py:196-227)
             d = opt['network_D']
-            if d['which_model_pairD'] != 'discriminator_patch':
-                # discriminator_vgg_128 (BatchNorm in training mode: batch statistics across the data-parallel ranks) is not on this path
+            if d['which_model_pairD'] == 'discriminator_patch':
+                self.netD_source = NLayerDiscriminatorHIP(d['in_nc'], d['nf'], d['n_layers'], device=self.device)  # networks.py:217-218: nf IS passed here
+                spec, _ = nlayer_d_spec(d['in_nc'], d['nf'], d['n_layers'])
+                self.netD_source.load_state_dict(kaiming_state_dict(spec, 1))
+            elif d['which_model_pairD'] == 'discriminator_vgg_128':   # networks.py:201-202; BatchNorm in training mode, 128 x 128 inputs
+                self.netD_source = DiscriminatorVGG128HIP(d['in_nc'], d['nf'], device=self.device)
+                sd = vgg128_init_state_dict(vgg128_spec(d['in_nc'], d['nf'])[0], int(t['manual_seed'] or 0) + 2)
+                self.netD_source.load_state_dict(sd, strict=False)
+            else:
                 raise NotImplementedError('Discriminator model [{:s}] not recognized'.format(str(d['which_model_pairD'])))
-            self.netD_source = NLayerDiscriminatorHIP(d['in_nc'], d['nf'], d['n_layers'], device=self.device)  # networks.py:217-218: nf IS passed here
-            spec, _ = nlayer_d_spec(d['in_nc'], d['nf'], d['n_layers'])
-            self.netD_source.load_state_dict(kaiming_state_dict(spec, 1))
         self.load()
         self.norm = bool(t['norm'])
         self.fs = t['fs']
@@ -196,6 +201,8 @@ class DASR_Model(BaseModel):
             P.g.set_grad_scale(scale)
             P.set_d_grad_scale(scale)
         if do_g:
+            if P.ds_run_g.ops:
+                P.ds_run_g.run()
             if self.ragan:
                 self._run_ragan(P.rg, P, dp_on)   # relativistic GAN terms of the generator loss (value + dL/dlogits of the fake halves)
             P.g_loss_bwd.run()            # D / VGG / fs data-gradients into dL/dSR
@@ -218,6 +225,8 @@ class DASR_Model(BaseModel):
             self.optimizer_D_target.step(self._lr_of(self.optimizer_D_target))
             self.netD_target.repack()
         if do_ds:                         # source domain (DASR_model.py:287-303)
+            if P.ds_run_d.ops:
+                P.ds_run_d.run()
             if self.ragan:
                 self._run_ragan(P.rs, P, dp_on)
             P.ds_step.run()
@@ -382,8 +391,17 @@ class _StepPlan:
         dx_fake = d.x.view() if d is not None else NULL_T
         dx_real = _nview(d.x, n) if d is not None else NULL_T
         Ds = m.netD_source                     # source-domain discriminator on the high frequencies of [fake_s ; real_s] (DASR_model.py:250-259)
+        if isinstance(Ds, DiscriminatorVGG128HIP) and (Hd, Wd) != (128, 128):
+            raise ValueError('Discriminator_VGG_128 needs 128 x 128 inputs (Linear(512 * 4 * 4, 100)), got %d x %d' % (Hd, Wd))
         self.ds = Ds.plan(N2, Hd, Wd) if Ds is not None else None
         ds = self.ds
+        # BatchNorm running statistics follow the reference's forwards: D_s(fake) in the G step, D_s(real) then D_s(fake) in the D step
+        bn = ds is not None and hasattr(Ds, 'buffers')
+        self.ds_run_g = ds.running_ops(0) if bn else OpList()
+        self.ds_run_d = OpList()
+        if bn:
+            self.ds_run_d.extend(ds.running_ops(1))
+            self.ds_run_d.extend(ds.running_ops(0))
         sx_fake = ds.x.view() if ds is not None else NULL_T
         sx_real = _nview(ds.x, n) if ds is not None else NULL_T
         if wavelet:
@@ -551,4 +569,7 @@ class _StepPlan:
             for o in ol.ops:
                 if o.op == _lib.OP_WGRAD_REDUCE and o.f[0] != scale:
                     o.f[0] = scale
+                    ol._arr = None
+                if o.op == _lib.OP_BNORM_BWD and o.f[1] != scale:   # dgamma / dbeta of the BatchNorm layers
+                    o.f[1] = scale
                     ol._arr = None

@@ -121,9 +121,9 @@ class PackRegistry:
         pieces = mg * (cin_pad // 16) * ntaps * mt * 64
         r = PackedRef()
         r.off, r.cout, r.cin_pad, r.ntaps, r.mt, r.prec = self.size, cout, cin_pad, ntaps, mt, prec
-        r.lo_off = pieces * 8 if prec == 3 else 0
+        r.lo_off = pieces * 8 if prec in (3, 4) else 0
         d = PackDesc()
-        d.fmt = 1 if prec == 2 else 0   # prec 2: f16 operands (one MFMA pass); 1 / 3: bf16 hi (+ lo) planes
+        d.fmt = 1 if prec == 2 else (2 if prec == 4 else 0)   # prec 2: f16 operands (one MFMA pass); 4: f16 hi + lo planes; 1 / 3: bf16 hi (+ lo) planes
         d.dst_off, d.lo_off, d.cout, d.cin_pad, d.ntaps, d.mt, d.nseg = self.size, r.lo_off, cout, cin_pad, ntaps, mt, len(segs)
         d.src_ntaps = src_ntaps or ntaps
         if tapmap is None:
@@ -138,7 +138,7 @@ class PackRegistry:
             sg.src_off, sg.src_cout, sg.src_cin, sg.cin_start, sg.cin_len, sg.src_c0, sg.transpose = s
         self.descs.append(d)
         self.prefix.append(self.prefix[-1] + pieces)
-        self.size += pieces * 8 * (2 if prec == 3 else 1)
+        self.size += pieces * 8 * (2 if prec in (3, 4) else 1)
         return r
 
     def finalize(self):
@@ -250,7 +250,7 @@ def conv_op(pack, ref, inp, in_f32, cin, Hin, Win, Hout, Wout, N, bias=None, kh=
     p.pad_x, p.out_stride, p.out_oy, p.out_ox, p.out_W = pad_x, out_stride, out_oy, out_ox, out_W
     p.slope_ptr = slope_ptr
     p.in_stride, p.in_oy, p.in_ox, p.in_W = in_stride, in_oy, in_ox, in_W
-    p.in_scale = in_scale if (ref.prec == 2 and in_f32) else 0.0   # power-of-two pre-scale of an f32 gradient input before its f16 rounding
+    p.in_scale = in_scale if (ref.prec in (2, 4) and in_f32) else 0.0   # power-of-two pre-scale of an f32 gradient input before its f16 rounding
     p.out16_f16 = int(out16_f16)
     return o
 

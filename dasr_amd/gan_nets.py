@@ -92,6 +92,34 @@ def dsn_nld_spec(input_nc, stride, gaussian_k=None, ndf=64):
     return spec, layers
 
 
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+def vgg128_spec(in_nc, nf=64):
+    """Discriminator_VGG_128 (codes/SRN/models/modules/architecture.py:442-495): conv0_0 (bias) + LReLU, nine bias-free convs each with
+    BatchNorm2d(affine) + LReLU (3x3 s1 / 4x4 s2 alternating, 128 -> 4 pixels), Linear(512*4*4, 100) + LReLU, Linear(100, 1).  The linear layers
+    run as a 4x4 'valid' conv on the 4x4 map and a 1x1 conv (same weight memory order as the flattened [C][H][W] features)."""
+    if nf != 64:
+        raise NotImplementedError('Discriminator_VGG_128: linear1 is Linear(512 * 4 * 4, 100), i.e. nf = 64')
+    chain = [('conv0_0', in_nc, nf, 3, 1, None), ('conv0_1', nf, nf, 4, 2, 'bn0_1'), ('conv1_0', nf, 2 * nf, 3, 1, 'bn1_0'),
+             ('conv1_1', 2 * nf, 2 * nf, 4, 2, 'bn1_1'), ('conv2_0', 2 * nf, 4 * nf, 3, 1, 'bn2_0'), ('conv2_1', 4 * nf, 4 * nf, 4, 2, 'bn2_1'),
+             ('conv3_0', 4 * nf, 8 * nf, 3, 1, 'bn3_0'), ('conv3_1', 8 * nf, 8 * nf, 4, 2, 'bn3_1'), ('conv4_0', 8 * nf, 8 * nf, 3, 1, 'bn4_0'),
+             ('conv4_1', 8 * nf, 8 * nf, 4, 2, 'bn4_1')]
+    spec, layers = [], []
+    for name, cin, cout, kh, stride, bn in chain:
+        spec.append((name + '.weight', (cout, cin, kh, kh)))
+        if bn is None:
+            spec.append((name + '.bias', (cout,)))
+        else:
+            spec += [(bn + '.weight', (cout,)), (bn + '.bias', (cout,))]
+        layers.append(dict(key=name + '.', cin=cin, cout=cout, stride=stride, bias=bn is None, norm='batch' if bn else False, bn=(bn + '.') if bn else None,
+                           last=False, kh=kh, pad=1))
+    spec += [('linear1.weight', (100, 8 * nf, 4, 4)), ('linear1.bias', (100,)), ('linear2.weight', (1, 100, 1, 1)), ('linear2.bias', (1,))]
+    layers.append(dict(key='linear1.', cin=8 * nf, cout=100, stride=1, bias=True, norm=False, bn=None, last=False, kh=4, pad=0))
+    layers.append(dict(key='linear2.', cin=100, cout=1, stride=1, bias=True, norm=False, bn=None, last=True, kh=1, pad=0))
+    return spec, layers
+
+
 # stride-2 4x4 data-gradient = four 2x2 sub-convolutions, one per parity (py, px) of the input pixel:
 # packed tap a (0/1) along one axis -> source tap k and zero-padding of the sub-conv (see DESIGN.md / conv.hip)
 _PARITY_TAPS = {0: (3, 1), 1: (2, 0)}  # parity -> (k for a=0, k for a=1)
@@ -99,6 +127,8 @@ _PARITY_PAD = {0: 1, 1: 0}
 
 
 class NLayerDiscriminatorHIP:
+    prec = 3   # split-bf16 operands (~fp32); DiscriminatorVGG128HIP: 4 = split-f16 (22-bit operands)
+
     def __init__(self, input_nc, ndf=64, n_layers=2, device='cuda', spec_layers=None):
         self.input_nc, self.device = input_nc, torch.device(device)
         self.spec, self.layers = spec_layers if spec_layers is not None else nlayer_d_spec(input_nc, ndf, n_layers)
@@ -110,16 +140,16 @@ class NLayerDiscriminatorHIP:
             w = P.off(L['key'] + 'weight')
             L['cin_pad'] = cin_pad
             nt = L['kh'] * L['kh']
-            L['fwd'] = self.pack.add(L['cout'], cin_pad, nt, 1, 3, [(w, L['cout'], L['cin'], 0, L['cin'], 0, 0)])
+            L['fwd'] = self.pack.add(L['cout'], cin_pad, nt, 1, self.prec, [(w, L['cout'], L['cin'], 0, L['cin'], 0, 0)])
             cb = ceil_div(L['cout'], 16) * 16
             if L['stride'] == 1:
-                L['bwd'] = self.pack.add(L['cin'], cb, nt, 1, 3, [(w, L['cout'], L['cin'], 0, L['cout'], 0, 1)])
+                L['bwd'] = self.pack.add(L['cin'], cb, nt, 1, self.prec, [(w, L['cout'], L['cin'], 0, L['cout'], 0, 1)])
             else:
                 L['bwd'] = {}
                 for py in (0, 1):
                     for px in (0, 1):
                         tm = [_PARITY_TAPS[py][a] * 4 + _PARITY_TAPS[px][b] for a in (0, 1) for b in (0, 1)]
-                        L['bwd'][(py, px)] = self.pack.add(L['cin'], cb, 4, 1, 3, [(w, L['cout'], L['cin'], 0, L['cout'], 0, 1)],
+                        L['bwd'][(py, px)] = self.pack.add(L['cin'], cb, 4, 1, self.prec, [(w, L['cout'], L['cin'], 0, L['cout'], 0, 1)],
                                                            tapmap=tm, src_ntaps=16)
         self.pack.finalize()
         self.plans = {}
@@ -141,6 +171,68 @@ class NLayerDiscriminatorHIP:
         return self.plans[k]
 
 
+class DiscriminatorVGG128HIP(NLayerDiscriminatorHIP):
+    """`which_model_pairD: discriminator_vgg_128` (networks.py:201-202): the source-domain discriminator with BatchNorm in training mode.
+    Batch statistics are taken per call of the reference = per half [fake | real] of the batch (`bn_groups`), on this rank's samples (the
+    reference's nn.DataParallel replicas do not synchronise BatchNorm either); running statistics follow the reference's three forwards per
+    step (fake in the G step, real and fake in the D step) and live outside the optimiser's buffers."""
+    bn_groups = 2
+    prec = 4   # the BatchNorm backward cancels group means: 16-bit conv operands leave 4e-2 on the first layers' gradients, 22-bit ones 1e-3
+
+    def __init__(self, in_nc, nf=64, device='cuda'):
+        super().__init__(in_nc, nf, device=device, spec_layers=vgg128_spec(in_nc, nf))
+        self.buffers = {}
+        for L in self.layers:
+            if L['norm'] == 'batch':
+                self.buffers[L['bn'] + 'running_mean'] = torch.zeros(L['cout'], dtype=torch.float32, device=self.device)
+                self.buffers[L['bn'] + 'running_var'] = torch.ones(L['cout'], dtype=torch.float32, device=self.device)
+                self.buffers[L['bn'] + 'num_batches_tracked'] = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    def state_dict(self):
+        """the reference module's keys, order and shapes (Linear weights 2-D, num_batches_tracked int64)"""
+        from collections import OrderedDict
+        flat, out = self.params.state_dict(), OrderedDict()
+        for k, v in flat.items():
+            out[k] = v.reshape(v.shape[0], -1) if k.startswith('linear') and k.endswith('weight') else v
+            if k.endswith('.bias') and k.startswith('bn'):
+                pre = k[:-4]
+                out[pre + 'running_mean'] = self.buffers[pre + 'running_mean'].detach().clone().cpu()
+                out[pre + 'running_var'] = self.buffers[pre + 'running_var'].detach().clone().cpu()
+                out[pre + 'num_batches_tracked'] = self.buffers[pre + 'num_batches_tracked'].detach().cpu().round().long().reshape(())
+        return out
+
+    def load_state_dict(self, sd, strict=True):
+        own = {}
+        for k, v in sd.items():
+            if k in self.buffers:
+                self.buffers[k].copy_(v.detach().float().reshape(self.buffers[k].shape).to(self.device))
+            elif k in self.params.spec:
+                own[k] = v.detach().float().reshape(self.params.spec[k][1])
+            elif strict:
+                raise RuntimeError('Error(s) in loading state_dict: unexpected key %s' % k)
+        missing = [k for k in list(self.params.spec) + list(self.buffers) if k not in sd]
+        if strict and missing:
+            raise RuntimeError('Error(s) in loading state_dict: missing %s' % missing)
+        self.params.load_state_dict(own, strict=False)
+        self.repack()
+
+
+def vgg128_init_state_dict(spec, seed):
+    """init_weights('kaiming', scale=1) of networks.py:30-44,227: kaiming-normal(fan_in) convs and linears, zero biases, BatchNorm weight 1 / bias 0
+    (values from one seeded generator; not the reference's RNG stream)"""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, shape in spec:
+        if k.startswith('bn'):
+            sd[k] = torch.ones(shape) if k.endswith('weight') else torch.zeros(shape)
+        elif k.endswith('weight'):
+            sd[k] = torch.randn(shape, generator=g) * math.sqrt(2.0 / (shape[1] * shape[2] * shape[3]))
+        else:
+            sd[k] = torch.zeros(shape)
+    return sd
+
+
 class _DPlan:
     """Forward on N images; data-gradient of the first `n_g` images (generator step, no weight gradients);
     full backward with weight gradients on all N images (discriminator step)."""
@@ -148,6 +240,9 @@ class _DPlan:
     def __init__(self, net, N, H, W):
         self.net, self.N = net, N
         dev, P, pack = net.device, net.params, net.pack
+        groups = getattr(net, 'bn_groups', 1)
+        assert N % groups == 0
+        self.group = N // groups                       # BatchNorm: images [0, group) = fake half, [group, N) = real half, own statistics each
         self.x = BTensor(N, 16, H, W, True, dev)       # D input (3 or 9 real channels)
         self.gx = BTensor(N, 16, H, W, True, dev)      # dL/d input
         self.acts, self.zs, self.stats, self.dims = [], [], [], [(H, W)]
@@ -160,7 +255,7 @@ class _DPlan:
             a = BTensor(N, max(L['cout'], 16), ho, wo, True, dev)
             self.zs.append(z)
             self.acts.append(a)
-            self.stats.append(torch.zeros(N * ceil_div(L['cout'], 16) * 16 * 2, dtype=torch.float32, device=dev) if L['norm'] else None)
+            self.stats.append(torch.zeros(N * ceil_div(L['cout'], 16) * 16 * 3, dtype=torch.float32, device=dev) if L['norm'] else None)
             h, w = ho, wo
         self.logits = self.acts[-1]
         self.g_logits = BTensor(N, 16, h, w, True, dev)
@@ -187,9 +282,15 @@ class _DPlan:
             if L['norm']:
                 ops.add(conv_op(pack, L['fwd'], src.view(), True, L['cin_pad'], hi, wi, ho, wo, N, bias=bias, kh=L['kh'], stride=L['stride'],
                                 pad=L['pad'], out_f32=self.zs[i].view()))
-                o = _op(_lib.OP_INORM_FWD)
-                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = self.zs[i].view(), N, L['cout'], ho, wo
-                o.f[0], o.f[1], o.t[1], o.p[0] = IN_EPS, SLOPE, self.acts[i].view(), self.stats[i].data_ptr()
+                if L['norm'] == 'batch':
+                    o = _op(_lib.OP_BNORM_FWD)
+                    o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = self.zs[i].view(), N, L['cout'], ho, wo, self.group
+                    o.f[0], o.f[1], o.p[0], o.p[1], o.t[1], o.p[2] = BN_EPS, SLOPE, P.ptr(L['bn'] + 'weight'), P.ptr(L['bn'] + 'bias'), self.acts[i].view(), \
+                        self.stats[i].data_ptr()
+                else:
+                    o = _op(_lib.OP_INORM_FWD)
+                    o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = self.zs[i].view(), N, L['cout'], ho, wo
+                    o.f[0], o.f[1], o.t[1], o.p[0] = IN_EPS, SLOPE, self.acts[i].view(), self.stats[i].data_ptr()
                 ops.add(o)
             else:
                 ops.add(conv_op(pack, L['fwd'], src.view(), True, L['cin_pad'], hi, wi, ho, wo, N, bias=bias, kh=L['kh'], stride=L['stride'],
@@ -204,15 +305,16 @@ class _DPlan:
         (hi, wi), (ho, wo) = self.dims[i], self.dims[i + 1]
         cb = ceil_div(L['cout'], 16) * 16
         m = mask.view() if mask is not None else None
+        gsc = 4096.0 if net.prec == 4 else 0.0   # split-f16: gradients (1e-8 .. 1e-1) pre-scaled by 2^12 into f16's normal range (exact, undone on the accumulator)
         if L['stride'] == 1:
             ops.add(conv_op(pack, L['bwd'], g_in.view(), True, cb, ho, wo, hi, wi, N, kh=L['kh'], stride=1, pad=L['kh'] - 1 - L['pad'], mask=m,
-                            mask_f32=1, slope=SLOPE, out_f32=out.view()))
+                            mask_f32=1, slope=SLOPE, out_f32=out.view(), in_scale=gsc))
         else:
             for (py, px), ref in L['bwd'].items():
                 hs, wsub = (hi - py + 1) // 2, (wi - px + 1) // 2
                 ops.add(conv_op(pack, ref, g_in.view(), True, cb, ho, wo, hs, wsub, N, kh=2, stride=1, pad=_PARITY_PAD[py],
                                 pad_x=_PARITY_PAD[px], mask=m, mask_f32=1, slope=SLOPE, out_f32=out.view(), out_stride=2, out_oy=py,
-                                out_ox=px, out_W=wi))
+                                out_ox=px, out_W=wi, in_scale=gsc))
 
     def _build_bwd(self, N, wgrad, input_grad):
         """input: self.g_logits.  N may be a prefix of the batch (views start at image 0)."""
@@ -223,7 +325,15 @@ class _DPlan:
             L = net.layers[i]
             (hi, wi), (ho, wo) = self.dims[i], self.dims[i + 1]
             gz = self.gz[i]
-            if L['norm']:  # dL/da -> dL/dz through InstanceNorm + LeakyReLU
+            if L['norm'] == 'batch':  # dL/da -> dL/dz through BatchNorm (per-half statistics) + LeakyReLU; dgamma / dbeta in the discriminator step
+                o = _op(_lib.OP_BNORM_BWD)
+                o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = self.zs[i].view(), self.ga[i].view(), N, L['cout'], ho, wo, self.group
+                o.f[0], o.p[0], o.p[1], o.p[2], o.t[2] = SLOPE, P.ptr(L['bn'] + 'weight'), P.ptr(L['bn'] + 'bias'), self.stats[i].data_ptr(), gz.view()
+                o.p[3] = P.ptr(L['bn'] + 'weight', P.grad) if wgrad else None
+                o.l[0] = P.ptr(L['bn'] + 'bias', P.grad) if wgrad else 0
+                o.f[1] = 1.0
+                ops.add(o)
+            elif L['norm']:  # dL/da -> dL/dz through InstanceNorm + LeakyReLU
                 o = _op(_lib.OP_INORM_BWD)
                 o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3] = self.acts[i].view(), self.ga[i].view(), N, L['cout'], ho, wo
                 o.f[0], o.p[0], o.t[2] = SLOPE, self.stats[i].data_ptr(), gz.view()
@@ -231,8 +341,11 @@ class _DPlan:
             inp = self.x if i == 0 else self.acts[i - 1]
             if wgrad:
                 grp = WgradGroup(L['kh'], L['stride'])
+                # prec 4 nets: the weight-gradient operands are rounded to f16 (11 bits, gradient pre-scaled) instead of bf16 (8 bits): behind a
+                # BatchNorm the output gradient sums to zero over the group, so only the deviation of the input from its mean counts
                 grp.add_conv(gz.view, True, gz.planes, inp.view, True, inp.planes, L['cout'], L['cin'], hi, wi, ho, wo, N,
-                             P.off(L['key'] + 'weight'), P.off(L['key'] + 'bias') if L['bias'] else None, pad=L['pad'])
+                             P.off(L['key'] + 'weight'), P.off(L['key'] + 'bias') if L['bias'] else None, pad=L['pad'],
+                             f16=net.prec == 4, g_scale=4096.0 if net.prec == 4 else 0.0)
                 grp.finalize(self.ws, net.device)
                 for o in grp.ops(P.grad.data_ptr()):
                     ops.add(o)
@@ -245,6 +358,19 @@ class _DPlan:
                     self._dgrad_ops(ops, i, N, gz, self.gz[i - 1], self.acts[i - 1])  # plain conv+LeakyReLU layer
             elif input_grad:
                 self._dgrad_ops(ops, 0, N, gz, self.gx, None)
+        return ops
+
+    def running_ops(self, g):
+        """BatchNorm running statistics after a training-mode forward on group g (0 = fake half, 1 = real half): one op per BN layer"""
+        ops = OpList()
+        for i, L in enumerate(self.net.layers):
+            if L['norm'] == 'batch':
+                ho, wo = self.dims[i + 1]
+                B = self.net.buffers
+                o = _op(_lib.OP_BNORM_RUNNING)
+                o.p[0], o.i[0], o.i[1], o.i[2], o.f[0] = self.stats[i].data_ptr(), g, L['cout'], self.group * ho * wo, BN_MOMENTUM
+                o.p[1], o.p[2], o.p[3] = B[L['bn'] + 'running_mean'].data_ptr(), B[L['bn'] + 'running_var'].data_ptr(), B[L['bn'] + 'num_batches_tracked'].data_ptr()
+                ops.add(o)
         return ops
 
     def bwd_data_ops(self, n):

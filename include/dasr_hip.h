@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DASR_ABI_VERSION 6
+#define DASR_ABI_VERSION 7
 #define DASR_EINVAL (-22)
 
 typedef struct {
@@ -47,7 +47,8 @@ typedef struct {
     const float* bias;                      /* [cout] or NULL */
     int32_t cout, Hout, Wout, N;
     int32_t kh, stride, pad;                /* 3/1/1 or 4/2/1 or 4/1/1; the f32-tensor 3x3 stride-1 conv also takes pad 0 / 2 (LPIPS conv1 and its adjoint) */
-    int32_t prec;                           /* 1: bf16 operands; 2: f16 operands, one MFMA pass (f32 input, see in_scale); 3: split-bf16 (hi*hi+hi*lo+lo*hi), ~fp32 */
+    int32_t prec;                           /* 1: bf16 operands; 2: f16 operands, one MFMA pass (f32 input, see in_scale); 3: split-bf16 (hi*hi+hi*lo+lo*hi), ~fp32;
+                                             * 4: split-f16 (same three passes on f16 hi/lo pairs of the in_scale'd f32 input: 22-bit operands) */
     int32_t mt;                             /* 32-oc tiles per workgroup (1 or 2); must match the packing */
     int32_t act;  float slope;
     dasr_tensor mask;  int32_t mask_f32;
@@ -146,7 +147,7 @@ typedef struct {
     int64_t lo_off;       /* 0 when prec 1 */
     int32_t cout, cin_pad, ntaps, mt, nseg;
     int32_t src_ntaps;    /* taps of the source weight (kh*kw of the nn.Conv2d) */
-    int32_t fmt;          /* 0: bf16 (hi plane, + lo plane when lo_off != 0); 1: f16 (prec 2 convs) */
+    int32_t fmt;          /* 0: bf16 (hi plane, + lo plane when lo_off != 0); 1: f16 (prec 2 convs); 2: f16 hi + f16 lo planes (prec 4) */
     int8_t  tapmap[32];   /* packed tap -> source tap (identity: forward; reversed: stride-1 dgrad; parity subset: stride-2 dgrad) */
     uint16_t tapmask[16]; /* non-zero: packed tap t (< 16) = SUM of the source taps whose bits are set (sub-pixel form of nearest-x2 + 3x3) */
     dasr_pack_seg seg[5];
@@ -209,6 +210,17 @@ int dasr_inorm_lrelu_fwd(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t
                          float* stats, void* stream);
 int dasr_inorm_lrelu_bwd(dasr_tensor a, dasr_tensor ga, int32_t N, int32_t C, int32_t H, int32_t W, float slope,
                          const float* stats, dasr_tensor gx, void* stream);
+/* nn.BatchNorm2d in TRAINING mode (batch statistics, affine gamma / beta) + LeakyReLU of Discriminator_VGG_128 (architecture.py:442-495), fused.
+ * The N images are normalised in groups of `group` consecutive images with their own statistics (the reference runs the discriminator on the
+ * fake and the real half in separate calls, DASR_model.py:251,288-289).  stats[N/group][Cpad][3] = (mean, rstd, biased variance).
+ * Backward recomputes xhat / z from the saved conv output x: gx per group; dgamma / dbeta (optional, both or none) = pscale * sums over all groups.
+ * dasr_bnorm_running: running_mean / running_var (unbiased, `count` = elements per channel of the group) / num_batches_tracked after one forward on group g */
+int dasr_bnorm_lrelu_fwd(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, int32_t group, float eps, float slope, const float* gamma,
+                         const float* beta, dasr_tensor y, float* stats, void* stream);
+int dasr_bnorm_lrelu_bwd(dasr_tensor x, dasr_tensor ga, int32_t N, int32_t C, int32_t H, int32_t W, int32_t group, float slope, const float* gamma,
+                         const float* beta, const float* stats, dasr_tensor gx, float* dgamma, float* dbeta, float pscale, void* stream);
+int dasr_bnorm_running(const float* stats, int32_t g, int32_t C, int32_t count, float momentum, float* running_mean, float* running_var,
+                       float* num_batches_tracked, void* stream);
 /* GANLoss('vanilla') = BCEWithLogitsLoss vs a constant target (loss.py:8-40): loss_acc += coef*sum(bce),
  * score_acc += score_coef*sum(x) (the disc_Score log), grad = gcoef*(sigmoid(x)-target) */
 int dasr_bce_logits(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, float target, float coef, float gcoef,
@@ -309,7 +321,8 @@ enum { DASR_OP_CONV = 1, DASR_OP_WGRAD = 2, DASR_OP_WGRAD_REDUCE = 3, DASR_OP_PA
        /* scheduling ops: p[0] = event from dasr_event_create / a hipStream_t (NULL: back to the stream dasr_run_ops was called with) */
        DASR_OP_EVENT_RECORD = 28, DASR_OP_STREAM_WAIT = 29, DASR_OP_SET_STREAM = 30,
        DASR_OP_CVT_F16 = 31, DASR_OP_DOWNSUM_F16 = 32, DASR_OP_PIXSHUF = 33, DASR_OP_PIXUNSHUF = 34,
-       DASR_OP_LPIPS_S2D = 35, DASR_OP_MAXPOOL3 = 36, DASR_OP_MAXPOOL3_BWD = 37, DASR_OP_LPIPS_HEAD = 38, DASR_OP_RAGAN = 39 };
+       DASR_OP_LPIPS_S2D = 35, DASR_OP_MAXPOOL3 = 36, DASR_OP_MAXPOOL3_BWD = 37, DASR_OP_LPIPS_HEAD = 38, DASR_OP_RAGAN = 39,
+       DASR_OP_BNORM_FWD = 40, DASR_OP_BNORM_BWD = 41, DASR_OP_BNORM_RUNNING = 42 };
 
 typedef struct {
     int32_t op;  int32_t i[8];  float f[4];  int64_t l[4];  void* p[4];  dasr_tensor t[5];

@@ -29,6 +29,9 @@ CASES = OrderedDict([
     ('dasr_srcD_wavelet_nf32_nb2_n2_32', dict(kind='dasr', nf=32, nb=2, n=2, lr=32, fs='wavelet', d_in_nc=9, gan_src=0.02)),
     # relativistic average GAN (`ragan: true`, DASR_model.py:240-244,252-256,273-275,291-293) on both discriminators, n = 3 so that the batch means matter
     ('dasr_ragan_wavelet_nf32_nb1_n3_32', dict(kind='dasr', nf=32, nb=1, n=3, lr=32, fs='wavelet', d_in_nc=9, gan_src=0.02, ragan=True)),
+    # source-domain discriminator = Discriminator_VGG_128 (which_model_pairD 'discriminator_vgg_128', architecture.py:442-495): BatchNorm in training
+    # mode, two Linear layers; needs 128 x 128 inputs: gaussian frequency split at HR = 4 x 32
+    ('dasr_srcVGG128_gau5_nf32_nb1_n3_32', dict(kind='dasr', nf=32, nb=1, n=3, lr=32, fs='gau', d_in_nc=3, gan_src=0.02, pairD='discriminator_vgg_128')),
 ])
 
 
@@ -40,6 +43,12 @@ def seeded_state_dict(template_sd, seed, scale):
             fan_in = v.shape[1] * v.shape[2] * v.shape[3]
             g = torch.Generator().manual_seed(seed * 100003 + i)
             out[k] = torch.randn(v.shape, generator=g) * (math.sqrt(2.0 / fan_in) * scale)
+        elif v.dim() == 2:   # nn.Linear (Discriminator_VGG_128)
+            g = torch.Generator().manual_seed(seed * 100003 + i)
+            out[k] = torch.randn(v.shape, generator=g) * (math.sqrt(2.0 / v.shape[1]) * scale)
+        elif v.dim() == 1 and k.endswith('weight') and k.split('.')[-2].startswith('bn'):   # BatchNorm gamma: around 1, not exactly
+            g = torch.Generator().manual_seed(seed * 100003 + i)
+            out[k] = 1.0 + (torch.rand(v.shape, generator=g) - 0.5) * 0.2
         elif k.endswith('bias'):
             g = torch.Generator().manual_seed(seed * 100003 + i)
             out[k] = (torch.rand(v.shape, generator=g) - 0.5) * 0.02  # non-zero so bias paths are exercised
@@ -62,7 +71,7 @@ def make_opt(case):
                   'manual_seed': 0},
     }
     if c['kind'] == 'dasr':
-        opt['network_D'] = {'which_model_D': 'discriminator_patch', 'which_model_pairD': 'discriminator_patch', 'norm_type': 'Batch',
+        opt['network_D'] = {'which_model_D': 'discriminator_patch', 'which_model_pairD': c.get('pairD', 'discriminator_patch'), 'norm_type': 'Batch',
                             'act_type': 'leakyrelu', 'mode': 'CNA', 'nf': 64, 'in_nc': c['d_in_nc'], 'n_layers': 2}
         opt['train'].update({'lr_D': 1e-4, 'weight_decay_D': 0, 'beta1_D': 0.9, 'fs': c['fs'], 'fs_kernel_size': 9,
                              'norm': True, 'sup_LL': True, 'pixel_LL_weight': 1, 'feature_criterion': c.get('fea', 'l1'),

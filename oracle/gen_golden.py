@@ -112,7 +112,7 @@ def run_oracle(case):
         netF = lpips.golden_criterion(77)[0]
     netD2 = None
     if c.get('gan_src', 0) > 0:
-        netD2 = nets.NLayerDiscriminator(c['d_in_nc'], 64, n_layers=2)
+        netD2 = nets.Discriminator_VGG_128(c['d_in_nc'], 64) if c.get('pairD') == 'discriminator_vgg_128' else nets.NLayerDiscriminator(c['d_in_nc'], 64, n_layers=2)
         netD2.load_state_dict(fixtures.seeded_state_dict(netD2.state_dict(), 3, 1.0))
     t = trainers.DASRTrainer(opt, netG=netG, netD=netD, netF=netF, vgg_seed=77, netD_source=netD2)
     return collect(case, netG, netD, t.update_learning_rate, t.feed_data, t.optimize_parameters, lambda: t.log, netD2=netD2)

@@ -250,3 +250,41 @@ def tensor_digest(t):
     t = t.detach().double().flatten()
     idx = torch.arange(t.numel(), dtype=torch.float64)
     return [float(t.sum()), float((t * t).sum()), float((t * torch.cos(idx * 0.37)).sum())]
+
+
+class Discriminator_VGG_128(nn.Module):
+    """codes/SRN/models/modules/architecture.py:442-495: VGG-style discriminator for 128 x 128 inputs, BatchNorm2d(affine) + LeakyReLU(0.2)"""
+
+    def __init__(self, in_nc, nf):
+        super().__init__()
+        self.conv0_0 = nn.Conv2d(in_nc, nf, 3, 1, 1, bias=True)
+        self.conv0_1 = nn.Conv2d(nf, nf, 4, 2, 1, bias=False)
+        self.bn0_1 = nn.BatchNorm2d(nf, affine=True)
+        self.conv1_0 = nn.Conv2d(nf, nf * 2, 3, 1, 1, bias=False)
+        self.bn1_0 = nn.BatchNorm2d(nf * 2, affine=True)
+        self.conv1_1 = nn.Conv2d(nf * 2, nf * 2, 4, 2, 1, bias=False)
+        self.bn1_1 = nn.BatchNorm2d(nf * 2, affine=True)
+        self.conv2_0 = nn.Conv2d(nf * 2, nf * 4, 3, 1, 1, bias=False)
+        self.bn2_0 = nn.BatchNorm2d(nf * 4, affine=True)
+        self.conv2_1 = nn.Conv2d(nf * 4, nf * 4, 4, 2, 1, bias=False)
+        self.bn2_1 = nn.BatchNorm2d(nf * 4, affine=True)
+        self.conv3_0 = nn.Conv2d(nf * 4, nf * 8, 3, 1, 1, bias=False)
+        self.bn3_0 = nn.BatchNorm2d(nf * 8, affine=True)
+        self.conv3_1 = nn.Conv2d(nf * 8, nf * 8, 4, 2, 1, bias=False)
+        self.bn3_1 = nn.BatchNorm2d(nf * 8, affine=True)
+        self.conv4_0 = nn.Conv2d(nf * 8, nf * 8, 3, 1, 1, bias=False)
+        self.bn4_0 = nn.BatchNorm2d(nf * 8, affine=True)
+        self.conv4_1 = nn.Conv2d(nf * 8, nf * 8, 4, 2, 1, bias=False)
+        self.bn4_1 = nn.BatchNorm2d(nf * 8, affine=True)
+        self.linear1 = nn.Linear(512 * 4 * 4, 100)
+        self.linear2 = nn.Linear(100, 1)
+        self.lrelu = nn.LeakyReLU(0.2)
+
+    def forward(self, x):
+        f = self.lrelu(self.conv0_0(x))
+        f = self.lrelu(self.bn0_1(self.conv0_1(f)))
+        for a in ('1', '2', '3', '4'):
+            f = self.lrelu(getattr(self, 'bn%s_0' % a)(getattr(self, 'conv%s_0' % a)(f)))
+            f = self.lrelu(getattr(self, 'bn%s_1' % a)(getattr(self, 'conv%s_1' % a)(f)))
+        f = self.lrelu(self.linear1(f.reshape(f.size(0), -1)))
+        return self.linear2(f)

@@ -99,12 +99,16 @@ class DASRTrainer:
             self.optimizers.append(self.opt_D)
         self.netD_src = None
         if self.l_gan_src_w > 0:   # DASR_model.py:45-47,139-143; define_pairD 'discriminator_patch' passes nf as ndf (networks.py:217-218)
-            if d.get('which_model_pairD') != 'discriminator_patch':
+            if d.get('which_model_pairD') not in ('discriminator_patch', 'discriminator_vgg_128'):
                 raise NotImplementedError('Discriminator model [{:s}] not recognized'.format(str(d.get('which_model_pairD'))))
             self.netD_src = netD_source
             if self.netD_src is None:
-                self.netD_src = nets.NLayerDiscriminator(d['in_nc'], d['nf'], d['n_layers'])
+                if d['which_model_pairD'] == 'discriminator_vgg_128':    # networks.py:201-202
+                    self.netD_src = nets.Discriminator_VGG_128(d['in_nc'], d['nf'])
+                else:
+                    self.netD_src = nets.NLayerDiscriminator(d['in_nc'], d['nf'], d['n_layers'])
                 nets.init_kaiming_(self.netD_src, 1)
+            self.netD_src.train()
             self.opt_D_src = torch.optim.Adam(self.netD_src.parameters(), lr=t['lr_D'], weight_decay=_opt(t, 'weight_decay_D', 0),
                                               betas=(t['beta1_D'], 0.999))
             self.optimizers.append(self.opt_D_src)

@@ -207,9 +207,10 @@ def test_vgg_forward_and_input_gradient(prec, act_tol, grad_tol, margins):
 
 
 @pytest.mark.parametrize('case', ['dasr_wavelet_nf32_nb2_n2_32', 'dasr_gau9_nf64_nb1_n1_32', 'dasr_lpips_wavelet_nf32_nb2_n2_32',
-                                  'dasr_srcD_wavelet_nf32_nb2_n2_32', 'dasr_ragan_wavelet_nf32_nb1_n3_32'])
-def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir):
+                                  'dasr_srcD_wavelet_nf32_nb2_n2_32', 'dasr_ragan_wavelet_nf32_nb1_n3_32', 'dasr_srcVGG128_gau5_nf32_nb1_n3_32'])
+def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir, margins):
     dev = _gpu()
+    GRAD_TOL = VGG128_STEP_TOL if 'VGG128' in case else globals()['GRAD_TOL']   # see the note at VGG128_GRAD_TOL
     torch.set_num_threads(8)
     from oracle import fixtures, nets, trainers
     from dasr_amd import options
@@ -228,7 +229,7 @@ def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir):
         crit, sdF = lpips.golden_criterion(77, golden_dir)
     netD2 = sdD2 = None
     if c.get('gan_src', 0) > 0:     # source-domain patch discriminator (define_pairD passes nf = 64 as ndf)
-        netD2 = nets.NLayerDiscriminator(c['d_in_nc'], 64, n_layers=2)
+        netD2 = nets.Discriminator_VGG_128(c['d_in_nc'], 64) if c.get('pairD') == 'discriminator_vgg_128' else nets.NLayerDiscriminator(c['d_in_nc'], 64, n_layers=2)
         sdD2 = fixtures.seeded_state_dict(netD2.state_dict(), 3, 1.0)
         netD2.load_state_dict(sdD2)
     t = trainers.DASRTrainer(opt, netG=netG, netD=netD, netF=crit, vgg_seed=77, netD_source=netD2)
@@ -276,11 +277,13 @@ def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir):
                 for (k, gv), pr in zip(d2.items(), netD2.parameters()):
                     if c.get('ragan') and k.endswith('model.8.bias'):
                         continue
-                    assert rel(gv, pr.grad) < GRAD_TOL, ('D_source', k, rel(gv, pr.grad))
+                    assert rel(gv.reshape(pr.grad.shape), pr.grad) < GRAD_TOL, ('D_source', k, rel(gv.reshape(pr.grad.shape), pr.grad))
                 np.testing.assert_allclose(np.array([float(v.double().norm()) for v in d2.values()]), gold['gradD2_norm'], rtol=GRAD_TOL, atol=1e-6)
             np.testing.assert_allclose(np.array([float(v.double().norm()) for v in gd.values()]), gold['gradG_norm'], rtol=GRAD_TOL)
             np.testing.assert_allclose(np.array([float(v.double().norm()) for v in dd.values()]), gold['gradD_norm'], rtol=GRAD_TOL, atol=1e-6)
-            print('%s: worst G grad rel err %.2e' % (case, worst))
+            w2 = max([rel(gv.reshape(pr.grad.shape), pr.grad) for (k, gv), pr in zip(m.netD_source.params.grad_dict().items(), netD2.parameters())
+                      if not (c.get('ragan') and k.endswith('model.8.bias'))]) if netD2 is not None else 0.0
+            margins('%s: worst gradient rel err G %.2e, D_source %.2e (bound %.0e)' % (case, worst, w2, GRAD_TOL))
 
 
 @pytest.mark.parametrize('n,n_glob,h,w', [(3, 3, 14, 14), (2, 6, 9, 11)])
@@ -327,3 +330,105 @@ def test_ragan_three_stage_loss_and_gradients(n, n_glob, h, w):
     assert abs(float(acc[0]) - float(la)) < 1e-5 * abs(float(la))
     assert abs(float(acc[1]) - float(A.detach()[:n].mean())) < 1e-5 and abs(float(acc[2]) - float(B.detach()[:n].mean())) < 1e-5
     assert rel(ga.nchw(1).cpu(), A.grad[:n]) < 1e-5 and rel(gb.nchw(1).cpu(), B.grad[:n]) < 1e-5
+
+
+def test_batchnorm_train_lrelu_forward_backward_two_groups():
+    """dasr_bnorm_lrelu_fwd / _bwd / _running against nn.BatchNorm2d(train) + LeakyReLU applied to the two halves of the batch separately"""
+    dev = _gpu()
+    from dasr_amd import _lib
+    from dasr_amd.engine import BTensor
+    g = torch.Generator().manual_seed(5)
+    n, C_, H, W = 3, 40, 9, 7
+    x = torch.randn(2 * n, C_, H, W, generator=g) * 2 + 0.5
+    bn = torch.nn.BatchNorm2d(C_)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.3 * torch.randn(C_, generator=g))
+        bn.bias.copy_(0.2 * torch.randn(C_, generator=g))
+    bn.train()
+    xr = x.clone().requires_grad_(True)
+    ga = torch.randn(2 * n, C_, H, W, generator=g)
+    y = torch.cat([F.leaky_relu(bn(xr[n:]), 0.2), F.leaky_relu(bn(xr[:n]), 0.2)])      # the reference's order: real half first, then fake
+    y = torch.cat([y[n:], y[:n]])
+    (y * ga).sum().backward()
+    Lib = _lib.lib()
+    xb, gab = to_blocked(x, dev), to_blocked(ga, dev)
+    yb, gxb = BTensor(2 * n, C_, H, W, True, dev), BTensor(2 * n, C_, H, W, True, dev)
+    gam, bet = bn.weight.detach().to(dev), bn.bias.detach().to(dev)
+    stats = torch.zeros(2 * 48 * 3, device=dev)
+    dg, db = torch.zeros(C_, device=dev), torch.zeros(C_, device=dev)
+    _lib.check(Lib.dasr_bnorm_lrelu_fwd(xb.view(), 2 * n, C_, H, W, n, 1e-5, 0.2, gam.data_ptr(), bet.data_ptr(), yb.view(), stats.data_ptr(), None))
+    _lib.check(Lib.dasr_bnorm_lrelu_bwd(xb.view(), gab.view(), 2 * n, C_, H, W, n, 0.2, gam.data_ptr(), bet.data_ptr(), stats.data_ptr(), gxb.view(),
+                                        dg.data_ptr(), db.data_ptr(), 1.0, None))
+    rm, rv, nbt = torch.zeros(C_, device=dev), torch.ones(C_, device=dev), torch.zeros(1, device=dev)
+    for grp in (1, 0):   # real, then fake: the order of the two reference forwards above
+        _lib.check(Lib.dasr_bnorm_running(stats.data_ptr(), grp, C_, n * H * W, 0.1, rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert rel(yb.nchw().cpu(), y.detach()) < 1e-5
+    assert rel(gxb.nchw().cpu(), xr.grad) < 1e-4
+    assert rel(dg.cpu(), bn.weight.grad) < 1e-4 and rel(db.cpu(), bn.bias.grad) < 1e-4
+    assert rel(rm.cpu(), bn.running_mean) < 1e-5 and rel(rv.cpu(), bn.running_var) < 1e-5 and int(nbt.item()) == int(bn.num_batches_tracked)
+
+
+# Discriminator_VGG_128: nine training-mode BatchNorm layers in a row with tiny statistics groups (n x 4 x 4 values per channel at the top).
+# Forward is accurate (logits 3e-5).  Backward: (i) the weight-gradient kernel rounds its f32 operands to bf16, which averages out over the
+# pixels of a map but not on the 1 x 1 maps of the two Linear layers (3e-3 there); (ii) each BatchNorm backward subtracts the group means of
+# gz and gz * xhat from gz -- a cancellation that amplifies the relative error of the incoming gradient -- so the data-gradient error grows
+# from 2.6e-3 at conv4_1 to 8.5e-3 at the input and 1.1e-2 .. 1.4e-2 on the first layers' weight gradients.  The gradient bound of THIS network
+# is 2e-2 (documented in DESIGN.md 4.7), margins logged; every other network keeps 1e-2.
+VGG128_GRAD_TOL = 2e-2
+# in the DASR step the discriminator sees high-frequency maps (0.75 + small detail): conv outputs with |mean| >> std in front of every BatchNorm,
+# the worst case for that cancellation.  The case is ill-conditioned in itself: the fp32 CPU oracle differs from the same oracle run in fp64 by
+# 3.2e-3 on the generator gradients and 1.2e-2 on D_source's (measured with identical weights); bound 3e-2 for this case only, margins logged
+VGG128_STEP_TOL = 3e-2
+
+
+def test_discriminator_vgg128_forward_backward_and_state_dict(margins):
+    dev = _gpu()
+    from dasr_amd.gan_nets import DiscriminatorVGG128HIP
+    from oracle import nets, fixtures
+    ref = nets.Discriminator_VGG_128(3, 64)
+    sd = fixtures.seeded_state_dict(ref.state_dict(), 3, 1.0)
+    ref.load_state_dict(sd)
+    ref.train()
+    D = DiscriminatorVGG128HIP(3, 64, device=dev)
+    D.load_state_dict(sd)
+    n = 2
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(2 * n, 3, 128, 128, generator=g)
+    p = D.plan(2 * n, 128, 128)
+    p.x.t.copy_(to_blocked(x, dev).t)
+    p.fwd.run()
+    out = torch.cat([ref(x[:n]), ref(x[n:])])              # separate calls per half: separate batch statistics
+    got = p.logits.nchw(1).cpu().reshape(2 * n, 1)
+    assert rel(got, out.detach()) < ACT_TOL, rel(got, out.detach())
+    gl = torch.randn(2 * n, 1, generator=g)
+    p.g_logits.t.copy_(to_blocked(gl.reshape(2 * n, 1, 1, 1), dev).t)
+    (out * gl).sum().backward()
+    p.bwd_full.run()
+    p.running_ops(0).run()
+    p.running_ops(1).run()
+    torch.cuda.synchronize()
+    gd = D.params.grad_dict()
+    worst, errs = 0.0, []
+    for (k, gv), pr in zip(gd.items(), ref.parameters()):
+        r = rel(gv.reshape(pr.grad.shape), pr.grad)
+        worst = max(worst, r)
+        errs.append('%s %.1e' % (k, r))
+    # generator-step path: data gradient of the fake half alone (its own batch statistics), down to the input image
+    xf = x[:n].clone().requires_grad_(True)
+    (ref(xf) * gl[:n]).sum().backward()
+    p.g_logits.t.copy_(to_blocked(gl.reshape(2 * n, 1, 1, 1), dev).t)
+    p.bwd_data_ops(n).run()
+    p.running_ops(0).run()        # the reference side just ran a third forward (fake half again), as the generator step does
+    torch.cuda.synchronize()
+    e_in = rel(p.gx.nchw(3).cpu()[:n], xf.grad)
+    margins('Discriminator_VGG_128 (BatchNorm, train mode): logits rel err %.2e (tol 1e-3); worst weight-gradient rel err %.2e, dL/dinput %.2e (bound %.0e): %s'
+            % (rel(got, out.detach()), worst, e_in, VGG128_GRAD_TOL, ' | '.join(errs[:6])))
+    assert worst < VGG128_GRAD_TOL and e_in < VGG128_GRAD_TOL, (worst, e_in)
+    sd2 = D.state_dict()
+    assert list(sd2.keys()) == list(ref.state_dict().keys())
+    for k, v in ref.state_dict().items():
+        assert tuple(sd2[k].shape) == tuple(v.shape) and sd2[k].dtype == v.dtype, k
+        if 'running' in k or 'num_batches' in k:
+            assert rel(sd2[k].float(), v.float()) < 1e-4, k
+    print('Discriminator_VGG_128: worst grad rel err %.2e' % worst)
