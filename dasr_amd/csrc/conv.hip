@@ -1378,7 +1378,9 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
         case 3111: return launch<4, true, 1, 4, 1, 2>(p, s);
         case 3112: return launch<4, true, 1, 4, 2, 1>(p, s);
         case 3113: return launch<4, true, 1, 2, 1, 4>(p, s);
+        case 3114: return launch<4, true, 1, 5, 1, 2>(p, s);
         case 3115: return launch<4, true, 1, 1, 1, 4>(p, s);
+        case 3116: return launch<4, true, 1, 3, 2, 1>(p, s);
         // prec 2: f16 operands, ONE MFMA pass on f32 activations (HR tail of the generator; VGG / discriminators / DSN when selected)
         case 2110: return launch<2, true, 1, 3, 1, 4>(p, s);
         case 2120: return launch<2, true, 2, 3, 1, 4>(p, s);

@@ -127,7 +127,7 @@ _PARITY_PAD = {0: 1, 1: 0}
 
 
 class NLayerDiscriminatorHIP:
-    prec = 3   # split-bf16 operands (~fp32); DiscriminatorVGG128HIP: 4 = split-f16 (22-bit operands)
+    prec = int(__import__('os').environ.get('DASR_D_PREC', '4'))   # 4: split-f16 operands (22 bits, default since round 2; DiscriminatorVGG128HIP always); 3: split-bf16 (16 bits)
 
     def __init__(self, input_nc, ndf=64, n_layers=2, device='cuda', spec_layers=None):
         self.input_nc, self.device = input_nc, torch.device(device)
@@ -412,7 +412,9 @@ class VGGFeatureHIP:
     """Frozen feature extractor: forward on N images, data-gradient w.r.t. the first n_g inputs."""
 
     def __init__(self, feature_layer=34, device='cuda', cfg=None, prec=None):
-        """prec 3 (default): split-bf16 operands on f32 tensors (~fp32, 3 MFMA passes).  prec 2: activations and gradients stored in f16
+        """prec 4 (default): split-f16 operands on f32 tensors (f16 hi + lo pairs, 22 mantissa bits, 3 MFMA passes; gradients pre-scaled by a
+        power of two): input-gradient error 4.9e-6 against the fp32 oracle.  prec 3: split-bf16 (16 bits), same cost: 6.5e-3 on the input
+        gradient (max-pool arg-max flips on 16-bit ties), the default until round 2.  prec 2: activations and gradients stored in f16
         (11-bit mantissa; gradients pre-scaled by a power of two), one f16 MFMA pass on the LDS-DMA dense-conv kernel: the full GAN step
         drops from 101 to 84 ms, but over the 16 un-damped layers the operand rounding adds up to 1.0e-3 on the features, and max-pool's
         arg-max routing turns 11-bit ties into an 11 % normwise error of dL/dx (1.2-1.6e-2 on the generator gradient of the full step) with
@@ -420,7 +422,7 @@ class VGGFeatureHIP:
         default.  prec 1: plain bf16 operands on f32 tensors (8x coarser than f16)."""
         import os
         self.device = torch.device(device)
-        self.prec = int(prec if prec is not None else os.environ.get('DASR_VGG_PREC', '3'))
+        self.prec = int(prec if prec is not None else os.environ.get('DASR_VGG_PREC', '4'))
         self.f16s = self.prec == 2
         self.spec, self.layers = vgg19_spec(feature_layer, cfg)
         self.params = ParamStore(self.spec, self.device)
@@ -486,6 +488,10 @@ class _VGGPlan:
         n = n_g
         self.g_feat = BTensor(N, self.feat.C, self.feat.H, self.feat.W, True, dev)
         self.gx = BTensor(N, 16, H, W, True, dev)
+        # prec 4 (split-f16): dL/dfeat of a mean loss is ~1 / element count; a power-of-two pre-scale keeps it in f16's normal range (exact)
+        import math
+        cnt = max(1, n_g * self.feat.C * self.feat.H * self.feat.W)
+        gsc = float(2.0 ** max(0, int(math.floor(math.log2(cnt))) - 3)) if net.prec == 4 else 0.0
         bwd = OpList()
         g = self.g_feat
         for li in range(len(net.layers) - 1, -1, -1):
@@ -495,7 +501,7 @@ class _VGGPlan:
             if kind == 'conv':
                 prev_relu = li > 0 and net.layers[li - 1][0] == 'conv' and net.layers[li - 1][4]
                 bwd.add(conv_op(pack, net.pk[(idx, 'b')], g.view(), True, cout, inp.H, inp.W, inp.H, inp.W, n,
-                                mask=inp.view() if prev_relu else None, mask_f32=1, slope=0.0, out_f32=gin.view()))
+                                mask=inp.view() if prev_relu else None, mask_f32=1, slope=0.0, out_f32=gin.view(), in_scale=gsc))
             else:
                 o = _op(_lib.OP_MAXPOOL_BWD)
                 o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.t[2] = inp.view(), g.view(), n, cout, g.H, g.W, 1, 1, gin.view()

@@ -31,6 +31,7 @@ SHIFT = (-.030, -.088, -.188)     # ScalingLayer, networks_basic.py:94-101
 SCALE = (.458, .448, .450)
 CHNS = (64, 192, 384, 256, 256)   # networks_basic.py:41-43
 EPS = 1e-10                       # normalize_tensor, models/util.py:42-44
+PREC = 4                          # split-f16 conv operands (f16 hi + lo pairs, 22 bits, three MFMA passes); 3 = split-bf16 (16 bits)
 #          key           cout cin  k  pad  followed by a MaxPool2d(3, 2)
 CONVS = (('features.0', 64, 3, 11, 2, True), ('features.3', 192, 64, 5, 2, True), ('features.6', 384, 192, 3, 1, False),
          ('features.8', 256, 384, 3, 1, False), ('features.10', 256, 256, 3, 1, False))
@@ -121,8 +122,8 @@ class LPIPSAlexHIP:
         for key, cout, cin, k, pad, pool in CONVS:
             wkey, kk, cin_ = (('c1.weight', 3, 48) if key == 'features.0' else (key + '.weight', k, cin))
             w = P.off(wkey)
-            self.pk[key] = self.pack.add(cout, cin_, kk * kk, 1, 3, [(w, cout, cin_, 0, cin_, 0, 0)])
-            self.pk[(key, 'b')] = self.pack.add(cin_, cout, kk * kk, 1, 3, [(w, cout, cin_, 0, cout, 0, 1)])
+            self.pk[key] = self.pack.add(cout, cin_, kk * kk, 1, PREC, [(w, cout, cin_, 0, cin_, 0, 0)])
+            self.pk[(key, 'b')] = self.pack.add(cin_, cout, kk * kk, 1, PREC, [(w, cout, cin_, 0, cout, 0, 1)])
         self.pack.finalize()
         self._sd = None
         self.plans = {}
@@ -233,6 +234,8 @@ class _LPIPSPlan:
         # head gradients (w.r.t. the pre-activations of relu_k, fake images only); the data-gradient chain adds into / reads them
         self.ghead = [BTensor(n, r.C, r.H, r.W, True, dev) for r in self.relu]
         self.gx = BTensor(n, 48, Hs, Ws, True, dev)
+        # split-f16: the head gradients (~1 / (n * pixels)) are pre-scaled by a power of two into f16's normal range (exact, undone on the accumulator)
+        gsc = float(2.0 ** max(0, int(math.floor(math.log2(max(1, n * H * W // 16)))) - 3)) if PREC == 4 else 0.0
         bwd = OpList()
         g = self.ghead[4]                                   # total gradient at relu5 = its head gradient
         for li in range(4, 0, -1):
@@ -241,7 +244,7 @@ class _LPIPSPlan:
             if CONVS[li - 1][5]:                            # relu_{li} -> pool -> conv: dgrad to the pooled grid, pool backward ADDS into the head gradient
                 pl = self.pool[li - 1]
                 gp = BTensor(n, pl.C, pl.H, pl.W, True, dev)
-                bwd.add(conv_op(pack, net.pk[(key, 'b')], g.view(), True, cout, pl.H, pl.W, pl.H, pl.W, n, kh=k, pad=pad, out_f32=gp.view()))
+                bwd.add(conv_op(pack, net.pk[(key, 'b')], g.view(), True, cout, pl.H, pl.W, pl.H, pl.W, n, kh=k, pad=pad, out_f32=gp.view(), in_scale=gsc))
                 o = _op(_lib.OP_MAXPOOL3_BWD)
                 o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.t[2], o.i[4], o.i[5] = below.view(), gp.view(), n, below.C, below.H, below.W, \
                     self.ghead[li - 1].view(), 1, 1
@@ -251,12 +254,12 @@ class _LPIPSPlan:
             else:                                           # relu -> conv: ReLU' mask in the epilogue, head gradient added behind it
                 gt = BTensor(n, below.C, below.H, below.W, True, dev)
                 bwd.add(conv_op(pack, net.pk[(key, 'b')], g.view(), True, cout, below.H, below.W, below.H, below.W, n, kh=k, pad=pad,
-                                mask=below.view(), mask_f32=1, slope=0.0, res1=self.ghead[li - 1].view(), beta1=1.0, out_f32=gt.view()))
+                                mask=below.view(), mask_f32=1, slope=0.0, res1=self.ghead[li - 1].view(), beta1=1.0, out_f32=gt.view(), in_scale=gsc))
                 bwd.keep.append(gt)
                 g = gt
         r1 = self.relu[0]
         bwd.add(conv_op(pack, net.pk[('features.0', 'b')], g.view(), True, 64, r1.H, r1.W, Hs, Ws, n, kh=3, pad=2, out_f32=self.gx.view(),
-                        flops=2.0 * n * r1.H * r1.W * 121 * 3 * 64))
+                        flops=2.0 * n * r1.H * r1.W * 121 * 3 * 64, in_scale=gsc))
         self.bwd = bwd
         self._sc = [2.0 / s for s in SCALE] + [0.0]
         self._sh = [-(1.0 + sh) / s for sh, s in zip(SHIFT, SCALE)] + [0.0]

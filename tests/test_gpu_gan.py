@@ -177,7 +177,7 @@ def test_discriminator_forward_backward(nc, hw):
 # 2x2 window, and values rounded to 11 bits tie or swap order in ~1e-3 of the windows (normwise error ~ sqrt of that fraction; even the
 # ~fp32 path shows 6.5e-3 from this mechanism).  The path is checked against its own documented bounds so that it stays correct; it is
 # NOT what the trainers use by default.
-@pytest.mark.parametrize('prec,act_tol,grad_tol', [(3, ACT_TOL, GRAD_TOL), (2, 2.5e-3, 0.2)], ids=['split_bf16', 'f16_storage_optin'])
+@pytest.mark.parametrize('prec,act_tol,grad_tol', [(3, ACT_TOL, GRAD_TOL), (4, ACT_TOL, GRAD_TOL), (2, 2.5e-3, 0.2)], ids=['split_bf16', 'split_f16', 'f16_storage_optin'])
 def test_vgg_forward_and_input_gradient(prec, act_tol, grad_tol, margins):
     dev = _gpu()
     from dasr_amd.gan_nets import VGGFeatureHIP
