@@ -1,4 +1,4 @@
-"""MFMA-pipe utilisation per kernel from two rocprofv3 --pmc passes (scripts/_r20.sh: DASR_STREAMS=1, bench.py --steps 1 --warmup 1):
+"""MFMA-pipe utilisation per kernel from two rocprofv3 --pmc passes (scripts/pmc_mfma_busy.sh: DASR_STREAMS=1, bench.py --steps 1 --warmup 1):
    busy % = (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) / (SQ_BUSY_CYCLES / 32 shader engines)
 The normalisation is checked on the MFMA-only probe kernel of the same run (must read ~100 %).
 python scripts/pmc_mfma_busy.py gpurun_out > profiles/<tag>_pmc_mfma_busy.txt"""
