@@ -57,7 +57,7 @@ def test_cfg1_step_batch16_equals_mean_of_halves_and_is_deterministic(margins, m
     e = rel(grads[0], 0.5 * (grads[2] + grads[3]))
     margins('configs[1] full size: grad(batch 16, two streams) vs mean of the two batch-8 halves: rel err %.2e (tol 1e-5); losses %.6f vs %.6f' % (
         e, losses[0], 0.5 * (losses[2] + losses[3])))
-    assert e < 1e-5 and abs(losses[0] - 0.5 * (losses[2] + losses[3])) < 1e-6
+    assert e < 1e-5 and abs(losses[0] - 0.5 * (losses[2] + losses[3])) < 5e-6   # the logged loss is an fp32 atomic sum over 12.6 M terms
 
 
 def test_cfg2_gan_step_32_crops_equals_mean_of_halves(margins):
