@@ -89,3 +89,35 @@ def test_training_driver_validates_and_eval_cli_reports_metrics(tmp_path):
     # same images through the quadrant path: PSNR within a small margin of the plain forward
     s2 = dtest.main(['-opt', _json_opt(tmp_path, 'f1_test_chop', False, {'chop': True, 'path': {'root': str(tmp_path), 'pretrain_model_G': str(g_path)}})])
     assert abs(s2['synset']['psnr'] - s['psnr']) < 1.0
+
+
+def test_dasr_training_driver_with_lpips_criterion_source_discriminator_and_val_lpips(tmp_path):
+    """the option surface of the shipped train_DASR*.json (feature_criterion LPIPS, val_lpips, patch discriminators for both domains) through
+    `python -m dasr_amd.train`: logs, validation with the LPIPS column, the three checkpoint files and a resumable training state"""
+    _gpu()
+    from dasr_amd import train
+    opt = json.loads(open(_json_opt(tmp_path, 'f4_dasr', True)).read())
+    opt.update(model='DASR', val_lpips=True, multiweights=True)
+    opt['datasets']['train'].update(batch_size=2, HR_size=128, n_batches=4)
+    opt['datasets']['val'].update(LR_size=32)
+    opt['path'].update(pretrain_model_D_target=None, pretrain_model_D_source=None)
+    opt['network_D'] = {'which_model_D': 'discriminator_patch', 'which_model_pairD': 'discriminator_patch', 'norm_type': 'Batch', 'act_type': 'leakyrelu',
+                        'mode': 'CNA', 'nf': 64, 'in_nc': 9, 'n_layers': 2}
+    opt['train'].update({'lr_D': 1e-4, 'weight_decay_D': 0, 'beta1_D': 0.9, 'fs': 'wavelet', 'fs_kernel_size': 9, 'norm': True, 'sup_LL': True,
+                         'pixel_LL_weight': 1, 'feature_criterion': 'LPIPS', 'feature_weight': 1, 'gan_type': 'vanilla', 'ragan': False,
+                         'gan_H_target': 0.005, 'gan_H_source': 0.005, 'G_update_inter': 1, 'D_update_inter': 1, 'niter': 4, 'val_freq': 2})
+    p = tmp_path / 'f4_dasr.json'
+    p.write_text(json.dumps(opt))
+    train.main(['-opt', str(p)])
+    root = tmp_path / 'experiments' / 'f4_dasr'
+    val = [f for f in os.listdir(root) if f.startswith('val_') and f.endswith('.log')]
+    txt = (root / val[0]).read_text()
+    assert 'psnr:' in txt and 'LPIPS:' in txt
+    tr = [f for f in os.listdir(root) if f.startswith('train_') and f.endswith('.log')]
+    log = (root / tr[0]).read_text()
+    for key in ('loss/l_g_pix', 'loss/l_g_fea', 'loss/l_g_gan_target_Hf', 'loss/l_g_gan_source_H', 'loss/l_d_target_total', 'loss/l_d_total'):
+        assert key in log, key
+    for f in ('latest_G.pth', 'latest_D_target.pth', 'latest_D_source.pth'):
+        assert (root / 'models' / f).exists(), f
+    st = torch.load(root / 'training_state' / '4.state', weights_only=False)
+    assert len(st['optimizers']) == 3 and len(st['schedulers']) == 3 and st['iter'] == 4
