@@ -361,9 +361,7 @@ class WgradGroup3:
         wp0 = self.parts[0][0]
         ntiles = wp0.N * ceil_div(wp0.Hout, 8) * ceil_div(wp0.Wout, 16)
         nparts = len(self.parts)
-        self.nsplit = max(1, min(ntiles, target_wgs // nparts))
-        if self.nsplit >= 16:
-            self.nsplit -= self.nsplit % 8
+        self.nsplit = max(1, min(ntiles, target_wgs // nparts))   # any count: 17 splits x 15 parts = 255 workgroups (the reduction takes any nsplit)
         off, red = 0, []
         for wp, tiles in self.parts:
             wp.ws_off = off

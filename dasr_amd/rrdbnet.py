@@ -187,6 +187,7 @@ class _Plan:
         self.net, self.N, self.h, self.w = net, N, h, w
         dev, nf, nb = net.device, net.nf, net.nb
         self.inference = inference
+        self.replica = replica
         self.grad = net.params.grad if (replica == 0 or inference) else torch.zeros_like(net.params.grad)
         # power-of-two pre-scale of the HR-tail gradients before their f16 rounding (prec 2): dL/dSR of a mean loss is ~1 / (N 3 H W) ~ 1e-7,
         # far below f16's normal range; scaled to ~2^-3.  Exact (power of two), undone in the conv epilogue / the wgrad reduction.
@@ -388,6 +389,19 @@ class _Plan:
             self._build_backward_tail_f32(ops, f16, gs)
         self._build_backward_trunk(ops)
 
+    def _wg3_target(self, nparts):
+        """workgroups of a 12-wave weight-gradient launch (one per CU, nothing co-resides with them): the whole chip for a single plan; with
+        k concurrent sub-batch replicas, replica 0 takes 256 // k and the last replica also the CUs the integer split counts leave over
+        (15 parts: 8 + 9 splits = 120 + 135 workgroups instead of 120 + 120)"""
+        if os.environ.get('DASR_WG3_TARGET'):
+            return int(os.environ['DASR_WG3_TARGET'])
+        k = max(1, getattr(self.net, 'concurrent_replicas', 1))
+        share = 256 // k
+        if k > 1 and self.replica == k - 1:
+            used = (k - 1) * nparts * max(1, share // nparts)
+            return max(share, 256 - used)
+        return share
+
     def _wg3(self, ops, conv_key, g, inp, cout, cin, Hin, Win, Hout, Wout, ups=0):
         """weight gradient of one 3x3 conv on f16 tensors (g pre-scaled by gscale) with the 12-wave kernel: one part per 64-channel block of
         the input x up to three 32-oc tiles"""
@@ -404,7 +418,7 @@ class _Plan:
                               Hin, Win, Hout, Wout, N, tiles, want_bias=(c0 == 0), ups=ups)
         grp.f16, grp.g_scale = True, self.gscale
         grp.flops = 2.0 * N * Hout * Wout * 9 * cin * cout
-        grp.finalize(self.ws, self.net.device, target_wgs=int(os.environ.get('DASR_WG3_TARGET', str(256 // max(1, getattr(self.net, 'concurrent_replicas', 1))))))
+        grp.finalize(self.ws, self.net.device, target_wgs=self._wg3_target(len(grp.parts)))
         for o in grp.ops(self.grad.data_ptr()):
             ops.add(o)
         ops.keep.append(grp)
@@ -522,8 +536,7 @@ class _Plan:
             nonlocal grp, n_in_grp
             if grp is None:
                 return
-            grp.finalize(self.ws, net.device,
-                         target_wgs=int(os.environ.get('DASR_WG3_TARGET', str(256 // max(1, getattr(net, 'concurrent_replicas', 1))))))
+            grp.finalize(self.ws, net.device, target_wgs=self._wg3_target(len(grp.parts)))
             for o in grp.ops(self.grad.data_ptr()):
                 ops.add(o)
             ops.keep.append(grp)
