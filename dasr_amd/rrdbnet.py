@@ -390,17 +390,11 @@ class _Plan:
         self._build_backward_trunk(ops)
 
     def _wg3_target(self, nparts):
-        """workgroups of a 12-wave weight-gradient launch (one per CU, nothing co-resides with them): the whole chip for a single plan; with
-        k concurrent sub-batch replicas, replica 0 takes 256 // k and the last replica also the CUs the integer split counts leave over
-        (15 parts: 8 + 9 splits = 120 + 135 workgroups instead of 120 + 120)"""
+        """workgroups of a 12-wave weight-gradient launch (one per CU, nothing co-resides with them): the whole chip for a single plan, an equal
+        share for each of k concurrent sub-batch replicas"""
         if os.environ.get('DASR_WG3_TARGET'):
             return int(os.environ['DASR_WG3_TARGET'])
-        k = max(1, getattr(self.net, 'concurrent_replicas', 1))
-        share = 256 // k
-        if k > 1 and self.replica == k - 1:
-            used = (k - 1) * nparts * max(1, share // nparts)
-            return max(share, 256 - used)
-        return share
+        return 256 // max(1, getattr(self.net, 'concurrent_replicas', 1))
 
     def _wg3(self, ops, conv_key, g, inp, cout, cin, Hin, Win, Hout, Wout, ups=0):
         """weight gradient of one 3x3 conv on f16 tensors (g pre-scaled by gscale) with the 12-wave kernel: one part per 64-channel block of
