@@ -148,6 +148,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise DasrHipError('libdasr_hip.so is missing (%s): run `python -m dasr_amd.build` or __graft_entry__.build(); '
                                'the DASR MI355X path has no fallback.' % LIB_PATH)
+        # torch first: its wheel bundles its own libamdhip64.so (SONAME libamdhip64.so.7, but NEEDED as "libamdhip64.so"); if this library is
+        # loaded before torch, /opt/rocm's runtime comes in with it and torch then maps a SECOND HIP runtime -- torch's streams and
+        # allocations are foreign to ours and the first launch fails (hipErrorNoDevice).  With torch loaded, our NEEDED
+        # libamdhip64.so.7 resolves by SONAME to the runtime torch uses.  (A C consumer without torch gets /opt/rocm's, alone.)
+        import torch  # noqa: F401
         L = C.CDLL(os.environ.get('DASR_HIP_LIB') or LIB_PATH)  # DASR_HIP_LIB: instrumented build for scripts/ (same ABI)
         for name, args in _SIGS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export it

@@ -121,3 +121,16 @@ def test_dasr_training_driver_with_lpips_criterion_source_discriminator_and_val_
         assert (root / 'models' / f).exists(), f
     st = torch.load(root / 'training_state' / '4.state', weights_only=False)
     assert len(st['optimizers']) == 3 and len(st['schedulers']) == 3 and st['iter'] == 4
+
+
+@pytest.mark.gpu
+def test_graft_entry_in_fresh_process():
+    """the driver's round-end check: build() then smoke() in a fresh interpreter (the library is loaded BEFORE anything else imports
+    torch there -- dasr_amd._lib must still end up on torch's HIP runtime)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', 'import __graft_entry__ as g; g.build(); g.smoke()'], cwd=root, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'smoke: l_pix' in r.stdout
