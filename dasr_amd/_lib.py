@@ -91,6 +91,7 @@ _SIGS = {
     'dasr_inorm_lrelu_fwd': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, Tensor, c_vp, c_vp],
     'dasr_inorm_lrelu_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, Tensor, c_vp],
     'dasr_bce_logits': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp, c_f32, Tensor, c_vp],
+    'dasr_gan_loss': [Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp, c_f32, Tensor, c_vp],
     'dasr_dwt_fwd': [Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, Tensor, c_vp],
     'dasr_dwt_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_vp],
     'dasr_lowpass': [Tensor, Tensor, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, Tensor, Tensor, c_i32, c_vp],
@@ -129,7 +130,7 @@ _SIGS = {
     'dasr_prof_end': [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lib = None
 
 

@@ -246,12 +246,16 @@ __global__ void bnorm_running_kernel(const float* __restrict__ stats, int g, int
 }
 
 // ---------------------------------------------------------------------------------------------------
-// BCEWithLogits(x, t) mean over C real channels (GANLoss 'vanilla', loss.py:8-40):
-// loss_acc[0] += coef * sum(max(x,0) - x t + log1p(exp(-|x|))); loss_acc[1] += coef_mean * sum(x) (disc score);
-// grad = gcoef * (sigmoid(x) - t) (zero on padded channels)
+// GANLoss(gan_type) against a constant target over C real channels (loss.py:8-40), MODE = gan_type:
+//   0 'vanilla'  BCEWithLogits: l = max(x,0) - x t + log1p(exp(-|x|)),  dl/dx = sigmoid(x) - t
+//   1 'lsgan'    MSE:           l = (x - t)^2,                          dl/dx = 2 (x - t)
+//   2 'wgan-gp'  l = -x if the target is the real label (t > 0.5) else x (the reference never applies its gradient penalty: DASR_model.py:114-118
+//                builds cri_gp, optimize_parameters does not use it)
+// loss_acc[0] += coef * sum(l); score_acc += score_coef * sum(x) (disc score); grad = gcoef * dl/dx (zero on padded channels)
 // ---------------------------------------------------------------------------------------------------
-__global__ void bce_logits_kernel(dasr_tensor x, int N, int C, int H, int W, float target, float coef, float gcoef, float* loss_acc,
-                                  float* score_acc, float score_coef, dasr_tensor grad) {
+template <int MODE>
+__global__ void gan_loss_kernel(dasr_tensor x, int N, int C, int H, int W, float target, float coef, float gcoef, float* loss_acc,
+                                float* score_acc, float score_coef, dasr_tensor grad) {
     __shared__ float red[4];
     const long long total = (long long)N * H * W;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -265,9 +269,18 @@ __global__ void bce_logits_kernel(dasr_tensor x, int N, int C, int H, int W, flo
         for (int j = 0; j < 16; ++j) g[j] = 0.f;
         for (int c = 0; c < C; ++c) {
             const float v = xp[c];
-            l += fmaxf(v, 0.f) - v * target + log1pf(expf(-fabsf(v)));
             sc += v;
-            g[c] = gcoef * (1.f / (1.f + expf(-v)) - target);
+            if (MODE == 0) {
+                l += fmaxf(v, 0.f) - v * target + log1pf(expf(-fabsf(v)));
+                g[c] = gcoef * (1.f / (1.f + expf(-v)) - target);
+            } else if (MODE == 1) {
+                l += (v - target) * (v - target);
+                g[c] = gcoef * 2.f * (v - target);
+            } else {
+                const float sgn = target > 0.5f ? -1.f : 1.f;
+                l += sgn * v;
+                g[c] = gcoef * sgn;
+            }
         }
         if (grad.p) {
             float* gp = (float*)grad.p + (size_t)n * grad.n_stride + (size_t)p * 16;
@@ -849,13 +862,23 @@ extern "C" int dasr_bnorm_running(const float* stats, int32_t g, int32_t C, int3
     return (int)hipGetLastError();
 }
 
+extern "C" int dasr_gan_loss(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, int32_t gan_type, float target, float coef, float gcoef,
+                             float* loss_acc, float* score_acc, float score_coef, dasr_tensor grad, void* stream) {
+    const long long total = (long long)N * H * W;
+    if (total <= 0 || C > 16 || gan_type < 0 || gan_type > 2) return DASR_EINVAL;
+    const dim3 g(nblk(total)), b(256);
+    if (gan_type == 0)
+        DASR_LAUNCH(gan_loss_kernel<0>, g, b, 0, as_stream(stream), x, N, C, H, W, target, coef, gcoef, loss_acc, score_acc, score_coef, grad);
+    else if (gan_type == 1)
+        DASR_LAUNCH(gan_loss_kernel<1>, g, b, 0, as_stream(stream), x, N, C, H, W, target, coef, gcoef, loss_acc, score_acc, score_coef, grad);
+    else
+        DASR_LAUNCH(gan_loss_kernel<2>, g, b, 0, as_stream(stream), x, N, C, H, W, target, coef, gcoef, loss_acc, score_acc, score_coef, grad);
+    return (int)hipGetLastError();
+}
+
 extern "C" int dasr_bce_logits(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, float target, float coef, float gcoef,
                                float* loss_acc, float* score_acc, float score_coef, dasr_tensor grad, void* stream) {
-    const long long total = (long long)N * H * W;
-    if (total <= 0 || C > 16) return DASR_EINVAL;
-    DASR_LAUNCH(bce_logits_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, target, coef, gcoef, loss_acc,
-                       score_acc, score_coef, grad);
-    return (int)hipGetLastError();
+    return dasr_gan_loss(x, N, C, H, W, 0, target, coef, gcoef, loss_acc, score_acc, score_coef, grad, stream);
 }
 
 extern "C" int dasr_ragan(dasr_tensor a, dasr_tensor b, int32_t N, int32_t H, int32_t W, int32_t stage, int32_t n_glob, float ta, float tb, float coef,

@@ -655,7 +655,7 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream0) {
             case DASR_OP_INORM_FWD: rc = dasr_inorm_lrelu_fwd(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.f[1], o.t[1], (float*)o.p[0], stream); break;
             case DASR_OP_INORM_BWD: rc = dasr_inorm_lrelu_bwd(o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], (const float*)o.p[0], o.t[2], stream); break;
             case DASR_OP_BCE:
-                rc = dasr_bce_logits(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.f[1], o.f[2], (float*)o.p[0], (float*)o.p[1], o.f[3], o.t[1], stream);
+                rc = dasr_gan_loss(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.f[0], o.f[1], o.f[2], (float*)o.p[0], (float*)o.p[1], o.f[3], o.t[1], stream);
                 break;
             case DASR_OP_DWT_FWD: rc = dasr_dwt_fwd(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[1], o.t[2], stream); break;
             case DASR_OP_DWT_BWD: rc = dasr_dwt_bwd(o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[2], o.i[5], stream); break;

@@ -74,8 +74,12 @@ class DASR_Model(BaseModel):
         self.multiweights = opt['multiweights']
         if opt['adaptive_weights']:
             raise NotImplementedError('adaptive_weights (DASR_Adaptive_Model) is outside the hot path')
-        if t['gan_type'] != 'vanilla':
+        gan_modes = {'vanilla': 0, 'lsgan': 1, 'wgan-gp': 2}   # GANLoss (loss.py:8-27); the reference never applies its gradient penalty
+        if str(t['gan_type']).lower() not in gan_modes:
             raise NotImplementedError('GAN type [{:s}] is not found'.format(str(t['gan_type'])))
+        self.gan_mode = gan_modes[str(t['gan_type']).lower()]
+        if self.gan_mode != 0 and t['ragan']:
+            raise NotImplementedError('ragan with gan_type [{:s}]: the relativistic kernel implements the vanilla (BCE) form only'.format(str(t['gan_type'])))
         self.ragan = bool(t['ragan'])   # relativistic average GAN: per-pixel batch means of the logits (all-reduced across data-parallel ranks)
         self.l_gan_H_target_w = t['gan_H_target'] or 0
         self.l_gan_H_source_w = (t['gan_H_source'] or 0) if self.is_train else 0
@@ -464,7 +468,7 @@ class _StepPlan:
             cnt = float(n * 1 * lg.H * lg.W)
             if not m.ragan:
                 o = add(fwd, _op(_lib.OP_BCE))
-                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = lg.view(), n, 1, lg.H, lg.W
+                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = lg.view(), n, 1, lg.H, lg.W, m.gan_mode
                 o.f[0], o.f[1], o.f[2], o.p[0], o.p[1], o.f[3], o.t[1] = 1.0, 1.0 / cnt, float(m.l_gan_H_target_w) / cnt, acc + 4 * A_GAN, None, 0.0, d.g_logits.view()
         if ds is not None:   # l_g_gan_source_Hf = w_src * BCE(D_s(fake_s), 1): value logged WITH the weight (DASR_model.py:258,316)
             fwd.extend(ds.fwd)
@@ -472,7 +476,7 @@ class _StepPlan:
             cnt = float(n * 1 * lg.H * lg.W)
             if not m.ragan:
                 o = add(fwd, _op(_lib.OP_BCE))
-                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = lg.view(), n, 1, lg.H, lg.W
+                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = lg.view(), n, 1, lg.H, lg.W, m.gan_mode
                 o.f[0], o.f[1], o.f[2], o.p[0], o.p[1], o.f[3], o.t[1] = 1.0, float(m.l_gan_H_source_w) / cnt, float(m.l_gan_H_source_w) / cnt, \
                     acc + 4 * A_GAN_SRC, None, 0.0, ds.g_logits.view()
         # relativistic average form (`ragan`, DASR_model.py:240-244,252-256): three stages per loss, the per-pixel batch sums are all-reduced between
@@ -546,7 +550,7 @@ class _StepPlan:
             cnt = float(n * lg.H * lg.W)
             for n0, target, a_loss, a_score in (() if m.ragan else ((n, 1.0, A_DREAL, A_SREAL), (0, 0.0, A_DFAKE, A_SFAKE))):
                 o = add(dstep, _op(_lib.OP_BCE))
-                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = _nview(lg, n0), n, 1, lg.H, lg.W
+                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = _nview(lg, n0), n, 1, lg.H, lg.W, m.gan_mode
                 o.f[0], o.f[1], o.f[2] = target, 0.5 / cnt, 0.5 / cnt
                 o.p[0], o.p[1], o.f[3], o.t[1] = acc + 4 * a_loss, acc + 4 * a_score, 1.0 / cnt, _nview(d.g_logits, n0)
             dstep.extend(d.bwd_full)
@@ -558,7 +562,7 @@ class _StepPlan:
             cnt = float(n * lg.H * lg.W)
             for n0, target, a_loss, a_score in (() if m.ragan else ((n, 1.0, A_DREAL_SRC, A_SREAL_SRC), (0, 0.0, A_DFAKE_SRC, A_SFAKE_SRC))):
                 o = add(sstep, _op(_lib.OP_BCE))
-                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3] = _nview(lg, n0), n, 1, lg.H, lg.W
+                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = _nview(lg, n0), n, 1, lg.H, lg.W, m.gan_mode
                 o.f[0], o.f[1], o.f[2] = target, 0.5 / cnt, 0.5 / cnt
                 o.p[0], o.p[1], o.f[3], o.t[1] = acc + 4 * a_loss, acc + 4 * a_score, 1.0 / cnt, _nview(self.ds.g_logits, n0)
             sstep.extend(self.ds.bwd_full)

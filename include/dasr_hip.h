@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DASR_ABI_VERSION 7
+#define DASR_ABI_VERSION 8
 #define DASR_EINVAL (-22)
 
 typedef struct {
@@ -225,6 +225,11 @@ int dasr_bnorm_running(const float* stats, int32_t g, int32_t C, int32_t count, 
  * score_acc += score_coef*sum(x) (the disc_Score log), grad = gcoef*(sigmoid(x)-target) */
 int dasr_bce_logits(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, float target, float coef, float gcoef,
                     float* loss_acc, float* score_acc, float score_coef, dasr_tensor grad, void* stream);
+/* GANLoss(gan_type) (loss.py:8-40; DASR_model.py:35): gan_type 0 'vanilla' (= dasr_bce_logits), 1 'lsgan' (MSELoss: (x-target)^2, grad
+ * gcoef*2(x-target)), 2 'wgan-gp' (-x when target is the real label (> 0.5), +x otherwise; the reference builds but never applies its
+ * gradient penalty, DASR_model.py:114-118).  Accumulators and grad as in dasr_bce_logits. */
+int dasr_gan_loss(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, int32_t gan_type, float target, float coef, float gcoef,
+                  float* loss_acc, float* score_acc, float score_coef, dasr_tensor grad, void* stream);
 /* relativistic average GAN loss (`ragan: true`, DASR_model.py:240-244,273-275): a, b = logit maps [N][1][H][W] of the two halves,
  *   L = coef * sum_{n,p} [ bce(a - mean_n(b), ta) + bce(b - mean_n(a), tb) ],  means per pixel over the GLOBAL batch (n_glob >= N samples).
  * Three stages so that data-parallel ranks can all-reduce (SUM) the two tiny per-pixel buffers in between (2*H*W floats each):

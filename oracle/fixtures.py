@@ -32,6 +32,9 @@ CASES = OrderedDict([
     # source-domain discriminator = Discriminator_VGG_128 (which_model_pairD 'discriminator_vgg_128', architecture.py:442-495): BatchNorm in training
     # mode, two Linear layers; needs 128 x 128 inputs: gaussian frequency split at HR = 4 x 32
     ('dasr_srcVGG128_gau5_nf32_nb1_n3_32', dict(kind='dasr', nf=32, nb=1, n=3, lr=32, fs='gau', d_in_nc=3, gan_src=0.02, pairD='discriminator_vgg_128')),
+    # gan_type 'lsgan' / 'wgan-gp' (GANLoss, loss.py:8-40) on both discriminators
+    ('dasr_lsgan_wavelet_nf32_nb1_n2_32', dict(kind='dasr', nf=32, nb=1, n=2, lr=32, fs='wavelet', d_in_nc=9, gan_src=0.02, gan_type='lsgan')),
+    ('dasr_wgan_gau9_nf32_nb1_n2_32', dict(kind='dasr', nf=32, nb=1, n=2, lr=32, fs='gau', d_in_nc=3, gan_src=0.02, gan_type='wgan-gp')),
 ])
 
 
@@ -75,7 +78,7 @@ def make_opt(case):
                             'act_type': 'leakyrelu', 'mode': 'CNA', 'nf': 64, 'in_nc': c['d_in_nc'], 'n_layers': 2}
         opt['train'].update({'lr_D': 1e-4, 'weight_decay_D': 0, 'beta1_D': 0.9, 'fs': c['fs'], 'fs_kernel_size': 9,
                              'norm': True, 'sup_LL': True, 'pixel_LL_weight': 1, 'feature_criterion': c.get('fea', 'l1'),
-                             'feature_weight': 1, 'gan_type': 'vanilla', 'ragan': bool(c.get('ragan', False)), 'gan_H_target': 0.01,
+                             'feature_weight': 1, 'gan_type': c.get('gan_type', 'vanilla'), 'ragan': bool(c.get('ragan', False)), 'gan_H_target': 0.01,
                              'gan_H_source': c.get('gan_src', 0), 'G_update_inter': 1, 'D_update_inter': 1})
     return opt
 

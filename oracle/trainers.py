@@ -57,6 +57,9 @@ class DASRTrainer:
         self.l_gan_w = t['gan_H_target']
         self.l_gan_src_w = _opt(t, 'gan_H_source', 0)
         self.ragan = bool(t.get('ragan'))
+        self.gan_type = str(t.get('gan_type') or 'vanilla').lower()
+        if self.gan_type not in ('vanilla', 'lsgan', 'wgan-gp'):
+            raise NotImplementedError('GAN type [{:s}] is not found'.format(self.gan_type))
         self.netG = netG if netG is not None else nets.RRDBNet(g['in_nc'], g['out_nc'], g['nf'], g['nb'], opt['scale'])
         if netG is None:
             nets.init_kaiming_(self.netG, 0.1)
@@ -139,8 +142,12 @@ class DASRTrainer:
         self.weights = F.interpolate(data['fake_w'], size=(hr.shape[2], hr.shape[3]), mode='bilinear', align_corners=False)
         self.n = self.var_L.shape[0] // 2
 
-    @staticmethod
-    def _bce(logits, target_val):
+    def _bce(self, logits, target_val):
+        """GANLoss(gan_type, 1.0, 0.0)(logits, target_is_real) (loss.py:8-40); the name is historical: 'vanilla' is BCEWithLogits"""
+        if self.gan_type == 'lsgan':
+            return F.mse_loss(logits, torch.full_like(logits, target_val))
+        if self.gan_type == 'wgan-gp':   # loss.py:21-23; the gradient penalty is built (DASR_model.py:114-118) but never applied
+            return -logits.mean() if target_val > 0.5 else logits.mean()
         return F.binary_cross_entropy_with_logits(logits, torch.full_like(logits, target_val))
 
     def optimize_parameters(self, step):

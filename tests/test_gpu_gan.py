@@ -73,6 +73,17 @@ def test_bce_dwt_lowpass_pool_misc():
     (0.01 * l).backward()
     assert abs(float(acc[0]) - float(l)) < 1e-5 and abs(float(acc[1]) - float(x.mean())) < 1e-5
     assert rel(gr.nchw(1).cpu(), xr.grad) < 1e-5
+    # GANLoss 'lsgan' (MSE) and 'wgan-gp' (-mean / +mean) against both labels (loss.py:8-40)
+    for mode, target, fn in ((1, 1.0, lambda v: F.mse_loss(v, torch.ones_like(v))), (1, 0.0, lambda v: F.mse_loss(v, torch.zeros_like(v))),
+                             (2, 1.0, lambda v: -v.mean()), (2, 0.0, lambda v: v.mean())):
+        acc.zero_()
+        _lib.check(L.dasr_gan_loss(xb.view(), 3, 1, 9, 11, mode, target, 1.0 / cnt, 0.01 / cnt, acc.data_ptr(), acc.data_ptr() + 4, 1.0 / cnt, gr.view(), _stream()))
+        xr = x.clone().requires_grad_(True)
+        l = fn(xr)
+        (0.01 * l).backward()
+        assert abs(float(acc[0]) - float(l)) < 1e-5 * max(1.0, abs(float(l))) and abs(float(acc[1]) - float(x.mean())) < 1e-5, (mode, target)
+        assert rel(gr.nchw(1).cpu(), xr.grad) < 1e-5, (mode, target)
+    assert L.dasr_gan_loss(xb.view(), 3, 1, 9, 11, 3, 1.0, 1.0, 1.0, acc.data_ptr(), None, 0.0, gr.view(), _stream()) != 0   # unknown gan_type
     # Haar DWT forward / adjoint
     img = torch.rand(2, 3, 16, 24, generator=g)
     ib = to_blocked(img, dev)
@@ -207,7 +218,8 @@ def test_vgg_forward_and_input_gradient(prec, act_tol, grad_tol, margins):
 
 
 @pytest.mark.parametrize('case', ['dasr_wavelet_nf32_nb2_n2_32', 'dasr_gau9_nf64_nb1_n1_32', 'dasr_lpips_wavelet_nf32_nb2_n2_32',
-                                  'dasr_srcD_wavelet_nf32_nb2_n2_32', 'dasr_ragan_wavelet_nf32_nb1_n3_32', 'dasr_srcVGG128_gau5_nf32_nb1_n3_32'])
+                                  'dasr_srcD_wavelet_nf32_nb2_n2_32', 'dasr_ragan_wavelet_nf32_nb1_n3_32', 'dasr_srcVGG128_gau5_nf32_nb1_n3_32',
+                                  'dasr_lsgan_wavelet_nf32_nb1_n2_32', 'dasr_wgan_gau9_nf32_nb1_n2_32'])
 def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir, margins):
     dev = _gpu()
     GRAD_TOL = VGG128_STEP_TOL if 'VGG128' in case else globals()['GRAD_TOL']   # see the note at VGG128_GRAD_TOL
@@ -216,6 +228,9 @@ def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir, margin
     from dasr_amd import options
     from dasr_amd.models import create_model
     c = fixtures.CASES[case]
+    # relativistic loss / Wasserstein loss: shifting every logit by a constant changes nothing (wgan: -mean(real) + mean(fake)), so the TRUE
+    # gradient of the discriminators' last bias is 0 (rounding noise on both sides)
+    zero_last_bias = bool(c.get('ragan')) or c.get('gan_type') == 'wgan-gp'
     opt = fixtures.make_opt(case)
     netG = nets.RRDBNet(3, 3, c['nf'], c['nb'], 4)
     sdG = fixtures.seeded_state_dict(netG.state_dict(), 1, 0.1)
@@ -254,7 +269,9 @@ def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir, margin
             ref_v, gold_v = t.log[k], float(gold['logs'][step - 1][keys.index(k)])
             tol = 2e-3 if step == 1 else 2e-2  # step 2 sees weights moved by a sign-normalised Adam update
             # disc_Score = mean of logits of magnitude ~0.1-1 that nearly cancels: absolute tolerance on that scale
-            atol = (2e-4 if step == 1 else 2e-3) if k.startswith('disc_Score') else 1e-5
+            # (the 'wgan-gp' losses ARE such means: -mean(real) + mean(fake))
+            scorelike = k.startswith('disc_Score') or (c.get('gan_type') == 'wgan-gp' and ('l_d_' in k or '_gan_' in k))
+            atol = (2e-4 if step == 1 else 2e-3) if scorelike else 1e-5
             assert abs(log[k] - ref_v) <= tol * max(1e-3, abs(ref_v)) + atol, (step, k, log[k], ref_v)
             assert abs(log[k] - gold_v) <= tol * max(1e-3, abs(gold_v)) + atol, (step, k, log[k], gold_v)
         if step == 1:
@@ -267,22 +284,22 @@ def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir, margin
                 assert r < GRAD_TOL, ('G', k, r)
             dd = m.netD_target.params.grad_dict()
             for (k, gv), pr in zip(dd.items(), netD.parameters()):
-                if c.get('ragan') and k.endswith('model.8.bias'):   # relativistic loss: shifting every logit by a constant changes nothing: the
-                    assert float(gv.abs().max()) < 1e-6 and float(pr.grad.abs().max()) < 1e-6   # true gradient of the last bias is 0 (rounding noise both sides)
+                if zero_last_bias and k.endswith('model.8.bias'):
+                    assert float(gv.abs().max()) < 1e-6 and float(pr.grad.abs().max()) < 1e-6
                     continue
                 r = rel(gv, pr.grad)
                 assert r < GRAD_TOL, ('D', k, r)
             if netD2 is not None:
                 d2 = m.netD_source.params.grad_dict()
                 for (k, gv), pr in zip(d2.items(), netD2.parameters()):
-                    if c.get('ragan') and k.endswith('model.8.bias'):
+                    if zero_last_bias and k.endswith('model.8.bias'):
                         continue
                     assert rel(gv.reshape(pr.grad.shape), pr.grad) < GRAD_TOL, ('D_source', k, rel(gv.reshape(pr.grad.shape), pr.grad))
                 np.testing.assert_allclose(np.array([float(v.double().norm()) for v in d2.values()]), gold['gradD2_norm'], rtol=GRAD_TOL, atol=1e-6)
             np.testing.assert_allclose(np.array([float(v.double().norm()) for v in gd.values()]), gold['gradG_norm'], rtol=GRAD_TOL)
             np.testing.assert_allclose(np.array([float(v.double().norm()) for v in dd.values()]), gold['gradD_norm'], rtol=GRAD_TOL, atol=1e-6)
             w2 = max([rel(gv.reshape(pr.grad.shape), pr.grad) for (k, gv), pr in zip(m.netD_source.params.grad_dict().items(), netD2.parameters())
-                      if not (c.get('ragan') and k.endswith('model.8.bias'))]) if netD2 is not None else 0.0
+                      if not (zero_last_bias and k.endswith('model.8.bias'))]) if netD2 is not None else 0.0
             margins('%s: worst gradient rel err G %.2e, D_source %.2e (bound %.0e)' % (case, worst, w2, GRAD_TOL))
 
 
