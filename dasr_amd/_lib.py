@@ -121,7 +121,7 @@ _SIGS = {
     'dasr_bnorm_lrelu_fwd': [Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, Tensor, c_vp, c_vp],
     'dasr_bnorm_lrelu_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, Tensor, c_vp, c_vp, c_f32, c_vp],
     'dasr_bnorm_running': [c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp],
-    'dasr_ragan': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, Tensor, Tensor, c_vp],
+    'dasr_ragan': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, Tensor, Tensor, c_vp],
     'dasr_lpips_s2d': [Tensor, c_i32, c_i32, c_i32, c_vp, c_vp, Tensor, c_i32, c_vp],
     'dasr_maxpool3s2': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_vp],
     'dasr_maxpool3s2_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_i32, c_vp],

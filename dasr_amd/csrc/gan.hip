@@ -305,9 +305,31 @@ __global__ void gan_loss_kernel(dasr_tensor x, int N, int C, int H, int W, float
 //            part[0:HW] = sum_n (sigmoid(za) - ta), part[HW:2HW] = sum_n (sigmoid(zb) - tb)    (-> all-reduce SUM)
 //   stage 2: ga = gcoef * ((sigmoid(za) - ta) - part_b / n_glob), gb = gcoef * ((sigmoid(zb) - tb) - part_a / n_glob)   (either may be null)
 // ---------------------------------------------------------------------------------------------------
+// FORM 0 (SRN, above): term(z, t) = BCE-with-logits, score = the raw logit.  FORM 1 (DSN `--ragan`, codes/DSN/train.py:221-223 + loss.py:11-41 on
+// model.py:98-106's sigmoid(x - mean_n(y))): term(z, t) = -log(sigmoid(z) + eps) for t > 0.5, -log(1 - sigmoid(z) + eps) for 0 <= t <= 0.5,
+// absent (0) for t < 0; score = sigmoid(z).
+template <int FORM>
+__device__ __forceinline__ void rel_term(float z, float t, float eps, float& l, float& q, float& s) {
+    s = 1.f / (1.f + expf(-z));
+    if (FORM == 0) {
+        l = fmaxf(z, 0.f) - z * t + log1pf(expf(-fabsf(z)));
+        q = s - t;
+    } else if (t < 0.f) {
+        l = 0.f;
+        q = 0.f;
+    } else if (t > 0.5f) {
+        l = -logf(s + eps);
+        q = -s * (1.f - s) / (s + eps);
+    } else {
+        l = -logf(1.f - s + eps);
+        q = s * (1.f - s) / (1.f - s + eps);
+    }
+}
+
+template <int FORM>
 __global__ void ragan_kernel(dasr_tensor a, dasr_tensor b, int N, int H, int W, int stage, float inv_nglob, float ta, float tb, float coef, float gcoef,
-                             float* __restrict__ sums, float* __restrict__ part, float* loss_acc, float* score_a, float* score_b, float score_coef,
-                             dasr_tensor ga, dasr_tensor gb) {
+                             float eps, float* __restrict__ sums, float* __restrict__ part, float* loss_acc, float* score_a, float* score_b,
+                             float score_coef, dasr_tensor ga, dasr_tensor gb) {
     __shared__ float red[4];
     const int HW = H * W;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -326,27 +348,31 @@ __global__ void ragan_kernel(dasr_tensor a, dasr_tensor b, int N, int H, int W, 
                 float qa = 0.f, qb = 0.f;
                 for (int n = 0; n < N; ++n) {
                     const float av = ap[(size_t)n * a.n_stride], bv = bp[(size_t)n * b.n_stride];
-                    const float za = av - mb, zb = bv - ma;
-                    l += fmaxf(za, 0.f) - za * ta + log1pf(expf(-fabsf(za))) + fmaxf(zb, 0.f) - zb * tb + log1pf(expf(-fabsf(zb)));
-                    qa += 1.f / (1.f + expf(-za)) - ta;
-                    qb += 1.f / (1.f + expf(-zb)) - tb;
-                    sca += av;
-                    scb += bv;
+                    float la, lb, da, db, sa, sb;
+                    rel_term<FORM>(av - mb, ta, eps, la, da, sa);
+                    rel_term<FORM>(bv - ma, tb, eps, lb, db, sb);
+                    l += la + lb;
+                    qa += da;
+                    qb += db;
+                    sca += FORM == 0 ? av : sa;
+                    scb += FORM == 0 ? bv : sb;
                 }
                 part[p] = qa;
                 part[HW + p] = qb;
             } else {
                 const float ca = part[p] * inv_nglob, cb = part[HW + p] * inv_nglob;
                 for (int n = 0; n < N; ++n) {
-                    const float za = ap[(size_t)n * a.n_stride] - mb, zb = bp[(size_t)n * b.n_stride] - ma;
+                    float la, lb, da, db, sa, sb;
+                    rel_term<FORM>(ap[(size_t)n * a.n_stride] - mb, ta, eps, la, da, sa);
+                    rel_term<FORM>(bp[(size_t)n * b.n_stride] - ma, tb, eps, lb, db, sb);
                     if (ga.p) {
                         f32x4* g = (f32x4*)((float*)ga.p + (size_t)n * ga.n_stride + (size_t)p * 16);
-                        g[0] = f32x4{gcoef * ((1.f / (1.f + expf(-za)) - ta) - cb), 0.f, 0.f, 0.f};
+                        g[0] = f32x4{gcoef * (da - cb), 0.f, 0.f, 0.f};
                         g[1] = g[2] = g[3] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                     if (gb.p) {
                         f32x4* g = (f32x4*)((float*)gb.p + (size_t)n * gb.n_stride + (size_t)p * 16);
-                        g[0] = f32x4{gcoef * ((1.f / (1.f + expf(-zb)) - tb) - ca), 0.f, 0.f, 0.f};
+                        g[0] = f32x4{gcoef * (db - ca), 0.f, 0.f, 0.f};
                         g[1] = g[2] = g[3] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
@@ -881,12 +907,18 @@ extern "C" int dasr_bce_logits(dasr_tensor x, int32_t N, int32_t C, int32_t H, i
     return dasr_gan_loss(x, N, C, H, W, 0, target, coef, gcoef, loss_acc, score_acc, score_coef, grad, stream);
 }
 
-extern "C" int dasr_ragan(dasr_tensor a, dasr_tensor b, int32_t N, int32_t H, int32_t W, int32_t stage, int32_t n_glob, float ta, float tb, float coef,
-                          float gcoef, float* sums, float* part, float* loss_acc, float* score_a, float* score_b, float score_coef, dasr_tensor ga,
-                          dasr_tensor gb, void* stream) {
-    if (N <= 0 || H <= 0 || W <= 0 || n_glob < N || stage < 0 || stage > 2 || !a.p || !b.p || !sums || (stage > 0 && !part)) return DASR_EINVAL;
-    DASR_LAUNCH(ragan_kernel, dim3(nblk((long long)H * W)), dim3(256), 0, as_stream(stream), a, b, N, H, W, stage, 1.f / (float)n_glob, ta, tb, coef, gcoef,
-                sums, part, loss_acc, score_a, score_b, score_coef, ga, gb);
+extern "C" int dasr_ragan(dasr_tensor a, dasr_tensor b, int32_t N, int32_t H, int32_t W, int32_t stage, int32_t n_glob, int32_t form, float ta, float tb,
+                          float coef, float gcoef, float eps, float* sums, float* part, float* loss_acc, float* score_a, float* score_b,
+                          float score_coef, dasr_tensor ga, dasr_tensor gb, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0 || n_glob < N || stage < 0 || stage > 2 || form < 0 || form > 1 || !a.p || !b.p || !sums || (stage > 0 && !part))
+        return DASR_EINVAL;
+    const dim3 g(nblk((long long)H * W)), blk(256);
+    if (form == 0)
+        DASR_LAUNCH(ragan_kernel<0>, g, blk, 0, as_stream(stream), a, b, N, H, W, stage, 1.f / (float)n_glob, ta, tb, coef, gcoef, eps, sums, part,
+                    loss_acc, score_a, score_b, score_coef, ga, gb);
+    else
+        DASR_LAUNCH(ragan_kernel<1>, g, blk, 0, as_stream(stream), a, b, N, H, W, stage, 1.f / (float)n_glob, ta, tb, coef, gcoef, eps, sums, part,
+                    loss_acc, score_a, score_b, score_coef, ga, gb);
     return (int)hipGetLastError();
 }
 

@@ -322,12 +322,13 @@ class DASR_Model(BaseModel):
             self.save_network(self.netD_source, 'D_source', iter_step)
 
 
-def _ragan_ops(lists, a, b, n, H, W, n_glob, ta, tb, coef, gcoef, sums, part, p_loss, p_sa, p_sb, score_coef, ga, gb):
-    """the three dasr_ragan stages of one relativistic loss, appended to lists[0..2] (include/dasr_hip.h)"""
+def _ragan_ops(lists, a, b, n, H, W, n_glob, ta, tb, coef, gcoef, sums, part, p_loss, p_sa, p_sb, score_coef, ga, gb, form=0, eps=0.0, stages=(0, 1, 2)):
+    """the three dasr_ragan stages of one relativistic loss, appended to lists[0..2] (include/dasr_hip.h); form 1 / eps: the DSN's form"""
     import struct
-    for stage in range(3):
+    for stage in stages:
         o = _op(_lib.OP_RAGAN)
-        o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = a, b, n, H, W, stage, n_glob
+        o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5] = a, b, n, H, W, stage, n_glob, form
+        o.l[2] = struct.unpack('<I', struct.pack('<f', eps))[0]
         o.f[0], o.f[1], o.f[2], o.f[3] = ta, tb, coef, gcoef
         o.p[0], o.p[1], o.p[2], o.p[3] = sums.data_ptr(), part.data_ptr(), p_loss, p_sa
         o.l[0] = p_sb or 0

@@ -26,7 +26,7 @@ from .engine import (BTensor, ParamStore, PackRegistry, OpList, WgradGroup, Work
                      ensure_runtime_ready, _stream)
 from .gan_nets import NLayerDiscriminatorHIP, VGGFeatureHIP, VGG16_CFG, fsd_spec, dsn_nld_spec
 from .models import AdamHIP
-from .dasr_model import gaussian_kernel2d, vgg_random_state_dict, _nview
+from .dasr_model import gaussian_kernel2d, vgg_random_state_dict, _nview, _ragan_ops
 
 logger = logging.getLogger('base')
 EPS = 1e-8
@@ -265,7 +265,7 @@ class DSNModel:
     def __init__(self, opt=None, device=None, **kw):
         o = dict(n_res_blocks=8, kernel_size=5, filter='gau', norm_layer='Instance', discriminator='FSD', generator='DeResnet', learning_rate=1e-4,
                  adam_beta_1=0.5, w_col=1.0, w_tex=0.005, w_per=0.01, per_type='VGG', vgg_path=None, vgg_seed=78, num_epochs=400,
-                 num_decay_epochs=150, upscale_factor=4)
+                 num_decay_epochs=150, upscale_factor=4, ragan=False)
         o.update(opt or {})
         o.update(kw)
         self.opt = o
@@ -293,6 +293,7 @@ class DSNModel:
                     self.netF.load_state_dict(vgg_random_state_dict(self.netF.spec, int(o['vgg_seed'])))
             else:
                 raise NotImplementedError('{} is not recognized'.format(o['per_type']))
+        self.ragan = bool(o['ragan'])   # --ragan (train.py:221-223): D(x, y) = sigmoid(D(x) - mean_n D(y)) (model.py:98-106)
         self.filter = o['filter'].lower()
         if self.filter not in ('gau', 'avg_pool', 'wavelet'):
             raise NotImplementedError('Frequency Separation type [{:s}] not recognized'.format(o['filter']))
@@ -357,6 +358,9 @@ class DSNModel:
         P.g.x_nchw.copy_(hr if self.netG.scale == 4 else bicubic_lr)
         P.bic_nchw.copy_(bicubic_lr)
         P.real_nchw.copy_(real_lr)
+        if self.ragan and self.dp is not None and self.dp.active:
+            raise NotImplementedError('--ragan under data parallelism: the batch means would have to be all-reduced between the loss stages (as the SRN '
+                                      'trainer does); the DSN iteration records them in one list')
         scale = self.dp.grad_scale if (self.dp is not None and self.dp.active) else 1.0
         if scale != P.scale:
             P.set_grad_scale(scale)
@@ -482,8 +486,19 @@ class _DSNPlan:
         f.extend(d.fwd)
         lg = d.logits
         cnt = float(N * lg.H * lg.W)
+        # --ragan: the same two terms on relativistic logits real - mean_n(fake), fake - mean_n(real): the three dasr_ragan stages back to back
+        # (whole loss -> acc[0]; scores = mean sigmoid of the relativistic logits); gradients of both halves incl. the mean terms
+        self.r_sums = self.r_part = None
+        if m.ragan:
+            hw = lg.H * lg.W
+            self.r_sums, self.r_part = (torch.zeros(2 * hw, dtype=torch.float32, device=dev) for _ in range(2))
+            rl = [OpList(), OpList(), OpList()]
+            _ragan_ops(rl, _nview(lg, N), lg.view(), N, lg.H, lg.W, N, 1.0, 0.0, 1.0 / cnt, 1.0 / cnt, self.r_sums, self.r_part, acc, acc + 4 * 4,
+                       acc + 4 * 5, 1.0 / cnt, _nview(d.g_logits, N), d.g_logits.view(), form=1, eps=EPS)
+            for l_ in rl:
+                f.extend(l_)
         # discriminator loss: -log(real) - log(1 - fake)   (acc[0], acc[1]); scores acc[4] (real), acc[5] (fake)
-        for n0, mode, a_loss, a_score in ((N, 0, 0, 4), (0, 1, 1, 5)):
+        for n0, mode, a_loss, a_score in (() if m.ragan else ((N, 0, 0, 4), (0, 1, 1, 5))):
             o = _op(_lib.OP_LOGLOSS)
             o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = _nview(lg, n0), N, lg.H, lg.W, mode, 0
             o.f[0], o.f[1], o.f[2], o.f[3] = EPS, 1.0 / cnt, 1.0 / cnt, 1.0 / cnt
@@ -529,11 +544,18 @@ class _DSNPlan:
         self.d_bwd = d.bwd_full
         # generator: texture loss gradient through D's data path (+ colour adjoint) -> g_fake -> G backward
         gb = OpList()
-        o = _op(_lib.OP_LOGLOSS)   # -log(fake_tex) on the fake half: value -> acc[2], gradient -> g_logits[:N]
-        o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = lg.view(), N, lg.H, lg.W, 0, 0
-        o.f[0], o.f[1], o.f[2], o.f[3] = EPS, 1.0 / cnt, float(o_['w_tex']) / cnt, 0.0
-        o.p[0], o.p[1], o.t[1] = acc + 4 * 2, None, d.g_logits.view()
-        gb.add(o)
+        if m.ragan:   # -log(sigmoid(fake - mean_n(real)) + eps): stage 0's sums are still valid, the real term is absent (t < 0), real carries no gradient
+            rl = [OpList(), OpList(), OpList()]
+            _ragan_ops(rl, _nview(lg, N), lg.view(), N, lg.H, lg.W, N, -1.0, 1.0, 1.0 / cnt, float(o_['w_tex']) / cnt, self.r_sums, self.r_part,
+                       acc + 4 * 2, None, None, 0.0, NULL_T, d.g_logits.view(), form=1, eps=EPS, stages=(1, 2))
+            gb.extend(rl[1])
+            gb.extend(rl[2])
+        else:
+            o = _op(_lib.OP_LOGLOSS)   # -log(fake_tex) on the fake half: value -> acc[2], gradient -> g_logits[:N]
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = lg.view(), N, lg.H, lg.W, 0, 0
+            o.f[0], o.f[1], o.f[2], o.f[3] = EPS, 1.0 / cnt, float(o_['w_tex']) / cnt, 0.0
+            o.p[0], o.p[1], o.t[1] = acc + 4 * 2, None, d.g_logits.view()
+            gb.add(o)
         gb.extend(d.bwd_data_ops(N))
         o = _op(_lib.OP_FILL)
         o.p[0], o.l[0], o.f[0] = g.g_fake.t.data_ptr(), g.g_fake.t.numel(), 0.0

@@ -4,8 +4,7 @@ Same flags and defaults as the reference's argparse block (train.py:24-72) and t
 DSNModel.iteration(hr, bicubic_lr, real_lr); schedulers step once per epoch (train.py:287-288); every
 `save_model_interval` epochs the `.tar` checkpoint dict of train.py:357-376 is written to
 <save_path>/checkpoints/iteration_<n>.tar and last_iteration.tar.  Accepted-but-unsupported choices fail the way the
-reference does for unknown strings (NotImplementedError): --ragan,
---wgan, --norm_layer Batch, --lpips_rot_flip.  --per_type LPIPS (the reference default) runs LPIPS(alex) with weights from --lpips_alexnet /
+reference does for unknown strings (NotImplementedError): --wgan, --norm_layer Batch, --lpips_rot_flip.  --ragan is supported (single rank).  --per_type LPIPS (the reference default) runs LPIPS(alex) with weights from --lpips_alexnet /
 --lpips_lin (seeded and logged when absent: they cannot be downloaded offline).  Data: the PIL/torchvision loaders
 (data_loader.py) stay on the reference's side of the boundary; any iterable of (hr, bicubic_lr, real_lr) tuples works, and
 `--dataset synthetic` ships fixed-seed random crops for benchmarks and tests.
@@ -76,8 +75,10 @@ def check_supported(o):
         raise NotImplementedError('Discriminator architecture [{:s}] not recognized'.format(o.discriminator))
     if o.lpips_rot_flip:
         raise NotImplementedError('--lpips_rot_flip (random rotations / flips in front of LPIPS, loss.py:97-110) is not on the MI355X path')
-    if o.ragan or o.wgan or not o.highpass or o.cat_or_sum != 'cat' or o.norm_layer != 'Instance':
-        raise NotImplementedError('DSN on MI355X covers the default path: DCGAN loss, high-pass front end, wavelet bands cat, Instance norm')
+    if o.wgan:
+        raise NotImplementedError('--wgan needs a gradient penalty (train.py:231-236: a second-order pass through D); not on the MI355X path')
+    if not o.highpass or o.cat_or_sum != 'cat' or o.norm_layer != 'Instance':
+        raise NotImplementedError('DSN on MI355X covers the default path: high-pass front end, wavelet bands cat, Instance norm')
     if o.disc_freq != 1 or o.gen_freq != 1:
         raise NotImplementedError('disc_freq / gen_freq other than 1')
 
@@ -113,7 +114,7 @@ def main(argv=None, loader=None):
     opt = dict(n_res_blocks=o.num_res_blocks, kernel_size=o.kernel_size, filter=o.filter, norm_layer=o.norm_layer, discriminator=o.discriminator,
                learning_rate=o.learning_rate, adam_beta_1=o.adam_beta_1, w_col=o.w_col, w_tex=o.w_tex, w_per=o.w_per if o.use_per_loss else 0.0,
                per_type=o.per_type, generator=o.generator, vgg_path=o.vgg_path, lpips_alexnet=o.lpips_alexnet, lpips_lin=o.lpips_lin, num_epochs=o.num_epochs, num_decay_epochs=o.num_decay_epochs,
-               upscale_factor=o.upscale_factor)
+               upscale_factor=o.upscale_factor, ragan=o.ragan)
     model = DSNModel(opt)
     if dp:
         model.dp = dp

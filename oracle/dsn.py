@@ -157,8 +157,12 @@ class Discriminator(nn.Module):
             return self.dwt(x)[1] * 0.5 + 0.5   # cat(LH, HL, HH), normalised (model.py:108-118)
         return self.filter(x)
 
-    def forward(self, x):
-        return torch.sigmoid(self.net(self.front(x)))
+    def forward(self, x, y=None):
+        """y given (train.py --ragan, :221-223): relativistic -- the per-pixel batch mean of D(y)'s logits is subtracted (model.py:98-106)"""
+        z = self.net(self.front(x))
+        if y is not None:
+            z = z - self.net(self.front(y)).mean(0, keepdim=True)
+        return torch.sigmoid(z)
 
 
 def vgg16_features31(seed):
@@ -177,10 +181,11 @@ def vgg16_features31(seed):
 
 
 class DSNTrainer:
-    """one training iteration of codes/DSN/train.py:204-285 (non-ragan, non-wgan, DeResnet)"""
+    """one training iteration of codes/DSN/train.py:204-285 (non-wgan; `ragan`: the relativistic discriminator calls of :221-223)"""
 
     def __init__(self, netG=None, netD=None, lr=1e-4, beta1=0.5, w_col=1.0, w_tex=0.005, w_per=0.01, per_type='VGG',
-                 kernel_size=5, filter_type='gau', norm_layer='Instance', vgg_seed=78, num_epochs=400, num_decay_epochs=150, netF=None):
+                 kernel_size=5, filter_type='gau', norm_layer='Instance', vgg_seed=78, num_epochs=400, num_decay_epochs=150, netF=None, ragan=False):
+        self.ragan = ragan
         self.G = netG if netG is not None else DeResnet()
         self.D = netD if netD is not None else Discriminator(kernel_size, norm_layer, filter_type)
         self.w_col, self.w_tex, self.w_per = w_col, w_tex, w_per
@@ -208,7 +213,7 @@ class DSNTrainer:
 
     def iteration(self, hr, bicubic_lr, real_lr):
         fake = self.G(bicubic_lr if isinstance(self.G, GeneratorDSGAN) else hr)   # codes/DSN/train.py:213-217
-        real_tex, fake_tex = self.D(real_lr), self.D(fake)
+        real_tex, fake_tex = (self.D(real_lr, fake), self.D(fake, real_lr)) if self.ragan else (self.D(real_lr), self.D(fake))
         d_loss = -torch.log(real_tex + 1e-8).mean() - torch.log(1 - fake_tex + 1e-8).mean()
         tex = torch.mean(-torch.log(fake_tex + 1e-8))
         col = F.l1_loss(self.color_filter(fake), self.color_filter(bicubic_lr))

@@ -28,6 +28,8 @@ DSN_CASES = {
     'dsn_gau5_nld_s1_b1_128': dict(filter='gau', k=5, norm='Instance', n=1, crop=128, arch='nld_s1'),
     # --generator DSGAN (model.py:7-22, train.py:213-215): the generator runs on the bicubic LR image
     'dsn_dsgan_gau5_inst_b2_128': dict(filter='gau', k=5, norm='Instance', n=2, crop=128, gen='DSGAN'),
+    # --ragan (train.py:221-223, model.py:98-106): relativistic discriminator outputs, n = 3 so that the batch means matter
+    'dsn_gau5_inst_b3_128_ragan': dict(filter='gau', k=5, norm='Instance', n=3, crop=128, ragan=True),
 }
 
 
@@ -48,7 +50,7 @@ def dsn_batch(c, seed=4321):
 def collect(G, D, color_filter, per_net, c, w=(1.0, 0.005, 0.01)):
     hr, bic, real = dsn_batch(c)
     fake = G(bic if c.get('gen') == 'DSGAN' else hr)
-    rt, ft = D(real), D(fake)
+    rt, ft = (D(real, fake), D(fake, real)) if c.get('ragan') else (D(real), D(fake))
     d_loss = -torch.log(rt + 1e-8).mean() - torch.log(1 - ft + 1e-8).mean()
     tex = torch.mean(-torch.log(ft + 1e-8))
     col = torch.nn.functional.l1_loss(color_filter(fake), color_filter(bic))

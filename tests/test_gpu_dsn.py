@@ -209,7 +209,7 @@ def test_deresnet_forward_backward():
 
 
 @pytest.mark.parametrize('case', ['dsn_gau5_inst_b2_128', 'dsn_wavelet_inst_b2_128', 'dsn_avg5_inst_b1_160', 'dsn_gau5_inst_b1_256_lpips',
-                                  'dsn_wavelet_nld_s2_b2_128', 'dsn_gau5_nld_s1_b1_128', 'dsn_dsgan_gau5_inst_b2_128'])
+                                  'dsn_wavelet_nld_s2_b2_128', 'dsn_gau5_nld_s1_b1_128', 'dsn_dsgan_gau5_inst_b2_128', 'dsn_gau5_inst_b3_128_ragan'])
 def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir):
     dev = _gpu()
     torch.set_num_threads(8)
@@ -227,8 +227,8 @@ def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir):
     if c.get('per') == 'LPIPS':     # --per_type LPIPS (reference default): real linear heads + the fixture's stand-in AlexNet
         from oracle import lpips
         crit, sdF = lpips.golden_criterion(78, golden_dir)
-    t = dsn.DSNTrainer(G, D, kernel_size=c['k'], filter_type=c['filter'], norm_layer=c['norm'], vgg_seed=78, w_per=0.01, per_type=c.get('per', 'VGG'), netF=crit)
-    m = DSNModel(dict(filter=c['filter'], kernel_size=c['k'], norm_layer=c['norm'], w_per=0.01, vgg_seed=78, per_type=c.get('per', 'VGG'), discriminator=c.get('arch', 'FSD'), generator=c.get('gen', 'DeResnet')), device=dev)
+    t = dsn.DSNTrainer(G, D, kernel_size=c['k'], filter_type=c['filter'], norm_layer=c['norm'], vgg_seed=78, w_per=0.01, per_type=c.get('per', 'VGG'), netF=crit, ragan=bool(c.get('ragan')))
+    m = DSNModel(dict(ragan=bool(c.get('ragan')), filter=c['filter'], kernel_size=c['k'], norm_layer=c['norm'], w_per=0.01, vgg_seed=78, per_type=c.get('per', 'VGG'), discriminator=c.get('arch', 'FSD'), generator=c.get('gen', 'DeResnet')), device=dev)
     assert list(m.netG.params.spec) == list(gold['G_keys']) and list(m.netD.params.spec) == list(gold['D_keys'])
     m.netG.load_state_dict(sdG)
     m.netD.load_state_dict(sdD)
@@ -251,10 +251,16 @@ def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir):
             gd, dd = m.netG.params.grad_dict(), m.netD.params.grad_dict()
             _check_grads(gd, [p.grad for p in G.parameters()], 'G')
             dpar = dict((k, v) for k, v in dd.items() if 'gaussian_filter' not in k)
-            _check_grads(dpar, [p.grad for p in D.parameters() if p.requires_grad], 'D')
+            dwant = [p.grad for p in D.parameters() if p.requires_grad]
+            if c.get('ragan'):   # relativistic logits: a constant shift of every logit changes nothing -> the true gradient of the last bias is 0
+                k_last = list(dpar)[-1]
+                assert k_last.endswith('bias') and float(dpar[k_last].abs().max()) < 1e-5 and float(dwant[-1].abs().max()) < 1e-5   # rounding noise of sums of O(1) terms
+                _check_grads(dict(list(dpar.items())[:-1]), dwant[:-1], 'D')
+            else:
+                _check_grads(dpar, dwant, 'D')
             big = np.array([v.numel() > 1 for v in gd.values()])
             np.testing.assert_allclose(np.array([float(v.double().norm()) for v in gd.values()])[big], gold['gradG_norm'][big], rtol=GRAD_TOL)
-            np.testing.assert_allclose(np.array([float(v.double().norm()) for v in dpar.values()]), gold['gradD_norm'], rtol=GRAD_TOL, atol=1e-6)
+            np.testing.assert_allclose(np.array([float(v.double().norm()) for v in dpar.values()]), gold['gradD_norm'], rtol=GRAD_TOL, atol=1e-5 if c.get('ragan') else 1e-6)
 
 
 def test_dsn_checkpoint_roundtrip(tmp_path):

@@ -325,8 +325,8 @@ def test_ragan_three_stage_loss_and_gradients(n, n_glob, h, w):
     Lib = _lib.lib()
 
     def stage(k):
-        _lib.check(Lib.dasr_ragan(a.view(), b.view(), n, h, w, k, n_glob, 1.0, 0.0, 0.5 / cnt, 0.5 / cnt, sums.data_ptr(), part.data_ptr(), acc.data_ptr(),
-                                  acc.data_ptr() + 4, acc.data_ptr() + 8, 1.0 / float(n * hw), ga.view(), gb.view(), None))
+        _lib.check(Lib.dasr_ragan(a.view(), b.view(), n, h, w, k, n_glob, 0, 1.0, 0.0, 0.5 / cnt, 0.5 / cnt, 0.0, sums.data_ptr(), part.data_ptr(),
+                                  acc.data_ptr(), acc.data_ptr() + 4, acc.data_ptr() + 8, 1.0 / float(n * hw), ga.view(), gb.view(), None))
         torch.cuda.synchronize()
 
     def others(fn):   # what the other ranks' stage would contribute to the all-reduced buffer
@@ -347,6 +347,41 @@ def test_ragan_three_stage_loss_and_gradients(n, n_glob, h, w):
     assert abs(float(acc[0]) - float(la)) < 1e-5 * abs(float(la))
     assert abs(float(acc[1]) - float(A.detach()[:n].mean())) < 1e-5 and abs(float(acc[2]) - float(B.detach()[:n].mean())) < 1e-5
     assert rel(ga.nchw(1).cpu(), A.grad[:n]) < 1e-5 and rel(gb.nchw(1).cpu(), B.grad[:n]) < 1e-5
+
+
+def test_ragan_dsn_form_loss_and_gradients():
+    """dasr_ragan form 1 (the DSN's --ragan: -log(sigmoid(x - mean_n(y)) + eps) terms, codes/DSN/train.py:221-223, loss.py:11-41) against torch
+    autograd: the discriminator loss (both terms, both gradients) and the generator's texture loss (fake term only, target 'real')"""
+    dev = _gpu()
+    from dasr_amd import _lib
+    from dasr_amd.engine import BTensor, NULL_T
+    g = torch.Generator().manual_seed(12)
+    n, h, w, eps = 3, 10, 13, 1e-8
+    R = (torch.randn(n, 1, h, w, generator=g) * 2).requires_grad_(True)   # real logits
+    Fk = (torch.randn(n, 1, h, w, generator=g) * 2).requires_grad_(True)  # fake logits
+    rt, ft = torch.sigmoid(R - Fk.mean(0, keepdim=True)), torch.sigmoid(Fk - R.mean(0, keepdim=True))
+    d_loss = -torch.log(rt + eps).mean() - torch.log(1 - ft + eps).mean()
+    gR, gF = torch.autograd.grad(d_loss, [R, Fk], retain_graph=True)
+    tex = torch.mean(-torch.log(ft + eps))
+    gF_tex, = torch.autograd.grad(0.005 * tex, [Fk])
+    a, b = to_blocked(R.detach(), dev), to_blocked(Fk.detach(), dev)
+    ga, gb = BTensor(n, 16, h, w, True, dev), BTensor(n, 16, h, w, True, dev)
+    hw, cnt = h * w, float(n * h * w)
+    sums, part = torch.zeros(2 * hw, device=dev), torch.zeros(2 * hw, device=dev)
+    acc = torch.zeros(4, device=dev)
+    Lib = _lib.lib()
+    for k in range(3):
+        _lib.check(Lib.dasr_ragan(a.view(), b.view(), n, h, w, k, n, 1, 1.0, 0.0, 1.0 / cnt, 1.0 / cnt, eps, sums.data_ptr(), part.data_ptr(),
+                                  acc.data_ptr(), acc.data_ptr() + 4, acc.data_ptr() + 8, 1.0 / cnt, ga.view(), gb.view(), None))
+    assert abs(float(acc[0]) - float(d_loss)) < 1e-5 * abs(float(d_loss))
+    assert abs(float(acc[1]) - float(rt.mean())) < 1e-5 and abs(float(acc[2]) - float(ft.mean())) < 1e-5
+    assert rel(ga.nchw(1).cpu(), gR) < 1e-5 and rel(gb.nchw(1).cpu(), gF) < 1e-5
+    acc.zero_()
+    for k in (1, 2):   # generator: the sums of stage 0 are still valid; real term absent (t < 0), fake term against the 'real' label
+        _lib.check(Lib.dasr_ragan(a.view(), b.view(), n, h, w, k, n, 1, -1.0, 1.0, 1.0 / cnt, 0.005 / cnt, eps, sums.data_ptr(), part.data_ptr(),
+                                  acc.data_ptr(), None, None, 0.0, NULL_T, gb.view(), None))
+    assert abs(float(acc[0]) - float(tex)) < 1e-5 * abs(float(tex))
+    assert rel(gb.nchw(1).cpu(), gF_tex) < 1e-5
 
 
 def test_batchnorm_train_lrelu_forward_backward_two_groups():

@@ -190,7 +190,8 @@ def test_dsn_cli_flags_and_lr_rule():
     assert (o.w_col, o.w_tex, o.w_per, o.kernel_size, o.filter, o.discriminator, o.generator) == (1, 0.005, 0.01, 5, 'gau', 'FSD', 'DeResnet')
     assert (o.dataset, o.per_type) == ('df2k', 'LPIPS')   # the reference's defaults (codes/DSN/train.py:38,54)
     dsn_train.check_supported(o)
-    for bad in (['--generator', 'SRGAN'], ['--discriminator', 'nld_s3'], ['--ragan'], ['--wgan'], ['--norm_layer', 'Batch'], ['--lpips_rot_flip']):
+    dsn_train.check_supported(dsn_train.build_parser().parse_args(['--ragan']))
+    for bad in (['--generator', 'SRGAN'], ['--discriminator', 'nld_s3'], ['--wgan'], ['--norm_layer', 'Batch'], ['--lpips_rot_flip']):
         with pytest.raises(NotImplementedError):
             dsn_train.check_supported(dsn_train.build_parser().parse_args(bad))
     # LambdaLR rule of train.py:154-157 against torch's scheduler
