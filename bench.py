@@ -408,6 +408,11 @@ def bench_srn(a, dp, dasr, as_secondary=False):
                 r1 = roofline_from_step(one_step, None, 1)
                 out['roofline']['single_stream'] = {'ms_per_step': round(ms1, 2), 'per_kernel': r1['per_kernel'],
                                                     'note': 'DASR_STREAMS=1: batch-%d launches, no overlap between launches' % batch}
+                # `frac` above is strictly flops / launch duration in the production schedule, where two launches share the chip; the same
+                # kernel with the chip to itself:
+                same = [k for k in r1['per_kernel'] if k['kernel'] == out['roofline'].get('kernel')]
+                if same:
+                    out['roofline']['frac_single_stream'] = same[0]['frac']
             else:
                 one_step()
                 one_step()
