@@ -305,7 +305,7 @@ __global__ void gan_loss_kernel(dasr_tensor x, int N, int C, int H, int W, float
 //            part[0:HW] = sum_n (sigmoid(za) - ta), part[HW:2HW] = sum_n (sigmoid(zb) - tb)    (-> all-reduce SUM)
 //   stage 2: ga = gcoef * ((sigmoid(za) - ta) - part_b / n_glob), gb = gcoef * ((sigmoid(zb) - tb) - part_a / n_glob)   (either may be null)
 // ---------------------------------------------------------------------------------------------------
-// FORM 0 (SRN, above): term(z, t) = BCE-with-logits, score = the raw logit.  FORM 1 (DSN `--ragan`, codes/DSN/train.py:221-223 + loss.py:11-41 on
+// FORM 0 (SRN, above): term(z, t) = BCE-with-logits, score = the raw logit; FORM 2 / 3: the same with GANLoss('lsgan') / ('wgan-gp') terms.  FORM 1 (DSN `--ragan`, codes/DSN/train.py:221-223 + loss.py:11-41 on
 // model.py:98-106's sigmoid(x - mean_n(y))): term(z, t) = -log(sigmoid(z) + eps) for t > 0.5, -log(1 - sigmoid(z) + eps) for 0 <= t <= 0.5,
 // absent (0) for t < 0; score = sigmoid(z).
 template <int FORM>
@@ -314,6 +314,12 @@ __device__ __forceinline__ void rel_term(float z, float t, float eps, float& l, 
     if (FORM == 0) {
         l = fmaxf(z, 0.f) - z * t + log1pf(expf(-fabsf(z)));
         q = s - t;
+    } else if (FORM == 2) {   // GANLoss('lsgan') on the relativistic logits
+        l = (z - t) * (z - t);
+        q = 2.f * (z - t);
+    } else if (FORM == 3) {   // GANLoss('wgan-gp'): -z against the real label, +z otherwise
+        q = t > 0.5f ? -1.f : 1.f;
+        l = q * z;
     } else if (t < 0.f) {
         l = 0.f;
         q = 0.f;
@@ -354,8 +360,8 @@ __global__ void ragan_kernel(dasr_tensor a, dasr_tensor b, int N, int H, int W, 
                     l += la + lb;
                     qa += da;
                     qb += db;
-                    sca += FORM == 0 ? av : sa;
-                    scb += FORM == 0 ? bv : sb;
+                    sca += FORM != 1 ? av : sa;
+                    scb += FORM != 1 ? bv : sb;
                 }
                 part[p] = qa;
                 part[HW + p] = qb;
@@ -910,15 +916,19 @@ extern "C" int dasr_bce_logits(dasr_tensor x, int32_t N, int32_t C, int32_t H, i
 extern "C" int dasr_ragan(dasr_tensor a, dasr_tensor b, int32_t N, int32_t H, int32_t W, int32_t stage, int32_t n_glob, int32_t form, float ta, float tb,
                           float coef, float gcoef, float eps, float* sums, float* part, float* loss_acc, float* score_a, float* score_b,
                           float score_coef, dasr_tensor ga, dasr_tensor gb, void* stream) {
-    if (N <= 0 || H <= 0 || W <= 0 || n_glob < N || stage < 0 || stage > 2 || form < 0 || form > 1 || !a.p || !b.p || !sums || (stage > 0 && !part))
+    if (N <= 0 || H <= 0 || W <= 0 || n_glob < N || stage < 0 || stage > 2 || form < 0 || form > 3 || !a.p || !b.p || !sums || (stage > 0 && !part))
         return DASR_EINVAL;
     const dim3 g(nblk((long long)H * W)), blk(256);
-    if (form == 0)
-        DASR_LAUNCH(ragan_kernel<0>, g, blk, 0, as_stream(stream), a, b, N, H, W, stage, 1.f / (float)n_glob, ta, tb, coef, gcoef, eps, sums, part,
-                    loss_acc, score_a, score_b, score_coef, ga, gb);
-    else
-        DASR_LAUNCH(ragan_kernel<1>, g, blk, 0, as_stream(stream), a, b, N, H, W, stage, 1.f / (float)n_glob, ta, tb, coef, gcoef, eps, sums, part,
-                    loss_acc, score_a, score_b, score_coef, ga, gb);
+#define DASR_RAGAN_FORM(F)                                                                                                                        \
+    DASR_LAUNCH(ragan_kernel<F>, g, blk, 0, as_stream(stream), a, b, N, H, W, stage, 1.f / (float)n_glob, ta, tb, coef, gcoef, eps, sums, part, \
+                loss_acc, score_a, score_b, score_coef, ga, gb)
+    switch (form) {
+        case 0: DASR_RAGAN_FORM(0); break;
+        case 1: DASR_RAGAN_FORM(1); break;
+        case 2: DASR_RAGAN_FORM(2); break;
+        default: DASR_RAGAN_FORM(3); break;
+    }
+#undef DASR_RAGAN_FORM
     return (int)hipGetLastError();
 }
 

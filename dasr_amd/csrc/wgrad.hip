@@ -893,7 +893,7 @@ extern "C" int dasr_probe_tr16(void* stream) {
     int h = -1;
     hipError_t e = hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, as_stream(stream));
     if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));
-    hipFree(d);
+    (void)hipFree(d);
     if (e != hipSuccess) return -(int)e;
     g_use_tr = h;
     return h;

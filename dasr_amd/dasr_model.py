@@ -78,8 +78,6 @@ class DASR_Model(BaseModel):
         if str(t['gan_type']).lower() not in gan_modes:
             raise NotImplementedError('GAN type [{:s}] is not found'.format(str(t['gan_type'])))
         self.gan_mode = gan_modes[str(t['gan_type']).lower()]
-        if self.gan_mode != 0 and t['ragan']:
-            raise NotImplementedError('ragan with gan_type [{:s}]: the relativistic kernel implements the vanilla (BCE) form only'.format(str(t['gan_type'])))
         self.ragan = bool(t['ragan'])   # relativistic average GAN: per-pixel batch means of the logits (all-reduced across data-parallel ranks)
         self.l_gan_H_target_w = t['gan_H_target'] or 0
         self.l_gan_H_source_w = (t['gan_H_source'] or 0) if self.is_train else 0
@@ -503,10 +501,10 @@ class _StepPlan:
                 g_fake, g_real = D_.g_logits.view(), _nview(D_.g_logits, n)
                 # generator: a = fake (target 1, gradient), b = real (target 0, detached)
                 _ragan_ops(self.rg, fake, real, n, lg.H, lg.W, n * world, 1.0, 0.0, 0.5 * float(w_log) / cnt, 0.5 * float(w_grad) / cnt, sums, part,
-                           acc + 4 * slot_g, None, None, 0.0, g_fake, NULL_T)
+                           acc + 4 * slot_g, None, None, 0.0, g_fake, NULL_T, form=(0, 2, 3)[m.gan_mode])
                 # discriminator: a = real (target 1), b = fake (target 0), both carry gradient; the whole loss goes to the "real" slot
                 _ragan_ops(lists_d, real, fake, n, lg.H, lg.W, n * world, 1.0, 0.0, 0.5 / cnt, 0.5 / cnt, sums, part,
-                           acc + 4 * slots_d[0], acc + 4 * slots_d[1], acc + 4 * slots_d[2], 1.0 / cnt, g_real, g_fake)
+                           acc + 4 * slots_d[0], acc + 4 * slots_d[1], acc + 4 * slots_d[2], 1.0 / cnt, g_real, g_fake, form=(0, 2, 3)[m.gan_mode])
         self.fwd = fwd
 
         # ---- generator-loss backward: everything that lands in dL/dSR ----------------------------------------------------

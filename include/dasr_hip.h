@@ -235,7 +235,7 @@ int dasr_gan_loss(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, int
  * Three stages so that data-parallel ranks can all-reduce (SUM) the two tiny per-pixel buffers in between (2*H*W floats each):
  *   stage 0: sums = [sum_n a ; sum_n b];   stage 1: loss_acc += coef * local loss, score_a/b += score_coef * sum a / b,
  *   part = [sum_n (sigmoid(za) - ta) ; sum_n (sigmoid(zb) - tb)];   stage 2: ga / gb (optional) = gcoef * d(sum)/da, /db incl. the mean terms
- * form 0: the SRN form above (score = mean logit).  form 1: the DSN's `--ragan` (codes/DSN/train.py:221-223, model.py:98-106, loss.py:11-41):
+ * form 0: the SRN form above (score = mean logit); form 2 / 3: the same with the GANLoss('lsgan') / ('wgan-gp') term instead of bce.  form 1: the DSN's `--ragan` (codes/DSN/train.py:221-223, model.py:98-106, loss.py:11-41):
  *   term(z, t) = -log(sigmoid(z) + eps) for t > 0.5, -log(1 - sigmoid(z) + eps) for 0 <= t <= 0.5, absent for t < 0; score = mean sigmoid(z). */
 int dasr_ragan(dasr_tensor a, dasr_tensor b, int32_t N, int32_t H, int32_t W, int32_t stage, int32_t n_glob, int32_t form, float ta, float tb,
                float coef, float gcoef, float eps, float* sums, float* part, float* loss_acc, float* score_a, float* score_b, float score_coef,

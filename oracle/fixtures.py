@@ -34,6 +34,7 @@ CASES = OrderedDict([
     ('dasr_srcVGG128_gau5_nf32_nb1_n3_32', dict(kind='dasr', nf=32, nb=1, n=3, lr=32, fs='gau', d_in_nc=3, gan_src=0.02, pairD='discriminator_vgg_128')),
     # gan_type 'lsgan' / 'wgan-gp' (GANLoss, loss.py:8-40) on both discriminators
     ('dasr_lsgan_wavelet_nf32_nb1_n2_32', dict(kind='dasr', nf=32, nb=1, n=2, lr=32, fs='wavelet', d_in_nc=9, gan_src=0.02, gan_type='lsgan')),
+    ('dasr_ragan_lsgan_wavelet_nf32_nb1_n3_32', dict(kind='dasr', nf=32, nb=1, n=3, lr=32, fs='wavelet', d_in_nc=9, gan_src=0.02, ragan=True, gan_type='lsgan')),
     ('dasr_wgan_gau9_nf32_nb1_n2_32', dict(kind='dasr', nf=32, nb=1, n=2, lr=32, fs='gau', d_in_nc=3, gan_src=0.02, gan_type='wgan-gp')),
 ])
 

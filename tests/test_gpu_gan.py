@@ -219,7 +219,7 @@ def test_vgg_forward_and_input_gradient(prec, act_tol, grad_tol, margins):
 
 @pytest.mark.parametrize('case', ['dasr_wavelet_nf32_nb2_n2_32', 'dasr_gau9_nf64_nb1_n1_32', 'dasr_lpips_wavelet_nf32_nb2_n2_32',
                                   'dasr_srcD_wavelet_nf32_nb2_n2_32', 'dasr_ragan_wavelet_nf32_nb1_n3_32', 'dasr_srcVGG128_gau5_nf32_nb1_n3_32',
-                                  'dasr_lsgan_wavelet_nf32_nb1_n2_32', 'dasr_wgan_gau9_nf32_nb1_n2_32'])
+                                  'dasr_lsgan_wavelet_nf32_nb1_n2_32', 'dasr_wgan_gau9_nf32_nb1_n2_32', 'dasr_ragan_lsgan_wavelet_nf32_nb1_n3_32'])
 def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir, margins):
     dev = _gpu()
     GRAD_TOL = VGG128_STEP_TOL if 'VGG128' in case else globals()['GRAD_TOL']   # see the note at VGG128_GRAD_TOL
@@ -301,6 +301,35 @@ def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir, margin
             w2 = max([rel(gv.reshape(pr.grad.shape), pr.grad) for (k, gv), pr in zip(m.netD_source.params.grad_dict().items(), netD2.parameters())
                       if not (zero_last_bias and k.endswith('model.8.bias'))]) if netD2 is not None else 0.0
             margins('%s: worst gradient rel err G %.2e, D_source %.2e (bound %.0e)' % (case, worst, w2, GRAD_TOL))
+
+
+@pytest.mark.parametrize('form', [2, 3], ids=['lsgan', 'wgan'])
+def test_ragan_lsgan_wgan_forms(form):
+    """dasr_ragan forms 2 / 3: GANLoss('lsgan') / ('wgan-gp') terms on the relativistic logits (DASR_model.py:273-275 with loss.py:17-23)"""
+    dev = _gpu()
+    from dasr_amd import _lib
+    from dasr_amd.engine import BTensor
+    g = torch.Generator().manual_seed(13)
+    n, h, w = 3, 9, 12
+    A = torch.randn(n, 1, h, w, generator=g).requires_grad_(True)
+    B = torch.randn(n, 1, h, w, generator=g).requires_grad_(True)
+    if form == 2:
+        term = lambda x, t: F.mse_loss(x, torch.full_like(x, t))
+    else:
+        term = lambda x, t: -x.mean() if t > 0.5 else x.mean()
+    L = (term(A - B.mean(0, keepdim=True), 1.0) + term(B - A.mean(0, keepdim=True), 0.0)) / 2
+    L.backward()
+    a, b = to_blocked(A.detach(), dev), to_blocked(B.detach(), dev)
+    ga, gb = BTensor(n, 16, h, w, True, dev), BTensor(n, 16, h, w, True, dev)
+    hw, cnt = h * w, float(n * h * w)
+    sums, part = torch.zeros(2 * hw, device=dev), torch.zeros(2 * hw, device=dev)
+    acc = torch.zeros(4, device=dev)
+    for k in range(3):
+        _lib.check(_lib.lib().dasr_ragan(a.view(), b.view(), n, h, w, k, n, form, 1.0, 0.0, 0.5 / cnt, 0.5 / cnt, 0.0, sums.data_ptr(), part.data_ptr(),
+                                         acc.data_ptr(), acc.data_ptr() + 4, acc.data_ptr() + 8, 1.0 / cnt, ga.view(), gb.view(), None))
+    assert abs(float(acc[0]) - float(L)) < 1e-5 * max(1.0, abs(float(L)))
+    assert abs(float(acc[1]) - float(A.detach().mean())) < 1e-5 and abs(float(acc[2]) - float(B.detach().mean())) < 1e-5
+    assert rel(ga.nchw(1).cpu(), A.grad) < 1e-5 and rel(gb.nchw(1).cpu(), B.grad) < 1e-5
 
 
 @pytest.mark.parametrize('n,n_glob,h,w', [(3, 3, 14, 14), (2, 6, 9, 11)])
