@@ -24,7 +24,7 @@ import torch
 from . import _lib
 from .engine import (BTensor, ParamStore, PackRegistry, OpList, WgradGroup, Workspace, conv_op, ceil_div, NULL_T, Op, Tensor,
                      ensure_runtime_ready, _stream)
-from .gan_nets import NLayerDiscriminatorHIP, VGGFeatureHIP, VGG16_CFG, fsd_spec, dsn_nld_spec
+from .gan_nets import NLayerDiscriminatorHIP, BatchNormDiscriminatorHIP, VGGFeatureHIP, VGG16_CFG, fsd_spec, dsn_nld_spec, fold_batchnorm_fsd
 from .models import AdamHIP
 from .dasr_model import gaussian_kernel2d, vgg_random_state_dict, _nview, _ragan_ops
 
@@ -53,14 +53,18 @@ def deresnet_spec(n_res_blocks=8, scale=4):
     return spec
 
 
-def default_init_state(spec):
-    """nn.Conv2d / nn.PReLU default initialisation in construction order (codes/DSN/train.py:77 seeds torch with 0)"""
+def default_init_state(spec, bn_prefixes=()):
+    """nn.Conv2d / nn.PReLU / nn.BatchNorm2d default initialisation in construction order (codes/DSN/train.py:77 seeds torch with 0)"""
     import math
     from torch.nn import init
     sd = OrderedDict()
     i = 0
     while i < len(spec):
         k, shape = spec[i]
+        if k.startswith(tuple(bn_prefixes)) and bn_prefixes:   # BatchNorm2d: weight 1, bias 0 (no RNG draw)
+            sd[k] = torch.ones(shape) if k.endswith('.weight') else torch.zeros(shape)
+            i += 1
+            continue
         if len(shape) == 1 and k.endswith('.weight'):  # PReLU
             sd[k] = torch.full(shape, 0.25)
             i += 1
@@ -275,9 +279,11 @@ class DSNModel:
         if self.d_arch not in ('fsd', 'nld_s1', 'nld_s2'):
             raise NotImplementedError('Discriminator architecture [{:s}] not recognized'.format(o['discriminator']))
         if o['upscale_factor'] != 4 or o['norm_layer'] not in ('Instance', 'Batch') or (self.d_arch != 'fsd' and o['norm_layer'] != 'Instance'):
-            raise NotImplementedError('DSN on MI355X: De_resnet x4 + FSD / nld_s1 / nld_s2 discriminator with Instance norm (FSD also Batch norm at inference)')
-        # norm_layer 'Batch': inference only (translate / ddm_of): BatchNorm in eval mode is folded into the convs at load time
-        self.bn_eval = o['norm_layer'] == 'Batch'
+            raise NotImplementedError('DSN on MI355X: De_resnet x4 + FSD / nld_s1 / nld_s2 discriminator with Instance norm (FSD also with Batch norm)')
+        # norm_layer 'Batch' (FSD, model.py:176-189): iteration() runs BatchNorm in training mode (statistics per discriminator call = per half
+        # [fake | real], as the reference's two calls); translate() / ddm_of() run it in eval mode: a conv-only copy with the running statistics
+        # folded in (refreshed when the weights changed)
+        self.bn = o['norm_layer'] == 'Batch'
         self.netF = None
         if o['w_per'] > 0:
             if o['per_type'] == 'LPIPS':      # PerceptualLoss() = LPIPS(alex) on the LR-size images (loss.py:68-69,84,108-114)
@@ -303,14 +309,23 @@ class DSNModel:
         self.netG = DeResnetHIP(o['n_res_blocks'], device=self.device, scale=4 if o['generator'].lower() == 'deresnet' else 1)
         nc = 9 if self.filter == 'wavelet' else 3
         gk = self.k if self.filter == 'gau' else None
+        self.netD_eval = None
         if self.d_arch == 'fsd':
-            spec_layers = fsd_spec(nc, gk, norm='BatchEval' if self.bn_eval else 'Instance')
+            spec_layers = fsd_spec(nc, gk, norm='Batch' if self.bn else 'Instance')
         else:   # codes/DSN/model.py:84-89: NLayerDiscriminator(n_layers=2) with stride 1 / 2
             spec_layers = dsn_nld_spec(nc, 1 if self.d_arch == 'nld_s1' else 2, gk)
-        self.netD = NLayerDiscriminatorHIP(nc, device=self.device, spec_layers=spec_layers)
         # default nn init, G first then D (codes/DSN/train.py:124-135 under torch.manual_seed(0))
         self.netG.load_state_dict(default_init_state(self.netG.spec))
-        self.netD.load_state_dict(default_init_state(self.netD.spec))
+        if self.bn:
+            self.netD = BatchNormDiscriminatorHIP(nc, device=self.device, spec_layers=spec_layers)
+            sd = default_init_state(self.netD.spec, bn_prefixes=[L['bn'] for L in self.netD.layers if L['norm'] == 'batch'])
+            sd.update({k: v.clone() for k, v in self.netD.buffers.items()})
+            self.netD.load_state_dict(sd)
+            self.netD_eval = NLayerDiscriminatorHIP(nc, device=self.device, spec_layers=fsd_spec(nc, gk, norm='BatchEval'))
+            self._d_eval_stale = True
+        else:
+            self.netD = NLayerDiscriminatorHIP(nc, device=self.device, spec_layers=spec_layers)
+            self.netD.load_state_dict(default_init_state(self.netD.spec))
         if self.filter != 'wavelet':
             w = gaussian_kernel2d(self.k) if self.filter == 'gau' else torch.full((self.k, self.k), 1.0 / (self.k * self.k))
             self.fw = w.contiguous().to(self.device)
@@ -343,16 +358,20 @@ class DSNModel:
         return self._plans[k]
 
     def load_discriminator_state(self, sd):
-        """state_dict of the reference Discriminator (codes/DSN/model.py:60-118).  FSD-Batch dicts are folded (eval-mode BatchNorm -> conv)"""
-        from .gan_nets import fold_batchnorm_fsd
-        if self.bn_eval:
-            self.bn_state = {k: v.clone() for k, v in sd.items()}   # kept for save(): the reference layout with the BN buffers
-            sd = fold_batchnorm_fsd(sd)
+        """state_dict of the reference Discriminator (codes/DSN/model.py:60-118), FSD-Batch ones with their BatchNorm buffers"""
         self.netD.load_state_dict(sd)
+        self._d_eval_stale = True
+
+    def inference_discriminator(self):
+        """the network translate() / ddm_of() run: netD itself, or for BatchNorm its eval()-mode equivalent (running statistics folded into the convs)"""
+        if not self.bn:
+            return self.netD
+        if self._d_eval_stale:
+            self.netD_eval.load_state_dict(fold_batchnorm_fsd(self.netD.state_dict()))
+            self._d_eval_stale = False
+        return self.netD_eval
 
     def iteration(self, hr, bicubic_lr, real_lr):
-        if self.bn_eval:
-            raise NotImplementedError('training with a BatchNorm discriminator (batch statistics across ranks) is not on the hot path; norm_layer=Instance')
         N, _, H, W = hr.shape
         P = self._plan(N, H, W)
         P.g.x_nchw.copy_(hr if self.netG.scale == 4 else bicubic_lr)
@@ -365,6 +384,9 @@ class DSNModel:
         if scale != P.scale:
             P.set_grad_scale(scale)
         P.fwd.run()     # G, front ends, D on [fake; real], all losses and loss gradients
+        if self.bn:     # BatchNorm running statistics, one update per discriminator call of the reference (train.py:221-226)
+            P.d_running.run()
+            self._d_eval_stale = True
         P.d_bwd.run()   # D weight gradients (pre-update graph)
         P.g_bwd.run()   # texture gradient through D's data path, colour adjoint, G backward
         if self.dp is not None and self.dp.active:
@@ -386,6 +408,7 @@ class DSNModel:
         (four [5,1,2] layers as the reference's table has it: 17x17) and divided by the coverage count = a count-normalised 17x17 box
         average (receptive_cal.py:34-60)."""
         n, _, H, W = img.shape
+        self.inference_discriminator()   # BatchNorm: refresh the folded eval-mode copy if the weights moved
         k = ('inf', n, H, W)
         if k not in self._plans:
             self._plans[k] = _InferPlan(self, n, H, W)
@@ -401,6 +424,7 @@ class DSNModel:
         if self.filter == 'wavelet':
             h, w = h // 2 * 2, w // 2 * 2
             lr = lr[..., :h, :w]
+        self.inference_discriminator()
         k = ('ddm', n, h, w)
         if k not in self._plans:
             self._plans[k] = _InferPlan(self, n, h, w, with_g=False)
@@ -436,9 +460,8 @@ class DSNModel:
         ck = torch.load(path, map_location='cpu', weights_only=False)
         self.netG.load_state_dict(ck['model_g_state_dict'])
         self.load_discriminator_state(ck['models_d_state_dict'])
-        if not self.bn_eval:
-            self.opt_g.load_state_dict(ck['optimizer_g_state_dict'])
-            self.opt_d.load_state_dict(ck['optimizer_d_state_dict'])
+        self.opt_g.load_state_dict(ck['optimizer_g_state_dict'])
+        self.opt_d.load_state_dict(ck['optimizer_d_state_dict'])
         self.epoch, self.iteration_count = ck['epoch'], ck['iteration']
 
 
@@ -484,6 +507,12 @@ class _DSNPlan:
                 o.f[0], o.f[1], o.t[2], o.t[3] = 0.5, 0.5, NULL_T, _nview(d.x, n0)
             f.add(o)
         f.extend(d.fwd)
+        # BatchNorm discriminator: the reference calls D(real) then D(fake) (with --ragan: net(real), net(fake), net(fake), net(real)); every call
+        # in training mode moves the running statistics once, with that call's batch statistics (group 0 = fake half, 1 = real half)
+        self.d_running = OpList()
+        if m.bn:
+            for grp_ in ((1, 0, 0, 1) if m.ragan else (1, 0)):
+                self.d_running.extend(d.running_ops(grp_))
         lg = d.logits
         cnt = float(N * lg.H * lg.W)
         # --ragan: the same two terms on relativistic logits real - mean_n(fake), fake - mean_n(real): the three dasr_ragan stages back to back
@@ -593,6 +622,8 @@ class _DSNPlan:
             for o in ol.ops:
                 if o.op == _lib.OP_WGRAD_REDUCE:
                     o.f[0] = scale
+                elif o.op == _lib.OP_BNORM_BWD and o.p[3]:   # dgamma / dbeta of a BatchNorm discriminator
+                    o.f[1] = scale
             ol._arr = None
 
 
@@ -609,7 +640,7 @@ class _InferPlan:
         h, w = (H // 4, W // 4) if with_g else (H, W)
         wav = m.filter == 'wavelet'
         hd, wd = (h // 2, w // 2) if wav else (h, w)
-        self.d = m.netD.plan(N, hd, wd)
+        self.d = m.inference_discriminator().plan(N, hd, wd)
         d = self.d
         self.dout, self.ddm = BTensor(N, 16, hd, wd, True, dev), BTensor(N, 16, hd, wd, True, dev)
         self.box = torch.full((DDM_RF * DDM_RF,), 1.0 / (DDM_RF * DDM_RF), dtype=torch.float32, device=dev)

@@ -4,7 +4,7 @@ Same flags and defaults as the reference's argparse block (train.py:24-72) and t
 DSNModel.iteration(hr, bicubic_lr, real_lr); schedulers step once per epoch (train.py:287-288); every
 `save_model_interval` epochs the `.tar` checkpoint dict of train.py:357-376 is written to
 <save_path>/checkpoints/iteration_<n>.tar and last_iteration.tar.  Accepted-but-unsupported choices fail the way the
-reference does for unknown strings (NotImplementedError): --wgan, --norm_layer Batch, --lpips_rot_flip.  --ragan is supported (single rank).  --per_type LPIPS (the reference default) runs LPIPS(alex) with weights from --lpips_alexnet /
+reference does for unknown strings (NotImplementedError): --wgan, --lpips_rot_flip, --norm_layer Batch with the nld discriminators.  --ragan is supported (single rank).  --per_type LPIPS (the reference default) runs LPIPS(alex) with weights from --lpips_alexnet /
 --lpips_lin (seeded and logged when absent: they cannot be downloaded offline).  Data: the PIL/torchvision loaders
 (data_loader.py) stay on the reference's side of the boundary; any iterable of (hr, bicubic_lr, real_lr) tuples works, and
 `--dataset synthetic` ships fixed-seed random crops for benchmarks and tests.
@@ -77,8 +77,8 @@ def check_supported(o):
         raise NotImplementedError('--lpips_rot_flip (random rotations / flips in front of LPIPS, loss.py:97-110) is not on the MI355X path')
     if o.wgan:
         raise NotImplementedError('--wgan needs a gradient penalty (train.py:231-236: a second-order pass through D); not on the MI355X path')
-    if not o.highpass or o.cat_or_sum != 'cat' or o.norm_layer != 'Instance':
-        raise NotImplementedError('DSN on MI355X covers the default path: high-pass front end, wavelet bands cat, Instance norm')
+    if not o.highpass or o.cat_or_sum != 'cat' or o.norm_layer not in ('Instance', 'Batch') or (o.norm_layer == 'Batch' and o.discriminator.lower() != 'fsd'):
+        raise NotImplementedError('DSN on MI355X covers: high-pass front end, wavelet bands cat, Instance norm (FSD also Batch norm)')
     if o.disc_freq != 1 or o.gen_freq != 1:
         raise NotImplementedError('disc_freq / gen_freq other than 1')
 

@@ -62,18 +62,23 @@ def fold_batchnorm_fsd(sd, eps=1e-5):
 
 def fsd_spec(input_nc, gaussian_k=None, norm='Instance'):
     """DSN DiscriminatorBasic (codes/DSN/model.py:173-210): 5x5 convs (all with bias) and a 1x1 head.  norm 'Instance': InstanceNorm after
-    the 2nd / 3rd conv; 'BatchEval': BatchNorm in eval mode, folded into those convs (fold_batchnorm_fsd), i.e. no norm op at all.
+    the 2nd / 3rd conv; 'Batch': BatchNorm2d in training mode there (BatchNormDiscriminatorHIP); 'BatchEval': BatchNorm in eval mode, folded
+    into those convs (fold_batchnorm_fsd), i.e. no norm op at all.
     gaussian_k: the frozen depthwise gaussian of the 'gau' front end is part of the reference state_dict."""
     spec = []
     if gaussian_k:
         spec.append(('filter.filter_low.filter.gaussian_filter.weight', (3, 1, gaussian_k, gaussian_k)))
     layers = []
-    inorm = norm == 'Instance'
-    for idx, cin, cout, kh, norm, last in ((0, input_nc, 64, 5, False, False), (2, 64, 128, 5, inorm, False), (5, 128, 256, 5, inorm, False),
-                                           (8, 256, 1, 1, False, True)):
+    nrm = {'Instance': True, 'Batch': 'batch', 'BatchEval': False}[norm]
+    for idx, cin, cout, kh, norm_l, last in ((0, input_nc, 64, 5, False, False), (2, 64, 128, 5, nrm, False), (5, 128, 256, 5, nrm, False),
+                                             (8, 256, 1, 1, False, True)):
         key = 'net.net.%d.' % idx
         spec += [(key + 'weight', (cout, cin, kh, kh)), (key + 'bias', (cout,))]
-        layers.append(dict(key=key, cin=cin, cout=cout, stride=1, bias=True, norm=norm, last=last, kh=kh, pad=(kh - 1) // 2))
+        bn = None
+        if norm_l == 'batch':   # nn.BatchNorm2d right after the conv (model.py:181-187): affine parameters in the optimiser, buffers beside it
+            bn = 'net.net.%d.' % (idx + 1)
+            spec += [(bn + 'weight', (cout,)), (bn + 'bias', (cout,))]
+        layers.append(dict(key=key, cin=cin, cout=cout, stride=1, bias=True, norm=norm_l, bn=bn, last=last, kh=kh, pad=(kh - 1) // 2))
     return spec, layers
 
 
@@ -171,16 +176,15 @@ class NLayerDiscriminatorHIP:
         return self.plans[k]
 
 
-class DiscriminatorVGG128HIP(NLayerDiscriminatorHIP):
-    """`which_model_pairD: discriminator_vgg_128` (networks.py:201-202): the source-domain discriminator with BatchNorm in training mode.
-    Batch statistics are taken per call of the reference = per half [fake | real] of the batch (`bn_groups`), on this rank's samples (the
-    reference's nn.DataParallel replicas do not synchronise BatchNorm either); running statistics follow the reference's three forwards per
-    step (fake in the G step, real and fake in the D step) and live outside the optimiser's buffers."""
+class BatchNormDiscriminatorHIP(NLayerDiscriminatorHIP):
+    """A discriminator whose layer table has BatchNorm2d (training mode) entries (`norm == 'batch'`, parameter prefix `bn`).
+    Batch statistics are taken per call of the reference = per half [fake | real] of the batch (`bn_groups`), on this rank's samples; the running
+    statistics live outside the optimiser's buffers and are updated by `_DPlan.running_ops(group)` in the order of the reference's forwards."""
     bn_groups = 2
     prec = 4   # the BatchNorm backward cancels group means: 16-bit conv operands leave 4e-2 on the first layers' gradients, 22-bit ones 1e-3
 
-    def __init__(self, in_nc, nf=64, device='cuda'):
-        super().__init__(in_nc, nf, device=device, spec_layers=vgg128_spec(in_nc, nf))
+    def __init__(self, input_nc, device='cuda', spec_layers=None):
+        super().__init__(input_nc, device=device, spec_layers=spec_layers)
         self.buffers = {}
         for L in self.layers:
             if L['norm'] == 'batch':
@@ -189,13 +193,14 @@ class DiscriminatorVGG128HIP(NLayerDiscriminatorHIP):
                 self.buffers[L['bn'] + 'num_batches_tracked'] = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     def state_dict(self):
-        """the reference module's keys, order and shapes (Linear weights 2-D, num_batches_tracked int64)"""
+        """the reference module's keys, order and shapes (BN buffers after the BN bias, num_batches_tracked int64)"""
         from collections import OrderedDict
         flat, out = self.params.state_dict(), OrderedDict()
+        bn_bias = {L['bn'] + 'bias': L['bn'] for L in self.layers if L['norm'] == 'batch'}
         for k, v in flat.items():
-            out[k] = v.reshape(v.shape[0], -1) if k.startswith('linear') and k.endswith('weight') else v
-            if k.endswith('.bias') and k.startswith('bn'):
-                pre = k[:-4]
+            out[k] = v
+            if k in bn_bias:
+                pre = bn_bias[k]
                 out[pre + 'running_mean'] = self.buffers[pre + 'running_mean'].detach().clone().cpu()
                 out[pre + 'running_var'] = self.buffers[pre + 'running_var'].detach().clone().cpu()
                 out[pre + 'num_batches_tracked'] = self.buffers[pre + 'num_batches_tracked'].detach().cpu().round().long().reshape(())
@@ -215,6 +220,20 @@ class DiscriminatorVGG128HIP(NLayerDiscriminatorHIP):
             raise RuntimeError('Error(s) in loading state_dict: missing %s' % missing)
         self.params.load_state_dict(own, strict=False)
         self.repack()
+
+
+class DiscriminatorVGG128HIP(BatchNormDiscriminatorHIP):
+    """`which_model_pairD: discriminator_vgg_128` (networks.py:201-202): the source-domain discriminator with BatchNorm in training mode (the
+    reference's nn.DataParallel replicas do not synchronise BatchNorm either); running statistics follow the reference's three forwards per
+    step (fake in the G step, real and fake in the D step)."""
+
+    def __init__(self, in_nc, nf=64, device='cuda'):
+        super().__init__(in_nc, device=device, spec_layers=vgg128_spec(in_nc, nf))
+
+    def state_dict(self):
+        """Linear weights 2-D as in the reference module"""
+        from collections import OrderedDict
+        return OrderedDict((k, v.reshape(v.shape[0], -1) if k.startswith('linear') and k.endswith('weight') else v) for k, v in super().state_dict().items())
 
 
 def vgg128_init_state_dict(spec, seed):

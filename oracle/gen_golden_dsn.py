@@ -30,6 +30,9 @@ DSN_CASES = {
     'dsn_dsgan_gau5_inst_b2_128': dict(filter='gau', k=5, norm='Instance', n=2, crop=128, gen='DSGAN'),
     # --ragan (train.py:221-223, model.py:98-106): relativistic discriminator outputs, n = 3 so that the batch means matter
     'dsn_gau5_inst_b3_128_ragan': dict(filter='gau', k=5, norm='Instance', n=3, crop=128, ragan=True),
+    # --norm_layer Batch (model.py:176-189): BatchNorm2d in training mode, statistics per discriminator call (the layout of the reference's test.tar)
+    'dsn_gau5_batch_b2_128': dict(filter='gau', k=5, norm='Batch', n=2, crop=128),
+    'dsn_avg5_batch_b3_128_ragan': dict(filter='avg_pool', k=5, norm='Batch', n=3, crop=128, ragan=True),
 }
 
 

@@ -209,7 +209,8 @@ def test_deresnet_forward_backward():
 
 
 @pytest.mark.parametrize('case', ['dsn_gau5_inst_b2_128', 'dsn_wavelet_inst_b2_128', 'dsn_avg5_inst_b1_160', 'dsn_gau5_inst_b1_256_lpips',
-                                  'dsn_wavelet_nld_s2_b2_128', 'dsn_gau5_nld_s1_b1_128', 'dsn_dsgan_gau5_inst_b2_128', 'dsn_gau5_inst_b3_128_ragan'])
+                                  'dsn_wavelet_nld_s2_b2_128', 'dsn_gau5_nld_s1_b1_128', 'dsn_dsgan_gau5_inst_b2_128', 'dsn_gau5_inst_b3_128_ragan',
+                                  'dsn_gau5_batch_b2_128', 'dsn_avg5_batch_b3_128_ragan'])
 def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir):
     dev = _gpu()
     torch.set_num_threads(8)
@@ -229,9 +230,10 @@ def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir):
         crit, sdF = lpips.golden_criterion(78, golden_dir)
     t = dsn.DSNTrainer(G, D, kernel_size=c['k'], filter_type=c['filter'], norm_layer=c['norm'], vgg_seed=78, w_per=0.01, per_type=c.get('per', 'VGG'), netF=crit, ragan=bool(c.get('ragan')))
     m = DSNModel(dict(ragan=bool(c.get('ragan')), filter=c['filter'], kernel_size=c['k'], norm_layer=c['norm'], w_per=0.01, vgg_seed=78, per_type=c.get('per', 'VGG'), discriminator=c.get('arch', 'FSD'), generator=c.get('gen', 'DeResnet')), device=dev)
-    assert list(m.netG.params.spec) == list(gold['G_keys']) and list(m.netD.params.spec) == list(gold['D_keys'])
+    d_keys = list(m.netD.state_dict()) if c['norm'] == 'Batch' else list(m.netD.params.spec)   # BatchNorm: buffers are part of the reference layout
+    assert list(m.netG.params.spec) == list(gold['G_keys']) and d_keys == list(gold['D_keys'])
     m.netG.load_state_dict(sdG)
-    m.netD.load_state_dict(sdD)
+    m.load_discriminator_state(sdD)
     m.netF.load_state_dict(sdF if sdF is not None else {'features.' + k: v for k, v in t.per.state_dict().items()})
     hr, bic, real = dsn_batch(c)
     from oracle import fixtures
@@ -261,6 +263,21 @@ def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir):
             big = np.array([v.numel() > 1 for v in gd.values()])
             np.testing.assert_allclose(np.array([float(v.double().norm()) for v in gd.values()])[big], gold['gradG_norm'][big], rtol=GRAD_TOL)
             np.testing.assert_allclose(np.array([float(v.double().norm()) for v in dpar.values()]), gold['gradD_norm'], rtol=GRAD_TOL, atol=1e-5 if c.get('ragan') else 1e-6)
+    if c['norm'] == 'Batch':   # running statistics after two iterations = four training-mode calls (real, fake, real, fake; --ragan: real, fake, fake, real
+        # per iteration = eight) + the reference key layout
+        sd_ref, sd_hip = D.state_dict(), m.netD.state_dict()
+        assert list(sd_hip.keys()) == list(sd_ref.keys())
+        for k in sd_ref:
+            if k.endswith('num_batches_tracked'):
+                assert int(sd_hip[k]) == int(sd_ref[k]) == (8 if c.get('ragan') else 4)
+            elif 'running' in k:
+                assert rel(sd_hip[k], sd_ref[k]) < 2e-3, (k, rel(sd_hip[k], sd_ref[k]))
+        # eval-mode inference with the trained statistics (translate / ddm_of fold them into the convs)
+        D.eval()
+        with torch.no_grad():
+            want = D(real)
+        got, _ = m.ddm_of(real.to(dev))
+        assert rel(got.cpu(), want) < 2e-3
 
 
 def test_dsn_checkpoint_roundtrip(tmp_path):
@@ -362,5 +379,11 @@ def test_fsd_batch_discriminator_matches_reference_test_tar(golden_dir, margins)
     margins('FSD-Batch discriminator with the reference test.tar weights: D_out rel err %.2e (tol 1e-3), max abs %.2e' % (
         e, float((dout.cpu() - want).abs().max())))
     assert dout.shape == want.shape and e < 1e-3
-    with pytest.raises(NotImplementedError):
-        m.iteration(torch.rand(1, 3, 128, 128).cuda(), torch.rand(1, 3, 32, 32).cuda(), torch.rand(1, 3, 32, 32).cuda())
+    # the checkpoint can be trained on (BatchNorm in training mode) and written back in the reference layout
+    sd0 = m.netD.state_dict()
+    assert list(sd0.keys()) == [k for k in sd.keys()]
+    m.iteration(torch.rand(2, 3, 128, 128).cuda(), torch.rand(2, 3, 32, 32).cuda(), torch.rand(2, 3, 32, 32).cuda())
+    sd1 = m.netD.state_dict()
+    assert int(sd1['net.net.3.num_batches_tracked']) == int(sd0['net.net.3.num_batches_tracked']) + 2
+    assert not torch.equal(sd1['net.net.2.weight'], sd0['net.net.2.weight']) and not torch.equal(sd1['net.net.3.running_mean'], sd0['net.net.3.running_mean'])
+    assert all(torch.isfinite(v.float()).all() for v in sd1.values())

@@ -191,7 +191,8 @@ def test_dsn_cli_flags_and_lr_rule():
     assert (o.dataset, o.per_type) == ('df2k', 'LPIPS')   # the reference's defaults (codes/DSN/train.py:38,54)
     dsn_train.check_supported(o)
     dsn_train.check_supported(dsn_train.build_parser().parse_args(['--ragan']))
-    for bad in (['--generator', 'SRGAN'], ['--discriminator', 'nld_s3'], ['--wgan'], ['--norm_layer', 'Batch'], ['--lpips_rot_flip']):
+    dsn_train.check_supported(dsn_train.build_parser().parse_args(['--norm_layer', 'Batch']))
+    for bad in (['--generator', 'SRGAN'], ['--discriminator', 'nld_s3'], ['--wgan'], ['--norm_layer', 'Batch', '--discriminator', 'nld_s1'], ['--norm_layer', 'Group'], ['--lpips_rot_flip']):
         with pytest.raises(NotImplementedError):
             dsn_train.check_supported(dsn_train.build_parser().parse_args(bad))
     # LambdaLR rule of train.py:154-157 against torch's scheduler
