@@ -590,6 +590,87 @@ extern "C" int dasr_probe_mfma_peak(int32_t iters, float* tflops_out, void* stre
     return 0;
 }
 
+// Neighbour-flag synchronisation probe (feasibility of a persistent per-RDB kernel): `blocks` co-resident workgroups, each
+// owns a tile of `tile_words` 32-bit words; per stage a workgroup rewrites its tile, publishes flag = stage, waits for its two ring
+// neighbours' flags and reads one word per thread of each neighbour's tile.
+//   nb_stride 8: the neighbours run on the same XCD (workgroup b is dispatched to XCD b % 8); 1: on other XCDs.
+//   scope 0: no synchronisation (cost floor: the stores and loads alone); 1: agent-scope release / acquire fences around the flag (L2 write-back
+//   and invalidate: what a kernel boundary does); 2: workgroup-scope fences (wait for the stores; the vector L1 is write-through) + agent-scope
+//   relaxed atomics for the flag AND the neighbour reads (sc1: served by the L2) -- coherent only when producer and consumer share an L2.
+// err[0] = a wait timed out, err[1] = number of stale neighbour reads.
+static __global__ __launch_bounds__(256) void tile_sync_kernel(int stages, int nb_stride, int scope, unsigned* flags, unsigned* tiles, int tile_words,
+                                                        unsigned* err) {
+    const int b = blockIdx.x, nb = gridDim.x;
+    const int left = (b + nb - nb_stride) % nb, right = (b + nb_stride) % nb;
+    unsigned* my = tiles + (size_t)b * tile_words;
+    const unsigned* lt = tiles + (size_t)left * tile_words + threadIdx.x % tile_words;
+    const unsigned* rt = tiles + (size_t)right * tile_words + threadIdx.x % tile_words;
+    unsigned bad = 0;
+    for (int s = 1; s <= stages; ++s) {
+        for (int i = threadIdx.x; i < tile_words; i += 256) my[i] = (unsigned)s;
+        if (scope == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        else if (scope == 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        unsigned l, r;
+        if (scope) {
+            if (threadIdx.x == 0) __hip_atomic_store(&flags[b], (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x < 2) {
+                const int n = threadIdx.x ? right : left;
+                int spins = 0;
+                while (__hip_atomic_load(&flags[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)s) {
+                    if (++spins > (1 << 21) || __hip_atomic_load(&err[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(&err[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __syncthreads();
+            if (scope == 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                l = *lt;
+                r = *rt;
+            } else {
+                l = __hip_atomic_load(lt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                r = __hip_atomic_load(rt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (l < (unsigned)s || r < (unsigned)s) ++bad;
+        } else {
+            l = *lt;
+            r = *rt;
+            if (l + r == 0xffffffffu) ++bad;   // keeps the loads
+        }
+    }
+    if (bad) atomicAdd(&err[1], bad);
+}
+
+extern "C" int dasr_probe_tile_sync(int32_t blocks, int32_t stages, int32_t nb_stride, int32_t scope, int32_t tile_words, float* us_per_stage,
+                                    int32_t* timed_out, int32_t* stale_reads, void* stream) {
+    if (blocks <= 0 || blocks > 2048 || stages <= 0 || nb_stride <= 0 || scope < 0 || scope > 2 || tile_words <= 0 || !us_per_stage) return DASR_EINVAL;
+    unsigned* buf = nullptr;
+    const size_t words = (size_t)blocks + (size_t)blocks * tile_words + 2;
+    HIP_TRY(hipMalloc(&buf, words * 4));
+    hipError_t e = hipMemsetAsync(buf, 0, words * 4, as_stream(stream));
+    unsigned *flags = buf, *tiles = buf + blocks, *err = buf + blocks + (size_t)blocks * tile_words;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    hipExtLaunchKernelGGL(tile_sync_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), e0, e1, 0, stages, nb_stride, scope, flags, tiles, tile_words, err);
+    if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));
+    float ms = 0.f;
+    unsigned res[2] = {0, 0};
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e == hipSuccess) e = hipMemcpy(res, err, 8, hipMemcpyDeviceToHost);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return (int)e;
+    *us_per_stage = ms * 1e3f / (float)stages;
+    if (timed_out) *timed_out = (int32_t)res[0];
+    if (stale_reads) *stale_reads = (int32_t)res[1];
+    return 0;
+}
+
 extern "C" int dasr_prof_begin(int32_t capacity) {
     if (capacity <= 0) return DASR_EINVAL;
     if (capacity > g_prof_cap) {

@@ -368,6 +368,13 @@ int dasr_prof_end(int32_t max_out, float* us_out, double* flops_out, double* byt
  * the clock its power state allows, in TFLOP/s; `iters` MFMA quads per wave (e.g. 20000 ~ 1.5 ms).  Synchronises the stream. */
 int dasr_probe_mfma_peak(int32_t iters, float* tflops_out, void* stream);
 
+/* Neighbour-flag synchronisation micro-benchmark (scripts/micro_sync.py): `blocks` co-resident workgroups rewrite a tile of
+ * `tile_words` words per stage, publish a flag, wait for two ring neighbours (`nb_stride` 8: same XCD, 1: other XCDs) and read their tiles.
+ * scope 0: no synchronisation (floor), 1: agent-scope release / acquire fences, 2: workgroup-scope fences + L2-served (sc1) flag and data
+ * accesses.  Returns microseconds per stage, whether a wait timed out, and the number of stale neighbour reads.  Synchronises the stream. */
+int dasr_probe_tile_sync(int32_t blocks, int32_t stages, int32_t nb_stride, int32_t scope, int32_t tile_words, float* us_per_stage,
+                         int32_t* timed_out, int32_t* stale_reads, void* stream);
+
 /* ---- diagnostics ----------------------------------------------------------------------------------*/
 int dasr_abi_version(void);
 /* 1 if ds_read_b64_tr_b16 has the lane mapping the wgrad kernel assumes on this device, 0 if not, <0 on error.
