@@ -388,6 +388,13 @@ def bench_srn(a, dp, dasr, as_secondary=False):
         peak_measured = pk.value if _lib.lib().dasr_probe_mfma_peak(20000, C.byref(pk), None) == 0 else None
         streams = len(getattr(model, '_out_plans', None) or [0])
         out['roofline'] = roofline_from_step(one_step, peak_measured, streams)
+        # the same MFMA-only stream on operands that toggle (random bf16 in (-1, 1)) and on all-zero operands: the spread is the clock the power
+        # management allows under that switching activity -- the ceiling an MFMA-bound kernel on real data can approach on this box
+        pr = {}
+        for mode, key in ((2, 'zeros'), (0, 'random_bf16')):
+            if _lib.lib().dasr_probe_mfma_data(19968, mode, C.byref(pk), None) == 0:
+                pr[key] = round(pk.value, 1)
+        out['roofline']['mfma_only_tflops_by_operand_data'] = pr
         log('roofline done')
     elif not as_secondary:
         one_step()  # the other ranks take part in the profiled step's collectives

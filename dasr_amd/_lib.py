@@ -110,6 +110,7 @@ _SIGS = {
     'dasr_lowpass_valid': [Tensor, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_vp],
     'dasr_run_ops': [c_vp, c_i32, c_vp],
     'dasr_last_failed_op': [],
+    'dasr_probe_mfma_data': [c_i32, c_i32, c_vp, c_vp],
     'dasr_probe_tile_sync': [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],
     'dasr_abi_version': [],
     'dasr_probe_tr16': [c_vp],

@@ -568,6 +568,72 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, float* sink) 
     if (t == 12345.678f) sink[0] = t;  // keeps the chain live
 }
 
+// The same instruction stream with operands that toggle: MODE 0 bf16 / 1 f16 fragments drawn from a per-lane LCG (values in (-1, 1), re-drawn
+// every 64 MFMA quads so that the loop stays issue-bound), 2 bf16 all-zero operands.  What differs between the modes is only the switching
+// activity in the MFMA datapath, i.e. the clock the power management allows.
+template <int MODE>
+static __global__ __launch_bounds__(256) void mfma_data_kernel(int iters, float* sink) {
+    unsigned st = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+    f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    for (int o = 0; o < iters; o += 64) {
+        float va[8], vb[8];
+        for (int j = 0; j < 8; ++j) {
+            st = st * 1664525u + 1013904223u;
+            va[j] = MODE == 2 ? 0.f : (float)(int)(st >> 8) * (1.f / 8388608.f) - 1.f;
+            st = st * 1664525u + 1013904223u;
+            vb[j] = MODE == 2 ? 0.f : (float)(int)(st >> 8) * (1.f / 8388608.f) - 1.f;
+        }
+        if (MODE == 1) {
+            f16x8 a, b;
+            for (int j = 0; j < 8; ++j) { a[j] = (_Float16)va[j]; b[j] = (_Float16)vb[j]; }
+            for (int i = 0; i < 64; ++i) {
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c2, 0, 0, 0);
+                c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c3, 0, 0, 0);
+            }
+        } else {
+            bf16x8 a, b;
+            for (int j = 0; j < 8; ++j) { a[j] = (bf16_t)va[j]; b[j] = (bf16_t)vb[j]; }
+            for (int i = 0; i < 64; ++i) {
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c2, 0, 0, 0);
+                c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c3, 0, 0, 0);
+            }
+        }
+    }
+    float t = 0.f;
+    for (int j = 0; j < 16; ++j) t += c0[j] + c1[j] + c2[j] + c3[j];
+    if (t == 12345.678f) sink[0] = t;
+}
+
+extern "C" int dasr_probe_mfma_data(int32_t iters, int32_t mode, float* tflops_out, void* stream) {
+    if (iters < 64 || mode < 0 || mode > 2 || !tflops_out) return DASR_EINVAL;
+    iters = iters / 64 * 64;
+    float* sink = nullptr;
+    HIP_TRY(hipMalloc(&sink, 16));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    const int blocks = 256 * 2;
+    for (int rep = 0; rep < 2; ++rep) {   // rep 0: warm-up (clock ramp), untimed
+        hipEvent_t a = rep ? e0 : nullptr, b = rep ? e1 : nullptr;
+        if (mode == 0) hipExtLaunchKernelGGL(mfma_data_kernel<0>, dim3(blocks), dim3(256), 0, as_stream(stream), a, b, 0, iters, sink);
+        else if (mode == 1) hipExtLaunchKernelGGL(mfma_data_kernel<1>, dim3(blocks), dim3(256), 0, as_stream(stream), a, b, 0, iters, sink);
+        else hipExtLaunchKernelGGL(mfma_data_kernel<2>, dim3(blocks), dim3(256), 0, as_stream(stream), a, b, 0, iters, sink);
+    }
+    hipError_t e = hipStreamSynchronize(as_stream(stream));
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    if (e != hipSuccess) return (int)e;
+    *tflops_out = (float)((double)blocks * 4.0 * (double)iters * 4.0 * 2.0 * 32 * 32 * 16 / ((double)ms * 1e-3) / 1e12);
+    return 0;
+}
+
 extern "C" int dasr_probe_mfma_peak(int32_t iters, float* tflops_out, void* stream) {
     if (iters <= 0 || !tflops_out) return DASR_EINVAL;
     float* sink = nullptr;

@@ -367,6 +367,9 @@ int dasr_prof_end(int32_t max_out, float* us_out, double* flops_out, double* byt
 /* MFMA-only micro-benchmark (every SIMD issuing back-to-back v_mfma_f32_32x32x16_bf16): the dense bf16 rate this box sustains at
  * the clock its power state allows, in TFLOP/s; `iters` MFMA quads per wave (e.g. 20000 ~ 1.5 ms).  Synchronises the stream. */
 int dasr_probe_mfma_peak(int32_t iters, float* tflops_out, void* stream);
+/* the same MFMA-only stream with operands that toggle: mode 0 bf16 / 1 f16 fragments from a per-lane random generator, 2 all-zero bf16
+ * operands; the differences are the clock the power management allows under that switching activity (scripts/micro_mfma.py) */
+int dasr_probe_mfma_data(int32_t iters, int32_t mode, float* tflops_out, void* stream);
 
 /* Neighbour-flag synchronisation micro-benchmark (scripts/micro_sync.py): `blocks` co-resident workgroups rewrite a tile of
  * `tile_words` words per stage, publish a flag, wait for two ring neighbours (`nb_stride` 8: same XCD, 1: other XCDs) and read their tiles.
