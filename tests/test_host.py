@@ -181,6 +181,16 @@ def test_dsn_default_init_replays_reference_rng_and_key_order(golden_dir):
         assert all(torch.equal(a[k], v) for k, v in G.state_dict().items())
         assert all(torch.equal(b[k], v) for k, v in D.state_dict().items())
     assert sum(v.numel() for v in a.values()) == 668238
+    # --norm_layer Batch: BatchNorm2d draws nothing from the RNG (weight 1, bias 0), the convs around it keep their draws
+    torch.manual_seed(0)
+    G, D = dsn.DeResnet(), dsn.Discriminator(5, 'Batch', 'gau')
+    torch.manual_seed(0)
+    d_spec, d_layers = fsd_spec(3, 5, norm='Batch')
+    M.default_init_state(M.deresnet_spec(8))
+    b = M.default_init_state(d_spec, bn_prefixes=[L['bn'] for L in d_layers if L['norm'] == 'batch'])
+    ref_sd = D.state_dict()
+    assert [k for k in ref_sd if 'running' not in k and 'num_batches' not in k] == [k for k, _ in d_spec]
+    assert all(torch.equal(b[k], ref_sd[k]) for k in b)
 
 
 def test_dsn_cli_flags_and_lr_rule():
