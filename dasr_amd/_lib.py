@@ -67,6 +67,7 @@ OP_CONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_DOWNSUM, OP_AXPBY, OP_FILL, OP_L
 OP_CVT_F16, OP_DOWNSUM_F16, OP_PIXSHUF, OP_PIXUNSHUF = 31, 32, 33, 34
 OP_LPIPS_S2D, OP_MAXPOOL3, OP_MAXPOOL3_BWD, OP_LPIPS_HEAD, OP_RAGAN = 35, 36, 37, 38, 39
 OP_BNORM_FWD, OP_BNORM_BWD, OP_BNORM_RUNNING = 40, 41, 42
+OP_DDM_SPREAD = 43
 
 _SIGS = {
     'dasr_conv': [C.POINTER(ConvParams), c_vp],
@@ -110,6 +111,7 @@ _SIGS = {
     'dasr_lowpass_valid': [Tensor, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_vp],
     'dasr_run_ops': [c_vp, c_i32, c_vp],
     'dasr_last_failed_op': [],
+    'dasr_ddm_spread': [Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, Tensor, c_vp],
     'dasr_probe_mfma_data': [c_i32, c_i32, c_vp, c_vp],
     'dasr_probe_tile_sync': [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],
     'dasr_abi_version': [],

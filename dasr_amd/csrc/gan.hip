@@ -1005,6 +1005,55 @@ extern "C" int dasr_bilinear_up(const float* src, int32_t N, int32_t h, int32_t 
     return (int)hipGetLastError();
 }
 
+// Domain-distance map for any discriminator conv table (codes/DSN/receptive_cal.py:34-60, create_dataset_modified.py:14-24): every D output
+// value (i, j) is added over its receptive-field window [lo(i), hi(i)) x [lo(j), hi(j)), lo(k) = int(max(0, start + k*jump - rf/2)),
+// hi(k) = int(start + k*jump + rf - rf/2), and the sum is divided by the number of windows covering the pixel (0/0 = NaN where none does, as in
+// the reference).  Gather form: one thread per map pixel sums the D values whose window contains it.  (jump, rf, start) come from the walk
+// over the WIDTH for both axes, as the reference has it.  FSD ([5,1,2] x 4) is the 17 x 17 count-normalised box of dasr_lowpass; this kernel
+// serves nld_s1 / nld_s2.
+__global__ void ddm_spread_kernel(dasr_tensor d, int N, int n_h, int n_w, int H, int W, int jump, int rf, float start, dasr_tensor out) {
+    const long long total = (long long)N * H * W;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int x = t % W, y = (t / W) % H, n = t / ((long long)W * H);
+    const int half = rf / 2;
+    auto range = [&](int p, int cnt, int& k0, int& k1) {   // candidate index range, then the exact window test
+        k0 = max(0, (int)floorf(((float)p - (float)(rf - half) - start) / (float)jump) - 1);
+        k1 = min(cnt - 1, (int)ceilf(((float)p + (float)half - start) / (float)jump) + 1);
+    };
+    auto covers = [&](int k, int p) {
+        const float c = start + (float)k * (float)jump;
+        return p >= (int)fmaxf(0.f, c - (float)half) && p < (int)(c + (float)(rf - half));
+    };
+    int i0, i1, j0, j1;
+    range(y, n_h, i0, i1);
+    range(x, n_w, j0, j1);
+    const float* dp = (const float*)d.p + (size_t)n * d.n_stride;
+    float sum = 0.f;
+    int ci = 0, cj = 0;
+    for (int j = j0; j <= j1; ++j) cj += covers(j, x) ? 1 : 0;
+    for (int i = i0; i <= i1; ++i) {
+        if (!covers(i, y)) continue;
+        ++ci;
+        for (int j = j0; j <= j1; ++j)
+            if (covers(j, x)) sum += dp[((size_t)i * n_w + j) * 16];
+    }
+    float* op = (float*)out.p + (size_t)n * out.n_stride + ((size_t)y * W + x) * 16;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    ((f32x4*)op)[0] = f32x4{sum / (float)(ci * cj), 0.f, 0.f, 0.f};
+    ((f32x4*)op)[1] = z;
+    ((f32x4*)op)[2] = z;
+    ((f32x4*)op)[3] = z;
+}
+
+extern "C" int dasr_ddm_spread(dasr_tensor d, int32_t N, int32_t n_h, int32_t n_w, int32_t H, int32_t W, int32_t jump, int32_t rf, float start,
+                               dasr_tensor out, void* stream) {
+    const long long total = (long long)N * H * W;
+    if (total <= 0 || n_h <= 0 || n_w <= 0 || jump <= 0 || rf <= 0 || !d.p || !out.p) return DASR_EINVAL;
+    DASR_LAUNCH(ddm_spread_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), d, N, n_h, n_w, H, W, jump, rf, start, out);
+    return (int)hipGetLastError();
+}
+
 extern "C" int dasr_logloss(dasr_tensor x, int32_t N, int32_t H, int32_t W, int32_t mode, float eps, float coef, float gcoef, float* loss_acc,
                             float* score_acc, float score_coef, dasr_tensor grad, int32_t accumulate, void* stream) {
     const long long total = (long long)N * H * W;

@@ -844,6 +844,7 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream0) {
             case DASR_OP_BNORM_RUNNING:
                 rc = dasr_bnorm_running((const float*)o.p[0], o.i[0], o.i[1], o.i[2], o.f[0], (float*)o.p[1], (float*)o.p[2], (float*)o.p[3], stream);
                 break;
+            case DASR_OP_DDM_SPREAD: rc = dasr_ddm_spread(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.i[6], o.f[0], o.t[1], stream); break;
             case DASR_OP_RAGAN:
                 rc = dasr_ragan(o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.f[0], o.f[1], o.f[2], o.f[3], *(const float*)&o.l[2],
                                 (float*)o.p[0], (float*)o.p[1], (float*)o.p[2], (float*)o.p[3], (float*)o.l[0], *(const float*)&o.l[1], o.t[2], o.t[3],

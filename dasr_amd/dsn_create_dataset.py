@@ -73,11 +73,11 @@ def _images(o, which):
 
 def main(argv=None):
     o = build_parser().parse_args(argv)
-    if o.generator != 'DeResnet':
+    if o.generator not in ('DeResnet', 'DSGAN'):
         raise NotImplementedError('Generator model [{:s}] not recognized'.format(o.generator))
-    if o.discriminator != 'FSD':
+    if o.discriminator not in ('FSD', 'nld_s1', 'nld_s2'):
         raise NotImplementedError('Please specified conv_net of discriminator.')
-    if o.wgan or not o.highpass or o.cat_or_sum != 'cat' or o.norm_layer not in ('Instance', 'Batch'):
+    if o.wgan or not o.highpass or o.cat_or_sum != 'cat' or o.norm_layer not in ('Instance', 'Batch') or (o.norm_layer == 'Batch' and o.discriminator != 'FSD'):
         raise NotImplementedError('DSN on MI355X covers the default path: DCGAN loss, high-pass front end, wavelet bands cat, Instance norm')
     if o.checkpoint is None:
         print('Use --checkpoint to define the model parameters used')
@@ -86,7 +86,8 @@ def main(argv=None):
     dirs = {k: os.path.join(out, k) for k in ('imgs_from_target', 'ddm_target', 'ddm_source')}
     for d in dirs.values():
         os.makedirs(d, exist_ok=True)
-    m = DSNModel(dict(n_res_blocks=o.num_res_blocks, kernel_size=o.kernel_size, filter=o.filter, norm_layer=o.norm_layer, w_per=0.0))
+    m = DSNModel(dict(n_res_blocks=o.num_res_blocks, kernel_size=o.kernel_size, filter=o.filter, norm_layer=o.norm_layer, w_per=0.0,
+                      discriminator=o.discriminator, generator=o.generator))
     m.load(o.checkpoint)
     print('Using model at epoch %d' % m.epoch)
     shutil.copyfile(o.checkpoint, os.path.join(out, o.name + '.tar'))

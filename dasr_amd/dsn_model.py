@@ -142,7 +142,7 @@ class DeResnetHIP:
 
 class _GPlan:
     def __init__(self, net, N, H, W):
-        assert H % 4 == 0 and W % 4 == 0
+        assert net.scale == 1 or (H % 4 == 0 and W % 4 == 0)
         self.net, self.N = net, N
         dev, P, pack, pk, nb = net.device, net.params, net.pack, net.pk, net.nb
         down = net.scale == 4
@@ -628,21 +628,35 @@ class _DSNPlan:
 
 
 DDM_RF = 17  # receptive field of the reference's conv table [[5,1,2]] * 4 for FSD (create_dataset_modified.py:120-121)
+# conv tables [kernel, stride, padding] the reference walks for the domain-distance map (create_dataset_modified.py:112-121)
+DDM_CONVNETS = {'fsd': [[5, 1, 2]] * 4, 'nld_s1': [[4, 1, 1]] * 4, 'nld_s2': [[4, 2, 1], [4, 2, 1], [4, 1, 1], [4, 1, 1]]}
+
+
+def receptive_walk(imsize, convnet):
+    """(number of features, jump, receptive field, centre of the first feature) after the conv table (receptive_cal.py:10-25,45-52)"""
+    import math
+    n, j, r, start = imsize, 1, 1, 0.5
+    for k, s_, p in convnet:
+        n_out = math.floor((n - k + 2 * p) / s_) + 1
+        pad_l = math.floor(((n_out - 1) * s_ - n + k) / 2)
+        j, r, start, n = j * s_, r + (k - 1) * j, start + ((k - 1) / 2 - pad_l) * j, n_out
+    return n, j, r, start
 
 
 class _InferPlan:
     """with_g: (H, W) is the HR input of the generator and the discriminator sees G's output; else (H, W) is an LR image fed to D"""
 
     def __init__(self, m, N, H, W, with_g=True):
-        if m.d_arch != 'fsd' or (with_g and m.netG.scale != 4):
-            raise NotImplementedError('dataset generation (create_dataset_modified.py:108-164) is built for De_resnet + the FSD discriminator only')
         dev = m.device
-        h, w = (H // 4, W // 4) if with_g else (H, W)
+        # De_resnet maps the image to 1/4 size; the DSGAN Generator keeps the size (create_dataset_modified.py:99-103 applies either to the image as is)
+        h, w = (H // 4, W // 4) if (with_g and m.netG.scale == 4) else (H, W)
         wav = m.filter == 'wavelet'
+        assert not wav or (h % 2 == 0 and w % 2 == 0), 'wavelet front end: even image size (ddm_of crops; translate expects it)'
         hd, wd = (h // 2, w // 2) if wav else (h, w)
         self.d = m.inference_discriminator().plan(N, hd, wd)
         d = self.d
-        self.dout, self.ddm = BTensor(N, 16, hd, wd, True, dev), BTensor(N, 16, hd, wd, True, dev)
+        nh, nw = d.logits.H, d.logits.W          # FSD keeps the map size; the nld discriminators shrink it
+        self.dout, self.ddm = BTensor(N, 16, nh, nw, True, dev), BTensor(N, 16, hd, wd, True, dev)
         self.box = torch.full((DDM_RF * DDM_RF,), 1.0 / (DDM_RF * DDM_RF), dtype=torch.float32, device=dev)
         ops = OpList()
         if with_g:
@@ -667,11 +681,19 @@ class _InferPlan:
         ops.add(o)
         ops.extend(d.fwd)
         o = _op(_lib.OP_SIGMOID_FWD)
-        o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1] = d.logits.view(), N, 1, hd, wd, self.dout.view()
+        o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1] = d.logits.view(), N, 1, nh, nw, self.dout.view()
         ops.add(o)
-        o = _op(_lib.OP_LOWPASS)   # count-normalised box average = spread over the receptive field / coverage count
-        o.t[0], o.t[1], o.p[0], o.i[4] = self.dout.view(), NULL_T, self.box.data_ptr(), DDM_RF
-        o.i[0], o.i[1], o.i[2], o.i[3], o.i[5], o.i[6] = N, 1, hd, wd, 0 | 2, 0
-        o.f[0], o.f[1], o.t[2], o.t[3] = 0.0, 0.0, self.ddm.view(), NULL_T
+        if m.d_arch == 'fsd':
+            o = _op(_lib.OP_LOWPASS)   # count-normalised box average = spread over the receptive field / coverage count
+            o.t[0], o.t[1], o.p[0], o.i[4] = self.dout.view(), NULL_T, self.box.data_ptr(), DDM_RF
+            o.i[0], o.i[1], o.i[2], o.i[3], o.i[5], o.i[6] = N, 1, hd, wd, 0 | 2, 0
+            o.f[0], o.f[1], o.t[2], o.t[3] = 0.0, 0.0, self.ddm.view(), NULL_T
+        else:                          # general receptive-field spread (jump / rf / start of the WIDTH walk for both axes, as the reference does)
+            n_h = receptive_walk(hd, DDM_CONVNETS[m.d_arch])[0]
+            n_w, jump, rf, start = receptive_walk(wd, DDM_CONVNETS[m.d_arch])
+            assert (n_h, n_w) == (nh, nw), ((n_h, n_w), (nh, nw))
+            o = _op(_lib.OP_DDM_SPREAD)
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.i[6] = self.dout.view(), N, nh, nw, hd, wd, jump, rf
+            o.f[0], o.t[1] = float(start), self.ddm.view()
         ops.add(o)
         self.ops = ops

@@ -286,6 +286,11 @@ int dasr_lpips_head(dasr_tensor f, int64_t pair_off, int32_t N, int32_t C, int32
                     float gcoef, float* loss_acc, dasr_tensor g0, int32_t relu_mask, void* stream);
 
 /* ---- DSN (codes/DSN) kernels ---------------------------------------------------------------------------------*/
+/* domain-distance map for any discriminator conv table (receptive_cal.py:34-60, create_dataset_modified.py:14-24,119-126): D output value
+ * (i, j) spread over its receptive-field window (jump / rf / start of the walk over the conv table), divided by the coverage count; d =
+ * [N][1][n_h][n_w] D output, out = [N][1][H][W] map (channel 0 of 16-channel fp32 planes).  FSD uses the equivalent 17 x 17 box of dasr_lowpass. */
+int dasr_ddm_spread(dasr_tensor d, int32_t N, int32_t n_h, int32_t n_w, int32_t H, int32_t W, int32_t jump, int32_t rf, float start,
+                    dasr_tensor out, void* stream);
 /* -log losses of codes/DSN/loss.py:11-41 on p = sigmoid(logit) (model.py:104-105): mode 0: -log(p+eps), mode 1:
  * -log(1-p+eps); loss_acc += coef*sum, score_acc += score_coef*sum(p), grad (+)= gcoef * d/dlogit */
 int dasr_logloss(dasr_tensor x, int32_t N, int32_t H, int32_t W, int32_t mode, float eps, float coef, float gcoef, float* loss_acc,
@@ -329,7 +334,7 @@ enum { DASR_OP_CONV = 1, DASR_OP_WGRAD = 2, DASR_OP_WGRAD_REDUCE = 3, DASR_OP_PA
        DASR_OP_EVENT_RECORD = 28, DASR_OP_STREAM_WAIT = 29, DASR_OP_SET_STREAM = 30,
        DASR_OP_CVT_F16 = 31, DASR_OP_DOWNSUM_F16 = 32, DASR_OP_PIXSHUF = 33, DASR_OP_PIXUNSHUF = 34,
        DASR_OP_LPIPS_S2D = 35, DASR_OP_MAXPOOL3 = 36, DASR_OP_MAXPOOL3_BWD = 37, DASR_OP_LPIPS_HEAD = 38, DASR_OP_RAGAN = 39,
-       DASR_OP_BNORM_FWD = 40, DASR_OP_BNORM_BWD = 41, DASR_OP_BNORM_RUNNING = 42 };
+       DASR_OP_BNORM_FWD = 40, DASR_OP_BNORM_BWD = 41, DASR_OP_BNORM_RUNNING = 42, DASR_OP_DDM_SPREAD = 43 };
 
 typedef struct {
     int32_t op;  int32_t i[8];  float f[4];  int64_t l[4];  void* p[4];  dasr_tensor t[5];

@@ -45,8 +45,8 @@ def domain_distance_map(d_out, img_shape, fs_type='gau', arch='FSD'):
     return spread(d_out, shape, lh, lw) / spread(np.ones_like(d_out), shape, lh, lw)
 
 
-def translate(G, D, img, fs_type):
+def translate(G, D, img, fs_type, arch='FSD'):
     with torch.no_grad():
         fake = G(img)
         d_out = D(fake).numpy()
-    return fake, d_out, domain_distance_map(d_out, fake.shape, fs_type)
+    return fake, d_out, domain_distance_map(d_out, fake.shape, fs_type, arch)

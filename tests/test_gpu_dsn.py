@@ -306,25 +306,33 @@ def test_dsn_checkpoint_roundtrip(tmp_path):
         assert torch.equal(v, m2.netD.state_dict()[k]), k
 
 
-@pytest.mark.parametrize('filt', ['gau', 'wavelet', 'avg_pool'])
-def test_dsn_translate_and_domain_distance_map(filt):
+@pytest.mark.parametrize('filt,arch,gen', [('gau', 'FSD', 'DeResnet'), ('wavelet', 'FSD', 'DeResnet'), ('avg_pool', 'FSD', 'DeResnet'),
+                                           ('gau', 'nld_s1', 'DeResnet'), ('wavelet', 'nld_s2', 'DeResnet'), ('avg_pool', 'nld_s2', 'DSGAN'),
+                                           ('gau', 'FSD', 'DSGAN')])
+def test_dsn_translate_and_domain_distance_map(filt, arch, gen):
     """dataset-generation inference: fake LR, discriminator map and ddm against the oracle nets + the restated
     receptive-field spreading"""
     dev = _gpu()
     from dasr_amd.dsn_model import DSNModel
     from oracle import dsn, dsn_dataset
     from oracle.gen_golden_dsn import dsn_state
-    G, D = dsn.DeResnet(), dsn.Discriminator(5, 'Instance', filt)
+    G = dsn.GeneratorDSGAN() if gen == 'DSGAN' else dsn.DeResnet()
+    D = dsn.Discriminator(5, 'Instance', filt, D_arch=arch)
     sdG, sdD = dsn_state(G.state_dict(), 21, 0.5), dsn_state(D.state_dict(), 22, 1.0)
     G.load_state_dict(sdG)
     D.load_state_dict(sdD)
-    m = DSNModel(dict(filter=filt, w_per=0.0), device=dev)
+    m = DSNModel(dict(filter=filt, w_per=0.0, discriminator=arch, generator=gen), device=dev)
     m.netG.load_state_dict(sdG)
     m.netD.load_state_dict(sdD)
     g = torch.Generator().manual_seed(31)
-    img = torch.rand(1, 3, 104, 88, generator=g)
+    if gen == 'DSGAN':
+        img = torch.rand(1, 3, 46, 38, generator=g)     # the DSGAN Generator keeps the size
+    elif arch == 'nld_s2':
+        img = torch.rand(1, 3, 232, 200, generator=g)   # two stride-2 convs behind the wavelet front end: 29 x 25 -> 5 x 4 outputs
+    else:
+        img = torch.rand(1, 3, 104, 88, generator=g)
     fake, d_out, ddm = m.translate(img.to(dev))
-    rf, rd, rddm = dsn_dataset.translate(G, D, img, filt)
+    rf, rd, rddm = dsn_dataset.translate(G, D, img, filt, arch)
     assert rel(fake.cpu(), rf) < ACT_TOL
     assert tuple(d_out.shape) == tuple(rd.shape)
     assert rel(d_out.cpu(), torch.from_numpy(rd)) < ACT_TOL
@@ -336,7 +344,7 @@ def test_dsn_translate_and_domain_distance_map(filt):
     with torch.no_grad():
         rd2 = D(lr_c).numpy()
     assert rel(d2.cpu(), torch.from_numpy(rd2)) < ACT_TOL
-    assert rel(ddm2.cpu().double(), torch.from_numpy(dsn_dataset.domain_distance_map(rd2, lr_c.shape, filt))) < ACT_TOL
+    assert rel(ddm2.cpu().double(), torch.from_numpy(dsn_dataset.domain_distance_map(rd2, lr_c.shape, filt, arch))) < ACT_TOL
 
 
 def test_dsn_dataset_cli_end_to_end(tmp_path):
