@@ -16,12 +16,16 @@ def main():
     import receptive_cal as rc
     out = {}
     rs = np.random.RandomState(3)
-    convnet = [[5, 1, 2]] * 4
-    for name, (h, w), fs in (('gau_23x31', (23, 31), 'gau'), ('wav_40x36', (40, 36), 'wavelet'), ('avg_12x9', (12, 9), 'avg_pool')):
+    # conv tables of create_dataset_modified.py:112-121; the FSD cases come first (and draw first from the generator), as in round 1
+    tables = {'FSD': [[5, 1, 2]] * 4, 'nld_s1': [[4, 1, 1]] * 4, 'nld_s2': [[4, 2, 1], [4, 2, 1], [4, 1, 1], [4, 1, 1]]}
+    for name, (h, w), fs, arch in (('gau_23x31', (23, 31), 'gau', 'FSD'), ('wav_40x36', (40, 36), 'wavelet', 'FSD'), ('avg_12x9', (12, 9), 'avg_pool', 'FSD'),
+                                   ('nld_s1_gau_26x22', (26, 22), 'gau', 'nld_s1'), ('nld_s2_avg_52x44', (52, 44), 'avg_pool', 'nld_s2'),
+                                   ('nld_s2_wav_54x68', (54, 68), 'wavelet', 'nld_s2'), ('nld_s1_wav_31x24', (31, 24), 'wavelet', 'nld_s1')):
+        convnet = tables[arch]
         hh, ww = (h // 2, w // 2) if fs == 'wavelet' else (h, w)
-        d_out = rs.rand(1, 1, hh, ww)  # the reference broadcasts patch[:, :, i, j] against a window: batch 1 only
         ddm = torch.zeros((1, 1, hh, ww))
         lh, lw = rc.receptive_cal(ddm.shape[2], convnet), rc.receptive_cal(ddm.shape[3], convnet)
+        d_out = rs.rand(1, 1, lh[0], lw[0])  # the discriminator map (FSD: the size of the image); batch 1: the reference broadcasts patch[:, :, i, j] against a window
         out[name + '_dout'] = d_out
         out[name + '_ddm'] = np.asarray(rc.getWeights(d_out, ddm, lh, lw))
         out[name + '_layers'] = np.array([lh, lw], dtype=np.float64)

@@ -23,6 +23,25 @@ def test_ddm_matches_reference(name, fs, hw, golden_dir):
     np.testing.assert_allclose(box, gold[name + '_ddm'], rtol=1e-10, atol=1e-12)
 
 
+@pytest.mark.parametrize('name,fs,hw,arch', [('nld_s1_gau_26x22', 'gau', (26, 22), 'nld_s1'), ('nld_s2_avg_52x44', 'avg_pool', (52, 44), 'nld_s2'),
+                                             ('nld_s2_wav_54x68', 'wavelet', (54, 68), 'nld_s2'), ('nld_s1_wav_31x24', 'wavelet', (31, 24), 'nld_s1')])
+def test_ddm_other_conv_tables_match_reference(name, fs, hw, arch, golden_dir):
+    """the nld_s1 / nld_s2 conv tables (create_dataset_modified.py:112-121): the discriminator map is smaller than the image; the restated spread
+    and the product's receptive-field walk (dasr_amd.dsn_model.receptive_walk, what parameterises dasr_ddm_spread) against the reference's
+    receptive_cal.py"""
+    from oracle import dsn_dataset as dd
+    from dasr_amd.dsn_model import receptive_walk, DDM_CONVNETS
+    gold = np.load(os.path.join(golden_dir, 'dsn_ddm.npz'))
+    d_out = gold[name + '_dout']
+    got = dd.domain_distance_map(d_out, (1, 3) + hw, fs, arch)
+    assert got.shape == gold[name + '_ddm'].shape and not np.isnan(gold[name + '_ddm']).any()
+    np.testing.assert_allclose(got, gold[name + '_ddm'], rtol=1e-12, atol=0)
+    h, w = gold[name + '_ddm'].shape[2:]
+    for n_px, row in ((h, 0), (w, 1)):
+        np.testing.assert_allclose(np.array(dd.receptive(n_px, dd.CONVNETS[arch]), dtype=np.float64), gold[name + '_layers'][row])
+        np.testing.assert_allclose(np.array(receptive_walk(n_px, DDM_CONVNETS[arch.lower()]), dtype=np.float64), gold[name + '_layers'][row])
+
+
 def test_cli_flags_and_unsupported_choices():
     from dasr_amd import dsn_create_dataset as cd
     o = cd.build_parser().parse_args([])
