@@ -217,3 +217,33 @@ def test_dsn_cli_flags_and_lr_rule():
         assert abs(m.lr() - opt.param_groups[0]['lr']) < 1e-12
         opt.step()
         sch.step()
+
+
+def test_fold_batchnorm_fsd_equals_eval_mode_network(golden_dir):
+    """gan_nets.fold_batchnorm_fsd (what DSNModel.translate / ddm_of run for a BatchNorm discriminator): the conv-only network with the folded
+    weights equals the FSD-Batch network in eval() mode -- on the reference's own test.tar weights and on random statistics"""
+    import torch.nn as nn
+    from dasr_amd.gan_nets import fold_batchnorm_fsd
+    from oracle import dsn
+    fx = np.load(os.path.join(golden_dir, 'dsn_fsd_batch_test_tar.npz'))
+    sd_tar = {k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith('w/')}
+    g = torch.Generator().manual_seed(3)
+    D = dsn.Discriminator(5, 'Batch', 'gau')
+    sd_rand = {k: v.clone() for k, v in D.state_dict().items()}
+    for k in sd_rand:
+        if k.endswith('running_mean'):
+            sd_rand[k] = torch.randn(sd_rand[k].shape, generator=g) * 0.3
+        elif k.endswith('running_var'):
+            sd_rand[k] = torch.rand(sd_rand[k].shape, generator=g) + 0.2
+        elif k.startswith(('net.net.3.', 'net.net.6.')) and k.endswith(('weight', 'bias')):
+            sd_rand[k] = torch.randn(sd_rand[k].shape, generator=g) * 0.5 + (1.0 if k.endswith('weight') else 0.0)
+    x = torch.rand(2, 3, 40, 36, generator=g)
+    for sd in (sd_tar, sd_rand):
+        D.load_state_dict(sd, strict=False)
+        D.eval()
+        plain = dsn.Discriminator(5, 'Instance', 'gau')
+        plain.net.net[3], plain.net.net[6] = nn.Identity(), nn.Identity()
+        plain.load_state_dict(fold_batchnorm_fsd({k: v for k, v in D.state_dict().items()}), strict=False)
+        with torch.no_grad():
+            want, got = D(x), plain(x)
+        assert float((got - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))
