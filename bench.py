@@ -43,7 +43,7 @@ PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak at 2.4 GHz (MI355X_
 
 def make_dasr_opt(nf, nb, fs, fea='l1'):
     o = make_opt(nf, nb)
-    o.update(model='DASR', multiweights=True)
+    o.update(model='DASR', multiweights=True, allow_random_perceptual=True)   # synthetic bench: seeded VGG19 / AlexNet (says so in `data`)
     o['path'].update(pretrain_model_D_target=None, pretrain_model_D_source=None)
     o['network_D'] = {'which_model_D': 'discriminator_patch', 'norm_type': 'Batch', 'act_type': 'leakyrelu', 'mode': 'CNA', 'nf': 64,
                       'in_nc': 9 if fs == 'wavelet' else 3, 'n_layers': 2}
@@ -299,7 +299,7 @@ def bench_dsn(a, dp, as_secondary=False):
     world = dp.world if dp else 1
     rank = dp.rank if dp else 0
     torch.manual_seed(0)
-    m = DSNModel(dict(filter=a.fs, w_per=0.01, per_type=a.per_type))
+    m = DSNModel(dict(filter=a.fs, w_per=0.01, per_type=a.per_type, allow_random_perceptual=True))   # synthetic bench: seeded perceptual net (says so in `data`)
     if dp:
         m.dp = dp
         for net in m.networks():
@@ -385,14 +385,15 @@ def bench_srn(a, dp, dasr, as_secondary=False):
     if rank == 0 and not as_secondary:
         import ctypes as C
         pk = C.c_float(0.0)
-        peak_measured = pk.value if _lib.lib().dasr_probe_mfma_peak(20000, C.byref(pk), None) == 0 else None
+        BL = _lib.bench_lib()   # probes live in libdasr_bench.so, not in the product library
+        peak_measured = pk.value if BL.dasr_probe_mfma_peak(20000, C.byref(pk), None) == 0 else None
         streams = len(getattr(model, '_out_plans', None) or [0])
         out['roofline'] = roofline_from_step(one_step, peak_measured, streams)
         # the same MFMA-only stream on operands that toggle (random bf16 in (-1, 1)) and on all-zero operands: the spread is the clock the power
         # management allows under that switching activity -- the ceiling an MFMA-bound kernel on real data can approach on this box
         pr = {}
         for mode, key in ((2, 'zeros'), (0, 'random_bf16')):
-            if _lib.lib().dasr_probe_mfma_data(19968, mode, C.byref(pk), None) == 0:
+            if BL.dasr_probe_mfma_data(19968, mode, C.byref(pk), None) == 0:
                 pr[key] = round(pk.value, 1)
         out['roofline']['mfma_only_tflops_by_operand_data'] = pr
         log('roofline done')

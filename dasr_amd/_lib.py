@@ -86,7 +86,7 @@ _SIGS = {
     'dasr_downsum2x_f16': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_f32, c_f32, Tensor, Tensor, c_vp],
     'dasr_downsum2x': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_f32, Tensor, Tensor, c_vp],
     'dasr_axpby': [Tensor, c_f32, Tensor, c_f32, c_i32, c_i32, c_i32, c_i32, Tensor, Tensor, c_f32, Tensor, c_f32, c_vp, c_vp],
-    'dasr_adam': [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp],
+    'dasr_adam': [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp, c_vp],
     'dasr_fill_f32': [c_vp, c_i64, c_f32, c_vp],
     'dasr_add_flat': [c_vp, c_vp, c_i64, c_vp],
     'dasr_inorm_lrelu_fwd': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, Tensor, c_vp, c_vp],
@@ -112,11 +112,8 @@ _SIGS = {
     'dasr_run_ops': [c_vp, c_i32, c_vp],
     'dasr_last_failed_op': [],
     'dasr_ddm_spread': [Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, Tensor, c_vp],
-    'dasr_probe_mfma_data': [c_i32, c_i32, c_vp, c_vp],
-    'dasr_probe_tile_sync': [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],
     'dasr_abi_version': [],
     'dasr_probe_tr16': [c_vp],
-    'dasr_probe_mfma_peak': [c_i32, c_vp, c_vp],
     'dasr_rccl_unique_id': [c_vp],
     'dasr_rccl_init': [c_vp, c_i32, c_i32, c_vp],
     'dasr_allreduce': [c_vp, c_vp, c_i64, c_vp],
@@ -134,8 +131,33 @@ _SIGS = {
     'dasr_prof_end': [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
 }
 
-ABI_VERSION = 8
+# micro-benchmark probes: libdasr_bench.so (include/dasr_hip_bench.h), never part of the product library
+_BENCH_SIGS = {
+    'dasr_probe_mfma_data': [c_i32, c_i32, c_vp, c_vp],
+    'dasr_probe_tile_sync': [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],
+    'dasr_probe_mfma_peak': [c_i32, c_vp, c_vp],
+}
+BENCH_LIB_PATH = os.path.join(HERE, 'libdasr_bench.so')
+
+ABI_VERSION = 9
 _lib = None
+_bench = None
+
+
+def bench_lib():
+    """the probe library (bench.py, scripts/micro_*.py); raises when it has not been built (`python -m dasr_amd.build --bench`)"""
+    global _bench
+    if _bench is None:
+        if not os.path.exists(BENCH_LIB_PATH):
+            raise DasrHipError('libdasr_bench.so is missing (%s): run `python -m dasr_amd.build --bench`' % BENCH_LIB_PATH)
+        import torch  # noqa: F401  (same HIP runtime as torch, see lib())
+        L = C.CDLL(BENCH_LIB_PATH)
+        for name, args in _BENCH_SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = c_i32
+        _bench = L
+    return _bench
 
 
 class DasrHipError(RuntimeError):

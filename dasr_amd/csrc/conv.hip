@@ -786,7 +786,7 @@ __device__ __forceinline__ void glds_dma_piece(int i, int ck, char* buf, __amdgp
     }
 }
 
-// ABL (micro-benchmarks only, results are wrong): bit 0 no DMA inside the main loop, bit 1 no fragment reads inside the main loop
+// ABL (micro-benchmarks only, results are wrong; instantiated with ABL != 0 only under -DDASR_BENCH = libdasr_hip_ablate.so): bit 0 no DMA inside the main loop, bit 1 no fragment reads inside the main loop
 // (stale registers), bit 2 no vmcnt wait / barrier per chunk, bit 3 no MFMAs: what each component costs per chunk (guide: ablate, don't guess)
 // F16: the 16-bit activations and packed weights are f16 (HR tail of the generator in f16 storage): v_mfma_f32_32x32x16_f16.
 // p.ups: nearest x2 up-sampling folded into the DMA source addresses (upconv_blcok, block.py:854-861): each lane fetches the 16 bytes of
@@ -1265,6 +1265,7 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                 case 9: return launch<1, false, 1, 3, 1, 4, 1, true, 1>(p, s);
                 case 10: return launch<1, false, 1, 3, 1, 4, 1, true, 2>(p, s);  // pipelined: prefetch distance 2, ds_write inside the MFMA stream
                 case 11: return launch<1, false, 1, 3, 1, 2, 1, true, 2>(p, s);
+#ifdef DASR_BENCH   // libdasr_hip_ablate.so only (python -m dasr_amd.build --ablate): the product library has no wrong-result instantiations
                 case 100: return launch_glds<1, 67, 4, 0>(p, s);   // ablation series (scripts/micro_conv.py --mode fwd): wrong results, timing only
                 case 101: return launch_glds<1, 67, 4, 1>(p, s);
                 case 102: return launch_glds<1, 67, 4, 2>(p, s);
@@ -1274,6 +1275,7 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                 case 108: return launch_glds<1, 67, 4, 8>(p, s);
                 case 112: return launch_glds<1, 67, 4, 12>(p, s);
                 case 115: return launch_glds<1, 67, 4, 15>(p, s);
+#endif
                 case 12:
                     switch (g_tune_epi ? classify_epi(p) : 0) {
                         case 67: return launch_glds<1, 67>(p, s);

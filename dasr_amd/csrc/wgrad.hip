@@ -294,6 +294,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __
 // one): the dense-block wgrad is bound by L2/HBM traffic, not by MFMA issue.
 // workspace per part: [split][tap][ot 3][oc 32][cin 64]; bias: [split][96]
 // ---------------------------------------------------------------------------------------------------------------
+// workgroup -> (part, pixel split).  nsplit_flags: bits 0-15 nsplit, bits 16-23 ppu, bit 24 staggered prefetch (wgrad3_kernel).
+// ppu = 0: block = part * nsplit + split; with nsplit a multiple of 8 every part's workgroup of one pixel split runs on XCD split % 8
+// (workgroup b -> XCD b % 8) and the G / X tiles the parts share are fetched into ONE L2.
+// ppu > 0 (grouped launches of many RDBs with few splits, nsplit not a multiple of 8): the parts come in units of ppu consecutive parts that
+// read the same slab pair (one RDB); unit u = (rdb, split) is placed on XCD u % 8 as a whole: block b -> xcd = b % 8, slot = b / 8,
+// unit = (slot / ppu) * 8 + xcd, part = rdb * ppu + slot % ppu.  The host only sets ppu when (nparts / ppu) * nsplit is a multiple of 8.
+__device__ __forceinline__ void w3_block_map(int nsplit_flags, int& part_id, int& split) {
+    const int nsplit = nsplit_flags & 0xffff, ppu = (nsplit_flags >> 16) & 0xff;
+    const int b = blockIdx.x;
+    if (ppu == 0) {
+        part_id = b / nsplit;
+        split = b - part_id * nsplit;
+    } else {
+        const int xcd = b & 7, slot = b >> 3;
+        const int su = slot / ppu, pin = slot - su * ppu;
+        const int unit = su * 8 + xcd;
+        const int rdb = unit / nsplit;
+        split = unit - rdb * nsplit;
+        part_id = rdb * ppu + pin;
+    }
+}
+
 struct W3 {
     static constexpr int NTAPS = 9, PH = 8, PW = 16, IH = 10, IW = 18;
     static constexpr int GPIX = PH * PW, IPIX = IH * IW;
@@ -317,13 +339,14 @@ __global__ __launch_bounds__(768, 1) void wgrad3_kernel(const dasr_wgrad_part* _
                                                         float* __restrict__ ws) {
     static_assert(!F16 || !F32, "wgrad3 F16: 16-bit f16 tensors");
     using C = W3;
-    const int nsplit = nsplit_flags & 0xffffff;
+    const int nsplit = nsplit_flags & 0xffff;
     const bool g_stagger_flag = (nsplit_flags >> 24) & 1;  // A/B: staggered in-compute prefetch issue
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* gl = smem;
     char* il = smem + C::G_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int part_id = blockIdx.x / nsplit, split = blockIdx.x - part_id * nsplit;
+    int part_id, split;
+    w3_block_map(nsplit_flags, part_id, split);
     const dasr_wgrad_part P = parts[part_id];
     const int pair = wave % 6, th = wave / 6;
     const int ot = pair >> 1, ct = pair & 1;
@@ -645,11 +668,13 @@ __device__ __forceinline__ void w3g_dma(const dasr_wgrad_part& P, const W3GTile&
     }
 }
 
-__global__ __launch_bounds__(768, 1) void wgrad3_glds_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit, float* __restrict__ ws) {
+__global__ __launch_bounds__(768, 1) void wgrad3_glds_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit_flags, float* __restrict__ ws) {
     using C = W3G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int part_id = blockIdx.x / nsplit, split = blockIdx.x - part_id * nsplit;
+    const int nsplit = nsplit_flags & 0xffff;
+    int part_id, split;
+    w3_block_map(nsplit_flags, part_id, split);
     const dasr_wgrad_part P = parts[part_id];
     const int pair = wave % 6, th = wave / 6;
     const int ot = pair >> 1, ct = pair & 1;
@@ -866,7 +891,7 @@ int launch_wgrad3(const dasr_wgrad_part* parts, int nparts, int nsplit, float* w
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, W3::LDS_BYTES + 16));
         attr_set = true;
     }
-    DASR_LAUNCH_TAG(__PRETTY_FUNCTION__, kfn, dim3(nparts * nsplit), dim3(W3::NT), W3::LDS_BYTES + 16, s, parts, nparts, nsplit | (g_wgrad3_stagger << 24), ws);
+    DASR_LAUNCH_TAG(__PRETTY_FUNCTION__, kfn, dim3(nparts * (nsplit & 0xffff)), dim3(W3::NT), W3::LDS_BYTES + 16, s, parts, nparts, nsplit | (g_wgrad3_stagger << 24), ws);
     return (int)hipGetLastError();
 }
 
@@ -876,7 +901,7 @@ int launch_wgrad3_glds(const dasr_wgrad_part* parts, int nparts, int nsplit, flo
         HIP_TRY(hipFuncSetAttribute((const void*)wgrad3_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W3G::LDS_BYTES));
         attr_set = true;
     }
-    DASR_LAUNCH(wgrad3_glds_kernel, dim3(nparts * nsplit), dim3(W3G::NT), W3G::LDS_BYTES, s, parts, nparts, nsplit, ws);
+    DASR_LAUNCH(wgrad3_glds_kernel, dim3(nparts * (nsplit & 0xffff)), dim3(W3G::NT), W3G::LDS_BYTES, s, parts, nparts, nsplit, ws);
     return (int)hipGetLastError();
 }
 
@@ -927,6 +952,11 @@ extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int3
                           float* ws, void* stream) {
     hipStream_t s = as_stream(stream);
     if (nparts <= 0 || nsplit <= 0) return DASR_EINVAL;
+    if (kh != 33 && (nsplit >> 16)) return DASR_EINVAL;   // the unit placement bits exist for the 12-wave 3x3 kernel only
+    if (kh == 33) {
+        const int ns = nsplit & 0xffff, ppu = (nsplit >> 16) & 0xff;
+        if (ns <= 0 || (nsplit >> 24) || (ppu && ((nparts % ppu) || (((long long)(nparts / ppu) * ns) & 7)))) return DASR_EINVAL;
+    }
     if (g_use_tr < 0) return DASR_EINVAL;  // dasr_probe_tr16 must run once per process (outside graph capture)
     const bool tr = g_use_tr == 1;
     if (kh == 33) {  // v3 layout: 6-wave workgroups, 3 oc tiles x 64 cin per part (3x3 stride 1 only)

@@ -129,9 +129,12 @@ class DASR_Model(BaseModel):
                     pf = opt['path']['pretrain_model_F']
                     if pf:
                         self.netF.load_state_dict(torch.load(pf, map_location='cpu'), strict=False)
-                    else:
-                        logger.warning('no path.pretrain_model_F: VGG19-54 uses seeded random weights (torchvision init rule)')
+                    elif opt['allow_random_perceptual']:
+                        logger.warning('allow_random_perceptual: VGG19-54 uses SEEDED RANDOM weights (torchvision init rule), no path.pretrain_model_F')
                         self.netF.load_state_dict(vgg_random_state_dict(self.netF.spec, int(t['vgg_seed'] or 77)))
+                    else:   # the reference always runs torchvision's pretrained VGG19 (architecture.py:1070); it cannot be downloaded offline
+                        raise FileNotFoundError('feature_criterion l1 needs pretrained VGG19 weights: set path.pretrain_model_F (torchvision vgg19 '
+                                                'state_dict) or allow_random_perceptual: true to train against a seeded random network')
                 elif self.l_fea_type == 'LPIPS':                             # PerceptualLoss() = LPIPS(alex) (DASR_model.py:97-98)
                     self.netF = load_lpips(opt, self.device, int(t['vgg_seed'] or 77))
                 else:
@@ -256,6 +259,8 @@ class DASR_Model(BaseModel):
         if getattr(self, '_acc_snapshot', None) is not None:
             acc, do_g, do_d, do_ds = self._acc_snapshot
             a = acc.tolist()
+            for o, what in zip(self.optimizers, ('generator', 'discriminator', 'source discriminator')):
+                o.check_finite(what)
             if do_g:
                 if self.l_pix_w > 0:
                     self.log_dict['loss/l_g_pix'] = a[A_PIX] / self._pix_div
@@ -400,7 +405,11 @@ class _StepPlan:
         ds = self.ds
         # BatchNorm running statistics follow the reference's forwards: D_s(fake) in the G step, D_s(real) then D_s(fake) in the D step
         bn = ds is not None and hasattr(Ds, 'buffers')
-        self.ds_run_g = ds.running_ops(0) if bn else OpList()
+        self.ds_run_g = OpList()
+        if bn:
+            self.ds_run_g.extend(ds.running_ops(0))
+            if m.ragan:   # the relativistic G loss also evaluates D_s(real) in training mode (DASR_model.py:253): fake, then real
+                self.ds_run_g.extend(ds.running_ops(1))
         self.ds_run_d = OpList()
         if bn:
             self.ds_run_d.extend(ds.running_ops(1))

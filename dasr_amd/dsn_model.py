@@ -269,7 +269,7 @@ class DSNModel:
     def __init__(self, opt=None, device=None, **kw):
         o = dict(n_res_blocks=8, kernel_size=5, filter='gau', norm_layer='Instance', discriminator='FSD', generator='DeResnet', learning_rate=1e-4,
                  adam_beta_1=0.5, w_col=1.0, w_tex=0.005, w_per=0.01, per_type='VGG', vgg_path=None, vgg_seed=78, num_epochs=400,
-                 num_decay_epochs=150, upscale_factor=4, ragan=False)
+                 num_decay_epochs=150, upscale_factor=4, ragan=False, allow_random_perceptual=False)
         o.update(opt or {})
         o.update(kw)
         self.opt = o
@@ -288,15 +288,19 @@ class DSNModel:
         if o['w_per'] > 0:
             if o['per_type'] == 'LPIPS':      # PerceptualLoss() = LPIPS(alex) on the LR-size images (loss.py:68-69,84,108-114)
                 from .lpips import load_lpips
-                self.netF = load_lpips({'path': {'lpips_alexnet': o.get('lpips_alexnet'), 'lpips_lin': o.get('lpips_lin')}}, self.device, int(o['vgg_seed']))
+                self.netF = load_lpips({'path': {'lpips_alexnet': o.get('lpips_alexnet'), 'lpips_lin': o.get('lpips_lin')},
+                                        'allow_random_perceptual': o['allow_random_perceptual']}, self.device, int(o['vgg_seed']))
             elif o['per_type'] == 'VGG':
                 self.netF = VGGFeatureHIP(30, device=self.device, cfg=VGG16_CFG)
                 if o['vgg_path']:
                     sd = torch.load(o['vgg_path'], map_location='cpu')
                     self.netF.load_state_dict({k: v for k, v in sd.items() if k in self.netF.params.spec})
-                else:
-                    logger.warning('no vgg_path: VGG16 perceptual net uses seeded random weights (torchvision init rule)')
+                elif o['allow_random_perceptual']:
+                    logger.warning('allow_random_perceptual: the VGG16 perceptual net uses SEEDED RANDOM weights (torchvision init rule), no vgg_path')
                     self.netF.load_state_dict(vgg_random_state_dict(self.netF.spec, int(o['vgg_seed'])))
+                else:   # the reference always runs torchvision's pretrained vgg16 (loss.py:47-63); it cannot be downloaded offline
+                    raise FileNotFoundError('--per_type VGG needs pretrained VGG16 weights: --vgg_path (torchvision vgg16 state_dict), or '
+                                            '--allow_random_perceptual to train against a seeded random network')
             else:
                 raise NotImplementedError('{} is not recognized'.format(o['per_type']))
         self.ragan = bool(o['ragan'])   # --ragan (train.py:221-223): D(x, y) = sigmoid(D(x) - mean_n D(y)) (model.py:98-106)
@@ -377,18 +381,32 @@ class DSNModel:
         P.g.x_nchw.copy_(hr if self.netG.scale == 4 else bicubic_lr)
         P.bic_nchw.copy_(bicubic_lr)
         P.real_nchw.copy_(real_lr)
-        if self.ragan and self.dp is not None and self.dp.active:
-            raise NotImplementedError('--ragan under data parallelism: the batch means would have to be all-reduced between the loss stages (as the SRN '
-                                      'trainer does); the DSN iteration records them in one list')
-        scale = self.dp.grad_scale if (self.dp is not None and self.dp.active) else 1.0
+        dp_on = self.dp is not None and self.dp.active
+        scale = self.dp.grad_scale if dp_on else 1.0
         if scale != P.scale:
             P.set_grad_scale(scale)
-        P.fwd.run()     # G, front ends, D on [fake; real], all losses and loss gradients
+        rg_dp = self.ragan and dp_on   # --ragan under data parallelism: per-pixel batch sums all-reduced between the three loss stages
+        if rg_dp:
+            if P.ragan_world != self.dp.world:
+                raise RuntimeError('the DSN plan was recorded for %d ranks, the process group has %d (attach model.dp before the first iteration)' % (P.ragan_world, self.dp.world))
+            c0, c1, _ = P.ragan_cuts_fwd
+            P.fwd.run(0, c0)                       # ... stage 0: per-pixel sums of the logits of both halves
+            self.dp.all_reduce_here(P.r_sums)
+            P.fwd.run(c0, c1)                      # stage 1: loss + per-pixel sums of the sigmoid terms
+            self.dp.all_reduce_here(P.r_part)
+            P.fwd.run(c1)                          # stage 2: gradients incl. the mean terms; colour / perceptual losses
+        else:
+            P.fwd.run()     # G, front ends, D on [fake; real], all losses and loss gradients
         if self.bn:     # BatchNorm running statistics, one update per discriminator call of the reference (train.py:221-226)
             P.d_running.run()
             self._d_eval_stale = True
         P.d_bwd.run()   # D weight gradients (pre-update graph)
-        P.g_bwd.run()   # texture gradient through D's data path, colour adjoint, G backward
+        if rg_dp:       # generator's relativistic texture loss: stage 1 (sums still valid) -> all-reduce -> stage 2, then the backward chain
+            P.g_bwd.run(0, P.ragan_cut_gbwd)
+            self.dp.all_reduce_here(P.r_part)
+            P.g_bwd.run(P.ragan_cut_gbwd)
+        else:
+            P.g_bwd.run()   # texture gradient through D's data path, colour adjoint, G backward
         if self.dp is not None and self.dp.active:
             self.dp.allreduce_mean(self.netD.params.grad)
             self.dp.allreduce_mean(self.netG.params.grad)
@@ -436,6 +454,8 @@ class DSNModel:
     def get_current_log(self):
         if getattr(self, '_pending', False):
             a = self.acc.tolist()
+            self.opt_g.check_finite('DSN generator')
+            self.opt_d.check_finite('DSN discriminator')
             o = self.opt
             self.log.update({'loss/d_tex_loss': a[0] + a[1], 'loss/g_tex_loss': a[2], 'loss/color_loss': a[3], 'loss/perceptual_loss': a[6],
                              'loss/g_overall_loss': o['w_col'] * a[3] + o['w_tex'] * a[2] + o['w_per'] * a[6], 'disc_score/real': a[4],
@@ -522,10 +542,16 @@ class _DSNPlan:
             hw = lg.H * lg.W
             self.r_sums, self.r_part = (torch.zeros(2 * hw, dtype=torch.float32, device=dev) for _ in range(2))
             rl = [OpList(), OpList(), OpList()]
-            _ragan_ops(rl, _nview(lg, N), lg.view(), N, lg.H, lg.W, N, 1.0, 0.0, 1.0 / cnt, 1.0 / cnt, self.r_sums, self.r_part, acc, acc + 4 * 4,
+            # data parallel: the batch means are means over the GLOBAL batch (n_glob = N * world); iteration() all-reduces the per-pixel sums
+            # between the stages, as the SRN trainer does (dasr_model.py::_run_ragan), so the lists are cut at the stage boundaries
+            world = m.dp.world if (getattr(m, 'dp', None) is not None and m.dp.active) else 1
+            self.ragan_world = world
+            _ragan_ops(rl, _nview(lg, N), lg.view(), N, lg.H, lg.W, N * world, 1.0, 0.0, 1.0 / cnt, 1.0 / cnt, self.r_sums, self.r_part, acc, acc + 4 * 4,
                        acc + 4 * 5, 1.0 / cnt, _nview(d.g_logits, N), d.g_logits.view(), form=1, eps=EPS)
+            self.ragan_cuts_fwd = []
             for l_ in rl:
                 f.extend(l_)
+                self.ragan_cuts_fwd.append(len(f.ops))
         # discriminator loss: -log(real) - log(1 - fake)   (acc[0], acc[1]); scores acc[4] (real), acc[5] (fake)
         for n0, mode, a_loss, a_score in (() if m.ragan else ((N, 0, 0, 4), (0, 1, 1, 5))):
             o = _op(_lib.OP_LOGLOSS)
@@ -575,9 +601,10 @@ class _DSNPlan:
         gb = OpList()
         if m.ragan:   # -log(sigmoid(fake - mean_n(real)) + eps): stage 0's sums are still valid, the real term is absent (t < 0), real carries no gradient
             rl = [OpList(), OpList(), OpList()]
-            _ragan_ops(rl, _nview(lg, N), lg.view(), N, lg.H, lg.W, N, -1.0, 1.0, 1.0 / cnt, float(o_['w_tex']) / cnt, self.r_sums, self.r_part,
+            _ragan_ops(rl, _nview(lg, N), lg.view(), N, lg.H, lg.W, N * self.ragan_world, -1.0, 1.0, 1.0 / cnt, float(o_['w_tex']) / cnt, self.r_sums, self.r_part,
                        acc + 4 * 2, None, None, 0.0, NULL_T, d.g_logits.view(), form=1, eps=EPS, stages=(1, 2))
             gb.extend(rl[1])
+            self.ragan_cut_gbwd = len(gb.ops)
             gb.extend(rl[2])
         else:
             o = _op(_lib.OP_LOGLOSS)   # -log(fake_tex) on the fake half: value -> acc[2], gradient -> g_logits[:N]

@@ -4,8 +4,9 @@ Same flags and defaults as the reference's argparse block (train.py:24-72) and t
 DSNModel.iteration(hr, bicubic_lr, real_lr); schedulers step once per epoch (train.py:287-288); every
 `save_model_interval` epochs the `.tar` checkpoint dict of train.py:357-376 is written to
 <save_path>/checkpoints/iteration_<n>.tar and last_iteration.tar.  Accepted-but-unsupported choices fail the way the
-reference does for unknown strings (NotImplementedError): --wgan, --lpips_rot_flip, --norm_layer Batch with the nld discriminators.  --ragan is supported (single rank).  --per_type LPIPS (the reference default) runs LPIPS(alex) with weights from --lpips_alexnet /
---lpips_lin (seeded and logged when absent: they cannot be downloaded offline).  Data: the PIL/torchvision loaders
+reference does for unknown strings (NotImplementedError): --wgan, --lpips_rot_flip, --norm_layer Batch with the nld discriminators.  --ragan is supported, also under data parallelism (the batch means are all-reduced between the loss stages).  --per_type LPIPS (the reference
+default) runs LPIPS(alex) with weights from --lpips_alexnet / --lpips_lin, --per_type VGG with --vgg_path; the pretrained files cannot be
+downloaded offline, a missing file is an error unless --allow_random_perceptual opts into a seeded random network.  Data: the PIL/torchvision loaders
 (data_loader.py) stay on the reference's side of the boundary; any iterable of (hr, bicubic_lr, real_lr) tuples works, and
 `--dataset synthetic` ships fixed-seed random crops for benchmarks and tests.
 """
@@ -65,10 +66,16 @@ def build_parser():
     p.add_argument('--vgg_path', default=None, type=str, help='torchvision vgg16 state_dict for --per_type VGG')
     p.add_argument('--lpips_alexnet', default=None, type=str, help='torchvision alexnet state_dict for --per_type LPIPS')
     p.add_argument('--lpips_lin', default=None, type=str, help="the reference's codes/PerceptualSimilarity/models/weights/v0.1/alex.pth")
+    p.add_argument('--allow_random_perceptual', action='store_true',
+                   help='run the perceptual term on a SEEDED RANDOM network when the pretrained weight files are not supplied (the reference always uses pretrained weights)')
     return p
 
 
-def check_supported(o):
+def check_supported(o, have_loader=True):
+    """everything that cannot run is refused HERE, before any model is built or any parameter is broadcast"""
+    if not have_loader and o.dataset != 'synthetic':
+        raise NotImplementedError('dataset [%s]: pass a loader of (hr, bicubic_lr, real_lr) batches to main(); only "synthetic" is built in '
+                                  '(the PIL / torchvision loaders of the reference stay on its side of the boundary)' % o.dataset)
     if o.generator not in ('DeResnet', 'DSGAN'):
         raise NotImplementedError('Generator model [{:s}] not recognized'.format(o.generator))
     if o.discriminator.lower() not in ('fsd', 'nld_s1', 'nld_s2'):
@@ -101,7 +108,7 @@ class SyntheticCrops:
 
 def main(argv=None, loader=None):
     o = build_parser().parse_args(argv)
-    check_supported(o)
+    check_supported(o, have_loader=loader is not None)
     logging.basicConfig(level=logging.INFO, format='%(asctime)s %(message)s')
     log = logging.getLogger('base')
     torch.manual_seed(0)  # train.py:76
@@ -114,7 +121,7 @@ def main(argv=None, loader=None):
     opt = dict(n_res_blocks=o.num_res_blocks, kernel_size=o.kernel_size, filter=o.filter, norm_layer=o.norm_layer, discriminator=o.discriminator,
                learning_rate=o.learning_rate, adam_beta_1=o.adam_beta_1, w_col=o.w_col, w_tex=o.w_tex, w_per=o.w_per if o.use_per_loss else 0.0,
                per_type=o.per_type, generator=o.generator, vgg_path=o.vgg_path, lpips_alexnet=o.lpips_alexnet, lpips_lin=o.lpips_lin, num_epochs=o.num_epochs, num_decay_epochs=o.num_decay_epochs,
-               upscale_factor=o.upscale_factor, ragan=o.ragan)
+               upscale_factor=o.upscale_factor, ragan=o.ragan, allow_random_perceptual=o.allow_random_perceptual)
     model = DSNModel(opt)
     if dp:
         model.dp = dp
@@ -127,8 +134,6 @@ def main(argv=None, loader=None):
         start_epoch = model.epoch + 1
         log.info('Continuing training at epoch %d' % start_epoch)
     if loader is None:
-        if o.dataset != 'synthetic':
-            raise NotImplementedError('dataset [%s]: pass a loader of (hr, bicubic_lr, real_lr) batches; only "synthetic" is built in' % o.dataset)
         per_rank = o.batch_size // (dp.world if dp else 1)
         loader = SyntheticCrops(per_rank, o.crop_size, o.iters_per_epoch, seed=1234 + rank)
     save_path = o.save_path or os.path.join('experiments', 'dsn_' + o.filter)

@@ -33,6 +33,15 @@ class BTensor:
         self.t = torch.zeros((N, self.planes, H, W, 16), dtype=torch.float32 if f32 else (torch.float16 if f16 else torch.bfloat16), device=device)
         self.esz = 4 if f32 else 2
 
+    @classmethod
+    def wrap(cls, t, C_, f32):
+        """blocked tensor over an existing torch tensor [N][planes][H][W][16] (e.g. images [n0, n1) of a larger allocation)"""
+        assert t.dim() == 5 and t.shape[4] == 16 and t.is_contiguous() and t.shape[1] == ceil_div(C_, 16)
+        b = cls.__new__(cls)
+        b.N, b.C, b.H, b.W, b.f32 = t.shape[0], C_, t.shape[2], t.shape[3], f32
+        b.planes, b.t, b.esz = t.shape[1], t, 4 if f32 else 2
+        return b
+
     def view(self, c0=0):
         """dasr_tensor starting at channel c0 (multiple of 16)."""
         assert c0 % 16 == 0 and c0 // 16 < self.planes, (c0, self.planes)
@@ -357,7 +366,9 @@ class WgradGroup3:
         wp.kh, wp.stride, wp.pad, wp.want_bias = 3, 1, 1, int(bool(want_bias))
         self.parts.append((wp, [(i, t) for i, t in enumerate(tiles) if t is not None]))
 
-    def finalize(self, workspace, device, target_wgs=256):
+    def finalize(self, workspace, device, target_wgs=256, ppu=0):
+        """ppu: the parts come in units of `ppu` consecutive parts that read the same tensors (one dense block); when the split count is not
+        a multiple of 8 the kernel then places each (unit, split) on one XCD (csrc/wgrad.hip, w3_block_map)"""
         wp0 = self.parts[0][0]
         ntiles = wp0.N * ceil_div(wp0.Hout, 8) * ceil_div(wp0.Wout, 16)
         nparts = len(self.parts)
@@ -367,6 +378,9 @@ class WgradGroup3:
             # lands on the same XCD and the G / X tiles the parts share are fetched once per XCD.  17 splits (255 workgroups instead of 240)
             # was 3 % faster on the launch but fetched 60 % more (351 vs 220 MB raw FETCH_SIZE per RRDB launch): not kept
             self.nsplit -= self.nsplit % 8
+        self.ppu = 0
+        if ppu and self.nsplit % 8 and nparts % ppu == 0 and ((nparts // ppu) * self.nsplit) % 8 == 0 and ppu < 256:
+            self.ppu = ppu
         off, red = 0, []
         for wp, tiles in self.parts:
             wp.ws_off = off
@@ -395,7 +409,8 @@ class WgradGroup3:
         a, b = Op(), Op()
         a.op = _lib.OP_WGRAD
         f16 = getattr(self, 'f16', False)   # 16-bit f16 tensors (gradient pre-scaled by g_scale): f16 MFMA, reduce scale x 1 / g_scale
-        a.p[0], a.i[0], a.i[1], a.i[2], a.i[3], a.i[4] = self.w_dev.data_ptr(), len(self.parts), self.nsplit, 33, 1, (2 if f16 else self.parts[0][0].g_f32)
+        a.p[0], a.i[0], a.i[1], a.i[2], a.i[3], a.i[4] = (self.w_dev.data_ptr(), len(self.parts), self.nsplit | (getattr(self, 'ppu', 0) << 16), 33, 1,
+                                                          (2 if f16 else self.parts[0][0].g_f32))
         a.flops = float(getattr(self, 'flops', 0.0))
         b.op = _lib.OP_WGRAD_REDUCE
         b.p[0], b.i[0], b.p[2], b.f[0] = self.r_dev.data_ptr(), self.n_red, grad_ptr, scale

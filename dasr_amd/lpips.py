@@ -78,24 +78,37 @@ logger = logging.getLogger('base')
 
 
 def load_lpips(opt, device, seed=77):
-    """LPIPS(alex) with weights from files when given: path.lpips_alexnet = torchvision's alexnet state_dict (features.*), path.lpips_lin =
-    the reference's codes/PerceptualSimilarity/models/weights/v0.1/alex.pth (lin*.model.1.weight).  The reference downloads / reads both
-    itself (pretrained_networks.py:60, dist_model.py:74-80); offline they cannot be fetched, so what is missing is seeded and logged."""
+    """LPIPS(alex) with weights from files: path.lpips_alexnet = torchvision's alexnet state_dict (features.*), path.lpips_lin = the
+    reference's codes/PerceptualSimilarity/models/weights/v0.1/alex.pth (lin*.model.1.weight).  The reference downloads / reads both itself
+    (pretrained_networks.py:60, dist_model.py:74-80), i.e. it ALWAYS runs the pretrained network.  Offline the files cannot be fetched, so a
+    missing file is an error unless the caller opts in with `allow_random_perceptual: true` (option file / --allow_random_perceptual): the
+    network is then seeded, `net.seeded` is set and every logged value is labelled LPIPS(random) -- it is not the LPIPS metric."""
+    pf, pl = opt['path']['lpips_alexnet'], opt['path']['lpips_lin']
+    allow = bool(opt.get('allow_random_perceptual') or opt['path'].get('allow_random_perceptual'))
+    missing = [n for n, v in (('path.lpips_alexnet', pf), ('path.lpips_lin', pl)) if not v]
+    if missing and not allow:
+        raise FileNotFoundError('LPIPS(alex) needs pretrained weights (%s missing): supply the files (INTEGRATION.md, "Perceptual-network weight '
+                                'files") or set allow_random_perceptual to train / evaluate against a seeded random network' % ', '.join(missing))
     net = LPIPSAlexHIP(device=device)
     sd = lpips_random_state_dict(seed)
-    pf, pl = opt['path']['lpips_alexnet'], opt['path']['lpips_lin']
     if pf:
         src = torch.load(pf, map_location='cpu')
         sd.update({k: v for k, v in src.items() if k.startswith('features.') and k in sd})
     else:
-        logger.warning('no path.lpips_alexnet: the LPIPS AlexNet backbone uses seeded random weights')
+        logger.warning('allow_random_perceptual: the LPIPS AlexNet backbone uses SEEDED RANDOM weights (no path.lpips_alexnet)')
     if pl:
         src = torch.load(pl, map_location='cpu')
         sd.update({k: v for k, v in src.items() if k.startswith('lin') and k in sd})
     else:
-        logger.warning('no path.lpips_lin: the LPIPS linear heads use seeded random non-negative weights')
+        logger.warning('allow_random_perceptual: the LPIPS linear heads use SEEDED RANDOM non-negative weights (no path.lpips_lin)')
     net.load_state_dict(sd)
+    net.seeded = bool(missing)
     return net
+
+
+def lpips_label(net):
+    """column label of the validation / test logs: a seeded network does not measure LPIPS"""
+    return 'LPIPS(random)' if getattr(net, 'seeded', False) else 'LPIPS'
 
 
 def lpips_metric(net, fake, real):

@@ -69,12 +69,21 @@ class AdamHIP:
     def __init__(self, params, lr, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8):
         self.params, self.lr, self.betas, self.wd, self.eps = params, lr, betas, weight_decay, eps
         self.step_count = 0
+        self.nonfinite = torch.zeros(1, dtype=torch.int32, device=params.device)   # set by the kernel when a gradient element is inf / NaN
 
     def step(self, lr):
         self.step_count += 1
         P = self.params
         _lib.check(_lib.lib().dasr_adam(P.flat.data_ptr(), P.grad.data_ptr(), P.m.data_ptr(), P.v.data_ptr(), P.total, lr,
-                                        self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, _stream()), 'adam')
+                                        self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, self.nonfinite.data_ptr(), _stream()), 'adam')
+
+    def check_finite(self, what='generator'):
+        """called where the trainer synchronises anyway (get_current_log): a non-finite gradient has reached the optimiser since the last check"""
+        if int(self.nonfinite.item()):
+            self.nonfinite.zero_()
+            raise FloatingPointError('inf / NaN in the %s gradients (the weights have absorbed it).  The HR tail stores activations and gradients in f16 '
+                                     'with a power-of-two pre-scale sized for mean losses of weight ~1: very large loss weights or activations above '
+                                     '65504 overflow it -- DASR_HR_PREC=3 keeps the tail in split-bf16 on f32 tensors.' % what)
 
     def state_dict(self, lr):
         P = self.params
@@ -116,6 +125,12 @@ class BaseModel:
     def update_learning_rate(self):
         for s in self.schedulers:
             s.step()
+
+    @property
+    def lpips_label(self):
+        """label of the val_lpips column: 'LPIPS(random)' when the metric network is seeded (allow_random_perceptual), see lpips.load_lpips"""
+        from .lpips import lpips_label
+        return lpips_label(getattr(self, 'cri_fea_lpips', None))
 
     def get_current_learning_rate(self):
         return self.schedulers[0].get_lr()
@@ -218,11 +233,14 @@ class SRModel(BaseModel):
         fill those gaps with each other's main loops.  DASR_STREAMS=1 disables it."""
         k = max(1, int(os.environ.get('DASR_STREAMS', '2')))
         if k == 1 or N % k or N // k < 4:
-            if (N, h, w, 0) not in self.netG.plans:
+            if (N, h, w, 0, 0, 0) not in self.netG.plans:
                 self.netG.concurrent_replicas = 1   # a plan built now has the chip to itself (wgrad split count)
             return [self.netG.plan(N, h, w)]
         self.netG.concurrent_replicas = k  # the 1-WG/CU wgrad launches of the replicas must fit on the chip together
-        return [self.netG.plan(N // k, h, w, replica=i) for i in range(k)]
+        # deferred dense-block weight gradients: the replicas work on image ranges of ONE set of slabs (TrunkStore) and the weight-gradient
+        # phase runs once over the whole batch after both data-gradient chains (rrdbnet.TrunkStore)
+        store = self.netG.trunk_store(N, h, w) if self.netG.defer_wgrad else None
+        return [self.netG.plan(N // k, h, w, replica=i, store=store, n0=i * (N // k)) for i in range(k)]
 
     @staticmethod
     def _whole_step(plan, loss_ops):
@@ -233,23 +251,24 @@ class SRModel(BaseModel):
             ws = OpList()
             ws.extend(plan.fwd)
             ws.extend(loss_ops)
-            plan.buckets, prev, prev_hi = [], 0, plan.net.params.total
-            for idx, lo in plan._marks:
+            plan.buckets, prev = [], 0
+            for idx, lo, hi in plan._marks:
                 ws.ops.extend(plan.bwd.ops[prev:idx])
                 ev = plan._event()
                 ws.ops.append(_sched(_lib.OP_EVENT_RECORD, ev))
-                plan.buckets.append((ev, lo, prev_hi))
-                prev, prev_hi = idx, lo
+                plan.buckets.append((ev, lo, hi))
+                prev = idx
             ws.ops.extend(plan.bwd.ops[prev:])
             ws.keep.extend(plan.bwd.keep)
             ws._arr = None
             plan.whole_step = ws
+            plan.whole_step_gen = getattr(plan, 'whole_step_gen', 0) + 1   # identifies THIS recording (id() of a rebuilt list can repeat)
         return plan.whole_step
 
     def _bucket_ops(self, plans):
         """per gradient bucket: op list for the communication stream = wait for every replica's boundary event, then add the private
         gradient slices of replicas 1.. into params.grad[lo:hi]"""
-        key = tuple(id(p.whole_step) for p in plans)
+        key = tuple((id(p), p.whole_step_gen) for p in plans)
         if getattr(self, '_bucket_key', None) != key:
             from .rrdbnet import _sched
             g, out = self.netG.params.grad, []
@@ -308,6 +327,9 @@ class SRModel(BaseModel):
             run_interleaved(steps, self._streams)
             g = self.netG.params.grad
             comm = self.dp.comm_stream if dp_on else None
+            store = plans[0].store if plans[0].shared_store else None
+            if store is not None and dp_on:
+                store.set_grad_scale(self.dp.grad_scale)
             if comm is not None:
                 # bucket k of the flat gradient buffer is summed over the sub-batch replicas and all-reduced over the ranks on the
                 # communication stream as soon as BOTH replica streams have passed its boundary event: the exchange overlaps the
@@ -318,12 +340,27 @@ class SRModel(BaseModel):
                         self.dp.all_reduce_here(g[lo:hi])
                 for st in self._streams:
                     cur.wait_stream(st)
+                if store is not None:
+                    # deferred dense-block weight gradients: one grouped launch sequence over the whole batch on the main stream; every group's
+                    # slice of the flat gradient buffer is all-reduced while the next group is computed
+                    for first_op, end_op, lo, hi in store.groups:
+                        store.phase.run(first_op, end_op)
+                        comm.wait_stream(cur)
+                        with torch.cuda.stream(comm):
+                            self.dp.all_reduce_here(g[lo:hi])
                 cur.wait_stream(comm)
             else:
                 for st in self._streams:
                     cur.wait_stream(st)
-                for plan in plans[1:]:
-                    _lib.check(L.dasr_add_flat(g.data_ptr(), plan.grad.data_ptr(), g.numel(), _stream()), 'add_flat')
+                if store is not None:
+                    # only the buckets outside the dense blocks hold per-replica weight gradients (HR tail + LR_conv, fea_conv)
+                    for _, lo, hi in plans[0].buckets:
+                        for plan in plans[1:]:
+                            _lib.check(L.dasr_add_flat(g.data_ptr() + 4 * lo, plan.grad.data_ptr() + 4 * lo, hi - lo, _stream()), 'add_flat')
+                    store.phase.run()
+                else:
+                    for plan in plans[1:]:
+                        _lib.check(L.dasr_add_flat(g.data_ptr(), plan.grad.data_ptr(), g.numel(), _stream()), 'add_flat')
                 if dp_on:
                     self.dp.allreduce_mean(g)
         self.optimizer_G.step(self.schedulers[0].get_lr())
@@ -347,6 +384,7 @@ class SRModel(BaseModel):
     def get_current_log(self):
         if 'l_pix' in self.log_dict:
             self.log_dict['l_pix'] = float(self._l_pix_dev.item())
+            self.optimizer_G.check_finite()
         return self.log_dict
 
     def test(self):

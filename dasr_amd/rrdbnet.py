@@ -137,13 +137,29 @@ class RRDBNetHIP:
         self.pack.run()
 
     # ---- plan ---------------------------------------------------------------------------------------
-    def plan(self, N, h, w, replica=0):
+    def plan(self, N, h, w, replica=0, store=None, n0=0):
         """replica > 0: an independent set of buffers for a sub-batch processed concurrently on another stream; its
-        weight gradients go to a private flat buffer (plan.grad) that the trainer adds to params.grad."""
-        key = (N, h, w, replica)
+        weight gradients go to a private flat buffer (plan.grad) that the trainer adds to params.grad.
+        store / n0: the dense-block slabs of this plan are images [n0, n0 + N) of a shared TrunkStore (sub-batch replicas of one batch): the
+        dense-block weight gradients are then NOT part of the plan's backward list but of store.phase (one launch over the whole batch)."""
+        key = (N, h, w, replica, id(store) if store is not None else 0, n0)
         if key not in self.plans:
-            self.plans[key] = _Plan(self, N, h, w, replica)
+            self.plans[key] = _Plan(self, N, h, w, replica, store=store, n0=n0)
         return self.plans[key]
+
+    @property
+    def defer_wgrad(self):
+        """dense-block weight gradients as a separate phase AFTER the data-gradient chain (default): grouped launches over the whole batch with the
+        chip to themselves, instead of one launch per RRDB interleaved with (and, under two sub-batch streams, competing with) the data-gradient
+        convs.  Costs one gradient slab per RDB (3 nb x 50 MB at batch 8 x 128^2) instead of a ring of four.  DASR_WG_DEFER=0: round-2 schedule."""
+        return os.environ.get('DASR_WG_DEFER', '1') != '0'
+
+    def trunk_store(self, N, h, w):
+        key = (N, h, w)
+        st = self.__dict__.setdefault('_stores', {})
+        if key not in st:
+            st[key] = TrunkStore(self, N, h, w)
+        return st[key]
 
     # convenience API used by the trainers / tests -------------------------------------------------------
     def state_dict(self):
@@ -180,14 +196,119 @@ def _sched(kind, handle):
     return o
 
 
+def rdb_wgrad_parts(grp, nf, pre, P, Gs, S, h, w, N):
+    """parts of the 12-wave weight-gradient kernel for the 5 convs of one dense block: one part per 64-channel block of the forward slab S x up
+    to three 32-oc tiles of the gradient slab Gs (= every conv that consumes those channels).  Returns (number of parts, algorithmic FLOPs)."""
+    gt = []  # gslab' oc tiles in order: conv5 (nf/32 tiles), conv4, conv3, conv2, conv1
+    for j in (5, 4, 3, 2, 1):
+        cout_j = nf if j == 5 else GC
+        for oc0 in range(0, cout_j, 32):
+            gt.append(dict(j=j, oc0=oc0, cout=cout_j, cin=nf + (j - 1) * GC))
+    n = 0
+    for c0 in range(0, nf + 4 * GC, 64):
+        need = [t for t in gt if t['cin'] > c0]
+        blk_ch = min(64, nf + 4 * GC - c0)
+        for k0 in range(0, len(need), 3):
+            sub = need[k0:k0 + 3]
+            tiles = []
+            for t in sub:
+                wkey = '%s%d.0.' % (pre, t['j'])
+                tiles.append(dict(dst_w_off=P.off(wkey + 'weight'), dst_b_off=P.off(wkey + 'bias') if c0 == 0 else None,
+                                  cout=t['cout'], cin=t['cin'], oc0=t['oc0'], c0=c0,
+                                  n_ctiles=min(2, ceil_div(min(t['cin'] - c0, 64), 32))))
+            grp.add_block(Gs.view(32 * k0), 2 * len(sub), S.view(c0), blk_ch // 16, ceil_div(blk_ch, 32),
+                          h, w, h, w, N, tiles, want_bias=(c0 == 0))
+            n += 1
+    return n, 2.0 * N * h * w * 9 * sum((nf + (j - 1) * GC) * (GC if j < 5 else nf) for j in range(1, 6))
+
+
+class TrunkStore:
+    """Forward slabs and gradient slabs of ALL dense blocks for a whole batch of N images (one allocation per RDB; sub-batch replicas work on
+    image ranges of it), and the deferred weight-gradient phase over them: after the data-gradient chain has filled every gradient slab, the
+    weight gradients of the 3 nb dense blocks are computed by a few grouped launches (16 + 4 + 2 + 1 RRDBs for nb = 23: every launch has
+    ~240 workgroups of 12 waves, one per CU, nothing co-resident; the big groups need no pixel split at all, so the fp32 partial-sum traffic
+    of round 2 -- 24.8 MB written and re-read per RRDB -- all but disappears)."""
+
+    def __init__(self, net, N, h, w):
+        self.net, self.N, self.h, self.w = net, N, h, w
+        dev, nf, nb = net.device, net.nf, net.nb
+        sc = nf + 4 * GC
+        mk = lambda: torch.zeros((N, ceil_div(sc, 16), h, w, 16), dtype=torch.bfloat16, device=dev)
+        self.slab_t = [mk() for _ in range(3 * nb)]
+        self.gslab_t = [mk() for _ in range(3 * nb)]
+        self.sc = sc
+        self.ws = Workspace(dev)
+        self._build_phase()
+        self.ws.finalize()
+
+    def slab(self, ridx, n0=0, N=None):
+        N = self.N if N is None else N
+        return BTensor.wrap(self.slab_t[ridx][n0:n0 + N], self.sc, False)
+
+    def gslab(self, ridx, n0=0, N=None):
+        N = self.N if N is None else N
+        return BTensor.wrap(self.gslab_t[ridx][n0:n0 + N], self.sc, False)
+
+    def _build_phase(self):
+        net, N, h, w = self.net, self.N, self.h, self.w
+        nf, nb, P = net.nf, net.nb, net.params
+        target = int(os.environ.get('DASR_WG3_TARGET', '256'))
+        gmax = max(1, int(os.environ.get('DASR_WG_GROUP', '16')))
+        self.phase = OpList()
+        self.groups = []   # (first op, end op, lo, hi): ops [first, end) complete params.grad[lo:hi]; descending parameter order
+        hi_rrdb = nb
+        ppr = None
+        while hi_rrdb > 0:
+            if ppr is None:   # parts per RRDB: count on a scratch group
+                tmp = WgradGroup3()
+                ppu, _ = rdb_wgrad_parts(tmp, nf, 'model.1.sub.0.RDB1.conv', P, self.gslab(0), self.slab(0), h, w, N)
+                ppr = 3 * ppu
+            G = 1
+            while G * 2 <= hi_rrdb and G * 2 <= gmax and G * 2 * ppr <= target:
+                G *= 2
+            lo_rrdb = hi_rrdb - G
+            grp = WgradGroup3()
+            grp.flops = 0.0
+            for i in range(hi_rrdb - 1, lo_rrdb - 1, -1):
+                for r in (3, 2, 1):
+                    ridx = 3 * i + (r - 1)
+                    _, fl = rdb_wgrad_parts(grp, nf, 'model.1.sub.%d.RDB%d.conv' % (i, r), P, self.gslab(ridx), self.slab(ridx), h, w, N)
+                    grp.flops += fl
+            grp.finalize(self.ws, net.device, target_wgs=target, ppu=ppu)
+            first = len(self.phase.ops)
+            for o in grp.ops(P.grad.data_ptr()):
+                self.phase.add(o)
+            self.phase.keep.append(grp)
+            lo = P.off('model.1.sub.%d.RDB1.conv1.0.weight' % lo_rrdb)
+            hi = P.off('model.1.sub.%d.RDB1.conv1.0.weight' % hi_rrdb) if hi_rrdb < nb else P.off('model.1.sub.%d.weight' % nb)
+            self.groups.append((first, len(self.phase.ops), lo, hi))
+            hi_rrdb = lo_rrdb
+
+    def set_grad_scale(self, scale):
+        changed = False
+        for o in self.phase.ops:
+            if o.op == _lib.OP_WGRAD_REDUCE and o.f[0] != scale:
+                o.f[0] = scale
+                changed = True
+        if changed:
+            self.phase._arr = None
+        return changed
+
+
 class _Plan:
     """Buffers + recorded forward / backward op lists for one (N, h, w)."""
 
-    def __init__(self, net, N, h, w, replica=0, inference=False):
+    def __init__(self, net, N, h, w, replica=0, inference=False, store=None, n0=0):
         self.net, self.N, self.h, self.w = net, N, h, w
         dev, nf, nb = net.device, net.nf, net.nb
         self.inference = inference
         self.replica = replica
+        # deferred dense-block weight gradients (TrunkStore): shared = the store belongs to a group of sub-batch replicas and the trainer runs
+        # its phase after all of them; otherwise the plan owns a store of its own batch and the phase is part of plan.bwd
+        self.defer = (not inference) and (store is not None or net.defer_wgrad)
+        self.shared_store = store is not None
+        self.store = store if store is not None else (TrunkStore(net, N, h, w) if self.defer else None)
+        self.n0 = n0
         self.grad = net.params.grad if (replica == 0 or inference) else torch.zeros_like(net.params.grad)
         # power-of-two pre-scale of the HR-tail gradients before their f16 rounding (prec 2): dL/dSR of a mean loss is ~1 / (N 3 H W) ~ 1e-7,
         # far below f16's normal range; scaled to ~2^-3.  Exact (power of two), undone in the conv epilogue / the wgrad reduction.
@@ -204,6 +325,8 @@ class _Plan:
         if inference:   # nothing is kept for a backward pass: two slabs alternate through the 3 nb dense blocks
             ab = [B(sc, h, w, False), B(sc, h, w, False)]
             self.slabs = [ab[i & 1] for i in range(3 * nb)]
+        elif self.defer:
+            self.slabs = [self.store.slab(r, n0, N) for r in range(3 * nb)]
         else:
             self.slabs = [B(sc, h, w, False) for _ in range(3 * nb)]
         self.stream = [B(nf, h, w, True) for _ in range(4)]
@@ -235,8 +358,9 @@ class _Plan:
         # (A side stream for the RDB weight gradients was tried in round 1 and was slower -- they take CUs from the serial data-gradient
         # chain of their own sub-batch -- and has been removed.)
         self.wg_batch = max(1, int(os.environ.get('DASR_WG_BATCH', '3')))
-        self.n_gslab = self.wg_batch + 1
-        self.gslab = [B(sc, h, w, False) for _ in range(self.n_gslab)]
+        self.n_gslab = 3 * nb if self.defer else self.wg_batch + 1
+        # deferred: one gradient slab per RDB, in the order the backward chain visits them (RDB 3 nb - 1 first)
+        self.gslab = [self.store.gslab(3 * nb - 1 - k, n0, N) for k in range(3 * nb)] if self.defer else [B(sc, h, w, False) for _ in range(self.n_gslab)]
         self.g_fea = B(nf, h, w, True)
         self.ws = Workspace(dev)
         self._build_forward()
@@ -513,16 +637,17 @@ class _Plan:
         # LR_conv (model.1.sub.nb): t0 = fea + LR_conv(x_last)
         lrk = 'model.1.sub.%d.' % nb
         self._wg(ops, lrk, self.g_t0, True, self.x_last, True, nf, nf, h, w, h, w)
-        self._marks = [(len(ops.ops), P.off(lrk + 'weight'))]
+        # gradient buckets: (index into ops, lo, hi): params.grad[lo:hi] is complete once ops[:index] have run
+        self._marks = [(len(ops.ops), P.off(lrk + 'weight'), P.total)]
         bucket_every = max(1, ceil_div(nb, 4))
         free = list(self.gstream)
         G = free[0]
         gs_cur = 0
         ops.add(conv_op(pack, pk['lr_b'], self.g_t0.view(), True, nf, h, w, h, w, N, out_f32=G.view(),
                         out_bf16=self.gslab[gs_cur].view(0), gamma=0.04))
-        # RRDB chain, reversed.  The weight gradients of `wgb` consecutive RDBs (default: the three of an RRDB) go into ONE launch: the
-        # split count per part drops by that factor, and with it the fp32 partial-sum traffic (49 MB written + read per RDB at 48 splits),
-        # the reduce work and two thirds of the launches.  Needs wgb + 1 gradient slabs in the ring.
+        # RRDB chain, reversed.  Round-2 schedule (DASR_WG_DEFER=0): the weight gradients of `wgb` consecutive RDBs (default: the three of an
+        # RRDB) go into ONE launch behind their data-gradient convs: wgb + 1 gradient slabs in a ring.  Deferred (default): no weight-gradient
+        # launch inside the chain; every RDB keeps its gradient slab and TrunkStore.phase computes all of them afterwards.
         wgb = self.wg_batch
         grp, n_in_grp = None, 0
 
@@ -546,32 +671,13 @@ class _Plan:
                     cin_b = nf + (4 - k) * GC
                     ops.add(conv_op(pack, pk[(i, r, 'b', k)], Gs.view(0), False, cin_b, h, w, h, w, N,
                                     mask=S.view(nf + (k - 1) * GC), mask_f32=0, out_bf16=Gs.view(cin_b)))
-                # weight gradients of the 5 convs of this RDB: one part per 64-channel block of the forward slab x up to three
-                # 32-oc tiles of gslab' (= every conv that consumes those channels)
-                pre = 'model.1.sub.%d.RDB%d.conv' % (i, r)
-                gt = []  # gslab' oc tiles in order: conv5 (nf/32 tiles), conv4, conv3, conv2, conv1
-                for j in (5, 4, 3, 2, 1):
-                    cout_j = nf if j == 5 else GC
-                    for oc0 in range(0, cout_j, 32):
-                        gt.append(dict(j=j, oc0=oc0, cout=cout_j, cin=nf + (j - 1) * GC))
-                if grp is None:
-                    grp = WgradGroup3()
-                    grp.flops = 0.0
-                for c0 in range(0, nf + 4 * GC, 64):
-                    need = [t for t in gt if t['cin'] > c0]
-                    blk_ch = min(64, nf + 4 * GC - c0)
-                    for k0 in range(0, len(need), 3):
-                        sub = need[k0:k0 + 3]
-                        tiles = []
-                        for t in sub:
-                            wkey = '%s%d.0.' % (pre, t['j'])
-                            tiles.append(dict(dst_w_off=P.off(wkey + 'weight'), dst_b_off=P.off(wkey + 'bias') if c0 == 0 else None,
-                                              cout=t['cout'], cin=t['cin'], oc0=t['oc0'], c0=c0,
-                                              n_ctiles=min(2, ceil_div(min(t['cin'] - c0, 64), 32))))
-                        grp.add_block(Gs.view(32 * k0), 2 * len(sub), S.view(c0), blk_ch // 16, ceil_div(blk_ch, 32),
-                                      h, w, h, w, N, tiles, want_bias=(c0 == 0))
-                grp.flops += 2.0 * N * h * w * 9 * sum((nf + (j - 1) * GC) * (GC if j < 5 else nf) for j in range(1, 6))
-                n_in_grp += 1
+                if not self.defer:
+                    if grp is None:
+                        grp = WgradGroup3()
+                        grp.flops = 0.0
+                    _, fl = rdb_wgrad_parts(grp, nf, 'model.1.sub.%d.RDB%d.conv' % (i, r), P, Gs, S, h, w, N)
+                    grp.flops += fl
+                    n_in_grp += 1
                 # g_x conv with the residual bookkeeping fused
                 Gin = next(b for b in free if b is not Grr and b is not Gout)
                 first = (ridx == 0)
@@ -590,10 +696,21 @@ class _Plan:
                 if n_in_grp >= wgb:
                     flush_wgrad()
             G = Gout
-            if i > 0 and i % bucket_every == 0:
+            if not self.defer and i > 0 and i % bucket_every == 0:
                 flush_wgrad()   # a gradient bucket is complete only when its weight gradients have been reduced
-                self._marks.append((len(ops.ops), P.off('model.1.sub.%d.RDB1.conv1.0.weight' % i)))
+                lo = P.off('model.1.sub.%d.RDB1.conv1.0.weight' % i)
+                self._marks.append((len(ops.ops), lo, self._marks[-1][1]))
         flush_wgrad()
+        rrdb0 = P.off('model.1.sub.0.RDB1.conv1.0.weight')
+        if self.defer and not self.shared_store:   # this plan owns the whole batch: the weight-gradient phase follows the chain in the same list
+            st = self.store
+            for first_op, end_op, lo, hi in st.groups:
+                ops.ops.extend(st.phase.ops[first_op:end_op])
+                self._marks.append((len(ops.ops), lo, hi))
+            ops.keep.append(st)
+            ops._arr = None
+        elif not self.defer:
+            self._marks.append((len(ops.ops), rrdb0, self._marks[-1][1]))
         # ShortcutBlock: g_fea = g_chain + g_t0
         o = Op()
         o.op = _lib.OP_AXPBY
@@ -602,7 +719,7 @@ class _Plan:
         o.t[2], o.t[3], o.f[2] = self.g_fea.view(), NULL_T, 1.0
         ops.add(o)
         self._wg(ops, 'model.0.', self.g_fea, True, self.x_in, True, nf, net.in_nc, h, w, h, w)
-        self._marks.append((len(ops.ops), 0))
+        self._marks.append((len(ops.ops), 0, rrdb0))
         self.bwd = ops
         self._segments = None
 
@@ -622,11 +739,11 @@ class _Plan:
         """backward op list cut at gradient-bucket boundaries: [(OpList, (lo, hi) of the flat grad buffer that is
         complete once the segment has run)], in execution order (the buffer fills from its end)."""
         if self._segments is None:
-            segs, prev_idx, prev_hi = [], 0, self.net.params.total
-            for idx, lo in self._marks:
+            segs, prev_idx = [], 0
+            for idx, lo, hi in self._marks:
                 ol = OpList()
                 ol.ops = self.bwd.ops[prev_idx:idx]
-                segs.append((ol, (lo, prev_hi)))
-                prev_idx, prev_hi = idx, lo
+                segs.append((ol, (lo, hi)))
+                prev_idx = idx
             self._segments = segs
         return self._segments

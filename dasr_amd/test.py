@@ -50,7 +50,7 @@ def evaluate(model, loader, opt, dataset_dir, logger, scale):
             res['psnr_y'].append(psnr_y)
             res['ssim_y'].append(ssim_y)
             if lpips is not None:
-                logger.info('{:20s} - PSNR: {:.6f} dB; SSIM: {:.6f}; PSNR_Y: {:.6f} dB; SSIM_Y: {:.6f}; LPIPS: {:.3f}.'.format(img_name, psnr, ssim, psnr_y, ssim_y, lpips))
+                logger.info('{:20s} - PSNR: {:.6f} dB; SSIM: {:.6f}; PSNR_Y: {:.6f} dB; SSIM_Y: {:.6f}; {}: {:.3f}.'.format(img_name, psnr, ssim, psnr_y, ssim_y, model.lpips_label, lpips))
             else:
                 logger.info('{:20s} - PSNR: {:.6f} dB; SSIM: {:.6f}; PSNR_Y: {:.6f} dB; SSIM_Y: {:.6f};.'.format(img_name, psnr, ssim, psnr_y, ssim_y))
         else:
@@ -89,8 +89,8 @@ def main(argv=None, loaders=None):
             summary[name] = {'psnr': ave_psnr, 'ssim': ave_ssim}
             if res['lpips']:
                 summary[name]['lpips'] = sum(res['lpips']) / len(res['lpips'])
-                logger.info('----Average PSNR/SSIM/LPIPS results for {}----\n\tPSNR: {:.6f} dB; SSIM: {:.6f}; LPIPS: {:.3f}\n'.format(
-                    name, ave_psnr, ave_ssim, summary[name]['lpips']))
+                logger.info('----Average PSNR/SSIM/{} results for {}----\n\tPSNR: {:.6f} dB; SSIM: {:.6f}; {}: {:.3f}\n'.format(
+                    model.lpips_label, name, ave_psnr, ave_ssim, model.lpips_label, summary[name]['lpips']))
             else:
                 logger.info('----Average PSNR/SSIM/LPIPS results for {}----\n\tPSNR: {:.6f} dB; SSIM: {:.6f}\n'.format(name, ave_psnr, ave_ssim))
             if res['psnr_y']:

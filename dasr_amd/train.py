@@ -105,7 +105,7 @@ def validate(model, val_set, opt, current_step, logger):
         log_info = '{}'.format(val_data['HR_path'][0].split('/')[-1])
         if opt['val_lpips']:      # train.py:194-197
             avg_lpips += float(visuals['LPIPS'])
-            log_info += '         LPIPS:{:.3f}'.format(float(visuals['LPIPS']))
+            log_info += '         {}:{:.3f}'.format(model.lpips_label, float(visuals['LPIPS']))
         logger.info(log_info)
         util.save_img(sr_img, os.path.join(img_dir, '{:s}_{:d}.png'.format(img_name, current_step)))
         if 'HR' in visuals:
@@ -202,7 +202,7 @@ def main(argv=None):
             if val_set is not None and opt['train']['val_freq'] and current_step % opt['train']['val_freq'] == 0 and rank == 0:
                 res = validate(model, val_set, opt, current_step, logger)
                 if opt['val_lpips']:   # train.py:226-228
-                    logging.getLogger('val').info('<epoch:{:3d}, iter:{:8,d}> psnr: {:.4e}, LPIPS: {:.4f}'.format(epoch, current_step, res[0], res[1]))
+                    logging.getLogger('val').info('<epoch:{:3d}, iter:{:8,d}> psnr: {:.4e}, {}: {:.4f}'.format(epoch, current_step, res[0], model.lpips_label, res[1]))
                 else:
                     logging.getLogger('val').info('<epoch:{:3d}, iter:{:8,d}> psnr: {:.4e}'.format(epoch, current_step, res))
             if current_step % opt['logger']['save_checkpoint_freq'] == 0 and rank == 0:

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DASR_ABI_VERSION 8
+#define DASR_ABI_VERSION 9
 #define DASR_EINVAL (-22)
 
 typedef struct {
@@ -194,9 +194,12 @@ int dasr_axpby(dasr_tensor x, float a, dasr_tensor z, float b, int32_t N, int32_
                const float* slope_ptr, void* stream);
 
 /* torch.optim.Adam step (DASR_model.py:129-143; SR_model.py:50-51) on flat fp32 buffers:
- * g += wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps) */
+ * g += wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * nonfinite_flag (optional, device int): bit 0 is OR-ed in when any gradient element is inf / NaN (the update itself is what torch would do);
+ * the trainers read it with their lazily synchronised log and raise -- e.g. an overflow of the f16-stored HR-tail gradients (DASR_HR_PREC=3
+ * keeps that tail in split-bf16 on f32 tensors). */
 int dasr_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-              float weight_decay, int32_t step, void* stream);
+              float weight_decay, int32_t step, int32_t* nonfinite_flag, void* stream);
 
 int dasr_fill_f32(float* p, int64_t n, float value, void* stream);
 /* y += x over flat fp32 buffers (sum of the gradient buffers of concurrently processed sub-batches) */
@@ -368,20 +371,6 @@ int dasr_rccl_destroy(void* comm);
  * static string naming the kernel variant.  Returns the number of records written (<= max_out) or a negative error. */
 int dasr_prof_begin(int32_t capacity);
 int dasr_prof_end(int32_t max_out, float* us_out, double* flops_out, double* bytes_out, int32_t* op_out, const char** tag_out);
-
-/* MFMA-only micro-benchmark (every SIMD issuing back-to-back v_mfma_f32_32x32x16_bf16): the dense bf16 rate this box sustains at
- * the clock its power state allows, in TFLOP/s; `iters` MFMA quads per wave (e.g. 20000 ~ 1.5 ms).  Synchronises the stream. */
-int dasr_probe_mfma_peak(int32_t iters, float* tflops_out, void* stream);
-/* the same MFMA-only stream with operands that toggle: mode 0 bf16 / 1 f16 fragments from a per-lane random generator, 2 all-zero bf16
- * operands; the differences are the clock the power management allows under that switching activity (scripts/micro_mfma.py) */
-int dasr_probe_mfma_data(int32_t iters, int32_t mode, float* tflops_out, void* stream);
-
-/* Neighbour-flag synchronisation micro-benchmark (scripts/micro_sync.py): `blocks` co-resident workgroups rewrite a tile of
- * `tile_words` words per stage, publish a flag, wait for two ring neighbours (`nb_stride` 8: same XCD, 1: other XCDs) and read their tiles.
- * scope 0: no synchronisation (floor), 1: agent-scope release / acquire fences, 2: workgroup-scope fences + L2-served (sc1) flag and data
- * accesses.  Returns microseconds per stage, whether a wait timed out, and the number of stale neighbour reads.  Synchronises the stream. */
-int dasr_probe_tile_sync(int32_t blocks, int32_t stages, int32_t nb_stride, int32_t scope, int32_t tile_words, float* us_per_stage,
-                         int32_t* timed_out, int32_t* stale_reads, void* stream);
 
 /* ---- diagnostics ----------------------------------------------------------------------------------*/
 int dasr_abi_version(void);

@@ -66,6 +66,7 @@ def make_opt(case):
     opt = {
         'is_train': True, 'gpu_ids': None, 'scale': 4, 'chop': False, 'val_lpips': False,
         'model': 'sr' if c['kind'] == 'sr' else 'DASR', 'multiweights': True,
+        'allow_random_perceptual': True,   # fixtures run seeded stand-ins of the pretrained VGG19 / AlexNet (they cannot be downloaded offline)
         'path': {'pretrain_model_G': None, 'pretrain_model_D_target': None, 'pretrain_model_D_source': None,
                  'models': '/tmp/dasr_golden', 'training_state': '/tmp/dasr_golden'},
         'network_G': {'which_model_G': 'RRDB_net', 'norm_type': None, 'mode': 'CNA', 'nf': c['nf'], 'nb': c['nb'],

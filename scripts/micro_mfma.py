@@ -3,7 +3,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dasr_amd import _lib
-L = _lib.lib()
+L = _lib.bench_lib()   # libdasr_bench.so (python -m dasr_amd.build --bench)
 torch.zeros(1, device='cuda')
 pk = C.c_float(0)
 for it in (9, 23, 90, 360, 3600, 20000, 90, 23, 9):

@@ -1,5 +1,5 @@
 """Cost of synchronising neighbouring workgroups through flags in global memory instead of a kernel boundary (dasr_probe_tile_sync,
-include/dasr_hip.h): the feasibility number for a persistent per-RDB kernel.
+include/dasr_hip_bench.h): the feasibility number for a persistent per-RDB kernel.
 python scripts/micro_sync.py [blocks=512] [stages=400]"""
 import ctypes as C
 import os
@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dasr_amd import _lib, engine
 engine.ensure_runtime_ready()
-L = _lib.lib()
+L = _lib.bench_lib()   # libdasr_bench.so (python -m dasr_amd.build --bench)
 blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 stages = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 us, to, stale = C.c_float(0), C.c_int32(0), C.c_int32(0)

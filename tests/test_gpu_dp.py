@@ -144,7 +144,7 @@ def _dsn_worker(rank, world, port, out):
     torch.cuda.set_device(0)
     dp = DataParallelGroup(backend='gloo') if world > 1 else None
     torch.manual_seed(0)
-    m = DSNModel(dict(filter='wavelet', w_per=0.01, vgg_seed=78))
+    m = DSNModel(dict(filter='wavelet', w_per=0.01, vgg_seed=78, allow_random_perceptual=True))
     m.netG.load_state_dict(dsn_state(m.netG.state_dict(), 21, 0.5))
     m.netD.load_state_dict(dsn_state(m.netD.state_dict(), 22, 1.0))
     if dp:

@@ -229,7 +229,7 @@ def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir):
         from oracle import lpips
         crit, sdF = lpips.golden_criterion(78, golden_dir)
     t = dsn.DSNTrainer(G, D, kernel_size=c['k'], filter_type=c['filter'], norm_layer=c['norm'], vgg_seed=78, w_per=0.01, per_type=c.get('per', 'VGG'), netF=crit, ragan=bool(c.get('ragan')))
-    m = DSNModel(dict(ragan=bool(c.get('ragan')), filter=c['filter'], kernel_size=c['k'], norm_layer=c['norm'], w_per=0.01, vgg_seed=78, per_type=c.get('per', 'VGG'), discriminator=c.get('arch', 'FSD'), generator=c.get('gen', 'DeResnet')), device=dev)
+    m = DSNModel(dict(ragan=bool(c.get('ragan')), filter=c['filter'], kernel_size=c['k'], norm_layer=c['norm'], w_per=0.01, vgg_seed=78, per_type=c.get('per', 'VGG'), discriminator=c.get('arch', 'FSD'), generator=c.get('gen', 'DeResnet'), allow_random_perceptual=True), device=dev)
     d_keys = list(m.netD.state_dict()) if c['norm'] == 'Batch' else list(m.netD.params.spec)   # BatchNorm: buffers are part of the reference layout
     assert list(m.netG.params.spec) == list(gold['G_keys']) and d_keys == list(gold['D_keys'])
     m.netG.load_state_dict(sdG)

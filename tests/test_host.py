@@ -247,3 +247,44 @@ def test_fold_batchnorm_fsd_equals_eval_mode_network(golden_dir):
         with torch.no_grad():
             want, got = D(x), plain(x)
         assert float((got - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))
+
+
+def test_product_library_has_no_probes_and_no_wrong_result_kernels():
+    """micro-benchmark probes live in libdasr_bench.so (include/dasr_hip_bench.h), the ablation instantiations of the dense conv
+    kernel (results wrong on purpose) only exist under -DDASR_BENCH (libdasr_hip_ablate.so); neither is in the product library or its header"""
+    from dasr_amd import build, _lib
+    blob = open(build.build(), 'rb').read()
+    assert blob.count(b'conv_glds_kernelILi1ELi67ELi4ELi0E') > 0          # the production instantiation is there ...
+    for abl in (1, 2, 3, 4, 7, 8, 12, 15):                                   # ... none of the ablated ones
+        assert blob.count(b'conv_glds_kernelILi1ELi67ELi4ELi%dE' % abl) == 0, abl
+    for sym in (b'dasr_probe_mfma', b'dasr_probe_tile_sync', b'mfma_peak_kernel', b'tile_sync_kernel'):
+        assert blob.count(sym) == 0, sym
+    hdr = open(os.path.join(ROOT, 'include', 'dasr_hip.h')).read()
+    assert 'dasr_probe_mfma' not in hdr and 'dasr_probe_tile_sync' not in hdr
+    bench = build.build_bench()
+    bhdr = open(os.path.join(ROOT, 'include', 'dasr_hip_bench.h')).read()
+    declared = set(re.findall(r'^\s*int\s+(dasr_\w+)\s*\(', bhdr, flags=re.M))
+    assert declared == set(_lib._BENCH_SIGS), declared ^ set(_lib._BENCH_SIGS)
+    bb = open(bench, 'rb').read()
+    for name in declared:
+        assert bb.count(name.encode()) > 0, name
+
+
+def test_perceptual_networks_refuse_to_run_seeded_without_opt_in():
+    """the reference always runs pretrained LPIPS / VGG weights; a missing weight file must not silently become a random
+    network.  load_lpips raises before touching the device; `allow_random_perceptual` is the explicit opt-in and labels the metric."""
+    from dasr_amd import lpips, dsn_train
+    with pytest.raises(FileNotFoundError):
+        lpips.load_lpips({'path': {'lpips_alexnet': None, 'lpips_lin': None}}, 'cpu')
+    with pytest.raises(FileNotFoundError):
+        lpips.load_lpips({'path': {'lpips_alexnet': None, 'lpips_lin': '/x/alex.pth'}, 'allow_random_perceptual': False}, 'cpu')
+
+    class _N:
+        seeded = True
+    assert lpips.lpips_label(_N()) == 'LPIPS(random)' and lpips.lpips_label(object()) == 'LPIPS'
+    # DSN CLI: the dataset and the opt-in are checked before any model is built
+    p = dsn_train.build_parser()
+    with pytest.raises(NotImplementedError):
+        dsn_train.check_supported(p.parse_args([]), have_loader=False)          # default --dataset df2k has no built-in loader
+    dsn_train.check_supported(p.parse_args(['--dataset', 'synthetic']), have_loader=False)
+    assert p.parse_args(['--allow_random_perceptual']).allow_random_perceptual is True and p.parse_args([]).allow_random_perceptual is False
