@@ -271,7 +271,7 @@ def setup_dist(a):
     from dasr_amd.dist import DataParallelGroup
     dp = DataParallelGroup() if world > 1 else None
     if dp:
-        torch.cuda.set_device(dp.local_rank)
+        torch.cuda.set_device(dp.device_index)
         import torch.distributed as dist
         assert dist.get_world_size() == a.gpus
     return dp

@@ -415,13 +415,19 @@ __global__ void dwt_fwd_kernel(dasr_tensor x, int N, int C, int H2, int W2, int 
     float L[16], Hh[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) L[j] = Hh[j] = 0.f;
-    const float s = norm ? 0.5f : 1.f, off = norm ? 0.5f : 0.f;
+    // norm bit 0: LL * 0.5, bands * 0.5 + 0.5; bit 1: the DSN discriminator's 'sum' format (codes/DSN/model.py:113-114): hc = (LH + HL + HH) / 3, C channels
+    const float s = (norm & 1) ? 0.5f : 1.f, off = (norm & 1) ? 0.5f : 0.f;
     for (int c = 0; c < C; ++c) {
         const float a = pa[c], b = pa[16 + c], cc = pc[c], d = pc[16 + c];
         L[c] = (a + b + cc + d) * 0.5f * s;
-        Hh[c] = (a + b - cc - d) * 0.5f * s + off;
-        Hh[C + c] = (a - b + cc - d) * 0.5f * s + off;
-        Hh[2 * C + c] = (a - b - cc + d) * 0.5f * s + off;
+        const float lh = (a + b - cc - d) * 0.5f * s + off, hl = (a - b + cc - d) * 0.5f * s + off, hh = (a - b - cc + d) * 0.5f * s + off;
+        if (norm & 2) {
+            Hh[c] = (lh + hl + hh) / 3.f;
+        } else {
+            Hh[c] = lh;
+            Hh[C + c] = hl;
+            Hh[2 * C + c] = hh;
+        }
     }
     const size_t po = ((size_t)yy * W2 + xx) * 16;
     if (ll.p) {
@@ -451,13 +457,15 @@ __global__ void dwt_bwd_kernel(dasr_tensor gll, dasr_tensor ghc, int N, int C, i
     const float* gh = ghc.p ? (const float*)ghc.p + (size_t)n * ghc.n_stride + po : nullptr;
     float* pa = (float*)gx.p + (size_t)n * gx.n_stride + ((size_t)(2 * yy) * W + 2 * xx) * 16;
     float* pc = pa + (size_t)W * 16;
-    const float s = (norm ? 0.5f : 1.f) * 0.5f;
+    const float s = ((norm & 1) ? 0.5f : 1.f) * 0.5f;
     float A[16], B[16], Cc[16], D[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) A[j] = B[j] = Cc[j] = D[j] = 0.f;
     for (int c = 0; c < C; ++c) {
         const float l = gl ? gl[c] : 0.f;
-        const float lh = gh ? gh[c] : 0.f, hl = gh ? gh[C + c] : 0.f, hh = gh ? gh[2 * C + c] : 0.f;
+        float lh, hl, hh;
+        if (norm & 2) lh = hl = hh = gh ? gh[c] * (1.f / 3.f) : 0.f;   // 'sum' format: every band receives a third of the gradient
+        else lh = gh ? gh[c] : 0.f, hl = gh ? gh[C + c] : 0.f, hh = gh ? gh[2 * C + c] : 0.f;
         A[c] = s * (l + lh + hl + hh);
         B[c] = s * (l + lh - hl - hh);
         Cc[c] = s * (l - lh + hl - hh);

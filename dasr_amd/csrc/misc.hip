@@ -135,15 +135,20 @@ __global__ void l1_loss_kernel(dasr_tensor sr, const float* __restrict__ hr, con
         for (int j = 0; j < 16; ++j) g[j] = 0.f;
         for (int c = 0; c < C; ++c) {
             const float d = s[c] - hr[(((long long)n * C + c) * H + y) * W + x];
-            part += wgt * fabsf(d);
-            g[c] = coef * wgt * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+            if (accumulate & 2) {   // nn.MSELoss (pixel_criterion 'l2', SR_model.py:33-36 / DASR_model.py:79-80)
+                part += wgt * d * d;
+                g[c] = 2.f * coef * wgt * d;
+            } else {
+                part += wgt * fabsf(d);
+                g[c] = coef * wgt * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+            }
         }
         if (grad.p) {
             float* gp = (float*)grad.p + (size_t)n * grad.n_stride + po;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 f32x4 o = {g[4 * j], g[4 * j + 1], g[4 * j + 2], g[4 * j + 3]};
-                if (accumulate) o += ((const f32x4*)gp)[j];
+                if (accumulate & 1) o += ((const f32x4*)gp)[j];
                 ((f32x4*)gp)[j] = o;
             }
         }

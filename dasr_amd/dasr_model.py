@@ -116,15 +116,16 @@ class DASR_Model(BaseModel):
             raise NotImplementedError('FS type [{:s}] not recognized.'.format(str(self.fs)))
         if self.is_train:
             self.l_pix_w = t['pixel_weight'] or 0
-            if self.l_pix_w > 0 and t['pixel_criterion'] != 'l1':
+            if self.l_pix_w > 0 and t['pixel_criterion'] not in ('l1', 'l2'):   # nn.L1Loss / nn.MSELoss (DASR_model.py:76-82)
                 raise NotImplementedError('Loss type [{:s}] not recognized.'.format(str(t['pixel_criterion'])))
+            self.pix_l2 = t['pixel_criterion'] == 'l2'   # used by the plain pixel term and the LL term; the multiweights pixel term is |.| always (:213-215)
             self.l_pix_LL_w = t['pixel_LL_weight'] or 0
             self.sup_LL = bool(t['sup_LL']) and self.l_pix_w > 0
             self.l_fea_w = t['feature_weight'] or 0
             self.netF = None
             self.l_fea_type = t['feature_criterion']
             if self.l_fea_w > 0:
-                if self.l_fea_type == 'l1':                                  # VGG19-54 feature L1 (DASR_model.py:93-94,105-106)
+                if self.l_fea_type in ('l1', 'l2'):                          # VGG19-54 feature L1 / MSE (DASR_model.py:93-96,105-106)
                     self.netF = VGGFeatureHIP(34, device=self.device)
                     pf = opt['path']['pretrain_model_F']
                     if pf:
@@ -379,7 +380,7 @@ class _StepPlan:
             cnt = float(n * 3 * H * W)
             o.t[0], o.p[0] = g.sr.view(), self.hr_nchw.data_ptr()
             o.p[1] = self.wmap.data_ptr() if m.multiweights else None
-            o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = n, 3, H, W, 1
+            o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = n, 3, H, W, 1 | (2 if (m.pix_l2 and not m.multiweights) else 0)
             # multiweights: l_g_pix = w * mean(W|d|) and total += w * l_g_pix  (DASR_model.py:213-218)
             self.pix_log_div = 1.0
             if m.multiweights:
@@ -438,7 +439,7 @@ class _StepPlan:
         if m.sup_LL:
             o = add(fwd, _op(_lib.OP_L1DIFF))
             cnt = float(n * 3 * Hd * Wd)
-            o.t[0], o.t[1], o.i[4] = self.fake_low.view(), self.real_low.view(), 1
+            o.t[0], o.t[1], o.i[4] = self.fake_low.view(), self.real_low.view(), 1 | (2 if m.pix_l2 else 0)
             o.i[0], o.i[1], o.i[2], o.i[3] = n, 3, Hd, Wd
             o.f[0], o.f[1], o.p[0], o.t[2] = 1.0 / cnt, float(m.l_pix_LL_w) / cnt, acc + 4 * A_LL, self.g_low.view()
         # VGG feature loss (source half): batch [fake_s; real_s]
@@ -466,7 +467,7 @@ class _StepPlan:
             o = add(fwd, _op(_lib.OP_L1DIFF))
             f = v.feat
             cnt = float(n * f.C * f.H * f.W)
-            o.t[0], o.t[1], o.i[4] = f.view(), _nview(f, n), 1
+            o.t[0], o.t[1], o.i[4] = f.view(), _nview(f, n), 1 | (2 if m.l_fea_type == 'l2' else 0)
             o.i[0], o.i[1], o.i[2], o.i[3] = n, f.C, f.H, f.W
             o.f[0], o.f[1], o.p[0], o.t[2] = 1.0 / cnt, float(m.l_fea_w) / cnt, acc + 4 * A_FEA, v.g_feat.view()
         # discriminator forward on [fake_t; real_t] and the generator's GAN loss

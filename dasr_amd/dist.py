@@ -20,13 +20,20 @@ class DataParallelGroup:
         self.world = int(os.environ.get('WORLD_SIZE', '1'))
         self.rank = int(os.environ.get('RANK', '0'))
         self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-        self.backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+        # DASR_DP_BACKEND=gloo: the exchange through gloo on device tensors instead of RCCL -- what makes a TWO-rank run of the real launcher
+        # path possible on a one-GPU box (RCCL refuses two ranks on one device); the ranks then share devices round-robin (device_index)
+        self.backend = backend or os.environ.get('DASR_DP_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         self.force = bool(force)
+        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if self.backend == 'nccl' and ndev and self.local_rank >= ndev:
+            raise RuntimeError('LOCAL_RANK %d but only %d visible device(s): one process per GPU (RCCL cannot share a device between ranks; '
+                               'DASR_DP_BACKEND=gloo does, for tests)' % (self.local_rank, ndev))
+        self.device_index = self.local_rank % ndev if ndev else 0
         if (self.world > 1 or force) and not dist.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
             if self.backend == 'nccl':
-                torch.cuda.set_device(self.local_rank)
+                torch.cuda.set_device(self.device_index)
             dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
         self.comm_stream = torch.cuda.Stream() if (self.backend == 'nccl' and torch.cuda.is_available()) else None
         self.pending = []

@@ -269,7 +269,7 @@ class DSNModel:
     def __init__(self, opt=None, device=None, **kw):
         o = dict(n_res_blocks=8, kernel_size=5, filter='gau', norm_layer='Instance', discriminator='FSD', generator='DeResnet', learning_rate=1e-4,
                  adam_beta_1=0.5, w_col=1.0, w_tex=0.005, w_per=0.01, per_type='VGG', vgg_path=None, vgg_seed=78, num_epochs=400,
-                 num_decay_epochs=150, upscale_factor=4, ragan=False, allow_random_perceptual=False)
+                 num_decay_epochs=150, upscale_factor=4, ragan=False, allow_random_perceptual=False, cat_or_sum='cat')
         o.update(opt or {})
         o.update(kw)
         self.opt = o
@@ -311,7 +311,11 @@ class DSNModel:
         if o['generator'].lower() not in ('deresnet', 'dsgan'):   # codes/DSN/train.py:124-129
             raise NotImplementedError('Generator model [{:s}] not recognized'.format(o['generator']))
         self.netG = DeResnetHIP(o['n_res_blocks'], device=self.device, scale=4 if o['generator'].lower() == 'deresnet' else 1)
-        nc = 9 if self.filter == 'wavelet' else 3
+        self.cs = str(o['cat_or_sum']).lower()   # wavelet bands of the discriminator input: 'cat' (9 channels) or 'sum' = (LH + HL + HH) / 3 (model.py:108-118)
+        if self.cs not in ('cat', 'sum'):
+            raise NotImplementedError('Wavelet format [{:s}] not recognized'.format(str(o['cat_or_sum'])))
+        self.dwt_norm = 1 | (2 if self.cs == 'sum' else 0)   # dasr_dwt_fwd / _bwd `norm` flags of the discriminator front end
+        nc = 9 if (self.filter == 'wavelet' and self.cs == 'cat') else 3
         gk = self.k if self.filter == 'gau' else None
         self.netD_eval = None
         if self.d_arch == 'fsd':
@@ -519,7 +523,7 @@ class _DSNPlan:
         for src, n0 in ((g.fake, 0), (self.real_b, N)):
             if wav:
                 o = _op(_lib.OP_DWT_FWD)
-                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[1], o.t[2] = src.view(), N, 3, hd, wd, 1, NULL_T, _nview(d.x, n0)
+                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[1], o.t[2] = src.view(), N, 3, hd, wd, m.dwt_norm, NULL_T, _nview(d.x, n0)
             else:
                 o = _op(_lib.OP_LOWPASS)
                 o.t[0], o.t[1], o.p[0], o.i[4] = src.view(), NULL_T, m.fw.data_ptr(), k
@@ -618,7 +622,7 @@ class _DSNPlan:
         gb.add(o)
         if wav:
             o = _op(_lib.OP_DWT_BWD)
-            o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[2], o.i[5] = self.g_col.view(), d.gx.view(), N, 3, hd, wd, 1, g.g_fake.view(), 1
+            o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[2], o.i[5] = self.g_col.view(), d.gx.view(), N, 3, hd, wd, m.dwt_norm, g.g_fake.view(), 1
             gb.add(o)
         else:
             o = _op(_lib.OP_LOWPASS)   # adjoint of the high-pass front end
@@ -699,7 +703,7 @@ class _InferPlan:
             self.src = src
         if wav:
             o = _op(_lib.OP_DWT_FWD)
-            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[1], o.t[2] = src.view(), N, 3, hd, wd, 1, NULL_T, d.x.view()
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[1], o.t[2] = src.view(), N, 3, hd, wd, m.dwt_norm, NULL_T, d.x.view()
         else:
             o = _op(_lib.OP_LOWPASS)
             o.t[0], o.t[1], o.p[0], o.i[4] = src.view(), NULL_T, m.fw.data_ptr(), m.k

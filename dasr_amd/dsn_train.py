@@ -84,7 +84,7 @@ def check_supported(o, have_loader=True):
         raise NotImplementedError('--lpips_rot_flip (random rotations / flips in front of LPIPS, loss.py:97-110) is not on the MI355X path')
     if o.wgan:
         raise NotImplementedError('--wgan needs a gradient penalty (train.py:231-236: a second-order pass through D); not on the MI355X path')
-    if not o.highpass or o.cat_or_sum != 'cat' or o.norm_layer not in ('Instance', 'Batch') or (o.norm_layer == 'Batch' and o.discriminator.lower() != 'fsd'):
+    if not o.highpass or o.cat_or_sum not in ('cat', 'sum') or o.norm_layer not in ('Instance', 'Batch') or (o.norm_layer == 'Batch' and o.discriminator.lower() != 'fsd'):
         raise NotImplementedError('DSN on MI355X covers: high-pass front end, wavelet bands cat, Instance norm (FSD also Batch norm)')
     if o.disc_freq != 1 or o.gen_freq != 1:
         raise NotImplementedError('disc_freq / gen_freq other than 1')
@@ -115,13 +115,13 @@ def main(argv=None, loader=None):
     dp = DataParallelGroup() if int(os.environ.get('WORLD_SIZE', '1')) > 1 else None
     rank = dp.rank if dp else 0
     if dp:
-        torch.cuda.set_device(dp.local_rank)
+        torch.cuda.set_device(dp.device_index)
     if o.debug:
         o.num_epochs, o.iters_per_epoch = min(o.num_epochs, 2), min(o.iters_per_epoch, 3)
     opt = dict(n_res_blocks=o.num_res_blocks, kernel_size=o.kernel_size, filter=o.filter, norm_layer=o.norm_layer, discriminator=o.discriminator,
                learning_rate=o.learning_rate, adam_beta_1=o.adam_beta_1, w_col=o.w_col, w_tex=o.w_tex, w_per=o.w_per if o.use_per_loss else 0.0,
                per_type=o.per_type, generator=o.generator, vgg_path=o.vgg_path, lpips_alexnet=o.lpips_alexnet, lpips_lin=o.lpips_lin, num_epochs=o.num_epochs, num_decay_epochs=o.num_decay_epochs,
-               upscale_factor=o.upscale_factor, ragan=o.ragan, allow_random_perceptual=o.allow_random_perceptual)
+               upscale_factor=o.upscale_factor, ragan=o.ragan, allow_random_perceptual=o.allow_random_perceptual, cat_or_sum=o.cat_or_sum)
     model = DSNModel(opt)
     if dp:
         model.dp = dp

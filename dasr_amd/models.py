@@ -192,8 +192,9 @@ class SRModel(BaseModel):
         self.netG = _define_G(opt, self.device)
         self.load()
         if self.is_train:
-            if t['pixel_criterion'] != 'l1':
+            if t['pixel_criterion'] not in ('l1', 'l2'):   # nn.L1Loss / nn.MSELoss (SR_model.py:31-37)
                 raise NotImplementedError('Loss type [{:s}] is not recognized.'.format(str(t['pixel_criterion'])))
+            self.pix_l2 = t['pixel_criterion'] == 'l2'
             self.l_pix_w = t['pixel_weight']
             wd = t['weight_decay_G'] if t['weight_decay_G'] else 0
             self.optimizer_G = AdamHIP(self.netG.params, t['lr_G'], (0.9, 0.999), wd)
@@ -220,7 +221,7 @@ class SRModel(BaseModel):
             o = Op()
             o.op = _lib.OP_L1LOSS
             o.t[0], o.p[0], o.p[1] = plan.sr.view(), hr_buf.data_ptr(), None
-            o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = N, C_, H, W, 0
+            o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = N, C_, H, W, (2 if self.pix_l2 else 0)
             o.f[0] = float(self.l_pix_w) / float(n_total * C_ * H * W)
             o.p[2], o.t[1] = self.loss_acc.data_ptr(), plan.g_sr.view()
             ops.add(o)

@@ -140,7 +140,7 @@ def main(argv=None):
     dp = DataParallelGroup() if int(os.environ.get('WORLD_SIZE', '1')) > 1 else None
     rank = dp.rank if dp else 0
     if dp:
-        torch.cuda.set_device(dp.local_rank)
+        torch.cuda.set_device(dp.device_index)
     resume_state = None
     if opt['path']['resume_state']:
         resume_state = torch.load(opt['path']['resume_state'], weights_only=False)

@@ -166,7 +166,9 @@ int dasr_blocked_to_nchw(dasr_tensor src, int32_t N, int32_t C, int32_t H, int32
 /* L1 pixel loss of SRModel (codes/SRN/models/SR_model.py:80) / DASR_Model (DASR_model.py:212-222):
  *   loss_acc[0] += coef * sum wm*|sr - hr|,   grad (blocked f32, zero beyond C) (+)= coef * wm * sign(sr - hr)
  * coef = weight / element count is computed by the caller; `weight_map` (NCHW [N][1][H][W]) is the optional
- * domain-distance map of the multiweights pixel loss (DASR_model.py:213-215). */
+ * domain-distance map of the multiweights pixel loss (DASR_model.py:213-215).
+ * accumulate bit 0: grad += instead of grad =; bit 1: squared error (nn.MSELoss, pixel_criterion 'l2', SR_model.py:33-36):
+ * loss_acc[0] += coef * sum wm*(sr - hr)^2, grad (+)= 2 coef wm (sr - hr). */
 int dasr_l1_loss(dasr_tensor sr, const float* hr_nchw, const float* weight_map, int32_t N, int32_t C, int32_t H, int32_t W,
                  float coef, float* loss_acc, dasr_tensor grad, int32_t accumulate, void* stream);
 

@@ -133,15 +133,18 @@ class NLayerDiscriminatorDSN(nn.Module):
 class Discriminator(nn.Module):
     """Discriminator(D_arch='FSD' | 'nld_s1' | 'nld_s2') with the frequency-separation front end (model.py:60-118); output = sigmoid"""
 
-    def __init__(self, kernel_size=5, norm_layer='Instance', filter_type='gau', D_arch='FSD'):
+    def __init__(self, kernel_size=5, norm_layer='Instance', filter_type='gau', D_arch='FSD', cs='cat'):
         super().__init__()
         self.filter_type = filter_type.lower()
+        self.cs = cs.lower()
+        if self.cs not in ('cat', 'sum'):
+            raise NotImplementedError('Wavelet format [{:s}] not recognized'.format(cs))   # model.py:117-118
         nc = 3
         if self.filter_type in ('gau', 'avg_pool'):
             self.filter = FilterHigh(kernel_size, include_pad=False, gaussian=self.filter_type == 'gau')
         elif self.filter_type == 'wavelet':
             self.dwt = nets.HaarDWT()
-            nc = 9
+            nc = 9 if self.cs == 'cat' else 3   # model.py:78
         else:
             raise NotImplementedError('Frequency Separation type [{:s}] not recognized'.format(filter_type))
         if D_arch.lower() == 'fsd':
@@ -154,7 +157,11 @@ class Discriminator(nn.Module):
 
     def front(self, x):
         if self.filter_type == 'wavelet':
-            return self.dwt(x)[1] * 0.5 + 0.5   # cat(LH, HL, HH), normalised (model.py:108-118)
+            hc = self.dwt(x)[1] * 0.5 + 0.5   # cat(LH, HL, HH), normalised (model.py:108-118)
+            if self.cs == 'sum':               # (LH + HL + HH) / 3 (model.py:113-114)
+                c = hc.shape[1] // 3
+                return (hc[:, :c] + hc[:, c:2 * c] + hc[:, 2 * c:]) / 3.
+            return hc
         return self.filter(x)
 
     def forward(self, x, y=None):

@@ -36,6 +36,12 @@ CASES = OrderedDict([
     ('dasr_lsgan_wavelet_nf32_nb1_n2_32', dict(kind='dasr', nf=32, nb=1, n=2, lr=32, fs='wavelet', d_in_nc=9, gan_src=0.02, gan_type='lsgan')),
     ('dasr_ragan_lsgan_wavelet_nf32_nb1_n3_32', dict(kind='dasr', nf=32, nb=1, n=3, lr=32, fs='wavelet', d_in_nc=9, gan_src=0.02, ragan=True, gan_type='lsgan')),
     ('dasr_wgan_gau9_nf32_nb1_n2_32', dict(kind='dasr', nf=32, nb=1, n=2, lr=32, fs='gau', d_in_nc=3, gan_src=0.02, gan_type='wgan-gp')),
+    # round 3: pixel_criterion / feature_criterion 'l2' = nn.MSELoss (SR_model.py:33-36, DASR_model.py:79-80,95-96); multiweights off so that the
+    # plain pixel term really goes through cri_pix (with multiweights the reference hard-codes |.|, DASR_model.py:213-215)
+    ('sr_l2_nf32_nb1_b2_32', dict(kind='sr', nf=32, nb=1, n=2, lr=32, pix='l2')),
+    ('dasr_l2_wavelet_nf32_nb1_n2_32', dict(kind='dasr', nf=32, nb=1, n=2, lr=32, fs='wavelet', d_in_nc=9, pix='l2', fea='l2', multiweights=False)),
+    # round 3: the GAN step at the full ESRGAN depth (nb = 23; n = 1 -> 2 crops through G)
+    ('dasr_wavelet_nf64_nb23_n1_32', dict(kind='dasr', nf=64, nb=23, n=1, lr=32, fs='wavelet', d_in_nc=9)),
 ])
 
 
@@ -65,14 +71,14 @@ def make_opt(case):
     c = CASES[case] if isinstance(case, str) else case
     opt = {
         'is_train': True, 'gpu_ids': None, 'scale': 4, 'chop': False, 'val_lpips': False,
-        'model': 'sr' if c['kind'] == 'sr' else 'DASR', 'multiweights': True,
+        'model': 'sr' if c['kind'] == 'sr' else 'DASR', 'multiweights': bool(c.get('multiweights', True)),
         'allow_random_perceptual': True,   # fixtures run seeded stand-ins of the pretrained VGG19 / AlexNet (they cannot be downloaded offline)
         'path': {'pretrain_model_G': None, 'pretrain_model_D_target': None, 'pretrain_model_D_source': None,
                  'models': '/tmp/dasr_golden', 'training_state': '/tmp/dasr_golden'},
         'network_G': {'which_model_G': 'RRDB_net', 'norm_type': None, 'mode': 'CNA', 'nf': c['nf'], 'nb': c['nb'],
                       'in_nc': 3, 'out_nc': 3, 'gc': 32, 'scale': 4, 'upsample_mode': c.get('upsample_mode')},
         'train': {'lr_G': 1e-4, 'weight_decay_G': 0, 'beta1_G': 0.9, 'lr_scheme': 'MultiStepLR',
-                  'lr_steps': [2, 4], 'lr_gamma': 0.5, 'pixel_criterion': 'l1', 'pixel_weight': 1.0,
+                  'lr_steps': [2, 4], 'lr_gamma': 0.5, 'pixel_criterion': c.get('pix', 'l1'), 'pixel_weight': 1.0,
                   'manual_seed': 0},
     }
     if c['kind'] == 'dasr':

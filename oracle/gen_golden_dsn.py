@@ -33,6 +33,8 @@ DSN_CASES = {
     # --norm_layer Batch (model.py:176-189): BatchNorm2d in training mode, statistics per discriminator call (the layout of the reference's test.tar)
     'dsn_gau5_batch_b2_128': dict(filter='gau', k=5, norm='Batch', n=2, crop=128),
     'dsn_avg5_batch_b3_128_ragan': dict(filter='avg_pool', k=5, norm='Batch', n=3, crop=128, ragan=True),
+    # --cat_or_sum sum (round 3; model.py:113-114): the discriminator sees (LH + HL + HH) / 3, three channels instead of nine
+    'dsn_wavelet_sum_inst_b2_128': dict(filter='wavelet', k=5, norm='Instance', n=2, crop=128, cs='sum'),
 }
 
 
@@ -108,7 +110,7 @@ def main():
             continue
         torch.manual_seed(0)
         G = rmodel.Generator(n_res_blocks=8) if c.get('gen') == 'DSGAN' else rmodel.De_resnet(n_res_blocks=8, scale=4)
-        D = rmodel.Discriminator(kernel_size=c['k'], D_arch=c.get('arch', 'FSD'), norm_layer=c['norm'], filter_type=c['filter'], cs='cat')
+        D = rmodel.Discriminator(kernel_size=c['k'], D_arch=c.get('arch', 'FSD'), norm_layer=c['norm'], filter_type=c['filter'], cs=c.get('cs', 'cat'))
         G.load_state_dict(dsn_state(G.state_dict(), 21, 0.5))
         D.load_state_dict(dsn_state(D.state_dict(), 22, 1.0))
         _cuda = nn.Module.cuda

@@ -135,7 +135,7 @@ def test_rccl_exchange_path_single_rank(streams, native, tmp_path):
         assert torch.equal(v, b['G'][k]), k
 
 
-def _dsn_worker(rank, world, port, out):
+def _dsn_worker(rank, world, port, out, ragan=False):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     import torch
     from dasr_amd.dist import DataParallelGroup
@@ -144,7 +144,7 @@ def _dsn_worker(rank, world, port, out):
     torch.cuda.set_device(0)
     dp = DataParallelGroup(backend='gloo') if world > 1 else None
     torch.manual_seed(0)
-    m = DSNModel(dict(filter='wavelet', w_per=0.01, vgg_seed=78, allow_random_perceptual=True))
+    m = DSNModel(dict(filter='wavelet', w_per=0.01, vgg_seed=78, allow_random_perceptual=True, ragan=ragan))
     m.netG.load_state_dict(dsn_state(m.netG.state_dict(), 21, 0.5))
     m.netD.load_state_dict(dsn_state(m.netD.state_dict(), 22, 1.0))
     if dp:
@@ -152,9 +152,11 @@ def _dsn_worker(rank, world, port, out):
         for net in m.networks():
             dp.broadcast_params(net.params.flat)
             net.repack()
-    hr, bic, real = dsn_batch(dict(n=2, crop=128))  # VGG16's five pools need >= 32 px LR
+    n = 4 if ragan else 2   # relativistic: two samples per rank, so the GLOBAL batch means differ from the per-rank ones
+    hr, bic, real = dsn_batch(dict(n=n, crop=128))  # VGG16's five pools need >= 32 px LR
     if dp:
-        hr, bic, real = (t[rank:rank + 1] for t in (hr, bic, real))
+        per = n // world
+        hr, bic, real = (t[rank * per:(rank + 1) * per] for t in (hr, bic, real))
     for _ in range(2):
         m.iteration(hr.cuda(), bic.cuda(), real.cuda())
     torch.cuda.synchronize()
@@ -163,19 +165,24 @@ def _dsn_worker(rank, world, port, out):
         dp.barrier()
 
 
-def test_dsn_two_rank_iteration_equals_full_batch(tmp_path):
+@pytest.mark.parametrize('ragan', [False, True], ids=['plain', 'ragan'])
+def test_dsn_two_rank_iteration_equals_full_batch(ragan, tmp_path):
+    """ragan (round 3): D(x, y) = sigmoid(D(x) - mean_n D(y)) couples the samples; under data parallelism the per-pixel batch sums are all-reduced
+    between the loss stages (dsn_model.py::iteration), so two ranks with two samples each must reproduce the four-sample step"""
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     import torch.multiprocessing as mp
     out = str(tmp_path / 'dsn_w%d_r%d.pt')
-    port = 29911 + (os.getpid() % 300)
-    mp.spawn(_dsn_worker, args=(1, port, out), nprocs=1, join=True)
-    mp.spawn(_dsn_worker, args=(2, port + 1, out), nprocs=2, join=True)
+    port = 29911 + (os.getpid() % 300) + 2 * int(ragan)
+    mp.spawn(_dsn_worker, args=(1, port, out, ragan), nprocs=1, join=True)
+    mp.spawn(_dsn_worker, args=(2, port + 1, out, ragan), nprocs=2, join=True)
     full = torch.load(out % (1, 0))
     r0, r1 = torch.load(out % (2, 0)), torch.load(out % (2, 1))
     for net in ('G', 'D'):
         for k, v in full[net].items():
             assert torch.equal(r0[net][k], r1[net][k]), (net, k)
+            if ragan and k == 'net.net.8.bias':
+                continue  # relativistic loss: shifting every logit changes nothing, the true gradient of the last bias is 0
             if k in ('net.net.2.bias', 'net.net.5.bias'):
                 continue  # bias in front of an InstanceNorm: true gradient 0, Adam turns the rounding noise into +-lr steps (no effect on D)
             d = (r0[net][k] - v).abs().max().item()

@@ -210,7 +210,7 @@ def test_deresnet_forward_backward():
 
 @pytest.mark.parametrize('case', ['dsn_gau5_inst_b2_128', 'dsn_wavelet_inst_b2_128', 'dsn_avg5_inst_b1_160', 'dsn_gau5_inst_b1_256_lpips',
                                   'dsn_wavelet_nld_s2_b2_128', 'dsn_gau5_nld_s1_b1_128', 'dsn_dsgan_gau5_inst_b2_128', 'dsn_gau5_inst_b3_128_ragan',
-                                  'dsn_gau5_batch_b2_128', 'dsn_avg5_batch_b3_128_ragan'])
+                                  'dsn_gau5_batch_b2_128', 'dsn_avg5_batch_b3_128_ragan', 'dsn_wavelet_sum_inst_b2_128'])
 def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir):
     dev = _gpu()
     torch.set_num_threads(8)
@@ -220,7 +220,7 @@ def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir):
     c = DSN_CASES[case]
     gold = np.load(os.path.join(golden_dir, case + '.npz'))
     G = dsn.GeneratorDSGAN() if c.get('gen') == 'DSGAN' else dsn.DeResnet()
-    D = dsn.Discriminator(c['k'], c['norm'], c['filter'], D_arch=c.get('arch', 'FSD'))
+    D = dsn.Discriminator(c['k'], c['norm'], c['filter'], D_arch=c.get('arch', 'FSD'), cs=c.get('cs', 'cat'))
     sdG, sdD = dsn_state(G.state_dict(), 21, 0.5), dsn_state(D.state_dict(), 22, 1.0)
     G.load_state_dict(sdG)
     D.load_state_dict(sdD)
@@ -229,7 +229,7 @@ def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir):
         from oracle import lpips
         crit, sdF = lpips.golden_criterion(78, golden_dir)
     t = dsn.DSNTrainer(G, D, kernel_size=c['k'], filter_type=c['filter'], norm_layer=c['norm'], vgg_seed=78, w_per=0.01, per_type=c.get('per', 'VGG'), netF=crit, ragan=bool(c.get('ragan')))
-    m = DSNModel(dict(ragan=bool(c.get('ragan')), filter=c['filter'], kernel_size=c['k'], norm_layer=c['norm'], w_per=0.01, vgg_seed=78, per_type=c.get('per', 'VGG'), discriminator=c.get('arch', 'FSD'), generator=c.get('gen', 'DeResnet'), allow_random_perceptual=True), device=dev)
+    m = DSNModel(dict(ragan=bool(c.get('ragan')), filter=c['filter'], kernel_size=c['k'], norm_layer=c['norm'], w_per=0.01, vgg_seed=78, per_type=c.get('per', 'VGG'), discriminator=c.get('arch', 'FSD'), generator=c.get('gen', 'DeResnet'), allow_random_perceptual=True, cat_or_sum=c.get('cs', 'cat')), device=dev)
     d_keys = list(m.netD.state_dict()) if c['norm'] == 'Batch' else list(m.netD.params.spec)   # BatchNorm: buffers are part of the reference layout
     assert list(m.netG.params.spec) == list(gold['G_keys']) and d_keys == list(gold['D_keys'])
     m.netG.load_state_dict(sdG)
