@@ -148,8 +148,25 @@ def roofline_from_step(run_step, peak_measured, streams, nsteps=1):
                       'average launch duration; headline = kernel with the largest total time; with streams > 1 launches of the sub-batch '
                       'streams overlap (kernel_time_over_wall = sum of launch durations / step wall time), so the chip-level rate of a kernel '
                       'is up to that factor above its per-launch rate',
-            'mfma_busy_pmc': busy, 'per_kernel': out[:8], 'truncated': truncated}
+            'mfma_busy_pmc': busy, 'per_kernel': out[:8], 'truncated': truncated,
+            # algorithmic FLOPs of the whole profiled step (sum over all MFMA launches of what the plan builder attributes to each op)
+            'tflop_per_step': round(sum(r['flops'] for r in rows.values()) / nsteps / 1e12, 3),
+            'profiled_step_ms': round(wall * 1e3 / nsteps, 2)}
     return roof
+
+
+def secondary_roofline(run_step, streams):
+    """roofline block of a secondary workload (configs[2] / configs[4]): the same live per-launch measurement as the headline, trimmed: the dominant
+    kernel's per-launch rate, the six largest kernels, the algorithmic FLOPs of the step and the step-level fraction of the dense bf16 peak"""
+    r = roofline_from_step(run_step, None, streams)
+    keep = ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel', 'avg_launch_us', 'flops_per_launch', 'kernel_time_over_wall', 'non_mfma_kernel_time_share',
+            'tflop_per_step', 'profiled_step_ms')
+    out = {k: r.get(k) for k in keep}
+    out['traffic'] = None   # no PMC pass committed for the secondary workloads' kernels
+    out['per_kernel'] = r['per_kernel'][:6]
+    if r.get('tflop_per_step') and r.get('profiled_step_ms'):
+        out['mfma_util_step'] = round(r['tflop_per_step'] / (r['profiled_step_ms'] * 1e-3) / PEAK_BF16_TFLOPS, 4)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -323,6 +340,10 @@ def bench_dsn(a, dp, as_secondary=False):
            'generator_tflops': round(ips * tf, 1)}
     if not as_secondary:
         out['log'] = m.get_current_log()
+    if rank == 0:
+        out['roofline'] = secondary_roofline(lambda: m.iteration(hr, bic, real), 1)
+    else:
+        m.iteration(hr, bic, real)
     return out
 
 
@@ -399,6 +420,11 @@ def bench_srn(a, dp, dasr, as_secondary=False):
         log('roofline done')
     elif not as_secondary:
         one_step()  # the other ranks take part in the profiled step's collectives
+    if as_secondary:
+        if rank == 0:
+            out['roofline'] = secondary_roofline(one_step, len(getattr(model, '_out_plans', None) or [0]))
+        else:
+            one_step()
     if not as_secondary and not dasr and streams_default() > 1 and not a.no_secondary:
         # (skipped with --no-secondary = the rocprofv3 / PMC runs, so profiles/*.csv hold launches of the production schedule only)
         # the same step with ONE stream (every launch covers the whole per-GPU batch and has the chip to itself): the per-launch rates of
@@ -479,7 +505,7 @@ def main():
                    lambda: bench_srn(sec_l, dp, True, as_secondary=True), lambda: bench_dsn(sec_l, dp, as_secondary=True)):
             try:
                 r = fn()
-                out['secondary'].append({k: r[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'dtype', 'config')})
+                out['secondary'].append({k: r[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'dtype', 'config', 'roofline') if k in r})
             except Exception as e:  # a secondary measurement must not take the headline line down
                 out['secondary'].append({'error': repr(e)})
         log('secondary done')

@@ -334,13 +334,16 @@ struct W3 {
 // 768 threads (register prefetch one tile ahead; per-thread piece geometry is computed once), then per pixel row r and tap:
 // A = G^T fragment [oc][16 pixels], B = X fragment [16 pixels shifted by the tap][cin], both gathered with ds_read_b64_tr_b16.
 // F16: the 16-bit tensors hold f16 (HR tail of the generator in f16 storage, gradients pre-scaled by a power of two): f16 MFMA
-template <bool USE_TR, bool F32, bool F16 = false>
+// ABL (instantiated != 0 only under -DDASR_BENCH = libdasr_hip_ablate.so; WRONG results, timing only): bit 0 no LDS commit / barriers after the first
+// tile, 1 no fragment reads after the first, 2 no MFMA, 3 no global prefetch -- what does each component of a tile cost?
+template <bool USE_TR, bool F32, bool F16 = false, int ABL = 0>
 __global__ __launch_bounds__(768, 1) void wgrad3_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit_flags,
                                                         float* __restrict__ ws) {
     static_assert(!F16 || !F32, "wgrad3 F16: 16-bit f16 tensors");
     using C = W3;
     const int nsplit = nsplit_flags & 0xffff;
     const bool g_stagger_flag = (nsplit_flags >> 24) & 1;  // A/B: staggered in-compute prefetch issue
+    constexpr int abl = ABL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* gl = smem;
     char* il = smem + C::G_BYTES;
@@ -461,14 +464,18 @@ __global__ __launch_bounds__(768, 1) void wgrad3_kernel(const dasr_wgrad_part* _
                 const int o = ibase + (ky * C::IW + kx) * 32;
                 b[0] = frag_tr(il, o, o + 4 * 32);
             }
+            if constexpr (abl & 2) {
+                a[1] = a[0];
+                b[1] = b[0];
+            }
             const int pf_step = next_tile >= 0 ? 5 * pair : -1;
 #pragma unroll
             for (int i = 0; i < C::PH * NA; ++i) {
                 const int r = i / NA, t = T0 + (i - r * NA);
                 if (i % 5 == 0 && i <= 25) {
-                    if (i == pf_step) prefetch(next_tile);
+                    if (i == pf_step && !(abl & 8)) prefetch(next_tile);
                 }
-                if (i + 1 < C::PH * NA) {
+                if (i + 1 < C::PH * NA && !(abl & 2)) {
                     const int r1 = (i + 1) / NA, t1 = T0 + ((i + 1) - r1 * NA);
                     const int ky1 = t1 / 3, kx1 = t1 - ky1 * 3;
                     const int o1 = ibase + ((r1 + ky1) * C::IW + kx1) * 32;
@@ -479,7 +486,8 @@ __global__ __launch_bounds__(768, 1) void wgrad3_kernel(const dasr_wgrad_part* _
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                acc[t - T0] = mfma16<F16>(a[r & 1], b[i & 1], acc[t - T0]);
+                if constexpr (!(abl & 4)) acc[t - T0] = mfma16<F16>(a[r & 1], b[i & 1], acc[t - T0]);
+                else asm volatile("" ::"v"(a[r & 1]), "v"(b[i & 1]));
                 if constexpr (!F32 && T0 == 0) {
                     if (t == 2 && P.want_bias && ct == 0) {
 #pragma unroll
@@ -520,15 +528,17 @@ __global__ __launch_bounds__(768, 1) void wgrad3_kernel(const dasr_wgrad_part* _
     int it = 0;
     for (int tile = split; tile < ntiles; tile += nsplit, ++it) {
         if (it == 2) WTRACE(2);
-        __syncthreads();
-        if (it == 2) WTRACE(3);
-        commit();
-        if (it == 2) WTRACE(4);
-        __syncthreads();
+        if (!(abl & 1) || it == 0) {
+            __syncthreads();
+            if (it == 2) WTRACE(3);
+            commit();
+            if (it == 2) WTRACE(4);
+            __syncthreads();
+        }
         if (it == 2) WTRACE(5);
         const int next_tile = tile + nsplit < ntiles ? tile + nsplit : -1;
         const bool stagger = USE_TR && active && g_stagger_flag;
-        if (next_tile >= 0 && !stagger) prefetch(next_tile);
+        if (next_tile >= 0 && !stagger && !(abl & 8)) prefetch(next_tile);
         if (it == 2) WTRACE(6);
         if (!active) continue;
         if (th == 0) compute(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{}, stagger ? next_tile : -1);
@@ -593,6 +603,17 @@ __global__ __launch_bounds__(768, 1) void wgrad3_kernel(const dasr_wgrad_part* _
 // current tile is multiplied: no staging registers, no ds_write, one barrier per tile.  48 one-KiB DMA instructions per tile
 // (6 G planes x 4, 4 X planes x 6), four per wave; each lane's source address is tile origin + a per-lane constant.
 // ---------------------------------------------------------------------------------------------------
+// One LDS-DMA instruction (64 lanes x 16 bytes -> 1 KiB of LDS at `lds_addr`, lane l at +16 l) issued through inline assembly.
+// Why not __builtin_amdgcn_raw_ptr_buffer_load_lds here: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 that
+// follows a pending LDS-DMA in program order (the transpose-read intrinsic carries no memory operand, so the waitcnt pass must assume it reads
+// what the DMA writes) -- with the DMA of the NEXT tile issued between the fragment reads of the current one, every k-step then waited for a full
+// global round trip (first wgrad4 build: 3.4 ms per launch instead of 2.2).  Issued from assembly WITHOUT a "memory" clobber (with one, the waitcnt
+// pass treats the statement itself as a pending vector-memory access and waits just the same) the compiler does not see the DMA at all; its
+// completion is awaited by the explicit `s_waitcnt vmcnt(0)` + barrier that ends every tile, which volatile asm cannot cross.
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_addr, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "m0");
+}
+
 struct W3G {
     static constexpr int PH = 8, PW = 16, IH = 10, IW = 18, GPIX = PH * PW, IPIX = IH * IW;
     static constexpr int GPLANE = GPIX * 32 + 128;           // 4 DMA instructions per plane
@@ -653,18 +674,17 @@ __device__ __forceinline__ W3GTile w3g_tile(const dasr_wgrad_part& P, int tile, 
 
 // the wave's k-th 1-KiB DMA instruction (j = wave + 12 k) of pixel tile T into `buf`
 __device__ __forceinline__ void w3g_dma(const dasr_wgrad_part& P, const W3GTile& T, const W3GPiece& pc, int j, char* buf, int HL, int WL) {
-    typedef __attribute__((address_space(3))) void* lds_ptr;
     if (j < 24) {
         const int oy = T.oy0 + pc.dy, ox = T.ox0 + pc.dx;
         const bool ok = (oy < P.Hout) & (ox < P.Wout);
         const unsigned off = ok ? (unsigned)((pc.rel + (oy * P.Wout + ox) * 16) * 2) : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(T.gb, (lds_ptr)(buf + pc.lds), 16, off, 0, 0, 0);
+        lds_dma16(T.gb, (unsigned)(size_t)(DASR_LDS char*)buf + pc.lds, off);
     } else {
         const int gy = T.oy0 - P.pad + pc.dy, gx = T.ox0 - P.pad + pc.dx;
         const bool ok = (gy >= 0) & (gy < HL) & (gx >= 0) & (gx < WL);
         const int sy = P.ups ? gy >> 1 : gy, sx = P.ups ? gx >> 1 : gx;
         const unsigned off = ok ? (unsigned)((pc.rel + (sy * P.Win + sx) * 16) * 2) : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(T.ib, (lds_ptr)(buf + pc.lds), 16, off, 0, 0, 0);
+        lds_dma16(T.ib, (unsigned)(size_t)(DASR_LDS char*)buf + pc.lds, off);
     }
 }
 
@@ -789,6 +809,230 @@ __global__ __launch_bounds__(768, 1) void wgrad3_glds_kernel(const dasr_wgrad_pa
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// wgrad v4 (round 3): the same parts (one 64-channel input block x up to three 32-oc tiles x 9 taps = 54 accumulator tiles) and the same
+// workspace layout as wgrad3, re-blocked around what the round-3 ablation of wgrad3 measured (profiles/r03e_wgrad3_ablation.txt: MFMA + fragment
+// reads alone 73 % of the launch, the register-staged global prefetch 21 %, the 12-wave LDS commit phase 4 %; 2.4 transposed LDS reads per MFMA):
+//  * FOUR waves, one per SIMD, wave = (cin tile ct, role).  A wave owns all 9 taps of its own oc tile (role 0: tile 0, role 1: tile 2) and a share
+//    of the taps of oc tile 1 (role 0: taps 0-3, role 1: taps 4-8): 13 / 14 accumulators (<= 256 AGPRs), 104 / 112 MFMAs per 8 x 16-pixel tile.
+//    The code of the two roles is IDENTICAL: the own tile reads its X fragments from a sliding register window (three halo rows x three column
+//    shifts, 3 new fragments per k-step); the shared tile's up to five X fragments are read at per-role LDS offsets held in scalar registers.
+//    0.7 fragment reads per MFMA (wgrad3: 1.2), one fragment set ahead of the MFMAs.
+//  * global -> LDS by LDS-DMA into the other buffer while the current tile is multiplied (no staging registers, no ds_write, ONE barrier per
+//    tile); the twelve 1-KiB DMA instructions of a wave are issued one or two per k-step between the MFMAs.
+// ---------------------------------------------------------------------------------------------------------------
+struct W4 {
+    static constexpr int PH = 8, PW = 16, IH = 10, IW = 18, GPIX = PH * PW, IPIX = IH * IW;
+    static constexpr int GPLANE = GPIX * 32 + 128;           // 4 DMA instructions per plane
+    static constexpr int IPLANE = 6 * 1024 + 128;            // 6 DMA instructions per plane (180 pixels = 5.6 KiB), = 128 (mod 256)
+    static constexpr int G_BYTES = 6 * GPLANE, I_BYTES = 4 * IPLANE;
+    static constexpr int BUF_BYTES = G_BYTES + I_BYTES;
+    static constexpr int LDS_BYTES = 3 * BUF_BYTES;          // ring of three tiles: 151 KB of the CU's 160
+    static constexpr int NT = 256, NDMA = 12;                // 48 DMA instructions per tile, 12 per wave
+};
+
+// ABL (instantiated != 0 only under -DDASR_BENCH, WRONG results): bit 0 no DMA after the prologue, bit 1 no fragment requests inside the k-steps,
+// bit 2 no MFMA, bit 3 no barrier / DMA wait per tile
+template <bool F16, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void wgrad4_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit_flags, float* __restrict__ ws) {
+    using C = W4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nsplit = nsplit_flags & 0xffff;
+    int part_id, split;
+    w3_block_map(nsplit_flags, part_id, split);
+    const dasr_wgrad_part P = parts[part_id];
+    const int ct = wave & 1, role = wave >> 1;
+    const int n_ot = (P.g_planes + 1) >> 1;
+    const int otA = role ? 2 : 0;
+    const bool act_ct = ct < P.n_ctiles;
+    const bool actA = act_ct && otA < n_ot, actB = act_ct && 1 < n_ot;
+    const int tiles_x = (P.Wout + C::PW - 1) / C::PW, tiles_y = (P.Hout + C::PH - 1) / C::PH;
+    const int ntiles = tiles_x * tiles_y * P.N;
+    const int HL = P.ups ? 2 * P.Hin : P.Hin, WL = P.ups ? 2 * P.Win : P.Win;
+    const int gg = lane >> 4, li = lane & 15;
+    const int fplane = gg & 1, khalf = gg >> 1;
+    const int frag_off = (8 * khalf + (li >> 2)) * 32 + (li & 3) * 8;
+    const int gbaseA = (otA * 2 + fplane) * C::GPLANE + frag_off, gbaseB = (2 + fplane) * C::GPLANE + frag_off;
+    const int ibase = C::G_BYTES + (ct * 2 + fplane) * C::IPLANE + frag_off;
+    const bool want_bias = P.want_bias && ct == 0;
+    // this wave's twelve DMA instructions per tile (1 KiB each): k < 6: quarter `wave` (32 pixels) of G plane k; k >= 6: sixth k - 6 (32 pixels) of X
+    // plane `wave`.  Per-lane geometry: ONE pixel position for all G pieces, six for the X pieces (packed dy | dx << 16, dy = 0x7fff: never valid);
+    // the plane offsets are wave-uniform.
+    const int half8 = (lane & 1) * 8;
+    int pos_g, pos_x[6];
+    {
+        const int pix = (wave * 64 + lane) >> 1;
+        pos_g = (pix >> 4) | ((pix & 15) << 16);
+    }
+    const bool x_plane_ok = (wave < P.in_planes) & (wave < 2 * P.n_ctiles);
+#pragma unroll
+    for (int sub = 0; sub < 6; ++sub) {
+        const int pix = (sub * 64 + lane) >> 1, iy = pix / C::IW;
+        pos_x[sub] = (((pix < C::IPIX) & x_plane_ok) ? iy : 0x7fff) | ((pix - iy * C::IW) << 16);
+    }
+    const int rel_x = wave * (int)P.in.cb_stride + half8;
+    auto dma = [&](int k, const W3GTile& T, unsigned buf) {   // buf: LDS byte address of the target buffer; k is a compile-time constant at every call site
+        if (k < 6) {
+            const int oy = T.oy0 + (pos_g & 0xffff), ox = T.ox0 + (pos_g >> 16);
+            const bool ok = (oy < P.Hout) & (ox < P.Wout) & (k < P.g_planes);
+            const unsigned off = ok ? (unsigned)((k * (int)P.g.cb_stride + half8 + (oy * P.Wout + ox) * 16) * 2) : OOB;
+            lds_dma16(T.gb, buf + k * C::GPLANE + wave * 1024, off);
+        } else {
+            const int sub = k - 6;
+            const int gy = T.oy0 - P.pad + (pos_x[sub] & 0xffff), gx = T.ox0 - P.pad + (pos_x[sub] >> 16);
+            const bool ok = (gy >= 0) & (gy < HL) & (gx >= 0) & (gx < WL);
+            const int sy = P.ups ? gy >> 1 : gy, sx = P.ups ? gx >> 1 : gx;
+            const unsigned off = ok ? (unsigned)((rel_x + (sy * P.Win + sx) * 16) * 2) : OOB;
+            lds_dma16(T.ib, buf + C::G_BYTES + wave * C::IPLANE + sub * 1024, off);
+        }
+    };
+    const unsigned lds0 = (unsigned)(size_t)(DASR_LDS char*)smem;   // LDS byte address of the dynamic shared memory
+    // ring of THREE tile buffers: the pieces of tile t + 2 are requested in the first k-steps of tile t, so the wait that ends tile t (for the
+    // pieces of tile t + 1, requested a whole tile earlier) never sees a load in flight
+    if (split < ntiles) {
+        const W3GTile T0 = w3g_tile(P, split, tiles_x, tiles_y);
+#pragma unroll
+        for (int k = 0; k < C::NDMA; ++k) dma(k, T0, lds0);
+    }
+    if (split + nsplit < ntiles) {
+        const W3GTile T1 = w3g_tile(P, split + nsplit, tiles_x, tiles_y);
+#pragma unroll
+        for (int k = 0; k < C::NDMA; ++k) dma(k, T1, lds0 + C::BUF_BYTES);
+        asm volatile("s_waitcnt vmcnt(12)");   // tile 0 has landed (this wave's pieces), tile 1 may still fly
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)");
+    }
+    __syncthreads();
+
+    // The two roles run two specialised copies of the whole tile loop + epilogue (a wave executes one): ONE wave per SIMD means nothing hides a
+    // stall and every instruction beside an MFMA costs issue time (~5 fit into an MFMA's 32 cycles), so the stream is laid out by hand and kept
+    // minimal: per k-step 13 / 14 MFMAs, 5 fragment requests (3 X fragments of halo row r + 2, the next row's two G fragments: 10 transposed
+    // LDS reads), all addresses = one VGPR per buffer + immediate offsets.  Role 0: shared-tile taps 0-3 = window (row r: kx 0-2), (row r+1: kx 0);
+    // role 1: taps 4-8 = (row r+1: kx 1, 2), (row r+2: kx 0-2).
+    auto body = [&](auto role_c) {
+        constexpr int ROLE = decltype(role_c)::value;
+        constexpr int NB = ROLE ? 5 : 4, TB0 = ROLE ? 4 : 0;
+        constexpr int NM = 9 + NB;
+        f32x16 accA[9], accB[NB];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) accA[t][j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) accB[t][j] = 0.f;
+        float bsumA = 0.f, bsumB = 0.f;
+        int cur = 0;   // ring slot of the current tile
+        for (int tile = split; tile < ntiles; tile += nsplit) {
+            const char* gA = smem + cur * C::BUF_BYTES + gbaseA;   // per-lane base addresses inside the current buffer: everything else is an immediate
+            const char* gB = smem + cur * C::BUF_BYTES + gbaseB;
+            const char* xb = smem + cur * C::BUF_BYTES + ibase;
+            const int slot2 = cur == 0 ? 2 : cur - 1;   // (cur + 2) % 3: the slot tile t - 1 was read from
+            const unsigned nbuf = lds0 + slot2 * C::BUF_BYTES;
+            const bool more = tile + 2 * nsplit < ntiles;   // a tile t + 2 exists: request it now
+            const W3GTile T = w3g_tile(P, more ? tile + 2 * nsplit : tile, tiles_x, tiles_y);
+            if (act_ct) {
+                bf16x8 win[3][3], ga[2], gb[2];
+#pragma unroll
+                for (int row = 0; row < 2; ++row)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) win[row][kx] = frag_tr(xb, (row * C::IW + kx) * 32, (row * C::IW + kx) * 32 + 4 * 32);
+                ga[0] = frag_tr(gA, 0, 4 * 32);
+                gb[0] = frag_tr(gB, 0, 4 * 32);
+                if constexpr (ABL & 2) {
+                    ga[1] = ga[0];
+                    gb[1] = gb[0];
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) win[2][kx] = win[0][kx];
+                }
+#pragma unroll
+                for (int r = 0; r < C::PH; ++r) {
+#pragma unroll
+                    for (int i = 0; i < NM; ++i) {
+                        // MFMA i of the k-step.  Order: everything that needs only halo rows r, r + 1 (in registers) first, ky = 2 last.
+                        // role 0: shared taps 0-3, own taps 0-5, own taps 6-8; role 1: shared taps 4, 5, own 0-5, own 6-8, shared 6-8
+                        int own = -1, sh = -1;
+                        if (ROLE == 0) {
+                            if (i < 4) sh = i;
+                            else own = i - 4;
+                        } else {
+                            if (i < 2) sh = 4 + i;
+                            else if (i < 11) own = i - 2;
+                            else sh = 6 + (i - 11);
+                        }
+                        if constexpr (!(ABL & 4)) {
+                            if (own >= 0) accA[own] = mfma16<F16>(ga[r & 1], win[(r + own / 3) % 3][own % 3], accA[own]);
+                            else accB[sh - TB0] = mfma16<F16>(gb[r & 1], win[(r + sh / 3) % 3][sh % 3], accB[sh - TB0]);
+                        } else {
+                            asm volatile("" ::"v"(ga[r & 1]), "v"(gb[r & 1]), "v"(win[(r + i / 3) % 3][i % 3]));
+                        }
+                        // at most one request behind each MFMA
+                        if (i < 3) {            // halo row r + 2 (first used >= 6 MFMAs later)
+                            if constexpr (!(ABL & 2)) win[(r + 2) % 3][i] = frag_tr(xb, ((r + 2) * C::IW + i) * 32, ((r + 2) * C::IW + i) * 32 + 4 * 32);
+                        } else if (i == 3) {
+                            if (r + 1 < C::PH && !(ABL & 2)) ga[(r + 1) & 1] = frag_tr(gA, (r + 1) * C::PW * 32, (r + 1) * C::PW * 32 + 4 * 32);
+                        } else if (i == 4) {
+                            if (r + 1 < C::PH && !(ABL & 2)) gb[(r + 1) & 1] = frag_tr(gB, (r + 1) * C::PW * 32, (r + 1) * C::PW * 32 + 4 * 32);
+                        } else if (i < 9) {     // this wave's DMA pieces of tile t + 2: four per k-step in the first three
+                            if (more && r < 3 && !(ABL & 1)) dma(4 * r + (i - 5), T, nbuf);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (want_bias) {   // sum over pixels of G from the 16-bit fragments: own tile; the shared tile by role 0 only
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) bsumA += frag_f32<F16>(ga[r & 1], j);
+                        if (ROLE == 0) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) bsumB += frag_f32<F16>(gb[r & 1], j);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else if (more && !(ABL & 1)) {
+#pragma unroll
+                for (int k = 0; k < C::NDMA; ++k) dma(k, T, nbuf);
+            }
+            // this wave's pieces of tile t + 1 have landed (the twelve of tile t + 2, if requested, may still fly) ...
+            if constexpr (!(ABL & 8)) {
+                if (more && !(ABL & 1)) asm volatile("s_waitcnt vmcnt(12)");
+                else asm volatile("s_waitcnt vmcnt(0)");
+                __syncthreads();                      // ... everybody's; and everybody is done reading the current buffer
+            }
+            cur = cur == 2 ? 0 : cur + 1;
+        }
+        // ---- partial sums of this pixel split: ws[part][split][tap 9][ot 3][oc 32][cin 64]; bias [split][96]
+        float* w0 = ws + P.ws_off + (size_t)split * 9 * 3 * 2048;
+        const int cin = ct * 32 + (lane & 31), h = lane >> 5;
+        if (actA) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                float* w = w0 + (size_t)t * 3 * 2048 + (size_t)otA * 2048;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) w[((j & 3) + 8 * (j >> 2) + 4 * h) * 64 + cin] = accA[t][j];
+            }
+        }
+        if (actB) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                float* w = w0 + (size_t)(TB0 + i) * 3 * 2048 + 2048;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) w[((j & 3) + 8 * (j >> 2) + 4 * h) * 64 + cin] = accB[i][j];
+            }
+        }
+        if (want_bias) {
+            const float tA = bsumA + __shfl_xor(bsumA, 32, 64), tB = bsumB + __shfl_xor(bsumB, 32, 64);
+            if (lane < 32) {
+                if (actA) ws[P.ws_bias_off + (size_t)split * 96 + otA * 32 + lane] = tA;
+                if (ROLE == 0 && actB) ws[P.ws_bias_off + (size_t)split * 96 + 32 + lane] = tB;
+            }
+        }
+    };
+    if (role == 0) body(std::integral_constant<int, 0>{});
+    else body(std::integral_constant<int, 1>{});
+}
+
 // deterministic split reduction.  One workgroup = one output channel x 16 input channels of one part; thread (split lane sl = t >> 4, cin =
 // t & 15) sums splits sl, sl + 16, ... of every tap (two accumulators, fixed order), the 16 lane sums meet in LDS and are added in a fixed
 // tree, and the reference layout [cout][cin][kh][kw] is written as ONE contiguous run of 16 * ntaps floats per workgroup (the first version
@@ -882,10 +1126,10 @@ int launch_wgrad(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws
     return (int)hipGetLastError();
 }
 
-extern int g_wgrad3_stagger;
-template <bool USE_TR, bool F32, bool F16 = false>
+extern int g_wgrad3_stagger, g_wgrad3_abl;
+template <bool USE_TR, bool F32, bool F16 = false, int ABL = 0>
 int launch_wgrad3(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws, hipStream_t s) {
-    auto kfn = wgrad3_kernel<USE_TR, F32, F16>;
+    auto kfn = wgrad3_kernel<USE_TR, F32, F16, ABL>;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, W3::LDS_BYTES + 16));
@@ -905,8 +1149,27 @@ int launch_wgrad3_glds(const dasr_wgrad_part* parts, int nparts, int nsplit, flo
     return (int)hipGetLastError();
 }
 
+template <bool F16, int ABL = 0>
+int launch_wgrad4(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws, hipStream_t s) {
+    auto kfn = wgrad4_kernel<F16, ABL>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, W4::LDS_BYTES));
+        attr_set = true;
+    }
+    DASR_LAUNCH_TAG(__PRETTY_FUNCTION__, kfn, dim3(nparts * (nsplit & 0xffff)), dim3(W4::NT), W4::LDS_BYTES, s, parts, nparts, nsplit, ws);
+    return (int)hipGetLastError();
+}
+
 int g_use_tr = -1;  // -1 unknown, 0 gather fallback, 1 transpose reads
+// 3x3 stride-1 weight gradients on 16-bit tensors: 0 = wgrad3_kernel (default), 1 = wgrad4_kernel (4 waves, LDS-DMA, register window).
+// Measured in round 3 (profiles/r03_wgrad_ablation.txt): wgrad4 halves the LDS fragment reads and removes the commit phase, but with ONE wave per
+// SIMD every LDS-DMA instruction that waits for the memory pipe also stops that SIMD's MFMAs: 0.79 PFLOP/s against wgrad3's 0.96 - 1.01 (three
+// waves per SIMD cover each other).  Both kernels move 110 B of L2 -> LDS traffic per MFMA; the chip sustains ~9 TB/s of it, which costs 0.95 ms
+// per grouped launch next to 1.3 - 1.6 ms of MFMA time: the weight gradient is bound by that SUM, not by either term.
+int g_wgrad4 = 0;
 int g_wgrad3_stagger = 1;
+int g_wgrad3_abl = 0;   // DASR_BENCH builds: ablation bits of wgrad3_kernel (dasr_wgrad_set_mode bits 3-6); ignored by the product build
 int g_wgrad3_glds = 0;  // LDS-DMA wgrad3: faster alone (490 vs 470 TFLOP/s) but its 101 KB of LDS keeps the other sub-batch stream off the CU: -2.5 % on the step
 
 }  // namespace
@@ -930,7 +1193,11 @@ extern "C" int dasr_debug_set_wtrace(void* buf) { return (int)hipMemcpyToSymbol(
 
 extern "C" int dasr_wgrad_set_mode(int use_tr) {
     g_wgrad3_stagger = (use_tr & 4) ? 0 : 1;  // bit 2: all waves request the next tile before computing (A/B)
+#ifdef DASR_BENCH
+    g_wgrad3_abl = (use_tr >> 3) & 0xf;
+#endif
     g_wgrad3_glds = (use_tr & 2) ? 1 : 0;  // bit 1: LDS-DMA wgrad3 instead of the register-staged one (A/B)
+    g_wgrad4 = (use_tr & 128) ? 1 : 0;     // bit 7: wgrad4_kernel instead of wgrad3_kernel (A/B)
     use_tr &= 1;
     g_use_tr = use_tr;
     return 0;
@@ -960,8 +1227,37 @@ extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int3
     if (g_use_tr < 0) return DASR_EINVAL;  // dasr_probe_tr16 must run once per process (outside graph capture)
     const bool tr = g_use_tr == 1;
     if (kh == 33) {  // v3 layout: 6-wave workgroups, 3 oc tiles x 64 cin per part (3x3 stride 1 only)
+#ifdef DASR_BENCH
+        if (tr && g_wgrad4 && f32 == 0) switch (g_wgrad3_abl) {
+            case 1: return launch_wgrad4<false, 1>(parts_dev, nparts, nsplit, ws, s);
+            case 2: return launch_wgrad4<false, 2>(parts_dev, nparts, nsplit, ws, s);
+            case 4: return launch_wgrad4<false, 4>(parts_dev, nparts, nsplit, ws, s);
+            case 8: return launch_wgrad4<false, 8>(parts_dev, nparts, nsplit, ws, s);
+            case 3: return launch_wgrad4<false, 3>(parts_dev, nparts, nsplit, ws, s);
+            case 6: return launch_wgrad4<false, 6>(parts_dev, nparts, nsplit, ws, s);
+            case 9: return launch_wgrad4<false, 9>(parts_dev, nparts, nsplit, ws, s);
+            case 11: return launch_wgrad4<false, 11>(parts_dev, nparts, nsplit, ws, s);
+            case 15: return launch_wgrad4<false, 15>(parts_dev, nparts, nsplit, ws, s);
+            default: break;
+        }
+#endif
+        if (tr && g_wgrad4 && f32 != 1) return f32 == 2 ? launch_wgrad4<true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad4<false>(parts_dev, nparts, nsplit, ws, s);
         if (f32 == 2) return tr ? launch_wgrad3<true, false, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3<false, false, true>(parts_dev, nparts, nsplit, ws, s);
         if (tr && !f32 && g_wgrad3_glds) return launch_wgrad3_glds(parts_dev, nparts, nsplit, ws, s);
+#ifdef DASR_BENCH
+        if (tr && !f32) switch (g_wgrad3_abl) {
+            case 1: return launch_wgrad3<true, false, false, 1>(parts_dev, nparts, nsplit, ws, s);
+            case 2: return launch_wgrad3<true, false, false, 2>(parts_dev, nparts, nsplit, ws, s);
+            case 4: return launch_wgrad3<true, false, false, 4>(parts_dev, nparts, nsplit, ws, s);
+            case 8: return launch_wgrad3<true, false, false, 8>(parts_dev, nparts, nsplit, ws, s);
+            case 6: return launch_wgrad3<true, false, false, 6>(parts_dev, nparts, nsplit, ws, s);
+            case 7: return launch_wgrad3<true, false, false, 7>(parts_dev, nparts, nsplit, ws, s);
+            case 9: return launch_wgrad3<true, false, false, 9>(parts_dev, nparts, nsplit, ws, s);
+            case 14: return launch_wgrad3<true, false, false, 14>(parts_dev, nparts, nsplit, ws, s);
+            case 15: return launch_wgrad3<true, false, false, 15>(parts_dev, nparts, nsplit, ws, s);
+            default: break;
+        }
+#endif
         if (tr) return f32 ? launch_wgrad3<true, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3<true, false>(parts_dev, nparts, nsplit, ws, s);
         return f32 ? launch_wgrad3<false, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3<false, false>(parts_dev, nparts, nsplit, ws, s);
     }

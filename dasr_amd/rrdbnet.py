@@ -225,9 +225,9 @@ def rdb_wgrad_parts(grp, nf, pre, P, Gs, S, h, w, N):
 class TrunkStore:
     """Forward slabs and gradient slabs of ALL dense blocks for a whole batch of N images (one allocation per RDB; sub-batch replicas work on
     image ranges of it), and the deferred weight-gradient phase over them: after the data-gradient chain has filled every gradient slab, the
-    weight gradients of the 3 nb dense blocks are computed by a few grouped launches (16 + 4 + 2 + 1 RRDBs for nb = 23: every launch has
-    ~240 workgroups of 12 waves, one per CU, nothing co-resident; the big groups need no pixel split at all, so the fp32 partial-sum traffic
-    of round 2 -- 24.8 MB written and re-read per RRDB -- all but disappears)."""
+    weight gradients of the 3 nb dense blocks are computed by a few grouped launches (4 RRDBs per launch by default, DASR_WG_GROUP: every
+    launch has ~240 workgroups of 12 waves, one per CU, nothing co-resident; four pixel splits instead of sixteen: a quarter of round 2's
+    fp32 partial-sum traffic of 24.8 MB written and re-read per RRDB)."""
 
     def __init__(self, net, N, h, w):
         self.net, self.N, self.h, self.w = net, N, h, w
@@ -253,7 +253,7 @@ class TrunkStore:
         net, N, h, w = self.net, self.N, self.h, self.w
         nf, nb, P = net.nf, net.nb, net.params
         target = int(os.environ.get('DASR_WG3_TARGET', '256'))
-        gmax = max(1, int(os.environ.get('DASR_WG_GROUP', '16')))
+        gmax = max(1, int(os.environ.get('DASR_WG_GROUP', '4')))   # RRDBs per launch: 4 measured best (16: -1 %, 1: -1.5 %; profiles/r03b_*)
         self.phase = OpList()
         self.groups = []   # (first op, end op, lo, hi): ops [first, end) complete params.grad[lo:hi]; descending parameter order
         hi_rrdb = nb

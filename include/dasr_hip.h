@@ -111,7 +111,9 @@ typedef struct {
 int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int32_t nsplit, int32_t kh, int32_t stride, int32_t f32,
                float* ws, void* stream);
 /* bit 0: 1 = ds_read_b64_tr_b16 gathers, 0 = scalar LDS gathers (dasr_probe_tr16 sets it from the device);
- * bit 1: dense-block wgrad staged by LDS-DMA instead of registers (A/B; default off). */
+ * bit 1: dense-block wgrad3 staged by LDS-DMA instead of registers (A/B; default off); bit 7: kh = 33 launches on 16-bit tensors run
+ * wgrad4_kernel (4 waves, LDS-DMA ring of three tiles, register window of X fragments; measured slower, kept as a tested alternative)
+ * instead of wgrad3_kernel (12 waves, register-staged). */
 int dasr_wgrad_set_mode(int32_t use_tr);
 
 typedef struct {
