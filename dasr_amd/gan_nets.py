@@ -443,6 +443,11 @@ class VGGFeatureHIP:
         self.device = torch.device(device)
         self.prec = int(prec if prec is not None else os.environ.get('DASR_VGG_PREC', '4'))
         self.f16s = self.prec == 2
+        # images [n_g, N) of a plan carry no gradient (the real HR half of the DASR feature loss, DASR_model.py:225; the bicubic LR half of the DSN
+        # perceptual loss, loss.py:119-130): their features are only the TARGET of an L1 / MSE, so the operand rounding of a single f16 MFMA pass
+        # (1e-3 on the features, zero-mean) enters the loss value in second order and the gradient only through sign flips of near-ties.  One
+        # pass instead of three on a third of the perceptual network's work.  DASR_VGG_NOGRAD_PREC=0: same precision as the gradient half.
+        self.nograd_prec = int(os.environ.get('DASR_VGG_NOGRAD_PREC', '2')) if self.prec in (3, 4) else 0
         self.spec, self.layers = vgg19_spec(feature_layer, cfg)
         self.params = ParamStore(self.spec, self.device)
         self.pack = PackRegistry(self.params)
@@ -457,6 +462,8 @@ class VGGFeatureHIP:
             mt_b = 2 if (self.prec in (1, 2) and cin % 64 == 0) else 1
             self.pk[idx] = self.pack.add(cout, cin_pad, 9, mt_f, self.prec, [(w, cout, cin, 0, cin, 0, 0)])
             self.pk[(idx, 'b')] = self.pack.add(cin, cout, 9, mt_b, self.prec, [(w, cout, cin, 0, cout, 0, 1)])
+            if self.nograd_prec and self.nograd_prec != self.prec:   # forward of the images that carry no gradient (see plan())
+                self.pk[(idx, 'r')] = self.pack.add(cout, cin_pad, 9, 2 if cout % 64 == 0 else 1, self.nograd_prec, [(w, cout, cin, 0, cin, 0, 0)])
         self.pack.finalize()
         self.plans = {}
 
@@ -474,6 +481,12 @@ class VGGFeatureHIP:
         return self.plans[k]
 
 
+def _nview_t(bt, n0):
+    """dasr_tensor view of images [n0:] of a blocked tensor"""
+    v = bt.view()
+    return Tensor(v.p + n0 * v.n_stride * bt.esz, v.n_stride, v.cb_stride)
+
+
 class _VGGPlan:
     def __init__(self, net, N, n_g, H, W):
         self.net, self.N, self.n_g = net, N, n_g
@@ -489,8 +502,13 @@ class _VGGPlan:
         for kind, idx, cin, cout, relu in net.layers:
             if kind == 'conv':
                 out = BTensor(N, cout, h, w, True, dev)
-                fwd.add(conv_op(pack, net.pk[idx], src.view(), True, ceil_div(cin, 16) * 16, h, w, h, w, N,
+                split = (idx, 'r') in net.pk and 0 < n_g < N
+                ng = n_g if split else N
+                fwd.add(conv_op(pack, net.pk[idx], src.view(), True, ceil_div(cin, 16) * 16, h, w, h, w, ng,
                                 bias=P.ptr('features.%d.bias' % idx), act=1 if relu else 0, slope=0.0, out_f32=out.view()))
+                if split:   # the no-gradient images: one f16 pass
+                    fwd.add(conv_op(pack, net.pk[(idx, 'r')], _nview_t(src, n_g), True, ceil_div(cin, 16) * 16, h, w, h, w, N - n_g,
+                                    bias=P.ptr('features.%d.bias' % idx), act=1 if relu else 0, slope=0.0, out_f32=_nview_t(out, n_g)))
             else:
                 h, w = h // 2, w // 2
                 out = BTensor(N, cout, h, w, True, dev)

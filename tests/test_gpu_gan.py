@@ -204,7 +204,12 @@ def test_vgg_forward_and_input_gradient(prec, act_tol, grad_tol, margins):
     p.fwd.run()
     xr = x.clone().requires_grad_(True)
     f = ref(xr)
-    e_f = rel(p.feat.nchw().cpu(), f.detach())
+    # image 0 carries the gradient (three-pass operands); image 1 is a no-gradient target: ONE f16 pass by default in the split modes (round 3,
+    # VGGFeatureHIP.nograd_prec): its features are held to the f16 path's documented bound, and only enter an L1 / MSE as the target
+    e_f = rel(p.feat.nchw().cpu()[:1], f.detach()[:1])
+    e_t = rel(p.feat.nchw().cpu()[1:], f.detach()[1:])
+    margins('VGG19-54 prec %d: no-gradient (target) image features rel err %.2e (bound 2.5e-3; one f16 pass when prec is 3 / 4)' % (prec, e_t))
+    assert e_t < 2.5e-3
     # dL/dfeat at the magnitude a mean feature loss produces (~1 / element count): the f16 path pre-scales gradients by a power of two
     # chosen for that magnitude (a unit-scale random gradient would overflow f16 in the middle of the stack)
     gf = torch.randn(f.shape, generator=g) / f[:1].numel()
