@@ -810,6 +810,168 @@ __global__ __launch_bounds__(768, 1) void wgrad3_glds_kernel(const dasr_wgrad_pa
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// wgrad3 with LOADER WAVES (round 3): the decomposition of wgrad3_glds_kernel (12 compute waves: oc tile x cin tile x tap half, 5 accumulators,
+// transposed LDS reads, double-buffered LDS image filled by LDS-DMA) plus FOUR waves, one per SIMD, that do nothing but issue the 48 DMA
+// instructions of the next pixel tile and wait for them.  The round-3 ablations (profiles/r03_wgrad_ablation.txt) showed that the weight gradient
+// pays the SUM of its MFMA time and of its L2 -> LDS transfer time: a wave that issues a load into a busy memory pipe stalls, and its MFMAs with
+// it.  Here the compute waves never touch vector memory inside the tile loop; the loaders stall instead, and a stalled loader costs no MFMA slot.
+// 16 waves x 128 registers: the compute side fits because nothing is staged through registers.
+// ---------------------------------------------------------------------------------------------------------------
+struct W3L {
+    static constexpr int NT = 1024, NLD = 4, NDMA = 12;   // 12 compute waves + 4 loaders; 48 DMA instructions per tile, 12 per loader
+    static constexpr int NBUF = 3;                        // ring of three tile images (151 KB): the loaders run one tile ahead of the wait
+    static constexpr int LDS_BYTES = NBUF * W3G::BUF_BYTES;
+};
+
+template <bool F16>
+__global__ __launch_bounds__(1024, 1) void wgrad3_ld_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit_flags, float* __restrict__ ws) {
+    using C = W3G;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nsplit = nsplit_flags & 0xffff;
+    int part_id, split;
+    w3_block_map(nsplit_flags, part_id, split);
+    const dasr_wgrad_part P = parts[part_id];
+    const int tiles_x = (P.Wout + C::PW - 1) / C::PW, tiles_y = (P.Hout + C::PH - 1) / C::PH;
+    const int ntiles = tiles_x * tiles_y * P.N;
+    const unsigned lds0 = (unsigned)(size_t)(DASR_LDS char*)smem;
+    if (wave >= 12) {
+        // ---- loader wave lw: quarter lw (32 pixels) of each of the 6 G planes, and the 6 sixths of X plane lw
+        const int lw = wave - 12;
+        const int HL = P.ups ? 2 * P.Hin : P.Hin, WL = P.ups ? 2 * P.Win : P.Win;
+        const int half8 = (lane & 1) * 8;
+        int pos_g, pos_x[6];
+        {
+            const int pix = (lw * 64 + lane) >> 1;
+            pos_g = (pix >> 4) | ((pix & 15) << 16);
+        }
+        const bool x_plane_ok = (lw < P.in_planes) & (lw < 2 * P.n_ctiles);
+#pragma unroll
+        for (int sub = 0; sub < 6; ++sub) {
+            const int pix = (sub * 64 + lane) >> 1, iy = pix / C::IW;
+            pos_x[sub] = (((pix < C::IPIX) & x_plane_ok) ? iy : 0x7fff) | ((pix - iy * C::IW) << 16);
+        }
+        const int rel_x = lw * (int)P.in.cb_stride + half8;
+        auto fill = [&](int tile, unsigned buf) {
+            const W3GTile T = w3g_tile(P, tile, tiles_x, tiles_y);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int oy = T.oy0 + (pos_g & 0xffff), ox = T.ox0 + (pos_g >> 16);
+                const bool ok = (oy < P.Hout) & (ox < P.Wout) & (k < P.g_planes);
+                const unsigned off = ok ? (unsigned)((k * (int)P.g.cb_stride + half8 + (oy * P.Wout + ox) * 16) * 2) : OOB;
+                lds_dma16(T.gb, buf + k * C::GPLANE + lw * 1024, off);
+            }
+#pragma unroll
+            for (int sub = 0; sub < 6; ++sub) {
+                const int gy = T.oy0 - P.pad + (pos_x[sub] & 0xffff), gx = T.ox0 - P.pad + (pos_x[sub] >> 16);
+                const bool ok = (gy >= 0) & (gy < HL) & (gx >= 0) & (gx < WL);
+                const int sy = P.ups ? gy >> 1 : gy, sx = P.ups ? gx >> 1 : gx;
+                const unsigned off = ok ? (unsigned)((rel_x + (sy * P.Win + sx) * 16) * 2) : OOB;
+                lds_dma16(T.ib, buf + C::G_BYTES + lw * C::IPLANE + sub * 1024, off);
+            }
+        };
+        // ring of three: during tile t the loaders request tile t + 2 (into the slot tile t - 1 was read from) and wait only for tile t + 1,
+        // requested a whole tile earlier: the barrier that ends a tile never waits for a load in flight
+        if (split < ntiles) fill(split, lds0);
+        if (split + nsplit < ntiles) {
+            fill(split + nsplit, lds0 + C::BUF_BYTES);
+            asm volatile("s_waitcnt vmcnt(12)");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)");
+        }
+        __syncthreads();
+        int cur = 0;
+        for (int tile = split; tile < ntiles; tile += nsplit) {
+            const int slot2 = cur == 0 ? 2 : cur - 1;
+            const bool more = tile + 2 * nsplit < ntiles;
+            if (more) {
+                fill(tile + 2 * nsplit, lds0 + slot2 * C::BUF_BYTES);
+                asm volatile("s_waitcnt vmcnt(12)");   // tile t + 1 has landed (this loader's share), tile t + 2 may fly ...
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)");
+            }
+            __syncthreads();                           // ... everybody's; and the compute waves are done with the current slot
+            cur = cur == 2 ? 0 : cur + 1;
+        }
+        return;
+    }
+    // ---- compute wave: pair = wave % 6 -> (oc tile, cin tile); taps 0..4 (wave < 6) or 5..8
+    const int pair = wave % 6, th = wave / 6;
+    const int ot = pair >> 1, ct = pair & 1;
+    const int n_ot = (P.g_planes + 1) >> 1;
+    const bool active = ct < P.n_ctiles && ot < n_ot;
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+    float bsum = 0.f;
+    const int gg = lane >> 4, li = lane & 15;
+    const int fplane = gg & 1, khalf = gg >> 1;
+    const int gbase = (ot * 2 + fplane) * C::GPLANE + (8 * khalf + (li >> 2)) * 32 + (li & 3) * 8;
+    const int ibase = C::G_BYTES + (ct * 2 + fplane) * C::IPLANE + (8 * khalf + (li >> 2)) * 32 + (li & 3) * 8;
+    // taps of this wave: th = 0 -> 0..4, th = 1 -> 5..8 (the fifth slot repeats tap 8's address and its MFMA is skipped): one code path
+    int tb[5];
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+        const int t = th ? (a < 4 ? 5 + a : 8) : a;
+        tb[a] = ibase + ((t / 3) * C::IW + (t % 3)) * 32;
+    }
+    const bool want_bias = P.want_bias && ct == 0 && th == 0;
+    __syncthreads();   // tile 0 is in LDS
+    int cur = 0;
+    for (int tile = split; tile < ntiles; tile += nsplit) {
+        const char* buf = smem + cur * C::BUF_BYTES;
+        cur = cur == 2 ? 0 : cur + 1;
+        if (active) {
+            bf16x8 a[2], b[2];
+            a[0] = frag_tr(buf, gbase, gbase + 4 * 32);
+            b[0] = frag_tr(buf, tb[0], tb[0] + 4 * 32);
+#pragma unroll
+            for (int i = 0; i < C::PH * 5; ++i) {
+                const int r = i / 5, t = i - r * 5;
+                if (i + 1 < C::PH * 5) {
+                    const int r1 = (i + 1) / 5, t1 = (i + 1) - r1 * 5;
+                    const int o1 = tb[t1] + r1 * C::IW * 32;
+                    b[(i + 1) & 1] = frag_tr(buf, o1, o1 + 4 * 32);
+                    if (t1 == 0) {
+                        const int g1 = gbase + r1 * C::PW * 32;
+                        a[r1 & 1] = frag_tr(buf, g1, g1 + 4 * 32);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (t < 4 || th == 0) acc[t] = mfma16<F16>(a[r & 1], b[i & 1], acc[t]);
+                if (t == 2 && want_bias) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum += frag_f32<F16>(a[r & 1], j);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+    if (active) {
+        float* w = ws + P.ws_off + (size_t)split * 9 * 3 * 2048 + (size_t)ot * 2048;
+        const int cin = ct * 32 + (lane & 31), h = lane >> 5;
+        const int t0 = th * 5, na = th ? 4 : 5;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            if (t < na) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int oc = (j & 3) + 8 * (j >> 2) + 4 * h;
+                    w[(size_t)(t0 + t) * 3 * 2048 + oc * 64 + cin] = acc[t][j];
+                }
+            }
+        }
+        if (want_bias) {
+            const float tot = bsum + __shfl_xor(bsum, 32, 64);
+            if (lane < 32) ws[P.ws_bias_off + (size_t)split * 96 + ot * 32 + lane] = tot;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // wgrad v4 (round 3): the same parts (one 64-channel input block x up to three 32-oc tiles x 9 taps = 54 accumulator tiles) and the same
 // workspace layout as wgrad3, re-blocked around what the round-3 ablation of wgrad3 measured (profiles/r03e_wgrad3_ablation.txt: MFMA + fragment
 // reads alone 73 % of the launch, the register-staged global prefetch 21 %, the 12-wave LDS commit phase 4 %; 2.4 transposed LDS reads per MFMA):
@@ -1161,7 +1323,20 @@ int launch_wgrad4(const dasr_wgrad_part* parts, int nparts, int nsplit, float* w
     return (int)hipGetLastError();
 }
 
+template <bool F16>
+int launch_wgrad3_ld(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws, hipStream_t s) {
+    auto kfn = wgrad3_ld_kernel<F16>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, W3L::LDS_BYTES));
+        attr_set = true;
+    }
+    DASR_LAUNCH_TAG(__PRETTY_FUNCTION__, kfn, dim3(nparts * (nsplit & 0xffff)), dim3(W3L::NT), W3L::LDS_BYTES, s, parts, nparts, nsplit, ws);
+    return (int)hipGetLastError();
+}
+
 int g_use_tr = -1;  // -1 unknown, 0 gather fallback, 1 transpose reads
+int g_wgrad3_ld = 1;  // 3x3 stride-1 weight gradients on 16-bit tensors: wgrad3_ld_kernel (12 compute + 4 loader waves); 0 = wgrad3_kernel
 // 3x3 stride-1 weight gradients on 16-bit tensors: 0 = wgrad3_kernel (default), 1 = wgrad4_kernel (4 waves, LDS-DMA, register window).
 // Measured in round 3 (profiles/r03_wgrad_ablation.txt): wgrad4 halves the LDS fragment reads and removes the commit phase, but with ONE wave per
 // SIMD every LDS-DMA instruction that waits for the memory pipe also stops that SIMD's MFMAs: 0.79 PFLOP/s against wgrad3's 0.96 - 1.01 (three
@@ -1198,6 +1373,7 @@ extern "C" int dasr_wgrad_set_mode(int use_tr) {
 #endif
     g_wgrad3_glds = (use_tr & 2) ? 1 : 0;  // bit 1: LDS-DMA wgrad3 instead of the register-staged one (A/B)
     g_wgrad4 = (use_tr & 128) ? 1 : 0;     // bit 7: wgrad4_kernel instead of wgrad3_kernel (A/B)
+    g_wgrad3_ld = (use_tr & 256) ? 0 : 1;  // bit 8: the register-staged 12-wave wgrad3_kernel instead of the loader-wave kernel (A/B)
     use_tr &= 1;
     g_use_tr = use_tr;
     return 0;
@@ -1241,6 +1417,8 @@ extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int3
             default: break;
         }
 #endif
+        if (tr && g_wgrad3_ld && !g_wgrad4 && !g_wgrad3_glds && !g_wgrad3_abl && f32 != 1)
+            return f32 == 2 ? launch_wgrad3_ld<true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3_ld<false>(parts_dev, nparts, nsplit, ws, s);
         if (tr && g_wgrad4 && f32 != 1) return f32 == 2 ? launch_wgrad4<true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad4<false>(parts_dev, nparts, nsplit, ws, s);
         if (f32 == 2) return tr ? launch_wgrad3<true, false, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3<false, false, true>(parts_dev, nparts, nsplit, ws, s);
         if (tr && !f32 && g_wgrad3_glds) return launch_wgrad3_glds(parts_dev, nparts, nsplit, ws, s);

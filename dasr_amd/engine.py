@@ -456,11 +456,12 @@ def ensure_runtime_ready():
         global TR16_OK
         TR16_OK = rc
         import os
-        if rc == 1 and (os.environ.get('DASR_WGRAD_GLDS', '') in ('0', '1') or os.environ.get('DASR_WGRAD_ABL') or os.environ.get('DASR_WGRAD4', '') in ('0', '1')):
+        if rc == 1 and (os.environ.get('DASR_WGRAD_GLDS', '') in ('0', '1') or os.environ.get('DASR_WGRAD_ABL') or os.environ.get('DASR_WGRAD4', '') in ('0', '1')
+                        or os.environ.get('DASR_WGRAD_LD', '') in ('0', '1')):
             # A/B switches of the 3x3 weight-gradient kernels: DASR_WGRAD_GLDS=1 LDS-DMA staged wgrad3; DASR_WGRAD4=1 the 4-wave wgrad4_kernel;
             # DASR_WGRAD_ABL: ablation bits, only honoured by libdasr_hip_ablate.so
             L.dasr_wgrad_set_mode(1 | (2 if os.environ.get('DASR_WGRAD_GLDS') == '1' else 0) | (int(os.environ.get('DASR_WGRAD_ABL', '0')) << 3) |
-                                  (128 if os.environ.get('DASR_WGRAD4') == '1' else 0))
+                                  (128 if os.environ.get('DASR_WGRAD4') == '1' else 0) | (256 if os.environ.get('DASR_WGRAD_LD') == '0' else 0))   # DASR_WGRAD_LD=0: register-staged wgrad3_kernel
     return TR16_OK
 
 
