@@ -145,6 +145,12 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
     // bf16 tensors of the specialised variants move 16 bytes per lane (v_permlane32_swap pairs the two half-waves' 4-channel groups):
     // half the VMEM instructions of the epilogue, each covering one contiguous KiB (the store tail is issue-bound, not bandwidth-bound)
     constexpr bool WIDE16 = !G && !IN_F32;
+    // f32 tensors of the specialised variants: in the MFMA D layout one 16-byte access per lane touches HALF of 32 different 64-byte lines (a pixel's
+    // 16-channel plane is one line; a lane holds 4 of its channels, its partner lane kh2 the next 4) -- the vector L1 moves whole lines, so the
+    // fp32 residual loads / stores of conv5 ran at half its rate and the epilogue took 20 k cycles (18 % of the workgroup).  v_permlane16_swap
+    // exchanges the 16-lane rows of the register sets g = 2 pr and 2 pr + 1: set A then holds all four channel quarters of pixels 0-15, set B of
+    // pixels 16-31 -- every instruction covers 16 complete lines.
+    constexpr bool WIDE32 = !G && STRIDE == 1;
     constexpr bool PIPE_EPI = !G && !(MT == 2 && (EPI & 16)) && (EPI & (4 | 8 | 16));
     u32x4 mk[2][4], r1v[2][4], r2v[2][4];
     auto group_addr = [&](int gi, unsigned (&eo)[4], unsigned (&cbv)[4]) {
@@ -168,9 +174,23 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
             eo[g] = cv ? pixel + (unsigned)(oc & 15) : OOB;
         }
     };
+    // WIDE32 addressing of group gi: element offset (within a plane) of this lane's 4 channels in register set A / B
+    auto group_addr32 = [&](int gi, unsigned (&e32)[2]) {
+        const int nt = gi / MT;
+        const int oy = oy0 + wave * NT + nt;
+        const unsigned q4 = 4u * (2u * (unsigned)(nn >> 4) + (unsigned)kh2);
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int ox = ox0 + (nn & 15) + 16 * st;
+            const bool pv = (oy < p.Hout) & (ox < p.Wout);
+            e32[st] = pv ? (unsigned)((oy * ostr + p.out_oy) * owid + ox * ostr + p.out_ox) * 16u + q4 : OOB;
+        }
+    };
     auto issue_loads = [&](int gi, int slot) {
         unsigned eo[4], cbv[4];
         group_addr(gi, eo, cbv);
+        unsigned e32[2];
+        if constexpr (WIDE32) group_addr32(gi, e32);
         if (has_mask && !PRE) {
             if constexpr (WIDE16) {
                 // one 16-byte load per lane and 16-channel plane: lanes 0-31 fetch channels 0-7, lanes 32-63 channels 8-15 of their pixel
@@ -195,11 +215,25 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
         }
         if (has_r1) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) r1v[slot][g] = __builtin_amdgcn_raw_buffer_load_b128(rr1, eo[g] != OOB ? (cbv[g] * r1_cb + eo[g]) * 4u : OOB, 0, 0);
+            for (int g = 0; g < 4; ++g) {
+                if constexpr (WIDE32) r1v[slot][g] = __builtin_amdgcn_raw_buffer_load_b128(rr1, e32[g & 1] != OOB ? (cbv[g] * r1_cb + e32[g & 1]) * 4u : OOB, 0, 0);
+                else r1v[slot][g] = __builtin_amdgcn_raw_buffer_load_b128(rr1, eo[g] != OOB ? (cbv[g] * r1_cb + eo[g]) * 4u : OOB, 0, 0);
+            }
         }
         if (has_r2) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) r2v[slot][g] = __builtin_amdgcn_raw_buffer_load_b128(rr2, eo[g] != OOB ? (cbv[g] * r2_cb + eo[g]) * 4u : OOB, 0, 0);
+            for (int g = 0; g < 4; ++g) {
+                if constexpr (WIDE32) r2v[slot][g] = __builtin_amdgcn_raw_buffer_load_b128(rr2, e32[g & 1] != OOB ? (cbv[g] * r2_cb + e32[g & 1]) * 4u : OOB, 0, 0);
+                else r2v[slot][g] = __builtin_amdgcn_raw_buffer_load_b128(rr2, eo[g] != OOB ? (cbv[g] * r2_cb + eo[g]) * 4u : OOB, 0, 0);
+            }
+        }
+    };
+    auto rows_swap = [&](u32x4& a, u32x4& b) {   // sets (2 pr, 2 pr + 1) <-> (A, B): an involution
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const auto r = __builtin_amdgcn_permlane16_swap(a[j], b[j], false, false);
+            a[j] = r[0];
+            b[j] = r[1];
         }
     };
     if constexpr (PIPE_EPI) issue_loads(0, 0);
@@ -278,12 +312,20 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                     for (int j = 0; j < 4; ++j) v[g][j] *= p.alpha;
             }
             if (has_r1) {
+                if constexpr (WIDE32) {
+                    rows_swap(r1v[slot][0], r1v[slot][1]);
+                    rows_swap(r1v[slot][2], r1v[slot][3]);
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[g][j] += p.beta1 * __uint_as_float(r1v[slot][g][j]);
             }
             if (has_r2) {
+                if constexpr (WIDE32) {
+                    rows_swap(r2v[slot][0], r2v[slot][1]);
+                    rows_swap(r2v[slot][2], r2v[slot][3]);
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -296,7 +338,18 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                     for (int j = 0; j < 4; ++j)
                         if ((mg * MT + mi) * 32 + 8 * g + 4 * kh2 + j >= p.cout) v[g][j] = 0.f;
             }
-            if (has_f32) {
+            if (has_f32 && WIDE32) {
+                unsigned e32[2];
+                group_addr32(gi, e32);
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    u32x4 oa = {__float_as_uint(v[2 * pr][0]), __float_as_uint(v[2 * pr][1]), __float_as_uint(v[2 * pr][2]), __float_as_uint(v[2 * pr][3])};
+                    u32x4 ob = {__float_as_uint(v[2 * pr + 1][0]), __float_as_uint(v[2 * pr + 1][1]), __float_as_uint(v[2 * pr + 1][2]), __float_as_uint(v[2 * pr + 1][3])};
+                    rows_swap(oa, ob);
+                    __builtin_amdgcn_raw_buffer_store_b128(oa, rof, e32[0] != OOB ? (cbv[2 * pr] * of_cb + e32[0]) * 4u : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(ob, rof, e32[1] != OOB ? (cbv[2 * pr] * of_cb + e32[1]) * 4u : OOB, 0, 0);
+                }
+            } else if (has_f32) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const u32x4 o = {__float_as_uint(v[g][0]), __float_as_uint(v[g][1]), __float_as_uint(v[g][2]), __float_as_uint(v[g][3])};
@@ -767,6 +820,9 @@ struct GCfg {
     static constexpr int W_BYTES = WPIECE * 16;
     static constexpr int BUF_BYTES = ACT_BYTES + W_BYTES;
     static constexpr int LDS_BYTES = 2 * BUF_BYTES;
+    // RING: three activation images + two weight images (the activations are requested TWO chunks ahead, the weights one)
+    static constexpr int RING_W_OFF = 3 * ACT_BYTES, RING_LDS_BYTES = 3 * ACT_BYTES + 2 * W_BYTES;
+    static constexpr int FLAG_OFF = RING_LDS_BYTES, FLAG_BYTES = 32;   // RING = 3: done[4] (16-byte aligned), landed
 };
 
 // one 16-byte-per-lane DMA piece of chunk ck: piece i < AR activations, else weights; the LDS base is wave-uniform.
@@ -786,17 +842,73 @@ __device__ __forceinline__ void glds_dma_piece(int i, int ck, char* buf, __amdgp
     }
 }
 
+// one 1-KiB LDS-DMA instruction of the loader wave (a free function: hipcc drops the host-side kernel handle when the builtin sits in the body of
+// a __global__ template behind `if constexpr` / in a lambda)
+__device__ __forceinline__ void glds_dma_1k(__amdgpu_buffer_rsrc_t rs, char* lds_dst, unsigned voff, unsigned soff) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)lds_dst, 16, voff, soff, 0, 0);
+}
+
+// LDS flag words of the barrier-free form (RING = 3): read / written through inline assembly so that neither the compiler's alias analysis nor its
+// waitcnt pass are involved; the "memory" clobber pins the compute waves' fragment reads on the right side of a poll / publish
+__device__ __forceinline__ int lds_peek(unsigned addr) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ void lds_poke(unsigned addr, int v) { asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_poke_nc(unsigned addr, int v) { asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(v)); }
+__device__ __forceinline__ int lds_peek_min4_nc(unsigned addr) {   // min of four consecutive words (the loader's view of the compute waves' progress)
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr));
+    const int a = (int)v[0] < (int)v[1] ? (int)v[0] : (int)v[1], b = (int)v[2] < (int)v[3] ? (int)v[2] : (int)v[3];
+    return __builtin_amdgcn_readfirstlane(a < b ? a : b);
+}
+
+// RING form: activation piece i of chunk ck into the activation image at `abase`; weight piece r of chunk ck into the weight image at `wbase`
+template <int MT, int NW>
+__device__ __forceinline__ void glds_dma_act(int i, int ck, char* abase, __amdgpu_buffer_rsrc_t rin, const unsigned* goff, unsigned in_chunk_bytes, int wave) {
+    using C = GCfg<MT, NW>;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(abase + (i * C::NTH + wave * 64) * 16), 16, goff[i], (unsigned)ck * in_chunk_bytes, 0, 0);
+}
+template <int MT, int NW>
+__device__ __forceinline__ void glds_dma_w(int r, int ck, char* wbase, __amdgpu_buffer_rsrc_t rw, int wave, int tid) {
+    using C = GCfg<MT, NW>;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    if (r * C::NTH + wave * 64 < C::WPIECE)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(wbase + (r * C::NTH + wave * 64) * 16), 16, (unsigned)(tid + r * C::NTH) * 16u, (unsigned)ck * (9u * MT * 1024u), 0, 0);
+}
+
 // ABL (micro-benchmarks only, results are wrong; instantiated with ABL != 0 only under -DDASR_BENCH = libdasr_hip_ablate.so): bit 0 no DMA inside the main loop, bit 1 no fragment reads inside the main loop
 // (stale registers), bit 2 no vmcnt wait / barrier per chunk, bit 3 no MFMAs: what each component costs per chunk (guide: ablate, don't guess)
 // F16: the 16-bit activations and packed weights are f16 (HR tail of the generator in f16 storage): v_mfma_f32_32x32x16_f16.
 // p.ups: nearest x2 up-sampling folded into the DMA source addresses (upconv_blcok, block.py:854-861): each lane fetches the 16 bytes of
 // low-resolution pixel (y >> 1, x >> 1); the four duplicates come from L2.
-template <int MT, int EPI, int NW, int ABL = 0, bool F16 = false>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(const dasr_conv_params p) {
+// RING (round 3): the per-chunk ablation of the step (profiles/r03_conv_ablation.txt) showed the Cout = 32 launches bound by how many bytes a CU
+// keeps in flight: with two chunk buffers a workgroup can request chunk k + 1 only while it multiplies chunk k (0.6 - 1.2 us) and the round trip
+// under load is ~2 us, so every chunk ends waiting; and every wave that stalls issuing its DMA pieces holds the whole workgroup at the chunk
+// barrier.  RING keeps THREE activation images and two weight images in LDS (78 KB: still two workgroups per CU): the activations of chunk k + 2
+// and the weights of chunk k + 1 are requested during chunk k, the wait that ends chunk k is a COUNTED vmcnt (the pieces of chunk k + 2 stay in
+// flight across the barrier) and the barrier is a raw s_barrier (__syncthreads() would drain vmcnt).
+// RING = 2: RING plus ONE LOADER WAVE per workgroup (wave NW): after the prologue it alone issues the LDS-DMA (the 9 weight instructions of chunk
+// k + 1, then the 20 activation instructions of chunk k + 2) and waits for it; the four compute waves only read fragments and multiply.  Measured
+// motivation (profiles/r03_conv_ablation.txt): with the DMA in the compute waves the chunk barrier costs 2.8 us per launch (the waves stall
+// unevenly while issuing into a busy memory pipe and then wait for each other), without DMA the same barrier costs nothing.
+// RING = 3: RING = 2 WITHOUT the chunk barrier.  Two flag words in LDS replace it: the loader publishes `landed` = index of the newest chunk that is
+// complete in LDS, every compute wave publishes done[w] = number of chunks it has finished reading; a compute wave starts chunk k when
+// landed >= k, the loader overwrites the images of chunk k - 1 when min(done) >= k.  The waves of a workgroup may drift up to two chunks apart:
+// what the barrier cost (each wave shares its SIMD with a wave of ANOTHER workgroup in another phase, so the four waves never take the same time
+// for a chunk, and a barrier per chunk pays the maximum every time) averages out.
+template <int MT, int EPI, int NW, int ABL = 0, bool F16 = false, int RING = 0>
+__global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (NW == 4 ? 2 : 1)) void conv_glds_kernel(const dasr_conv_params p) {
     using C = GCfg<MT, NW>;
     constexpr int NT = C::NT;
+    constexpr bool LW = RING >= 2, FLAGS = RING == 3;
+    static_assert(!FLAGS || NW == 4, "done[] is read as one 16-byte word");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool is_loader = LW && wave == NW;
 #ifdef DASR_TRACE
     if (g_trace && threadIdx.x == 0) g_trace[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -852,10 +964,97 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
     const unsigned in_chunk_bytes = (unsigned)(a_cbstr * 2);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc((const bf16_t*)a_w + (size_t)mg * nchunks * 9 * MT * 512);
     constexpr int NP = C::AR + C::WR;
+    static_assert(!RING || (C::AR <= 15), "counted vmcnt");
     // chunk 0 is requested before the fragment addresses and accumulators are set up: the DMA round trip overlaps that ALU work
+    if constexpr (RING != 0) {   // issue order = landing order the counted waits rely on: act(0), w(0), act(1)
+        if (!is_loader) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) glds_dma_piece<MT, NW>(i, rot, smem, rin, rw, goff, in_chunk_bytes, wave, tid);
+            for (int i = 0; i < C::AR; ++i) glds_dma_act<MT, NW>(i, 0, smem, rin, goff, in_chunk_bytes, wave);
+#pragma unroll
+            for (int r = 0; r < C::WR; ++r) glds_dma_w<MT, NW>(r, 0, smem + C::RING_W_OFF, rw, wave, tid);
+            if (nchunks > 1 && !FLAGS) {   // (FLAGS: the loader requests chunk 1 as well, `landed` is then its business alone)
+#pragma unroll
+                for (int i = 0; i < C::AR; ++i) glds_dma_act<MT, NW>(i, 1, smem + C::ACT_BYTES, rin, goff, in_chunk_bytes, wave);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) glds_dma_piece<MT, NW>(i, rot, smem, rin, rw, goff, in_chunk_bytes, wave, tid);
+    }
     TRACE_STAMP(1);
+    if constexpr (LW) {
+        if (is_loader) {
+            // ---- loader wave: every DMA instruction after the prologue.  Activation instruction j (0 .. AR*NW-1) fills LDS bytes [1024 j, 1024 j + 1024) of an
+            // activation image (pieces q = 64 j + lane), weight instruction j (0 .. 9 MT - 1) bytes [1024 j, ...) of a weight image
+            constexpr int NA = C::AR * NW, NWI = C::WPIECE / 64;
+            static_assert(C::WPIECE % 64 == 0 && NA + NWI + NA <= 63, "vmcnt is a 6-bit counter");
+            unsigned lgoff[NA];
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int q = lane + 64 * j;
+                const int pp = q >> 1, h = (q & 1) ^ ((pp >> 3) & 1);
+                const int iy = pp / C::IW, ix = pp - iy * C::IW;
+                const int gy = iy0 + iy, gx = ix0 + ix;
+                const int us = (a_remap >> 8) & 1;
+                const bool ok = (pp < C::NPIX) & (gy >= 0) & (gy < (a_Hin << us)) & (gx >= 0) & (gx < (a_Win << us));
+                lgoff[j] = ok ? (unsigned)((((gy >> us) * a_Win + (gx >> us)) * 16 + 8 * h) * 2) : OOB;
+            }
+            constexpr int WAIT_A = 0x0F70 | (NA & 15) | ((NA >> 4) << 14);   // s_waitcnt vmcnt(NA)
+            if constexpr (FLAGS) {
+                const unsigned flags = (unsigned)(size_t)(DASR_LDS char*)smem + C::FLAG_OFF;
+                __builtin_amdgcn_s_setprio(3);   // a late request stalls four waves, a late MFMA one
+                lds_poke_nc(flags + 4 * (lane & 7), 0);   // done[0..3] = 0, landed = 0 (chunk 0: the prologue barrier), three spare words
+                if (nchunks > 1) {
+#pragma unroll
+                    for (int j = 0; j < NA; ++j) glds_dma_1k(rin, smem + C::ACT_BYTES + j * 1024, lgoff[j], in_chunk_bytes);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)");
+                __builtin_amdgcn_s_barrier();   // chunk 0 (requested by the compute waves) is in LDS, the flags are initialised
+                int aslot = 0;
+                for (int ck = 0; ck + 1 < nchunks; ++ck) {
+                    char* nwbuf = smem + C::RING_W_OFF + ((ck + 1) & 1) * C::W_BYTES;
+                    char* nabuf = smem + (aslot == 0 ? 2 : aslot - 1) * C::ACT_BYTES;
+                    const bool more2 = ck + 2 < nchunks;
+                    // the weight image of chunk ck + 1 and the activation image of chunk ck + 2 were last read for chunk ck - 1
+                    while (ck > 0 && lds_peek_min4_nc(flags) < ck) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                    for (int j = 0; j < NWI; ++j) glds_dma_1k(rw, nwbuf + j * 1024, (unsigned)(lane + 64 * j) * 16u, (unsigned)(ck + 1) * (9u * MT * 1024u));
+                    if (more2) {
+#pragma unroll
+                        for (int j = 0; j < NA; ++j) glds_dma_1k(rin, nabuf + j * 1024, lgoff[j], (unsigned)(ck + 2) * in_chunk_bytes);
+                        __builtin_amdgcn_s_waitcnt(WAIT_A);   // the weights of chunk ck + 1 and (requested a chunk ago) its activations have landed
+                    } else {
+                        __builtin_amdgcn_s_waitcnt(0x0F70);
+                    }
+                    lds_poke_nc(flags + 16, ck + 1);   // landed = ck + 1
+                    aslot = aslot == 2 ? 0 : aslot + 1;
+                }
+                __builtin_amdgcn_s_barrier();   // pairs with the compute waves' barrier in front of the epilogue (which reuses LDS)
+                return;
+            }
+            __builtin_amdgcn_s_barrier();   // chunk 0 (requested by the compute waves) is in LDS
+            int aslot = 0;
+            for (int ck = 0; ck < nchunks; ++ck) {
+                char* nwbuf = smem + C::RING_W_OFF + ((ck + 1) & 1) * C::W_BYTES;
+                char* nabuf = smem + (aslot == 0 ? 2 : aslot - 1) * C::ACT_BYTES;
+                const bool more = ck + 1 < nchunks, more2 = ck + 2 < nchunks;
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < NWI; ++j) glds_dma_1k(rw, nwbuf + j * 1024, (unsigned)(lane + 64 * j) * 16u, (unsigned)(ck + 1) * (9u * MT * 1024u));
+                }
+                if (more2) {
+#pragma unroll
+                    for (int j = 0; j < NA; ++j) glds_dma_1k(rin, nabuf + j * 1024, lgoff[j], (unsigned)(ck + 2) * in_chunk_bytes);
+                    __builtin_amdgcn_s_waitcnt(WAIT_A);   // the weights of chunk ck + 1 and (requested a chunk ago) its activations have landed
+                } else {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                }
+                __builtin_amdgcn_s_barrier();
+                aslot = aslot == 2 ? 0 : aslot + 1;
+            }
+            return;
+        }
+    }
     // ---- fragment read addresses: row rr (0..5) of this wave's 6 input rows, column shift kx; lane (nn, kh2)
     const int nn = lane & 31, kh2 = lane >> 5;
     int baddr[6][3];
@@ -866,7 +1065,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
             const int pp = (wave * NT + rr) * C::IW + nn + kx;
             baddr[rr][kx] = ((pp << 1) + (kh2 ^ ((pp >> 3) & 1))) << 4;
         }
-    const int aoff = C::ACT_BYTES + lane * 16;
+    const int aoff = lane * 16;   // relative to the chunk's weight image
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -876,18 +1075,35 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[mi][nt][j] = 0.f;
 
-
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's DMA pieces have landed
-    __syncthreads();
+    if constexpr (RING != 0) {
+        if (nchunks > 1 && !FLAGS) __builtin_amdgcn_s_waitcnt(0x0F70 | C::AR);   // vmcnt(AR): chunk 0 has landed, the activation pieces of chunk 1 may fly
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();
+    } else {
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's DMA pieces have landed
+        __syncthreads();
+    }
     TRACE_STAMP(2);
 
-    constexpr bool PRE = EPI == 68 && MT == 1 && !ABL;
+    constexpr bool PRE = EPI == 68 && MT == 1 && !ABL && RING < 2;   // (the loader-wave form runs three waves per SIMD: no registers left for the prefetched mask)
     MaskPre<NT * MT> mpre;
     bf16x8 fb[2][6], fa[2][MT];
+    int aslot = 0;   // RING: activation image of the current chunk (ck % 3)
+    const unsigned flag_base = (unsigned)(size_t)(DASR_LDS char*)smem + C::FLAG_OFF;
+    int landed_seen = 0;
     for (int ck = 0; ck < nchunks; ++ck) {
-        const char* buf = smem + (ck & 1) * C::BUF_BYTES;
+        if constexpr (FLAGS) {   // chunk ck is complete in LDS once the loader has published landed >= ck (peeked during the previous chunk: rarely a wait)
+            while (landed_seen < ck) {
+                landed_seen = lds_peek(flag_base + 16);
+                if (landed_seen < ck) __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        const char* buf = RING != 0 ? smem + aslot * C::ACT_BYTES : smem + (ck & 1) * C::BUF_BYTES;                   // activation image
+        const char* wbuf = RING != 0 ? smem + C::RING_W_OFF + (ck & 1) * C::W_BYTES : buf + C::ACT_BYTES;            // weight image
         char* nbuf = smem + ((ck + 1) & 1) * C::BUF_BYTES;
-        const bool more = ck + 1 < nchunks;
+        char* nwbuf = smem + C::RING_W_OFF + ((ck + 1) & 1) * C::W_BYTES;                                            // RING: weights of chunk ck + 1
+        char* nabuf = smem + (aslot == 0 ? 2 : aslot - 1) * C::ACT_BYTES;                                            // RING: activations of chunk ck + 2 -> the image chunk ck - 1 used
+        const bool more = ck + 1 < nchunks, more2 = ck + 2 < nchunks;
         if constexpr (PRE) {
             if (!more) mask_prefetch<MT, NT>(p, mpre, tid, mg, n, oy0, ox0);   // last chunk: the memory pipe is idle, the epilogue finds the mask in registers
         }
@@ -899,7 +1115,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
 #pragma unroll
             for (int rr = 0; rr < 6; ++rr) fb[0][rr] = *(const bf16x8*)(buf + baddr[rr][0]);
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi) fa[0][mi] = *(const bf16x8*)(buf + aoff + (0 * MT + mi) * 1024);
+            for (int mi = 0; mi < MT; ++mi) fa[0][mi] = *(const bf16x8*)(wbuf + aoff + (0 * MT + mi) * 1024);
         }
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
@@ -907,13 +1123,26 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
             if (s + 1 < 9 && rd) {
                 const int kx1 = (s + 1) / 3, ky1 = (s + 1) - kx1 * 3;
 #pragma unroll
-                for (int mi = 0; mi < MT; ++mi) fa[(s + 1) & 1][mi] = *(const bf16x8*)(buf + aoff + ((ky1 * 3 + kx1) * MT + mi) * 1024);
+                for (int mi = 0; mi < MT; ++mi) fa[(s + 1) & 1][mi] = *(const bf16x8*)(wbuf + aoff + ((ky1 * 3 + kx1) * MT + mi) * 1024);
                 if (ky == 1 && kx < 2) {  // rows of the next phase, requested one step before they are needed
 #pragma unroll
                     for (int rr = 0; rr < 6; ++rr) fb[(kx + 1) & 1][rr] = *(const bf16x8*)(buf + baddr[rr][kx + 1]);
                 }
             }
-            if (more && s < 4 && !(ABL & 1)) {  // all pieces of the next chunk are requested in the first steps: they have the rest of the chunk to land
+            if constexpr (LW) {
+                // (the loader wave issues every DMA instruction)
+            } else if constexpr (RING != 0) {   // issue order: the weights of chunk ck + 1 first, then the activations of chunk ck + 2 (the counted wait below)
+                if (s < 4 && !(ABL & 1)) {
+#pragma unroll
+                    for (int j = s * NP / 4; j < (s + 1) * NP / 4; ++j) {
+                        if (j < C::WR) {
+                            if (more) glds_dma_w<MT, NW>(j, ck + 1, nwbuf, rw, wave, tid);
+                        } else if (more2) {
+                            glds_dma_act<MT, NW>(j - C::WR, ck + 2, nabuf, rin, goff, in_chunk_bytes, wave);
+                        }
+                    }
+                }
+            } else if (more && s < 4 && !(ABL & 1)) {  // all pieces of the next chunk are requested in the first steps: they have the rest of the chunk to land
 #pragma unroll
                 for (int i = s * NP / 4; i < (s + 1) * NP / 4; ++i) glds_dma_piece<MT, NW>(i, ckn, nbuf, rin, rw, goff, in_chunk_bytes, wave, tid);
             }
@@ -933,14 +1162,31 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_glds_kernel(con
             __builtin_amdgcn_sched_barrier(0);
         }
         if (ck == 2) TRACE_STAMP(9);
-        if constexpr (!(ABL & 4)) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);
+        if constexpr (FLAGS) {
+            lds_poke(flag_base + 4 * wave, ck + 1);            // done[wave]: this wave has read everything it needs of chunk ck
+            if (more) landed_seen = lds_peek(flag_base + 16);  // (the round trip overlaps the MFMAs still in the pipe)
+            aslot = aslot == 2 ? 0 : aslot + 1;
+        } else if constexpr (LW) {
+            if (ck == 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // this wave's activation pieces of chunk 1 (the prologue's); later chunks: the loader waits
+            __builtin_amdgcn_s_barrier();
+            aslot = aslot == 2 ? 0 : aslot + 1;
+        } else if constexpr (RING != 0) {
+            // chunk ck + 1 (its activations were requested a whole chunk ago, its weights at the top of this one) has landed once only the AR
+            // activation pieces of chunk ck + 2 are still outstanding
+            if (more2) __builtin_amdgcn_s_waitcnt(0x0F70 | C::AR);
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_s_barrier();   // every wave's pieces of chunk ck + 1 are in LDS; every wave is done reading chunk ck
+            aslot = aslot == 2 ? 0 : aslot + 1;
+        } else if constexpr (!(ABL & 4)) {
+            if constexpr (!(ABL & 16)) __builtin_amdgcn_s_waitcnt(0x0F70);   // ABL bit 4: the barrier without the DMA wait
             if (ck == 2) TRACE_STAMP(10);
-            __syncthreads();
+            if constexpr (ABL & 32) __builtin_amdgcn_s_barrier();              // ABL bit 5 (with bit 4): raw s_barrier instead of __syncthreads()
+            else __syncthreads();
         }
         if (ck == 2) TRACE_STAMP(11);
     }
     TRACE_STAMP(4);
+    if constexpr (FLAGS) __builtin_amdgcn_s_barrier();   // the waves drift: nobody may still read fragments when the epilogue reuses LDS for the bias
     conv_epilogue<false, MT, NT, 1, EPI, F16 ? 1 : 0, PRE>(p, acc, smem, bias_reg, tid, mg, n, oy0, ox0, &mpre);
     TRACE_STAMP(6);
 #ifdef DASR_TRACE
@@ -1111,16 +1357,18 @@ int launch_ring3(const dasr_conv_params& p, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-template <int MT, int EPI = 0, int NW = 4, int ABL = 0, bool F16 = false>
+template <int MT, int EPI = 0, int NW = 4, int ABL = 0, bool F16 = false, int RING = 0>
 int launch_glds(const dasr_conv_params& p, hipStream_t s) {
     using C = GCfg<MT, NW>;
     static bool attr_set = false;
-    auto kfn = conv_glds_kernel<MT, EPI, NW, ABL, F16>;
+    auto kfn = conv_glds_kernel<MT, EPI, NW, ABL, F16, RING>;
+    constexpr int LDS = RING == 3 ? C::RING_LDS_BYTES + C::FLAG_BYTES : (RING != 0 ? C::RING_LDS_BYTES : C::LDS_BYTES);
+    constexpr int NTHREADS = C::NTH + (RING >= 2 ? 64 : 0);
     if ((p.cin & 15) || p.kh != 3 || p.stride != 1 || p.pad != 1 || p.in_f32 || p.prec != (F16 ? 2 : 1) || (p.pad_x >= 0 && p.pad_x != 1) || p.in_stride > 1)
         return DASR_EINVAL;
     if (p.out_bf16.p && (p.out16_f16 != 0) != F16) return DASR_EINVAL;   // the 16-bit output format of this kernel is its operand format (compile time)
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
     const int cout_tiles = (p.cout + 31) >> 5;
@@ -1128,7 +1376,7 @@ int launch_glds(const dasr_conv_params& p, hipStream_t s) {
     const int tiles_x = (p.Wout + C::TW - 1) / C::TW, tiles_y = (p.Hout + C::TH - 1) / C::TH;
     const long long grid = (long long)MG * tiles_x * tiles_y * p.N;
     if (grid <= 0 || grid > 0x7fffffffLL) return DASR_EINVAL;
-    DASR_LAUNCH_TAG(__PRETTY_FUNCTION__, kfn, dim3((unsigned)grid), dim3(C::NTH), C::LDS_BYTES, s, p);
+    DASR_LAUNCH_TAG(__PRETTY_FUNCTION__, kfn, dim3((unsigned)grid), dim3(NTHREADS), LDS, s, p);
     return (int)hipGetLastError();
 }
 
@@ -1275,12 +1523,32 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                 case 108: return launch_glds<1, 67, 4, 8>(p, s);
                 case 112: return launch_glds<1, 67, 4, 12>(p, s);
                 case 115: return launch_glds<1, 67, 4, 15>(p, s);
+                case 116: return launch_glds<1, 67, 4, 16>(p, s);   // barrier per chunk, no DMA wait
+                case 117: return launch_glds<1, 67, 4, 17>(p, s);   // no DMA in the loop, no wait, barrier kept
 #endif
                 case 12:
                     switch (g_tune_epi ? classify_epi(p) : 0) {
                         case 67: return launch_glds<1, 67>(p, s);
                         case 68: return launch_glds<1, 68>(p, s);
                         default: return launch_glds<1, 0>(p, s);
+                    }
+                case 15:   // RING: three activation images + two weight images, counted vmcnt (round 3)
+                    switch (g_tune_epi ? classify_epi(p) : 0) {
+                        case 67: return launch_glds<1, 67, 4, 0, false, 1>(p, s);
+                        case 68: return launch_glds<1, 68, 4, 0, false, 1>(p, s);
+                        default: return launch_glds<1, 0, 4, 0, false, 1>(p, s);
+                    }
+                case 17:   // RING + loader wave, flag words instead of the chunk barrier
+                    switch (g_tune_epi ? classify_epi(p) : 0) {
+                        case 67: return launch_glds<1, 67, 4, 0, false, 3>(p, s);
+                        case 68: return launch_glds<1, 68, 4, 0, false, 3>(p, s);
+                        default: return launch_glds<1, 0, 4, 0, false, 3>(p, s);
+                    }
+                case 16:   // RING + one loader wave per workgroup
+                    switch (g_tune_epi ? classify_epi(p) : 0) {
+                        case 67: return launch_glds<1, 67, 4, 0, false, 2>(p, s);
+                        case 68: return launch_glds<1, 68, 4, 0, false, 2>(p, s);
+                        default: return launch_glds<1, 0, 4, 0, false, 2>(p, s);
                     }
                 case 14:  // 8 waves, 32x32 tile, three-buffer ring with counted vmcnt (no drain inside the main loop)
                     switch (g_tune_epi ? classify_epi(p) : 0) {

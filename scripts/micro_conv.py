@@ -13,6 +13,7 @@ ap.add_argument('--streams', type=int, default=1)
 ap.add_argument('--noout', type=int, default=0)
 ap.add_argument('--zero', type=int, default=0, help='1: zero-filled activations and weights (DVFS: how much of the time is clock, not cycles)')
 ap.add_argument('--mode', type=str, default='fwd', help='fwd: bias+lrelu->bf16 | dgrad: mask->bf16 | conv5: bias, alpha, res1 -> f32+bf16')
+ap.add_argument('--alias5', type=int, default=0, help='conv5 mode: bit 0 residual aliased, bit 1 fp32 output aliased, bit 2 in-place')
 ap.add_argument('--alias', type=int, default=0, help='1: all images alias image 0 on the input, 2: also on the output (cache-resident working set)')
 a = ap.parse_args()
 engine.ensure_runtime_ready()
@@ -47,7 +48,14 @@ for s in range(a.streams):
         if a.mode == 'dgrad':
             ol.add(conv_op(pack, ref, xv, False, a.cin, a.hw, a.hw, a.hw, a.hw, n, mask=yv, mask_f32=0, out_bf16=ym.view()))
         elif a.mode == 'conv5':
-            ol.add(conv_op(pack, ref, xv, False, a.cin, a.hw, a.hw, a.hw, a.hw, n, bias=P.ptr('b'), alpha=0.2, res1=rf.view(), beta1=1.0, out_f32=of.view(), out_bf16=yv))
+            rv, ov = rf.view(), of.view()
+            if a.alias5 & 1:   # fp32 residual: every image reads image 0's
+                rv.n_stride = 0
+            if a.alias5 & 2:   # fp32 output: every image writes image 0's
+                ov.n_stride = 0
+            if a.alias5 & 4:   # fp32 output written over the residual (in place, as a read-modify-write stream would)
+                ov = rf.view()
+            ol.add(conv_op(pack, ref, xv, False, a.cin, a.hw, a.hw, a.hw, a.hw, n, bias=P.ptr('b'), alpha=0.2, res1=rv, beta1=1.0, out_f32=ov, out_bf16=yv))
         else:
             ol.add(conv_op(pack, ref, xv, False, a.cin, a.hw, a.hw, a.hw, a.hw, n, bias=P.ptr('b'), act=1, out_bf16=None if a.noout else yv, out_f32=None))
     ol.keep += [x, y, ym, rf, of]
@@ -63,7 +71,7 @@ t0 = time.perf_counter()
 run(); torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 fl = 2.0 * a.n * a.hw * a.hw * 9 * a.cin * a.cout * a.reps
-print('%s alias %d zero %d ' % (a.mode, a.alias, a.zero) + 'cin %d cout %d N %d streams %d tune [%s]: %.1f us/launch-set, %.0f TFLOP/s' % (a.cin, a.cout, a.n, a.streams, a.tune, dt / a.reps * 1e6, fl / dt / 1e12))
+print('%s alias %d/%d zero %d ' % (a.mode, a.alias, a.alias5, a.zero) + 'cin %d cout %d N %d streams %d tune [%s]: %.1f us/launch-set, %.0f TFLOP/s' % (a.cin, a.cout, a.n, a.streams, a.tune, dt / a.reps * 1e6, fl / dt / 1e12))
 
 if os.environ.get('DASR_HIP_LIB'):
     import ctypes, numpy as np

@@ -131,6 +131,47 @@ def test_conv_tuning_variants_match_torch(case, variant):
         _lib.check(L.dasr_set_tuning(key, 12))
 
 
+@pytest.mark.parametrize('tune64', [12, 13], ids=['4waves', '8waves'])
+@pytest.mark.parametrize('bias,res2', [(False, False), (True, False), (False, True), (True, True)], ids=['e232', 'e233', 'e248', 'e249'])
+@pytest.mark.parametrize('H,W', [(20, 36), (37, 45), (32, 64)], ids=['20x36', '37x45', '32x64'])
+def test_conv5_epilogue_variants_match_torch(bias, res2, H, W, tune64):
+    """conv5 of a dense block: 0.2 * conv + x (+ the RRDB's second residual) -> fp32 stream + bf16 shadow, the compile-time epilogues
+    232 / 233 / 248 / 249 of the LDS-DMA kernel (round 3: the fp32 residual loads and stores go through v_permlane16_swap so that every
+    instruction covers whole 64-byte lines) -- on ragged sizes (partial tiles in both directions) and on both workgroup shapes"""
+    dev = _gpu()
+    from dasr_amd import _lib
+    from dasr_amd.engine import BTensor, OpList, conv_op
+    L = _lib.lib()
+    cin, cout, N = 96, 64, 3
+    w, b, P, pack, ref = make_conv(cout, cin, 3, 2, 1, dev, 17)
+    g = torch.Generator().manual_seed(23)
+    x = bf16r(torch.randn(N, cin, H, W, generator=g))
+    r1 = torch.randn(N, cout, H, W, generator=g)
+    r2 = torch.randn(N, cout, H, W, generator=g)
+    xb, r1b, r2b = to_blocked(x, False, dev), to_blocked(r1, True, dev), to_blocked(r2, True, dev)
+    of = BTensor(N, cout, H, W, True, dev)
+    ob = BTensor(N, cout, H, W, False, dev)
+    ops = OpList()
+    kw = dict(alpha=0.04, res1=r1b.view(), beta1=0.2, out_f32=of.view(), out_bf16=ob.view())
+    if bias:
+        kw['bias'] = P.ptr('b')
+    if res2:
+        kw.update(res2=r2b.view(), beta2=1.0)
+    ops.add(conv_op(pack, ref, xb.view(), False, cin, H, W, H, W, N, **kw))
+    _lib.check(L.dasr_set_tuning(2, tune64))
+    try:
+        ops.run()
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(L.dasr_set_tuning(2, 13))
+    y = F.conv2d(x.double(), bf16r(w).double(), b.double() if bias else None, padding=1)
+    y = 0.04 * y + 0.2 * r1.double() + (r2.double() if res2 else 0.0)
+    got = of.nchw().cpu()
+    assert rel(got, y.float()) < 2e-5, rel(got, y.float())
+    assert (got - y.float()).abs().max().item() < 1e-4   # a mis-addressed pixel would be O(1)
+    assert rel(ob.nchw().cpu(), bf16r(y.float())) < 5e-3
+
+
 def test_conv_prec3_is_fp32_grade():
     """split-bf16 must be ~fp32 accurate on un-rounded operands (this is what the residual stream relies on)."""
     dev = _gpu()
