@@ -23,7 +23,7 @@ class ConvParams(C.Structure):
                 ('alpha', c_f32), ('res1', Tensor), ('beta1', c_f32), ('res2', Tensor), ('beta2', c_f32),
                 ('out_f32', Tensor), ('out_bf16', Tensor), ('gamma', c_f32), ('xcd_remap', c_i32),
                 ('pad_x', c_i32), ('out_stride', c_i32), ('out_oy', c_i32), ('out_ox', c_i32), ('out_W', c_i32), ('slope_ptr', c_vp),
-                ('in_stride', c_i32), ('in_oy', c_i32), ('in_ox', c_i32), ('in_W', c_i32), ('in_scale', c_f32), ('out16_f16', c_i32)]
+                ('in_stride', c_i32), ('in_oy', c_i32), ('in_ox', c_i32), ('in_W', c_i32), ('in_scale', c_f32), ('out16_f16', c_i32), ('in_wrap', c_i32), ('out16_lo', c_i32)]
 
 
 class WgradPart(C.Structure):
@@ -83,6 +83,7 @@ _SIGS = {
     'dasr_pixel_shuffle_f16': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_vp],
     'dasr_pixel_unshuffle_f16': [Tensor, Tensor, c_f32, c_i32, c_i32, c_i32, c_i32, Tensor, c_vp],
     'dasr_cvt_f16': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, Tensor, c_vp],
+    'dasr_cvt_split16': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, Tensor, c_i32, c_vp],
     'dasr_downsum2x_f16': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_f32, c_f32, Tensor, Tensor, c_vp],
     'dasr_downsum2x': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_f32, Tensor, Tensor, c_vp],
     'dasr_axpby': [Tensor, c_f32, Tensor, c_f32, c_i32, c_i32, c_i32, c_i32, Tensor, Tensor, c_f32, Tensor, c_f32, c_vp, c_vp],
@@ -139,7 +140,7 @@ _BENCH_SIGS = {
 }
 BENCH_LIB_PATH = os.path.join(HERE, 'libdasr_bench.so')
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 _lib = None
 _bench = None
 

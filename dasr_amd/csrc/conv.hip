@@ -127,6 +127,7 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
     const __amdgpu_buffer_rsrc_t rob = make_rsrc((bf16_t*)p.out_bf16.p + (size_t)n * p.out_bf16.n_stride);
     const unsigned mask_cb = (unsigned)p.mask.cb_stride, r1_cb = (unsigned)p.res1.cb_stride, r2_cb = (unsigned)p.res2.cb_stride;
     const unsigned of_cb = (unsigned)p.out_f32.cb_stride, ob_cb = (unsigned)p.out_bf16.cb_stride;
+    const unsigned lo_pl = (unsigned)p.out16_lo;   // split 16-bit output: the remainder goes lo_pl planes further (wave-uniform; 0 = plain)
     f32x4 bia[MT][4];
     if (has_bias) {
         float* bl = (float*)smem;
@@ -372,6 +373,21 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                     const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
                     const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};   // lanes 0-31: channels 0-7 of the plane, lanes 32-63: channels 8-15
                     __builtin_amdgcn_raw_buffer_store_b128(o, rob, eo[2 * pr] != OOB ? (cbv[2 * pr] * ob_cb + eo[2 * pr] + 4u * kh2) * 2u : OOB, 0, 0);
+                    if (lo_pl) {   // remainder plane: lo = round16(value - hi)
+                        bf16x4 la, lb;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float va = gm ? v[2 * pr][j] * p.gamma : v[2 * pr][j], vb = gm ? v[2 * pr + 1][j] * p.gamma : v[2 * pr + 1][j];
+                            const float ha = f16out ? (float)(f16_t)va : (float)(bf16_t)va, hb = f16out ? (float)(f16_t)vb : (float)(bf16_t)vb;   // (re-rounded, not read back from the packed vector)
+                            la[j] = f16out ? __builtin_bit_cast(bf16_t, (f16_t)(va - ha)) : (bf16_t)(va - ha);
+                            lb[j] = f16out ? __builtin_bit_cast(bf16_t, (f16_t)(vb - hb)) : (bf16_t)(vb - hb);
+                        }
+                        const u32x2 a2 = __builtin_bit_cast(u32x2, la), b2 = __builtin_bit_cast(u32x2, lb);
+                        const auto q0 = __builtin_amdgcn_permlane32_swap(a2[0], b2[0], false, false);
+                        const auto q1 = __builtin_amdgcn_permlane32_swap(a2[1], b2[1], false, false);
+                        const u32x4 o2 = {q0[0], q1[0], q0[1], q1[1]};
+                        __builtin_amdgcn_raw_buffer_store_b128(o2, rob, eo[2 * pr] != OOB ? ((cbv[2 * pr] + lo_pl) * ob_cb + eo[2 * pr] + 4u * kh2) * 2u : OOB, 0, 0);
+                    }
                 }
             } else if (has_bf16) {
                 const bool gm = scaled && p.gamma != 1.f;
@@ -391,6 +407,16 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                     }
 #endif
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), rob, eo[g] != OOB ? (cbv[g] * ob_cb + eo[g]) * 2u : OOB, 0, 0);
+                    if (lo_pl) {
+                        bf16x4 lb;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float vv = gm ? v[g][j] * p.gamma : v[g][j];
+                            const float hh = f16out ? (float)(f16_t)vv : (float)(bf16_t)vv;
+                            lb[j] = f16out ? __builtin_bit_cast(bf16_t, (f16_t)(vv - hh)) : (bf16_t)(vv - hh);
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lb), rob, eo[g] != OOB ? ((cbv[g] + lo_pl) * ob_cb + eo[g]) * 2u : OOB, 0, 0);
+                    }
                 }
             }
         }
@@ -829,11 +855,11 @@ struct GCfg {
 // (A free function, not a lambda: hipcc drops the host-side kernel handle when this builtin sits in a lambda of a __global__ template.)
 template <int MT, int NW>
 __device__ __forceinline__ void glds_dma_piece(int i, int ck, char* buf, __amdgpu_buffer_rsrc_t rin, __amdgpu_buffer_rsrc_t rw, const unsigned* goff,
-                                               unsigned in_chunk_bytes, int wave, int tid) {
+                                               unsigned in_chunk_bytes, int wave, int tid, int ckp) {
     using C = GCfg<MT, NW>;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     if (i < C::AR) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(buf + (i * C::NTH + wave * 64) * 16), 16, goff[i], (unsigned)ck * in_chunk_bytes, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(buf + (i * C::NTH + wave * 64) * 16), 16, goff[i], (unsigned)ckp * in_chunk_bytes, 0, 0);
     } else {
         const int r = i - C::AR;
         if (r * C::NTH + wave * 64 < C::WPIECE)
@@ -941,6 +967,7 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
     const int oy0 = ty * C::TH, ox0 = tx * C::TW;
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
     const int nchunks = a_cin >> 4;
+    const int in_wrap = p.in_wrap > 0 ? p.in_wrap : 0x7fffffff;   // split 16-bit input: chunks >= in_wrap read the hi planes a second time
     constexpr int rot = 0;   // (per-workgroup chunk-order rotation was tried against L2 hot-spotting of the shared weight blocks: no effect)
     float bias_reg = 0.f;
     {
@@ -979,7 +1006,7 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < NP; ++i) glds_dma_piece<MT, NW>(i, rot, smem, rin, rw, goff, in_chunk_bytes, wave, tid);
+        for (int i = 0; i < NP; ++i) glds_dma_piece<MT, NW>(i, rot, smem, rin, rw, goff, in_chunk_bytes, wave, tid, rot);
     }
     TRACE_STAMP(1);
     if constexpr (LW) {
@@ -1108,6 +1135,7 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
             if (!more) mask_prefetch<MT, NT>(p, mpre, tid, mg, n, oy0, ox0);   // last chunk: the memory pipe is idle, the epilogue finds the mask in registers
         }
         const int ckn = ck + 1 + rot < nchunks ? ck + 1 + rot : ck + 1 + rot - nchunks;  // global index of the next chunk
+        const int ckp = ckn >= in_wrap ? ckn - in_wrap : ckn;                            // ... and the input plane group it reads
         if (ck == 2) TRACE_STAMP(8);
         // step s = kx * 3 + ky; B rows of phase kx live in fb[kx & 1], A of step s in fa[s & 1]
         const bool rd = !(ABL & 2) || ck == 0;   // ablation: fragments are read in the first chunk only
@@ -1144,7 +1172,7 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
                 }
             } else if (more && s < 4 && !(ABL & 1)) {  // all pieces of the next chunk are requested in the first steps: they have the rest of the chunk to land
 #pragma unroll
-                for (int i = s * NP / 4; i < (s + 1) * NP / 4; ++i) glds_dma_piece<MT, NW>(i, ckn, nbuf, rin, rw, goff, in_chunk_bytes, wave, tid);
+                for (int i = s * NP / 4; i < (s + 1) * NP / 4; ++i) glds_dma_piece<MT, NW>(i, ckn, nbuf, rin, rw, goff, in_chunk_bytes, wave, tid, ckp);
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(ABL & 8)) {
@@ -1501,6 +1529,13 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
     if (p.kh < 1 || p.kh > 5) return DASR_EINVAL;
     if (p.mask.p && (p.mask_f32 != 0) != (p.in_f32 != 0)) return DASR_EINVAL;  // mask dtype is tied to the input dtype
     if (p.ups && !p.in_f32 && p.prec != 2) return DASR_EINVAL;
+    if (p.in_wrap < 0 || p.out16_lo < 0) return DASR_EINVAL;
+    if (p.in_wrap || p.out16_lo) {   // split 16-bit tensors: the LDS-DMA kernel only (a 16-bit input, 3x3 / stride 1 / pad 1, one-pass precisions)
+        if (p.in_f32 || p.kh != 3 || p.stride != 1 || p.pad != 1 || !(p.prec == 1 || p.prec == 2) || p.ups || p.out_stride > 1) return DASR_EINVAL;
+        if (p.in_wrap && (p.cin >> 4) * 2 != p.in_wrap * 3) return DASR_EINVAL;   // cin = 3 * 16K virtual channels, in_wrap = 2K
+        if (p.out16_lo && !p.out_bf16.p) return DASR_EINVAL;
+        if (p.prec == 1 && ((p.mt == 1 && g_tune_rdb32 != 12) || (p.mt == 2 && g_tune_rdb64 != 12 && g_tune_rdb64 != 13))) return DASR_EINVAL;   // (A/B variants of the first-generation kernel do not know the layout)
+    }
     switch (key) {
         // prec 1, bf16 input (RDB dense-block convs, fwd and dgrad)
         case 10:

@@ -633,6 +633,85 @@ __global__ void maxpool_bwd_kernel(dasr_tensor x, dasr_tensor gy, int N, int C, 
     }
 }
 
+// the same on SPLIT 16-bit tensors (value = hi + lo, the lo planes follow the ncb hi planes: dasr_conv_params::in_wrap): the pair of the
+// first maximum is copied / its gradient pair routed, nothing is re-rounded
+template <typename T>
+__global__ void maxpool_fwd_split_kernel(dasr_tensor x, int N, int C, int Ho, int Wo, dasr_tensor y) {
+    const int ncb = (C + 15) >> 4;
+    const long long total = (long long)N * ncb * Ho * Wo * 4;
+    const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= total) return;
+    const int q = gi & 3;
+    long long i = gi >> 2;
+    const int xx = i % Wo; i /= Wo;
+    const int yy = i % Ho; i /= Ho;
+    const int cb = i % ncb;
+    const int n = i / ncb;
+    const int W = 2 * Wo;
+    const size_t xlo = (size_t)ncb * x.cb_stride, ylo = (size_t)ncb * y.cb_stride;
+    const T* xp = (const T*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + q * 4;
+    T* yp = (T*)y.p + (size_t)n * y.n_stride + (size_t)cb * y.cb_stride + ((size_t)yy * Wo + xx) * 16 + q * 4;
+    float m[4];
+    T mh[4], ml[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { m[j] = -3.4e38f; mh[j] = (T)0.f; ml[j] = (T)0.f; }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const T* s = xp + ((size_t)(2 * yy + (d >> 1)) * W + 2 * xx + (d & 1)) * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const T h = s[j], l = s[xlo + j];
+            const float v = (float)h + (float)l;
+            if (v > m[j]) { m[j] = v; mh[j] = h; ml[j] = l; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { yp[j] = mh[j]; yp[ylo + j] = ml[j]; }
+}
+
+// GSPLIT false: only the activations x are split, the gradients are plain 16-bit tensors
+template <typename T, bool GSPLIT>
+__global__ void maxpool_bwd_split_kernel(dasr_tensor x, dasr_tensor gy, int N, int C, int Ho, int Wo, dasr_tensor gx, int relu_mask) {
+    const int ncb = (C + 15) >> 4;
+    const long long total = (long long)N * ncb * Ho * Wo * 4;
+    const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= total) return;
+    const int q = gi & 3;
+    long long i = gi >> 2;
+    const int xx = i % Wo; i /= Wo;
+    const int yy = i % Ho; i /= Ho;
+    const int cb = i % ncb;
+    const int n = i / ncb;
+    const int W = 2 * Wo;
+    const size_t xlo = (size_t)ncb * x.cb_stride, glo = (size_t)ncb * gy.cb_stride, olo = (size_t)ncb * gx.cb_stride;
+    const T* xp = (const T*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + q * 4;
+    const T* gp = (const T*)gy.p + (size_t)n * gy.n_stride + (size_t)cb * gy.cb_stride + ((size_t)yy * Wo + xx) * 16 + q * 4;
+    T* op = (T*)gx.p + (size_t)n * gx.n_stride + (size_t)cb * gx.cb_stride + q * 4;
+    float m[4];
+    int am[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { m[j] = -3.4e38f; am[j] = 0; }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const T* s = xp + ((size_t)(2 * yy + (d >> 1)) * W + 2 * xx + (d & 1)) * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = (float)s[j] + (float)s[xlo + j];
+            if (v > m[j]) { m[j] = v; am[j] = d; }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        T* o = op + ((size_t)(2 * yy + (d >> 1)) * W + 2 * xx + (d & 1)) * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool hit = am[j] == d && !(relu_mask && m[j] <= 0.f);
+            o[j] = hit ? gp[j] : (T)0.f;
+            if (GSPLIT) o[olo + j] = hit ? gp[glo + j] : (T)0.f;
+        }
+    }
+}
+
 // L1 between two blocked tensors over all C channels: loss_acc += coef*sum|a-b|; ga = gcoef*sign(a-b)
 template <typename T>
 __global__ void l1_diff_kernel(dasr_tensor a, dasr_tensor b, int N, int C, int H, int W, float coef, float gcoef, float* loss_acc, dasr_tensor ga,
@@ -670,7 +749,7 @@ __global__ void l1_diff_kernel(dasr_tensor a, dasr_tensor b, int N, int C, int H
 
 // y[c] = x[c] * sc[c] + sh[c] on C (<=4) channels of plane 0 (VGG input normalisation and its adjoint);
 // optional accumulate into y (used for dL/dSR += dL/dnorm / std)
-template <typename TO>
+template <typename TO, bool SPLIT = false>
 __global__ void affine4_kernel(dasr_tensor x, int N, int C, int H, int W, f32x4 sc, f32x4 sh, dasr_tensor y, int accumulate) {
     const long long total = (long long)N * H * W;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -682,6 +761,16 @@ __global__ void affine4_kernel(dasr_tensor x, int N, int C, int H, int W, f32x4 
     for (int j = 0; j < 4; ++j)
         if (j >= C) v[j] = 0.f;
     TO* o = (TO*)y.p + (size_t)n * y.n_stride + (size_t)p * 16;
+    if (SPLIT) {   // split 16-bit tensor of one plane pair: hi in plane 0, the remainder in plane 1
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float vv = j < 4 ? v[j] : 0.f;
+            const TO h = (TO)vv;
+            o[j] = h;
+            o[y.cb_stride + j] = (TO)(vv - (float)h);
+        }
+        return;
+    }
     if (accumulate) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (TO)((float)o[j] + v[j]);
@@ -968,7 +1057,9 @@ extern "C" int dasr_lowpass(dasr_tensor x, dasr_tensor x2, const float* w, int32
 extern "C" int dasr_maxpool2(dasr_tensor x, int32_t is_f32, int32_t N, int32_t C, int32_t Ho, int32_t Wo, dasr_tensor y, void* stream) {
     const long long total = (long long)N * ((C + 15) / 16) * Ho * Wo * 4;
     if (total <= 0) return DASR_EINVAL;
-    if (is_f32 == 2) DASR_LAUNCH(maxpool_fwd_kernel<f16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
+    if (is_f32 == 3) DASR_LAUNCH(maxpool_fwd_split_kernel<f16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
+    else if (is_f32 == 4) DASR_LAUNCH(maxpool_fwd_split_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
+    else if (is_f32 == 2) DASR_LAUNCH(maxpool_fwd_kernel<f16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
     else if (is_f32) DASR_LAUNCH(maxpool_fwd_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
     else DASR_LAUNCH(maxpool_fwd_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
     return (int)hipGetLastError();
@@ -978,7 +1069,10 @@ extern "C" int dasr_maxpool2_bwd(dasr_tensor x, dasr_tensor gy, int32_t is_f32, 
                                  int32_t relu_mask, void* stream) {
     const long long total = (long long)N * ((C + 15) / 16) * Ho * Wo * 4;
     if (total <= 0) return DASR_EINVAL;
-    if (is_f32 == 2) DASR_LAUNCH(maxpool_bwd_kernel<f16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
+    if (is_f32 == 3) DASR_LAUNCH((maxpool_bwd_split_kernel<f16_t, true>), dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
+    else if (is_f32 == 4) DASR_LAUNCH((maxpool_bwd_split_kernel<bf16_t, true>), dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
+    else if (is_f32 == 5) DASR_LAUNCH((maxpool_bwd_split_kernel<f16_t, false>), dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
+    else if (is_f32 == 2) DASR_LAUNCH(maxpool_bwd_kernel<f16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
     else if (is_f32) DASR_LAUNCH(maxpool_bwd_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
     else DASR_LAUNCH(maxpool_bwd_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
     return (int)hipGetLastError();
@@ -1000,7 +1094,9 @@ extern "C" int dasr_affine4(dasr_tensor x, int32_t N, int32_t C, int32_t H, int3
     const long long total = (long long)N * H * W;
     if (total <= 0 || C > 4) return DASR_EINVAL;
     const f32x4 sc = {scale4[0], scale4[1], scale4[2], scale4[3]}, sh = {shift4[0], shift4[1], shift4[2], shift4[3]};
-    if (y_f32 == 2) DASR_LAUNCH(affine4_kernel<f16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, sc, sh, y, accumulate);
+    if (y_f32 == 3 && !accumulate) DASR_LAUNCH((affine4_kernel<f16_t, true>), dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, sc, sh, y, accumulate);
+    else if (y_f32 == 3) return DASR_EINVAL;
+    else if (y_f32 == 2) DASR_LAUNCH(affine4_kernel<f16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, sc, sh, y, accumulate);
     else if (y_f32) DASR_LAUNCH(affine4_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, sc, sh, y, accumulate);
     else DASR_LAUNCH(affine4_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, sc, sh, y, accumulate);
     return (int)hipGetLastError();

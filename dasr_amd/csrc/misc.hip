@@ -24,9 +24,12 @@ __global__ void pack_kernel(const dasr_pack_desc* __restrict__ descs, int ndesc,
     const int tap = q % D.ntaps;
     q /= D.ntaps;
     const int nchunks = D.cin_pad >> 4;
-    const int ck = q % nchunks;
+    const int ckv = q % nchunks;
     const int mg = q / nchunks;
     const int oc = (mg * D.mt + mi) * 32 + (lane & 31);
+    // fmt 3 / 4 (split 16-bit tensors, dasr_conv_params::in_wrap): cin_pad counts 3K virtual chunks [hi | hi | lo] of K real ones
+    const int kreal = D.fmt >= 3 ? nchunks / 3 : nchunks;
+    const int part = ckv / kreal, ck = ckv - part * kreal;
     const int c0 = ck * 16 + 8 * (lane >> 5);
     bf16x8 vh, vl;
 #pragma unroll
@@ -57,7 +60,8 @@ __global__ void pack_kernel(const dasr_pack_desc* __restrict__ descs, int ndesc,
         bf16_t h, l;
         split_bf16(v, h, l);
         if (D.fmt == 1) h = __builtin_bit_cast(bf16_t, (f16_t)v);   // f16 bit pattern (prec 2 convs)
-        if (D.fmt == 2) split_f16(v, h, l);                           // f16 hi + lo planes (prec 4 convs)
+        if (D.fmt == 2 || D.fmt == 3) split_f16(v, h, l);             // f16 hi + lo planes (prec 4 convs) / virtual chunks (fmt 3)
+        if (D.fmt >= 3 && part == 2) h = l;                           // third group of virtual chunks: the remainders
         vh[e] = h;
         vl[e] = l;
     }
@@ -315,6 +319,28 @@ __global__ void cvt_f16_kernel(dasr_tensor x, int N, int C, int H, int W, float 
     *(f16x4*)((f16_t*)y.p + (size_t)n * y.n_stride + (size_t)cb * y.cb_stride + e) = o;
 }
 
+// split 16-bit copy of scale * x: hi = round16(scale * x) into the first ncb planes of y, lo = round16(scale * x - hi) into the next ncb
+template <typename T>
+__global__ void cvt_split16_kernel(dasr_tensor x, int N, int C, int H, int W, float scale, dasr_tensor y) {
+    const int ncb = (C + 15) >> 4;
+    const long long per_plane = (long long)H * W * 4, total = (long long)N * ncb * per_plane;
+    const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= total) return;
+    const long long e = (gi % per_plane) * 4;
+    long long t = gi / per_plane;
+    const int cb = t % ncb, n = t / ncb;
+    const f32x4 v = *(const f32x4*)((const float*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + e);
+    T* yp = (T*)y.p + (size_t)n * y.n_stride + (size_t)cb * y.cb_stride + e;
+    const size_t lo = (size_t)ncb * y.cb_stride;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float vv = v[j] * scale;
+        const T h = (T)vv;
+        yp[j] = h;
+        yp[lo + j] = (T)(vv - (float)h);
+    }
+}
+
 // backward of nn.Upsample(nearest, 2) on f16 tensors: dst[y][x] = out_scale * (LeakyReLU' mask) * sum of the 2x2 block of src;
 // dst is f16 (df.p == NULL) or f32.  thread per (n, cb, y, x, 4-channel quad) at the LOW resolution
 __global__ void downsum2x_f16_kernel(dasr_tensor src, int N, int C, int H, int W, dasr_tensor mask, float slope, float out_scale, dasr_tensor df,
@@ -425,6 +451,14 @@ extern "C" int dasr_cvt_f16(dasr_tensor x, int32_t N, int32_t C, int32_t H, int3
     const long long total = (long long)N * ((C + 15) / 16) * H * W * 4;
     if (total <= 0 || !x.p || !y.p) return DASR_EINVAL;
     DASR_LAUNCH(cvt_f16_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, scale, y);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_cvt_split16(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, float scale, dasr_tensor y, int32_t f16, void* stream) {
+    const long long total = (long long)N * ((C + 15) / 16) * H * W * 4;
+    if (total <= 0 || !x.p || !y.p) return DASR_EINVAL;
+    if (f16) DASR_LAUNCH(cvt_split16_kernel<f16_t>, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, scale, y);
+    else DASR_LAUNCH(cvt_split16_kernel<bf16_t>, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, scale, y);
     return (int)hipGetLastError();
 }
 
@@ -650,7 +684,10 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream0) {
             case DASR_OP_SET_STREAM: stream = o.p[0] ? o.p[0] : stream0; break;
             case DASR_OP_PIXSHUF: rc = dasr_pixel_shuffle_f16(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1], stream); break;
             case DASR_OP_PIXUNSHUF: rc = dasr_pixel_unshuffle_f16(o.t[0], o.t[1], o.f[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[2], stream); break;
-            case DASR_OP_CVT_F16: rc = dasr_cvt_f16(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1], stream); break;
+            case DASR_OP_CVT_F16:   // i[4]: 0 plain f16 copy, 1 split f16, 2 split bf16
+                rc = o.i[4] ? dasr_cvt_split16(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1], o.i[4] == 1, stream)
+                            : dasr_cvt_f16(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1], stream);
+                break;
             case DASR_OP_DOWNSUM_F16: rc = dasr_downsum2x_f16(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1], o.f[0], o.f[1], o.t[2], o.t[3], stream); break;
             case DASR_OP_BNORM_FWD:
                 rc = dasr_bnorm_lrelu_fwd(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.f[0], o.f[1], (const float*)o.p[0], (const float*)o.p[1], o.t[1],

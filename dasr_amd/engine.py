@@ -132,7 +132,12 @@ class PackRegistry:
         r.off, r.cout, r.cin_pad, r.ntaps, r.mt, r.prec = self.size, cout, cin_pad, ntaps, mt, prec
         r.lo_off = pieces * 8 if prec in (3, 4) else 0
         d = PackDesc()
-        d.fmt = 1 if prec == 2 else (2 if prec == 4 else 0)   # prec 2: f16 operands (one MFMA pass); 4: f16 hi + lo planes; 1 / 3: bf16 hi (+ lo) planes
+        # prec 2: f16 operands (one MFMA pass); 4: f16 hi + lo planes; 1 / 3: bf16 hi (+ lo) planes; 5 (f16) / 6 (bf16): split 16-bit TENSORS -- cin_pad
+        # counts 3K virtual chunks [hi | hi | lo] for one launch of the LDS-DMA kernel (conv_op in_wrap); the conv itself runs as prec 2 / 1
+        d.fmt = {2: 1, 4: 2, 5: 3, 6: 4}.get(prec, 0)
+        if prec in (5, 6):
+            assert cin_pad % 48 == 0
+            r.prec = 2 if prec == 5 else 1
         d.dst_off, d.lo_off, d.cout, d.cin_pad, d.ntaps, d.mt, d.nseg = self.size, r.lo_off, cout, cin_pad, ntaps, mt, len(segs)
         d.src_ntaps = src_ntaps or ntaps
         if tapmap is None:
@@ -236,13 +241,14 @@ def run_interleaved(lists, streams, chunk=None):
 
 def conv_op(pack, ref, inp, in_f32, cin, Hin, Win, Hout, Wout, N, bias=None, kh=3, stride=1, pad=1, ups=0, act=0, slope=SLOPE,
             mask=None, mask_f32=0, alpha=1.0, res1=None, beta1=0.0, res2=None, beta2=0.0, out_f32=None, out_bf16=None, gamma=1.0,
-            pad_x=-1, out_stride=1, out_oy=0, out_ox=0, out_W=0, slope_ptr=None, in_stride=1, in_oy=0, in_ox=0, in_W=0, flops=None, in_scale=0.0, out16_f16=0):
+            pad_x=-1, out_stride=1, out_oy=0, out_ox=0, out_W=0, slope_ptr=None, in_stride=1, in_oy=0, in_ox=0, in_W=0, flops=None, in_scale=0.0, out16_f16=0,
+            in_wrap=0, out16_lo=0):
     """flops: algorithmic FLOPs of the reference op this launch stands for (default: 2 * outputs * taps * cin * cout of the launch
     itself; the sub-pixel upconv launches pass a quarter of the reference's 3x3 conv on the up-sampled grid instead)."""
     assert cin == ref.cin_pad, (cin, ref.cin_pad)
     o = Op()
     o.op = _lib.OP_CONV
-    o.flops = float(flops) if flops is not None else 2.0 * N * Hout * Wout * kh * kh * cin * ref.cout
+    o.flops = float(flops) if flops is not None else 2.0 * N * Hout * Wout * kh * kh * (cin // 3 if in_wrap else cin) * ref.cout
     p = o.conv
     p.inp, p.in_f32, p.Hin, p.Win, p.ups, p.cin = inp, int(in_f32), Hin, Win, ups, cin
     p.w, p.w_lo_off, p.bias = pack.ptr(ref), ref.lo_off, bias
@@ -261,6 +267,7 @@ def conv_op(pack, ref, inp, in_f32, cin, Hin, Win, Hout, Wout, N, bias=None, kh=
     p.in_stride, p.in_oy, p.in_ox, p.in_W = in_stride, in_oy, in_ox, in_W
     p.in_scale = in_scale if (ref.prec in (2, 4) and in_f32) else 0.0   # power-of-two pre-scale of an f32 gradient input before its f16 rounding
     p.out16_f16 = int(out16_f16)
+    p.in_wrap, p.out16_lo = int(in_wrap), int(out16_lo)   # split 16-bit tensors (SplitTensor): 2K input planes before the hi planes repeat; K' output planes
     return o
 
 

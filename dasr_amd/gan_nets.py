@@ -430,7 +430,7 @@ def vgg19_spec(feature_layer=34, cfg=None):
 class VGGFeatureHIP:
     """Frozen feature extractor: forward on N images, data-gradient w.r.t. the first n_g inputs."""
 
-    def __init__(self, feature_layer=34, device='cuda', cfg=None, prec=None):
+    def __init__(self, feature_layer=34, device='cuda', cfg=None, prec=None, bwd_prec=None):
         """prec 4 (default): split-f16 operands on f32 tensors (f16 hi + lo pairs, 22 mantissa bits, 3 MFMA passes; gradients pre-scaled by a
         power of two): input-gradient error 4.9e-6 against the fp32 oracle.  prec 3: split-bf16 (16 bits), same cost: 6.5e-3 on the input
         gradient (max-pool arg-max flips on 16-bit ties), the default until round 2.  prec 2: activations and gradients stored in f16
@@ -441,13 +441,21 @@ class VGGFeatureHIP:
         default.  prec 1: plain bf16 operands on f32 tensors (8x coarser than f16)."""
         import os
         self.device = torch.device(device)
-        self.prec = int(prec if prec is not None else os.environ.get('DASR_VGG_PREC', '4'))
+        self.prec = int(prec if prec is not None else os.environ.get('DASR_VGG_PREC', '5'))
         self.f16s = self.prec == 2
+        # prec 5 (round 3, default): the SAME 22-bit operands as prec 4, but activations and gradients are STORED split (f16 hi planes + f16
+        # remainder planes, 4 bytes per element like f32) so that the three products hi*hi + lo*hi + hi*lo are one launch of the LDS-DMA dense-conv
+        # kernel over 3K virtual chunks (dasr_conv_params::in_wrap) instead of three passes of the register-staged first-generation kernel
+        self.split = self.prec == 5
+        # prec 5, data gradient: the gradients are NOT what decides max-pool's arg-max routing or the ReLU masks (the forward activations are, and
+        # they keep 22 bits), so their rounding enters dL/dx like noise: one f16 pass (11-bit gradients and weights, pre-scaled) instead of three
+        # on split gradients -- 3 of the 7 pass-equivalents of the perceptual network become 1.  DASR_VGG_BWD_PREC=5: three passes.
+        self.bwd_prec = int(bwd_prec if bwd_prec is not None else os.environ.get('DASR_VGG_BWD_PREC', '2')) if self.split else self.prec
         # images [n_g, N) of a plan carry no gradient (the real HR half of the DASR feature loss, DASR_model.py:225; the bicubic LR half of the DSN
         # perceptual loss, loss.py:119-130): their features are only the TARGET of an L1 / MSE, so the operand rounding of a single f16 MFMA pass
         # (1e-3 on the features, zero-mean) enters the loss value in second order and the gradient only through sign flips of near-ties.  One
         # pass instead of three on a third of the perceptual network's work.  DASR_VGG_NOGRAD_PREC=0: same precision as the gradient half.
-        self.nograd_prec = int(os.environ.get('DASR_VGG_NOGRAD_PREC', '2')) if self.prec in (3, 4) else 0
+        self.nograd_prec = int(os.environ.get('DASR_VGG_NOGRAD_PREC', '2')) if self.prec in (3, 4, 5) else 0
         self.spec, self.layers = vgg19_spec(feature_layer, cfg)
         self.params = ParamStore(self.spec, self.device)
         self.pack = PackRegistry(self.params)
@@ -458,10 +466,14 @@ class VGGFeatureHIP:
                 continue
             w = P.off('features.%d.weight' % idx)
             cin_pad = ceil_div(cin, 16) * 16
-            mt_f = 2 if (self.prec in (1, 2) and cout % 64 == 0) else 1
-            mt_b = 2 if (self.prec in (1, 2) and cin % 64 == 0) else 1
-            self.pk[idx] = self.pack.add(cout, cin_pad, 9, mt_f, self.prec, [(w, cout, cin, 0, cin, 0, 0)])
-            self.pk[(idx, 'b')] = self.pack.add(cin, cout, 9, mt_b, self.prec, [(w, cout, cin, 0, cout, 0, 1)])
+            mt_f = 2 if (self.prec in (1, 2, 5) and cout % 64 == 0) else 1
+            mt_b = 2 if (self.prec in (1, 2, 5) and cin % 64 == 0) else 1
+            v3 = 3 if self.split else 1   # split tensors: 3K virtual chunks [hi | hi | lo]
+            self.pk[idx] = self.pack.add(cout, v3 * cin_pad, 9, mt_f, self.prec, [(w, cout, cin, 0, cin, 0, 0)])
+            if self.split and self.bwd_prec == 2:
+                self.pk[(idx, 'b')] = self.pack.add(cin, cout, 9, mt_b, 2, [(w, cout, cin, 0, cout, 0, 1)])
+            else:
+                self.pk[(idx, 'b')] = self.pack.add(cin, v3 * cout, 9, mt_b, self.prec, [(w, cout, cin, 0, cout, 0, 1)])
             if self.nograd_prec and self.nograd_prec != self.prec:   # forward of the images that carry no gradient (see plan())
                 self.pk[(idx, 'r')] = self.pack.add(cout, cin_pad, 9, 2 if cout % 64 == 0 else 1, self.nograd_prec, [(w, cout, cin, 0, cin, 0, 0)])
         self.pack.finalize()
@@ -493,6 +505,8 @@ class _VGGPlan:
         dev, P, pack = net.device, net.params, net.pack
         if net.f16s:
             return self._init_f16(N, n_g, H, W)
+        if net.split:
+            return self._init_split(N, n_g, H, W)
         self.x_flag = 1                           # dtype code of x for dasr_affine4 (1 f32, 2 f16)
         self.x = BTensor(N, 16, H, W, True, dev)  # normalised input
         self.outs = []
@@ -549,14 +563,100 @@ class _VGGPlan:
     def input_copy_op(self, src_view, n0, n, H, W):
         """op that writes `n` images of a blocked f32 tensor (<= 16 channels) into x[n0 : n0 + n] (DSN: no input normalisation)"""
         dst = Tensor(self.x.view().p + n0 * self.x.view().n_stride * self.x.esz, self.x.view().n_stride, self.x.view().cb_stride)
-        o = _op(_lib.OP_CVT_F16 if self.net.f16s else _lib.OP_AXPBY)
-        if self.net.f16s:
-            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1] = src_view, n, 16, H, W, 1.0, dst
+        o = _op(_lib.OP_CVT_F16 if (self.net.f16s or self.net.split) else _lib.OP_AXPBY)
+        if self.net.f16s or self.net.split:
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1], o.i[4] = src_view, n, 16, H, W, 1.0, dst, int(self.net.split)
         else:
             o.t[0], o.f[0], o.t[1], o.f[1] = src_view, 1.0, NULL_T, 0.0
             o.i[0], o.i[1], o.i[2], o.i[3] = n, 16, H, W
             o.t[2], o.t[3], o.f[2], o.t[4] = dst, NULL_T, 1.0, NULL_T
         return o
+
+    def _init_split(self, N, n_g, H, W):
+        """split-f16 storage (prec 5): every activation up to the last conv and every gradient below it is a SPLIT tensor -- K planes of f16 `hi`
+        followed by K planes of f16 remainders (22 mantissa bits; gradients pre-scaled by gscale) -- and every 3x3 conv is one launch of the
+        LDS-DMA dense-conv kernel over 3K virtual chunks.  The images [n_g, N) that carry no gradient run one f16 pass over their hi planes
+        (nograd_prec 2, see __init__).  The last conv writes f32, a pool behind it (vgg16.features[:31]) runs in f32, dL/dx is f32."""
+        import math
+        net = self.net
+        dev, P, pack = net.device, net.params, net.pack
+        c16 = lambda c: ceil_div(c, 16) * 16
+        Bs = lambda C_, h, w: BTensor(N, 2 * c16(C_), h, w, False, dev, f16=True)   # planes [0, K) hi, [K, 2K) lo
+        Bf = lambda C_, h, w: BTensor(N, C_, h, w, True, dev)
+        self.x_flag = 3
+        self.x = Bs(16, H, W)
+        self.outs = []
+        h, w = H, W
+        fwd = OpList()
+        src, src_c = self.x, 16
+        nl = len(net.layers)
+        lc = max(i for i, L in enumerate(net.layers) if L[0] == 'conv')   # last conv: the hand-off to f32
+        one_pass = bool(net.nograd_prec) and 0 < n_g < N
+        ng = n_g if one_pass else N
+        for li, (kind, idx, cin, cout, relu) in enumerate(net.layers):
+            if kind == 'conv':
+                last = li == lc
+                out = Bf(cout, h, w) if last else Bs(cout, h, w)
+                kin = c16(cin) // 16
+                bias = P.ptr('features.%d.bias' % idx)
+                fwd.add(conv_op(pack, net.pk[idx], src.view(), False, 3 * c16(cin), h, w, h, w, ng, bias=bias, act=1 if relu else 0, slope=0.0,
+                                out_f32=out.view() if last else None, out_bf16=None if last else out.view(), out16_f16=0 if last else 1,
+                                in_wrap=2 * kin, out16_lo=0 if last else c16(cout) // 16))
+                if one_pass:   # the no-gradient images: one f16 pass over the hi planes, hi planes out (their lo planes stay zero)
+                    fwd.add(conv_op(pack, net.pk[(idx, 'r')], _nview_t(src, n_g), False, c16(cin), h, w, h, w, N - n_g, bias=bias,
+                                    act=1 if relu else 0, slope=0.0, out_f32=_nview_t(out, n_g) if last else None,
+                                    out_bf16=None if last else _nview_t(out, n_g), out16_f16=0 if last else 1))
+            else:
+                h, w = h // 2, w // 2
+                out = Bf(cout, h, w) if li > lc else Bs(cout, h, w)
+                o = _op(_lib.OP_MAXPOOL)
+                o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[1] = src.view(), N, cout, h, w, (1 if li > lc else 3), out.view()
+                fwd.add(o)
+            self.outs.append(out)
+            src = out
+        self.feat = src
+        self.fwd = fwd
+        n = n_g
+        self.g_feat = Bf(self.feat.C, self.feat.H, self.feat.W)
+        self.gx = Bf(16, H, W)
+        # dL/dfeat of a mean loss over n_g x C x h x w elements is ~1 / count: scaled to ~2^-3 before it is split (exact power of two)
+        cnt = max(1, n_g * self.feat.C * self.feat.H * self.feat.W)
+        self.gscale = float(2.0 ** max(0, int(math.floor(math.log2(cnt))) - 3))
+        bwd = OpList()
+        g = self.g_feat
+        gsplit = net.bwd_prec == 5
+        Bg = Bs if gsplit else (lambda C_, h_, w_: BTensor(N, C_, h_, w_, False, dev, f16=True))
+        for li in range(nl - 1, -1, -1):
+            kind, idx, cin, cout, relu = net.layers[li]
+            inp = self.x if li == 0 else self.outs[li - 1]
+            if kind == 'conv':
+                if li == lc:   # f32 gradient of the last conv's output -> pre-scaled split (or plain f16) tensor
+                    gs = Bg(cout, g.H, g.W)
+                    o = _op(_lib.OP_CVT_F16)
+                    o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1], o.i[4] = g.view(), n, cout, g.H, g.W, self.gscale, gs.view(), int(gsplit)
+                    bwd.add(o)
+                    g = gs
+                prev_relu = li > 0 and net.layers[li - 1][0] == 'conv' and net.layers[li - 1][4]
+                kg = c16(cout) // 16
+                hh, ww = g.H, g.W
+                gcin, gwrap = (3 * c16(cout), 2 * kg) if gsplit else (c16(cout), 0)
+                if li == 0:   # dL/d(normalised input): f32, un-scaled
+                    bwd.add(conv_op(pack, net.pk[(idx, 'b')], g.view(), False, gcin, hh, ww, hh, ww, n, alpha=1.0 / self.gscale,
+                                    out_f32=self.gx.view(), in_wrap=gwrap))
+                    break
+                gin = Bg(cin, hh, ww)
+                # mask = sign of the forward activation = sign of its hi plane (a non-zero value never rounds to a zero of the other sign)
+                bwd.add(conv_op(pack, net.pk[(idx, 'b')], g.view(), False, gcin, hh, ww, hh, ww, n,
+                                mask=inp.view() if prev_relu else None, mask_f32=0, slope=0.0, out_bf16=gin.view(), out16_f16=1,
+                                in_wrap=gwrap, out16_lo=c16(cin) // 16 if gsplit else 0))
+            else:
+                f32 = li > lc
+                gin = Bf(cout, inp.H, inp.W) if f32 else Bg(cout, inp.H, inp.W)
+                o = _op(_lib.OP_MAXPOOL_BWD)
+                o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.t[2] = inp.view(), g.view(), n, cout, g.H, g.W, (1 if f32 else (3 if gsplit else 5)), 1, gin.view()
+                bwd.add(o)
+            g = gin
+        self.bwd = bwd
 
     def _init_f16(self, N, n_g, H, W):
         """f16 storage: every activation up to the last conv (and, backward, every gradient below it, pre-scaled by gscale) is an f16 tensor;

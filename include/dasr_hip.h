@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DASR_ABI_VERSION 9
+#define DASR_ABI_VERSION 10
 #define DASR_EINVAL (-22)
 
 typedef struct {
@@ -72,6 +72,15 @@ typedef struct {
     /* non-zero: the 16-bit output tensor (`out_bf16`) is written as f16 instead of bf16 (activations of the generator's HR tail are
      * kept in f16: 11-bit mantissa, one MFMA pass in the consuming conv, prec 2 with in_f32 = 0) */
     int32_t out16_f16;
+    /* SPLIT 16-BIT TENSORS (round 3): a tensor of C channels held as 2K planes of 16-bit elements (K = ceil(C/16)): planes [0, K) the rounded
+     * value `hi`, planes [K, 2K) the remainder lo = round16(v - hi) -- 22 (f16) or 16 (bf16) mantissa bits in the same 4 bytes per element as
+     * f32, but in the layout the LDS-DMA dense-conv kernel streams.  The split-precision product hi*hi + lo*hi + hi*lo (prec 3 / 4 on f32
+     * tensors: three MFMA passes over operands split on the fly) then is ONE launch of that kernel over 3K "virtual" chunks:
+     *   in_wrap = 2K, cin = 3 * 16K: chunk c reads plane (c < in_wrap ? c : c - in_wrap) of `in`, i.e. hi, lo, hi again; the weights are
+     *   packed as [hi | hi | lo] (dasr_pack_weights fmt 3 / 4).  0: plain tensor.
+     *   out16_lo = K' > 0: the 16-bit output is written split: hi into plane cb, lo = round16(gamma * v - hi) into plane cb + K'.
+     * LDS-DMA kernel only (16-bit input, 3x3 / stride 1 / pad 1, prec 1 or 2). */
+    int32_t in_wrap, out16_lo;
 } dasr_conv_params;
 
 int dasr_conv(const dasr_conv_params* p, void* stream);
@@ -149,7 +158,9 @@ typedef struct {
     int64_t lo_off;       /* 0 when prec 1 */
     int32_t cout, cin_pad, ntaps, mt, nseg;
     int32_t src_ntaps;    /* taps of the source weight (kh*kw of the nn.Conv2d) */
-    int32_t fmt;          /* 0: bf16 (hi plane, + lo plane when lo_off != 0); 1: f16 (prec 2 convs); 2: f16 hi + f16 lo planes (prec 4) */
+    int32_t fmt;          /* 0: bf16 (hi plane, + lo plane when lo_off != 0); 1: f16 (prec 2 convs); 2: f16 hi + f16 lo planes (prec 4);
+                           * 3 (f16) / 4 (bf16): cin_pad = 3 * 16K virtual channels [hi | hi | lo] of 16K real ones, one plane (split 16-bit tensors,
+                           * dasr_conv_params::in_wrap; segments address the real channels) */
     int8_t  tapmap[32];   /* packed tap -> source tap (identity: forward; reversed: stride-1 dgrad; parity subset: stride-2 dgrad) */
     uint16_t tapmask[16]; /* non-zero: packed tap t (< 16) = SUM of the source taps whose bits are set (sub-pixel form of nearest-x2 + 3x3) */
     dasr_pack_seg seg[5];
@@ -182,6 +193,8 @@ int dasr_downsum2x(dasr_tensor src, int32_t N, int32_t C, int32_t H, int32_t W, 
 /* f16 storage of the generator's HR tail: y (f16, blocked) = f16(scale * x) of a blocked f32 tensor (dL/dSR -> pre-scaled f16 gradient), and
  * the backward of nn.Upsample(nearest,2) on f16 tensors: dst = out_scale * mask' * (2x2 block sum of src); dst_f32 and/or dst_f16 */
 int dasr_cvt_f16(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, float scale, dasr_tensor y, void* stream);
+/* split 16-bit copy (dasr_conv_params::in_wrap): y planes [0, K) = round16(scale * x), planes [K, 2K) = round16(scale * x - hi); f16 != 0: IEEE half, else bfloat16 */
+int dasr_cvt_split16(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, float scale, dasr_tensor y, int32_t f16, void* stream);
 int dasr_downsum2x_f16(dasr_tensor src, int32_t N, int32_t C, int32_t H, int32_t W, dasr_tensor mask /* f16, optional */, float slope,
                        float out_scale, dasr_tensor dst_f32, dasr_tensor dst_f16, void* stream);
 
@@ -258,7 +271,8 @@ int dasr_dwt_bwd(dasr_tensor gll, dasr_tensor ghc, int32_t N, int32_t C, int32_t
  * with x = dL/dlow, x2 = dL/dhigh (either may be null). */
 int dasr_lowpass(dasr_tensor x, dasr_tensor x2, const float* w, int32_t k, int32_t N, int32_t C, int32_t H, int32_t W,
                  int32_t mode, float a_h, float b_h, dasr_tensor out_low, dasr_tensor out_high, int32_t accumulate, void* stream);
-/* nn.MaxPool2d(2,2) of the VGG19 feature stack, forward and backward (Ho, Wo = pooled size); is_f32: 0 bf16, 1 f32, 2 f16 tensors */
+/* nn.MaxPool2d(2,2) of the VGG19 feature stack, forward and backward (Ho, Wo = pooled size); is_f32: 0 bf16, 1 f32, 2 f16 tensors; 3 / 4: split f16 / bf16 tensors (C channels in 2 * ceil(C/16) planes: hi planes, then lo planes);
+ * backward only: 5 = split f16 activations x, plain f16 gradients */
 int dasr_maxpool2(dasr_tensor x, int32_t is_f32, int32_t N, int32_t C, int32_t Ho, int32_t Wo, dasr_tensor y, void* stream);
 /* relu_mask: also zero the gradient where the pooled maximum is <= 0 (the ReLU' of the conv feeding the pool) */
 int dasr_maxpool2_bwd(dasr_tensor x, dasr_tensor gy, int32_t is_f32, int32_t N, int32_t C, int32_t Ho, int32_t Wo, dasr_tensor gx,
@@ -267,7 +281,7 @@ int dasr_maxpool2_bwd(dasr_tensor x, dasr_tensor gy, int32_t is_f32, int32_t N, 
  * ga = gcoef*sign(a-b).  is_f32 bit 1 set: squared form (MSE of the DSN VGG16 perceptual loss, loss.py:119-130). */
 int dasr_l1_diff(dasr_tensor a, dasr_tensor b, int32_t is_f32, int32_t N, int32_t C, int32_t H, int32_t W, float coef, float gcoef,
                  float* loss_acc, dasr_tensor ga, void* stream);
-/* per-channel affine on <=4 channels (VGG input normalisation architecture.py:1086-1087 and its adjoint); y_f32: 0 bf16, 1 f32, 2 f16 output */
+/* per-channel affine on <=4 channels (VGG input normalisation architecture.py:1086-1087 and its adjoint); y_f32: 0 bf16, 1 f32, 2 f16 output, 3 split f16 (hi in plane 0, remainder in plane 1; no accumulate) */
 int dasr_affine4(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, const float* scale4, const float* shift4, dasr_tensor y,
                  int32_t y_f32, int32_t accumulate, void* stream);
 /* F.interpolate(bilinear, align_corners=False) of the domain-distance map (DASR_model.py:173-174), NCHW [N][1][h][w] */

@@ -172,6 +172,81 @@ def test_conv5_epilogue_variants_match_torch(bias, res2, H, W, tune64):
     assert rel(ob.nchw().cpu(), bf16r(y.float())) < 5e-3
 
 
+def _to_split(x, dev, f16=True):
+    """NCHW f32 -> split 16-bit blocked tensor [N][2K][H][W][16]: hi planes, then remainder planes"""
+    from dasr_amd.engine import BTensor
+    N, C_, H, W = x.shape
+    K = (C_ + 15) // 16
+    b = to_blocked(x, True, dev).t   # [N][K][H][W][16] f32
+    dt = torch.float16 if f16 else torch.bfloat16
+    hi = b.to(dt)
+    lo = (b - hi.float()).to(dt)
+    out = BTensor(N, 32 * K, H, W, False, dev, f16=f16)
+    out.t[:, :K] = hi
+    out.t[:, K:] = lo
+    return out
+
+
+def _from_split(bt, C_):
+    K = bt.planes // 2
+    v = bt.t[:, :K].float() + bt.t[:, K:].float()
+    return v.permute(0, 1, 4, 2, 3).reshape(bt.N, K * 16, bt.H, bt.W)[:, :C_].cpu()
+
+
+@pytest.mark.parametrize('f16', [True, False], ids=['f16', 'bf16'])
+@pytest.mark.parametrize('cin,cout,mode', [(40, 64, 'fwd'), (64, 32, 'fwd'), (3, 64, 'fwd'), (64, 40, 'dgrad'), (128, 128, 'dgrad'), (64, 3, 'f32out')])
+def test_conv_on_split_tensors_is_fp32_grade(cin, cout, mode, f16):
+    """split 16-bit tensors (dasr_conv_params::in_wrap / out16_lo, round 3): hi planes + remainder planes, the three-term product as ONE launch
+    of the LDS-DMA kernel over 3K virtual chunks -- must be as accurate as the split precisions on f32 tensors (prec 3 / 4): 16 (bf16) or 22
+    (f16) mantissa bits per operand.  fwd: bias + ReLU -> split output; dgrad: ReLU' mask from a 16-bit activation -> split output;
+    f32out: scaled fp32 output (the hand-off at the first / last layer)"""
+    dev = _gpu()
+    from dasr_amd.engine import BTensor, OpList, conv_op
+    N, H, W = 2, 20, 36
+    mt = 2 if cout % 64 == 0 else 1
+    c16 = lambda c: (c + 15) // 16 * 16
+    w, b, P, pack, ref = make_conv(cout, cin, 3, mt, 1, dev, 29)   # (ref unused: a second pack in the virtual-chunk format)
+    from dasr_amd.engine import PackRegistry
+    pack = PackRegistry(P)
+    ref = pack.add(cout, 3 * c16(cin), 9, mt, 5 if f16 else 6, [(0, cout, cin, 0, cin, 0, 0)])
+    pack.finalize()
+    pack.run()
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(N, cin, H, W, generator=g)
+    xs = _to_split(x, dev, f16)
+    xv = _from_split(xs, cin).double()        # the values the kernel sees
+    dt = torch.float16 if f16 else torch.bfloat16
+    wv = (w.to(dt).float() + (w - w.to(dt).float()).to(dt).float()).double()
+    y = F.conv2d(xv, wv, None, padding=1)
+    kin = c16(cin) // 16
+    ops = OpList()
+    if mode == 'fwd':
+        out = BTensor(N, 2 * c16(cout), H, W, False, dev, f16=f16)
+        ops.add(conv_op(pack, ref, xs.view(), False, 3 * c16(cin), H, W, H, W, N, bias=P.ptr('b'), act=1, slope=0.0, out_bf16=out.view(),
+                        out16_f16=int(f16), in_wrap=2 * kin, out16_lo=c16(cout) // 16))
+        y = F.relu(y + b.double().view(1, -1, 1, 1))
+    elif mode == 'dgrad':
+        msk = torch.randn(N, cout, H, W, generator=g)
+        mb = BTensor(N, cout, H, W, False, dev, f16=f16)
+        mb.t.copy_(to_blocked(msk, True, dev).t.to(dt))
+        out = BTensor(N, 2 * c16(cout), H, W, False, dev, f16=f16)
+        ops.add(conv_op(pack, ref, xs.view(), False, 3 * c16(cin), H, W, H, W, N, mask=mb.view(), mask_f32=0, slope=0.0, out_bf16=out.view(),
+                        out16_f16=int(f16), in_wrap=2 * kin, out16_lo=c16(cout) // 16))
+        y = torch.where(msk.to(dt).double() > 0, y, torch.zeros_like(y))
+    else:
+        out = BTensor(N, cout, H, W, True, dev)
+        ops.add(conv_op(pack, ref, xs.view(), False, 3 * c16(cin), H, W, H, W, N, alpha=0.125, out_f32=out.view(), in_wrap=2 * kin))
+        y = 0.125 * y
+    ops.run()
+    torch.cuda.synchronize()
+    got = out.nchw().cpu() if mode == 'f32out' else _from_split(out, cout)
+    tol = 3e-6 if f16 else 1.5e-4   # operand bits: 22 / 16; the dropped lo*lo term and the split of the output are below that
+    assert rel(got, y.float()) < tol, rel(got, y.float())
+    if mode != 'f32out' and cout % 16:   # padded channels of the last plane pair stay zero
+        K = c16(cout) // 16
+        assert float(out.t[:, K - 1, :, :, cout % 16:].abs().max()) == 0.0 and float(out.t[:, 2 * K - 1, :, :, cout % 16:].abs().max()) == 0.0
+
+
 def test_conv_prec3_is_fp32_grade():
     """split-bf16 must be ~fp32 accurate on un-rounded operands (this is what the residual stream relies on)."""
     dev = _gpu()
