@@ -109,6 +109,7 @@ _SIGS = {
     'dasr_event_create': [],
     'dasr_event_destroy': [c_vp],
     'dasr_prelu_grad': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_vp],
+    'dasr_prelu_grad_f16': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_vp],
     'dasr_lowpass_valid': [Tensor, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_vp],
     'dasr_run_ops': [c_vp, c_i32, c_vp],
     'dasr_last_failed_op': [],

@@ -880,6 +880,7 @@ __global__ void sigmoid_fwd_kernel(dasr_tensor x, int N, int C, int H, int W, da
 
 // nn.PReLU() with one shared slope a: y = x > 0 ? x : a x.  Given y and gx = dL/dx (already masked by PReLU'),
 // dL/da = sum_{y <= 0} (gx / a) * (y / a).  Two deterministic stages: per-block partials, then one block.
+template <typename T>   // float: f32 tensors; f16_t: the f16 shadows of the DSN generator's backward (gx pre-scaled, undone through `scale`)
 __global__ void prelu_grad_partial_kernel(dasr_tensor y, dasr_tensor gx, int N, int C, int H, int W, float* __restrict__ partial) {
     __shared__ float red[4];
     const int ncb = (C + 15) >> 4;
@@ -891,11 +892,12 @@ __global__ void prelu_grad_partial_kernel(dasr_tensor y, dasr_tensor gx, int N, 
         long long t = gi / per;
         const int cb = t % ncb;
         const int n = t / ncb;
-        const f32x4 yv = *(const f32x4*)((const float*)y.p + (size_t)n * y.n_stride + (size_t)cb * y.cb_stride + e);
-        const f32x4 gv = *(const f32x4*)((const float*)gx.p + (size_t)n * gx.n_stride + (size_t)cb * gx.cb_stride + e);
+        typedef T T4 __attribute__((ext_vector_type(4)));
+        const T4 yv = *(const T4*)((const T*)y.p + (size_t)n * y.n_stride + (size_t)cb * y.cb_stride + e);
+        const T4 gv = *(const T4*)((const T*)gx.p + (size_t)n * gx.n_stride + (size_t)cb * gx.cb_stride + e);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (yv[j] <= 0.f) s += gv[j] * yv[j];
+            if ((float)yv[j] <= 0.f) s += (float)gv[j] * (float)yv[j];
     }
     const float tot = block_sum_256(s, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
@@ -1187,7 +1189,17 @@ extern "C" int dasr_prelu_grad(dasr_tensor y, dasr_tensor gx, int32_t N, int32_t
     // 1024 workgroups (4 per CU: the streaming read of two tensors needs the occupancy), one partial each; `scratch256` holds 1024 floats
     const long long vec = (long long)N * ((C + 15) / 16) * H * W * 4;
     const int nb = (int)(vec < 1024LL * 256 ? (vec + 255) / 256 : 1024);
-    DASR_LAUNCH(prelu_grad_partial_kernel, dim3(nb), dim3(256), 0, as_stream(stream), y, gx, N, C, H, W, scratch256);
+    DASR_LAUNCH(prelu_grad_partial_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), y, gx, N, C, H, W, scratch256);
+    DASR_LAUNCH(prelu_grad_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), scratch256, nb, slope, dst, scale);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_prelu_grad_f16(dasr_tensor y, dasr_tensor gx, int32_t N, int32_t C, int32_t H, int32_t W, const float* slope, float* scratch256,
+                                   float* dst, float scale, void* stream) {
+    if ((long long)N * C * H * W <= 0) return DASR_EINVAL;
+    const long long vec = (long long)N * ((C + 15) / 16) * H * W * 4;
+    const int nb = (int)(vec < 1024LL * 256 ? (vec + 255) / 256 : 1024);
+    DASR_LAUNCH(prelu_grad_partial_kernel<f16_t>, dim3(nb), dim3(256), 0, as_stream(stream), y, gx, N, C, H, W, scratch256);
     DASR_LAUNCH(prelu_grad_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), scratch256, nb, slope, dst, scale);
     return (int)hipGetLastError();
 }

@@ -674,7 +674,10 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream0) {
                 break;
             case DASR_OP_SIGMOID_BWD: rc = dasr_sigmoid_bwd(o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.t[2], stream); break;
             case DASR_OP_PRELU_GRAD:
-                rc = dasr_prelu_grad(o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], (const float*)o.p[0], (float*)o.p[1], (float*)o.p[2], o.f[0], stream);
+                // i[4] != 0: y and gx are f16 tensors, gx pre-scaled by 1 / f[1]
+                rc = o.i[4] ? dasr_prelu_grad_f16(o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], (const float*)o.p[0], (float*)o.p[1], (float*)o.p[2],
+                                                  o.f[0] * (o.f[1] != 0.f ? o.f[1] : 1.f), stream)
+                            : dasr_prelu_grad(o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], (const float*)o.p[0], (float*)o.p[1], (float*)o.p[2], o.f[0], stream);
                 break;
             case DASR_OP_LOWPASS_VALID: rc = dasr_lowpass_valid(o.t[0], (const float*)o.p[0], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], o.i[5], o.t[1], o.i[6], stream); break;
             case DASR_OP_ADD_FLAT: rc = dasr_add_flat((float*)o.p[0], (const float*)o.p[1], o.l[0], stream); break;

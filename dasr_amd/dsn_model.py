@@ -12,7 +12,11 @@ weights coming from `vgg_state` / `vgg_path` or, offline, from a seeded random i
 LPIPS(alex)(fake, bicubic LR).mean() (loss.py:68-69,84,108-114; dasr_amd/lpips.py), weights from `lpips_alexnet` / `lpips_lin` or seeded.
 nn.PReLU slopes are read from the parameter buffer at run time; their derivative masks use the sign of the layer
 output, which equals the sign of the pre-activation while the slope stays positive (init 0.25).
-Everything runs in split-bf16 (prec 3) on fp32 activations.
+Forward: split-bf16 (prec 3, ~fp32) on fp32 activations.  Backward of the generator's residual blocks (round 3, DASR_DSN_BWD16=0 restores
+the fp32-tensor path): every forward conv also writes an f16 shadow of its output, the gradient stream carries an f16 shadow pre-scaled by a
+power of two; the 16 data-gradient convs then are ONE f16 pass of the LDS-DMA dense-conv kernel (instead of three split-bf16 passes of the
+register-staged one) and the 16 weight gradients run on the 12-wave LDS-DMA kernel.  The rounding of a gradient to 11 bits enters the
+weight gradients like noise (nothing downstream is decided by it -- the PReLU masks come from the forward activations).
 """
 import ctypes as C
 import logging
@@ -22,7 +26,7 @@ from collections import OrderedDict
 import torch
 
 from . import _lib
-from .engine import (BTensor, ParamStore, PackRegistry, OpList, WgradGroup, Workspace, conv_op, ceil_div, NULL_T, Op, Tensor,
+from .engine import (BTensor, ParamStore, PackRegistry, OpList, WgradGroup, WgradGroup3, Workspace, conv_op, ceil_div, NULL_T, Op, Tensor,
                      ensure_runtime_ready, _stream)
 from .gan_nets import NLayerDiscriminatorHIP, BatchNormDiscriminatorHIP, VGGFeatureHIP, VGG16_CFG, fsd_spec, dsn_nld_spec, fold_batchnorm_fsd
 from .models import AdamHIP
@@ -120,6 +124,12 @@ class DeResnetHIP:
             fb('d0', 'down_sample.0.', 64, 64, 2)
             fb('d2', 'down_sample.2.', 64, 64, 2)
         fb('out', 'block_output.', 3, 64)
+        self.bwd16 = os.environ.get('DASR_DSN_BWD16', '1') != '0'
+        if self.bwd16:   # data gradient of the residual-block convs: one f16 pass on 16-bit tensors
+            for k in range(n_res_blocks):
+                for j in (1, 2):
+                    w = P.off('res_blocks.%d.conv%d.weight' % (k, j))
+                    self.pk['r%d_%d_b16' % (k, j)] = self.pack.add(64, 64, 9, 2, 2, [(w, 64, 64, 0, 64, 0, 1)])
         self.pack.finalize()
         self.plans = {}
 
@@ -160,6 +170,17 @@ class _GPlan:
             self.g_d2, self.g_d1 = B(64, H4, W4), B(64, H2, W2)
         self.g_s = [B(64, H, W) for _ in range(2)]
         self.g_h = B(64, H, W)
+        b16 = net.bwd16
+        if b16:
+            import math
+            B16 = lambda: BTensor(N, 64, H, W, False, dev, f16=True)
+            self.s16 = [B16() for _ in range(nb)]       # f16 shadows of the residual stream s[0 .. nb-1] and of the block-internal activations
+            self.h16 = [B16() for _ in range(nb)]
+            self.g_s16 = [B16() for _ in range(2)]      # gscale * dL/ds, gscale * dL/dh in f16
+            self.g_h16 = B16()
+            # dL/dfake of the mean losses is ~1 / (number of output elements): a power of two puts it at ~2^-3 before the f16 rounding
+            self.gscale = float(2.0 ** max(0, int(math.floor(math.log2(max(1, N * 3 * H4 * W4)))) - 3))
+        sh = lambda t: ({'out_bf16': t.view(), 'out16_f16': 1} if b16 else {})
         self.scratch = torch.zeros(1024, dtype=torch.float32, device=dev)
         self.ws = Workspace(dev)
         sp = lambda key: P.ptr(key)
@@ -169,13 +190,13 @@ class _GPlan:
         o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[0], o.t[1] = self.x_nchw.data_ptr(), N, 3, H, W, self.x_in.view(), NULL_T
         f.add(o)
         f.add(conv_op(pack, pk['in'], self.x_in.view(), True, 16, H, W, H, W, N, bias=sp('block_input.0.bias'), act=1,
-                      slope_ptr=sp('block_input.1.weight'), out_f32=self.s[0].view()))
+                      slope_ptr=sp('block_input.1.weight'), out_f32=self.s[0].view(), **(sh(self.s16[0]) if (b16 and nb) else {})))
         for k in range(nb):
             pre = 'res_blocks.%d.' % k
             f.add(conv_op(pack, pk['r%d_1' % k], self.s[k].view(), True, 64, H, W, H, W, N, bias=sp(pre + 'conv1.bias'), act=1,
-                          slope_ptr=sp(pre + 'prelu.weight'), out_f32=self.h[k].view()))
+                          slope_ptr=sp(pre + 'prelu.weight'), out_f32=self.h[k].view(), **sh(self.h16[k] if b16 else None)))
             f.add(conv_op(pack, pk['r%d_2' % k], self.h[k].view(), True, 64, H, W, H, W, N, bias=sp(pre + 'conv2.bias'),
-                          res1=self.s[k].view(), beta1=1.0, out_f32=self.s[k + 1].view()))
+                          res1=self.s[k].view(), beta1=1.0, out_f32=self.s[k + 1].view(), **(sh(self.s16[k + 1]) if (b16 and k + 1 < nb) else {})))
         if down:
             f.add(conv_op(pack, pk['d0'], self.s[nb].view(), True, 64, H, W, H2, W2, N, bias=sp('down_sample.0.bias'), stride=2, act=1,
                           slope_ptr=sp('down_sample.1.weight'), out_f32=self.d1.view()))
@@ -200,10 +221,25 @@ class _GPlan:
                 b.add(op)
             b.keep.append(grp)
 
-        def prelu_grad(key, y, gx, h, w):
+        def wg16(key, g16, inp16):
+            """weight gradient of a 64 -> 64 conv from the f16 shadows (g16 holds gscale * dL/dy): the 12-wave LDS-DMA kernel, one part = the 64
+            input channels x the two 32-oc tiles"""
+            grp = WgradGroup3()
+            tiles = [dict(dst_w_off=P.off(key + 'weight'), dst_b_off=P.off(key + 'bias'), cout=64, cin=64, oc0=oc0, c0=0, n_ctiles=2) for oc0 in (0, 32)]
+            grp.add_block(g16.view(), 4, inp16.view(), 4, 2, H, W, H, W, N, tiles, want_bias=True)
+            grp.f16, grp.g_scale = True, self.gscale
+            grp.flops = 2.0 * N * H * W * 9 * 64 * 64
+            grp.finalize(self.ws, dev)
+            for op in grp.ops(G):
+                b.add(op)
+            b.keep.append(grp)
+
+        def prelu_grad(key, y, gx, h, w, f16=False):
             o = _op(_lib.OP_PRELU_GRAD)
             o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3] = y.view(), gx.view(), N, 64, h, w
             o.p[0], o.p[1], o.p[2], o.f[0] = sp(key), self.scratch.data_ptr(), P.ptr(key, P.grad), 1.0
+            if f16:   # f16 shadows: the gradient carries gscale
+                o.i[4], o.f[1] = 1, 1.0 / self.gscale
             b.add(o)
             self._prelu_ops.append(o)
 
@@ -233,8 +269,26 @@ class _GPlan:
             dgrad_s2('d0', self.g_d1, gs, None, None, H, W, H2, W2)
         else:   # Generator (DSGAN): the output conv reads the residual stream directly (no activation in between)
             b.add(conv_op(pack, pk['out_b'], self.gz_out.view(), True, 16, H, W, H, W, N, out_f32=gs.view()))
+        if b16 and nb:   # gscale * dL/ds[nb] in f16
+            o = _op(_lib.OP_CVT_F16)
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1] = gs.view(), N, 64, H, W, self.gscale, self.g_s16[0].view()
+            b.add(o)
+        gs16 = self.g_s16[0] if b16 else None
         for k in range(nb - 1, -1, -1):
             pre = 'res_blocks.%d.' % k
+            if b16:
+                inv = 1.0 / self.gscale
+                wg16(pre + 'conv2.', gs16, self.h16[k])
+                b.add(conv_op(pack, pk['r%d_2_b16' % k], gs16.view(), False, 64, H, W, H, W, N, mask=self.h16[k].view(), mask_f32=0,
+                              slope_ptr=sp(pre + 'prelu.weight'), alpha=inv, out_bf16=self.g_h16.view(), out16_f16=1, gamma=self.gscale))
+                prelu_grad(pre + 'prelu.weight', self.h16[k], self.g_h16, H, W, f16=True)   # (dL/dh is never materialised in f32)
+                wg16(pre + 'conv1.', self.g_h16, self.s16[k])
+                nxt = self.g_s[1] if gs is self.g_s[0] else self.g_s[0]
+                nxt16 = self.g_s16[1] if gs16 is self.g_s16[0] else self.g_s16[0]
+                b.add(conv_op(pack, pk['r%d_1_b16' % k], self.g_h16.view(), False, 64, H, W, H, W, N, alpha=inv, res1=gs.view(), beta1=1.0,
+                              out_f32=nxt.view(), out_bf16=nxt16.view(), out16_f16=1, gamma=self.gscale))
+                gs, gs16 = nxt, nxt16
+                continue
             wg(pre + 'conv2.', gs, self.h[k], 64, 64, H, W, H, W)
             b.add(conv_op(pack, pk['r%d_2_b' % k], gs.view(), True, 64, H, W, H, W, N, mask=self.h[k].view(), mask_f32=1,
                           slope_ptr=sp(pre + 'prelu.weight'), out_f32=self.g_h.view()))

@@ -325,6 +325,10 @@ int dasr_sigmoid_fwd(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, 
  * scratch256: 1024 floats (one partial per workgroup of the first stage; the name is historical) */
 int dasr_prelu_grad(dasr_tensor y, dasr_tensor gx, int32_t N, int32_t C, int32_t H, int32_t W, const float* slope, float* scratch256,
                     float* dst, float scale, void* stream);
+/* the same on f16 tensors (the DSN generator's 16-bit backward: y = f16 shadow of the layer output, gx = power-of-two pre-scaled f16 gradient;
+ * the caller folds 1 / pre-scale into `scale`) */
+int dasr_prelu_grad_f16(dasr_tensor y, dasr_tensor gx, int32_t N, int32_t C, int32_t H, int32_t W, const float* slope, float* scratch256,
+                        float* dst, float scale, void* stream);
 /* un-padded low-pass of the colour loss (FilterLow(padding=False), loss.py:52-56): mode 0 forward (H-k+1 x W-k+1 out),
  * mode 1 adjoint */
 int dasr_lowpass_valid(dasr_tensor x, const float* w, int32_t k, int32_t N, int32_t C, int32_t H, int32_t W, int32_t mode,
