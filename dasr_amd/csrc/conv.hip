@@ -152,7 +152,7 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
     // exchanges the 16-lane rows of the register sets g = 2 pr and 2 pr + 1: set A then holds all four channel quarters of pixels 0-15, set B of
     // pixels 16-31 -- every instruction covers 16 complete lines.
     constexpr bool WIDE32 = !G && STRIDE == 1;
-    constexpr bool PIPE_EPI = !G && !(MT == 2 && (EPI & 16)) && (EPI & (4 | 8 | 16));
+    constexpr bool PIPE_EPI = !G && !(MT == 2 && (EPI & 16) && (EPI & 8)) && (EPI & (4 | 8 | 16));   // (the 64-channel kernel with BOTH residuals in the epilogue has no registers for it)
     u32x4 mk[2][4], r1v[2][4], r2v[2][4];
     auto group_addr = [&](int gi, unsigned (&eo)[4], unsigned (&cbv)[4]) {
         const int nt = gi / MT, mi = gi - nt * MT;
@@ -1095,12 +1095,39 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
     const int aoff = lane * 16;   // relative to the chunk's weight image
 
     f32x16 acc[MT][NT];
+    // R1_PRE (conv5 of a dense block: alpha * conv + beta1 * x -> fp32 stream): the epilogue's residual fetch kept ONE group of four 1-KiB loads
+    // per wave in flight (32 KB per CU against ~2 us of loaded latency: ~15 B/clk) and took 20 k cycles = 18 % of the workgroup
+    // (profiles/r03_conv_ablation.txt).  The residual is fetched HERE instead, straight into the accumulator registers -- all 32 loads of a wave
+    // (128 KB per workgroup) in flight behind the DMA of chunk 0 -- and the MFMAs accumulate on top of (beta1 / alpha) * x; the epilogue only
+    // scales by alpha and stores.  fp32 throughout: alpha * ((beta1 / alpha) x + conv) differs from alpha * conv + beta1 * x by ~1e-7 relative.
+    constexpr bool R1_PRE = MT == 2 && EPI != 0 && (EPI & 8) && !ABL && RING == 0;
+    if constexpr (R1_PRE) {
+        const __amdgpu_buffer_rsrc_t rr1 = make_rsrc((const float*)p.res1.p + (size_t)n * p.res1.n_stride);
+        const unsigned r1_cb = (unsigned)p.res1.cb_stride;
+        const int nn_ = lane & 31, kh_ = lane >> 5;
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
+        for (int nt = 0; nt < NT; ++nt) {
+            const int oy = oy0 + wave * NT + nt, ox = ox0 + nn_;
+            const bool pv = (oy < a_Hout) & (ox < a_Wout);
+            const unsigned pixel = (unsigned)((oy + p.out_oy) * (p.out_W > 0 ? p.out_W : a_Wout) + ox + p.out_ox) * 16u;   // (as conv_epilogue::group_addr with out_stride 1)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc[mi][nt][j] = 0.f;
+                for (int g = 0; g < 4; ++g) {
+                    const int oc = (mg * MT + mi) * 32 + 8 * g + 4 * kh_;
+                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rr1, pv ? ((unsigned)(oc >> 4) * r1_cb + pixel + (unsigned)(oc & 15)) * 4u : OOB, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[mi][nt][4 * g + j] = __uint_as_float(t[j]);
+                }
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[mi][nt][j] = 0.f;
+    }
 
     if constexpr (RING != 0) {
         if (nchunks > 1 && !FLAGS) __builtin_amdgcn_s_waitcnt(0x0F70 | C::AR);   // vmcnt(AR): chunk 0 has landed, the activation pieces of chunk 1 may fly
@@ -1109,6 +1136,13 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
     } else {
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's DMA pieces have landed
         __syncthreads();
+    }
+    if constexpr (R1_PRE) {
+        const float c1 = p.beta1 / p.alpha;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mi][nt] *= c1;
     }
     TRACE_STAMP(2);
 
@@ -1215,7 +1249,7 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
     }
     TRACE_STAMP(4);
     if constexpr (FLAGS) __builtin_amdgcn_s_barrier();   // the waves drift: nobody may still read fragments when the epilogue reuses LDS for the bias
-    conv_epilogue<false, MT, NT, 1, EPI, F16 ? 1 : 0, PRE>(p, acc, smem, bias_reg, tid, mg, n, oy0, ox0, &mpre);
+    conv_epilogue<false, MT, NT, 1, R1_PRE ? (EPI & ~8) : EPI, F16 ? 1 : 0, PRE>(p, acc, smem, bias_reg, tid, mg, n, oy0, ox0, &mpre);
     TRACE_STAMP(6);
 #ifdef DASR_TRACE
     __builtin_amdgcn_s_waitcnt(0);

@@ -886,7 +886,8 @@ __global__ void prelu_grad_partial_kernel(dasr_tensor y, dasr_tensor gx, int N, 
     const int ncb = (C + 15) >> 4;
     const long long per = (long long)H * W * 4;
     const long long total = (long long)N * ncb * per;
-    float s = 0.f;
+    double s = 0.0;   // the terms cancel (a slope gradient is a small difference of large sums): per-thread sums in double keep the result independent
+                      // of how the batch is split over launches / ranks to ~1e-6 instead of ~1e-3
     for (long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += (long long)gridDim.x * blockDim.x) {
         const long long e = (gi % per) * 4;
         long long t = gi / per;
@@ -897,18 +898,18 @@ __global__ void prelu_grad_partial_kernel(dasr_tensor y, dasr_tensor gx, int N, 
         const T4 gv = *(const T4*)((const T*)gx.p + (size_t)n * gx.n_stride + (size_t)cb * gx.cb_stride + e);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if ((float)yv[j] <= 0.f) s += (float)gv[j] * (float)yv[j];
+            if ((float)yv[j] <= 0.f) s += (double)((float)gv[j] * (float)yv[j]);
     }
-    const float tot = block_sum_256(s, red);
+    const float tot = block_sum_256((float)s, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
 __global__ __launch_bounds__(256) void prelu_grad_final_kernel(const float* __restrict__ partial, int nblocks, const float* __restrict__ slope,
                                                                float* __restrict__ dst, float scale) {
     __shared__ float red[4];
-    float s = 0.f;
-    for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];   // fixed order per thread, fixed tree across threads: deterministic
-    const float tot = block_sum_256(s, red);
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += (double)partial[i];   // fixed order per thread, fixed tree across threads: deterministic
+    const float tot = block_sum_256((float)s, red);
     if (threadIdx.x == 0) {
         const float a = *slope;
         *dst = scale * tot / (a * a);

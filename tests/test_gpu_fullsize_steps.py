@@ -93,9 +93,16 @@ def test_cfg2_gan_step_32_crops_equals_mean_of_halves(margins):
     assert eG < 1e-4 and eD < 1e-4 and worst_log < 1e-4
 
 
-def test_dsn_iteration_batch8_of_256_equals_mean_of_halves(margins):
-    """configs[4] per-GPU shape: batch 8 of 256x256 HR crops, wavelet filter, VGG16 term on.  InstanceNorm / all losses are per sample."""
+@pytest.mark.parametrize('bwd16', [1, 0], ids=['f16_backward_default', 'fp32_tensor_backward'])
+def test_dsn_iteration_batch8_of_256_equals_mean_of_halves(bwd16, margins, monkeypatch):
+    """configs[4] per-GPU shape: batch 8 of 256x256 HR crops, wavelet filter, VGG16 term on.  InstanceNorm / all losses are per sample.
+    The full batch and its halves differ by ~3e-5 already in dL/dfake (different reduction orders in the losses).  The fp32-tensor backward
+    (DASR_DSN_BWD16=0, ~fp32 operands) carries that through: 1e-4.  The default backward rounds the gradient stream to f16 (11 bits) per layer:
+    a 3e-5 perturbation flips roundings, so the two runs differ like two draws of the rounding noise -- ~1e-4 on the conv weight gradients
+    (averaged over 5e5 pixels), up to ~1e-3 on the scalar PReLU slope gradients (sums that cancel); both far inside the 1e-2 parity budget
+    (profiles/r03_parity_margins.log: 16-bit vs fp32-tensor backward 3-5e-4 / 4.7e-3)."""
     dev = _gpu()
+    monkeypatch.setenv('DASR_DSN_BWD16', str(bwd16))
     from dasr_amd.dsn_model import DSNModel
     from oracle.gen_golden_dsn import dsn_state, dsn_batch
     hr, bic, real = dsn_batch(dict(n=8, crop=256))
@@ -103,6 +110,7 @@ def test_dsn_iteration_batch8_of_256_equals_mean_of_halves(margins):
     for lo, hi in ((0, 8), (0, 4), (4, 8)):
         torch.manual_seed(0)
         m = DSNModel(dict(filter='wavelet', w_per=0.01, vgg_seed=78, allow_random_perceptual=True), device=dev)
+        assert m.netG.bwd16 == bool(bwd16)
         m.netG.load_state_dict(dsn_state(m.netG.state_dict(), 21, 0.5))
         m.netD.load_state_dict(dsn_state(m.netD.state_dict(), 22, 1.0))
         m.iteration(hr[lo:hi].to(dev), bic[lo:hi].to(dev), real[lo:hi].to(dev))
@@ -111,13 +119,18 @@ def test_dsn_iteration_batch8_of_256_equals_mean_of_halves(margins):
         del m
         torch.cuda.empty_cache()
     (gG, gD, log), (gGa, gDa, la), (gGb, gDb, lb) = out
-    worst = 0.0
+    worst, worst_slope = 0.0, 0.0
     for full, a, b in ((gG, gGa, gGb), (gD, gDa, gDb)):
         for k in full:
             want = 0.5 * (a[k] + b[k])
             if float(want.double().norm()) < 1e-7 * max(1.0, float(full[k].numel()) ** 0.5):
                 continue   # biases in front of an InstanceNorm: true gradient 0, rounding noise on both sides
-            worst = max(worst, rel(full[k], want))
+            if full is gG and full[k].numel() == 1:
+                worst_slope = max(worst_slope, rel(full[k], want))
+            else:
+                worst = max(worst, rel(full[k], want))
     wl = max(abs(log[k] - 0.5 * (la[k] + lb[k])) / max(1e-3, abs(log[k])) for k in log)
-    margins('DSN full size (batch 8 of 256^2): worst per-tensor grad rel err vs mean of halves %.2e (tol 1e-4), worst log entry %.2e (tol 1e-4)' % (worst, wl))
-    assert worst < 1e-4 and wl < 1e-4
+    tol, tol_slope = (3e-4, 3e-3) if bwd16 else (1e-4, 1e-4)
+    margins('DSN full size (batch 8 of 256^2, %s backward): worst per-tensor grad rel err vs mean of halves %.2e (tol %.0e), PReLU slopes %.2e (tol %.0e), '
+            'worst log entry %.2e (tol 1e-4)' % ('f16' if bwd16 else 'fp32-tensor', worst, tol, worst_slope, tol_slope, wl))
+    assert worst < tol and worst_slope < tol_slope and wl < 1e-4
