@@ -66,7 +66,8 @@ def make_opt(nf, nb):
 # ---------------------------------------------------------------------------------------------------------------------------
 # roofline: per-kernel durations of one production step
 # ---------------------------------------------------------------------------------------------------------------------------
-_KNAME = {'launch_glds': 'conv_glds_kernel', 'launch_ring3': 'conv_ring3_kernel', 'launch': 'conv_kernel', 'launch_wgrad': 'wgrad_kernel', 'launch_wgrad3': 'wgrad3_kernel'}
+_KNAME = {'launch_glds': 'conv_glds_kernel', 'launch_ring3': 'conv_ring3_kernel', 'launch': 'conv_kernel', 'launch_wgrad': 'wgrad_kernel', 'launch_wgrad3': 'wgrad3_kernel', 'launch_wgrad3_ld': 'wgrad3_ld_kernel',
+          'launch_wgrad4': 'wgrad4_kernel'}
 
 
 def kernel_name(tag):

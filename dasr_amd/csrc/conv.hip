@@ -911,10 +911,13 @@ __device__ __forceinline__ void glds_dma_w(int r, int ck, char* wbase, __amdgpu_
 // F16: the 16-bit activations and packed weights are f16 (HR tail of the generator in f16 storage): v_mfma_f32_32x32x16_f16.
 // p.ups: nearest x2 up-sampling folded into the DMA source addresses (upconv_blcok, block.py:854-861): each lane fetches the 16 bytes of
 // low-resolution pixel (y >> 1, x >> 1); the four duplicates come from L2.
-// RING (round 3): the per-chunk ablation of the step (profiles/r03_conv_ablation.txt) showed the Cout = 32 launches bound by how many bytes a CU
-// keeps in flight: with two chunk buffers a workgroup can request chunk k + 1 only while it multiplies chunk k (0.6 - 1.2 us) and the round trip
-// under load is ~2 us, so every chunk ends waiting; and every wave that stalls issuing its DMA pieces holds the whole workgroup at the chunk
-// barrier.  RING keeps THREE activation images and two weight images in LDS (78 KB: still two workgroups per CU): the activations of chunk k + 2
+// RING = 1 / 2 / 3 (round 3, dasr_set_tuning key 1 = 15 / 16 / 17): three restructurings of the load path, built against the per-chunk ablation of
+// the step (profiles/r03_conv_ablation.txt), all parity-green and ALL MEASURED FLAT OR SLOWER than the default (RING = 0) -- kept as selectable,
+// tested variants and as the record of what does not limit this kernel (not the depth of the prefetch, not the DMA issue slots of the MFMA waves,
+// not the chunk barrier itself; the L2 -> LDS volume per MFMA is what is paid).
+// The hypothesis of RING = 1: with two chunk buffers a workgroup can request chunk k + 1 only while it multiplies chunk k (0.6 - 1.2 us) and the
+// round trip under load is ~2 us, so every chunk ends waiting.  RING keeps THREE activation images and two weight images in LDS (78 KB: still
+// two workgroups per CU): the activations of chunk k + 2
 // and the weights of chunk k + 1 are requested during chunk k, the wait that ends chunk k is a COUNTED vmcnt (the pieces of chunk k + 2 stay in
 // flight across the barrier) and the barrier is a raw s_barrier (__syncthreads() would drain vmcnt).
 // RING = 2: RING plus ONE LOADER WAVE per workgroup (wave NW): after the prologue it alone issues the LDS-DMA (the 9 weight instructions of chunk
