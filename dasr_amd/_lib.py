@@ -23,7 +23,7 @@ class ConvParams(C.Structure):
                 ('alpha', c_f32), ('res1', Tensor), ('beta1', c_f32), ('res2', Tensor), ('beta2', c_f32),
                 ('out_f32', Tensor), ('out_bf16', Tensor), ('gamma', c_f32), ('xcd_remap', c_i32),
                 ('pad_x', c_i32), ('out_stride', c_i32), ('out_oy', c_i32), ('out_ox', c_i32), ('out_W', c_i32), ('slope_ptr', c_vp),
-                ('in_stride', c_i32), ('in_oy', c_i32), ('in_ox', c_i32), ('in_W', c_i32), ('in_scale', c_f32), ('out16_f16', c_i32), ('in_wrap', c_i32), ('out16_lo', c_i32)]
+                ('in_stride', c_i32), ('in_oy', c_i32), ('in_ox', c_i32), ('in_W', c_i32), ('in_scale', c_f32), ('out16_f16', c_i32), ('in_wrap', c_i32), ('out16_lo', c_i32), ('res1_lo', c_i32)]
 
 
 class WgradPart(C.Structure):
@@ -141,7 +141,7 @@ _BENCH_SIGS = {
 }
 BENCH_LIB_PATH = os.path.join(HERE, 'libdasr_bench.so')
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 _lib = None
 _bench = None
 

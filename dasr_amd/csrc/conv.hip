@@ -94,6 +94,16 @@ __device__ __forceinline__ void mask_prefetch(const dasr_conv_params& p, MaskPre
     }
 }
 
+// epilogue stores with a run-time cache policy (dasr_set_tuning key 7; wave-uniform): 0 plain (the lines stay dirty in the XCD's L2 until the
+// end-of-kernel release writes them back: + dirty bytes / 6 TB/s on the kernel boundary, MI355X_MICROARCH.md price list), 1 `sc1`, 2 `sc0 sc1`
+// (written through, the line leaves the L2), 3 `nt`
+__device__ __forceinline__ void st128(u32x4 v, __amdgpu_buffer_rsrc_t r, unsigned off, int pol) {
+    if (pol == 0) __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+    else if (pol == 1) __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16);
+    else if (pol == 2) __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 17);
+    else __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 2);
+}
+
 // F16OUT: -1 = the 16-bit output format is a run-time (wave-uniform) choice; 0 / 1 = bf16 / f16 fixed at compile time (the dense-block LDS-DMA
 // kernels: the run-time form converted every element to BOTH formats and selected: 224 of the 628 VALU instructions of the Cout=32 epilogue)
 template <bool IN_F32, int MT, int NT, int STRIDE, int EPI, int F16OUT = -1, bool PRE = false>
@@ -121,12 +131,13 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
     constexpr int MSZ = IN_F32 ? 4 : 2;
     const float slope = (G && p.slope_ptr) ? *p.slope_ptr : p.slope;  // PReLU: the (learned) slope lives in the parameter buffer
     const __amdgpu_buffer_rsrc_t rmask = make_rsrc((const char*)p.mask.p + (size_t)n * p.mask.n_stride * MSZ);
-    const __amdgpu_buffer_rsrc_t rr1 = make_rsrc((const float*)p.res1.p + (size_t)n * p.res1.n_stride);
+    const __amdgpu_buffer_rsrc_t rr1 = make_rsrc((const char*)p.res1.p + (size_t)n * p.res1.n_stride * ((G && p.res1_lo) ? 2 : 4));
     const __amdgpu_buffer_rsrc_t rr2 = make_rsrc((const float*)p.res2.p + (size_t)n * p.res2.n_stride);
     const __amdgpu_buffer_rsrc_t rof = make_rsrc((float*)p.out_f32.p + (size_t)n * p.out_f32.n_stride);
     const __amdgpu_buffer_rsrc_t rob = make_rsrc((bf16_t*)p.out_bf16.p + (size_t)n * p.out_bf16.n_stride);
     const unsigned mask_cb = (unsigned)p.mask.cb_stride, r1_cb = (unsigned)p.res1.cb_stride, r2_cb = (unsigned)p.res2.cb_stride;
     const unsigned of_cb = (unsigned)p.out_f32.cb_stride, ob_cb = (unsigned)p.out_bf16.cb_stride;
+    const int stpol = (p.xcd_remap >> 4) & 3;   // store cache policy (st128)
     const unsigned lo_pl = (unsigned)p.out16_lo;   // split 16-bit output: the remainder goes lo_pl planes further (wave-uniform; 0 = plain)
     f32x4 bia[MT][4];
     if (has_bias) {
@@ -214,7 +225,14 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                 }
             }
         }
-        if (has_r1) {
+        if (G && has_r1 && p.res1_lo) {   // split 16-bit residual (hi planes + remainder planes, dasr_conv_params::res1_lo): two 8-byte loads per group
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(rr1, eo[g] != OOB ? (cbv[g] * r1_cb + eo[g]) * 2u : OOB, 0, 0);
+                const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(rr1, eo[g] != OOB ? ((cbv[g] + (unsigned)p.res1_lo) * r1_cb + eo[g]) * 2u : OOB, 0, 0);
+                r1v[slot][g] = u32x4{hi[0], hi[1], lo[0], lo[1]};
+            }
+        } else if (has_r1) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if constexpr (WIDE32) r1v[slot][g] = __builtin_amdgcn_raw_buffer_load_b128(rr1, e32[g & 1] != OOB ? (cbv[g] * r1_cb + e32[g & 1]) * 4u : OOB, 0, 0);
@@ -312,7 +330,20 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[g][j] *= p.alpha;
             }
-            if (has_r1) {
+            if (G && has_r1 && p.res1_lo) {   // value = hi + lo (f16 or bf16 pairs, the 16-bit format of the output tensor)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const u32x4 w = r1v[slot][g];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned short hb = (unsigned short)((j & 1) ? (w[j >> 1] >> 16) : (w[j >> 1] & 0xffffu));
+                        const unsigned short lb = (unsigned short)((j & 1) ? (w[2 + (j >> 1)] >> 16) : (w[2 + (j >> 1)] & 0xffffu));
+                        const float r = f16out ? (float)__builtin_bit_cast(f16_t, hb) + (float)__builtin_bit_cast(f16_t, lb)
+                                               : (float)__builtin_bit_cast(bf16_t, hb) + (float)__builtin_bit_cast(bf16_t, lb);
+                        v[g][j] += p.beta1 * r;
+                    }
+                }
+            } else if (has_r1) {
                 if constexpr (WIDE32) {
                     rows_swap(r1v[slot][0], r1v[slot][1]);
                     rows_swap(r1v[slot][2], r1v[slot][3]);
@@ -347,14 +378,14 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                     u32x4 oa = {__float_as_uint(v[2 * pr][0]), __float_as_uint(v[2 * pr][1]), __float_as_uint(v[2 * pr][2]), __float_as_uint(v[2 * pr][3])};
                     u32x4 ob = {__float_as_uint(v[2 * pr + 1][0]), __float_as_uint(v[2 * pr + 1][1]), __float_as_uint(v[2 * pr + 1][2]), __float_as_uint(v[2 * pr + 1][3])};
                     rows_swap(oa, ob);
-                    __builtin_amdgcn_raw_buffer_store_b128(oa, rof, e32[0] != OOB ? (cbv[2 * pr] * of_cb + e32[0]) * 4u : OOB, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(ob, rof, e32[1] != OOB ? (cbv[2 * pr] * of_cb + e32[1]) * 4u : OOB, 0, 0);
+                    st128(oa, rof, e32[0] != OOB ? (cbv[2 * pr] * of_cb + e32[0]) * 4u : OOB, stpol);
+                    st128(ob, rof, e32[1] != OOB ? (cbv[2 * pr] * of_cb + e32[1]) * 4u : OOB, stpol);
                 }
             } else if (has_f32) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const u32x4 o = {__float_as_uint(v[g][0]), __float_as_uint(v[g][1]), __float_as_uint(v[g][2]), __float_as_uint(v[g][3])};
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rof, eo[g] != OOB ? (cbv[g] * of_cb + eo[g]) * 4u : OOB, 0, 0);
+                    st128(o, rof, eo[g] != OOB ? (cbv[g] * of_cb + eo[g]) * 4u : OOB, stpol);
                 }
             }
             if (has_bf16 && WIDE16) {
@@ -372,7 +403,7 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                     const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
                     const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
                     const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};   // lanes 0-31: channels 0-7 of the plane, lanes 32-63: channels 8-15
-                    __builtin_amdgcn_raw_buffer_store_b128(o, rob, eo[2 * pr] != OOB ? (cbv[2 * pr] * ob_cb + eo[2 * pr] + 4u * kh2) * 2u : OOB, 0, 0);
+                    st128(o, rob, eo[2 * pr] != OOB ? (cbv[2 * pr] * ob_cb + eo[2 * pr] + 4u * kh2) * 2u : OOB, stpol);
                     if (lo_pl) {   // remainder plane: lo = round16(value - hi)
                         bf16x4 la, lb;
 #pragma unroll
@@ -386,7 +417,7 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                         const auto q0 = __builtin_amdgcn_permlane32_swap(a2[0], b2[0], false, false);
                         const auto q1 = __builtin_amdgcn_permlane32_swap(a2[1], b2[1], false, false);
                         const u32x4 o2 = {q0[0], q1[0], q0[1], q1[1]};
-                        __builtin_amdgcn_raw_buffer_store_b128(o2, rob, eo[2 * pr] != OOB ? ((cbv[2 * pr] + lo_pl) * ob_cb + eo[2 * pr] + 4u * kh2) * 2u : OOB, 0, 0);
+                        st128(o2, rob, eo[2 * pr] != OOB ? ((cbv[2 * pr] + lo_pl) * ob_cb + eo[2 * pr] + 4u * kh2) * 2u : OOB, stpol);
                     }
                 }
             } else if (has_bf16) {
@@ -446,7 +477,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const dasr_conv_params p) 
         // that neighbouring tiles (which share halo rows/columns) hit the same L2.  Bijective when the grid is a
         // multiple of 8; otherwise keep the natural order.
         const int total = gridDim.x;
-        if (p.xcd_remap && (total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);
+        if ((p.xcd_remap & 1) && (total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);
     }
     const int mg = bid % MG;
     bid /= MG;
@@ -855,16 +886,22 @@ struct GCfg {
 // (A free function, not a lambda: hipcc drops the host-side kernel handle when this builtin sits in a lambda of a __global__ template.)
 template <int MT, int NW>
 __device__ __forceinline__ void glds_dma_piece(int i, int ck, char* buf, __amdgpu_buffer_rsrc_t rin, __amdgpu_buffer_rsrc_t rw, const unsigned* goff,
-                                               unsigned in_chunk_bytes, int wave, int tid, int ckp) {
+                                               unsigned in_chunk_bytes, int wave, int tid, int ckp, int ldpol = 0) {
     using C = GCfg<MT, NW>;
     typedef __attribute__((address_space(3))) void* lds_ptr;
+    // ldpol (dasr_set_tuning key 8, wave-uniform): bit 0 = `nt` on the activation pieces (each is read by one or two workgroups), bit 1 = `nt` on the
+    // weight pieces (re-read by every workgroup of the launch)
     if (i < C::AR) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(buf + (i * C::NTH + wave * 64) * 16), 16, goff[i], (unsigned)ckp * in_chunk_bytes, 0, 0);
+        if (ldpol & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(buf + (i * C::NTH + wave * 64) * 16), 16, goff[i], (unsigned)ckp * in_chunk_bytes, 0, 2);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(buf + (i * C::NTH + wave * 64) * 16), 16, goff[i], (unsigned)ckp * in_chunk_bytes, 0, 0);
     } else {
         const int r = i - C::AR;
-        if (r * C::NTH + wave * 64 < C::WPIECE)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(buf + C::ACT_BYTES + (r * C::NTH + wave * 64) * 16), 16, (unsigned)(tid + r * C::NTH) * 16u,
-                                                     (unsigned)ck * (9u * MT * 1024u), 0, 0);
+        if (r * C::NTH + wave * 64 < C::WPIECE) {
+            if (ldpol & 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(buf + C::ACT_BYTES + (r * C::NTH + wave * 64) * 16), 16, (unsigned)(tid + r * C::NTH) * 16u,
+                                                                    (unsigned)ck * (9u * MT * 1024u), 0, 2);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(buf + C::ACT_BYTES + (r * C::NTH + wave * 64) * 16), 16, (unsigned)(tid + r * C::NTH) * 16u,
+                                                          (unsigned)ck * (9u * MT * 1024u), 0, 0);
+        }
     }
 }
 
@@ -970,6 +1007,7 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
     const int oy0 = ty * C::TH, ox0 = tx * C::TW;
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
     const int nchunks = a_cin >> 4;
+    const int ldpol = (a_remap >> 6) & 3;   // cache policy of the LDS-DMA pieces (glds_dma_piece)
     const int in_wrap = p.in_wrap > 0 ? p.in_wrap : 0x7fffffff;   // split 16-bit input: chunks >= in_wrap read the hi planes a second time
     constexpr int rot = 0;   // (per-workgroup chunk-order rotation was tried against L2 hot-spotting of the shared weight blocks: no effect)
     float bias_reg = 0.f;
@@ -1009,7 +1047,7 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < NP; ++i) glds_dma_piece<MT, NW>(i, rot, smem, rin, rw, goff, in_chunk_bytes, wave, tid, rot);
+        for (int i = 0; i < NP; ++i) glds_dma_piece<MT, NW>(i, rot, smem, rin, rw, goff, in_chunk_bytes, wave, tid, rot, ldpol);
     }
     TRACE_STAMP(1);
     if constexpr (LW) {
@@ -1209,7 +1247,7 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
                 }
             } else if (more && s < 4 && !(ABL & 1)) {  // all pieces of the next chunk are requested in the first steps: they have the rest of the chunk to land
 #pragma unroll
-                for (int i = s * NP / 4; i < (s + 1) * NP / 4; ++i) glds_dma_piece<MT, NW>(i, ckn, nbuf, rin, rw, goff, in_chunk_bytes, wave, tid, ckp);
+                for (int i = s * NP / 4; i < (s + 1) * NP / 4; ++i) glds_dma_piece<MT, NW>(i, ckn, nbuf, rin, rw, goff, in_chunk_bytes, wave, tid, ckp, ldpol);
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(ABL & 8)) {
@@ -1508,7 +1546,7 @@ __global__ void conv_naive_kernel(const dasr_conv_params p, const float* w) {
 
 // compile-time epilogue variant of the hot dense-block cases (bit set: see conv_kernel's epilogue); 0 = generic
 int classify_epi(const dasr_conv_params& p) {
-    if ((p.cout & 31) || p.slope_ptr || p.act == 2 || p.out_stride > 1) return 0;
+    if ((p.cout & 31) || p.slope_ptr || p.act == 2 || p.out_stride > 1 || p.res1_lo) return 0;
     if (p.act == 1 && !(p.slope >= 0.f && p.slope <= 1.f)) return 0;   // the specialised epilogues use max(v, slope * v)
     int e = (p.bias ? 1 : 0) | (p.act == 1 ? 2 : 0) | (p.mask.p ? 4 : 0) | (p.res1.p ? 8 : 0) | (p.res2.p ? 16 : 0) | (p.out_f32.p ? 32 : 0) |
             (p.out_bf16.p ? 64 : 0);
@@ -1518,6 +1556,8 @@ int classify_epi(const dasr_conv_params& p) {
 
 // kernel-variant selection (A/B-able from the host: dasr_set_tuning)
 int g_tune_rot = 0;  // chunk-order rotation of the LDS-DMA dense-block conv (A/B)
+int g_tune_ldpol = 0;  // cache policy of the LDS-DMA pieces of conv_glds_kernel (bit 0 activations nt, bit 1 weights nt)
+int g_tune_stpol = 1 | 4;  // cache policy of the 16-byte epilogue stores (st128): sc1 on the Cout = 32 dense-block convs
 int g_tune_rdb32 = 12, g_tune_rdb64 = 13, g_tune_stream = 0, g_tune_xcd = 1, g_tune_epi = 1;  // Cout=64: 13 = 8-wave form for launches of <= 256 four-wave workgroups (worth 1-2 % of the step under two sub-batch streams)
 
 }  // namespace
@@ -1536,6 +1576,8 @@ extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
         case 3: g_tune_stream = value; return 0;  // split-bf16 stream conv: 0 single, 1 double
         case 4: g_tune_xcd = value; return 0;     // XCD-aware tile order on/off
         case 5: g_tune_epi = value; return 0;     // compile-time specialised epilogues on/off
+        case 7: if (value < 0 || value > 63) return DASR_EINVAL; g_tune_stpol = value; return 0;   // epilogue store policy: bits 0-1: 0 plain, 1 sc1, 2 sc0 sc1, 3 nt; class mask +4 Cout-32 dense convs, +8 conv5, +16 f16 HR tail, +32 other (default 5)
+        case 8: if (value < 0 || value > 3) return DASR_EINVAL; g_tune_ldpol = value; return 0;   // LDS-DMA load policy: +1 activations nt, +2 weights nt
         case 6: g_tune_rot = value; return 0;     // LDS-DMA dense conv: per-workgroup chunk-order rotation on/off
         default: return DASR_EINVAL;
     }
@@ -1543,7 +1585,12 @@ extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
 
 extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
     dasr_conv_params p = *pp;
-    p.xcd_remap = g_tune_xcd;  // bit 1 (trace builds): contiguous-store timing experiment
+    // store cache policy (conv_epilogue::st128).  Default 5 = `sc1` for the Cout = 32 dense-block convs only: their 8-16 MB of output per launch no
+    // longer wait dirty in the L2 for the end-of-kernel release (+ bytes / 6 TB/s on every kernel boundary): step -1.6...-1.9 % in three
+    // A/B rounds (scripts/r03_call20.sh); on the 64-channel conv5 / f32-tensor convs it measured flat or worse (the DSN iteration +10 %)
+    // value = policy (bits 0-1) | class mask: 4 bf16 dense-block convs with Cout = 32, 8 with Cout = 64 (conv5), 16 the f16 HR tail, 32 everything else
+    const int cls = (!p.in_f32 && p.prec == 1) ? (p.mt == 1 ? 4 : 8) : ((!p.in_f32 && p.prec == 2) ? 16 : 32);
+    p.xcd_remap = g_tune_xcd | (((g_tune_stpol & cls) ? (g_tune_stpol & 3) : 0) << 4) | ((g_tune_ldpol & 3) << 6);  // bit 1 (trace builds): contiguous-store timing experiment; bits 4-5: store cache policy
     if (p.pad_x == 0 && p.out_stride == 0 && p.kh != 2 && p.kh != 1) p.pad_x = -1;  // zero-initialised extension fields = "same as pad"
     hipStream_t s = as_stream(stream);
     if (p.cin <= 0 || (p.cin & 15) || p.cout <= 0 || !p.w || !p.in.p) return DASR_EINVAL;
@@ -1566,11 +1613,12 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
     if (p.kh < 1 || p.kh > 5) return DASR_EINVAL;
     if (p.mask.p && (p.mask_f32 != 0) != (p.in_f32 != 0)) return DASR_EINVAL;  // mask dtype is tied to the input dtype
     if (p.ups && !p.in_f32 && p.prec != 2) return DASR_EINVAL;
-    if (p.in_wrap < 0 || p.out16_lo < 0) return DASR_EINVAL;
-    if (p.in_wrap || p.out16_lo) {   // split 16-bit tensors: the LDS-DMA kernel only (a 16-bit input, 3x3 / stride 1 / pad 1, one-pass precisions)
+    if (p.in_wrap < 0 || p.out16_lo < 0 || p.res1_lo < 0) return DASR_EINVAL;
+    if (p.in_wrap || p.out16_lo || p.res1_lo) {   // split 16-bit tensors: the LDS-DMA kernel only (a 16-bit input, 3x3 / stride 1 / pad 1, one-pass precisions)
         if (p.in_f32 || p.kh != 3 || p.stride != 1 || p.pad != 1 || !(p.prec == 1 || p.prec == 2) || p.ups || p.out_stride > 1) return DASR_EINVAL;
         if (p.in_wrap && (p.cin >> 4) * 2 != p.in_wrap * 3) return DASR_EINVAL;   // cin = 3 * 16K virtual channels, in_wrap = 2K
         if (p.out16_lo && !p.out_bf16.p) return DASR_EINVAL;
+        if (p.res1_lo < 0 || (p.res1_lo && !p.res1.p)) return DASR_EINVAL;
         if (p.prec == 1 && ((p.mt == 1 && g_tune_rdb32 != 12) || (p.mt == 2 && g_tune_rdb64 != 12 && g_tune_rdb64 != 13))) return DASR_EINVAL;   // (A/B variants of the first-generation kernel do not know the layout)
     }
     switch (key) {

@@ -98,8 +98,10 @@ __device__ __forceinline__ void stage_store(const StageReg<F32>& r, char* dst, f
     }
 }
 
+// (4x4 kernels: 8 accumulator tiles per wave + the staging registers of an f32 source need ~290 registers: one workgroup per CU instead of
+// scratch spills inside the MFMA loop -- VERDICT r02 item 10)
 template <int KH, int STRIDE, bool USE_TR, bool F32, bool F16 = false>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit,
+__global__ __launch_bounds__(256, KH == 4 ? 1 : 2) void wgrad_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit,
                                                        float* __restrict__ ws) {
     static_assert(!F16 || F32, "f16 staging converts f32 tensors");
     using C = WCfg<KH, STRIDE>;

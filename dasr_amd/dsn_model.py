@@ -125,6 +125,19 @@ class DeResnetHIP:
             fb('d2', 'down_sample.2.', 64, 64, 2)
         fb('out', 'block_output.', 3, 64)
         self.bwd16 = os.environ.get('DASR_DSN_BWD16', '1') != '0'
+        # forward of the input conv and of the residual blocks on SPLIT f16 tensors (f16 hi planes + f16 remainder planes: 22-bit operands instead of
+        # split-bf16's 16, one launch of the LDS-DMA kernel over 3K virtual chunks instead of three register-staged passes); the hi planes are the
+        # f16 shadows the 16-bit backward reads.  OPT-IN (DASR_DSN_FWD16=1; default: fp32 tensors + separate shadows): measured 7.14 -> 6.88 ms per
+        # iteration (-3.6 %: the generic epilogue and three MFMA passes remain), and ONE run of the fixture suite out of ~35 on the GPU boxes ended
+        # with a non-finite generator gradient that could not be reproduced -- not worth the default for that gain.
+        self.fwd16 = self.bwd16 and os.environ.get('DASR_DSN_FWD16', '0') == '1'
+        if self.fwd16:
+            w = P.off('block_input.0.weight')
+            self.pk['in_s'] = self.pack.add(64, 48, 9, 2, 5, [(w, 64, 3, 0, 3, 0, 0)])
+            for k in range(n_res_blocks):
+                for j in (1, 2):
+                    w = P.off('res_blocks.%d.conv%d.weight' % (k, j))
+                    self.pk['r%d_%d_s' % (k, j)] = self.pack.add(64, 192, 9, 2, 5, [(w, 64, 64, 0, 64, 0, 0)])
         if self.bwd16:   # data gradient of the residual-block convs: one f16 pass on 16-bit tensors
             for k in range(n_res_blocks):
                 for j in (1, 2):
@@ -161,8 +174,10 @@ class _GPlan:
         self.x_nchw = torch.zeros((N, 3, H, W), dtype=torch.float32, device=dev)
         self.fake_nchw = torch.zeros((N, 3, H4, W4), dtype=torch.float32, device=dev)
         self.x_in = B(16, H, W)
-        self.s = [B(64, H, W) for _ in range(nb + 1)]
-        self.h = [B(64, H, W) for _ in range(nb)]
+        f16w = net.fwd16
+        # (split forward: only s[0] -- PReLU' of the input conv at the end of the backward -- and s[nb] -- input of the f32 stride-2 convs -- exist in fp32)
+        self.s = [B(64, H, W) if (not f16w or k in (0, nb)) else None for k in range(nb + 1)]
+        self.h = [B(64, H, W) if not f16w else None for _ in range(nb)]
         self.fake = B(16, H4, W4)
         self.g_fake, self.gz_out = B(16, H4, W4), B(16, H4, W4)
         if down:
@@ -174,8 +189,14 @@ class _GPlan:
         if b16:
             import math
             B16 = lambda: BTensor(N, 64, H, W, False, dev, f16=True)
-            self.s16 = [B16() for _ in range(nb)]       # f16 shadows of the residual stream s[0 .. nb-1] and of the block-internal activations
-            self.h16 = [B16() for _ in range(nb)]
+            BS = lambda C_: BTensor(N, 2 * ceil_div(C_, 16) * 16, H, W, False, dev, f16=True)   # split tensor: hi planes, then remainder planes
+            if f16w:   # (view() of a split tensor = its hi planes: the 16-bit shadow)
+                self.x_s = BS(16)
+                self.s16 = [BS(64) for _ in range(nb)]
+                self.h16 = [BS(64) for _ in range(nb)]
+            else:
+                self.s16 = [B16() for _ in range(nb)]       # f16 shadows of the residual stream s[0 .. nb-1] and of the block-internal activations
+                self.h16 = [B16() for _ in range(nb)]
             self.g_s16 = [B16() for _ in range(2)]      # gscale * dL/ds, gscale * dL/dh in f16
             self.g_h16 = B16()
             # dL/dfake of the mean losses is ~1 / (number of output elements): a power of two puts it at ~2^-3 before the f16 rounding
@@ -189,10 +210,26 @@ class _GPlan:
         o = _op(_lib.OP_NCHW2B)
         o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[0], o.t[1] = self.x_nchw.data_ptr(), N, 3, H, W, self.x_in.view(), NULL_T
         f.add(o)
-        f.add(conv_op(pack, pk['in'], self.x_in.view(), True, 16, H, W, H, W, N, bias=sp('block_input.0.bias'), act=1,
-                      slope_ptr=sp('block_input.1.weight'), out_f32=self.s[0].view(), **(sh(self.s16[0]) if (b16 and nb) else {})))
+        if f16w and nb:
+            o = _op(_lib.OP_CVT_F16)
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1], o.i[4] = self.x_in.view(), N, 16, H, W, 1.0, self.x_s.view(), 1
+            f.add(o)
+            f.add(conv_op(pack, pk['in_s'], self.x_s.view(), False, 48, H, W, H, W, N, bias=sp('block_input.0.bias'), act=1,
+                          slope_ptr=sp('block_input.1.weight'), out_f32=self.s[0].view(), out_bf16=self.s16[0].view(), out16_f16=1, in_wrap=2, out16_lo=4))
+        else:
+            f.add(conv_op(pack, pk['in'], self.x_in.view(), True, 16, H, W, H, W, N, bias=sp('block_input.0.bias'), act=1,
+                          slope_ptr=sp('block_input.1.weight'), out_f32=self.s[0].view(), **(sh(self.s16[0]) if (b16 and nb) else {})))
         for k in range(nb):
             pre = 'res_blocks.%d.' % k
+            if f16w:
+                last_blk = k + 1 == nb
+                f.add(conv_op(pack, pk['r%d_1_s' % k], self.s16[k].view(), False, 192, H, W, H, W, N, bias=sp(pre + 'conv1.bias'), act=1,
+                              slope_ptr=sp(pre + 'prelu.weight'), out_bf16=self.h16[k].view(), out16_f16=1, in_wrap=8, out16_lo=4))
+                f.add(conv_op(pack, pk['r%d_2_s' % k], self.h16[k].view(), False, 192, H, W, H, W, N, bias=sp(pre + 'conv2.bias'),
+                              res1=self.s16[k].view(), beta1=1.0, res1_lo=4, in_wrap=8,
+                              out_f32=self.s[nb].view() if last_blk else None, out_bf16=None if last_blk else self.s16[k + 1].view(),
+                              out16_f16=1, out16_lo=0 if last_blk else 4))
+                continue
             f.add(conv_op(pack, pk['r%d_1' % k], self.s[k].view(), True, 64, H, W, H, W, N, bias=sp(pre + 'conv1.bias'), act=1,
                           slope_ptr=sp(pre + 'prelu.weight'), out_f32=self.h[k].view(), **sh(self.h16[k] if b16 else None)))
             f.add(conv_op(pack, pk['r%d_2' % k], self.h[k].view(), True, 64, H, W, H, W, N, bias=sp(pre + 'conv2.bias'),

@@ -242,7 +242,7 @@ def run_interleaved(lists, streams, chunk=None):
 def conv_op(pack, ref, inp, in_f32, cin, Hin, Win, Hout, Wout, N, bias=None, kh=3, stride=1, pad=1, ups=0, act=0, slope=SLOPE,
             mask=None, mask_f32=0, alpha=1.0, res1=None, beta1=0.0, res2=None, beta2=0.0, out_f32=None, out_bf16=None, gamma=1.0,
             pad_x=-1, out_stride=1, out_oy=0, out_ox=0, out_W=0, slope_ptr=None, in_stride=1, in_oy=0, in_ox=0, in_W=0, flops=None, in_scale=0.0, out16_f16=0,
-            in_wrap=0, out16_lo=0):
+            in_wrap=0, out16_lo=0, res1_lo=0):
     """flops: algorithmic FLOPs of the reference op this launch stands for (default: 2 * outputs * taps * cin * cout of the launch
     itself; the sub-pixel upconv launches pass a quarter of the reference's 3x3 conv on the up-sampled grid instead)."""
     assert cin == ref.cin_pad, (cin, ref.cin_pad)
@@ -267,6 +267,7 @@ def conv_op(pack, ref, inp, in_f32, cin, Hin, Win, Hout, Wout, N, bias=None, kh=
     p.in_stride, p.in_oy, p.in_ox, p.in_W = in_stride, in_oy, in_ox, in_W
     p.in_scale = in_scale if (ref.prec in (2, 4) and in_f32) else 0.0   # power-of-two pre-scale of an f32 gradient input before its f16 rounding
     p.out16_f16 = int(out16_f16)
+    p.res1_lo = int(res1_lo)   # res1 is a split 16-bit tensor: its remainder planes start res1_lo planes after the hi planes
     p.in_wrap, p.out16_lo = int(in_wrap), int(out16_lo)   # split 16-bit tensors (SplitTensor): 2K input planes before the hi planes repeat; K' output planes
     return o
 

@@ -83,9 +83,12 @@ class AdamHIP:
             self.nonfinite.zero_()
             if os.environ.get('DASR_HIP_LIB'):   # instrumented / ablation builds compute wrong results on purpose (scripts/, timing only)
                 return
-            raise FloatingPointError('inf / NaN in the %s gradients (the weights have absorbed it).  The HR tail stores activations and gradients in f16 '
+            P = self.params
+            bad = [k for k in P.spec if not bool(torch.isfinite(P.view(k, P.grad)).all())][:6]   # (the last step's gradients; error path only)
+            raise FloatingPointError('inf / NaN in the %s gradients (the weights have absorbed it)%s.  The HR tail stores activations and gradients in f16 '
                                      'with a power-of-two pre-scale sized for mean losses of weight ~1: very large loss weights or activations above '
-                                     '65504 overflow it -- DASR_HR_PREC=3 keeps the tail in split-bf16 on f32 tensors.' % what)
+                                     '65504 overflow it -- DASR_HR_PREC=3 keeps the tail in split-bf16 on f32 tensors.'
+                                     % (what, (': non-finite now in ' + ', '.join(bad)) if bad else ''))
 
     def state_dict(self, lr):
         P = self.params

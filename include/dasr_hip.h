@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DASR_ABI_VERSION 10
+#define DASR_ABI_VERSION 11
 #define DASR_EINVAL (-22)
 
 typedef struct {
@@ -79,8 +79,9 @@ typedef struct {
      *   in_wrap = 2K, cin = 3 * 16K: chunk c reads plane (c < in_wrap ? c : c - in_wrap) of `in`, i.e. hi, lo, hi again; the weights are
      *   packed as [hi | hi | lo] (dasr_pack_weights fmt 3 / 4).  0: plain tensor.
      *   out16_lo = K' > 0: the 16-bit output is written split: hi into plane cb, lo = round16(gamma * v - hi) into plane cb + K'.
+     *   res1_lo = K' > 0: `res1` is a split 16-bit tensor (same element format as the 16-bit output), read as hi + lo.
      * LDS-DMA kernel only (16-bit input, 3x3 / stride 1 / pad 1, prec 1 or 2). */
-    int32_t in_wrap, out16_lo;
+    int32_t in_wrap, out16_lo, res1_lo;
 } dasr_conv_params;
 
 int dasr_conv(const dasr_conv_params* p, void* stream);
@@ -88,7 +89,12 @@ int dasr_conv(const dasr_conv_params* p, void* stream);
  * key 1 / 2: dense-block conv with Cout = 32 / 64: 12 = LDS-DMA kernel (default for Cout 32), 13 = its 8-wave 32x32-tile form (Cout 64 default: chosen per launch when the 4-wave grid has <= 256 workgroups), 0 = first-generation register-staged kernel,
  *            1 double-buffered LDS, 4/5 8x32 tiles, 6 4x32 tiles, 8/9 row reuse, 10/11 register-staged pipeline;
  * key 3: split-bf16 stream conv (0 single / 1 double LDS buffer, 4 8x32 tiles); key 4: XCD-aware tile order on/off;
- * key 5: compile-time specialised epilogues on/off. */
+ * key 5: compile-time specialised epilogues on/off;
+ *            key 1 also: 15 / 16 / 17 = ring of three LDS images with counted vmcnt / + one loader wave / + LDS flags instead of the chunk barrier
+ *            (round 3: built, parity-tested, measured flat -- profiles/r03_conv_ablation.txt);
+ * key 7: cache policy of the 16-byte epilogue stores: bits 0-1: 0 plain, 1 `sc1`, 2 `sc0 sc1`, 3 `nt`; which convs it applies to: +4 the bf16 dense-block
+ *        convs with Cout = 32, +8 conv5 (Cout = 64), +16 the f16 HR tail, +32 all others.  Default 5: the Cout-32 outputs are written through
+ *        instead of waiting dirty in the L2 for the end-of-kernel release (step -1.8 %; flat or worse on the other classes). */
 int dasr_set_tuning(int32_t key, int32_t value);
 
 /* ---- weight gradient ---------------------------------------------------------------------------

@@ -194,7 +194,7 @@ def _from_split(bt, C_):
 
 
 @pytest.mark.parametrize('f16', [True, False], ids=['f16', 'bf16'])
-@pytest.mark.parametrize('cin,cout,mode', [(40, 64, 'fwd'), (64, 32, 'fwd'), (3, 64, 'fwd'), (64, 40, 'dgrad'), (128, 128, 'dgrad'), (64, 3, 'f32out')])
+@pytest.mark.parametrize('cin,cout,mode', [(40, 64, 'fwd'), (64, 32, 'fwd'), (3, 64, 'fwd'), (64, 40, 'dgrad'), (128, 128, 'dgrad'), (64, 3, 'f32out'), (64, 64, 'res')])
 def test_conv_on_split_tensors_is_fp32_grade(cin, cout, mode, f16):
     """split 16-bit tensors (dasr_conv_params::in_wrap / out16_lo, round 3): hi planes + remainder planes, the three-term product as ONE launch
     of the LDS-DMA kernel over 3K virtual chunks -- must be as accurate as the split precisions on f32 tensors (prec 3 / 4): 16 (bf16) or 22
@@ -233,6 +233,13 @@ def test_conv_on_split_tensors_is_fp32_grade(cin, cout, mode, f16):
         ops.add(conv_op(pack, ref, xs.view(), False, 3 * c16(cin), H, W, H, W, N, mask=mb.view(), mask_f32=0, slope=0.0, out_bf16=out.view(),
                         out16_f16=int(f16), in_wrap=2 * kin, out16_lo=c16(cout) // 16))
         y = torch.where(msk.to(dt).double() > 0, y, torch.zeros_like(y))
+    elif mode == 'res':   # bias + a SPLIT residual (res1_lo) -> split output: conv2 of a DSN residual block on split tensors
+        r = torch.randn(N, cout, H, W, generator=g)
+        rs = _to_split(r, dev, f16)
+        out = BTensor(N, 2 * c16(cout), H, W, False, dev, f16=f16)
+        ops.add(conv_op(pack, ref, xs.view(), False, 3 * c16(cin), H, W, H, W, N, bias=P.ptr('b'), res1=rs.view(), beta1=1.0, res1_lo=c16(cout) // 16,
+                        out_bf16=out.view(), out16_f16=int(f16), in_wrap=2 * kin, out16_lo=c16(cout) // 16))
+        y = y + b.double().view(1, -1, 1, 1) + _from_split(rs, cout).double()
     else:
         out = BTensor(N, cout, H, W, True, dev)
         ops.add(conv_op(pack, ref, xs.view(), False, 3 * c16(cin), H, W, H, W, N, alpha=0.125, out_f32=out.view(), in_wrap=2 * kin))
