@@ -94,14 +94,15 @@ __device__ __forceinline__ void mask_prefetch(const dasr_conv_params& p, MaskPre
     }
 }
 
-// epilogue stores with a run-time cache policy (dasr_set_tuning key 7; wave-uniform): 0 plain (the lines stay dirty in the XCD's L2 until the
-// end-of-kernel release writes them back: + dirty bytes / 6 TB/s on the kernel boundary, MI355X_MICROARCH.md price list), 1 `sc1`, 2 `sc0 sc1`
-// (written through, the line leaves the L2), 3 `nt`
-__device__ __forceinline__ void st128(u32x4 v, __amdgpu_buffer_rsrc_t r, unsigned off, int pol) {
-    if (pol == 0) __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
-    else if (pol == 1) __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16);
-    else if (pol == 2) __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 17);
-    else __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 2);
+// 16-byte epilogue store.  SC1 (compile time: the bf16 dense-block convs with Cout = 32, forward and data gradient): `sc1` = written through, the
+// line leaves the XCD's L2.  With plain stores the 8-16 MB a launch writes stay dirty in the L2 until the end-of-kernel release writes them back
+// (+ dirty bytes / 6 TB/s on every kernel boundary, MI355X_MICROARCH.md price list); measured in round 3 with a run-time switch, three A/B
+// rounds on one box: plain 32.92-33.02 ms / step, sc1 32.28-32.50, `sc0 sc1` the same, `nt` flat; on the 64-channel conv5, the f16 HR tail and
+// the f32-tensor convs sc1 measured flat or worse (DSN iteration +10 %), so they keep plain stores (profiles/r03_conv_ablation.txt section 5)
+template <bool SC1>
+__device__ __forceinline__ void st128(u32x4 v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    if constexpr (SC1) __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16);
+    else __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
 }
 
 // F16OUT: -1 = the 16-bit output format is a run-time (wave-uniform) choice; 0 / 1 = bf16 / f16 fixed at compile time (the dense-block LDS-DMA
@@ -137,7 +138,7 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
     const __amdgpu_buffer_rsrc_t rob = make_rsrc((bf16_t*)p.out_bf16.p + (size_t)n * p.out_bf16.n_stride);
     const unsigned mask_cb = (unsigned)p.mask.cb_stride, r1_cb = (unsigned)p.res1.cb_stride, r2_cb = (unsigned)p.res2.cb_stride;
     const unsigned of_cb = (unsigned)p.out_f32.cb_stride, ob_cb = (unsigned)p.out_bf16.cb_stride;
-    const int stpol = (p.xcd_remap >> 4) & 3;   // store cache policy (st128)
+    constexpr bool SC1 = MT == 1 && !IN_F32 && F16OUT == 0;   // bf16 dense-block convs with Cout = 32 (st128)
     const unsigned lo_pl = (unsigned)p.out16_lo;   // split 16-bit output: the remainder goes lo_pl planes further (wave-uniform; 0 = plain)
     f32x4 bia[MT][4];
     if (has_bias) {
@@ -378,14 +379,14 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                     u32x4 oa = {__float_as_uint(v[2 * pr][0]), __float_as_uint(v[2 * pr][1]), __float_as_uint(v[2 * pr][2]), __float_as_uint(v[2 * pr][3])};
                     u32x4 ob = {__float_as_uint(v[2 * pr + 1][0]), __float_as_uint(v[2 * pr + 1][1]), __float_as_uint(v[2 * pr + 1][2]), __float_as_uint(v[2 * pr + 1][3])};
                     rows_swap(oa, ob);
-                    st128(oa, rof, e32[0] != OOB ? (cbv[2 * pr] * of_cb + e32[0]) * 4u : OOB, stpol);
-                    st128(ob, rof, e32[1] != OOB ? (cbv[2 * pr] * of_cb + e32[1]) * 4u : OOB, stpol);
+                    st128<SC1>(oa, rof, e32[0] != OOB ? (cbv[2 * pr] * of_cb + e32[0]) * 4u : OOB);
+                    st128<SC1>(ob, rof, e32[1] != OOB ? (cbv[2 * pr] * of_cb + e32[1]) * 4u : OOB);
                 }
             } else if (has_f32) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const u32x4 o = {__float_as_uint(v[g][0]), __float_as_uint(v[g][1]), __float_as_uint(v[g][2]), __float_as_uint(v[g][3])};
-                    st128(o, rof, eo[g] != OOB ? (cbv[g] * of_cb + eo[g]) * 4u : OOB, stpol);
+                    st128<SC1>(o, rof, eo[g] != OOB ? (cbv[g] * of_cb + eo[g]) * 4u : OOB);
                 }
             }
             if (has_bf16 && WIDE16) {
@@ -403,7 +404,7 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                     const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
                     const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
                     const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};   // lanes 0-31: channels 0-7 of the plane, lanes 32-63: channels 8-15
-                    st128(o, rob, eo[2 * pr] != OOB ? (cbv[2 * pr] * ob_cb + eo[2 * pr] + 4u * kh2) * 2u : OOB, stpol);
+                    st128<SC1>(o, rob, eo[2 * pr] != OOB ? (cbv[2 * pr] * ob_cb + eo[2 * pr] + 4u * kh2) * 2u : OOB);
                     if (lo_pl) {   // remainder plane: lo = round16(value - hi)
                         bf16x4 la, lb;
 #pragma unroll
@@ -417,7 +418,7 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                         const auto q0 = __builtin_amdgcn_permlane32_swap(a2[0], b2[0], false, false);
                         const auto q1 = __builtin_amdgcn_permlane32_swap(a2[1], b2[1], false, false);
                         const u32x4 o2 = {q0[0], q1[0], q0[1], q1[1]};
-                        st128(o2, rob, eo[2 * pr] != OOB ? ((cbv[2 * pr] + lo_pl) * ob_cb + eo[2 * pr] + 4u * kh2) * 2u : OOB, stpol);
+                        st128<SC1>(o2, rob, eo[2 * pr] != OOB ? ((cbv[2 * pr] + lo_pl) * ob_cb + eo[2 * pr] + 4u * kh2) * 2u : OOB);
                     }
                 }
             } else if (has_bf16) {
@@ -886,22 +887,17 @@ struct GCfg {
 // (A free function, not a lambda: hipcc drops the host-side kernel handle when this builtin sits in a lambda of a __global__ template.)
 template <int MT, int NW>
 __device__ __forceinline__ void glds_dma_piece(int i, int ck, char* buf, __amdgpu_buffer_rsrc_t rin, __amdgpu_buffer_rsrc_t rw, const unsigned* goff,
-                                               unsigned in_chunk_bytes, int wave, int tid, int ckp, int ldpol = 0) {
+                                               unsigned in_chunk_bytes, int wave, int tid, int ckp) {
     using C = GCfg<MT, NW>;
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    // ldpol (dasr_set_tuning key 8, wave-uniform): bit 0 = `nt` on the activation pieces (each is read by one or two workgroups), bit 1 = `nt` on the
-    // weight pieces (re-read by every workgroup of the launch)
+    // (cache policy `nt` on these loads, measured in round 3: activations flat, weights +4 % step time -- default policy kept)
     if (i < C::AR) {
-        if (ldpol & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(buf + (i * C::NTH + wave * 64) * 16), 16, goff[i], (unsigned)ckp * in_chunk_bytes, 0, 2);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(buf + (i * C::NTH + wave * 64) * 16), 16, goff[i], (unsigned)ckp * in_chunk_bytes, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(buf + (i * C::NTH + wave * 64) * 16), 16, goff[i], (unsigned)ckp * in_chunk_bytes, 0, 0);
     } else {
         const int r = i - C::AR;
-        if (r * C::NTH + wave * 64 < C::WPIECE) {
-            if (ldpol & 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(buf + C::ACT_BYTES + (r * C::NTH + wave * 64) * 16), 16, (unsigned)(tid + r * C::NTH) * 16u,
-                                                                    (unsigned)ck * (9u * MT * 1024u), 0, 2);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(buf + C::ACT_BYTES + (r * C::NTH + wave * 64) * 16), 16, (unsigned)(tid + r * C::NTH) * 16u,
-                                                          (unsigned)ck * (9u * MT * 1024u), 0, 0);
-        }
+        if (r * C::NTH + wave * 64 < C::WPIECE)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(buf + C::ACT_BYTES + (r * C::NTH + wave * 64) * 16), 16, (unsigned)(tid + r * C::NTH) * 16u,
+                                                     (unsigned)ck * (9u * MT * 1024u), 0, 0);
     }
 }
 
@@ -1007,7 +1003,6 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
     const int oy0 = ty * C::TH, ox0 = tx * C::TW;
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
     const int nchunks = a_cin >> 4;
-    const int ldpol = (a_remap >> 6) & 3;   // cache policy of the LDS-DMA pieces (glds_dma_piece)
     const int in_wrap = p.in_wrap > 0 ? p.in_wrap : 0x7fffffff;   // split 16-bit input: chunks >= in_wrap read the hi planes a second time
     constexpr int rot = 0;   // (per-workgroup chunk-order rotation was tried against L2 hot-spotting of the shared weight blocks: no effect)
     float bias_reg = 0.f;
@@ -1047,7 +1042,7 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < NP; ++i) glds_dma_piece<MT, NW>(i, rot, smem, rin, rw, goff, in_chunk_bytes, wave, tid, rot, ldpol);
+        for (int i = 0; i < NP; ++i) glds_dma_piece<MT, NW>(i, rot, smem, rin, rw, goff, in_chunk_bytes, wave, tid, rot);
     }
     TRACE_STAMP(1);
     if constexpr (LW) {
@@ -1247,7 +1242,7 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
                 }
             } else if (more && s < 4 && !(ABL & 1)) {  // all pieces of the next chunk are requested in the first steps: they have the rest of the chunk to land
 #pragma unroll
-                for (int i = s * NP / 4; i < (s + 1) * NP / 4; ++i) glds_dma_piece<MT, NW>(i, ckn, nbuf, rin, rw, goff, in_chunk_bytes, wave, tid, ckp, ldpol);
+                for (int i = s * NP / 4; i < (s + 1) * NP / 4; ++i) glds_dma_piece<MT, NW>(i, ckn, nbuf, rin, rw, goff, in_chunk_bytes, wave, tid, ckp);
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(ABL & 8)) {
@@ -1556,8 +1551,6 @@ int classify_epi(const dasr_conv_params& p) {
 
 // kernel-variant selection (A/B-able from the host: dasr_set_tuning)
 int g_tune_rot = 0;  // chunk-order rotation of the LDS-DMA dense-block conv (A/B)
-int g_tune_ldpol = 0;  // cache policy of the LDS-DMA pieces of conv_glds_kernel (bit 0 activations nt, bit 1 weights nt)
-int g_tune_stpol = 1 | 4;  // cache policy of the 16-byte epilogue stores (st128): sc1 on the Cout = 32 dense-block convs
 int g_tune_rdb32 = 12, g_tune_rdb64 = 13, g_tune_stream = 0, g_tune_xcd = 1, g_tune_epi = 1;  // Cout=64: 13 = 8-wave form for launches of <= 256 four-wave workgroups (worth 1-2 % of the step under two sub-batch streams)
 
 }  // namespace
@@ -1576,8 +1569,6 @@ extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
         case 3: g_tune_stream = value; return 0;  // split-bf16 stream conv: 0 single, 1 double
         case 4: g_tune_xcd = value; return 0;     // XCD-aware tile order on/off
         case 5: g_tune_epi = value; return 0;     // compile-time specialised epilogues on/off
-        case 7: if (value < 0 || value > 63) return DASR_EINVAL; g_tune_stpol = value; return 0;   // epilogue store policy: bits 0-1: 0 plain, 1 sc1, 2 sc0 sc1, 3 nt; class mask +4 Cout-32 dense convs, +8 conv5, +16 f16 HR tail, +32 other (default 5)
-        case 8: if (value < 0 || value > 3) return DASR_EINVAL; g_tune_ldpol = value; return 0;   // LDS-DMA load policy: +1 activations nt, +2 weights nt
         case 6: g_tune_rot = value; return 0;     // LDS-DMA dense conv: per-workgroup chunk-order rotation on/off
         default: return DASR_EINVAL;
     }
@@ -1585,12 +1576,7 @@ extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
 
 extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
     dasr_conv_params p = *pp;
-    // store cache policy (conv_epilogue::st128).  Default 5 = `sc1` for the Cout = 32 dense-block convs only: their 8-16 MB of output per launch no
-    // longer wait dirty in the L2 for the end-of-kernel release (+ bytes / 6 TB/s on every kernel boundary): step -1.6...-1.9 % in three
-    // A/B rounds (scripts/r03_call20.sh); on the 64-channel conv5 / f32-tensor convs it measured flat or worse (the DSN iteration +10 %)
-    // value = policy (bits 0-1) | class mask: 4 bf16 dense-block convs with Cout = 32, 8 with Cout = 64 (conv5), 16 the f16 HR tail, 32 everything else
-    const int cls = (!p.in_f32 && p.prec == 1) ? (p.mt == 1 ? 4 : 8) : ((!p.in_f32 && p.prec == 2) ? 16 : 32);
-    p.xcd_remap = g_tune_xcd | (((g_tune_stpol & cls) ? (g_tune_stpol & 3) : 0) << 4) | ((g_tune_ldpol & 3) << 6);  // bit 1 (trace builds): contiguous-store timing experiment; bits 4-5: store cache policy
+    p.xcd_remap = g_tune_xcd;  // bit 1 (trace builds): contiguous-store timing experiment
     if (p.pad_x == 0 && p.out_stride == 0 && p.kh != 2 && p.kh != 1) p.pad_x = -1;  // zero-initialised extension fields = "same as pad"
     hipStream_t s = as_stream(stream);
     if (p.cin <= 0 || (p.cin & 15) || p.cout <= 0 || !p.w || !p.in.p) return DASR_EINVAL;

@@ -92,9 +92,7 @@ int dasr_conv(const dasr_conv_params* p, void* stream);
  * key 5: compile-time specialised epilogues on/off;
  *            key 1 also: 15 / 16 / 17 = ring of three LDS images with counted vmcnt / + one loader wave / + LDS flags instead of the chunk barrier
  *            (round 3: built, parity-tested, measured flat -- profiles/r03_conv_ablation.txt);
- * key 7: cache policy of the 16-byte epilogue stores: bits 0-1: 0 plain, 1 `sc1`, 2 `sc0 sc1`, 3 `nt`; which convs it applies to: +4 the bf16 dense-block
- *        convs with Cout = 32, +8 conv5 (Cout = 64), +16 the f16 HR tail, +32 all others.  Default 5: the Cout-32 outputs are written through
- *        instead of waiting dirty in the L2 for the end-of-kernel release (step -1.8 %; flat or worse on the other classes). */
+ * (round 3: the Cout-32 dense-block convs store their output `sc1`, written through -- measured with a run-time switch, now compile time.) */
 int dasr_set_tuning(int32_t key, int32_t value);
 
 /* ---- weight gradient ---------------------------------------------------------------------------
