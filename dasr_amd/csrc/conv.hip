@@ -982,15 +982,16 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
     const void* a_in = p.in.p;
     const void* a_w = p.w;
     long long a_nstr = p.in.n_stride, a_cbstr = p.in.cb_stride;
+    int a_wrap = p.in_wrap;
     asm volatile("" : "+s"(a_cout), "+s"(a_Wout), "+s"(a_Hout), "+s"(a_remap), "+s"(a_cin), "+s"(a_Hin), "+s"(a_Win), "+s"(a_bias), "+s"(a_in), "+s"(a_w),
-                 "+s"(a_nstr), "+s"(a_cbstr));
+                 "+s"(a_nstr), "+s"(a_cbstr), "+s"(a_wrap));
     const int cout_tiles = (a_cout + 31) >> 5;
     const int MG = (cout_tiles + MT - 1) / MT;
     const int tiles_x = (a_Wout + C::TW - 1) / C::TW, tiles_y = (a_Hout + C::TH - 1) / C::TH;
     int bid = blockIdx.x;
     {   // XCD-aware tile order as a select, not a branch: the whole prologue stays ONE basic block, so hipcc batches every kernel-argument
         // load into a single scalar-memory round trip at the top (three serialised round trips of ~0.4 us each before)
-        const int total = gridDim.x;
+        const int total = (int)((unsigned)a_remap >> 12);   // grid size from the launcher (gridDim.x is a hidden kernel argument: a second scalar-memory round trip)
         const int remapped = (bid & 7) * (total >> 3) + (bid >> 3);
         bid = ((a_remap & 1) && (total & 7) == 0) ? remapped : bid;
     }
@@ -1003,7 +1004,7 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
     const int oy0 = ty * C::TH, ox0 = tx * C::TW;
     const int iy0 = oy0 - 1, ix0 = ox0 - 1;
     const int nchunks = a_cin >> 4;
-    const int in_wrap = p.in_wrap > 0 ? p.in_wrap : 0x7fffffff;   // split 16-bit input: chunks >= in_wrap read the hi planes a second time
+    const int in_wrap = a_wrap > 0 ? a_wrap : 0x7fffffff;   // split 16-bit input: chunks >= in_wrap read the hi planes a second time
     constexpr int rot = 0;   // (per-workgroup chunk-order rotation was tried against L2 hot-spotting of the shared weight blocks: no effect)
     float bias_reg = 0.f;
     {
@@ -1473,8 +1474,10 @@ int launch_glds(const dasr_conv_params& p, hipStream_t s) {
     const int MG = (cout_tiles + MT - 1) / MT;
     const int tiles_x = (p.Wout + C::TW - 1) / C::TW, tiles_y = (p.Hout + C::TH - 1) / C::TH;
     const long long grid = (long long)MG * tiles_x * tiles_y * p.N;
-    if (grid <= 0 || grid > 0x7fffffffLL) return DASR_EINVAL;
-    DASR_LAUNCH_TAG(__PRETTY_FUNCTION__, kfn, dim3((unsigned)grid), dim3(NTHREADS), LDS, s, p);
+    if (grid <= 0 || grid >= (1LL << 20)) return DASR_EINVAL;
+    dasr_conv_params q = p;
+    q.xcd_remap = (p.xcd_remap & 0xfff) | (int)((unsigned)grid << 12);   // bits 12-31: the grid size (conv_glds_kernel reads it instead of gridDim.x)
+    DASR_LAUNCH_TAG(__PRETTY_FUNCTION__, kfn, dim3((unsigned)grid), dim3(NTHREADS), LDS, s, q);
     return (int)hipGetLastError();
 }
 
