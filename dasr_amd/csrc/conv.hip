@@ -139,7 +139,9 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
     const unsigned mask_cb = (unsigned)p.mask.cb_stride, r1_cb = (unsigned)p.res1.cb_stride, r2_cb = (unsigned)p.res2.cb_stride;
     const unsigned of_cb = (unsigned)p.out_f32.cb_stride, ob_cb = (unsigned)p.out_bf16.cb_stride;
     constexpr bool SC1 = MT == 1 && !IN_F32 && F16OUT == 0;   // bf16 dense-block convs with Cout = 32 (st128)
-    const unsigned lo_pl = (unsigned)p.out16_lo;   // split 16-bit output: the remainder goes lo_pl planes further (wave-uniform; 0 = plain)
+    // split 16-bit output: the remainder goes lo_pl planes further (wave-uniform; 0 = plain).  The specialised bf16 epilogues (dense blocks) do not
+    // carry the branch: classify_epi sends a bf16 split output to the generic epilogue
+    const unsigned lo_pl = (G || F16OUT != 0) ? (unsigned)p.out16_lo : 0u;
     f32x4 bia[MT][4];
     if (has_bias) {
         float* bl = (float*)smem;
@@ -977,14 +979,20 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
     TRACE_STAMP(0);
     // every kernel argument the prologue needs, fetched in ONE scalar-memory batch (hipcc otherwise sinks each s_load next to its first
     // use: three dependent ~0.4 us round trips before the first DMA could be issued); the empty asm pins the batch here
-    int a_cout = p.cout, a_Wout = p.Wout, a_Hout = p.Hout, a_remap = p.xcd_remap | (p.ups << 8), a_cin = p.cin, a_Hin = p.Hin, a_Win = p.Win;
+    int a_cout = p.cout, a_Wout = p.Wout, a_Hout = p.Hout, a_remap = p.xcd_remap, a_ups = p.ups, a_cin = p.cin, a_Hin = p.Hin, a_Win = p.Win;
     const void* a_bias = p.bias;
     const void* a_in = p.in.p;
     const void* a_w = p.w;
     long long a_nstr = p.in.n_stride, a_cbstr = p.in.cb_stride;
     int a_wrap = p.in_wrap;
+    // (the plain "s" inputs: what the EPILOGUE reads from the parameter block rides in the same batch -- its own scalar-memory round trip in front
+    // of the stores otherwise; ONE asm statement, or hipcc forms a second batch behind the first wait)
     asm volatile("" : "+s"(a_cout), "+s"(a_Wout), "+s"(a_Hout), "+s"(a_remap), "+s"(a_cin), "+s"(a_Hin), "+s"(a_Win), "+s"(a_bias), "+s"(a_in), "+s"(a_w),
-                 "+s"(a_nstr), "+s"(a_cbstr), "+s"(a_wrap));
+                 "+s"(a_nstr), "+s"(a_cbstr), "+s"(a_wrap), "+s"(a_ups)
+                 : "s"(p.slope), "s"(p.out_stride), "s"(p.out_oy), "s"(p.out_ox), "s"(p.out_W), "s"(p.alpha), "s"(p.gamma), "s"(p.out16_lo), "s"(p.N));
+    // (p.N is not needed: it keeps the fourth register of the {cout, Hout, Wout, N} load from being re-used by a later load of the batch, whose
+    // write-after-write hazard would bring the first wait back)
+    a_remap |= a_ups << 8;   // (no arithmetic on a loaded value IN FRONT of the asm: its wait would split the batch)
     const int cout_tiles = (a_cout + 31) >> 5;
     const int MG = (cout_tiles + MT - 1) / MT;
     const int tiles_x = (a_Wout + C::TW - 1) / C::TW, tiles_y = (a_Hout + C::TH - 1) / C::TH;
@@ -1544,7 +1552,7 @@ __global__ void conv_naive_kernel(const dasr_conv_params p, const float* w) {
 
 // compile-time epilogue variant of the hot dense-block cases (bit set: see conv_kernel's epilogue); 0 = generic
 int classify_epi(const dasr_conv_params& p) {
-    if ((p.cout & 31) || p.slope_ptr || p.act == 2 || p.out_stride > 1 || p.res1_lo) return 0;
+    if ((p.cout & 31) || p.slope_ptr || p.act == 2 || p.out_stride > 1 || p.res1_lo || (p.out16_lo && !p.out16_f16)) return 0;
     if (p.act == 1 && !(p.slope >= 0.f && p.slope <= 1.f)) return 0;   // the specialised epilogues use max(v, slope * v)
     int e = (p.bias ? 1 : 0) | (p.act == 1 ? 2 : 0) | (p.mask.p ? 4 : 0) | (p.res1.p ? 8 : 0) | (p.res2.p ? 16 : 0) | (p.out_f32.p ? 32 : 0) |
             (p.out_bf16.p ? 64 : 0);
