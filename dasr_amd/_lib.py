@@ -97,8 +97,8 @@ _SIGS = {
     'dasr_dwt_fwd': [Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, Tensor, c_vp],
     'dasr_dwt_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_vp],
     'dasr_lowpass': [Tensor, Tensor, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, Tensor, Tensor, c_i32, c_vp],
-    'dasr_maxpool2': [Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, c_vp],
-    'dasr_maxpool2_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_vp],
+    'dasr_maxpool2': [Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_vp],
+    'dasr_maxpool2_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_i32, c_vp],
     'dasr_l1_diff': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, Tensor, c_vp],
     'dasr_affine4': [Tensor, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, Tensor, c_i32, c_i32, c_vp],
     'dasr_bilinear_up': [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
@@ -141,7 +141,7 @@ _BENCH_SIGS = {
 }
 BENCH_LIB_PATH = os.path.join(HERE, 'libdasr_bench.so')
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 _lib = None
 _bench = None
 

@@ -569,7 +569,7 @@ __global__ void lowpass_kernel(dasr_tensor x, dasr_tensor x2, const float* __res
 // MaxPool2d(2,2) forward / backward (first maximum in scan order wins, like ATen), f32 or bf16 tensors
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void maxpool_fwd_kernel(dasr_tensor x, int N, int C, int Ho, int Wo, dasr_tensor y) {
+__global__ void maxpool_fwd_kernel(dasr_tensor x, int N, int C, int Ho, int Wo, dasr_tensor y, int Win) {
     const int ncb = (C + 15) >> 4;
     const long long total = (long long)N * ncb * Ho * Wo * 4;
     const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -580,7 +580,7 @@ __global__ void maxpool_fwd_kernel(dasr_tensor x, int N, int C, int Ho, int Wo, 
     const int yy = i % Ho; i /= Ho;
     const int cb = i % ncb;
     const int n = i / ncb;
-    const int W = 2 * Wo;
+    const int W = Win > 0 ? Win : 2 * Wo;   // row stride of the input: an odd input width drops its last column (nn.MaxPool2d floors)
     const T* xp = (const T*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + q * 4;
     T* yp = (T*)y.p + (size_t)n * y.n_stride + (size_t)cb * y.cb_stride + ((size_t)yy * Wo + xx) * 16 + q * 4;
     float m[4];
@@ -597,7 +597,7 @@ __global__ void maxpool_fwd_kernel(dasr_tensor x, int N, int C, int Ho, int Wo, 
 }
 
 template <typename T>
-__global__ void maxpool_bwd_kernel(dasr_tensor x, dasr_tensor gy, int N, int C, int Ho, int Wo, dasr_tensor gx, int relu_mask) {
+__global__ void maxpool_bwd_kernel(dasr_tensor x, dasr_tensor gy, int N, int C, int Ho, int Wo, dasr_tensor gx, int relu_mask, int Win) {
     const int ncb = (C + 15) >> 4;
     const long long total = (long long)N * ncb * Ho * Wo * 4;
     const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -608,7 +608,7 @@ __global__ void maxpool_bwd_kernel(dasr_tensor x, dasr_tensor gy, int N, int C, 
     const int yy = i % Ho; i /= Ho;
     const int cb = i % ncb;
     const int n = i / ncb;
-    const int W = 2 * Wo;
+    const int W = Win > 0 ? Win : 2 * Wo;   // row stride of the input: an odd input width drops its last column (nn.MaxPool2d floors)
     const T* xp = (const T*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + q * 4;
     const T* gp = (const T*)gy.p + (size_t)n * gy.n_stride + (size_t)cb * gy.cb_stride + ((size_t)yy * Wo + xx) * 16 + q * 4;
     T* op = (T*)gx.p + (size_t)n * gx.n_stride + (size_t)cb * gx.cb_stride + q * 4;
@@ -636,7 +636,7 @@ __global__ void maxpool_bwd_kernel(dasr_tensor x, dasr_tensor gy, int N, int C, 
 // the same on SPLIT 16-bit tensors (value = hi + lo, the lo planes follow the ncb hi planes: dasr_conv_params::in_wrap): the pair of the
 // first maximum is copied / its gradient pair routed, nothing is re-rounded
 template <typename T>
-__global__ void maxpool_fwd_split_kernel(dasr_tensor x, int N, int C, int Ho, int Wo, dasr_tensor y) {
+__global__ void maxpool_fwd_split_kernel(dasr_tensor x, int N, int C, int Ho, int Wo, dasr_tensor y, int Win) {
     const int ncb = (C + 15) >> 4;
     const long long total = (long long)N * ncb * Ho * Wo * 4;
     const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -647,7 +647,7 @@ __global__ void maxpool_fwd_split_kernel(dasr_tensor x, int N, int C, int Ho, in
     const int yy = i % Ho; i /= Ho;
     const int cb = i % ncb;
     const int n = i / ncb;
-    const int W = 2 * Wo;
+    const int W = Win > 0 ? Win : 2 * Wo;   // row stride of the input: an odd input width drops its last column (nn.MaxPool2d floors)
     const size_t xlo = (size_t)ncb * x.cb_stride, ylo = (size_t)ncb * y.cb_stride;
     const T* xp = (const T*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + q * 4;
     T* yp = (T*)y.p + (size_t)n * y.n_stride + (size_t)cb * y.cb_stride + ((size_t)yy * Wo + xx) * 16 + q * 4;
@@ -671,7 +671,7 @@ __global__ void maxpool_fwd_split_kernel(dasr_tensor x, int N, int C, int Ho, in
 
 // GSPLIT false: only the activations x are split, the gradients are plain 16-bit tensors
 template <typename T, bool GSPLIT>
-__global__ void maxpool_bwd_split_kernel(dasr_tensor x, dasr_tensor gy, int N, int C, int Ho, int Wo, dasr_tensor gx, int relu_mask) {
+__global__ void maxpool_bwd_split_kernel(dasr_tensor x, dasr_tensor gy, int N, int C, int Ho, int Wo, dasr_tensor gx, int relu_mask, int Win) {
     const int ncb = (C + 15) >> 4;
     const long long total = (long long)N * ncb * Ho * Wo * 4;
     const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -682,7 +682,7 @@ __global__ void maxpool_bwd_split_kernel(dasr_tensor x, dasr_tensor gy, int N, i
     const int yy = i % Ho; i /= Ho;
     const int cb = i % ncb;
     const int n = i / ncb;
-    const int W = 2 * Wo;
+    const int W = Win > 0 ? Win : 2 * Wo;   // row stride of the input: an odd input width drops its last column (nn.MaxPool2d floors)
     const size_t xlo = (size_t)ncb * x.cb_stride, glo = (size_t)ncb * gy.cb_stride, olo = (size_t)ncb * gx.cb_stride;
     const T* xp = (const T*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + q * 4;
     const T* gp = (const T*)gy.p + (size_t)n * gy.n_stride + (size_t)cb * gy.cb_stride + ((size_t)yy * Wo + xx) * 16 + q * 4;
@@ -1057,27 +1057,29 @@ extern "C" int dasr_lowpass(dasr_tensor x, dasr_tensor x2, const float* w, int32
     return (int)hipGetLastError();
 }
 
-extern "C" int dasr_maxpool2(dasr_tensor x, int32_t is_f32, int32_t N, int32_t C, int32_t Ho, int32_t Wo, dasr_tensor y, void* stream) {
+extern "C" int dasr_maxpool2(dasr_tensor x, int32_t is_f32, int32_t N, int32_t C, int32_t Ho, int32_t Wo, dasr_tensor y, int32_t Win, void* stream) {
+    if (Win != 0 && Win != 2 * Wo && Win != 2 * Wo + 1) return DASR_EINVAL;
     const long long total = (long long)N * ((C + 15) / 16) * Ho * Wo * 4;
     if (total <= 0) return DASR_EINVAL;
-    if (is_f32 == 3) DASR_LAUNCH(maxpool_fwd_split_kernel<f16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
-    else if (is_f32 == 4) DASR_LAUNCH(maxpool_fwd_split_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
-    else if (is_f32 == 2) DASR_LAUNCH(maxpool_fwd_kernel<f16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
-    else if (is_f32) DASR_LAUNCH(maxpool_fwd_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
-    else DASR_LAUNCH(maxpool_fwd_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y);
+    if (is_f32 == 3) DASR_LAUNCH(maxpool_fwd_split_kernel<f16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y, Win);
+    else if (is_f32 == 4) DASR_LAUNCH(maxpool_fwd_split_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y, Win);
+    else if (is_f32 == 2) DASR_LAUNCH(maxpool_fwd_kernel<f16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y, Win);
+    else if (is_f32) DASR_LAUNCH(maxpool_fwd_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y, Win);
+    else DASR_LAUNCH(maxpool_fwd_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, C, Ho, Wo, y, Win);
     return (int)hipGetLastError();
 }
 
 extern "C" int dasr_maxpool2_bwd(dasr_tensor x, dasr_tensor gy, int32_t is_f32, int32_t N, int32_t C, int32_t Ho, int32_t Wo, dasr_tensor gx,
-                                 int32_t relu_mask, void* stream) {
+                                 int32_t relu_mask, int32_t Win, void* stream) {
+    if (Win != 0 && Win != 2 * Wo && Win != 2 * Wo + 1) return DASR_EINVAL;
     const long long total = (long long)N * ((C + 15) / 16) * Ho * Wo * 4;
     if (total <= 0) return DASR_EINVAL;
-    if (is_f32 == 3) DASR_LAUNCH((maxpool_bwd_split_kernel<f16_t, true>), dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
-    else if (is_f32 == 4) DASR_LAUNCH((maxpool_bwd_split_kernel<bf16_t, true>), dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
-    else if (is_f32 == 5) DASR_LAUNCH((maxpool_bwd_split_kernel<f16_t, false>), dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
-    else if (is_f32 == 2) DASR_LAUNCH(maxpool_bwd_kernel<f16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
-    else if (is_f32) DASR_LAUNCH(maxpool_bwd_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
-    else DASR_LAUNCH(maxpool_bwd_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask);
+    if (is_f32 == 3) DASR_LAUNCH((maxpool_bwd_split_kernel<f16_t, true>), dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask, Win);
+    else if (is_f32 == 4) DASR_LAUNCH((maxpool_bwd_split_kernel<bf16_t, true>), dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask, Win);
+    else if (is_f32 == 5) DASR_LAUNCH((maxpool_bwd_split_kernel<f16_t, false>), dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask, Win);
+    else if (is_f32 == 2) DASR_LAUNCH(maxpool_bwd_kernel<f16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask, Win);
+    else if (is_f32) DASR_LAUNCH(maxpool_bwd_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask, Win);
+    else DASR_LAUNCH(maxpool_bwd_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, gy, N, C, Ho, Wo, gx, relu_mask, Win);
     return (int)hipGetLastError();
 }
 

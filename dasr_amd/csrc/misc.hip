@@ -662,8 +662,8 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream0) {
             case DASR_OP_LOWPASS:
                 rc = dasr_lowpass(o.t[0], o.t[1], (const float*)o.p[0], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], o.i[5], o.f[0], o.f[1], o.t[2], o.t[3], o.i[6], stream);
                 break;
-            case DASR_OP_MAXPOOL: rc = dasr_maxpool2(o.t[0], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1], stream); break;
-            case DASR_OP_MAXPOOL_BWD: rc = dasr_maxpool2_bwd(o.t[0], o.t[1], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], o.t[2], o.i[5], stream); break;
+            case DASR_OP_MAXPOOL: rc = dasr_maxpool2(o.t[0], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1], o.i[6], stream); break;   // i[6]: input width (0 = 2 * Wo)
+            case DASR_OP_MAXPOOL_BWD: rc = dasr_maxpool2_bwd(o.t[0], o.t[1], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], o.t[2], o.i[5], o.i[6], stream); break;
             case DASR_OP_L1DIFF:
                 rc = dasr_l1_diff(o.t[0], o.t[1], o.i[4], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.f[1], (float*)o.p[0], o.t[2], stream);
                 break;

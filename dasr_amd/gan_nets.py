@@ -502,6 +502,10 @@ def _nview_t(bt, n0):
 class _VGGPlan:
     def __init__(self, net, N, n_g, H, W):
         self.net, self.N, self.n_g = net, N, n_g
+        # EVERY tensor an op of this plan points at must stay referenced: the ops hold raw device pointers.  (Until round 3 the intermediate
+        # gradient tensors of the backward chain were locals of the builder: freed when it returned, their memory stayed untouched only as long as
+        # the caching allocator did not hand it out again -- the cause of a rare non-finite-gradient failure of the DSN fixtures.)
+        self._keep = []
         dev, P, pack = net.device, net.params, net.pack
         if net.f16s:
             return self._init_f16(N, n_g, H, W)
@@ -528,6 +532,7 @@ class _VGGPlan:
                 out = BTensor(N, cout, h, w, True, dev)
                 o = _op(_lib.OP_MAXPOOL)
                 o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[1] = src.view(), N, cout, h, w, 1, out.view()
+                o.i[6] = src.W   # input width (odd widths: the last column is dropped)
                 fwd.add(o)
             self.outs.append(out)
             src = out
@@ -549,6 +554,7 @@ class _VGGPlan:
             kind, idx, cin, cout, relu = net.layers[li]
             inp = self.x if li == 0 else self.outs[li - 1]
             gin = self.gx if li == 0 else BTensor(N, inp.C, inp.H, inp.W, True, dev)
+            self._keep.append(gin)
             if kind == 'conv':
                 prev_relu = li > 0 and net.layers[li - 1][0] == 'conv' and net.layers[li - 1][4]
                 bwd.add(conv_op(pack, net.pk[(idx, 'b')], g.view(), True, cout, inp.H, inp.W, inp.H, inp.W, n,
@@ -556,6 +562,7 @@ class _VGGPlan:
             else:
                 o = _op(_lib.OP_MAXPOOL_BWD)
                 o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.t[2] = inp.view(), g.view(), n, cout, g.H, g.W, 1, 1, gin.view()
+                o.i[6] = inp.W
                 bwd.add(o)
             g = gin
         self.bwd = bwd
@@ -581,8 +588,11 @@ class _VGGPlan:
         net = self.net
         dev, P, pack = net.device, net.params, net.pack
         c16 = lambda c: ceil_div(c, 16) * 16
-        Bs = lambda C_, h, w: BTensor(N, 2 * c16(C_), h, w, False, dev, f16=True)   # planes [0, K) hi, [K, 2K) lo
-        Bf = lambda C_, h, w: BTensor(N, C_, h, w, True, dev)
+        def kept(t):
+            self._keep.append(t)
+            return t
+        Bs = lambda C_, h, w: kept(BTensor(N, 2 * c16(C_), h, w, False, dev, f16=True))   # planes [0, K) hi, [K, 2K) lo
+        Bf = lambda C_, h, w: kept(BTensor(N, C_, h, w, True, dev))
         self.x_flag = 3
         self.x = Bs(16, H, W)
         self.outs = []
@@ -611,6 +621,7 @@ class _VGGPlan:
                 out = Bf(cout, h, w) if li > lc else Bs(cout, h, w)
                 o = _op(_lib.OP_MAXPOOL)
                 o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[1] = src.view(), N, cout, h, w, (1 if li > lc else 3), out.view()
+                o.i[6] = src.W   # input width (odd widths: the last column is dropped)
                 fwd.add(o)
             self.outs.append(out)
             src = out
@@ -625,7 +636,7 @@ class _VGGPlan:
         bwd = OpList()
         g = self.g_feat
         gsplit = net.bwd_prec == 5
-        Bg = Bs if gsplit else (lambda C_, h_, w_: BTensor(N, C_, h_, w_, False, dev, f16=True))
+        Bg = Bs if gsplit else (lambda C_, h_, w_: kept(BTensor(N, C_, h_, w_, False, dev, f16=True)))
         for li in range(nl - 1, -1, -1):
             kind, idx, cin, cout, relu = net.layers[li]
             inp = self.x if li == 0 else self.outs[li - 1]
@@ -654,6 +665,7 @@ class _VGGPlan:
                 gin = Bf(cout, inp.H, inp.W) if f32 else Bg(cout, inp.H, inp.W)
                 o = _op(_lib.OP_MAXPOOL_BWD)
                 o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.t[2] = inp.view(), g.view(), n, cout, g.H, g.W, (1 if f32 else (3 if gsplit else 5)), 1, gin.view()
+                o.i[6] = inp.W
                 bwd.add(o)
             g = gin
         self.bwd = bwd
@@ -665,8 +677,11 @@ class _VGGPlan:
         import math
         net = self.net
         dev, P, pack = net.device, net.params, net.pack
-        Bh = lambda C_, h, w: BTensor(N, C_, h, w, False, dev, f16=True)
-        Bf = lambda C_, h, w: BTensor(N, C_, h, w, True, dev)
+        def kept(t):
+            self._keep.append(t)
+            return t
+        Bh = lambda C_, h, w: kept(BTensor(N, C_, h, w, False, dev, f16=True))
+        Bf = lambda C_, h, w: kept(BTensor(N, C_, h, w, True, dev))
         self.x_flag = 2
         self.x = Bh(16, H, W)
         self.outs = []
@@ -686,6 +701,7 @@ class _VGGPlan:
                 out = Bf(cout, h, w) if li > lc else Bh(cout, h, w)
                 o = _op(_lib.OP_MAXPOOL)
                 o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[1] = src.view(), N, cout, h, w, (1 if li > lc else 2), out.view()
+                o.i[6] = src.W   # input width (odd widths: the last column is dropped)
                 fwd.add(o)
             self.outs.append(out)
             src = out
@@ -722,6 +738,7 @@ class _VGGPlan:
                 gin = Bf(inp.C, inp.H, inp.W) if f32 else Bh(inp.C, inp.H, inp.W)
                 o = _op(_lib.OP_MAXPOOL_BWD)
                 o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.i[5], o.t[2] = inp.view(), g.view(), n, cout, g.H, g.W, (1 if f32 else 2), 1, gin.view()
+                o.i[6] = inp.W
                 bwd.add(o)
             g = gin
         self.bwd = bwd

@@ -84,6 +84,16 @@ class AdamHIP:
             if os.environ.get('DASR_HIP_LIB'):   # instrumented / ablation builds compute wrong results on purpose (scripts/, timing only)
                 return
             P = self.params
+            if os.environ.get('DASR_DBG_DUMP'):   # debugging aid: which plan tensors hold non-finite values right now
+                import gc
+                for o in gc.get_objects():
+                    if type(o).__name__.endswith('Plan'):
+                        for k, t in list(vars(o).items()):
+                            for i, x in enumerate(t if isinstance(t, (list, tuple)) else [t]):
+                                tt = getattr(x, 't', None)
+                                if torch.is_tensor(tt) and tt.is_floating_point() and not bool(torch.isfinite(tt.float()).all()):
+                                    nf = (~torch.isfinite(tt.float())).nonzero()
+                                    print('[dbg] %s.%s[%d] %s %s: %d non-finite, first at %s' % (type(o).__name__, k, i, tuple(tt.shape), tt.dtype, len(nf), nf[0].tolist()))
             bad = [k for k in P.spec if not bool(torch.isfinite(P.view(k, P.grad)).all())][:6]   # (the last step's gradients; error path only)
             raise FloatingPointError('inf / NaN in the %s gradients (the weights have absorbed it)%s.  The HR tail stores activations and gradients in f16 '
                                      'with a power-of-two pre-scale sized for mean losses of weight ~1: very large loss weights or activations above '

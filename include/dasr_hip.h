@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DASR_ABI_VERSION 11
+#define DASR_ABI_VERSION 12
 #define DASR_EINVAL (-22)
 
 typedef struct {
@@ -275,12 +275,13 @@ int dasr_dwt_bwd(dasr_tensor gll, dasr_tensor ghc, int32_t N, int32_t C, int32_t
  * with x = dL/dlow, x2 = dL/dhigh (either may be null). */
 int dasr_lowpass(dasr_tensor x, dasr_tensor x2, const float* w, int32_t k, int32_t N, int32_t C, int32_t H, int32_t W,
                  int32_t mode, float a_h, float b_h, dasr_tensor out_low, dasr_tensor out_high, int32_t accumulate, void* stream);
-/* nn.MaxPool2d(2,2) of the VGG19 feature stack, forward and backward (Ho, Wo = pooled size); is_f32: 0 bf16, 1 f32, 2 f16 tensors; 3 / 4: split f16 / bf16 tensors (C channels in 2 * ceil(C/16) planes: hi planes, then lo planes);
+/* nn.MaxPool2d(2,2) of the VGG19 feature stack, forward and backward (Ho, Wo = pooled size; Win = width of the INPUT: 2 Wo or 2 Wo + 1 --
+ * an odd input drops its last row / column as nn.MaxPool2d's floor does; 0 = 2 Wo.  Round 3: before, odd inputs were mis-addressed); is_f32: 0 bf16, 1 f32, 2 f16 tensors; 3 / 4: split f16 / bf16 tensors (C channels in 2 * ceil(C/16) planes: hi planes, then lo planes);
  * backward only: 5 = split f16 activations x, plain f16 gradients */
-int dasr_maxpool2(dasr_tensor x, int32_t is_f32, int32_t N, int32_t C, int32_t Ho, int32_t Wo, dasr_tensor y, void* stream);
+int dasr_maxpool2(dasr_tensor x, int32_t is_f32, int32_t N, int32_t C, int32_t Ho, int32_t Wo, dasr_tensor y, int32_t Win, void* stream);
 /* relu_mask: also zero the gradient where the pooled maximum is <= 0 (the ReLU' of the conv feeding the pool) */
 int dasr_maxpool2_bwd(dasr_tensor x, dasr_tensor gy, int32_t is_f32, int32_t N, int32_t C, int32_t Ho, int32_t Wo, dasr_tensor gx,
-                      int32_t relu_mask, void* stream);
+                      int32_t relu_mask, int32_t Win, void* stream);
 /* L1 between two blocked tensors (feature loss DASR_model.py:224-229; LL loss :220-222): loss_acc += coef*sum|a-b|,
  * ga = gcoef*sign(a-b).  is_f32 bit 1 set: squared form (MSE of the DSN VGG16 perceptual loss, loss.py:119-130). */
 int dasr_l1_diff(dasr_tensor a, dasr_tensor b, int32_t is_f32, int32_t N, int32_t C, int32_t H, int32_t W, float coef, float gcoef,

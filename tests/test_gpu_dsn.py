@@ -53,10 +53,11 @@ def _check_grads(got, want, tag):
         r = rel(gv, wv)
         worst = max(worst, r)
         assert r < GRAD_TOL, (tag, k, r)
+    rs = 0.0
     if sg:
-        r = rel(torch.cat(sg), torch.cat(sw))
-        assert r < GRAD_TOL, (tag, 'prelu slopes', r)
-    return worst
+        rs = rel(torch.cat(sg), torch.cat(sw))
+        assert rs < GRAD_TOL, (tag, 'prelu slopes', rs)
+    return worst, rs
 
 
 @pytest.mark.parametrize('kh,stride,cin,cout,hw', [(5, 1, 3, 64, (19, 33)), (5, 1, 64, 128, (20, 24)), (1, 1, 256, 1, (13, 17)),
@@ -204,16 +205,17 @@ def test_deresnet_forward_backward():
     p.g_fake.t.copy_(to_blocked(gy, dev).t)
     (y * gy).sum().backward()
     p.bwd.run()
-    worst = _check_grads(G.params.grad_dict(), [p.grad for p in ref.parameters()], 'G')
-    print('De_resnet worst grad rel err %.2e' % worst)
+    worst, slopes = _check_grads(G.params.grad_dict(), [p.grad for p in ref.parameters()], 'G')
+    print('De_resnet worst grad rel err %.2e, PReLU slopes %.2e' % (worst, slopes))
 
 
 @pytest.mark.parametrize('case', ['dsn_gau5_inst_b2_128', 'dsn_wavelet_inst_b2_128', 'dsn_avg5_inst_b1_160', 'dsn_gau5_inst_b1_256_lpips',
                                   'dsn_wavelet_nld_s2_b2_128', 'dsn_gau5_nld_s1_b1_128', 'dsn_dsgan_gau5_inst_b2_128', 'dsn_gau5_inst_b3_128_ragan',
                                   'dsn_gau5_batch_b2_128', 'dsn_avg5_batch_b3_128_ragan', 'dsn_wavelet_sum_inst_b2_128',
                                   'dsn_gau5_inst_b2_128+fwd16', 'dsn_dsgan_gau5_inst_b2_128+fwd16'])
-def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir, monkeypatch):
+def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir, monkeypatch, margins):
     dev = _gpu()
+    case_id = case
     if case.endswith('+fwd16'):   # the opt-in forward on split f16 tensors (dsn_model.DeResnetHIP.fwd16)
         case = case[:-6]
         monkeypatch.setenv('DASR_DSN_FWD16', '1')
@@ -255,15 +257,18 @@ def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir, mo
             assert rel(m.fake.cpu(), t.fake) < ACT_TOL
             np.testing.assert_allclose(fixtures.subsample(m.fake.cpu()).numpy(), gold['fake_sub'], rtol=0, atol=2e-4)
             gd, dd = m.netG.params.grad_dict(), m.netD.params.grad_dict()
-            _check_grads(gd, [p.grad for p in G.parameters()], 'G')
+            wg_, ws_ = _check_grads(gd, [p.grad for p in G.parameters()], 'G')
+            e_fake = rel(m.fake.cpu(), t.fake)
             dpar = dict((k, v) for k, v in dd.items() if 'gaussian_filter' not in k)
             dwant = [p.grad for p in D.parameters() if p.requires_grad]
             if c.get('ragan'):   # relativistic logits: a constant shift of every logit changes nothing -> the true gradient of the last bias is 0
                 k_last = list(dpar)[-1]
                 assert k_last.endswith('bias') and float(dpar[k_last].abs().max()) < 1e-5 and float(dwant[-1].abs().max()) < 1e-5   # rounding noise of sums of O(1) terms
-                _check_grads(dict(list(dpar.items())[:-1]), dwant[:-1], 'D')
+                wd_, _ = _check_grads(dict(list(dpar.items())[:-1]), dwant[:-1], 'D')
             else:
-                _check_grads(dpar, dwant, 'D')
+                wd_, _ = _check_grads(dpar, dwant, 'D')
+            margins('DSN iteration %s: fake rel err %.2e (tol %.0e); worst gradient rel err G %.2e, G PReLU slopes (jointly) %.2e, D %.2e (tol %.0e)'
+                    % (case_id, e_fake, ACT_TOL, wg_, ws_, wd_, GRAD_TOL))
             big = np.array([v.numel() > 1 for v in gd.values()])
             np.testing.assert_allclose(np.array([float(v.double().norm()) for v in gd.values()])[big], gold['gradG_norm'][big], rtol=GRAD_TOL)
             np.testing.assert_allclose(np.array([float(v.double().norm()) for v in dpar.values()]), gold['gradD_norm'], rtol=GRAD_TOL, atol=1e-5 if c.get('ragan') else 1e-6)
