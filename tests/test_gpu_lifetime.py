@@ -81,6 +81,23 @@ def test_dasr_trainer_plans_keep_their_tensors(margins):
     margins('plan lifetime check (DASR trainer, VGG criterion): %d device pointers in the recorded ops, all inside live tensors' % n)
 
 
+def test_sr_trainer_plans_keep_their_tensors():
+    """the L1 trainer (two sub-batch streams, deferred grouped weight gradients, TrunkStore views) and its inference plan"""
+    _gpu()
+    from oracle import fixtures
+    from dasr_amd import options
+    from dasr_amd.models import create_model
+    case = 'sr_nf64_nb2_b8_32'
+    opt = fixtures.make_opt(case)
+    opt['gpu_ids'] = [0]
+    m = create_model(options.dict_to_nonedict(opt))
+    m.feed_data(fixtures.make_batch(case))
+    m.optimize_parameters(1)
+    m.test()
+    torch.cuda.synchronize()
+    _check_all_plans('SR')
+
+
 @pytest.mark.parametrize('per', ['VGG', 'LPIPS'])
 def test_dsn_model_plans_keep_their_tensors(per):
     _gpu()
