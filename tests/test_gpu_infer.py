@@ -43,8 +43,9 @@ def _json_opt(tmp_path, name, is_train, extra=None):
     return str(p)
 
 
+@pytest.mark.parametrize('hw', [(52, 44), (53, 47)], ids=['52x44', '53x47_odd'])
 @pytest.mark.parametrize('chop', [False, True])
-def test_inference_matches_oracle(chop):
+def test_inference_matches_oracle(chop, hw):
     dev = _gpu()
     from oracle import fixtures, nets, util_ref
     from dasr_amd import options
@@ -58,8 +59,9 @@ def test_inference_matches_oracle(chop):
     net.load_state_dict(sd)
     m.netG.load_state_dict(sd)
     g = torch.Generator().manual_seed(8)
-    x = torch.rand(1, 3, 52, 44, generator=g)
-    m.feed_data({'LR': x, 'HR': torch.rand(1, 3, 208, 176, generator=g)}, False)
+    H, W = hw
+    x = torch.rand(1, 3, H, W, generator=g)
+    m.feed_data({'LR': x, 'HR': torch.rand(1, 3, 4 * H, 4 * W, generator=g)}, False)
     m.test()
     with torch.no_grad():
         want = util_ref.forward_chop(x, 4, net, shave=20, min_size=320000) if chop else net(x)
@@ -67,7 +69,7 @@ def test_inference_matches_oracle(chop):
     assert tuple(got.shape) == tuple(want.shape)
     assert rel(got, want) < 1e-3, rel(got, want)
     vis = m.get_current_visuals()
-    assert set(vis) >= {'LR', 'SR', 'HR'} and tuple(vis['SR'].shape) == (3, 208, 176)
+    assert set(vis) >= {'LR', 'SR', 'HR'} and tuple(vis['SR'].shape) == (3, 4 * H, 4 * W)
 
 
 def test_training_driver_validates_and_eval_cli_reports_metrics(tmp_path):
