@@ -28,17 +28,44 @@ def rnd(x, fmt, scale=1.0):
     raise ValueError(fmt)
 
 
+_BT = torch.tensor([[1., 0., -1., 0.], [0., 1., 1., 0.], [0., -1., 1., 0.], [0., 1., 0., -1.]])
+_G = torch.tensor([[1., 0., 0.], [.5, .5, .5], [.5, -.5, .5], [0., 0., 1.]])
+_AT = torch.tensor([[1., 1., 1., 0.], [0., 1., -1., -1.]])
+
+
+def winograd_conv(x, w, op_fmt='bf16'):
+    """3x3 / pad 1 conv as Winograd F(2x2, 3x3) with the rounding an MFMA implementation would have: the operands arrive in bf16 (storage), the
+    TRANSFORMED input tiles B^T d B and weights G g G^T are rounded to `op_fmt` again (they are what the matrix cores multiply), products and the
+    output transform A^T m A stay in fp32.  ('emulate the transform rounding ... if gradients stay < 1e-2 build a micro-kernel')"""
+    N, C_, H, W = x.shape
+    K = w.shape[0]
+    assert H % 2 == 0 and W % 2 == 0
+    xp = F.pad(rnd(x, 'bf16'), (1, 1, 1, 1))
+    d = xp.unfold(2, 4, 2).unfold(3, 4, 2)                               # [N, C, H/2, W/2, 4, 4]
+    V = rnd(torch.einsum('ij,nchwjk,lk->nchwil', _BT, d, _BT), op_fmt)
+    U = rnd(torch.einsum('ij,kcjl,ml->kcim', _G, rnd(w, 'bf16'), _G), op_fmt)
+    M = torch.einsum('kcim,nchwim->nkhwim', U, V)
+    Y = torch.einsum('ai,nkhwim,bm->nkhwab', _AT, M, _AT)                # [N, K, H/2, W/2, 2, 2]
+    return Y.permute(0, 1, 2, 4, 3, 5).reshape(N, K, H, W)
+
+
 class RConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, fx, fw, fg):
         ctx.save_for_backward(x, w)
         ctx.f = (fx, fw, fg)
+        if fx == 'wino':   # Winograd on bf16 operands (forward and data gradient), direct bf16 weight gradient
+            return winograd_conv(x, w) + b.view(1, -1, 1, 1)
         return F.conv2d(rnd(x, fx), rnd(w, fw), b, 1, 1)
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         fx, fw, fg = ctx.f
+        if fx == 'wino':
+            gx = winograd_conv(g, w.transpose(0, 1).flip(2, 3))
+            gw = torch.nn.grad.conv2d_weight(rnd(x, 'bf16'), w.shape, rnd(g, 'bf16'), 1, 1)
+            return gx, gw, g.sum((0, 2, 3)), None, None, None
         gs = 2.0 ** 24 if fg == 'f16' else 1.0
         gr = rnd(g, fg, gs)
         gx = torch.nn.grad.conv2d_input(x.shape, rnd(w, fw), gr, 1, 1)
@@ -96,7 +123,9 @@ def main():
     S3, BF = ('bf16x2', 'bf16x2', 'bf16x2'), ('bf16', 'bf16', 'bf16')
     F16 = ('f16', 'f16', 'f16')
     F16X = ('f16', 'bf16x2', 'f16')      # activations / gradients rounded once to f16, weights exact (2 MFMA passes)
+    WINO = ('wino', 'wino', 'wino')
     recipes = {
+        'W  rdb WINOGRAD F(2x2,3x3) on bf16 (transformed operands re-rounded to bf16) | others as A': dict(rdb=WINO, fea=S3, lr=S3, up=S3, hr0=S3, hr1=S3),
         'A  rdb bf16 | fea lr up hr0 hr1 split-bf16 (round 1)': dict(rdb=BF, fea=S3, lr=S3, up=S3, hr0=S3, hr1=S3),
         'E  rdb bf16 | fea lr hr1 split | up hr0 f16 1-pass': dict(rdb=BF, fea=S3, lr=S3, up=F16, hr0=F16, hr1=S3),
         'E2 rdb bf16 | fea lr hr1 split | up hr0 f16 x exact-w 2-pass': dict(rdb=BF, fea=S3, lr=S3, up=F16X, hr0=F16X, hr1=S3),
