@@ -46,7 +46,7 @@ def _check_all_plans(tag):
             if o.op == _lib.OP_CONV:
                 c = o.conv
                 ptrs += [c.inp.p, c.mask.p, c.res1.p, c.res2.p, c.out_f32.p, c.out_bf16.p, c.w, c.bias, c.slope_ptr]
-            if o.op in (_lib.OP_WGRAD, _lib.OP_WGRAD_REDUCE, _lib.OP_PACK, _lib.OP_L1LOSS, _lib.OP_PRELU_GRAD, _lib.OP_NCHW2B, _lib.OP_B2NCHW):
+            if o.op not in (_lib.OP_EVENT_RECORD, _lib.OP_STREAM_WAIT, _lib.OP_SET_STREAM):   # (those carry host-side event / stream handles)
                 ptrs += [o.p[j] for j in range(4)]
             for p in ptrs:
                 if p:
