@@ -53,6 +53,14 @@ def _check_all_plans(tag):
                     n_ptr += 1
                     if not _inside(iv, int(p)):
                         bad.append((k, o.op, hex(int(p))))
+        for grp in ol.keep:   # weight-gradient groups: the part descriptors (copied into a device table) point at gradient / input tensors
+            for entry in getattr(grp, 'parts', []):
+                wp = entry[0]
+                for p in (wp.g.p, wp.inp.p):
+                    if p:
+                        n_ptr += 1
+                        if not _inside(iv, int(p)):
+                            bad.append(('wgrad part', type(grp).__name__, hex(int(p))))
     assert n_ptr > 50, (tag, n_ptr)
     assert not bad, (tag, len(bad), bad[:8])
     return n_ptr
