@@ -71,3 +71,18 @@ def test_haar_invariants():
     # perfect reconstruction of the top-left sample: a = (LL+LH+HL+HH)/2
     a = (ll + hc[:, 0:3] + hc[:, 3:6] + hc[:, 6:9]) * 0.5
     assert torch.allclose(a, x[:, :, 0::2, 0::2], atol=1e-6)
+
+
+def test_precision_probe_winograd_emulation_is_a_convolution():
+    """oracle/precision_probe.py::winograd_conv (the F(2x2,3x3) emulation behind the Winograd precision figure in DESIGN 4.8): with exact
+    transforms it must equal the direct 3x3 / pad 1 convolution of the bf16-rounded operands; with re-rounded transformed operands it must stay
+    within a few bf16 ulps of it"""
+    import torch
+    import torch.nn.functional as F
+    from oracle.precision_probe import winograd_conv
+    g = torch.Generator().manual_seed(0)
+    x, w = torch.randn(2, 8, 8, 12, generator=g), torch.randn(5, 8, 3, 3, generator=g)
+    ref = F.conv2d(x.bfloat16().float(), w.bfloat16().float(), None, 1, 1)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    assert rel(winograd_conv(x, w, 'f32'), ref) < 1e-6
+    assert 1e-4 < rel(winograd_conv(x, w, 'bf16'), ref) < 1e-2
