@@ -359,7 +359,7 @@ class DSNModel:
     def __init__(self, opt=None, device=None, **kw):
         o = dict(n_res_blocks=8, kernel_size=5, filter='gau', norm_layer='Instance', discriminator='FSD', generator='DeResnet', learning_rate=1e-4,
                  adam_beta_1=0.5, w_col=1.0, w_tex=0.005, w_per=0.01, per_type='VGG', vgg_path=None, vgg_seed=78, num_epochs=400,
-                 num_decay_epochs=150, upscale_factor=4, ragan=False, allow_random_perceptual=False, cat_or_sum='cat')
+                 num_decay_epochs=150, upscale_factor=4, ragan=False, allow_random_perceptual=False, cat_or_sum='cat', disc_freq=1, gen_freq=1)
         o.update(opt or {})
         o.update(kw)
         self.opt = o
@@ -393,6 +393,11 @@ class DSNModel:
                                             '--allow_random_perceptual to train against a seeded random network')
             else:
                 raise NotImplementedError('{} is not recognized'.format(o['per_type']))
+        # --disc_freq / --gen_freq (codes/DSN/train.py:55-56, 206, 229, 251): the counter advances at the top of an iteration, a network steps when
+        # the counter is a multiple of its frequency (forward, losses and BatchNorm running statistics happen every iteration)
+        self.disc_freq, self.gen_freq = int(o['disc_freq']), int(o['gen_freq'])
+        if self.disc_freq < 1 or self.gen_freq < 1:
+            raise ValueError('disc_freq / gen_freq must be >= 1')
         self.ragan = bool(o['ragan'])   # --ragan (train.py:221-223): D(x, y) = sigmoid(D(x) - mean_n D(y)) (model.py:98-106)
         self.filter = o['filter'].lower()
         if self.filter not in ('gau', 'avg_pool', 'wavelet'):
@@ -494,22 +499,28 @@ class DSNModel:
         if self.bn:     # BatchNorm running statistics, one update per discriminator call of the reference (train.py:221-226)
             P.d_running.run()
             self._d_eval_stale = True
-        P.d_bwd.run()   # D weight gradients (pre-update graph)
-        if rg_dp:       # generator's relativistic texture loss: stage 1 (sums still valid) -> all-reduce -> stage 2, then the backward chain
+        self.iteration_count += 1   # (train.py:206: before the frequency checks)
+        upd_d, upd_g = self.iteration_count % self.disc_freq == 0, self.iteration_count % self.gen_freq == 0
+        if upd_d:
+            P.d_bwd.run()   # D weight gradients (pre-update graph)
+        if upd_g and rg_dp:   # generator's relativistic texture loss: stage 1 (sums still valid) -> all-reduce -> stage 2, then the backward chain
             P.g_bwd.run(0, P.ragan_cut_gbwd)
             self.dp.all_reduce_here(P.r_part)
             P.g_bwd.run(P.ragan_cut_gbwd)
-        else:
+        elif upd_g:
             P.g_bwd.run()   # texture gradient through D's data path, colour adjoint, G backward
         if self.dp is not None and self.dp.active:
-            self.dp.allreduce_mean(self.netD.params.grad)
-            self.dp.allreduce_mean(self.netG.params.grad)
+            if upd_d:
+                self.dp.allreduce_mean(self.netD.params.grad)
+            if upd_g:
+                self.dp.allreduce_mean(self.netG.params.grad)
         lr = self.lr()
-        self.opt_d.step(lr)
-        self.netD.repack()
-        self.opt_g.step(lr)
-        self.netG.repack()
-        self.iteration_count += 1
+        if upd_d:
+            self.opt_d.step(lr)
+            self.netD.repack()
+        if upd_g:
+            self.opt_g.step(lr)
+            self.netG.repack()
         self.fake = P.g.fake_nchw
         self._pending = True
 

@@ -86,8 +86,8 @@ def check_supported(o, have_loader=True):
         raise NotImplementedError('--wgan needs a gradient penalty (train.py:231-236: a second-order pass through D); not on the MI355X path')
     if not o.highpass or o.cat_or_sum not in ('cat', 'sum') or o.norm_layer not in ('Instance', 'Batch') or (o.norm_layer == 'Batch' and o.discriminator.lower() != 'fsd'):
         raise NotImplementedError('DSN on MI355X covers: high-pass front end, wavelet bands cat, Instance norm (FSD also Batch norm)')
-    if o.disc_freq != 1 or o.gen_freq != 1:
-        raise NotImplementedError('disc_freq / gen_freq other than 1')
+    if o.disc_freq < 1 or o.gen_freq < 1:
+        raise ValueError('--disc_freq / --gen_freq must be >= 1')
 
 
 class SyntheticCrops:

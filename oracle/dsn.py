@@ -191,8 +191,12 @@ class DSNTrainer:
     """one training iteration of codes/DSN/train.py:204-285 (non-wgan; `ragan`: the relativistic discriminator calls of :221-223)"""
 
     def __init__(self, netG=None, netD=None, lr=1e-4, beta1=0.5, w_col=1.0, w_tex=0.005, w_per=0.01, per_type='VGG',
-                 kernel_size=5, filter_type='gau', norm_layer='Instance', vgg_seed=78, num_epochs=400, num_decay_epochs=150, netF=None, ragan=False):
+                 kernel_size=5, filter_type='gau', norm_layer='Instance', vgg_seed=78, num_epochs=400, num_decay_epochs=150, netF=None, ragan=False,
+                 disc_freq=1, gen_freq=1):
         self.ragan = ragan
+        # --disc_freq / --gen_freq (train.py:55-56): `iteration += 1` at the top of the loop body (:206), the discriminator steps when
+        # iteration % disc_freq == 0 (:229), the generator when iteration % gen_freq == 0 (:251)
+        self.disc_freq, self.gen_freq, self.iteration_count = int(disc_freq), int(gen_freq), 0
         self.G = netG if netG is not None else DeResnet()
         self.D = netD if netD is not None else Discriminator(kernel_size, norm_layer, filter_type)
         self.w_col, self.w_tex, self.w_per = w_col, w_tex, w_per
@@ -232,16 +236,20 @@ class DSNTrainer:
         if self.per is not None:
             per = F.mse_loss(self.per(fake), self.per(bicubic_lr))
             g_loss = g_loss + self.w_per * per
+        self.iteration_count += 1
+        upd_d, upd_g = self.iteration_count % self.disc_freq == 0, self.iteration_count % self.gen_freq == 0
         d_params = [p for p in self.D.parameters() if p.requires_grad]
         g_params = list(self.G.parameters())
-        gd = torch.autograd.grad(d_loss, d_params, retain_graph=True)
-        gg = torch.autograd.grad(g_loss, g_params)
-        for p, g in zip(d_params, gd):
-            p.grad = g
-        for p, g in zip(g_params, gg):
-            p.grad = g
-        self.opt_d.step()
-        self.opt_g.step()
+        gd = torch.autograd.grad(d_loss, d_params, retain_graph=True) if upd_d else None
+        gg = torch.autograd.grad(g_loss, g_params) if upd_g else None
+        if upd_d:
+            for p, g in zip(d_params, gd):
+                p.grad = g
+            self.opt_d.step()
+        if upd_g:
+            for p, g in zip(g_params, gg):
+                p.grad = g
+            self.opt_g.step()
         self.fake = fake.detach()
         self.log.update({'loss/d_tex_loss': d_loss.item(), 'loss/g_tex_loss': tex.item(), 'loss/color_loss': col.item(),
                          'loss/perceptual_loss': per.item(), 'loss/g_overall_loss': g_loss.item(),

@@ -404,3 +404,47 @@ def test_fsd_batch_discriminator_matches_reference_test_tar(golden_dir, margins)
     assert int(sd1['net.net.3.num_batches_tracked']) == int(sd0['net.net.3.num_batches_tracked']) + 2
     assert not torch.equal(sd1['net.net.2.weight'], sd0['net.net.2.weight']) and not torch.equal(sd1['net.net.3.running_mean'], sd0['net.net.3.running_mean'])
     assert all(torch.isfinite(v.float()).all() for v in sd1.values())
+
+
+def test_dsn_update_frequencies_follow_the_reference_loop():
+    """--disc_freq 2 --gen_freq 3 (codes/DSN/train.py:55-56, 206, 229, 251): the iteration counter advances first; D steps on iterations 2 and 4, G on
+    iteration 3; forward and losses run every iteration.  Checked against the oracle loop: which network moved when, and the weights after four
+    iterations (Adam: a weight moves by <= lr per step)."""
+    dev = _gpu()
+    torch.set_num_threads(8)
+    from dasr_amd.dsn_model import DSNModel
+    from oracle import dsn
+    from oracle.gen_golden_dsn import dsn_state, dsn_batch
+    G, D = dsn.DeResnet(), dsn.Discriminator(5, 'Instance', 'gau')
+    sdG, sdD = dsn_state(G.state_dict(), 21, 0.5), dsn_state(D.state_dict(), 22, 1.0)
+    G.load_state_dict(sdG)
+    D.load_state_dict(sdD)
+    t = dsn.DSNTrainer(G, D, kernel_size=5, filter_type='gau', vgg_seed=78, w_per=0.0, disc_freq=2, gen_freq=3)
+    m = DSNModel(dict(filter='gau', kernel_size=5, w_per=0.0, disc_freq=2, gen_freq=3), device=dev)
+    m.netG.load_state_dict(sdG)
+    m.load_discriminator_state(sdD)
+    hr, bic, real = dsn_batch(dict(n=2, crop=64))
+    snap = lambda net: {k: v.clone() for k, v in net.state_dict().items() if 'gaussian_filter' not in k}
+    same = lambda a, b: all(torch.equal(a[k].cpu(), b[k].cpu()) for k in a)
+    g_prev, d_prev = snap(m.netG), snap(m.netD)
+    moved = []
+    for it in (1, 2, 3, 4):
+        t.iteration(hr, bic, real)
+        m.iteration(hr.to(dev), bic.to(dev), real.to(dev))
+        log = m.get_current_log()
+        for k, ref_v in t.log.items():
+            if k in ('loss/g_tex_loss', 'loss/g_overall_loss') and it % 3:
+                continue   # the generator's texture term is evaluated with its backward pass: only on generator iterations (the reference logs it there, train.py:263-268)
+            assert abs(log[k] - ref_v) <= 2e-2 * max(1e-3, abs(ref_v)) + 1e-5, (it, k, log[k], ref_v)
+        g_now, d_now = snap(m.netG), snap(m.netD)
+        moved.append((not same(g_now, g_prev), not same(d_now, d_prev)))
+        g_prev, d_prev = g_now, d_now
+    assert moved == [(False, False), (False, True), (True, False), (False, True)], moved
+    assert m.iteration_count == 4
+    for net, ref in ((m.netG, G), (m.netD, D)):
+        rsd = ref.state_dict()
+        for k, v in net.state_dict().items():
+            if 'gaussian_filter' in k:
+                continue
+            d = (v.cpu() - rsd[k]).abs().max().item()
+            assert d <= 2.2e-4, (k, d)   # at most two Adam steps of lr 1e-4 apart (sign flips of ~0 gradients)
