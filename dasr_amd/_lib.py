@@ -112,6 +112,7 @@ _SIGS = {
     'dasr_prelu_grad_f16': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_vp],
     'dasr_lowpass_valid': [Tensor, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_vp],
     'dasr_run_ops': [c_vp, c_i32, c_vp],
+    'dasr_run_ops_mt': [c_vp, c_vp, c_vp, c_i32],
     'dasr_last_failed_op': [],
     'dasr_ddm_spread': [Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, Tensor, c_vp],
     'dasr_abi_version': [],
@@ -141,7 +142,7 @@ _BENCH_SIGS = {
 }
 BENCH_LIB_PATH = os.path.join(HERE, 'libdasr_bench.so')
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 _lib = None
 _bench = None
 

@@ -67,7 +67,7 @@ def build(force=False, verbose=False, trace=False, ablate=False):
             sys.stderr.write(out.decode())
         if p.returncode != 0:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl']
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl', '-pthread']
     subprocess.check_call(cmd)
     out, LIB = LIB, os.path.join(HERE, 'libdasr_hip.so')
     return out

@@ -1,5 +1,9 @@
 // Weight packing, HBM-bound elementwise kernels, fused Adam and the op-list executor (gfx950).
 #include "common.h"
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 namespace {
 
@@ -559,7 +563,7 @@ extern "C" int dasr_event_destroy(void* ev) { return ev ? (int)hipEventDestroy((
 
 extern "C" int dasr_abi_version(void) { return DASR_ABI_VERSION; }
 
-static int g_last_failed_op = -1;
+static thread_local int g_last_failed_op = -1;   // per enqueue thread; dasr_run_ops_mt copies the failing list's value to its caller
 extern "C" int dasr_last_failed_op(void) { return g_last_failed_op; }
 
 // ---- profiling session (see DASR_LAUNCH in common.h) ------------------------------------------------------------------------
@@ -571,15 +575,22 @@ struct ProfRec {
     int op;
 };
 ProfRec* g_prof = nullptr;
-int g_prof_cap = 0, g_prof_n = 0;
-bool g_prof_on = false;
-double g_prof_flops = 0.0, g_prof_bytes = 0.0;  // algorithmic work of the op being dispatched (consumed by its first launch)
-int g_prof_op = 0;
+int g_prof_cap = 0;
+std::atomic<int> g_prof_n{0};
+std::atomic<bool> g_prof_on{false};
+// algorithmic work of the op being dispatched (consumed by its first launch); per enqueue thread (dasr_run_ops_mt)
+thread_local double g_prof_flops = 0.0, g_prof_bytes = 0.0;
+thread_local int g_prof_op = 0;
 }  // namespace
 
 bool dasr_prof_slot(const char* tag, hipEvent_t* e0, hipEvent_t* e1) {
-    if (!g_prof_on || g_prof_n >= g_prof_cap) return false;
-    ProfRec& r = g_prof[g_prof_n++];
+    if (!g_prof_on.load(std::memory_order_relaxed)) return false;
+    const int slot = g_prof_n.fetch_add(1, std::memory_order_relaxed);
+    if (slot >= g_prof_cap) {
+        g_prof_n.store(g_prof_cap, std::memory_order_relaxed);
+        return false;
+    }
+    ProfRec& r = g_prof[slot];
     r.tag = tag;
     r.flops = g_prof_flops;
     r.bytes = g_prof_bytes;
@@ -602,15 +613,16 @@ extern "C" int dasr_prof_begin(int32_t capacity) {
             g_prof_cap = i + 1;
         }
     }
-    g_prof_n = 0;
-    g_prof_on = true;
+    g_prof_n.store(0);
+    g_prof_on.store(true);
     return 0;
 }
 
 extern "C" int dasr_prof_end(int32_t max_out, float* us_out, double* flops_out, double* bytes_out, int32_t* op_out, const char** tag_out) {
-    g_prof_on = false;
+    g_prof_on.store(false);
     HIP_TRY(hipDeviceSynchronize());
-    const int n = g_prof_n < max_out ? g_prof_n : max_out;
+    const int recorded = g_prof_n.load() < g_prof_cap ? g_prof_n.load() : g_prof_cap;
+    const int n = recorded < max_out ? recorded : max_out;
     for (int i = 0; i < n; ++i) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, g_prof[i].e0, g_prof[i].e1));
@@ -724,4 +736,100 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream0) {
         }
     }
     return 0;
+}
+
+// ---- multi-threaded enqueue ---------------------------------------------------------------------------------------------------
+// The sub-batch replicas of a training step are independent op lists on their own HIP streams.  One host thread enqueues ~250-400 k
+// launches/s; with three or four replica streams (5 000+ launches per step at configs[1]) a single enqueuer is what the GPU waits for.
+// dasr_run_ops_mt gives every list its own enqueue thread (a persistent pool: list 0 runs on the caller, lists 1.. on workers bound to the
+// caller's device), and returns when every list has been ENQUEUED (not executed).  Events recorded / waited inside the lists keep their meaning:
+// hipEventRecord / hipStreamWaitEvent are ordered per stream, and an event another list waits for must have been recorded by an EARLIER call
+// (the trainers only wait for replica events on the communication stream after this function has returned).
+namespace {
+struct EnqWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    const dasr_op* ops = nullptr;
+    int n = 0, dev = 0, rc = 0, failed = -1;
+    void* stream = nullptr;
+    bool has_work = false, done = false, quit = false;
+    void loop() {
+        int cur_dev = -1;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return has_work || quit; });
+            if (quit) return;
+            has_work = false;
+            lk.unlock();
+            int r = 0;
+            if (cur_dev != dev) {
+                r = (int)hipSetDevice(dev);
+                cur_dev = dev;
+            }
+            if (r == 0) r = dasr_run_ops(ops, n, stream);
+            const int f = dasr_last_failed_op();
+            lk.lock();
+            rc = r;
+            failed = f;
+            done = true;
+            cv.notify_all();
+        }
+    }
+};
+constexpr int kMaxEnqWorkers = 7;
+EnqWorker* g_enq[kMaxEnqWorkers] = {};
+std::mutex g_enq_mutex;   // one dasr_run_ops_mt call at a time
+struct EnqPoolReaper {
+    ~EnqPoolReaper() {
+        for (auto*& w : g_enq) {
+            if (!w) continue;
+            {
+                std::lock_guard<std::mutex> lk(w->m);
+                w->quit = true;
+            }
+            w->cv.notify_all();
+            if (w->th.joinable()) w->th.join();
+            delete w;
+            w = nullptr;
+        }
+    }
+} g_enq_reaper;
+}  // namespace
+
+extern "C" int dasr_run_ops_mt(const dasr_op* const* lists, const int32_t* counts, void* const* streams, int32_t nlists) {
+    if (nlists <= 0 || nlists > kMaxEnqWorkers + 1 || !lists || !counts || !streams) return DASR_EINVAL;
+    std::lock_guard<std::mutex> guard(g_enq_mutex);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    for (int i = 1; i < nlists; ++i) {
+        EnqWorker*& w = g_enq[i - 1];
+        if (!w) {
+            w = new EnqWorker();
+            w->th = std::thread([w] { w->loop(); });
+        }
+        {
+            std::lock_guard<std::mutex> lk(w->m);
+            w->ops = lists[i];
+            w->n = counts[i];
+            w->stream = streams[i];
+            w->dev = dev;
+            w->done = false;
+            w->has_work = true;
+        }
+        w->cv.notify_all();
+    }
+    int rc = dasr_run_ops(lists[0], counts[0], streams[0]);
+    int failed = rc ? dasr_last_failed_op() : -1;
+    for (int i = 1; i < nlists; ++i) {
+        EnqWorker* w = g_enq[i - 1];
+        std::unique_lock<std::mutex> lk(w->m);
+        w->cv.wait(lk, [&] { return w->done; });
+        if (rc == 0 && w->rc != 0) {
+            rc = w->rc;
+            failed = w->failed | (i << 24);   // bits 24..: index of the failing list
+        }
+    }
+    if (rc != 0) g_last_failed_op = failed;
+    return rc;
 }

@@ -126,7 +126,7 @@ class DASR_Model(BaseModel):
             self.l_fea_type = t['feature_criterion']
             if self.l_fea_w > 0:
                 if self.l_fea_type in ('l1', 'l2'):                          # VGG19-54 feature L1 / MSE (DASR_model.py:93-96,105-106)
-                    self.netF = VGGFeatureHIP(34, device=self.device)
+                    self.netF = VGGFeatureHIP(34, device=self.device, mse_target=(self.l_fea_type == 'l2'))
                     pf = opt['path']['pretrain_model_F']
                     if pf:
                         self.netF.load_state_dict(torch.load(pf, map_location='cpu'), strict=False)
@@ -255,13 +255,16 @@ class DASR_Model(BaseModel):
                 for sums, part in P.r_bufs:
                     self.dp.all_reduce_here(sums if stage == 0 else part)
 
+    def check_finite(self):
+        for o, what in zip(self.optimizers, ('generator', 'discriminator', 'source discriminator')):
+            o.check_finite(what)
+
     def get_current_log(self):
         """one device->host sync, only when the caller logs (the reference syncs 5-9 times every step, App. C-8)"""
         if getattr(self, '_acc_snapshot', None) is not None:
             acc, do_g, do_d, do_ds = self._acc_snapshot
             a = acc.tolist()
-            for o, what in zip(self.optimizers, ('generator', 'discriminator', 'source discriminator')):
-                o.check_finite(what)
+            self.check_finite()
             if do_g:
                 if self.l_pix_w > 0:
                     self.log_dict['loss/l_g_pix'] = a[A_PIX] / self._pix_div

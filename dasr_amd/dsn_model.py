@@ -198,8 +198,11 @@ class _GPlan:
                 self.h16 = [B16() for _ in range(nb)]
             self.g_s16 = [B16() for _ in range(2)]      # gscale * dL/ds, gscale * dL/dh in f16
             self.g_h16 = B16()
-            # dL/dfake of the mean losses is ~1 / (number of output elements): a power of two puts it at ~2^-3 before the f16 rounding
-            self.gscale = float(2.0 ** max(0, int(math.floor(math.log2(max(1, N * 3 * H4 * W4)))) - 3))
+            # dL/dfake of the mean losses is ~(largest loss weight) / (number of output elements): a power of two puts it at ~2^-3 before the f16
+            # rounding.  net.loss_weight = max(w_col, w_tex, w_per) (set by DSNModel; 1 for a bare generator): with w_col = 0 the gradient is
+            # 2-3 orders smaller and would otherwise sit in f16's subnormal range (the non-finite flag only sees overflow)
+            lw = float(getattr(net, 'loss_weight', 1.0)) or 1.0
+            self.gscale = float(2.0 ** max(0, min(60, int(math.floor(math.log2(max(1.0, N * 3 * H4 * W4 / lw)))) - 3)))
         sh = lambda t: ({'out_bf16': t.view(), 'out16_f16': 1} if b16 else {})
         self.scratch = torch.zeros(1024, dtype=torch.float32, device=dev)
         self.ws = Workspace(dev)
@@ -381,7 +384,7 @@ class DSNModel:
                 self.netF = load_lpips({'path': {'lpips_alexnet': o.get('lpips_alexnet'), 'lpips_lin': o.get('lpips_lin')},
                                         'allow_random_perceptual': o['allow_random_perceptual']}, self.device, int(o['vgg_seed']))
             elif o['per_type'] == 'VGG':
-                self.netF = VGGFeatureHIP(30, device=self.device, cfg=VGG16_CFG)
+                self.netF = VGGFeatureHIP(30, device=self.device, cfg=VGG16_CFG, mse_target=True)   # loss.py:58-63: MSE of VGG16 features
                 if o['vgg_path']:
                     sd = torch.load(o['vgg_path'], map_location='cpu')
                     self.netF.load_state_dict({k: v for k, v in sd.items() if k in self.netF.params.spec})
@@ -406,6 +409,7 @@ class DSNModel:
         if o['generator'].lower() not in ('deresnet', 'dsgan'):   # codes/DSN/train.py:124-129
             raise NotImplementedError('Generator model [{:s}] not recognized'.format(o['generator']))
         self.netG = DeResnetHIP(o['n_res_blocks'], device=self.device, scale=4 if o['generator'].lower() == 'deresnet' else 1)
+        self.netG.loss_weight = max(float(o['w_col']), float(o['w_tex']), float(o['w_per']))   # sizes the f16 pre-scale of the 16-bit backward (_GPlan.gscale)
         self.cs = str(o['cat_or_sum']).lower()   # wavelet bands of the discriminator input: 'cat' (9 channels) or 'sum' = (LH + HL + HH) / 3 (model.py:108-118)
         if self.cs not in ('cat', 'sum'):
             raise NotImplementedError('Wavelet format [{:s}] not recognized'.format(str(o['cat_or_sum'])))
@@ -455,7 +459,9 @@ class DSNModel:
         self.epoch += 1
 
     def _plan(self, N, H, W):
-        k = (N, H, W)
+        # the relativistic ops bake the data-parallel world size into their batch-mean divisor: a plan is valid for ONE world size
+        world = self.dp.world if (self.dp is not None and self.dp.active) else 1
+        k = (N, H, W, world if self.ragan else 0)
         if k not in self._plans:
             self._plans[k] = _DSNPlan(self, N, H, W)
         return self._plans[k]
@@ -556,11 +562,14 @@ class DSNModel:
         P.ops.run()
         return P.dout.nchw(1), P.ddm.nchw(1)
 
+    def check_finite(self):
+        self.opt_g.check_finite('DSN generator')
+        self.opt_d.check_finite('DSN discriminator')
+
     def get_current_log(self):
         if getattr(self, '_pending', False):
             a = self.acc.tolist()
-            self.opt_g.check_finite('DSN generator')
-            self.opt_d.check_finite('DSN discriminator')
+            self.check_finite()
             o = self.opt
             self.log.update({'loss/d_tex_loss': a[0] + a[1], 'loss/g_tex_loss': a[2], 'loss/color_loss': a[3], 'loss/perceptual_loss': a[6],
                              'loss/g_overall_loss': o['w_col'] * a[3] + o['w_tex'] * a[2] + o['w_per'] * a[6], 'disc_score/real': a[4],

@@ -106,6 +106,15 @@ class SyntheticCrops:
             yield torch.rand(b, 3, c, c, generator=g), torch.rand(b, 3, c // 4, c // 4, generator=g), torch.rand(b, 3, c // 4, c // 4, generator=g)
 
 
+def model_options(o):
+    """argparse namespace -> DSNModel option dict: every flag the model acts on (a flag missing here silently keeps the model default)"""
+    return dict(n_res_blocks=o.num_res_blocks, kernel_size=o.kernel_size, filter=o.filter, norm_layer=o.norm_layer, discriminator=o.discriminator,
+                learning_rate=o.learning_rate, adam_beta_1=o.adam_beta_1, w_col=o.w_col, w_tex=o.w_tex, w_per=o.w_per if o.use_per_loss else 0.0,
+                per_type=o.per_type, generator=o.generator, vgg_path=o.vgg_path, lpips_alexnet=o.lpips_alexnet, lpips_lin=o.lpips_lin, num_epochs=o.num_epochs,
+                num_decay_epochs=o.num_decay_epochs, upscale_factor=o.upscale_factor, ragan=o.ragan, allow_random_perceptual=o.allow_random_perceptual,
+                cat_or_sum=o.cat_or_sum, disc_freq=o.disc_freq, gen_freq=o.gen_freq)   # train.py:55-56, 229, 251
+
+
 def main(argv=None, loader=None):
     o = build_parser().parse_args(argv)
     check_supported(o, have_loader=loader is not None)
@@ -118,10 +127,7 @@ def main(argv=None, loader=None):
         torch.cuda.set_device(dp.device_index)
     if o.debug:
         o.num_epochs, o.iters_per_epoch = min(o.num_epochs, 2), min(o.iters_per_epoch, 3)
-    opt = dict(n_res_blocks=o.num_res_blocks, kernel_size=o.kernel_size, filter=o.filter, norm_layer=o.norm_layer, discriminator=o.discriminator,
-               learning_rate=o.learning_rate, adam_beta_1=o.adam_beta_1, w_col=o.w_col, w_tex=o.w_tex, w_per=o.w_per if o.use_per_loss else 0.0,
-               per_type=o.per_type, generator=o.generator, vgg_path=o.vgg_path, lpips_alexnet=o.lpips_alexnet, lpips_lin=o.lpips_lin, num_epochs=o.num_epochs, num_decay_epochs=o.num_decay_epochs,
-               upscale_factor=o.upscale_factor, ragan=o.ragan, allow_random_perceptual=o.allow_random_perceptual, cat_or_sum=o.cat_or_sum)
+    opt = model_options(o)
     model = DSNModel(opt)
     if dp:
         model.dp = dp
@@ -146,6 +152,8 @@ def main(argv=None, loader=None):
         for hr, bic, real in loader:
             model.iteration(hr.to(dev, non_blocking=True), bic.to(dev, non_blocking=True), real.to(dev, non_blocking=True))
         model.end_epoch()
+        if rank != 0:
+            model.check_finite()   # rank 0 checks inside get_current_log below: all ranks raise together
         if rank == 0:
             lg = model.get_current_log()
             log.info('[%d/%d] iter %d lr %.3e ' % (epoch, o.num_epochs, model.iteration_count, model.lr()) +

@@ -239,6 +239,31 @@ def run_interleaved(lists, streams, chunk=None):
                     l.run(c[k], c[k + 1])
 
 
+def run_parallel(lists, streams):
+    """Enqueue independent op lists on their own streams.  Default: one enqueue THREAD per list inside the library (dasr_run_ops_mt) -- with
+    three or four sub-batch replicas a step is 5 000+ launches, more than one host thread feeds in the time the GPU needs for them.
+    DASR_ENQ=chunk: the single-threaded chunk interleave of rounds 1-3 (run_interleaved).  While a stream capture is open (hipGraph) the
+    lists are enqueued by the capturing thread."""
+    import os
+    lists = [l for l in lists]
+    if len(lists) == 1 or os.environ.get('DASR_ENQ', 'mt') == 'chunk' or torch.cuda.is_current_stream_capturing():
+        return run_interleaved(lists, streams)
+    n = len(lists)
+    for l in lists:
+        if l._arr is None:
+            l._arr = (Op * len(l.ops))(*l.ops)
+    ptrs = (C.c_void_p * n)(*[C.addressof(l._arr) for l in lists])
+    cnts = (C.c_int32 * n)(*[len(l.ops) for l in lists])
+    sts = (C.c_void_p * n)(*[st.cuda_stream for st in streams])
+    L = _lib.lib()
+    rc = L.dasr_run_ops_mt(ptrs, cnts, sts, n)
+    if rc != 0:
+        k = L.dasr_last_failed_op()
+        li, oi = (k >> 24) & 0x7f, k & 0xffffff
+        kind = lists[li].ops[oi].op if (0 <= li < n and 0 <= oi < len(lists[li].ops)) else -1
+        raise _lib.DasrHipError('dasr_run_ops_mt: list %d op #%d (kind %d) failed with code %d' % (li, oi, kind, rc))
+
+
 def conv_op(pack, ref, inp, in_f32, cin, Hin, Win, Hout, Wout, N, bias=None, kh=3, stride=1, pad=1, ups=0, act=0, slope=SLOPE,
             mask=None, mask_f32=0, alpha=1.0, res1=None, beta1=0.0, res2=None, beta2=0.0, out_f32=None, out_bf16=None, gamma=1.0,
             pad_x=-1, out_stride=1, out_oy=0, out_ox=0, out_W=0, slope_ptr=None, in_stride=1, in_oy=0, in_ox=0, in_W=0, flops=None, in_scale=0.0, out16_f16=0,

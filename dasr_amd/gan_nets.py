@@ -430,7 +430,7 @@ def vgg19_spec(feature_layer=34, cfg=None):
 class VGGFeatureHIP:
     """Frozen feature extractor: forward on N images, data-gradient w.r.t. the first n_g inputs."""
 
-    def __init__(self, feature_layer=34, device='cuda', cfg=None, prec=None, bwd_prec=None):
+    def __init__(self, feature_layer=34, device='cuda', cfg=None, prec=None, bwd_prec=None, mse_target=False):
         """prec 4 (default): split-f16 operands on f32 tensors (f16 hi + lo pairs, 22 mantissa bits, 3 MFMA passes; gradients pre-scaled by a
         power of two): input-gradient error 4.9e-6 against the fp32 oracle.  prec 3: split-bf16 (16 bits), same cost: 6.5e-3 on the input
         gradient (max-pool arg-max flips on 16-bit ties), the default until round 2.  prec 2: activations and gradients stored in f16
@@ -455,7 +455,9 @@ class VGGFeatureHIP:
         # perceptual loss, loss.py:119-130): their features are only the TARGET of an L1 / MSE, so the operand rounding of a single f16 MFMA pass
         # (1e-3 on the features, zero-mean) enters the loss value in second order and the gradient only through sign flips of near-ties.  One
         # pass instead of three on a third of the perceptual network's work.  DASR_VGG_NOGRAD_PREC=0: same precision as the gradient half.
-        self.nograd_prec = int(os.environ.get('DASR_VGG_NOGRAD_PREC', '2')) if self.prec in (3, 4, 5) else 0
+        # mse_target (feature_criterion l2, the DSN's VGG16 MSE): the gradient is 2 (f_fake - f_target) / n, the target's rounding error enters it in
+        # FIRST order, so the target half keeps the precision of the gradient half unless the environment variable asks for the one-pass form.
+        self.nograd_prec = int(os.environ.get('DASR_VGG_NOGRAD_PREC', '0' if mse_target else '2')) if self.prec in (3, 4, 5) else 0
         self.spec, self.layers = vgg19_spec(feature_layer, cfg)
         self.params = ParamStore(self.spec, self.device)
         self.pack = PackRegistry(self.params)

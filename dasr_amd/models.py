@@ -15,7 +15,7 @@ from collections import Counter, OrderedDict
 import torch
 
 from . import _lib
-from .engine import Op, OpList, NULL_T, ensure_runtime_ready, _stream, run_interleaved
+from .engine import Op, OpList, NULL_T, ensure_runtime_ready, _stream, run_parallel
 from .init import kaiming_state_dict
 from .rrdbnet import RRDBNetHIP, rrdbnet_param_spec
 
@@ -77,11 +77,14 @@ class AdamHIP:
         _lib.check(_lib.lib().dasr_adam(P.flat.data_ptr(), P.grad.data_ptr(), P.m.data_ptr(), P.v.data_ptr(), P.total, lr,
                                         self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, self.nonfinite.data_ptr(), _stream()), 'adam')
 
-    def check_finite(self, what='generator'):
-        """called where the trainer synchronises anyway (get_current_log): a non-finite gradient has reached the optimiser since the last check"""
+    def check_finite(self, what='generator', hint=None):
+        """a non-finite gradient has reached the optimiser since the last check?  Costs one device->host sync: called where the trainer
+        synchronises anyway (get_current_log) and by the drivers on EVERY rank at the logging interval (under data parallelism the flag is set on
+        all ranks -- the gradients are all-reduced in front of Adam -- so all ranks raise together instead of rank 0 leaving the others inside
+        the next collective).  DASR_ALLOW_NONFINITE=1: instrumented / ablation builds (scripts/) compute wrong results on purpose."""
         if int(self.nonfinite.item()):
             self.nonfinite.zero_()
-            if os.environ.get('DASR_HIP_LIB'):   # instrumented / ablation builds compute wrong results on purpose (scripts/, timing only)
+            if os.environ.get('DASR_ALLOW_NONFINITE') == '1':
                 return
             P = self.params
             if os.environ.get('DASR_DBG_DUMP'):   # debugging aid: which plan tensors hold non-finite values right now
@@ -95,10 +98,12 @@ class AdamHIP:
                                     nf = (~torch.isfinite(tt.float())).nonzero()
                                     print('[dbg] %s.%s[%d] %s %s: %d non-finite, first at %s' % (type(o).__name__, k, i, tuple(tt.shape), tt.dtype, len(nf), nf[0].tolist()))
             bad = [k for k in P.spec if not bool(torch.isfinite(P.view(k, P.grad)).all())][:6]   # (the last step's gradients; error path only)
-            raise FloatingPointError('inf / NaN in the %s gradients (the weights have absorbed it)%s.  The HR tail stores activations and gradients in f16 '
-                                     'with a power-of-two pre-scale sized for mean losses of weight ~1: very large loss weights or activations above '
-                                     '65504 overflow it -- DASR_HR_PREC=3 keeps the tail in split-bf16 on f32 tensors.'
-                                     % (what, (': non-finite now in ' + ', '.join(bad)) if bad else ''))
+            hint = hint or ('Paths of this network that store activations / gradients in f16 with a power-of-two pre-scale sized for mean losses of weight ~1 '
+                            '(very large loss weights or activations above 65504 overflow them): the HR tail of the RRDBNet generator (DASR_HR_PREC=3 keeps it '
+                            'in split-bf16 on f32 tensors), the 16-bit backward of the DSN generator (DASR_DSN_BWD16=0), the one-pass f16 data gradient of the '
+                            'perceptual VGG (DASR_VGG_BWD_PREC=5).')
+            raise FloatingPointError('inf / NaN in the %s gradients (the weights have absorbed it)%s.  %s'
+                                     % (what, (': non-finite now in ' + ', '.join(bad)) if bad else '', hint))
 
     def state_dict(self, lr):
         P = self.params
@@ -248,7 +253,8 @@ class SRModel(BaseModel):
         (2 per CU) and ~35 % of every kernel is ramp / first-load / epilogue latency; two independent half-batches
         fill those gaps with each other's main loops.  DASR_STREAMS=1 disables it."""
         k = max(1, int(os.environ.get('DASR_STREAMS', '2')))
-        if k == 1 or N % k or N // k < 4:
+        k = min(k, N // 4) if N >= 8 else 1   # a replica keeps at least 4 crops (128 workgroups per dense-block launch at 128 x 128)
+        if k <= 1:
             if (N, h, w, 0, 0, 0) not in self.netG.plans:
                 self.netG.concurrent_replicas = 1   # a plan built now has the chip to itself (wgrad split count)
             return [self.netG.plan(N, h, w)]
@@ -256,7 +262,9 @@ class SRModel(BaseModel):
         # deferred dense-block weight gradients: the replicas work on image ranges of ONE set of slabs (TrunkStore) and the weight-gradient
         # phase runs once over the whole batch after both data-gradient chains (rrdbnet.TrunkStore)
         store = self.netG.trunk_store(N, h, w) if self.netG.defer_wgrad else None
-        return [self.netG.plan(N // k, h, w, replica=i, store=store, n0=i * (N // k)) for i in range(k)]
+        sizes = [N // k + (1 if i < N % k else 0) for i in range(k)]   # uneven splits allowed (16 -> 6 + 5 + 5)
+        offs = [sum(sizes[:i]) for i in range(k)]
+        return [self.netG.plan(sizes[i], h, w, replica=i, store=store, n0=offs[i]) for i in range(k)]
 
     @staticmethod
     def _whole_step(plan, loss_ops):
@@ -326,21 +334,20 @@ class SRModel(BaseModel):
                     self.dp.reduce_async(g[lo:hi])
                 self.dp.wait()
         else:
-            if not hasattr(self, '_streams'):
+            if len(getattr(self, '_streams', ())) != len(plans):
                 self._streams = [torch.cuda.Stream() for _ in plans]
             cur = torch.cuda.current_stream()
-            per = N // len(plans)
             steps = []
             for i, (plan, st) in enumerate(zip(plans, self._streams)):
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
                     loss_ops, hr_buf = self._ops_for(plan, N)
-                    hr_buf.copy_(self.real_H[i * per:(i + 1) * per])
-                    plan.set_input(self.var_L[i * per:(i + 1) * per])
+                    hr_buf.copy_(self.real_H[plan.n0:plan.n0 + plan.N])
+                    plan.set_input(self.var_L[plan.n0:plan.n0 + plan.N])
                     if dp_on and plan.set_grad_scale(self.dp.grad_scale) and hasattr(plan, 'whole_step'):
                         del plan.whole_step  # the recorded list holds copies of the patched reduce ops
                 steps.append(self._whole_step(plan, loss_ops))
-            run_interleaved(steps, self._streams)
+            run_parallel(steps, self._streams)
             g = self.netG.params.grad
             comm = self.dp.comm_stream if dp_on else None
             store = plans[0].store if plans[0].shared_store else None
@@ -397,10 +404,14 @@ class SRModel(BaseModel):
     def fake_H(self, v):
         self._fake_H = v
 
+    def check_finite(self):
+        """raise FloatingPointError if a non-finite gradient reached an optimiser since the last check (every rank; see AdamHIP.check_finite)"""
+        self.optimizer_G.check_finite('generator')
+
     def get_current_log(self):
         if 'l_pix' in self.log_dict:
             self.log_dict['l_pix'] = float(self._l_pix_dev.item())
-            self.optimizer_G.check_finite()
+            self.check_finite()
         return self.log_dict
 
     def test(self):

@@ -194,6 +194,8 @@ def main(argv=None):
                 batch = shard_minibatch(batch, dp.rank, dp.world)
             model.feed_data(batch, True)
             model.optimize_parameters(current_step)
+            if current_step % opt['logger']['print_freq'] == 0 and rank != 0:
+                model.check_finite()   # rank 0 checks inside get_current_log: all ranks raise together (the flag is set behind the all-reduce)
             if current_step % opt['logger']['print_freq'] == 0 and rank == 0:
                 msg = '<epoch:{:3d}, iter:{:8,d}, lr:{:.3e}> '.format(epoch, current_step, model.get_current_learning_rate())
                 for k, v in model.get_current_log().items():

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DASR_ABI_VERSION 12
+#define DASR_ABI_VERSION 13
 #define DASR_EINVAL (-22)
 
 typedef struct {
@@ -373,6 +373,12 @@ typedef struct {
 } dasr_op;
 
 int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream);
+/* Enqueue `nlists` independent op lists, list i on streams[i], each from its own host thread (list 0 on the caller, a persistent pool for
+ * the rest, bound to the caller's device); returns when every list has been enqueued.  For the sub-batch replica streams of a training step
+ * (dasr_amd/models.py: three or four replicas are 5 000+ launches per step -- more than one enqueue thread feeds).  nlists <= 8.  On failure
+ * dasr_last_failed_op() = op index | (list index << 24).  Replaces nothing in the reference (its step is one autograd graph on one stream,
+ * codes/SRN/models/SR_model.py:77-85). */
+int dasr_run_ops_mt(const dasr_op* const* lists, const int32_t* counts, void* const* streams, int32_t nlists);
 /* events for the scheduling ops (hipEventDisableTiming); independent work of one list can be moved to a second stream this way
  * (the dense-block weight gradients are not on the data-gradient chain's critical path) */
 void* dasr_event_create(void);

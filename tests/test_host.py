@@ -205,6 +205,14 @@ def test_dsn_cli_flags_and_lr_rule():
     for bad in (['--generator', 'SRGAN'], ['--discriminator', 'nld_s3'], ['--wgan'], ['--norm_layer', 'Batch', '--discriminator', 'nld_s1'], ['--norm_layer', 'Group'], ['--lpips_rot_flip']):
         with pytest.raises(NotImplementedError):
             dsn_train.check_supported(dsn_train.build_parser().parse_args(bad))
+    # every flag the model acts on reaches its option dict (--disc_freq / --gen_freq were parsed, accepted and then dropped)
+    o2 = dsn_train.build_parser().parse_args(['--disc_freq', '2', '--gen_freq', '3', '--ragan', '--cat_or_sum', 'sum', '--filter', 'wavelet', '--w_col', '0.5'])
+    mo = dsn_train.model_options(o2)
+    assert (mo['disc_freq'], mo['gen_freq'], mo['ragan'], mo['cat_or_sum'], mo['filter'], mo['w_col']) == (2, 3, True, 'sum', 'wavelet', 0.5)
+    import inspect, re
+    dflt = re.search(r"o = dict\((.*?)\)\n", inspect.getsource(dsn_model.DSNModel.__init__), re.S).group(1)
+    model_keys = set(re.findall(r"(\w+)=", dflt)) - {'vgg_seed'}   # (vgg_seed: no CLI flag)
+    assert model_keys <= set(mo), model_keys - set(mo)   # every default of the model that a CLI flag backs is forwarded
     # LambdaLR rule of train.py:154-157 against torch's scheduler
     m = dsn_model.DSNModel.__new__(dsn_model.DSNModel)
     m.opt = dict(num_epochs=10, num_decay_epochs=4, learning_rate=2e-4)
