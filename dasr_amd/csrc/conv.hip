@@ -1573,9 +1573,15 @@ extern "C" int dasr_debug_set_trace(void* buf) {
 #endif
 
 extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
+#ifndef DASR_BENCH
+    // product library: one dense-block conv kernel; the only live choice is the workgroup shape rule of the Cout = 64 launches (key 2)
+    if (key == 2 && (value == 12 || value == 13)) { g_tune_rdb64 = value; return 0; }
+    if ((key == 1 && value == 12) || (key == 3 && value == 0) || (key == 4 && value == 1) || (key == 5 && value == 1) || (key == 6 && value == 0)) return 0;
+    return DASR_EINVAL;   // the A/B variants of rounds 1-3 live in libdasr_hip_ablate.so (python -m dasr_amd.build --ablate)
+#else
     switch (key) {
-        case 1: g_tune_rdb32 = value; return 0;   // Cout=32 dense conv: 12 LDS-DMA kernel (default), 13 its 8-wave 32x32-tile form; first-generation kernel: 0 single LDS buffer, 1 double,
-                                                   // 4/5 8x32 tiles, 6 4x32 tiles, 8/9 row reuse, 10/11 register-staged pipeline
+        case 1: g_tune_rdb32 = value; return 0;   // Cout=32 dense conv: 12 LDS-DMA kernel (default), 13 its 8-wave 32x32-tile form, 14-17 ring / loader / flag forms;
+                                                   // first-generation kernel: 0 single LDS buffer, 1 double, 4/5 8x32 tiles, 6 4x32 tiles, 8/9 row reuse, 10/11 register-staged pipeline
         case 2: g_tune_rdb64 = value; return 0;   // Cout=64 dense conv: same codes as key 1
         case 3: g_tune_stream = value; return 0;  // split-bf16 stream conv: 0 single, 1 double
         case 4: g_tune_xcd = value; return 0;     // XCD-aware tile order on/off
@@ -1583,6 +1589,7 @@ extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
         case 6: g_tune_rot = value; return 0;     // LDS-DMA dense conv: per-workgroup chunk-order rotation on/off
         default: return DASR_EINVAL;
     }
+#endif
 }
 
 extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
@@ -1621,6 +1628,8 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
     switch (key) {
         // prec 1, bf16 input (RDB dense-block convs, fwd and dgrad)
         case 10:
+#ifdef DASR_BENCH   // libdasr_hip_ablate.so only (python -m dasr_amd.build --ablate): A/B variants measured slower in rounds 1-3 and the wrong-result
+                    // ablation series; the product library has exactly one dense-block conv kernel (conv_glds_kernel)
             switch (g_tune_rdb32) {
                 case 1: return launch<1, false, 1, 3, 1, 4, 1, true>(p, s);
                 case 4: return launch<1, false, 1, 3, 1, 2>(p, s);          // 8x32 tiles: 2x the workgroups
@@ -1630,7 +1639,12 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                 case 9: return launch<1, false, 1, 3, 1, 4, 1, true, 1>(p, s);
                 case 10: return launch<1, false, 1, 3, 1, 4, 1, true, 2>(p, s);  // pipelined: prefetch distance 2, ds_write inside the MFMA stream
                 case 11: return launch<1, false, 1, 3, 1, 2, 1, true, 2>(p, s);
-#ifdef DASR_BENCH   // libdasr_hip_ablate.so only (python -m dasr_amd.build --ablate): the product library has no wrong-result instantiations
+                case 0:   // first-generation register-staged kernel
+                    switch (g_tune_epi ? classify_epi(p) : 0) {
+                        case 67: return launch<1, false, 1, 3, 1, 4, 1, false, 0, 67>(p, s);
+                        case 68: return launch<1, false, 1, 3, 1, 4, 1, false, 0, 68>(p, s);
+                        default: return launch<1, false, 1, 3, 1, 4>(p, s);
+                    }
                 case 100: return launch_glds<1, 67, 4, 0>(p, s);   // ablation series (scripts/micro_conv.py --mode fwd): wrong results, timing only
                 case 101: return launch_glds<1, 67, 4, 1>(p, s);
                 case 102: return launch_glds<1, 67, 4, 2>(p, s);
@@ -1642,13 +1656,6 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                 case 115: return launch_glds<1, 67, 4, 15>(p, s);
                 case 116: return launch_glds<1, 67, 4, 16>(p, s);   // barrier per chunk, no DMA wait
                 case 117: return launch_glds<1, 67, 4, 17>(p, s);   // no DMA in the loop, no wait, barrier kept
-#endif
-                case 12:
-                    switch (g_tune_epi ? classify_epi(p) : 0) {
-                        case 67: return launch_glds<1, 67>(p, s);
-                        case 68: return launch_glds<1, 68>(p, s);
-                        default: return launch_glds<1, 0>(p, s);
-                    }
                 case 15:   // RING: three activation images + two weight images, counted vmcnt (round 3)
                     switch (g_tune_epi ? classify_epi(p) : 0) {
                         case 67: return launch_glds<1, 67, 4, 0, false, 1>(p, s);
@@ -1681,13 +1688,14 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                     }
                 default: break;
             }
+#endif
             switch (g_tune_epi ? classify_epi(p) : 0) {
-                case 67: return launch<1, false, 1, 3, 1, 4, 1, false, 0, 67>(p, s);  // bias + LeakyReLU -> bf16 slab planes (forward conv1-4)
-                case 68: return launch<1, false, 1, 3, 1, 4, 1, false, 0, 68>(p, s);  // LeakyReLU' mask -> bf16 gslab planes (data gradient)
-                default: break;
+                case 67: return launch_glds<1, 67>(p, s);   // bias + LeakyReLU -> bf16 slab planes (forward conv1-4)
+                case 68: return launch_glds<1, 68>(p, s);   // LeakyReLU' mask -> bf16 gslab planes (data gradient)
+                default: return launch_glds<1, 0>(p, s);
             }
-            return launch<1, false, 1, 3, 1, 4>(p, s);
         case 20:
+#ifdef DASR_BENCH
             switch (g_tune_rdb64) {
                 case 1: return launch<1, false, 2, 3, 1, 4, 1, true>(p, s);
                 case 4: return launch<1, false, 2, 3, 1, 2>(p, s);
@@ -1696,48 +1704,44 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                 case 9: return launch<1, false, 2, 3, 1, 4, 1, true, 1>(p, s);
                 case 10: return launch<1, false, 2, 3, 1, 4, 1, true, 2>(p, s);
                 case 11: return launch<1, false, 2, 3, 1, 2, 1, true, 2>(p, s);
-                case 12:
+                case 0:
                     switch (g_tune_epi ? classify_epi(p) : 0) {
-                        case 233: return launch_glds<2, 233>(p, s);
-                        case 249: return launch_glds<2, 249>(p, s);
-                        case 232: return launch_glds<2, 232>(p, s);
-                        case 248: return launch_glds<2, 248>(p, s);
-                        default: return launch_glds<2, 0>(p, s);
-                    }
-                case 13:  // auto: the 8-wave form when the 4-wave grid would not exceed one workgroup per CU (sub-batch launches), else 4 waves
-                    if ((long long)p.N * ((p.Hout + 15) / 16) * ((p.Wout + 31) / 32) * ((p.cout + 63) / 64) > 256) {
-                        switch (g_tune_epi ? classify_epi(p) : 0) {
-                            case 233: return launch_glds<2, 233>(p, s);
-                            case 249: return launch_glds<2, 249>(p, s);
-                            case 232: return launch_glds<2, 232>(p, s);
-                            case 248: return launch_glds<2, 248>(p, s);
-                            default: return launch_glds<2, 0>(p, s);
-                        }
-                    }
-                    switch (g_tune_epi ? classify_epi(p) : 0) {
-                        case 233: return launch_glds<2, 233, 8>(p, s);
-                        case 249: return launch_glds<2, 249, 8>(p, s);
-                        case 232: return launch_glds<2, 232, 8>(p, s);
-                        case 248: return launch_glds<2, 248, 8>(p, s);
-                        default: return launch_glds<2, 0, 8>(p, s);
+                        case 233: return launch<1, false, 2, 3, 1, 4, 1, false, 0, 233>(p, s);
+                        case 249: return launch<1, false, 2, 3, 1, 4, 1, false, 0, 249>(p, s);
+                        case 232: return launch<1, false, 2, 3, 1, 4, 1, false, 0, 232>(p, s);
+                        case 248: return launch<1, false, 2, 3, 1, 4, 1, false, 0, 248>(p, s);
+                        default: return launch<1, false, 2, 3, 1, 4>(p, s);
                     }
                 default: break;
+            }
+#endif
+            // one kernel, two workgroup shapes: 13 (default) = the 8-wave form when the 4-wave grid would not exceed one workgroup per CU
+            // (sub-batch launches), else 4 waves; 12 = always 4 waves
+            if (g_tune_rdb64 == 12 || (long long)p.N * ((p.Hout + 15) / 16) * ((p.Wout + 31) / 32) * ((p.cout + 63) / 64) > 256) {
+                switch (g_tune_epi ? classify_epi(p) : 0) {
+                    case 233: return launch_glds<2, 233>(p, s);   // conv5: bias, alpha, one residual -> fp32 stream + bf16 shadow
+                    case 249: return launch_glds<2, 249>(p, s);   // conv5 of RDB3: two residuals (RRDB skip fused)
+                    case 232: return launch_glds<2, 232>(p, s);   // data gradient w.r.t. the RDB input
+                    case 248: return launch_glds<2, 248>(p, s);
+                    default: return launch_glds<2, 0>(p, s);
+                }
             }
             switch (g_tune_epi ? classify_epi(p) : 0) {
-                case 233: return launch<1, false, 2, 3, 1, 4, 1, false, 0, 233>(p, s);  // conv5: bias, alpha, one residual -> fp32 stream + bf16 shadow
-                case 249: return launch<1, false, 2, 3, 1, 4, 1, false, 0, 249>(p, s);  // conv5 of RDB3: two residuals (RRDB skip fused)
-                case 232: return launch<1, false, 2, 3, 1, 4, 1, false, 0, 232>(p, s);  // data gradient w.r.t. the RDB input
-                case 248: return launch<1, false, 2, 3, 1, 4, 1, false, 0, 248>(p, s);
-                default: break;
+                case 233: return launch_glds<2, 233, 8>(p, s);
+                case 249: return launch_glds<2, 249, 8>(p, s);
+                case 232: return launch_glds<2, 232, 8>(p, s);
+                case 248: return launch_glds<2, 248, 8>(p, s);
+                default: return launch_glds<2, 0, 8>(p, s);
             }
-            return launch<1, false, 2, 3, 1, 4>(p, s);
         // prec 1, f32 input (VGG perceptual branch)
         case 110: return launch<1, true, 1, 3, 1, 4>(p, s);
         case 120: return launch<1, true, 2, 3, 1, 4>(p, s);
         // prec 3, f32 input (residual-stream convs of the generator, discriminator)
         case 1110:
+#ifdef DASR_BENCH
             if (g_tune_stream == 1) return launch<3, true, 1, 3, 1, 4, 1, true>(p, s);
             if (g_tune_stream == 4) return launch<3, true, 1, 3, 1, 2>(p, s);
+#endif
             return launch<3, true, 1, 3, 1, 4>(p, s);
         case 1111: return launch<3, true, 1, 4, 1, 2>(p, s);
         case 1112: return launch<3, true, 1, 4, 2, 1>(p, s);

@@ -690,6 +690,7 @@ __device__ __forceinline__ void w3g_dma(const dasr_wgrad_part& P, const W3GTile&
     }
 }
 
+#ifdef DASR_BENCH   // measured alternative of round 3 (libdasr_hip_ablate.so only); the product's 3x3 weight-gradient kernel is wgrad3_ld_kernel
 __global__ __launch_bounds__(768, 1) void wgrad3_glds_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit_flags, float* __restrict__ ws) {
     using C = W3G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -810,6 +811,8 @@ __global__ __launch_bounds__(768, 1) void wgrad3_glds_kernel(const dasr_wgrad_pa
     if (g_wtrace && threadIdx.x == 0) g_wtrace[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
+
+#endif  // DASR_BENCH
 
 // ---------------------------------------------------------------------------------------------------------------
 // wgrad3 with LOADER WAVES (round 3): the decomposition of wgrad3_glds_kernel (12 compute waves: oc tile x cin tile x tap half, 5 accumulators,
@@ -1303,6 +1306,7 @@ int launch_wgrad3(const dasr_wgrad_part* parts, int nparts, int nsplit, float* w
     return (int)hipGetLastError();
 }
 
+#ifdef DASR_BENCH
 int launch_wgrad3_glds(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -1312,6 +1316,7 @@ int launch_wgrad3_glds(const dasr_wgrad_part* parts, int nparts, int nsplit, flo
     DASR_LAUNCH(wgrad3_glds_kernel, dim3(nparts * (nsplit & 0xffff)), dim3(W3G::NT), W3G::LDS_BYTES, s, parts, nparts, nsplit, ws);
     return (int)hipGetLastError();
 }
+#endif
 
 template <bool F16, int ABL = 0>
 int launch_wgrad4(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws, hipStream_t s) {
@@ -1369,15 +1374,16 @@ extern "C" int dasr_debug_set_wtrace(void* buf) { return (int)hipMemcpyToSymbol(
 #endif
 
 extern "C" int dasr_wgrad_set_mode(int use_tr) {
-    g_wgrad3_stagger = (use_tr & 4) ? 0 : 1;  // bit 2: all waves request the next tile before computing (A/B)
 #ifdef DASR_BENCH
+    g_wgrad3_stagger = (use_tr & 4) ? 0 : 1;  // bit 2: all waves request the next tile before computing (A/B)
     g_wgrad3_abl = (use_tr >> 3) & 0xf;
-#endif
     g_wgrad3_glds = (use_tr & 2) ? 1 : 0;  // bit 1: LDS-DMA wgrad3 instead of the register-staged one (A/B)
     g_wgrad4 = (use_tr & 128) ? 1 : 0;     // bit 7: wgrad4_kernel instead of wgrad3_kernel (A/B)
     g_wgrad3_ld = (use_tr & 256) ? 0 : 1;  // bit 8: the register-staged 12-wave wgrad3_kernel instead of the loader-wave kernel (A/B)
-    use_tr &= 1;
-    g_use_tr = use_tr;
+#else
+    if (use_tr & ~1) return DASR_EINVAL;   // the kernel-selection bits exist in libdasr_hip_ablate.so only
+#endif
+    g_use_tr = use_tr & 1;
     return 0;
 }
 
@@ -1404,8 +1410,8 @@ extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int3
     }
     if (g_use_tr < 0) return DASR_EINVAL;  // dasr_probe_tr16 must run once per process (outside graph capture)
     const bool tr = g_use_tr == 1;
-    if (kh == 33) {  // v3 layout: 6-wave workgroups, 3 oc tiles x 64 cin per part (3x3 stride 1 only)
-#ifdef DASR_BENCH
+    if (kh == 33) {  // 3x3 stride 1 on 16-bit tensors: one part = 64 input channels x up to three 32-oc tiles; wgrad3_ld_kernel (12 compute + 4 loader waves)
+#ifdef DASR_BENCH   // libdasr_hip_ablate.so: the measured alternatives of rounds 2-3 (wgrad3_kernel, wgrad3_glds_kernel, wgrad4_kernel) and their ablations
         if (tr && g_wgrad4 && f32 == 0) switch (g_wgrad3_abl) {
             case 1: return launch_wgrad4<false, 1>(parts_dev, nparts, nsplit, ws, s);
             case 2: return launch_wgrad4<false, 2>(parts_dev, nparts, nsplit, ws, s);
@@ -1418,13 +1424,8 @@ extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int3
             case 15: return launch_wgrad4<false, 15>(parts_dev, nparts, nsplit, ws, s);
             default: break;
         }
-#endif
-        if (tr && g_wgrad3_ld && !g_wgrad4 && !g_wgrad3_glds && !g_wgrad3_abl && f32 != 1)
-            return f32 == 2 ? launch_wgrad3_ld<true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3_ld<false>(parts_dev, nparts, nsplit, ws, s);
         if (tr && g_wgrad4 && f32 != 1) return f32 == 2 ? launch_wgrad4<true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad4<false>(parts_dev, nparts, nsplit, ws, s);
-        if (f32 == 2) return tr ? launch_wgrad3<true, false, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3<false, false, true>(parts_dev, nparts, nsplit, ws, s);
         if (tr && !f32 && g_wgrad3_glds) return launch_wgrad3_glds(parts_dev, nparts, nsplit, ws, s);
-#ifdef DASR_BENCH
         if (tr && !f32) switch (g_wgrad3_abl) {
             case 1: return launch_wgrad3<true, false, false, 1>(parts_dev, nparts, nsplit, ws, s);
             case 2: return launch_wgrad3<true, false, false, 2>(parts_dev, nparts, nsplit, ws, s);
@@ -1437,9 +1438,10 @@ extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int3
             case 15: return launch_wgrad3<true, false, false, 15>(parts_dev, nparts, nsplit, ws, s);
             default: break;
         }
+        if (tr && !g_wgrad3_ld && f32 != 1) return f32 == 2 ? launch_wgrad3<true, false, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3<true, false>(parts_dev, nparts, nsplit, ws, s);
 #endif
-        if (tr) return f32 ? launch_wgrad3<true, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3<true, false>(parts_dev, nparts, nsplit, ws, s);
-        return f32 ? launch_wgrad3<false, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3<false, false>(parts_dev, nparts, nsplit, ws, s);
+        if (!tr || f32 == 1) return DASR_EINVAL;   // gfx950 has ds_read_b64_tr_b16 (dasr_probe_tr16 confirms it); the grouped 3x3 form exists for 16-bit tensors only
+        return f32 == 2 ? launch_wgrad3_ld<true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3_ld<false>(parts_dev, nparts, nsplit, ws, s);
     }
     if (kh == 3 && stride == 1) return dispatch_wgrad<3, 1>(parts_dev, nparts, nsplit, tr, f32, ws, s);
     if (kh == 4 && stride == 1) return dispatch_wgrad<4, 1>(parts_dev, nparts, nsplit, tr, f32, ws, s);

@@ -13,6 +13,18 @@ import torch
 import torch.distributed as dist
 
 
+# process-level switches that change what a rank COMPUTES (numerics) or how its step is scheduled: they must agree on every rank, or the
+# replicas silently diverge.  Checked by DataParallelGroup at start-up.
+RANK_CONSISTENT_ENV = ('DASR_HR_PREC', 'DASR_VGG_PREC', 'DASR_VGG_BWD_PREC', 'DASR_VGG_NOGRAD_PREC', 'DASR_D_PREC', 'DASR_DSN_BWD16', 'DASR_DSN_FWD16',
+                       'DASR_STREAMS', 'DASR_ENQ', 'DASR_TUNE', 'DASR_HIP_LIB', 'DASR_RCCL_NATIVE', 'DASR_DP_BACKEND', 'DASR_ALLOW_NONFINITE')
+
+
+def env_fingerprint():
+    import hashlib
+    items = [(k, os.environ.get(k, '')) for k in RANK_CONSISTENT_ENV]
+    return hashlib.sha1(repr(items).encode()).hexdigest(), items
+
+
 class DataParallelGroup:
     def __init__(self, backend=None, force=False):
         """force: build the process group and run the exchange code even with a single rank (exercises the RCCL / communication-
@@ -41,8 +53,20 @@ class DataParallelGroup:
         # dasr_allreduce -- plain pointers, a stream, no torch types) instead of torch.distributed's RCCL front end; the 128-byte unique
         # id travels through the torch.distributed store.  Default: torch's front end (same RCCL underneath).
         self.native = None
+        if self.world > 1:
+            self.check_env_agreement()
         if self.backend == 'nccl' and self.active and os.environ.get('DASR_RCCL_NATIVE', '0') == '1':
             self._init_native()
+
+    def check_env_agreement(self):
+        """every rank must run with the same DASR_* numerics / schedule switches: one all-gather of a hash at start-up, a loud error otherwise"""
+        digest, items = env_fingerprint()
+        got = [None] * self.world
+        dist.all_gather_object(got, (self.rank, digest, items))
+        if len(set(g[1] for g in got)) > 1:
+            ref = dict(got[0][2])
+            diff = sorted(set(k for g in got for k, v in g[2] if ref.get(k) != v))
+            raise RuntimeError('data-parallel ranks disagree on %s: %s' % (', '.join(diff), '; '.join('rank %d: %s' % (g[0], {k: v for k, v in g[2] if k in diff}) for g in got)))
 
     def _init_native(self):
         import ctypes as C

@@ -228,8 +228,7 @@ class OpList:
 def run_interleaved(lists, streams, chunk=None):
     """Enqueue several op lists on their own streams, alternating in chunks so that every hardware queue gets work
     early (the host enqueues ~250k launches/s; a whole 1200-op list first would leave the other stream idle for ms)."""
-    import os
-    chunk = chunk or int(os.environ.get('DASR_ENQ_CHUNK', '48'))
+    chunk = chunk or 48
     # dasr_run_ops forgets a DASR_OP_SET_STREAM redirect when it returns, so a list is only cut where it is back on its own stream
     cuts = [l.safe_cuts(chunk) for l in lists]
     for k in range(max(len(c) for c in cuts) - 1):
@@ -488,13 +487,8 @@ def ensure_runtime_ready():
         _PROBED = True
         global TR16_OK
         TR16_OK = rc
-        import os
-        if rc == 1 and (os.environ.get('DASR_WGRAD_GLDS', '') in ('0', '1') or os.environ.get('DASR_WGRAD_ABL') or os.environ.get('DASR_WGRAD4', '') in ('0', '1')
-                        or os.environ.get('DASR_WGRAD_LD', '') in ('0', '1')):
-            # A/B switches of the 3x3 weight-gradient kernels: DASR_WGRAD_GLDS=1 LDS-DMA staged wgrad3; DASR_WGRAD4=1 the 4-wave wgrad4_kernel;
-            # DASR_WGRAD_ABL: ablation bits, only honoured by libdasr_hip_ablate.so
-            L.dasr_wgrad_set_mode(1 | (2 if os.environ.get('DASR_WGRAD_GLDS') == '1' else 0) | (int(os.environ.get('DASR_WGRAD_ABL', '0')) << 3) |
-                                  (128 if os.environ.get('DASR_WGRAD4') == '1' else 0) | (256 if os.environ.get('DASR_WGRAD_LD') == '0' else 0))   # DASR_WGRAD_LD=0: register-staged wgrad3_kernel
+        if rc != 1:   # every gfx950 has ds_read_b64_tr_b16; a device without it is not an MI355X
+            raise _lib.DasrHipError('dasr_probe_tr16: this device has no transposing LDS reads (not gfx950); the weight-gradient kernels need them')
     return TR16_OK
 
 

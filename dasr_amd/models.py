@@ -261,7 +261,7 @@ class SRModel(BaseModel):
         self.netG.concurrent_replicas = k  # the 1-WG/CU wgrad launches of the replicas must fit on the chip together
         # deferred dense-block weight gradients: the replicas work on image ranges of ONE set of slabs (TrunkStore) and the weight-gradient
         # phase runs once over the whole batch after both data-gradient chains (rrdbnet.TrunkStore)
-        store = self.netG.trunk_store(N, h, w) if self.netG.defer_wgrad else None
+        store = self.netG.trunk_store(N, h, w)
         sizes = [N // k + (1 if i < N % k else 0) for i in range(k)]   # uneven splits allowed (16 -> 6 + 5 + 5)
         offs = [sum(sizes[:i]) for i in range(k)]
         return [self.netG.plan(sizes[i], h, w, replica=i, store=store, n0=offs[i]) for i in range(k)]

@@ -47,13 +47,15 @@ class RRDBNetHIP:
         self.params = ParamStore(rrdbnet_param_spec(in_nc, out_nc, nf, nb, upsample_mode), self.device)
         self.rdb_prec, self.stream_prec = rdb_prec, stream_prec
         self.hr_prec = int(os.environ.get('DASR_HR_PREC', '2')) if stream_prec == 3 else stream_prec
-        # f16 STORAGE of the HR tail (u1, u2, h0 and their gradients live in HBM as f16): the consumers then run on the LDS-DMA dense-conv
-        # kernel / the 12-wave wgrad kernel with the f16 MFMA instead of the register-staged f32-input kernels (3x faster there), and the
-        # HR tensors cost half the bytes.  DASR_HR_STORE=f32 keeps f32 tensors (f16 rounding while staging)
-        self.hr_f16s = self.hr_prec == 2 and os.environ.get('DASR_HR_STORE', 'f16') == 'f16'
+        # hr_prec 2 (default): f16 STORAGE of the HR tail (u1, u2, h0 and their gradients live in HBM as f16): the consumers run on the LDS-DMA
+        # dense-conv kernel / the grouped wgrad kernel with the f16 MFMA, and the HR tensors cost half the bytes.  DASR_HR_PREC=3 (numerics
+        # switch): split-bf16 on f32 tensors (sub-pixel form of the upconvs), the fall-back when f16's range is not enough.
+        if self.hr_prec not in (2, 3):
+            raise ValueError('DASR_HR_PREC must be 2 (f16 storage) or 3 (split-bf16 on f32 tensors)')
+        self.hr_f16s = self.hr_prec == 2
         self.ps = upsample_mode == 'pixelshuffle'
         if self.ps and not self.hr_f16s:
-            raise NotImplementedError('the PixelShuffle upsampler is built on the f16-storage HR tail (unset DASR_HR_PREC / DASR_HR_STORE)')
+            raise NotImplementedError('the PixelShuffle upsampler is built on the f16-storage HR tail (unset DASR_HR_PREC)')
         self.pack = PackRegistry(self.params)
         self._register_packs()
         self.pack.finalize()
@@ -71,7 +73,7 @@ class RRDBNetHIP:
         # HR-tail weight gradients 5e-4 normwise -- the tolerances are 1e-3 / 1e-2.  fea_conv and LR_conv feed the residual stream of
         # the whole trunk and stay split-bf16.  DASR_HR_PREC=3 restores split-bf16 everywhere.
         hp = self.hr_prec
-        hmt = 2 if (hp == 2 and nf % 64 == 0 and os.environ.get('DASR_HR_MT', '1') == '2') else 1
+        hmt = 1
         self.pk = {}
         # stream convs, forward (prec 3 -> mt 1)
         self.pk['fea'] = self.pack.add(nf, 16, 9, 1, sp, [(P.off('model.0.weight'), nf, self.in_nc, 0, self.in_nc, 0, 0)])
@@ -100,7 +102,7 @@ class RRDBNetHIP:
         # input pixel, channel pair and 2x2 output block.  Row taps per parity: py=0 reads rows (i-1, i) with (w0, w1+w2), py=1 rows
         # (i, i+1) with (w0+w1, w2); same along x.  The data gradient is the transpose: per parity a 2x2 conv of that parity's
         # sub-grid of the output gradient with the tap order reversed, summed over the four parities.
-        self.subpixel = os.environ.get('DASR_SUBPIXEL', '1') == '1' and not self.hr_f16s
+        self.subpixel = not self.hr_f16s   # f32-tensor tail (DASR_HR_PREC=3): the upconvs run in their sub-pixel form
         rows = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}   # parity -> source taps of packed tap a = 0, 1
         for name, key in (() if self.hr_f16s else (('up1', 'model.3.weight'), ('up2', 'model.6.weight'))):
             for py in (0, 1):
@@ -147,12 +149,10 @@ class RRDBNetHIP:
             self.plans[key] = _Plan(self, N, h, w, replica, store=store, n0=n0)
         return self.plans[key]
 
-    @property
-    def defer_wgrad(self):
-        """dense-block weight gradients as a separate phase AFTER the data-gradient chain (default): grouped launches over the whole batch with the
-        chip to themselves, instead of one launch per RRDB interleaved with (and, under two sub-batch streams, competing with) the data-gradient
-        convs.  Costs one gradient slab per RDB (3 nb x 50 MB at batch 8 x 128^2) instead of a ring of four.  DASR_WG_DEFER=0: round-2 schedule."""
-        return os.environ.get('DASR_WG_DEFER', '1') != '0'
+    # dense-block weight gradients run as a separate phase AFTER the data-gradient chain (TrunkStore.phase): grouped launches over the whole batch
+    # with the chip to themselves, instead of one launch per RRDB interleaved with (and, under two sub-batch streams, competing with) the
+    # data-gradient convs (round 2's schedule, -1.2 ms; removed in round 4).  Costs one gradient slab per RDB (3 nb x 50 MB at batch 8 x 128^2).
+    defer_wgrad = True
 
     def trunk_store(self, N, h, w):
         key = (N, h, w)
@@ -225,7 +225,7 @@ def rdb_wgrad_parts(grp, nf, pre, P, Gs, S, h, w, N):
 class TrunkStore:
     """Forward slabs and gradient slabs of ALL dense blocks for a whole batch of N images (one allocation per RDB; sub-batch replicas work on
     image ranges of it), and the deferred weight-gradient phase over them: after the data-gradient chain has filled every gradient slab, the
-    weight gradients of the 3 nb dense blocks are computed by a few grouped launches (4 RRDBs per launch by default, DASR_WG_GROUP: every
+    weight gradients of the 3 nb dense blocks are computed by a few grouped launches (4 RRDBs per launch: every
     launch has ~240 workgroups of 12 waves, one per CU, nothing co-resident; four pixel splits instead of sixteen: a quarter of round 2's
     fp32 partial-sum traffic of 24.8 MB written and re-read per RRDB)."""
 
@@ -252,8 +252,8 @@ class TrunkStore:
     def _build_phase(self):
         net, N, h, w = self.net, self.N, self.h, self.w
         nf, nb, P = net.nf, net.nb, net.params
-        target = int(os.environ.get('DASR_WG3_TARGET', '256'))
-        gmax = max(1, int(os.environ.get('DASR_WG_GROUP', '4')))   # RRDBs per launch: 4 measured best (16: -1 %, 1: -1.5 %; profiles/r03b_*)
+        target = 256   # workgroups per launch: one 16-wave workgroup per CU
+        gmax = 4       # RRDBs per launch: 4 measured best (16: -1 %, 1: -1.5 %; profiles/r03_wgrad_ablation.txt)
         self.phase = OpList()
         self.groups = []   # (first op, end op, lo, hi): ops [first, end) complete params.grad[lo:hi]; descending parameter order
         hi_rrdb = nb
@@ -305,7 +305,7 @@ class _Plan:
         self.replica = replica
         # deferred dense-block weight gradients (TrunkStore): shared = the store belongs to a group of sub-batch replicas and the trainer runs
         # its phase after all of them; otherwise the plan owns a store of its own batch and the phase is part of plan.bwd
-        self.defer = (not inference) and (store is not None or net.defer_wgrad)
+        self.defer = not inference
         self.shared_store = store is not None
         self.store = store if store is not None else (TrunkStore(net, N, h, w) if self.defer else None)
         self.n0 = n0
@@ -325,10 +325,8 @@ class _Plan:
         if inference:   # nothing is kept for a backward pass: two slabs alternate through the 3 nb dense blocks
             ab = [B(sc, h, w, False), B(sc, h, w, False)]
             self.slabs = [ab[i & 1] for i in range(3 * nb)]
-        elif self.defer:
-            self.slabs = [self.store.slab(r, n0, N) for r in range(3 * nb)]
         else:
-            self.slabs = [B(sc, h, w, False) for _ in range(3 * nb)]
+            self.slabs = [self.store.slab(r, n0, N) for r in range(3 * nb)]
         self.stream = [B(nf, h, w, True) for _ in range(4)]
         self.t0 = B(nf, h, w, True)
         hs = net.hr_f16s
@@ -354,13 +352,9 @@ class _Plan:
         self.g2b = Bh(nf, H2, W2)
         self.g_t0 = B(nf, h, w, True)
         self.gstream = [B(nf, h, w, True) for _ in range(4)]
-        # weight gradients of `wg_batch` consecutive RDBs share one launch (see _build_backward_trunk): wg_batch + 1 gradient slabs rotate.
-        # (A side stream for the RDB weight gradients was tried in round 1 and was slower -- they take CUs from the serial data-gradient
-        # chain of their own sub-batch -- and has been removed.)
-        self.wg_batch = max(1, int(os.environ.get('DASR_WG_BATCH', '3')))
-        self.n_gslab = 3 * nb if self.defer else self.wg_batch + 1
-        # deferred: one gradient slab per RDB, in the order the backward chain visits them (RDB 3 nb - 1 first)
-        self.gslab = [self.store.gslab(3 * nb - 1 - k, n0, N) for k in range(3 * nb)] if self.defer else [B(sc, h, w, False) for _ in range(self.n_gslab)]
+        # one gradient slab per RDB (kept for the deferred weight-gradient phase), in the order the backward chain visits them (RDB 3 nb - 1 first)
+        self.n_gslab = 3 * nb
+        self.gslab = [self.store.gslab(3 * nb - 1 - k, n0, N) for k in range(3 * nb)]
         self.g_fea = B(nf, h, w, True)
         self.ws = Workspace(dev)
         self._build_forward()
@@ -516,8 +510,6 @@ class _Plan:
     def _wg3_target(self, nparts):
         """workgroups of a 12-wave weight-gradient launch (one per CU, nothing co-resides with them): the whole chip for a single plan, an equal
         share for each of k concurrent sub-batch replicas"""
-        if os.environ.get('DASR_WG3_TARGET'):
-            return int(os.environ['DASR_WG3_TARGET'])
         return 256 // max(1, getattr(self.net, 'concurrent_replicas', 1))
 
     def _wg3(self, ops, conv_key, g, inp, cout, cin, Hin, Win, Hout, Wout, ups=0):
@@ -639,28 +631,13 @@ class _Plan:
         self._wg(ops, lrk, self.g_t0, True, self.x_last, True, nf, nf, h, w, h, w)
         # gradient buckets: (index into ops, lo, hi): params.grad[lo:hi] is complete once ops[:index] have run
         self._marks = [(len(ops.ops), P.off(lrk + 'weight'), P.total)]
-        bucket_every = max(1, ceil_div(nb, 4))
         free = list(self.gstream)
         G = free[0]
         gs_cur = 0
         ops.add(conv_op(pack, pk['lr_b'], self.g_t0.view(), True, nf, h, w, h, w, N, out_f32=G.view(),
                         out_bf16=self.gslab[gs_cur].view(0), gamma=0.04))
-        # RRDB chain, reversed.  Round-2 schedule (DASR_WG_DEFER=0): the weight gradients of `wgb` consecutive RDBs (default: the three of an
-        # RRDB) go into ONE launch behind their data-gradient convs: wgb + 1 gradient slabs in a ring.  Deferred (default): no weight-gradient
-        # launch inside the chain; every RDB keeps its gradient slab and TrunkStore.phase computes all of them afterwards.
-        wgb = self.wg_batch
-        grp, n_in_grp = None, 0
-
-        def flush_wgrad():
-            nonlocal grp, n_in_grp
-            if grp is None:
-                return
-            grp.finalize(self.ws, net.device, target_wgs=self._wg3_target(len(grp.parts)))
-            for o in grp.ops(self.grad.data_ptr()):
-                ops.add(o)
-            ops.keep.append(grp)
-            grp, n_in_grp = None, 0
-
+        # RRDB chain, reversed.  No weight-gradient launch inside the chain: every RDB keeps its gradient slab and TrunkStore.phase computes all
+        # of them afterwards (grouped launches over the whole batch).
         for i in range(nb - 1, -1, -1):
             Grr = G  # grad wrt the RRDB output
             Gout = None  # grad wrt the current RDB output (None: it is 0.2*Grr, folded into the epilogue)
@@ -671,17 +648,10 @@ class _Plan:
                     cin_b = nf + (4 - k) * GC
                     ops.add(conv_op(pack, pk[(i, r, 'b', k)], Gs.view(0), False, cin_b, h, w, h, w, N,
                                     mask=S.view(nf + (k - 1) * GC), mask_f32=0, out_bf16=Gs.view(cin_b)))
-                if not self.defer:
-                    if grp is None:
-                        grp = WgradGroup3()
-                        grp.flops = 0.0
-                    _, fl = rdb_wgrad_parts(grp, nf, 'model.1.sub.%d.RDB%d.conv' % (i, r), P, Gs, S, h, w, N)
-                    grp.flops += fl
-                    n_in_grp += 1
                 # g_x conv with the residual bookkeeping fused
                 Gin = next(b for b in free if b is not Grr and b is not Gout)
                 first = (ridx == 0)
-                nxt = None if first else self.gslab[(gs_cur + 1) % self.n_gslab].view(0)
+                nxt = None if first else self.gslab[gs_cur + 1].view(0)
                 if r == 3:
                     ops.add(conv_op(pack, pk[(i, r, 'b', 0)], Gs.view(0), False, nf + 4 * GC, h, w, h, w, N,
                                     res1=Grr.view(), beta1=0.2, out_f32=Gin.view(), out_bf16=nxt, gamma=0.2))
@@ -692,25 +662,16 @@ class _Plan:
                     ops.add(conv_op(pack, pk[(i, r, 'b', 0)], Gs.view(0), False, nf + 4 * GC, h, w, h, w, N,
                                     res1=Gout.view(), beta1=1.0, res2=Grr.view(), beta2=1.0, out_f32=Gin.view(), out_bf16=nxt, gamma=0.04))
                 Gout = Gin
-                gs_cur = (gs_cur + 1) % self.n_gslab
-                if n_in_grp >= wgb:
-                    flush_wgrad()
+                gs_cur += 1
             G = Gout
-            if not self.defer and i > 0 and i % bucket_every == 0:
-                flush_wgrad()   # a gradient bucket is complete only when its weight gradients have been reduced
-                lo = P.off('model.1.sub.%d.RDB1.conv1.0.weight' % i)
-                self._marks.append((len(ops.ops), lo, self._marks[-1][1]))
-        flush_wgrad()
         rrdb0 = P.off('model.1.sub.0.RDB1.conv1.0.weight')
-        if self.defer and not self.shared_store:   # this plan owns the whole batch: the weight-gradient phase follows the chain in the same list
+        if not self.shared_store:   # this plan owns the whole batch: the weight-gradient phase follows the chain in the same list
             st = self.store
             for first_op, end_op, lo, hi in st.groups:
                 ops.ops.extend(st.phase.ops[first_op:end_op])
                 self._marks.append((len(ops.ops), lo, hi))
             ops.keep.append(st)
             ops._arr = None
-        elif not self.defer:
-            self._marks.append((len(ops.ops), rrdb0, self._marks[-1][1]))
         # ShortcutBlock: g_fea = g_chain + g_t0
         o = Op()
         o.op = _lib.OP_AXPBY

@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, case, out, streams):
+def _worker(rank, world, port, case, out, streams, shard=None):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                       DASR_STREAMS=str(streams))
     import torch
@@ -39,17 +39,27 @@ def _worker(rank, world, port, case, out, streams):
     batch = fixtures.make_batch(case)
     if dp:
         batch = shard_minibatch(batch, rank, world)
+    elif shard is not None:   # single process on ONE rank's shard (what a replica of the reference's nn.DataParallel sees)
+        batch = shard_minibatch(batch, shard[0], shard[1])
+    grads = None
     for step in (1, 2):
         m.update_learning_rate()
         m.feed_data(batch, True) if kind == 'dasr' else m.feed_data(batch)
         m.optimize_parameters(step)
+        if step == 1:
+            torch.cuda.synchronize()
+            grads = {'G': m.netG.params.grad_dict()}
+            if kind == 'dasr':
+                grads['D'] = m.netD_target.params.grad_dict()
+                if m.netD_source is not None:
+                    grads['D2'] = m.netD_source.params.grad_dict()
     torch.cuda.synchronize()
-    res = {'G': m.netG.state_dict(), 'log': dict(m.get_current_log())}
+    res = {'G': m.netG.state_dict(), 'log': dict(m.get_current_log()), 'grads': grads}
     if kind == 'dasr':
         res['D'] = m.netD_target.state_dict()
         if m.netD_source is not None:
             res['D2'] = m.netD_source.state_dict()
-    torch.save(res, out % (world, rank))
+    torch.save(res, out % (world, rank if shard is None else 100 + shard[0]))
     if dp:
         dp.barrier()
 
@@ -86,6 +96,74 @@ def test_two_rank_step_equals_full_batch_step(case, streams, tmp_path, margins):
                if not (isinstance(case, dict) and case.get('ragan') and k == 'model.8.bias'))
     margins('DP 2 ranks vs full batch (%s, %d streams): max |dw| after 2 Adam steps %.2e (bound 3.2e-4)' % (
         case if isinstance(case, str) else ('sr_nf64_nb2_b16_32' if case['kind'] == 'sr' else 'dasr_ragan_srcD_n4'), streams, dmax))
+
+
+# configs[3]'s partition at world 8: global n = 16 -> 2 source + 2 target crops per rank, [fake ; real] halves balanced on
+# every rank (dist.shard_minibatch), InstanceNorm patch discriminator + VGG features: per-sample ops only, so 8 ranks == the full batch
+W8 = dict(kind='dasr', nf=32, nb=1, n=16, lr=32, fs='wavelet', d_in_nc=9)
+
+
+def test_eight_rank_step_equals_full_batch_step(tmp_path, margins):
+    """eight processes on this one device (gloo on CUDA tensors; RCCL refuses to share a device): the rank-0 weights after two steps equal the
+    single-process step on the 16 + 16 crops, all eight replicas bit-identical.  Replaces nn.DataParallel (networks.py:144-146) at the world
+    size the driver's scaling run uses; no 8-GPU hardware is available to the builder, this is the by-construction check."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'w%d_r%d.pt')
+    port = 29111 + (os.getpid() % 300)
+    mp.spawn(_worker, args=(1, port, W8, out, 1), nprocs=1, join=True)
+    mp.spawn(_worker, args=(8, port + 1, W8, out, 1), nprocs=8, join=True)
+    full = torch.load(out % (1, 0))
+    rs = [torch.load(out % (8, r)) for r in range(8)]
+    dmax = 0.0
+    for net in ('G', 'D'):
+        for k, v in full[net].items():
+            for r in rs[1:]:
+                assert torch.equal(rs[0][net][k], r[net][k]), (net, k)
+            d = (rs[0][net][k] - v).abs().max().item()
+            dmax = max(dmax, d)
+            assert d <= 3.2e-4, (net, k, d)
+            assert ((rs[0][net][k] - v).abs() > 2e-5).float().mean().item() < 0.02, (net, k)
+        for k, g in full['grads'][net].items():   # step-1 gradients: mean over the 8 shards == full batch
+            e = float((rs[0]['grads'][net][k] - g).norm() / (g.norm() + 1e-30))
+            assert e < 2e-5 or float(g.norm()) < 1e-9, (net, k, e)
+    margins('DP 8 ranks vs full batch (dasr n=16, 2 + 2 crops per rank): max |dw| after 2 Adam steps %.2e (bound 3.2e-4)' % dmax)
+
+
+# BatchNorm source discriminator under data parallelism: batch statistics are PER RANK (as in the reference's nn.DataParallel replicas,
+# gan_nets.py / DESIGN 4.7), so the two-rank step is NOT the full-batch step: it is the mean of the two single-rank steps on the shards
+BN2 = dict(kind='dasr', nf=32, nb=1, n=4, lr=32, fs='gau', d_in_nc=3, gan_src=0.02, pairD='discriminator_vgg_128')
+
+
+def test_two_rank_batchnorm_discriminator_uses_per_rank_statistics(tmp_path, margins):
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'w%d_r%d.pt')
+    port = 29711 + (os.getpid() % 300)
+    for sh in (0, 1):
+        mp.spawn(_worker, args=(1, port + sh, BN2, out, 1, (sh, 2)), nprocs=1, join=True)
+    mp.spawn(_worker, args=(2, port + 2, BN2, out, 1), nprocs=2, join=True)
+    s0, s1 = torch.load(out % (1, 100)), torch.load(out % (1, 101))
+    r0, r1 = torch.load(out % (2, 0)), torch.load(out % (2, 1))
+    worst = 0.0
+    for net in ('G', 'D', 'D2'):
+        for k, g0 in s0['grads'][net].items():
+            want = 0.5 * (g0 + s1['grads'][net][k])
+            got = r0['grads'][net][k]
+            assert torch.equal(got, r1['grads'][net][k]), (net, k)
+            e = float((got - want).norm() / (want.norm() + 1e-30))
+            worst = max(worst, e)
+            assert e < 1e-4 or float(want.norm()) < 1e-9, (net, k, e)
+        for k, v in r0[net].items():
+            if 'running' in k or 'num_batches' in k:
+                continue   # BatchNorm buffers are per-rank state (each replica tracks the statistics of its own shard, like nn.DataParallel's replica 0)
+            assert torch.equal(v, r1[net][k]), (net, k)
+    # ... and it differs from pooled statistics: rank 0's running mean is that of ITS shard
+    k_rm = [k for k in r0['D2'] if k.endswith('running_mean')][0]
+    assert torch.allclose(r0['D2'][k_rm], s0['D2'][k_rm], rtol=1e-4, atol=1e-6) and not torch.allclose(r0['D2'][k_rm], r1['D2'][k_rm], rtol=1e-4, atol=1e-7)
+    margins('DP 2 ranks, BatchNorm source discriminator: gradients == mean of the per-shard steps, worst rel err %.2e (bound 1e-4)' % worst)
 
 
 def _rccl_worker(rank, port, out, streams, use_dp, native=0):
@@ -135,7 +213,7 @@ def test_rccl_exchange_path_single_rank(streams, native, tmp_path):
         assert torch.equal(v, b['G'][k]), k
 
 
-def _dsn_worker(rank, world, port, out, ragan=False):
+def _dsn_worker(rank, world, port, out, ragan=False, n_total=None):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     import torch
     from dasr_amd.dist import DataParallelGroup
@@ -152,7 +230,7 @@ def _dsn_worker(rank, world, port, out, ragan=False):
         for net in m.networks():
             dp.broadcast_params(net.params.flat)
             net.repack()
-    n = 4 if ragan else 2   # relativistic: two samples per rank, so the GLOBAL batch means differ from the per-rank ones
+    n = n_total or (4 if ragan else 2)   # relativistic: two samples per rank, so the GLOBAL batch means differ from the per-rank ones
     hr, bic, real = dsn_batch(dict(n=n, crop=128))  # VGG16's five pools need >= 32 px LR
     if dp:
         per = n // world
@@ -189,3 +267,27 @@ def test_dsn_two_rank_iteration_equals_full_batch(ragan, tmp_path):
             assert d <= 4.2e-4, (net, k, d)   # two Adam steps at lr 1e-4: a flipped ~0 gradient moves a weight by <= 2*lr per step
             if v.numel() > 64:
                 assert ((r0[net][k] - v).abs() > 2e-5).float().mean().item() < 0.03, (net, k)
+
+
+def test_dsn_eight_rank_iteration_equals_full_batch(tmp_path):
+    """configs[4]'s data-parallel leg by construction: batch 8 -> ONE crop per rank (InstanceNorm discriminator on a 1-image
+    rank, per-sample ops only); eight processes on one device over gloo reproduce the 8-crop iteration"""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'dsn_w%d_r%d.pt')
+    port = 29311 + (os.getpid() % 300)
+    mp.spawn(_dsn_worker, args=(1, port, out, False, 8), nprocs=1, join=True)
+    mp.spawn(_dsn_worker, args=(8, port + 1, out, False, 8), nprocs=8, join=True)
+    full = torch.load(out % (1, 0))
+    rs = [torch.load(out % (8, r)) for r in range(8)]
+    for net in ('G', 'D'):
+        for k, v in full[net].items():
+            for r in rs[1:]:
+                assert torch.equal(rs[0][net][k], r[net][k]), (net, k)
+            if k in ('net.net.2.bias', 'net.net.5.bias'):
+                continue  # bias in front of an InstanceNorm: true gradient 0
+            d = (rs[0][net][k] - v).abs().max().item()
+            assert d <= 4.2e-4, (net, k, d)
+            if v.numel() > 64:
+                assert ((rs[0][net][k] - v).abs() > 2e-5).float().mean().item() < 0.03, (net, k)

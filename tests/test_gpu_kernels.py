@@ -115,20 +115,30 @@ def test_conv_forward_matches_torch(case):
         assert float(pad_part.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('variant', [0, 1, 4, 5, 8, 9, 10, 11, 13])
-@pytest.mark.parametrize('case', CONV_CASES[:3], ids=[c[0] for c in CONV_CASES[:3]])
-def test_conv_tuning_variants_match_torch(case, variant):
-    """the A/B-able variants of the dense-block conv (dasr_set_tuning keys 1, 2; default 12 = LDS-DMA kernel, 0 = first-generation
-    kernel, others: double buffering, tile heights, row reuse, register-staged pipeline)"""
+def test_product_library_has_one_dense_conv_family():
+    """round 4: the A/B variants of rounds 1-3 (first-generation tilings, ring / loader / flag forms, dasr_set_tuning keys 1-6) live in
+    libdasr_hip_ablate.so only; the product library accepts the defaults and the workgroup-shape rule of the Cout = 64 launches (key 2)"""
     _gpu()
     from dasr_amd import _lib
     L = _lib.lib()
-    key = 2 if case[3] == 2 else 1
-    _lib.check(L.dasr_set_tuning(key, variant))
+    for key, value in ((1, 0), (1, 13), (1, 14), (1, 15), (2, 0), (2, 8), (3, 1), (4, 0), (5, 0), (6, 1)):
+        assert L.dasr_set_tuning(key, value) == -22, (key, value)
+    for key, value in ((1, 12), (2, 12), (2, 13), (3, 0), (4, 1), (5, 1), (6, 0)):
+        assert L.dasr_set_tuning(key, value) == 0, (key, value)
+    assert L.dasr_wgrad_set_mode(1 | 128) == -22 and L.dasr_wgrad_set_mode(1 | 2) == -22 and L.dasr_wgrad_set_mode(1) == 0
+
+
+@pytest.mark.parametrize('case', [c for c in CONV_CASES[:3] if c[3] == 2], ids=[c[0] for c in CONV_CASES[:3] if c[3] == 2])
+def test_conv64_four_wave_shape_matches_torch(case):
+    """dasr_set_tuning(2, 12): Cout = 64 launches always in the 4-wave shape (default 13: 8 waves for launches of <= 256 four-wave workgroups)"""
+    _gpu()
+    from dasr_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.dasr_set_tuning(2, 12))
     try:
         test_conv_forward_matches_torch(case)
     finally:
-        _lib.check(L.dasr_set_tuning(key, 12))
+        _lib.check(L.dasr_set_tuning(2, 13))
 
 
 @pytest.mark.parametrize('tune64', [12, 13], ids=['4waves', '8waves'])

@@ -178,31 +178,8 @@ def test_checkpoint_layout_roundtrip(tmp_path):
         assert torch.equal(v, m2.netG.state_dict()[k]), k
 
 
-def test_wgrad4_kernel_equals_wgrad3_kernel():
-    """the 4-wave LDS-DMA weight-gradient kernel of round 3 (dasr_wgrad_set_mode bit 7; slower than the 12-wave wgrad3_kernel, kept as an alternative,
-    DESIGN.md) must give the same gradients: same step twice on fresh models, once per kernel -- dense blocks (bf16) and HR tail (f16) launches"""
-    dev = _gpu()
-    from oracle import fixtures
-    from dasr_amd import options, _lib, engine
-    from dasr_amd.models import create_model
-    if engine.ensure_runtime_ready() != 1:
-        pytest.skip('transpose LDS reads not available')
-    case = 'sr_nf64_nb2_b2_32'
-    L = _lib.lib()
-    grads = []
-    try:
-        for mode in (1, 1 | 128):
-            _lib.check(L.dasr_wgrad_set_mode(mode))
-            opt = fixtures.make_opt(case)
-            opt['gpu_ids'] = [0]
-            m = create_model(options.dict_to_nonedict(opt))
-            m.netG.load_state_dict(fixtures.seeded_state_dict(m.netG.state_dict(), 1, 0.1))
-            m.update_learning_rate()
-            m.feed_data(fixtures.make_batch(case))
-            m.optimize_parameters(1)
-            torch.cuda.synchronize()
-            grads.append(m.netG.params.grad_dict())
-    finally:
-        _lib.check(L.dasr_wgrad_set_mode(1))
-    worst = max(rel(grads[1][k], v) for k, v in grads[0].items())
-    assert worst < 2e-5, worst   # same products, different fp32 summation order
+def test_sr_step_with_split_bf16_hr_tail(golden_dir, margins, monkeypatch):
+    """DASR_HR_PREC=3: the HR tail on f32 tensors in split-bf16 with sub-pixel upconvs -- the fall-back the non-finite-gradient guard points to when
+    f16's range is not enough (models.py::AdamHIP.check_finite); same fixture, same tolerances as the default f16-storage tail"""
+    monkeypatch.setenv('DASR_HR_PREC', '3')
+    test_sr_step_matches_oracle_and_reference_fixture('sr_nf64_nb2_b2_32', golden_dir, margins)

@@ -153,6 +153,48 @@ def test_gloo_world2_bucketed_allreduce(tmp_path):
     assert r0['max'] == 1.0 and r1['max'] == 1.0
 
 
+def _env_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    if rank == 1:
+        os.environ['DASR_VGG_PREC'] = '2'   # one rank with a different numerics switch
+    from dasr_amd.dist import DataParallelGroup
+    try:
+        DataParallelGroup(backend='gloo')
+        msg = 'no error'
+    except RuntimeError as e:
+        msg = str(e)
+    open(out % rank, 'w').write(msg)
+
+
+def test_ranks_must_agree_on_numerics_switches(tmp_path):
+    """defaults-by-environment-variable is how an 8-rank run silently diverges between ranks; the group hashes the
+    DASR_* numerics / schedule switches at start-up and every rank fails loudly on a mismatch"""
+    import torch.multiprocessing as mp
+    port = 29811 + (os.getpid() % 200)
+    out = str(tmp_path / 'env_r%d.txt')
+    mp.spawn(_env_worker, args=(2, port, out), nprocs=2, join=True)
+    for r in (0, 1):
+        msg = open(out % r).read()
+        assert 'disagree on DASR_VGG_PREC' in msg, msg
+
+
+def test_product_library_carries_one_kernel_family_per_op():
+    """the measured-slower alternatives (wgrad3_kernel, wgrad3_glds_kernel, wgrad4_kernel, conv_ring3_kernel, the
+    ring / loader-wave forms of the dense conv) are compiled into libdasr_hip_ablate.so (-DDASR_BENCH) only"""
+    from dasr_amd import _lib
+    data = open(_lib.LIB_PATH, "rb").read()
+    fams = set(m.decode() for m in re.findall(rb'(conv_ring3_kernel|wgrad4_kernel|wgrad3_glds_kernel|wgrad3_kernel|wgrad3_ld_kernel|conv_glds_kernel|conv_kernel|wgrad_kernel)', data))
+    assert fams == {'conv_glds_kernel', 'conv_kernel', 'wgrad3_ld_kernel', 'wgrad_kernel'}, fams
+    # no ring / loader-wave instantiation of the LDS-DMA conv (template argument RING != 0): mangled names end in ...Lb<F16>ELi<RING>EEEv...
+    rings = set(re.findall(rb'conv_glds_kernelILi\d+ELi\d+ELi\d+ELi(\d+)ELb[01]ELi(\d+)EE', data))
+    assert rings and all(abl == b'0' and ring == b'0' for abl, ring in rings), rings
+    # the environment switches that selected them are gone from the host code
+    src = ''.join(open(os.path.join(ROOT, 'dasr_amd', f)).read() for f in os.listdir(os.path.join(ROOT, 'dasr_amd')) if f.endswith('.py'))
+    for gone in ('DASR_WGRAD4', 'DASR_WGRAD_GLDS', 'DASR_WGRAD_LD', 'DASR_WGRAD_ABL', 'DASR_WG_DEFER', 'DASR_WG_BATCH', 'DASR_WG_GROUP', 'DASR_WG3_TARGET',
+                 'DASR_HR_STORE', 'DASR_HR_MT', 'DASR_SUBPIXEL', 'DASR_ENQ_CHUNK'):
+        assert gone not in src, gone
+
+
 def test_product_path_does_not_import_oracle():
     for root, _, files in os.walk(os.path.join(ROOT, 'dasr_amd')):
         for f in files:
