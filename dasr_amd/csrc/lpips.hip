@@ -23,7 +23,23 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 // mode 0: y[n][c][Y][X][by*4+bx] = sc[c] * x[n][c][4Y+by-2][4X+bx-2] + sh[c] inside the image, 0 outside (the conv's zero padding is applied
 // to the SCALED input); y has 3 planes (plane = colour), Hs x Ws = (H+4)/4 x (W+4)/4.
 // mode 1 (adjoint): x[n][c][y][x] += sc[c] * y[n][c][(y+2)>>2][(x+2)>>2][((y+2)&3)*4 + ((x+2)&3)]  (x: plane 0 of a blocked tensor, channels 0..2)
-__global__ void lpips_s2d_kernel(dasr_tensor x, int N, int H, int W, f32x4 sc, f32x4 sh, dasr_tensor y, int mode) {
+// xf (DSN --lpips_rot_flip, codes/DSN/loss.py:149-168): the network sees T(x) instead of x, T = one of the 8 symmetries of the square:
+// T(x)[i][j] = x[u][v] with (u, v) = (i, j), swapped if bit 0 (transpose), then u -> H-1-u if bit 1, v -> W-1-v if bit 2.  Mode 0 reads through
+// that map; mode 1 routes the gradient of T(x) back to the pixel it came from.  Transposing forms need H == W.
+__device__ __forceinline__ void dihedral_src(int i, int j, int H, int W, int xf, int& u, int& v) {
+    u = (xf & 1) ? j : i;
+    v = (xf & 1) ? i : j;
+    if (xf & 2) u = H - 1 - u;
+    if (xf & 4) v = W - 1 - v;
+}
+__device__ __forceinline__ void dihedral_dst(int u, int v, int H, int W, int xf, int& i, int& j) {   // inverse of dihedral_src
+    if (xf & 2) u = H - 1 - u;
+    if (xf & 4) v = W - 1 - v;
+    i = (xf & 1) ? v : u;
+    j = (xf & 1) ? u : v;
+}
+
+__global__ void lpips_s2d_kernel(dasr_tensor x, int N, int H, int W, f32x4 sc, f32x4 sh, dasr_tensor y, int mode, int xf) {
     const int Hs = (H + 4) >> 2, Ws = (W + 4) >> 2;
     if (mode == 0) {
         const long long total = (long long)N * 3 * Hs * Ws * 4;   // one thread: one colour, one s2d pixel, one row `by` of its 4x4 block
@@ -42,7 +58,9 @@ __global__ void lpips_s2d_kernel(dasr_tensor x, int N, int H, int W, f32x4 sc, f
         for (int bx = 0; bx < 4; ++bx) {
             const int sx = 4 * X + bx - 2;
             const bool ok = (sy >= 0) & (sy < H) & (sx >= 0) & (sx < W);
-            v[bx] = ok ? xp[((size_t)sy * W + sx) * 16] * sc[c] + sh[c] : 0.f;
+            int u = sy, w_ = sx;
+            if (xf) dihedral_src(sy, sx, H, W, xf, u, w_);
+            v[bx] = ok ? xp[((size_t)u * W + w_) * 16] * sc[c] + sh[c] : 0.f;
         }
         *(f32x4*)((float*)y.p + (size_t)n * y.n_stride + (size_t)c * y.cb_stride + ((size_t)Y * Ws + X) * 16 + by * 4) = v;
     } else {
@@ -51,9 +69,15 @@ __global__ void lpips_s2d_kernel(dasr_tensor x, int N, int H, int W, f32x4 sc, f
         if (gi >= total) return;
         const int n = gi / ((long long)H * W);
         const long long p = gi - (long long)n * H * W;
-        const int py = p / W, px = p - (long long)py * W;
-        const int Y = (py + 2) >> 2, X = (px + 2) >> 2, b = ((py + 2) & 3) * 4 + ((px + 2) & 3);
+        int py = p / W, px = p - (long long)py * W;   // the pixel of x that receives the gradient; (py, px) below: where it sits in T(x)
         float* xp = (float*)x.p + (size_t)n * x.n_stride + (size_t)p * 16;
+        if (xf) {
+            int i, j;
+            dihedral_dst(py, px, H, W, xf, i, j);
+            py = i;
+            px = j;
+        }
+        const int Y = (py + 2) >> 2, X = (px + 2) >> 2, b = ((py + 2) & 3) * 4 + ((px + 2) & 3);
         const float* yp = (const float*)y.p + (size_t)n * y.n_stride + ((size_t)Y * Ws + X) * 16 + b;
 #pragma unroll
         for (int c = 0; c < 3; ++c) xp[c] += sc[c] * yp[(size_t)c * y.cb_stride];
@@ -199,11 +223,13 @@ __global__ void lpips_head_kernel(dasr_tensor f, long long pair_off, int N, int 
 
 extern "C" int dasr_lpips_s2d(dasr_tensor x, int32_t N, int32_t H, int32_t W, const float* scale4, const float* shift4, dasr_tensor y, int32_t mode,
                               void* stream) {
-    if (N <= 0 || H <= 0 || W <= 0 || (H & 3) || (W & 3) || (mode != 0 && mode != 1)) return DASR_EINVAL;
+    const int xf = (mode >> 4) & 7;   // bits 4-6: symmetry of the square applied in front of the network (transpose, flip rows, flip columns)
+    mode &= 15;
+    if (N <= 0 || H <= 0 || W <= 0 || (H & 3) || (W & 3) || (mode != 0 && mode != 1) || ((xf & 1) && H != W)) return DASR_EINVAL;
     const int Hs = (H + 4) >> 2, Ws = (W + 4) >> 2;
     const long long total = mode == 0 ? (long long)N * 3 * Hs * Ws * 4 : (long long)N * H * W;
     const f32x4 sc = {scale4[0], scale4[1], scale4[2], 0.f}, sh = {shift4[0], shift4[1], shift4[2], 0.f};
-    DASR_LAUNCH(lpips_s2d_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, H, W, sc, sh, y, mode);
+    DASR_LAUNCH(lpips_s2d_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, H, W, sc, sh, y, mode, xf);
     return (int)hipGetLastError();
 }
 

@@ -297,9 +297,34 @@ class DASR_Model(BaseModel):
         if not tsamples and self.opt['val_lpips']:
             self.LPIPS = lpips_metric(self.cri_fea_lpips, self.fake_H, self.var_H)   # DASR_model.py:340-344
 
+    def filter_high(self, x):
+        """self.filter_high of the reference (DASR_model.py:58,61-66: FilterHigh(kernel_size=fs_kernel_size, gaussian = fs is not 'avgpool'),
+        architecture.py:1228-1243): 0.5 + 0.5 * (x - lowpass(x)), k x k depthwise filter with zero padding, on the device (dasr_lowpass).
+        x: NCHW fp32 CUDA tensor -> NCHW fp32 CUDA tensor.  Used by the training-sample visuals (train.py:123-172)."""
+        from .engine import BTensor
+        N, C_, H, W = x.shape
+        k = int(self.opt['train']['fs_kernel_size'] or 5)
+        key = ('fh', k, self.fs == 'avgpool')
+        if getattr(self, '_fh_w', (None,))[0] != key:
+            w = torch.full((k, k), 1.0 / (k * k)) if self.fs == 'avgpool' else gaussian_kernel2d(k)
+            self._fh_w = (key, w.contiguous().to(self.device))
+        xb, hb = BTensor(N, 16, H, W, True, self.device), BTensor(N, 16, H, W, True, self.device)
+        out = torch.empty((N, C_, H, W), dtype=torch.float32, device=self.device)
+        L = _lib.lib()
+        st = _stream()
+        _lib.check(L.dasr_nchw_to_blocked(x.contiguous().data_ptr(), N, C_, H, W, xb.view(), NULL_T, st), 'nchw_to_blocked')
+        _lib.check(L.dasr_lowpass(xb.view(), NULL_T, self._fh_w[1].data_ptr(), k, N, C_, H, W, 0, 0.5, 0.5, NULL_T, hb.view(), 0, st), 'lowpass')
+        _lib.check(L.dasr_blocked_to_nchw(hb.view(), N, C_, H, W, out.data_ptr(), st), 'blocked_to_nchw')
+        return out
+
     def get_current_visuals(self, need_HR=True, tsamples=False):
         out = OrderedDict()
         out['LR'] = self.var_L.detach()[0].float().cpu()
+        if tsamples:   # DASR_model.py:353-357: high-frequency views of the SR batch and of the ground truth
+            out['hf'] = self.filter_high(self.fake_H).float().cpu()
+            out['gt_hf'] = self.filter_high(self.var_H).float().cpu()
+            out['HR'] = self.var_H.detach()[0].float().cpu()
+            out['HR_hf'] = out['gt_hf'].clone()
         out['SR'] = self.fake_H.detach().float().cpu() if tsamples else self.fake_H.detach()[0].float().cpu()
         if not tsamples and self.opt['val_lpips']:
             out['LPIPS'] = self.LPIPS.detach().float().cpu()

@@ -356,13 +356,44 @@ class _GPlan:
         self.bwd._arr = None
 
 
+def symmetry_code(k_rot, flip_rows, flip_cols):
+    """torch.flip(torch.flip(torch.rot90(x, k_rot, [2, 3]), rows?), cols?) as ONE of the 8 symmetries of the square in dasr_lpips_s2d's encoding:
+    T(x)[i][j] = x[u][v], (u, v) = (i, j) swapped if bit 0, then u -> H-1-u if bit 1, v -> W-1-v if bit 2.  Found by matching on an index grid."""
+    idx = torch.arange(9).reshape(1, 1, 3, 3)
+    t = torch.rot90(idx, k_rot, [2, 3])
+    if flip_rows:
+        t = torch.flip(t, (2,))
+    if flip_cols:
+        t = torch.flip(t, (3,))
+    for code in range(8):
+        got = torch.empty(3, 3, dtype=torch.long)
+        for i in range(3):
+            for j in range(3):
+                u, v = (j, i) if code & 1 else (i, j)
+                u = 2 - u if code & 2 else u
+                v = 2 - v if code & 4 else v
+                got[i, j] = idx[0, 0, u, v]
+        if torch.equal(got, t[0, 0]):
+            return code
+    raise AssertionError('not a symmetry of the square')
+
+
+def draw_symmetry():
+    """PerceptualLoss.forward (codes/DSN/loss.py:155-168): k_rot, then the two flip coins, from python's global `random` in that order"""
+    import random
+    k_rot = random.choice([-1, 0, 1])
+    rows = random.choice([True, False])
+    cols = random.choice([True, False])
+    return symmetry_code(k_rot, rows, cols)
+
+
 class DSNModel:
     """iteration(hr, bicubic_lr, real_lr) / end_epoch() / save(path) / load(path)"""
 
     def __init__(self, opt=None, device=None, **kw):
         o = dict(n_res_blocks=8, kernel_size=5, filter='gau', norm_layer='Instance', discriminator='FSD', generator='DeResnet', learning_rate=1e-4,
                  adam_beta_1=0.5, w_col=1.0, w_tex=0.005, w_per=0.01, per_type='VGG', vgg_path=None, vgg_seed=78, num_epochs=400,
-                 num_decay_epochs=150, upscale_factor=4, ragan=False, allow_random_perceptual=False, cat_or_sum='cat', disc_freq=1, gen_freq=1)
+                 num_decay_epochs=150, upscale_factor=4, ragan=False, allow_random_perceptual=False, cat_or_sum='cat', disc_freq=1, gen_freq=1, lpips_rot_flip=False)
         o.update(opt or {})
         o.update(kw)
         self.opt = o
@@ -409,6 +440,9 @@ class DSNModel:
         if o['generator'].lower() not in ('deresnet', 'dsgan'):   # codes/DSN/train.py:124-129
             raise NotImplementedError('Generator model [{:s}] not recognized'.format(o['generator']))
         self.netG = DeResnetHIP(o['n_res_blocks'], device=self.device, scale=4 if o['generator'].lower() == 'deresnet' else 1)
+        # --lpips_rot_flip (train.py:52, loss.py:66,149-168): a random symmetry of the square on both LPIPS inputs, drawn from python's `random` per
+        # generator-loss evaluation in the reference's order; only PerceptualLoss (= per_type LPIPS) has it, the VGG16 term ignores the flag
+        self.lpips_rot_flip = bool(o['lpips_rot_flip']) and o['per_type'] == 'LPIPS' and o['w_per'] > 0
         self.netG.loss_weight = max(float(o['w_col']), float(o['w_tex']), float(o['w_per']))   # sizes the f16 pre-scale of the 16-bit backward (_GPlan.gscale)
         self.cs = str(o['cat_or_sum']).lower()   # wavelet bands of the discriminator input: 'cat' (9 channels) or 'sum' = (LH + HL + HH) / 3 (model.py:108-118)
         if self.cs not in ('cat', 'sum'):
@@ -490,6 +524,8 @@ class DSNModel:
         scale = self.dp.grad_scale if dp_on else 1.0
         if scale != P.scale:
             P.set_grad_scale(scale)
+        if self.lpips_rot_flip and (self.iteration_count + 1) % self.gen_freq == 0:   # drawn where the reference evaluates its generator loss (train.py:251-259)
+            P.set_symmetry(draw_symmetry())
         rg_dp = self.ragan and dp_on   # --ragan under data parallelism: per-pixel batch sums all-reduced between the three loss stages
         if rg_dp:
             if P.ragan_world != self.dp.world:
@@ -691,6 +727,7 @@ class _DSNPlan:
         lpips = m.netF is not None and o_['per_type'] == 'LPIPS'
         if lpips:                # perceptual: LPIPS(fake, bicubic).mean() -> acc[6]; head gradients (weight w_per) in the forward list
             self.v = m.netF.plan(2 * N, N, h, w)
+            self.sym_ops = [(f, len(f.ops), 0), (f, len(f.ops) + 1, 0)]   # (list, index, base mode) of the LPIPS input / adjoint ops: set_symmetry()
             f.add(self.v.input_op(g.fake.view(), 0, N))
             f.add(self.v.input_op(self.bic_b.view(), N, N))
             f.extend(self.v.fwd)
@@ -745,6 +782,7 @@ class _DSNPlan:
             gb.add(o)
         if lpips:
             gb.extend(self.v.bwd)
+            self.sym_ops.append((gb, len(gb.ops), 1))
             gb.add(self.v.adjoint_op(g.g_fake.view()))
         elif self.v is not None:
             gb.extend(self.v.bwd)
@@ -755,6 +793,13 @@ class _DSNPlan:
             gb.add(o)
         gb.extend(g.bwd)
         self.g_bwd = gb
+
+    def set_symmetry(self, xf):
+        """LPIPS sees T(fake), T(bicubic): xf = symmetry code of dasr_lpips_s2d (bits: transpose, flip rows, flip columns); 0 = identity"""
+        if xf and (xf & 1) and self.v.H != self.v.W:
+            raise ValueError('--lpips_rot_flip with a rotation needs square crops (torch.rot90 would change the shape)')
+        for lst, idx, base in getattr(self, 'sym_ops', ()):
+            lst.set_i(idx, 3, base | (xf << 4))
 
     def set_grad_scale(self, scale):
         self.scale = scale

@@ -193,6 +193,13 @@ class OpList:
         self.keep.extend(other.keep)
         self._arr = None
 
+    def set_i(self, idx, slot, value):
+        """patch integer argument `slot` of op `idx` in place (recorded list AND its ctypes image): for the few arguments that change from call to
+        call while the plan stays recorded (e.g. the random symmetry of DSN --lpips_rot_flip)"""
+        self.ops[idx].i[slot] = value
+        if self._arr is not None:
+            self._arr[idx].i[slot] = value
+
     def safe_cuts(self, chunk):
         """[0, c1, c2, ..., len]: chunk boundaries of about `chunk` ops at which no stream redirect (OP_SET_STREAM) is open"""
         key = ('cuts', chunk, len(self.ops))

@@ -133,6 +133,43 @@ def setup_logger(name, root, phase, level=logging.INFO, screen=False):
         lg.addHandler(sh)
 
 
+def training_samples(model, opt, current_step, tb_logger, logger, n_samples=5):
+    """the `save_tsamples` branch of the reference driver (codes/SRN/train.py:123-172): five random (fake LR, real LR, HR) triples, centre-cropped to
+    128 x 128 LR / 512 x 512 HR, go through model.test(tsamples=True); per triple one image [fake SR | HR | real SR] over [their high-frequency
+    views] is written to TensorBoard (`train/train_samples_{i}`) -- and, here, also as a PNG under <experiments_root>/tsamples.  The file lists
+    come from datasets.train.dataroot_{fake_LR, real_LR, HR} like the reference's (PIL); a 'synthetic' train set draws seeded random crops."""
+    ds = opt['datasets']['train']
+    dirs = [ds.get('dataroot_fake_LR'), ds.get('dataroot_real_LR'), ds.get('dataroot_HR')]
+    from .tb_writer import png_encode
+    out_dir = os.path.join(opt['path']['experiments_root'] or '.', 'tsamples')
+    os.makedirs(out_dir, exist_ok=True)
+    lists = None
+    if all(d and os.path.isdir(d) for d in dirs):
+        lists = [os.listdir(d) for d in dirs]   # (unsorted, like the reference)
+    for i in range(n_samples):
+        if lists is not None:
+            from PIL import Image
+            idx = np.random.choice(range(len(lists[0])))
+            fake_LR, real_LR, HR = (np.array(Image.open(os.path.join(d, l[idx]))) for d, l in zip(dirs, lists))
+        else:
+            g = torch.Generator().manual_seed(int(np.random.randint(0, 2 ** 31 - 1)))
+            fake_LR, real_LR, HR = ((torch.rand(s, s, 3, generator=g) * 255).to(torch.uint8).numpy() for s in (128, 128, 512))
+        crop = lambda a, r: a[a.shape[0] // 2 - r:a.shape[0] // 2 + r, a.shape[1] // 2 - r:a.shape[1] // 2 + r, :]
+        fake_LR, real_LR, HR = crop(fake_LR, 64), crop(real_LR, 64), crop(HR, 256)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(np.transpose(a[:, :, :3], (2, 0, 1)))).float().unsqueeze(0) / 255
+        model.feed_data({'LR': torch.cat([t(fake_LR), t(real_LR)], 0), 'HR': t(HR)}, False)
+        model.test(tsamples=True)
+        v = model.get_current_visuals(tsamples=True)
+        image_1 = torch.cat([v['SR'][0], v['HR'], v['SR'][1]], dim=2).clamp(0, 1)
+        image_2 = torch.cat([v['hf'][0], v['HR_hf'][0], v['hf'][1]], dim=2).clamp(0, 1)
+        image = torch.cat([image_1, image_2], dim=1)
+        if tb_logger is not None:
+            tb_logger.add_image('train/train_samples_{}'.format(i), image, current_step)
+        with open(os.path.join(out_dir, '{:d}_{:d}.png'.format(current_step, i)), 'wb') as f:
+            f.write(png_encode(image)[0])
+    logger.info('Saved training Samples')
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('-opt', type=str, required=True, help='Path to option JSON file.')
@@ -167,6 +204,11 @@ def main(argv=None):
     np.random.seed(seed)
     torch.manual_seed(seed)
 
+    # tensorboard scalars / images (train.py:57-59): written by dasr_amd.tb_writer (no tensorboardX in an air-gapped image); same tags as the reference
+    tb_logger = None
+    if opt['use_tb_logger'] and 'debug' not in opt['name'] and rank == 0:
+        from .tb_writer import SummaryWriter
+        tb_logger = SummaryWriter(os.path.join(opt['path']['tb_logger'] or os.path.join(opt['path']['root'] or '.', 'SRN_tb_logger'), opt['name']))
     train_set = create_dataset(opt['datasets']['train'], opt)
     val_set = create_dataset(opt['datasets']['val'], opt) if opt['datasets'].get('val') else None
     if rank == 0:
@@ -200,13 +242,22 @@ def main(argv=None):
                 msg = '<epoch:{:3d}, iter:{:8,d}, lr:{:.3e}> '.format(epoch, current_step, model.get_current_learning_rate())
                 for k, v in model.get_current_log().items():
                     msg += '{:s}: {:.4e} '.format(k, v)
+                    if tb_logger is not None:
+                        tb_logger.add_scalar(k, v, current_step)
                 logger.info(msg)
+            if opt['train']['save_tsamples'] and current_step % opt['train']['save_tsamples'] == 0 and rank == 0:
+                if not hasattr(model, 'filter_high'):
+                    raise NotImplementedError('save_tsamples needs the DASR trainer (get_current_visuals(tsamples=True), DASR_model.py:349-366)')
+                training_samples(model, opt, current_step, tb_logger, logger)
             if val_set is not None and opt['train']['val_freq'] and current_step % opt['train']['val_freq'] == 0 and rank == 0:
                 res = validate(model, val_set, opt, current_step, logger)
                 if opt['val_lpips']:   # train.py:226-228
                     logging.getLogger('val').info('<epoch:{:3d}, iter:{:8,d}> psnr: {:.4e}, {}: {:.4f}'.format(epoch, current_step, res[0], model.lpips_label, res[1]))
                 else:
                     logging.getLogger('val').info('<epoch:{:3d}, iter:{:8,d}> psnr: {:.4e}'.format(epoch, current_step, res))
+                if tb_logger is not None:   # train.py:231-233
+                    tb_logger.add_scalar('psnr', res[0] if opt['val_lpips'] else res, current_step)
+                    tb_logger.add_scalar('LPIPS', res[1] if opt['val_lpips'] else 0.0, current_step)
             if current_step % opt['logger']['save_checkpoint_freq'] == 0 and rank == 0:
                 logger.info('Saving models and training states.')
                 model.save(current_step)
@@ -215,6 +266,8 @@ def main(argv=None):
         logger.info('Saving the final model.')
         model.save('latest')
         logger.info('End of training.')
+        if tb_logger is not None:
+            tb_logger.close()
 
 
 if __name__ == '__main__':

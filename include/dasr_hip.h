@@ -298,7 +298,10 @@ int dasr_bilinear_up(const float* src, int32_t N, int32_t h, int32_t w, int32_t 
  * dasr_conv (prec 3); these are the layers around them, all on blocked f32 tensors. */
 /* mode 0: ScalingLayer (networks_basic.py:94-101, with the 2x-1 of models/util.py:36-38 folded into scale4/shift4) + 4x4 space-to-depth of
  * the 3-channel image (plane 0 of x) zero-padded by 2: y[c][Y][X][4*by+bx] = scale4[c]*x[c][4Y+by-2][4X+bx-2] + shift4[c], 3 planes of
- * (H+4)/4 x (W+4)/4 -- the 11x11/s4/p2 conv becomes 3x3/s1/p0 on 48 channels.  mode 1: adjoint, ACCUMULATED into channels 0..2 of x. */
+ * (H+4)/4 x (W+4)/4 -- the 11x11/s4/p2 conv becomes 3x3/s1/p0 on 48 channels.  mode 1: adjoint, ACCUMULATED into channels 0..2 of x.
+ * mode bits 4-6 (DSN --lpips_rot_flip, PerceptualLoss.forward codes/DSN/loss.py:155-168: torch.rot90 / torch.flip of both images in front of
+ * LPIPS): the network sees T(x), T(x)[i][j] = x[u][v], (u, v) = (i, j) swapped if bit 4, u -> H-1-u if bit 5, v -> W-1-v if bit 6; mode 1 routes
+ * the gradient back through the same map.  Transposing forms need H == W. */
 int dasr_lpips_s2d(dasr_tensor x, int32_t N, int32_t H, int32_t W, const float* scale4, const float* shift4, dasr_tensor y, int32_t mode,
                    void* stream);
 /* nn.MaxPool2d(3, 2) of torchvision alexnet.features[2] / [5] on H x W inputs (output (H-3)/2+1), and its backward: gather form, first

@@ -187,13 +187,27 @@ def vgg16_features31(seed):
     return net
 
 
+def rot_flip_pair(x, y):
+    """PerceptualLoss.forward with rotations = flips = True (codes/DSN/loss.py:155-168): the same random symmetry of the square on both images,
+    drawn from python's global `random`: k_rot, then the row-flip coin, then the column-flip coin"""
+    import random
+    k_rot = random.choice([-1, 0, 1])
+    x, y = torch.rot90(x, k_rot, [2, 3]), torch.rot90(y, k_rot, [2, 3])
+    if random.choice([True, False]):
+        x, y = torch.flip(x, (2,)), torch.flip(y, (2,))
+    if random.choice([True, False]):
+        x, y = torch.flip(x, (3,)), torch.flip(y, (3,))
+    return x, y
+
+
 class DSNTrainer:
     """one training iteration of codes/DSN/train.py:204-285 (non-wgan; `ragan`: the relativistic discriminator calls of :221-223)"""
 
     def __init__(self, netG=None, netD=None, lr=1e-4, beta1=0.5, w_col=1.0, w_tex=0.005, w_per=0.01, per_type='VGG',
                  kernel_size=5, filter_type='gau', norm_layer='Instance', vgg_seed=78, num_epochs=400, num_decay_epochs=150, netF=None, ragan=False,
-                 disc_freq=1, gen_freq=1):
+                 disc_freq=1, gen_freq=1, lpips_rot_flip=False):
         self.ragan = ragan
+        self.lpips_rot_flip = bool(lpips_rot_flip)   # --lpips_rot_flip (train.py:52, loss.py:66,149-168)
         # --disc_freq / --gen_freq (train.py:55-56): `iteration += 1` at the top of the loop body (:206), the discriminator steps when
         # iteration % disc_freq == 0 (:229), the generator when iteration % gen_freq == 0 (:251)
         self.disc_freq, self.gen_freq, self.iteration_count = int(disc_freq), int(gen_freq), 0
@@ -231,7 +245,8 @@ class DSNTrainer:
         g_loss = self.w_col * col + self.w_tex * tex
         per = torch.zeros(())
         if self.lpips is not None:
-            per = self.lpips(fake, bicubic_lr)
+            x, y = rot_flip_pair(fake, bicubic_lr) if self.lpips_rot_flip else (fake, bicubic_lr)
+            per = self.lpips(x, y)
             g_loss = g_loss + self.w_per * per
         if self.per is not None:
             per = F.mse_loss(self.per(fake), self.per(bicubic_lr))

@@ -35,6 +35,9 @@ DSN_CASES = {
     'dsn_avg5_batch_b3_128_ragan': dict(filter='avg_pool', k=5, norm='Batch', n=3, crop=128, ragan=True),
     # --cat_or_sum sum (round 3; model.py:113-114): the discriminator sees (LH + HL + HH) / 3, three channels instead of nine
     'dsn_wavelet_sum_inst_b2_128': dict(filter='wavelet', k=5, norm='Instance', n=2, crop=128, cs='sum'),
+    # --lpips_rot_flip (round 4; train.py:52, loss.py:66,149-168): random rot90 / flips of both images in front of LPIPS, python `random` seeded
+    # per call (seed 3 draws k_rot = -1, flip rows, no column flip; seed + 1 for the second iteration)
+    'dsn_gau5_inst_b2_256_lpips_rotflip': dict(filter='gau', k=5, norm='Instance', n=2, crop=256, per='LPIPS', rot_flip=True, rseed=3),
 }
 
 
@@ -54,6 +57,9 @@ def dsn_batch(c, seed=4321):
 
 def collect(G, D, color_filter, per_net, c, w=(1.0, 0.005, 0.01)):
     hr, bic, real = dsn_batch(c)
+    if c.get('rot_flip'):
+        import random
+        random.seed(c['rseed'])
     fake = G(bic if c.get('gen') == 'DSGAN' else hr)
     rt, ft = (D(real, fake), D(fake, real)) if c.get('ragan') else (D(real), D(fake))
     d_loss = -torch.log(rt + 1e-8).mean() - torch.log(1 - ft + 1e-8).mean()
@@ -116,7 +122,8 @@ def main():
         _cuda = nn.Module.cuda
         nn.Module.cuda = lambda self, *a, **k: self   # loss.py:63-64 moves the colour filter to the GPU unconditionally
         try:
-            gl = rloss.GeneratorLoss(kernel_size=c['k'], per_type=c.get('per', 'VGG'), filter=c['filter'], w_col=1, w_tex=0.005, w_per=0.01)
+            gl = rloss.GeneratorLoss(kernel_size=c['k'], per_type=c.get('per', 'VGG'), filter=c['filter'], w_col=1, w_tex=0.005, w_per=0.01,
+                                     lpips_rot_flip=bool(c.get('rot_flip')))
         finally:
             nn.Module.cuda = _cuda
         if c['filter'] == 'wavelet':

@@ -212,7 +212,7 @@ def test_deresnet_forward_backward():
 @pytest.mark.parametrize('case', ['dsn_gau5_inst_b2_128', 'dsn_wavelet_inst_b2_128', 'dsn_avg5_inst_b1_160', 'dsn_gau5_inst_b1_256_lpips',
                                   'dsn_wavelet_nld_s2_b2_128', 'dsn_gau5_nld_s1_b1_128', 'dsn_dsgan_gau5_inst_b2_128', 'dsn_gau5_inst_b3_128_ragan',
                                   'dsn_gau5_batch_b2_128', 'dsn_avg5_batch_b3_128_ragan', 'dsn_wavelet_sum_inst_b2_128',
-                                  'dsn_gau5_inst_b2_128+fwd32', 'dsn_dsgan_gau5_inst_b2_128+fwd32'])
+                                  'dsn_gau5_inst_b2_128+fwd32', 'dsn_dsgan_gau5_inst_b2_128+fwd32', 'dsn_gau5_inst_b2_256_lpips_rotflip'])
 def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir, monkeypatch, margins):
     dev = _gpu()
     case_id = case
@@ -234,8 +234,10 @@ def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir, mo
     if c.get('per') == 'LPIPS':     # --per_type LPIPS (reference default): real linear heads + the fixture's stand-in AlexNet
         from oracle import lpips
         crit, sdF = lpips.golden_criterion(78, golden_dir)
-    t = dsn.DSNTrainer(G, D, kernel_size=c['k'], filter_type=c['filter'], norm_layer=c['norm'], vgg_seed=78, w_per=0.01, per_type=c.get('per', 'VGG'), netF=crit, ragan=bool(c.get('ragan')))
-    m = DSNModel(dict(ragan=bool(c.get('ragan')), filter=c['filter'], kernel_size=c['k'], norm_layer=c['norm'], w_per=0.01, vgg_seed=78, per_type=c.get('per', 'VGG'), discriminator=c.get('arch', 'FSD'), generator=c.get('gen', 'DeResnet'), allow_random_perceptual=True, cat_or_sum=c.get('cs', 'cat')), device=dev)
+    t = dsn.DSNTrainer(G, D, kernel_size=c['k'], filter_type=c['filter'], norm_layer=c['norm'], vgg_seed=78, w_per=0.01, per_type=c.get('per', 'VGG'), netF=crit, ragan=bool(c.get('ragan')),
+                       lpips_rot_flip=bool(c.get('rot_flip')))
+    m = DSNModel(dict(ragan=bool(c.get('ragan')), filter=c['filter'], kernel_size=c['k'], norm_layer=c['norm'], w_per=0.01, vgg_seed=78, per_type=c.get('per', 'VGG'), discriminator=c.get('arch', 'FSD'), generator=c.get('gen', 'DeResnet'), allow_random_perceptual=True, cat_or_sum=c.get('cs', 'cat'),
+                      lpips_rot_flip=bool(c.get('rot_flip'))), device=dev)
     d_keys = list(m.netD.state_dict()) if c['norm'] == 'Batch' else list(m.netD.params.spec)   # BatchNorm: buffers are part of the reference layout
     assert list(m.netG.params.spec) == list(gold['G_keys']) and d_keys == list(gold['D_keys'])
     m.netG.load_state_dict(sdG)
@@ -243,8 +245,13 @@ def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir, mo
     m.netF.load_state_dict(sdF if sdF is not None else {'features.' + k: v for k, v in t.per.state_dict().items()})
     hr, bic, real = dsn_batch(c)
     from oracle import fixtures
+    import random
     for step in (1, 2):
+        # --lpips_rot_flip: both sides draw the symmetry from python's `random` like the reference (loss.py:155-168); step 1 = the fixture's seed
+        # (k_rot -1, rows flipped), step 2 = seed + 1 (k_rot -1, columns flipped)
+        random.seed(c.get('rseed', 0) + step - 1)
         t.iteration(hr, bic, real)
+        random.seed(c.get('rseed', 0) + step - 1)
         m.iteration(hr.to(dev), bic.to(dev), real.to(dev))
         log = m.get_current_log()
         tol = 2e-3 if step == 1 else 2e-2

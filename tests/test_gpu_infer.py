@@ -99,7 +99,7 @@ def test_dasr_training_driver_with_lpips_criterion_source_discriminator_and_val_
     _gpu()
     from dasr_amd import train
     opt = json.loads(open(_json_opt(tmp_path, 'f4_dasr', True)).read())
-    opt.update(model='DASR', val_lpips=True, multiweights=True, allow_random_perceptual=True)   # no pretrained AlexNet offline: explicit opt-in
+    opt.update(model='DASR', val_lpips=True, multiweights=True, allow_random_perceptual=True, use_tb_logger=True)   # no pretrained AlexNet offline: explicit opt-in
     opt['datasets']['train'].update(batch_size=2, HR_size=128, n_batches=4)
     opt['datasets']['val'].update(LR_size=32)
     opt['path'].update(pretrain_model_D_target=None, pretrain_model_D_source=None)
@@ -107,7 +107,9 @@ def test_dasr_training_driver_with_lpips_criterion_source_discriminator_and_val_
                         'mode': 'CNA', 'nf': 64, 'in_nc': 9, 'n_layers': 2}
     opt['train'].update({'lr_D': 1e-4, 'weight_decay_D': 0, 'beta1_D': 0.9, 'fs': 'wavelet', 'fs_kernel_size': 9, 'norm': True, 'sup_LL': True,
                          'pixel_LL_weight': 1, 'feature_criterion': 'LPIPS', 'feature_weight': 1, 'gan_type': 'vanilla', 'ragan': False,
-                         'gan_H_target': 0.005, 'gan_H_source': 0.005, 'G_update_inter': 1, 'D_update_inter': 1, 'niter': 4, 'val_freq': 2})
+                         'gan_H_target': 0.005, 'gan_H_source': 0.005, 'G_update_inter': 1, 'D_update_inter': 1, 'niter': 4, 'val_freq': 2,
+                         'save_tsamples': 4})
+    opt['logger']['print_freq'] = 2
     p = tmp_path / 'f4_dasr.json'
     p.write_text(json.dumps(opt))
     train.main(['-opt', str(p)])
@@ -123,6 +125,34 @@ def test_dasr_training_driver_with_lpips_criterion_source_discriminator_and_val_
         assert (root / 'models' / f).exists(), f
     st = torch.load(root / 'training_state' / '4.state', weights_only=False)
     assert len(st['optimizers']) == 3 and len(st['schedulers']) == 3 and st['iter'] == 4
+    # round 4: the save_tsamples branch (train.py:123-172) and the tensorboard scalars / images (train.py:112-121,168,231-233)
+    assert 'Saved training Samples' in log
+    pngs = sorted((root / 'tsamples').glob('4_*.png'))
+    assert len(pngs) == 5
+    from dasr_amd import tb_writer
+    tb_files = list((tmp_path / 'SRN_tb_logger' / 'f4_dasr').glob('events.out.tfevents.*'))
+    assert len(tb_files) == 1
+    ev = tb_writer.read_events(str(tb_files[0]))
+    tags = set(t for _, t, _ in ev)
+    assert {'loss/l_g_pix', 'loss/l_d_target_total', 'psnr', 'LPIPS'} <= tags and {'train/train_samples_%d' % i for i in range(5)} <= tags
+    img = [v for _, t, v in ev if t == 'train/train_samples_0'][0]
+    assert img[0] == 'image' and (img[1], img[2]) == (2 * 512, 3 * 512)   # [fake SR | HR | real SR] over their high-frequency views
+
+
+def test_filter_high_visual_matches_reference_filter(golden_dir):
+    """DASR_Model.filter_high (the `hf` / `HR_hf` visuals of get_current_visuals(tsamples=True), DASR_model.py:353-357) against the oracle's
+    FilterHigh(kernel_size, gaussian=True) (architecture.py:1228-1243)"""
+    dev = _gpu()
+    from oracle import nets
+    from dasr_amd import options
+    from dasr_amd.dasr_model import DASR_Model
+    m = DASR_Model.__new__(DASR_Model)
+    m.opt = options.dict_to_nonedict({'train': {'fs_kernel_size': 9}})
+    m.device, m.fs = dev, 'wavelet'
+    x = torch.rand(2, 3, 40, 56, generator=torch.Generator().manual_seed(3))
+    want = nets.FilterHigh(kernel_size=9, gaussian=True)(x)
+    got = m.filter_high(x.to(dev)).cpu()
+    assert rel(got, want) < 1e-5, rel(got, want)
 
 
 @pytest.mark.gpu

@@ -244,7 +244,7 @@ def test_dsn_cli_flags_and_lr_rule():
     dsn_train.check_supported(o)
     dsn_train.check_supported(dsn_train.build_parser().parse_args(['--ragan']))
     dsn_train.check_supported(dsn_train.build_parser().parse_args(['--norm_layer', 'Batch']))
-    for bad in (['--generator', 'SRGAN'], ['--discriminator', 'nld_s3'], ['--wgan'], ['--norm_layer', 'Batch', '--discriminator', 'nld_s1'], ['--norm_layer', 'Group'], ['--lpips_rot_flip']):
+    for bad in (['--generator', 'SRGAN'], ['--discriminator', 'nld_s3'], ['--wgan'], ['--norm_layer', 'Batch', '--discriminator', 'nld_s1'], ['--norm_layer', 'Group']):
         with pytest.raises(NotImplementedError):
             dsn_train.check_supported(dsn_train.build_parser().parse_args(bad))
     # every flag the model acts on reaches its option dict (--disc_freq / --gen_freq were parsed, accepted and then dropped)
@@ -255,6 +255,20 @@ def test_dsn_cli_flags_and_lr_rule():
     dflt = re.search(r"o = dict\((.*?)\)\n", inspect.getsource(dsn_model.DSNModel.__init__), re.S).group(1)
     model_keys = set(re.findall(r"(\w+)=", dflt)) - {'vgg_seed'}   # (vgg_seed: no CLI flag)
     assert model_keys <= set(mo), model_keys - set(mo)   # every default of the model that a CLI flag backs is forwarded
+    dsn_train.check_supported(dsn_train.build_parser().parse_args(['--lpips_rot_flip']))
+    # the 12 (k_rot, flip, flip) draws of loss.py:155-168 map onto the 8 symmetries of the square, identity for (0, F, F)
+    codes = {(k, a, b): dsn_model.symmetry_code(k, a, b) for k in (-1, 0, 1) for a in (False, True) for b in (False, True)}
+    assert codes[(0, False, False)] == 0 and set(codes.values()) == set(range(8))
+    x = torch.rand(1, 1, 5, 5)
+    for (k, a, b), code in codes.items():
+        t = torch.rot90(x, k, [2, 3])
+        t = torch.flip(t, (2,)) if a else t
+        t = torch.flip(t, (3,)) if b else t
+        i, j = torch.meshgrid(torch.arange(5), torch.arange(5), indexing='ij')
+        u, v = (j, i) if code & 1 else (i, j)
+        u = 4 - u if code & 2 else u
+        v = 4 - v if code & 4 else v
+        assert torch.equal(x[0, 0][u, v], t[0, 0]), (k, a, b, code)
     # LambdaLR rule of train.py:154-157 against torch's scheduler
     m = dsn_model.DSNModel.__new__(dsn_model.DSNModel)
     m.opt = dict(num_epochs=10, num_decay_epochs=4, learning_rate=2e-4)
@@ -338,3 +352,30 @@ def test_perceptual_networks_refuse_to_run_seeded_without_opt_in():
         dsn_train.check_supported(p.parse_args([]), have_loader=False)          # default --dataset df2k has no built-in loader
     dsn_train.check_supported(p.parse_args(['--dataset', 'synthetic']), have_loader=False)
     assert p.parse_args(['--allow_random_perceptual']).allow_random_perceptual is True and p.parse_args([]).allow_random_perceptual is False
+
+
+def test_tensorboard_event_writer_roundtrip(tmp_path):
+    """dasr_amd.tb_writer: the scalars / sample images of the reference drivers (codes/SRN/train.py:112-121,168,231-233; codes/DSN/train.py:245-270)
+    as TensorBoard event files without the tensorboardX package: TFRecord framing with masked CRC32C, hand-encoded Event / Summary protobufs"""
+    from dasr_amd import tb_writer as tw
+    assert tw.crc32c(b'123456789') == 0xE3069283          # the CRC-32C check value (RFC 3720 B.4)
+    assert tw.masked_crc(b'') == 0xA282EAD8
+    w = tw.SummaryWriter(str(tmp_path / 'tb'))
+    w.add_scalar('loss/l_g_pix', 0.125, 7)
+    w.add_scalar('psnr', 27.5, 1000)
+    img = torch.rand(3, 6, 10)
+    w.add_image('train/train_samples_0', img, 1000)
+    w.close()
+    ev = tw.read_events(w.path)
+    assert ev[0] == (7, 'loss/l_g_pix', 0.125) and ev[1] == (1000, 'psnr', 27.5)
+    step, tag, (kind, h, wd, png) = ev[2]
+    assert (step, tag, kind, h, wd) == (1000, 'train/train_samples_0', 'image', 6, 10) and png[:8] == b'\x89PNG\r\n\x1a\n'
+    try:
+        from PIL import Image
+        import io
+        import numpy as np
+        back = np.asarray(Image.open(io.BytesIO(png)))
+        want = (img.clamp(0, 1) * 255.0 + 0.5).to(torch.uint8).permute(1, 2, 0).numpy()
+        assert back.shape == (6, 10, 3) and np.array_equal(back, want)
+    except ImportError:
+        pass

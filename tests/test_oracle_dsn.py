@@ -26,7 +26,8 @@ def test_dsn_oracle_matches_reference_fixture(case, golden_dir):
         from oracle import lpips
         crit = lpips.golden_criterion(78, golden_dir)[0]
     t = dsn.DSNTrainer(G, D, kernel_size=c['k'], filter_type=c['filter'], norm_layer=c['norm'], vgg_seed=78, per_type=c.get('per', 'VGG'), netF=crit)
-    got = collect(G, D, t.color_filter, t.lpips if crit is not None else t.per, c)
+    per_net = (t.lpips if crit is not None else t.per) if not c.get('rot_flip') else (lambda x, y: t.lpips(*dsn.rot_flip_pair(x, y)))
+    got = collect(G, D, t.color_filter, per_net, c)
     for k in ('fake_sub', 'real_tex_sub', 'fake_tex_sub', 'losses'):
         np.testing.assert_allclose(got[k], ref[k], rtol=2e-5, atol=1e-7, err_msg=k)
     np.testing.assert_allclose(got['gradG_norm'], ref['gradG_norm'], rtol=1e-3, atol=1e-10)
