@@ -96,14 +96,18 @@ def profiled_steps(run_step, nsteps=1, capacity=16384):
     n = L.dasr_prof_end(capacity, us, fl, by, op, tg)
     if n < 0:
         raise RuntimeError('dasr_prof_end: %d' % n)
-    recs = [(tg[i].decode(), us[i], fl[i]) for i in range(n)]
+    recs = [(tg[i].decode(), us[i], fl[i], (op[i] >> 8) & 0xff) for i in range(n)]   # (kernel tag, duration us, algorithmic flops, time bucket)
     return recs, wall, n >= capacity
 
 
 def roofline_from_step(run_step, peak_measured, streams, nsteps=1):
     recs, wall, truncated = profiled_steps(run_step, nsteps)
-    rows = {}
-    for tag, us, fl in recs:
+    rows, buckets = {}, {}
+    for tag, us, fl, bk in recs:
+        b = buckets.setdefault(bk, [0, 0.0, 0.0])
+        b[0] += 1
+        b[1] += us
+        b[2] += fl
         r = rows.setdefault(tag, {'launches': 0, 'total_us': 0.0, 'flops': 0.0})
         r['launches'] += 1
         r['total_us'] += us
@@ -153,17 +157,32 @@ def roofline_from_step(run_step, peak_measured, streams, nsteps=1):
             # algorithmic FLOPs of the whole profiled step (sum over all MFMA launches of what the plan builder attributes to each op)
             'tflop_per_step': round(sum(r['flops'] for r in rows.values()) / nsteps / 1e12, 3),
             'profiled_step_ms': round(wall * 1e3 / nsteps, 2)}
+    # where the step's kernel time goes, by the plan builders' bucket tags (dasr_amd/engine.py BUCKETS): launches, summed launch durations (streams
+    # overlap: the sum exceeds the wall time by kernel_time_over_wall), algorithmic TFLOP and the resulting rate
+    from dasr_amd.engine import BUCKETS
+    roof['buckets'] = [{'bucket': BUCKETS.get(k, str(k)), 'launches': v[0] // nsteps, 'kernel_ms': round(v[1] / nsteps / 1e3, 3),
+                        'share': round(v[1] / ksum, 4) if ksum else None, 'tflop': round(v[2] / nsteps / 1e12, 3),
+                        'tflops_rate': round(v[2] / v[1] / 1e6, 1) if v[1] > 0 and v[2] > 0 else None}
+                       for k, v in sorted(buckets.items(), key=lambda kv: -kv[1][1])]
     return roof
 
 
-def secondary_roofline(run_step, streams):
+def secondary_roofline(run_step, streams, workload=None):
     """roofline block of a secondary workload (configs[2] / configs[4]): the same live per-launch measurement as the headline, trimmed: the dominant
     kernel's per-launch rate, the six largest kernels, the algorithmic FLOPs of the step and the step-level fraction of the dense bf16 peak"""
     r = roofline_from_step(run_step, None, streams)
     keep = ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel', 'avg_launch_us', 'flops_per_launch', 'kernel_time_over_wall', 'non_mfma_kernel_time_share',
-            'tflop_per_step', 'profiled_step_ms')
+            'tflop_per_step', 'profiled_step_ms', 'buckets')
     out = {k: r.get(k) for k in keep}
-    out['traffic'] = None   # no PMC pass committed for the secondary workloads' kernels
+    out['traffic'], out['traffic_source'] = None, None
+    try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes of this workload (profiles/pmc_traffic.json, `workloads`)
+        pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+        ent = pm.get('workloads', {}).get(workload, {}).get(out.get('kernel'))
+        if ent:
+            out['traffic'] = int((ent['fetch_size_kb_raw'] * pm['fetch_correction_gfx950'] + ent['write_size_kb']) * 1024.0)
+            out['traffic_source'] = pm['source'].split(':')[0].replace('_pmc_traffic.txt', '_%s_pmc_traffic.txt' % workload)
+    except Exception:
+        pass
     out['per_kernel'] = r['per_kernel'][:6]
     if r.get('tflop_per_step') and r.get('profiled_step_ms'):
         out['mfma_util_step'] = round(r['tflop_per_step'] / (r['profiled_step_ms'] * 1e-3) / PEAK_BF16_TFLOPS, 4)
@@ -342,7 +361,7 @@ def bench_dsn(a, dp, as_secondary=False):
     if not as_secondary:
         out['log'] = m.get_current_log()
     if rank == 0:
-        out['roofline'] = secondary_roofline(lambda: m.iteration(hr, bic, real), 1)
+        out['roofline'] = secondary_roofline(lambda: m.iteration(hr, bic, real), 1, 'dsn_lpips' if a.per_type == 'LPIPS' else 'dsn_vgg')
     else:
         m.iteration(hr, bic, real)
     return out
@@ -423,7 +442,7 @@ def bench_srn(a, dp, dasr, as_secondary=False):
         one_step()  # the other ranks take part in the profiled step's collectives
     if as_secondary:
         if rank == 0:
-            out['roofline'] = secondary_roofline(one_step, len(getattr(model, '_out_plans', None) or [0]))
+            out['roofline'] = secondary_roofline(one_step, len(getattr(model, '_out_plans', None) or [0]), 'dasr_lpips' if a.fea == 'LPIPS' else 'dasr_vgg')
         else:
             one_step()
     if not as_secondary and not dasr and streams_default() > 1 and not a.no_secondary:

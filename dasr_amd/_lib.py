@@ -38,7 +38,7 @@ class WgradReducePart(C.Structure):
     _fields_ = [('ws_off', c_i64), ('ws_bias_off', c_i64), ('nsplit', c_i32), ('ntaps', c_i32), ('oc0', c_i32), ('c0', c_i32),
                 ('cout', c_i32), ('cin', c_i32), ('n_ctiles', c_i32), ('dst_w_off', c_i64), ('dst_b_off', c_i64),
                 ('flip_io', c_i32), ('split_stride', c_i64), ('tap_stride', c_i64), ('bias_stride', c_i64),
-                ('tap0', c_i32), ('ntaps_total', c_i32)]
+                ('tap0', c_i32), ('ntaps_total', c_i32), ('bias_nsplit', c_i32), ('reserved_', c_i32)]
 
 
 class PackSeg(C.Structure):
@@ -84,6 +84,7 @@ _SIGS = {
     'dasr_pixel_unshuffle_f16': [Tensor, Tensor, c_f32, c_i32, c_i32, c_i32, c_i32, Tensor, c_vp],
     'dasr_cvt_f16': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, Tensor, c_vp],
     'dasr_cvt_split16': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, Tensor, c_i32, c_vp],
+    'dasr_f16_residual': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, Tensor, c_vp],
     'dasr_downsum2x_f16': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_f32, c_f32, Tensor, Tensor, c_vp],
     'dasr_downsum2x': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_f32, Tensor, Tensor, c_vp],
     'dasr_axpby': [Tensor, c_f32, Tensor, c_f32, c_i32, c_i32, c_i32, c_i32, Tensor, Tensor, c_f32, Tensor, c_f32, c_vp, c_vp],
@@ -142,7 +143,7 @@ _BENCH_SIGS = {
 }
 BENCH_LIB_PATH = os.path.join(HERE, 'libdasr_bench.so')
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 _lib = None
 _bench = None
 

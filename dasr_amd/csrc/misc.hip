@@ -323,6 +323,23 @@ __global__ void cvt_f16_kernel(dasr_tensor x, int N, int C, int H, int W, float 
     *(f16x4*)((f16_t*)y.p + (size_t)n * y.n_stride + (size_t)cb * y.cb_stride + e) = o;
 }
 
+// y (f32) = x - f16(scale * x) / scale: what an f16 operand rounding leaves behind.  The weight gradients of the BatchNorm discriminators run as
+// g.x + g.x_lo + g_lo.x on the f16 MFMA (three parts of one launch, 22-bit operands) -- the residual tensors are these.
+__global__ void f16_residual_kernel(dasr_tensor x, int N, int C, int H, int W, float scale, dasr_tensor y) {
+    const int ncb = (C + 15) >> 4;
+    const long long per_plane = (long long)H * W * 4, total = (long long)N * ncb * per_plane;
+    const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= total) return;
+    const long long e = (gi % per_plane) * 4;
+    long long t = gi / per_plane;
+    const int cb = t % ncb, n = t / ncb;
+    const f32x4 v = *(const f32x4*)((const float*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + e);
+    const float inv = 1.f / scale;
+    f32x4 o;
+    for (int j = 0; j < 4; ++j) o[j] = v[j] - (float)(f16_t)(v[j] * scale) * inv;
+    *(f32x4*)((float*)y.p + (size_t)n * y.n_stride + (size_t)cb * y.cb_stride + e) = o;
+}
+
 // split 16-bit copy of scale * x: hi = round16(scale * x) into the first ncb planes of y, lo = round16(scale * x - hi) into the next ncb
 template <typename T>
 __global__ void cvt_split16_kernel(dasr_tensor x, int N, int C, int H, int W, float scale, dasr_tensor y) {
@@ -463,6 +480,13 @@ extern "C" int dasr_cvt_split16(dasr_tensor x, int32_t N, int32_t C, int32_t H, 
     if (total <= 0 || !x.p || !y.p) return DASR_EINVAL;
     if (f16) DASR_LAUNCH(cvt_split16_kernel<f16_t>, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, scale, y);
     else DASR_LAUNCH(cvt_split16_kernel<bf16_t>, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, scale, y);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_f16_residual(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, float scale, dasr_tensor y, void* stream) {
+    const long long total = (long long)N * ((C + 15) / 16) * H * W * 4;
+    if (total <= 0 || !x.p || !y.p || !(scale > 0.f)) return DASR_EINVAL;
+    DASR_LAUNCH(f16_residual_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), x, N, C, H, W, scale, y);
     return (int)hipGetLastError();
 }
 
@@ -642,7 +666,7 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream0) {
         int rc = 0;
         g_prof_flops = o.flops;
         g_prof_bytes = o.bytes;
-        g_prof_op = o.op;
+        g_prof_op = o.op | ((o.i[7] & 0xff) << 8);   // i[7]: the plan builder's time-bucket tag (no kernel reads it), returned by dasr_prof_end
         switch (o.op) {
             case DASR_OP_CONV: rc = dasr_conv(&o.conv, stream); break;
             case DASR_OP_WGRAD:
@@ -699,9 +723,10 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream0) {
             case DASR_OP_SET_STREAM: stream = o.p[0] ? o.p[0] : stream0; break;
             case DASR_OP_PIXSHUF: rc = dasr_pixel_shuffle_f16(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1], stream); break;
             case DASR_OP_PIXUNSHUF: rc = dasr_pixel_unshuffle_f16(o.t[0], o.t[1], o.f[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[2], stream); break;
-            case DASR_OP_CVT_F16:   // i[4]: 0 plain f16 copy, 1 split f16, 2 split bf16
-                rc = o.i[4] ? dasr_cvt_split16(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1], o.i[4] == 1, stream)
-                            : dasr_cvt_f16(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1], stream);
+            case DASR_OP_CVT_F16:   // i[4]: 0 plain f16 copy, 1 split f16, 2 split bf16, 3 f32 residual of the f16 rounding
+                rc = o.i[4] == 3 ? dasr_f16_residual(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1], stream)
+                     : o.i[4]    ? dasr_cvt_split16(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1], o.i[4] == 1, stream)
+                                 : dasr_cvt_f16(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1], stream);
                 break;
             case DASR_OP_DOWNSUM_F16: rc = dasr_downsum2x_f16(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1], o.f[0], o.f[1], o.t[2], o.t[3], stream); break;
             case DASR_OP_BNORM_FWD:

@@ -1218,6 +1218,42 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const dasr_wgrad_redu
     const int ntaps = min(P.ntaps, NT - P.tap0);                        // taps of this part that exist in the kernel window
     const int n_c = min(min(32 * P.n_ctiles, P.cin - P.c0), 64) - cg * 16;   // valid input channels of this 16-channel group (may be <= 0)
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    if (P.nsplit <= 4 && ntaps <= 16) {
+        // few splits (the grouped dense-block launches of the RRDB trunk: 60 parts x 4 pixel splits): the 16 split lanes would be three quarters
+        // idle and a workgroup would move 2.3 KB.  Instead ONE workgroup per output channel covers all four 16-channel groups: lane group
+        // sl = 4 * (channel group) + split, nine independent loads per thread, one contiguous run of 64 * ntaps floats out.  Same summation
+        // order as the general path ((s0 + s1) + (s2 + s3)): bit-identical results.
+        if (cg != 0) return;   // (uniform per block)
+        const int n_all = min(min(32 * P.n_ctiles, P.cin - P.c0), 64);
+        const int cgi = sl >> 2, sp = sl & 3, c = cgi * 16 + cl;
+        if (c < n_all && sp < P.nsplit) {
+            const float* src = ws + P.ws_off + (size_t)sp * sstride + oc * 64 + c;
+            float q[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) q[t] = t < ntaps ? src[(long long)t * tstride] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                if (t < ntaps) red[(sl * 16 + cl) * 17 + t] = q[t];
+        } else if (c < n_all) {
+            for (int t = 0; t < ntaps; ++t) red[(sl * 16 + cl) * 17 + t] = 0.f;
+        }
+        __syncthreads();
+        float* dst = grad + P.dst_w_off + ((long long)goc * P.cin + P.c0) * NT + P.tap0;
+        const int nvalid = n_all * ntaps;
+        for (int o = threadIdx.x; o < nvalid; o += 256) {
+            const int cc = o / ntaps, tap = o - cc * ntaps;
+            const float* r = red + (((cc >> 4) * 4) * 16 + (cc & 15)) * 17 + tap;
+            const float tot = (r[0] + r[16 * 17]) + (r[2 * 16 * 17] + r[3 * 16 * 17]);
+            dst[ntaps == NT ? (long long)o : (long long)cc * NT + tap] = tot * scale;
+        }
+        if (P.dst_b_off >= 0 && threadIdx.x < 64) {
+            float b = threadIdx.x < (P.bias_nsplit > 0 ? P.bias_nsplit : P.nsplit) ? ws[P.ws_bias_off + (size_t)threadIdx.x * bstride + oc] : 0.f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) b += __shfl_xor(b, o, 64);
+            if (threadIdx.x == 0) grad[P.dst_b_off + goc] = b * scale;
+        }
+        return;
+    }
     if (n_c > 0) {
         const float* src = ws + P.ws_off + oc * 64 + cg * 16 + cl;
         for (int tap0 = 0; tap0 < ntaps; tap0 += 3) {      // three taps x eight splits = 24 independent loads in flight per thread: the
@@ -1259,7 +1295,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const dasr_wgrad_redu
     }
     if (cg == 0 && P.dst_b_off >= 0 && threadIdx.x < 64) {   // bias of this output channel: lane l sums splits l, l + 64, ...; fixed xor tree
         float b = 0.f;
-        for (int sp = threadIdx.x; sp < P.nsplit; sp += 64) b += ws[P.ws_bias_off + (size_t)sp * bstride + oc];
+        const int nb_ = P.bias_nsplit > 0 ? P.bias_nsplit : P.nsplit;
+        for (int sp = threadIdx.x; sp < nb_; sp += 64) b += ws[P.ws_bias_off + (size_t)sp * bstride + oc];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) b += __shfl_xor(b, o, 64);
         if (threadIdx.x == 0) grad[P.dst_b_off + goc] = b * scale;

@@ -196,8 +196,11 @@ class _GPlan:
             else:
                 self.s16 = [B16() for _ in range(nb)]       # f16 shadows of the residual stream s[0 .. nb-1] and of the block-internal activations
                 self.h16 = [B16() for _ in range(nb)]
-            self.g_s16 = [B16() for _ in range(2)]      # gscale * dL/ds, gscale * dL/dh in f16
-            self.g_h16 = B16()
+            # gscale * dL/ds[j] (j = 0 .. nb) and gscale * dL/dh[k] in f16: ONE buffer per level (round 4), so that the 2 nb weight gradients of the
+            # residual blocks run as ONE grouped launch behind the data-gradient chain (16 parts x 16 pixel splits instead of 16 launches of
+            # 1 part x 256 splits: a sixteenth of the partial-sum traffic, one reduce instead of sixteen); 2 nb x 67 MB at batch 8 x 256^2
+            self.g_s16 = [B16() if j > 0 else None for j in range(nb + 1)]
+            self.g_h16 = [B16() for _ in range(nb)]
             # dL/dfake of the mean losses is ~(largest loss weight) / (number of output elements): a power of two puts it at ~2^-3 before the f16
             # rounding.  net.loss_weight = max(w_col, w_tex, w_per) (set by DSNModel; 1 for a bare generator): with w_col = 0 the gradient is
             # 2-3 orders smaller and would otherwise sit in f16's subnormal range (the non-finite flag only sees overflow)
@@ -247,7 +250,7 @@ class _GPlan:
         o = _op(_lib.OP_B2NCHW)
         o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.p[0] = self.fake.view(), N, 3, H4, W4, self.fake_nchw.data_ptr()
         f.add(o)
-        self.fwd = f
+        self.fwd = f.tag(1)
         # ---- backward (input: g_fake = dL/d fake) ----
         b = OpList()
         G = P.grad.data_ptr()
@@ -255,19 +258,6 @@ class _GPlan:
         def wg(key, g, inp, cout, cin, hi, wi, ho, wo, stride=1):
             grp = WgradGroup(3, stride)
             grp.add_conv(g.view, True, g.planes, inp.view, True, inp.planes, cout, cin, hi, wi, ho, wo, N, P.off(key + 'weight'), P.off(key + 'bias'))
-            grp.finalize(self.ws, dev)
-            for op in grp.ops(G):
-                b.add(op)
-            b.keep.append(grp)
-
-        def wg16(key, g16, inp16):
-            """weight gradient of a 64 -> 64 conv from the f16 shadows (g16 holds gscale * dL/dy): the 12-wave LDS-DMA kernel, one part = the 64
-            input channels x the two 32-oc tiles"""
-            grp = WgradGroup3()
-            tiles = [dict(dst_w_off=P.off(key + 'weight'), dst_b_off=P.off(key + 'bias'), cout=64, cin=64, oc0=oc0, c0=0, n_ctiles=2) for oc0 in (0, 32)]
-            grp.add_block(g16.view(), 4, inp16.view(), 4, 2, H, W, H, W, N, tiles, want_bias=True)
-            grp.f16, grp.g_scale = True, self.gscale
-            grp.flops = 2.0 * N * H * W * 9 * 64 * 64
             grp.finalize(self.ws, dev)
             for op in grp.ops(G):
                 b.add(op)
@@ -310,23 +300,34 @@ class _GPlan:
             b.add(conv_op(pack, pk['out_b'], self.gz_out.view(), True, 16, H, W, H, W, N, out_f32=gs.view()))
         if b16 and nb:   # gscale * dL/ds[nb] in f16
             o = _op(_lib.OP_CVT_F16)
-            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1] = gs.view(), N, 64, H, W, self.gscale, self.g_s16[0].view()
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1] = gs.view(), N, 64, H, W, self.gscale, self.g_s16[nb].view()
             b.add(o)
-        gs16 = self.g_s16[0] if b16 else None
+        wgrp = None
+        if b16 and nb:
+            wgrp = WgradGroup3()
+            wgrp.f16, wgrp.g_scale, wgrp.flops = True, self.gscale, 0.0
+
+        def wg16_part(key, g16, inp16):
+            """weight gradient of a 64 -> 64 conv from the f16 shadows (g16 holds gscale * dL/dy) as one part of the grouped launch: the 64 input
+            channels x the two 32-oc tiles"""
+            tiles = [dict(dst_w_off=P.off(key + 'weight'), dst_b_off=P.off(key + 'bias'), cout=64, cin=64, oc0=oc0, c0=0, n_ctiles=2) for oc0 in (0, 32)]
+            wgrp.add_block(g16.view(), 4, inp16.view(), 4, 2, H, W, H, W, N, tiles, want_bias=True)
+            wgrp.flops += 2.0 * N * H * W * 9 * 64 * 64
+
         for k in range(nb - 1, -1, -1):
             pre = 'res_blocks.%d.' % k
             if b16:
                 inv = 1.0 / self.gscale
-                wg16(pre + 'conv2.', gs16, self.h16[k])
+                gs16, g_h16 = self.g_s16[k + 1], self.g_h16[k]
+                wg16_part(pre + 'conv2.', gs16, self.h16[k])
                 b.add(conv_op(pack, pk['r%d_2_b16' % k], gs16.view(), False, 64, H, W, H, W, N, mask=self.h16[k].view(), mask_f32=0,
-                              slope_ptr=sp(pre + 'prelu.weight'), alpha=inv, out_bf16=self.g_h16.view(), out16_f16=1, gamma=self.gscale))
-                prelu_grad(pre + 'prelu.weight', self.h16[k], self.g_h16, H, W, f16=True)   # (dL/dh is never materialised in f32)
-                wg16(pre + 'conv1.', self.g_h16, self.s16[k])
+                              slope_ptr=sp(pre + 'prelu.weight'), alpha=inv, out_bf16=g_h16.view(), out16_f16=1, gamma=self.gscale))
+                prelu_grad(pre + 'prelu.weight', self.h16[k], g_h16, H, W, f16=True)   # (dL/dh is never materialised in f32)
+                wg16_part(pre + 'conv1.', g_h16, self.s16[k])
                 nxt = self.g_s[1] if gs is self.g_s[0] else self.g_s[0]
-                nxt16 = self.g_s16[1] if gs16 is self.g_s16[0] else self.g_s16[0]
-                b.add(conv_op(pack, pk['r%d_1_b16' % k], self.g_h16.view(), False, 64, H, W, H, W, N, alpha=inv, res1=gs.view(), beta1=1.0,
-                              out_f32=nxt.view(), out_bf16=nxt16.view(), out16_f16=1, gamma=self.gscale))
-                gs, gs16 = nxt, nxt16
+                b.add(conv_op(pack, pk['r%d_1_b16' % k], g_h16.view(), False, 64, H, W, H, W, N, alpha=inv, res1=gs.view(), beta1=1.0,
+                              out_f32=nxt.view(), out_bf16=self.g_s16[k].view() if k > 0 else None, out16_f16=1, gamma=self.gscale))   # (level 0 has no 16-bit consumer)
+                gs = nxt
                 continue
             wg(pre + 'conv2.', gs, self.h[k], 64, 64, H, W, H, W)
             b.add(conv_op(pack, pk['r%d_2_b' % k], gs.view(), True, 64, H, W, H, W, N, mask=self.h[k].view(), mask_f32=1,
@@ -336,6 +337,11 @@ class _GPlan:
             nxt = self.g_s[1] if gs is self.g_s[0] else self.g_s[0]
             b.add(conv_op(pack, pk['r%d_1_b' % k], self.g_h.view(), True, 64, H, W, H, W, N, res1=gs.view(), beta1=1.0, out_f32=nxt.view()))
             gs = nxt
+        if wgrp is not None:   # all 2 nb residual-block weight gradients: one launch of 2 nb parts, one reduce
+            wgrp.finalize(self.ws, dev)
+            for op in wgrp.ops(G):
+                b.add(op)
+            b.keep.append(wgrp)
         # s[0] = PReLU(conv_in(x)): apply PReLU' to dL/ds0, then the input conv's weight gradient
         o = _op(_lib.OP_AXPBY)
         o.t[0], o.f[0], o.t[1], o.f[1] = gs.view(), 1.0, NULL_T, 0.0
@@ -344,7 +350,7 @@ class _GPlan:
         b.add(o)
         prelu_grad('block_input.1.weight', self.s[0], self.g_h, H, W)
         wg('block_input.0.', self.g_h, self.x_in, 64, 3, H, W, H, W)
-        self.bwd = b
+        self.bwd = b.tag(4)
         self.ws.finalize()
 
     def set_grad_scale(self, scale):

@@ -13,6 +13,12 @@ from ._lib import Tensor, ConvParams, WgradPart, WgradReducePart, PackDesc, Op
 
 SLOPE = 0.2
 
+# time buckets of a training step (OpList.tag / bench.py `buckets`)
+BUCKETS = {1: 'G forward: trunk fea_conv .. LR_conv (DSN: whole generator)', 2: 'G HR tail forward', 3: 'G HR tail backward (data + weight gradients)',
+           4: 'G trunk data gradient (DSN: generator backward)', 5: 'G trunk weight gradients (deferred phase + reduce)', 6: 'perceptual net forward, gradient images',
+           7: 'perceptual net forward, target images (one pass)', 8: 'perceptual net data gradient', 9: 'discriminator forward',
+           10: 'discriminator backward (data + weight gradients)', 11: 'G other backward (LR_conv, fea_conv)', 0: 'losses / filters / layout / optimiser'}
+
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -193,6 +199,14 @@ class OpList:
         self.keep.extend(other.keep)
         self._arr = None
 
+    def tag(self, bucket, start=0, end=None):
+        """time-bucket tag (Op.i[7], read by no kernel; bench.py's per-bucket table) on the not yet tagged ops [start, end)"""
+        for o in self.ops[start:end]:
+            if o.i[7] == 0:
+                o.i[7] = bucket
+        self._arr = None
+        return self
+
     def set_i(self, idx, slot, value):
         """patch integer argument `slot` of op `idx` in place (recorded list AND its ctypes image): for the few arguments that change from call to
         call while the plan stays recorded (e.g. the random symmetry of DSN --lpips_rot_flip)"""
@@ -311,10 +325,14 @@ class WgradGroup:
         self.parts = []  # (WgradPart, WgradReducePart)
 
     def add_conv(self, g, g_f32, g_planes_total, inp, in_f32, in_planes_total, cout, cin, Hin, Win, Hout, Wout, N,
-                 dst_w_off, dst_b_off, pad=None, ups=0, f16=False, g_scale=0.0):
+                 dst_w_off, dst_b_off, pad=None, ups=0, f16=False, g_scale=0.0, split=None):
         """g / inp are BTensor-like callables c0 -> dasr_tensor view.  f16: the f32 tensors are rounded to f16 (g pre-scaled by the
-        power of two g_scale) instead of bf16 while staging; the reduce op undoes the scale."""
+        power of two g_scale) instead of bf16 while staging; the reduce op undoes the scale.
+        split = (g_lo, inp_lo) (views like g / inp, filled by dasr_f16_residual): 22-bit operands on the f16 MFMA -- every part becomes THREE
+        parts g.x, g.x_lo, g_lo.x whose partial sums lie behind one another as 3 * nsplit splits of ONE reduce part (the bias partials, which come
+        from the unrounded gradient, only from the first)."""
         assert not f16 or (g_f32 and in_f32)
+        assert split is None or f16
         self.f16 = bool(f16) or getattr(self, 'f16', False)
         self.g_scale = float(g_scale) if f16 and g_scale else getattr(self, 'g_scale', 0.0)
         ntaps = self.kh * self.kh
@@ -323,26 +341,32 @@ class WgradGroup:
         self.flops = getattr(self, 'flops', 0.0) + 2.0 * N * Hout * Wout * ntaps * cin * cout
         pad = (self.kh - 1) // 2 if pad is None else pad
         cin_pad = ceil_div(cin, 16) * 16
+        variants = [(g, inp)] if split is None else [(g, inp), (g, split[1]), (split[0], inp)]
         for oc0 in range(0, cout, 32):
             for c0 in range(0, cin_pad, 64):
                 for tap0 in range(0, ntaps, tpp):
-                    wp, rp = WgradPart(), WgradReducePart()
-                    wp.g, wp.g_f32 = g(oc0), int(g_f32)
-                    wp.inp, wp.in_f32 = inp(c0), int(in_f32)
-                    wp.ups = ups
-                    wp.n_ctiles = min(2, ceil_div(cin_pad - c0, 32))
-                    wp.g_planes = min(2, g_planes_total - oc0 // 16)
-                    wp.in_planes = min(4, in_planes_total - c0 // 16)
-                    wp.Hin, wp.Win, wp.Hout, wp.Wout, wp.N = Hin, Win, Hout, Wout, N
-                    wp.kh, wp.stride, wp.pad, wp.tap0 = self.kh, self.stride, pad, tap0
+                    rp = WgradReducePart()
                     first = dst_b_off is not None and c0 == 0 and tap0 == 0
-                    wp.want_bias = 1 if first else 0
-                    wp.g_scale = float(g_scale) if f16 else 0.0
-                    rp.ntaps, rp.oc0, rp.c0, rp.cout, rp.cin, rp.n_ctiles = min(tpp, ntaps - tap0), oc0, c0, cout, cin, wp.n_ctiles
+                    wps = []
+                    for vi, (gv, xv) in enumerate(variants):
+                        wp = WgradPart()
+                        wp.g, wp.g_f32 = gv(oc0), int(g_f32)
+                        wp.inp, wp.in_f32 = xv(c0), int(in_f32)
+                        wp.ups = ups
+                        wp.n_ctiles = min(2, ceil_div(cin_pad - c0, 32))
+                        wp.g_planes = min(2, g_planes_total - oc0 // 16)
+                        wp.in_planes = min(4, in_planes_total - c0 // 16)
+                        wp.Hin, wp.Win, wp.Hout, wp.Wout, wp.N = Hin, Win, Hout, Wout, N
+                        wp.kh, wp.stride, wp.pad, wp.tap0 = self.kh, self.stride, pad, tap0
+                        wp.want_bias = 1 if (first and vi == 0) else 0
+                        wp.g_scale = float(g_scale) if f16 else 0.0
+                        wps.append(wp)
+                    rp.ntaps, rp.oc0, rp.c0, rp.cout, rp.cin, rp.n_ctiles = min(tpp, ntaps - tap0), oc0, c0, cout, cin, wps[0].n_ctiles
                     rp.tap0, rp.ntaps_total = tap0, ntaps
                     rp.dst_w_off = dst_w_off
                     rp.dst_b_off = dst_b_off if first else -1
-                    self.parts.append((wp, rp))
+                    for wp in wps:
+                        self.parts.append((wp, rp if wp is wps[0] else None, len(wps) if wp is wps[0] else 0))
 
     def finalize(self, workspace, device, target_wgs=768):
         wp0 = self.parts[0][0]
@@ -352,20 +376,28 @@ class WgradGroup:
         self.nsplit = max(1, min(ntiles, target_wgs // nparts))
         if self.nsplit >= 16:
             self.nsplit -= self.nsplit % 8  # same pixel split -> same XCD (block id % 8) for every part: shared L2 lines
-        ntaps = self.kh * self.kh
         off = 0
-        for wp, rp in self.parts:
-            wp.ws_off = rp.ws_off = off
+        reds = []
+        for wp, rp, nvar in self.parts:   # a reduce part owns `nvar` consecutive wgrad parts (split operands: 3) = nvar * nsplit splits
+            wp.ws_off = off
+            if rp is not None:
+                rp.ws_off = off
+                rp.nsplit = self.nsplit * nvar
+                rp.bias_nsplit = self.nsplit if nvar > 1 else 0
+                rp.split_stride, rp.tap_stride, rp.bias_stride = self.tpp * 2048, 2048, 32
+                reds.append(rp)
             off += self.nsplit * self.tpp * 2048
-            wp.ws_bias_off = rp.ws_bias_off = off
+        for wp, rp, nvar in self.parts:   # bias partials behind all weight partials (only the first variant of a conv's first part writes them)
+            wp.ws_bias_off = off
+            if rp is not None:
+                rp.ws_bias_off = off
             off += self.nsplit * 32
-            rp.nsplit = self.nsplit
-            rp.split_stride, rp.tap_stride, rp.bias_stride = self.tpp * 2048, 2048, 32
         self.ws_floats = off
         self.workspace = workspace
         workspace.reserve(off)
         wa = (WgradPart * nparts)(*[p[0] for p in self.parts])
-        ra = (WgradReducePart * nparts)(*[p[1] for p in self.parts])
+        ra = (WgradReducePart * len(reds))(*reds)
+        self.n_red = len(reds)
         self.w_dev = torch.frombuffer(bytearray(bytes(wa)), dtype=torch.uint8).to(device)
         self.r_dev = torch.frombuffer(bytearray(bytes(ra)), dtype=torch.uint8).to(device)
 
@@ -379,7 +411,7 @@ class WgradGroup:
         a.i[4] = self.parts[0][0].g_f32 | (2 if getattr(self, 'f16', False) else 0)
         a.flops = float(getattr(self, 'flops', 0.0))
         b.op = _lib.OP_WGRAD_REDUCE
-        b.p[0], b.i[0], b.p[2], b.f[0] = self.r_dev.data_ptr(), len(self.parts), grad_ptr, scale
+        b.p[0], b.i[0], b.p[2], b.f[0] = self.r_dev.data_ptr(), self.n_red, grad_ptr, scale
         gs = getattr(self, 'g_scale', 0.0)
         b.f[1] = 1.0 / gs if gs else 0.0   # second factor of the reduce scale (f[0] stays the data-parallel 1/world): undoes the f16 pre-scale
         self.workspace.register(a, b)

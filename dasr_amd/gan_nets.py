@@ -182,6 +182,10 @@ class BatchNormDiscriminatorHIP(NLayerDiscriminatorHIP):
     statistics live outside the optimiser's buffers and are updated by `_DPlan.running_ops(group)` in the order of the reference's forwards."""
     bn_groups = 2
     prec = 4   # the BatchNorm backward cancels group means: 16-bit conv operands leave 4e-2 on the first layers' gradients, 22-bit ones 1e-3
+    # weight gradients with 22-bit operands too (round 4): dW = g.x + g.x_lo + g_lo.x, x_lo / g_lo = what the f16 rounding of the staged operand
+    # drops (dasr_f16_residual), three parts of one launch of the f16 weight-gradient kernel.  With 11-bit operands the DASR step's D_source
+    # gradients were 1.3e-2 off an fp64 run of the reference step; emulated on the oracle: 4.6e-3 -> 1.9e-3 (oracle/bn_probe.py)
+    split_wgrad = True
 
     def __init__(self, input_nc, device='cuda', spec_layers=None):
         super().__init__(input_nc, device=device, spec_layers=spec_layers)
@@ -282,8 +286,8 @@ class _DPlan:
         self.ga = [BTensor(N, a.C, a.H, a.W, True, dev) for a in self.acts[:-1]]
         self.gz = [BTensor(N, a.C, a.H, a.W, True, dev) for a in self.acts[:-1]] + [self.g_logits]
         self.ws = Workspace(dev)
-        self.fwd = self._build_fwd(N)
-        self.bwd_full = self._build_bwd(N, wgrad=True, input_grad=False)
+        self.fwd = self._build_fwd(N).tag(9)
+        self.bwd_full = self._build_bwd(N, wgrad=True, input_grad=False).tag(10)
         self.bwd_data = {}
         self.ws.finalize()
 
@@ -359,12 +363,21 @@ class _DPlan:
                 ops.add(o)
             inp = self.x if i == 0 else self.acts[i - 1]
             if wgrad:
+                split = None
+                if getattr(net, 'split_wgrad', False) and net.prec == 4:
+                    g_lo, x_lo = BTensor(N, gz.C, gz.H, gz.W, True, net.device), BTensor(N, inp.C, inp.H, inp.W, True, net.device)
+                    for src, dst, sc in ((gz, g_lo, 4096.0), (inp, x_lo, 1.0)):
+                        o = _op(_lib.OP_CVT_F16)
+                        o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], o.t[1], o.i[4] = src.view(), N, src.C, src.H, src.W, sc, dst.view(), 3
+                        ops.add(o)
+                    ops.keep += [g_lo, x_lo]
+                    split = (g_lo.view, x_lo.view)
                 grp = WgradGroup(L['kh'], L['stride'])
                 # prec 4 nets: the weight-gradient operands are rounded to f16 (11 bits, gradient pre-scaled) instead of bf16 (8 bits): behind a
                 # BatchNorm the output gradient sums to zero over the group, so only the deviation of the input from its mean counts
                 grp.add_conv(gz.view, True, gz.planes, inp.view, True, inp.planes, L['cout'], L['cin'], hi, wi, ho, wo, N,
                              P.off(L['key'] + 'weight'), P.off(L['key'] + 'bias') if L['bias'] else None, pad=L['pad'],
-                             f16=net.prec == 4, g_scale=4096.0 if net.prec == 4 else 0.0)
+                             f16=net.prec == 4, g_scale=4096.0 if net.prec == 4 else 0.0, split=split)
                 grp.finalize(self.ws, net.device)
                 for o in grp.ops(P.grad.data_ptr()):
                     ops.add(o)
@@ -396,7 +409,7 @@ class _DPlan:
         """data-gradient only (generator step) for the first n images"""
         if n not in self.bwd_data:
             ws_before = self.ws.need
-            self.bwd_data[n] = self._build_bwd(n, wgrad=False, input_grad=True)
+            self.bwd_data[n] = self._build_bwd(n, wgrad=False, input_grad=True).tag(10)
             assert self.ws.need == ws_before
         return self.bwd_data[n]
 
@@ -539,7 +552,7 @@ class _VGGPlan:
             self.outs.append(out)
             src = out
         self.feat = src
-        self.fwd = fwd
+        self.fwd = fwd.tag(6)
         # data gradient for the first n_g images.  Gradients handed between layers are w.r.t. PRE-activation values:
         # a dgrad conv's epilogue applies the ReLU' of the layer that produced its input; a pool's backward applies the
         # ReLU' of the conv feeding the pool (every VGG pool follows a ReLU).
@@ -567,7 +580,7 @@ class _VGGPlan:
                 o.i[6] = inp.W
                 bwd.add(o)
             g = gin
-        self.bwd = bwd
+        self.bwd = bwd.tag(8)
 
     def input_copy_op(self, src_view, n0, n, H, W):
         """op that writes `n` images of a blocked f32 tensor (<= 16 channels) into x[n0 : n0 + n] (DSN: no input normalisation)"""
@@ -618,6 +631,7 @@ class _VGGPlan:
                     fwd.add(conv_op(pack, net.pk[(idx, 'r')], _nview_t(src, n_g), False, c16(cin), h, w, h, w, N - n_g, bias=bias,
                                     act=1 if relu else 0, slope=0.0, out_f32=_nview_t(out, n_g) if last else None,
                                     out_bf16=None if last else _nview_t(out, n_g), out16_f16=0 if last else 1))
+                    fwd.ops[-1].i[7] = 7
             else:
                 h, w = h // 2, w // 2
                 out = Bf(cout, h, w) if li > lc else Bs(cout, h, w)
@@ -628,7 +642,7 @@ class _VGGPlan:
             self.outs.append(out)
             src = out
         self.feat = src
-        self.fwd = fwd
+        self.fwd = fwd.tag(6)
         n = n_g
         self.g_feat = Bf(self.feat.C, self.feat.H, self.feat.W)
         self.gx = Bf(16, H, W)
@@ -670,7 +684,7 @@ class _VGGPlan:
                 o.i[6] = inp.W
                 bwd.add(o)
             g = gin
-        self.bwd = bwd
+        self.bwd = bwd.tag(8)
 
     def _init_f16(self, N, n_g, H, W):
         """f16 storage: every activation up to the last conv (and, backward, every gradient below it, pre-scaled by gscale) is an f16 tensor;
@@ -708,7 +722,7 @@ class _VGGPlan:
             self.outs.append(out)
             src = out
         self.feat = src
-        self.fwd = fwd
+        self.fwd = fwd.tag(6)
         n = n_g
         self.g_feat = Bf(self.feat.C, self.feat.H, self.feat.W)
         self.gx = Bf(16, H, W)
@@ -743,4 +757,4 @@ class _VGGPlan:
                 o.i[6] = inp.W
                 bwd.add(o)
             g = gin
-        self.bwd = bwd
+        self.bwd = bwd.tag(8)

@@ -243,7 +243,7 @@ class _LPIPSPlan:
                 src, h, w = pl, hp, wp
             else:
                 self.pool.append(None)
-        self.fwd = fwd
+        self.fwd = fwd.tag(6)
         # head gradients (w.r.t. the pre-activations of relu_k, fake images only); the data-gradient chain adds into / reads them
         self.ghead = [BTensor(n, r.C, r.H, r.W, True, dev) for r in self.relu]
         self.gx = BTensor(n, 48, Hs, Ws, True, dev)
@@ -273,7 +273,7 @@ class _LPIPSPlan:
         r1 = self.relu[0]
         bwd.add(conv_op(pack, net.pk[('features.0', 'b')], g.view(), True, 64, r1.H, r1.W, Hs, Ws, n, kh=3, pad=2, out_f32=self.gx.view(),
                         flops=2.0 * n * r1.H * r1.W * 121 * 3 * 64, in_scale=gsc))
-        self.bwd = bwd
+        self.bwd = bwd.tag(8)
         self._sc = [2.0 / s for s in SCALE] + [0.0]
         self._sh = [-(1.0 + sh) / s for sh, s in zip(SHIFT, SCALE)] + [0.0]
 

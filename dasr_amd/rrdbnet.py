@@ -283,6 +283,7 @@ class TrunkStore:
             hi = P.off('model.1.sub.%d.RDB1.conv1.0.weight' % hi_rrdb) if hi_rrdb < nb else P.off('model.1.sub.%d.weight' % nb)
             self.groups.append((first, len(self.phase.ops), lo, hi))
             hi_rrdb = lo_rrdb
+        self.phase.tag(5)
 
     def set_grad_scale(self, scale):
         changed = False
@@ -419,6 +420,7 @@ class _Plan:
         if net.hr_f16s:
             ops.add(conv_op(pack, pk['lr'], X.view(), True, nf, h, w, h, w, N, bias=P.ptr(lrb), res1=self.fea.view(), beta1=1.0,
                             out_f32=self.t0.view(), out_bf16=self.t0h.view(), out16_f16=1))
+            ops.tag(1)
             if net.ps:   # pixelshuffle_block (block.py:838-851): conv nf -> 4 nf, PixelShuffle(2), LeakyReLU (applied before the shuffle: it is elementwise)
                 for name, bkey, src, pre, dst, hi, wi in (('up1', 'model.2.bias', self.t0h, self.ps1, self.u1, h, w), ('up2', 'model.5.bias', self.u1, self.ps2, self.u2, H2, W2)):
                     ops.add(conv_op(pack, pk[name], src.view(), False, nf, hi, wi, hi, wi, N, bias=P.ptr(bkey), act=1, out_bf16=pre.view(), out16_f16=1))
@@ -436,10 +438,11 @@ class _Plan:
             o.op = _lib.OP_B2NCHW
             o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.p[0] = self.sr.view(), N, net.out_nc, H4, W4, self.sr_nchw.data_ptr()
             ops.add(o)
-            self.fwd = ops
+            self.fwd = ops.tag(2)
             return
         ops.add(conv_op(pack, pk['lr'], X.view(), True, nf, h, w, h, w, N, bias=P.ptr(lrb), res1=self.fea.view(), beta1=1.0,
                         out_f32=self.t0.view()))
+        ops.tag(1)
         for name, bkey, src, dst, hi, wi in (('up1', 'model.3.bias', self.t0, self.u1, h, w), ('up2', 'model.6.bias', self.u1, self.u2, H2, W2)):
             if not net.subpixel:
                 ops.add(conv_op(pack, pk[name], src.view(), True, nf, hi, wi, 2 * hi, 2 * wi, N, bias=P.ptr(bkey), ups=1, act=1, out_f32=dst.view()))
@@ -457,7 +460,7 @@ class _Plan:
         o.op = _lib.OP_B2NCHW
         o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.p[0] = self.sr.view(), N, net.out_nc, H4, W4, self.sr_nchw.data_ptr()
         ops.add(o)
-        self.fwd = ops
+        self.fwd = ops.tag(2)
 
     # ---- backward (input: self.g_sr filled by a loss kernel) -----------------------------------------------
     def _wg(self, ops, conv_key, g, g_f32, inp, in_f32, cout, cin, Hin, Win, Hout, Wout, ups=0, groups=None, f16=False):
@@ -505,6 +508,7 @@ class _Plan:
             self._build_backward_tail_f16(ops)
         else:
             self._build_backward_tail_f32(ops, f16, gs)
+        ops.tag(3)
         self._build_backward_trunk(ops)
 
     def _wg3_target(self, nparts):
@@ -629,6 +633,7 @@ class _Plan:
         # LR_conv (model.1.sub.nb): t0 = fea + LR_conv(x_last)
         lrk = 'model.1.sub.%d.' % nb
         self._wg(ops, lrk, self.g_t0, True, self.x_last, True, nf, nf, h, w, h, w)
+        ops.tag(11)
         # gradient buckets: (index into ops, lo, hi): params.grad[lo:hi] is complete once ops[:index] have run
         self._marks = [(len(ops.ops), P.off(lrk + 'weight'), P.total)]
         free = list(self.gstream)
@@ -664,6 +669,7 @@ class _Plan:
                 Gout = Gin
                 gs_cur += 1
             G = Gout
+        ops.tag(4)
         rrdb0 = P.off('model.1.sub.0.RDB1.conv1.0.weight')
         if not self.shared_store:   # this plan owns the whole batch: the weight-gradient phase follows the chain in the same list
             st = self.store
@@ -681,6 +687,7 @@ class _Plan:
         ops.add(o)
         self._wg(ops, 'model.0.', self.g_fea, True, self.x_in, True, nf, net.in_nc, h, w, h, w)
         self._marks.append((len(ops.ops), 0, rrdb0))
+        ops.tag(11)
         self.bwd = ops
         self._segments = None
 

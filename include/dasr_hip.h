@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DASR_ABI_VERSION 13
+#define DASR_ABI_VERSION 14
 #define DASR_EINVAL (-22)
 
 typedef struct {
@@ -138,6 +138,8 @@ typedef struct {
     /* workspace strides (floats); 0 = the 4-wave layout [split][tap][32][64] / bias [split][32] */
     int64_t split_stride, tap_stride, bias_stride;
     int32_t tap0, ntaps_total;              /* part covers taps [tap0, tap0+ntaps) of a kernel with ntaps_total taps (0: = ntaps) */
+    int32_t bias_nsplit, reserved_;         /* splits that carry a bias partial (0: = nsplit).  Split-operand weight gradients (three wgrad parts
+                                             * g.x, g.x_lo, g_lo.x laid out as 3 * nsplit consecutive splits) sum the bias over the first nsplit only */
 } dasr_wgrad_reduce_part;
 
 int dasr_wgrad_reduce(const dasr_wgrad_reduce_part* parts_dev, int32_t nparts, const float* ws, float* grad_flat,
@@ -199,6 +201,10 @@ int dasr_downsum2x(dasr_tensor src, int32_t N, int32_t C, int32_t H, int32_t W, 
 int dasr_cvt_f16(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, float scale, dasr_tensor y, void* stream);
 /* split 16-bit copy (dasr_conv_params::in_wrap): y planes [0, K) = round16(scale * x), planes [K, 2K) = round16(scale * x - hi); f16 != 0: IEEE half, else bfloat16 */
 int dasr_cvt_split16(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, float scale, dasr_tensor y, int32_t f16, void* stream);
+/* y (f32) = x - f16(scale * x) / scale on a blocked f32 tensor: the part of x an f16 operand rounding drops.  Used to run the weight gradients of
+ * the BatchNorm discriminators (Discriminator_VGG_128 architecture.py:442-495, FSD-Batch codes/DSN/model.py:176-189) with 22-bit operands on the
+ * f16 MFMA: dW = g.x + g.x_lo + g_lo.x as three parts of one dasr_wgrad launch (their D gradients were 1.3e-2 off an fp64 run). */
+int dasr_f16_residual(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, float scale, dasr_tensor y, void* stream);
 int dasr_downsum2x_f16(dasr_tensor src, int32_t N, int32_t C, int32_t H, int32_t W, dasr_tensor mask /* f16, optional */, float slope,
                        float out_scale, dasr_tensor dst_f32, dasr_tensor dst_f16, void* stream);
 
@@ -403,7 +409,8 @@ int dasr_rccl_destroy(void* comm);
  * Between dasr_prof_begin and dasr_prof_end every kernel launch of the library (up to `capacity`) carries its own start/stop
  * events on its launch stream (hipExtLaunchKernel: the dispatch's begin/end timestamps, what rocprofv3 --kernel-trace prints).
  * dasr_prof_end synchronises the device and returns, per launch in issue order: duration in microseconds, the algorithmic
- * flops / bytes of the op it belongs to (dasr_op.flops / .bytes, attributed to the op's first launch), the op kind and a
+ * flops / bytes of the op it belongs to (dasr_op.flops / .bytes, attributed to the op's first launch), the op kind (bits 0-7; bits 8-15: the
+ * plan builder's time-bucket tag dasr_op.i[7], which no kernel reads) and a
  * static string naming the kernel variant.  Returns the number of records written (<= max_out) or a negative error. */
 int dasr_prof_begin(int32_t capacity);
 int dasr_prof_end(int32_t max_out, float* us_out, double* flops_out, double* bytes_out, int32_t* op_out, const char** tag_out);

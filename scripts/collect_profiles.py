@@ -23,5 +23,19 @@ out = {'source': 'profiles/%s_pmc_traffic.txt: rocprofv3 --pmc FETCH_SIZE / --pm
 for k, v in f.items():
     if k in w:
         out['kernels'][k] = {'fetch_size_kb_raw': round(v['avg_kb'], 1), 'write_size_kb': round(w[k]['avg_kb'], 1), 'launches': v['launches']}
+# secondary workloads (configs[2] with VGG19-54 / LPIPS, configs[4] with VGG16 / LPIPS): kernel stats of scripts/prof_secondary.sh and the PMC passes
+# of scripts/r04/call3.sh (gpurun_out/pmcs_<workload>_<COUNTER>_summary.json), keyed like bench.py's `secondary` entries
+out['workloads'] = {}
+for wl in ('dasr_vgg', 'dasr_lpips', 'dsn_vgg', 'dsn_lpips'):
+    st = os.path.join(G, 'prof_sec', wl + '_kernel_stats.csv')
+    if os.path.exists(st):
+        shutil.copy(st, os.path.join(P, '%s_%s_kernel_stats.csv' % (tag, wl)))
+    fs, wsz = (os.path.join(G, 'pmcs_%s_%s_summary.json' % (wl, c)) for c in ('FETCH_SIZE', 'WRITE_SIZE'))
+    if os.path.exists(fs) and os.path.exists(wsz):
+        f2, w2 = json.load(open(fs)), json.load(open(wsz))
+        out['workloads'][wl] = {k: {'fetch_size_kb_raw': round(v['avg_kb'], 1), 'write_size_kb': round(w2[k]['avg_kb'], 1), 'launches': v['launches']}
+                                for k, v in f2.items() if k in w2}
+        txt2 = open(fs.replace('.json', '.txt')).read() + open(wsz.replace('.json', '.txt')).read()
+        open(os.path.join(P, '%s_%s_pmc_traffic.txt' % (tag, wl)), 'w').write(txt2)
 json.dump(out, open(os.path.join(P, 'pmc_traffic.json'), 'w'), indent=1)
-print('collected', tag, len(out['kernels']), 'kernels')
+print('collected', tag, len(out['kernels']), 'kernels;', {k: len(v) for k, v in out['workloads'].items()})
