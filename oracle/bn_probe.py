@@ -127,9 +127,9 @@ def build(variant):
         if isinstance(v, nn.Module):
             v.double()
     v = variant
-    if v.get('g'):   # generator dense blocks
+    if v.get('g'):   # generator dense blocks: one format for all five roundings, or a tuple (fwd x, fwd w / dgrad w, dgrad g, wgrad x, wgrad g)
         rdb = [m for n, m in g64.named_modules() if 'RDB' in n]
-        patch_convs(rdb, (v['g'],) * 5)
+        patch_convs(rdb, v['g'] if isinstance(v['g'], tuple) else (v['g'],) * 5)
     if v.get('g_stream'):
         oth = [m for n, m in g64.named_modules() if 'RDB' not in n]
         patch_convs(oth, (v['g_stream'],) * 5)
@@ -166,6 +166,11 @@ def main():
     variants = [
         ('fp32 everything (the CPU reference)', None),
         ('G-bf16 (dense blocks bf16, stream convs bf16x2)', dict(g='bf16', g_stream='bf16x2')),
+        ('G dense blocks: only the WEIGHTS bf16 in the forward', dict(g=('exact', 'bf16', 'exact', 'exact', 'exact'))),
+        ('G dense blocks: only the ACTIVATIONS bf16 in the forward', dict(g=('bf16', 'exact', 'exact', 'exact', 'exact'))),
+        ('G dense blocks: data gradient, g bf16 (w exact)', dict(g=('exact', 'exact', 'bf16', 'exact', 'exact'))),
+        ('G dense blocks: weight gradient operands bf16', dict(g=('exact', 'exact', 'exact', 'bf16', 'bf16'))),
+        ('G dense blocks all f16 (11-bit) instead of bf16', dict(g='f16', g_stream='bf16x2')),
         ('D-x22 fwd/dgrad f16x2, wgrad f16', dict(d='f16x2', d_wg='f16')),
         ('D-x22 fwd/dgrad f16x2, wgrad f16x2', dict(d='f16x2', d_wg='f16x2')),
         ('D bf16x3 everywhere', dict(d='bf16x3', d_wg='bf16x3')),
@@ -196,7 +201,7 @@ def main():
             gS = {n: p.grad for n, p in netD2.named_parameters()}
         else:
             gG, gS, _ = build(v)
-        wg, ws = worst(gG, refG), worst(gS, refS)
+        wg, ws = worst(gG, refG), worst(gS, refS)   # (fw also rounds the data gradient's weights: RConv passes one weight format)
         print('%-52s G worst %.2e (%s)   D_source worst %.2e (%s)' % (name, wg[0], wg[1], ws[0], ws[1]))
         sys.stdout.flush()
 

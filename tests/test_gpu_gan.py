@@ -245,7 +245,8 @@ def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir, margin
     """round 3 additions: pixel_criterion / feature_criterion 'l2' (MSE; multiweights off so the plain pixel term goes through cri_pix), and the GAN
     step at the full ESRGAN depth nb = 23 (VERDICT r2 weak #2)"""
     dev = _gpu()
-    GRAD_TOL = VGG128_STEP_TOL if 'VGG128' in case else globals()['GRAD_TOL']   # see the note at VGG128_GRAD_TOL
+    GRAD_TOL = globals()['GRAD_TOL']
+    G_TOL = VGG128_STEP_G_TOL if 'VGG128' in case else GRAD_TOL   # see the note at VGG128_STEP_G_TOL: the generator's bf16 operands on an ill-conditioned case
     torch.set_num_threads(8)
     from oracle import fixtures, nets, trainers
     from dasr_amd import options
@@ -317,7 +318,7 @@ def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir, margin
             for (k, gv), pr in zip(gd.items(), netG.parameters()):
                 r = rel(gv, pr.grad)
                 worst = max(worst, r)
-                assert r < GRAD_TOL, ('G', k, r)
+                assert r < G_TOL, ('G', k, r)
             dd = m.netD_target.params.grad_dict()
             for (k, gv), pr in zip(dd.items(), netD.parameters()):
                 if zero_last_bias and k.endswith('model.8.bias'):
@@ -332,11 +333,11 @@ def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir, margin
                         continue
                     assert rel(gv.reshape(pr.grad.shape), pr.grad) < GRAD_TOL, ('D_source', k, rel(gv.reshape(pr.grad.shape), pr.grad))
                 np.testing.assert_allclose(np.array([float(v.double().norm()) for v in d2.values()]), gold['gradD2_norm'], rtol=GRAD_TOL, atol=1e-6)
-            np.testing.assert_allclose(np.array([float(v.double().norm()) for v in gd.values()]), gold['gradG_norm'], rtol=GRAD_TOL)
+            np.testing.assert_allclose(np.array([float(v.double().norm()) for v in gd.values()]), gold['gradG_norm'], rtol=G_TOL)
             np.testing.assert_allclose(np.array([float(v.double().norm()) for v in dd.values()]), gold['gradD_norm'], rtol=GRAD_TOL, atol=1e-6)
             w2 = max([rel(gv.reshape(pr.grad.shape), pr.grad) for (k, gv), pr in zip(m.netD_source.params.grad_dict().items(), netD2.parameters())
                       if not (zero_last_bias and k.endswith('model.8.bias'))]) if netD2 is not None else 0.0
-            margins('%s: worst gradient rel err G %.2e, D_source %.2e (bound %.0e)' % (case, worst, w2, GRAD_TOL))
+            margins('%s: worst gradient rel err G %.2e (bound %.0e), D_source %.2e (bound %.0e)' % (case, worst, G_TOL, w2, GRAD_TOL))
             if t64 is not None:
                 per_g = sorted(((rel(gv, pr.grad), k) for (k, gv), pr in zip(gd.items(), t64.netG.parameters())), reverse=True)
                 e_g = per_g[0][0]
@@ -346,8 +347,8 @@ def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir, margin
                 o_s = max(rel(p32.grad, p64.grad) for p32, p64 in zip(netD2.parameters(), t64.netD_src.parameters()))
                 margins('%s vs the fp64 oracle: HIP worst gradient rel err G %.2e, D_target %.2e, D_source %.2e; the fp32 oracle itself: G %.2e, '
                         'D_source %.2e; worst G tensors: %s' % (case, e_g, e_d, e_s, o_g, o_s, ' '.join('%s %.1e' % (k, e) for e, k in per_g[:4])))
-                assert e_g < VGG128_GRAD_TOL and e_d < 1e-2, (e_g, e_d)
-                assert e_s < VGG128_GRAD_TOL, e_s   # the BatchNorm network's own documented bound (fp32 accumulation behind nine BatchNorms)
+                assert e_g < VGG128_STEP_G_TOL and e_d < 1e-2, (e_g, e_d)
+                assert e_s < 1.1 * o_s, (e_s, o_s)   # no further from exact arithmetic than the fp32 PyTorch-CPU reference is (fp32 accumulation behind nine BatchNorms)
 
 
 @pytest.mark.parametrize('form', [2, 3], ids=['lsgan', 'wgan'])
@@ -498,16 +499,22 @@ def test_batchnorm_train_lrelu_forward_backward_two_groups():
 
 
 # Discriminator_VGG_128: nine training-mode BatchNorm layers in a row with tiny statistics groups (n x 4 x 4 values per channel at the top).
-# Forward is accurate (logits 3e-5).  Backward: (i) the weight-gradient kernel rounds its f32 operands to bf16, which averages out over the
-# pixels of a map but not on the 1 x 1 maps of the two Linear layers (3e-3 there); (ii) each BatchNorm backward subtracts the group means of
-# gz and gz * xhat from gz -- a cancellation that amplifies the relative error of the incoming gradient -- so the data-gradient error grows
-# from 2.6e-3 at conv4_1 to 8.5e-3 at the input and 1.1e-2 .. 1.4e-2 on the first layers' weight gradients.  The gradient bound of THIS network
-# is 2e-2 (documented in DESIGN.md 4.7), margins logged; every other network keeps 1e-2.
-VGG128_GRAD_TOL = 2e-2
-# in the DASR step the discriminator sees high-frequency maps (0.75 + small detail): conv outputs with |mean| >> std in front of every BatchNorm,
-# the worst case for that cancellation.  The case is ill-conditioned in itself: the fp32 CPU oracle differs from the same oracle run in fp64 by
-# 3.2e-3 on the generator gradients and 1.2e-2 on D_source's (measured with identical weights); bound 3e-2 for this case only, margins logged
-VGG128_STEP_TOL = 3e-2
+# Forward is accurate (logits 5e-6), the data gradient too (dL/dinput 4e-6: split-f16 operands).  The weight / BatchNorm-parameter gradients sit
+# 3.5 - 4.6e-3 from the fp32 torch reference: that is the noise floor of fp32 ACCUMULATION on this network (each BatchNorm backward subtracts
+# the group means of gz and gz * xhat from gz), not operand rounding -- 22-bit weight-gradient operands (round 4, dW = g.x + g.x_lo + g_lo.x)
+# leave it unchanged.  Bound: the north_star's 1e-2 (round 3: 2e-2).
+VGG128_GRAD_TOL = 1e-2
+# The DASR step with this network as D_source (dasr_srcVGG128_gau5_nf32_nb1_n3_32) is ill-conditioned: the discriminator sees high-frequency maps
+# (0.75 + small detail), conv outputs with |mean| >> std in front of every BatchNorm.  Measured (oracle/bn_probe.py, profiles/r04_bn_probe.txt:
+# the reference step in fp64 = truth, ONE component at a time degraded to the arithmetic of the HIP path):
+#   * fp32 PyTorch-CPU (the reference itself): G 3.2e-3, D_source 1.2e-2 from the fp64 result;
+#   * D_source in the HIP path's arithmetic (22-bit conv operands, fp32 BatchNorm): 3.5e-4 on the G gradients, 1.9 - 4.6e-3 on D_source's;
+#   * the generator's dense blocks with bf16 operands -- the north_star's dtype -- and EVERYTHING ELSE EXACT: G 1.24e-2 (9.8e-3 from the bf16
+#     rounding of the weights alone: a coherent 2^-9 perturbation of the network that the BatchNorm discriminator's gradient amplifies).
+# So: D_target and D_source must meet the north_star's 1e-2 against the fp32 reference, and D_source must be no further from the fp64 result than
+# the fp32 reference is (+10 %); the G gradients of THIS case are bounded by 2e-2 = what bf16 dense-block operands give on it (observed 1.46e-2
+# against fp32, 1.49e-2 against fp64); every other case keeps 1e-2 (observed 3.2 - 5.2e-3).  tests/test_bn_conditioning.py pins the 1.24e-2 on CPU.
+VGG128_STEP_G_TOL = 2e-2
 
 
 def test_discriminator_vgg128_forward_backward_and_state_dict(margins):
