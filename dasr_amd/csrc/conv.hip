@@ -1758,6 +1758,18 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                 default: return launch_glds<1, 0, 4, 0, true>(p, s);
             }
         case 2020:
+            // conv5-class epilogues (alpha, residuals -> fp32 stream + 16-bit shadow): the dense blocks in f16 storage (DASR_RDB_PREC=2, rrdbnet.py);
+            // same workgroup-shape rule as the bf16 launches
+            if (p.res1.p) {
+                const bool four = g_tune_rdb64 == 12 || (long long)p.N * ((p.Hout + 15) / 16) * ((p.Wout + 31) / 32) * ((p.cout + 63) / 64) > 256;
+                switch (g_tune_epi ? classify_epi(p) : 0) {
+                    case 233: return four ? launch_glds<2, 233, 4, 0, true>(p, s) : launch_glds<2, 233, 8, 0, true>(p, s);
+                    case 249: return four ? launch_glds<2, 249, 4, 0, true>(p, s) : launch_glds<2, 249, 8, 0, true>(p, s);
+                    case 232: return four ? launch_glds<2, 232, 4, 0, true>(p, s) : launch_glds<2, 232, 8, 0, true>(p, s);
+                    case 248: return four ? launch_glds<2, 248, 4, 0, true>(p, s) : launch_glds<2, 248, 8, 0, true>(p, s);
+                    default: return launch_glds<2, 0, 4, 0, true>(p, s);
+                }
+            }
             switch (g_tune_epi ? classify_epi(p) : 0) {
                 case 67: return launch_glds<2, 67, 4, 0, true>(p, s);
                 case 68: return launch_glds<2, 68, 4, 0, true>(p, s);

@@ -13,6 +13,7 @@ the G step are not computed.
 import ctypes as C
 import logging
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -81,7 +82,16 @@ class DASR_Model(BaseModel):
         self.ragan = bool(t['ragan'])   # relativistic average GAN: per-pixel batch means of the logits (all-reduced across data-parallel ranks)
         self.l_gan_H_target_w = t['gan_H_target'] or 0
         self.l_gan_H_source_w = (t['gan_H_source'] or 0) if self.is_train else 0
-        self.netG = _define_G(opt, self.device)
+        # the BatchNorm source discriminator (which_model_pairD: discriminator_vgg_128) makes the generator's gradient ill-conditioned in the
+        # generator's own weights: with bf16 dense blocks the G gradients sit 1.2e-2 from an exact evaluation whatever the discriminator path does
+        # (profiles/r04_bn_probe.txt); f16 storage of the dense blocks (same MFMA rate, 8x finer operands) brings them inside the 1e-2 tolerance.
+        # Selected automatically for that configuration unless DASR_RDB_PREC says otherwise.
+        rdb_prec = None
+        if (self.is_train and self.l_gan_H_source_w > 0 and (opt['network_D'] or {}).get('which_model_pairD') == 'discriminator_vgg_128'
+                and not os.environ.get('DASR_RDB_PREC')):
+            rdb_prec = 2
+            logger.info('which_model_pairD discriminator_vgg_128: dense blocks of the generator in f16 storage (DASR_RDB_PREC=1 restores bf16)')
+        self.netG = _define_G(opt, self.device, rdb_prec)
         self.netD_target = None
         if self.is_train and self.l_gan_H_target_w > 0:
             d = opt['network_D']
@@ -122,6 +132,7 @@ class DASR_Model(BaseModel):
             self.l_pix_LL_w = t['pixel_LL_weight'] or 0
             self.sup_LL = bool(t['sup_LL']) and self.l_pix_w > 0
             self.l_fea_w = t['feature_weight'] or 0
+            self.netG.loss_weight = float(max(self.l_pix_w, self.l_fea_w, self.l_gan_H_target_w, self.l_gan_H_source_w) or 1.0)   # f16 dense blocks: sizes TrunkStore.gscale
             self.netF = None
             self.l_fea_type = t['feature_criterion']
             if self.l_fea_w > 0:

@@ -184,7 +184,7 @@ class BaseModel:
             self.schedulers[i].load_state_dict(s)
 
 
-def _define_G(opt, device):
+def _define_G(opt, device, rdb_prec=None):
     """networks.py:83-147 restricted to the hot-path generator (RRDB_net, upconv)."""
     g = opt['network_G']
     which = g['which_model_G']
@@ -193,7 +193,8 @@ def _define_G(opt, device):
     # `upsample_mode` is an extension of the option surface: the reference's define_G hard-wires 'upconv' (networks.py:96-99) although
     # its RRDBNet also implements 'pixelshuffle' (architecture.py:186-191); absent / null = the reference's behaviour
     um = g['upsample_mode'] or 'upconv'
-    net = RRDBNetHIP(in_nc=g['in_nc'], out_nc=g['out_nc'], nf=g['nf'], nb=g['nb'], upscale=g['scale'], device=device, upsample_mode=um)
+    # rdb_prec: operand format of the dense blocks (None: DASR_RDB_PREC or bf16; 2: f16 storage, see RRDBNetHIP)
+    net = RRDBNetHIP(in_nc=g['in_nc'], out_nc=g['out_nc'], nf=g['nf'], nb=g['nb'], upscale=g['scale'], device=device, upsample_mode=um, rdb_prec=rdb_prec)
     if opt['is_train']:
         logger.info('Initialization method [kaiming]')
         net.load_state_dict(kaiming_state_dict(rrdbnet_param_spec(g['in_nc'], g['out_nc'], g['nf'], g['nb'], um), 0.1))
@@ -216,6 +217,7 @@ class SRModel(BaseModel):
                 raise NotImplementedError('Loss type [{:s}] is not recognized.'.format(str(t['pixel_criterion'])))
             self.pix_l2 = t['pixel_criterion'] == 'l2'
             self.l_pix_w = t['pixel_weight']
+            self.netG.loss_weight = float(self.l_pix_w or 1.0)   # sizes the f16 pre-scale of the dense-block gradients when DASR_RDB_PREC=2 (TrunkStore.gscale)
             wd = t['weight_decay_G'] if t['weight_decay_G'] else 0
             self.optimizer_G = AdamHIP(self.netG.params, t['lr_G'], (0.9, 0.999), wd)
             self.optimizers.append(self.optimizer_G)

@@ -38,14 +38,23 @@ def rrdbnet_param_spec(in_nc, out_nc, nf, nb, upsample_mode='upconv'):
 
 
 class RRDBNetHIP:
-    def __init__(self, in_nc=3, out_nc=3, nf=64, nb=23, upscale=4, device='cuda', rdb_prec=1, stream_prec=3, upsample_mode='upconv'):
+    def __init__(self, in_nc=3, out_nc=3, nf=64, nb=23, upscale=4, device='cuda', rdb_prec=None, stream_prec=3, upsample_mode='upconv'):
         assert upscale == 4 and nf % 32 == 0 and in_nc <= 16 and out_nc <= 16
         if upsample_mode not in ('upconv', 'pixelshuffle'):
             raise NotImplementedError('upsample mode [{:s}] is not found'.format(str(upsample_mode)))   # architecture.py:190
         self.in_nc, self.out_nc, self.nf, self.nb, self.upsample_mode = in_nc, out_nc, nf, nb, upsample_mode
         self.device = torch.device(device)
         self.params = ParamStore(rrdbnet_param_spec(in_nc, out_nc, nf, nb, upsample_mode), self.device)
+        # dense-block operand format: 1 = bf16 (the north_star's dtype, default), 2 = f16 STORAGE of the dense slabs and their gradients (11-bit operands,
+        # gradients pre-scaled by a power of two: round 4, DASR_RDB_PREC=2 or rdb_prec=2).  Same MFMA rate; 8x finer operand rounding: on the
+        # ill-conditioned BatchNorm source-discriminator step the G gradients go from 1.5e-2 to < 1e-2 of the fp32 reference (profiles/r04_bn_probe.txt),
+        # which is why DASR_Model selects it for `which_model_pairD: discriminator_vgg_128`.  Range: activations beyond 65504 overflow (flagged by Adam).
+        if rdb_prec is None:
+            rdb_prec = int(os.environ.get('DASR_RDB_PREC', '1'))
+        if rdb_prec not in (1, 2):
+            raise ValueError('rdb_prec / DASR_RDB_PREC must be 1 (bf16) or 2 (f16 storage)')
         self.rdb_prec, self.stream_prec = rdb_prec, stream_prec
+        self.rdb_f16 = rdb_prec == 2
         self.hr_prec = int(os.environ.get('DASR_HR_PREC', '2')) if stream_prec == 3 else stream_prec
         # hr_prec 2 (default): f16 STORAGE of the HR tail (u1, u2, h0 and their gradients live in HBM as f16): the consumers run on the LDS-DMA
         # dense-conv kernel / the grouped wgrad kernel with the f16 MFMA, and the HR tensors cost half the bytes.  DASR_HR_PREC=3 (numerics
@@ -67,7 +76,7 @@ class RRDBNetHIP:
 
     def _register_packs(self):
         nf, P, sp = self.nf, self.params, self.stream_prec
-        mt_nf = 2 if (nf >= 64 and self.rdb_prec == 1) else 1
+        mt_nf = 2 if (nf >= 64 and self.rdb_prec in (1, 2)) else 1
         # HR tail (the two upconvs, HR_conv0, HR_conv1: 7.6 % of the FLOPs but a fifth of the step in split-bf16): f16 operands, ONE
         # MFMA pass.  Measured on the oracle with emulated operand rounding (oracle/precision_probe.py, nf64 nb23): SR output 2.4e-5,
         # HR-tail weight gradients 5e-4 normwise -- the tolerances are 1e-3 / 1e-2.  fea_conv and LR_conv feed the residual stream of
@@ -233,7 +242,12 @@ class TrunkStore:
         self.net, self.N, self.h, self.w = net, N, h, w
         dev, nf, nb = net.device, net.nf, net.nb
         sc = nf + 4 * GC
-        mk = lambda: torch.zeros((N, ceil_div(sc, 16), h, w, 16), dtype=torch.bfloat16, device=dev)
+        mk = lambda: torch.zeros((N, ceil_div(sc, 16), h, w, 16), dtype=torch.float16 if net.rdb_f16 else torch.bfloat16, device=dev)
+        # f16 dense blocks: every gradient slab holds gscale * dL/d(.); ONE power of two for the whole batch (the replicas of a step share the slabs and
+        # the grouped weight-gradient launches), sized like the HR tail's: dL/d(trunk) of a mean loss is ~1 / (N 3 16 h w), brought to ~2^-3
+        import math
+        lw = float(getattr(net, 'loss_weight', 1.0)) or 1.0   # largest loss weight in front of the generator (trainers set it; 1 for a bare net)
+        self.gscale = float(2.0 ** max(0, min(60, int(math.floor(math.log2(max(1.0, N * 3 * 16 * h * w / lw)))) - 3))) if net.rdb_f16 else 1.0
         self.slab_t = [mk() for _ in range(3 * nb)]
         self.gslab_t = [mk() for _ in range(3 * nb)]
         self.sc = sc
@@ -274,6 +288,8 @@ class TrunkStore:
                     ridx = 3 * i + (r - 1)
                     _, fl = rdb_wgrad_parts(grp, nf, 'model.1.sub.%d.RDB%d.conv' % (i, r), P, self.gslab(ridx), self.slab(ridx), h, w, N)
                     grp.flops += fl
+            if net.rdb_f16:
+                grp.f16, grp.g_scale = True, self.gscale
             grp.finalize(self.ws, net.device, target_wgs=target, ppu=ppu)
             first = len(self.phase.ops)
             for o in grp.ops(P.grad.data_ptr()):
@@ -324,7 +340,7 @@ class _Plan:
         self.x_in = B(16, h, w, True)
         self.fea = B(nf, h, w, True)
         if inference:   # nothing is kept for a backward pass: two slabs alternate through the 3 nb dense blocks
-            ab = [B(sc, h, w, False), B(sc, h, w, False)]
+            ab = [BTensor(N, sc, h, w, False, dev, f16=net.rdb_f16) for _ in range(2)]
             self.slabs = [ab[i & 1] for i in range(3 * nb)]
         else:
             self.slabs = [self.store.slab(r, n0, N) for r in range(3 * nb)]
@@ -381,8 +397,9 @@ class _Plan:
         o.t[0], o.t[1] = self.x_in.view(), NULL_T
         ops.add(o)
         # fea_conv: fp32 stream + bf16 shadow into the first dense slab
+        f16 = int(net.rdb_f16)   # dense slabs in f16 storage: every 16-bit output of the trunk is f16
         ops.add(conv_op(pack, pk['fea'], self.x_in.view(), True, 16, h, w, h, w, N, bias=P.ptr('model.0.bias'),
-                        out_f32=self.fea.view(), out_bf16=self.slabs[0].view(0)))
+                        out_f32=self.fea.view(), out_bf16=self.slabs[0].view(0), out16_f16=f16))
         X = self.fea  # fp32 input of the current RDB
         free = list(self.stream)
         self.rdb_in = []
@@ -395,16 +412,16 @@ class _Plan:
                 for j in range(1, 5):
                     cin = nf + (j - 1) * GC
                     ops.add(conv_op(pack, pk[(i, r, j)], S.view(0), False, cin, h, w, h, w, N, bias=P.ptr('%s%d.0.bias' % (pre, j)),
-                                    act=1, out_bf16=S.view(cin)))
+                                    act=1, out_bf16=S.view(cin), out16_f16=f16))
                 last = (ridx == 3 * nb - 1)
                 Y = next(b for b in free if b is not X and b is not Xrrdb)
                 nxt = None if last else self.slabs[ridx + 1].view(0)
                 if r < 3:
                     ops.add(conv_op(pack, pk[(i, r, 5)], S.view(0), False, nf + 4 * GC, h, w, h, w, N, bias=P.ptr(pre + '5.0.bias'),
-                                    alpha=0.2, res1=X.view(), beta1=1.0, out_f32=Y.view(), out_bf16=nxt))
+                                    alpha=0.2, res1=X.view(), beta1=1.0, out_f32=Y.view(), out_bf16=nxt, out16_f16=f16))
                 else:  # RDB3 + RRDB residual fused: 0.2*(0.2*c + x3) + x_rrdb
                     ops.add(conv_op(pack, pk[(i, r, 5)], S.view(0), False, nf + 4 * GC, h, w, h, w, N, bias=P.ptr(pre + '5.0.bias'),
-                                    alpha=0.04, res1=X.view(), beta1=0.2, res2=Xrrdb.view(), beta2=1.0, out_f32=Y.view(), out_bf16=nxt))
+                                    alpha=0.04, res1=X.view(), beta1=0.2, res2=Xrrdb.view(), beta2=1.0, out_f32=Y.view(), out_bf16=nxt, out16_f16=f16))
                 X = Y
             if i in getattr(net, 'debug_taps', ()):   # tests: fp32 copy of this RRDB's output (the stream buffers rotate)
                 self.taps = getattr(self, 'taps', {})
@@ -639,8 +656,10 @@ class _Plan:
         free = list(self.gstream)
         G = free[0]
         gs_cur = 0
+        f16 = int(net.rdb_f16)
+        gsc = self.store.gscale   # f16 dense blocks: the gradient slabs hold gsc * dL/d(.) (1.0 for bf16 storage); the fp32 gradient stream stays unscaled
         ops.add(conv_op(pack, pk['lr_b'], self.g_t0.view(), True, nf, h, w, h, w, N, out_f32=G.view(),
-                        out_bf16=self.gslab[gs_cur].view(0), gamma=0.04))
+                        out_bf16=self.gslab[gs_cur].view(0), gamma=0.04 * gsc, out16_f16=f16))
         # RRDB chain, reversed.  No weight-gradient launch inside the chain: every RDB keeps its gradient slab and TrunkStore.phase computes all
         # of them afterwards (grouped launches over the whole batch).
         for i in range(nb - 1, -1, -1):
@@ -652,20 +671,21 @@ class _Plan:
                 for k in range(4, 0, -1):
                     cin_b = nf + (4 - k) * GC
                     ops.add(conv_op(pack, pk[(i, r, 'b', k)], Gs.view(0), False, cin_b, h, w, h, w, N,
-                                    mask=S.view(nf + (k - 1) * GC), mask_f32=0, out_bf16=Gs.view(cin_b)))
+                                    mask=S.view(nf + (k - 1) * GC), mask_f32=0, out_bf16=Gs.view(cin_b), out16_f16=f16))
                 # g_x conv with the residual bookkeeping fused
                 Gin = next(b for b in free if b is not Grr and b is not Gout)
                 first = (ridx == 0)
                 nxt = None if first else self.gslab[gs_cur + 1].view(0)
                 if r == 3:
                     ops.add(conv_op(pack, pk[(i, r, 'b', 0)], Gs.view(0), False, nf + 4 * GC, h, w, h, w, N,
-                                    res1=Grr.view(), beta1=0.2, out_f32=Gin.view(), out_bf16=nxt, gamma=0.2))
+                                    res1=Grr.view(), beta1=0.2, out_f32=Gin.view(), out_bf16=nxt, gamma=0.2 * gsc, alpha=1.0 / gsc, out16_f16=f16))
                 elif r == 2:
                     ops.add(conv_op(pack, pk[(i, r, 'b', 0)], Gs.view(0), False, nf + 4 * GC, h, w, h, w, N,
-                                    res1=Gout.view(), beta1=1.0, out_f32=Gin.view(), out_bf16=nxt, gamma=0.2))
+                                    res1=Gout.view(), beta1=1.0, out_f32=Gin.view(), out_bf16=nxt, gamma=0.2 * gsc, alpha=1.0 / gsc, out16_f16=f16))
                 else:
                     ops.add(conv_op(pack, pk[(i, r, 'b', 0)], Gs.view(0), False, nf + 4 * GC, h, w, h, w, N,
-                                    res1=Gout.view(), beta1=1.0, res2=Grr.view(), beta2=1.0, out_f32=Gin.view(), out_bf16=nxt, gamma=0.04))
+                                    res1=Gout.view(), beta1=1.0, res2=Grr.view(), beta2=1.0, out_f32=Gin.view(), out_bf16=nxt, gamma=0.04 * gsc, alpha=1.0 / gsc,
+                                    out16_f16=f16))
                 Gout = Gin
                 gs_cur += 1
             G = Gout

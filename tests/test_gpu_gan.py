@@ -239,14 +239,22 @@ def test_vgg_on_odd_sizes(prec, margins):
 
 @pytest.mark.parametrize('case', ['dasr_wavelet_nf32_nb2_n2_32', 'dasr_gau9_nf64_nb1_n1_32', 'dasr_lpips_wavelet_nf32_nb2_n2_32',
                                   'dasr_srcD_wavelet_nf32_nb2_n2_32', 'dasr_ragan_wavelet_nf32_nb1_n3_32', 'dasr_srcVGG128_gau5_nf32_nb1_n3_32',
+                                  'dasr_srcVGG128_gau5_nf32_nb1_n3_32+bf16', 'dasr_wavelet_nf32_nb2_n2_32+f16',
                                   'dasr_lsgan_wavelet_nf32_nb1_n2_32', 'dasr_wgan_gau9_nf32_nb1_n2_32', 'dasr_ragan_lsgan_wavelet_nf32_nb1_n3_32',
                                   'dasr_l2_wavelet_nf32_nb1_n2_32', 'dasr_wavelet_nf64_nb23_n1_32'])
-def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir, margins):
+def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir, margins, monkeypatch):
     """round 3 additions: pixel_criterion / feature_criterion 'l2' (MSE; multiweights off so the plain pixel term goes through cri_pix), and the GAN
     step at the full ESRGAN depth nb = 23 (VERDICT r2 weak #2)"""
     dev = _gpu()
+    case_id = case
+    if case.endswith('+bf16'):     # the BatchNorm case with the generator's dense blocks forced back to bf16 (default for it: f16 storage, dasr_model.py)
+        case = case[:-5]
+        monkeypatch.setenv('DASR_RDB_PREC', '1')
+    elif case.endswith('+f16'):    # an ordinary GAN fixture with f16 dense blocks
+        case = case[:-4]
+        monkeypatch.setenv('DASR_RDB_PREC', '2')
     GRAD_TOL = globals()['GRAD_TOL']
-    G_TOL = VGG128_STEP_G_TOL if 'VGG128' in case else GRAD_TOL   # see the note at VGG128_STEP_G_TOL: the generator's bf16 operands on an ill-conditioned case
+    G_TOL = VGG128_STEP_G_TOL if case_id.endswith('+bf16') else GRAD_TOL   # see the note at VGG128_STEP_G_TOL: the generator's bf16 operands on an ill-conditioned case
     torch.set_num_threads(8)
     from oracle import fixtures, nets, trainers
     from dasr_amd import options
@@ -337,7 +345,7 @@ def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir, margin
             np.testing.assert_allclose(np.array([float(v.double().norm()) for v in dd.values()]), gold['gradD_norm'], rtol=GRAD_TOL, atol=1e-6)
             w2 = max([rel(gv.reshape(pr.grad.shape), pr.grad) for (k, gv), pr in zip(m.netD_source.params.grad_dict().items(), netD2.parameters())
                       if not (zero_last_bias and k.endswith('model.8.bias'))]) if netD2 is not None else 0.0
-            margins('%s: worst gradient rel err G %.2e (bound %.0e), D_source %.2e (bound %.0e)' % (case, worst, G_TOL, w2, GRAD_TOL))
+            margins('%s: worst gradient rel err G %.2e (bound %.0e), D_source %.2e (bound %.0e)' % (case_id, worst, G_TOL, w2, GRAD_TOL))
             if t64 is not None:
                 per_g = sorted(((rel(gv, pr.grad), k) for (k, gv), pr in zip(gd.items(), t64.netG.parameters())), reverse=True)
                 e_g = per_g[0][0]
@@ -346,8 +354,8 @@ def test_dasr_step_matches_oracle_and_reference_fixture(case, golden_dir, margin
                 o_g = max(rel(p32.grad, p64.grad) for p32, p64 in zip(netG.parameters(), t64.netG.parameters()))
                 o_s = max(rel(p32.grad, p64.grad) for p32, p64 in zip(netD2.parameters(), t64.netD_src.parameters()))
                 margins('%s vs the fp64 oracle: HIP worst gradient rel err G %.2e, D_target %.2e, D_source %.2e; the fp32 oracle itself: G %.2e, '
-                        'D_source %.2e; worst G tensors: %s' % (case, e_g, e_d, e_s, o_g, o_s, ' '.join('%s %.1e' % (k, e) for e, k in per_g[:4])))
-                assert e_g < VGG128_STEP_G_TOL and e_d < 1e-2, (e_g, e_d)
+                        'D_source %.2e; worst G tensors: %s' % (case_id, e_g, e_d, e_s, o_g, o_s, ' '.join('%s %.1e' % (k, e) for e, k in per_g[:4])))
+                assert e_g < (VGG128_STEP_G_TOL if case_id.endswith('+bf16') else 1.1e-2) and e_d < 1e-2, (e_g, e_d)
                 assert e_s < 1.1 * o_s, (e_s, o_s)   # no further from exact arithmetic than the fp32 PyTorch-CPU reference is (fp32 accumulation behind nine BatchNorms)
 
 

@@ -183,3 +183,12 @@ def test_sr_step_with_split_bf16_hr_tail(golden_dir, margins, monkeypatch):
     f16's range is not enough (models.py::AdamHIP.check_finite); same fixture, same tolerances as the default f16-storage tail"""
     monkeypatch.setenv('DASR_HR_PREC', '3')
     test_sr_step_matches_oracle_and_reference_fixture('sr_nf64_nb2_b2_32', golden_dir, margins)
+
+
+@pytest.mark.parametrize('case', ['sr_nf64_nb2_b8_32', 'sr_nf64_nb23_b2_32', 'cfg1_sr_nf32_nb4_b2_64'])
+def test_sr_step_with_f16_dense_blocks(case, golden_dir, margins, monkeypatch):
+    """DASR_RDB_PREC=2 (round 4): dense slabs and their gradients in f16 storage (11-bit operands, gradients pre-scaled by a power of two) instead of
+    bf16 -- the numerics switch DASR_Model selects for the BatchNorm source discriminator.  Same fixtures and tolerances as the bf16 default: the
+    two-stream production schedule (batch 8), the full depth nb = 23, and nf = 32 (conv5 on the Cout-32 path)"""
+    monkeypatch.setenv('DASR_RDB_PREC', '2')
+    test_sr_step_matches_oracle_and_reference_fixture(case, golden_dir, margins)
