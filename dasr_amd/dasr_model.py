@@ -224,6 +224,9 @@ class DASR_Model(BaseModel):
                 self._run_ragan(P.rg, P, dp_on)   # relativistic GAN terms of the generator loss (value + dL/dlogits of the fake halves)
             P.g_loss_bwd.run()            # D / VGG / fs data-gradients into dL/dSR
             gG = self.netG.params.grad
+            if P.g.store.calibrate_due():   # f16 dense blocks (rrdbnet.TrunkStore): measure dL/d(trunk output) behind the HR tail, patch the scale, restart
+                P.g.bwd.run(0, P.g.tail_end)
+                P.g.store.set_gscale_from(float(P.g.g_t0.t.abs().max().item()))
             if not dp_on:
                 P.g.bwd.run()
             else:

@@ -326,6 +326,9 @@ class SRModel(BaseModel):
             plan.set_input(self.var_L)
             plan.fwd.run()
             loss_ops.run()
+            if plan.store.calibrate_due():   # f16 dense blocks: measure dL/d(trunk output) behind the HR tail, then run the backward from the start
+                plan.bwd.run(0, plan.tail_end)
+                plan.store.set_gscale_from(float(plan.g_t0.t.abs().max().item()))
             if not dp_on:
                 plan.bwd.run()
             else:
@@ -339,6 +342,18 @@ class SRModel(BaseModel):
             if len(getattr(self, '_streams', ())) != len(plans):
                 self._streams = [torch.cuda.Stream() for _ in plans]
             cur = torch.cuda.current_stream()
+            if plans[0].store.calibrate_due():
+                # f16 dense blocks: the replicas share ONE gradient scale (their slabs feed the same grouped weight-gradient launches), measured on a
+                # dry run of replica 0 -- forward, loss, HR-tail backward: no optimiser / gradient-buffer side effects (loss_acc is cleared below)
+                p0 = plans[0]
+                l0, hb0 = self._ops_for(p0, N)
+                hb0.copy_(self.real_H[p0.n0:p0.n0 + p0.N])
+                p0.set_input(self.var_L[p0.n0:p0.n0 + p0.N])
+                p0.fwd.run()
+                l0.run()
+                p0.bwd.run(0, p0.tail_end)
+                p0.store.set_gscale_from(float(p0.g_t0.t.abs().max().item()))
+                _lib.check(L.dasr_fill_f32(self.loss_acc.data_ptr(), 4, 0.0, _stream()), 'fill')
             steps = []
             for i, (plan, st) in enumerate(zip(plans, self._streams)):
                 st.wait_stream(cur)

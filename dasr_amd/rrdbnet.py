@@ -246,8 +246,13 @@ class TrunkStore:
         # f16 dense blocks: every gradient slab holds gscale * dL/d(.); ONE power of two for the whole batch (the replicas of a step share the slabs and
         # the grouped weight-gradient launches), sized like the HR tail's: dL/d(trunk) of a mean loss is ~1 / (N 3 16 h w), brought to ~2^-3
         import math
-        lw = float(getattr(net, 'loss_weight', 1.0)) or 1.0   # largest loss weight in front of the generator (trainers set it; 1 for a bare net)
-        self.gscale = float(2.0 ** max(0, min(60, int(math.floor(math.log2(max(1.0, N * 3 * 16 * h * w / lw)))) - 3))) if net.rdb_f16 else 1.0
+        # The magnitude of dL/d(trunk) depends on the weights (kaiming x 0.1 at init: ~1e-5 of dL/dSR; a trained net: orders of magnitude more), so the
+        # scale is CALIBRATED from data: the trainers measure max |dL/d(trunk output)| behind the HR tail (calibrate_due / set_gscale: on the first
+        # step of a plan and every CALIB_EVERY steps after it, one host sync) and every op that carries the scale is patched in place.  f16 has
+        # 30 normal binades; the calibration puts the largest slab entry at ~1, so a drift of 2^+-8 between two calibrations is harmless, and
+        # an overflow reaches Adam's non-finite guard.
+        self.gscale = 1.0
+        self._scaled_ops, self._plans, self.steps_since_calib = [], [], None
         self.slab_t = [mk() for _ in range(3 * nb)]
         self.gslab_t = [mk() for _ in range(3 * nb)]
         self.sc = sc
@@ -300,6 +305,46 @@ class TrunkStore:
             self.groups.append((first, len(self.phase.ops), lo, hi))
             hi_rrdb = lo_rrdb
         self.phase.tag(5)
+
+    CALIB_EVERY = 256
+
+    def register_scaled(self, op, base_gamma, has_alpha):
+        """conv op whose 16-bit output carries the gradient scale (gamma = base_gamma * gscale) and, with has_alpha, whose accumulator is un-scaled
+        for the fp32 gradient stream (alpha = 1 / gscale)"""
+        self._scaled_ops.append((op, float(base_gamma), bool(has_alpha)))
+
+    def calibrate_due(self):
+        """f16 dense blocks: True when the gradient scale has to be (re-)measured before this step's dense-block backward"""
+        if not self.net.rdb_f16:
+            return False
+        due = self.steps_since_calib is None or self.steps_since_calib >= self.CALIB_EVERY
+        if not due:
+            self.steps_since_calib += 1
+        return due
+
+    def set_gscale_from(self, g_t0_absmax):
+        """g_t0_absmax: max |dL/d(trunk output)| (host float).  The first planes of the first gradient slab hold 0.04 * gscale * that: brought to ~1."""
+        import math
+        a = 0.04 * float(g_t0_absmax)
+        s = 1.0 if not (a > 0.0 and math.isfinite(a)) else float(2.0 ** max(-60, min(60, -int(math.ceil(math.log2(a))))))
+        self.steps_since_calib = 0
+        if s == self.gscale:
+            return s
+        self.gscale = s
+        for o, bg, has_alpha in self._scaled_ops:
+            o.conv.gamma = bg * s
+            if has_alpha:
+                o.conv.alpha = 1.0 / s
+        for o in self.phase.ops:
+            if o.op == _lib.OP_WGRAD_REDUCE:
+                o.f[1] = 1.0 / s
+        self.phase._arr = None
+        for pl in self._plans:   # every recorded list that holds copies of the patched ops
+            pl.bwd._arr = None
+            pl._segments = None
+            if hasattr(pl, 'whole_step'):
+                pl.whole_step._arr = None
+        return s
 
     def set_grad_scale(self, scale):
         changed = False
@@ -526,7 +571,9 @@ class _Plan:
         else:
             self._build_backward_tail_f32(ops, f16, gs)
         ops.tag(3)
+        self.tail_end = len(ops.ops)   # ops [0, tail_end): the HR tail's backward; self.g_t0 = dL/d(trunk output) is complete behind them
         self._build_backward_trunk(ops)
+        self.store._plans.append(self)
 
     def _wg3_target(self, nparts):
         """workgroups of a 12-wave weight-gradient launch (one per CU, nothing co-resides with them): the whole chip for a single plan, an equal
@@ -660,6 +707,8 @@ class _Plan:
         gsc = self.store.gscale   # f16 dense blocks: the gradient slabs hold gsc * dL/d(.) (1.0 for bf16 storage); the fp32 gradient stream stays unscaled
         ops.add(conv_op(pack, pk['lr_b'], self.g_t0.view(), True, nf, h, w, h, w, N, out_f32=G.view(),
                         out_bf16=self.gslab[gs_cur].view(0), gamma=0.04 * gsc, out16_f16=f16))
+        if f16:
+            self.store.register_scaled(ops.ops[-1], 0.04, False)
         # RRDB chain, reversed.  No weight-gradient launch inside the chain: every RDB keeps its gradient slab and TrunkStore.phase computes all
         # of them afterwards (grouped launches over the whole batch).
         for i in range(nb - 1, -1, -1):
@@ -686,6 +735,8 @@ class _Plan:
                     ops.add(conv_op(pack, pk[(i, r, 'b', 0)], Gs.view(0), False, nf + 4 * GC, h, w, h, w, N,
                                     res1=Gout.view(), beta1=1.0, res2=Grr.view(), beta2=1.0, out_f32=Gin.view(), out_bf16=nxt, gamma=0.04 * gsc, alpha=1.0 / gsc,
                                     out16_f16=f16))
+                if f16:
+                    self.store.register_scaled(ops.ops[-1], 0.04 if r == 1 else 0.2, True)
                 Gout = Gin
                 gs_cur += 1
             G = Gout

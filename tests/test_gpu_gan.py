@@ -520,8 +520,11 @@ VGG128_GRAD_TOL = 1e-2
 #   * the generator's dense blocks with bf16 operands -- the north_star's dtype -- and EVERYTHING ELSE EXACT: G 1.24e-2 (9.8e-3 from the bf16
 #     rounding of the weights alone: a coherent 2^-9 perturbation of the network that the BatchNorm discriminator's gradient amplifies).
 # So: D_target and D_source must meet the north_star's 1e-2 against the fp32 reference, and D_source must be no further from the fp64 result than
-# the fp32 reference is (+10 %); the G gradients of THIS case are bounded by 2e-2 = what bf16 dense-block operands give on it (observed 1.46e-2
-# against fp32, 1.49e-2 against fp64); every other case keeps 1e-2 (observed 3.2 - 5.2e-3).  tests/test_bn_conditioning.py pins the 1.24e-2 on CPU.
+# the fp32 reference is (+10 %).  For the G gradients the product path answers the probe: for `which_model_pairD: discriminator_vgg_128` DASR_Model
+# runs the generator's dense blocks in f16 STORAGE (rrdbnet.py rdb_prec 2: 11-bit operands, gradient slabs scaled by a calibrated power of two) --
+# the case then meets 1e-2 like every other (observed 8.5e-3 against fp32, 8.4e-3 against fp64; other cases 3e-4 .. 5e-3).  The `+bf16` variant of
+# the case forces bf16 dense blocks back (DASR_RDB_PREC=1) and keeps the 2e-2 bound that bf16 operands give on it (observed 1.46e-2);
+# tests/test_bn_conditioning.py pins the 1.24e-2 of bf16 dense blocks alone on the CPU.
 VGG128_STEP_G_TOL = 2e-2
 
 

@@ -192,3 +192,35 @@ def test_sr_step_with_f16_dense_blocks(case, golden_dir, margins, monkeypatch):
     two-stream production schedule (batch 8), the full depth nb = 23, and nf = 32 (conv5 on the Cout-32 path)"""
     monkeypatch.setenv('DASR_RDB_PREC', '2')
     test_sr_step_matches_oracle_and_reference_fixture(case, golden_dir, margins)
+
+
+def test_f16_dense_block_gradient_scale_is_consistently_patched(monkeypatch):
+    """DASR_RDB_PREC=2: the dense-block gradient slabs hold gscale * dL/d(.), gscale a power of two calibrated from max |dL/d(trunk output)| and patched
+    into every op that carries it (rrdbnet.TrunkStore.set_gscale_from).  The gradients must not depend on the scale beyond f16 rounding: the same step with the
+    calibration forced 2^5 off (both directions) gives the same weight gradients; the two-replica schedule (batch 8) calibrates on a dry run of replica 0"""
+    dev = _gpu()
+    monkeypatch.setenv('DASR_RDB_PREC', '2')
+    from oracle import fixtures
+    from dasr_amd import options, rrdbnet
+    from dasr_amd.models import create_model
+    case = 'sr_nf64_nb2_b8_32'
+    grads, scales = [], []
+    orig = rrdbnet.TrunkStore.set_gscale_from
+    for factor in (1.0, 32.0, 1.0 / 32.0):
+        monkeypatch.setattr(rrdbnet.TrunkStore, 'set_gscale_from', lambda self, a, f=factor: orig(self, a * f))
+        opt = fixtures.make_opt(case)
+        opt['gpu_ids'] = [0]
+        m = create_model(options.dict_to_nonedict(opt))
+        m.netG.load_state_dict(fixtures.seeded_state_dict(m.netG.state_dict(), 1, 0.1))
+        m.update_learning_rate()
+        m.feed_data(fixtures.make_batch(case))
+        m.optimize_parameters(1)
+        torch.cuda.synchronize()
+        assert len(m._out_plans) == 2 and m._out_plans[0].store is m._out_plans[1].store
+        scales.append(m._out_plans[0].store.gscale)
+        grads.append(m.netG.params.grad_dict())
+        m.get_current_log()   # (raises if a gradient overflowed)
+    assert scales[1] == scales[0] / 32.0 and scales[2] == scales[0] * 32.0 and scales[0] > 1.0
+    for other in grads[1:]:
+        worst = max(rel(other[k], v) for k, v in grads[0].items())
+        assert worst < 2e-3, worst
