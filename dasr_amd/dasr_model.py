@@ -254,9 +254,19 @@ class DASR_Model(BaseModel):
                 self.dp.allreduce_mean(self.netD_source.params.grad)
             self.optimizer_D_source.step(self._lr_of(self.optimizer_D_source))
             self.netD_source.repack()
-        self.fake_H = P.g.read_output()
+        self._fake_H, self._fake_plan = None, P.g   # NCHW copy of the SR batch on demand (fake_H property)
         self._acc_snapshot = (self.acc, do_g, do_d, do_ds)
         self._pix_div = getattr(P, 'pix_log_div', 1.0)
+
+    @property
+    def fake_H(self):
+        if getattr(self, '_fake_H', None) is None and getattr(self, '_fake_plan', None) is not None:
+            return self._fake_plan.read_output()
+        return getattr(self, '_fake_H', None)
+
+    @fake_H.setter
+    def fake_H(self, v):
+        self._fake_H, self._fake_plan = v, None
 
     def _run_ragan(self, lists, P, dp_on):
         """stage 0 -> (all-reduce of the per-pixel logit sums) -> stage 1 -> (all-reduce of the per-pixel sigmoid sums) -> stage 2: the batch

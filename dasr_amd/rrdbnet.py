@@ -428,7 +428,20 @@ class _Plan:
         self.x_nchw.copy_(x)
 
     def read_output(self):
+        """SR output as NCHW fp32.  Training plans convert on demand (one launch when somebody looks at the images -- visuals, tests -- instead of
+        a 16 x 3 x 512 x 512 layout pass in every step); inference plans have the conversion at the end of their forward list."""
+        if self._out_ops is not None:
+            self._out_ops.run()
         return self.sr_nchw
+
+    def _add_output_op(self, fwd, o):
+        """the blocked -> NCHW conversion of the SR output: part of the forward list for inference plans, on demand (read_output) for training plans"""
+        if self.inference:
+            fwd.add(o)
+            self._out_ops = None
+        else:
+            self._out_ops = OpList()
+            self._out_ops.add(o)
 
     # ---- forward --------------------------------------------------------------------------------------
     def _build_forward(self):
@@ -499,7 +512,7 @@ class _Plan:
             o = Op()
             o.op = _lib.OP_B2NCHW
             o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.p[0] = self.sr.view(), N, net.out_nc, H4, W4, self.sr_nchw.data_ptr()
-            ops.add(o)
+            self._add_output_op(ops, o)
             self.fwd = ops.tag(2)
             return
         ops.add(conv_op(pack, pk['lr'], X.view(), True, nf, h, w, h, w, N, bias=P.ptr(lrb), res1=self.fea.view(), beta1=1.0,
@@ -521,7 +534,7 @@ class _Plan:
         o = Op()
         o.op = _lib.OP_B2NCHW
         o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.p[0] = self.sr.view(), N, net.out_nc, H4, W4, self.sr_nchw.data_ptr()
-        ops.add(o)
+        self._add_output_op(ops, o)
         self.fwd = ops.tag(2)
 
     # ---- backward (input: self.g_sr filled by a loss kernel) -----------------------------------------------

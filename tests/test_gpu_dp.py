@@ -10,9 +10,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, case, out, streams, shard=None):
+def _worker(rank, world, port, case, out, streams, shard=None, env=None):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                       DASR_STREAMS=str(streams))
+    os.environ.update(env or {})
     import torch
     from oracle import fixtures
     from dasr_amd import options
@@ -70,8 +71,8 @@ B16 = dict(kind='sr', nf=64, nb=2, n=16, lr=32)   # 8 crops per rank -> two sub-
 RAGAN4 = dict(kind='dasr', nf=32, nb=1, n=4, lr=32, fs='wavelet', d_in_nc=9, gan_src=0.02, ragan=True)
 
 
-@pytest.mark.parametrize('case,streams', [('sr_nf64_nb2_b2_32', 1), ('dasr_wavelet_nf32_nb2_n2_32', 1), (B16, 1), (B16, 2), (RAGAN4, 1)],
-                         ids=['sr_b2-1stream', 'dasr_n2-1stream', 'sr_b16-1stream', 'sr_b16-2streams', 'dasr_ragan_srcD_n4'])
+@pytest.mark.parametrize('case,streams', [('sr_nf64_nb2_b2_32', 1), ('dasr_wavelet_nf32_nb2_n2_32', 1), (B16, 1), (B16, 2), (RAGAN4, 1), (B16, 20)],
+                         ids=['sr_b2-1stream', 'dasr_n2-1stream', 'sr_b16-1stream', 'sr_b16-2streams', 'dasr_ragan_srcD_n4', 'sr_b16-2streams-f16'])
 def test_two_rank_step_equals_full_batch_step(case, streams, tmp_path, margins):
     """streams = 2: the DP x two-sub-batch-stream combination (replica gradient buffers summed, then reduced over the ranks);
     the single-process side runs the same DASR_STREAMS so that both schedules are compared like for like"""
@@ -80,8 +81,11 @@ def test_two_rank_step_equals_full_batch_step(case, streams, tmp_path, margins):
     import torch.multiprocessing as mp
     out = str(tmp_path / 'w%d_r%d.pt')
     port = 29611 + (os.getpid() % 300)
-    mp.spawn(_worker, args=(1, port, case, out, streams), nprocs=1, join=True)
-    mp.spawn(_worker, args=(2, port + 1, case, out, streams), nprocs=2, join=True)
+    env = None
+    if streams == 20:   # f16 storage of the dense blocks (DASR_RDB_PREC=2): every rank calibrates its own power-of-two gradient scale -- exact, so the ranks still agree
+        streams, env = 2, {'DASR_RDB_PREC': '2'}
+    mp.spawn(_worker, args=(1, port, case, out, streams, None, env), nprocs=1, join=True)
+    mp.spawn(_worker, args=(2, port + 1, case, out, streams, None, env), nprocs=2, join=True)
     full = torch.load(out % (1, 0))
     r0, r1 = torch.load(out % (2, 0)), torch.load(out % (2, 1))
     for net in [k for k in ('G', 'D', 'D2') if k in full]:
