@@ -409,7 +409,9 @@ def bench_srn(a, dp, dasr, as_secondary=False):
     full = (a.nf == 64 and a.nb == 23 and s == 128)
     out = {'metric': 'SR train images/sec (4x, 128->512)', 'value': round(ips, 3), 'unit': 'images/s', 'n_gpus': world,
            'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2), 'higher_is_better': True,
-           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16 MFMA operands, fp32 accumulate / fp32 residual stream',
+           'scaling': 'weak', 'vs_baseline': None,
+           'dtype': ('f16 MFMA operands (DASR_RDB_PREC=2), fp32 accumulate / fp32 residual stream' if getattr(model.netG, 'rdb_f16', False)
+                     else 'bf16 MFMA operands, fp32 accumulate / fp32 residual stream'),
            'data': 'synthetic (torch.rand, seed 1234+rank; kaiming x0.1 weights, seed 0)',
            'config': {'workload': ('configs[2]: full SRN GAN step (RRDBNet nf=%d nb=%d + NLayer patch-D + %s perceptual, fs=%s), %d G crops of '
                                    '%dx%d LR per GPU (n=%d source + %d target)' % (a.nf, a.nb, 'LPIPS(alex)' if a.fea == 'LPIPS' else 'VGG19-54', a.fs, batch,

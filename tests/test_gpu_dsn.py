@@ -296,6 +296,36 @@ def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir, mo
         assert rel(got.cpu(), want) < 2e-3
 
 
+def test_dsn_iteration_without_colour_loss(margins):
+    """--w_col 0: only the texture (0.005) and perceptual (0.01) terms drive the generator, dL/dfake is 2-3 orders smaller than with the
+    colour term; the power-of-two pre-scale of the generator's 16-bit backward folds the largest loss weight in (dsn_model._GPlan.gscale), so the
+    pre-scaled gradients stay in f16's normal range.  Against the oracle (pinned to the reference's modules by the fixtures above), north_star tolerances."""
+    dev = _gpu()
+    torch.set_num_threads(8)
+    from dasr_amd.dsn_model import DSNModel
+    from oracle import dsn
+    from oracle.gen_golden_dsn import DSN_CASES, dsn_state, dsn_batch
+    c = DSN_CASES['dsn_gau5_inst_b2_128']
+    G, D = dsn.DeResnet(), dsn.Discriminator(c['k'], c['norm'], c['filter'])
+    sdG, sdD = dsn_state(G.state_dict(), 21, 0.5), dsn_state(D.state_dict(), 22, 1.0)
+    G.load_state_dict(sdG)
+    D.load_state_dict(sdD)
+    t = dsn.DSNTrainer(G, D, kernel_size=c['k'], filter_type=c['filter'], norm_layer=c['norm'], vgg_seed=78, w_col=0.0, w_per=0.01, per_type='VGG')
+    m = DSNModel(dict(filter=c['filter'], kernel_size=c['k'], norm_layer=c['norm'], w_col=0.0, w_per=0.01, vgg_seed=78, per_type='VGG', allow_random_perceptual=True), device=dev)
+    m.netG.load_state_dict(sdG)
+    m.load_discriminator_state(sdD)
+    m.netF.load_state_dict({'features.' + k: v for k, v in t.per.state_dict().items()})
+    hr, bic, real = dsn_batch(c)
+    t.iteration(hr, bic, real)
+    m.iteration(hr.to(dev), bic.to(dev), real.to(dev))
+    log = m.get_current_log()
+    for k, ref_v in t.log.items():
+        assert abs(log[k] - ref_v) <= 2e-3 * max(1e-3, abs(ref_v)) + 1e-5, (k, log[k], ref_v)
+    wg_, ws_ = _check_grads(m.netG.params.grad_dict(), [p.grad for p in G.parameters()], 'G')
+    assert m._plan(2, 128, 128).g.gscale == 65536.0   # 1 / max(w_tex, w_per) = 100 folded in: 2^7 above the 512 of w_col = 1
+    margins('DSN iteration with w_col 0 (texture + perceptual terms only): worst gradient rel err G %.2e, PReLU slopes %.2e (tol %.0e)' % (wg_, ws_, GRAD_TOL))
+
+
 def test_dsn_checkpoint_roundtrip(tmp_path):
     dev = _gpu()
     from dasr_amd.dsn_model import DSNModel
