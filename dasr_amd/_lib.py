@@ -68,6 +68,7 @@ OP_CVT_F16, OP_DOWNSUM_F16, OP_PIXSHUF, OP_PIXUNSHUF = 31, 32, 33, 34
 OP_LPIPS_S2D, OP_MAXPOOL3, OP_MAXPOOL3_BWD, OP_LPIPS_HEAD, OP_RAGAN = 35, 36, 37, 38, 39
 OP_BNORM_FWD, OP_BNORM_BWD, OP_BNORM_RUNNING = 40, 41, 42
 OP_DDM_SPREAD = 43
+OP_INORM_JVP, OP_INORM_SECOND, OP_GRAD_PENALTY, OP_FILL_SCALED = 44, 45, 46, 47
 
 _SIGS = {
     'dasr_conv': [C.POINTER(ConvParams), c_vp],
@@ -93,6 +94,10 @@ _SIGS = {
     'dasr_add_flat': [c_vp, c_vp, c_i64, c_vp],
     'dasr_inorm_lrelu_fwd': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, Tensor, c_vp, c_vp],
     'dasr_inorm_lrelu_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, Tensor, c_vp],
+    'dasr_inorm_lrelu_jvp': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, Tensor, c_vp],
+    'dasr_inorm_second': [Tensor, Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, Tensor, c_i32, c_vp],
+    'dasr_grad_penalty': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp],
+    'dasr_fill_scaled': [Tensor, c_i32, c_i32, c_i32, c_i32, c_vp, c_f32, c_vp],
     'dasr_bce_logits': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp, c_f32, Tensor, c_vp],
     'dasr_gan_loss': [Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp, c_f32, Tensor, c_vp],
     'dasr_dwt_fwd': [Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, Tensor, Tensor, c_vp],
@@ -143,7 +148,7 @@ _BENCH_SIGS = {
 }
 BENCH_LIB_PATH = os.path.join(HERE, 'libdasr_bench.so')
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 _lib = None
 _bench = None
 

@@ -118,6 +118,156 @@ __global__ __launch_bounds__(256) void inorm_lrelu_bwd_kernel(dasr_tensor a, das
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Second-order pieces of InstanceNorm2d + LeakyReLU for the DSN's `--wgan` gradient penalty (codes/DSN/train.py:231-236:
+// torch.autograd.grad(mean D(sample), sample, create_graph=True) and its backward).  With xhat = (z - mu) r, r = (var + eps)^-1/2 (from the saved
+// output a = lrelu(xhat) and the saved r), the Jacobian of InstanceNorm is SYMMETRIC, J t = r (t - mean t - xhat mean(xhat t)):
+//   * inorm_lrelu_jvp: forward-mode tangent through IN + LeakyReLU:  out = lrelu'(a) * J t          (the backward kernel above computes J (lrelu'(a) g))
+//   * inorm_second:    the adjoint of  z -> J(z) t  for fixed tangent t and upstream w = lrelu'(a) * ga (ga = adjoint of the tangent output):
+//       out (+)= -r^2 [ xhat (mean(w t) - mean w mean t - 3 mean(w xhat) mean(xhat t)) + mean(xhat t) (w - mean w) + mean(w xhat) (t - mean t) ]
+//     (derivation and numeric check against torch's double backward: tests/test_gpu_wgan.py)
+// One workgroup per (n, 16-channel plane) like the kernels above; fixed-order reductions.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void inorm_lrelu_jvp_kernel(dasr_tensor a, dasr_tensor t, int C, int H, int W, float slope,
+                                                              const float* __restrict__ stats, dasr_tensor out) {
+    __shared__ f32x4 red[16];
+    const int ncb = (C + 15) >> 4;
+    const int n = blockIdx.x / ncb, cb = blockIdx.x - n * ncb;
+    const int q = threadIdx.x & 3, pl = threadIdx.x >> 2;
+    const float* ap = (const float*)a.p + (size_t)n * a.n_stride + (size_t)cb * a.cb_stride + q * 4;
+    const float* tp = (const float*)t.p + (size_t)n * t.n_stride + (size_t)cb * t.cb_stride + q * 4;
+    float* op = (float*)out.p + (size_t)n * out.n_stride + (size_t)cb * out.cb_stride + q * 4;
+    const int HW = H * W;
+    const float inv_slope = 1.f / slope;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    for (int p = pl; p < HW; p += 64) {
+        const f32x4 av = *(const f32x4*)(ap + (size_t)p * 16);
+        const f32x4 tv = *(const f32x4*)(tp + (size_t)p * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = av[j] > 0.f ? av[j] : av[j] * inv_slope;
+            s1[j] += tv[j];
+            s2[j] += tv[j] * xh;
+        }
+    }
+    const f32x4 m1 = quad_reduce(s1, red) * (1.f / HW);
+    const f32x4 m2 = quad_reduce(s2, red) * (1.f / HW);
+    f32x4 rstd;
+    const float* st = stats + ((size_t)n * ncb * 16 + cb * 16 + q * 4) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rstd[j] = st[2 * j + 1];
+    for (int p = pl; p < HW; p += 64) {
+        const f32x4 av = *(const f32x4*)(ap + (size_t)p * 16);
+        const f32x4 tv = *(const f32x4*)(tp + (size_t)p * 16);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool pos = av[j] > 0.f;
+            const float xh = pos ? av[j] : av[j] * inv_slope;
+            o[j] = (pos ? 1.f : slope) * rstd[j] * (tv[j] - m1[j] - xh * m2[j]);
+        }
+        *(f32x4*)(op + (size_t)p * 16) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void inorm_second_kernel(dasr_tensor a, dasr_tensor t, dasr_tensor ga, int C, int H, int W, float slope,
+                                                           const float* __restrict__ stats, dasr_tensor out, int accumulate) {
+    __shared__ f32x4 red[16];
+    const int ncb = (C + 15) >> 4;
+    const int n = blockIdx.x / ncb, cb = blockIdx.x - n * ncb;
+    const int q = threadIdx.x & 3, pl = threadIdx.x >> 2;
+    const float* ap = (const float*)a.p + (size_t)n * a.n_stride + (size_t)cb * a.cb_stride + q * 4;
+    const float* tp = (const float*)t.p + (size_t)n * t.n_stride + (size_t)cb * t.cb_stride + q * 4;
+    const float* gp = (const float*)ga.p + (size_t)n * ga.n_stride + (size_t)cb * ga.cb_stride + q * 4;
+    float* op = (float*)out.p + (size_t)n * out.n_stride + (size_t)cb * out.cb_stride + q * 4;
+    const int HW = H * W;
+    const float inv_slope = 1.f / slope, inv = 1.f / HW;
+    f32x4 sw = {0.f, 0.f, 0.f, 0.f}, sz = sw, swx = sw, sxz = sw, swz = sw;
+    for (int p = pl; p < HW; p += 64) {
+        const f32x4 av = *(const f32x4*)(ap + (size_t)p * 16);
+        const f32x4 tv = *(const f32x4*)(tp + (size_t)p * 16);
+        const f32x4 gv = *(const f32x4*)(gp + (size_t)p * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool pos = av[j] > 0.f;
+            const float xh = pos ? av[j] : av[j] * inv_slope;
+            const float w = pos ? gv[j] : gv[j] * slope;
+            sw[j] += w;
+            sz[j] += tv[j];
+            swx[j] += w * xh;
+            sxz[j] += xh * tv[j];
+            swz[j] += w * tv[j];
+        }
+    }
+    const f32x4 mw = quad_reduce(sw, red) * inv, mz = quad_reduce(sz, red) * inv, pw = quad_reduce(swx, red) * inv, pz = quad_reduce(sxz, red) * inv,
+                qq = quad_reduce(swz, red) * inv;
+    f32x4 r2, k0;
+    const float* st = stats + ((size_t)n * ncb * 16 + cb * 16 + q * 4) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r2[j] = st[2 * j + 1] * st[2 * j + 1];
+        k0[j] = qq[j] - mw[j] * mz[j] - 3.f * pw[j] * pz[j];
+    }
+    for (int p = pl; p < HW; p += 64) {
+        const f32x4 av = *(const f32x4*)(ap + (size_t)p * 16);
+        const f32x4 tv = *(const f32x4*)(tp + (size_t)p * 16);
+        const f32x4 gv = *(const f32x4*)(gp + (size_t)p * 16);
+        f32x4 o = accumulate ? *(const f32x4*)(op + (size_t)p * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool pos = av[j] > 0.f;
+            const float xh = pos ? av[j] : av[j] * inv_slope;
+            const float w = pos ? gv[j] : gv[j] * slope;
+            o[j] -= r2[j] * (xh * k0[j] + pz[j] * (w - mw[j]) + pw[j] * (tv[j] - mz[j]));
+        }
+        *(f32x4*)(op + (size_t)p * 16) = o;
+    }
+}
+
+// gradient penalty of the DSN's --wgan (train.py:233-236): nrm = || g ||_2 over the C real channels of a blocked f32 tensor (ALL images),
+// pen = weight (nrm - 1)^2.  Two launches: per-workgroup partial sums of squares into `part` (deterministic: fixed grid, fixed order), then one workgroup
+// adds them in order and writes out[0] = nrm, out[1] = pen, out[2] = dpen/dnrm / nrm = 2 weight (nrm - 1) / nrm (the factor in front of
+// d<g_const, g(theta)>/dtheta), and loss_acc[0] += pen.
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(dasr_tensor g, int N, int C, int H, int W, float* __restrict__ part) {
+    __shared__ float red[4];
+    const long long HW = (long long)H * W, total = (long long)N * HW;
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int n = i / HW;
+        const long long p = i - (long long)n * HW;
+        const float* gp = (const float*)g.p + (size_t)n * g.n_stride + (size_t)p * 16;
+        for (int c = 0; c < C; ++c) s += gp[(size_t)(c >> 4) * g.cb_stride + (c & 15)] * gp[(size_t)(c >> 4) * g.cb_stride + (c & 15)];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void gp_finalize_kernel(const float* __restrict__ part, int nblk, float weight, float* __restrict__ out, float* __restrict__ loss_acc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float s = 0.f;
+    for (int i = 0; i < nblk; ++i) s += part[i];
+    const float nrm = sqrtf(s);
+    const float pen = weight * (nrm - 1.f) * (nrm - 1.f);
+    out[0] = nrm;
+    out[1] = pen;
+    out[2] = nrm > 0.f ? 2.f * weight * (nrm - 1.f) / nrm : 0.f;
+    if (loss_acc) loss_acc[0] += pen;
+}
+
+// dst[i] = factor * (*scalar) over the C real channels of a blocked f32 tensor (zero elsewhere): a constant upstream gradient whose value lives on the device
+__global__ void fill_scaled_kernel(dasr_tensor x, int N, int C, int H, int W, const float* __restrict__ scalar, float factor) {
+    const int ncb = (C + 15) >> 4;
+    const long long per_plane = (long long)H * W * 16, total = (long long)N * ncb * per_plane;
+    const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= total) return;
+    const long long e = gi % per_plane;
+    long long tq = gi / per_plane;
+    const int cb = tq % ncb, n = tq / ncb;
+    const int c = cb * 16 + (int)(e & 15);
+    ((float*)x.p)[(size_t)n * x.n_stride + (size_t)cb * x.cb_stride + e] = c < C ? factor * scalar[0] : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // BatchNorm2d in TRAINING mode (batch statistics, affine) + LeakyReLU, as in Discriminator_VGG_128 (architecture.py:442-495).
 // The batch is processed in GROUPS of `group` consecutive images with their own statistics: the reference calls the discriminator
 // separately on the fake and on the real half (DASR_model.py:251,288-289), here both halves go through one launch.
@@ -416,7 +566,8 @@ __global__ void dwt_fwd_kernel(dasr_tensor x, int N, int C, int H2, int W2, int 
 #pragma unroll
     for (int j = 0; j < 16; ++j) L[j] = Hh[j] = 0.f;
     // norm bit 0: LL * 0.5, bands * 0.5 + 0.5; bit 1: the DSN discriminator's 'sum' format (codes/DSN/model.py:113-114): hc = (LH + HL + HH) / 3, C channels
-    const float s = (norm & 1) ? 0.5f : 1.f, off = (norm & 1) ? 0.5f : 0.f;
+    // bit 2: the LINEAR part only (no + 0.5): the tangent of the normalised bands (second-order pass of the DSN's --wgan penalty)
+    const float s = (norm & 1) ? 0.5f : 1.f, off = ((norm & 1) && !(norm & 4)) ? 0.5f : 0.f;
     for (int c = 0; c < C; ++c) {
         const float a = pa[c], b = pa[16 + c], cc = pc[c], d = pc[16 + c];
         L[c] = (a + b + cc + d) * 0.5f * s;
@@ -967,6 +1118,35 @@ extern "C" int dasr_inorm_lrelu_bwd(dasr_tensor a, dasr_tensor ga, int32_t N, in
                                     const float* stats, dasr_tensor gx, void* stream) {
     if (N <= 0 || C <= 0) return DASR_EINVAL;
     DASR_LAUNCH(inorm_lrelu_bwd_kernel, dim3(N * ((C + 15) / 16)), dim3(256), 0, as_stream(stream), a, ga, C, H, W, slope, stats, gx);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_inorm_lrelu_jvp(dasr_tensor a, dasr_tensor t, int32_t N, int32_t C, int32_t H, int32_t W, float slope, const float* stats, dasr_tensor out,
+                                    void* stream) {
+    if (N <= 0 || C <= 0 || !a.p || !t.p || !out.p || !stats) return DASR_EINVAL;
+    DASR_LAUNCH(inorm_lrelu_jvp_kernel, dim3(N * ((C + 15) / 16)), dim3(256), 0, as_stream(stream), a, t, C, H, W, slope, stats, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_inorm_second(dasr_tensor a, dasr_tensor t, dasr_tensor ga, int32_t N, int32_t C, int32_t H, int32_t W, float slope, const float* stats,
+                                 dasr_tensor out, int32_t accumulate, void* stream) {
+    if (N <= 0 || C <= 0 || !a.p || !t.p || !ga.p || !out.p || !stats) return DASR_EINVAL;
+    DASR_LAUNCH(inorm_second_kernel, dim3(N * ((C + 15) / 16)), dim3(256), 0, as_stream(stream), a, t, ga, C, H, W, slope, stats, out, accumulate);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_grad_penalty(dasr_tensor g, int32_t N, int32_t C, int32_t H, int32_t W, float weight, float* part256, float* out3, float* loss_acc,
+                                 void* stream) {
+    if (N <= 0 || C <= 0 || C > 16 || H <= 0 || W <= 0 || !g.p || !part256 || !out3) return DASR_EINVAL;
+    DASR_LAUNCH(sumsq_partial_kernel, dim3(256), dim3(256), 0, as_stream(stream), g, N, C, H, W, part256);
+    DASR_LAUNCH(gp_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), part256, 256, weight, out3, loss_acc);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_fill_scaled(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, const float* scalar, float factor, void* stream) {
+    const long long total = (long long)N * ((C + 15) / 16) * H * W * 16;
+    if (total <= 0 || !x.p || !scalar) return DASR_EINVAL;
+    DASR_LAUNCH(fill_scaled_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), x, N, C, H, W, scalar, factor);
     return (int)hipGetLastError();
 }
 

@@ -399,7 +399,7 @@ class DSNModel:
     def __init__(self, opt=None, device=None, **kw):
         o = dict(n_res_blocks=8, kernel_size=5, filter='gau', norm_layer='Instance', discriminator='FSD', generator='DeResnet', learning_rate=1e-4,
                  adam_beta_1=0.5, w_col=1.0, w_tex=0.005, w_per=0.01, per_type='VGG', vgg_path=None, vgg_seed=78, num_epochs=400,
-                 num_decay_epochs=150, upscale_factor=4, ragan=False, allow_random_perceptual=False, cat_or_sum='cat', disc_freq=1, gen_freq=1, lpips_rot_flip=False)
+                 num_decay_epochs=150, upscale_factor=4, ragan=False, allow_random_perceptual=False, cat_or_sum='cat', disc_freq=1, gen_freq=1, lpips_rot_flip=False, wgan=False)
         o.update(opt or {})
         o.update(kw)
         self.opt = o
@@ -439,6 +439,11 @@ class DSNModel:
         if self.disc_freq < 1 or self.gen_freq < 1:
             raise ValueError('disc_freq / gen_freq must be >= 1')
         self.ragan = bool(o['ragan'])   # --ragan (train.py:221-223): D(x, y) = sigmoid(D(x) - mean_n D(y)) (model.py:98-106)
+        # --wgan (train.py:45,231-241; model.py:104-105; loss.py:18-19,33-36): no sigmoid, Wasserstein terms -mean(real) + mean(fake), generator term
+        # mean(-fake), gradient penalty 10 (||d mean D(sample) / d sample|| - 1)^2 with its second-order pass through the discriminator (_GradPenaltyPlan)
+        self.wgan = bool(o['wgan'])
+        if self.wgan and self.ragan:
+            raise NotImplementedError('--wgan together with --ragan is not on the MI355X path')
         self.filter = o['filter'].lower()
         if self.filter not in ('gau', 'avg_pool', 'wavelet'):
             raise NotImplementedError('Frequency Separation type [{:s}] not recognized'.format(o['filter']))
@@ -551,6 +556,10 @@ class DSNModel:
         upd_d, upd_g = self.iteration_count % self.disc_freq == 0, self.iteration_count % self.gen_freq == 0
         if upd_d:
             P.d_bwd.run()   # D weight gradients (pre-update graph)
+            if self.wgan:   # + the gradient penalty: one mixing weight per iteration from torch's global RNG, drawn only when D steps (train.py:231-233)
+                P.gp.set_mix(torch.rand(1).item())
+                P.gp.ops.run()
+                _lib.check(_lib.lib().dasr_add_flat(self.netD.params.grad.data_ptr(), P.gp.grad.data_ptr(), P.gp.grad.numel(), _stream()), 'add_flat')
         if upd_g and rg_dp:   # generator's relativistic texture loss: stage 1 (sums still valid) -> all-reduce -> stage 2, then the backward chain
             P.g_bwd.run(0, P.ragan_cut_gbwd)
             self.dp.all_reduce_here(P.r_part)
@@ -613,9 +622,11 @@ class DSNModel:
             a = self.acc.tolist()
             self.check_finite()
             o = self.opt
-            self.log.update({'loss/d_tex_loss': a[0] + a[1], 'loss/g_tex_loss': a[2], 'loss/color_loss': a[3], 'loss/perceptual_loss': a[6],
+            self.log.update({'loss/d_tex_loss': a[0] + a[1] + (a[7] if self.wgan else 0.0), 'loss/g_tex_loss': a[2], 'loss/color_loss': a[3], 'loss/perceptual_loss': a[6],
                              'loss/g_overall_loss': o['w_col'] * a[3] + o['w_tex'] * a[2] + o['w_per'] * a[6], 'disc_score/real': a[4],
                              'disc_score/fake': a[5]})
+            if self.wgan:
+                self.log['disc_score/gradient_penalty'] = a[7]   # train.py:247-248
             self._pending = False
         return self.log
 
@@ -639,6 +650,155 @@ class DSNModel:
         self.opt_g.load_state_dict(ck['optimizer_g_state_dict'])
         self.opt_d.load_state_dict(ck['optimizer_d_state_dict'])
         self.epoch, self.iteration_count = ck['epoch'], ck['iteration']
+
+
+class _GradPenaltyPlan:
+    """--wgan (codes/DSN/train.py:231-241): grad_pen = 10 (|| d mean D(sample) / d sample ||_2 - 1)^2 on sample = r real + (1 - r) fake (ONE r per iteration),
+    and its gradient w.r.t. the discriminator's weights -- the reference gets it from torch.autograd.grad(..., create_graph=True) + backward.
+    Here: with g = d mean D / d sample (first-order backward to the input) and c = d pen / d ||g|| / ||g||, d pen / d theta = c * d <g_const, g(theta)> / d theta, and
+    <g_const, g(theta)> = the DIRECTIONAL derivative of mean D(sample; theta) along g_const -- a forward-mode tangent pass through the discriminator (convs on the
+    tangent, lrelu' masks, the symmetric InstanceNorm Jacobian: dasr_inorm_lrelu_jvp) followed by ONE reverse pass over the (primal, tangent) pair: every conv weight
+    receives adj_z (x) a + adj_zdot (x) adot (one weight-gradient launch over both pairs), InstanceNorm contributes its second-order term (dasr_inorm_second).
+    All on the device in one recorded list; the mixing weight is patched into the first op per iteration."""
+
+    def __init__(self, plan, m, N, h, w, hd, wd, acc_slot):
+        from .gan_nets import _DPlan, SLOPE as D_SLOPE
+        net, dev, d = m.netD, m.device, plan.d
+        if any(L['norm'] == 'batch' for L in net.layers):
+            raise NotImplementedError('--wgan with --norm_layer Batch: the second-order pass is built for InstanceNorm discriminators')
+        self.dg = dg = _DPlan(net, N, hd, wd)       # the discriminator on the N mixed images (its own activations / statistics)
+        nl = len(net.layers)
+        nc = net.layers[0]['cin']
+        P, pack = net.params, net.pack
+        wav = m.filter == 'wavelet'
+        k = m.k
+        norm_valid = 2 if m.filter == 'avg_pool' else 0
+        B = lambda t: BTensor(N, t.C, t.H, t.W, True, dev)
+        self.g_img, self.t0 = BTensor(N, 16, h, w, True, dev), BTensor(N, 16, hd, wd, True, dev)
+        self.part, self.out3 = torch.zeros(256, dtype=torch.float32, device=dev), torch.zeros(4, dtype=torch.float32, device=dev)
+        self.one = torch.ones(1, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros_like(P.grad)         # the penalty's weight gradients (entries no conv of the pass owns stay zero: last bias, frozen filter)
+        self.ws = Workspace(dev)
+        ops = OpList()
+        # ---- sample (already behind the linear front end: F(r real + (1 - r) fake) = r F(real) + (1 - r) F(fake), the + 0.5 of the normalisation included)
+        o = _op(_lib.OP_AXPBY)
+        o.t[0], o.f[0], o.t[1], o.f[1] = _nview(d.x, N), 0.5, d.x.view(), 0.5       # f[0] = r (real half), f[1] = 1 - r (fake half): set_mix()
+        o.i[0], o.i[1], o.i[2], o.i[3] = N, nc, hd, wd
+        o.t[2], o.t[3], o.f[2], o.t[4] = dg.x.view(), NULL_T, 1.0, NULL_T
+        self.mix_op = len(ops.ops)
+        ops.add(o)
+        ops.extend(dg.fwd)
+        lg = dg.logits
+        cnt = float(N * lg.H * lg.W)
+        o = _op(_lib.OP_FILL_SCALED)                  # d mean D / d D = 1 / cnt
+        o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.p[0], o.f[0] = dg.g_logits.view(), N, 1, lg.H, lg.W, self.one.data_ptr(), 1.0 / cnt
+        ops.add(o)
+        ops.extend(dg.bwd_data_ops(N))                # -> dg.gx = d mean D / d (front-end output)
+        o = _op(_lib.OP_FILL)
+        o.p[0], o.l[0], o.f[0] = self.g_img.t.data_ptr(), self.g_img.t.numel(), 0.0
+        ops.add(o)
+        if wav:                                       # adjoint of the front end -> g = d mean D / d sample (image space)
+            o = _op(_lib.OP_DWT_BWD)
+            o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[2], o.i[5] = NULL_T, dg.gx.view(), N, 3, hd, wd, m.dwt_norm, self.g_img.view(), 1
+        else:
+            o = _op(_lib.OP_LOWPASS)
+            o.t[0], o.t[1], o.p[0], o.i[4] = NULL_T, dg.gx.view(), m.fw.data_ptr(), k
+            o.i[0], o.i[1], o.i[2], o.i[3], o.i[5], o.i[6] = N, 3, h, w, 1 | norm_valid, 1
+            o.f[0], o.f[1], o.t[2], o.t[3] = 0.5, 0.0, self.g_img.view(), NULL_T
+        ops.add(o)
+        o = _op(_lib.OP_GRAD_PENALTY)                 # out3 = {||g||, 10 (||g|| - 1)^2, 20 (||g|| - 1) / ||g||}; acc[slot] += the penalty
+        o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0] = self.g_img.view(), N, 3, h, w, 10.0
+        o.p[0], o.p[1], o.p[2] = self.part.data_ptr(), self.out3.data_ptr(), m.acc.data_ptr() + 4 * acc_slot
+        ops.add(o)
+        # ---- tangent pass along u = g: t0 = (linear part of the front end)(g)
+        if wav:
+            o = _op(_lib.OP_DWT_FWD)
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.t[1], o.t[2] = self.g_img.view(), N, 3, hd, wd, m.dwt_norm | 4, NULL_T, self.t0.view()
+        else:
+            o = _op(_lib.OP_LOWPASS)
+            o.t[0], o.t[1], o.p[0], o.i[4] = self.g_img.view(), NULL_T, m.fw.data_ptr(), k
+            o.i[0], o.i[1], o.i[2], o.i[3], o.i[5], o.i[6] = N, 3, h, w, 0 | norm_valid, 0
+            o.f[0], o.f[1], o.t[2], o.t[3] = 0.5, 0.0, NULL_T, self.t0.view()
+        ops.add(o)
+        keep = []
+        adot, zdot = [None] * nl, [None] * nl        # tangents of the layer outputs (after norm + lrelu) / of the conv outputs in front of a norm
+        src = self.t0
+        for i, L in enumerate(net.layers[:-1]):
+            (hi, wi), (ho, wo) = dg.dims[i], dg.dims[i + 1]
+            if L['norm']:
+                zdot[i] = B(dg.zs[i])
+                adot[i] = B(dg.acts[i])
+                ops.add(conv_op(pack, L['fwd'], src.view(), True, L['cin_pad'], hi, wi, ho, wo, N, kh=L['kh'], stride=L['stride'], pad=L['pad'], out_f32=zdot[i].view()))
+                o = _op(_lib.OP_INORM_JVP)
+                o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3] = dg.acts[i].view(), zdot[i].view(), N, L['cout'], ho, wo
+                o.f[0], o.p[0], o.t[2] = D_SLOPE, dg.stats[i].data_ptr(), adot[i].view()
+                ops.add(o)
+            else:   # conv + lrelu: adot = lrelu'(a) * conv(tangent) (the mask multiplies the conv output in the epilogue; no bias on a tangent)
+                adot[i] = B(dg.acts[i])
+                ops.add(conv_op(pack, L['fwd'], src.view(), True, L['cin_pad'], hi, wi, ho, wo, N, kh=L['kh'], stride=L['stride'], pad=L['pad'],
+                                mask=dg.acts[i].view(), mask_f32=1, slope=D_SLOPE, out_f32=adot[i].view()))
+            src = adot[i]
+        # ---- reverse pass over (primal, tangent): s = mean(conv_last(adot)), upstream c / cnt
+        Ll = net.layers[-1]
+        gz = B(dg.g_logits)                           # adjoint of the last conv's TANGENT output
+        o = _op(_lib.OP_FILL_SCALED)
+        o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.p[0], o.f[0] = gz.view(), N, 1, lg.H, lg.W, self.out3.data_ptr() + 8, 1.0 / cnt
+        ops.add(o)
+        GS = 256.0   # power-of-two pre-scale of the f16-staged weight-gradient operands (the adjoints here are c / cnt ~ 1e-2 .. 1e1)
+
+        def wgrad(i, pairs, bias):
+            L = net.layers[i]
+            (hi, wi), (ho, wo) = dg.dims[i], dg.dims[i + 1]
+            grp = WgradGroup(L['kh'], L['stride'])
+            (g0, x0), more = pairs[0], pairs[1:]
+            grp.add_conv(g0.view, True, g0.planes, x0.view, True, x0.planes, L['cout'], L['cin'], hi, wi, ho, wo, N, P.off(L['key'] + 'weight'),
+                         P.off(L['key'] + 'bias') if (bias and L['bias']) else None, pad=L['pad'], f16=net.prec == 4, g_scale=GS if net.prec == 4 else 0.0,
+                         more_pairs=[(gg.view, xx.view) for gg, xx in more])
+            grp.finalize(self.ws, dev)
+            for op in grp.ops(self.grad.data_ptr()):
+                ops.add(op)
+            ops.keep.append(grp)
+
+        i = nl - 1
+        wgrad(i, [(gz, adot[i - 1])], bias=False)     # the last conv's bias does not enter the directional derivative
+        g_adot, g_a = B(dg.acts[i - 1]), None         # adjoints of adot[i-1] (tangent path) and of a[i-1] (primal path; none yet)
+        dg._dgrad_ops(ops, i, N, gz, g_adot, None)
+        for i in range(nl - 2, -1, -1):
+            L = net.layers[i]
+            inp_a = dg.x if i == 0 else dg.acts[i - 1]
+            inp_adot = self.t0 if i == 0 else adot[i - 1]
+            if L['norm']:
+                g_zdot, g_z = B(dg.zs[i]), B(dg.zs[i])
+                for ga_, out_ in ((g_adot, g_zdot),) + (((g_a, g_z),) if g_a is not None else ()):   # J (lrelu'(a) ga): the first-order InstanceNorm backward on both adjoints
+                    o = _op(_lib.OP_INORM_BWD)
+                    o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3] = dg.acts[i].view(), ga_.view(), N, L['cout'], dg.dims[i + 1][0], dg.dims[i + 1][1]
+                    o.f[0], o.p[0], o.t[2] = D_SLOPE, dg.stats[i].data_ptr(), out_.view()
+                    ops.add(o)
+                o = _op(_lib.OP_INORM_SECOND)        # + the dependence of J on z: tangent zdot, upstream lrelu'(a) * g_adot
+                o.t[0], o.t[1], o.t[2], o.i[0], o.i[1], o.i[2], o.i[3] = dg.acts[i].view(), zdot[i].view(), g_adot.view(), N, L['cout'], dg.dims[i + 1][0], dg.dims[i + 1][1]
+                o.f[0], o.p[0], o.t[3], o.i[4] = D_SLOPE, dg.stats[i].data_ptr(), g_z.view(), 1 if g_a is not None else 0
+                ops.add(o)
+                mask = None
+            else:   # conv + lrelu: the adjoints pass through lrelu'(a) (applied as the mask of the data-gradient convs of the layer ABOVE, see below)
+                g_zdot, g_z = g_adot, g_a
+                mask = None
+            wgrad(i, [(g_z, inp_a), (g_zdot, inp_adot)] if g_z is not None else [(g_zdot, inp_adot)], bias=g_z is not None)
+            if i > 0:
+                below = net.layers[i - 1]
+                n_adot, n_a = B(dg.acts[i - 1]), (B(dg.acts[i - 1]) if g_z is not None else None)
+                m_ = None if below['norm'] else dg.acts[i - 1]     # plain conv + lrelu below: its lrelu' is the mask of these data-gradient convs
+                dg._dgrad_ops(ops, i, N, g_zdot, n_adot, m_)
+                if g_z is not None:
+                    dg._dgrad_ops(ops, i, N, g_z, n_a, m_)
+                keep += [g_adot, g_a, g_zdot, g_z]
+                g_adot, g_a = n_adot, n_a
+        self.keep = keep + [g_adot, g_a, gz] + adot + zdot
+        self.ws.finalize()
+        self.ops = ops.tag(10)
+
+    def set_mix(self, r):
+        self.ops.set_f(self.mix_op, 0, float(r))
+        self.ops.set_f(self.mix_op, 1, 1.0 - float(r))
 
 
 class _DSNPlan:
@@ -709,7 +869,13 @@ class _DSNPlan:
                 f.extend(l_)
                 self.ragan_cuts_fwd.append(len(f.ops))
         # discriminator loss: -log(real) - log(1 - fake)   (acc[0], acc[1]); scores acc[4] (real), acc[5] (fake)
-        for n0, mode, a_loss, a_score in (() if m.ragan else ((N, 0, 0, 4), (0, 1, 1, 5))):
+        for n0, target, a_loss, a_score in (((N, 1.0, 0, 4), (0, 0.0, 1, 5)) if m.wgan else ()):   # --wgan: -mean(real) + mean(fake) on the raw map (loss.py:33-36)
+            o = _op(_lib.OP_BCE)
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = _nview(lg, n0), N, 1, lg.H, lg.W, 2
+            o.f[0], o.f[1], o.f[2] = target, 1.0 / cnt, 1.0 / cnt
+            o.p[0], o.p[1], o.f[3], o.t[1] = acc + 4 * a_loss, acc + 4 * a_score, 1.0 / cnt, _nview(d.g_logits, n0)
+            f.add(o)
+        for n0, mode, a_loss, a_score in (() if (m.ragan or m.wgan) else ((N, 0, 0, 4), (0, 1, 1, 5))):
             o = _op(_lib.OP_LOGLOSS)
             o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = _nview(lg, n0), N, lg.H, lg.W, mode, 0
             o.f[0], o.f[1], o.f[2], o.f[3] = EPS, 1.0 / cnt, 1.0 / cnt, 1.0 / cnt
@@ -754,6 +920,7 @@ class _DSNPlan:
         self.fwd = f
         # D weight gradients from the pre-update graph
         self.d_bwd = d.bwd_full
+        self.gp = _GradPenaltyPlan(self, m, N, h, w, hd, wd, acc_slot=7) if m.wgan else None   # value -> acc[7], weight gradients -> gp.grad
         # generator: texture loss gradient through D's data path (+ colour adjoint) -> g_fake -> G backward
         gb = OpList()
         if m.ragan:   # -log(sigmoid(fake - mean_n(real)) + eps): stage 0's sums are still valid, the real term is absent (t < 0), real carries no gradient
@@ -763,6 +930,12 @@ class _DSNPlan:
             gb.extend(rl[1])
             self.ragan_cut_gbwd = len(gb.ops)
             gb.extend(rl[2])
+        elif m.wgan:   # generator_loss(wasserstein): mean(-fake_tex) (loss.py:18-19): value -> acc[2], gradient w_tex * (-1 / cnt) -> g_logits[:N]
+            o = _op(_lib.OP_BCE)
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = lg.view(), N, 1, lg.H, lg.W, 2
+            o.f[0], o.f[1], o.f[2] = 1.0, 1.0 / cnt, float(o_['w_tex']) / cnt
+            o.p[0], o.p[1], o.f[3], o.t[1] = acc + 4 * 2, None, 0.0, d.g_logits.view()
+            gb.add(o)
         else:
             o = _op(_lib.OP_LOGLOSS)   # -log(fake_tex) on the fake half: value -> acc[2], gradient -> g_logits[:N]
             o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = lg.view(), N, lg.H, lg.W, 0, 0
@@ -810,7 +983,7 @@ class _DSNPlan:
     def set_grad_scale(self, scale):
         self.scale = scale
         self.g.set_grad_scale(scale)
-        for ol in (self.d_bwd, self.g_bwd):
+        for ol in (self.d_bwd, self.g_bwd) + ((self.gp.ops,) if self.gp is not None else ()):
             for o in ol.ops:
                 if o.op == _lib.OP_WGRAD_REDUCE:
                     o.f[0] = scale

@@ -207,6 +207,12 @@ class OpList:
         self._arr = None
         return self
 
+    def set_f(self, idx, slot, value):
+        """patch float argument `slot` of op `idx` in place (see set_i)"""
+        self.ops[idx].f[slot] = value
+        if self._arr is not None:
+            self._arr[idx].f[slot] = value
+
     def set_i(self, idx, slot, value):
         """patch integer argument `slot` of op `idx` in place (recorded list AND its ctypes image): for the few arguments that change from call to
         call while the plan stays recorded (e.g. the random symmetry of DSN --lpips_rot_flip)"""
@@ -325,12 +331,14 @@ class WgradGroup:
         self.parts = []  # (WgradPart, WgradReducePart)
 
     def add_conv(self, g, g_f32, g_planes_total, inp, in_f32, in_planes_total, cout, cin, Hin, Win, Hout, Wout, N,
-                 dst_w_off, dst_b_off, pad=None, ups=0, f16=False, g_scale=0.0, split=None):
+                 dst_w_off, dst_b_off, pad=None, ups=0, f16=False, g_scale=0.0, split=None, more_pairs=()):
         """g / inp are BTensor-like callables c0 -> dasr_tensor view.  f16: the f32 tensors are rounded to f16 (g pre-scaled by the
         power of two g_scale) instead of bf16 while staging; the reduce op undoes the scale.
         split = (g_lo, inp_lo) (views like g / inp, filled by dasr_f16_residual): 22-bit operands on the f16 MFMA -- every part becomes THREE
         parts g.x, g.x_lo, g_lo.x whose partial sums lie behind one another as 3 * nsplit splits of ONE reduce part (the bias partials, which come
-        from the unrounded gradient, only from the first)."""
+        from the unrounded gradient, only from the first).
+        more_pairs = [(g2, inp2), ...]: further (gradient, input) pairs whose products are summed into the SAME weight gradient (the second-order pass
+        of the DSN's --wgan penalty: dW = adj_z (x) a + adj_zdot (x) adot); same mechanism, the bias partials come from the first pair only."""
         assert not f16 or (g_f32 and in_f32)
         assert split is None or f16
         self.f16 = bool(f16) or getattr(self, 'f16', False)
@@ -341,7 +349,7 @@ class WgradGroup:
         self.flops = getattr(self, 'flops', 0.0) + 2.0 * N * Hout * Wout * ntaps * cin * cout
         pad = (self.kh - 1) // 2 if pad is None else pad
         cin_pad = ceil_div(cin, 16) * 16
-        variants = [(g, inp)] if split is None else [(g, inp), (g, split[1]), (split[0], inp)]
+        variants = ([(g, inp)] if split is None else [(g, inp), (g, split[1]), (split[0], inp)]) + list(more_pairs)
         for oc0 in range(0, cout, 32):
             for c0 in range(0, cin_pad, 64):
                 for tap0 in range(0, ntaps, tpp):

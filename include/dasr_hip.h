@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DASR_ABI_VERSION 14
+#define DASR_ABI_VERSION 15
 #define DASR_EINVAL (-22)
 
 typedef struct {
@@ -240,6 +240,19 @@ int dasr_inorm_lrelu_fwd(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t
                          float* stats, void* stream);
 int dasr_inorm_lrelu_bwd(dasr_tensor a, dasr_tensor ga, int32_t N, int32_t C, int32_t H, int32_t W, float slope,
                          const float* stats, dasr_tensor gx, void* stream);
+/* Second-order pieces for the DSN's --wgan gradient penalty (codes/DSN/train.py:231-236: torch.autograd.grad(..., create_graph=True) through the
+ * discriminator and the backward of that).  InstanceNorm's Jacobian is symmetric, J t = rstd (t - mean t - xhat mean(xhat t)):
+ * dasr_inorm_lrelu_jvp: forward-mode tangent  out = lrelu'(a) * J t  (a = saved forward output, t = tangent of the conv output);
+ * dasr_inorm_second: adjoint of z -> J(z) t for fixed t, upstream w = lrelu'(a) * ga:
+ *   out (+)= -rstd^2 [ xhat (mean(w t) - mean w mean t - 3 mean(w xhat) mean(xhat t)) + mean(xhat t) (w - mean w) + mean(w xhat) (t - mean t) ];
+ * dasr_grad_penalty: nrm = ||g||_2 over the C (<= 16) real channels of ALL images, out3 = {nrm, weight (nrm - 1)^2, 2 weight (nrm - 1) / nrm},
+ *   loss_acc[0] += the penalty; part256 = 256 floats of scratch (deterministic two-stage sum);
+ * dasr_fill_scaled: x = factor * scalar[0] on the C real channels (a constant upstream gradient whose value was computed on the device). */
+int dasr_inorm_lrelu_jvp(dasr_tensor a, dasr_tensor t, int32_t N, int32_t C, int32_t H, int32_t W, float slope, const float* stats, dasr_tensor out, void* stream);
+int dasr_inorm_second(dasr_tensor a, dasr_tensor t, dasr_tensor ga, int32_t N, int32_t C, int32_t H, int32_t W, float slope, const float* stats,
+                      dasr_tensor out, int32_t accumulate, void* stream);
+int dasr_grad_penalty(dasr_tensor g, int32_t N, int32_t C, int32_t H, int32_t W, float weight, float* part256, float* out3, float* loss_acc, void* stream);
+int dasr_fill_scaled(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, const float* scalar, float factor, void* stream);
 /* nn.BatchNorm2d in TRAINING mode (batch statistics, affine gamma / beta) + LeakyReLU of Discriminator_VGG_128 (architecture.py:442-495), fused.
  * The N images are normalised in groups of `group` consecutive images with their own statistics (the reference runs the discriminator on the
  * fake and the real half in separate calls, DASR_model.py:251,288-289).  stats[N/group][Cpad][3] = (mean, rstd, biased variance).
@@ -373,7 +386,9 @@ enum { DASR_OP_CONV = 1, DASR_OP_WGRAD = 2, DASR_OP_WGRAD_REDUCE = 3, DASR_OP_PA
        DASR_OP_EVENT_RECORD = 28, DASR_OP_STREAM_WAIT = 29, DASR_OP_SET_STREAM = 30,
        DASR_OP_CVT_F16 = 31, DASR_OP_DOWNSUM_F16 = 32, DASR_OP_PIXSHUF = 33, DASR_OP_PIXUNSHUF = 34,
        DASR_OP_LPIPS_S2D = 35, DASR_OP_MAXPOOL3 = 36, DASR_OP_MAXPOOL3_BWD = 37, DASR_OP_LPIPS_HEAD = 38, DASR_OP_RAGAN = 39,
-       DASR_OP_BNORM_FWD = 40, DASR_OP_BNORM_BWD = 41, DASR_OP_BNORM_RUNNING = 42, DASR_OP_DDM_SPREAD = 43 };
+       DASR_OP_BNORM_FWD = 40, DASR_OP_BNORM_BWD = 41, DASR_OP_BNORM_RUNNING = 42, DASR_OP_DDM_SPREAD = 43,
+       /* --wgan gradient penalty (round 4) */
+       DASR_OP_INORM_JVP = 44, DASR_OP_INORM_SECOND = 45, DASR_OP_GRAD_PENALTY = 46, DASR_OP_FILL_SCALED = 47 };
 
 typedef struct {
     int32_t op;  int32_t i[8];  float f[4];  int64_t l[4];  void* p[4];  dasr_tensor t[5];

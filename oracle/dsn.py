@@ -133,8 +133,9 @@ class NLayerDiscriminatorDSN(nn.Module):
 class Discriminator(nn.Module):
     """Discriminator(D_arch='FSD' | 'nld_s1' | 'nld_s2') with the frequency-separation front end (model.py:60-118); output = sigmoid"""
 
-    def __init__(self, kernel_size=5, norm_layer='Instance', filter_type='gau', D_arch='FSD', cs='cat'):
+    def __init__(self, kernel_size=5, norm_layer='Instance', filter_type='gau', D_arch='FSD', cs='cat', wgan=False):
         super().__init__()
+        self.wgan = bool(wgan)   # --wgan (model.py:61,65,104-105): no sigmoid on the output map
         self.filter_type = filter_type.lower()
         self.cs = cs.lower()
         if self.cs not in ('cat', 'sum'):
@@ -169,7 +170,7 @@ class Discriminator(nn.Module):
         z = self.net(self.front(x))
         if y is not None:
             z = z - self.net(self.front(y)).mean(0, keepdim=True)
-        return torch.sigmoid(z)
+        return z if self.wgan else torch.sigmoid(z)
 
 
 def vgg16_features31(seed):
@@ -205,8 +206,9 @@ class DSNTrainer:
 
     def __init__(self, netG=None, netD=None, lr=1e-4, beta1=0.5, w_col=1.0, w_tex=0.005, w_per=0.01, per_type='VGG',
                  kernel_size=5, filter_type='gau', norm_layer='Instance', vgg_seed=78, num_epochs=400, num_decay_epochs=150, netF=None, ragan=False,
-                 disc_freq=1, gen_freq=1, lpips_rot_flip=False):
+                 disc_freq=1, gen_freq=1, lpips_rot_flip=False, wgan=False):
         self.ragan = ragan
+        self.wgan = bool(wgan)   # --wgan (train.py:45,231-241; loss.py:11-41): Wasserstein terms on the un-squashed map + gradient penalty
         self.lpips_rot_flip = bool(lpips_rot_flip)   # --lpips_rot_flip (train.py:52, loss.py:66,149-168)
         # --disc_freq / --gen_freq (train.py:55-56): `iteration += 1` at the top of the loop body (:206), the discriminator steps when
         # iteration % disc_freq == 0 (:229), the generator when iteration % gen_freq == 0 (:251)
@@ -239,8 +241,24 @@ class DSNTrainer:
     def iteration(self, hr, bicubic_lr, real_lr):
         fake = self.G(bicubic_lr if isinstance(self.G, GeneratorDSGAN) else hr)   # codes/DSN/train.py:213-217
         real_tex, fake_tex = (self.D(real_lr, fake), self.D(fake, real_lr)) if self.ragan else (self.D(real_lr), self.D(fake))
-        d_loss = -torch.log(real_tex + 1e-8).mean() - torch.log(1 - fake_tex + 1e-8).mean()
-        tex = torch.mean(-torch.log(fake_tex + 1e-8))
+        self.iteration_count += 1
+        upd_d, upd_g = self.iteration_count % self.disc_freq == 0, self.iteration_count % self.gen_freq == 0
+        if self.wgan:
+            # train.py:231-236: ONE random mixing weight for the whole batch (torch's global RNG, drawn only when the discriminator steps), the gradient
+            # of the MEAN output w.r.t. the mixed images, and 10 (||gradient||_2 - 1)^2 with the norm over the whole batch tensor
+            grad_pen = fake.new_zeros(())
+            if upd_d:
+                rand = torch.rand(1).item()
+                sample = rand * real_lr + (1 - rand) * fake
+                gp_tex = self.D(sample)
+                gradient = torch.autograd.grad(gp_tex.mean(), sample, create_graph=True)[0]
+                grad_pen = 10 * (gradient.norm() - 1) ** 2
+            d_loss = -real_tex.mean() + fake_tex.mean() + grad_pen   # loss.py:33-36
+            tex = torch.mean(-fake_tex)                              # loss.py:18-19
+            self.grad_pen = float(grad_pen)
+        else:
+            d_loss = -torch.log(real_tex + 1e-8).mean() - torch.log(1 - fake_tex + 1e-8).mean()
+            tex = torch.mean(-torch.log(fake_tex + 1e-8))
         col = F.l1_loss(self.color_filter(fake), self.color_filter(bicubic_lr))
         g_loss = self.w_col * col + self.w_tex * tex
         per = torch.zeros(())
@@ -251,8 +269,6 @@ class DSNTrainer:
         if self.per is not None:
             per = F.mse_loss(self.per(fake), self.per(bicubic_lr))
             g_loss = g_loss + self.w_per * per
-        self.iteration_count += 1
-        upd_d, upd_g = self.iteration_count % self.disc_freq == 0, self.iteration_count % self.gen_freq == 0
         d_params = [p for p in self.D.parameters() if p.requires_grad]
         g_params = list(self.G.parameters())
         gd = torch.autograd.grad(d_loss, d_params, retain_graph=True) if upd_d else None
@@ -269,6 +285,8 @@ class DSNTrainer:
         self.log.update({'loss/d_tex_loss': d_loss.item(), 'loss/g_tex_loss': tex.item(), 'loss/color_loss': col.item(),
                          'loss/perceptual_loss': per.item(), 'loss/g_overall_loss': g_loss.item(),
                          'disc_score/real': real_tex.mean().item(), 'disc_score/fake': fake_tex.mean().item()})
+        if self.wgan:
+            self.log['disc_score/gradient_penalty'] = self.grad_pen   # train.py:247-248
 
     def end_epoch(self):
         self.sched_d.step()

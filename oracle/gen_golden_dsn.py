@@ -37,6 +37,10 @@ DSN_CASES = {
     'dsn_wavelet_sum_inst_b2_128': dict(filter='wavelet', k=5, norm='Instance', n=2, crop=128, cs='sum'),
     # --lpips_rot_flip (round 4; train.py:52, loss.py:66,149-168): random rot90 / flips of both images in front of LPIPS, python `random` seeded
     # per call (seed 3 draws k_rot = -1, flip rows, no column flip; seed + 1 for the second iteration)
+    # --wgan (round 4; train.py:45,231-241, model.py:104-105, loss.py:11-41): no sigmoid, Wasserstein terms, gradient penalty 10 (||d mean D(sample) / d sample|| - 1)^2
+    # on ONE random mix of the real and fake batch (torch.manual_seed(c['tseed']) in front of the draw), second-order pass through the discriminator
+    'dsn_gau5_inst_b2_128_wgan': dict(filter='gau', k=5, norm='Instance', n=2, crop=128, wgan=True, tseed=11),
+    'dsn_wavelet_inst_b2_128_wgan': dict(filter='wavelet', k=5, norm='Instance', n=2, crop=128, wgan=True, tseed=12),
     'dsn_gau5_inst_b2_256_lpips_rotflip': dict(filter='gau', k=5, norm='Instance', n=2, crop=256, per='LPIPS', rot_flip=True, rseed=3),
 }
 
@@ -62,8 +66,18 @@ def collect(G, D, color_filter, per_net, c, w=(1.0, 0.005, 0.01)):
         random.seed(c['rseed'])
     fake = G(bic if c.get('gen') == 'DSGAN' else hr)
     rt, ft = (D(real, fake), D(fake, real)) if c.get('ragan') else (D(real), D(fake))
-    d_loss = -torch.log(rt + 1e-8).mean() - torch.log(1 - ft + 1e-8).mean()
-    tex = torch.mean(-torch.log(ft + 1e-8))
+    if c.get('wgan'):   # the statements of train.py:231-241 / loss.py:18-19,33-36 with the reference's modules
+        torch.manual_seed(c['tseed'])
+        rand = torch.rand(1).item()
+        sample = rand * real + (1 - rand) * fake
+        gp_tex = D(sample)
+        gradient = torch.autograd.grad(gp_tex.mean(), sample, create_graph=True)[0]
+        grad_pen = 10 * (gradient.norm() - 1) ** 2
+        d_loss = -rt.mean() + ft.mean() + grad_pen
+        tex = torch.mean(-ft)
+    else:
+        d_loss = -torch.log(rt + 1e-8).mean() - torch.log(1 - ft + 1e-8).mean()
+        tex = torch.mean(-torch.log(ft + 1e-8))
     col = torch.nn.functional.l1_loss(color_filter(fake), color_filter(bic))
     per = per_net(fake, bic) if c.get('per') == 'LPIPS' else torch.nn.functional.mse_loss(per_net(fake), per_net(bic))
     g_loss = w[0] * col + w[1] * tex + w[2] * per
@@ -72,7 +86,7 @@ def collect(G, D, color_filter, per_net, c, w=(1.0, 0.005, 0.01)):
     gg = torch.autograd.grad(g_loss, list(G.parameters()))
     return {'fake_sub': fixtures.subsample(fake).numpy(), 'real_tex_sub': fixtures.subsample(rt).detach().numpy(),
             'fake_tex_sub': fixtures.subsample(ft).detach().numpy(),
-            'losses': np.array([d_loss.item(), tex.item(), col.item(), per.item(), g_loss.item()]),
+            'losses': np.array([d_loss.item(), tex.item(), col.item(), per.item(), g_loss.item()] + ([float(grad_pen)] if c.get('wgan') else [])),
             'gradG_norm': np.array([float(x.double().norm()) for x in gg]), 'gradD_norm': np.array([float(x.double().norm()) for x in gd]),
             'G_keys': np.array(list(G.state_dict().keys())), 'D_keys': np.array(list(D.state_dict().keys()))}
 
@@ -116,7 +130,8 @@ def main():
             continue
         torch.manual_seed(0)
         G = rmodel.Generator(n_res_blocks=8) if c.get('gen') == 'DSGAN' else rmodel.De_resnet(n_res_blocks=8, scale=4)
-        D = rmodel.Discriminator(kernel_size=c['k'], D_arch=c.get('arch', 'FSD'), norm_layer=c['norm'], filter_type=c['filter'], cs=c.get('cs', 'cat'))
+        D = rmodel.Discriminator(kernel_size=c['k'], D_arch=c.get('arch', 'FSD'), norm_layer=c['norm'], filter_type=c['filter'], cs=c.get('cs', 'cat'),
+                                 wgan=bool(c.get('wgan')))
         G.load_state_dict(dsn_state(G.state_dict(), 21, 0.5))
         D.load_state_dict(dsn_state(D.state_dict(), 22, 1.0))
         _cuda = nn.Module.cuda

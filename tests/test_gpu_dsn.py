@@ -212,7 +212,8 @@ def test_deresnet_forward_backward():
 @pytest.mark.parametrize('case', ['dsn_gau5_inst_b2_128', 'dsn_wavelet_inst_b2_128', 'dsn_avg5_inst_b1_160', 'dsn_gau5_inst_b1_256_lpips',
                                   'dsn_wavelet_nld_s2_b2_128', 'dsn_gau5_nld_s1_b1_128', 'dsn_dsgan_gau5_inst_b2_128', 'dsn_gau5_inst_b3_128_ragan',
                                   'dsn_gau5_batch_b2_128', 'dsn_avg5_batch_b3_128_ragan', 'dsn_wavelet_sum_inst_b2_128',
-                                  'dsn_gau5_inst_b2_128+fwd32', 'dsn_dsgan_gau5_inst_b2_128+fwd32', 'dsn_gau5_inst_b2_256_lpips_rotflip'])
+                                  'dsn_gau5_inst_b2_128+fwd32', 'dsn_dsgan_gau5_inst_b2_128+fwd32', 'dsn_gau5_inst_b2_256_lpips_rotflip',
+                                  'dsn_gau5_inst_b2_128_wgan', 'dsn_wavelet_inst_b2_128_wgan'])
 def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir, monkeypatch, margins):
     dev = _gpu()
     case_id = case
@@ -226,7 +227,7 @@ def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir, mo
     c = DSN_CASES[case]
     gold = np.load(os.path.join(golden_dir, case + '.npz'))
     G = dsn.GeneratorDSGAN() if c.get('gen') == 'DSGAN' else dsn.DeResnet()
-    D = dsn.Discriminator(c['k'], c['norm'], c['filter'], D_arch=c.get('arch', 'FSD'), cs=c.get('cs', 'cat'))
+    D = dsn.Discriminator(c['k'], c['norm'], c['filter'], D_arch=c.get('arch', 'FSD'), cs=c.get('cs', 'cat'), wgan=bool(c.get('wgan')))
     sdG, sdD = dsn_state(G.state_dict(), 21, 0.5), dsn_state(D.state_dict(), 22, 1.0)
     G.load_state_dict(sdG)
     D.load_state_dict(sdD)
@@ -235,9 +236,9 @@ def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir, mo
         from oracle import lpips
         crit, sdF = lpips.golden_criterion(78, golden_dir)
     t = dsn.DSNTrainer(G, D, kernel_size=c['k'], filter_type=c['filter'], norm_layer=c['norm'], vgg_seed=78, w_per=0.01, per_type=c.get('per', 'VGG'), netF=crit, ragan=bool(c.get('ragan')),
-                       lpips_rot_flip=bool(c.get('rot_flip')))
+                       lpips_rot_flip=bool(c.get('rot_flip')), wgan=bool(c.get('wgan')))
     m = DSNModel(dict(ragan=bool(c.get('ragan')), filter=c['filter'], kernel_size=c['k'], norm_layer=c['norm'], w_per=0.01, vgg_seed=78, per_type=c.get('per', 'VGG'), discriminator=c.get('arch', 'FSD'), generator=c.get('gen', 'DeResnet'), allow_random_perceptual=True, cat_or_sum=c.get('cs', 'cat'),
-                      lpips_rot_flip=bool(c.get('rot_flip'))), device=dev)
+                      lpips_rot_flip=bool(c.get('rot_flip')), wgan=bool(c.get('wgan'))), device=dev)
     d_keys = list(m.netD.state_dict()) if c['norm'] == 'Batch' else list(m.netD.params.spec)   # BatchNorm: buffers are part of the reference layout
     assert list(m.netG.params.spec) == list(gold['G_keys']) and d_keys == list(gold['D_keys'])
     m.netG.load_state_dict(sdG)
@@ -250,15 +251,19 @@ def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir, mo
         # --lpips_rot_flip: both sides draw the symmetry from python's `random` like the reference (loss.py:155-168); step 1 = the fixture's seed
         # (k_rot -1, rows flipped), step 2 = seed + 1 (k_rot -1, columns flipped)
         random.seed(c.get('rseed', 0) + step - 1)
+        torch.manual_seed(c.get('tseed', 0) + step - 1)    # --wgan: the mixing weight of the gradient penalty comes from torch's global RNG (train.py:232)
         t.iteration(hr, bic, real)
         random.seed(c.get('rseed', 0) + step - 1)
+        torch.manual_seed(c.get('tseed', 0) + step - 1)
         m.iteration(hr.to(dev), bic.to(dev), real.to(dev))
         log = m.get_current_log()
         tol = 2e-3 if step == 1 else 2e-2
         for k, ref_v in t.log.items():
             assert abs(log[k] - ref_v) <= tol * max(1e-3, abs(ref_v)) + 1e-5, (step, k, log[k], ref_v)
         if step == 1:
-            gl = gold['losses']  # d_loss, tex, col, per, g_loss from the reference modules
+            gl = gold['losses'][:5]  # d_loss, tex, col, per, g_loss from the reference modules (--wgan fixtures: + the gradient penalty)
+            if c.get('wgan'):
+                assert abs(log['disc_score/gradient_penalty'] - float(gold['losses'][5])) < 2e-3 * float(gold['losses'][5])
             got = [log['loss/d_tex_loss'], log['loss/g_tex_loss'], log['loss/color_loss'], log['loss/perceptual_loss'], log['loss/g_overall_loss']]
             np.testing.assert_allclose(got, gl, rtol=2e-3, atol=1e-5)
             assert rel(m.fake.cpu(), t.fake) < ACT_TOL

@@ -1,0 +1,129 @@
+"""DSN --wgan (codes/DSN/train.py:231-241): the second-order pieces (InstanceNorm tangent / second-order adjoint, gradient-penalty finalisation) against
+torch's forward-mode / double-backward autograd, and the whole penalty -- value and weight gradients -- of the FSD discriminator against
+torch.autograd.grad(..., create_graph=True) on the oracle net; the iteration fixtures (from the reference's modules) run in tests/test_gpu_dsn.py."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda')
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def to_blocked(x, dev):
+    from dasr_amd.engine import BTensor
+    N, C_, H, W = x.shape
+    b = BTensor(N, C_, H, W, True, dev)
+    t = torch.zeros((N, b.planes * 16, H, W))
+    t[:, :C_] = x
+    b.t.copy_(t.reshape(N, b.planes, 16, H, W).permute(0, 1, 3, 4, 2).contiguous().to(dev))
+    return b
+
+
+def test_instance_norm_tangent_and_second_order_adjoint():
+    dev = _gpu()
+    from dasr_amd import _lib
+    from dasr_amd.engine import BTensor, _stream
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    N, C_, H, W = 2, 24, 9, 13
+    z = (torch.randn(N, C_, H, W, generator=g) * 1.5 + 0.3).double().requires_grad_(True)
+    zd = torch.randn(N, C_, H, W, generator=g).double()
+    ga = torch.randn(N, C_, H, W, generator=g).double()
+    fn = lambda t: F.leaky_relu(F.instance_norm(t, eps=1e-5), 0.2)
+    _, adot_fm = torch.autograd.functional.jvp(fn, (z.detach(),), (zd,))            # forward-mode value (its graph is NOT differentiable in z: checked by hand)
+    mean = lambda t: t.mean((2, 3), keepdim=True)
+    mu = mean(z)
+    r = 1.0 / torch.sqrt(mean((z - mu) ** 2) + 1e-5)
+    y = (z - mu) * r
+    adot = torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.2)) * r * (zd - mean(zd) - y * mean(y * zd))   # lrelu'(a) J(z) zd, differentiable in z
+    assert rel(adot.detach(), adot_fm) < 1e-12
+    want_second, = torch.autograd.grad((adot * ga).sum(), z)    # d <ga, lrelu'(a) J(z) zd> / dz (agrees with central differences to 1e-9)
+    zb, zdb, gab = to_blocked(z.detach().float(), dev), to_blocked(zd.float(), dev), to_blocked(ga.float(), dev)
+    ab, out = BTensor(N, C_, H, W, True, dev), BTensor(N, C_, H, W, True, dev)
+    stats = torch.zeros(N * 32 * 2, device=dev)
+    _lib.check(L.dasr_inorm_lrelu_fwd(zb.view(), N, C_, H, W, 1e-5, 0.2, ab.view(), stats.data_ptr(), _stream()))
+    _lib.check(L.dasr_inorm_lrelu_jvp(ab.view(), zdb.view(), N, C_, H, W, 0.2, stats.data_ptr(), out.view(), _stream()))
+    torch.cuda.synchronize()
+    assert rel(out.nchw(C_).cpu(), adot.detach()) < 1e-5
+    _lib.check(L.dasr_inorm_second(ab.view(), zdb.view(), gab.view(), N, C_, H, W, 0.2, stats.data_ptr(), out.view(), 0, _stream()))
+    torch.cuda.synchronize()
+    assert rel(out.nchw(C_).cpu(), want_second) < 2e-5
+    out.t.fill_(1.0)
+    _lib.check(L.dasr_inorm_second(ab.view(), zdb.view(), gab.view(), N, C_, H, W, 0.2, stats.data_ptr(), out.view(), 1, _stream()))
+    torch.cuda.synchronize()
+    assert rel(out.nchw(C_).cpu(), want_second + 1.0) < 2e-5
+    # gradient-penalty finalisation and the scaled fill
+    gi = torch.randn(3, 3, 10, 12, generator=g) * 0.05
+    gb = to_blocked(gi, dev)
+    part, out3, acc = torch.zeros(256, device=dev), torch.zeros(4, device=dev), torch.zeros(1, device=dev)
+    _lib.check(L.dasr_grad_penalty(gb.view(), 3, 3, 10, 12, 10.0, part.data_ptr(), out3.data_ptr(), acc.data_ptr(), _stream()))
+    nrm = float(gi.double().norm())
+    o = out3.cpu().tolist()
+    assert abs(o[0] - nrm) < 1e-6 * nrm and abs(o[1] - 10 * (nrm - 1) ** 2) < 1e-5 and abs(o[2] - 20 * (nrm - 1) / nrm) < 1e-4 * abs(o[2]) and abs(float(acc) - o[1]) < 1e-6
+    fb = BTensor(3, 16, 4, 5, True, dev)
+    fb.t.fill_(7.0)
+    _lib.check(L.dasr_fill_scaled(fb.view(), 3, 1, 4, 5, out3.data_ptr() + 8, 0.25, _stream()))
+    torch.cuda.synchronize()
+    v = fb.t.cpu()
+    assert torch.allclose(v[..., 0], torch.full_like(v[..., 0], 0.25 * o[2])) and float(v[..., 1:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('filt,arch', [('gau', 'FSD'), ('wavelet', 'FSD'), ('avg_pool', 'nld_s2'), ('gau', 'nld_s1')])
+def test_gradient_penalty_value_and_weight_gradients(filt, arch, margins):
+    """the penalty and d penalty / d theta of one mixing weight against torch.autograd.grad(create_graph=True) + backward on the oracle discriminator"""
+    dev = _gpu()
+    torch.set_num_threads(8)
+    from dasr_amd.dsn_model import DSNModel
+    from oracle import dsn
+    from oracle.gen_golden_dsn import dsn_state, dsn_batch
+    D = dsn.Discriminator(5, 'Instance', filt, D_arch=arch, wgan=True)
+    sdD = dsn_state(D.state_dict(), 22, 1.0)
+    D.load_state_dict(sdD)
+    m = DSNModel(dict(filter=filt, kernel_size=5, discriminator=arch, w_per=0.0, wgan=True), device=dev)
+    m.load_discriminator_state(sdD)
+    N, crop = 2, 128
+    _, fake, real = dsn_batch(dict(n=N, crop=crop))
+    P = m._plan(N, crop, crop)
+    # the plan's discriminator input = front end of [fake; real]: fill it through the plan's own front-end ops by feeding `fake` as G's output
+    P.g.fake.t.copy_(to_blocked(fake, dev).t)
+    P.real_nchw.copy_(real)
+    P.bic_nchw.copy_(real)
+    # run only the ops behind the generator: everything from the first op after G's forward list
+    P.fwd.run(len(P.g.fwd.ops))
+    r = 0.37
+    P.gp.set_mix(r)
+    P.gp.ops.run()
+    torch.cuda.synchronize()
+    sample = (r * real + (1 - r) * fake).requires_grad_(True)
+    out = D(sample)
+    grad = torch.autograd.grad(out.mean(), sample, create_graph=True)[0]
+    pen = 10 * (grad.norm() - 1) ** 2
+    dparams = [p for p in D.parameters() if p.requires_grad]
+    want = torch.autograd.grad(pen, dparams, allow_unused=True)
+    got_pen = float(P.gp.out3[1])
+    got = m.netD.params.spec
+    errs = []
+    for (k, p), wv in zip([(k, p) for k, p in D.named_parameters() if p.requires_grad], want):
+        o_, shape, n_ = got[k]
+        gv = P.gp.grad[o_:o_ + n_].view(shape).cpu()
+        if wv is None or float(wv.norm()) < 1e-9:
+            assert float(gv.abs().max()) < 1e-6, k
+            continue
+        if k.endswith(('.2.bias', '.5.bias')):   # bias in front of an InstanceNorm: it cancels in the norm, the true gradient is 0 -- rounding noise on both sides
+            assert float(gv.abs().max()) < 1e-4 * max(float(x.abs().max()) for x in want if x is not None), k
+            continue
+        errs.append((rel(gv, wv), k))
+    errs.sort(reverse=True)
+    margins('DSN --wgan gradient penalty (%s front end, %s): value %.6f vs %.6f, ||g|| %.5f; worst weight-gradient rel err %.2e at %s (tol 1e-2)'
+            % (filt, arch, got_pen, float(pen), float(P.gp.out3[0]), errs[0][0], errs[0][1]))
+    assert abs(got_pen - float(pen)) < 2e-4 * abs(float(pen))
+    assert errs[0][0] < 1e-2, errs[:4]

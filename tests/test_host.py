@@ -244,7 +244,8 @@ def test_dsn_cli_flags_and_lr_rule():
     dsn_train.check_supported(o)
     dsn_train.check_supported(dsn_train.build_parser().parse_args(['--ragan']))
     dsn_train.check_supported(dsn_train.build_parser().parse_args(['--norm_layer', 'Batch']))
-    for bad in (['--generator', 'SRGAN'], ['--discriminator', 'nld_s3'], ['--wgan'], ['--norm_layer', 'Batch', '--discriminator', 'nld_s1'], ['--norm_layer', 'Group']):
+    for bad in (['--generator', 'SRGAN'], ['--discriminator', 'nld_s3'], ['--wgan', '--ragan'], ['--wgan', '--norm_layer', 'Batch'],
+                ['--norm_layer', 'Batch', '--discriminator', 'nld_s1'], ['--norm_layer', 'Group']):
         with pytest.raises(NotImplementedError):
             dsn_train.check_supported(dsn_train.build_parser().parse_args(bad))
     # every flag the model acts on reaches its option dict (--disc_freq / --gen_freq were parsed, accepted and then dropped)
@@ -256,6 +257,7 @@ def test_dsn_cli_flags_and_lr_rule():
     model_keys = set(re.findall(r"(\w+)=", dflt)) - {'vgg_seed'}   # (vgg_seed: no CLI flag)
     assert model_keys <= set(mo), model_keys - set(mo)   # every default of the model that a CLI flag backs is forwarded
     dsn_train.check_supported(dsn_train.build_parser().parse_args(['--lpips_rot_flip']))
+    dsn_train.check_supported(dsn_train.build_parser().parse_args(['--wgan']))
     # the 12 (k_rot, flip, flip) draws of loss.py:155-168 map onto the 8 symmetries of the square, identity for (0, F, F)
     codes = {(k, a, b): dsn_model.symmetry_code(k, a, b) for k in (-1, 0, 1) for a in (False, True) for b in (False, True)}
     assert codes[(0, False, False)] == 0 and set(codes.values()) == set(range(8))

@@ -16,7 +16,7 @@ def test_dsn_oracle_matches_reference_fixture(case, golden_dir):
     c = DSN_CASES[case]
     ref = np.load(os.path.join(golden_dir, case + '.npz'))
     G = dsn.GeneratorDSGAN() if c.get('gen') == 'DSGAN' else dsn.DeResnet()
-    D = dsn.Discriminator(c['k'], c['norm'], c['filter'], D_arch=c.get('arch', 'FSD'), cs=c.get('cs', 'cat'))
+    D = dsn.Discriminator(c['k'], c['norm'], c['filter'], D_arch=c.get('arch', 'FSD'), cs=c.get('cs', 'cat'), wgan=bool(c.get('wgan')))
     assert list(G.state_dict().keys()) == list(ref['G_keys'])
     assert list(D.state_dict().keys()) == list(ref['D_keys'])
     G.load_state_dict(dsn_state(G.state_dict(), 21, 0.5))
