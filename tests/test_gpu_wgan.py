@@ -127,3 +127,20 @@ def test_gradient_penalty_value_and_weight_gradients(filt, arch, margins):
             % (filt, arch, got_pen, float(pen), float(P.gp.out3[0]), errs[0][0], errs[0][1]))
     assert abs(got_pen - float(pen)) < 2e-4 * abs(float(pen))
     assert errs[0][0] < 1e-2, errs[:4]
+
+
+def test_dsn_train_cli_with_wgan_and_tensorboard_scalars(tmp_path):
+    """`python -m dasr_amd.dsn_train --wgan ...` end to end: two epochs of three iterations on the synthetic loader, the log carries the gradient penalty, the
+    event file the reference's tags (codes/DSN/train.py:245-270), the checkpoint loads back"""
+    _gpu()
+    import os
+    from dasr_amd import dsn_train, tb_writer
+    save = str(tmp_path / 'dsn_wgan')
+    m = dsn_train.main(['--debug', '--wgan', '--batch_size', '2', '--crop_size', '128', '--filter', 'gau', '--save_path', save, '--save_model_interval', '1',
+                        '--no_per_loss', '--dataset', 'synthetic', '--disc_freq', '1', '--gen_freq', '2'])
+    log = m.get_current_log()
+    assert m.wgan and log['disc_score/gradient_penalty'] > 0 and all(v == v for v in log.values())
+    assert abs(log['loss/d_tex_loss'] - (-log['disc_score/real'] + log['disc_score/fake'] + log['disc_score/gradient_penalty'])) < 1e-4 * abs(log['loss/d_tex_loss'])
+    ev = tb_writer.read_events([os.path.join(save, 'logs', f) for f in os.listdir(os.path.join(save, 'logs'))][0])
+    assert {'loss/d_tex_loss', 'loss/g_tex_loss', 'disc_score/real', 'disc_score/fake', 'disc_score/gradient_penalty'} <= set(t for _, t, _ in ev)
+    assert os.path.exists(os.path.join(save, 'checkpoints', 'last_iteration.tar'))
