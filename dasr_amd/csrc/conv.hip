@@ -1031,8 +1031,11 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
         const int us = (a_remap >> 8) & 1;   // nearest x2: the conv runs on the (2 Hin) x (2 Win) grid, the source pixel is (gy >> 1, gx >> 1)
         const bool ok = (pp < C::NPIX) & (gy >= 0) & (gy < (a_Hin << us)) & (gx >= 0) & (gx < (a_Win << us));  // bitwise: keeps the prologue one basic block
         goff[r] = ok ? (unsigned)((((gy >> us) * a_Win + (gx >> us)) * 16 + 8 * h) * 2) : OOB;
+        // ABL bit 6: every workgroup reads its activations from the first 256 KB of image 0's planes (cache-resident after the first touch): the
+        // instruction stream, the LDS-DMA count and the output traffic are unchanged, the fabric (MALL / HBM) read traffic is gone
+        if constexpr ((ABL & 64) != 0) goff[r] = ok ? (goff[r] & 0x3ffffu) : OOB;
     }
-    const __amdgpu_buffer_rsrc_t rin = make_rsrc((const bf16_t*)a_in + (size_t)n * a_nstr);
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc((const bf16_t*)a_in + ((ABL & 64) ? (size_t)0 : (size_t)n * a_nstr));
     const unsigned in_chunk_bytes = (unsigned)(a_cbstr * 2);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc((const bf16_t*)a_w + (size_t)mg * nchunks * 9 * MT * 512);
     constexpr int NP = C::AR + C::WR;
@@ -1145,7 +1148,7 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
     // (profiles/r03_conv_ablation.txt).  The residual is fetched HERE instead, straight into the accumulator registers -- all 32 loads of a wave
     // (128 KB per workgroup) in flight behind the DMA of chunk 0 -- and the MFMAs accumulate on top of (beta1 / alpha) * x; the epilogue only
     // scales by alpha and stores.  fp32 throughout: alpha * ((beta1 / alpha) x + conv) differs from alpha * conv + beta1 * x by ~1e-7 relative.
-    constexpr bool R1_PRE = MT == 2 && EPI != 0 && (EPI & 8) && !ABL && RING == 0;
+    constexpr bool R1_PRE = MT == 2 && EPI != 0 && (EPI & 8) && !(ABL & 63) && RING == 0;
     if constexpr (R1_PRE) {
         const __amdgpu_buffer_rsrc_t rr1 = make_rsrc((const float*)p.res1.p + (size_t)n * p.res1.n_stride);
         const unsigned r1_cb = (unsigned)p.res1.cb_stride;
@@ -1191,7 +1194,7 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
     }
     TRACE_STAMP(2);
 
-    constexpr bool PRE = EPI == 68 && MT == 1 && !ABL && RING < 2;   // (the loader-wave form runs three waves per SIMD: no registers left for the prefetched mask)
+    constexpr bool PRE = EPI == 68 && MT == 1 && !(ABL & 63) && RING < 2;   // (the loader-wave form runs three waves per SIMD: no registers left for the prefetched mask)
     MaskPre<NT * MT> mpre;
     bf16x8 fb[2][6], fa[2][MT];
     int aslot = 0;   // RING: activation image of the current chunk (ck % 3)
@@ -1656,6 +1659,11 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                 case 115: return launch_glds<1, 67, 4, 15>(p, s);
                 case 116: return launch_glds<1, 67, 4, 16>(p, s);   // barrier per chunk, no DMA wait
                 case 117: return launch_glds<1, 67, 4, 17>(p, s);   // no DMA in the loop, no wait, barrier kept
+                case 164:   // activations read from a cache-resident 256 KB window (round 4: is the fabric read traffic what bounds these launches?)
+                    switch (classify_epi(p)) {
+                        case 68: return launch_glds<1, 68, 4, 64>(p, s);
+                        default: return launch_glds<1, 67, 4, 64>(p, s);
+                    }
                 case 15:   // RING: three activation images + two weight images, counted vmcnt (round 3)
                     switch (g_tune_epi ? classify_epi(p) : 0) {
                         case 67: return launch_glds<1, 67, 4, 0, false, 1>(p, s);
@@ -1711,6 +1719,21 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                         case 232: return launch<1, false, 2, 3, 1, 4, 1, false, 0, 232>(p, s);
                         case 248: return launch<1, false, 2, 3, 1, 4, 1, false, 0, 248>(p, s);
                         default: return launch<1, false, 2, 3, 1, 4>(p, s);
+                    }
+                case 164:
+                    if ((long long)p.N * ((p.Hout + 15) / 16) * ((p.Wout + 31) / 32) * ((p.cout + 63) / 64) > 256) {
+                        switch (classify_epi(p)) {
+                            case 249: return launch_glds<2, 249, 4, 64>(p, s);
+                            case 232: return launch_glds<2, 232, 4, 64>(p, s);
+                            case 248: return launch_glds<2, 248, 4, 64>(p, s);
+                            default: return launch_glds<2, 233, 4, 64>(p, s);
+                        }
+                    }
+                    switch (classify_epi(p)) {
+                        case 249: return launch_glds<2, 249, 8, 64>(p, s);
+                        case 232: return launch_glds<2, 232, 8, 64>(p, s);
+                        case 248: return launch_glds<2, 248, 8, 64>(p, s);
+                        default: return launch_glds<2, 233, 8, 64>(p, s);
                     }
                 default: break;
             }
