@@ -447,6 +447,34 @@ def bench_srn(a, dp, dasr, as_secondary=False):
             out['roofline'] = secondary_roofline(one_step, len(getattr(model, '_out_plans', None) or [0]), 'dasr_lpips' if a.fea == 'LPIPS' else 'dasr_vgg')
         else:
             one_step()
+    if not as_secondary and not dasr and world == 1 and full and not a.no_secondary:
+        # The same production step (same plans, launches and bytes) on ALL-ZERO operands: what the data-dependent shader clock costs on this box
+        # (profiles/r04_zero_data.txt).  Reported beside the measurement, never as `value`.
+        P = model.netG.params
+        saved = (P.flat.clone(), P.m.clone(), P.v.clone())
+        kept = dict(data)
+        try:
+            for k in data:
+                data[k] = torch.zeros_like(kept[k])
+            P.flat.zero_(); P.m.zero_(); P.v.zero_()
+            model.netG.repack()
+            one_step()
+            one_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                one_step()
+            torch.cuda.synchronize()
+            ms0 = (time.perf_counter() - t0) / 4 * 1e3
+            out['roofline']['zero_operand_step'] = {
+                'ms_per_step': round(ms0, 2), 'mfma_util_step': round(batch * TFLOP_PER_IMAGE_TRAIN / (ms0 / 1e3) / PEAK_BF16_TFLOPS, 4),
+                'note': 'same launches and bytes, every weight and image zero: no operand toggling, the shader clock holds; the difference to '
+                        'ms_per_step is the data-dependent clock, not code'}
+        finally:
+            data.update(kept)
+            P.flat.copy_(saved[0]); P.m.copy_(saved[1]); P.v.copy_(saved[2])
+            model.netG.repack()
+            del saved
     if not as_secondary and not dasr and streams_default() > 1 and not a.no_secondary:
         # (skipped with --no-secondary = the rocprofv3 / PMC runs, so profiles/*.csv hold launches of the production schedule only)
         # the same step with ONE stream (every launch covers the whole per-GPU batch and has the chip to itself): the per-launch rates of

@@ -1720,21 +1720,6 @@ extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {
                         case 248: return launch<1, false, 2, 3, 1, 4, 1, false, 0, 248>(p, s);
                         default: return launch<1, false, 2, 3, 1, 4>(p, s);
                     }
-                case 164:
-                    if ((long long)p.N * ((p.Hout + 15) / 16) * ((p.Wout + 31) / 32) * ((p.cout + 63) / 64) > 256) {
-                        switch (classify_epi(p)) {
-                            case 249: return launch_glds<2, 249, 4, 64>(p, s);
-                            case 232: return launch_glds<2, 232, 4, 64>(p, s);
-                            case 248: return launch_glds<2, 248, 4, 64>(p, s);
-                            default: return launch_glds<2, 233, 4, 64>(p, s);
-                        }
-                    }
-                    switch (classify_epi(p)) {
-                        case 249: return launch_glds<2, 249, 8, 64>(p, s);
-                        case 232: return launch_glds<2, 232, 8, 64>(p, s);
-                        case 248: return launch_glds<2, 248, 8, 64>(p, s);
-                        default: return launch_glds<2, 233, 8, 64>(p, s);
-                    }
                 default: break;
             }
 #endif
