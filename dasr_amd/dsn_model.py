@@ -613,6 +613,103 @@ class DSNModel:
         P.ops.run()
         return P.dout.nchw(1), P.ddm.nchw(1)
 
+    # ---- validation pass of the training driver (codes/DSN/train.py:293-355) ----
+    def generate(self, img):
+        """forward-only generator pass: img [n,3,H,W] in [0,1] -> fake [n,3,H/4,W/4] (DSGAN generator: same size); the result lives in the plan
+        (valid until the next call).  Plans of the last two image shapes are kept: validation folders mix sizes."""
+        n, _, H, W = img.shape
+        key = ('gen', n, H, W)
+        lru = self.__dict__.setdefault('_gen_lru', OrderedDict())
+        if key in lru:
+            lru.move_to_end(key)
+        else:
+            gp = self.netG.plan(n, H, W)
+            ops = OpList()
+            ops.extend(gp.fwd)
+            lru[key] = (ops, gp)
+            while len(lru) > 2:
+                old, (_, gp_old) = lru.popitem(last=False)
+                if not any(getattr(P, 'g', None) is gp_old for P in self._plans.values()):   # (a training / inference plan of that shape keeps it)
+                    self.netG.plans.pop((old[1], old[2], old[3]), None)
+        ops, gp = lru[key]
+        gp.x_nchw.copy_(img)
+        ops.run()
+        return gp.fake_nchw
+
+    def _colour_filter(self, x):
+        """GeneratorLoss.color_filter (loss.py:50-58,103-107): FilterLow(padding=False) for gau / avg_pool, Haar LL * 0.5 for wavelet"""
+        import torch.nn.functional as F
+        if self.filter == 'wavelet':   # DWTForward(J=1, 'haar', mode='reflect'): an odd side is extended by one mirrored sample; LL * 0.5 = 2x2 mean
+            x = F.pad(x, (0, x.shape[3] % 2, 0, x.shape[2] % 2), mode='reflect')
+            return F.avg_pool2d(x, 2)
+        return F.conv2d(x, self.fw.view(1, 1, self.k, self.k).expand(3, 1, self.k, self.k), groups=3)
+
+    def perceptual_distance(self, x, y):
+        """g_loss_module.perceptual_loss(x, y) without gradient: LPIPS(alex)(x, y, normalize=True).mean() or MSE of the VGG16 features (loss.py:108-130)
+        on the HIP networks; nan when the model was built without a perceptual net (w_per = 0)."""
+        if self.netF is None:
+            return torch.full((), float('nan'), device=self.device)
+        n, _, h, w = x.shape
+        if self.opt['per_type'] == 'LPIPS':
+            if h % 4 or w % 4:   # the stride-4 first conv runs as a space-to-depth conv on this path: whole 4x4 cells only
+                if not self.__dict__.get('_warned_lpips_crop'):
+                    logger.warning('validation LPIPS: %dx%d image centre-cropped to multiples of 4', h, w)
+                    self._warned_lpips_crop = True
+                h4, w4 = h // 4 * 4, w // 4 * 4
+                y0, x0 = (h - h4) // 2, (w - w4) // 2
+                x, y = x[..., y0:y0 + h4, x0:x0 + w4], y[..., y0:y0 + h4, x0:x0 + w4]
+            return self.netF.distance(x.contiguous(), y.contiguous())
+        key = ('valper', n, h, w)
+        lru = self.__dict__.setdefault('_valper_lru', OrderedDict())
+        if key in lru:
+            lru.move_to_end(key)
+        else:
+            v = self.netF.plan(2 * n, 2 * n, h, w)
+            nchw = torch.zeros((2 * n, 3, h, w), dtype=torch.float32, device=self.device)
+            img = BTensor(2 * n, 16, h, w, True, self.device)
+            ops = OpList()
+            o = _op(_lib.OP_NCHW2B)
+            o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[0], o.t[1] = nchw.data_ptr(), 2 * n, 3, h, w, img.view(), NULL_T
+            ops.add(o)
+            ops.add(v.input_copy_op(img.view(), 0, 2 * n, h, w))
+            ops.extend(v.fwd)
+            ops.keep += [v, nchw, img]
+            lru[key] = (ops, nchw, v)
+            while len(lru) > 2:
+                old, _ = lru.popitem(last=False)
+                self.netF.plans.pop((2 * old[1], 2 * old[1], old[2], old[3]), None)
+        ops, nchw, v = lru[key]
+        nchw[:n].copy_(x)
+        nchw[n:].copy_(y)
+        ops.run()
+        f = v.feat.nchw()
+        return torch.mean((f[:n] - f[n:]) ** 2)
+
+    def validation_metrics(self, fake, target):
+        """the six per-image validation terms of train.py:313-321 for fake = clamp(G(input), 0, 1) against the paired LR image: mse, psnr,
+        rgb_loss (L1 of the per-channel means), mean_loss (L1 of the image means), perceptual_loss, color_loss -- device scalars"""
+        import torch.nn.functional as F
+        mse = ((fake - target) ** 2).mean()
+        return OrderedDict([
+            ('mse', mse), ('psnr', -10 * torch.log10(mse)),
+            ('rgb_error', F.l1_loss(fake.mean(3).mean(2), target.mean(3).mean(2))),
+            ('mean_error', F.l1_loss(fake.reshape(fake.shape[0], -1).mean(1), target.reshape(target.shape[0], -1).mean(1))),
+            ('perceptual_error', self.perceptual_distance(fake, target)),
+            ('color_error', F.l1_loss(self._colour_filter(fake), self._colour_filter(target)))])
+
+    def filter_low(self, x):
+        """model.FilterLow(kernel_size, gaussian = filter == 'gau', include_pad=False) of the validation image strips (train.py:141): same-size low-pass
+        (zero padding; the box average counts only the pixels inside)"""
+        import torch.nn.functional as F
+        k, p = self.k, (self.k - 1) // 2
+        if self.filter == 'gau':
+            return F.conv2d(x, self.fw.view(1, 1, k, k).expand(3, 1, k, k), padding=p, groups=3)
+        return F.avg_pool2d(x, k, stride=1, padding=p, count_include_pad=False)
+
+    def filter_high(self, x):
+        """model.FilterHigh(..., normalize=True): 0.5 + 0.5 (x - low(x)) (train.py:142)"""
+        return 0.5 + 0.5 * (x - self.filter_low(x))
+
     def check_finite(self):
         self.opt_g.check_finite('DSN generator')
         self.opt_d.check_finite('DSN discriminator')

@@ -6,9 +6,12 @@ DSNModel.iteration(hr, bicubic_lr, real_lr); schedulers step once per epoch (tra
 <save_path>/checkpoints/iteration_<n>.tar and last_iteration.tar.  Accepted-but-unsupported choices fail the way the
 reference does for unknown strings (NotImplementedError): --wgan with --ragan or --norm_layer Batch, --norm_layer Batch with the nld discriminators.  --ragan is supported, also under data parallelism (the batch means are all-reduced between the loss stages).  --per_type LPIPS (the reference
 default) runs LPIPS(alex) with weights from --lpips_alexnet / --lpips_lin, --per_type VGG with --vgg_path; the pretrained files cannot be
-downloaded offline, a missing file is an error unless --allow_random_perceptual opts into a seeded random network.  Data: the PIL/torchvision loaders
-(data_loader.py) stay on the reference's side of the boundary; any iterable of (hr, bicubic_lr, real_lr) tuples works, and
-`--dataset synthetic` ships fixed-seed random crops for benchmarks and tests.
+downloaded offline, a missing file is an error unless --allow_random_perceptual opts into a seeded random network.  Data: `--dataset aim2019 |
+ntire2020 | realsr | camerasr` read the image folders `--paths` (the reference's codes/paths.yml, train.py:82-83) names for `--artifacts`, through
+dasr_amd.dsn_data (the reference's Train_/Val_Deresnet_Dataset on PIL tensors, no torchvision); any iterable of (hr, bicubic_lr, real_lr) tuples
+passed to main(loader=, val_loader=) works too, and `--dataset synthetic` ships fixed-seed random crops for benchmarks and tests.  Every
+`val_interval` epochs the validation pass of train.py:293-355 runs over the paired validation folders (mse, psnr, rgb / mean / perceptual / colour
+errors as `val/*` scalars), every `val_img_interval` epochs it also writes the `val/target_fake_crop_low_high_<i>` image strips.
 """
 import argparse
 import json
@@ -36,7 +39,8 @@ def build_parser():
     p.add_argument('--val_img_interval', default=5, type=int)
     p.add_argument('--save_model_interval', default=5, type=int)
     p.add_argument('--artifacts', default='tdsr', type=str)
-    p.add_argument('--dataset', default='df2k', type=str)   # reference default (train.py:38); only 'synthetic' is built in: anything else needs a loader
+    p.add_argument('--dataset', default='df2k', type=str)   # reference default (train.py:38), which its own loop cannot unpack; built in: the four
+    #                                                          Train_Deresnet_Dataset branches (aim2019, ntire2020, realsr, camerasr) and 'synthetic'
     p.add_argument('--flips', dest='flips', action='store_true')
     p.add_argument('--rotations', dest='rotations', action='store_true')
     p.add_argument('--num_res_blocks', default=8, type=int)
@@ -63,6 +67,7 @@ def build_parser():
     p.add_argument('--debug', dest='debug', action='store_true')
     # additions of this build
     p.add_argument('--iters_per_epoch', default=100, type=int, help='synthetic dataset: iterations per epoch')
+    p.add_argument('--paths', default='../paths.yml', type=str, help="yaml file with the dataset folders (the reference reads '../paths.yml', train.py:82)")
     p.add_argument('--vgg_path', default=None, type=str, help='torchvision vgg16 state_dict for --per_type VGG')
     p.add_argument('--lpips_alexnet', default=None, type=str, help='torchvision alexnet state_dict for --per_type LPIPS')
     p.add_argument('--lpips_lin', default=None, type=str, help="the reference's codes/PerceptualSimilarity/models/weights/v0.1/alex.pth")
@@ -73,9 +78,10 @@ def build_parser():
 
 def check_supported(o, have_loader=True):
     """everything that cannot run is refused HERE, before any model is built or any parameter is broadcast"""
-    if not have_loader and o.dataset != 'synthetic':
-        raise NotImplementedError('dataset [%s]: pass a loader of (hr, bicubic_lr, real_lr) batches to main(); only "synthetic" is built in '
-                                  '(the PIL / torchvision loaders of the reference stay on its side of the boundary)' % o.dataset)
+    from .dsn_data import DERESNET_DATASETS
+    if not have_loader and o.dataset != 'synthetic' and o.dataset not in DERESNET_DATASETS:
+        raise NotImplementedError("dataset [%s]: built in are aim2019 / ntire2020 / realsr / camerasr (image folders from --paths, the reference's "
+                                  "Train_Deresnet_Dataset branches) and 'synthetic'; or pass a loader of (hr, bicubic_lr, real_lr) batches to main()" % o.dataset)
     if o.generator not in ('DeResnet', 'DSGAN'):
         raise NotImplementedError('Generator model [{:s}] not recognized'.format(o.generator))
     if o.discriminator.lower() not in ('fsd', 'nld_s1', 'nld_s2'):
@@ -113,7 +119,42 @@ def model_options(o):
                 cat_or_sum=o.cat_or_sum, disc_freq=o.disc_freq, gen_freq=o.gen_freq, lpips_rot_flip=o.lpips_rot_flip, wgan=o.wgan)   # train.py:55-56, 229, 251
 
 
-def main(argv=None, loader=None):
+def validate(model, val_loader, o, tb, epoch, log):
+    """train.py:293-355: every validation pair through the generator (clamped to [0, 1]); mse / psnr / rgb / mean / perceptual / colour errors
+    averaged over the set as `val/*` scalars; on `val_img_interval` epochs strips of (target, fake, random LR crop, low-pass, high-pass of the fake)
+    in the reference's 400 x 400 display transform, five validation images per grid"""
+    from .dsn_data import display_transform
+    from .util import make_grid
+    dev = model.device
+    with_images = epoch % o.val_img_interval == 0 and epoch != 0
+    sums, count, strips = None, 0, []
+    for hr, bic, disc, target in val_loader:
+        inp = bic if o.generator == 'DSGAN' else hr
+        fake = model.generate(inp.to(dev)).clamp(0, 1)
+        target = target.to(dev)
+        m = model.validation_metrics(fake, target)
+        vals = torch.stack([v.float() for v in m.values()])
+        sums = vals if sums is None else sums + vals
+        keys = list(m.keys())
+        count += 1
+        if with_images:
+            strips += [display_transform(t[0]) for t in (target, fake, disc, model.filter_low(fake), model.filter_high(fake))]
+    if not count:
+        return {}
+    avg = dict(zip(keys, (sums / count).tolist()))   # one host sync per validation pass
+    log.info('[validation] epoch %d iter %d ' % (epoch, model.iteration_count) + ' '.join('%s: %.4e' % kv for kv in avg.items()))
+    if tb is not None:
+        for k, v in avg.items():
+            tb.add_scalar('val/' + k, v, model.iteration_count)
+        if with_images:
+            per_grid = 5 * 5   # n_val_images (the five views) x 5 validation images per grid (train.py:347-353)
+            for index in range(max(1, len(strips) // per_grid)):
+                chunk = strips[index * per_grid:(index + 1) * per_grid] if len(strips) >= per_grid else strips
+                tb.add_image('val/target_fake_crop_low_high_' + str(index), make_grid(torch.stack(chunk), nrow=5, padding=5), model.iteration_count)
+    return avg
+
+
+def main(argv=None, loader=None, val_loader=None):
     o = build_parser().parse_args(argv)
     check_supported(o, have_loader=loader is not None)
     logging.basicConfig(level=logging.INFO, format='%(asctime)s %(message)s')
@@ -121,6 +162,7 @@ def main(argv=None, loader=None):
     torch.manual_seed(0)  # train.py:76
     dp = DataParallelGroup() if int(os.environ.get('WORLD_SIZE', '1')) > 1 else None
     rank = dp.rank if dp else 0
+    world = dp.world if dp else 1
     if dp:
         torch.cuda.set_device(dp.device_index)
     if o.debug:
@@ -137,9 +179,14 @@ def main(argv=None, loader=None):
         model.load(o.checkpoint)
         start_epoch = model.epoch + 1
         log.info('Continuing training at epoch %d' % start_epoch)
-    if loader is None:
-        per_rank = o.batch_size // (dp.world if dp else 1)
-        loader = SyntheticCrops(per_rank, o.crop_size, o.iters_per_epoch, seed=1234 + rank)
+    if loader is None and o.dataset == 'synthetic':
+        loader = SyntheticCrops(o.batch_size // world, o.crop_size, o.iters_per_epoch, seed=1234 + rank)
+    elif loader is None:   # train.py:81-115: image folders from paths.yml
+        from . import dsn_data
+        train_set, val_set = dsn_data.make_datasets(o, dsn_data.load_paths(o.paths))
+        loader = dsn_data.make_loader(train_set, o.batch_size, True, o.num_workers, seed=0, rank=rank, world=world)
+        if val_loader is None:
+            val_loader = dsn_data.make_loader(val_set, 1, False, min(1, o.num_workers))
     save_path = o.save_path or os.path.join('experiments', 'dsn_' + o.filter)
     if o.saving and rank == 0:
         os.makedirs(os.path.join(save_path, 'checkpoints'), exist_ok=True)
@@ -163,6 +210,9 @@ def main(argv=None, loader=None):
             if tb is not None:
                 for k, v in lg.items():
                     tb.add_scalar(k, v, model.iteration_count)
+                tb.add_scalar('param/learning_rate', model.lr(), epoch)   # train.py:289-290
+            if val_loader is not None and (epoch % o.val_interval == 0 or epoch % o.val_img_interval == 0):
+                validate(model, val_loader, o, tb, epoch, log)
             if o.saving and epoch % o.save_model_interval == 0:
                 model.save(os.path.join(save_path, 'checkpoints', 'iteration_{}.tar'.format(model.iteration_count)))
                 model.save(os.path.join(save_path, 'checkpoints', 'last_iteration.tar'))

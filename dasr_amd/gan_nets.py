@@ -504,6 +504,9 @@ class VGGFeatureHIP:
     def plan(self, N, n_g, H, W):
         k = (N, n_g, H, W)
         if k not in self.plans:
+            npool = sum(1 for L in self.layers if L[0] != 'conv')
+            if (H >> npool) < 1 or (W >> npool) < 1:   # (torch raises "Output size is too small" from the pool that would produce an empty map)
+                raise ValueError('images of %dx%d are too small for this feature extractor: %d 2x2 max-pools need at least %d pixels per side' % (H, W, npool, 1 << npool))
             self.plans[k] = _VGGPlan(self, N, n_g, H, W)
         return self.plans[k]
 
