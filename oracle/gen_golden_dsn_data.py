@@ -11,7 +11,7 @@ import torch
 from .ref_import import _mod
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
-CASES = [((3, 64, 64), 0.25, True), ((3, 40, 52), 0.25, True), ((3, 37, 53), 0.25, True), ((3, 32, 48), 0.5, True), ((3, 256, 256), 0.25, True),
+CASES = [((3, 64, 64), 0.25, True), ((3, 40, 52), 0.25, True), ((3, 37, 53), 0.25, True), ((3, 32, 48), 0.5, True), ((3, 96, 128), 0.25, True),
          ((3, 16, 12), 2.0, True), ((3, 21, 10), 4.0, True)]   # (antialiasing=False trips over an empty mirror patch in the reference: not a case its datasets use)
 
 
