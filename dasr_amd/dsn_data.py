@@ -107,22 +107,11 @@ def center_crop(img, size):
     return img[:, y:y + size, x:x + size]
 
 
-def _augment(img, crop_size, flips, rotations):
-    """RandomVerticalFlip, RandomHorizontalFlip (p = 0.5 when `flips`), RandomCrop(crop_size), then a quarter-turn by a random multiple of 90
-    degrees when `rotations` (TF.rotate of the square crop, counter-clockwise): data_loader.py:27-31,43-47"""
-    if flips and random.random() < 0.5:
-        img = img.flip(1)
-    if flips and random.random() < 0.5:
-        img = img.flip(2)
-    img = random_crop(img, crop_size)
-    if rotations:
-        img = torch.rot90(img, random.choice([0, 1, 2, 3]), (1, 2))
-    return img
-
-
 def load_augmented_crop(path, crop_size, flips, rotations):
-    """_augment(open_image(path), ...) without converting the whole image to floats: the crop window is cut from the decoded 8-bit image first and
-    the flips are applied to the crop (a uniformly random window of the flipped image = the flip of a uniformly random window)"""
+    """RandomVerticalFlip, RandomHorizontalFlip (p = 0.5 when `flips`), RandomCrop(crop_size), then a quarter-turn by a random multiple of 90 degrees
+    when `rotations` (TF.rotate of the square crop, counter-clockwise): data_loader.py:27-31,43-47 -- without converting the whole image to floats:
+    the crop window is cut from the decoded 8-bit image first and the flips are applied to the crop (a uniformly random window of the flipped
+    image = the flip of a uniformly random window)"""
     from PIL import Image
     with Image.open(path) as im:
         w, h = im.size
