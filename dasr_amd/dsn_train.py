@@ -147,10 +147,9 @@ def validate(model, val_loader, o, tb, epoch, log):
         for k, v in avg.items():
             tb.add_scalar('val/' + k, v, model.iteration_count)
         if with_images:
-            per_grid = 5 * 5   # n_val_images (the five views) x 5 validation images per grid (train.py:347-353)
-            for index in range(max(1, len(strips) // per_grid)):
-                chunk = strips[index * per_grid:(index + 1) * per_grid] if len(strips) >= per_grid else strips
-                tb.add_image('val/target_fake_crop_low_high_' + str(index), make_grid(torch.stack(chunk), nrow=5, padding=5), model.iteration_count)
+            per_grid = 5 * 5   # n_val_images (the five views) x 5 validation images per grid: torch.chunk(all, count // 25) as train.py:347-353 has it
+            for index, chunk in enumerate(torch.chunk(torch.stack(strips), max(1, len(strips) // per_grid))):   # (fewer than five images: one grid)
+                tb.add_image('val/target_fake_crop_low_high_' + str(index), make_grid(chunk, nrow=5, padding=5), model.iteration_count)
     return avg
 
 
