@@ -475,8 +475,8 @@ def bench_srn(a, dp, dasr, as_secondary=False):
             P.flat.copy_(saved[0]); P.m.copy_(saved[1]); P.v.copy_(saved[2])
             model.netG.repack()
             del saved
-    if not as_secondary and not dasr and streams_default() > 1 and not a.no_secondary:
-        # (skipped with --no-secondary = the rocprofv3 / PMC runs, so profiles/*.csv hold launches of the production schedule only)
+    if not as_secondary and not dasr and streams_default() > 1 and len(getattr(model, '_out_plans', None) or [0]) > 1 and not a.no_secondary:
+        # (only when the production schedule runs sub-batch streams: the chained-trunk schedule is single-stream already; skipped with --no-secondary = the rocprofv3 / PMC runs, so profiles/*.csv hold launches of the production schedule only)
         # the same step with ONE stream (every launch covers the whole per-GPU batch and has the chip to itself): the per-launch rates of
         # the kernels without the overlap of the sub-batch streams.  Not the production schedule: reported beside it, never as `value`.
         os.environ['DASR_STREAMS'] = '1'

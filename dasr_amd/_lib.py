@@ -69,9 +69,11 @@ OP_LPIPS_S2D, OP_MAXPOOL3, OP_MAXPOOL3_BWD, OP_LPIPS_HEAD, OP_RAGAN = 35, 36, 37
 OP_BNORM_FWD, OP_BNORM_BWD, OP_BNORM_RUNNING = 40, 41, 42
 OP_DDM_SPREAD = 43
 OP_INORM_JVP, OP_INORM_SECOND, OP_GRAD_PENALTY, OP_FILL_SCALED = 44, 45, 46, 47
+OP_CONV_CHAIN = 48
 
 _SIGS = {
     'dasr_conv': [C.POINTER(ConvParams), c_vp],
+    'dasr_conv_chain': [c_vp, C.POINTER(ConvParams), c_vp, c_i32, c_vp, c_vp, c_vp],
     'dasr_conv_naive': [C.POINTER(ConvParams), c_vp, c_vp],
     'dasr_set_tuning': [c_i32, c_i32],
     'dasr_wgrad': [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
@@ -148,7 +150,7 @@ _BENCH_SIGS = {
 }
 BENCH_LIB_PATH = os.path.join(HERE, 'libdasr_bench.so')
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 _lib = None
 _bench = None
 

@@ -107,7 +107,7 @@ __device__ __forceinline__ void st128(u32x4 v, __amdgpu_buffer_rsrc_t r, unsigne
 
 // F16OUT: -1 = the 16-bit output format is a run-time (wave-uniform) choice; 0 / 1 = bf16 / f16 fixed at compile time (the dense-block LDS-DMA
 // kernels: the run-time form converted every element to BOTH formats and selected: 224 of the 628 VALU instructions of the Cout=32 epilogue)
-template <bool IN_F32, int MT, int NT, int STRIDE, int EPI, int F16OUT = -1, bool PRE = false>
+template <bool IN_F32, int MT, int NT, int STRIDE, int EPI, int F16OUT = -1, bool PRE = false, bool FSC1 = false>
 __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 (&acc)[MT][NT], char* smem, float bias_reg, int tid, int mg, int n,
                                               int oy0, int ox0, const MaskPre<NT * MT>* pre = nullptr) {
     const int lane = tid & 63, wave = tid >> 6, nn = lane & 31, kh2 = lane >> 5;
@@ -138,7 +138,7 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
     const __amdgpu_buffer_rsrc_t rob = make_rsrc((bf16_t*)p.out_bf16.p + (size_t)n * p.out_bf16.n_stride);
     const unsigned mask_cb = (unsigned)p.mask.cb_stride, r1_cb = (unsigned)p.res1.cb_stride, r2_cb = (unsigned)p.res2.cb_stride;
     const unsigned of_cb = (unsigned)p.out_f32.cb_stride, ob_cb = (unsigned)p.out_bf16.cb_stride;
-    constexpr bool SC1 = MT == 1 && !IN_F32 && F16OUT == 0;   // bf16 dense-block convs with Cout = 32 (st128)
+    constexpr bool SC1 = FSC1 || (MT == 1 && !IN_F32 && F16OUT == 0);   // bf16 dense-block convs with Cout = 32 (st128); FSC1: every store of a chained layer (conv_chain_kernel)
     // split 16-bit output: the remainder goes lo_pl planes further (wave-uniform; 0 = plain).  The specialised bf16 epilogues (dense blocks) do not
     // carry the branch: classify_epi sends a bf16 split output to the generic epilogue
     const unsigned lo_pl = (G || F16OUT != 0) ? (unsigned)p.out16_lo : 0u;
@@ -1309,6 +1309,234 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
 }
 
 // ---------------------------------------------------------------------------------------------------
+// conv_chain_kernel (round 4): a CHAIN of dense-block convs in ONE persistent launch -- the forward trunk of the generator
+// (conv1-4 + conv5 of every RDB, 5 x 3 x nb layers of the same geometry) without a kernel boundary between layers.
+//
+// What a boundary costs per layer (profiles/r04_kernel_budget.txt: ~10 us of non-MFMA time in a 20 us Cout-32 launch): kernel end / start
+// (1.7 us), workgroup ramp (1.5 us), the argument round trip and the first DMA round trip (2 us), all of it with the matrix cores idle.
+// Round 2 measured that replacing the boundary by neighbour flags costs the same ~3 us per stage WHEN THE WAIT IS EXPOSED
+// (profiles/r02i_micro_sync.txt).  In a dense block it need not be: layer L reads planes [0, cin/16) of the slab, of which only the LAST
+// cout(L-1)/16 planes come from layer L-1 -- everything before is at least two layers old and final.  A workgroup therefore starts layer L
+// immediately on the old planes and looks at its neighbours' flags only before it requests the first chunk that holds layer L-1's output
+// (dep_chunk): 2-8 chunks = 5-20 us after it published its own flag.  Only conv1 of an RDB (all 64 input channels come from the previous
+// conv5) waits up front.
+//
+// Coherence.  Workgroup b is dispatched to XCD b % 8 (checked against HW_REG_XCC_ID, err bit 2); all tiles of image n are given to workgroups of
+// XCD n % 8, so every halo a tile reads was written by a CU of its own XCD and the XCD's L2 is the coherence point (the per-XCD L2s are not
+// coherent with each other without agent-scope fences that cost 30-70 us per use).  Data stores and the flag store are write-through (sc1: with
+// plain stores a few lines per 10^4 were not yet in the L2 when vmcnt(0) returned); flag polls bypass the vector L1 (sc0 sc1); halo data is
+// first touched after the flag (the L1 was invalidated at kernel start, a 128-byte L1 line never spans two tiles: tiles are 32 pixels = 1 KiB
+// wide per plane row).
+// Co-residency: every workgroup of the launch must be resident (a waiting tile spins): grid <= 2 workgroups x 256 CUs, checked by the launcher;
+// a spin gives up after ~1 s and sets err bit 1 (the results are then wrong, the launch still ends).
+// ---------------------------------------------------------------------------------------------------
+struct ChainSync {
+    __amdgpu_buffer_rsrc_t rflags;
+    int* err;
+    unsigned f0;          // this launch's stage base: flag value every tile of the launch starts with
+    int base, ty, tx, tiles_y, tiles_x;
+
+    // layer `layer` may read the outputs of layer - 1 in the halo: the eight neighbours have published f0 + layer
+    __device__ __forceinline__ void wait(int layer, int tid) const {
+        if (layer > 0) {
+            if (tid < 9 && tid != 4) {
+                const int y = ty + tid / 3 - 1, x = tx + tid % 3 - 1;
+                if ((y >= 0) & (y < tiles_y) & (x >= 0) & (x < tiles_x)) {
+                    const unsigned off = (unsigned)(base + y * tiles_x + x) * 4u, target = f0 + (unsigned)layer;
+                    int spins = 0;
+                    while ((int)(__builtin_amdgcn_raw_buffer_load_b32(rflags, off, 0, 17) - target) < 0) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1 << 21)) {
+                            atomicOr(err, 2);
+                            break;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // every store of this tile's layer has been acknowledged; then the flag
+    __device__ __forceinline__ void publish(int layer, int tid) const {
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        if (tid == 0) __builtin_amdgcn_raw_buffer_store_b32(f0 + (unsigned)layer + 1u, rflags, (unsigned)(base + ty * tiles_x + tx) * 4u, 0, 16);
+    }
+};
+
+template <int MT, int EPI, bool F16>
+__device__ __forceinline__ void chain_layer(const dasr_conv_params& p, char* smem, const int tid, const int n, const int oy0, const int ox0,
+                                            const unsigned (&goff)[GCfg<1, 4>::AR], const int dep_chunk, const ChainSync& cs, const int layer) {
+    using C = GCfg<MT, 4>;
+    constexpr int NT = C::NT, NW = 4;
+    static_assert(GCfg<1, 4>::AR == GCfg<2, 4>::AR, "the activation pieces do not depend on MT");
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchunks = p.cin >> 4;
+    float bias_reg;
+    {
+        const unsigned bo = ((p.bias != nullptr) & (tid < 32 * MT)) ? (unsigned)tid * 4u : OOB;
+        bias_reg = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(p.bias), bo, 0, 0));
+    }
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc((const bf16_t*)p.in.p + (size_t)n * p.in.n_stride);
+    const unsigned in_chunk_bytes = (unsigned)(p.in.cb_stride * 2);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w);
+    constexpr int NP = C::AR + C::WR;
+    if (dep_chunk <= 0) cs.wait(layer, tid);   // every input plane comes from the previous layer (conv1 of an RDB reads the previous conv5's shadow)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) glds_dma_piece<MT, NW>(i, 0, smem, rin, rw, goff, in_chunk_bytes, wave, tid, 0);
+    const int nn = lane & 31, kh2 = lane >> 5;
+    int baddr[6][3];
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int pp = (wave * NT + rr) * C::IW + nn + kx;
+            baddr[rr][kx] = ((pp << 1) + (kh2 ^ ((pp >> 3) & 1))) << 4;
+        }
+    const int aoff = lane * 16;
+    f32x16 acc[MT][NT];
+    constexpr bool R1_PRE = MT == 2 && (EPI & 8);   // conv5: the fp32 residual lands in the accumulators behind chunk 0's DMA (see conv_glds_kernel)
+    if constexpr (R1_PRE) {
+        const __amdgpu_buffer_rsrc_t rr1 = make_rsrc((const float*)p.res1.p + (size_t)n * p.res1.n_stride);
+        const unsigned r1_cb = (unsigned)p.res1.cb_stride;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int oy = oy0 + wave * NT + nt, ox = ox0 + nn;
+            const bool pv = (oy < p.Hout) & (ox < p.Wout);
+            const unsigned pixel = (unsigned)(oy * p.Wout + ox) * 16u;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int oc = mi * 32 + 8 * g + 4 * kh2;
+                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rr1, pv ? ((unsigned)(oc >> 4) * r1_cb + pixel + (unsigned)(oc & 15)) * 4u : OOB, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[mi][nt][4 * g + j] = __uint_as_float(t[j]);
+                }
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[mi][nt][j] = 0.f;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    if constexpr (R1_PRE) {
+        const float c1 = p.beta1 / p.alpha;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mi][nt] *= c1;
+    }
+    constexpr bool PRE = EPI == 68 && MT == 1;   // data gradient of conv1-4: the LeakyReLU' mask of the output tile is fetched during the last chunk (see conv_glds_kernel)
+    MaskPre<NT * MT> mpre;
+    bf16x8 fb[2][6], fa[2][MT];
+    for (int ck = 0; ck < nchunks; ++ck) {
+        const char* buf = smem + (ck & 1) * C::BUF_BYTES;
+        const char* wbuf = buf + C::ACT_BYTES;
+        char* nbuf = smem + ((ck + 1) & 1) * C::BUF_BYTES;
+        const bool more = ck + 1 < nchunks;
+        if (ck + 1 == dep_chunk) cs.wait(layer, tid);   // the next chunk is the first that holds the previous layer's output: the neighbours must have published it
+        if constexpr (PRE) {
+            if (!more) mask_prefetch<MT, NT>(p, mpre, tid, 0, n, oy0, ox0);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) fb[0][rr] = *(const bf16x8*)(buf + baddr[rr][0]);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) fa[0][mi] = *(const bf16x8*)(wbuf + aoff + (0 * MT + mi) * 1024);
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            const int kx = s / 3, ky = s - kx * 3;
+            if (s + 1 < 9) {
+                const int kx1 = (s + 1) / 3, ky1 = (s + 1) - kx1 * 3;
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) fa[(s + 1) & 1][mi] = *(const bf16x8*)(wbuf + aoff + ((ky1 * 3 + kx1) * MT + mi) * 1024);
+                if (ky == 1 && kx < 2) {
+#pragma unroll
+                    for (int rr = 0; rr < 6; ++rr) fb[(kx + 1) & 1][rr] = *(const bf16x8*)(buf + baddr[rr][kx + 1]);
+                }
+            }
+            if (more && s < 4) {
+#pragma unroll
+                for (int i = s * NP / 4; i < (s + 1) * NP / 4; ++i) glds_dma_piece<MT, NW>(i, ck + 1, nbuf, rin, rw, goff, in_chunk_bytes, wave, tid, ck + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mi][nt] = mfma16<F16>(fa[s & 1][mi], fb[kx & 1][nt + ky], acc[mi][nt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+    }
+    conv_epilogue<false, MT, NT, 1, R1_PRE ? (EPI & ~8) : EPI, F16 ? 1 : 0, PRE, true>(p, acc, smem, bias_reg, tid, 0, n, oy0, ox0, &mpre);
+    cs.publish(layer, tid);
+}
+
+template <bool F16, bool BWD>
+__global__ __launch_bounds__(256, 2) void conv_chain_kernel(const dasr_conv_params* __restrict__ layers, const int* __restrict__ dep_chunk, int nlayers,
+                                                           int tiles_y, int tiles_x, unsigned* flags, unsigned* tickets, int* err) {
+    using C = GCfg<1, 4>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int T = tiles_y * tiles_x;
+    // Which tile this workgroup owns follows from WHERE IT RUNS, not from its index: the dispatcher's round-robin over the XCDs (workgroup b -> XCD
+    // b % 8) holds for a kernel that has the chip to itself and fewer workgroups than slots, but not for the 512-workgroup launch that fills every
+    // slot (measured: workgroups land off their index once XCDs fill up).  Every workgroup reads its XCC id and draws a ticket from that XCD's
+    // counter (an atomic in the XCD's own L2: only its CUs touch the word): ticket -> (image of this XCD, tile).  The launch fills the chip exactly
+    // (grid = 512 = 2 workgroups x 256 CUs, all resident, checked by the launcher), so every XCD hosts exactly grid / 8 workgroups and the tickets
+    // of an XCD cover its images' tiles exactly once; the counters run on from launch to launch (ticket % quota).
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int xcd = (int)(xcc & 7u);
+    const int quota = (int)(gridDim.x >> 3);
+    int* tk = (int*)smem;
+    if (tid == 0) tk[0] = (int)(atomicAdd(tickets + xcd, 1u) % (unsigned)quota);
+    __syncthreads();
+    const int j = __builtin_amdgcn_readfirstlane(tk[0]);
+    __syncthreads();
+    const int img = j / T, tile = j - img * T;
+    const int n = xcd + 8 * img;                        // all tiles of image n on XCD n % 8
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    ChainSync cs;
+    cs.rflags = make_rsrc(flags);
+    cs.err = err;
+    cs.base = n * T;
+    cs.ty = ty, cs.tx = tx, cs.tiles_y = tiles_y, cs.tiles_x = tiles_x;
+    cs.f0 = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_raw_buffer_load_b32(cs.rflags, (unsigned)(cs.base + tile) * 4u, 0, 17));
+    const int oy0 = ty * C::TH, ox0 = tx * C::TW;
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int Hin = layers[0].Hin, Win = layers[0].Win;
+    unsigned goff[C::AR];
+#pragma unroll
+    for (int r = 0; r < C::AR; ++r) {
+        const int q = tid + r * C::NTH;
+        const int pp = q >> 1, h = (q & 1) ^ ((pp >> 3) & 1);
+        const int iy = pp / C::IW, ix = pp - iy * C::IW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        const bool ok = (pp < C::NPIX) & (gy >= 0) & (gy < Hin) & (gx >= 0) & (gx < Win);
+        goff[r] = ok ? (unsigned)(((gy * Win + gx) * 16 + 8 * h) * 2) : OOB;
+    }
+    for (int L = 0; L < nlayers; ++L) {
+        const dasr_conv_params& p = layers[L];
+        const int dep = dep_chunk[L];
+        if constexpr (BWD) {   // data-gradient chain: mask -> 16-bit planes; alpha, one / two fp32 residuals -> fp32 + 16-bit (no bias)
+            if (p.mt == 1) chain_layer<1, 68, F16>(p, smem, tid, n, oy0, ox0, goff, dep, cs, L);
+            else if (p.res2.p != nullptr) chain_layer<2, 248, F16>(p, smem, tid, n, oy0, ox0, goff, dep, cs, L);
+            else chain_layer<2, 232, F16>(p, smem, tid, n, oy0, ox0, goff, dep, cs, L);
+        } else {
+            if (p.mt == 1) chain_layer<1, 67, F16>(p, smem, tid, n, oy0, ox0, goff, dep, cs, L);
+            else if (p.res2.p != nullptr) chain_layer<2, 249, F16>(p, smem, tid, n, oy0, ox0, goff, dep, cs, L);
+            else chain_layer<2, 233, F16>(p, smem, tid, n, oy0, ox0, goff, dep, cs, L);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Dense-block convolution, third generation ("ring3"): Cout = 32 (MT = 1), 8 waves, 32 x 32 output pixels per workgroup, one workgroup
 // per CU.  Same LDS image, fragment reuse and epilogue as conv_glds_kernel; what changes is the staging pipeline:
 //  * THREE chunk buffers in a ring (3 x 48 KiB).  The DMA of chunk k+2 is issued while chunk k is multiplied, and the top of chunk k
@@ -1593,6 +1821,51 @@ extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
         default: return DASR_EINVAL;
     }
 #endif
+}
+
+// host_layers: the same nlayers parameter blocks the device array holds (the launcher validates them; the kernel reads the device copy)
+extern "C" int dasr_conv_chain(const dasr_conv_params* dev_layers, const dasr_conv_params* host_layers, const int32_t* dev_dep_chunk, int32_t nlayers,
+                               uint32_t* dev_flags, int32_t* dev_err, void* stream) {
+    using C = GCfg<2, 4>;
+    if (!dev_layers || !host_layers || !dev_dep_chunk || nlayers <= 0 || !dev_flags || !dev_err) return DASR_EINVAL;
+    const dasr_conv_params& p0 = host_layers[0];
+    const bool f16 = p0.prec == 2;
+    const bool bwd = classify_epi(p0) == 68 || classify_epi(p0) == 232 || classify_epi(p0) == 248;
+    for (int i = 0; i < nlayers; ++i) {
+        const dasr_conv_params& p = host_layers[i];
+        // one geometry for the whole chain: dense 3x3 / stride 1 / pad 1 on 16-bit tensors, every layer one m-group of its workgroup shape
+        if (p.kh != 3 || p.stride != 1 || p.pad != 1 || p.in_f32 || p.prec != p0.prec || (p.cin & 15) || p.cin <= 0 || p.ups || p.in_wrap || p.out16_lo || p.res1_lo) return DASR_EINVAL;
+        if (p.Hin != p0.Hin || p.Win != p0.Win || p.Hout != p0.Hin || p.Wout != p0.Win || p.N != p0.N || p.out_stride > 1 || p.in_stride > 1 || p.out_W || p.out_oy || p.out_ox) return DASR_EINVAL;
+        if (!(p.mt == 1 || p.mt == 2) || p.cout != 32 * p.mt || !p.w || !p.in.p || p.slope_ptr || p.mask_f32) return DASR_EINVAL;
+        if ((p.out16_f16 != 0) != f16 || (p.prec != 1 && p.prec != 2)) return DASR_EINVAL;
+        const int epi = classify_epi(p);
+        // forward: conv1-4 bias + LeakyReLU -> 16-bit planes (67), conv5 bias, alpha, one / two fp32 residuals -> fp32 + 16-bit (233 / 249);
+        // data gradient: LeakyReLU' mask -> 16-bit planes (68), alpha, one / two fp32 residuals -> fp32 + 16-bit (232 / 248)
+        const bool ok = bwd ? (p.mt == 1 ? epi == 68 : (epi == 232 || epi == 248)) : (p.mt == 1 ? epi == 67 : (epi == 233 || epi == 249));
+        if (!ok) return DASR_EINVAL;
+    }
+    const int tiles_x = (p0.Wout + C::TW - 1) / C::TW, tiles_y = (p0.Hout + C::TH - 1) / C::TH;
+    const long long grid = (long long)tiles_x * tiles_y * p0.N;
+    if ((p0.N & 7) || grid != 512) return DASR_EINVAL;   // whole images per XCD; the launch fills the chip exactly (2 workgroups x 256 CUs): see the ticket comment in the kernel
+    hipStream_t s = as_stream(stream);
+    static bool attr_set[4] = {false, false, false, false};
+    const int v = (f16 ? 1 : 0) | (bwd ? 2 : 0);
+#define DASR_CHAIN_LAUNCH(F16_, BWD_, NAME)                                                                                                              \
+    {                                                                                                                                                    \
+        auto kfn = conv_chain_kernel<F16_, BWD_>;                                                                                                        \
+        if (!attr_set[v]) {                                                                                                                              \
+            HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));                                    \
+            attr_set[v] = true;                                                                                                                          \
+        }                                                                                                                                                \
+        DASR_LAUNCH_TAG(NAME, kfn, dim3((unsigned)grid), dim3(256), C::LDS_BYTES, s, dev_layers, (const int*)dev_dep_chunk, (int)nlayers, tiles_y, tiles_x, \
+                        dev_flags, dev_flags + grid, dev_err);                                                                                           \
+    }
+    if (v == 0) DASR_CHAIN_LAUNCH(false, false, "conv_chain_kernel<bf16, fwd>")
+    else if (v == 1) DASR_CHAIN_LAUNCH(true, false, "conv_chain_kernel<f16, fwd>")
+    else if (v == 2) DASR_CHAIN_LAUNCH(false, true, "conv_chain_kernel<bf16, bwd>")
+    else DASR_CHAIN_LAUNCH(true, true, "conv_chain_kernel<f16, bwd>")
+#undef DASR_CHAIN_LAUNCH
+    return (int)hipGetLastError();
 }
 
 extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {

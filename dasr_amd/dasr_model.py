@@ -282,6 +282,8 @@ class DASR_Model(BaseModel):
     def check_finite(self):
         for o, what in zip(self.optimizers, ('generator', 'discriminator', 'source discriminator')):
             o.check_finite(what)
+        for plan in self.netG.plans.values():   # chained trunk launches (rrdbnet._Plan.check_chain): a broken neighbour wait invalidates the step
+            plan.check_chain()
 
     def get_current_log(self):
         """one device->host sync, only when the caller logs (the reference syncs 5-9 times every step, App. C-8)"""

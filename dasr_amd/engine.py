@@ -323,6 +323,39 @@ def conv_op(pack, ref, inp, in_f32, cin, Hin, Win, Hout, Wout, N, bias=None, kh=
     return o
 
 
+class ConvChain:
+    """One persistent launch for a chain of dense-block conv ops of one geometry (dasr_conv_chain, include/dasr_hip.h): the forward trunk of the
+    generator without kernel boundaries between its layers.  `ops`: the conv Ops in execution order (their parameter blocks are copied);
+    dep_chunks[i]: first 16-channel input chunk of layer i that holds layer i - 1's output (<= 0: all of them).  flags / err: shared per (N, h, w)
+    plan -- the flag words count stages monotonically across launches, err stays zero unless a launch went wrong (check())."""
+
+    def __init__(self, ops, dep_chunks, n_images, n_tiles, device, flags=None, err=None):
+        assert len(ops) == len(dep_chunks) and ops
+        n = len(ops)
+        self.host = (_lib.ConvParams * n)(*[o.conv for o in ops])
+        raw = torch.frombuffer(bytearray(bytes(self.host)), dtype=torch.uint8)
+        self.dev = raw.to(device)
+        self.dep = torch.tensor([int(d) for d in dep_chunks], dtype=torch.int32, device=device)
+        self.flags = flags if flags is not None else torch.zeros(n_images * n_tiles + 8, dtype=torch.int32, device=device)   # + the per-XCD ticket counters
+        self.err = err if err is not None else torch.zeros(1, dtype=torch.int32, device=device)
+        self.n = n
+        self.flops = sum(o.flops for o in ops)
+
+    def op(self):
+        o = Op()
+        o.op = _lib.OP_CONV_CHAIN
+        o.p[0], o.p[1], o.p[2], o.p[3] = self.dev.data_ptr(), C.cast(self.host, C.c_void_p).value, self.dep.data_ptr(), self.flags.data_ptr()
+        o.l[0], o.i[0] = self.err.data_ptr(), self.n
+        o.flops = self.flops
+        return o
+
+    def check(self):
+        """host sync: raises if a launch of this chain flagged a broken neighbour wait / XCD placement"""
+        e = int(self.err.item())
+        if e:
+            raise RuntimeError('conv chain: device error word %d (bit 1: a neighbour wait gave up)' % e)
+
+
 class WgradGroup:
     """Parts of one wgrad launch (same kernel size / stride) + the matching reduce table."""
 

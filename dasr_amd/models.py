@@ -256,6 +256,8 @@ class SRModel(BaseModel):
         fill those gaps with each other's main loops.  DASR_STREAMS=1 disables it."""
         k = max(1, int(os.environ.get('DASR_STREAMS', '2')))
         k = min(k, N // 4) if N >= 8 else 1   # a replica keeps at least 4 crops (128 workgroups per dense-block launch at 128 x 128)
+        if self.netG.chain_ok(N, h, w):
+            k = 1   # the whole batch fills the chip exactly: the trunk runs as persistent chained launches (rrdbnet._Plan), which beat the two-stream schedule
         if k <= 1:
             if (N, h, w, 0, 0, 0) not in self.netG.plans:
                 self.netG.concurrent_replicas = 1   # a plan built now has the chip to itself (wgrad split count)
@@ -424,6 +426,8 @@ class SRModel(BaseModel):
     def check_finite(self):
         """raise FloatingPointError if a non-finite gradient reached an optimiser since the last check (every rank; see AdamHIP.check_finite)"""
         self.optimizer_G.check_finite('generator')
+        for plan in (getattr(self, '_out_plans', None) or []):
+            plan.check_chain()
 
     def get_current_log(self):
         if 'l_pix' in self.log_dict:

@@ -12,7 +12,7 @@ from collections import OrderedDict
 import torch
 
 from . import _lib
-from .engine import (BTensor, ParamStore, PackRegistry, OpList, WgradGroup, WgradGroup3, Workspace, conv_op, ceil_div, SLOPE, NULL_T)
+from .engine import (BTensor, ParamStore, PackRegistry, OpList, WgradGroup, WgradGroup3, Workspace, conv_op, ceil_div, SLOPE, NULL_T, ConvChain)
 from ._lib import Op, Tensor
 
 GC = 32  # growth channels are hard-wired to 32 in the reference (architecture.py:183)
@@ -55,6 +55,9 @@ class RRDBNetHIP:
             raise ValueError('rdb_prec / DASR_RDB_PREC must be 1 (bf16) or 2 (f16 storage)')
         self.rdb_prec, self.stream_prec = rdb_prec, stream_prec
         self.rdb_f16 = rdb_prec == 2
+        # DASR_CHAIN (default 1): the trunk's dense-block convs, forward and data gradient, as persistent chained launches where the batch fills the chip
+        # exactly (chain_ok; _Plan._build_forward).  bf16 storage only: the f16 path re-patches scale factors of recorded ops (TrunkStore.set_gscale_from)
+        self.chain = os.environ.get('DASR_CHAIN', '1') == '1' and not self.rdb_f16
         self.hr_prec = int(os.environ.get('DASR_HR_PREC', '2')) if stream_prec == 3 else stream_prec
         # hr_prec 2 (default): f16 STORAGE of the HR tail (u1, u2, h0 and their gradients live in HBM as f16): the consumers run on the LDS-DMA
         # dense-conv kernel / the grouped wgrad kernel with the f16 MFMA, and the HR tensors cost half the bytes.  DASR_HR_PREC=3 (numerics
@@ -146,6 +149,10 @@ class RRDBNetHIP:
 
     def repack(self):
         self.pack.run()
+
+    def chain_ok(self, N, h, w):
+        """a training plan of this shape runs its trunk as chained launches: whole images per XCD and the launch fills the chip exactly (dasr_conv_chain)"""
+        return bool(self.chain and N % 8 == 0 and N * ceil_div(h, 16) * ceil_div(w, 32) == 512 and not getattr(self, 'debug_taps', ()))
 
     # ---- plan ---------------------------------------------------------------------------------------
     def plan(self, N, h, w, replica=0, store=None, n0=0):
@@ -423,6 +430,15 @@ class _Plan:
         self._build_backward()
         self.ws.finalize()
 
+    def check_chain(self):
+        """host sync: raise if a chained launch of this plan flagged a broken neighbour wait (the results of that step are not valid)"""
+        if getattr(self, 'chain', None) is not None:
+            try:
+                self.chain.check()
+            except RuntimeError as e:
+                raise RuntimeError(str(e) + '.  The chained trunk launches (dasr_conv_chain) need the GPU to themselves -- another process sharing the '
+                                   'device breaks their workgroup placement; DASR_CHAIN=0 restores one launch per conv.')
+
     # ---- IO -----------------------------------------------------------------------------------------
     def set_input(self, x):
         self.x_nchw.copy_(x)
@@ -461,6 +477,13 @@ class _Plan:
         X = self.fea  # fp32 input of the current RDB
         free = list(self.stream)
         self.rdb_in = []
+        # DASR_CHAIN=1: the dense-block convs of the trunk as ONE persistent launch (dasr_conv_chain): no kernel boundary between layers, a tile waits for
+        # its neighbour tiles only before the input chunks the previous layer produced.  Needs whole images per XCD (N % 8 == 0) and every workgroup
+        # resident with the chip exactly full (N * tiles == 512); the taps of the tests sit between layers and keep the per-layer launches.
+        tiles = ceil_div(h, 16) * ceil_div(w, 32)
+        chain = [] if (net.chain_ok(N, h, w) and not self.inference) else None
+        trunk_ops = ops if chain is None else OpList()
+        main_ops, ops = ops, trunk_ops
         for i in range(nb):
             Xrrdb = X
             for r in (1, 2, 3):
@@ -490,6 +513,18 @@ class _Plan:
                 o.i[0], o.i[1], o.i[2], o.i[3] = N, nf, h, w
                 o.t[2], o.t[3], o.f[2] = self.taps[i].view(), NULL_T, 1.0
                 ops.add(o)
+        ops = main_ops
+        self.chain = None
+        if chain is not None:
+            # dep_chunk: conv1 of an RDB reads only what the previous conv5 (or fea_conv, a kernel earlier) wrote; conv j > 1 and conv5 read GC new channels
+            # (the last two 16-channel chunks) from the layer in front of them
+            body = [o for o in trunk_ops.ops if o.op == _lib.OP_CONV]
+            assert len(body) == len(trunk_ops.ops) == 15 * nb
+            deps = [0 if k % 5 == 0 else (o.conv.cin // 16) - GC // 16 for k, o in enumerate(body)]
+            self.chain = ConvChain(body[:-1], deps[:-1], N, tiles, net.device)   # (the last conv5 has no 16-bit shadow to write: its own launch)
+            ops.add(self.chain.op())
+            ops.add(body[-1])
+            ops.keep.append(self.chain)
         self.x_last = X
         lrb = 'model.1.sub.%d.bias' % nb
         if net.hr_f16s:
@@ -724,6 +759,12 @@ class _Plan:
             self.store.register_scaled(ops.ops[-1], 0.04, False)
         # RRDB chain, reversed.  No weight-gradient launch inside the chain: every RDB keeps its gradient slab and TrunkStore.phase computes all
         # of them afterwards (grouped launches over the whole batch).
+        # DASR_CHAIN=1 (see _build_forward): the 15 nb data-gradient convs as one persistent chained launch (bf16 storage only: the f16 path patches
+        # the scale factors of recorded ops when the gradient scale is re-calibrated, the chain holds copies)
+        use_chain = self.chain is not None and not f16
+        main_ops = ops
+        if use_chain:
+            ops = OpList()
         for i in range(nb - 1, -1, -1):
             Grr = G  # grad wrt the RRDB output
             Gout = None  # grad wrt the current RDB output (None: it is 0.2*Grr, folded into the epilogue)
@@ -753,6 +794,16 @@ class _Plan:
                 Gout = Gin
                 gs_cur += 1
             G = Gout
+        if use_chain:
+            body = list(ops.ops)
+            assert len(body) == 15 * nb and all(o.op == _lib.OP_CONV for o in body)
+            deps = [0 if k % 5 == 0 else (o.conv.cin // 16) - GC // 16 for k, o in enumerate(body)]
+            tiles = ceil_div(h, 16) * ceil_div(w, 32)
+            self.chain_b = ConvChain(body[:-1], deps[:-1], N, tiles, net.device, err=self.chain.err)   # (the last conv writes no 16-bit planes: its own launch)
+            ops = main_ops
+            ops.add(self.chain_b.op())
+            ops.add(body[-1])
+            ops.keep.append(self.chain_b)
         ops.tag(4)
         rrdb0 = P.off('model.1.sub.0.RDB1.conv1.0.weight')
         if not self.shared_store:   # this plan owns the whole batch: the weight-gradient phase follows the chain in the same list

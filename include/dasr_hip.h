@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DASR_ABI_VERSION 15
+#define DASR_ABI_VERSION 16
 #define DASR_EINVAL (-22)
 
 typedef struct {
@@ -85,6 +85,18 @@ typedef struct {
 } dasr_conv_params;
 
 int dasr_conv(const dasr_conv_params* p, void* stream);
+/* A chain of dense-block convs in ONE persistent launch (round 4; replaces the per-layer launches of ResidualDenseBlock_5C / RRDB forward,
+ * codes/SRN/models/modules/block.py:254-309, for the trunk of RRDBNet, architecture.py:174-205).  Layer L is dasr_conv(layers[L]) -- same arithmetic,
+ * bit-identical results -- but a tile of the image goes from layer to layer inside the launch and waits for its eight neighbour tiles (flags in
+ * `flags`, one word per tile, zero at allocation) only before it reads the first input chunk that holds layer L-1's output (dep_chunk[L], in
+ * 16-channel chunks; <= 0: every chunk).  Constraints (DASR_EINVAL otherwise): 3x3 / stride 1 / pad 1 on 16-bit tensors of ONE geometry,
+ * cout == 32 * mt, the term sets of the dense-block forward (bias + LeakyReLU -> 16-bit planes; bias, alpha, one or two fp32 residuals -> fp32 +
+ * 16-bit), N a multiple of 8 (whole images per XCD) and N * tiles == 512 (the launch fills the chip exactly: every workgroup resident, every XCD
+ * hosts the tiles of its own images).  `flags`: N * tiles + 8 words (the last eight: per-XCD ticket counters).  `err` (device word, zero at
+ * allocation): bit 1 a neighbour wait gave up -- the results are then not valid.
+ * dev_layers / dev_dep_chunk: device copies the kernel reads; host_layers: the same blocks in host memory (validated by the launcher). */
+int dasr_conv_chain(const dasr_conv_params* dev_layers, const dasr_conv_params* host_layers, const int32_t* dev_dep_chunk, int32_t nlayers,
+                    uint32_t* dev_flags, int32_t* dev_err, void* stream);
 /* kernel-variant knobs for A/B runs (bench.py --sweep / --tune); defaults are the tuned choice.
  * key 1 / 2: dense-block conv with Cout = 32 / 64: 12 = LDS-DMA kernel (default for Cout 32), 13 = its 8-wave 32x32-tile form (Cout 64 default: chosen per launch when the 4-wave grid has <= 256 workgroups), 0 = first-generation register-staged kernel,
  *            1 double-buffered LDS, 4/5 8x32 tiles, 6 4x32 tiles, 8/9 row reuse, 10/11 register-staged pipeline;
@@ -388,7 +400,8 @@ enum { DASR_OP_CONV = 1, DASR_OP_WGRAD = 2, DASR_OP_WGRAD_REDUCE = 3, DASR_OP_PA
        DASR_OP_LPIPS_S2D = 35, DASR_OP_MAXPOOL3 = 36, DASR_OP_MAXPOOL3_BWD = 37, DASR_OP_LPIPS_HEAD = 38, DASR_OP_RAGAN = 39,
        DASR_OP_BNORM_FWD = 40, DASR_OP_BNORM_BWD = 41, DASR_OP_BNORM_RUNNING = 42, DASR_OP_DDM_SPREAD = 43,
        /* --wgan gradient penalty (round 4) */
-       DASR_OP_INORM_JVP = 44, DASR_OP_INORM_SECOND = 45, DASR_OP_GRAD_PENALTY = 46, DASR_OP_FILL_SCALED = 47 };
+       DASR_OP_INORM_JVP = 44, DASR_OP_INORM_SECOND = 45, DASR_OP_GRAD_PENALTY = 46, DASR_OP_FILL_SCALED = 47,
+       DASR_OP_CONV_CHAIN = 48   /* p[0] device layers, p[1] host layers, p[2] device dep_chunk, i[0] nlayers, p[3] device flags; l[0] device err word */ };
 
 typedef struct {
     int32_t op;  int32_t i[8];  float f[4];  int64_t l[4];  void* p[4];  dasr_tensor t[5];

@@ -38,9 +38,13 @@ def _sr_model(nf, nb):
     return m
 
 
-def test_cfg1_step_batch16_equals_mean_of_halves_and_is_deterministic(margins, monkeypatch):
-    """configs[1] exactly: batch 16 -> two sub-batch streams of 8 (production schedule); the halves of 8 run as ONE batch-8 plan each"""
+@pytest.mark.parametrize('chain', ['1', '0'], ids=['chained_trunk', 'two_streams'])
+def test_cfg1_step_batch16_equals_mean_of_halves_and_is_deterministic(chain, margins, monkeypatch):
+    """configs[1] exactly.  chained_trunk (production schedule since round 4): batch 16 = ONE plan whose trunk runs as two persistent chained launches
+    (dasr_conv_chain); two_streams (DASR_CHAIN=0, the schedule of rounds 1-3): two sub-batch streams of 8.  The halves of 8 run as one batch-8 plan each
+    with per-layer launches (8 x 32 tiles do not fill the chip: no chain)."""
     dev = _gpu()
+    monkeypatch.setenv('DASR_CHAIN', chain)
     g = torch.Generator().manual_seed(1234)
     data = {'LR': torch.rand(16, 3, 128, 128, generator=g), 'HR': torch.rand(16, 3, 512, 512, generator=g)}
     grads, losses = [], []
@@ -51,7 +55,9 @@ def test_cfg1_step_batch16_equals_mean_of_halves_and_is_deterministic(margins, m
         m.feed_data(_shard(data, lo, hi))
         m.optimize_parameters(1)
         torch.cuda.synchronize()
-        assert len(m._out_plans) == (2 if hi - lo == 16 else 1)
+        assert len(m._out_plans) == (2 if (hi - lo == 16 and chain == '0') else 1)
+        assert (m._out_plans[0].chain is not None) == (hi - lo == 16 and chain == '1')
+        m.check_finite()
         grads.append(m.netG.params.grad.clone())
         losses.append(m.get_current_log()['l_pix'])
         del m
@@ -59,8 +65,8 @@ def test_cfg1_step_batch16_equals_mean_of_halves_and_is_deterministic(margins, m
     assert torch.equal(grads[0], grads[1])                              # fixed-order reductions: bit-exact run to run
     assert all(torch.isfinite(x).all() for x in grads) and 0.1 < losses[0] < 1.0   # x0.1 weights: |HR - small output| ~ 0.5
     e = rel(grads[0], 0.5 * (grads[2] + grads[3]))
-    margins('configs[1] full size: grad(batch 16, two streams) vs mean of the two batch-8 halves: rel err %.2e (tol 1e-5); losses %.6f vs %.6f' % (
-        e, losses[0], 0.5 * (losses[2] + losses[3])))
+    margins('configs[1] full size: grad(batch 16, %s) vs mean of the two batch-8 halves: rel err %.2e (tol 1e-5); losses %.6f vs %.6f' % (
+        'chained trunk' if chain == '1' else 'two streams', e, losses[0], 0.5 * (losses[2] + losses[3])))
     assert e < 1e-5 and abs(losses[0] - 0.5 * (losses[2] + losses[3])) < 5e-6   # the logged loss is an fp32 atomic sum over 12.6 M terms
 
 
@@ -157,7 +163,8 @@ def test_cfg1_exact_step_matches_the_oracle(margins):
     m.feed_data(data)
     m.optimize_parameters(1)
     torch.cuda.synchronize()
-    assert len(m._out_plans) == 2
+    assert len(m._out_plans) == 1 and m._out_plans[0].chain is not None and m._out_plans[0].chain_b is not None   # the production schedule: chained trunk launches
+    m.check_finite()
     got_g = m.netG.params.grad_dict()
     got_loss = m.get_current_log()['l_pix']
     got_sr = m.fake_H.cpu()
@@ -172,7 +179,7 @@ def test_cfg1_exact_step_matches_the_oracle(margins):
         srs.append(sr.detach())
     e_sr = rel(got_sr, torch.cat(srs, 0))
     errs = sorted(((rel(got_g[k], p.grad), k) for k, p in ref.named_parameters()), reverse=True)
-    margins('configs[1] exactly (nf64 nb23, batch 16 x 128^2, two streams) vs the fp32 oracle: SR rel err %.2e (tol 1e-3), loss %.6f vs %.6f, worst gradient rel err %.2e '
+    margins('configs[1] exactly (nf64 nb23, batch 16 x 128^2, chained trunk launches) vs the fp32 oracle: SR rel err %.2e (tol 1e-3), loss %.6f vs %.6f, worst gradient rel err %.2e '
             'at %s (tol 1e-2, %d tensors), median %.2e' % (e_sr, got_loss, loss, errs[0][0], errs[0][1], len(errs), errs[len(errs) // 2][0]))
     assert e_sr < 1e-3 and abs(got_loss - loss) < 2e-5 * abs(loss) + 1e-6
     assert errs[0][0] < 1e-2, errs[:3]
