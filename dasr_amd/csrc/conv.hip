@@ -1346,7 +1346,10 @@ struct ChainSync {
                     int spins = 0;
                     while ((int)(__builtin_amdgcn_raw_buffer_load_b32(rflags, off, 0, 17) - target) < 0) {
                         __builtin_amdgcn_s_sleep(2);
-                        if (++spins > (1 << 21)) {
+                        ++spins;
+                        // give up after ~1 s -- or at once when another wait of this launch has given up already (the launch is lost either way:
+                        // ONE timeout per launch, not one per layer, when the placement assumption is broken, e.g. by a second process on the device)
+                        if (spins > (1 << 21) || ((spins & 1023) == 0 && __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(err), 0, 0, 17) != 0)) {
                             atomicOr(err, 2);
                             break;
                         }

@@ -41,6 +41,10 @@ class DataParallelGroup:
             raise RuntimeError('LOCAL_RANK %d but only %d visible device(s): one process per GPU (RCCL cannot share a device between ranks; '
                                'DASR_DP_BACKEND=gloo does, for tests)' % (self.local_rank, ndev))
         self.device_index = self.local_rank % ndev if ndev else 0
+        if ndev and self.world > ndev and os.environ.get('DASR_CHAIN') is None:
+            # ranks SHARE a device (the gloo test set-up): the chained trunk launches (dasr_conv_chain) need every workgroup slot of the GPU for one
+            # launch -- two processes doing that on one device starve each other.  Per-layer launches there; every rank applies the same rule.
+            os.environ['DASR_CHAIN'] = '0'
         if (self.world > 1 or force) and not dist.is_initialized():
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
