@@ -1850,6 +1850,17 @@ extern "C" int dasr_conv_chain(const dasr_conv_params* dev_layers, const dasr_co
     const int tiles_x = (p0.Wout + C::TW - 1) / C::TW, tiles_y = (p0.Hout + C::TH - 1) / C::TH;
     const long long grid = (long long)tiles_x * tiles_y * p0.N;
     if ((p0.N & 7) || grid != 512) return DASR_EINVAL;   // whole images per XCD; the launch fills the chip exactly (2 workgroups x 256 CUs): see the ticket comment in the kernel
+    {
+        static int n_cu = -1;   // (a partitioned device -- CPX / DPX -- exposes fewer CUs per logical GPU: the launch would not be resident as a whole)
+        if (n_cu < 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDevice(&dev));
+            HIP_TRY(hipGetDeviceProperties(&prop, dev));
+            n_cu = prop.multiProcessorCount;
+        }
+        if (n_cu != 256) return DASR_EINVAL;
+    }
     hipStream_t s = as_stream(stream);
     static bool attr_set[4] = {false, false, false, false};
     const int v = (f16 ? 1 : 0) | (bwd ? 2 : 0);

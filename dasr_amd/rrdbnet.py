@@ -152,7 +152,11 @@ class RRDBNetHIP:
 
     def chain_ok(self, N, h, w):
         """a training plan of this shape runs its trunk as chained launches: whole images per XCD and the launch fills the chip exactly (dasr_conv_chain)"""
-        return bool(self.chain and N % 8 == 0 and N * ceil_div(h, 16) * ceil_div(w, 32) == 512 and not getattr(self, 'debug_taps', ()))
+        if not (self.chain and N % 8 == 0 and N * ceil_div(h, 16) * ceil_div(w, 32) == 512 and not getattr(self, 'debug_taps', ())):
+            return False
+        if not hasattr(self, '_cus'):   # 512 workgroups = 2 per CU of a whole MI355X (8 XCDs x 32 CUs); a partitioned device (CPX / DPX) has fewer
+            self._cus = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == 'cuda' else 0
+        return self._cus == 256
 
     # ---- plan ---------------------------------------------------------------------------------------
     def plan(self, N, h, w, replica=0, store=None, n0=0):
