@@ -1321,14 +1321,14 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
 // (dep_chunk): 2-8 chunks = 5-20 us after it published its own flag.  Only conv1 of an RDB (all 64 input channels come from the previous
 // conv5) waits up front.
 //
-// Coherence.  Workgroup b is dispatched to XCD b % 8 (checked against HW_REG_XCC_ID, err bit 2); all tiles of image n are given to workgroups of
-// XCD n % 8, so every halo a tile reads was written by a CU of its own XCD and the XCD's L2 is the coherence point (the per-XCD L2s are not
+// Coherence.  All tiles of image n are given to workgroups that RUN on XCD n % 8 (every workgroup reads HW_REG_XCC_ID and draws its tile from that XCD's
+// ticket counter, see the kernel), so every halo a tile reads was written by a CU of its own XCD and the XCD's L2 is the coherence point (the per-XCD L2s are not
 // coherent with each other without agent-scope fences that cost 30-70 us per use).  Data stores and the flag store are write-through (sc1: with
 // plain stores a few lines per 10^4 were not yet in the L2 when vmcnt(0) returned); flag polls bypass the vector L1 (sc0 sc1); halo data is
 // first touched after the flag (the L1 was invalidated at kernel start, a 128-byte L1 line never spans two tiles: tiles are 32 pixels = 1 KiB
 // wide per plane row).
-// Co-residency: every workgroup of the launch must be resident (a waiting tile spins): grid <= 2 workgroups x 256 CUs, checked by the launcher;
-// a spin gives up after ~1 s and sets err bit 1 (the results are then wrong, the launch still ends).
+// Co-residency: every workgroup of the launch must be resident (a waiting tile spins) and every XCD must host exactly its share: grid == 2 workgroups x
+// 256 CUs, checked by the launcher; a spin gives up after ~1 s and sets err bit 1 (the results are then wrong, the launch still ends).
 // ---------------------------------------------------------------------------------------------------
 struct ChainSync {
     __amdgpu_buffer_rsrc_t rflags;
