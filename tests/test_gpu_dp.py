@@ -170,8 +170,11 @@ def test_two_rank_batchnorm_discriminator_uses_per_rank_statistics(tmp_path, mar
     margins('DP 2 ranks, BatchNorm source discriminator: gradients == mean of the per-shard steps, worst rel err %.2e (bound 1e-4)' % worst)
 
 
+CHAIN16 = dict(kind='sr', nf=64, nb=1, n=16, lr=128)   # 16 x 32 tiles fill the chip: the trunk runs as chained launches (dasr_conv_chain)
+
+
 def _rccl_worker(rank, port, out, streams, use_dp, native=0):
-    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DASR_STREAMS=str(streams),
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), DASR_STREAMS=str(abs(streams)),
                       DASR_RCCL_NATIVE=str(native))
     import torch
     from oracle import fixtures
@@ -179,6 +182,7 @@ def _rccl_worker(rank, port, out, streams, use_dp, native=0):
     from dasr_amd.dist import DataParallelGroup
     from dasr_amd.models import create_model
     torch.cuda.set_device(0)
+    B16 = CHAIN16 if streams < 0 else globals()['B16']
     opt = fixtures.make_opt(B16)
     opt['gpu_ids'] = [0]
     m = create_model(options.dict_to_nonedict(opt))
@@ -193,22 +197,26 @@ def _rccl_worker(rank, port, out, streams, use_dp, native=0):
         m.feed_data(batch)
         m.optimize_parameters(step)
     torch.cuda.synchronize()
+    if streams < 0:
+        assert len(m._out_plans) == 1 and m._out_plans[0].chain is not None and m._out_plans[0].chain_b is not None
     torch.save({'G': m.netG.state_dict(), 'l_pix': m.get_current_log()['l_pix']}, out % int(use_dp))
     if use_dp:
         m.dp.barrier()
         assert m.dp.max_over_ranks(1.5) == 1.5
 
 
-@pytest.mark.parametrize('streams,native', [(1, 0), (2, 0), (2, 1)], ids=['1stream-torch', '2streams-torch', '2streams-c_abi'])
+@pytest.mark.parametrize('streams,native', [(1, 0), (2, 0), (2, 1), (-1, 0)], ids=['1stream-torch', '2streams-torch', '2streams-c_abi', 'chained_trunk-torch'])
 def test_rccl_exchange_path_single_rank(streams, native, tmp_path):
     """The RCCL code path (backend 'nccl': communication stream, bucket events, all-reduce enqueued behind the boundary events of
     both replica streams) executed for real on this one-GPU box with a communicator of ONE rank (RCCL refuses two ranks on one
-    device).  The exchange is the identity, so the step must reproduce the no-DP step bit for bit."""
+    device).  The exchange is the identity, so the step must reproduce the no-DP step bit for bit.
+    chained_trunk: a shape whose trunk runs as persistent chained launches -- the first gradient bucket's all-reduce (an RCCL kernel on the communication
+    stream) is in flight while the 512-workgroup data-gradient chain starts, exactly as on a multi-GPU node."""
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     import torch.multiprocessing as mp
     out = str(tmp_path / 'rccl_%d.pt')
-    port = 29411 + (os.getpid() % 300) + streams
+    port = 29411 + (os.getpid() % 300) + abs(streams) + (7 if streams < 0 else 0)
     mp.spawn(_rccl_worker, args=(port, out, streams, False), nprocs=1, join=True)
     mp.spawn(_rccl_worker, args=(port, out, streams, True, native), nprocs=1, join=True)
     a, b = torch.load(out % 0), torch.load(out % 1)
