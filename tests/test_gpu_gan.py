@@ -578,3 +578,36 @@ def test_discriminator_vgg128_forward_backward_and_state_dict(margins):
         if 'running' in k or 'num_batches' in k:
             assert rel(sd2[k].float(), v.float()) < 1e-4, k
     print('Discriminator_VGG_128: worst grad rel err %.2e' % worst)
+
+
+def test_gan_step_with_chained_trunk_launches_is_bit_identical(monkeypatch):
+    """the GAN trainer on a shape whose generator batch fills the chip (8 source + 8 target crops of 128 x 128: 16 x 32 tiles): the trunk of its generator plan
+    runs as persistent chained launches (rrdbnet._Plan, dasr_conv_chain) -- generator / discriminator weights after two steps and every logged term must be
+    bit-identical to the per-layer launches"""
+    _gpu()
+    from oracle import fixtures
+    from dasr_amd import options
+    from dasr_amd.models import create_model
+    case = dict(kind='dasr', nf=64, nb=1, n=8, lr=128, fs='wavelet', d_in_nc=9)
+    batch = fixtures.make_batch(case, seed=21)
+    outs = []
+    for chain in ('0', '1'):
+        monkeypatch.setenv('DASR_CHAIN', chain)
+        torch.manual_seed(0)
+        o = fixtures.make_opt(case)
+        o['gpu_ids'] = [0]
+        o['train']['vgg_seed'] = 77
+        m = create_model(options.dict_to_nonedict(o))
+        for step in (1, 2):
+            m.update_learning_rate()
+            m.feed_data(batch, True)
+            m.optimize_parameters(step)
+        log = dict(m.get_current_log())   # (host sync; includes the chains' error word)
+        plans = list(m.netG.plans.values())
+        assert any(getattr(p, 'chain', None) is not None for p in plans) == (chain == '1')
+        outs.append((m.netG.params.flat.clone(), m.netD_target.params.flat.clone(), m.fake_H.clone(), log))
+    (g0, d0, s0, l0), (g1, d1, s1, l1) = outs
+    assert torch.equal(s0, s1) and torch.equal(g0, g1) and torch.equal(d0, d1)
+    for k in l0:
+        if not k.startswith('disc_Score'):
+            assert abs(l0[k] - l1[k]) <= 1e-6 * max(1e-3, abs(l0[k])), (k, l0[k], l1[k])   # (logged losses are atomic sums: order varies from run to run)
