@@ -44,6 +44,8 @@ def test_cfg1_step_batch16_equals_mean_of_halves_and_is_deterministic(chain, mar
     (dasr_conv_chain); two_streams (DASR_CHAIN=0, the schedule of rounds 1-3): two sub-batch streams of 8.  The halves of 8 run as one batch-8 plan each
     with per-layer launches (8 x 32 tiles do not fill the chip: no chain)."""
     dev = _gpu()
+    if chain == '1' and torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip('the chained launches need a whole 256-CU MI355X (RRDBNetHIP.chain_ok)')
     monkeypatch.setenv('DASR_CHAIN', chain)
     g = torch.Generator().manual_seed(1234)
     data = {'LR': torch.rand(16, 3, 128, 128, generator=g), 'HR': torch.rand(16, 3, 512, 512, generator=g)}
@@ -163,7 +165,8 @@ def test_cfg1_exact_step_matches_the_oracle(margins):
     m.feed_data(data)
     m.optimize_parameters(1)
     torch.cuda.synchronize()
-    assert len(m._out_plans) == 1 and m._out_plans[0].chain is not None and m._out_plans[0].chain_b is not None   # the production schedule: chained trunk launches
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert len(m._out_plans) == 1 and m._out_plans[0].chain is not None and m._out_plans[0].chain_b is not None   # the production schedule: chained trunk launches
     m.check_finite()
     got_g = m.netG.params.grad_dict()
     got_loss = m.get_current_log()['l_pix']

@@ -585,6 +585,8 @@ def test_gan_step_with_chained_trunk_launches_is_bit_identical(monkeypatch):
     runs as persistent chained launches (rrdbnet._Plan, dasr_conv_chain) -- generator / discriminator weights after two steps and every logged term must be
     bit-identical to the per-layer launches"""
     _gpu()
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip('the chained launches need a whole 256-CU MI355X (RRDBNetHIP.chain_ok)')
     from oracle import fixtures
     from dasr_amd import options
     from dasr_amd.models import create_model

@@ -233,6 +233,8 @@ def test_chained_trunk_launches_are_bit_identical_to_per_layer_launches(shape, m
     (dasr_conv_chain).  Same arithmetic in the same order: SR output, every gradient and the weights after two Adam steps must be BIT-identical to the
     per-layer launches, and the device error word stays zero (no neighbour wait gave up)."""
     _gpu()
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip('the chained launches need a whole 256-CU MI355X (RRDBNetHIP.chain_ok)')
     from oracle import fixtures
     from dasr_amd import options
     from dasr_amd.models import create_model
@@ -268,5 +270,8 @@ def test_chain_refuses_shapes_that_do_not_fill_the_chip():
     _gpu()
     from dasr_amd.rrdbnet import RRDBNetHIP
     net = RRDBNetHIP(3, 3, 64, 1, device='cuda')
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        assert not net.chain_ok(16, 128, 128)   # a partitioned device: never
+        return
     assert net.chain_ok(16, 128, 128) and net.chain_ok(8, 128, 256) and net.chain_ok(32, 64, 128)
     assert not net.chain_ok(16, 64, 64) and not net.chain_ok(4, 256, 256) and not net.chain_ok(12, 128, 128) and not net.chain_ok(32, 128, 128)
