@@ -91,7 +91,7 @@ _SIGS = {
     'dasr_downsum2x_f16': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_f32, c_f32, Tensor, Tensor, c_vp],
     'dasr_downsum2x': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_i32, c_f32, Tensor, Tensor, c_vp],
     'dasr_axpby': [Tensor, c_f32, Tensor, c_f32, c_i32, c_i32, c_i32, c_i32, Tensor, Tensor, c_f32, Tensor, c_f32, c_vp, c_vp],
-    'dasr_adam': [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp, c_vp],
+    'dasr_adam': [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp, c_vp, c_vp],
     'dasr_fill_f32': [c_vp, c_i64, c_f32, c_vp],
     'dasr_add_flat': [c_vp, c_vp, c_i64, c_vp],
     'dasr_inorm_lrelu_fwd': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, Tensor, c_vp, c_vp],
@@ -147,10 +147,11 @@ _BENCH_SIGS = {
     'dasr_probe_mfma_data': [c_i32, c_i32, c_vp, c_vp],
     'dasr_probe_tile_sync': [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],
     'dasr_probe_mfma_peak': [c_i32, c_vp, c_vp],
+    'dasr_probe_spin': [c_i32, c_i32, c_vp],
 }
 BENCH_LIB_PATH = os.path.join(HERE, 'libdasr_bench.so')
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 _lib = None
 _bench = None
 

@@ -207,3 +207,17 @@ extern "C" int dasr_probe_tile_sync(int32_t blocks, int32_t stages, int32_t nb_s
     return 0;
 }
 
+
+// `blocks` workgroups of 256 threads that do nothing but hold their workgroup slots for `micros` microseconds (s_memrealtime: the 100 MHz constant clock),
+// asynchronous on `stream`.  Stand-in for a collective's kernels on the communication stream in tests/test_gpu_dp.py: whatever runs next to it finds
+// `blocks` slots taken (the chained trunk launches, dasr_conv_chain, need every slot of the device).
+__global__ void spin_kernel(long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+extern "C" int dasr_probe_spin(int32_t blocks, int32_t micros, void* stream) {
+    if (blocks <= 0 || blocks > 4096 || micros <= 0 || micros > 2000000) return DASR_EINVAL;
+    hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (long long)micros * 100);
+    return (int)hipGetLastError();
+}

@@ -58,6 +58,52 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
+// ---- deterministic grid-wide sums (round 5) ------------------------------------------------------------------------------------------
+// The logged loss / score terms (loss_acc += coef * sum over the grid) used to be one fp32 atomicAdd per workgroup: the order of the adds varied from
+// run to run, and with it the last bits of every logged value (two runs of one step differed by ~1e-6 relative).  Now every workgroup
+// stores its partial sums into a scratch row (write-through, `sc1`), draws an arrival ticket, and the LAST workgroup to arrive sums all partials in a
+// FIXED order (thread t: partials t, t + 256, ...; then the xor-butterfly over the lanes and the four waves in index order) and adds the total to the
+// accumulator -- ONE add per launch, so the value no longer depends on which workgroup ran when.  The partials are read back with `sc1` loads (agent
+// scope: the per-XCD L2s are not coherent with each other, MI355X_MICROARCH.md "inter-workgroup visibility").
+// The scratch row belongs to (accumulator address, stream): launches that share it are ordered by the stream (dasr_red_scratch, misc.hip).
+struct dasr_red {
+    float* part;         // [K][gridDim.x] partial sums; nullptr: nothing to accumulate
+    unsigned* ticket;    // arrival counter, zero between launches
+};
+dasr_red dasr_red_scratch(const void* key_acc, hipStream_t s, unsigned nblocks, int k);   // misc.hip; k <= 3
+
+// Called by ALL 256 threads of every workgroup of a 1-D grid; v[k] = this workgroup's partial sum (the same value in every thread, or at least in
+// thread 0); acc[k] (may be null) += coef[k] * (sum over the grid of v[k]).
+template <int K>
+__device__ __forceinline__ void grid_sum_commit(const dasr_red r, const float (&v)[K], float* const (&acc)[K], const float (&coef)[K]) {
+    if (!r.part) return;
+    __shared__ unsigned gs_last;
+    __shared__ float gs_red[K][4];
+    const unsigned nb = gridDim.x;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) __hip_atomic_store(r.part + (size_t)k * nb + blockIdx.x, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the partials have left this XCD before the ticket is drawn
+        gs_last = __hip_atomic_fetch_add(r.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1u;
+    }
+    __syncthreads();
+    if (!gs_last) return;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float s = 0.f;
+        for (unsigned i = threadIdx.x; i < nb; i += 256u) s += __hip_atomic_load(r.part + (size_t)k * nb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) gs_red[k][threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (acc[k]) atomicAdd(acc[k], ((gs_red[k][0] + gs_red[k][1]) + (gs_red[k][2] + gs_red[k][3])) * coef[k]);   // (an atomic only because another STREAM may add to the same word)
+        __hip_atomic_store(r.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch on this stream
+    }
+}
+
 // Every kernel launch of the library goes through DASR_LAUNCH.  While a profiling session is open (dasr_prof_begin, used by
 // bench.py for the `roofline` block) the launch carries its own start/stop events (hipExtLaunchKernelGGL: the dispatch's own
 // begin/end timestamps, the same ones rocprofv3 --kernel-trace reports); otherwise it is a plain launch.

@@ -405,7 +405,7 @@ __global__ void bnorm_running_kernel(const float* __restrict__ stats, int g, int
 // ---------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ void gan_loss_kernel(dasr_tensor x, int N, int C, int H, int W, float target, float coef, float gcoef, float* loss_acc,
-                                float* score_acc, float score_coef, dasr_tensor grad) {
+                                float* score_acc, float score_coef, dasr_tensor grad, dasr_red rs) {
     __shared__ float red[4];
     const long long total = (long long)N * H * W;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -438,12 +438,10 @@ __global__ void gan_loss_kernel(dasr_tensor x, int N, int C, int H, int W, float
             for (int j = 0; j < 4; ++j) ((f32x4*)gp)[j] = f32x4{g[4 * j], g[4 * j + 1], g[4 * j + 2], g[4 * j + 3]};
         }
     }
-    const float tl = block_sum_256(l, red);
-    const float ts = block_sum_256(sc, red);
-    if (threadIdx.x == 0) {
-        if (loss_acc) atomicAdd(loss_acc, tl * coef);
-        if (score_acc) atomicAdd(score_acc, ts * score_coef);
-    }
+    const float v[2] = {block_sum_256(l, red), block_sum_256(sc, red)};
+    float* const acc[2] = {loss_acc, score_acc};
+    const float cf[2] = {coef, score_coef};
+    grid_sum_commit<2>(rs, v, acc, cf);   // fixed-order sums over the grid (common.h)
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -485,7 +483,7 @@ __device__ __forceinline__ void rel_term(float z, float t, float eps, float& l, 
 template <int FORM>
 __global__ void ragan_kernel(dasr_tensor a, dasr_tensor b, int N, int H, int W, int stage, float inv_nglob, float ta, float tb, float coef, float gcoef,
                              float eps, float* __restrict__ sums, float* __restrict__ part, float* loss_acc, float* score_a, float* score_b,
-                             float score_coef, dasr_tensor ga, dasr_tensor gb) {
+                             float score_coef, dasr_tensor ga, dasr_tensor gb, dasr_red rs) {
     __shared__ float red[4];
     const int HW = H * W;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -536,12 +534,10 @@ __global__ void ragan_kernel(dasr_tensor a, dasr_tensor b, int N, int H, int W, 
         }
     }
     if (stage == 1) {
-        const float tl = block_sum_256(l, red), t1 = block_sum_256(sca, red), t2 = block_sum_256(scb, red);
-        if (threadIdx.x == 0) {
-            if (loss_acc) atomicAdd(loss_acc, tl * coef);
-            if (score_a) atomicAdd(score_a, t1 * score_coef);
-            if (score_b) atomicAdd(score_b, t2 * score_coef);
-        }
+        const float v[3] = {block_sum_256(l, red), block_sum_256(sca, red), block_sum_256(scb, red)};
+        float* const acc[3] = {loss_acc, score_a, score_b};
+        const float cf[3] = {coef, score_coef, score_coef};
+        grid_sum_commit<3>(rs, v, acc, cf);
     }
 }
 
@@ -866,7 +862,7 @@ __global__ void maxpool_bwd_split_kernel(dasr_tensor x, dasr_tensor gy, int N, i
 // L1 between two blocked tensors over all C channels: loss_acc += coef*sum|a-b|; ga = gcoef*sign(a-b)
 template <typename T>
 __global__ void l1_diff_kernel(dasr_tensor a, dasr_tensor b, int N, int C, int H, int W, float coef, float gcoef, float* loss_acc, dasr_tensor ga,
-                               int squared) {
+                               int squared, dasr_red rs) {
     __shared__ float red[4];
     const int ncb = (C + 15) >> 4;
     const long long per = (long long)H * W * 4;
@@ -894,8 +890,10 @@ __global__ void l1_diff_kernel(dasr_tensor a, dasr_tensor b, int N, int C, int H
             for (int j = 0; j < 4; ++j) gp[j] = (T)g[j];
         }
     }
-    const float tl = block_sum_256(l, red);
-    if (threadIdx.x == 0 && loss_acc) atomicAdd(loss_acc, tl * coef);
+    const float v[1] = {block_sum_256(l, red)};
+    float* const acc[1] = {loss_acc};
+    const float cf[1] = {coef};
+    grid_sum_commit<1>(rs, v, acc, cf);
 }
 
 // y[c] = x[c] * sc[c] + sh[c] on C (<=4) channels of plane 0 (VGG input normalisation and its adjoint);
@@ -960,7 +958,7 @@ __global__ void bilinear_up_kernel(const float* __restrict__ src, int N, int h, 
 // mode 0: l = -log(p + eps); mode 1: l = -log(1 - p + eps), p = sigmoid(x) on channel 0.
 // loss_acc += coef*sum(l); score_acc += score_coef*sum(p); grad (+)= gcoef * dl/dx
 __global__ void logloss_kernel(dasr_tensor x, int N, int H, int W, int mode, float eps, float coef, float gcoef, float* loss_acc,
-                               float* score_acc, float score_coef, dasr_tensor grad, int accumulate) {
+                               float* score_acc, float score_coef, dasr_tensor grad, int accumulate, dasr_red rs) {
     __shared__ float red[4];
     const long long total = (long long)N * H * W;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -989,12 +987,10 @@ __global__ void logloss_kernel(dasr_tensor x, int N, int H, int W, int mode, flo
             if (!accumulate) { ((f32x4*)gp)[1] = z; ((f32x4*)gp)[2] = z; ((f32x4*)gp)[3] = z; }
         }
     }
-    const float tl = block_sum_256(l, red);
-    const float ts = block_sum_256(sc, red);
-    if (threadIdx.x == 0) {
-        if (loss_acc) atomicAdd(loss_acc, tl * coef);
-        if (score_acc) atomicAdd(score_acc, ts * score_coef);
-    }
+    const float v[2] = {block_sum_256(l, red), block_sum_256(sc, red)};
+    float* const acc[2] = {loss_acc, score_acc};
+    const float cf[2] = {coef, score_coef};
+    grid_sum_commit<2>(rs, v, acc, cf);   // fixed-order sums over the grid (common.h)
 }
 
 // gz = g * y * (1 - y) on C (<= 4) channels of plane 0 (y = sigmoid output of the generator, model.py:55)
@@ -1179,12 +1175,15 @@ extern "C" int dasr_gan_loss(dasr_tensor x, int32_t N, int32_t C, int32_t H, int
     const long long total = (long long)N * H * W;
     if (total <= 0 || C > 16 || gan_type < 0 || gan_type > 2) return DASR_EINVAL;
     const dim3 g(nblk(total)), b(256);
+    const void* key = loss_acc ? (const void*)loss_acc : (const void*)score_acc;
+    const dasr_red rs = dasr_red_scratch(key, as_stream(stream), g.x, 2);
+    if (key && !rs.part) return DASR_EINVAL;
     if (gan_type == 0)
-        DASR_LAUNCH(gan_loss_kernel<0>, g, b, 0, as_stream(stream), x, N, C, H, W, target, coef, gcoef, loss_acc, score_acc, score_coef, grad);
+        DASR_LAUNCH(gan_loss_kernel<0>, g, b, 0, as_stream(stream), x, N, C, H, W, target, coef, gcoef, loss_acc, score_acc, score_coef, grad, rs);
     else if (gan_type == 1)
-        DASR_LAUNCH(gan_loss_kernel<1>, g, b, 0, as_stream(stream), x, N, C, H, W, target, coef, gcoef, loss_acc, score_acc, score_coef, grad);
+        DASR_LAUNCH(gan_loss_kernel<1>, g, b, 0, as_stream(stream), x, N, C, H, W, target, coef, gcoef, loss_acc, score_acc, score_coef, grad, rs);
     else
-        DASR_LAUNCH(gan_loss_kernel<2>, g, b, 0, as_stream(stream), x, N, C, H, W, target, coef, gcoef, loss_acc, score_acc, score_coef, grad);
+        DASR_LAUNCH(gan_loss_kernel<2>, g, b, 0, as_stream(stream), x, N, C, H, W, target, coef, gcoef, loss_acc, score_acc, score_coef, grad, rs);
     return (int)hipGetLastError();
 }
 
@@ -1199,9 +1198,12 @@ extern "C" int dasr_ragan(dasr_tensor a, dasr_tensor b, int32_t N, int32_t H, in
     if (N <= 0 || H <= 0 || W <= 0 || n_glob < N || stage < 0 || stage > 2 || form < 0 || form > 3 || !a.p || !b.p || !sums || (stage > 0 && !part))
         return DASR_EINVAL;
     const dim3 g(nblk((long long)H * W)), blk(256);
+    const void* key = stage != 1 ? nullptr : (loss_acc ? (const void*)loss_acc : (score_a ? (const void*)score_a : (const void*)score_b));
+    const dasr_red rs = dasr_red_scratch(key, as_stream(stream), g.x, 3);
+    if (key && !rs.part) return DASR_EINVAL;
 #define DASR_RAGAN_FORM(F)                                                                                                                        \
     DASR_LAUNCH(ragan_kernel<F>, g, blk, 0, as_stream(stream), a, b, N, H, W, stage, 1.f / (float)n_glob, ta, tb, coef, gcoef, eps, sums, part, \
-                loss_acc, score_a, score_b, score_coef, ga, gb)
+                loss_acc, score_a, score_b, score_coef, ga, gb, rs)
     switch (form) {
         case 0: DASR_RAGAN_FORM(0); break;
         case 1: DASR_RAGAN_FORM(1); break;
@@ -1269,8 +1271,10 @@ extern "C" int dasr_l1_diff(dasr_tensor a, dasr_tensor b, int32_t is_f32, int32_
     is_f32 &= 1;
     const long long total = (long long)N * ((C + 15) / 16) * H * W * 4;
     if (total <= 0) return DASR_EINVAL;
-    if (is_f32) DASR_LAUNCH(l1_diff_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), a, b, N, C, H, W, coef, gcoef, loss_acc, ga, squared);
-    else DASR_LAUNCH(l1_diff_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), a, b, N, C, H, W, coef, gcoef, loss_acc, ga, squared);
+    const dasr_red rs = dasr_red_scratch(loss_acc, as_stream(stream), nblk(total), 1);
+    if (loss_acc && !rs.part) return DASR_EINVAL;
+    if (is_f32) DASR_LAUNCH(l1_diff_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), a, b, N, C, H, W, coef, gcoef, loss_acc, ga, squared, rs);
+    else DASR_LAUNCH(l1_diff_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), a, b, N, C, H, W, coef, gcoef, loss_acc, ga, squared, rs);
     return (int)hipGetLastError();
 }
 
@@ -1347,8 +1351,11 @@ extern "C" int dasr_logloss(dasr_tensor x, int32_t N, int32_t H, int32_t W, int3
                             float* score_acc, float score_coef, dasr_tensor grad, int32_t accumulate, void* stream) {
     const long long total = (long long)N * H * W;
     if (total <= 0) return DASR_EINVAL;
+    const void* key = loss_acc ? (const void*)loss_acc : (const void*)score_acc;
+    const dasr_red rs = dasr_red_scratch(key, as_stream(stream), nblk(total), 2);
+    if (key && !rs.part) return DASR_EINVAL;
     DASR_LAUNCH(logloss_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, H, W, mode, eps, coef, gcoef, loss_acc, score_acc,
-                       score_coef, grad, accumulate);
+                       score_coef, grad, accumulate, rs);
     return (int)hipGetLastError();
 }
 

@@ -159,7 +159,7 @@ __global__ void maxpool3s2_bwd_kernel(dasr_tensor x, dasr_tensor gy, int N, int 
 //   g0_c = gcoef * [ a_c / s_0 - f0_c * (sum_k a_k f0_k) / (sqrt(sum f0^2) * s_0^2) ],  a_c = 2 w_c (u_c - v_c),  zero where f0_c <= 0 when relu_mask
 // (the gradient handed on is w.r.t. the PRE-activation of the ReLU that produced f0, like the conv data-gradient epilogues expect)
 __global__ void lpips_head_kernel(dasr_tensor f, long long pair_off, int N, int C, int H, int W, const float* __restrict__ lin, float eps, float coef,
-                                  float gcoef, float* loss_acc, dasr_tensor g0, int relu_mask) {
+                                  float gcoef, float* loss_acc, dasr_tensor g0, int relu_mask, dasr_red rs) {
     __shared__ float red[4];
     const int ncb = C >> 4;
     const long long total = (long long)N * H * W;
@@ -215,8 +215,10 @@ __global__ void lpips_head_kernel(dasr_tensor f, long long pair_off, int N, int 
             }
         }
     }
-    const float t = block_sum_256(val, red);
-    if (threadIdx.x == 0 && loss_acc) atomicAdd(loss_acc, t * coef);
+    const float v[1] = {block_sum_256(val, red)};
+    float* const acc[1] = {loss_acc};
+    const float cf[1] = {coef};
+    grid_sum_commit<1>(rs, v, acc, cf);   // fixed-order sum over the grid (common.h)
 }
 
 }  // namespace
@@ -252,7 +254,9 @@ extern "C" int dasr_lpips_head(dasr_tensor f, int64_t pair_off, int32_t N, int32
                                float gcoef, float* loss_acc, dasr_tensor g0, int32_t relu_mask, void* stream) {
     if (N <= 0 || C <= 0 || (C & 15) || H <= 0 || W <= 0 || !lin) return DASR_EINVAL;
     const long long total = (long long)N * H * W;
+    const dasr_red rs = dasr_red_scratch(loss_acc, as_stream(stream), nblk(total), 1);
+    if (loss_acc && !rs.part) return DASR_EINVAL;
     DASR_LAUNCH(lpips_head_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), f, (long long)pair_off, N, C, H, W, lin, eps, coef, gcoef, loss_acc,
-                g0, relu_mask);
+                g0, relu_mask, rs);
     return (int)hipGetLastError();
 }

@@ -2,8 +2,10 @@
 #include "common.h"
 #include <atomic>
 #include <condition_variable>
+#include <map>
 #include <mutex>
 #include <thread>
+#include <tuple>
 
 namespace {
 
@@ -126,7 +128,7 @@ __global__ void blocked_to_nchw_kernel(dasr_tensor s, int N, int C, int H, int W
 
 // one thread per pixel (plane 0 only: C <= 16)
 __global__ void l1_loss_kernel(dasr_tensor sr, const float* __restrict__ hr, const float* __restrict__ wm, int N, int C, int H, int W,
-                               float coef, float* loss_acc, dasr_tensor grad, int accumulate) {
+                               float coef, float* loss_acc, dasr_tensor grad, int accumulate, dasr_red rs) {
     const long long total = (long long)N * H * W;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     float part = 0.f;
@@ -165,7 +167,10 @@ __global__ void l1_loss_kernel(dasr_tensor sr, const float* __restrict__ hr, con
     __shared__ float red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
     __syncthreads();
-    if (threadIdx.x == 0 && loss_acc) atomicAdd(loss_acc, (red[0] + red[1] + red[2] + red[3]) * coef);
+    const float v[1] = {red[0] + red[1] + red[2] + red[3]};
+    float* const acc[1] = {loss_acc};
+    const float cf[1] = {coef};
+    grid_sum_commit<1>(rs, v, acc, cf);   // loss_acc += coef * (sum over the grid), summed in a fixed order
 }
 
 // thread per (n, cb, y, x) at the LOW resolution
@@ -237,7 +242,10 @@ __global__ void axpby_kernel(dasr_tensor x, float a, dasr_tensor z, float b, int
 }
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            long long n, float step_size, float beta1, float beta2, float eps, float wd, float inv_sqrt_bc2, int* __restrict__ nonfinite) {
+                            long long n, float step_size, float beta1, float beta2, float eps, float wd, float inv_sqrt_bc2, int* __restrict__ nonfinite,
+                            const int* __restrict__ gate) {
+    if (gate && *gate != 0) return;   // (wave-uniform scalar load) the gradients of this step are not valid -- e.g. a chained trunk launch flagged a broken
+                                      // neighbour wait: weights and moments stay untouched until the host has looked at the word
     bool bad = false;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float gi = g[i];
@@ -293,8 +301,10 @@ extern "C" int dasr_l1_loss(dasr_tensor sr, const float* hr_nchw, const float* w
                             float coef, float* loss_acc, dasr_tensor grad, int32_t accumulate, void* stream) {
     const long long total = (long long)N * H * W;
     if (total <= 0 || C > 16) return DASR_EINVAL;
+    const dasr_red rs = dasr_red_scratch(loss_acc, as_stream(stream), blocks_for(total), 1);
+    if (loss_acc && !rs.part) return DASR_EINVAL;
     DASR_LAUNCH(l1_loss_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), sr, hr_nchw, weight_map, N, C, H, W, coef,
-                       loss_acc, grad, accumulate);
+                       loss_acc, grad, accumulate, rs);
     return (int)hipGetLastError();
 }
 
@@ -508,14 +518,14 @@ extern "C" int dasr_axpby(dasr_tensor x, float a, dasr_tensor z, float b, int32_
 }
 
 extern "C" int dasr_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                         float weight_decay, int32_t step, int32_t* nonfinite_flag, void* stream) {
+                         float weight_decay, int32_t step, int32_t* nonfinite_flag, const int32_t* gate_flag, void* stream) {
     if (n <= 0 || step <= 0) return DASR_EINVAL;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     DASR_LAUNCH(adam_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p, g, m, v, (long long)n, step_size, beta1, beta2, eps,
-                       weight_decay, inv_sqrt_bc2, nonfinite_flag);
+                       weight_decay, inv_sqrt_bc2, nonfinite_flag, gate_flag);
     return (int)hipGetLastError();
 }
 
@@ -589,6 +599,40 @@ extern "C" int dasr_abi_version(void) { return DASR_ABI_VERSION; }
 
 static thread_local int g_last_failed_op = -1;   // per enqueue thread; dasr_run_ops_mt copies the failing list's value to its caller
 extern "C" int dasr_last_failed_op(void) { return g_last_failed_op; }
+
+// ---- scratch rows of the deterministic grid sums (grid_sum_commit, common.h) -------------------------------------------------
+// One row per (device, accumulator address, stream): launches that use the same row are ordered by their stream, so a row is never shared by two
+// kernels in flight; rows are allocated on first use (the warm-up steps) and only ever grow (the old allocation of a grown row stays alive: a kernel
+// enqueued earlier may still write it).  [ticket word | pad to 256 B | K x nblocks partials]
+namespace {
+struct RedRow {
+    char* base;
+    size_t floats;
+};
+std::mutex g_red_mu;
+std::map<std::tuple<int, const void*, hipStream_t>, RedRow> g_red_rows;
+}  // namespace
+
+dasr_red dasr_red_scratch(const void* key_acc, hipStream_t s, unsigned nblocks, int k) {
+    dasr_red r = {nullptr, nullptr};
+    if (!key_acc || nblocks == 0 || k <= 0) return r;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return r;
+    const size_t need = (size_t)k * nblocks;
+    std::lock_guard<std::mutex> lock(g_red_mu);
+    RedRow& row = g_red_rows[std::make_tuple(dev, key_acc, s)];
+    if (!row.base || row.floats < need) {
+        const size_t cap = need < 4096 ? 4096 : need + need / 2;
+        char* nb = nullptr;
+        if (hipMalloc((void**)&nb, 256 + cap * sizeof(float)) != hipSuccess) return r;   // (a launcher that gets no row reports DASR_EINVAL)
+        if (hipMemset(nb, 0, 256) != hipSuccess) return r;
+        row.base = nb;   // the previous allocation is kept (see above)
+        row.floats = cap;
+    }
+    r.ticket = (unsigned*)row.base;
+    r.part = (float*)(row.base + 256);
+    return r;
+}
 
 // ---- profiling session (see DASR_LAUNCH in common.h) ------------------------------------------------------------------------
 namespace {

@@ -154,14 +154,14 @@ class DASR_Model(BaseModel):
             self.G_update_inter = t['G_update_inter'] or 1
             self.D_update_inter = t['D_update_inter'] or 1
             wd_G = t['weight_decay_G'] or 0
-            self.optimizer_G = AdamHIP(self.netG.params, t['lr_G'], (t['beta1_G'], 0.999), wd_G)
+            self.optimizer_G = AdamHIP(self.netG.params, t['lr_G'], (t['beta1_G'], 0.999), wd_G, gate=self.netG.chain_err)
             self.optimizers.append(self.optimizer_G)
             if self.netD_target is not None:
                 wd_D = t['weight_decay_D'] or 0
-                self.optimizer_D_target = AdamHIP(self.netD_target.params, t['lr_D'], (t['beta1_D'], 0.999), wd_D)
+                self.optimizer_D_target = AdamHIP(self.netD_target.params, t['lr_D'], (t['beta1_D'], 0.999), wd_D, gate=self.netG.chain_err)   # (its input is G's output)
                 self.optimizers.append(self.optimizer_D_target)
             if self.netD_source is not None:   # DASR_model.py:139-143
-                self.optimizer_D_source = AdamHIP(self.netD_source.params, t['lr_D'], (t['beta1_D'], 0.999), t['weight_decay_D'] or 0)
+                self.optimizer_D_source = AdamHIP(self.netD_source.params, t['lr_D'], (t['beta1_D'], 0.999), t['weight_decay_D'] or 0, gate=self.netG.chain_err)
                 self.optimizers.append(self.optimizer_D_source)
             if t['lr_scheme'] != 'MultiStepLR':
                 raise NotImplementedError('MultiStepLR learning rate scheme is enough.')
@@ -230,10 +230,7 @@ class DASR_Model(BaseModel):
             if not dp_on:
                 P.g.bwd.run()
             else:
-                for seg, (lo, hi) in P.g.bwd_segments():
-                    seg.run()
-                    self.dp.reduce_async(gG[lo:hi])
-                self.dp.wait()
+                P.g.run_backward_dp(self.dp, gG)   # bucket-wise exchange overlapped with the backward, never across a chained launch
             self.optimizer_G.step(self.schedulers[0].get_lr())
             self.netG.repack()
         if do_d:

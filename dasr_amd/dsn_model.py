@@ -532,6 +532,11 @@ class DSNModel:
         P.bic_nchw.copy_(bicubic_lr)
         P.real_nchw.copy_(real_lr)
         dp_on = self.dp is not None and self.dp.active
+        if self.wgan and dp_on and self.dp.world > 1:
+            # the reference (one process) takes ONE gradient norm over the whole batch: || d mean_global D / d sample ||.  A per-rank norm over the local
+            # shard is ~sqrt(world) times larger, so 10 (||g|| - 1)^2 and its weight gradients would silently differ; the exchange of
+            # sum ||g_r||^2 between the norm and the tangent / reverse pass is not built
+            raise NotImplementedError('--wgan under data parallelism (world %d): the gradient penalty needs the norm over the global batch' % self.dp.world)
         scale = self.dp.grad_scale if dp_on else 1.0
         if scale != P.scale:
             P.set_grad_scale(scale)

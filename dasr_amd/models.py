@@ -66,8 +66,11 @@ class MultiStepLR:
 class AdamHIP:
     """torch.optim.Adam (eps 1e-8, no amsgrad, L2 weight decay) over a ParamStore's flat buffers."""
 
-    def __init__(self, params, lr, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8):
+    def __init__(self, params, lr, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8, gate=None):
+        """gate: device int32 word; while it is non-zero a step changes nothing (dasr_adam gate_flag).  The trainers pass the error word of the
+        generator's chained trunk launches (RRDBNetHIP.chain_err): a step whose trunk ran behind a broken neighbour wait never reaches the weights."""
         self.params, self.lr, self.betas, self.wd, self.eps = params, lr, betas, weight_decay, eps
+        self.gate = gate
         self.step_count = 0
         self.nonfinite = torch.zeros(1, dtype=torch.int32, device=params.device)   # set by the kernel when a gradient element is inf / NaN
 
@@ -75,7 +78,8 @@ class AdamHIP:
         self.step_count += 1
         P = self.params
         _lib.check(_lib.lib().dasr_adam(P.flat.data_ptr(), P.grad.data_ptr(), P.m.data_ptr(), P.v.data_ptr(), P.total, lr,
-                                        self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, self.nonfinite.data_ptr(), _stream()), 'adam')
+                                        self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, self.nonfinite.data_ptr(),
+                                        self.gate.data_ptr() if self.gate is not None else None, _stream()), 'adam')
 
     def check_finite(self, what='generator', hint=None):
         """a non-finite gradient has reached the optimiser since the last check?  Costs one device->host sync: called where the trainer
@@ -163,6 +167,8 @@ class BaseModel:
     def save_network(self, network, network_label, iter_step):
         """{iter}_{label}.pth = plain state_dict of CPU tensors (base_model.py:49-58)."""
         path = os.path.join(self.opt['path']['models'], '{}_{}.pth'.format(iter_step, network_label))
+        if hasattr(self, 'check_finite'):
+            self.check_finite()   # (host sync) never write weights behind a non-finite gradient or an invalid chained launch (ADVICE r04)
         torch.save(network.state_dict(), path)
 
     def load_network(self, load_path, network, strict=True):
@@ -219,7 +225,7 @@ class SRModel(BaseModel):
             self.l_pix_w = t['pixel_weight']
             self.netG.loss_weight = float(self.l_pix_w or 1.0)   # sizes the f16 pre-scale of the dense-block gradients when DASR_RDB_PREC=2 (TrunkStore.gscale)
             wd = t['weight_decay_G'] if t['weight_decay_G'] else 0
-            self.optimizer_G = AdamHIP(self.netG.params, t['lr_G'], (0.9, 0.999), wd)
+            self.optimizer_G = AdamHIP(self.netG.params, t['lr_G'], (0.9, 0.999), wd, gate=self.netG.chain_err)
             self.optimizers.append(self.optimizer_G)
             if t['lr_scheme'] != 'MultiStepLR':
                 raise NotImplementedError('MultiStepLR learning rate scheme is enough.')
@@ -335,11 +341,7 @@ class SRModel(BaseModel):
                 plan.bwd.run()
             else:
                 plan.set_grad_scale(self.dp.grad_scale)
-                g = self.netG.params.grad
-                for seg, (lo, hi) in plan.bwd_segments():
-                    seg.run()
-                    self.dp.reduce_async(g[lo:hi])
-                self.dp.wait()
+                plan.run_backward_dp(self.dp, self.netG.params.grad)   # bucket-wise exchange overlapped with the backward, never across a chained launch
         else:
             if len(getattr(self, '_streams', ())) != len(plans):
                 self._streams = [torch.cuda.Stream() for _ in plans]

@@ -58,6 +58,10 @@ class RRDBNetHIP:
         # DASR_CHAIN (default 1): the trunk's dense-block convs, forward and data gradient, as persistent chained launches where the batch fills the chip
         # exactly (chain_ok; _Plan._build_forward).  bf16 storage only: the f16 path re-patches scale factors of recorded ops (TrunkStore.set_gscale_from)
         self.chain = os.environ.get('DASR_CHAIN', '1') == '1' and not self.rdb_f16
+        # ONE error word for every chained launch of this network (all plans): non-zero = a neighbour wait gave up, the step's results are not valid.
+        # The optimisers that depend on this generator take it as their gate (AdamHIP(gate=...): such a step never reaches the weights); the trainers
+        # read it where they synchronise anyway (log interval, checkpoints) and raise (check_chain).
+        self.chain_err = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.hr_prec = int(os.environ.get('DASR_HR_PREC', '2')) if stream_prec == 3 else stream_prec
         # hr_prec 2 (default): f16 STORAGE of the HR tail (u1, u2, h0 and their gradients live in HBM as f16): the consumers run on the LDS-DMA
         # dense-conv kernel / the grouped wgrad kernel with the f16 MFMA, and the HR tensors cost half the bytes.  DASR_HR_PREC=3 (numerics
@@ -153,6 +157,9 @@ class RRDBNetHIP:
     def chain_ok(self, N, h, w):
         """a training plan of this shape runs its trunk as chained launches: whole images per XCD and the launch fills the chip exactly (dasr_conv_chain)"""
         if not (self.chain and N % 8 == 0 and N * ceil_div(h, 16) * ceil_div(w, 32) == 512 and not getattr(self, 'debug_taps', ())):
+            return False
+        from . import dist as _dist
+        if _dist.SHARED_DEVICE:   # another rank of this job runs on the same GPU (gloo test set-up): the launch would not have the chip to itself
             return False
         if not hasattr(self, '_cus'):   # 512 workgroups = 2 per CU of a whole MI355X (8 XCDs x 32 CUs); a partitioned device (CPX / DPX) has fewer
             self._cus = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == 'cuda' else 0
@@ -525,7 +532,7 @@ class _Plan:
             body = [o for o in trunk_ops.ops if o.op == _lib.OP_CONV]
             assert len(body) == len(trunk_ops.ops) == 15 * nb
             deps = [0 if k % 5 == 0 else (o.conv.cin // 16) - GC // 16 for k, o in enumerate(body)]
-            self.chain = ConvChain(body[:-1], deps[:-1], N, tiles, net.device)   # (the last conv5 has no 16-bit shadow to write: its own launch)
+            self.chain = ConvChain(body[:-1], deps[:-1], N, tiles, net.device, err=net.chain_err)   # (the last conv5 has no 16-bit shadow to write: its own launch)
             ops.add(self.chain.op())
             ops.add(body[-1])
             ops.keep.append(self.chain)
@@ -841,6 +848,27 @@ class _Plan:
             self.bwd._arr = None
             self._segments = None
         return changed
+
+    def run_backward_dp(self, dp, g):
+        """the backward list in gradient-bucket segments, every finished bucket handed to the exchange (dp.reduce_async: SUM all-reduce on the
+        communication stream, overlapped with the segments that follow) -- EXCEPT across a chained launch: dasr_conv_chain needs every workgroup slot
+        of the device for its 512 resident workgroups, and a collective's kernels in flight on the communication stream would hold some of them
+        (VERDICT / ADVICE r04).  A bucket that is complete in front of a segment with a chained launch is therefore held back and handed over together
+        with that segment's own bucket: its event is recorded behind the chain, so the exchange overlaps the grouped weight-gradient launches only.
+        (The forward chain of the next step is safe by the same rule: the trainers wait for the communication stream -- dp.wait() -- in front of the
+        optimiser step.)"""
+        segs = self.bwd_segments()
+        has_chain = [any(o.op == _lib.OP_CONV_CHAIN for o in seg.ops) for seg, _ in segs]
+        held = []
+        for k, (seg, (lo, hi)) in enumerate(segs):
+            seg.run()
+            held.append((lo, hi))
+            if k + 1 < len(segs) and has_chain[k + 1]:
+                continue
+            for a, b in held:
+                dp.reduce_async(g[a:b])
+            held = []
+        dp.wait()
 
     def bwd_segments(self):
         """backward op list cut at gradient-bucket boundaries: [(OpList, (lo, hi) of the flat grad buffer that is

@@ -29,11 +29,49 @@ def _crc32c_table():
 _TAB = _crc32c_table()
 
 
-def crc32c(data):
-    c = 0xFFFFFFFF
+def _crc_bytes(c, data):
     for b in data:
         c = _TAB[(c ^ b) & 0xFF] ^ (c >> 8)
-    return c ^ 0xFFFFFFFF
+    return c
+
+
+_ZERO_OPS = {}   # L -> [4][256] tables: register value after L zero bytes, per byte lane of the start value (the update is linear over GF(2))
+
+
+def _zero_advance_tables(L):
+    import numpy as np
+    if L not in _ZERO_OPS:
+        tab = np.array(_TAB, dtype=np.uint32)
+        c = (np.arange(256, dtype=np.uint32)[None, :] << (8 * np.arange(4, dtype=np.uint32))[:, None]).reshape(-1)
+        for _ in range(L):
+            c = tab[c & 0xFF] ^ (c >> 8)
+        _ZERO_OPS[L] = [[int(v) for v in row] for row in c.reshape(4, 256)]
+    return _ZERO_OPS[L]
+
+
+def crc32c(data):
+    """CRC-32C (Castagnoli) of a bytes-like object.  Records of a few KB go through the byte loop; the MB-sized PNG payloads of add_image
+    (validation grids, training samples) are cut into 1024 equal chunks whose registers advance TOGETHER, one numpy table look-up per byte position,
+    and are then chained with the 'L zero bytes' operator -- the update is linear over GF(2): state(s, D) = state(s, 0^|D|) xor state(0, D).
+    (The per-byte Python loop cost seconds per image on rank 0 while the other data-parallel ranks waited at the next collective)"""
+    n = len(data)
+    K = 1024
+    if n < 16 * K:
+        return _crc_bytes(0xFFFFFFFF, data) ^ 0xFFFFFFFF
+    import numpy as np
+    L = n // K
+    a = np.frombuffer(bytes(data[:K * L]) if not isinstance(data, bytes) else data[:K * L], dtype=np.uint8).reshape(K, L)
+    tab = np.array(_TAB, dtype=np.uint32)
+    c = np.zeros(K, dtype=np.uint32)
+    c[0] = 0xFFFFFFFF
+    cols = np.ascontiguousarray(a.T)   # [L][K]: one row per byte position
+    for j in range(L):
+        c = tab[(c ^ cols[j]) & 0xFF] ^ (c >> 8)
+    Z = _zero_advance_tables(L)
+    s = int(c[0])
+    for k in range(1, K):
+        s = Z[0][s & 0xFF] ^ Z[1][(s >> 8) & 0xFF] ^ Z[2][(s >> 16) & 0xFF] ^ Z[3][s >> 24] ^ int(c[k])
+    return _crc_bytes(s, data[K * L:]) ^ 0xFFFFFFFF
 
 
 def masked_crc(data):

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DASR_ABI_VERSION 16
+#define DASR_ABI_VERSION 17
 #define DASR_EINVAL (-22)
 
 typedef struct {
@@ -236,9 +236,12 @@ int dasr_axpby(dasr_tensor x, float a, dasr_tensor z, float b, int32_t N, int32_
  * g += wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
  * nonfinite_flag (optional, device int): bit 0 is OR-ed in when any gradient element is inf / NaN (the update itself is what torch would do);
  * the trainers read it with their lazily synchronised log and raise -- e.g. an overflow of the f16-stored HR-tail gradients (DASR_HR_PREC=3
- * keeps that tail in split-bf16 on f32 tensors). */
+ * keeps that tail in split-bf16 on f32 tensors).
+ * gate_flag (optional, device int; ABI 17): when the word is non-zero the launch changes NOTHING (weights and moments untouched).  The trainers pass the
+ * error word of the generator's chained trunk launches (dasr_conv_chain `err`): gradients computed behind a broken neighbour wait never reach the
+ * weights; the host raises at its next synchronisation point (log interval, checkpoint). */
 int dasr_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-              float weight_decay, int32_t step, int32_t* nonfinite_flag, void* stream);
+              float weight_decay, int32_t step, int32_t* nonfinite_flag, const int32_t* gate_flag, void* stream);
 
 int dasr_fill_f32(float* p, int64_t n, float value, void* stream);
 /* y += x over flat fp32 buffers (sum of the gradient buffers of concurrently processed sub-batches) */

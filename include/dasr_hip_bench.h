@@ -26,6 +26,10 @@ int dasr_probe_mfma_data(int32_t iters, int32_t mode, float* tflops_out, void* s
 int dasr_probe_tile_sync(int32_t blocks, int32_t stages, int32_t nb_stride, int32_t scope, int32_t tile_words, float* us_per_stage,
                          int32_t* timed_out, int32_t* stale_reads, void* stream);
 
+/* `blocks` workgroups (256 threads) that only hold their slots for `micros` microseconds; asynchronous on `stream`.  Tests use it as a stand-in for a
+ * collective's kernels on the communication stream (the chained trunk launches of the product library need every workgroup slot of the device). */
+int dasr_probe_spin(int32_t blocks, int32_t micros, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,7 @@ def test_cfg1_step_batch16_equals_mean_of_halves_and_is_deterministic(chain, mar
         del m
         torch.cuda.empty_cache()
     assert torch.equal(grads[0], grads[1])                              # fixed-order reductions: bit-exact run to run
+    assert losses[0] == losses[1]                                      # ... and so is the logged loss (fixed-order grid sum, csrc/common.h)
     assert all(torch.isfinite(x).all() for x in grads) and 0.1 < losses[0] < 1.0   # x0.1 weights: |HR - small output| ~ 0.5
     e = rel(grads[0], 0.5 * (grads[2] + grads[3]))
     margins('configs[1] full size: grad(batch 16, %s) vs mean of the two batch-8 halves: rel err %.2e (tol 1e-5); losses %.6f vs %.6f' % (
@@ -103,6 +104,38 @@ def test_cfg2_gan_step_32_crops_equals_mean_of_halves(margins):
             'l_g_pix %.4f l_g_fea %.4f l_d %.4f' % (eG, eD, worst_log, log['loss/l_g_pix'], log['loss/l_g_fea'], log['loss/l_d_target_total']))
     assert all(v == v and abs(v) < 1e4 for v in log.values())
     assert eG < 1e-4 and eD < 1e-4 and worst_log < 1e-4
+
+
+def test_cfg2_gan_step_and_its_log_are_deterministic():
+    """configs[2] twice from the same weights and batch: gradients, weights AND every entry of get_current_log() bit-identical (the
+    logged terms were fp32 atomicAdd sums whose order varied from run to run; now fixed-order grid sums)"""
+    dev = _gpu()
+    from oracle import fixtures
+    from dasr_amd import options
+    from dasr_amd.models import create_model
+    case = dict(kind='dasr', nf=64, nb=23, n=16, lr=128, fs='wavelet', d_in_nc=9)
+    batch = fixtures.make_batch(case)
+    out = []
+    for _ in range(2):
+        opt = fixtures.make_opt(case)
+        opt['gpu_ids'] = [0]
+        opt['train']['vgg_seed'] = 77
+        m = create_model(options.dict_to_nonedict(opt))
+        m.netG.load_state_dict(fixtures.seeded_state_dict(m.netG.state_dict(), 1, 0.1))
+        m.netD_target.load_state_dict(fixtures.seeded_state_dict(m.netD_target.state_dict(), 2, 1.0))
+        for step in (1, 2):
+            m.update_learning_rate()
+            m.feed_data(batch, True)
+            m.optimize_parameters(step)
+        log = dict(m.get_current_log())
+        out.append((m.netG.params.grad.clone(), m.netD_target.params.grad.clone(), m.netG.params.flat.clone(), log))
+        del m
+        torch.cuda.empty_cache()
+    (gG, gD, wG, l0), (gG1, gD1, wG1, l1) = out
+    assert torch.equal(gG, gG1) and torch.equal(gD, gD1) and torch.equal(wG, wG1)
+    assert list(l0.keys()) == list(l1.keys()) and len(l0) >= 5
+    for k in l0:
+        assert l0[k] == l1[k], (k, l0[k], l1[k])
 
 
 @pytest.mark.parametrize('bwd16', [1, 0], ids=['f16_backward_default', 'fp32_tensor_backward'])

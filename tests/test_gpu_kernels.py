@@ -415,5 +415,5 @@ def test_elementwise_and_adam():
         pt.grad = gg.clone()
         opt.step()
         gd = gg.to(dev)
-        _lib.check(L.dasr_adam(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), 1000, 1e-3, 0.9, 0.999, 1e-8, 0.01, i + 1, None, _stream()))
+        _lib.check(L.dasr_adam(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), 1000, 1e-3, 0.9, 0.999, 1e-8, 0.01, i + 1, None, None, _stream()))
     assert torch.allclose(pd.cpu(), pt.detach(), rtol=1e-5, atol=1e-7)
