@@ -107,7 +107,9 @@ __device__ __forceinline__ void st128(u32x4 v, __amdgpu_buffer_rsrc_t r, unsigne
 
 // F16OUT: -1 = the 16-bit output format is a run-time (wave-uniform) choice; 0 / 1 = bf16 / f16 fixed at compile time (the dense-block LDS-DMA
 // kernels: the run-time form converted every element to BOTH formats and selected: 224 of the 628 VALU instructions of the Cout=32 epilogue)
-template <bool IN_F32, int MT, int NT, int STRIDE, int EPI, int F16OUT = -1, bool PRE = false, bool FSC1 = false>
+// BIAS_STAGED: the caller has already put the m-group's bias into LDS at `smem` and synchronised (conv_chain_kernel V2: staged in front of the last chunk
+// barrier of the main loop, in a region no DMA touches) -- no hand-over barrier here
+template <bool IN_F32, int MT, int NT, int STRIDE, int EPI, int F16OUT = -1, bool PRE = false, bool FSC1 = false, bool BIAS_STAGED = false>
 __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 (&acc)[MT][NT], char* smem, float bias_reg, int tid, int mg, int n,
                                               int oy0, int ox0, const MaskPre<NT * MT>* pre = nullptr) {
     const int lane = tid & 63, wave = tid >> 6, nn = lane & 31, kh2 = lane >> 5;
@@ -145,8 +147,10 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
     f32x4 bia[MT][4];
     if (has_bias) {
         float* bl = (float*)smem;
-        if (tid < 32 * MT) bl[tid] = bias_reg;
-        __syncthreads();
+        if constexpr (!BIAS_STAGED) {
+            if (tid < 32 * MT) bl[tid] = bias_reg;
+            __syncthreads();
+        }
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -1330,6 +1334,19 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
 // Co-residency: every workgroup of the launch must be resident (a waiting tile spins) and every XCD must host exactly its share: grid == 2 workgroups x
 // 256 CUs, checked by the launcher; a spin gives up after ~1 s and sets err bit 1 (the results are then wrong, the launch still ends).
 // ---------------------------------------------------------------------------------------------------
+#ifdef DASR_TRACE
+// per-workgroup accumulators of the chained launches: g_trace[2^20 + block * 64 + type * 8 + phase] (behind the per-launch stamps of the other kernels) (type 0 conv1 of a dense block, 1 conv2-4, 2 conv5-class;
+// phase 0 entry (flag wait + chunk-0 request), 1 chunk 0 landed, 2 main loop, 3 (inside 2) flag poll, 4 epilogue issue, 5 publish, 6 items, 7 chunks)
+#define CH_T() (g_trace && threadIdx.x == 0 ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
+#define CH_ACC(type, phase, val)                                                                           \
+    do {                                                                                                   \
+        if (g_trace && threadIdx.x == 0) g_trace[(size_t)(1 << 20) + (size_t)blockIdx.x * 64 + (type) * 8 + (phase)] += (val); \
+    } while (0)
+#else
+#define CH_T() 0ull
+#define CH_ACC(type, phase, val) do {} while (0)
+#endif
+
 struct ChainSync {
     __amdgpu_buffer_rsrc_t rflags;
     int* err;
@@ -1375,6 +1392,9 @@ __device__ __forceinline__ void chain_layer(const dasr_conv_params& p, char* sme
     static_assert(GCfg<1, 4>::AR == GCfg<2, 4>::AR, "the activation pieces do not depend on MT");
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nchunks = p.cin >> 4;
+    const int ttype = MT == 2 ? 2 : (dep_chunk <= 1 ? 0 : 1);
+    (void)ttype;
+    const unsigned long long t_a = CH_T();
     float bias_reg;
     {
         const unsigned bo = ((p.bias != nullptr) & (tid < 32 * MT)) ? (unsigned)tid * 4u : OOB;
@@ -1387,6 +1407,7 @@ __device__ __forceinline__ void chain_layer(const dasr_conv_params& p, char* sme
     if (dep_chunk <= 0) cs.wait(layer, tid);   // every input plane comes from the previous layer (conv1 of an RDB reads the previous conv5's shadow)
 #pragma unroll
     for (int i = 0; i < NP; ++i) glds_dma_piece<MT, NW>(i, 0, smem, rin, rw, goff, in_chunk_bytes, wave, tid, 0);
+    const unsigned long long t_b = CH_T();
     const int nn = lane & 31, kh2 = lane >> 5;
     int baddr[6][3];
 #pragma unroll
@@ -1437,12 +1458,19 @@ __device__ __forceinline__ void chain_layer(const dasr_conv_params& p, char* sme
     constexpr bool PRE = EPI == 68 && MT == 1;   // data gradient of conv1-4: the LeakyReLU' mask of the output tile is fetched during the last chunk (see conv_glds_kernel)
     MaskPre<NT * MT> mpre;
     bf16x8 fb[2][6], fa[2][MT];
+    const unsigned long long t_c = CH_T();
+    unsigned long long t_poll = 0;
+    (void)t_poll;
     for (int ck = 0; ck < nchunks; ++ck) {
         const char* buf = smem + (ck & 1) * C::BUF_BYTES;
         const char* wbuf = buf + C::ACT_BYTES;
         char* nbuf = smem + ((ck + 1) & 1) * C::BUF_BYTES;
         const bool more = ck + 1 < nchunks;
-        if (ck + 1 == dep_chunk) cs.wait(layer, tid);   // the next chunk is the first that holds the previous layer's output: the neighbours must have published it
+        if (ck + 1 == dep_chunk) {   // the next chunk is the first that holds the previous layer's output: the neighbours must have published it
+            const unsigned long long t0 = CH_T();
+            cs.wait(layer, tid);
+            t_poll += CH_T() - t0;
+        }
         if constexpr (PRE) {
             if (!more) mask_prefetch<MT, NT>(p, mpre, tid, 0, n, oy0, ox0);
         }
@@ -1476,8 +1504,20 @@ __device__ __forceinline__ void chain_layer(const dasr_conv_params& p, char* sme
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
     }
+    const unsigned long long t_d = CH_T();
     conv_epilogue<false, MT, NT, 1, R1_PRE ? (EPI & ~8) : EPI, F16 ? 1 : 0, PRE, true>(p, acc, smem, bias_reg, tid, 0, n, oy0, ox0, &mpre);
+    const unsigned long long t_e = CH_T();
     cs.publish(layer, tid);
+    const unsigned long long t_f = CH_T();
+    CH_ACC(ttype, 0, t_b - t_a);
+    CH_ACC(ttype, 1, t_c - t_b);
+    CH_ACC(ttype, 2, t_d - t_c);
+    CH_ACC(ttype, 3, t_poll);
+    CH_ACC(ttype, 4, t_e - t_d);
+    CH_ACC(ttype, 5, t_f - t_e);
+    CH_ACC(ttype, 6, 1ull);
+    CH_ACC(ttype, 7, (unsigned long long)nchunks);
+    (void)t_a; (void)t_b; (void)t_c; (void)t_d; (void)t_e; (void)t_f;
 }
 
 template <bool F16, bool BWD>
@@ -1535,6 +1575,307 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const dasr_conv_para
             if (p.mt == 1) chain_layer<1, 67, F16>(p, smem, tid, n, oy0, ox0, goff, dep, cs, L);
             else if (p.res2.p != nullptr) chain_layer<2, 249, F16>(p, smem, tid, n, oy0, ox0, goff, dep, cs, L);
             else chain_layer<2, 233, F16>(p, smem, tid, n, oy0, ox0, goff, dep, cs, L);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv_chain2_kernel (round 5): the chained launch, second form.  Same arithmetic, same tile / XCD / flag protocol as conv_chain_kernel; what changes is
+// what a workgroup does BETWEEN two main loops (~7 us of a ~18 us Cout-32 layer had the matrix pipe idle) and how many tiles it owns:
+//  * work items.  A workgroup owns `tpw` tiles (tiles j, j + 64, ... of its XCD's tile list) and walks the items (layer 0, tile 0), (layer 0, tile 1), ...,
+//    (layer 1, tile 0), ...: batches of 512 * tpw tiles (configs[2]: 32 crops of 128 x 128 = 1024) run chained too, not only the exact fit of configs[1].
+//    A wait always refers to an item that is strictly earlier in (layer, slot) order, so the walk cannot deadlock.
+//  * chunk 0 of the NEXT item is requested in front of the epilogue of the current one whenever it holds only planes that are at least two layers old
+//    (every item but conv1 of a dense block, whose 64 input channels all come from the layer before): the DMA round trip (~2 us under load) and the
+//    epilogue's store drain overlap, and the barrier that ends `publish` is also the barrier that says "chunk 0 is in LDS" -- the next main loop starts
+//    at once.  LDS: chunk k lives in buffer k & 1 at a FIXED offset (the 64-channel layout) for both workgroup shapes, all chunk counts are even, so the
+//    last chunk of an item sits in buffer 1 and buffer 0 is free when its main loop ends.
+//  * the bias is handed round through a 256-byte LDS area outside the chunk buffers, written in front of the LAST chunk barrier of the main loop: no
+//    separate hand-over barrier in the epilogue.
+//  * the neighbour-flag poll in the middle of a layer happens in front of the chunk barrier that precedes the first dependent request instead of
+//    bringing its own barrier.
+// Barriers per item: chunks + 1 (V1: chunks + 4).  Bit-identical results (same MFMA order, same epilogue arithmetic).
+// ---------------------------------------------------------------------------------------------------
+struct Chain2 {
+    static constexpr int BUF1 = GCfg<2, 4>::BUF_BYTES;              // offset of buffer 1 for BOTH workgroup shapes
+    static constexpr int XOFF = 2 * BUF1;                            // extra area: bias[64] floats, then f0[8] words
+    static constexpr int LDS_BYTES = XOFF + 512;
+    static constexpr int MAX_TPW = 8;
+};
+
+
+// the eight neighbours of tile (ty, tx) have published `target`: polled by lanes 0..8 of wave 0 (no barrier of its own: the caller's next barrier hands the
+// result to the other waves)
+__device__ __forceinline__ void chain_poll(const ChainSync& cs, int layer, int tid) {
+    if (layer > 0 && tid < 9 && tid != 4) {
+        const int y = cs.ty + tid / 3 - 1, x = cs.tx + tid % 3 - 1;
+        if ((y >= 0) & (y < cs.tiles_y) & (x >= 0) & (x < cs.tiles_x)) {
+            const unsigned off = (unsigned)(cs.base + y * cs.tiles_x + x) * 4u, target = cs.f0 + (unsigned)layer;
+            int spins = 0;
+            while ((int)(__builtin_amdgcn_raw_buffer_load_b32(cs.rflags, off, 0, 17) - target) < 0) {
+                __builtin_amdgcn_s_sleep(2);
+                ++spins;
+                if (spins > (1 << 21) || ((spins & 1023) == 0 && __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(cs.err), 0, 0, 17) != 0)) {
+                    atomicOr(cs.err, 2);
+                    break;
+                }
+            }
+        }
+    }
+}
+
+struct ChainNext {        // the item behind the current one, if its chunk 0 may be requested early.  Plain scalars, fetched from the layer table by the kernel
+    bool on;              // body (scalar loads through the __restrict__ kernel argument; through a pointer kept in a struct hipcc falls back to vector loads
+    const void* in;       // and a waterfall loop around the buffer descriptor)
+    long long n_stride;
+    const void* w;
+    int mt, n, oy0, ox0;
+};
+
+// chunk 0 (activations of tile (n, oy0, ox0) + weights) of the next item's layer into LDS buffer 0; mt = workgroup shape of that layer (run-time: the
+// requesting item may have the other one); Hin, Win: the chain's one geometry
+__device__ __forceinline__ void chain_request_chunk0(const ChainNext& nx, int Hin, int Win, char* smem, int tid, int wave) {
+    using C = GCfg<1, 4>;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc((const bf16_t*)nx.in + (size_t)nx.n * nx.n_stride);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(nx.w);
+    const int mt = nx.mt, oy0 = nx.oy0, ox0 = nx.ox0;
+#pragma unroll
+    for (int r = 0; r < C::AR; ++r) {
+        const int q = tid + r * C::NTH;
+        const int pp = q >> 1, h = (q & 1) ^ ((pp >> 3) & 1);
+        const int iy = pp / C::IW, ix = pp - iy * C::IW;
+        const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
+        const bool ok = (pp < C::NPIX) & (gy >= 0) & (gy < Hin) & (gx >= 0) & (gx < Win);
+        const unsigned go = ok ? (unsigned)(((gy * Win + gx) * 16 + 8 * h) * 2) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(smem + (r * C::NTH + wave * 64) * 16), 16, go, 0, 0, 0);
+    }
+    const int wpiece = 9 * mt * 64;
+#pragma unroll
+    for (int r = 0; r < GCfg<2, 4>::WR; ++r) {
+        if (r * C::NTH + wave * 64 < wpiece)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + C::ACT_BYTES + (r * C::NTH + wave * 64) * 16), 16, (unsigned)(tid + r * C::NTH) * 16u, 0, 0, 0);
+    }
+}
+
+template <int MT, int EPI, bool F16>
+__device__ __forceinline__ void chain_item(const dasr_conv_params& p, char* smem, const int tid, const int n, const int oy0, const int ox0, const int dep_chunk,
+                                           const ChainSync& cs, const int layer, const bool have0, const ChainNext& nx) {
+    using C = GCfg<MT, 4>;
+    constexpr int NT = C::NT, NW = 4;
+    constexpr int TYPE = MT == 2 ? 2 : -1;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchunks = p.cin >> 4;
+    const int ttype = TYPE >= 0 ? TYPE : (dep_chunk <= 1 ? 0 : 1);
+    (void)ttype;
+    const unsigned long long t_a = CH_T();
+    float bias_reg;
+    {
+        const unsigned bo = ((p.bias != nullptr) & (tid < 32 * MT)) ? (unsigned)tid * 4u : OOB;
+        bias_reg = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(make_rsrc(p.bias), bo, 0, 0));
+    }
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc((const bf16_t*)p.in.p + (size_t)n * p.in.n_stride);
+    const unsigned in_chunk_bytes = (unsigned)(p.in.cb_stride * 2);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w);
+    constexpr int NP = C::AR + C::WR;
+    unsigned goff[C::AR];
+#pragma unroll
+    for (int r = 0; r < C::AR; ++r) {
+        const int q = tid + r * C::NTH;
+        const int pp = q >> 1, h = (q & 1) ^ ((pp >> 3) & 1);
+        const int iy = pp / C::IW, ix = pp - iy * C::IW;
+        const int gy = oy0 - 1 + iy, gx = ox0 - 1 + ix;
+        const bool ok = (pp < C::NPIX) & (gy >= 0) & (gy < p.Hin) & (gx >= 0) & (gx < p.Win);
+        goff[r] = ok ? (unsigned)(((gy * p.Win + gx) * 16 + 8 * h) * 2) : OOB;
+    }
+    if (!have0) {
+        if (dep_chunk <= 1) {   // every input plane comes from the previous layer (conv1 of a dense block): the neighbours first
+            chain_poll(cs, layer, tid);
+            if (layer > 0) __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) glds_dma_piece<MT, NW>(i, 0, smem, rin, rw, goff, in_chunk_bytes, wave, tid, 0);
+    }
+    const unsigned long long t_b = CH_T();
+    const int nn = lane & 31, kh2 = lane >> 5;
+    int baddr[6][3];
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int pp = (wave * NT + rr) * C::IW + nn + kx;
+            baddr[rr][kx] = ((pp << 1) + (kh2 ^ ((pp >> 3) & 1))) << 4;
+        }
+    const int aoff = lane * 16;
+    f32x16 acc[MT][NT];
+    constexpr bool R1_PRE = MT == 2 && (EPI & 8);   // conv5: the fp32 residual lands in the accumulators (see conv_glds_kernel)
+    if constexpr (R1_PRE) {
+        const __amdgpu_buffer_rsrc_t rr1 = make_rsrc((const float*)p.res1.p + (size_t)n * p.res1.n_stride);
+        const unsigned r1_cb = (unsigned)p.res1.cb_stride;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int oy = oy0 + wave * NT + nt, ox = ox0 + nn;
+            const bool pv = (oy < p.Hout) & (ox < p.Wout);
+            const unsigned pixel = (unsigned)(oy * p.Wout + ox) * 16u;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int oc = mi * 32 + 8 * g + 4 * kh2;
+                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rr1, pv ? ((unsigned)(oc >> 4) * r1_cb + pixel + (unsigned)(oc & 15)) * 4u : OOB, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[mi][nt][4 * g + j] = __uint_as_float(t[j]);
+                }
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[mi][nt][j] = 0.f;
+    }
+    if (!have0) {   // (have0: the previous item's publish waited for this wave's pieces and its barrier covered all four waves)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+    }
+    if constexpr (R1_PRE) {
+        const float c1 = p.beta1 / p.alpha;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mi][nt] *= c1;
+    }
+    const unsigned long long t_c = CH_T();
+    unsigned long long t_poll = 0;
+    (void)t_poll;
+    constexpr bool PRE = EPI == 68 && MT == 1;
+    MaskPre<NT * MT> mpre;
+    bf16x8 fb[2][6], fa[2][MT];
+    float* bl = (float*)(smem + Chain2::XOFF);
+    for (int ck = 0; ck < nchunks; ++ck) {
+        const char* buf = smem + (ck & 1) * Chain2::BUF1;
+        const char* wbuf = buf + C::ACT_BYTES;
+        char* nbuf = smem + ((ck + 1) & 1) * Chain2::BUF1;
+        const bool more = ck + 1 < nchunks;
+        if constexpr (PRE) {
+            if (!more) mask_prefetch<MT, NT>(p, mpre, tid, 0, n, oy0, ox0);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) fb[0][rr] = *(const bf16x8*)(buf + baddr[rr][0]);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) fa[0][mi] = *(const bf16x8*)(wbuf + aoff + (0 * MT + mi) * 1024);
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            const int kx = s / 3, ky = s - kx * 3;
+            if (s + 1 < 9) {
+                const int kx1 = (s + 1) / 3, ky1 = (s + 1) - kx1 * 3;
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) fa[(s + 1) & 1][mi] = *(const bf16x8*)(wbuf + aoff + ((ky1 * 3 + kx1) * MT + mi) * 1024);
+                if (ky == 1 && kx < 2) {
+#pragma unroll
+                    for (int rr = 0; rr < 6; ++rr) fb[(kx + 1) & 1][rr] = *(const bf16x8*)(buf + baddr[rr][kx + 1]);
+                }
+            }
+            if (more && s < 4) {
+#pragma unroll
+                for (int i = s * NP / 4; i < (s + 1) * NP / 4; ++i) glds_dma_piece<MT, NW>(i, ck + 1, nbuf, rin, rw, goff, in_chunk_bytes, wave, tid, ck + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mi][nt] = mfma16<F16>(fa[s & 1][mi], fb[kx & 1][nt + ky], acc[mi][nt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ck + 2 == dep_chunk) {   // the request after next is the first that holds the previous layer's output: the neighbours must have published it
+            const unsigned long long t0 = CH_T();
+            chain_poll(cs, layer, tid);
+            t_poll += CH_T() - t0;
+        }
+        if (!more && tid < 32 * MT) bl[tid] = bias_reg;   // bias hand-over rides on the last chunk barrier
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+    }
+    const unsigned long long t_d = CH_T();
+    if (nx.on) chain_request_chunk0(nx, p.Hin, p.Win, smem, tid, wave);   // buffer 0 is free: the last chunk (odd index) sat in buffer 1
+    conv_epilogue<false, MT, NT, 1, R1_PRE ? (EPI & ~8) : EPI, F16 ? 1 : 0, PRE, true, true>(p, acc, (char*)bl, bias_reg, tid, 0, n, oy0, ox0, &mpre);
+    const unsigned long long t_e = CH_T();
+    cs.publish(layer, tid);
+    const unsigned long long t_f = CH_T();
+    CH_ACC(ttype, 0, t_b - t_a);
+    CH_ACC(ttype, 1, t_c - t_b);
+    CH_ACC(ttype, 2, t_d - t_c);
+    CH_ACC(ttype, 3, t_poll);
+    CH_ACC(ttype, 4, t_e - t_d);
+    CH_ACC(ttype, 5, t_f - t_e);
+    CH_ACC(ttype, 6, 1ull);
+    CH_ACC(ttype, 7, (unsigned long long)nchunks);
+    (void)t_a; (void)t_b; (void)t_c; (void)t_d; (void)t_e; (void)t_f;
+}
+
+template <bool F16, bool BWD>
+__global__ __launch_bounds__(256, 2) void conv_chain2_kernel(const dasr_conv_params* __restrict__ layers, const int* __restrict__ dep_chunk, int nlayers,
+                                                            int tiles_y, int tiles_x, unsigned* flags, unsigned* tickets, int* err, int tpw) {
+    using C = GCfg<1, 4>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int T = tiles_y * tiles_x;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int xcd = (int)(xcc & 7u);
+    const int quota = (int)(gridDim.x >> 3);
+    int* xi = (int*)(smem + Chain2::XOFF + 256);   // [0..7] f0 of this workgroup's tiles, [8] ticket
+    const __amdgpu_buffer_rsrc_t rflags = make_rsrc(flags);
+    if (tid == 0) xi[8] = (int)(atomicAdd(tickets + xcd, 1u) % (unsigned)quota);
+    __syncthreads();
+    const int j = __builtin_amdgcn_readfirstlane(xi[8]);
+    if (tid < tpw) {   // stage base of every tile this workgroup owns (the flag words count on from launch to launch)
+        const int idx = j + quota * tid;
+        const int img = idx / T, tile = idx - img * T;
+        xi[tid] = (int)__builtin_amdgcn_raw_buffer_load_b32(rflags, (unsigned)((xcd + 8 * img) * T + tile) * 4u, 0, 17);
+    }
+    __syncthreads();
+    bool have0 = false;
+    for (int L = 0; L < nlayers; ++L) {
+        const dasr_conv_params& p = layers[L];
+        const int dep = dep_chunk[L];
+        for (int slot = 0; slot < tpw; ++slot) {
+            const int idx = j + quota * slot;
+            const int img = idx / T, tile = idx - img * T;
+            const int n = xcd + 8 * img;                        // all tiles of image n on XCD n % 8
+            const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+            ChainSync cs;
+            cs.rflags = rflags;
+            cs.err = err;
+            cs.base = n * T;
+            cs.ty = ty, cs.tx = tx, cs.tiles_y = tiles_y, cs.tiles_x = tiles_x;
+            cs.f0 = (unsigned)__builtin_amdgcn_readfirstlane(xi[slot]);
+            const int oy0 = ty * C::TH, ox0 = tx * C::TW;
+            // the item behind this one: (L, slot + 1), or (L + 1, 0); its chunk 0 may be requested early iff it holds old planes only
+            ChainNext nx;
+            {
+                const bool same = slot + 1 < tpw;
+                const int Ln = same ? L : L + 1, sn = same ? slot + 1 : 0;
+                const int Lc = Ln < nlayers ? Ln : nlayers - 1;
+                const dasr_conv_params& pn = layers[Lc];
+                const int idn = j + quota * sn;
+                const int imn = idn / T, tin = idn - imn * T;
+                const int tyn = tin / tiles_x, txn = tin - tyn * tiles_x;
+                nx.on = Ln < nlayers && dep_chunk[Lc] > 1;
+                nx.in = pn.in.p, nx.n_stride = pn.in.n_stride, nx.w = pn.w, nx.mt = pn.mt;
+                nx.n = xcd + 8 * imn, nx.oy0 = tyn * C::TH, nx.ox0 = txn * C::TW;
+            }
+            if constexpr (BWD) {
+                if (p.mt == 1) chain_item<1, 68, F16>(p, smem, tid, n, oy0, ox0, dep, cs, L, have0, nx);
+                else if (p.res2.p != nullptr) chain_item<2, 248, F16>(p, smem, tid, n, oy0, ox0, dep, cs, L, have0, nx);
+                else chain_item<2, 232, F16>(p, smem, tid, n, oy0, ox0, dep, cs, L, have0, nx);
+            } else {
+                if (p.mt == 1) chain_item<1, 67, F16>(p, smem, tid, n, oy0, ox0, dep, cs, L, have0, nx);
+                else if (p.res2.p != nullptr) chain_item<2, 249, F16>(p, smem, tid, n, oy0, ox0, dep, cs, L, have0, nx);
+                else chain_item<2, 233, F16>(p, smem, tid, n, oy0, ox0, dep, cs, L, have0, nx);
+            }
+            have0 = nx.on;
         }
     }
 }
@@ -1796,6 +2137,7 @@ int classify_epi(const dasr_conv_params& p) {
 
 // kernel-variant selection (A/B-able from the host: dasr_set_tuning)
 int g_tune_rot = 0;  // chunk-order rotation of the LDS-DMA dense-block conv (A/B)
+int g_chain_form = 2;  // chained launches: 2 = conv_chain2_kernel (round 5: work items, early chunk-0 request, 512 * tpw tiles), 1 = conv_chain_kernel (round 4, exact fit only)
 int g_tune_rdb32 = 12, g_tune_rdb64 = 13, g_tune_stream = 0, g_tune_xcd = 1, g_tune_epi = 1;  // Cout=64: 13 = 8-wave form for launches of <= 256 four-wave workgroups (worth 1-2 % of the step under two sub-batch streams)
 
 }  // namespace
@@ -1810,6 +2152,7 @@ extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
 #ifndef DASR_BENCH
     // product library: one dense-block conv kernel; the only live choice is the workgroup shape rule of the Cout = 64 launches (key 2)
     if (key == 2 && (value == 12 || value == 13)) { g_tune_rdb64 = value; return 0; }
+    if (key == 7 && (value == 1 || value == 2)) { g_chain_form = value; return 0; }   // form of the chained launches (same results; A/B)
     if ((key == 1 && value == 12) || (key == 3 && value == 0) || (key == 4 && value == 1) || (key == 5 && value == 1) || (key == 6 && value == 0)) return 0;
     return DASR_EINVAL;   // the A/B variants of rounds 1-3 live in libdasr_hip_ablate.so (python -m dasr_amd.build --ablate)
 #else
@@ -1821,6 +2164,7 @@ extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
         case 4: g_tune_xcd = value; return 0;     // XCD-aware tile order on/off
         case 5: g_tune_epi = value; return 0;     // compile-time specialised epilogues on/off
         case 6: g_tune_rot = value; return 0;     // LDS-DMA dense conv: per-workgroup chunk-order rotation on/off
+        case 7: if (value != 1 && value != 2) return DASR_EINVAL; g_chain_form = value; return 0;   // form of the chained launches
         default: return DASR_EINVAL;
     }
 #endif
@@ -1848,8 +2192,17 @@ extern "C" int dasr_conv_chain(const dasr_conv_params* dev_layers, const dasr_co
         if (!ok) return DASR_EINVAL;
     }
     const int tiles_x = (p0.Wout + C::TW - 1) / C::TW, tiles_y = (p0.Hout + C::TH - 1) / C::TH;
-    const long long grid = (long long)tiles_x * tiles_y * p0.N;
-    if ((p0.N & 7) || grid != 512) return DASR_EINVAL;   // whole images per XCD; the launch fills the chip exactly (2 workgroups x 256 CUs): see the ticket comment in the kernel
+    const long long ntiles = (long long)tiles_x * tiles_y * p0.N;
+    const long long grid = 512;   // the launch fills the chip exactly (2 workgroups x 256 CUs, all resident): see the ticket comment in the kernels
+    if ((p0.N & 7) || ntiles < grid || ntiles % grid) return DASR_EINVAL;   // whole images per XCD; every workgroup owns ntiles / 512 tiles
+    const int tpw = (int)(ntiles / grid);
+    const bool form2 = g_chain_form == 2;
+    if (!form2 && tpw != 1) return DASR_EINVAL;
+    if (form2) {
+        if (tpw > Chain2::MAX_TPW) return DASR_EINVAL;
+        for (int i = 0; i < nlayers; ++i)
+            if ((host_layers[i].cin >> 4) & 1) return DASR_EINVAL;   // even chunk counts: the last chunk of an item sits in LDS buffer 1 (conv_chain2_kernel)
+    }
     {
         static int n_cu = -1;   // (a partitioned device -- CPX / DPX -- exposes fewer CUs per logical GPU: the launch would not be resident as a whole)
         if (n_cu < 0) {
@@ -1875,11 +2228,28 @@ extern "C" int dasr_conv_chain(const dasr_conv_params* dev_layers, const dasr_co
         DASR_LAUNCH_TAG(NAME, kfn, dim3((unsigned)grid), dim3(256), C::LDS_BYTES, s, dev_layers, (const int*)dev_dep_chunk, (int)nlayers, tiles_y, tiles_x, \
                         dev_flags, dev_flags + grid, dev_err);                                                                                           \
     }
-    if (v == 0) DASR_CHAIN_LAUNCH(false, false, "conv_chain_kernel<false, false>")
+    static bool attr2_set[4] = {false, false, false, false};
+#define DASR_CHAIN2_LAUNCH(F16_, BWD_, NAME)                                                                                                             \
+    {                                                                                                                                                    \
+        auto kfn = conv_chain2_kernel<F16_, BWD_>;                                                                                                       \
+        if (!attr2_set[v]) {                                                                                                                             \
+            HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, Chain2::LDS_BYTES));                               \
+            attr2_set[v] = true;                                                                                                                         \
+        }                                                                                                                                                \
+        DASR_LAUNCH_TAG(NAME, kfn, dim3((unsigned)grid), dim3(256), Chain2::LDS_BYTES, s, dev_layers, (const int*)dev_dep_chunk, (int)nlayers, tiles_y, tiles_x, \
+                        dev_flags, dev_flags + ntiles, dev_err, tpw);                                                                                    \
+    }
+    if (form2) {
+        if (v == 0) DASR_CHAIN2_LAUNCH(false, false, "conv_chain2_kernel<false, false>")
+        else if (v == 1) DASR_CHAIN2_LAUNCH(true, false, "conv_chain2_kernel<true, false>")
+        else if (v == 2) DASR_CHAIN2_LAUNCH(false, true, "conv_chain2_kernel<false, true>")
+        else DASR_CHAIN2_LAUNCH(true, true, "conv_chain2_kernel<true, true>")
+    } else if (v == 0) DASR_CHAIN_LAUNCH(false, false, "conv_chain_kernel<false, false>")
     else if (v == 1) DASR_CHAIN_LAUNCH(true, false, "conv_chain_kernel<true, false>")
     else if (v == 2) DASR_CHAIN_LAUNCH(false, true, "conv_chain_kernel<false, true>")
     else DASR_CHAIN_LAUNCH(true, true, "conv_chain_kernel<true, true>")
 #undef DASR_CHAIN_LAUNCH
+#undef DASR_CHAIN2_LAUNCH
     return (int)hipGetLastError();
 }
 

@@ -20,10 +20,10 @@ for k, v in busy.items():
         continue
     b, s = v['avg_kb'] / 1024.0, sq[k]['avg_kb'] / 32.0
     print('%-52s %9d %16.0f %14.0f %9.1f %%' % (k[:52], v['launches'], b, s, 100.0 * b / s))
-    if k.startswith('conv_glds_kernel') or k.startswith('conv_chain_kernel') or k in ('wgrad3_ld_kernel<false>', 'wgrad3_kernel<true, false, false, 0>'):   # bf16 trunk kernels (not the f16 HR tail)
+    if k.startswith('conv_glds_kernel') or k.startswith('conv_chain') or k in ('wgrad3_ld_kernel<false>', 'wgrad3_kernel<true, false, false, 0>'):   # bf16 trunk kernels (not the f16 HR tail)
         tot_b += b * v['launches']
         tot_s += s * sq[k]['launches']
-print('RRDB trunk kernels (conv_chain_kernel<*>, conv_glds_kernel<*>, wgrad3_ld_kernel<false>), time-weighted: %.1f %% MFMA busy' % (100.0 * tot_b / tot_s))
+print('RRDB trunk kernels (conv_chain*_kernel<*>, conv_glds_kernel<*>, wgrad3_ld_kernel<false>), time-weighted: %.1f %% MFMA busy' % (100.0 * tot_b / tot_s))
 if len(sys.argv) > 3:   # python scripts/pmc_mfma_busy.py gpurun_out <tag> profiles/pmc_mfma_busy.json : the table bench.py reads
     out = {'source': 'profiles/%s_pmc_mfma_busy.txt: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / --pmc SQ_BUSY_CYCLES (separate passes, --kernel-trace only) over '
                      '`DASR_STREAMS=1 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary`; busy = (MFMA_BUSY/1024 SIMDs)/(SQ_BUSY/32 shader engines); '
