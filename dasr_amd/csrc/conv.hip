@@ -132,7 +132,7 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
     const bool chan_tail = G ? true : false;          // cout not a multiple of 32 (specialised variants require it)
     const int ostr = p.out_stride > 1 ? p.out_stride : 1, owid = p.out_W > 0 ? p.out_W : p.Wout;  // strided sub-grid output (stride-2 dgrad)
     constexpr int MSZ = IN_F32 ? 4 : 2;
-    const float slope = (G && p.slope_ptr) ? *p.slope_ptr : p.slope;  // PReLU: the (learned) slope lives in the parameter buffer
+    const float slope = p.slope_ptr ? *p.slope_ptr : p.slope;  // PReLU: the (learned) slope lives in the parameter buffer (round 5: also in the specialised variants)
     const __amdgpu_buffer_rsrc_t rmask = make_rsrc((const char*)p.mask.p + (size_t)n * p.mask.n_stride * MSZ);
     const __amdgpu_buffer_rsrc_t rr1 = make_rsrc((const char*)p.res1.p + (size_t)n * p.res1.n_stride * ((G && p.res1_lo) ? 2 : 4));
     const __amdgpu_buffer_rsrc_t rr2 = make_rsrc((const float*)p.res2.p + (size_t)n * p.res2.n_stride);
@@ -288,7 +288,12 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[g][j] += bia[mi][g][j];
             }
-            if (act_lrelu && !G) {   // specialised variants (classify_epi: slope in [0, 1]): LeakyReLU = max(v, slope * v), two VALU ops per element, not three
+            if (act_lrelu && !G && p.slope_ptr) {   // specialised variants with a learned PReLU slope (any sign / size): select, three VALU ops per element
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[g][j] = v[g][j] > 0.f ? v[g][j] : slope * v[g][j];
+            } else if (act_lrelu && !G) {   // specialised variants (classify_epi: slope in [0, 1]): LeakyReLU = max(v, slope * v), two VALU ops per element, not three
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -1347,6 +1352,34 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
 #define CH_ACC(type, phase, val) do {} while (0)
 #endif
 
+// Phase offset between the two images an XCD hosts (round 5).  Every CU runs two workgroups of a chained launch; a workgroup alternates between its main
+// loops (matrix pipe + LDS-DMA) and the phases between them (neighbour waits, epilogue stores, first-chunk round trips: a third of its time, matrix pipe
+// idle).  Tiles of ONE image are locked in phase by their neighbour flags; two images are independent.  Workgroups of odd images therefore start
+// `stagger` ticks of the 100 MHz constant clock late (dasr_set_tuning key 8, microseconds): where the two workgroups of a CU belong to different images
+// (the usual placement: tickets follow the dispatch order, one image per "slot layer" of the XCD), one's idle phases then fall into the other's main loops.
+__device__ __forceinline__ void chain_stagger(int img, int stagger) {
+    if ((img & 1) && stagger > 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < (long long)stagger) __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+#ifdef DASR_TRACE
+// where a workgroup of a chained launch ran: g_trace[2^20 + block * 64 + 56 ...] = HW_ID register, ticket, XCC id
+#define CH_WHERE(ticket, xcc)                                                                  \
+    do {                                                                                       \
+        if (g_trace && threadIdx.x == 0) {                                                     \
+            unsigned hw;                                                                       \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                   \
+            g_trace[(size_t)(1 << 20) + (size_t)blockIdx.x * 64 + 56] = hw;                    \
+            g_trace[(size_t)(1 << 20) + (size_t)blockIdx.x * 64 + 57] = (unsigned)(ticket);    \
+            g_trace[(size_t)(1 << 20) + (size_t)blockIdx.x * 64 + 58] = (unsigned)(xcc);       \
+        }                                                                                      \
+    } while (0)
+#else
+#define CH_WHERE(ticket, xcc) do {} while (0)
+#endif
+
 struct ChainSync {
     __amdgpu_buffer_rsrc_t rflags;
     int* err;
@@ -1522,7 +1555,7 @@ __device__ __forceinline__ void chain_layer(const dasr_conv_params& p, char* sme
 
 template <bool F16, bool BWD>
 __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const dasr_conv_params* __restrict__ layers, const int* __restrict__ dep_chunk, int nlayers,
-                                                           int tiles_y, int tiles_x, unsigned* flags, unsigned* tickets, int* err) {
+                                                           int tiles_y, int tiles_x, unsigned* flags, unsigned* tickets, int* err, int stagger) {
     using C = GCfg<1, 4>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1545,6 +1578,8 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const dasr_conv_para
     const int img = j / T, tile = j - img * T;
     const int n = xcd + 8 * img;                        // all tiles of image n on XCD n % 8
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    CH_WHERE(j, xcc);
+    chain_stagger(img, stagger);
     ChainSync cs;
     cs.rflags = make_rsrc(flags);
     cs.err = err;
@@ -1816,7 +1851,7 @@ __device__ __forceinline__ void chain_item(const dasr_conv_params& p, char* smem
 
 template <bool F16, bool BWD>
 __global__ __launch_bounds__(256, 2) void conv_chain2_kernel(const dasr_conv_params* __restrict__ layers, const int* __restrict__ dep_chunk, int nlayers,
-                                                            int tiles_y, int tiles_x, unsigned* flags, unsigned* tickets, int* err, int tpw) {
+                                                            int tiles_y, int tiles_x, unsigned* flags, unsigned* tickets, int* err, int tpw, int stagger) {
     using C = GCfg<1, 4>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1836,6 +1871,8 @@ __global__ __launch_bounds__(256, 2) void conv_chain2_kernel(const dasr_conv_par
         xi[tid] = (int)__builtin_amdgcn_raw_buffer_load_b32(rflags, (unsigned)((xcd + 8 * img) * T + tile) * 4u, 0, 17);
     }
     __syncthreads();
+    CH_WHERE(j, xcc);
+    chain_stagger(j / T, stagger);
     bool have0 = false;
     for (int L = 0; L < nlayers; ++L) {
         const dasr_conv_params& p = layers[L];
@@ -2127,8 +2164,8 @@ __global__ void conv_naive_kernel(const dasr_conv_params p, const float* w) {
 
 // compile-time epilogue variant of the hot dense-block cases (bit set: see conv_kernel's epilogue); 0 = generic
 int classify_epi(const dasr_conv_params& p) {
-    if ((p.cout & 31) || p.slope_ptr || p.act == 2 || p.out_stride > 1 || p.res1_lo || (p.out16_lo && !p.out16_f16)) return 0;
-    if (p.act == 1 && !(p.slope >= 0.f && p.slope <= 1.f)) return 0;   // the specialised epilogues use max(v, slope * v)
+    if ((p.cout & 31) || p.act == 2 || p.out_stride > 1 || p.res1_lo || (p.out16_lo && !p.out16_f16)) return 0;
+    if (p.act == 1 && !p.slope_ptr && !(p.slope >= 0.f && p.slope <= 1.f)) return 0;   // the specialised epilogues use max(v, slope * v) for a constant slope, a select for a learned one (slope_ptr)
     int e = (p.bias ? 1 : 0) | (p.act == 1 ? 2 : 0) | (p.mask.p ? 4 : 0) | (p.res1.p ? 8 : 0) | (p.res2.p ? 16 : 0) | (p.out_f32.p ? 32 : 0) |
             (p.out_bf16.p ? 64 : 0);
     if (p.res1.p || p.alpha != 1.f || p.gamma != 1.f) e |= 128;
@@ -2137,7 +2174,10 @@ int classify_epi(const dasr_conv_params& p) {
 
 // kernel-variant selection (A/B-able from the host: dasr_set_tuning)
 int g_tune_rot = 0;  // chunk-order rotation of the LDS-DMA dense-block conv (A/B)
-int g_chain_form = 2;  // chained launches: 2 = conv_chain2_kernel (round 5: work items, early chunk-0 request, 512 * tpw tiles), 1 = conv_chain_kernel (round 4, exact fit only)
+int g_chain_stagger_us = 0;  // chained launches: start offset of the odd images (chain_stagger), microseconds
+int g_chain_form = 1;  // chained launches: 1 = conv_chain_kernel (round 4) where the batch is the exact fit of 512 tiles, conv_chain2_kernel (round 5: work items, 512 * tpw
+                       // tiles) otherwise; 2 = conv_chain2_kernel always.  Same-box A/B at configs[1] (profiles/r05_chain_trace.txt): form 1 9.1 ms per chain, form 2 10.3 ms --
+                       // the early chunk-0 request of form 2 queues the epilogue's stores behind the DMA
 int g_tune_rdb32 = 12, g_tune_rdb64 = 13, g_tune_stream = 0, g_tune_xcd = 1, g_tune_epi = 1;  // Cout=64: 13 = 8-wave form for launches of <= 256 four-wave workgroups (worth 1-2 % of the step under two sub-batch streams)
 
 }  // namespace
@@ -2153,6 +2193,7 @@ extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
     // product library: one dense-block conv kernel; the only live choice is the workgroup shape rule of the Cout = 64 launches (key 2)
     if (key == 2 && (value == 12 || value == 13)) { g_tune_rdb64 = value; return 0; }
     if (key == 7 && (value == 1 || value == 2)) { g_chain_form = value; return 0; }   // form of the chained launches (same results; A/B)
+    if (key == 8 && value >= 0 && value <= 2000) { g_chain_stagger_us = value; return 0; }   // start offset of the odd images of a chained launch, microseconds
     if ((key == 1 && value == 12) || (key == 3 && value == 0) || (key == 4 && value == 1) || (key == 5 && value == 1) || (key == 6 && value == 0)) return 0;
     return DASR_EINVAL;   // the A/B variants of rounds 1-3 live in libdasr_hip_ablate.so (python -m dasr_amd.build --ablate)
 #else
@@ -2165,6 +2206,7 @@ extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
         case 5: g_tune_epi = value; return 0;     // compile-time specialised epilogues on/off
         case 6: g_tune_rot = value; return 0;     // LDS-DMA dense conv: per-workgroup chunk-order rotation on/off
         case 7: if (value != 1 && value != 2) return DASR_EINVAL; g_chain_form = value; return 0;   // form of the chained launches
+        case 8: if (value < 0 || value > 2000) return DASR_EINVAL; g_chain_stagger_us = value; return 0;
         default: return DASR_EINVAL;
     }
 #endif
@@ -2196,8 +2238,7 @@ extern "C" int dasr_conv_chain(const dasr_conv_params* dev_layers, const dasr_co
     const long long grid = 512;   // the launch fills the chip exactly (2 workgroups x 256 CUs, all resident): see the ticket comment in the kernels
     if ((p0.N & 7) || ntiles < grid || ntiles % grid) return DASR_EINVAL;   // whole images per XCD; every workgroup owns ntiles / 512 tiles
     const int tpw = (int)(ntiles / grid);
-    const bool form2 = g_chain_form == 2;
-    if (!form2 && tpw != 1) return DASR_EINVAL;
+    const bool form2 = g_chain_form == 2 || tpw > 1;
     if (form2) {
         if (tpw > Chain2::MAX_TPW) return DASR_EINVAL;
         for (int i = 0; i < nlayers; ++i)
@@ -2226,7 +2267,7 @@ extern "C" int dasr_conv_chain(const dasr_conv_params* dev_layers, const dasr_co
             attr_set[v] = true;                                                                                                                          \
         }                                                                                                                                                \
         DASR_LAUNCH_TAG(NAME, kfn, dim3((unsigned)grid), dim3(256), C::LDS_BYTES, s, dev_layers, (const int*)dev_dep_chunk, (int)nlayers, tiles_y, tiles_x, \
-                        dev_flags, dev_flags + grid, dev_err);                                                                                           \
+                        dev_flags, dev_flags + grid, dev_err, g_chain_stagger_us * 100);                                                                 \
     }
     static bool attr2_set[4] = {false, false, false, false};
 #define DASR_CHAIN2_LAUNCH(F16_, BWD_, NAME)                                                                                                             \
@@ -2237,7 +2278,7 @@ extern "C" int dasr_conv_chain(const dasr_conv_params* dev_layers, const dasr_co
             attr2_set[v] = true;                                                                                                                         \
         }                                                                                                                                                \
         DASR_LAUNCH_TAG(NAME, kfn, dim3((unsigned)grid), dim3(256), Chain2::LDS_BYTES, s, dev_layers, (const int*)dev_dep_chunk, (int)nlayers, tiles_y, tiles_x, \
-                        dev_flags, dev_flags + ntiles, dev_err, tpw);                                                                                    \
+                        dev_flags, dev_flags + ntiles, dev_err, tpw, g_chain_stagger_us * 100);                                                          \
     }
     if (form2) {
         if (v == 0) DASR_CHAIN2_LAUNCH(false, false, "conv_chain2_kernel<false, false>")

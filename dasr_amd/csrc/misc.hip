@@ -625,7 +625,9 @@ dasr_red dasr_red_scratch(const void* key_acc, hipStream_t s, unsigned nblocks, 
         const size_t cap = need < 4096 ? 4096 : need + need / 2;
         char* nb = nullptr;
         if (hipMalloc((void**)&nb, 256 + cap * sizeof(float)) != hipSuccess) return r;   // (a launcher that gets no row reports DASR_EINVAL)
-        if (hipMemset(nb, 0, 256) != hipSuccess) return r;
+        if (hipMemsetAsync(nb, 0, 256, s) != hipSuccess) return r;   // on the launch stream: ordered in front of the row's first kernel (a plain hipMemset
+                                                                      // runs on the null stream, which a non-blocking stream does not wait for: the ticket of a
+                                                                      // replica stream's first launch started from garbage and its sum was lost)
         row.base = nb;   // the previous allocation is kept (see above)
         row.floats = cap;
     }

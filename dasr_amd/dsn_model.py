@@ -94,7 +94,7 @@ _P3_TAPS = {0: (1, -1), 1: (2, 0)}
 
 
 class DeResnetHIP:
-    def __init__(self, n_res_blocks=8, device='cuda', scale=4):
+    def __init__(self, n_res_blocks=8, device='cuda', scale=4, fwd_mode=None):
         assert scale in (1, 4)
         self.nb, self.device, self.scale = n_res_blocks, torch.device(device), scale
         self.spec = deresnet_spec(n_res_blocks, scale)
@@ -129,7 +129,21 @@ class DeResnetHIP:
         # split-bf16's 16, one launch of the LDS-DMA kernel over 3K virtual chunks instead of three register-staged passes); the hi planes are the
         # f16 shadows the 16-bit backward reads.  7.14 -> 6.88 ms per iteration (the generic epilogue and three MFMA passes remain).
         # DASR_DSN_FWD16=0: fp32 tensors + separate shadows.
-        self.fwd16 = self.bwd16 and os.environ.get('DASR_DSN_FWD16', '1') != '0'
+        # Round 5 (the split forward sat at 4.7e-7 on the activations against a 1e-3 budget and paid three MFMA passes for it):
+        # DASR_DSN_FWD16=2, the default -- the residual blocks in ONE f16 pass, exactly as the RRDB trunk runs its dense blocks: the residual stream s[k]
+        # stays fp32 (conv2 adds its fp32 input and writes fp32 + an f16 shadow), conv1 / conv2 read the f16 shadows (11-bit operands, fp32
+        # accumulation).  `fwd_mode` may also be forced per network (DSNModel selects the split forward, 1, for BatchNorm discriminators, whose
+        # ill-conditioned statistics amplify the generator's rounding -- same reasoning as the f16 dense blocks of the SRN BatchNorm case).
+        fm = os.environ.get('DASR_DSN_FWD16', '2') if fwd_mode is None else str(fwd_mode)
+        if fm not in ('0', '1', '2'):
+            raise ValueError('DASR_DSN_FWD16 must be 0 (fp32 tensors), 1 (split f16 tensors, three passes) or 2 (one f16 pass)')
+        self.fwd16 = self.bwd16 and fm == '1'
+        self.fwd1p = self.bwd16 and fm == '2'
+        if self.fwd1p:
+            for k in range(n_res_blocks):
+                for j in (1, 2):
+                    w = P.off('res_blocks.%d.conv%d.weight' % (k, j))
+                    self.pk['r%d_%d_f' % (k, j)] = self.pack.add(64, 64, 9, 2, 2, [(w, 64, 64, 0, 64, 0, 0)])
         if self.fwd16:
             w = P.off('block_input.0.weight')
             self.pk['in_s'] = self.pack.add(64, 48, 9, 2, 5, [(w, 64, 3, 0, 3, 0, 0)])
@@ -175,8 +189,8 @@ class _GPlan:
         self.x_in = B(16, H, W)
         f16w = net.fwd16
         # (split forward: only s[0] -- PReLU' of the input conv at the end of the backward -- and s[nb] -- input of the f32 stride-2 convs -- exist in fp32)
-        self.s = [B(64, H, W) if (not f16w or k in (0, nb)) else None for k in range(nb + 1)]
-        self.h = [B(64, H, W) if not f16w else None for _ in range(nb)]
+        self.s = [B(64, H, W) if (not f16w or k in (0, nb)) else None for k in range(nb + 1)]   # (one f16 pass, net.fwd1p: every level -- the fp32 residual stream)
+        self.h = [B(64, H, W) if not (f16w or net.fwd1p) else None for _ in range(nb)]
         self.fake = B(16, H4, W4)
         self.g_fake, self.gz_out = B(16, H4, W4), B(16, H4, W4)
         if down:
@@ -193,13 +207,13 @@ class _GPlan:
                 self.x_s = BS(16)
                 self.s16 = [BS(64) for _ in range(nb)]
                 self.h16 = [BS(64) for _ in range(nb)]
-            else:
-                self.s16 = [B16() for _ in range(nb)]       # f16 shadows of the residual stream s[0 .. nb-1] and of the block-internal activations
+            else:   # (one f16 pass: also a shadow of level nb -- nobody reads it, but conv2 of the last block then runs the same compile-time epilogue as the others)
+                self.s16 = [B16() for _ in range(nb + (1 if net.fwd1p else 0))]       # f16 shadows of the residual stream s[0 .. nb-1] and of the block-internal activations
                 self.h16 = [B16() for _ in range(nb)]
             # gscale * dL/ds[j] (j = 0 .. nb) and gscale * dL/dh[k] in f16: ONE buffer per level (round 4), so that the 2 nb weight gradients of the
             # residual blocks run as ONE grouped launch behind the data-gradient chain (16 parts x 16 pixel splits instead of 16 launches of
             # 1 part x 256 splits: a sixteenth of the partial-sum traffic, one reduce instead of sixteen); 2 nb x 67 MB at batch 8 x 256^2
-            self.g_s16 = [B16() if j > 0 else None for j in range(nb + 1)]
+            self.g_s16 = [B16() for j in range(nb + 1)]   # (level 0 has no 16-bit consumer; written all the same: one epilogue variant for all blocks)
             self.g_h16 = [B16() for _ in range(nb)]
             # dL/dfake of the mean losses is ~(largest loss weight) / (number of output elements): a power of two puts it at ~2^-3 before the f16
             # rounding.  net.loss_weight = max(w_col, w_tex, w_per) (set by DSNModel; 1 for a bare generator): with w_col = 0 the gradient is
@@ -226,6 +240,13 @@ class _GPlan:
                           slope_ptr=sp('block_input.1.weight'), out_f32=self.s[0].view(), **(sh(self.s16[0]) if (b16 and nb) else {})))
         for k in range(nb):
             pre = 'res_blocks.%d.' % k
+            if net.fwd1p:   # one f16 pass per conv on the f16 shadows; fp32 residual stream
+                f.add(conv_op(pack, pk['r%d_1_f' % k], self.s16[k].view(), False, 64, H, W, H, W, N, bias=sp(pre + 'conv1.bias'), act=1,
+                              slope_ptr=sp(pre + 'prelu.weight'), out_bf16=self.h16[k].view(), out16_f16=1))
+                f.add(conv_op(pack, pk['r%d_2_f' % k], self.h16[k].view(), False, 64, H, W, H, W, N, bias=sp(pre + 'conv2.bias'),
+                              res1=self.s[k].view(), beta1=1.0, out_f32=self.s[k + 1].view(),
+                              out_bf16=self.s16[k + 1].view(), out16_f16=1))
+                continue
             if f16w:
                 last_blk = k + 1 == nb
                 f.add(conv_op(pack, pk['r%d_1_s' % k], self.s16[k].view(), False, 192, H, W, H, W, N, bias=sp(pre + 'conv1.bias'), act=1,
@@ -321,12 +342,12 @@ class _GPlan:
                 gs16, g_h16 = self.g_s16[k + 1], self.g_h16[k]
                 wg16_part(pre + 'conv2.', gs16, self.h16[k])
                 b.add(conv_op(pack, pk['r%d_2_b16' % k], gs16.view(), False, 64, H, W, H, W, N, mask=self.h16[k].view(), mask_f32=0,
-                              slope_ptr=sp(pre + 'prelu.weight'), alpha=inv, out_bf16=g_h16.view(), out16_f16=1, gamma=self.gscale))
+                              slope_ptr=sp(pre + 'prelu.weight'), out_bf16=g_h16.view(), out16_f16=1))   # (gscale * dL/ds in, gscale * dL/dh out: no rescaling)
                 prelu_grad(pre + 'prelu.weight', self.h16[k], g_h16, H, W, f16=True)   # (dL/dh is never materialised in f32)
                 wg16_part(pre + 'conv1.', g_h16, self.s16[k])
                 nxt = self.g_s[1] if gs is self.g_s[0] else self.g_s[0]
                 b.add(conv_op(pack, pk['r%d_1_b16' % k], g_h16.view(), False, 64, H, W, H, W, N, alpha=inv, res1=gs.view(), beta1=1.0,
-                              out_f32=nxt.view(), out_bf16=self.g_s16[k].view() if k > 0 else None, out16_f16=1, gamma=self.gscale))   # (level 0 has no 16-bit consumer)
+                              out_f32=nxt.view(), out_bf16=self.g_s16[k].view(), out16_f16=1, gamma=self.gscale))
                 gs = nxt
                 continue
             wg(pre + 'conv2.', gs, self.h[k], 64, 64, H, W, H, W)
@@ -450,7 +471,9 @@ class DSNModel:
         self.k = o['kernel_size']
         if o['generator'].lower() not in ('deresnet', 'dsgan'):   # codes/DSN/train.py:124-129
             raise NotImplementedError('Generator model [{:s}] not recognized'.format(o['generator']))
-        self.netG = DeResnetHIP(o['n_res_blocks'], device=self.device, scale=4 if o['generator'].lower() == 'deresnet' else 1)
+        # BatchNorm discriminators: the generator keeps the split (22-bit) forward unless DASR_DSN_FWD16 says otherwise (DeResnetHIP.__init__)
+        fwd_mode = 1 if (o['norm_layer'] == 'Batch' and os.environ.get('DASR_DSN_FWD16') is None) else None
+        self.netG = DeResnetHIP(o['n_res_blocks'], device=self.device, scale=4 if o['generator'].lower() == 'deresnet' else 1, fwd_mode=fwd_mode)
         # --lpips_rot_flip (train.py:52, loss.py:66,149-168): a random symmetry of the square on both LPIPS inputs, drawn from python's `random` per
         # generator-loss evaluation in the reference's order; only PerceptualLoss (= per_type LPIPS) has it, the VGG16 term ignores the flag
         self.lpips_rot_flip = bool(o['lpips_rot_flip']) and o['per_type'] == 'LPIPS' and o['w_per'] > 0

@@ -159,7 +159,7 @@ class RRDBNetHIP:
         (dasr_conv_chain: 512 resident workgroups, each owns N * tiles / 512 tiles -- 1 at configs[1], 2 at configs[2]'s 32 crops; the round-4 form of the
         kernel, DASR_TUNE=7=1, only runs the exact fit)"""
         ntiles = N * ceil_div(h, 16) * ceil_div(w, 32)
-        tpw_ok = ntiles == 512 if _lib.tuning_value(7, 2) == 1 else (ntiles >= 512 and ntiles % 512 == 0 and ntiles // 512 <= 8)
+        tpw_ok = ntiles >= 512 and ntiles % 512 == 0 and ntiles // 512 <= int(os.environ.get('DASR_CHAIN_TPW', '8'))   # DASR_CHAIN_TPW=1: exact fit only (A/B)
         if not (self.chain and N % 8 == 0 and tpw_ok and not getattr(self, 'debug_taps', ())):
             return False
         from . import dist as _dist

@@ -67,7 +67,12 @@ def main(argv=None, loaders=None):
             util.mkdir(path)
     opt = option.dict_to_nonedict(opt)
     if opt['save_RealorFake']:
-        raise NotImplementedError('save_RealorFake (discriminator visual) is not available on the MI355X path')
+        # codes/SRN/test.py:44,65-66,77: the patch map comes from visuals['realorfake'], which only DePatchGAN_wavelet_model.get_current_visuals
+        # (DePatchGAN_wavelet_model.py:287-309, model 'De_patch_wavelet_GAN': the SRN tree's own copy of the DSN, outside SURVEY 8) produces; with the
+        # trainers this path serves ('sr', 'DASR') the reference's test.py itself stops with KeyError at test.py:66.  The DSN's patch maps are written by
+        # `python -m dasr_amd.dsn_create_dataset` (fake LR + domain-distance map, codes/DSN/create_dataset_modified.py).
+        raise NotImplementedError("save_RealorFake needs model 'De_patch_wavelet_GAN' (its get_current_visuals is the only one with a 'realorfake' entry); "
+                                  "use dasr_amd.dsn_create_dataset for the DSN's discriminator maps")
     setup_logger('base', opt['path']['log'], 'test', screen=True)
     logger = logging.getLogger('base')
     logger.info(option.dict2str(opt))

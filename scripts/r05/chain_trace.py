@@ -28,6 +28,8 @@ def main():
     ap.add_argument('--nb', type=int, default=23)
     ap.add_argument('--lr', type=int, default=128)
     ap.add_argument('--time-only', action='store_true')
+    ap.add_argument('--stagger', type=str, default='', help='comma list of start offsets (us) of the odd images: launch durations of both chains per value (form 1)')
+    ap.add_argument('--forms', type=str, default='1,2')
     a = ap.parse_args()
     os.environ.setdefault('DASR_ALLOW_NONFINITE', '1')
     os.environ['DASR_STREAMS'] = '1'
@@ -43,7 +45,36 @@ def main():
     m = create_model(options.dict_to_nonedict(bench.make_opt(64, a.nb)))
     g = torch.Generator().manual_seed(1234)
     data = {'LR': torch.rand(a.n, 3, a.lr, a.lr, generator=g).cuda(), 'HR': torch.rand(a.n, 3, 4 * a.lr, 4 * a.lr, generator=g).cuda()}
-    for form in (1, 2):
+    if a.stagger:
+        _lib.check(L.dasr_set_tuning(7, 1))
+        for st in (1, 2):
+            m.update_learning_rate()
+            m.feed_data(data)
+            m.optimize_parameters(st)
+        torch.cuda.synchronize()
+        plan = m._out_plans[0]
+        for rnd in (1, 2):
+            for us_off in [int(x) for x in a.stagger.split(',')]:
+                _lib.check(L.dasr_set_tuning(8, us_off))
+                row = []
+                for ch in (plan.chain, plan.chain_b):
+                    one = OpList()
+                    one.add(ch.op())
+                    one.run()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(4):
+                        one.run()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    row.append(e0.elapsed_time(e1) / 4 * 1e3)
+                print('stagger %4d us: forward chain %.1f us, data-gradient chain %.1f us per launch' % (us_off, row[0], row[1]))
+                sys.stdout.flush()
+        _lib.check(L.dasr_set_tuning(8, 0))
+        plan.check_chain()
+        return
+    for form in [int(x) for x in a.forms.split(',')]:
         ntiles = a.n * ((a.lr + 15) // 16) * ((a.lr + 31) // 32)
         if form == 1 and ntiles != 512:
             continue
@@ -76,6 +107,18 @@ def main():
                 torch.cuda.synchronize()
                 _lib.check(L.dasr_debug_set_trace(None))
                 t = buf[CH_BASE:CH_BASE + 512 * 64].view(512, 8, 8).cpu().numpy().astype(np.float64)
+                raw = buf[CH_BASE:CH_BASE + 512 * 64].view(512, 64).cpu().numpy()
+                hw, tick, xcc = raw[:, 56], raw[:, 57], raw[:, 58] & 7
+                cu_key = xcc * 4096 + ((hw >> 13) & 7) * 64 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 15)   # (XCC, SE_ID, SH_ID, CU_ID) of HW_REG_HW_ID
+                T = ntiles // a.n
+                img = tick // T
+                cus = {}
+                for k, im in zip(cu_key.tolist(), img.tolist()):
+                    cus.setdefault(k, []).append(im)
+                sizes = sorted(len(v) for v in cus.values())
+                mixed = sum(1 for v in cus.values() if len(set(v)) > 1)
+                print('    placement: %d workgroups on %d distinct (XCC, SE, SH, CU) ids, workgroups per id min %d max %d; ids that host tiles of two different images: %d' % (
+                    len(tick), len(cus), sizes[0], sizes[-1], mixed))
                 names = ['entry', 'chunk0', 'loop', '(poll)', 'epilogue', 'publish']
                 for ty, tn in enumerate(('conv1 (64 ch in, waits up front)', 'conv2-4 (Cout 32)', 'conv5-class (Cout 64)')):
                     items = t[:, ty, 6]
@@ -89,7 +132,7 @@ def main():
                     print('        ' + '  '.join('%s %6.0f' % (nm, per[:, i].mean()) for i, nm in enumerate(names)) +
                           '  | loop per chunk %5.0f (MFMA-bound at 2 waves/SIMD: %d)' % ((per[:, 2].mean() - per[:, 3].mean()) / chunks, 2304 if ty < 2 else 4608))
             sys.stdout.flush()
-    _lib.check(L.dasr_set_tuning(7, 2))
+    _lib.check(L.dasr_set_tuning(7, 1))
 
 
 if __name__ == '__main__':

@@ -227,13 +227,13 @@ def test_f16_dense_block_gradient_scale_is_consistently_patched(monkeypatch):
 
 
 @pytest.mark.parametrize('shape', [(16, 128, 128, 2, 2), (8, 256, 128, 1, 2), (32, 128, 128, 1, 2), (16, 128, 256, 2, 2), (24, 128, 256, 1, 2), (16, 128, 128, 2, 1)],
-                         ids=['16x128x128', '8x256x128', '32x128x128-2tiles', '16x128x256-2tiles', '24x128x256-3tiles', '16x128x128-round4_form'])
+                         ids=['16x128x128-form2', '8x256x128-form2', '32x128x128-2tiles', '16x128x256-2tiles', '24x128x256-3tiles', '16x128x128-form1'])
 def test_chained_trunk_launches_are_bit_identical_to_per_layer_launches(shape, monkeypatch):
     """DASR_CHAIN (default on where the batch is a multiple of what fills the chip, RRDBNetHIP.chain_ok): the 15 nb dense-block convs of the forward and of
     the data gradient each run as ONE persistent launch in which a tile waits for its neighbour tiles only before the input chunks the previous layer wrote
     (dasr_conv_chain).  Same arithmetic in the same order: SR output, every gradient and the weights after two Adam steps must be BIT-identical to the
     per-layer launches, and the device error word stays zero (no neighbour wait gave up).  Round 5: workgroups that own two / three tiles (1024 / 1536
-    tiles: configs[2]'s 32 crops), and the round-4 form of the kernel (dasr_set_tuning key 7 = 1) next to the default one."""
+    tiles: configs[2]'s 32 crops) run conv_chain2_kernel; the exact fit runs conv_chain_kernel by default (dasr_set_tuning key 7 = 1) and conv_chain2_kernel with key 7 = 2."""
     _gpu()
     if torch.cuda.get_device_properties(0).multi_processor_count != 256:
         pytest.skip('the chained launches need a whole 256-CU MI355X (RRDBNetHIP.chain_ok)')
@@ -246,7 +246,6 @@ def test_chained_trunk_launches_are_bit_identical_to_per_layer_launches(shape, m
     batch = fixtures.make_batch(case, seed=11)
     outs = []
     monkeypatch.setenv('DASR_STREAMS', '1')   # like for like: one plan over the whole batch on both sides (the sub-batch schedule sums the weight gradients in another order)
-    monkeypatch.setenv('DASR_TUNE', '7=%d' % form)   # (read by chain_ok; the library itself is switched below -- it may be loaded already)
     _lib.check(_lib.lib().dasr_set_tuning(7, form))
     try:
         for chain in ('0', '1'):
@@ -271,7 +270,7 @@ def test_chained_trunk_launches_are_bit_identical_to_per_layer_launches(shape, m
             del m
             torch.cuda.empty_cache()
     finally:
-        _lib.check(_lib.lib().dasr_set_tuning(7, 2))
+        _lib.check(_lib.lib().dasr_set_tuning(7, 1))
     (s0, g0, w0), (s1, g1, w1) = outs
     assert torch.equal(s0, s1) and torch.equal(g0, g1) and torch.equal(w0, w1)
 
