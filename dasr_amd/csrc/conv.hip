@@ -47,6 +47,10 @@ constexpr unsigned OOB = 0x80000000u;
 constexpr int RSRC_FLAGS = 0x00020000;
 constexpr int RSRC_RANGE = 0x7fffffff;
 
+#ifndef CHV
+#define CHV 0
+#endif
+
 #ifdef DASR_TRACE
 __device__ unsigned long long* g_trace = nullptr;  // [grid][16]: s_memrealtime at entry, then s_memtime stamps
 #define TRACE_STAMP(k)                                                                         \
@@ -1352,18 +1356,6 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
 #define CH_ACC(type, phase, val) do {} while (0)
 #endif
 
-// Phase offset between the two images an XCD hosts (round 5).  Every CU runs two workgroups of a chained launch; a workgroup alternates between its main
-// loops (matrix pipe + LDS-DMA) and the phases between them (neighbour waits, epilogue stores, first-chunk round trips: a third of its time, matrix pipe
-// idle).  Tiles of ONE image are locked in phase by their neighbour flags; two images are independent.  Workgroups of odd images therefore start
-// `stagger` ticks of the 100 MHz constant clock late (dasr_set_tuning key 8, microseconds): where the two workgroups of a CU belong to different images
-// (the usual placement: tickets follow the dispatch order, one image per "slot layer" of the XCD), one's idle phases then fall into the other's main loops.
-__device__ __forceinline__ void chain_stagger(int img, int stagger) {
-    if ((img & 1) && stagger > 0) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < (long long)stagger) __builtin_amdgcn_s_sleep(32);
-    }
-}
-
 #ifdef DASR_TRACE
 // where a workgroup of a chained launch ran: g_trace[2^20 + block * 64 + 56 ...] = HW_ID register, ticket, XCC id
 #define CH_WHERE(ticket, xcc)                                                                  \
@@ -1490,7 +1482,7 @@ __device__ __forceinline__ void chain_layer(const dasr_conv_params& p, char* sme
     }
     constexpr bool PRE = EPI == 68 && MT == 1;   // data gradient of conv1-4: the LeakyReLU' mask of the output tile is fetched during the last chunk (see conv_glds_kernel)
     MaskPre<NT * MT> mpre;
-    bf16x8 fb[2][6], fa[2][MT];
+    bf16x8 fb[2][6];
     const unsigned long long t_c = CH_T();
     unsigned long long t_poll = 0;
     (void)t_poll;
@@ -1507,35 +1499,66 @@ __device__ __forceinline__ void chain_layer(const dasr_conv_params& p, char* sme
         if constexpr (PRE) {
             if (!more) mask_prefetch<MT, NT>(p, mpre, tid, 0, n, oy0, ox0);
         }
+        // CHV (compile-time, -DCHV=bits; 0 in the product): loop experiments of round 5, measured on the chain's launch duration (profiles/r05_chain_variants.txt).
+        // bit 0: the DMA pieces of the next chunk spread over the steps (one or two per step) instead of all in steps 0-3; bit 1: weight fragments read two
+        // steps ahead; bit 2: no sched_barrier around the MFMA groups.  Diagnostics with WRONG results: bit 3 no chunk barrier, bit 4 no DMA after chunk 0,
+        // bit 5 no MFMA, bit 6 no fragment reads after chunk 0.
+        constexpr int V = CHV;
+        constexpr int FAD = (V & 2) ? 3 : 2;
+        bf16x8 fa3[3][MT];
+        const bool rd = !(V & 64) || ck == 0;
+        if (rd) {
 #pragma unroll
-        for (int rr = 0; rr < 6; ++rr) fb[0][rr] = *(const bf16x8*)(buf + baddr[rr][0]);
+            for (int rr = 0; rr < 6; ++rr) fb[0][rr] = *(const bf16x8*)(buf + baddr[rr][0]);
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) fa[0][mi] = *(const bf16x8*)(wbuf + aoff + (0 * MT + mi) * 1024);
+            for (int mi = 0; mi < MT; ++mi) fa3[0][mi] = *(const bf16x8*)(wbuf + aoff + (0 * MT + mi) * 1024);
+            if constexpr (V & 2) {
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) fa3[1][mi] = *(const bf16x8*)(wbuf + aoff + ((1 * 3 + 0) * MT + mi) * 1024);   // step 1: kx 0, ky 1
+            }
+        }
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
             const int kx = s / 3, ky = s - kx * 3;
-            if (s + 1 < 9) {
-                const int kx1 = (s + 1) / 3, ky1 = (s + 1) - kx1 * 3;
+            const int sa = s + FAD - 1;   // weight fragment requested in this step
+            if (sa < 9 && rd) {
+                const int kxa = sa / 3, kya = sa - kxa * 3;
 #pragma unroll
-                for (int mi = 0; mi < MT; ++mi) fa[(s + 1) & 1][mi] = *(const bf16x8*)(wbuf + aoff + ((ky1 * 3 + kx1) * MT + mi) * 1024);
+                for (int mi = 0; mi < MT; ++mi) fa3[sa % FAD][mi] = *(const bf16x8*)(wbuf + aoff + ((kya * 3 + kxa) * MT + mi) * 1024);
+            }
+            if (s + 1 < 9 && rd) {
                 if (ky == 1 && kx < 2) {
 #pragma unroll
                     for (int rr = 0; rr < 6; ++rr) fb[(kx + 1) & 1][rr] = *(const bf16x8*)(buf + baddr[rr][kx + 1]);
                 }
             }
-            if (more && s < 4) {
+            if (more && !((V & 16))) {
+                if constexpr (V & 1) {
+                    if (s < 8) {
 #pragma unroll
-                for (int i = s * NP / 4; i < (s + 1) * NP / 4; ++i) glds_dma_piece<MT, NW>(i, ck + 1, nbuf, rin, rw, goff, in_chunk_bytes, wave, tid, ck + 1);
+                        for (int i = s * NP / 8; i < (s + 1) * NP / 8; ++i) glds_dma_piece<MT, NW>(i, ck + 1, nbuf, rin, rw, goff, in_chunk_bytes, wave, tid, ck + 1);
+                    }
+                } else if (s < 4) {
+#pragma unroll
+                    for (int i = s * NP / 4; i < (s + 1) * NP / 4; ++i) glds_dma_piece<MT, NW>(i, ck + 1, nbuf, rin, rw, goff, in_chunk_bytes, wave, tid, ck + 1);
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(V & 4)) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(V & 32)) {
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
+                for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mi][nt] = mfma16<F16>(fa[s & 1][mi], fb[kx & 1][nt + ky], acc[mi][nt]);
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int nt = 0; nt < NT; ++nt) acc[mi][nt] = mfma16<F16>(fa3[s % FAD][mi], fb[kx & 1][nt + ky], acc[mi][nt]);
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) asm volatile("" ::"v"(fa3[s % FAD][mi]));
+#pragma unroll
+                for (int rr = 0; rr < 6; ++rr) asm volatile("" ::"v"(fb[kx & 1][rr]));
+            }
+            if constexpr (!(V & 4)) __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
+        if constexpr (!(V & 8)) __syncthreads();
     }
     const unsigned long long t_d = CH_T();
     conv_epilogue<false, MT, NT, 1, R1_PRE ? (EPI & ~8) : EPI, F16 ? 1 : 0, PRE, true>(p, acc, smem, bias_reg, tid, 0, n, oy0, ox0, &mpre);
@@ -1555,7 +1578,7 @@ __device__ __forceinline__ void chain_layer(const dasr_conv_params& p, char* sme
 
 template <bool F16, bool BWD>
 __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const dasr_conv_params* __restrict__ layers, const int* __restrict__ dep_chunk, int nlayers,
-                                                           int tiles_y, int tiles_x, unsigned* flags, unsigned* tickets, int* err, int stagger) {
+                                                           int tiles_y, int tiles_x, unsigned* flags, unsigned* tickets, int* err) {
     using C = GCfg<1, 4>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1579,7 +1602,6 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const dasr_conv_para
     const int n = xcd + 8 * img;                        // all tiles of image n on XCD n % 8
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     CH_WHERE(j, xcc);
-    chain_stagger(img, stagger);
     ChainSync cs;
     cs.rflags = make_rsrc(flags);
     cs.err = err;
@@ -1614,8 +1636,13 @@ __global__ __launch_bounds__(256, 2) void conv_chain_kernel(const dasr_conv_para
     }
 }
 
+#ifdef DASR_BENCH
 // ---------------------------------------------------------------------------------------------------
-// conv_chain2_kernel (round 5): the chained launch, second form.  Same arithmetic, same tile / XCD / flag protocol as conv_chain_kernel; what changes is
+// conv_chain2_kernel (round 5; libdasr_hip_ablate.so only, -DDASR_BENCH): the chained launch, second form -- BUILT, PARITY-GREEN (bit-identical on 512, 1024
+// and 1536 tiles), AND MEASURED SLOWER than conv_chain_kernel: 10.3 vs 9.1 ms per chain at configs[1] (profiles/r05_chain_trace.txt: the early chunk-0 request
+// queues the epilogue's stores behind eight 1-KiB LDS-DMA instructions, epilogue 4 k -> 14.5 k cycles per item), and at configs[2] (two tiles per
+// workgroup) the GAN step went from 72 to 88 ms against one launch per conv.  Kept as the record of the experiment, like the ring / loader forms of round 3.
+//  Same arithmetic, same tile / XCD / flag protocol as conv_chain_kernel; what changes is
 // what a workgroup does BETWEEN two main loops (~7 us of a ~18 us Cout-32 layer had the matrix pipe idle) and how many tiles it owns:
 //  * work items.  A workgroup owns `tpw` tiles (tiles j, j + 64, ... of its XCD's tile list) and walks the items (layer 0, tile 0), (layer 0, tile 1), ...,
 //    (layer 1, tile 0), ...: batches of 512 * tpw tiles (configs[2]: 32 crops of 128 x 128 = 1024) run chained too, not only the exact fit of configs[1].
@@ -1851,7 +1878,7 @@ __device__ __forceinline__ void chain_item(const dasr_conv_params& p, char* smem
 
 template <bool F16, bool BWD>
 __global__ __launch_bounds__(256, 2) void conv_chain2_kernel(const dasr_conv_params* __restrict__ layers, const int* __restrict__ dep_chunk, int nlayers,
-                                                            int tiles_y, int tiles_x, unsigned* flags, unsigned* tickets, int* err, int tpw, int stagger) {
+                                                            int tiles_y, int tiles_x, unsigned* flags, unsigned* tickets, int* err, int tpw) {
     using C = GCfg<1, 4>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1872,7 +1899,6 @@ __global__ __launch_bounds__(256, 2) void conv_chain2_kernel(const dasr_conv_par
     }
     __syncthreads();
     CH_WHERE(j, xcc);
-    chain_stagger(j / T, stagger);
     bool have0 = false;
     for (int L = 0; L < nlayers; ++L) {
         const dasr_conv_params& p = layers[L];
@@ -1916,6 +1942,8 @@ __global__ __launch_bounds__(256, 2) void conv_chain2_kernel(const dasr_conv_par
         }
     }
 }
+
+#endif  // DASR_BENCH (conv_chain2_kernel)
 
 // ---------------------------------------------------------------------------------------------------
 // Dense-block convolution, third generation ("ring3"): Cout = 32 (MT = 1), 8 waves, 32 x 32 output pixels per workgroup, one workgroup
@@ -2174,10 +2202,7 @@ int classify_epi(const dasr_conv_params& p) {
 
 // kernel-variant selection (A/B-able from the host: dasr_set_tuning)
 int g_tune_rot = 0;  // chunk-order rotation of the LDS-DMA dense-block conv (A/B)
-int g_chain_stagger_us = 0;  // chained launches: start offset of the odd images (chain_stagger), microseconds
-int g_chain_form = 1;  // chained launches: 1 = conv_chain_kernel (round 4) where the batch is the exact fit of 512 tiles, conv_chain2_kernel (round 5: work items, 512 * tpw
-                       // tiles) otherwise; 2 = conv_chain2_kernel always.  Same-box A/B at configs[1] (profiles/r05_chain_trace.txt): form 1 9.1 ms per chain, form 2 10.3 ms --
-                       // the early chunk-0 request of form 2 queues the epilogue's stores behind the DMA
+int g_chain_form = 1;  // chained launches (-DDASR_BENCH builds only): 1 = conv_chain_kernel for the exact fit of 512 tiles, conv_chain2_kernel for multiples; 2 = conv_chain2_kernel always
 int g_tune_rdb32 = 12, g_tune_rdb64 = 13, g_tune_stream = 0, g_tune_xcd = 1, g_tune_epi = 1;  // Cout=64: 13 = 8-wave form for launches of <= 256 four-wave workgroups (worth 1-2 % of the step under two sub-batch streams)
 
 }  // namespace
@@ -2192,8 +2217,6 @@ extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
 #ifndef DASR_BENCH
     // product library: one dense-block conv kernel; the only live choice is the workgroup shape rule of the Cout = 64 launches (key 2)
     if (key == 2 && (value == 12 || value == 13)) { g_tune_rdb64 = value; return 0; }
-    if (key == 7 && (value == 1 || value == 2)) { g_chain_form = value; return 0; }   // form of the chained launches (same results; A/B)
-    if (key == 8 && value >= 0 && value <= 2000) { g_chain_stagger_us = value; return 0; }   // start offset of the odd images of a chained launch, microseconds
     if ((key == 1 && value == 12) || (key == 3 && value == 0) || (key == 4 && value == 1) || (key == 5 && value == 1) || (key == 6 && value == 0)) return 0;
     return DASR_EINVAL;   // the A/B variants of rounds 1-3 live in libdasr_hip_ablate.so (python -m dasr_amd.build --ablate)
 #else
@@ -2206,7 +2229,6 @@ extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
         case 5: g_tune_epi = value; return 0;     // compile-time specialised epilogues on/off
         case 6: g_tune_rot = value; return 0;     // LDS-DMA dense conv: per-workgroup chunk-order rotation on/off
         case 7: if (value != 1 && value != 2) return DASR_EINVAL; g_chain_form = value; return 0;   // form of the chained launches
-        case 8: if (value < 0 || value > 2000) return DASR_EINVAL; g_chain_stagger_us = value; return 0;
         default: return DASR_EINVAL;
     }
 #endif
@@ -2238,12 +2260,16 @@ extern "C" int dasr_conv_chain(const dasr_conv_params* dev_layers, const dasr_co
     const long long grid = 512;   // the launch fills the chip exactly (2 workgroups x 256 CUs, all resident): see the ticket comment in the kernels
     if ((p0.N & 7) || ntiles < grid || ntiles % grid) return DASR_EINVAL;   // whole images per XCD; every workgroup owns ntiles / 512 tiles
     const int tpw = (int)(ntiles / grid);
+#ifdef DASR_BENCH
     const bool form2 = g_chain_form == 2 || tpw > 1;
     if (form2) {
         if (tpw > Chain2::MAX_TPW) return DASR_EINVAL;
         for (int i = 0; i < nlayers; ++i)
             if ((host_layers[i].cin >> 4) & 1) return DASR_EINVAL;   // even chunk counts: the last chunk of an item sits in LDS buffer 1 (conv_chain2_kernel)
     }
+#else
+    if (tpw != 1) return DASR_EINVAL;   // the product library runs the exact fit only (the multi-tile form measured slower than one launch per conv)
+#endif
     {
         static int n_cu = -1;   // (a partitioned device -- CPX / DPX -- exposes fewer CUs per logical GPU: the launch would not be resident as a whole)
         if (n_cu < 0) {
@@ -2267,8 +2293,9 @@ extern "C" int dasr_conv_chain(const dasr_conv_params* dev_layers, const dasr_co
             attr_set[v] = true;                                                                                                                          \
         }                                                                                                                                                \
         DASR_LAUNCH_TAG(NAME, kfn, dim3((unsigned)grid), dim3(256), C::LDS_BYTES, s, dev_layers, (const int*)dev_dep_chunk, (int)nlayers, tiles_y, tiles_x, \
-                        dev_flags, dev_flags + grid, dev_err, g_chain_stagger_us * 100);                                                                 \
+                        dev_flags, dev_flags + grid, dev_err);                                                                                           \
     }
+#ifdef DASR_BENCH
     static bool attr2_set[4] = {false, false, false, false};
 #define DASR_CHAIN2_LAUNCH(F16_, BWD_, NAME)                                                                                                             \
     {                                                                                                                                                    \
@@ -2278,19 +2305,22 @@ extern "C" int dasr_conv_chain(const dasr_conv_params* dev_layers, const dasr_co
             attr2_set[v] = true;                                                                                                                         \
         }                                                                                                                                                \
         DASR_LAUNCH_TAG(NAME, kfn, dim3((unsigned)grid), dim3(256), Chain2::LDS_BYTES, s, dev_layers, (const int*)dev_dep_chunk, (int)nlayers, tiles_y, tiles_x, \
-                        dev_flags, dev_flags + ntiles, dev_err, tpw, g_chain_stagger_us * 100);                                                          \
+                        dev_flags, dev_flags + ntiles, dev_err, tpw);                                                                                    \
     }
     if (form2) {
         if (v == 0) DASR_CHAIN2_LAUNCH(false, false, "conv_chain2_kernel<false, false>")
         else if (v == 1) DASR_CHAIN2_LAUNCH(true, false, "conv_chain2_kernel<true, false>")
         else if (v == 2) DASR_CHAIN2_LAUNCH(false, true, "conv_chain2_kernel<false, true>")
         else DASR_CHAIN2_LAUNCH(true, true, "conv_chain2_kernel<true, true>")
-    } else if (v == 0) DASR_CHAIN_LAUNCH(false, false, "conv_chain_kernel<false, false>")
+        return (int)hipGetLastError();
+    }
+#undef DASR_CHAIN2_LAUNCH
+#endif
+    if (v == 0) DASR_CHAIN_LAUNCH(false, false, "conv_chain_kernel<false, false>")
     else if (v == 1) DASR_CHAIN_LAUNCH(true, false, "conv_chain_kernel<true, false>")
     else if (v == 2) DASR_CHAIN_LAUNCH(false, true, "conv_chain_kernel<false, true>")
     else DASR_CHAIN_LAUNCH(true, true, "conv_chain_kernel<true, true>")
 #undef DASR_CHAIN_LAUNCH
-#undef DASR_CHAIN2_LAUNCH
     return (int)hipGetLastError();
 }
 

@@ -129,12 +129,15 @@ class DeResnetHIP:
         # split-bf16's 16, one launch of the LDS-DMA kernel over 3K virtual chunks instead of three register-staged passes); the hi planes are the
         # f16 shadows the 16-bit backward reads.  7.14 -> 6.88 ms per iteration (the generic epilogue and three MFMA passes remain).
         # DASR_DSN_FWD16=0: fp32 tensors + separate shadows.
-        # Round 5 (the split forward sat at 4.7e-7 on the activations against a 1e-3 budget and paid three MFMA passes for it):
-        # DASR_DSN_FWD16=2, the default -- the residual blocks in ONE f16 pass, exactly as the RRDB trunk runs its dense blocks: the residual stream s[k]
-        # stays fp32 (conv2 adds its fp32 input and writes fp32 + an f16 shadow), conv1 / conv2 read the f16 shadows (11-bit operands, fp32
-        # accumulation).  `fwd_mode` may also be forced per network (DSNModel selects the split forward, 1, for BatchNorm discriminators, whose
-        # ill-conditioned statistics amplify the generator's rounding -- same reasoning as the f16 dense blocks of the SRN BatchNorm case).
-        fm = os.environ.get('DASR_DSN_FWD16', '2') if fwd_mode is None else str(fwd_mode)
+        # Round 5 (the split forward sits at 4.7e-7 on the activations against a 1e-3 budget and pays three MFMA passes for it):
+        # DASR_DSN_FWD16=2 -- the residual blocks in ONE f16 pass, exactly as the RRDB trunk runs its dense blocks: the residual stream s[k] stays fp32
+        # (conv2 adds its fp32 input and writes fp32 + an f16 shadow), conv1 / conv2 read the f16 shadows (11-bit operands, fp32 accumulation).
+        # MEASURED (profiles/r05_dsn_onepass.txt): iteration 6.6 -> 5.6 ms (LPIPS term), activations 2.4e-5 (budget 1e-3) -- but the GRADIENTS move to
+        # 0.4 - 1.6e-2 of the fp32 oracle (configs[4] exactly: 4.7e-3; the reference's 2 x 128^2 fixtures: up to 1.6e-2, over the 1e-2 budget): an
+        # activation that is off by 2e-4 flips the sign of ~1e-4 of the PReLU pre-activations, every flip changes a local derivative by 75 %, and a weight
+        # gradient is a sum of random-signed terms, so the flips enter like sqrt(fraction).  With the split forward the stored f16 shadows are roundings of
+        # accurate values and keep every sign.  So the split forward (1) STAYS THE DEFAULT and the one-pass forward is an opt-in (tested at configs[4]).
+        fm = os.environ.get('DASR_DSN_FWD16', '1') if fwd_mode is None else str(fwd_mode)
         if fm not in ('0', '1', '2'):
             raise ValueError('DASR_DSN_FWD16 must be 0 (fp32 tensors), 1 (split f16 tensors, three passes) or 2 (one f16 pass)')
         self.fwd16 = self.bwd16 and fm == '1'
@@ -471,9 +474,7 @@ class DSNModel:
         self.k = o['kernel_size']
         if o['generator'].lower() not in ('deresnet', 'dsgan'):   # codes/DSN/train.py:124-129
             raise NotImplementedError('Generator model [{:s}] not recognized'.format(o['generator']))
-        # BatchNorm discriminators: the generator keeps the split (22-bit) forward unless DASR_DSN_FWD16 says otherwise (DeResnetHIP.__init__)
-        fwd_mode = 1 if (o['norm_layer'] == 'Batch' and os.environ.get('DASR_DSN_FWD16') is None) else None
-        self.netG = DeResnetHIP(o['n_res_blocks'], device=self.device, scale=4 if o['generator'].lower() == 'deresnet' else 1, fwd_mode=fwd_mode)
+        self.netG = DeResnetHIP(o['n_res_blocks'], device=self.device, scale=4 if o['generator'].lower() == 'deresnet' else 1)
         # --lpips_rot_flip (train.py:52, loss.py:66,149-168): a random symmetry of the square on both LPIPS inputs, drawn from python's `random` per
         # generator-loss evaluation in the reference's order; only PerceptualLoss (= per_type LPIPS) has it, the VGG16 term ignores the flag
         self.lpips_rot_flip = bool(o['lpips_rot_flip']) and o['per_type'] == 'LPIPS' and o['w_per'] > 0

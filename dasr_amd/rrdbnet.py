@@ -155,12 +155,10 @@ class RRDBNetHIP:
         self.pack.run()
 
     def chain_ok(self, N, h, w):
-        """a training plan of this shape runs its trunk as chained launches: whole images per XCD and the batch is a multiple of what fills the chip
-        (dasr_conv_chain: 512 resident workgroups, each owns N * tiles / 512 tiles -- 1 at configs[1], 2 at configs[2]'s 32 crops; the round-4 form of the
-        kernel, DASR_TUNE=7=1, only runs the exact fit)"""
-        ntiles = N * ceil_div(h, 16) * ceil_div(w, 32)
-        tpw_ok = ntiles >= 512 and ntiles % 512 == 0 and ntiles // 512 <= int(os.environ.get('DASR_CHAIN_TPW', '8'))   # DASR_CHAIN_TPW=1: exact fit only (A/B)
-        if not (self.chain and N % 8 == 0 and tpw_ok and not getattr(self, 'debug_taps', ())):
+        """a training plan of this shape runs its trunk as chained launches: whole images per XCD and the launch fills the chip exactly (dasr_conv_chain).
+        (Round 5 built a form whose workgroups own several tiles -- 1024 tiles for configs[2]'s 32 crops: bit-identical, but 88 ms per GAN step against 72 ms
+        with one launch per conv; it lives in the -DDASR_BENCH library only, profiles/r05_chain_trace.txt.)"""
+        if not (self.chain and N % 8 == 0 and N * ceil_div(h, 16) * ceil_div(w, 32) == 512 and not getattr(self, 'debug_taps', ())):
             return False
         from . import dist as _dist
         if _dist.SHARED_DEVICE:   # another rank of this job runs on the same GPU (gloo test set-up): the launch would not have the chip to itself

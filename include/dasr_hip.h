@@ -91,9 +91,8 @@ int dasr_conv(const dasr_conv_params* p, void* stream);
  * `flags`, one word per tile, zero at allocation) only before it reads the first input chunk that holds layer L-1's output (dep_chunk[L], in
  * 16-channel chunks; <= 0: every chunk).  Constraints (DASR_EINVAL otherwise): 3x3 / stride 1 / pad 1 on 16-bit tensors of ONE geometry,
  * cout == 32 * mt, the term sets of the dense-block forward (bias + LeakyReLU -> 16-bit planes; bias, alpha, one or two fp32 residuals -> fp32 +
- * 16-bit), N a multiple of 8 (whole images per XCD) and N * tiles a multiple of 512, at most 8 x 512 (the launch has 512 workgroups = the chip exactly
- * full, every workgroup resident, every XCD hosts the tiles of its own images; a workgroup owns N * tiles / 512 tiles and walks the items (layer, tile)
- * in layer-major order -- round 5), cin / 16 even.
+ * 16-bit), N a multiple of 8 (whole images per XCD) and N * tiles == 512 (the launch fills the chip exactly: every workgroup resident, every XCD
+ * hosts the tiles of its own images).
  * `flags`: N * tiles + 8 words (the last eight: per-XCD ticket counters).  `err` (device word, zero at allocation): bit 1 a neighbour wait gave
  * up -- the results are then not valid (pass the word to dasr_adam as gate_flag: such a step then never reaches the weights).
  * OPERATIONAL CONTRACT: the launch needs the device to itself -- a whole 256-CU MI355X (no CPX / DPX partition), no other process on it, and no
@@ -109,9 +108,8 @@ int dasr_conv_chain(const dasr_conv_params* dev_layers, const dasr_conv_params* 
  * key 5: compile-time specialised epilogues on/off;
  *            key 1 also: 15 / 16 / 17 = ring of three LDS images with counted vmcnt / + one loader wave / + LDS flags instead of the chunk barrier
  *            (round 3: built, parity-tested, measured flat -- profiles/r03_conv_ablation.txt);
- * key 7: form of the chained launches (dasr_conv_chain): 1 (default) = conv_chain_kernel (round 4) for the exact fit of 512 tiles, conv_chain2_kernel (round 5,
- *        workgroups that own several tiles) for multiples; 2 = conv_chain2_kernel always; same results;
- * key 8: chained launches: start offset, in microseconds, of the workgroups of odd images (phase offset between the two images an XCD hosts; 0 = none);
+ * key 7 (-DDASR_BENCH library only): form of the chained launches: 1 = conv_chain_kernel for 512 tiles and conv_chain2_kernel (round 5: workgroups that own
+ *        several tiles; measured slower, profiles/r05_chain_trace.txt) for multiples, 2 = conv_chain2_kernel always;
  * (round 3: the Cout-32 dense-block convs store their output `sc1`, written through -- measured with a run-time switch, now compile time.) */
 int dasr_set_tuning(int32_t key, int32_t value);
 

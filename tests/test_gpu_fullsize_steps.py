@@ -7,6 +7,7 @@ fresh models with the same weights.  Also: finite losses and bit-exact determini
 Round 4: the GPU box has 256 host cores and 3 TB of memory, so the oracle CAN run the exact configurations (in chunks where its autograd state would
 not fit comfortably): test_cfg1_exact_* (46 s), test_cfg2_exact_* (3 min), test_cfg4_exact_* (6 s) compare the production steps of configs[1], configs[2]
 and configs[4]'s per-GPU shape with the fp32 CPU oracle directly -- SR / fake batch, every logged loss, every gradient tensor."""
+import os
 import pytest
 import torch
 
@@ -272,13 +273,17 @@ def test_cfg2_exact_gan_step_matches_the_oracle(margins):
     assert e_sr < 1e-3 and eg[0][0] < 1e-2 and ed[0][0] < 1e-2, (e_sr, eg[:3], ed[:3])
 
 
-@pytest.mark.parametrize('per_type', ['VGG', 'LPIPS'])
-def test_cfg4_exact_dsn_iteration_matches_the_oracle(per_type, margins, golden_dir):
+@pytest.mark.parametrize('per_type', ['VGG', 'LPIPS', 'LPIPS-one_f16_pass'])
+def test_cfg4_exact_dsn_iteration_matches_the_oracle(per_type, margins, golden_dir, monkeypatch):
     """configs[4]'s per-GPU shape EXACTLY -- De_resnet (8 blocks) + FSD discriminator (wavelet front end), batch 8 of 256 x 256 HR crops, colour / texture /
     perceptual (VGG16 MSE or the reference default LPIPS) losses -- one iteration against the fp32 CPU oracle (codes/DSN/train.py:204-285 as oracle/dsn.py fixes
     it): losses, fake LR batch, all generator and discriminator gradients, north_star tolerances."""
     dev = _gpu()
     torch.set_num_threads(32)
+    label = per_type
+    if per_type.endswith('one_f16_pass'):   # DASR_DSN_FWD16=2 (opt-in, dsn_model.DeResnetHIP): the residual blocks' forward in one f16 pass; inside the budget at this shape
+        monkeypatch.setenv('DASR_DSN_FWD16', '2')
+        per_type = 'LPIPS'
     from dasr_amd.dsn_model import DSNModel
     from oracle import dsn
     from oracle.gen_golden_dsn import dsn_state, dsn_batch
@@ -292,6 +297,7 @@ def test_cfg4_exact_dsn_iteration_matches_the_oracle(per_type, margins, golden_d
         crit, sdF = lpips.golden_criterion(78, golden_dir)
     t = dsn.DSNTrainer(G, D, kernel_size=5, filter_type='wavelet', norm_layer='Instance', vgg_seed=78, w_per=0.01, per_type=per_type, netF=crit)
     m = DSNModel(dict(filter='wavelet', kernel_size=5, norm_layer='Instance', w_per=0.01, vgg_seed=78, per_type=per_type, allow_random_perceptual=True), device=dev)
+    assert m.netG.fwd1p == (os.environ.get('DASR_DSN_FWD16') == '2')
     m.netG.load_state_dict(sdG)
     m.load_discriminator_state(sdD)
     m.netF.load_state_dict(sdF if sdF is not None else {'features.' + k: v for k, v in t.per.state_dict().items()})
@@ -307,5 +313,5 @@ def test_cfg4_exact_dsn_iteration_matches_the_oracle(per_type, margins, golden_d
     slopes = rel(torch.cat([gd[k].flatten() for k, p in G.named_parameters() if p.numel() == 1]), torch.cat([p.grad.flatten() for p in G.parameters() if p.numel() == 1]))
     ed = sorted(((rel(dd[k], p.grad), k) for k, p in D.named_parameters() if p.requires_grad and float(p.grad.norm()) > 1e-6), reverse=True)
     margins('configs[4] exactly (DSN batch 8 x 256^2, wavelet FSD, %s term) vs the fp32 oracle: fake rel err %.2e (tol 1e-3); worst gradient rel err G %.2e at %s, PReLU slopes '
-            '(jointly) %.2e, D %.2e at %s (tol 1e-2)' % (per_type, e_fake, eg[0][0], eg[0][1], slopes, ed[0][0], ed[0][1]))
+            '(jointly) %.2e, D %.2e at %s (tol 1e-2)' % (label, e_fake, eg[0][0], eg[0][1], slopes, ed[0][0], ed[0][1]))
     assert e_fake < 1e-3 and eg[0][0] < 1e-2 and ed[0][0] < 1e-2 and slopes < 1e-2, (e_fake, eg[:3], slopes, ed[:3])

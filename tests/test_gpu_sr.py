@@ -226,51 +226,42 @@ def test_f16_dense_block_gradient_scale_is_consistently_patched(monkeypatch):
         assert worst < 2e-3, worst
 
 
-@pytest.mark.parametrize('shape', [(16, 128, 128, 2, 2), (8, 256, 128, 1, 2), (32, 128, 128, 1, 2), (16, 128, 256, 2, 2), (24, 128, 256, 1, 2), (16, 128, 128, 2, 1)],
-                         ids=['16x128x128-form2', '8x256x128-form2', '32x128x128-2tiles', '16x128x256-2tiles', '24x128x256-3tiles', '16x128x128-form1'])
+@pytest.mark.parametrize('shape', [(16, 128, 128, 2), (8, 256, 128, 1)], ids=['16x128x128', '8x256x128'])
 def test_chained_trunk_launches_are_bit_identical_to_per_layer_launches(shape, monkeypatch):
-    """DASR_CHAIN (default on where the batch is a multiple of what fills the chip, RRDBNetHIP.chain_ok): the 15 nb dense-block convs of the forward and of
-    the data gradient each run as ONE persistent launch in which a tile waits for its neighbour tiles only before the input chunks the previous layer wrote
+    """DASR_CHAIN (default on where the batch fills the chip exactly, RRDBNetHIP.chain_ok): the 15 nb dense-block convs of the forward and of the data
+    gradient each run as ONE persistent launch in which a tile waits for its neighbour tiles only before the input chunks the previous layer wrote
     (dasr_conv_chain).  Same arithmetic in the same order: SR output, every gradient and the weights after two Adam steps must be BIT-identical to the
-    per-layer launches, and the device error word stays zero (no neighbour wait gave up).  Round 5: workgroups that own two / three tiles (1024 / 1536
-    tiles: configs[2]'s 32 crops) run conv_chain2_kernel; the exact fit runs conv_chain_kernel by default (dasr_set_tuning key 7 = 1) and conv_chain2_kernel with key 7 = 2."""
+    per-layer launches, and the device error word stays zero (no neighbour wait gave up)."""
     _gpu()
     if torch.cuda.get_device_properties(0).multi_processor_count != 256:
         pytest.skip('the chained launches need a whole 256-CU MI355X (RRDBNetHIP.chain_ok)')
     from oracle import fixtures
     from dasr_amd import options
     from dasr_amd.models import create_model
-    n, h, w, nb, form = shape
-    from dasr_amd import _lib
+    n, h, w, nb = shape
     case = dict(kind='sr', nf=64, nb=nb, n=n, lr=(h, w))
     batch = fixtures.make_batch(case, seed=11)
     outs = []
     monkeypatch.setenv('DASR_STREAMS', '1')   # like for like: one plan over the whole batch on both sides (the sub-batch schedule sums the weight gradients in another order)
-    _lib.check(_lib.lib().dasr_set_tuning(7, form))
-    try:
-        for chain in ('0', '1'):
-            monkeypatch.setenv('DASR_CHAIN', chain)
-            torch.manual_seed(0)
-            o = fixtures.make_opt(case)
-            o['gpu_ids'] = [0]
-            m = create_model(options.dict_to_nonedict(o))
-            assert m.netG.chain_ok(n, h, w) == (chain == '1')
-            for step in (1, 2):
-                m.update_learning_rate()
-                m.feed_data(batch)
-                m.optimize_parameters(step)
-            m.check_finite()                         # includes the chains' error word
-            plans = m._out_plans
-            if chain == '1':
-                assert len(plans) == 1 and plans[0].chain is not None and plans[0].chain_b is not None
-                assert plans[0].chain.n == 15 * nb - 1 and plans[0].chain_b.n == 15 * nb - 1
-            else:
-                assert all(getattr(p, 'chain', None) is None for p in plans)
-            outs.append((m.fake_H.clone(), m.netG.params.grad.clone(), m.netG.params.flat.clone()))
-            del m
-            torch.cuda.empty_cache()
-    finally:
-        _lib.check(_lib.lib().dasr_set_tuning(7, 1))
+    for chain in ('0', '1'):
+        monkeypatch.setenv('DASR_CHAIN', chain)
+        torch.manual_seed(0)
+        o = fixtures.make_opt(case)
+        o['gpu_ids'] = [0]
+        m = create_model(options.dict_to_nonedict(o))
+        assert m.netG.chain_ok(n, h, w) == (chain == '1')
+        for step in (1, 2):
+            m.update_learning_rate()
+            m.feed_data(batch)
+            m.optimize_parameters(step)
+        m.check_finite()                         # includes the chains' error word
+        plans = m._out_plans
+        if chain == '1':
+            assert len(plans) == 1 and plans[0].chain is not None and plans[0].chain_b is not None
+            assert plans[0].chain.n == 15 * nb - 1 and plans[0].chain_b.n == 15 * nb - 1
+        else:
+            assert all(getattr(p, 'chain', None) is None for p in plans)
+        outs.append((m.fake_H.clone(), m.netG.params.grad.clone(), m.netG.params.flat.clone()))
     (s0, g0, w0), (s1, g1, w1) = outs
     assert torch.equal(s0, s1) and torch.equal(g0, g1) and torch.equal(w0, w1)
 
@@ -283,5 +274,4 @@ def test_chain_refuses_shapes_that_do_not_fill_the_chip():
         assert not net.chain_ok(16, 128, 128)   # a partitioned device: never
         return
     assert net.chain_ok(16, 128, 128) and net.chain_ok(8, 128, 256) and net.chain_ok(32, 64, 128)
-    assert net.chain_ok(32, 128, 128) and net.chain_ok(24, 128, 256)   # two / three tiles per workgroup (round 5)
-    assert not net.chain_ok(16, 64, 64) and not net.chain_ok(4, 256, 256) and not net.chain_ok(12, 128, 128) and not net.chain_ok(24, 128, 128)
+    assert not net.chain_ok(16, 64, 64) and not net.chain_ok(4, 256, 256) and not net.chain_ok(12, 128, 128) and not net.chain_ok(32, 128, 128)
