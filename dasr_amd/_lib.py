@@ -78,7 +78,7 @@ _SIGS = {
     'dasr_set_tuning': [c_i32, c_i32],
     'dasr_wgrad': [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
     'dasr_wgrad_set_mode': [c_i32],
-    'dasr_wgrad_reduce': [c_vp, c_i32, c_vp, c_vp, c_f32, c_vp],
+    'dasr_wgrad_reduce': [c_vp, c_i32, c_vp, c_vp, c_f32, c_i32, c_vp],
     'dasr_pack_weights': [c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp],
     'dasr_nchw_to_blocked': [c_vp, c_i32, c_i32, c_i32, c_i32, Tensor, Tensor, c_vp],
     'dasr_blocked_to_nchw': [Tensor, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
@@ -98,7 +98,7 @@ _SIGS = {
     'dasr_inorm_lrelu_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, Tensor, c_vp],
     'dasr_inorm_lrelu_jvp': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, Tensor, c_vp],
     'dasr_inorm_second': [Tensor, Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, Tensor, c_i32, c_vp],
-    'dasr_grad_penalty': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp],
+    'dasr_grad_penalty': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp],
     'dasr_fill_scaled': [Tensor, c_i32, c_i32, c_i32, c_i32, c_vp, c_f32, c_vp],
     'dasr_bce_logits': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp, c_f32, Tensor, c_vp],
     'dasr_gan_loss': [Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp, c_f32, Tensor, c_vp],

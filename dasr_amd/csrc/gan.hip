@@ -242,15 +242,29 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(dasr_tensor g, int N
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-__global__ void gp_finalize_kernel(const float* __restrict__ part, int nblk, float weight, float* __restrict__ out, float* __restrict__ loss_acc) {
+// stage 0: everything (one rank).  Data parallel (the reference takes ONE norm over the global batch, train.py:231-236): stage 1 leaves this rank's
+// sum of squares in out[3]; the caller SUM-all-reduces that word; stage 2 finishes with inv_w = 1 / world: the gradient of the GLOBAL mean output
+// restricted to this rank's samples is g_r / world, so ||g||^2 = sum_r ||g_r||^2 / world^2, and d pen / d theta = c sum_r <g_r, d g_r / d theta> / world^2:
+// the upstream factor of this rank's reverse pass is c / world, the other 1 / world is the data-parallel factor every weight-gradient reduction of the
+// rank carries (dasr_wgrad_reduce `scale`), and the ranks' weight gradients are SUMMED
+__global__ void gp_finalize_kernel(const float* __restrict__ part, int nblk, float weight, float* __restrict__ out, float* __restrict__ loss_acc, int stage,
+                                   float inv_w) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float s = 0.f;
-    for (int i = 0; i < nblk; ++i) s += part[i];
+    if (stage == 2) {
+        s = out[3] * inv_w * inv_w;
+    } else {
+        for (int i = 0; i < nblk; ++i) s += part[i];
+        if (stage == 1) {
+            out[3] = s;
+            return;
+        }
+    }
     const float nrm = sqrtf(s);
     const float pen = weight * (nrm - 1.f) * (nrm - 1.f);
     out[0] = nrm;
     out[1] = pen;
-    out[2] = nrm > 0.f ? 2.f * weight * (nrm - 1.f) / nrm : 0.f;
+    out[2] = nrm > 0.f ? 2.f * weight * (nrm - 1.f) / nrm * inv_w : 0.f;
     if (loss_acc) loss_acc[0] += pen;
 }
 
@@ -1132,10 +1146,10 @@ extern "C" int dasr_inorm_second(dasr_tensor a, dasr_tensor t, dasr_tensor ga, i
 }
 
 extern "C" int dasr_grad_penalty(dasr_tensor g, int32_t N, int32_t C, int32_t H, int32_t W, float weight, float* part256, float* out3, float* loss_acc,
-                                 void* stream) {
-    if (N <= 0 || C <= 0 || C > 16 || H <= 0 || W <= 0 || !g.p || !part256 || !out3) return DASR_EINVAL;
-    DASR_LAUNCH(sumsq_partial_kernel, dim3(256), dim3(256), 0, as_stream(stream), g, N, C, H, W, part256);
-    DASR_LAUNCH(gp_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), part256, 256, weight, out3, loss_acc);
+                                 int32_t stage, int32_t world, void* stream) {
+    if (N <= 0 || C <= 0 || C > 16 || H <= 0 || W <= 0 || !g.p || !part256 || !out3 || stage < 0 || stage > 2 || world < 1 || (stage == 0 && world != 1)) return DASR_EINVAL;
+    if (stage != 2) DASR_LAUNCH(sumsq_partial_kernel, dim3(256), dim3(256), 0, as_stream(stream), g, N, C, H, W, part256);
+    DASR_LAUNCH(gp_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), part256, 256, weight, out3, stage == 1 ? nullptr : loss_acc, stage, 1.f / (float)world);
     return (int)hipGetLastError();
 }
 

@@ -1209,7 +1209,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const dasr_wgrad_redu
                                                            const float* __restrict__ ws, float* __restrict__ grad, float scale) {
     __shared__ float red[16 * 16 * 17];
     const dasr_wgrad_reduce_part P = parts[blockIdx.y];
-    const int oc = blockIdx.x >> 2, cg = blockIdx.x & 3, goc = P.oc0 + oc;
+    // gridDim.x == 32 (the launcher's `few_splits`): every part takes the few-splits path below, which needs ONE workgroup per output channel -- the three
+    // of four workgroups that only returned cost more than the work (7680 workgroups per launch of the grouped trunk gradients: 55 us for 18 MB, dispatch-bound)
+    const bool per_oc = gridDim.x == 32;
+    const int oc = per_oc ? blockIdx.x : blockIdx.x >> 2, cg = per_oc ? 0 : blockIdx.x & 3, goc = P.oc0 + oc;
     if (goc >= P.cout) return;   // uniform per block
     const int per = P.ntaps * 32 * 64;
     const long long sstride = P.split_stride > 0 ? P.split_stride : per, tstride = P.tap_stride > 0 ? P.tap_stride : 2048;
@@ -1490,8 +1493,8 @@ extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int3
 }
 
 extern "C" int dasr_wgrad_reduce(const dasr_wgrad_reduce_part* parts_dev, int32_t nparts, const float* ws, float* grad_flat,
-                                 float scale, void* stream) {
+                                 float scale, int32_t few_splits, void* stream) {
     if (nparts <= 0) return DASR_EINVAL;
-    DASR_LAUNCH(wgrad_reduce_kernel, dim3(128, nparts), dim3(256), 0, as_stream(stream), parts_dev, nparts, ws, grad_flat, scale);
+    DASR_LAUNCH(wgrad_reduce_kernel, dim3(few_splits ? 32 : 128, nparts), dim3(256), 0, as_stream(stream), parts_dev, nparts, ws, grad_flat, scale);
     return (int)hipGetLastError();
 }

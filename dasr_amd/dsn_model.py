@@ -466,8 +466,11 @@ class DSNModel:
         # --wgan (train.py:45,231-241; model.py:104-105; loss.py:18-19,33-36): no sigmoid, Wasserstein terms -mean(real) + mean(fake), generator term
         # mean(-fake), gradient penalty 10 (||d mean D(sample) / d sample|| - 1)^2 with its second-order pass through the discriminator (_GradPenaltyPlan)
         self.wgan = bool(o['wgan'])
-        if self.wgan and self.ragan:
-            raise NotImplementedError('--wgan together with --ragan is not on the MI355X path')
+        # --wgan with --ragan (train.py:221-236, model.py:98-106): without the sigmoid the relativistic terms are linear in the logits, the per-pixel batch
+        # means only shift them: -mean(real_tex) + mean(fake_tex) = 2 (mean D(fake) - mean D(real)), mean(-fake_tex) = -mean D(fake) + mean D(real), the
+        # gradient penalty sees D(sample) alone.  So the combination is the --wgan plan with the discriminator's Wasserstein gradients doubled and the
+        # logged terms recombined (get_current_log); `rel` = the three-stage sigmoid form of --ragan alone
+        self.rel = self.ragan and not self.wgan
         self.filter = o['filter'].lower()
         if self.filter not in ('gau', 'avg_pool', 'wavelet'):
             raise NotImplementedError('Frequency Separation type [{:s}] not recognized'.format(o['filter']))
@@ -530,7 +533,7 @@ class DSNModel:
     def _plan(self, N, H, W):
         # the relativistic ops bake the data-parallel world size into their batch-mean divisor: a plan is valid for ONE world size
         world = self.dp.world if (self.dp is not None and self.dp.active) else 1
-        k = (N, H, W, world if self.ragan else 0)
+        k = (N, H, W, world if (self.rel or self.wgan) else 0)
         if k not in self._plans:
             self._plans[k] = _DSNPlan(self, N, H, W)
         return self._plans[k]
@@ -556,17 +559,12 @@ class DSNModel:
         P.bic_nchw.copy_(bicubic_lr)
         P.real_nchw.copy_(real_lr)
         dp_on = self.dp is not None and self.dp.active
-        if self.wgan and dp_on and self.dp.world > 1:
-            # the reference (one process) takes ONE gradient norm over the whole batch: || d mean_global D / d sample ||.  A per-rank norm over the local
-            # shard is ~sqrt(world) times larger, so 10 (||g|| - 1)^2 and its weight gradients would silently differ; the exchange of
-            # sum ||g_r||^2 between the norm and the tangent / reverse pass is not built
-            raise NotImplementedError('--wgan under data parallelism (world %d): the gradient penalty needs the norm over the global batch' % self.dp.world)
         scale = self.dp.grad_scale if dp_on else 1.0
         if scale != P.scale:
             P.set_grad_scale(scale)
         if self.lpips_rot_flip and (self.iteration_count + 1) % self.gen_freq == 0:   # drawn where the reference evaluates its generator loss (train.py:251-259)
             P.set_symmetry(draw_symmetry())
-        rg_dp = self.ragan and dp_on   # --ragan under data parallelism: per-pixel batch sums all-reduced between the three loss stages
+        rg_dp = self.rel and dp_on   # --ragan under data parallelism: per-pixel batch sums all-reduced between the three loss stages
         if rg_dp:
             if P.ragan_world != self.dp.world:
                 raise RuntimeError('the DSN plan was recorded for %d ranks, the process group has %d (attach model.dp before the first iteration)' % (P.ragan_world, self.dp.world))
@@ -586,8 +584,22 @@ class DSNModel:
         if upd_d:
             P.d_bwd.run()   # D weight gradients (pre-update graph)
             if self.wgan:   # + the gradient penalty: one mixing weight per iteration from torch's global RNG, drawn only when D steps (train.py:231-233)
-                P.gp.set_mix(torch.rand(1).item())
-                P.gp.ops.run()
+                # (data parallel: ONE weight for the global batch -- rank 0's draw -- and ONE gradient norm over it: the ranks' sums of squares are
+                # all-reduced between the norm and the tangent / reverse pass)
+                r = torch.rand(1)
+                if dp_on and self.dp.world > 1:
+                    rd = r.to(self.device)
+                    self.dp.broadcast_params(rd)
+                    r = rd.cpu()
+                P.gp.set_mix(float(r.item()))
+                if P.gp.world > 1:
+                    if not dp_on or self.dp.world != P.gp.world:
+                        raise RuntimeError('the DSN plan was recorded for %d ranks (attach model.dp before the first iteration)' % P.gp.world)
+                    P.gp.ops.run(0, P.gp.cut)
+                    self.dp.all_reduce_here(P.gp.out3[3:4])
+                    P.gp.ops.run(P.gp.cut)
+                else:
+                    P.gp.ops.run()
                 _lib.check(_lib.lib().dasr_add_flat(self.netD.params.grad.data_ptr(), P.gp.grad.data_ptr(), P.gp.grad.numel(), _stream()), 'add_flat')
         if upd_g and rg_dp:   # generator's relativistic texture loss: stage 1 (sums still valid) -> all-reduce -> stage 2, then the backward chain
             P.g_bwd.run(0, P.ragan_cut_gbwd)
@@ -748,6 +760,9 @@ class DSNModel:
             a = self.acc.tolist()
             self.check_finite()
             o = self.opt
+            if self.wgan and self.ragan:   # a[0] = -mean D(real), a[1] = mean D(fake), a[2] = -mean D(fake), scores a[4] / a[5] = mean D(real) / mean D(fake)
+                w = a[0] + a[1]            # -> -mean(real_tex) = mean(fake_tex) = mean D(fake) - mean D(real); mean(-fake_tex) = -mean D(fake) + mean D(real)
+                a[0], a[1], a[2], a[4], a[5] = w, w, a[2] + a[4], a[4] - a[5], a[5] - a[4]
             self.log.update({'loss/d_tex_loss': a[0] + a[1] + (a[7] if self.wgan else 0.0), 'loss/g_tex_loss': a[2], 'loss/color_loss': a[3], 'loss/perceptual_loss': a[6],
                              'loss/g_overall_loss': o['w_col'] * a[3] + o['w_tex'] * a[2] + o['w_per'] * a[6], 'disc_score/real': a[4],
                              'disc_score/fake': a[5]})
@@ -832,10 +847,17 @@ class _GradPenaltyPlan:
             o.i[0], o.i[1], o.i[2], o.i[3], o.i[5], o.i[6] = N, 3, h, w, 1 | norm_valid, 1
             o.f[0], o.f[1], o.t[2], o.t[3] = 0.5, 0.0, self.g_img.view(), NULL_T
         ops.add(o)
-        o = _op(_lib.OP_GRAD_PENALTY)                 # out3 = {||g||, 10 (||g|| - 1)^2, 20 (||g|| - 1) / ||g||}; acc[slot] += the penalty
-        o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0] = self.g_img.view(), N, 3, h, w, 10.0
-        o.p[0], o.p[1], o.p[2] = self.part.data_ptr(), self.out3.data_ptr(), m.acc.data_ptr() + 4 * acc_slot
-        ops.add(o)
+        # out3 = {||g||, 10 (||g|| - 1)^2, 20 (||g|| - 1) / ||g||}; acc[slot] += the penalty.  Data parallel: two stages around the all-reduce of the ranks'
+        # sums of squares (dasr_grad_penalty; DSNModel.iteration runs ops[:cut], all-reduces out3[3], runs ops[cut:])
+        self.world = m.dp.world if (getattr(m, 'dp', None) is not None and m.dp.active) else 1
+        for stage in ((0,) if self.world == 1 else (1, 2)):
+            o = _op(_lib.OP_GRAD_PENALTY)
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0] = self.g_img.view(), N, 3, h, w, 10.0
+            o.p[0], o.p[1], o.p[2] = self.part.data_ptr(), self.out3.data_ptr(), m.acc.data_ptr() + 4 * acc_slot
+            o.i[4], o.i[5] = stage, self.world
+            ops.add(o)
+            if stage == 1:
+                self.cut = len(ops.ops)
         # ---- tangent pass along u = g: t0 = (linear part of the front end)(g)
         if wav:
             o = _op(_lib.OP_DWT_FWD)
@@ -980,7 +1002,7 @@ class _DSNPlan:
         # --ragan: the same two terms on relativistic logits real - mean_n(fake), fake - mean_n(real): the three dasr_ragan stages back to back
         # (whole loss -> acc[0]; scores = mean sigmoid of the relativistic logits); gradients of both halves incl. the mean terms
         self.r_sums = self.r_part = None
-        if m.ragan:
+        if m.rel:
             hw = lg.H * lg.W
             self.r_sums, self.r_part = (torch.zeros(2 * hw, dtype=torch.float32, device=dev) for _ in range(2))
             rl = [OpList(), OpList(), OpList()]
@@ -998,10 +1020,10 @@ class _DSNPlan:
         for n0, target, a_loss, a_score in (((N, 1.0, 0, 4), (0, 0.0, 1, 5)) if m.wgan else ()):   # --wgan: -mean(real) + mean(fake) on the raw map (loss.py:33-36)
             o = _op(_lib.OP_BCE)
             o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = _nview(lg, n0), N, 1, lg.H, lg.W, 2
-            o.f[0], o.f[1], o.f[2] = target, 1.0 / cnt, 1.0 / cnt
+            o.f[0], o.f[1], o.f[2] = target, 1.0 / cnt, (2.0 if m.ragan else 1.0) / cnt   # (--ragan: both relativistic terms carry every logit once)
             o.p[0], o.p[1], o.f[3], o.t[1] = acc + 4 * a_loss, acc + 4 * a_score, 1.0 / cnt, _nview(d.g_logits, n0)
             f.add(o)
-        for n0, mode, a_loss, a_score in (() if (m.ragan or m.wgan) else ((N, 0, 0, 4), (0, 1, 1, 5))):
+        for n0, mode, a_loss, a_score in (() if (m.rel or m.wgan) else ((N, 0, 0, 4), (0, 1, 1, 5))):
             o = _op(_lib.OP_LOGLOSS)
             o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = _nview(lg, n0), N, lg.H, lg.W, mode, 0
             o.f[0], o.f[1], o.f[2], o.f[3] = EPS, 1.0 / cnt, 1.0 / cnt, 1.0 / cnt
@@ -1049,7 +1071,7 @@ class _DSNPlan:
         self.gp = _GradPenaltyPlan(self, m, N, h, w, hd, wd, acc_slot=7) if m.wgan else None   # value -> acc[7], weight gradients -> gp.grad
         # generator: texture loss gradient through D's data path (+ colour adjoint) -> g_fake -> G backward
         gb = OpList()
-        if m.ragan:   # -log(sigmoid(fake - mean_n(real)) + eps): stage 0's sums are still valid, the real term is absent (t < 0), real carries no gradient
+        if m.rel:   # -log(sigmoid(fake - mean_n(real)) + eps): stage 0's sums are still valid, the real term is absent (t < 0), real carries no gradient
             rl = [OpList(), OpList(), OpList()]
             _ragan_ops(rl, _nview(lg, N), lg.view(), N, lg.H, lg.W, N * self.ragan_world, -1.0, 1.0, 1.0 / cnt, float(o_['w_tex']) / cnt, self.r_sums, self.r_part,
                        acc + 4 * 2, None, None, 0.0, NULL_T, d.g_logits.view(), form=1, eps=EPS, stages=(1, 2))

@@ -453,6 +453,7 @@ class WgradGroup:
         a.flops = float(getattr(self, 'flops', 0.0))
         b.op = _lib.OP_WGRAD_REDUCE
         b.p[0], b.i[0], b.p[2], b.f[0] = self.r_dev.data_ptr(), self.n_red, grad_ptr, scale
+        b.i[1] = 1 if (self.tpp <= 16 and all(rp is None or rp.nsplit <= 4 for _, rp, _ in self.parts)) else 0   # few_splits: one reduce workgroup per output channel
         gs = getattr(self, 'g_scale', 0.0)
         b.f[1] = 1.0 / gs if gs else 0.0   # second factor of the reduce scale (f[0] stays the data-parallel 1/world): undoes the f16 pre-scale
         self.workspace.register(a, b)
@@ -526,6 +527,7 @@ class WgradGroup3:
         a.flops = float(getattr(self, 'flops', 0.0))
         b.op = _lib.OP_WGRAD_REDUCE
         b.p[0], b.i[0], b.p[2], b.f[0] = self.r_dev.data_ptr(), self.n_red, grad_ptr, scale
+        b.i[1] = 1 if self.nsplit <= 4 else 0   # few_splits (9 taps): one reduce workgroup per output channel
         gs = getattr(self, 'g_scale', 0.0)
         b.f[1] = 1.0 / gs if (f16 and gs) else 0.0
         self.workspace.register(a, b)

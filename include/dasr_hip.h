@@ -160,8 +160,10 @@ typedef struct {
                                              * g.x, g.x_lo, g_lo.x laid out as 3 * nsplit consecutive splits) sum the bias over the first nsplit only */
 } dasr_wgrad_reduce_part;
 
+/* few_splits != 0 (ABI 17): the caller guarantees nsplit <= 4 and ntaps <= 16 for EVERY part (the grouped dense-block launches): one workgroup per
+ * output channel is launched instead of four (same results; the other three only returned). */
 int dasr_wgrad_reduce(const dasr_wgrad_reduce_part* parts_dev, int32_t nparts, const float* ws, float* grad_flat,
-                      float scale, void* stream);
+                      float scale, int32_t few_splits, void* stream);
 
 /* ---- weight packing ------------------------------------------------------------------------------
  * fp32 master weights (reference layout [cout][cin][kh][kw], nn.Conv2d) -> bf16 MFMA-fragment order
@@ -266,13 +268,16 @@ int dasr_inorm_lrelu_bwd(dasr_tensor a, dasr_tensor ga, int32_t N, int32_t C, in
  * dasr_inorm_lrelu_jvp: forward-mode tangent  out = lrelu'(a) * J t  (a = saved forward output, t = tangent of the conv output);
  * dasr_inorm_second: adjoint of z -> J(z) t for fixed t, upstream w = lrelu'(a) * ga:
  *   out (+)= -rstd^2 [ xhat (mean(w t) - mean w mean t - 3 mean(w xhat) mean(xhat t)) + mean(xhat t) (w - mean w) + mean(w xhat) (t - mean t) ];
- * dasr_grad_penalty: nrm = ||g||_2 over the C (<= 16) real channels of ALL images, out3 = {nrm, weight (nrm - 1)^2, 2 weight (nrm - 1) / nrm},
- *   loss_acc[0] += the penalty; part256 = 256 floats of scratch (deterministic two-stage sum);
+ * dasr_grad_penalty: nrm = ||g||_2 over the C (<= 16) real channels of ALL images, out3 (FOUR floats) = {nrm, weight (nrm - 1)^2, 2 weight (nrm - 1) / nrm, -},
+ *   loss_acc[0] += the penalty; part256 = 256 floats of scratch (deterministic two-stage sum).  stage 0 / world 1: all of it.  Data parallel (the
+ *   reference's norm is over the global batch): stage 1 leaves the local sum of squares in out3[3], the caller SUM-all-reduces that word, stage 2 finishes
+ *   with nrm^2 = out3[3] / world^2 and out3[2] scaled by 1 / world (the reverse pass's weight-gradient reductions carry the other 1 / world; the ranks' gradients are summed);
  * dasr_fill_scaled: x = factor * scalar[0] on the C real channels (a constant upstream gradient whose value was computed on the device). */
 int dasr_inorm_lrelu_jvp(dasr_tensor a, dasr_tensor t, int32_t N, int32_t C, int32_t H, int32_t W, float slope, const float* stats, dasr_tensor out, void* stream);
 int dasr_inorm_second(dasr_tensor a, dasr_tensor t, dasr_tensor ga, int32_t N, int32_t C, int32_t H, int32_t W, float slope, const float* stats,
                       dasr_tensor out, int32_t accumulate, void* stream);
-int dasr_grad_penalty(dasr_tensor g, int32_t N, int32_t C, int32_t H, int32_t W, float weight, float* part256, float* out3, float* loss_acc, void* stream);
+int dasr_grad_penalty(dasr_tensor g, int32_t N, int32_t C, int32_t H, int32_t W, float weight, float* part256, float* out3, float* loss_acc, int32_t stage,
+                      int32_t world, void* stream);
 int dasr_fill_scaled(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t W, const float* scalar, float factor, void* stream);
 /* nn.BatchNorm2d in TRAINING mode (batch statistics, affine gamma / beta) + LeakyReLU of Discriminator_VGG_128 (architecture.py:442-495), fused.
  * The N images are normalised in groups of `group` consecutive images with their own statistics (the reference runs the discriminator on the

@@ -284,7 +284,7 @@ def test_chained_step_survives_interference_on_the_communication_stream(tmp_path
         assert torch.equal(v, b['G'][k]), k
 
 
-def _dsn_worker(rank, world, port, out, ragan=False, n_total=None):
+def _dsn_worker(rank, world, port, out, ragan=False, n_total=None, wgan=False):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     import torch
     from dasr_amd.dist import DataParallelGroup
@@ -293,7 +293,7 @@ def _dsn_worker(rank, world, port, out, ragan=False, n_total=None):
     torch.cuda.set_device(0)
     dp = DataParallelGroup(backend='gloo') if world > 1 else None
     torch.manual_seed(0)
-    m = DSNModel(dict(filter='wavelet', w_per=0.01, vgg_seed=78, allow_random_perceptual=True, ragan=ragan))
+    m = DSNModel(dict(filter='wavelet', w_per=0.01, vgg_seed=78, allow_random_perceptual=True, ragan=ragan, wgan=wgan))
     m.netG.load_state_dict(dsn_state(m.netG.state_dict(), 21, 0.5))
     m.netD.load_state_dict(dsn_state(m.netD.state_dict(), 22, 1.0))
     if dp:
@@ -301,7 +301,7 @@ def _dsn_worker(rank, world, port, out, ragan=False, n_total=None):
         for net in m.networks():
             dp.broadcast_params(net.params.flat)
             net.repack()
-    n = n_total or (4 if ragan else 2)   # relativistic: two samples per rank, so the GLOBAL batch means differ from the per-rank ones
+    n = n_total or (4 if (ragan or wgan) else 2)   # relativistic / gradient penalty: two samples per rank, so the GLOBAL batch means (norm) differ from the per-rank ones
     hr, bic, real = dsn_batch(dict(n=n, crop=128))  # VGG16's five pools need >= 32 px LR
     if dp:
         per = n // world
@@ -314,17 +314,20 @@ def _dsn_worker(rank, world, port, out, ragan=False, n_total=None):
         dp.barrier()
 
 
-@pytest.mark.parametrize('ragan', [False, True], ids=['plain', 'ragan'])
-def test_dsn_two_rank_iteration_equals_full_batch(ragan, tmp_path):
+@pytest.mark.parametrize('mode', ['plain', 'ragan', 'wgan', 'wgan_ragan'])
+def test_dsn_two_rank_iteration_equals_full_batch(mode, tmp_path):
     """ragan (round 3): D(x, y) = sigmoid(D(x) - mean_n D(y)) couples the samples; under data parallelism the per-pixel batch sums are all-reduced
-    between the loss stages (dsn_model.py::iteration), so two ranks with two samples each must reproduce the four-sample step"""
+    between the loss stages (dsn_model.py::iteration), so two ranks with two samples each must reproduce the four-sample step.
+    wgan (round 5): the gradient penalty's ONE norm over the global batch -- the ranks' sums of squares are all-reduced between the norm and the
+    tangent / reverse pass, the mixing weight is rank 0's draw."""
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     import torch.multiprocessing as mp
+    ragan, wgan = mode in ('ragan', 'wgan_ragan'), mode in ('wgan', 'wgan_ragan')
     out = str(tmp_path / 'dsn_w%d_r%d.pt')
-    port = 29911 + (os.getpid() % 300) + 2 * int(ragan)
-    mp.spawn(_dsn_worker, args=(1, port, out, ragan), nprocs=1, join=True)
-    mp.spawn(_dsn_worker, args=(2, port + 1, out, ragan), nprocs=2, join=True)
+    port = 29911 + (os.getpid() % 300) + 2 * ['plain', 'ragan', 'wgan', 'wgan_ragan'].index(mode)
+    mp.spawn(_dsn_worker, args=(1, port, out, ragan, None, wgan), nprocs=1, join=True)
+    mp.spawn(_dsn_worker, args=(2, port + 1, out, ragan, None, wgan), nprocs=2, join=True)
     full = torch.load(out % (1, 0))
     r0, r1 = torch.load(out % (2, 0)), torch.load(out % (2, 1))
     for net in ('G', 'D'):

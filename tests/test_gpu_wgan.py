@@ -65,10 +65,21 @@ def test_instance_norm_tangent_and_second_order_adjoint():
     gi = torch.randn(3, 3, 10, 12, generator=g) * 0.05
     gb = to_blocked(gi, dev)
     part, out3, acc = torch.zeros(256, device=dev), torch.zeros(4, device=dev), torch.zeros(1, device=dev)
-    _lib.check(L.dasr_grad_penalty(gb.view(), 3, 3, 10, 12, 10.0, part.data_ptr(), out3.data_ptr(), acc.data_ptr(), _stream()))
+    _lib.check(L.dasr_grad_penalty(gb.view(), 3, 3, 10, 12, 10.0, part.data_ptr(), out3.data_ptr(), acc.data_ptr(), 0, 1, _stream()))
     nrm = float(gi.double().norm())
     o = out3.cpu().tolist()
     assert abs(o[0] - nrm) < 1e-6 * nrm and abs(o[1] - 10 * (nrm - 1) ** 2) < 1e-5 and abs(o[2] - 20 * (nrm - 1) / nrm) < 1e-4 * abs(o[2]) and abs(float(acc) - o[1]) < 1e-6
+    # the data-parallel form: stage 1 -> (all-reduce of out3[3]) -> stage 2; with the same tensor on "both of two ranks" the global norm is ||g|| / sqrt(2)
+    out3b, acc2 = torch.zeros(4, device=dev), torch.zeros(1, device=dev)
+    _lib.check(L.dasr_grad_penalty(gb.view(), 3, 3, 10, 12, 10.0, part.data_ptr(), out3b.data_ptr(), acc2.data_ptr(), 1, 2, _stream()))
+    torch.cuda.synchronize()
+    assert abs(float(out3b[3]) - nrm * nrm) < 1e-5 * nrm * nrm and float(acc2) == 0.0
+    out3b[3] *= 2.0
+    _lib.check(L.dasr_grad_penalty(gb.view(), 3, 3, 10, 12, 10.0, part.data_ptr(), out3b.data_ptr(), acc2.data_ptr(), 2, 2, _stream()))
+    torch.cuda.synchronize()
+    n2 = nrm / 2 ** 0.5
+    o2 = out3b.cpu().tolist()
+    assert abs(o2[0] - n2) < 1e-6 * n2 and abs(o2[1] - 10 * (n2 - 1) ** 2) < 1e-5 and abs(o2[2] - 20 * (n2 - 1) / n2 / 2) < 1e-4 * abs(o2[2]) and abs(float(acc2) - o2[1]) < 1e-6
     fb = BTensor(3, 16, 4, 5, True, dev)
     fb.t.fill_(7.0)
     _lib.check(L.dasr_fill_scaled(fb.view(), 3, 1, 4, 5, out3.data_ptr() + 8, 0.25, _stream()))
@@ -127,6 +138,40 @@ def test_gradient_penalty_value_and_weight_gradients(filt, arch, margins):
             % (filt, arch, got_pen, float(pen), float(P.gp.out3[0]), errs[0][0], errs[0][1]))
     assert abs(got_pen - float(pen)) < 2e-4 * abs(float(pen))
     assert errs[0][0] < 1e-2, errs[:4]
+
+
+@pytest.mark.parametrize('filt', ['gau', 'wavelet'])
+def test_wgan_with_ragan_iteration_matches_the_oracle(filt, margins):
+    """--wgan together with --ragan (codes/DSN/train.py:221-241, model.py:98-106): relativistic logits without the sigmoid.  One iteration (both updates)
+    against the fp32 oracle trainer: every logged term, the fake batch, generator and discriminator gradients at the north_star tolerances."""
+    dev = _gpu()
+    torch.set_num_threads(8)
+    from dasr_amd.dsn_model import DSNModel
+    from oracle import dsn
+    from oracle.gen_golden_dsn import dsn_state, dsn_batch
+    G, D = dsn.DeResnet(), dsn.Discriminator(5, 'Instance', filt, wgan=True)
+    sdG, sdD = dsn_state(G.state_dict(), 21, 0.5), dsn_state(D.state_dict(), 22, 1.0)
+    G.load_state_dict(sdG)
+    D.load_state_dict(sdD)
+    t = dsn.DSNTrainer(G, D, kernel_size=5, filter_type=filt, norm_layer='Instance', w_per=0.0, ragan=True, wgan=True)
+    m = DSNModel(dict(filter=filt, kernel_size=5, norm_layer='Instance', w_per=0.0, ragan=True, wgan=True), device=dev)
+    m.netG.load_state_dict(sdG)
+    m.load_discriminator_state(sdD)
+    hr, bic, real = dsn_batch(dict(n=3, crop=128))
+    torch.manual_seed(5)
+    t.iteration(hr, bic, real)          # (draws the mixing weight from torch's global RNG ...)
+    torch.manual_seed(5)
+    m.iteration(hr.to(dev), bic.to(dev), real.to(dev))   # (... and so does the HIP trainer: same seed, same weight)
+    log = m.get_current_log()
+    for k, ref_v in t.log.items():
+        assert abs(log[k] - ref_v) <= 2e-3 * max(1e-3, abs(ref_v)) + 1e-5, (k, log[k], ref_v)
+    e_fake = rel(m.fake.cpu(), t.fake)
+    gd, dd = m.netG.params.grad_dict(), m.netD.params.grad_dict()
+    eg = sorted(((rel(gd[k], p.grad), k) for k, p in G.named_parameters() if p.numel() > 1), reverse=True)
+    ed = sorted(((rel(dd[k], p.grad), k) for k, p in D.named_parameters() if p.requires_grad and p.grad is not None and float(p.grad.norm()) > 1e-6), reverse=True)
+    margins('DSN --wgan --ragan iteration (%s front end) vs the fp32 oracle: fake %.2e (tol 1e-3); worst gradient rel err G %.2e at %s, D %.2e at %s (tol 1e-2); d_tex_loss %.5f '
+            'gradient_penalty %.5f' % (filt, e_fake, eg[0][0], eg[0][1], ed[0][0], ed[0][1], log['loss/d_tex_loss'], log['disc_score/gradient_penalty']))
+    assert e_fake < 1e-3 and eg[0][0] < 1e-2 and ed[0][0] < 1e-2, (e_fake, eg[:3], ed[:3])
 
 
 def test_dsn_train_cli_with_wgan_and_tensorboard_scalars(tmp_path):
