@@ -31,7 +31,7 @@ class WgradPart(C.Structure):
                 ('g_planes', c_i32), ('in_planes', c_i32),
                 ('Hin', c_i32), ('Win', c_i32), ('Hout', c_i32), ('Wout', c_i32), ('N', c_i32),
                 ('kh', c_i32), ('stride', c_i32), ('pad', c_i32), ('want_bias', c_i32),
-                ('ws_off', c_i64), ('ws_bias_off', c_i64), ('tap0', c_i32), ('g_scale', c_f32), ('nsplit_part', c_i32), ('reserved_', c_i32)]
+                ('ws_off', c_i64), ('ws_bias_off', c_i64), ('tap0', c_i32), ('g_scale', c_f32)]
 
 
 class WgradReducePart(C.Structure):
@@ -79,7 +79,6 @@ _SIGS = {
     'dasr_wgrad': [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
     'dasr_wgrad_set_mode': [c_i32],
     'dasr_wgrad_reduce': [c_vp, c_i32, c_vp, c_vp, c_f32, c_i32, c_vp],
-    'dasr_wgrad_map': [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp],
     'dasr_pack_weights': [c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp],
     'dasr_nchw_to_blocked': [c_vp, c_i32, c_i32, c_i32, c_i32, Tensor, Tensor, c_vp],
     'dasr_blocked_to_nchw': [Tensor, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],

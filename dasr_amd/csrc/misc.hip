@@ -716,8 +716,7 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream0) {
         switch (o.op) {
             case DASR_OP_CONV: rc = dasr_conv(&o.conv, stream); break;
             case DASR_OP_WGRAD:
-                if (o.p[2]) rc = dasr_wgrad_map((const dasr_wgrad_part*)o.p[0], o.i[0], (const int32_t*)o.p[2], o.i[5], o.i[4], (float*)o.p[1], stream);   // balanced 12-wave launch
-                else rc = dasr_wgrad((const dasr_wgrad_part*)o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], (float*)o.p[1], stream);
+                rc = dasr_wgrad((const dasr_wgrad_part*)o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], (float*)o.p[1], stream);
                 break;
             case DASR_OP_WGRAD_REDUCE:
                 rc = dasr_wgrad_reduce((const dasr_wgrad_reduce_part*)o.p[0], o.i[0], (const float*)o.p[1], (float*)o.p[2],

@@ -829,27 +829,14 @@ struct W3L {
 };
 
 template <bool F16>
-// bmap != nullptr (round 5, dasr_wgrad_map): workgroup b works on (part, pixel split) = (bmap[b] >> 8, bmap[b] & 255), or on nothing (bmap[b] < 0); the
-// part's own split count is P.nsplit_part.  The host balances the launch with it: a part's MFMA work is its number of (oc tile, cin tile) pairs (1..6),
-// and a part with fewer pairs gets fewer, longer pixel splits -- every workgroup then carries about the same work instead of the light parts idling
-// next to the full ones (one workgroup per CU: a launch lasts as long as its heaviest workgroup).
-__global__ __launch_bounds__(1024, 1) void wgrad3_ld_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit_flags, float* __restrict__ ws,
-                                                            const int* __restrict__ bmap) {
+__global__ __launch_bounds__(1024, 1) void wgrad3_ld_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit_flags, float* __restrict__ ws) {
     using C = W3G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int nsplit = nsplit_flags & 0xffff;
+    const int nsplit = nsplit_flags & 0xffff;
     int part_id, split;
-    if (bmap) {
-        const int e = bmap[blockIdx.x];
-        if (e < 0) return;   // (uniform per workgroup, in front of every barrier)
-        part_id = e >> 8;
-        split = e & 255;
-    } else {
-        w3_block_map(nsplit_flags, part_id, split);
-    }
+    w3_block_map(nsplit_flags, part_id, split);
     const dasr_wgrad_part P = parts[part_id];
-    if (bmap) nsplit = P.nsplit_part;
     const int tiles_x = (P.Wout + C::PW - 1) / C::PW, tiles_y = (P.Hout + C::PH - 1) / C::PH;
     const int ntiles = tiles_x * tiles_y * P.N;
     const unsigned lds0 = (unsigned)(size_t)(DASR_LDS char*)smem;
@@ -1384,14 +1371,14 @@ int launch_wgrad4(const dasr_wgrad_part* parts, int nparts, int nsplit, float* w
 }
 
 template <bool F16>
-int launch_wgrad3_ld(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws, hipStream_t s, const int* bmap = nullptr, int nblocks = 0) {
+int launch_wgrad3_ld(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws, hipStream_t s) {
     auto kfn = wgrad3_ld_kernel<F16>;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, W3L::LDS_BYTES));
         attr_set = true;
     }
-    DASR_LAUNCH_TAG(__PRETTY_FUNCTION__, kfn, dim3(bmap ? nblocks : nparts * (nsplit & 0xffff)), dim3(W3L::NT), W3L::LDS_BYTES, s, parts, nparts, nsplit, ws, bmap);
+    DASR_LAUNCH_TAG(__PRETTY_FUNCTION__, kfn, dim3(nparts * (nsplit & 0xffff)), dim3(W3L::NT), W3L::LDS_BYTES, s, parts, nparts, nsplit, ws);
     return (int)hipGetLastError();
 }
 
@@ -1451,14 +1438,6 @@ int dispatch_wgrad(const dasr_wgrad_part* parts, int nparts, int nsplit, bool tr
     return f32 ? launch_wgrad<KH, STRIDE, false, true>(parts, nparts, nsplit, ws, s) : launch_wgrad<KH, STRIDE, false, false>(parts, nparts, nsplit, ws, s);
 }
 }  // namespace
-
-extern "C" int dasr_wgrad_map(const dasr_wgrad_part* parts_dev, int32_t nparts, const int32_t* block_map_dev, int32_t nblocks, int32_t f32, float* ws,
-                              void* stream) {
-    if (nparts <= 0 || nparts >= (1 << 23) || !block_map_dev || nblocks <= 0 || (f32 != 0 && f32 != 2)) return DASR_EINVAL;
-    if (g_use_tr != 1) return DASR_EINVAL;   // dasr_probe_tr16 must have run (and found ds_read_b64_tr_b16)
-    return f32 == 2 ? launch_wgrad3_ld<true>(parts_dev, nparts, 1, ws, as_stream(stream), block_map_dev, nblocks)
-                    : launch_wgrad3_ld<false>(parts_dev, nparts, 1, ws, as_stream(stream), block_map_dev, nblocks);
-}
 
 extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int32_t nsplit, int32_t kh, int32_t stride, int32_t f32,
                           float* ws, void* stream) {

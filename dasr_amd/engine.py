@@ -479,28 +479,12 @@ class WgradGroup3:
         wp.kh, wp.stride, wp.pad, wp.want_bias = 3, 1, 1, int(bool(want_bias))
         self.parts.append((wp, [(i, t) for i, t in enumerate(tiles) if t is not None]))
 
-    @staticmethod
-    def part_load(tiles):
-        """MFMA work of a part per pixel: its (oc tile, cin tile) pairs, 1..6"""
-        return sum(t['n_ctiles'] for _, t in tiles)
-
-    @staticmethod
-    def balanced_splits(loads, s_full):
-        """splits per part when a full part (6 pairs) gets s_full: proportional to the part's pairs, rounded up"""
-        return [max(1, -(-l * s_full // 6)) for l in loads]
-
-    def finalize(self, workspace, device, target_wgs=256, ppu=0, s_full=0):
+    def finalize(self, workspace, device, target_wgs=256, ppu=0):
         """ppu: the parts come in units of `ppu` consecutive parts that read the same tensors (one dense block); when the split count is not
-        a multiple of 8 the kernel then places each (unit, split) on one XCD (csrc/wgrad.hip, w3_block_map).
-        s_full > 0 (round 5, dasr_wgrad_map): BALANCED launch -- a part with p of the 6 (oc tile, cin tile) pairs gets ceil(p s_full / 6) pixel splits, so
-        every workgroup carries about the same MFMA work (one workgroup per CU: the launch lasts as long as its heaviest workgroup; with one split
-        count for all parts the dense block's 3- and 5-pair parts idled next to the 6-pair ones: 26 of 30 wave slots busy).  The workgroup table orders
-        the workgroups by (dense block, split parity) -- those read the same pixel tiles of the same slabs -- and deals them to the XCDs in runs."""
+        a multiple of 8 the kernel then places each (unit, split) on one XCD (csrc/wgrad.hip, w3_block_map)"""
         wp0 = self.parts[0][0]
         ntiles = wp0.N * ceil_div(wp0.Hout, 8) * ceil_div(wp0.Wout, 16)
         nparts = len(self.parts)
-        if s_full > 0:
-            return self._finalize_balanced(workspace, device, ntiles, s_full, ppu or nparts)
         self.nsplit = max(1, min(ntiles, target_wgs // nparts))
         if self.nsplit >= 8:
             # a multiple of 8: workgroup b runs on XCD b % 8, so with block = part * nsplit + split every part's workgroup of a given pixel split
@@ -534,54 +518,12 @@ class WgradGroup3:
         self.w_dev = torch.frombuffer(bytearray(bytes(wa)), dtype=torch.uint8).to(device)
         self.r_dev = torch.frombuffer(bytearray(bytes(ra)), dtype=torch.uint8).to(device)
 
-    def _finalize_balanced(self, workspace, device, ntiles, s_full, ppu):
-        loads = [self.part_load(tiles) for _, tiles in self.parts]
-        splits = [min(s, ntiles, 255) for s in self.balanced_splits(loads, s_full)]
-        self.nsplit, self.ppu = max(splits), 0
-        off, red, wgs = 0, [], []
-        for pi, ((wp, tiles), sp) in enumerate(zip(self.parts, splits)):
-            wp.nsplit_part = sp
-            wp.ws_off = off
-            off += sp * 9 * 3 * 2048
-            wp.ws_bias_off = off
-            off += sp * 96
-            for ot, t in tiles:
-                rp = WgradReducePart()
-                rp.ws_off, rp.ws_bias_off = wp.ws_off + ot * 2048, wp.ws_bias_off + ot * 32
-                rp.nsplit, rp.ntaps, rp.oc0, rp.c0 = sp, 9, t['oc0'], t['c0']
-                rp.cout, rp.cin, rp.n_ctiles = t['cout'], t['cin'], t['n_ctiles']
-                rp.dst_w_off = t['dst_w_off']
-                rp.dst_b_off = t['dst_b_off'] if t.get('dst_b_off') is not None else -1
-                rp.split_stride, rp.tap_stride, rp.bias_stride = 9 * 3 * 2048, 3 * 2048, 96
-                red.append(rp)
-            for s in range(sp):   # (unit = dense block, parity of the split): the workgroups of a unit walk overlapping pixel tiles of the same two slabs
-                wgs.append(((pi // ppu, s % 2, pi, s), (pi << 8) | s))
-        wgs.sort()
-        per = ceil_div(len(wgs), 8)   # workgroup b runs on XCD b % 8 (a launch of <= 256 workgroups of 16 waves: one per CU): XCD x gets run x of the sorted list
-        assert per * 8 <= 256 * 4, 'a balanced weight-gradient launch is sized for one workgroup per CU'
-        table = []
-        for k in range(per):
-            for x in range(8):
-                i = x * per + k
-                table.append(wgs[i][1] if i < len(wgs) else -1)
-        self.n_red, self.ws_floats, self.workspace = len(red), off, workspace
-        self.n_wgs = len(wgs)
-        workspace.reserve(off)
-        nparts = len(self.parts)
-        wa = (WgradPart * nparts)(*[p[0] for p in self.parts])
-        ra = (WgradReducePart * len(red))(*red)
-        self.w_dev = torch.frombuffer(bytearray(bytes(wa)), dtype=torch.uint8).to(device)
-        self.r_dev = torch.frombuffer(bytearray(bytes(ra)), dtype=torch.uint8).to(device)
-        self.map_dev = torch.tensor(table, dtype=torch.int32, device=device)
-
     def ops(self, grad_ptr, scale=1.0):
         a, b = Op(), Op()
         a.op = _lib.OP_WGRAD
         f16 = getattr(self, 'f16', False)   # 16-bit f16 tensors (gradient pre-scaled by g_scale): f16 MFMA, reduce scale x 1 / g_scale
         a.p[0], a.i[0], a.i[1], a.i[2], a.i[3], a.i[4] = (self.w_dev.data_ptr(), len(self.parts), self.nsplit | (getattr(self, 'ppu', 0) << 16), 33, 1,
                                                           (2 if f16 else self.parts[0][0].g_f32))
-        if getattr(self, 'map_dev', None) is not None:   # balanced launch (dasr_wgrad_map): the workgroup table
-            a.p[2], a.i[5] = self.map_dev.data_ptr(), int(self.map_dev.numel())
         a.flops = float(getattr(self, 'flops', 0.0))
         b.op = _lib.OP_WGRAD_REDUCE
         b.p[0], b.i[0], b.p[2], b.f[0] = self.r_dev.data_ptr(), self.n_red, grad_ptr, scale

@@ -295,8 +295,6 @@ class TrunkStore:
         gmax = 4       # RRDBs per launch: 4 measured best (16: -1 %, 1: -1.5 %; profiles/r03_wgrad_ablation.txt)
         self.phase = OpList()
         self.groups = []   # (first op, end op, lo, hi): ops [first, end) complete params.grad[lo:hi]; descending parameter order
-        if os.environ.get('DASR_WGRAD_BALANCE', '1') != '0':
-            return self._build_phase_balanced(target)
         hi_rrdb = nb
         ppr = None
         while hi_rrdb > 0:
@@ -326,52 +324,6 @@ class TrunkStore:
             hi = P.off('model.1.sub.%d.RDB1.conv1.0.weight' % hi_rrdb) if hi_rrdb < nb else P.off('model.1.sub.%d.weight' % nb)
             self.groups.append((first, len(self.phase.ops), lo, hi))
             hi_rrdb = lo_rrdb
-        self.phase.tag(5)
-
-    def _build_phase_balanced(self, target):
-        """Round 5: balanced grouped launches (engine.WgradGroup3.finalize(s_full=...), dasr_wgrad_map).  The five parts of a dense block carry 6, 6, 6, 3 and 5
-        (oc tile, cin tile) pairs; with ONE split count for all of them (round 3: 4 splits, 12 dense blocks = 240 workgroups per launch, 6 launches) the 3- and
-        5-pair workgroups idle next to the 6-pair ones.  Here a part gets splits in proportion to its pairs (4 / 4 / 4 / 2 / 4: 18 workgroups per dense block),
-        which fits 14 dense blocks into the 256 one-per-CU slots: 5 launches of the same duration instead of 6.  The group size is searched, not
-        hard-wired: the launch count times the per-workgroup work is minimised over the split count of a full part."""
-        net, N, h, w = self.net, self.N, self.h, self.w
-        nf, nb, P = net.nf, net.nb, net.params
-        tmp = WgradGroup3()
-        ppu, _ = rdb_wgrad_parts(tmp, nf, 'model.1.sub.0.RDB1.conv', P, self.gslab(0), self.slab(0), h, w, N)
-        loads = [WgradGroup3.part_load(tiles) for _, tiles in tmp.parts]
-        n_rdb = 3 * nb
-        best = None
-        for s_full in range(1, 9):
-            per = sum(WgradGroup3.balanced_splits(loads, s_full))
-            R = min(n_rdb, target // per)
-            if R < 1:
-                continue
-            launches = ceil_div(n_rdb, R)
-            cost = (launches * 6.0 / s_full, launches)
-            if best is None or cost < best[0]:
-                best = (cost, s_full, R)
-        _, s_full, R = best
-        self.wgrad_s_full, self.wgrad_rdbs_per_launch = s_full, R
-        name = lambda ridx: 'model.1.sub.%d.RDB%d.conv1.0.weight' % (ridx // 3, ridx % 3 + 1)
-        hi_r = n_rdb
-        while hi_r > 0:
-            lo_r = max(0, hi_r - R)
-            grp = WgradGroup3()
-            grp.flops = 0.0
-            for ridx in range(hi_r - 1, lo_r - 1, -1):
-                _, fl = rdb_wgrad_parts(grp, nf, 'model.1.sub.%d.RDB%d.conv' % (ridx // 3, ridx % 3 + 1), P, self.gslab(ridx), self.slab(ridx), h, w, N)
-                grp.flops += fl
-            if net.rdb_f16:
-                grp.f16, grp.g_scale = True, self.gscale
-            grp.finalize(self.ws, net.device, target_wgs=target, ppu=ppu, s_full=s_full)
-            first = len(self.phase.ops)
-            for o in grp.ops(P.grad.data_ptr()):
-                self.phase.add(o)
-            self.phase.keep.append(grp)
-            lo = P.off(name(lo_r))
-            hi = P.off(name(hi_r)) if hi_r < n_rdb else P.off('model.1.sub.%d.weight' % nb)
-            self.groups.append((first, len(self.phase.ops), lo, hi))
-            hi_r = lo_r
         self.phase.tag(5)
 
     CALIB_EVERY = 256

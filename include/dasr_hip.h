@@ -133,7 +133,6 @@ typedef struct {
     int32_t tap0;                           /* first tap of this part (5x5 kernels are split into parts of <= 10 taps) */
     float g_scale;                          /* f16 staging (f32 & 2): g is multiplied by g_scale (power of two, 0 = 1) before rounding; the caller folds
                                              * 1/g_scale into dasr_wgrad_reduce's scale */
-    int32_t nsplit_part, reserved_;         /* dasr_wgrad_map: this part's own number of pixel splits (workspace [nsplit_part][...]) */
 } dasr_wgrad_part;
 
 /* f32 bit 0: g and in tensors of ALL parts are f32 (rounded while staging) instead of bf16; bit 1: ... rounded to f16 (11-bit mantissa,
@@ -142,11 +141,6 @@ typedef struct {
  * (g_planes = 2/4/6), workspace [split][tap][3][32][64], bias [split][96]. */
 int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int32_t nsplit, int32_t kh, int32_t stride, int32_t f32,
                float* ws, void* stream);
-/* The kh = 33 kernel with an explicit workgroup table (round 5): workgroup b of the launch works on part block_map[b] >> 8, pixel split block_map[b] & 255
- * (of that part's nsplit_part splits), or exits at once when block_map[b] < 0.  Lets the caller (a) give parts with fewer (oc tile, cin tile) pairs fewer,
- * longer splits, so that every workgroup of a one-workgroup-per-CU launch carries the same MFMA work, and (b) place the workgroups that read the same
- * tensors on one XCD (workgroup b runs on XCD b % 8 while the launch has <= 256 workgroups).  f32: 0 bf16 tensors, 2 f16 tensors. */
-int dasr_wgrad_map(const dasr_wgrad_part* parts_dev, int32_t nparts, const int32_t* block_map_dev, int32_t nblocks, int32_t f32, float* ws, void* stream);
 /* bit 0: 1 = ds_read_b64_tr_b16 gathers, 0 = scalar LDS gathers (dasr_probe_tr16 sets it from the device);
  * bit 1: dense-block wgrad3 staged by LDS-DMA instead of registers (A/B; default off); bit 7: kh = 33 launches on 16-bit tensors run
  * wgrad4_kernel (4 waves, LDS-DMA ring of three tiles, register window of X fragments; measured slower, kept as a tested alternative)
