@@ -1503,7 +1503,8 @@ __device__ __forceinline__ void chain_layer(const dasr_conv_params& p, char* sme
         // bit 0: the DMA pieces of the next chunk spread over the steps (one or two per step) instead of all in steps 0-3; bit 1: weight fragments read two
         // steps ahead; bit 2: no sched_barrier around the MFMA groups.  Diagnostics with WRONG results: bit 3 no chunk barrier, bit 4 no DMA after chunk 0,
         // bit 5 no MFMA, bit 6 no fragment reads after chunk 0.  (Also tried, in git history only: conv5 storing and publishing its 16-bit shadow in front of the
-        // fp32 stream -- 29.53-29.57 vs 29.46-29.49 ms per step.)
+        // fp32 stream -- 29.53-29.57 vs 29.46-29.49 ms per step; plain instead of write-through stores for that fp32 stream, which only the same tile reads again --
+        // 29.44-29.53 vs 29.33-29.46 ms.)
         constexpr int V = CHV;
         constexpr int FAD = (V & 2) ? 3 : 2;
         bf16x8 fa3[3][MT];
