@@ -231,7 +231,7 @@ class SRModel(BaseModel):
                 raise NotImplementedError('MultiStepLR learning rate scheme is enough.')
             self.schedulers.append(MultiStepLR(t['lr_G'], t['lr_steps'], t['lr_gamma']))
             self.log_dict = OrderedDict()
-            self.loss_acc = torch.zeros(4, dtype=torch.float32, device=self.device)
+            self.loss_acc = torch.zeros(8, dtype=torch.float32, device=self.device)   # one slot per sub-batch replica stream (<= 8): the logged loss is their sum in slot order -- the same value run to run for any replica count
         self._step_ops = {}
 
     def feed_data(self, data, need_HR=True):
@@ -251,7 +251,7 @@ class SRModel(BaseModel):
             o.t[0], o.p[0], o.p[1] = plan.sr.view(), hr_buf.data_ptr(), None
             o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = N, C_, H, W, (2 if self.pix_l2 else 0)
             o.f[0] = float(self.l_pix_w) / float(n_total * C_ * H * W)
-            o.p[2], o.t[1] = self.loss_acc.data_ptr(), plan.g_sr.view()
+            o.p[2], o.t[1] = self.loss_acc.data_ptr() + 4 * (plan.replica % 8), plan.g_sr.view()
             ops.add(o)
             self._step_ops[key] = (ops, hr_buf)
         return self._step_ops[key]
@@ -325,7 +325,7 @@ class SRModel(BaseModel):
         N, _, h, w = self.var_L.shape
         plans = self._sub_plans(N, h, w)
         L = _lib.lib()
-        _lib.check(L.dasr_fill_f32(self.loss_acc.data_ptr(), 4, 0.0, _stream()), 'fill')
+        _lib.check(L.dasr_fill_f32(self.loss_acc.data_ptr(), 8, 0.0, _stream()), 'fill')
         dp_on = self.dp is not None and self.dp.active
         if len(plans) == 1:
             plan = plans[0]
@@ -357,7 +357,7 @@ class SRModel(BaseModel):
                 l0.run()
                 p0.bwd.run(0, p0.tail_end)
                 p0.store.set_gscale_from(float(p0.g_t0.t.abs().max().item()))
-                _lib.check(L.dasr_fill_f32(self.loss_acc.data_ptr(), 4, 0.0, _stream()), 'fill')
+                _lib.check(L.dasr_fill_f32(self.loss_acc.data_ptr(), 8, 0.0, _stream()), 'fill')
             steps = []
             for i, (plan, st) in enumerate(zip(plans, self._streams)):
                 st.wait_stream(cur)
@@ -411,7 +411,7 @@ class SRModel(BaseModel):
         self.netG.repack()
         self._out_plans = plans
         self._fake_H = None
-        self._l_pix_dev = self.loss_acc[0:1]
+        self._l_pix_dev = self.loss_acc
         self.log_dict['l_pix'] = None  # materialised lazily by get_current_log (no per-step host sync)
 
     @property
@@ -433,7 +433,7 @@ class SRModel(BaseModel):
 
     def get_current_log(self):
         if 'l_pix' in self.log_dict:
-            self.log_dict['l_pix'] = float(self._l_pix_dev.item())
+            self.log_dict['l_pix'] = float(sum(self._l_pix_dev.tolist()))   # (replica slots added in index order, in double)
             self.check_finite()
         return self.log_dict
 
