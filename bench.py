@@ -180,7 +180,9 @@ def secondary_roofline(run_step, streams, workload=None):
         ent = pm.get('workloads', {}).get(workload, {}).get(out.get('kernel'))
         if ent:
             out['traffic'] = int((ent['fetch_size_kb_raw'] * pm['fetch_correction_gfx950'] + ent['write_size_kb']) * 1024.0)
-            out['traffic_source'] = pm['source'].split(':')[0].replace('_pmc_traffic.txt', '_%s_pmc_traffic.txt' % workload)
+            tag = pm.get('workloads_tag')   # the secondary workloads' PMC passes may come from an earlier session than the headline's (profiles/pmc_traffic.json)
+            out['traffic_source'] = ('profiles/%s_%s_pmc_traffic.txt' % (tag, workload)) if tag else \
+                pm['source'].split(':')[0].replace('_pmc_traffic.txt', '_%s_pmc_traffic.txt' % workload)
     except Exception:
         pass
     out['per_kernel'] = r['per_kernel'][:6]
