@@ -155,17 +155,27 @@ class RRDBNetHIP:
         self.pack.run()
 
     def chain_ok(self, N, h, w):
-        """a training plan of this shape runs its trunk as chained launches: whole images per XCD and the launch fills the chip exactly (dasr_conv_chain).
-        (Round 5 built a form whose workgroups own several tiles -- 1024 tiles for configs[2]'s 32 crops: bit-identical, but 88 ms per GAN step against 72 ms
+        """a training plan of this shape runs its trunk as chained launches (dasr_conv_chain): chain_split(N, h, w) > 0"""
+        return self.chain_split(N, h, w) > 0
+
+    def chain_split(self, N, h, w):
+        """number of image sub-batches the trunk of a training plan runs as chained launches, 0 = one launch per conv.  A chained launch needs whole
+        images per XCD and exactly 512 tiles (dasr_conv_chain): N images of T tiles qualify when N T = 512 k and N / k is a multiple of 8 -- the plan then
+        runs k launches BACK TO BACK over image ranges of N / k (k = 1 at configs[1]; k = 2 for configs[2]'s 32 crops of 128 x 128: at batch 32 the
+        per-layer launches run a dense block in 274 + 287 us, two chained half-batches in 2 x (131 + 129) us).
+        (Round 5 also built a form whose workgroups own several tiles -- one launch over 1024 tiles: bit-identical, but 88 ms per GAN step against 72 ms
         with one launch per conv; it lives in the -DDASR_BENCH library only, profiles/r05_chain_trace.txt.)"""
-        if not (self.chain and N % 8 == 0 and N * ceil_div(h, 16) * ceil_div(w, 32) == 512 and not getattr(self, 'debug_taps', ())):
-            return False
+        ntiles = N * ceil_div(h, 16) * ceil_div(w, 32)
+        k = ntiles // 512
+        kmax = int(os.environ.get('DASR_CHAIN_SPLIT', '4'))   # DASR_CHAIN_SPLIT=1: exact fit only (A/B)
+        if not (self.chain and k >= 1 and k <= kmax and ntiles == 512 * k and N % k == 0 and (N // k) % 8 == 0 and not getattr(self, 'debug_taps', ())):
+            return 0
         from . import dist as _dist
         if _dist.SHARED_DEVICE:   # another rank of this job runs on the same GPU (gloo test set-up): the launch would not have the chip to itself
-            return False
+            return 0
         if not hasattr(self, '_cus'):   # 512 workgroups = 2 per CU of a whole MI355X (8 XCDs x 32 CUs); a partitioned device (CPX / DPX) has fewer
             self._cus = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == 'cuda' else 0
-        return self._cus == 256
+        return k if self._cus == 256 else 0
 
     # ---- plan ---------------------------------------------------------------------------------------
     def plan(self, N, h, w, replica=0, store=None, n0=0):
@@ -223,6 +233,23 @@ def _sched(kind, handle):
     o.op = kind
     o.p[0] = handle
     return o
+
+
+def _sub_batch_conv(o, n0, n, N):
+    """copy of a dense-block conv Op restricted to images [n0, n0 + n) of its N: every tensor view moves by n0 images (the chained launches of a batch that is a
+    multiple of the 512-tile fit run one sub-batch after the other, RRDBNetHIP.chain_split)"""
+    import ctypes as C
+    q = Op()
+    C.memmove(C.addressof(q), C.addressof(o), C.sizeof(Op))
+    c = q.conv
+    assert c.N == N and not c.res1_lo and not c.in_wrap and not c.out16_lo
+    for name, esz in (('inp', 4 if c.in_f32 else 2), ('mask', 4 if c.mask_f32 else 2), ('res1', 4), ('res2', 4), ('out_f32', 4), ('out_bf16', 2)):
+        t = getattr(c, name)
+        if t.p:
+            t.p = t.p + n0 * t.n_stride * esz
+    c.N = n
+    q.flops = o.flops * n / N
+    return q
 
 
 def rdb_wgrad_parts(grp, nf, pre, P, Gs, S, h, w, N):
@@ -494,7 +521,8 @@ class _Plan:
         # its neighbour tiles only before the input chunks the previous layer produced.  Needs whole images per XCD (N % 8 == 0) and every workgroup
         # resident with the chip exactly full (N * tiles == 512); the taps of the tests sit between layers and keep the per-layer launches.
         tiles = ceil_div(h, 16) * ceil_div(w, 32)
-        chain = [] if (net.chain_ok(N, h, w) and not self.inference) else None
+        nsub = 0 if self.inference else net.chain_split(N, h, w)   # sub-batches of 512 tiles, each one chained launch (1 at configs[1], 2 at configs[2])
+        chain = [] if nsub else None
         trunk_ops = ops if chain is None else OpList()
         main_ops, ops = ops, trunk_ops
         for i in range(nb):
@@ -534,10 +562,16 @@ class _Plan:
             body = [o for o in trunk_ops.ops if o.op == _lib.OP_CONV]
             assert len(body) == len(trunk_ops.ops) == 15 * nb
             deps = [0 if k % 5 == 0 else (o.conv.cin // 16) - GC // 16 for k, o in enumerate(body)]
-            self.chain = ConvChain(body[:-1], deps[:-1], N, tiles, net.device, err=net.chain_err)   # (the last conv5 has no 16-bit shadow to write: its own launch)
-            ops.add(self.chain.op())
+            per = N // nsub
+            self.chains = []   # (the last conv5 has no 16-bit shadow to write: its own launch, over the whole batch)
+            for sb in range(nsub):
+                sub = body[:-1] if nsub == 1 else [_sub_batch_conv(o, sb * per, per, N) for o in body[:-1]]
+                ch = ConvChain(sub, deps[:-1], per, tiles, net.device, err=net.chain_err)
+                self.chains.append(ch)
+                ops.add(ch.op())
+                ops.keep.append(ch)
+            self.chain = self.chains[0]
             ops.add(body[-1])
-            ops.keep.append(self.chain)
         self.x_last = X
         lrb = 'model.1.sub.%d.bias' % nb
         if net.hr_f16s:
@@ -812,11 +846,18 @@ class _Plan:
             assert len(body) == 15 * nb and all(o.op == _lib.OP_CONV for o in body)
             deps = [0 if k % 5 == 0 else (o.conv.cin // 16) - GC // 16 for k, o in enumerate(body)]
             tiles = ceil_div(h, 16) * ceil_div(w, 32)
-            self.chain_b = ConvChain(body[:-1], deps[:-1], N, tiles, net.device, err=self.chain.err)   # (the last conv writes no 16-bit planes: its own launch)
+            nsub = len(self.chains)
+            per = N // nsub
             ops = main_ops
-            ops.add(self.chain_b.op())
+            self.chains_b = []   # (the last conv writes no 16-bit planes: its own launch)
+            for sb in range(nsub):
+                sub = body[:-1] if nsub == 1 else [_sub_batch_conv(o, sb * per, per, N) for o in body[:-1]]
+                ch = ConvChain(sub, deps[:-1], per, tiles, net.device, err=self.chain.err)
+                self.chains_b.append(ch)
+                ops.add(ch.op())
+                ops.keep.append(ch)
+            self.chain_b = self.chains_b[0]
             ops.add(body[-1])
-            ops.keep.append(self.chain_b)
         ops.tag(4)
         rrdb0 = P.off('model.1.sub.0.RDB1.conv1.0.weight')
         if not self.shared_store:   # this plan owns the whole batch: the weight-gradient phase follows the chain in the same list

@@ -226,12 +226,13 @@ def test_f16_dense_block_gradient_scale_is_consistently_patched(monkeypatch):
         assert worst < 2e-3, worst
 
 
-@pytest.mark.parametrize('shape', [(16, 128, 128, 2), (8, 256, 128, 1)], ids=['16x128x128', '8x256x128'])
+@pytest.mark.parametrize('shape', [(16, 128, 128, 2), (8, 256, 128, 1), (32, 128, 128, 1), (24, 128, 256, 1)], ids=['16x128x128', '8x256x128', '32x128x128-two_sub_batches', '24x128x256-three_sub_batches'])
 def test_chained_trunk_launches_are_bit_identical_to_per_layer_launches(shape, monkeypatch):
     """DASR_CHAIN (default on where the batch fills the chip exactly, RRDBNetHIP.chain_ok): the 15 nb dense-block convs of the forward and of the data
     gradient each run as ONE persistent launch in which a tile waits for its neighbour tiles only before the input chunks the previous layer wrote
     (dasr_conv_chain).  Same arithmetic in the same order: SR output, every gradient and the weights after two Adam steps must be BIT-identical to the
-    per-layer launches, and the device error word stays zero (no neighbour wait gave up)."""
+    per-layer launches, and the device error word stays zero (no neighbour wait gave up).  Round 5: batches of k x 512 tiles run k chained launches back to
+    back over image ranges (RRDBNetHIP.chain_split: configs[2]'s 32 crops = two launches of 16)."""
     _gpu()
     if torch.cuda.get_device_properties(0).multi_processor_count != 256:
         pytest.skip('the chained launches need a whole 256-CU MI355X (RRDBNetHIP.chain_ok)')
@@ -259,6 +260,7 @@ def test_chained_trunk_launches_are_bit_identical_to_per_layer_launches(shape, m
         if chain == '1':
             assert len(plans) == 1 and plans[0].chain is not None and plans[0].chain_b is not None
             assert plans[0].chain.n == 15 * nb - 1 and plans[0].chain_b.n == 15 * nb - 1
+            assert len(plans[0].chains) == len(plans[0].chains_b) == m.netG.chain_split(n, h, w) == n * ((h + 15) // 16) * ((w + 31) // 32) // 512
         else:
             assert all(getattr(p, 'chain', None) is None for p in plans)
         outs.append((m.fake_H.clone(), m.netG.params.grad.clone(), m.netG.params.flat.clone()))
@@ -274,4 +276,6 @@ def test_chain_refuses_shapes_that_do_not_fill_the_chip():
         assert not net.chain_ok(16, 128, 128)   # a partitioned device: never
         return
     assert net.chain_ok(16, 128, 128) and net.chain_ok(8, 128, 256) and net.chain_ok(32, 64, 128)
-    assert not net.chain_ok(16, 64, 64) and not net.chain_ok(4, 256, 256) and not net.chain_ok(12, 128, 128) and not net.chain_ok(32, 128, 128)
+    assert not net.chain_ok(16, 64, 64) and not net.chain_ok(4, 256, 256) and not net.chain_ok(12, 128, 128) and not net.chain_ok(24, 128, 128)
+    assert (net.chain_split(16, 128, 128), net.chain_split(32, 128, 128), net.chain_split(48, 128, 128), net.chain_split(20, 128, 128)) == (1, 2, 3, 0)   # (20: 640 tiles)
+    assert net.chain_split(80, 128, 128) == 0   # five sub-batches: over the limit of four (DASR_CHAIN_SPLIT)
