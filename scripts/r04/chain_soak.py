@@ -15,6 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--more', type=int, default=2000)
+    ap.add_argument('--batch', type=int, default=16, help='32: two chained launches over 16-image sub-batches per direction (RRDBNetHIP.chain_split, round 5)')
     a = ap.parse_args()
     os.environ['DASR_STREAMS'] = '1'
     import torch
@@ -22,7 +23,7 @@ def main():
     from dasr_amd import options
     from dasr_amd.models import create_model
     g = torch.Generator().manual_seed(99)
-    pool = [{'LR': torch.rand(16, 3, 128, 128, generator=g).cuda(), 'HR': torch.rand(16, 3, 512, 512, generator=g).cuda()} for _ in range(4)]
+    pool = [{'LR': torch.rand(a.batch, 3, 128, 128, generator=g).cuda(), 'HR': torch.rand(a.batch, 3, 512, 512, generator=g).cuda()} for _ in range(4)]
     finals = []
     for chain in ('1', '0'):
         os.environ['DASR_CHAIN'] = chain
