@@ -207,15 +207,6 @@ def lib():
     return _lib
 
 
-def tuning_value(key, default):
-    """value of dasr_set_tuning key `key` as selected through DASR_TUNE ("k=v,k=v"), else `default` (host logic that must agree with the library's variant)"""
-    for kv in [x for x in os.environ.get('DASR_TUNE', '').split(',') if x]:
-        k, v = kv.split('=')
-        if int(k) == key:
-            return int(v)
-    return default
-
-
 def check(rc, what=''):
     if rc != 0:
         raise DasrHipError('%s failed with code %d' % (what or 'dasr call', rc))

@@ -2204,7 +2204,9 @@ int classify_epi(const dasr_conv_params& p) {
 
 // kernel-variant selection (A/B-able from the host: dasr_set_tuning)
 int g_tune_rot = 0;  // chunk-order rotation of the LDS-DMA dense-block conv (A/B)
-int g_chain_form = 1;  // chained launches (-DDASR_BENCH builds only): 1 = conv_chain_kernel for the exact fit of 512 tiles, conv_chain2_kernel for multiples; 2 = conv_chain2_kernel always
+#ifdef DASR_BENCH
+int g_chain_form = 1;  // chained launches: 1 = conv_chain_kernel for the exact fit of 512 tiles, conv_chain2_kernel for multiples; 2 = conv_chain2_kernel always
+#endif
 int g_tune_rdb32 = 12, g_tune_rdb64 = 13, g_tune_stream = 0, g_tune_xcd = 1, g_tune_epi = 1;  // Cout=64: 13 = 8-wave form for launches of <= 256 four-wave workgroups (worth 1-2 % of the step under two sub-batch streams)
 
 }  // namespace
