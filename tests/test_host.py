@@ -382,3 +382,58 @@ def test_tensorboard_event_writer_roundtrip(tmp_path):
         assert back.shape == (6, 10, 3) and np.array_equal(back, want)
     except ImportError:
         pass
+
+
+def test_dp_backward_never_hands_a_bucket_to_the_exchange_in_front_of_a_chained_launch():
+    """rrdbnet._Plan.run_backward_dp: a chained launch needs every workgroup slot of the device, so no collective may be in flight while
+    it runs.  The gradient bucket that is complete in front of a segment with a chained launch is held back and handed over together with that segment's own
+    bucket; every other bucket goes out right behind its segment (overlap with the weight-gradient launches); the call ends with dp.wait().  Pure host
+    logic: stub segments / stub group, no device."""
+    from types import SimpleNamespace as NS
+    from dasr_amd import _lib
+    from dasr_amd.rrdbnet import _Plan
+    events = []
+
+    def seg(name, kinds):
+        return NS(ops=[NS(op=k) for k in kinds], run=lambda name=name: events.append(('run', name)))
+
+    CONV, CHAIN, WG = _lib.OP_CONV, _lib.OP_CONV_CHAIN, _lib.OP_WGRAD
+    segs = [(seg('hr_tail', [CONV, WG]), (900, 1000)), (seg('chain+wgrad0', [CONV, CHAIN, CONV, WG]), (600, 900)), (seg('wgrad1', [WG]), (300, 600)),
+            (seg('fea', [CONV, WG]), (0, 300))]
+    plan = NS(bwd_segments=lambda: segs)
+    dp = NS(reduce_async=lambda sl: events.append(('reduce', (sl.start, sl.stop))), wait=lambda: events.append(('wait',)))
+
+    class G:
+        def __getitem__(self, sl):
+            return sl
+    _Plan.run_backward_dp(plan, dp, G())
+    assert events == [('run', 'hr_tail'), ('run', 'chain+wgrad0'), ('reduce', (900, 1000)), ('reduce', (600, 900)), ('run', 'wgrad1'), ('reduce', (300, 600)),
+                      ('run', 'fea'), ('reduce', (0, 300)), ('wait',)], events
+    # without a chained launch in the list: every bucket right behind its segment
+    events.clear()
+    segs[1] = (seg('per_layer', [CONV, CONV, WG]), (600, 900))
+    _Plan.run_backward_dp(plan, dp, G())
+    assert events[:4] == [('run', 'hr_tail'), ('reduce', (900, 1000)), ('run', 'per_layer'), ('reduce', (600, 900))] and events[-1] == ('wait',)
+
+
+def test_chain_split_rule():
+    """RRDBNetHIP.chain_split: which batches run their trunk as chained launches, and as how many image sub-batches (host rule; a whole 256-CU device assumed)"""
+    from types import SimpleNamespace as NS
+    from dasr_amd.rrdbnet import RRDBNetHIP
+    net = NS(chain=True, _cus=256)
+    f = lambda N, h, w: RRDBNetHIP.chain_split(net, N, h, w)
+    assert (f(16, 128, 128), f(8, 256, 128), f(32, 64, 128), f(32, 128, 128), f(24, 128, 256), f(64, 128, 128)) == (1, 1, 1, 2, 3, 4)
+    assert (f(16, 64, 64), f(12, 128, 128), f(20, 128, 128), f(24, 128, 128), f(80, 128, 128), f(4, 256, 256)) == (0, 0, 0, 0, 0, 0)   # too few / not 512 k / images per XCD / > 4
+    assert RRDBNetHIP.chain_split(NS(chain=False, _cus=256), 16, 128, 128) == 0 and RRDBNetHIP.chain_split(NS(chain=True, _cus=64), 16, 128, 128) == 0
+
+
+def test_crc32c_fast_path_equals_the_byte_loop():
+    """tb_writer.crc32c: records above 16 KB go through the chunk-parallel numpy path (the per-byte loop cost seconds per image); same value as
+    the byte loop at every size class, and the CRC-32C check value of '123456789'"""
+    from dasr_amd import tb_writer as t
+    assert t.crc32c(b'123456789') == 0xE3069283
+    rng = random.Random(7) if 'random' in globals() else __import__('random').Random(7)
+    for n in (0, 1, 4095, 16383, 16384, 16385, 100003, 300000):
+        d = bytes(rng.getrandbits(8) for _ in range(n))
+        assert t.crc32c(d) == (t._crc_bytes(0xFFFFFFFF, d) ^ 0xFFFFFFFF), n
+    assert t.crc32c(bytearray(b'x' * 20000)) == t.crc32c(b'x' * 20000)   # (any bytes-like object)
