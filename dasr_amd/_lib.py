@@ -70,10 +70,12 @@ OP_BNORM_FWD, OP_BNORM_BWD, OP_BNORM_RUNNING = 40, 41, 42
 OP_DDM_SPREAD = 43
 OP_INORM_JVP, OP_INORM_SECOND, OP_GRAD_PENALTY, OP_FILL_SCALED = 44, 45, 46, 47
 OP_CONV_CHAIN = 48
+OP_RDB_CHAIN = 49
 
 _SIGS = {
     'dasr_conv': [C.POINTER(ConvParams), c_vp],
     'dasr_conv_chain': [c_vp, C.POINTER(ConvParams), c_vp, c_i32, c_vp, c_vp, c_vp],
+    'dasr_rdb_chain': [c_vp, C.POINTER(ConvParams), c_i32, c_vp, c_vp, c_vp],
     'dasr_conv_naive': [C.POINTER(ConvParams), c_vp, c_vp],
     'dasr_set_tuning': [c_i32, c_i32],
     'dasr_wgrad': [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],

@@ -2209,6 +2209,8 @@ int g_chain_form = 1;  // chained launches: 1 = conv_chain_kernel for the exact 
 #endif
 int g_tune_rdb32 = 12, g_tune_rdb64 = 13, g_tune_stream = 0, g_tune_xcd = 1, g_tune_epi = 1;  // Cout=64: 13 = 8-wave form for launches of <= 256 four-wave workgroups (worth 1-2 % of the step under two sub-batch streams)
 
+#include "rdb_is.h"
+
 }  // namespace
 
 #ifdef DASR_TRACE
@@ -2326,6 +2328,47 @@ extern "C" int dasr_conv_chain(const dasr_conv_params* dev_layers, const dasr_co
     else DASR_CHAIN_LAUNCH(true, true, "conv_chain_kernel<true, true>")
 #undef DASR_CHAIN_LAUNCH
     return (int)hipGetLastError();
+}
+
+// The chained trunk launch, input-stationary form (rdb_is.h): nlayers = 5 x (dense blocks), layers[5 b + k] = conv k + 1 of block b as dasr_conv would run it.
+extern "C" int dasr_rdb_chain(const dasr_conv_params* dev_layers, const dasr_conv_params* host_layers, int32_t nlayers, uint32_t* dev_flags, int32_t* dev_err, void* stream) {
+    if (!dev_layers || !host_layers || nlayers <= 0 || nlayers % 5 || !dev_flags || !dev_err) return DASR_EINVAL;
+    const dasr_conv_params& p0 = host_layers[0];
+    if (p0.prec != 1) return DASR_EINVAL;   // bf16 storage (the f16 dense blocks keep the per-layer launches)
+    const int e0 = classify_epi(p0);
+    const bool bwd = e0 == 68;
+    if (!bwd && e0 != 67) return DASR_EINVAL;
+    for (int i = 0; i < nlayers; ++i) {
+        const dasr_conv_params& p = host_layers[i];
+        const dasr_conv_params& pb = host_layers[i - i % 5];
+        const int k = i % 5;
+        if (p.kh != 3 || p.stride != 1 || p.pad != 1 || p.in_f32 || p.prec != 1 || p.ups || p.in_wrap || p.out16_lo || p.res1_lo || p.out16_f16) return DASR_EINVAL;
+        if (p.Hin != p0.Hin || p.Win != p0.Win || p.Hout != p0.Hin || p.Wout != p0.Win || p.N != p0.N || p.out_stride > 1 || p.in_stride > 1 || p.out_W || p.out_oy || p.out_ox) return DASR_EINVAL;
+        if (p.cin != 64 + 32 * k || p.mt != (k == 4 ? 2 : 1) || p.cout != 32 * p.mt || !p.w || !p.in.p || p.slope_ptr || p.mask_f32) return DASR_EINVAL;
+        if (p.in.p != pb.in.p || p.in.n_stride != pb.in.n_stride || p.in.cb_stride != pb.in.cb_stride) return DASR_EINVAL;   // one slab per dense block
+        const int epi = classify_epi(p);
+        // forward: conv1-4 bias + LeakyReLU -> 16-bit planes (67), conv5 bias, alpha, one / two fp32 residuals -> fp32 (+ 16-bit) (233 / 249, 169 / 185);
+        // data gradient: LeakyReLU' mask -> 16-bit planes (68), alpha, one / two fp32 residuals -> fp32 (+ 16-bit) (232 / 248, 168 / 184)
+        const bool ok = k < 4 ? epi == (bwd ? 68 : 67) : ((epi & ~(16 | 64)) == (bwd ? 168 : 169) && p.res1.p && p.alpha != 0.f);
+        if (!ok) return DASR_EINVAL;
+    }
+    const int tiles_x = (p0.Wout + ISC::TW - 1) / ISC::TW, tiles_y = (p0.Hout + ISC::TH - 1) / ISC::TH;
+    const long long ntiles = (long long)tiles_x * tiles_y * p0.N;
+    if ((p0.N & 7) || ntiles < 256 || ntiles % 256 || ntiles / 256 > ISC::MAX_TPW) return DASR_EINVAL;   // whole images per XCD; one workgroup per CU, every one owns ntiles / 256 tiles
+    {
+        static int n_cu = -1;
+        if (n_cu < 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDevice(&dev));
+            HIP_TRY(hipGetDeviceProperties(&prop, dev));
+            n_cu = prop.multiProcessorCount;
+        }
+        if (n_cu != 256) return DASR_EINVAL;
+    }
+    const int tpw = (int)(ntiles / 256);
+    if (bwd) return launch_rdb_is<false, true>(dev_layers, nlayers / 5, tiles_y, tiles_x, tpw, dev_flags, dev_flags + ntiles, dev_err, as_stream(stream), "rdb_is_kernel<false, true>");
+    return launch_rdb_is<false, false>(dev_layers, nlayers / 5, tiles_y, tiles_x, tpw, dev_flags, dev_flags + ntiles, dev_err, as_stream(stream), "rdb_is_kernel<false, false>");
 }
 
 extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {

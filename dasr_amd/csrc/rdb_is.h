@@ -1,0 +1,578 @@
+// ---------------------------------------------------------------------------------------------------
+// rdb_is_kernel (round 6): the chained trunk launch, INPUT-STATIONARY form.  Included by conv.hip inside its anonymous namespace (it shares
+// conv_epilogue, the LDS image and the flag protocol of conv_chain_kernel).
+//
+// Why.  conv_chain_kernel runs a dense block (ResidualDenseBlock_5C, codes/SRN/models/modules/block.py:254-286) layer by layer: conv_k re-stages its
+// whole input, so per block and tile 40 activation chunks (640 channel planes) go L2 -> LDS for 12 distinct ones, and the Cout-32 layers (199 B of
+// LDS-DMA per MFMA) run at 60-70 % of the matrix pipe (profiles/r05_chain_trace.txt).  Here every 16-channel chunk of the block's slab is staged ONCE
+// and multiplied into the accumulators of EVERY conv that consumes it:
+//     group x (4 chunks)  -> conv1 | conv2 conv3 conv4 conv5       group x1 (2 chunks) -> conv2 | conv3 conv4 conv5
+//     group x2            -> conv3 | conv4 conv5                   group x3 -> conv4 | conv5          group x4 -> conv5
+// ("pass A | pass B": the conv that the group completes runs first, its epilogue stores x_k, and the pass over the remaining convs covers the
+// round trip store -> flag -> neighbours' flags -> halo DMA of x_k.)  12 activation chunks instead of 40 per block and tile; the weight volume is
+// unchanged (479 KB per block and tile), so 714 KB instead of 1262 KB of LDS-DMA per block and tile.  The MFMA work, the order in which every accumulator
+// receives its (chunk, tap) products and the epilogue arithmetic are those of conv_glds_kernel / conv_chain_kernel: results are BIT-IDENTICAL.
+//
+// Shape.  The five convs of a block need 32 + 32 + 32 + 32 + 64 = 192 output channels of accumulators per pixel; at most 160 are live at once (conv1 is
+// finished before the others start).  One workgroup of 8 waves per CU (two waves per SIMD, 256 registers each), tile 16 x 32 pixels, wave w owns rows
+// 2w, 2w + 1 (NT = 2 n-tiles of 32 pixels): 160 accumulator registers per lane.  LDS (160 KB, one workgroup): four activation-chunk slots (chunk c of
+// the slab lives in slot c & 3: x in 0-3, x1 -> 0,1, x2 -> 2,3, x3 -> 0,1, x4 -> 2,3) + a ring of four 18-KB weight granules, filled three steps ahead.
+// A STEP = one weight granule: one conv (9 KB, 18 MFMAs per wave), two Cout-32 convs on the same chunk (2 x 9 KB, the B fragments shared) or conv5
+// (18 KB); one raw s_barrier per step, every wait a COUNTED vmcnt (nothing drains the LDS-DMA queue inside the launch).  34 steps per block and tile.
+// A workgroup owns `tpw` tiles (tile j of tpw images of its XCD) and walks (block 0, tile 0), (block 0, tile 1), ..., (block 1, tile 0), ...: the wait
+// of a tile for its neighbours' conv5 (conv_chain_kernel: 25 k cycles per block, exposed) is covered by the other tile's block.
+// Flags, XCD placement (all tiles of image n on XCD n % 8), write-through stores, error word: as conv_chain_kernel.  A neighbour wait is a POLL
+// PIPELINE, not a spin: wave 0 requests the nine flag words by LDS-DMA at the start of a step, every wave reads them from LDS after the step's barrier;
+// only when a group is still missing where it is needed does the workgroup spin (and counts it: err stays 0, the time shows in the trace).
+// ---------------------------------------------------------------------------------------------------
+#ifndef IS_PUB_DELAY
+#define IS_PUB_DELAY 1
+#endif
+struct ISC {
+    static constexpr int NW = 8, NTH = 512, NT = 2, TH = 16, TW = 32, IH = 18, IW = 34, NPIX = IH * IW;
+    static constexpr int APIECE = NPIX * 2;                  // 16-byte pieces of one activation chunk (1224)
+    static constexpr int AR = (APIECE + NTH - 1) / NTH;      // DMA rounds per chunk (3, the last one partial)
+    static constexpr int ACT_SLOT = 20480, NSLOT = 4;        // >= APIECE * 16 = 19584
+    static constexpr int W_OFF = NSLOT * ACT_SLOT;
+    static constexpr int WGRAN = 18432, NWG = 4;
+    static constexpr int X_OFF = W_OFF + NWG * WGRAN;        // 155648
+    static constexpr int BIAS_OFF = X_OFF;                   // [2 item parities][5 layers][64 floats]
+    static constexpr int POLL_OFF = X_OFF + 2560;            // [MAX_TPW][16 words]: the newest flag values seen of a tile's nine (self + 8 neighbours) words
+    static constexpr int MAX_TPW = 8;
+    static constexpr int F0_OFF = POLL_OFF + MAX_TPW * 64;   // f0[MAX_TPW], ticket
+    static constexpr int LDS_BYTES = 163840;
+    static constexpr int NSTEP = 34;
+    static constexpr int PUB_DELAY = IS_PUB_DELAY;           // a conv's flag goes out at the end of the PUB_DELAY-th step behind its epilogue (its stores have that long to be acknowledged)
+};
+
+// the static program of one dense block on one tile: kind 1 = one Cout-32 conv u0, 2 = two Cout-32 convs u0, u1 on the same chunk, 5 = conv5; c = chunk of the slab
+struct ISStep { int kind, u0, u1, c; };
+constexpr ISStep IS_PROG[ISC::NSTEP] = {
+    {1, 0, 0, 0}, {1, 0, 0, 1}, {1, 0, 0, 2}, {1, 0, 0, 3},                                                      // x -> conv1            | epilogue conv1 (x1)
+    {2, 1, 2, 0}, {1, 3, 0, 0}, {5, 4, 4, 0}, {2, 1, 2, 1}, {1, 3, 0, 1}, {5, 4, 4, 1},
+    {2, 1, 2, 2}, {1, 3, 0, 2}, {5, 4, 4, 2}, {2, 1, 2, 3}, {1, 3, 0, 3}, {5, 4, 4, 3},                          // x -> conv2-5
+    {1, 1, 0, 4}, {1, 1, 0, 5},                                                                                  // x1 -> conv2           | epilogue conv2 (x2)
+    {2, 2, 3, 4}, {5, 4, 4, 4}, {2, 2, 3, 5}, {5, 4, 4, 5},                                                      // x1 -> conv3-5
+    {1, 2, 0, 6}, {1, 2, 0, 7},                                                                                  // x2 -> conv3           | epilogue conv3 (x3)
+    {1, 3, 0, 6}, {5, 4, 4, 6}, {1, 3, 0, 7}, {5, 4, 4, 7},                                                      // x2 -> conv4, conv5
+    {1, 3, 0, 8}, {1, 3, 0, 9},                                                                                  // x3 -> conv4           | epilogue conv4 (x4)
+    {5, 4, 4, 8}, {5, 4, 4, 9},                                                                                  // x3 -> conv5
+    {5, 4, 4, 10}, {5, 4, 4, 11}};                                                                               // x4 -> conv5           | epilogue conv5
+// group k (x_k, k = 1..4; 5 = the next item's x): awaited during steps [IS_WIN0, IS_WIN1), its DMA may be issued from step IS_WIN0 on (the slots are free then), it is
+// read first in step IS_WIN1
+constexpr int IS_WIN0[6] = {0, 10, 18, 24, 30, 32}, IS_WIN1[6] = {0, 16, 22, 28, 32, 34};
+constexpr int is_group_of_step(int t) {
+    for (int k = 1; k <= 5; ++k)
+        if (t >= IS_WIN0[k] && t < IS_WIN1[k]) return k;
+    return 0;
+}
+constexpr int is_epi_after(int t) { return t == 3 ? 0 : t == 17 ? 1 : t == 23 ? 2 : t == 29 ? 3 : t == 33 ? 4 : -1; }
+
+template <int TV>
+struct ISInt { static constexpr int value = TV; };
+
+__device__ __forceinline__ void is_wait_vm(int n) {   // s_waitcnt vmcnt(min(n, 15)), n wave-uniform (a smaller count than allowed only waits longer)
+    switch (n) {
+        case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+        case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;
+        case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
+        case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
+        case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
+        case 5: __builtin_amdgcn_s_waitcnt(0x0F75); break;
+        case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break;
+        case 7: __builtin_amdgcn_s_waitcnt(0x0F77); break;
+        case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break;
+        case 9: __builtin_amdgcn_s_waitcnt(0x0F79); break;
+        case 10: __builtin_amdgcn_s_waitcnt(0x0F7A); break;
+        case 11: __builtin_amdgcn_s_waitcnt(0x0F7B); break;
+        case 12: __builtin_amdgcn_s_waitcnt(0x0F7C); break;
+        case 13: __builtin_amdgcn_s_waitcnt(0x0F7D); break;
+        case 14: __builtin_amdgcn_s_waitcnt(0x0F7E); break;
+        default: __builtin_amdgcn_s_waitcnt(0x0F7F); break;
+    }
+}
+
+// LDS-DMA helpers (free functions: see glds_dma_piece).  Every one returns the number of VMEM instructions THIS WAVE issued (wave-uniform).
+__device__ __forceinline__ int is_dma_w(__amdgpu_buffer_rsrc_t rw, char* dst, unsigned src_off, int npieces, int wave, int tid) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    int n = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        if (r * ISC::NTH + wave * 64 < npieces) {   // (whole waves: npieces is a multiple of 64)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(dst + (r * ISC::NTH + wave * 64) * 16), 16, (unsigned)(tid + r * ISC::NTH) * 16u, src_off, 0, 0);
+            ++n;
+        }
+    }
+    return n;
+}
+__device__ __forceinline__ int is_dma_act(__amdgpu_buffer_rsrc_t rin, char* slot, const unsigned (&goff)[ISC::AR], unsigned src_off, int wave, int tid) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    int n = 0;
+#pragma unroll
+    for (int r = 0; r < ISC::AR; ++r) {
+        if (r * ISC::NTH + wave * 64 < ISC::APIECE) {
+            if (tid + r * ISC::NTH < ISC::APIECE)   // (the last wave of the last round is partial: the pieces behind the chunk would land in the next slot)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(slot + (r * ISC::NTH + wave * 64) * 16), 16, goff[r], src_off, 0, 0);
+            ++n;
+        }
+    }
+    return n;
+}
+// nine flag words (self + eight neighbours; a missing neighbour = self) -> LDS, past the L1 / L2 (sc0 sc1); lanes 0-8 of one wave
+__device__ __forceinline__ void is_dma_poll(__amdgpu_buffer_rsrc_t rflags, char* dst, unsigned voff) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rflags, (lds_ptr)dst, 4, voff, 0, 0, 17);
+}
+__device__ __forceinline__ void is_dma_bias(__amdgpu_buffer_rsrc_t rb, char* dst, unsigned voff) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)dst, 4, voff, 0, 0, 0);
+}
+
+struct ISGeo {            // one tile of the workgroup's list
+    int n, oy0, ox0;
+    unsigned goff[ISC::AR];   // per-thread source offsets of the activation DMA pieces
+    unsigned nbo;             // lanes 0-8: byte offset of the flag word of neighbour `lane` (self where there is none)
+    unsigned selfo;           // byte offset of the tile's own flag word
+    unsigned f0;              // the tile's flag value at kernel start
+    int slot;
+};
+
+#ifdef DASR_TRACE
+#define IS_T() (g_trace && threadIdx.x == 0 ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
+#define IS_ACC(k, val)                                                                                     \
+    do {                                                                                                   \
+        if (g_trace && threadIdx.x == 0) g_trace[(size_t)(1 << 20) + (size_t)blockIdx.x * 64 + (k)] += (val); \
+    } while (0)
+#else
+#define IS_T() 0ull
+#define IS_ACC(k, val) do {} while (0)
+#endif
+
+// one step's MFMA body.  a0 / a1: the accumulators of the step's one or two m-tiles (NT = 2 n-tiles each); A fragment of (tap, m-tile mi) at
+// wbuf + tap * TS + mi * MIS (+ lane * 16): conv5's granule is [tap][mi][1 KB] (TS 2048, MIS 1024), two Cout-32 convs are [conv][tap][1 KB] (TS 1024, MIS 9216).
+// B fragments: the wave's four input rows per kx, reused across ky (as conv_glds_kernel).  mid(s) runs between the fragment requests and the MFMAs of tap step s.
+template <int NU, int TS, int MIS, bool F16, class Mid>
+__device__ __forceinline__ void is_body(f32x16 (&a0)[2], f32x16 (&a1)[2], const char* abuf, const char* wbuf, const int (&baddr)[4][3], const int aoff, Mid&& mid) {
+    bf16x8 fb[2][4], fa[2][NU];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) fb[0][rr] = *(const bf16x8*)(abuf + baddr[rr][0]);
+#pragma unroll
+    for (int mi = 0; mi < NU; ++mi) fa[0][mi] = *(const bf16x8*)(wbuf + aoff + mi * MIS);
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        const int kx = s / 3, ky = s - kx * 3;
+        if (s + 1 < 9) {
+            const int kx1 = (s + 1) / 3, ky1 = (s + 1) - kx1 * 3;
+#pragma unroll
+            for (int mi = 0; mi < NU; ++mi) fa[(s + 1) & 1][mi] = *(const bf16x8*)(wbuf + aoff + (ky1 * 3 + kx1) * TS + mi * MIS);
+            if (ky == 1 && kx < 2) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) fb[(kx + 1) & 1][rr] = *(const bf16x8*)(abuf + baddr[rr][kx + 1]);
+            }
+        }
+        mid(s);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            a0[nt] = mfma16<F16>(fa[s & 1][0], fb[kx & 1][nt + ky], a0[nt]);
+            if constexpr (NU == 2) a1[nt] = mfma16<F16>(fa[s & 1][1], fb[kx & 1][nt + ky], a1[nt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+
+template <bool F16, bool BWD>
+__global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* __restrict__ layers, const int nrdb, const int tiles_y, const int tiles_x, const int tpw,
+                                                        unsigned* flags, unsigned* tickets, int* err) {
+    using C = ISC;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = tiles_y * tiles_x;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int xcd = (int)(xcc & 7u);
+    const int quota = (int)(gridDim.x >> 3);
+    int* xi = (int*)(smem + C::F0_OFF);   // [0 .. MAX_TPW) f0 of this workgroup's tiles, [MAX_TPW] ticket
+    const __amdgpu_buffer_rsrc_t rflags = make_rsrc(flags);
+    if (tid == 0) xi[C::MAX_TPW] = (int)(atomicAdd(tickets + xcd, 1u) % (unsigned)quota);
+    __syncthreads();
+    const int j = __builtin_amdgcn_readfirstlane(xi[C::MAX_TPW]);
+    if (tid < tpw) {   // stage base of every tile this workgroup owns (the flag words count on from launch to launch)
+        const int idx = j + quota * tid;
+        const int img = idx / T, tile = idx - img * T;
+        xi[tid] = (int)__builtin_amdgcn_raw_buffer_load_b32(rflags, (unsigned)((xcd + 8 * img) * T + tile) * 4u, 0, 17);
+    }
+    __syncthreads();
+    if (tid < tpw * 16) ((int*)(smem + C::POLL_OFF))[tid] = xi[tid >> 4];   // "newest value seen" of every polled word: a lower bound of the truth at all times
+    CH_WHERE(j, xcc);
+    const int Hin = layers[0].Hin, Win = layers[0].Win;
+    __syncthreads();
+
+    auto geo_of = [&](int slot) {
+        ISGeo q;
+        const int idx = j + quota * slot;
+        const int img = idx / T, tile = idx - img * T;
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        q.n = xcd + 8 * img;   // all tiles of image n on XCD n % 8
+        q.oy0 = ty * C::TH, q.ox0 = tx * C::TW;
+        q.slot = slot;
+#pragma unroll
+        for (int r = 0; r < C::AR; ++r) {
+            const int qq = tid + r * C::NTH;
+            const int pp = qq >> 1, h = (qq & 1) ^ ((pp >> 3) & 1);
+            const int iy = pp / C::IW, ix = pp - iy * C::IW;
+            const int gy = q.oy0 - 1 + iy, gx = q.ox0 - 1 + ix;
+            const bool ok = (pp < C::NPIX) & (gy >= 0) & (gy < Hin) & (gx >= 0) & (gx < Win);
+            q.goff[r] = ok ? (unsigned)(((gy * Win + gx) * 16 + 8 * h) * 2) : OOB;
+        }
+        q.selfo = (unsigned)(q.n * T + tile) * 4u;
+        {
+            const int l9 = lane < 9 ? lane : 4;
+            const int y = ty + l9 / 3 - 1, x = tx + l9 % 3 - 1;
+            const bool in = (y >= 0) & (y < tiles_y) & (x >= 0) & (x < tiles_x);
+            q.nbo = in ? (unsigned)(q.n * T + y * tiles_x + x) * 4u : q.selfo;
+        }
+        q.f0 = (unsigned)__builtin_amdgcn_readfirstlane(xi[slot]);
+        return q;
+    };
+
+    // ---- per-lane fragment addresses (the image of conv_glds_kernel; wave w: output rows 2w, 2w + 1 = input rows 2w .. 2w + 3)
+    const int nn = lane & 31, kh2 = lane >> 5;
+    int baddr[4][3];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int pp = (wave * C::NT + rr) * C::IW + nn + kx;
+            baddr[rr][kx] = ((pp << 1) + (kh2 ^ ((pp >> 3) & 1))) << 4;
+        }
+    const int aoff = lane * 16;
+
+    // ---- VMEM bookkeeping of this wave (LDS-DMA instructions only: epilogue loads / stores are not counted, which can only make a wait longer)
+    int issued = 0, mk0 = 0, mk1 = 0;
+    int g = 0;                                     // global step counter: the granule of step g lives in ring slot g & 3
+    bool pub_on = false;                           // a flag store is pending: value pub_val to word pub_off once every op up to pub_mark is acknowledged, at the end of step pub_due
+    int pub_mark = 0, pub_due = 0;
+    unsigned pub_off = 0, pub_val = 0;
+    int mark_x = 0;                                // `issued` behind the DMA of the current item's x chunks
+    const int total_steps = nrdb * tpw * C::NSTEP;
+
+    auto flag_store = [&]() {
+        if (tid == 0) __builtin_amdgcn_raw_buffer_store_b32(pub_val, rflags, pub_off, 0, 16);
+        pub_on = false;
+    };
+    auto flush_pub = [&]() {   // blocking form: every store of this workgroup acknowledged, then the flag
+        if (pub_on) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_s_barrier();
+            flag_store();
+        }
+    };
+    // the nine words of tile q have reached `target` (newest values seen, in LDS)
+    auto poll_ready = [&](const ISGeo& q, unsigned target) -> bool {
+        const unsigned v = ((const unsigned*)(smem + C::POLL_OFF))[q.slot * 16 + (lane < 9 ? lane : 0)];
+        return __builtin_amdgcn_ballot_w64((int)(v - target) < 0) == 0ull;
+    };
+    // spin until they have (a group is not there where it is needed): the only place where the matrix pipe waits for a neighbour
+    auto block_until = [&](const ISGeo& q, unsigned target) {
+        const unsigned long long t0 = IS_T();
+        flush_pub();
+        if (wave == 0 && lane < 9) {
+            int spins = 0;
+            unsigned v;
+            while ((int)((v = __builtin_amdgcn_raw_buffer_load_b32(rflags, q.nbo, 0, 17)) - target) < 0) {
+                __builtin_amdgcn_s_sleep(2);
+                ++spins;
+                if (spins > (1 << 21) || ((spins & 1023) == 0 && __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(err), 0, 0, 17) != 0)) {
+                    atomicOr(err, 2);
+                    break;
+                }
+            }
+            ((unsigned*)(smem + C::POLL_OFF))[q.slot * 16 + lane] = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        IS_ACC(3, IS_T() - t0);
+        IS_ACC(11, 1ull);
+    };
+
+    ISGeo cur = geo_of(0);
+    // ---- prologue: x of the first item, the weights of steps 0-2, the biases of the first item
+    {
+        const dasr_conv_params& p0 = layers[0];
+        const __amdgpu_buffer_rsrc_t rin0 = make_rsrc((const bf16_t*)p0.in.p + (size_t)cur.n * p0.in.n_stride);
+        const unsigned icb0 = (unsigned)(p0.in.cb_stride * 2);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) issued += is_dma_act(rin0, smem + c * C::ACT_SLOT, cur.goff, (unsigned)c * icb0, wave, tid);
+        mark_x = issued;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) issued += is_dma_w(make_rsrc(p0.w), smem + C::W_OFF + t * C::WGRAN, (unsigned)t * 9216u, 576, wave, tid);
+        if (!BWD && wave < 5) {
+            const dasr_conv_params& pb = layers[wave];
+            is_dma_bias(make_rsrc(pb.bias), smem + C::BIAS_OFF + wave * 256, (pb.bias != nullptr && lane < 32 * pb.mt) ? (unsigned)lane * 4u : OOB);
+            ++issued;
+        }
+        mk0 = mk1 = issued;
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // (the one full drain of the launch: granule 0 is read by the first step)
+    }
+
+    f32x16 A0[1][2], A1[1][2], A2[1][2], A3[1][2], A5[2][2];
+
+    int item = 0;
+    for (int r = 0; r < nrdb; ++r) {
+        for (int slot = 0; slot < tpw; ++slot, ++item) {
+            const int L0 = 5 * r;
+            const int par = item & 1;
+            const dasr_conv_params& pl0 = layers[L0];
+            const __amdgpu_buffer_rsrc_t rin = make_rsrc((const bf16_t*)pl0.in.p + (size_t)cur.n * pl0.in.n_stride);
+            const unsigned icb = (unsigned)(pl0.in.cb_stride * 2);
+            // the item behind this one
+            const int sn = slot + 1 < tpw ? slot + 1 : 0, rn = slot + 1 < tpw ? r : r + 1;
+            const bool has_next = rn < nrdb;
+            const int L0n = has_next ? 5 * rn : L0;
+            // packed weights of this item's five convs and of the next item's conv1 (scalar registers: no scalar-memory round trip inside a step)
+            const void* wp0 = layers[L0].w;
+            const void* wp1 = layers[L0 + 1].w;
+            const void* wp2 = layers[L0 + 2].w;
+            const void* wp3 = layers[L0 + 3].w;
+            const void* wp4 = layers[L0 + 4].w;
+            const void* wpn = layers[L0n].w;
+            auto wptr = [&](int u, bool next) -> const void* { return next ? wpn : (u == 0 ? wp0 : u == 1 ? wp1 : u == 2 ? wp2 : u == 3 ? wp3 : wp4); };
+
+            // x of this item is in LDS (requested at the end of the previous item / in the prologue)
+            {
+                const unsigned long long t0 = IS_T();
+                is_wait_vm(issued - mark_x);
+                __builtin_amdgcn_s_barrier();
+                IS_ACC(4, IS_T() - t0);
+            }
+            // conv5's accumulators start from (beta1 / alpha) * x in fp32 (R1_PRE of conv_glds_kernel: the MFMAs accumulate on top, the epilogue scales by alpha).
+            // Requested here, scaled in front of conv1's epilogue (step 3): four steps for the round trip.
+            const dasr_conv_params& p5 = layers[L0 + 4];
+            {
+                const __amdgpu_buffer_rsrc_t rr1 = make_rsrc((const float*)p5.res1.p + (size_t)cur.n * p5.res1.n_stride);
+                const unsigned r1_cb = (unsigned)p5.res1.cb_stride;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int oy = cur.oy0 + wave * 2 + nt, ox = cur.ox0 + nn;
+                    const bool pv = (oy < p5.Hout) & (ox < p5.Wout);
+                    const unsigned pixel = (unsigned)(oy * p5.Wout + ox) * 16u;
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const int oc = mi * 32 + 8 * gq + 4 * kh2;
+                            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rr1, pv ? ((unsigned)(oc >> 4) * r1_cb + pixel + (unsigned)(oc & 15)) * 4u : OOB, 0, 0);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) A5[mi][nt][4 * gq + e] = __uint_as_float(t[e]);
+                        }
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) A0[0][nt][e] = 0.f, A1[0][nt][e] = 0.f, A2[0][nt][e] = 0.f, A3[0][nt][e] = 0.f;
+
+            bool arr_issued = false;     // the group awaited in the current window has been requested
+            int mark_act = 0;            // `issued` behind that request
+            bool next_x_issued = false;
+
+            auto request_group = [&](int c0) {   // chunks c0, c0 + 1 of this item's slab
+                issued += is_dma_act(rin, smem + (c0 & 3) * C::ACT_SLOT, cur.goff, (unsigned)c0 * icb, wave, tid);
+                issued += is_dma_act(rin, smem + ((c0 + 1) & 3) * C::ACT_SLOT, cur.goff, (unsigned)(c0 + 1) * icb, wave, tid);
+                arr_issued = true;
+                mark_act = issued;
+            };
+            auto request_next_x = [&](const ISGeo& nxt) {
+                const dasr_conv_params& pn = layers[L0n];
+                const __amdgpu_buffer_rsrc_t rinn = make_rsrc((const bf16_t*)pn.in.p + (size_t)nxt.n * pn.in.n_stride);
+                const unsigned icbn = (unsigned)(pn.in.cb_stride * 2);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) issued += is_dma_act(rinn, smem + c * C::ACT_SLOT, nxt.goff, (unsigned)c * icbn, wave, tid);
+                mark_x = issued;
+                next_x_issued = true;
+            };
+
+            auto do_step = [&](auto tc) {
+                constexpr int TT = decltype(tc)::value;
+                constexpr ISStep d = IS_PROG[TT];
+                constexpr int GK = is_group_of_step(TT);            // group awaited during this step (0: none)
+                constexpr bool MUST = GK >= 1 && GK <= 4 && TT + 1 == IS_WIN1[GK];   // the group is read in the next step
+                const char* abuf = smem + (d.c & 3) * C::ACT_SLOT;
+                const char* wbuf = smem + C::W_OFF + (g & 3) * C::WGRAN;
+                char* wnext = smem + C::W_OFF + ((g + 3) & 3) * C::WGRAN;
+                if constexpr (GK != 0 && TT == IS_WIN0[GK > 0 ? GK : 1]) arr_issued = false;
+                // ---- what this step requests besides its MFMAs
+                bool act_now = false, poll_now = false;
+                unsigned target = 0;
+                if constexpr (GK >= 1 && GK <= 4) {
+                    target = cur.f0 + (unsigned)(L0 + GK);
+                    if (!arr_issued) {
+                        if (poll_ready(cur, target)) act_now = true;
+                        else poll_now = !pub_on;   // (our own flag is one of the nine: nothing to see before it is out)
+                    }
+                } else if constexpr (GK == 5) {
+                    if (has_next && rn > 0) {   // (block 0 reads what an earlier kernel wrote)
+                        const ISGeo nq = geo_of(sn);
+                        poll_now = !poll_ready(nq, nq.f0 + (unsigned)L0n);
+                    }
+                }
+                int poll_mark = 0;
+                auto mid = [&](int s) {
+                    if (s == 0) {
+                        if (poll_now && wave == 0) {
+                            if constexpr (GK == 5) {
+                                const ISGeo nq = geo_of(sn);
+                                if (lane < 9) is_dma_poll(rflags, smem + C::POLL_OFF + nq.slot * 64, nq.nbo);
+                            } else {
+                                if (lane < 9) is_dma_poll(rflags, smem + C::POLL_OFF + cur.slot * 64, cur.nbo);
+                            }
+                            ++issued;
+                            poll_mark = issued;
+                        }
+                        if (g + 3 < total_steps) {   // weights of step g + 3
+                            constexpr int T3 = (TT + 3) % C::NSTEP;
+                            constexpr ISStep e = IS_PROG[T3];
+                            constexpr bool NX = TT + 3 >= C::NSTEP;
+                            if constexpr (e.kind == 5) {
+                                issued += is_dma_w(make_rsrc(wptr(4, NX)), wnext, (unsigned)e.c * 18432u, 1152, wave, tid);
+                            } else {
+                                issued += is_dma_w(make_rsrc(wptr(e.u0, NX)), wnext, (unsigned)e.c * 9216u, 576, wave, tid);
+                                if constexpr (e.kind == 2) issued += is_dma_w(make_rsrc(wptr(e.u1, NX)), wnext + 9216, (unsigned)e.c * 9216u, 576, wave, tid);
+                            }
+                        }
+                    }
+                    if (s == 2) {
+                        if constexpr (GK >= 1 && GK <= 4) {
+                            if (act_now) request_group(4 + 2 * (GK - 1));
+                        }
+                    }
+                };
+                const unsigned long long t0 = IS_T();
+                if constexpr (d.kind == 1) {
+                    if constexpr (d.u0 == 0) is_body<1, 1024, 0, F16>(A0[0], A0[0], abuf, wbuf, baddr, aoff, mid);
+                    else if constexpr (d.u0 == 1) is_body<1, 1024, 0, F16>(A1[0], A1[0], abuf, wbuf, baddr, aoff, mid);
+                    else if constexpr (d.u0 == 2) is_body<1, 1024, 0, F16>(A2[0], A2[0], abuf, wbuf, baddr, aoff, mid);
+                    else is_body<1, 1024, 0, F16>(A3[0], A3[0], abuf, wbuf, baddr, aoff, mid);
+                } else if constexpr (d.kind == 2) {
+                    if constexpr (d.u0 == 1) is_body<2, 1024, 9216, F16>(A1[0], A2[0], abuf, wbuf, baddr, aoff, mid);
+                    else is_body<2, 1024, 9216, F16>(A2[0], A3[0], abuf, wbuf, baddr, aoff, mid);
+                    static_assert(d.kind != 2 || (d.u0 == 1 && d.u1 == 2) || (d.u0 == 2 && d.u1 == 3), "pairs of the program");
+                } else {
+                    is_body<2, 2048, 1024, F16>(A5[0], A5[1], abuf, wbuf, baddr, aoff, mid);
+                }
+                const unsigned long long t1 = IS_T();
+                // ---- end of the step: everything requested up to the end of step g - 2 has landed (the granule of step g + 1 among it); flag words / publish / group as due
+                int nwait = issued - mk0;
+                if (poll_now && wave == 0) nwait = min(nwait, issued - poll_mark);
+                bool do_pub = false;
+                if (pub_on && g >= pub_due) do_pub = true, nwait = min(nwait, issued - pub_mark);
+                if constexpr (MUST) {
+                    if (arr_issued) nwait = min(nwait, issued - mark_act);
+                }
+                is_wait_vm(nwait);
+                __builtin_amdgcn_s_barrier();
+                if (do_pub) flag_store();
+                mk0 = mk1, mk1 = issued;
+                ++g;
+                const unsigned long long t2 = IS_T();
+                IS_ACC(d.kind == 1 ? 0 : 1, t1 - t0);
+                IS_ACC(2, t2 - t1);
+                IS_ACC(d.kind == 1 ? 8 : 9, 1ull);
+                if constexpr (MUST) {
+                    if (!arr_issued) {   // not there where it is needed: spin, then request and wait for it
+                        block_until(cur, target);
+                        request_group(4 + 2 * (GK - 1));
+                        const unsigned long long t3 = IS_T();
+                        __builtin_amdgcn_s_waitcnt(0x0F70);
+                        __builtin_amdgcn_s_barrier();
+                        IS_ACC(3, IS_T() - t3);
+                    }
+                }
+                // ---- epilogue of the conv this step completed
+                constexpr int EU = is_epi_after(TT);
+                if constexpr (EU == 0) {   // conv5's accumulators: (beta1 / alpha) * x (see above)
+                    const unsigned long long t3 = IS_T();
+                    const float c1 = p5.beta1 / p5.alpha;
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            A5[mi][nt] *= c1;
+                            asm volatile("" : "+v"(A5[mi][nt]));   // (here, not sunk behind the next step's DMA requests: the wait for the residual would drain them)
+                        }
+                    IS_ACC(7, IS_T() - t3);
+                }
+                if constexpr (EU >= 0) {
+                    const unsigned long long t4 = IS_T();
+                    const dasr_conv_params& p = layers[L0 + EU];
+                    char* bl = smem + C::BIAS_OFF + par * 1280 + EU * 256;
+                    if constexpr (EU == 4) {
+                        if (has_next) {   // x of the next item (+ its biases) goes out in front of the conv5 epilogue when its neighbours are there already (the usual case: another tile's
+                                          // block, finished an item ago); else behind it (a workgroup with one tile waits for its own conv5 there)
+                            const ISGeo nq = geo_of(sn);
+                            if (rn == 0 || poll_ready(nq, nq.f0 + (unsigned)L0n)) request_next_x(nq);
+                            if (!BWD && wave < 5) {
+                                const dasr_conv_params& pb = layers[L0n + wave];
+                                is_dma_bias(make_rsrc(pb.bias), smem + C::BIAS_OFF + (par ^ 1) * 1280 + wave * 256, (pb.bias != nullptr && lane < 32 * pb.mt) ? (unsigned)lane * 4u : OOB);
+                                ++issued;
+                            }
+                        }
+                        const bool two = p.res2.p != nullptr, sh = p.out_bf16.p != nullptr;
+                        constexpr int E0 = BWD ? 160 : 161;   // alpha, fp32 out (+ bias forward); + 16 second residual, + 64 the 16-bit shadow
+                        if (two && sh) conv_epilogue<false, 2, 2, 1, E0 + 80, F16 ? 1 : 0, false, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                        else if (sh) conv_epilogue<false, 2, 2, 1, E0 + 64, F16 ? 1 : 0, false, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                        else if (two) conv_epilogue<false, 2, 2, 1, E0 + 16, F16 ? 1 : 0, false, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                        else conv_epilogue<false, 2, 2, 1, E0, F16 ? 1 : 0, false, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                    } else if constexpr (EU == 0) {
+                        conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true>(p, A0, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                    } else if constexpr (EU == 1) {
+                        conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true>(p, A1, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                    } else if constexpr (EU == 2) {
+                        conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true>(p, A2, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                    } else {
+                        conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true>(p, A3, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                    }
+                    // the flag of this conv: PUB_DELAY steps from now (an older one that is still pending goes out first)
+                    flush_pub();
+                    pub_on = true, pub_mark = issued, pub_due = g + C::PUB_DELAY - 1;
+                    pub_off = cur.selfo, pub_val = cur.f0 + (unsigned)(L0 + EU + 1);
+                    IS_ACC(EU == 4 ? 6 : 5, IS_T() - t4);
+                }
+            };
+            // the 34 steps, unrolled at compile time
+            auto run = [&](auto self, auto tc) -> void {
+                constexpr int TT = decltype(tc)::value;
+                if constexpr (TT < C::NSTEP) {
+                    do_step(tc);
+                    self(self, ISInt<TT + 1>{});
+                }
+            };
+            run(run, ISInt<0>{});
+            IS_ACC(10, 1ull);
+            {
+                const ISGeo nxt = geo_of(sn);
+                if (has_next && !next_x_issued) {   // the next item's neighbours were not there in front of the conv5 epilogue: wait for them now
+                    block_until(nxt, nxt.f0 + (unsigned)L0n);
+                    request_next_x(nxt);
+                }
+                cur = nxt;
+            }
+        }
+    }
+    flush_pub();
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+}
+
+template <bool F16, bool BWD>
+int launch_rdb_is(const dasr_conv_params* dev_layers, int nrdb, int tiles_y, int tiles_x, int tpw, unsigned* flags, unsigned* tickets, int* err, hipStream_t s, const char* name) {
+    static bool attr_set = false;
+    auto kfn = rdb_is_kernel<F16, BWD>;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, ISC::LDS_BYTES));
+        attr_set = true;
+    }
+    DASR_LAUNCH_TAG(name, kfn, dim3(256), dim3(ISC::NTH), ISC::LDS_BYTES, s, dev_layers, nrdb, tiles_y, tiles_x, tpw, flags, tickets, err);
+    return (int)hipGetLastError();
+}

@@ -329,8 +329,10 @@ class ConvChain:
     dep_chunks[i]: first 16-channel input chunk of layer i that holds layer i - 1's output (<= 0: all of them).  flags / err: shared per (N, h, w)
     plan -- the flag words count stages monotonically across launches, err stays zero unless a launch went wrong (check())."""
 
-    def __init__(self, ops, dep_chunks, n_images, n_tiles, device, flags=None, err=None):
+    def __init__(self, ops, dep_chunks, n_images, n_tiles, device, flags=None, err=None, form='layer'):
         assert len(ops) == len(dep_chunks) and ops
+        assert form in ('layer', 'is')   # 'is': the input-stationary launch (dasr_rdb_chain): whole dense blocks, five layers each
+        self.form = form
         n = len(ops)
         self.host = (_lib.ConvParams * n)(*[o.conv for o in ops])
         raw = torch.frombuffer(bytearray(bytes(self.host)), dtype=torch.uint8)
@@ -343,7 +345,7 @@ class ConvChain:
 
     def op(self):
         o = Op()
-        o.op = _lib.OP_CONV_CHAIN
+        o.op = _lib.OP_RDB_CHAIN if self.form == 'is' else _lib.OP_CONV_CHAIN
         o.p[0], o.p[1], o.p[2], o.p[3] = self.dev.data_ptr(), C.cast(self.host, C.c_void_p).value, self.dep.data_ptr(), self.flags.data_ptr()
         o.l[0], o.i[0] = self.err.data_ptr(), self.n
         o.flops = self.flops

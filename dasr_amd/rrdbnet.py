@@ -58,6 +58,10 @@ class RRDBNetHIP:
         # DASR_CHAIN (default 1): the trunk's dense-block convs, forward and data gradient, as persistent chained launches where the batch fills the chip
         # exactly (chain_ok; _Plan._build_forward).  bf16 storage only: the f16 path re-patches scale factors of recorded ops (TrunkStore.set_gscale_from)
         self.chain = os.environ.get('DASR_CHAIN', '1') == '1' and not self.rdb_f16
+        # DASR_CHAIN_FORM: 'is' (round 6) = the chained launches in their input-stationary form (dasr_rdb_chain: every slab chunk staged once per dense block,
+        # one 8-wave workgroup per CU owning N * tiles / 256 tiles); 'layer' = round 4's layer-by-layer form (dasr_conv_chain, exactly 512 tiles per launch)
+        self.chain_form = os.environ.get('DASR_CHAIN_FORM', 'layer')
+        assert self.chain_form in ('is', 'layer')
         # ONE error word for every chained launch of this network (all plans): non-zero = a neighbour wait gave up, the step's results are not valid.
         # The optimisers that depend on this generator take it as their gate (AdamHIP(gate=...): such a step never reaches the weights); the trainers
         # read it where they synchronise anyway (log interval, checkpoints) and raise (check_chain).
@@ -166,10 +170,15 @@ class RRDBNetHIP:
         (Round 5 also built a form whose workgroups own several tiles -- one launch over 1024 tiles: bit-identical, but 88 ms per GAN step against 72 ms
         with one launch per conv; it lives in the -DDASR_BENCH library only, profiles/r05_chain_trace.txt.)"""
         ntiles = N * ceil_div(h, 16) * ceil_div(w, 32)
-        k = ntiles // 512
-        kmax = int(os.environ.get('DASR_CHAIN_SPLIT', '4'))   # DASR_CHAIN_SPLIT=1: exact fit only (A/B)
-        if not (self.chain and k >= 1 and k <= kmax and ntiles == 512 * k and N % k == 0 and (N // k) % 8 == 0 and not getattr(self, 'debug_taps', ())):
-            return 0
+        if self.chain_form == 'is':   # one launch: whole images per XCD, every one of the 256 workgroups owns ntiles / 256 (<= 8) tiles; 64 + 4 x 32 channel slabs
+            if not (self.chain and N % 8 == 0 and ntiles % 256 == 0 and 1 <= ntiles // 256 <= 8 and self.nf == 64 and not getattr(self, 'debug_taps', ())):
+                return 0
+            k = 1
+        else:
+            k = ntiles // 512
+            kmax = int(os.environ.get('DASR_CHAIN_SPLIT', '4'))   # DASR_CHAIN_SPLIT=1: exact fit only (A/B)
+            if not (self.chain and k >= 1 and k <= kmax and ntiles == 512 * k and N % k == 0 and (N // k) % 8 == 0 and not getattr(self, 'debug_taps', ())):
+                return 0
         from . import dist as _dist
         if _dist.SHARED_DEVICE:   # another rank of this job runs on the same GPU (gloo test set-up): the launch would not have the chip to itself
             return 0
@@ -563,15 +572,21 @@ class _Plan:
             assert len(body) == len(trunk_ops.ops) == 15 * nb
             deps = [0 if k % 5 == 0 else (o.conv.cin // 16) - GC // 16 for k, o in enumerate(body)]
             per = N // nsub
-            self.chains = []   # (the last conv5 has no 16-bit shadow to write: its own launch, over the whole batch)
-            for sb in range(nsub):
-                sub = body[:-1] if nsub == 1 else [_sub_batch_conv(o, sb * per, per, N) for o in body[:-1]]
-                ch = ConvChain(sub, deps[:-1], per, tiles, net.device, err=net.chain_err)
+            self.chains = []   # (the last conv5 has no 16-bit shadow to write: its own launch, over the whole batch; the input-stationary form runs it too)
+            if net.chain_form == 'is':
+                ch = ConvChain(body, deps, N, tiles, net.device, err=net.chain_err, form='is')
                 self.chains.append(ch)
                 ops.add(ch.op())
                 ops.keep.append(ch)
+            else:
+                for sb in range(nsub):
+                    sub = body[:-1] if nsub == 1 else [_sub_batch_conv(o, sb * per, per, N) for o in body[:-1]]
+                    ch = ConvChain(sub, deps[:-1], per, tiles, net.device, err=net.chain_err)
+                    self.chains.append(ch)
+                    ops.add(ch.op())
+                    ops.keep.append(ch)
+                ops.add(body[-1])
             self.chain = self.chains[0]
-            ops.add(body[-1])
         self.x_last = X
         lrb = 'model.1.sub.%d.bias' % nb
         if net.hr_f16s:
@@ -850,14 +865,20 @@ class _Plan:
             per = N // nsub
             ops = main_ops
             self.chains_b = []   # (the last conv writes no 16-bit planes: its own launch)
-            for sb in range(nsub):
-                sub = body[:-1] if nsub == 1 else [_sub_batch_conv(o, sb * per, per, N) for o in body[:-1]]
-                ch = ConvChain(sub, deps[:-1], per, tiles, net.device, err=self.chain.err)
+            if net.chain_form == 'is':
+                ch = ConvChain(body, deps, N, tiles, net.device, err=self.chain.err, form='is')
                 self.chains_b.append(ch)
                 ops.add(ch.op())
                 ops.keep.append(ch)
+            else:
+                for sb in range(nsub):
+                    sub = body[:-1] if nsub == 1 else [_sub_batch_conv(o, sb * per, per, N) for o in body[:-1]]
+                    ch = ConvChain(sub, deps[:-1], per, tiles, net.device, err=self.chain.err)
+                    self.chains_b.append(ch)
+                    ops.add(ch.op())
+                    ops.keep.append(ch)
+                ops.add(body[-1])
             self.chain_b = self.chains_b[0]
-            ops.add(body[-1])
         ops.tag(4)
         rrdb0 = P.off('model.1.sub.0.RDB1.conv1.0.weight')
         if not self.shared_store:   # this plan owns the whole batch: the weight-gradient phase follows the chain in the same list
@@ -901,7 +922,7 @@ class _Plan:
         (The forward chain of the next step is safe by the same rule: the trainers wait for the communication stream -- dp.wait() -- in front of the
         optimiser step.)"""
         segs = self.bwd_segments()
-        has_chain = [any(o.op == _lib.OP_CONV_CHAIN for o in seg.ops) for seg, _ in segs]
+        has_chain = [any(o.op in (_lib.OP_CONV_CHAIN, _lib.OP_RDB_CHAIN) for o in seg.ops) for seg, _ in segs]
         held = []
         for k, (seg, (lo, hi)) in enumerate(segs):
             seg.run()

@@ -101,6 +101,17 @@ int dasr_conv(const dasr_conv_params* p, void* stream);
  * dev_layers / dev_dep_chunk: device copies the kernel reads; host_layers: the same blocks in host memory (validated by the launcher). */
 int dasr_conv_chain(const dasr_conv_params* dev_layers, const dasr_conv_params* host_layers, const int32_t* dev_dep_chunk, int32_t nlayers,
                     uint32_t* dev_flags, int32_t* dev_err, void* stream);
+/* The same chain, INPUT-STATIONARY form (round 6; replaces ResidualDenseBlock_5C.forward, codes/SRN/models/modules/block.py:280-286, and its data
+ * gradient, for the whole trunk of RRDBNet, architecture.py:174-205, in one launch).  layers[5 b + k], k = 0..4, are the five convs of dense block b
+ * exactly as dasr_conv would run them (cin = 64 + 32 k on ONE slab, cout 32 / 32 / 32 / 32 / 64; forward: bias + LeakyReLU -> 16-bit planes, conv5 bias,
+ * alpha, one or two fp32 residuals -> fp32 stream (+ 16-bit planes of the next slab, may be absent on the last block); data gradient: LeakyReLU' mask ->
+ * 16-bit planes, alpha, residuals -> fp32 (+ 16-bit)) -- bit-identical results -- but every 16-channel chunk of the slab is staged in LDS ONCE and
+ * multiplied into the accumulators of every conv of the block that consumes it (12 chunks per block and tile instead of 40), one workgroup of 8 waves per
+ * CU, each owning N * tiles / 256 tiles of 16 x 32 pixels (csrc/rdb_is.h).  Constraints (DASR_EINVAL otherwise): bf16 storage, nlayers a multiple of 5,
+ * N a multiple of 8 (whole images per XCD), N * tiles a multiple of 256 and at most 2048.  flags / err / operational contract: as dasr_conv_chain (the
+ * launch needs all 256 CUs of the device to itself: 256 workgroups with 160 KB of LDS each, all resident). */
+int dasr_rdb_chain(const dasr_conv_params* dev_layers, const dasr_conv_params* host_layers, int32_t nlayers, uint32_t* dev_flags, int32_t* dev_err,
+                   void* stream);
 /* kernel-variant knobs for A/B runs (bench.py --sweep / --tune); defaults are the tuned choice.
  * key 1 / 2: dense-block conv with Cout = 32 / 64: 12 = LDS-DMA kernel (default for Cout 32), 13 = its 8-wave 32x32-tile form (Cout 64 default: chosen per launch when the 4-wave grid has <= 256 workgroups), 0 = first-generation register-staged kernel,
  *            1 double-buffered LDS, 4/5 8x32 tiles, 6 4x32 tiles, 8/9 row reuse, 10/11 register-staged pipeline;
@@ -415,7 +426,8 @@ enum { DASR_OP_CONV = 1, DASR_OP_WGRAD = 2, DASR_OP_WGRAD_REDUCE = 3, DASR_OP_PA
        DASR_OP_BNORM_FWD = 40, DASR_OP_BNORM_BWD = 41, DASR_OP_BNORM_RUNNING = 42, DASR_OP_DDM_SPREAD = 43,
        /* --wgan gradient penalty (round 4) */
        DASR_OP_INORM_JVP = 44, DASR_OP_INORM_SECOND = 45, DASR_OP_GRAD_PENALTY = 46, DASR_OP_FILL_SCALED = 47,
-       DASR_OP_CONV_CHAIN = 48   /* p[0] device layers, p[1] host layers, p[2] device dep_chunk, i[0] nlayers, p[3] device flags; l[0] device err word */ };
+       DASR_OP_CONV_CHAIN = 48,  /* p[0] device layers, p[1] host layers, p[2] device dep_chunk, i[0] nlayers, p[3] device flags; l[0] device err word */
+       DASR_OP_RDB_CHAIN = 49    /* dasr_rdb_chain: p[0] device layers, p[1] host layers, i[0] nlayers, p[3] device flags; l[0] device err word */ };
 
 typedef struct {
     int32_t op;  int32_t i[8];  float f[4];  int64_t l[4];  void* p[4];  dasr_tensor t[5];
