@@ -2354,7 +2354,9 @@ extern "C" int dasr_rdb_chain(const dasr_conv_params* dev_layers, const dasr_con
     }
     const int tiles_x = (p0.Wout + ISC::TW - 1) / ISC::TW, tiles_y = (p0.Hout + ISC::TH - 1) / ISC::TH;
     const long long ntiles = (long long)tiles_x * tiles_y * p0.N;
-    if ((p0.N & 7) || ntiles < 256 || ntiles % 256 || ntiles / 256 > ISC::MAX_TPW) return DASR_EINVAL;   // whole images per XCD; one workgroup per CU, every one owns ntiles / 256 tiles
+    // whole images per XCD; one workgroup per CU, every one owns ntiles / 256 tiles -- and every tile of an image must be worked on AT THE SAME TIME (a tile waits for its
+    // neighbours inside a dense block): the 32 workgroups of an XCD hold whole images, i.e. tiles per image divides 32
+    if ((p0.N & 7) || ntiles < 256 || ntiles % 256 || ntiles / 256 > ISC::MAX_TPW || 32 % (tiles_x * tiles_y)) return DASR_EINVAL;
     {
         static int n_cu = -1;
         if (n_cu < 0) {

@@ -40,6 +40,7 @@ struct ISC {
     static constexpr int POLL_OFF = X_OFF + 2560;            // [MAX_TPW][16 words]: the newest flag values seen of a tile's nine (self + 8 neighbours) words
     static constexpr int MAX_TPW = 8;
     static constexpr int F0_OFF = POLL_OFF + MAX_TPW * 64;   // f0[MAX_TPW], ticket
+    static constexpr int DEC_OFF = F0_OFF + 64;              // decision words [2 step parities][2]: {target reached ? target : target - 1, tile slot}, written by wave 0
     static constexpr int LDS_BYTES = 163840;
     static constexpr int NSTEP = 34;
     static constexpr int PUB_DELAY = IS_PUB_DELAY;           // a conv's flag goes out at the end of the PUB_DELAY-th step behind its epilogue (its stores have that long to be acknowledged)
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
     }
     __syncthreads();
     if (tid < tpw * 16) ((int*)(smem + C::POLL_OFF))[tid] = xi[tid >> 4];   // "newest value seen" of every polled word: a lower bound of the truth at all times
+    if (tid < 4) ((unsigned*)(smem + C::DEC_OFF))[tid] = 0xffffffffu;
     CH_WHERE(j, xcc);
     const int Hin = layers[0].Hin, Win = layers[0].Win;
     __syncthreads();
@@ -268,11 +270,6 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
             __builtin_amdgcn_s_barrier();
             flag_store();
         }
-    };
-    // the nine words of tile q have reached `target` (newest values seen, in LDS)
-    auto poll_ready = [&](const ISGeo& q, unsigned target) -> bool {
-        const unsigned v = ((const unsigned*)(smem + C::POLL_OFF))[q.slot * 16 + (lane < 9 ? lane : 0)];
-        return __builtin_amdgcn_ballot_w64((int)(v - target) < 0) == 0ull;
     };
     // spin until they have (a group is not there where it is needed): the only place where the matrix pipe waits for a neighbour
     auto block_until = [&](const ISGeo& q, unsigned target) {
@@ -376,7 +373,8 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
 
             bool arr_issued = false;     // the group awaited in the current window has been requested
             int mark_act = 0;            // `issued` behind that request
-            bool next_x_issued = false;
+            bool next_x_issued = false, next_rdy = false;
+            const unsigned f0n = (unsigned)__builtin_amdgcn_readfirstlane(xi[sn]);
 
             auto request_group = [&](int c0) {   // chunks c0, c0 + 1 of this item's slab
                 issued += is_dma_act(rin, smem + (c0 & 3) * C::ACT_SLOT, cur.goff, (unsigned)c0 * icb, wave, tid);
@@ -403,19 +401,27 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                 const char* wbuf = smem + C::W_OFF + (g & 3) * C::WGRAN;
                 char* wnext = smem + C::W_OFF + ((g + 3) & 3) * C::WGRAN;
                 if constexpr (GK != 0 && TT == IS_WIN0[GK > 0 ? GK : 1]) arr_issued = false;
-                // ---- what this step requests besides its MFMAs
+                // ---- what this step requests besides its MFMAs.  Whether a group's nine flag words have reached their target is decided by WAVE 0 ALONE (at the end of
+                // the step in which it polled, from the words its LDS-DMA brought) and handed to the other waves through a decision word in LDS across the step's
+                // barrier: every wave takes the same branch (a wave reading the polled words itself could see a newer poll than its neighbours)
                 bool act_now = false, poll_now = false;
                 unsigned target = 0;
+                int pslot = 0;
+                auto decided = [&]() -> bool {   // wave 0's decision of the previous step: this (target, tile)?
+                    const unsigned* dw = (const unsigned*)(smem + C::DEC_OFF) + ((g - 1) & 1) * 2;
+                    return __builtin_amdgcn_readfirstlane(dw[0]) == target && __builtin_amdgcn_readfirstlane(dw[1]) == (unsigned)pslot;
+                };
                 if constexpr (GK >= 1 && GK <= 4) {
-                    target = cur.f0 + (unsigned)(L0 + GK);
+                    target = cur.f0 + (unsigned)(L0 + GK), pslot = cur.slot;
                     if (!arr_issued) {
-                        if (poll_ready(cur, target)) act_now = true;
+                        if (decided()) act_now = true;
                         else poll_now = !pub_on;   // (our own flag is one of the nine: nothing to see before it is out)
                     }
                 } else if constexpr (GK == 5) {
-                    if (has_next && rn > 0) {   // (block 0 reads what an earlier kernel wrote)
-                        const ISGeo nq = geo_of(sn);
-                        poll_now = !poll_ready(nq, nq.f0 + (unsigned)L0n);
+                    if (has_next && rn > 0 && !next_rdy) {   // (block 0 reads what an earlier kernel wrote)
+                        target = f0n + (unsigned)L0n, pslot = sn;
+                        if (decided()) next_rdy = true;
+                        else poll_now = true;
                     }
                 }
                 int poll_mark = 0;
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                         if (poll_now && wave == 0) {
                             if constexpr (GK == 5) {
                                 const ISGeo nq = geo_of(sn);
-                                if (lane < 9) is_dma_poll(rflags, smem + C::POLL_OFF + nq.slot * 64, nq.nbo);
+                                if (lane < 9) is_dma_poll(rflags, smem + C::POLL_OFF + sn * 64, nq.nbo);
                             } else {
                                 if (lane < 9) is_dma_poll(rflags, smem + C::POLL_OFF + cur.slot * 64, cur.nbo);
                             }
@@ -472,6 +478,12 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                     if (arr_issued) nwait = min(nwait, issued - mark_act);
                 }
                 is_wait_vm(nwait);
+                if (poll_now && wave == 0) {   // the polled words have landed: decide for everybody
+                    const unsigned v = ((const unsigned*)(smem + C::POLL_OFF))[pslot * 16 + (lane < 9 ? lane : 0)];
+                    const bool rdy = __builtin_amdgcn_ballot_w64((int)(v - target) < 0) == 0ull;
+                    if (lane < 2) ((unsigned*)(smem + C::DEC_OFF))[(g & 1) * 2 + lane] = lane == 0 ? (rdy ? target : target - 1u) : (unsigned)pslot;
+                    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the decision is in LDS before the barrier
+                }
                 __builtin_amdgcn_s_barrier();
                 if (do_pub) flag_store();
                 mk0 = mk1, mk1 = issued;
@@ -511,8 +523,11 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                     if constexpr (EU == 4) {
                         if (has_next) {   // x of the next item (+ its biases) goes out in front of the conv5 epilogue when its neighbours are there already (the usual case: another tile's
                                           // block, finished an item ago); else behind it (a workgroup with one tile waits for its own conv5 there)
-                            const ISGeo nq = geo_of(sn);
-                            if (rn == 0 || poll_ready(nq, nq.f0 + (unsigned)L0n)) request_next_x(nq);
+                            if (rn > 0 && !next_rdy) {   // (wave 0's decision at the end of this step)
+                                const unsigned* dw = (const unsigned*)(smem + C::DEC_OFF) + ((g - 1) & 1) * 2;
+                                next_rdy = __builtin_amdgcn_readfirstlane(dw[0]) == f0n + (unsigned)L0n && __builtin_amdgcn_readfirstlane(dw[1]) == (unsigned)sn;
+                            }
+                            if (rn == 0 || next_rdy) request_next_x(geo_of(sn));
                             if (!BWD && wave < 5) {
                                 const dasr_conv_params& pb = layers[L0n + wave];
                                 is_dma_bias(make_rsrc(pb.bias), smem + C::BIAS_OFF + (par ^ 1) * 1280 + wave * 256, (pb.bias != nullptr && lane < 32 * pb.mt) ? (unsigned)lane * 4u : OOB);

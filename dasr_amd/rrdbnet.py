@@ -170,8 +170,10 @@ class RRDBNetHIP:
         (Round 5 also built a form whose workgroups own several tiles -- one launch over 1024 tiles: bit-identical, but 88 ms per GAN step against 72 ms
         with one launch per conv; it lives in the -DDASR_BENCH library only, profiles/r05_chain_trace.txt.)"""
         ntiles = N * ceil_div(h, 16) * ceil_div(w, 32)
-        if self.chain_form == 'is':   # one launch: whole images per XCD, every one of the 256 workgroups owns ntiles / 256 (<= 8) tiles; 64 + 4 x 32 channel slabs
-            if not (self.chain and N % 8 == 0 and ntiles % 256 == 0 and 1 <= ntiles // 256 <= 8 and self.nf == 64 and not getattr(self, 'debug_taps', ())):
+        if self.chain_form == 'is':   # one launch: whole images per XCD, every one of the 256 workgroups owns ntiles / 256 (<= 8) tiles; 64 + 4 x 32 channel slabs;
+            # all tiles of an image in flight at once (32 workgroups per XCD): tiles per image divides 32
+            tpi = ceil_div(h, 16) * ceil_div(w, 32)
+            if not (self.chain and N % 8 == 0 and ntiles % 256 == 0 and 1 <= ntiles // 256 <= 8 and 32 % tpi == 0 and self.nf == 64 and not getattr(self, 'debug_taps', ())):
                 return 0
             k = 1
         else:

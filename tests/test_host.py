@@ -420,11 +420,16 @@ def test_chain_split_rule():
     """RRDBNetHIP.chain_split: which batches run their trunk as chained launches, and as how many image sub-batches (host rule; a whole 256-CU device assumed)"""
     from types import SimpleNamespace as NS
     from dasr_amd.rrdbnet import RRDBNetHIP
-    net = NS(chain=True, _cus=256)
+    net = NS(chain=True, _cus=256, chain_form='layer', nf=64)
     f = lambda N, h, w: RRDBNetHIP.chain_split(net, N, h, w)
     assert (f(16, 128, 128), f(8, 256, 128), f(32, 64, 128), f(32, 128, 128), f(24, 128, 256), f(64, 128, 128)) == (1, 1, 1, 2, 3, 4)
     assert (f(16, 64, 64), f(12, 128, 128), f(20, 128, 128), f(24, 128, 128), f(80, 128, 128), f(4, 256, 256)) == (0, 0, 0, 0, 0, 0)   # too few / not 512 k / images per XCD / > 4
-    assert RRDBNetHIP.chain_split(NS(chain=False, _cus=256), 16, 128, 128) == 0 and RRDBNetHIP.chain_split(NS(chain=True, _cus=64), 16, 128, 128) == 0
+    assert RRDBNetHIP.chain_split(NS(chain=False, _cus=256, chain_form='layer'), 16, 128, 128) == 0 and RRDBNetHIP.chain_split(NS(chain=True, _cus=64, chain_form='layer'), 16, 128, 128) == 0
+    # the input-stationary form (round 6, dasr_rdb_chain): one launch; whole images per XCD, N * tiles a multiple of 256 (<= 8 tiles per workgroup), tiles per image divides 32
+    net = NS(chain=True, _cus=256, chain_form='is', nf=64)
+    assert (f(16, 128, 128), f(8, 128, 128), f(32, 128, 128), f(64, 128, 128), f(16, 64, 128), f(64, 64, 64), f(8, 128, 112)) == (1, 1, 1, 1, 1, 1, 1)
+    assert (f(8, 256, 128), f(24, 128, 256), f(12, 128, 128), f(16, 64, 64), f(4, 256, 256), f(128, 128, 128), f(16, 32, 32)) == (0, 0, 0, 0, 0, 0, 0)   # 64 tiles per image / ... / > 8 per workgroup / < 256 tiles
+    assert RRDBNetHIP.chain_split(NS(chain=True, _cus=256, chain_form='is', nf=32), 16, 128, 128) == 0
 
 
 def test_crc32c_fast_path_equals_the_byte_loop():
