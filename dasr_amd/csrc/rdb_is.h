@@ -346,8 +346,10 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
             }
             // conv5's accumulators start from (beta1 / alpha) * x in fp32 (R1_PRE of conv_glds_kernel: the MFMAs accumulate on top, the epilogue scales by alpha).
             // Requested here, scaled in front of conv1's epilogue (step 3): four steps for the round trip.
+            // (A conv5 WITHOUT a 16-bit shadow -- the last block of the trunk -- is one dasr_conv runs with its generic epilogue, alpha * acc + beta1 * x: same here.)
             const dasr_conv_params& p5 = layers[L0 + 4];
-            {
+            const bool r1pre = p5.out_bf16.p != nullptr;
+            if (r1pre) {
                 const __amdgpu_buffer_rsrc_t rr1 = make_rsrc((const float*)p5.res1.p + (size_t)cur.n * p5.res1.n_stride);
                 const unsigned r1_cb = (unsigned)p5.res1.cb_stride;
 #pragma unroll
@@ -365,6 +367,13 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                             for (int e = 0; e < 4; ++e) A5[mi][nt][4 * gq + e] = __uint_as_float(t[e]);
                         }
                 }
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) A5[mi][nt][e] = 0.f;
             }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
@@ -506,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                 constexpr int EU = is_epi_after(TT);
                 if constexpr (EU == 0) {   // conv5's accumulators: (beta1 / alpha) * x (see above)
                     const unsigned long long t3 = IS_T();
-                    const float c1 = p5.beta1 / p5.alpha;
+                    const float c1 = r1pre ? p5.beta1 / p5.alpha : 1.f;
 #pragma unroll
                     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -538,8 +547,8 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                         constexpr int E0 = BWD ? 160 : 161;   // alpha, fp32 out (+ bias forward); + 16 second residual, + 64 the 16-bit shadow
                         if (two && sh) conv_epilogue<false, 2, 2, 1, E0 + 80, F16 ? 1 : 0, false, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
                         else if (sh) conv_epilogue<false, 2, 2, 1, E0 + 64, F16 ? 1 : 0, false, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
-                        else if (two) conv_epilogue<false, 2, 2, 1, E0 + 16, F16 ? 1 : 0, false, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
-                        else conv_epilogue<false, 2, 2, 1, E0, F16 ? 1 : 0, false, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                        else if (two) conv_epilogue<false, 2, 2, 1, E0 + 8 + 16, F16 ? 1 : 0, false, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                        else conv_epilogue<false, 2, 2, 1, E0 + 8, F16 ? 1 : 0, false, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
                     } else if constexpr (EU == 0) {
                         conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true>(p, A0, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
                     } else if constexpr (EU == 1) {
