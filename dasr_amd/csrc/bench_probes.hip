@@ -221,3 +221,59 @@ extern "C" int dasr_probe_spin(int32_t blocks, int32_t micros, void* stream) {
     hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (long long)micros * 100);
     return (int)hipGetLastError();
 }
+
+// Store-path probe (round 6): `blocks` workgroups of 512 threads, each writes `kb` KiB of its own region with 16-byte-per-lane stores (1 KiB per wave
+// instruction, mode 0 plain / 1 sc1 write-through), `reps` times back to back with `gap` s_sleep(16) between the bursts; cycles of the burst
+// (issue of the first store to vmcnt(0) of the last) are summed per workgroup.  What a CU / an XCD / the chip sustains when every epilogue stores at once.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+static __global__ __launch_bounds__(512) void store_probe_kernel(char* buf0, int kb, int mode, int reps, int gap, unsigned long long* cyc) {
+    const bool roam = (mode & 4) != 0;   // mode & 4: every burst goes to a fresh region (reps regions of gridDim.x * kb KiB: past the 256 MB Infinity Cache)
+    char* buf = buf0;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int per_wave = kb / 8;   // KiB per wave = store instructions per wave
+    u32x4_t v = {(unsigned)tid, 1u, 2u, 3u};
+    unsigned long long total = 0;
+    // mode & 2: the address pattern of rdb_is_kernel's conv5 epilogue instead of a linear region (kb must be 192): workgroup b = tile (b % 32) of image b / 32 of a
+    // [N][4 planes][128][128][16] fp32 tensor followed by a [N][12 planes][128][128][16] 16-bit tensor; wave w owns rows 2w, 2w + 1 of the 16 x 32-pixel tile
+    const int img = blockIdx.x / 32, tile = blockIdx.x % 32, ty = tile / 4, tx = tile % 4;
+    const size_t nimg = (gridDim.x + 31) / 32;
+    for (int rep = 0; rep < reps; ++rep) {
+        __syncthreads();
+        if (roam) buf = buf0 + (size_t)rep * gridDim.x * kb * 1024;
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(buf + (size_t)blockIdx.x * kb * 1024), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)buf, 0, 0x7fffffff, 0x00020000);
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        if (mode & 2) {
+            for (int nt = 0; nt < 2; ++nt)
+                for (int pl = 0; pl < 4; ++pl) {
+                    const unsigned pix = (unsigned)((ty * 16 + wave * 2 + nt) * 128 + tx * 32);
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const unsigned off = (unsigned)(((size_t)(img * 4 + pl) * 16384 + pix + hf * 16) * 64) + lane * 16;
+                        if (mode & 1) __builtin_amdgcn_raw_buffer_store_b128(v, rt, off, 0, 16);
+                        else __builtin_amdgcn_raw_buffer_store_b128(v, rt, off, 0, 0);
+                    }
+                    const unsigned off2 = (unsigned)(nimg * 4 * 16384 * 64 + ((size_t)(img * 12 + pl) * 16384 + pix) * 32) + lane * 16;
+                    if (mode & 1) __builtin_amdgcn_raw_buffer_store_b128(v, rt, off2, 0, 16);
+                    else __builtin_amdgcn_raw_buffer_store_b128(v, rt, off2, 0, 0);
+                }
+        } else
+        for (int i = 0; i < per_wave; ++i) {
+            const unsigned off = (unsigned)((wave * per_wave + i) * 1024 + lane * 16);
+            if (mode & 1) __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16);
+            else __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        total += __builtin_readcyclecounter() - t0;
+        for (int g = 0; g < gap; ++g) __builtin_amdgcn_s_sleep(16);
+        v[1] += 1u;
+    }
+    if (tid == 0) cyc[blockIdx.x] = total;
+}
+
+extern "C" int dasr_probe_store(void* buf, int32_t blocks, int32_t kb, int32_t mode, int32_t reps, int32_t gap, unsigned long long* cyc_out, void* stream) {
+    if (!buf || blocks <= 0 || kb <= 0 || (kb & 7) || !cyc_out) return DASR_EINVAL;
+    hipLaunchKernelGGL(store_probe_kernel, dim3((unsigned)blocks), dim3(512), 0, as_stream(stream), (char*)buf, kb, mode, reps, gap, cyc_out);
+    HIP_TRY(hipGetLastError());
+    return (int)hipStreamSynchronize(as_stream(stream));
+}

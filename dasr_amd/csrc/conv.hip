@@ -105,6 +105,9 @@ __device__ __forceinline__ void mask_prefetch(const dasr_conv_params& p, MaskPre
 // the f32-tensor convs sc1 measured flat or worse (DSN iteration +10 %), so they keep plain stores (profiles/r03_conv_ablation.txt section 5)
 template <bool SC1>
 __device__ __forceinline__ void st128(u32x4 v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+#if defined(IS_ABL) && (IS_ABL & 32)   // (timing experiment: the epilogues' arithmetic without their stores -- out-of-range offsets are dropped by the hardware)
+    off |= OOB;
+#endif
     if constexpr (SC1) __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16);
     else __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
 }
@@ -113,7 +116,9 @@ __device__ __forceinline__ void st128(u32x4 v, __amdgpu_buffer_rsrc_t r, unsigne
 // kernels: the run-time form converted every element to BOTH formats and selected: 224 of the 628 VALU instructions of the Cout=32 epilogue)
 // BIAS_STAGED: the caller has already put the m-group's bias into LDS at `smem` and synchronised (conv_chain_kernel V2: staged in front of the last chunk
 // barrier of the main loop, in a region no DMA touches) -- no hand-over barrier here
-template <bool IN_F32, int MT, int NT, int STRIDE, int EPI, int F16OUT = -1, bool PRE = false, bool FSC1 = false, bool BIAS_STAGED = false>
+// CONST_SLOPE: the caller guarantees p.slope_ptr == nullptr (the chained launches validate it): without it hipcc turns `slope_ptr ? *slope_ptr : slope` into an
+// unconditional vector load from a selected address, and its `s_waitcnt vmcnt(0)` drains every LDS-DMA request in flight (rdb_is_kernel: the weights of the next three steps)
+template <bool IN_F32, int MT, int NT, int STRIDE, int EPI, int F16OUT = -1, bool PRE = false, bool FSC1 = false, bool BIAS_STAGED = false, bool CONST_SLOPE = false>
 __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 (&acc)[MT][NT], char* smem, float bias_reg, int tid, int mg, int n,
                                               int oy0, int ox0, const MaskPre<NT * MT>* pre = nullptr) {
     const int lane = tid & 63, wave = tid >> 6, nn = lane & 31, kh2 = lane >> 5;
@@ -136,7 +141,7 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
     const bool chan_tail = G ? true : false;          // cout not a multiple of 32 (specialised variants require it)
     const int ostr = p.out_stride > 1 ? p.out_stride : 1, owid = p.out_W > 0 ? p.out_W : p.Wout;  // strided sub-grid output (stride-2 dgrad)
     constexpr int MSZ = IN_F32 ? 4 : 2;
-    const float slope = p.slope_ptr ? *p.slope_ptr : p.slope;  // PReLU: the (learned) slope lives in the parameter buffer (round 5: also in the specialised variants)
+    const float slope = (!CONST_SLOPE && p.slope_ptr) ? *p.slope_ptr : p.slope;  // PReLU: the (learned) slope lives in the parameter buffer (round 5: also in the specialised variants)
     const __amdgpu_buffer_rsrc_t rmask = make_rsrc((const char*)p.mask.p + (size_t)n * p.mask.n_stride * MSZ);
     const __amdgpu_buffer_rsrc_t rr1 = make_rsrc((const char*)p.res1.p + (size_t)n * p.res1.n_stride * ((G && p.res1_lo) ? 2 : 4));
     const __amdgpu_buffer_rsrc_t rr2 = make_rsrc((const float*)p.res2.p + (size_t)n * p.res2.n_stride);
@@ -144,7 +149,11 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
     const __amdgpu_buffer_rsrc_t rob = make_rsrc((bf16_t*)p.out_bf16.p + (size_t)n * p.out_bf16.n_stride);
     const unsigned mask_cb = (unsigned)p.mask.cb_stride, r1_cb = (unsigned)p.res1.cb_stride, r2_cb = (unsigned)p.res2.cb_stride;
     const unsigned of_cb = (unsigned)p.out_f32.cb_stride, ob_cb = (unsigned)p.out_bf16.cb_stride;
+#ifdef IS_PLAIN_ST   // (timing experiment of round 6: what do the write-through stores of the chained epilogues cost?)
+    constexpr bool SC1 = !FSC1 && (MT == 1 && !IN_F32 && F16OUT == 0);
+#else
     constexpr bool SC1 = FSC1 || (MT == 1 && !IN_F32 && F16OUT == 0);   // bf16 dense-block convs with Cout = 32 (st128); FSC1: every store of a chained layer (conv_chain_kernel)
+#endif
     // split 16-bit output: the remainder goes lo_pl planes further (wave-uniform; 0 = plain).  The specialised bf16 epilogues (dense blocks) do not
     // carry the branch: classify_epi sends a bf16 split output to the generic epilogue
     const unsigned lo_pl = (G || F16OUT != 0) ? (unsigned)p.out16_lo : 0u;
@@ -292,7 +301,7 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[g][j] += bia[mi][g][j];
             }
-            if (act_lrelu && !G && p.slope_ptr) {   // specialised variants with a learned PReLU slope (any sign / size): select, three VALU ops per element
+            if (act_lrelu && !G && !CONST_SLOPE && p.slope_ptr) {   // specialised variants with a learned PReLU slope (any sign / size): select, three VALU ops per element
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -394,8 +403,13 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                     u32x4 oa = {__float_as_uint(v[2 * pr][0]), __float_as_uint(v[2 * pr][1]), __float_as_uint(v[2 * pr][2]), __float_as_uint(v[2 * pr][3])};
                     u32x4 ob = {__float_as_uint(v[2 * pr + 1][0]), __float_as_uint(v[2 * pr + 1][1]), __float_as_uint(v[2 * pr + 1][2]), __float_as_uint(v[2 * pr + 1][3])};
                     rows_swap(oa, ob);
-                    st128<SC1>(oa, rof, e32[0] != OOB ? (cbv[2 * pr] * of_cb + e32[0]) * 4u : OOB);
-                    st128<SC1>(ob, rof, e32[1] != OOB ? (cbv[2 * pr] * of_cb + e32[1]) * 4u : OOB);
+#ifdef IS_F32_PLAIN   // (timing experiment of round 6)
+                    constexpr bool SCF = SC1 && !FSC1;
+#else
+                    constexpr bool SCF = SC1;
+#endif
+                    st128<SCF>(oa, rof, e32[0] != OOB ? (cbv[2 * pr] * of_cb + e32[0]) * 4u : OOB);
+                    st128<SCF>(ob, rof, e32[1] != OOB ? (cbv[2 * pr] * of_cb + e32[1]) * 4u : OOB);
                 }
             } else if (has_f32) {
 #pragma unroll
@@ -2207,6 +2221,7 @@ int g_tune_rot = 0;  // chunk-order rotation of the LDS-DMA dense-block conv (A/
 #ifdef DASR_BENCH
 int g_chain_form = 1;  // chained launches: 1 = conv_chain_kernel for the exact fit of 512 tiles, conv_chain2_kernel for multiples; 2 = conv_chain2_kernel always
 #endif
+int g_tune_is_stagger = 0;   // rdb_is_kernel: start offset between XCDs (units of ~4 us)
 int g_tune_rdb32 = 12, g_tune_rdb64 = 13, g_tune_stream = 0, g_tune_xcd = 1, g_tune_epi = 1;  // Cout=64: 13 = 8-wave form for launches of <= 256 four-wave workgroups (worth 1-2 % of the step under two sub-batch streams)
 
 #include "rdb_is.h"
@@ -2220,6 +2235,7 @@ extern "C" int dasr_debug_set_trace(void* buf) {
 #endif
 
 extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
+    if (key == 9 && value >= 0 && value <= 64) { g_tune_is_stagger = value; return 0; }   // rdb_is_kernel: XCD start stagger
 #ifndef DASR_BENCH
     // product library: one dense-block conv kernel; the only live choice is the workgroup shape rule of the Cout = 64 launches (key 2)
     if (key == 2 && (value == 12 || value == 13)) { g_tune_rdb64 = value; return 0; }
@@ -2369,8 +2385,8 @@ extern "C" int dasr_rdb_chain(const dasr_conv_params* dev_layers, const dasr_con
         if (n_cu != 256) return DASR_EINVAL;
     }
     const int tpw = (int)(ntiles / 256);
-    if (bwd) return launch_rdb_is<false, true>(dev_layers, nlayers / 5, tiles_y, tiles_x, tpw, dev_flags, dev_flags + ntiles, dev_err, as_stream(stream), "rdb_is_kernel<false, true>");
-    return launch_rdb_is<false, false>(dev_layers, nlayers / 5, tiles_y, tiles_x, tpw, dev_flags, dev_flags + ntiles, dev_err, as_stream(stream), "rdb_is_kernel<false, false>");
+    if (bwd) return launch_rdb_is<false, true>(dev_layers, nlayers / 5, tiles_y, tiles_x, tpw, dev_flags, dev_flags + ntiles, dev_err, as_stream(stream), "rdb_is_kernel<false, true>", g_tune_is_stagger);
+    return launch_rdb_is<false, false>(dev_layers, nlayers / 5, tiles_y, tiles_x, tpw, dev_flags, dev_flags + ntiles, dev_err, as_stream(stream), "rdb_is_kernel<false, false>", g_tune_is_stagger);
 }
 
 extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {

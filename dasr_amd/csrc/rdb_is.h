@@ -25,6 +25,12 @@
 // PIPELINE, not a spin: wave 0 requests the nine flag words by LDS-DMA at the start of a step, every wave reads them from LDS after the step's barrier;
 // only when a group is still missing where it is needed does the workgroup spin (and counts it: err stays 0, the time shows in the trace).
 // ---------------------------------------------------------------------------------------------------
+#ifndef IS_ABL
+#define IS_ABL 0   // timing experiments with WRONG results (scripts/r06_is_ablate.sh): 1 no epilogues, 2 no weight DMA, 4 no MFMA, 8 no activation DMA, 16 no residual preload
+#endif
+#ifndef IS_WDIST
+#define IS_WDIST 3   // the weights of step g + IS_WDIST are requested in step g (ring of four granules: at most 3)
+#endif
 #ifndef IS_PUB_DELAY
 #define IS_PUB_DELAY 1
 #endif
@@ -41,6 +47,7 @@ struct ISC {
     static constexpr int MAX_TPW = 8;
     static constexpr int F0_OFF = POLL_OFF + MAX_TPW * 64;   // f0[MAX_TPW], ticket
     static constexpr int DEC_OFF = F0_OFF + 64;              // decision words [2 step parities][2]: {target reached ? target : target - 1, tile slot}, written by wave 0
+    static constexpr int TRC_OFF = DEC_OFF + 64;             // trace builds: 16 64-bit accumulators
     static constexpr int LDS_BYTES = 163840;
     static constexpr int NSTEP = 34;
     static constexpr int PUB_DELAY = IS_PUB_DELAY;           // a conv's flag goes out at the end of the PUB_DELAY-th step behind its epilogue (its stores have that long to be acknowledged)
@@ -140,9 +147,10 @@ struct ISGeo {            // one tile of the workgroup's list
 
 #ifdef DASR_TRACE
 #define IS_T() (g_trace && threadIdx.x == 0 ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
+// (accumulated in LDS, copied out once at the end: a global read-modify-write per stamp would sit in the VMEM queue the kernel counts)
 #define IS_ACC(k, val)                                                                                     \
     do {                                                                                                   \
-        if (g_trace && threadIdx.x == 0) g_trace[(size_t)(1 << 20) + (size_t)blockIdx.x * 64 + (k)] += (val); \
+        if (g_trace && threadIdx.x == 0) ((unsigned long long*)(smem + ISC::TRC_OFF))[k] += (val);           \
     } while (0)
 #else
 #define IS_T() 0ull
@@ -175,8 +183,13 @@ __device__ __forceinline__ void is_body(f32x16 (&a0)[2], f32x16 (&a1)[2], const 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            a0[nt] = mfma16<F16>(fa[s & 1][0], fb[kx & 1][nt + ky], a0[nt]);
-            if constexpr (NU == 2) a1[nt] = mfma16<F16>(fa[s & 1][1], fb[kx & 1][nt + ky], a1[nt]);
+            if constexpr (IS_ABL & 4) {
+                asm volatile("" ::"v"(fa[s & 1][0]), "v"(fb[kx & 1][nt + ky]));
+                if constexpr (NU == 2) asm volatile("" ::"v"(fa[s & 1][1]));
+            } else {
+                a0[nt] = mfma16<F16>(fa[s & 1][0], fb[kx & 1][nt + ky], a0[nt]);
+                if constexpr (NU == 2) a1[nt] = mfma16<F16>(fa[s & 1][1], fb[kx & 1][nt + ky], a1[nt]);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -185,7 +198,7 @@ __device__ __forceinline__ void is_body(f32x16 (&a0)[2], f32x16 (&a1)[2], const 
 
 template <bool F16, bool BWD>
 __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* __restrict__ layers, const int nrdb, const int tiles_y, const int tiles_x, const int tpw,
-                                                        unsigned* flags, unsigned* tickets, int* err) {
+                                                        unsigned* flags, unsigned* tickets, int* err, const int stagger) {
     using C = ISC;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -207,6 +220,9 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
     __syncthreads();
     if (tid < tpw * 16) ((int*)(smem + C::POLL_OFF))[tid] = xi[tid >> 4];   // "newest value seen" of every polled word: a lower bound of the truth at all times
     if (tid < 4) ((unsigned*)(smem + C::DEC_OFF))[tid] = 0xffffffffu;
+#ifdef DASR_TRACE
+    if (tid < 16) ((unsigned long long*)(smem + C::TRC_OFF))[tid] = 0ull;
+#endif
     CH_WHERE(j, xcc);
     const int Hin = layers[0].Hin, Win = layers[0].Win;
     __syncthreads();
@@ -258,6 +274,8 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
     int pub_mark = 0, pub_due = 0;
     unsigned pub_off = 0, pub_val = 0;
     int mark_x = 0;                                // `issued` behind the DMA of the current item's x chunks
+    bool poll_pend = false;                        // wave 0: a poll of flag words is in flight (requested behind poll_mark)
+    int poll_mark = 0;
     const int total_steps = nrdb * tpw * C::NSTEP;
 
     auto flag_store = [&]() {
@@ -271,6 +289,9 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
             flag_store();
         }
     };
+    // (Round 6 also built the publish as a non-blocking queue -- every wave checks IB_STS.vm_cnt at the end of a step, wave 0 stores the flag once all eight have seen their
+    // stores acknowledged: 9.7 ms per chain against 8.7 ms.  The flag then leaves up to two steps later, and what bounds this kernel is exactly that chain: epilogue stores
+    // acknowledged -> flag -> the neighbours' poll -> their halo DMA; waiting for the stores at the end of the next step is the shortest form.  profiles/r06_is_chain.txt)
     // spin until they have (a group is not there where it is needed): the only place where the matrix pipe waits for a neighbour
     auto block_until = [&](const ISGeo& q, unsigned target) {
         const unsigned long long t0 = IS_T();
@@ -294,6 +315,9 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
         IS_ACC(11, 1ull);
     };
 
+    // XCD stagger (tuning key 9): XCD k starts k * stagger * ~4 us late, so that the eight XCDs (which never wait for each other: whole images per XCD) reach
+    // their store / DMA bursts at different times
+    for (int i = 0; i < xcd * stagger; ++i) __builtin_amdgcn_s_sleep(127);
     ISGeo cur = geo_of(0);
     // ---- prologue: x of the first item, the weights of steps 0-2, the biases of the first item
     {
@@ -304,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
         for (int c = 0; c < 4; ++c) issued += is_dma_act(rin0, smem + c * C::ACT_SLOT, cur.goff, (unsigned)c * icb0, wave, tid);
         mark_x = issued;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) issued += is_dma_w(make_rsrc(p0.w), smem + C::W_OFF + t * C::WGRAN, (unsigned)t * 9216u, 576, wave, tid);
+        for (int t = 0; t < IS_WDIST; ++t) issued += is_dma_w(make_rsrc(p0.w), smem + C::W_OFF + t * C::WGRAN, (unsigned)t * 9216u, 576, wave, tid);
         if (!BWD && wave < 5) {
             const dasr_conv_params& pb = layers[wave];
             is_dma_bias(make_rsrc(pb.bias), smem + C::BIAS_OFF + wave * 256, (pb.bias != nullptr && lane < 32 * pb.mt) ? (unsigned)lane * 4u : OOB);
@@ -340,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
             // x of this item is in LDS (requested at the end of the previous item / in the prologue)
             {
                 const unsigned long long t0 = IS_T();
-                is_wait_vm(issued - mark_x);
+                is_wait_vm(__builtin_amdgcn_readfirstlane(issued - mark_x));
                 __builtin_amdgcn_s_barrier();
                 IS_ACC(4, IS_T() - t0);
             }
@@ -348,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
             // Requested here, scaled in front of conv1's epilogue (step 3): four steps for the round trip.
             // (A conv5 WITHOUT a 16-bit shadow -- the last block of the trunk -- is one dasr_conv runs with its generic epilogue, alpha * acc + beta1 * x: same here.)
             const dasr_conv_params& p5 = layers[L0 + 4];
-            const bool r1pre = p5.out_bf16.p != nullptr;
+            const bool r1pre = p5.out_bf16.p != nullptr && !(IS_ABL & 16);
             if (r1pre) {
                 const __amdgpu_buffer_rsrc_t rr1 = make_rsrc((const float*)p5.res1.p + (size_t)cur.n * p5.res1.n_stride);
                 const unsigned r1_cb = (unsigned)p5.res1.cb_stride;
@@ -386,8 +410,8 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
             const unsigned f0n = (unsigned)__builtin_amdgcn_readfirstlane(xi[sn]);
 
             auto request_group = [&](int c0) {   // chunks c0, c0 + 1 of this item's slab
-                issued += is_dma_act(rin, smem + (c0 & 3) * C::ACT_SLOT, cur.goff, (unsigned)c0 * icb, wave, tid);
-                issued += is_dma_act(rin, smem + ((c0 + 1) & 3) * C::ACT_SLOT, cur.goff, (unsigned)(c0 + 1) * icb, wave, tid);
+                if constexpr (!(IS_ABL & 8)) issued += is_dma_act(rin, smem + (c0 & 3) * C::ACT_SLOT, cur.goff, (unsigned)c0 * icb, wave, tid);
+                if constexpr (!(IS_ABL & 8)) issued += is_dma_act(rin, smem + ((c0 + 1) & 3) * C::ACT_SLOT, cur.goff, (unsigned)(c0 + 1) * icb, wave, tid);
                 arr_issued = true;
                 mark_act = issued;
             };
@@ -396,7 +420,8 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                 const __amdgpu_buffer_rsrc_t rinn = make_rsrc((const bf16_t*)pn.in.p + (size_t)nxt.n * pn.in.n_stride);
                 const unsigned icbn = (unsigned)(pn.in.cb_stride * 2);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) issued += is_dma_act(rinn, smem + c * C::ACT_SLOT, nxt.goff, (unsigned)c * icbn, wave, tid);
+                for (int c = 0; c < 4; ++c)
+                    if constexpr (!(IS_ABL & 8)) issued += is_dma_act(rinn, smem + c * C::ACT_SLOT, nxt.goff, (unsigned)c * icbn, wave, tid);
                 mark_x = issued;
                 next_x_issued = true;
             };
@@ -408,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                 constexpr bool MUST = GK >= 1 && GK <= 4 && TT + 1 == IS_WIN1[GK];   // the group is read in the next step
                 const char* abuf = smem + (d.c & 3) * C::ACT_SLOT;
                 const char* wbuf = smem + C::W_OFF + (g & 3) * C::WGRAN;
-                char* wnext = smem + C::W_OFF + ((g + 3) & 3) * C::WGRAN;
+                char* wnext = smem + C::W_OFF + ((g + IS_WDIST) & 3) * C::WGRAN;
                 if constexpr (GK != 0 && TT == IS_WIN0[GK > 0 ? GK : 1]) arr_issued = false;
                 // ---- what this step requests besides its MFMAs.  Whether a group's nine flag words have reached their target is decided by WAVE 0 ALONE (at the end of
                 // the step in which it polled, from the words its LDS-DMA brought) and handed to the other waves through a decision word in LDS across the step's
@@ -420,20 +445,34 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                     const unsigned* dw = (const unsigned*)(smem + C::DEC_OFF) + ((g - 1) & 1) * 2;
                     return __builtin_amdgcn_readfirstlane(dw[0]) == target && __builtin_amdgcn_readfirstlane(dw[1]) == (unsigned)pslot;
                 };
+                bool need = false;   // a group is awaited and not yet known to be there
                 if constexpr (GK >= 1 && GK <= 4) {
                     target = cur.f0 + (unsigned)(L0 + GK), pslot = cur.slot;
                     if (!arr_issued) {
                         if (decided()) act_now = true;
-                        else poll_now = !pub_on;   // (our own flag is one of the nine: nothing to see before it is out)
+                        else need = true, poll_now = !pub_on && !poll_pend;   // (our own flag is one of the nine: nothing to see before it is out)
                     }
                 } else if constexpr (GK == 5) {
                     if (has_next && rn > 0 && !next_rdy) {   // (block 0 reads what an earlier kernel wrote)
                         target = f0n + (unsigned)L0n, pslot = sn;
                         if (decided()) next_rdy = true;
-                        else poll_now = true;
+                        else need = true, poll_now = !poll_pend;
                     }
                 }
-                int poll_mark = 0;
+                constexpr int EU_AFTER = is_epi_after(TT);
+                auto prefetch_w = [&]() {   // weights of step g + 3 (g: this step)
+                    if (g + IS_WDIST < total_steps && !(IS_ABL & 2)) {
+                        constexpr int T3 = (TT + IS_WDIST) % C::NSTEP;
+                        constexpr ISStep e = IS_PROG[T3];
+                        constexpr bool NX = TT + IS_WDIST >= C::NSTEP;
+                        if constexpr (e.kind == 5) {
+                            issued += is_dma_w(make_rsrc(wptr(4, NX)), wnext, (unsigned)e.c * 18432u, 1152, wave, tid);
+                        } else {
+                            issued += is_dma_w(make_rsrc(wptr(e.u0, NX)), wnext, (unsigned)e.c * 9216u, 576, wave, tid);
+                            if constexpr (e.kind == 2) issued += is_dma_w(make_rsrc(wptr(e.u1, NX)), wnext + 9216, (unsigned)e.c * 9216u, 576, wave, tid);
+                        }
+                    }
+                };
                 auto mid = [&](int s) {
                     if (s == 0) {
                         if (poll_now && wave == 0) {
@@ -445,18 +484,10 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                             }
                             ++issued;
                             poll_mark = issued;
+                            poll_pend = true;
                         }
-                        if (g + 3 < total_steps) {   // weights of step g + 3
-                            constexpr int T3 = (TT + 3) % C::NSTEP;
-                            constexpr ISStep e = IS_PROG[T3];
-                            constexpr bool NX = TT + 3 >= C::NSTEP;
-                            if constexpr (e.kind == 5) {
-                                issued += is_dma_w(make_rsrc(wptr(4, NX)), wnext, (unsigned)e.c * 18432u, 1152, wave, tid);
-                            } else {
-                                issued += is_dma_w(make_rsrc(wptr(e.u0, NX)), wnext, (unsigned)e.c * 9216u, 576, wave, tid);
-                                if constexpr (e.kind == 2) issued += is_dma_w(make_rsrc(wptr(e.u1, NX)), wnext + 9216, (unsigned)e.c * 9216u, 576, wave, tid);
-                            }
-                        }
+                        if constexpr (EU_AFTER < 0) prefetch_w();   // (a step that ends in an epilogue requests them BEHIND the epilogue's stores: a store queued behind LDS-DMA
+                                                                    // instructions waits for their data, profiles/r05_chain_trace.txt form 2 / r06_is_trace.txt)
                     }
                     if (s == 2) {
                         if constexpr (GK >= 1 && GK <= 4) {
@@ -479,27 +510,37 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                 }
                 const unsigned long long t1 = IS_T();
                 // ---- end of the step: everything requested up to the end of step g - 2 has landed (the granule of step g + 1 among it); flag words / publish / group as due
-                int nwait = issued - mk0;
-                if (poll_now && wave == 0) nwait = min(nwait, issued - poll_mark);
+                int nwait = issued - (IS_WDIST >= 3 ? mk0 : mk1);
                 bool do_pub = false;
                 if (pub_on && g >= pub_due) do_pub = true, nwait = min(nwait, issued - pub_mark);
                 if constexpr (MUST) {
                     if (arr_issued) nwait = min(nwait, issued - mark_act);
                 }
-                is_wait_vm(nwait);
-                if (poll_now && wave == 0) {   // the polled words have landed: decide for everybody
-                    const unsigned v = ((const unsigned*)(smem + C::POLL_OFF))[pslot * 16 + (lane < 9 ? lane : 0)];
-                    const bool rdy = __builtin_amdgcn_ballot_w64((int)(v - target) < 0) == 0ull;
-                    if (lane < 2) ((unsigned*)(smem + C::DEC_OFF))[(g & 1) * 2 + lane] = lane == 0 ? (rdy ? target : target - 1u) : (unsigned)pslot;
-                    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the decision is in LDS before the barrier
+                is_wait_vm(__builtin_amdgcn_readfirstlane(nwait));
+                const unsigned long long t1b = IS_T();
+                if (poll_pend && wave == 0) {   // have the polled words landed?  Asked, not waited for: the hardware's count of this wave's outstanding VMEM operations
+                                                // (IB_STS.vm_cnt; it includes what `issued` does not count, so "landed" can only be late, never early)
+                    unsigned ib;
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_IB_STS)" : "=s"(ib));
+                    const int out = (int)((ib & 15u) | (((ib >> 22) & 3u) << 4));
+                    if (out <= issued - poll_mark) {
+                        poll_pend = false;
+                        if (need) {   // decide for everybody
+                            const unsigned v = ((const unsigned*)(smem + C::POLL_OFF))[pslot * 16 + (lane < 9 ? lane : 0)];
+                            const bool rdy = __builtin_amdgcn_ballot_w64((int)(v - target) < 0) == 0ull;
+                            if (lane < 2) ((unsigned*)(smem + C::DEC_OFF))[(g & 1) * 2 + lane] = lane == 0 ? (rdy ? target : target - 1u) : (unsigned)pslot;
+                            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the decision is in LDS before the barrier
+                        }
+                    }
                 }
                 __builtin_amdgcn_s_barrier();
                 if (do_pub) flag_store();
                 mk0 = mk1, mk1 = issued;
-                ++g;
                 const unsigned long long t2 = IS_T();
                 IS_ACC(d.kind == 1 ? 0 : 1, t1 - t0);
                 IS_ACC(2, t2 - t1);
+                IS_ACC(d.kind == 1 ? 12 : 13, t1b - t1);   // (of 2: the counted vmcnt wait alone, by step kind)
+                IS_ACC(d.kind == 1 ? 14 : 15, t2 - t1b);   // (of 2: decision + barrier)
                 IS_ACC(d.kind == 1 ? 8 : 9, 1ull);
                 if constexpr (MUST) {
                     if (!arr_issued) {   // not there where it is needed: spin, then request and wait for it
@@ -533,37 +574,49 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                         if (has_next) {   // x of the next item (+ its biases) goes out in front of the conv5 epilogue when its neighbours are there already (the usual case: another tile's
                                           // block, finished an item ago); else behind it (a workgroup with one tile waits for its own conv5 there)
                             if (rn > 0 && !next_rdy) {   // (wave 0's decision at the end of this step)
-                                const unsigned* dw = (const unsigned*)(smem + C::DEC_OFF) + ((g - 1) & 1) * 2;
+                                const unsigned* dw = (const unsigned*)(smem + C::DEC_OFF) + (g & 1) * 2;
                                 next_rdy = __builtin_amdgcn_readfirstlane(dw[0]) == f0n + (unsigned)L0n && __builtin_amdgcn_readfirstlane(dw[1]) == (unsigned)sn;
                             }
-                            if (rn == 0 || next_rdy) request_next_x(geo_of(sn));
-                            if (!BWD && wave < 5) {
-                                const dasr_conv_params& pb = layers[L0n + wave];
-                                is_dma_bias(make_rsrc(pb.bias), smem + C::BIAS_OFF + (par ^ 1) * 1280 + wave * 256, (pb.bias != nullptr && lane < 32 * pb.mt) ? (unsigned)lane * 4u : OOB);
-                                ++issued;
-                            }
                         }
-                        const bool two = p.res2.p != nullptr, sh = p.out_bf16.p != nullptr;
+                        const bool two = p.res2.p != nullptr && !(IS_ABL & 1), sh = p.out_bf16.p != nullptr;
                         constexpr int E0 = BWD ? 160 : 161;   // alpha, fp32 out (+ bias forward); + 16 second residual, + 64 the 16-bit shadow
-                        if (two && sh) conv_epilogue<false, 2, 2, 1, E0 + 80, F16 ? 1 : 0, false, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
-                        else if (sh) conv_epilogue<false, 2, 2, 1, E0 + 64, F16 ? 1 : 0, false, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
-                        else if (two) conv_epilogue<false, 2, 2, 1, E0 + 8 + 16, F16 ? 1 : 0, false, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
-                        else conv_epilogue<false, 2, 2, 1, E0 + 8, F16 ? 1 : 0, false, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                        if constexpr (IS_ABL & 1) {
+                            asm volatile("" ::"v"(A5[0][0]), "v"(A5[0][1]), "v"(A5[1][0]), "v"(A5[1][1]));
+                        } else if (two && sh) conv_epilogue<false, 2, 2, 1, E0 + 80, F16 ? 1 : 0, false, true, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                        else if (sh) conv_epilogue<false, 2, 2, 1, E0 + 64, F16 ? 1 : 0, false, true, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                        else if (two) conv_epilogue<false, 2, 2, 1, E0 + 8 + 16, F16 ? 1 : 0, false, true, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                        else conv_epilogue<false, 2, 2, 1, E0 + 8, F16 ? 1 : 0, false, true, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
                     } else if constexpr (EU == 0) {
-                        conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true>(p, A0, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                        if constexpr (IS_ABL & 1) asm volatile("" ::"v"(A0[0][0]), "v"(A0[0][1]));
+                        else conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true, true>(p, A0, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
                     } else if constexpr (EU == 1) {
-                        conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true>(p, A1, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                        if constexpr (IS_ABL & 1) asm volatile("" ::"v"(A1[0][0]), "v"(A1[0][1]));
+                        else conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true, true>(p, A1, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
                     } else if constexpr (EU == 2) {
-                        conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true>(p, A2, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                        if constexpr (IS_ABL & 1) asm volatile("" ::"v"(A2[0][0]), "v"(A2[0][1]));
+                        else conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true, true>(p, A2, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
                     } else {
-                        conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true>(p, A3, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                        if constexpr (IS_ABL & 1) asm volatile("" ::"v"(A3[0][0]), "v"(A3[0][1]));
+                        else conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true, true>(p, A3, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
                     }
                     // the flag of this conv: PUB_DELAY steps from now (an older one that is still pending goes out first)
                     flush_pub();
-                    pub_on = true, pub_mark = issued, pub_due = g + C::PUB_DELAY - 1;
+                    pub_on = true, pub_mark = issued, pub_due = g + C::PUB_DELAY;
                     pub_off = cur.selfo, pub_val = cur.f0 + (unsigned)(L0 + EU + 1);
+                    // ... and only now the LDS-DMA requests this step held back: the weights of step g + 3, the next item's x
+                    prefetch_w();
+                    if constexpr (EU == 4) {
+                        if (has_next && (rn == 0 || next_rdy)) request_next_x(geo_of(sn));
+                        if (has_next && !BWD && wave < 5) {
+                            const dasr_conv_params& pb = layers[L0n + wave];
+                            is_dma_bias(make_rsrc(pb.bias), smem + C::BIAS_OFF + (par ^ 1) * 1280 + wave * 256, (pb.bias != nullptr && lane < 32 * pb.mt) ? (unsigned)lane * 4u : OOB);
+                            ++issued;
+                        }
+                    }
+                    mk1 = issued;   // (they count as requests of this step: the end of step g + 2 waits for them)
                     IS_ACC(EU == 4 ? 6 : 5, IS_T() - t4);
                 }
+                ++g;
             };
             // the 34 steps, unrolled at compile time
             auto run = [&](auto self, auto tc) -> void {
@@ -587,16 +640,19 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
     }
     flush_pub();
     __builtin_amdgcn_s_waitcnt(0x0F70);
+#ifdef DASR_TRACE
+    if (g_trace && tid < 16) g_trace[(size_t)(1 << 20) + (size_t)blockIdx.x * 64 + tid] = ((unsigned long long*)(smem + C::TRC_OFF))[tid];
+#endif
 }
 
 template <bool F16, bool BWD>
-int launch_rdb_is(const dasr_conv_params* dev_layers, int nrdb, int tiles_y, int tiles_x, int tpw, unsigned* flags, unsigned* tickets, int* err, hipStream_t s, const char* name) {
+int launch_rdb_is(const dasr_conv_params* dev_layers, int nrdb, int tiles_y, int tiles_x, int tpw, unsigned* flags, unsigned* tickets, int* err, hipStream_t s, const char* name, int stagger) {
     static bool attr_set = false;
     auto kfn = rdb_is_kernel<F16, BWD>;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, ISC::LDS_BYTES));
         attr_set = true;
     }
-    DASR_LAUNCH_TAG(name, kfn, dim3(256), dim3(ISC::NTH), ISC::LDS_BYTES, s, dev_layers, nrdb, tiles_y, tiles_x, tpw, flags, tickets, err);
+    DASR_LAUNCH_TAG(name, kfn, dim3(256), dim3(ISC::NTH), ISC::LDS_BYTES, s, dev_layers, nrdb, tiles_y, tiles_x, tpw, flags, tickets, err, stagger);
     return (int)hipGetLastError();
 }

@@ -30,6 +30,11 @@ int dasr_probe_tile_sync(int32_t blocks, int32_t stages, int32_t nb_stride, int3
  * collective's kernels on the communication stream (the chained trunk launches of the product library need every workgroup slot of the device). */
 int dasr_probe_spin(int32_t blocks, int32_t micros, void* stream);
 
+/* Store-path probe (round 6, scripts/micro_store.py): `blocks` workgroups of 512 threads each write `kb` KiB (multiple of 8) of their own region of `buf` (blocks * kb KiB) with
+ * 16-byte-per-lane stores, mode 0 plain / 1 sc1 (write-through), `reps` bursts separated by `gap` x s_sleep(16); cyc_out[block] = cycles spent in the bursts (first store
+ * issued .. last store acknowledged).  Synchronises the stream. */
+int dasr_probe_store(void* buf, int32_t blocks, int32_t kb, int32_t mode, int32_t reps, int32_t gap, unsigned long long* cyc_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
