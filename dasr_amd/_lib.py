@@ -126,6 +126,7 @@ _SIGS = {
     'dasr_last_failed_op': [],
     'dasr_ddm_spread': [Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, Tensor, c_vp],
     'dasr_abi_version': [],
+    'dasr_red_release': [],
     'dasr_probe_tr16': [c_vp],
     'dasr_rccl_unique_id': [c_vp],
     'dasr_rccl_init': [c_vp, c_i32, c_i32, c_vp],
@@ -150,10 +151,11 @@ _BENCH_SIGS = {
     'dasr_probe_tile_sync': [c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp],
     'dasr_probe_mfma_peak': [c_i32, c_vp, c_vp],
     'dasr_probe_spin': [c_i32, c_i32, c_vp],
+    'dasr_probe_store': [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
 }
 BENCH_LIB_PATH = os.path.join(HERE, 'libdasr_bench.so')
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 _lib = None
 _bench = None
 

@@ -71,6 +71,7 @@ struct dasr_red {
     unsigned* ticket;    // arrival counter, zero between launches
 };
 dasr_red dasr_red_scratch(const void* key_acc, hipStream_t s, unsigned nblocks, int k);   // misc.hip; k <= 3
+int dasr_red_error();   // misc.hip: what a launcher returns when it got no row (DASR_ECAPTURE: refused under stream capture; else DASR_EINVAL)
 
 // Called by ALL 256 threads of every workgroup of a 1-D grid; v[k] = this workgroup's partial sum (the same value in every thread, or at least in
 // thread 0); acc[k] (may be null) += coef[k] * (sum over the grid of v[k]).

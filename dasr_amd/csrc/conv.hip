@@ -118,7 +118,10 @@ __device__ __forceinline__ void st128(u32x4 v, __amdgpu_buffer_rsrc_t r, unsigne
 // barrier of the main loop, in a region no DMA touches) -- no hand-over barrier here
 // CONST_SLOPE: the caller guarantees p.slope_ptr == nullptr (the chained launches validate it): without it hipcc turns `slope_ptr ? *slope_ptr : slope` into an
 // unconditional vector load from a selected address, and its `s_waitcnt vmcnt(0)` drains every LDS-DMA request in flight (rdb_is_kernel: the weights of the next three steps)
-template <bool IN_F32, int MT, int NT, int STRIDE, int EPI, int F16OUT = -1, bool PRE = false, bool FSC1 = false, bool BIAS_STAGED = false, bool CONST_SLOPE = false>
+// BMODE / BH (rdb_is_kernel: a conv's flag waits for the acknowledgement of its stores, and the neighbours need only the tile's border): 1 = only the border pixels of the
+// BH x 32-pixel tile are computed and stored (everything else is out of range: no loads, no stores), 2 = the 16-bit output skips the border pixels (already stored by a
+// BMODE 1 call), everything else is complete.  0 = plain.
+template <bool IN_F32, int MT, int NT, int STRIDE, int EPI, int F16OUT = -1, bool PRE = false, bool FSC1 = false, bool BIAS_STAGED = false, bool CONST_SLOPE = false, int BMODE = 0, int BH = 16>
 __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 (&acc)[MT][NT], char* smem, float bias_reg, int tid, int mg, int n,
                                               int oy0, int ox0, const MaskPre<NT * MT>* pre = nullptr) {
     const int lane = tid & 63, wave = tid >> 6, nn = lane & 31, kh2 = lane >> 5;
@@ -196,7 +199,8 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
             c = nn & 15;
         }
         const int oy = oy0 + r, ox = ox0 + c;
-        const bool pv = (oy < p.Hout) & (ox < p.Wout);
+        bool pv = (oy < p.Hout) & (ox < p.Wout);
+        if constexpr (BMODE == 1) pv &= (r == 0) | (r == BH - 1) | (c == 0) | (c == 31);
         const unsigned pixel = (unsigned)((oy * ostr + p.out_oy) * owid + ox * ostr + p.out_ox) * 16u;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -433,7 +437,12 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                     const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
                     const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
                     const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};   // lanes 0-31: channels 0-7 of the plane, lanes 32-63: channels 8-15
-                    st128<SC1>(o, rob, eo[2 * pr] != OOB ? (cbv[2 * pr] * ob_cb + eo[2 * pr] + 4u * kh2) * 2u : OOB);
+                    bool keep = true;
+                    if constexpr (BMODE == 2) {
+                        const int rl = wave * NT + nt;
+                        keep = !((rl == 0) | (rl == BH - 1) | (nn == 0) | (nn == 31));
+                    }
+                    st128<SC1>(o, rob, (eo[2 * pr] != OOB && keep) ? (cbv[2 * pr] * ob_cb + eo[2 * pr] + 4u * kh2) * 2u : OOB);
                     if (lo_pl) {   // remainder plane: lo = round16(value - hi)
                         bf16x4 la, lb;
 #pragma unroll

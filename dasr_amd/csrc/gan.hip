@@ -1191,7 +1191,7 @@ extern "C" int dasr_gan_loss(dasr_tensor x, int32_t N, int32_t C, int32_t H, int
     const dim3 g(nblk(total)), b(256);
     const void* key = loss_acc ? (const void*)loss_acc : (const void*)score_acc;
     const dasr_red rs = dasr_red_scratch(key, as_stream(stream), g.x, 2);
-    if (key && !rs.part) return DASR_EINVAL;
+    if (key && !rs.part) return dasr_red_error();
     if (gan_type == 0)
         DASR_LAUNCH(gan_loss_kernel<0>, g, b, 0, as_stream(stream), x, N, C, H, W, target, coef, gcoef, loss_acc, score_acc, score_coef, grad, rs);
     else if (gan_type == 1)
@@ -1214,7 +1214,7 @@ extern "C" int dasr_ragan(dasr_tensor a, dasr_tensor b, int32_t N, int32_t H, in
     const dim3 g(nblk((long long)H * W)), blk(256);
     const void* key = stage != 1 ? nullptr : (loss_acc ? (const void*)loss_acc : (score_a ? (const void*)score_a : (const void*)score_b));
     const dasr_red rs = dasr_red_scratch(key, as_stream(stream), g.x, 3);
-    if (key && !rs.part) return DASR_EINVAL;
+    if (key && !rs.part) return dasr_red_error();
 #define DASR_RAGAN_FORM(F)                                                                                                                        \
     DASR_LAUNCH(ragan_kernel<F>, g, blk, 0, as_stream(stream), a, b, N, H, W, stage, 1.f / (float)n_glob, ta, tb, coef, gcoef, eps, sums, part, \
                 loss_acc, score_a, score_b, score_coef, ga, gb, rs)
@@ -1286,7 +1286,7 @@ extern "C" int dasr_l1_diff(dasr_tensor a, dasr_tensor b, int32_t is_f32, int32_
     const long long total = (long long)N * ((C + 15) / 16) * H * W * 4;
     if (total <= 0) return DASR_EINVAL;
     const dasr_red rs = dasr_red_scratch(loss_acc, as_stream(stream), nblk(total), 1);
-    if (loss_acc && !rs.part) return DASR_EINVAL;
+    if (loss_acc && !rs.part) return dasr_red_error();
     if (is_f32) DASR_LAUNCH(l1_diff_kernel<float>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), a, b, N, C, H, W, coef, gcoef, loss_acc, ga, squared, rs);
     else DASR_LAUNCH(l1_diff_kernel<bf16_t>, dim3(nblk(total)), dim3(256), 0, as_stream(stream), a, b, N, C, H, W, coef, gcoef, loss_acc, ga, squared, rs);
     return (int)hipGetLastError();
@@ -1367,7 +1367,7 @@ extern "C" int dasr_logloss(dasr_tensor x, int32_t N, int32_t H, int32_t W, int3
     if (total <= 0) return DASR_EINVAL;
     const void* key = loss_acc ? (const void*)loss_acc : (const void*)score_acc;
     const dasr_red rs = dasr_red_scratch(key, as_stream(stream), nblk(total), 2);
-    if (key && !rs.part) return DASR_EINVAL;
+    if (key && !rs.part) return dasr_red_error();
     DASR_LAUNCH(logloss_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), x, N, H, W, mode, eps, coef, gcoef, loss_acc, score_acc,
                        score_coef, grad, accumulate, rs);
     return (int)hipGetLastError();

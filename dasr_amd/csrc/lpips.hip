@@ -255,7 +255,7 @@ extern "C" int dasr_lpips_head(dasr_tensor f, int64_t pair_off, int32_t N, int32
     if (N <= 0 || C <= 0 || (C & 15) || H <= 0 || W <= 0 || !lin) return DASR_EINVAL;
     const long long total = (long long)N * H * W;
     const dasr_red rs = dasr_red_scratch(loss_acc, as_stream(stream), nblk(total), 1);
-    if (loss_acc && !rs.part) return DASR_EINVAL;
+    if (loss_acc && !rs.part) return dasr_red_error();
     DASR_LAUNCH(lpips_head_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), f, (long long)pair_off, N, C, H, W, lin, eps, coef, gcoef, loss_acc,
                 g0, relu_mask, rs);
     return (int)hipGetLastError();

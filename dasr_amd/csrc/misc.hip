@@ -302,7 +302,7 @@ extern "C" int dasr_l1_loss(dasr_tensor sr, const float* hr_nchw, const float* w
     const long long total = (long long)N * H * W;
     if (total <= 0 || C > 16) return DASR_EINVAL;
     const dasr_red rs = dasr_red_scratch(loss_acc, as_stream(stream), blocks_for(total), 1);
-    if (loss_acc && !rs.part) return DASR_EINVAL;
+    if (loss_acc && !rs.part) return dasr_red_error();
     DASR_LAUNCH(l1_loss_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), sr, hr_nchw, weight_map, N, C, H, W, coef,
                        loss_acc, grad, accumulate, rs);
     return (int)hipGetLastError();
@@ -611,7 +611,25 @@ struct RedRow {
 };
 std::mutex g_red_mu;
 std::map<std::tuple<int, const void*, hipStream_t>, RedRow> g_red_rows;
+thread_local bool g_red_capture_refused = false;
 }  // namespace
+
+// DASR_ECAPTURE if the last dasr_red_scratch of this thread refused to allocate under stream capture, else DASR_EINVAL (what a launcher without a row returns)
+int dasr_red_error() {
+    const bool c = g_red_capture_refused;
+    g_red_capture_refused = false;
+    return c ? DASR_ECAPTURE : DASR_EINVAL;
+}
+
+// Frees every scratch row (the rows are keyed by (device, accumulator address, stream) and otherwise live as long as the process: a process that builds and drops many
+// models -- the test suite -- calls this between them).  The caller guarantees that no launch that uses a row is in flight.
+extern "C" int dasr_red_release(void) {
+    std::lock_guard<std::mutex> lock(g_red_mu);
+    for (auto& kv : g_red_rows)
+        if (kv.second.base) (void)hipFree(kv.second.base);
+    g_red_rows.clear();
+    return 0;
+}
 
 dasr_red dasr_red_scratch(const void* key_acc, hipStream_t s, unsigned nblocks, int k) {
     dasr_red r = {nullptr, nullptr};
@@ -622,6 +640,13 @@ dasr_red dasr_red_scratch(const void* key_acc, hipStream_t s, unsigned nblocks, 
     std::lock_guard<std::mutex> lock(g_red_mu);
     RedRow& row = g_red_rows[std::make_tuple(dev, key_acc, s)];
     if (!row.base || row.floats < need) {
+        //  a row is allocated on the first launch of its (accumulator, stream): not under stream capture (hipMalloc is illegal there and would
+        // invalidate the capture) -- the launcher then reports DASR_ECAPTURE; run the list once eagerly before capturing it, as engine.run_parallel does
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+            g_red_capture_refused = true;
+            return r;
+        }
         const size_t cap = need < 4096 ? 4096 : need + need / 2;
         char* nb = nullptr;
         if (hipMalloc((void**)&nb, 256 + cap * sizeof(float)) != hipSuccess) return r;   // (a launcher that gets no row reports DASR_EINVAL)

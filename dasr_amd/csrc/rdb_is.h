@@ -28,6 +28,10 @@
 #ifndef IS_ABL
 #define IS_ABL 0   // timing experiments with WRONG results (scripts/r06_is_ablate.sh): 1 no epilogues, 2 no weight DMA, 4 no MFMA, 8 no activation DMA, 16 no residual preload
 #endif
+#ifndef IS_BORDER
+#define IS_BORDER 0   // 1: epilogues store the border pixels of their 16-bit planes first and the flag waits for those only (conv_epilogue BMODE).  Built, bit-identical, and
+                      // SLOWER (9.9 / 10.6 ms per chain against 8.7 / 9.0): the second pass doubles the epilogue's store instructions and arithmetic -- profiles/r06_is_chain.txt
+#endif
 #ifndef IS_WDIST
 #define IS_WDIST 3   // the weights of step g + IS_WDIST are requested in step g (ring of four granules: at most 3)
 #endif
@@ -79,7 +83,7 @@ constexpr int is_epi_after(int t) { return t == 3 ? 0 : t == 17 ? 1 : t == 23 ? 
 template <int TV>
 struct ISInt { static constexpr int value = TV; };
 
-__device__ __forceinline__ void is_wait_vm(int n) {   // s_waitcnt vmcnt(min(n, 15)), n wave-uniform (a smaller count than allowed only waits longer)
+__device__ __forceinline__ void is_wait_vm(int n) {   // s_waitcnt vmcnt(min(n, 31)), n wave-uniform (a smaller count than allowed only waits longer)
     switch (n) {
         case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;
         case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;
@@ -96,7 +100,23 @@ __device__ __forceinline__ void is_wait_vm(int n) {   // s_waitcnt vmcnt(min(n, 
         case 12: __builtin_amdgcn_s_waitcnt(0x0F7C); break;
         case 13: __builtin_amdgcn_s_waitcnt(0x0F7D); break;
         case 14: __builtin_amdgcn_s_waitcnt(0x0F7E); break;
-        default: __builtin_amdgcn_s_waitcnt(0x0F7F); break;
+        case 15: __builtin_amdgcn_s_waitcnt(0x0F7F); break;
+        case 16: __builtin_amdgcn_s_waitcnt(0x4F70); break;
+        case 17: __builtin_amdgcn_s_waitcnt(0x4F71); break;
+        case 18: __builtin_amdgcn_s_waitcnt(0x4F72); break;
+        case 19: __builtin_amdgcn_s_waitcnt(0x4F73); break;
+        case 20: __builtin_amdgcn_s_waitcnt(0x4F74); break;
+        case 21: __builtin_amdgcn_s_waitcnt(0x4F75); break;
+        case 22: __builtin_amdgcn_s_waitcnt(0x4F76); break;
+        case 23: __builtin_amdgcn_s_waitcnt(0x4F77); break;
+        case 24: __builtin_amdgcn_s_waitcnt(0x4F78); break;
+        case 25: __builtin_amdgcn_s_waitcnt(0x4F79); break;
+        case 26: __builtin_amdgcn_s_waitcnt(0x4F7A); break;
+        case 27: __builtin_amdgcn_s_waitcnt(0x4F7B); break;
+        case 28: __builtin_amdgcn_s_waitcnt(0x4F7C); break;
+        case 29: __builtin_amdgcn_s_waitcnt(0x4F7D); break;
+        case 30: __builtin_amdgcn_s_waitcnt(0x4F7E); break;
+        default: __builtin_amdgcn_s_waitcnt(0x4F7F); break;
     }
 }
 
@@ -271,8 +291,9 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
     int issued = 0, mk0 = 0, mk1 = 0;
     int g = 0;                                     // global step counter: the granule of step g lives in ring slot g & 3
     bool pub_on = false;                           // a flag store is pending: value pub_val to word pub_off once every op up to pub_mark is acknowledged, at the end of step pub_due
-    int pub_mark = 0, pub_due = 0;
+    int pub_mark = 0, pub_due = 0, pub_late = 0;
     unsigned pub_off = 0, pub_val = 0;
+    int own_mark = 0;                              // `issued` behind ALL stores of the newest epilogue
     int mark_x = 0;                                // `issued` behind the DMA of the current item's x chunks
     bool poll_pend = false;                        // wave 0: a poll of flag words is in flight (requested behind poll_mark)
     int poll_mark = 0;
@@ -410,6 +431,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
             const unsigned f0n = (unsigned)__builtin_amdgcn_readfirstlane(xi[sn]);
 
             auto request_group = [&](int c0) {   // chunks c0, c0 + 1 of this item's slab
+                if constexpr (IS_BORDER) is_wait_vm(__builtin_amdgcn_readfirstlane(issued - own_mark));   // (the flag covered the border only: this tile's own interior pixels must be in memory)
                 if constexpr (!(IS_ABL & 8)) issued += is_dma_act(rin, smem + (c0 & 3) * C::ACT_SLOT, cur.goff, (unsigned)c0 * icb, wave, tid);
                 if constexpr (!(IS_ABL & 8)) issued += is_dma_act(rin, smem + ((c0 + 1) & 3) * C::ACT_SLOT, cur.goff, (unsigned)(c0 + 1) * icb, wave, tid);
                 arr_issued = true;
@@ -512,7 +534,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                 // ---- end of the step: everything requested up to the end of step g - 2 has landed (the granule of step g + 1 among it); flag words / publish / group as due
                 int nwait = issued - (IS_WDIST >= 3 ? mk0 : mk1);
                 bool do_pub = false;
-                if (pub_on && g >= pub_due) do_pub = true, nwait = min(nwait, issued - pub_mark);
+                if (pub_on && g >= pub_due) do_pub = true, nwait = min(nwait, issued - pub_mark + pub_late);
                 if constexpr (MUST) {
                     if (arr_issued) nwait = min(nwait, issued - mark_act);
                 }
@@ -570,6 +592,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                     const unsigned long long t4 = IS_T();
                     const dasr_conv_params& p = layers[L0 + EU];
                     char* bl = smem + C::BIAS_OFF + par * 1280 + EU * 256;
+                    int pmark = issued, nlate = 0;
                     if constexpr (EU == 4) {
                         if (has_next) {   // x of the next item (+ its biases) goes out in front of the conv5 epilogue when its neighbours are there already (the usual case: another tile's
                                           // block, finished an item ago); else behind it (a workgroup with one tile waits for its own conv5 there)
@@ -580,29 +603,49 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                         }
                         const bool two = p.res2.p != nullptr && !(IS_ABL & 1), sh = p.out_bf16.p != nullptr;
                         constexpr int E0 = BWD ? 160 : 161;   // alpha, fp32 out (+ bias forward); + 16 second residual, + 64 the 16-bit shadow
+                        // BORDER FIRST (IS_BORDER): the neighbours read only the border pixels of the 16-bit planes, and the flag waits for the acknowledgement of what it covers:
+                        // pass 1 stores those pixels alone (a few KB per tile), the flag's bookkeeping is taken behind it, pass 2 stores the rest (and the fp32 stream)
                         if constexpr (IS_ABL & 1) {
                             asm volatile("" ::"v"(A5[0][0]), "v"(A5[0][1]), "v"(A5[1][0]), "v"(A5[1][1]));
-                        } else if (two && sh) conv_epilogue<false, 2, 2, 1, E0 + 80, F16 ? 1 : 0, false, true, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
-                        else if (sh) conv_epilogue<false, 2, 2, 1, E0 + 64, F16 ? 1 : 0, false, true, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
-                        else if (two) conv_epilogue<false, 2, 2, 1, E0 + 8 + 16, F16 ? 1 : 0, false, true, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
-                        else conv_epilogue<false, 2, 2, 1, E0 + 8, F16 ? 1 : 0, false, true, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
-                    } else if constexpr (EU == 0) {
-                        if constexpr (IS_ABL & 1) asm volatile("" ::"v"(A0[0][0]), "v"(A0[0][1]));
-                        else conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true, true>(p, A0, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
-                    } else if constexpr (EU == 1) {
-                        if constexpr (IS_ABL & 1) asm volatile("" ::"v"(A1[0][0]), "v"(A1[0][1]));
-                        else conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true, true>(p, A1, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
-                    } else if constexpr (EU == 2) {
-                        if constexpr (IS_ABL & 1) asm volatile("" ::"v"(A2[0][0]), "v"(A2[0][1]));
-                        else conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true, true>(p, A2, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                        } else if (two && sh) {
+                            if constexpr (IS_BORDER) conv_epilogue<false, 2, 2, 1, E0 + 80 - 32, F16 ? 1 : 0, false, true, true, true, 1, C::TH>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                            pmark = issued;
+                            conv_epilogue<false, 2, 2, 1, E0 + 80, F16 ? 1 : 0, false, true, true, true, IS_BORDER ? 2 : 0, C::TH>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                            nlate = 24;
+                        } else if (sh) {
+                            if constexpr (IS_BORDER) conv_epilogue<false, 2, 2, 1, E0 + 64 - 32, F16 ? 1 : 0, false, true, true, true, 1, C::TH>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                            pmark = issued;
+                            conv_epilogue<false, 2, 2, 1, E0 + 64, F16 ? 1 : 0, false, true, true, true, IS_BORDER ? 2 : 0, C::TH>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                            nlate = 24;
+                        } else if (two) {   // (no 16-bit output: nothing a neighbour waits for)
+                            conv_epilogue<false, 2, 2, 1, E0 + 8 + 16, F16 ? 1 : 0, false, true, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                            pmark = issued, nlate = 0;
+                        } else {
+                            conv_epilogue<false, 2, 2, 1, E0 + 8, F16 ? 1 : 0, false, true, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                            pmark = issued, nlate = 0;
+                        }
                     } else {
-                        if constexpr (IS_ABL & 1) asm volatile("" ::"v"(A3[0][0]), "v"(A3[0][1]));
-                        else conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true, true>(p, A3, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                        auto epi14 = [&](f32x16 (&A)[1][2]) {
+                            if constexpr (IS_ABL & 1) {
+                                asm volatile("" ::"v"(A[0][0]), "v"(A[0][1]));
+                            } else {
+                                if constexpr (IS_BORDER) conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true, true, 1, C::TH>(p, A, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                                pmark = issued;
+                                conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true, true, IS_BORDER ? 2 : 0, C::TH>(p, A, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                                nlate = 4;
+                            }
+                        };
+                        if constexpr (EU == 0) epi14(A0);
+                        else if constexpr (EU == 1) epi14(A1);
+                        else if constexpr (EU == 2) epi14(A2);
+                        else epi14(A3);
                     }
                     // the flag of this conv: PUB_DELAY steps from now (an older one that is still pending goes out first)
                     flush_pub();
-                    pub_on = true, pub_mark = issued, pub_due = g + C::PUB_DELAY;
+                    pub_on = true, pub_mark = pmark, pub_due = g + C::PUB_DELAY;
+                    pub_late = IS_BORDER ? nlate : 0;   // store instructions of pass 2: issued behind the mark, not covered by the flag
                     pub_off = cur.selfo, pub_val = cur.f0 + (unsigned)(L0 + EU + 1);
+                    own_mark = issued;                  // this tile's own planes are complete in memory once everything up to here is acknowledged (request_group waits for it)
                     // ... and only now the LDS-DMA requests this step held back: the weights of step g + 3, the next item's x
                     prefetch_w();
                     if constexpr (EU == 4) {

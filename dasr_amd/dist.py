@@ -150,6 +150,18 @@ class DataParallelGroup:
         if self.active:
             dist.barrier()
 
+    def sync_error_words(self, words):
+        """the device-side error / gate words (the chained launches' error word, Adam's non-finite flag) are per rank; a rank whose word tripped skips its
+        updates alone and raises alone, the others block in the next collective.  Called where every rank synchronises anyway (the logging interval): each int32
+        word becomes the MAX over the ranks, so every rank gates and raises together."""
+        if not self.active or not words:
+            return
+        dev = 'cuda' if self.backend == 'nccl' else 'cpu'
+        t = torch.stack([w.reshape(-1)[0].to(dev) for w in words]).to(torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        for i, w in enumerate(words):
+            w.reshape(-1)[0:1].copy_(t[i:i + 1])
+
     def max_over_ranks(self, value):
         if not self.active:
             return value

@@ -216,7 +216,7 @@ class _GPlan:
             # gscale * dL/ds[j] (j = 0 .. nb) and gscale * dL/dh[k] in f16: ONE buffer per level (round 4), so that the 2 nb weight gradients of the
             # residual blocks run as ONE grouped launch behind the data-gradient chain (16 parts x 16 pixel splits instead of 16 launches of
             # 1 part x 256 splits: a sixteenth of the partial-sum traffic, one reduce instead of sixteen); 2 nb x 67 MB at batch 8 x 256^2
-            self.g_s16 = [B16() for j in range(nb + 1)]   # (level 0 has no 16-bit consumer; written all the same: one epilogue variant for all blocks)
+            self.g_s16 = [None] + [B16() for j in range(1, nb + 1)]   # (level 0 has no 16-bit consumer: not allocated, not written -- ADVICE r05: 67 MB and one store stream at 8 x 256^2)
             self.g_h16 = [B16() for _ in range(nb)]
             # dL/dfake of the mean losses is ~(largest loss weight) / (number of output elements): a power of two puts it at ~2^-3 before the f16
             # rounding.  net.loss_weight = max(w_col, w_tex, w_per) (set by DSNModel; 1 for a bare generator): with w_col = 0 the gradient is
@@ -350,7 +350,7 @@ class _GPlan:
                 wg16_part(pre + 'conv1.', g_h16, self.s16[k])
                 nxt = self.g_s[1] if gs is self.g_s[0] else self.g_s[0]
                 b.add(conv_op(pack, pk['r%d_1_b16' % k], g_h16.view(), False, 64, H, W, H, W, N, alpha=inv, res1=gs.view(), beta1=1.0,
-                              out_f32=nxt.view(), out_bf16=self.g_s16[k].view(), out16_f16=1, gamma=self.gscale))
+                              out_f32=nxt.view(), out_bf16=self.g_s16[k].view() if k > 0 else None, out16_f16=1, gamma=self.gscale))
                 gs = nxt
                 continue
             wg(pre + 'conv2.', gs, self.h[k], 64, 64, H, W, H, W)

@@ -68,7 +68,9 @@ class AdamHIP:
 
     def __init__(self, params, lr, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8, gate=None):
         """gate: device int32 word; while it is non-zero a step changes nothing (dasr_adam gate_flag).  The trainers pass the error word of the
-        generator's chained trunk launches (RRDBNetHIP.chain_err): a step whose trunk ran behind a broken neighbour wait never reaches the weights."""
+        generator's chained trunk launches (RRDBNetHIP.chain_err): a step whose trunk ran behind a broken neighbour wait never reaches the weights.
+        (The host-side step_count still advances on a gated step: such a run is not resumed -- the trainers raise at the next logging interval, on every
+        rank under data parallelism (DataParallelGroup.sync_error_words), and refuse to write a checkpoint while the word is set.)"""
         self.params, self.lr, self.betas, self.wd, self.eps = params, lr, betas, weight_decay, eps
         self.gate = gate
         self.step_count = 0
@@ -427,6 +429,8 @@ class SRModel(BaseModel):
 
     def check_finite(self):
         """raise FloatingPointError if a non-finite gradient reached an optimiser since the last check (every rank; see AdamHIP.check_finite)"""
+        if self.dp is not None and self.dp.active:   # every rank sees every rank's words: all gate / raise together
+            self.dp.sync_error_words([self.optimizer_G.nonfinite, self.netG.chain_err])
         self.optimizer_G.check_finite('generator')
         for plan in (getattr(self, '_out_plans', None) or []):
             plan.check_chain()

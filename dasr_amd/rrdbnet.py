@@ -60,8 +60,8 @@ class RRDBNetHIP:
         self.chain = os.environ.get('DASR_CHAIN', '1') == '1' and not self.rdb_f16
         # DASR_CHAIN_FORM: 'is' (round 6) = the chained launches in their input-stationary form (dasr_rdb_chain: every slab chunk staged once per dense block,
         # one 8-wave workgroup per CU owning N * tiles / 256 tiles); 'layer' = round 4's layer-by-layer form (dasr_conv_chain, exactly 512 tiles per launch)
-        self.chain_form = os.environ.get('DASR_CHAIN_FORM', 'layer')
-        assert self.chain_form in ('is', 'layer')
+        self.chain_form = os.environ.get('DASR_CHAIN_FORM', 'auto')   # 'auto': the layer form where it fits, else the input-stationary form (chain_choice)
+        assert self.chain_form in ('auto', 'is', 'layer')
         # ONE error word for every chained launch of this network (all plans): non-zero = a neighbour wait gave up, the step's results are not valid.
         # The optimisers that depend on this generator take it as their gate (AdamHIP(gate=...): such a step never reaches the weights); the trainers
         # read it where they synchronise anyway (log interval, checkpoints) and raise (check_chain).
@@ -159,34 +159,49 @@ class RRDBNetHIP:
         self.pack.run()
 
     def chain_ok(self, N, h, w):
-        """a training plan of this shape runs its trunk as chained launches (dasr_conv_chain): chain_split(N, h, w) > 0"""
+        """a training plan of this shape runs its trunk as chained launches (dasr_conv_chain / dasr_rdb_chain): chain_split(N, h, w) > 0"""
         return self.chain_split(N, h, w) > 0
 
     def chain_split(self, N, h, w):
-        """number of image sub-batches the trunk of a training plan runs as chained launches, 0 = one launch per conv.  A chained launch needs whole
-        images per XCD and exactly 512 tiles (dasr_conv_chain): N images of T tiles qualify when N T = 512 k and N / k is a multiple of 8 -- the plan then
-        runs k launches BACK TO BACK over image ranges of N / k (k = 1 at configs[1]; k = 2 for configs[2]'s 32 crops of 128 x 128: at batch 32 the
-        per-layer launches run a dense block in 274 + 287 us, two chained half-batches in 2 x (131 + 129) us).
-        (Round 5 also built a form whose workgroups own several tiles -- one launch over 1024 tiles: bit-identical, but 88 ms per GAN step against 72 ms
-        with one launch per conv; it lives in the -DDASR_BENCH library only, profiles/r05_chain_trace.txt.)"""
-        ntiles = N * ceil_div(h, 16) * ceil_div(w, 32)
-        if self.chain_form == 'is':   # one launch: whole images per XCD, every one of the 256 workgroups owns ntiles / 256 (<= 8) tiles; 64 + 4 x 32 channel slabs;
-            # all tiles of an image in flight at once (32 workgroups per XCD): tiles per image divides 32
-            tpi = ceil_div(h, 16) * ceil_div(w, 32)
-            if not (self.chain and N % 8 == 0 and ntiles % 256 == 0 and 1 <= ntiles // 256 <= 8 and 32 % tpi == 0 and self.nf == 64 and not getattr(self, 'debug_taps', ())):
-                return 0
-            k = 1
-        else:
-            k = ntiles // 512
-            kmax = int(os.environ.get('DASR_CHAIN_SPLIT', '4'))   # DASR_CHAIN_SPLIT=1: exact fit only (A/B)
-            if not (self.chain and k >= 1 and k <= kmax and ntiles == 512 * k and N % k == 0 and (N // k) % 8 == 0 and not getattr(self, 'debug_taps', ())):
-                return 0
+        """number of chained launches per direction the trunk of a training plan of this shape runs as, 0 = one launch per conv (see chain_choice)"""
+        return self.chain_choice(N, h, w)[1]
+
+    def chain_choice(self, N, h, w):
+        """(form, k, why): how the trunk of a training plan of this shape runs.
+        form 'layer', k >= 1: round 4's layer-by-layer chained launches (dasr_conv_chain).  A launch needs whole images per XCD and exactly 512 tiles: N images of T
+            tiles qualify when N T = 512 k and N / k is a multiple of 8 -- the plan then runs k launches BACK TO BACK over image ranges of N / k (k = 1 at configs[1];
+            k = 2 for configs[2]'s 32 crops of 128 x 128: at batch 32 the per-layer launches run a dense block in 274 + 287 us, two chained half-batches in 2 x (131 + 129) us).
+            (Round 5 also built a form whose workgroups own several tiles -- bit-identical, but 88 ms per GAN step against 72 ms; -DDASR_BENCH library only.)
+        form 'is', k = 1: round 6's input-stationary chained launch (dasr_rdb_chain, csrc/rdb_is.h): every slab chunk staged once per dense block, one 8-wave workgroup
+            per CU owning N T / 256 (<= 8) tiles; whole images per XCD (N % 8 == 0), N T a multiple of 256, and every tile of an image in flight at once (T divides 32).
+            Measured (profiles/r06_shapes.txt): level with the layer form where both apply (31.3 vs 30.6 ms at 16 x 128^2), 6-23 % faster than one launch per conv where
+            only it applies (batch 8 / 24 of 128^2, 16 x 64 x 128, 32 x 64^2) -- so DASR_CHAIN_FORM=auto (default) takes 'layer' where it fits and 'is' otherwise.
+        form None, k = 0: one launch per conv; `why` names the clause that refused both forms (logged once per plan)."""
+        T = ceil_div(h, 16) * ceil_div(w, 32)
+        ntiles = N * T
+        if not self.chain:
+            return None, 0, 'chained launches are off (DASR_CHAIN=0 or f16 dense blocks)'
+        if getattr(self, 'debug_taps', ()):
+            return None, 0, 'debug taps between the layers'
         from . import dist as _dist
         if _dist.SHARED_DEVICE:   # another rank of this job runs on the same GPU (gloo test set-up): the launch would not have the chip to itself
-            return 0
-        if not hasattr(self, '_cus'):   # 512 workgroups = 2 per CU of a whole MI355X (8 XCDs x 32 CUs); a partitioned device (CPX / DPX) has fewer
+            return None, 0, 'another rank of this job shares the device'
+        if not hasattr(self, '_cus'):   # a chained launch fills a whole MI355X (8 XCDs x 32 CUs) exactly; a partitioned device (CPX / DPX) has fewer CUs
             self._cus = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == 'cuda' else 0
-        return k if self._cus == 256 else 0
+        if self._cus != 256:
+            return None, 0, 'the device does not expose 256 CUs (partitioned, or no GPU)'
+        why = []
+        if self.chain_form in ('auto', 'layer'):
+            k = ntiles // 512
+            kmax = int(os.environ.get('DASR_CHAIN_SPLIT', '4'))   # DASR_CHAIN_SPLIT=1: exact fit only (A/B)
+            if k >= 1 and k <= kmax and ntiles == 512 * k and N % k == 0 and (N // k) % 8 == 0:
+                return 'layer', k, ''
+            why.append('layer form: %d tiles are not 512 k (k <= %d) with N / k a multiple of 8' % (ntiles, kmax))
+        if self.chain_form in ('auto', 'is'):
+            if N % 8 == 0 and ntiles % 256 == 0 and 1 <= ntiles // 256 <= 8 and 32 % T == 0 and self.nf == 64:
+                return 'is', 1, ''
+            why.append('input-stationary form: needs N %% 8 == 0, N x tiles a multiple of 256 (<= 2048), tiles per image (%d) a divisor of 32, nf 64' % T)
+        return None, 0, '; '.join(why)
 
     # ---- plan ---------------------------------------------------------------------------------------
     def plan(self, N, h, w, replica=0, store=None, n0=0):
@@ -532,7 +547,15 @@ class _Plan:
         # its neighbour tiles only before the input chunks the previous layer produced.  Needs whole images per XCD (N % 8 == 0) and every workgroup
         # resident with the chip exactly full (N * tiles == 512); the taps of the tests sit between layers and keep the per-layer launches.
         tiles = ceil_div(h, 16) * ceil_div(w, 32)
-        nsub = 0 if self.inference else net.chain_split(N, h, w)   # sub-batches of 512 tiles, each one chained launch (1 at configs[1], 2 at configs[2])
+        # (a plan built as one of several CONCURRENT sub-batch replicas never chains -- a chained launch needs every workgroup slot of the device, two of
+        # them at once starve each other until the neighbour waits time out)
+        form, nsub, why = (None, 0, 'inference plan') if self.inference else net.chain_choice(N, h, w)
+        if nsub and (self.shared_store or self.replica > 0 or getattr(net, 'concurrent_replicas', 1) > 1):
+            form, nsub, why = None, 0, 'the plan is one of several concurrent sub-batch replicas'
+        self.chain_form, self.chain_why = form, why
+        if not self.inference:
+            import logging
+            logging.getLogger('base').info('RRDBNet trunk at %d x %d x %d: %s' % (N, h, w, ('%d chained launch(es) per direction, %s form' % (nsub, form)) if nsub else ('one launch per conv (%s)' % why)))
         chain = [] if nsub else None
         trunk_ops = ops if chain is None else OpList()
         main_ops, ops = ops, trunk_ops
@@ -575,7 +598,7 @@ class _Plan:
             deps = [0 if k % 5 == 0 else (o.conv.cin // 16) - GC // 16 for k, o in enumerate(body)]
             per = N // nsub
             self.chains = []   # (the last conv5 has no 16-bit shadow to write: its own launch, over the whole batch; the input-stationary form runs it too)
-            if net.chain_form == 'is':
+            if self.chain_form == 'is':
                 ch = ConvChain(body, deps, N, tiles, net.device, err=net.chain_err, form='is')
                 self.chains.append(ch)
                 ops.add(ch.op())
@@ -867,7 +890,7 @@ class _Plan:
             per = N // nsub
             ops = main_ops
             self.chains_b = []   # (the last conv writes no 16-bit planes: its own launch)
-            if net.chain_form == 'is':
+            if self.chain_form == 'is':
                 ch = ConvChain(body, deps, N, tiles, net.device, err=self.chain.err, form='is')
                 self.chains_b.append(ch)
                 ops.add(ch.op())
@@ -925,11 +948,12 @@ class _Plan:
         optimiser step.)"""
         segs = self.bwd_segments()
         has_chain = [any(o.op in (_lib.OP_CONV_CHAIN, _lib.OP_RDB_CHAIN) for o in seg.ops) for seg, _ in segs]
-        held = []
+        last_chain = max([k for k, c in enumerate(has_chain) if c], default=-1)   # (ADVICE r05: EVERY bucket in front of the last chain-bearing segment is held, not only the one
+        held = []                                                                  #  directly in front of it: a bucket mark ahead of the trunk must not bring the overlap back)
         for k, (seg, (lo, hi)) in enumerate(segs):
             seg.run()
             held.append((lo, hi))
-            if k + 1 < len(segs) and has_chain[k + 1]:
+            if k < last_chain:
                 continue
             for a, b in held:
                 dp.reduce_async(g[a:b])

@@ -21,8 +21,9 @@
 extern "C" {
 #endif
 
-#define DASR_ABI_VERSION 17
+#define DASR_ABI_VERSION 18
 #define DASR_EINVAL (-22)
+#define DASR_ECAPTURE (-16)   /* a launch needed a device allocation (the scratch row of a deterministic grid sum, first use per accumulator and stream) while its stream was being captured */
 
 typedef struct {
     void*   p;          /* base of plane 0 (device pointer) */
@@ -471,6 +472,9 @@ int dasr_prof_end(int32_t max_out, float* us_out, double* flops_out, double* byt
 
 /* ---- diagnostics ----------------------------------------------------------------------------------*/
 int dasr_abi_version(void);
+/* Frees the scratch rows of the deterministic grid sums (one per (device, loss accumulator, stream), allocated on first use and otherwise kept for the life of the
+ * process).  The caller guarantees that no launch of this library is in flight.  Returns 0. */
+int dasr_red_release(void);
 /* 1 if ds_read_b64_tr_b16 has the lane mapping the wgrad kernel assumes on this device, 0 if not, <0 on error.
  * Must be called once per process before dasr_wgrad (it also selects the wgrad gather mode). */
 int dasr_probe_tr16(void* stream);

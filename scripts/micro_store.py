@@ -8,7 +8,6 @@ import torch
 from dasr_amd import _lib, engine
 engine.ensure_runtime_ready()
 L = _lib.bench_lib()
-L.dasr_probe_store.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
 buf = torch.zeros(256 * 192 * 1024 * 41, dtype=torch.uint8, device='cuda')   # 2 GB: 40 regions of 48 MB for the roaming modes
 cyc = torch.zeros(256, dtype=torch.int64, device='cuda')
 print('%-8s %-6s %-20s %10s %12s' % ('blocks', 'KiB', 'store', 'cycles', 'B/clk/CU'))

@@ -226,20 +226,27 @@ def test_f16_dense_block_gradient_scale_is_consistently_patched(monkeypatch):
         assert worst < 2e-3, worst
 
 
-@pytest.mark.parametrize('shape', [(16, 128, 128, 2), (8, 256, 128, 1), (32, 128, 128, 1), (24, 128, 256, 1)], ids=['16x128x128', '8x256x128', '32x128x128-two_sub_batches', '24x128x256-three_sub_batches'])
+@pytest.mark.parametrize('shape', [(16, 128, 128, 2, 'layer'), (8, 256, 128, 1, 'layer'), (32, 128, 128, 1, 'layer'), (24, 128, 256, 1, 'layer'),
+                                   (16, 128, 128, 2, 'is'), (8, 128, 128, 2, 'is'), (32, 128, 128, 1, 'is'), (24, 128, 128, 1, 'is'), (64, 64, 64, 1, 'is'), (8, 128, 112, 3, 'is')],
+                         ids=['16x128x128', '8x256x128', '32x128x128-two_sub_batches', '24x128x256-three_sub_batches',
+                              'is-16x128x128-two_tiles_per_workgroup', 'is-8x128x128-one_tile', 'is-32x128x128-four_tiles', 'is-24x128x128-three_tiles', 'is-64x64x64-four_images_per_xcd',
+                              'is-8x128x112-partial_tiles-rrdb_residual'])
 def test_chained_trunk_launches_are_bit_identical_to_per_layer_launches(shape, monkeypatch):
     """DASR_CHAIN (default on where the batch fills the chip exactly, RRDBNetHIP.chain_ok): the 15 nb dense-block convs of the forward and of the data
     gradient each run as ONE persistent launch in which a tile waits for its neighbour tiles only before the input chunks the previous layer wrote
     (dasr_conv_chain).  Same arithmetic in the same order: SR output, every gradient and the weights after two Adam steps must be BIT-identical to the
     per-layer launches, and the device error word stays zero (no neighbour wait gave up).  Round 5: batches of k x 512 tiles run k chained launches back to
-    back over image ranges (RRDBNetHIP.chain_split: configs[2]'s 32 crops = two launches of 16)."""
+    back over image ranges (RRDBNetHIP.chain_split: configs[2]'s 32 crops = two launches of 16).  Round 6: the INPUT-STATIONARY form (dasr_rdb_chain, csrc/rdb_is.h: every slab
+    chunk staged once per dense block, every accumulator receives its products in the order of the per-layer kernel) -- one launch over all 15 nb convs, one to eight tiles per
+    workgroup, one to four images per XCD and slot, partial tiles, the RRDB residual (nb 3: three dense blocks with the second fp32 residual)."""
     _gpu()
     if torch.cuda.get_device_properties(0).multi_processor_count != 256:
         pytest.skip('the chained launches need a whole 256-CU MI355X (RRDBNetHIP.chain_ok)')
     from oracle import fixtures
     from dasr_amd import options
     from dasr_amd.models import create_model
-    n, h, w, nb = shape
+    n, h, w, nb, form = shape
+    monkeypatch.setenv('DASR_CHAIN_FORM', form)
     case = dict(kind='sr', nf=64, nb=nb, n=n, lr=(h, w))
     batch = fixtures.make_batch(case, seed=11)
     outs = []
@@ -258,9 +265,12 @@ def test_chained_trunk_launches_are_bit_identical_to_per_layer_launches(shape, m
         m.check_finite()                         # includes the chains' error word
         plans = m._out_plans
         if chain == '1':
-            assert len(plans) == 1 and plans[0].chain is not None and plans[0].chain_b is not None
-            assert plans[0].chain.n == 15 * nb - 1 and plans[0].chain_b.n == 15 * nb - 1
-            assert len(plans[0].chains) == len(plans[0].chains_b) == m.netG.chain_split(n, h, w) == n * ((h + 15) // 16) * ((w + 31) // 32) // 512
+            assert len(plans) == 1 and plans[0].chain is not None and plans[0].chain_b is not None and plans[0].chain.form == plans[0].chain_b.form == form
+            if form == 'is':
+                assert plans[0].chain.n == 15 * nb and plans[0].chain_b.n == 15 * nb and len(plans[0].chains) == len(plans[0].chains_b) == m.netG.chain_split(n, h, w) == 1
+            else:
+                assert plans[0].chain.n == 15 * nb - 1 and plans[0].chain_b.n == 15 * nb - 1
+                assert len(plans[0].chains) == len(plans[0].chains_b) == m.netG.chain_split(n, h, w) == n * ((h + 15) // 16) * ((w + 31) // 32) // 512
         else:
             assert all(getattr(p, 'chain', None) is None for p in plans)
         outs.append((m.fake_H.clone(), m.netG.params.grad.clone(), m.netG.params.flat.clone()))
@@ -276,6 +286,7 @@ def test_chain_refuses_shapes_that_do_not_fill_the_chip():
         assert not net.chain_ok(16, 128, 128)   # a partitioned device: never
         return
     assert net.chain_ok(16, 128, 128) and net.chain_ok(8, 128, 256) and net.chain_ok(32, 64, 128)
-    assert not net.chain_ok(16, 64, 64) and not net.chain_ok(4, 256, 256) and not net.chain_ok(12, 128, 128) and not net.chain_ok(24, 128, 128)
+    assert not net.chain_ok(16, 64, 64) and not net.chain_ok(4, 256, 256) and not net.chain_ok(12, 128, 128) and not net.chain_ok(16, 192, 192)
+    assert net.chain_choice(24, 128, 128)[:2] == ('is', 1) and net.chain_choice(8, 128, 128)[:2] == ('is', 1) and net.chain_choice(16, 128, 128)[:2] == ('layer', 1)
     assert (net.chain_split(16, 128, 128), net.chain_split(32, 128, 128), net.chain_split(48, 128, 128), net.chain_split(20, 128, 128)) == (1, 2, 3, 0)   # (20: 640 tiles)
     assert net.chain_split(80, 128, 128) == 0   # five sub-batches: over the limit of four (DASR_CHAIN_SPLIT)

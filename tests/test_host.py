@@ -421,15 +421,25 @@ def test_chain_split_rule():
     from types import SimpleNamespace as NS
     from dasr_amd.rrdbnet import RRDBNetHIP
     net = NS(chain=True, _cus=256, chain_form='layer', nf=64)
-    f = lambda N, h, w: RRDBNetHIP.chain_split(net, N, h, w)
+    f = lambda N, h, w: RRDBNetHIP.chain_choice(net, N, h, w)[1]
     assert (f(16, 128, 128), f(8, 256, 128), f(32, 64, 128), f(32, 128, 128), f(24, 128, 256), f(64, 128, 128)) == (1, 1, 1, 2, 3, 4)
     assert (f(16, 64, 64), f(12, 128, 128), f(20, 128, 128), f(24, 128, 128), f(80, 128, 128), f(4, 256, 256)) == (0, 0, 0, 0, 0, 0)   # too few / not 512 k / images per XCD / > 4
-    assert RRDBNetHIP.chain_split(NS(chain=False, _cus=256, chain_form='layer'), 16, 128, 128) == 0 and RRDBNetHIP.chain_split(NS(chain=True, _cus=64, chain_form='layer'), 16, 128, 128) == 0
+    g = lambda ns: RRDBNetHIP.chain_choice(ns, 16, 128, 128)[1]
+    assert g(NS(chain=False, _cus=256, chain_form='layer')) == 0 and g(NS(chain=True, _cus=64, chain_form='layer')) == 0
     # the input-stationary form (round 6, dasr_rdb_chain): one launch; whole images per XCD, N * tiles a multiple of 256 (<= 8 tiles per workgroup), tiles per image divides 32
     net = NS(chain=True, _cus=256, chain_form='is', nf=64)
     assert (f(16, 128, 128), f(8, 128, 128), f(32, 128, 128), f(64, 128, 128), f(16, 64, 128), f(64, 64, 64), f(8, 128, 112)) == (1, 1, 1, 1, 1, 1, 1)
     assert (f(8, 256, 128), f(24, 128, 256), f(12, 128, 128), f(16, 64, 64), f(4, 256, 256), f(128, 128, 128), f(16, 32, 32)) == (0, 0, 0, 0, 0, 0, 0)   # 64 tiles per image / ... / > 8 per workgroup / < 256 tiles
-    assert RRDBNetHIP.chain_split(NS(chain=True, _cus=256, chain_form='is', nf=32), 16, 128, 128) == 0
+    assert g(NS(chain=True, _cus=256, chain_form='is', nf=32)) == 0
+    # the default: the layer form where it fits, else the input-stationary form; the refusal names its clause (the decisions at batch 12 / 20 / 24 x 128^2, 16 x 192^2)
+    net = NS(chain=True, _cus=256, chain_form='auto', nf=64)
+    c = lambda N, h, w: RRDBNetHIP.chain_choice(net, N, h, w)[:2]
+    assert (c(16, 128, 128), c(32, 128, 128), c(8, 256, 128), c(24, 128, 256)) == (('layer', 1), ('layer', 2), ('layer', 1), ('layer', 3))
+    assert (c(8, 128, 128), c(24, 128, 128), c(40, 128, 128), c(16, 64, 128), c(32, 64, 64)) == (('is', 1),) * 5
+    assert (c(12, 128, 128), c(20, 128, 128), c(16, 192, 192), c(16, 32, 32)) == ((None, 0),) * 4
+    why = RRDBNetHIP.chain_choice(net, 16, 192, 192)[2]
+    assert 'layer form' in why and 'input-stationary form' in why and '72' in why   # 12 x 6 tiles per image: not a divisor of 32, 1152 tiles not 512 k
+    assert 'DASR_CHAIN=0' in RRDBNetHIP.chain_choice(NS(chain=False), 16, 128, 128)[2]
 
 
 def test_crc32c_fast_path_equals_the_byte_loop():
