@@ -100,7 +100,25 @@ def profiled_steps(run_step, nsteps=1, capacity=16384):
     return recs, wall, n >= capacity
 
 
-def roofline_from_step(run_step, peak_measured, streams, nsteps=1):
+def dominant_kernel_timed(run_step, raw_tag, nsteps):
+    """average launch duration of ONE kernel family over `nsteps` ordinary steps: a profiling session filtered to its launches (dasr_prof_filter: two events per
+    matching launch, nothing else), and the wall time of those steps.  VERDICT r05 item 3: a step in which every launch carries events ran ~6 % slower than a timed step
+    and the per-launch figure of the chained launches inherited it (9.5-9.9 ms in the bench line against 8.9 ms in rocprofv3's kernel stats)."""
+    from dasr_amd import _lib
+    L = _lib.lib()
+    key = raw_tag.split('(')[0].split('::')[-1] if '::' in raw_tag else raw_tag   # launcher name, or the kernel's own tag
+    key = key[:100]
+    torch.cuda.synchronize()
+    _lib.check(L.dasr_prof_filter(key.encode()), 'prof_filter')
+    try:
+        recs, wall, _ = profiled_steps(run_step, nsteps, capacity=4096)
+    finally:
+        _lib.check(L.dasr_prof_filter(None), 'prof_filter')
+    us = [r[1] for r in recs if r[0] == raw_tag]
+    return (sum(us) / len(us) if us else None), len(us), wall / nsteps * 1e3
+
+
+def roofline_from_step(run_step, peak_measured, streams, nsteps=1, timed_steps=0):
     recs, wall, truncated = profiled_steps(run_step, nsteps)
     rows, buckets = {}, {}
     for tag, us, fl, bk in recs:
@@ -125,6 +143,17 @@ def roofline_from_step(run_step, peak_measured, streams, nsteps=1):
                     'share_of_kernel_time': round(r['total_us'] / ksum, 4)})
     other = sum(r['total_us'] for r in rows.values() if r['flops'] <= 0)
     head = dict(out[0]) if out else {}
+    head_raw = max((kv for kv in rows.items() if kv[1]['flops'] > 0), key=lambda kv: kv[1]['total_us'])[0] if out else None
+    timed = None
+    if head and timed_steps > 0:
+        # the dominant kernel again, over ordinary steps: only ITS launches carry events (two per launch); this is the figure `achieved` / `frac` are computed from
+        t_us, t_n, t_ms = dominant_kernel_timed(run_step, head_raw, timed_steps)
+        if t_us:
+            timed = {'avg_launch_us': round(t_us, 2), 'launches': t_n, 'steps': timed_steps, 'ms_per_step_of_those_steps': round(t_ms, 2),
+                     'avg_launch_us_in_fully_instrumented_step': head['avg_launch_us']}
+            head['avg_launch_us'] = round(t_us, 2)
+            head['achieved'] = round(head['flops_per_launch'] / t_us / 1e6, 1)
+            head['frac'] = round(head['achieved'] / PEAK_BF16_TFLOPS, 4)
     overlap = ksum / (wall * 1e6) if wall > 0 else None
     traffic, tsrc = None, None
     try:  # HBM bytes per launch of the headline kernel: from the committed PMC passes (rocprofv3 --pmc cannot run inside bench.py)
@@ -146,11 +175,14 @@ def roofline_from_step(run_step, peak_measured, streams, nsteps=1):
             'flops_per_launch': head.get('flops_per_launch'),
             'peak_at_observed_clock': round(peak_measured, 1) if peak_measured else None,
             'frac_of_peak_at_observed_clock': round(head['achieved'] / peak_measured, 4) if (peak_measured and head) else None,
+            'dominant_kernel_over_ordinary_steps': timed,
             'streams': streams, 'kernel_time_over_wall': round(overlap, 3) if overlap else None,
             'non_mfma_kernel_time_share': round(other / ksum, 4) if ksum else None,
-            'method': 'one extra production step after the timed region; every launch has its own start/stop events on its launch stream '
-                      '(hipExtLaunchKernel = the dispatch timestamps rocprofv3 --kernel-trace reports); achieved = algorithmic FLOPs per launch / '
-                      'average launch duration; headline = kernel with the largest total time; with streams > 1 launches of the sub-batch '
+            'method': 'one extra production step after the timed region in which every launch has its own start/stop events on its launch stream '
+                      '(hipExtLaunchKernel = the dispatch timestamps rocprofv3 --kernel-trace reports) gives the per-kernel table and names the headline '
+                      'kernel (largest total time); the headline kernel is then timed AGAIN over ordinary steps in which only its launches carry events '
+                      '(dominant_kernel_over_ordinary_steps: the fully instrumented step runs ~6 % slower and inflated it); achieved = algorithmic FLOPs '
+                      'per launch / that average launch duration; with streams > 1 launches of the sub-batch '
                       'streams overlap (kernel_time_over_wall = sum of launch durations / step wall time), so the chip-level rate of a kernel '
                       'is up to that factor above its per-launch rate',
             'mfma_busy_pmc': busy, 'per_kernel': out[:8], 'truncated': truncated,
@@ -433,7 +465,7 @@ def bench_srn(a, dp, dasr, as_secondary=False):
         BL = _lib.bench_lib()   # probes live in libdasr_bench.so, not in the product library
         peak_measured = pk.value if BL.dasr_probe_mfma_peak(20000, C.byref(pk), None) == 0 else None
         streams = len(getattr(model, '_out_plans', None) or [0])
-        out['roofline'] = roofline_from_step(one_step, peak_measured, streams)
+        out['roofline'] = roofline_from_step(one_step, peak_measured, streams, timed_steps=max(2, min(a.steps, 6)))
         # the same MFMA-only stream on operands that toggle (random bf16 in (-1, 1)) and on all-zero operands: the spread is the clock the power
         # management allows under that switching activity -- the ceiling an MFMA-bound kernel on real data can approach on this box
         pr = {}
@@ -441,6 +473,11 @@ def bench_srn(a, dp, dasr, as_secondary=False):
             if BL.dasr_probe_mfma_data(19968, mode, C.byref(pk), None) == 0:
                 pr[key] = round(pk.value, 1)
         out['roofline']['mfma_only_tflops_by_operand_data'] = pr
+        if pr.get('random_bf16') and out['roofline'].get('achieved'):
+            # the dense-MFMA rate THIS box sustains on operands that toggle (the clock its power management allows under that switching activity): the ceiling an
+            # MFMA-bound kernel on real data can approach here; `peak` / `frac` stay the guide's 2.5 PFLOP/s
+            out['roofline']['peak_on_data'] = pr['random_bf16']
+            out['roofline']['frac_of_peak_on_data'] = round(out['roofline']['achieved'] / pr['random_bf16'], 4)
         log('roofline done')
     elif not as_secondary:
         one_step()  # the other ranks take part in the profiled step's collectives

@@ -126,6 +126,7 @@ _SIGS = {
     'dasr_last_failed_op': [],
     'dasr_ddm_spread': [Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, Tensor, c_vp],
     'dasr_abi_version': [],
+    'dasr_prof_filter': [C.c_char_p],
     'dasr_red_release': [],
     'dasr_probe_tr16': [c_vp],
     'dasr_rccl_unique_id': [c_vp],

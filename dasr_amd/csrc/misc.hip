@@ -1,5 +1,6 @@
 // Weight packing, HBM-bound elementwise kernels, fused Adam and the op-list executor (gfx950).
 #include "common.h"
+#include <string.h>
 #include <atomic>
 #include <condition_variable>
 #include <map>
@@ -676,10 +677,12 @@ std::atomic<bool> g_prof_on{false};
 // algorithmic work of the op being dispatched (consumed by its first launch); per enqueue thread (dasr_run_ops_mt)
 thread_local double g_prof_flops = 0.0, g_prof_bytes = 0.0;
 thread_local int g_prof_op = 0;
+char g_prof_filter[128] = {0};   // non-empty: only launches whose tag contains it get events (dasr_prof_filter)
 }  // namespace
 
 bool dasr_prof_slot(const char* tag, hipEvent_t* e0, hipEvent_t* e1) {
     if (!g_prof_on.load(std::memory_order_relaxed)) return false;
+    if (g_prof_filter[0] && !strstr(tag, g_prof_filter)) return false;
     const int slot = g_prof_n.fetch_add(1, std::memory_order_relaxed);
     if (slot >= g_prof_cap) {
         g_prof_n.store(g_prof_cap, std::memory_order_relaxed);
@@ -694,6 +697,15 @@ bool dasr_prof_slot(const char* tag, hipEvent_t* e0, hipEvent_t* e1) {
     *e0 = r.e0;
     *e1 = r.e1;
     return true;
+}
+
+extern "C" int dasr_prof_filter(const char* substr) {
+    if (g_prof_on.load()) return DASR_EINVAL;   // between sessions only
+    const size_t n = substr ? strlen(substr) : 0;
+    if (n >= sizeof(g_prof_filter)) return DASR_EINVAL;
+    memset(g_prof_filter, 0, sizeof(g_prof_filter));
+    if (n) memcpy(g_prof_filter, substr, n);
+    return 0;
 }
 
 extern "C" int dasr_prof_begin(int32_t capacity) {

@@ -469,6 +469,10 @@ int dasr_rccl_destroy(void* comm);
  * static string naming the kernel variant.  Returns the number of records written (<= max_out) or a negative error. */
 int dasr_prof_begin(int32_t capacity);
 int dasr_prof_end(int32_t max_out, float* us_out, double* flops_out, double* bytes_out, int32_t* op_out, const char** tag_out);
+/* Restricts the NEXT profiling sessions to launches whose tag (kernel name / launcher signature) contains `substr` (NULL or "": every launch again).  A session over
+ * one kernel family costs two events per matching launch and nothing else: bench.py times the dominant kernel this way over ordinary steps (round 6: a step in which
+ * EVERY launch carries events runs ~6 % slower and over-reported the chained launches by 7-11 %).  DASR_EINVAL while a session is open. */
+int dasr_prof_filter(const char* substr);
 
 /* ---- diagnostics ----------------------------------------------------------------------------------*/
 int dasr_abi_version(void);
