@@ -106,8 +106,8 @@ def dominant_kernel_timed(run_step, raw_tag, nsteps):
     and the per-launch figure of the chained launches inherited it (9.5-9.9 ms in the bench line against 8.9 ms in rocprofv3's kernel stats)."""
     from dasr_amd import _lib
     L = _lib.lib()
-    key = raw_tag.split('(')[0].split('::')[-1] if '::' in raw_tag else raw_tag   # launcher name, or the kernel's own tag
-    key = key[:100]
+    m = re.search(r'(\w+)\(', raw_tag)   # launcher tags are __PRETTY_FUNCTION__ strings ("int ns::launch_x(args) [T = ...]"): filter on the function's name; kernels tag themselves
+    key = (m.group(1) if m else raw_tag)[:100]
     torch.cuda.synchronize()
     _lib.check(L.dasr_prof_filter(key.encode()), 'prof_filter')
     try:
@@ -407,7 +407,7 @@ def bench_srn(a, dp, dasr, as_secondary=False):
     world = dp.world if dp else 1
     rank = dp.rank if dp else 0
     torch.manual_seed(0)
-    batch = (32 if dasr else 16) if as_secondary else a.batch
+    batch = (getattr(a, 'sec_batch', None) or (32 if dasr else 16)) if as_secondary else a.batch
     model = create_model(options.dict_to_nonedict(make_dasr_opt(a.nf, a.nb, a.fs, a.fea) if dasr else make_opt(a.nf, a.nb)))
     if dp:
         model.dp = dp
@@ -447,7 +447,7 @@ def bench_srn(a, dp, dasr, as_secondary=False):
            'dtype': ('f16 MFMA operands (DASR_RDB_PREC=2), fp32 accumulate / fp32 residual stream' if getattr(model.netG, 'rdb_f16', False)
                      else 'bf16 MFMA operands, fp32 accumulate / fp32 residual stream'),
            'data': 'synthetic (torch.rand, seed 1234+rank; kaiming x0.1 weights, seed 0)',
-           'config': {'workload': ('configs[2]: full SRN GAN step (RRDBNet nf=%d nb=%d + NLayer patch-D + %s perceptual, fs=%s), %d G crops of '
+           'config': {'workload': ((getattr(a, 'sec_label', None) or 'configs[2]') + ': full SRN GAN step (RRDBNet nf=%d nb=%d + NLayer patch-D + %s perceptual, fs=%s), %d G crops of '
                                    '%dx%d LR per GPU (n=%d source + %d target)' % (a.nf, a.nb, 'LPIPS(alex)' if a.fea == 'LPIPS' else 'VGG19-54', a.fs, batch,
                                                                                   s, s, batch // 2, batch // 2))
                       if dasr else
@@ -465,7 +465,7 @@ def bench_srn(a, dp, dasr, as_secondary=False):
         BL = _lib.bench_lib()   # probes live in libdasr_bench.so, not in the product library
         peak_measured = pk.value if BL.dasr_probe_mfma_peak(20000, C.byref(pk), None) == 0 else None
         streams = len(getattr(model, '_out_plans', None) or [0])
-        out['roofline'] = roofline_from_step(one_step, peak_measured, streams, timed_steps=max(2, min(a.steps, 6)))
+        out['roofline'] = roofline_from_step(one_step, peak_measured, streams, timed_steps=max(2, min(a.steps, 6)) if world == 1 else 0)   # (the other ranks run ONE matching step)
         # the same MFMA-only stream on operands that toggle (random bf16 in (-1, 1)) and on all-zero operands: the spread is the clock the power
         # management allows under that switching activity -- the ceiling an MFMA-bound kernel on real data can approach on this box
         pr = {}
@@ -590,8 +590,13 @@ def main():
         out['secondary'] = []
         sec_l = argparse.Namespace(**vars(sec))
         sec_l.fea, sec_l.per_type = 'LPIPS', 'LPIPS'   # the criteria the reference's shipped configs / CLI defaults select
+        # the shape the reference's SHIPPED training config runs (codes/SRN/options/train/train_DASR.json:21-22: batch_size 8 -> 2 n = 16 G crops, HR_size 128 -> 32 x 32 LR;
+        # LPIPS criterion): 32 tiles of 16 x 32 pixels per conv launch -- what a user who drops that JSON in gets
+        sec_ship = argparse.Namespace(**vars(sec_l))
+        sec_ship.lr_size, sec_ship.sec_batch, sec_ship.sec_label = 32, 16, 'shipped shape (train_DASR.json: batch_size 8, HR_size 128)'
         for fn in (lambda: bench_srn(sec, dp, True, as_secondary=True), lambda: bench_dsn(sec, dp, as_secondary=True),
-                   lambda: bench_srn(sec_l, dp, True, as_secondary=True), lambda: bench_dsn(sec_l, dp, as_secondary=True)):
+                   lambda: bench_srn(sec_l, dp, True, as_secondary=True), lambda: bench_dsn(sec_l, dp, as_secondary=True),
+                   lambda: bench_srn(sec_ship, dp, True, as_secondary=True)):
             try:
                 r = fn()
                 out['secondary'].append({k: r[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'dtype', 'config', 'roofline') if k in r})

@@ -84,7 +84,7 @@ _SIGS = {
     'dasr_pack_weights': [c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp],
     'dasr_nchw_to_blocked': [c_vp, c_i32, c_i32, c_i32, c_i32, Tensor, Tensor, c_vp],
     'dasr_blocked_to_nchw': [Tensor, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp],
-    'dasr_l1_loss': [Tensor, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, Tensor, c_i32, c_vp],
+    'dasr_l1_loss': [Tensor, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, Tensor, c_i32, c_f32, c_vp],
     'dasr_pixel_shuffle_f16': [Tensor, c_i32, c_i32, c_i32, c_i32, Tensor, c_vp],
     'dasr_pixel_unshuffle_f16': [Tensor, Tensor, c_f32, c_i32, c_i32, c_i32, c_i32, Tensor, c_vp],
     'dasr_cvt_f16': [Tensor, c_i32, c_i32, c_i32, c_i32, c_f32, Tensor, c_vp],

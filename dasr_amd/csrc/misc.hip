@@ -129,7 +129,7 @@ __global__ void blocked_to_nchw_kernel(dasr_tensor s, int N, int C, int H, int W
 
 // one thread per pixel (plane 0 only: C <= 16)
 __global__ void l1_loss_kernel(dasr_tensor sr, const float* __restrict__ hr, const float* __restrict__ wm, int N, int C, int H, int W,
-                               float coef, float* loss_acc, dasr_tensor grad, int accumulate, dasr_red rs) {
+                               float coef, float* loss_acc, dasr_tensor grad, int accumulate, float gscale, dasr_red rs) {
     const long long total = (long long)N * H * W;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     float part = 0.f;
@@ -154,7 +154,17 @@ __global__ void l1_loss_kernel(dasr_tensor sr, const float* __restrict__ hr, con
                 g[c] = coef * wgt * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
             }
         }
-        if (grad.p) {
+        if (grad.p && (accumulate & 4)) {
+            // f16 gradient tensor (round 6; the generator's f16 HR tail): f16(gscale * g) straight from here -- no padded fp32 image (64 B per pixel for 12 B of
+            // payload) and no conversion pass behind it.  Only the channel groups that hold a real channel are written: the tensor is zero beyond them and stays so.
+            f16_t* gp = (f16_t*)grad.p + (size_t)n * grad.n_stride + po;
+            for (int j = 0; j < (C + 3) / 4; ++j) {
+                f16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (f16_t)(g[4 * j + e] * gscale);
+                ((f16x4*)gp)[j] = o;
+            }
+        } else if (grad.p) {
             float* gp = (float*)grad.p + (size_t)n * grad.n_stride + po;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -299,13 +309,14 @@ extern "C" int dasr_blocked_to_nchw(dasr_tensor src, int32_t N, int32_t C, int32
 }
 
 extern "C" int dasr_l1_loss(dasr_tensor sr, const float* hr_nchw, const float* weight_map, int32_t N, int32_t C, int32_t H, int32_t W,
-                            float coef, float* loss_acc, dasr_tensor grad, int32_t accumulate, void* stream) {
+                            float coef, float* loss_acc, dasr_tensor grad, int32_t accumulate, float grad_scale, void* stream) {
     const long long total = (long long)N * H * W;
     if (total <= 0 || C > 16) return DASR_EINVAL;
+    if ((accumulate & 4) && (accumulate & 1)) return DASR_EINVAL;   // the f16 gradient form does not accumulate
     const dasr_red rs = dasr_red_scratch(loss_acc, as_stream(stream), blocks_for(total), 1);
     if (loss_acc && !rs.part) return dasr_red_error();
     DASR_LAUNCH(l1_loss_kernel, dim3(blocks_for(total)), dim3(256), 0, as_stream(stream), sr, hr_nchw, weight_map, N, C, H, W, coef,
-                       loss_acc, grad, accumulate, rs);
+                       loss_acc, grad, accumulate, grad_scale != 0.f ? grad_scale : 1.f, rs);
     return (int)hipGetLastError();
 }
 
@@ -767,7 +778,7 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream0) {
             case DASR_OP_FILL: rc = dasr_fill_f32((float*)o.p[0], o.l[0], o.f[0], stream); break;
             case DASR_OP_L1LOSS:
                 rc = dasr_l1_loss(o.t[0], (const float*)o.p[0], (const float*)o.p[1], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], (float*)o.p[2], o.t[1],
-                                  o.i[4], stream);
+                                  o.i[4], o.f[1], stream);
                 break;
             case DASR_OP_NCHW2B: rc = dasr_nchw_to_blocked((const float*)o.p[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[0], o.t[1], stream); break;
             case DASR_OP_B2NCHW: rc = dasr_blocked_to_nchw(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], (float*)o.p[0], stream); break;

@@ -254,6 +254,10 @@ class SRModel(BaseModel):
             o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = N, C_, H, W, (2 if self.pix_l2 else 0)
             o.f[0] = float(self.l_pix_w) / float(n_total * C_ * H * W)
             o.p[2], o.t[1] = self.loss_acc.data_ptr() + 4 * (plan.replica % 8), plan.g_sr.view()
+            fused = plan.take_f16_loss_gradient()   # (f16 HR tail: dL/dSR goes straight into its f16 input, pre-scaled; no fp32 image, no conversion pass)
+            if fused is not None:
+                o.t[1], o.f[1] = fused
+                o.i[4] |= 4
             ops.add(o)
             self._step_ops[key] = (ops, hr_buf)
         return self._step_ops[key]

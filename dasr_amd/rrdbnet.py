@@ -496,6 +496,23 @@ class _Plan:
         self._build_backward()
         self.ws.finalize()
 
+    def take_f16_loss_gradient(self):
+        """A trainer whose ONLY term in dL/dSR is one pixel loss (SRModel) may write it straight into the f16 tensor the HR tail's backward starts from -- pre-scaled by
+        the returned power of two -- instead of filling the padded fp32 image plan.g_sr (64 B per pixel for 12 B of payload) that a conversion pass then re-reads
+        (0.3 ms of the configs[1] step).  Returns (view of the f16 tensor, scale) and drops the conversion from plan.bwd, or None where the backward
+        does not start from an f16 tensor (fp32 HR tail).  Call once, before the plan's step lists are recorded."""
+        if self.g_sr16 is None or getattr(self, '_loss16_taken', False) or hasattr(self, 'whole_step'):
+            return None
+        o = self.bwd.ops[0]
+        assert o.op == _lib.OP_CVT_F16 and o.t[1].p == self.g_sr16.view().p
+        del self.bwd.ops[0]
+        self.bwd._arr = None
+        self.tail_end -= 1
+        self._marks = [(idx - 1, lo, hi) for idx, lo, hi in self._marks]
+        self._segments = None
+        self._loss16_taken = True
+        return self.g_sr16.view(), self.gscale
+
     def check_chain(self):
         """host sync: raise if a chained launch of this plan flagged a broken neighbour wait (the results of that step are not valid)"""
         if getattr(self, 'chain', None) is not None:

@@ -219,9 +219,11 @@ int dasr_blocked_to_nchw(dasr_tensor src, int32_t N, int32_t C, int32_t H, int32
  * coef = weight / element count is computed by the caller; `weight_map` (NCHW [N][1][H][W]) is the optional
  * domain-distance map of the multiweights pixel loss (DASR_model.py:213-215).
  * accumulate bit 0: grad += instead of grad =; bit 1: squared error (nn.MSELoss, pixel_criterion 'l2', SR_model.py:33-36):
- * loss_acc[0] += coef * sum wm*(sr - hr)^2, grad (+)= 2 coef wm (sr - hr). */
+ * loss_acc[0] += coef * sum wm*(sr - hr)^2, grad (+)= 2 coef wm (sr - hr);
+ * bit 2 (round 6; not with bit 0): `grad` is an f16 tensor and receives f16(grad_scale * g) -- the generator's f16 HR tail takes dL/dSR in that form (a power-of-two
+ * pre-scale keeps it inside f16's range); only the 4-channel groups that hold a real channel are written.  grad_scale 0 = 1. */
 int dasr_l1_loss(dasr_tensor sr, const float* hr_nchw, const float* weight_map, int32_t N, int32_t C, int32_t H, int32_t W,
-                 float coef, float* loss_acc, dasr_tensor grad, int32_t accumulate, void* stream);
+                 float coef, float* loss_acc, dasr_tensor grad, int32_t accumulate, float grad_scale, void* stream);
 
 /* backward of nn.Upsample(nearest,2) (block.py:857): dst[y][x] = sum of the 2x2 block of src (Hs=2H, Ws=2W);
  * optional LeakyReLU' mask (mask>0 ? 1 : slope) from the forward activation at the low resolution. */

@@ -393,9 +393,14 @@ def test_elementwise_and_adam():
     acc = torch.zeros(4, device=dev)
     gr = BTensor(2, 16, 10, 14, True, dev)
     coef = 1.0 / x.numel()
-    _lib.check(L.dasr_l1_loss(b.view(), hrd.data_ptr(), None, 2, 3, 10, 14, coef, acc.data_ptr(), gr.view(), 0, _stream()))
+    _lib.check(L.dasr_l1_loss(b.view(), hrd.data_ptr(), None, 2, 3, 10, 14, coef, acc.data_ptr(), gr.view(), 0, 0.0, _stream()))
     assert abs(float(acc[0]) - float((x - hr).abs().mean())) < 1e-6
     assert torch.allclose(gr.nchw(3).cpu(), torch.sign(x - hr) * coef, atol=1e-9)
+    # ... the same gradient straight into an f16 tensor, pre-scaled by a power of two (round 6: no padded fp32 image + conversion pass in front of the f16 HR tail)
+    g16 = BTensor(2, 16, 10, 14, False, dev, f16=True)
+    g16.t.fill_(0.0)
+    _lib.check(L.dasr_l1_loss(b.view(), hrd.data_ptr(), None, 2, 3, 10, 14, coef, None, g16.view(), 4, 1024.0, _stream()))
+    assert torch.equal(g16.nchw(3).cpu(), (torch.sign(x - hr) * coef * 1024.0).half().float()) and float(g16.t[:, :, :, :, 3:].abs().max()) == 0.0
     # 2x2 down-sum with LeakyReLU' mask
     s = torch.randn(1, 32, 8, 12, generator=g)
     m = torch.randn(1, 32, 4, 6, generator=g)
