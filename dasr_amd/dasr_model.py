@@ -276,9 +276,12 @@ class DASR_Model(BaseModel):
                 for sums, part in P.r_bufs:
                     self.dp.all_reduce_here(sums if stage == 0 else part)
 
-    def check_finite(self):
-        if getattr(self, 'dp', None) is not None and self.dp.active:   # every rank sees every rank's words: all gate / raise together
+    def sync_error_words(self):
+        """as SRModel.sync_error_words: every rank, logging interval, in front of check_finite"""
+        if getattr(self, 'dp', None) is not None and self.dp.active:
             self.dp.sync_error_words([o.nonfinite for o in self.optimizers] + [self.netG.chain_err])
+
+    def check_finite(self):
         for o, what in zip(self.optimizers, ('generator', 'discriminator', 'source discriminator')):
             o.check_finite(what)
         for plan in self.netG.plans.values():   # chained trunk launches (rrdbnet._Plan.check_chain): a broken neighbour wait invalidates the step

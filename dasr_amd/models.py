@@ -433,11 +433,15 @@ class SRModel(BaseModel):
 
     def check_finite(self):
         """raise FloatingPointError if a non-finite gradient reached an optimiser since the last check (every rank; see AdamHIP.check_finite)"""
-        if self.dp is not None and self.dp.active:   # every rank sees every rank's words: all gate / raise together
-            self.dp.sync_error_words([self.optimizer_G.nonfinite, self.netG.chain_err])
         self.optimizer_G.check_finite('generator')
         for plan in (getattr(self, '_out_plans', None) or []):
             plan.check_chain()
+
+    def sync_error_words(self):
+        """data parallelism: called by the drivers on EVERY rank at the logging interval, in front of check_finite (a collective: never from a rank-0-only path such as a
+        checkpoint write): every rank then holds the MAX of every rank's error words and all gate / raise together (DataParallelGroup.sync_error_words)"""
+        if self.dp is not None and self.dp.active:
+            self.dp.sync_error_words([self.optimizer_G.nonfinite, self.netG.chain_err])
 
     def get_current_log(self):
         if 'l_pix' in self.log_dict:

@@ -236,6 +236,8 @@ def main(argv=None):
                 batch = shard_minibatch(batch, dp.rank, dp.world)
             model.feed_data(batch, True)
             model.optimize_parameters(current_step)
+            if current_step % opt['logger']['print_freq'] == 0 and dp and hasattr(model, 'sync_error_words'):
+                model.sync_error_words()   # (collective, every rank) every rank holds the MAX of every rank's device error words from here on: all gate / raise together
             if current_step % opt['logger']['print_freq'] == 0 and rank != 0:
                 model.check_finite()   # rank 0 checks inside get_current_log: all ranks raise together (the flag is set behind the all-reduce)
             if current_step % opt['logger']['print_freq'] == 0 and rank == 0:
