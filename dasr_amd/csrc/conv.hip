@@ -2378,10 +2378,17 @@ extern "C" int dasr_rdb_chain(const dasr_conv_params* dev_layers, const dasr_con
         if (!ok) return DASR_EINVAL;
     }
     const int tiles_x = (p0.Wout + ISC::TW - 1) / ISC::TW, tiles_y = (p0.Hout + ISC::TH - 1) / ISC::TH;
-    const long long ntiles = (long long)tiles_x * tiles_y * p0.N;
-    // whole images per XCD; one workgroup per CU, every one owns ntiles / 256 tiles -- and every tile of an image must be worked on AT THE SAME TIME (a tile waits for its
-    // neighbours inside a dense block): the 32 workgroups of an XCD hold whole images, i.e. tiles per image divides 32
-    if ((p0.N & 7) || ntiles < 256 || ntiles % 256 || ntiles / 256 > ISC::MAX_TPW || 32 % (tiles_x * tiles_y)) return DASR_EINVAL;
+    const int T = tiles_x * tiles_y;
+    const long long ntiles = (long long)T * p0.N;
+    // Geometry: whole images per XCD (N % 8 == 0: image n lives on XCD n % 8), q workgroups per XCD (one per CU, q <= 32), each owning tpw = (tiles per XCD) / q <= 8 tiles --
+    // and every tile of an image must be worked on AT THE SAME TIME (a tile waits for its neighbours inside a dense block): the q workgroups of an XCD hold whole images,
+    // q % T == 0.  The largest such q is taken: 16 x 128^2 -> q 32, 2 tiles each; the reference's shipped 16 crops of 32 x 32 -> q 4, one tile each (a 32-workgroup launch).
+    if ((p0.N & 7) || T <= 0) return DASR_EINVAL;
+    const long long per_xcd = ntiles / 8;
+    int q = 0;
+    for (int c = 32 - 32 % T; c >= T; c -= T)
+        if (per_xcd % c == 0 && per_xcd / c <= ISC::MAX_TPW) { q = c; break; }
+    if (T > 32 || q == 0) return DASR_EINVAL;
     {
         static int n_cu = -1;
         if (n_cu < 0) {
@@ -2393,9 +2400,9 @@ extern "C" int dasr_rdb_chain(const dasr_conv_params* dev_layers, const dasr_con
         }
         if (n_cu != 256) return DASR_EINVAL;
     }
-    const int tpw = (int)(ntiles / 256);
-    if (bwd) return launch_rdb_is<false, true>(dev_layers, nlayers / 5, tiles_y, tiles_x, tpw, dev_flags, dev_flags + ntiles, dev_err, as_stream(stream), "rdb_is_kernel<false, true>", g_tune_is_stagger);
-    return launch_rdb_is<false, false>(dev_layers, nlayers / 5, tiles_y, tiles_x, tpw, dev_flags, dev_flags + ntiles, dev_err, as_stream(stream), "rdb_is_kernel<false, false>", g_tune_is_stagger);
+    const int tpw = (int)(per_xcd / q), grid = 8 * q;
+    if (bwd) return launch_rdb_is<false, true>(dev_layers, nlayers / 5, tiles_y, tiles_x, tpw, dev_flags, dev_flags + ntiles, dev_err, as_stream(stream), "rdb_is_kernel<false, true>", g_tune_is_stagger, grid);
+    return launch_rdb_is<false, false>(dev_layers, nlayers / 5, tiles_y, tiles_x, tpw, dev_flags, dev_flags + ntiles, dev_err, as_stream(stream), "rdb_is_kernel<false, false>", g_tune_is_stagger, grid);
 }
 
 extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {

@@ -689,13 +689,13 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
 }
 
 template <bool F16, bool BWD>
-int launch_rdb_is(const dasr_conv_params* dev_layers, int nrdb, int tiles_y, int tiles_x, int tpw, unsigned* flags, unsigned* tickets, int* err, hipStream_t s, const char* name, int stagger) {
+int launch_rdb_is(const dasr_conv_params* dev_layers, int nrdb, int tiles_y, int tiles_x, int tpw, unsigned* flags, unsigned* tickets, int* err, hipStream_t s, const char* name, int stagger, int grid) {
     static bool attr_set = false;
     auto kfn = rdb_is_kernel<F16, BWD>;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, ISC::LDS_BYTES));
         attr_set = true;
     }
-    DASR_LAUNCH_TAG(name, kfn, dim3(256), dim3(ISC::NTH), ISC::LDS_BYTES, s, dev_layers, nrdb, tiles_y, tiles_x, tpw, flags, tickets, err, stagger);
+    DASR_LAUNCH_TAG(name, kfn, dim3((unsigned)grid), dim3(ISC::NTH), ISC::LDS_BYTES, s, dev_layers, nrdb, tiles_y, tiles_x, tpw, flags, tickets, err, stagger);
     return (int)hipGetLastError();
 }

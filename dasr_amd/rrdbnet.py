@@ -166,14 +166,25 @@ class RRDBNetHIP:
         """number of chained launches per direction the trunk of a training plan of this shape runs as, 0 = one launch per conv (see chain_choice)"""
         return self.chain_choice(N, h, w)[1]
 
+    @staticmethod
+    def is_geometry(N, T):
+        """(workgroups per XCD, tiles per workgroup) of an input-stationary chained launch over N images of T tiles, or None (mirrors dasr_rdb_chain, csrc/conv.hip)"""
+        if N % 8 or T <= 0 or T > 32:
+            return None
+        per_xcd = N * T // 8
+        for q in range(32 - 32 % T, T - 1, -T):
+            if per_xcd % q == 0 and per_xcd // q <= 8:
+                return q, per_xcd // q
+        return None
+
     def chain_choice(self, N, h, w):
         """(form, k, why): how the trunk of a training plan of this shape runs.
         form 'layer', k >= 1: round 4's layer-by-layer chained launches (dasr_conv_chain).  A launch needs whole images per XCD and exactly 512 tiles: N images of T
             tiles qualify when N T = 512 k and N / k is a multiple of 8 -- the plan then runs k launches BACK TO BACK over image ranges of N / k (k = 1 at configs[1];
             k = 2 for configs[2]'s 32 crops of 128 x 128: at batch 32 the per-layer launches run a dense block in 274 + 287 us, two chained half-batches in 2 x (131 + 129) us).
             (Round 5 also built a form whose workgroups own several tiles -- bit-identical, but 88 ms per GAN step against 72 ms; -DDASR_BENCH library only.)
-        form 'is', k = 1: round 6's input-stationary chained launch (dasr_rdb_chain, csrc/rdb_is.h): every slab chunk staged once per dense block, one 8-wave workgroup
-            per CU owning N T / 256 (<= 8) tiles; whole images per XCD (N % 8 == 0), N T a multiple of 256, and every tile of an image in flight at once (T divides 32).
+        form 'is', k = 1: round 6's input-stationary chained launch (dasr_rdb_chain, csrc/rdb_is.h): every slab chunk staged once per dense block, 8 q <= 256 workgroups of
+            8 waves (one per CU) owning up to 8 tiles each; whole images per XCD (N % 8 == 0) and every tile of an image in flight at once (is_geometry).
             Measured (profiles/r06_shapes.txt): level with the layer form where both apply (31.3 vs 30.6 ms at 16 x 128^2), 6-23 % faster than one launch per conv where
             only it applies (batch 8 / 24 of 128^2, 16 x 64 x 128, 32 x 64^2) -- so DASR_CHAIN_FORM=auto (default) takes 'layer' where it fits and 'is' otherwise.
         form None, k = 0: one launch per conv; `why` names the clause that refused both forms (logged once per plan)."""
@@ -198,9 +209,10 @@ class RRDBNetHIP:
                 return 'layer', k, ''
             why.append('layer form: %d tiles are not 512 k (k <= %d) with N / k a multiple of 8' % (ntiles, kmax))
         if self.chain_form in ('auto', 'is'):
-            if N % 8 == 0 and ntiles % 256 == 0 and 1 <= ntiles // 256 <= 8 and 32 % T == 0 and self.nf == 64:
+            if RRDBNetHIP.is_geometry(N, T) is not None and self.nf == 64:
                 return 'is', 1, ''
-            why.append('input-stationary form: needs N %% 8 == 0, N x tiles a multiple of 256 (<= 2048), tiles per image (%d) a divisor of 32, nf 64' % T)
+            why.append('input-stationary form: needs nf 64, N %% 8 == 0 and q <= 32 workgroups per XCD with q a multiple of the %d tiles per image, q dividing the %s tiles per XCD, '
+                       'at most 8 tiles per workgroup' % (T, ('%d' % (ntiles // 8)) if N % 8 == 0 else 'N x tiles / 8'))
         return None, 0, '; '.join(why)
 
     # ---- plan ---------------------------------------------------------------------------------------

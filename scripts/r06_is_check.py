@@ -24,7 +24,7 @@ def main():
     import torch
     os.environ.setdefault('DASR_ALLOW_NONFINITE', '1')
     if '--bench' not in sys.argv:
-        shapes = ((16, 128, 128, 1), (8, 128, 128, 2), (32, 128, 128, 1), (16, 128, 128, 3), (16, 64, 128, 2), (64, 64, 64, 1), (8, 128, 112, 1))
+        shapes = ((16, 128, 128, 1), (8, 128, 128, 2), (32, 128, 128, 1), (16, 128, 128, 3), (16, 64, 128, 2), (64, 64, 64, 1), (8, 128, 112, 1), (16, 32, 32, 2), (16, 64, 64, 1))
         for (n, h, w, nb) in shapes:
             g = torch.Generator().manual_seed(5)
             data = {'LR': torch.rand(n, 3, h, w, generator=g).cuda(), 'HR': torch.rand(n, 3, 4 * h, 4 * w, generator=g).cuda()}

@@ -227,10 +227,10 @@ def test_f16_dense_block_gradient_scale_is_consistently_patched(monkeypatch):
 
 
 @pytest.mark.parametrize('shape', [(16, 128, 128, 2, 'layer'), (8, 256, 128, 1, 'layer'), (32, 128, 128, 1, 'layer'), (24, 128, 256, 1, 'layer'),
-                                   (16, 128, 128, 2, 'is'), (8, 128, 128, 2, 'is'), (32, 128, 128, 1, 'is'), (24, 128, 128, 1, 'is'), (64, 64, 64, 1, 'is'), (8, 128, 112, 3, 'is')],
+                                   (16, 128, 128, 2, 'is'), (8, 128, 128, 2, 'is'), (32, 128, 128, 1, 'is'), (24, 128, 128, 1, 'is'), (64, 64, 64, 1, 'is'), (8, 128, 112, 3, 'is'), (16, 32, 32, 2, 'is'), (16, 64, 64, 1, 'is')],
                          ids=['16x128x128', '8x256x128', '32x128x128-two_sub_batches', '24x128x256-three_sub_batches',
                               'is-16x128x128-two_tiles_per_workgroup', 'is-8x128x128-one_tile', 'is-32x128x128-four_tiles', 'is-24x128x128-three_tiles', 'is-64x64x64-four_images_per_xcd',
-                              'is-8x128x112-partial_tiles-rrdb_residual'])
+                              'is-8x128x112-partial_tiles-rrdb_residual', 'is-16x32x32-shipped_shape-32_workgroups', 'is-16x64x64-128_workgroups'])
 def test_chained_trunk_launches_are_bit_identical_to_per_layer_launches(shape, monkeypatch):
     """DASR_CHAIN (default on where the batch fills the chip exactly, RRDBNetHIP.chain_ok): the 15 nb dense-block convs of the forward and of the data
     gradient each run as ONE persistent launch in which a tile waits for its neighbour tiles only before the input chunks the previous layer wrote
@@ -286,7 +286,7 @@ def test_chain_refuses_shapes_that_do_not_fill_the_chip():
         assert not net.chain_ok(16, 128, 128)   # a partitioned device: never
         return
     assert net.chain_ok(16, 128, 128) and net.chain_ok(8, 128, 256) and net.chain_ok(32, 64, 128)
-    assert not net.chain_ok(16, 64, 64) and not net.chain_ok(4, 256, 256) and not net.chain_ok(12, 128, 128) and not net.chain_ok(16, 192, 192)
+    assert not net.chain_ok(4, 256, 256) and not net.chain_ok(12, 128, 128) and not net.chain_ok(16, 192, 192)
     assert net.chain_choice(24, 128, 128)[:2] == ('is', 1) and net.chain_choice(8, 128, 128)[:2] == ('is', 1) and net.chain_choice(16, 128, 128)[:2] == ('layer', 1)
     assert (net.chain_split(16, 128, 128), net.chain_split(32, 128, 128), net.chain_split(48, 128, 128), net.chain_split(20, 128, 128)) == (1, 2, 3, 0)   # (20: 640 tiles)
     assert net.chain_split(80, 128, 128) == 0   # five sub-batches: over the limit of four (DASR_CHAIN_SPLIT)

@@ -428,17 +428,21 @@ def test_chain_split_rule():
     assert g(NS(chain=False, _cus=256, chain_form='layer')) == 0 and g(NS(chain=True, _cus=64, chain_form='layer')) == 0
     # the input-stationary form (round 6, dasr_rdb_chain): one launch; whole images per XCD, N * tiles a multiple of 256 (<= 8 tiles per workgroup), tiles per image divides 32
     net = NS(chain=True, _cus=256, chain_form='is', nf=64)
-    assert (f(16, 128, 128), f(8, 128, 128), f(32, 128, 128), f(64, 128, 128), f(16, 64, 128), f(64, 64, 64), f(8, 128, 112)) == (1, 1, 1, 1, 1, 1, 1)
-    assert (f(8, 256, 128), f(24, 128, 256), f(12, 128, 128), f(16, 64, 64), f(4, 256, 256), f(128, 128, 128), f(16, 32, 32)) == (0, 0, 0, 0, 0, 0, 0)   # 64 tiles per image / ... / > 8 per workgroup / < 256 tiles
+    assert (f(16, 128, 128), f(8, 128, 128), f(32, 128, 128), f(64, 128, 128), f(16, 64, 128), f(64, 64, 64), f(8, 128, 112), f(16, 64, 64), f(16, 32, 32)) == (1,) * 9
+    assert (f(8, 256, 128), f(24, 128, 256), f(12, 128, 128), f(4, 256, 256), f(128, 128, 128), f(16, 192, 192)) == (0, 0, 0, 0, 0, 0)   # 64 tiles per image / ... / N % 8 / > 8 per workgroup / 72 tiles per image
+    # launch geometry (workgroups per XCD, tiles per workgroup): mirrors dasr_rdb_chain
+    G = RRDBNetHIP.is_geometry
+    assert (G(16, 32), G(8, 32), G(24, 32), G(64, 32), G(16, 2), G(32, 2), G(16, 8), G(64, 8), G(16, 16)) == ((32, 2), (32, 1), (32, 3), (32, 8), (4, 1), (8, 1), (16, 1), (32, 2), (32, 1))
+    assert G(128, 32) is None and G(8, 64) is None and G(12, 32) is None
     assert g(NS(chain=True, _cus=256, chain_form='is', nf=32)) == 0
     # the default: the layer form where it fits, else the input-stationary form; the refusal names its clause (the decisions at batch 12 / 20 / 24 x 128^2, 16 x 192^2)
     net = NS(chain=True, _cus=256, chain_form='auto', nf=64)
     c = lambda N, h, w: RRDBNetHIP.chain_choice(net, N, h, w)[:2]
     assert (c(16, 128, 128), c(32, 128, 128), c(8, 256, 128), c(24, 128, 256)) == (('layer', 1), ('layer', 2), ('layer', 1), ('layer', 3))
-    assert (c(8, 128, 128), c(24, 128, 128), c(40, 128, 128), c(16, 64, 128), c(32, 64, 64)) == (('is', 1),) * 5
-    assert (c(12, 128, 128), c(20, 128, 128), c(16, 192, 192), c(16, 32, 32)) == ((None, 0),) * 4
+    assert (c(8, 128, 128), c(24, 128, 128), c(40, 128, 128), c(16, 64, 128), c(32, 64, 64), c(16, 32, 32)) == (('is', 1),) * 6   # (16 crops of 32 x 32: the reference's shipped shape)
+    assert (c(12, 128, 128), c(20, 128, 128), c(16, 192, 192)) == ((None, 0),) * 3
     why = RRDBNetHIP.chain_choice(net, 16, 192, 192)[2]
-    assert 'layer form' in why and 'input-stationary form' in why and '72' in why   # 12 x 6 tiles per image: not a divisor of 32, 1152 tiles not 512 k
+    assert 'layer form' in why and 'input-stationary form' in why and '72' in why   # 12 x 6 tiles per image: more than the 32 workgroups of an XCD, 1152 tiles not 512 k
     assert 'DASR_CHAIN=0' in RRDBNetHIP.chain_choice(NS(chain=False), 16, 128, 128)[2]
 
 
