@@ -26,7 +26,7 @@
 // only when a group is still missing where it is needed does the workgroup spin (and counts it: err stays 0, the time shows in the trace).
 // ---------------------------------------------------------------------------------------------------
 #ifndef IS_ABL
-#define IS_ABL 0   // timing experiments with WRONG results (scripts/r06_is_ablate.sh): 1 no epilogues, 2 no weight DMA, 4 no MFMA, 8 no activation DMA, 16 no residual preload
+#define IS_ABL 0   // timing experiments with WRONG results (scripts/r06/is_ablate.sh): 1 no epilogues, 2 no weight DMA, 4 no MFMA, 8 no activation DMA, 16 no residual preload
 #endif
 #ifndef IS_BORDER
 #define IS_BORDER 0   // 1: epilogues store the border pixels of their 16-bit planes first and the flag waits for those only (conv_epilogue BMODE).  Built, bit-identical, and

@@ -1,8 +1,8 @@
 #!/bin/bash
 # compile-time ablations of rdb_is_kernel (csrc/rdb_is.h IS_ABL bits, WRONG results, timing only) as separate libraries dasr_amd/libdasr_hip_isabl<bits>.so:
-#   bash scripts/r06_is_ablate.sh 1 2 4 ...   then   DASR_HIP_LIB=dasr_amd/libdasr_hip_isabl1.so python scripts/r06_is_trace.py
+#   bash scripts/r06/is_ablate.sh 1 2 4 ...   then   DASR_HIP_LIB=dasr_amd/libdasr_hip_isabl1.so python scripts/r06/is_trace.py
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 python -m dasr_amd.build > /dev/null 2>&1
 B=dasr_amd/build
 for v in "$@"; do

@@ -1,10 +1,10 @@
 """Round 6: the input-stationary chained launches (DASR_CHAIN_FORM=is, dasr_rdb_chain) against the per-layer launches: bit-identical SR output, gradients and
-weights after two steps at small sizes, then (--bench) the configs[1] step time of per-layer / layer chain / input-stationary chain.   python scripts/r06_is_check.py [--bench]"""
+weights after two steps at small sizes, then (--bench) the configs[1] step time of per-layer / layer chain / input-stationary chain.   python scripts/r06/is_check.py [--bench]"""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

@@ -1,6 +1,6 @@
 """Round 6 debugging aid: where do the input-stationary chained launches first differ from the per-layer launches?  Compares every dense slab (16-bit planes) of the forward pass."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 os.environ.setdefault('DASR_ALLOW_NONFINITE', '1')

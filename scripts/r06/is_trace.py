@@ -1,6 +1,6 @@
 """Where an input-stationary chained launch (rdb_is_kernel, DASR_CHAIN_FORM=is) spends its cycles: per-workgroup accumulators of the -DDASR_TRACE build.
 
-  python -m dasr_amd.build --trace && DASR_HIP_LIB=dasr_amd/libdasr_hip_trace.so python scripts/r06_is_trace.py [--n 16] [--nb 23]
+  python -m dasr_amd.build --trace && DASR_HIP_LIB=dasr_amd/libdasr_hip_trace.so python scripts/r06/is_trace.py [--n 16] [--nb 23]
 
 Accumulators (cycles of thread 0 = wave 0, summed over the launch, per workgroup): 0 steps with one Cout-32 conv (18 MFMAs per wave), 1 steps with two m-tiles (36 MFMAs per wave),
 2 end-of-step wait + barrier, 3 blocking waits (a group missing where it is needed), 4 item start (x landed + barrier), 5 epilogues conv1-4 (+ flush of an older flag),
@@ -10,7 +10,7 @@ import ctypes
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 CH_BASE = 1 << 20
 

@@ -1,12 +1,12 @@
 """Round 6: SR step time (nf 64, nb 23) at several batch shapes under the three trunk schedules: per-layer launches (DASR_CHAIN=0), the layer-by-layer chained launches
 (DASR_CHAIN_FORM=layer, eligible at 512 k tiles only) and the input-stationary chained launch (DASR_CHAIN_FORM=is: N * tiles a multiple of 256, tiles per image divides 32).
-python scripts/r06_shapes.py [--shapes 8x128x128,16x128x128,...]"""
+python scripts/r06/shapes.py [--shapes 8x128x128,16x128x128,...]"""
 import argparse
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 
