@@ -509,7 +509,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                             poll_pend = true;
                         }
                         if constexpr (EU_AFTER < 0) prefetch_w();   // (a step that ends in an epilogue requests them BEHIND the epilogue's stores: a store queued behind LDS-DMA
-                                                                    // instructions waits for their data, profiles/r05_chain_trace.txt form 2 / r06_is_trace.txt)
+                                                                    // instructions waits for their data, profiles/r05_chain_trace.txt form 2 / r06_is_chain.txt)
                     }
                     if (s == 2) {
                         if constexpr (GK >= 1 && GK <= 4) {

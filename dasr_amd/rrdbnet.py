@@ -185,7 +185,7 @@ class RRDBNetHIP:
             (Round 5 also built a form whose workgroups own several tiles -- bit-identical, but 88 ms per GAN step against 72 ms; -DDASR_BENCH library only.)
         form 'is', k = 1: round 6's input-stationary chained launch (dasr_rdb_chain, csrc/rdb_is.h): every slab chunk staged once per dense block, 8 q <= 256 workgroups of
             8 waves (one per CU) owning up to 8 tiles each; whole images per XCD (N % 8 == 0) and every tile of an image in flight at once (is_geometry).
-            Measured (profiles/r06_shapes.txt): level with the layer form where both apply (31.3 vs 30.6 ms at 16 x 128^2), 6-23 % faster than one launch per conv where
+            Measured (profiles/r06_is_chain.txt): level with the layer form where both apply (31.3 vs 30.6 ms at 16 x 128^2), 6-23 % faster than one launch per conv where
             only it applies (batch 8 / 24 of 128^2, 16 x 64 x 128, 32 x 64^2) -- so DASR_CHAIN_FORM=auto (default) takes 'layer' where it fits and 'is' otherwise.
         form None, k = 0: one launch per conv; `why` names the clause that refused both forms (logged once per plan)."""
         T = ceil_div(h, 16) * ceil_div(w, 32)
