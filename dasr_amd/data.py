@@ -119,10 +119,47 @@ class DeviceUnpairedDataset:
                 yield self.batch(idx)
 
 
+def _bicubic_resample_matrix(n_in, scale):
+    """(n_out x n_in) matrix of MATLAB's imresize along one axis: bicubic kernel (a = -0.5), widened by 1 / scale and scaled by `scale` when shrinking (antialiasing), rows
+    normalised to sum 1, samples beyond the ends mirrored about the edge (the edge sample itself repeated).  Output sample k (1-based) sits at u = k / scale + (1 - 1 / scale) / 2
+    in input coordinates.  What codes/SRN/data/util.py:243-297 + the per-row products of imresize_np (:367-433) compute, as one dense matrix in float64."""
+    import math
+    n_out = int(math.ceil(n_in * scale))
+    width = 4.0 / scale if scale < 1 else 4.0
+    taps = int(math.ceil(width)) + 2
+    k = torch.arange(1, n_out + 1, dtype=torch.float64)
+    u = k / scale + 0.5 * (1.0 - 1.0 / scale)
+    left = torch.floor(u - width / 2.0)
+    idx = left[:, None] + torch.arange(taps, dtype=torch.float64)[None, :]        # 1-based input positions
+    d = (u[:, None] - idx) * (scale if scale < 1 else 1.0)
+    a = d.abs()
+    w = torch.where(a <= 1, 1.5 * a ** 3 - 2.5 * a ** 2 + 1, torch.where(a <= 2, -0.5 * a ** 3 + 2.5 * a ** 2 - 4 * a + 2, torch.zeros_like(a)))
+    if scale < 1:
+        w = w * scale
+    w = w / w.sum(1, keepdim=True)
+    j = idx.long() - 1                                                              # 0-based; mirror: -1 -> 0, -2 -> 1, n -> n - 1, n + 1 -> n - 2
+    j = torch.where(j < 0, -j - 1, j)
+    j = torch.where(j >= n_in, 2 * n_in - 1 - j, j).clamp_(0, n_in - 1)
+    M = torch.zeros(n_out, n_in, dtype=torch.float64)
+    M.scatter_add_(1, j, w)
+    return M
+
+
+def imresize_matlab(img, scale):
+    """MATLAB-style bicubic resize with antialiasing of a CHW float tensor by `scale` (both axes; rows first, as the reference): the LR images of `mode: "LRHR"` datasets
+    without an LR folder (codes/SRN/data/LRHR_dataset.py:85, util.imresize_np).  Pinned by tests/golden/imresize.npz (generated by the reference's function)."""
+    C_, H, W = img.shape
+    Mh, Mw = _bicubic_resample_matrix(H, scale), _bicubic_resample_matrix(W, scale)
+    x = img.to(torch.float64)
+    return torch.einsum('oh,chw,pw->cop', Mh, x, Mw).to(img.dtype)
+
+
 class DevicePairedDataset:
     """`mode: "LRHR"` with LR files given (codes/SRN/data/LRHR_dataset.py:44-126, train phase): {'LR','HR'} batches assembled on the
     device.  Per sample the reference draws random.randint twice (crop origin in the LR image) and then util.augment's coins.
-    (On-the-fly LR generation by MATLAB-style imresize and the too-small-image resize stay on the reference's side.)"""
+    Without `dataroot_LR` the LR images are made from the HR images by MATLAB-style bicubic down-sampling (imresize_matlab), once, at construction: the reference's train
+    phase does the same per sample with random_scale_list = [1] (LRHR_dataset.py:63-88) whenever the HR size is a multiple of `scale` -- the case taken here; other sizes
+    go through cv2.resize(INTER_LINEAR) there first, and an HR image smaller than HR_size is resized: both stay on the reference's side (NotImplementedError)."""
 
     def __init__(self, ds_opt, scale=4, images=None, device=None, shuffle=None, drop_last=True):
         ensure_runtime_ready()
@@ -132,9 +169,14 @@ class DevicePairedDataset:
         self.use_flip, self.use_rot = bool(ds_opt.get('use_flip')), bool(ds_opt.get('use_rot'))
         self.shuffle = bool(ds_opt.get('use_shuffle')) if shuffle is None else shuffle
         if images is None:
-            if not ds_opt.get('dataroot_LR'):
-                raise NotImplementedError('LRHR without dataroot_LR: LR images are made by imresize on the host in the reference; provide LR files')
-            images = {'LR': [load_image(p) for p in image_paths(ds_opt['dataroot_LR'])], 'HR': [load_image(p) for p in image_paths(ds_opt['dataroot_HR'])]}
+            hr = [load_image(p) for p in image_paths(ds_opt['dataroot_HR'])]
+            images = {'HR': hr, 'LR': [load_image(p) for p in image_paths(ds_opt['dataroot_LR'])] if ds_opt.get('dataroot_LR') else None}
+        if images.get('LR') is None:   # down-sampling on the fly (LRHR_dataset.py:63-88)
+            for t in images['HR']:
+                if t.shape[1] % scale or t.shape[2] % scale:
+                    raise NotImplementedError('LRHR without dataroot_LR: HR image of %d x %d is not a multiple of scale %d (the reference resizes it with cv2 first); '
+                                              'crop the HR images or provide LR files' % (t.shape[1], t.shape[2], scale))
+            images = dict(images, LR=[imresize_matlab(t.float().cpu(), 1.0 / scale) for t in images['HR']])
         self.img = {k: [t.to(self.device, torch.float32).contiguous() for t in v] for k, v in images.items()}
         assert self.img['HR'], 'Error: HR path is empty.'
         assert len(self.img['LR']) == len(self.img['HR']), 'HR and LR datasets have different number of images - {}, {}.'.format(

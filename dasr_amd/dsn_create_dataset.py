@@ -39,6 +39,7 @@ def build_parser():
     # additions of this build
     p.add_argument('--target_dir', default=None, type=str, help='folder of target-domain HR images (replaces ../paths.yml)')
     p.add_argument('--source_dir', default=None, type=str, help='folder of source-domain LR images (for --including_source_ddm)')
+    p.add_argument('--paths', default='../paths.yml', type=str, help="yaml file with the dataset folders (the reference reads '../paths.yml', create_dataset_modified.py:49-50)")
     p.add_argument('--out_root', default='DSN_results', type=str)
     p.add_argument('--n_synthetic', default=4, type=int)
     return p
@@ -56,8 +57,25 @@ def _save_png(t, path):
     Image.fromarray(a).save(path)
 
 
+# --dataset name -> (first key, second key) of paths.yml (codes/DSN/create_dataset_modified.py:52-81)
+DATASETS = {'aim2019': ('aim2019', 'tdsr'), 'ntire2020': ('ntire2020', 'tdsr'), 'realsr_tddiv2k': ('realsr', 'tddiv2k'), 'realsr_tdrealsr': ('realsr', 'tdrealsr'),
+            'realsr_tdrealsr_2x': ('realsr', 'tdrealsr_x2'), 'camerasr': ('camerasr', 'tdsr')}
+
+
+def _named_dir(o, which):
+    """folder of `which` ('source' / 'target') images of --dataset through the paths file, as the reference resolves it"""
+    if o.dataset not in DATASETS:
+        return None
+    from .dsn_data import load_paths
+    a, b = DATASETS[o.dataset]
+    try:
+        return load_paths(o.paths)[a][b][which]
+    except (KeyError, TypeError):
+        raise KeyError("%s has no entry ['%s']['%s']['%s'] (codes/paths.yml layout)" % (o.paths, a, b, which))
+
+
 def _images(o, which):
-    d = o.target_dir if which == 'target' else o.source_dir
+    d = (o.target_dir if which == 'target' else o.source_dir) or _named_dir(o, which)
     if d:
         for f in sorted(os.listdir(d)):
             if f.endswith(IMG_EXT):
@@ -68,7 +86,7 @@ def _images(o, which):
             hw = (160, 192) if which == 'target' else (40, 48)
             yield '%s_%03d.png' % (which, i), torch.rand(1, 3, *hw, generator=g)
     else:
-        raise NotImplementedError('dataset [%s]: pass --target_dir / --source_dir (the reference resolves names through ../paths.yml)' % o.dataset)
+        raise NotImplementedError('dataset [%s]: known names are %s (folders from --paths) and synthetic; or pass --target_dir / --source_dir' % (o.dataset, ' / '.join(sorted(DATASETS))))
 
 
 def main(argv=None):

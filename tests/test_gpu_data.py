@@ -33,6 +33,19 @@ def test_device_batches_equal_reference_dataset(golden_dir):
     random.seed(31)
     b = dp.batch([2, 0, 4])
     assert torch.equal(b['LR'].cpu(), torch.from_numpy(gold['p_LR'])) and torch.equal(b['HR'].cpu(), torch.from_numpy(gold['p_HR']))
+    # LRHR WITHOUT an LR folder (LRHR_dataset.py:63-88): the LR images are MATLAB-style bicubic down-samplings of the HR images (imresize_matlab, pinned to the
+    # reference's util.imresize_np by tests/golden/imresize.npz): same batches as a dataset that is handed those LR images, same random draws
+    from dasr_amd.data import imresize_matlab
+    lr_made = [imresize_matlab(t, 0.25) for t in imgs['HR']]
+    d_fly = DevicePairedDataset({'batch_size': 3, 'HR_size': 32, 'use_flip': True, 'use_rot': True, 'use_shuffle': False}, scale=4, images={'LR': None, 'HR': imgs['HR']})
+    d_ref = DevicePairedDataset({'batch_size': 3, 'HR_size': 32, 'use_flip': True, 'use_rot': True, 'use_shuffle': False}, scale=4, images={'LR': lr_made, 'HR': imgs['HR']})
+    random.seed(77)
+    b1 = d_fly.batch([1, 3, 0])
+    random.seed(77)
+    b2 = d_ref.batch([1, 3, 0])
+    assert torch.equal(b1['LR'], b2['LR']) and torch.equal(b1['HR'], b2['HR']) and tuple(b1['LR'].shape) == (3, 3, 8, 8)
+    with pytest.raises(NotImplementedError):   # an HR size that is not a multiple of the scale goes through cv2.resize in the reference first
+        DevicePairedDataset({'batch_size': 1, 'HR_size': 32, 'use_flip': False, 'use_rot': False}, scale=4, images={'LR': None, 'HR': [torch.rand(3, 50, 64)]})
     # iterator protocol / shapes / device
     batches = list(DeviceUnpairedDataset({'batch_size': 2, 'HR_size': 32, 'use_flip': False, 'use_rot': False, 'use_shuffle': True}, scale=4, images=imgs))
     assert len(batches) == 2 and batches[0]['HR'].is_cuda and tuple(batches[0]['fake_w'].shape) == (2, 1, 8, 8)

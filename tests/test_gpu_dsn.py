@@ -417,6 +417,21 @@ def test_dsn_dataset_cli_end_to_end(tmp_path):
     assert ddm.dtype == np.float64 and ddm.shape == (1, 1, 20, 24) and 0 < ddm.min() and ddm.max() < 1
     dds = np.load(os.path.join(out, 'ddm_source', 'source_001.npy'))
     assert dds.shape == (1, 1, 20, 24)
+    # --dataset <name> resolved through the reference's paths.yml layout (create_dataset_modified.py:49-81), here realsr_tdrealsr -> PATHS['realsr']['tdrealsr']
+    from PIL import Image as _I
+    src, tgt = tmp_path / 'src', tmp_path / 'tgt'
+    src.mkdir(), tgt.mkdir()
+    g = np.random.default_rng(3)
+    for i in range(2):
+        _I.fromarray(g.integers(0, 255, (64, 80, 3), dtype=np.uint8)).save(str(tgt / ('t%d.png' % i)))
+        _I.fromarray(g.integers(0, 255, (16, 20, 3), dtype=np.uint8)).save(str(src / ('s%d.png' % i)))
+    py = tmp_path / 'paths.yml'
+    py.write_text('realsr:\n  tdrealsr:\n    source: %s\n    target: %s\n' % (src, tgt))
+    out2, n2 = dsn_create_dataset.main(['--checkpoint', ck, '--filter', 'wavelet', '--name', 'gen2', '--out_root', str(tmp_path / 'res'), '--including_source_ddm',
+                                        '--dataset', 'realsr_tdrealsr', '--paths', str(py)])
+    assert n2 == 2 and sorted(os.listdir(os.path.join(out2, 'imgs_from_target'))) == ['t0.png', 't1.png'] and sorted(os.listdir(os.path.join(out2, 'ddm_source'))) == ['s0.npy', 's1.npy']
+    with pytest.raises(NotImplementedError):
+        dsn_create_dataset.main(['--checkpoint', ck, '--filter', 'wavelet', '--name', 'gen3', '--out_root', str(tmp_path / 'res'), '--dataset', 'nope'])
 
 
 def test_fsd_batch_discriminator_matches_reference_test_tar(golden_dir, margins):

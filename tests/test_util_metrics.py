@@ -71,3 +71,16 @@ def test_make_grid_layout():
     g = util.make_grid(t, nrow=2)
     assert tuple(g.shape) == (3, 2 * 4 + 2, 2 * 4 + 2)
     assert torch.equal(g[:, 2:4, 2:4], t[0]) and torch.equal(g[:, 2:4, 6:8], t[1]) and torch.equal(g[:, 6:8, 2:4], t[2])
+
+
+def test_matlab_imresize_matches_the_reference(golden_dir):
+    """dasr_amd.data.imresize_matlab (LR images of LRHR datasets without an LR folder) against the reference's data/util.py::imresize_np on five seeded images
+    (tests/golden/imresize.npz, oracle/gen_golden_imresize.py): x1/4 and x1/2, sizes where the antialiased kernel reaches over both edges"""
+    import numpy as np
+    import torch
+    from dasr_amd.data import imresize_matlab
+    g = np.load(os.path.join(golden_dir, 'imresize.npz'))
+    for i in range(5):
+        x = torch.from_numpy(g['in%d' % i]).permute(2, 0, 1)
+        y = imresize_matlab(x, 1.0 / int(g['scale%d' % i])).permute(1, 2, 0).numpy()
+        assert y.shape == g['out%d' % i].shape and float(np.abs(y - g['out%d' % i]).max()) < 5e-7, i
