@@ -46,7 +46,12 @@ def _check_all_plans(tag):
             if o.op == _lib.OP_CONV:
                 c = o.conv
                 ptrs += [c.inp.p, c.mask.p, c.res1.p, c.res2.p, c.out_f32.p, c.out_bf16.p, c.w, c.bias, c.slope_ptr]
-            if o.op not in (_lib.OP_EVENT_RECORD, _lib.OP_STREAM_WAIT, _lib.OP_SET_STREAM):   # (those carry host-side event / stream handles)
+            if o.op in (_lib.OP_CONV_CHAIN, _lib.OP_RDB_CHAIN):   # p[1] is the HOST copy of the layer table (validated by the launcher): kept alive by a ConvChain in ol.keep
+                import ctypes as C
+                hosts = [C.cast(ch.host, C.c_void_p).value for ch in ol.keep if hasattr(ch, 'host')]
+                assert o.p[1] in hosts, (tag, k, 'host layer table of a chained launch is not kept by its list')
+                ptrs += [o.p[0], o.p[2], o.p[3], o.l[0]]
+            elif o.op not in (_lib.OP_EVENT_RECORD, _lib.OP_STREAM_WAIT, _lib.OP_SET_STREAM):   # (those carry host-side event / stream handles)
                 ptrs += [o.p[j] for j in range(4)]
             for p in ptrs:
                 if p:
