@@ -2377,18 +2377,30 @@ extern "C" int dasr_rdb_chain(const dasr_conv_params* dev_layers, const dasr_con
         const bool ok = k < 4 ? epi == (bwd ? 68 : 67) : ((epi & ~(16 | 64)) == (bwd ? 168 : 169) && p.res1.p && p.alpha != 0.f);
         if (!ok) return DASR_EINVAL;
     }
-    const int tiles_x = (p0.Wout + ISC::TW - 1) / ISC::TW, tiles_y = (p0.Hout + ISC::TH - 1) / ISC::TH;
-    const int T = tiles_x * tiles_y;
-    const long long ntiles = (long long)T * p0.N;
     // Geometry: whole images per XCD (N % 8 == 0: image n lives on XCD n % 8), q workgroups per XCD (one per CU, q <= 32), each owning tpw = (tiles per XCD) / q <= 8 tiles --
     // and every tile of an image must be worked on AT THE SAME TIME (a tile waits for its neighbours inside a dense block): the q workgroups of an XCD hold whole images,
-    // q % T == 0.  The largest such q is taken: 16 x 128^2 -> q 32, 2 tiles each; the reference's shipped 16 crops of 32 x 32 -> q 4, one tile each (a 32-workgroup launch).
-    if ((p0.N & 7) || T <= 0) return DASR_EINVAL;
-    const long long per_xcd = ntiles / 8;
-    int q = 0;
-    for (int c = 32 - 32 % T; c >= T; c -= T)
-        if (per_xcd % c == 0 && per_xcd / c <= ISC::MAX_TPW) { q = c; break; }
-    if (T > 32 || q == 0) return DASR_EINVAL;
+    // q % T == 0.  The largest such q is taken: 16 x 128^2 -> q 32, 2 tiles each.  Tiles are 16 x 32 pixels; where that fills less than the chip and tiles of 8 x 32 fill
+    // more of it, those are taken (the reference's shipped 16 crops of 32 x 32: 64 workgroups with half the work each instead of 32).
+    if (p0.N & 7) return DASR_EINVAL;
+    const int tiles_x = (p0.Wout + ISC::TW - 1) / ISC::TW;
+    auto geometry = [&](int th, int& q_out, int& tpw_out) -> bool {   // workgroups per XCD / tiles per workgroup for tiles of th rows
+        const int T = tiles_x * ((p0.Hout + th - 1) / th);
+        if (T <= 0 || T > 32) return false;
+        const long long per_xcd = (long long)T * p0.N / 8;
+        for (int c = 32 - 32 % T; c >= T; c -= T)
+            if (per_xcd % c == 0 && per_xcd / c <= ISC::MAX_TPW) {
+                q_out = c, tpw_out = (int)(per_xcd / c);
+                return true;
+            }
+        return false;
+    };
+    int q16 = 0, t16 = 0, q8 = 0, t8 = 0;
+    const bool ok16 = geometry(16, q16, t16), ok8 = geometry(8, q8, t8);
+    if (!ok16 && !ok8) return DASR_EINVAL;
+    const bool small = !ok16 || (ok8 && q16 < 32 && q8 > q16);
+    const int th = small ? 8 : 16, q = small ? q8 : q16, tpw = small ? t8 : t16, grid = 8 * q;
+    const int tiles_y = (p0.Hout + th - 1) / th;
+    const long long ntiles = (long long)tiles_x * tiles_y * p0.N;
     {
         static int n_cu = -1;
         if (n_cu < 0) {
@@ -2400,9 +2412,15 @@ extern "C" int dasr_rdb_chain(const dasr_conv_params* dev_layers, const dasr_con
         }
         if (n_cu != 256) return DASR_EINVAL;
     }
-    const int tpw = (int)(per_xcd / q), grid = 8 * q;
-    if (bwd) return launch_rdb_is<false, true>(dev_layers, nlayers / 5, tiles_y, tiles_x, tpw, dev_flags, dev_flags + ntiles, dev_err, as_stream(stream), "rdb_is_kernel<false, true>", g_tune_is_stagger, grid);
-    return launch_rdb_is<false, false>(dev_layers, nlayers / 5, tiles_y, tiles_x, tpw, dev_flags, dev_flags + ntiles, dev_err, as_stream(stream), "rdb_is_kernel<false, false>", g_tune_is_stagger, grid);
+    // (the ticket counters sit behind the flag words of the LARGEST tile count a caller may have to provide for: N x ceil(H / 8) x ceil(W / 32))
+    unsigned* tickets = dev_flags + (long long)tiles_x * ((p0.Hout + 7) / 8) * p0.N;
+    (void)ntiles;
+    if (small) {
+        if (bwd) return launch_rdb_is<false, true, 1>(dev_layers, nlayers / 5, tiles_y, tiles_x, tpw, dev_flags, tickets, dev_err, as_stream(stream), "rdb_is_kernel<false, true, 1>", g_tune_is_stagger, grid);
+        return launch_rdb_is<false, false, 1>(dev_layers, nlayers / 5, tiles_y, tiles_x, tpw, dev_flags, tickets, dev_err, as_stream(stream), "rdb_is_kernel<false, false, 1>", g_tune_is_stagger, grid);
+    }
+    if (bwd) return launch_rdb_is<false, true, 2>(dev_layers, nlayers / 5, tiles_y, tiles_x, tpw, dev_flags, tickets, dev_err, as_stream(stream), "rdb_is_kernel<false, true, 2>", g_tune_is_stagger, grid);
+    return launch_rdb_is<false, false, 2>(dev_layers, nlayers / 5, tiles_y, tiles_x, tpw, dev_flags, tickets, dev_err, as_stream(stream), "rdb_is_kernel<false, false, 2>", g_tune_is_stagger, grid);
 }
 
 extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {

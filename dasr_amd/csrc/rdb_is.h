@@ -38,23 +38,30 @@
 #ifndef IS_PUB_DELAY
 #define IS_PUB_DELAY 1
 #endif
-struct ISC {
-    static constexpr int NW = 8, NTH = 512, NT = 2, TH = 16, TW = 32, IH = 18, IW = 34, NPIX = IH * IW;
-    static constexpr int APIECE = NPIX * 2;                  // 16-byte pieces of one activation chunk (1224)
-    static constexpr int AR = (APIECE + NTH - 1) / NTH;      // DMA rounds per chunk (3, the last one partial)
-    static constexpr int ACT_SLOT = 20480, NSLOT = 4;        // >= APIECE * 16 = 19584
-    static constexpr int W_OFF = NSLOT * ACT_SLOT;
-    static constexpr int WGRAN = 18432, NWG = 4;
-    static constexpr int X_OFF = W_OFF + NWG * WGRAN;        // 155648
+struct ISC {   // what does not depend on the tile height
+    static constexpr int NW = 8, NTH = 512, TW = 32, IW = 34;
+    static constexpr int WGRAN = 18432, NWG = 4, NSLOT = 4;
+    static constexpr int LDS_BYTES = 163840;
+    static constexpr int X_OFF = LDS_BYTES - 8192;           // the last 8 KB: biases, polled flag words, decision words (the same offsets for every tile height)
     static constexpr int BIAS_OFF = X_OFF;                   // [2 item parities][5 layers][64 floats]
     static constexpr int POLL_OFF = X_OFF + 2560;            // [MAX_TPW][16 words]: the newest flag values seen of a tile's nine (self + 8 neighbours) words
     static constexpr int MAX_TPW = 8;
     static constexpr int F0_OFF = POLL_OFF + MAX_TPW * 64;   // f0[MAX_TPW], ticket
     static constexpr int DEC_OFF = F0_OFF + 64;              // decision words [2 step parities][2]: {target reached ? target : target - 1, tile slot}, written by wave 0
     static constexpr int TRC_OFF = DEC_OFF + 64;             // trace builds: 16 64-bit accumulators
-    static constexpr int LDS_BYTES = 163840;
     static constexpr int NSTEP = 34;
     static constexpr int PUB_DELAY = IS_PUB_DELAY;           // a conv's flag goes out at the end of the PUB_DELAY-th step behind its epilogue (its stores have that long to be acknowledged)
+};
+// NT = output rows per wave: 2 = tiles of 16 x 32 pixels (the full-chip shapes), 1 = tiles of 8 x 32 (launches that would otherwise fill less of the chip: the reference's
+// shipped 32 x 32 crops run as 64 instead of 32 workgroups; half the MFMA work per step and workgroup)
+template <int NT_>
+struct ISCfg : ISC {
+    static constexpr int NT = NT_, TH = NW * NT, IH = TH + 2, NPIX = IH * IW;
+    static constexpr int APIECE = NPIX * 2;                            // 16-byte pieces of one activation chunk (1224 / 680)
+    static constexpr int AR = (APIECE + NTH - 1) / NTH;                // DMA rounds per chunk (the last one partial)
+    static constexpr int ACT_SLOT = (APIECE * 16 + 1023) / 1024 * 1024;   // 20480 / 11264
+    static constexpr int W_OFF = NSLOT * ACT_SLOT;
+    static_assert(W_OFF + NWG * WGRAN <= X_OFF, "LDS budget");
 };
 
 // the static program of one dense block on one tile: kind 1 = one Cout-32 conv u0, 2 = two Cout-32 convs u0, u1 on the same chunk, 5 = conv5; c = chunk of the slab
@@ -133,13 +140,15 @@ __device__ __forceinline__ int is_dma_w(__amdgpu_buffer_rsrc_t rw, char* dst, un
     }
     return n;
 }
-__device__ __forceinline__ int is_dma_act(__amdgpu_buffer_rsrc_t rin, char* slot, const unsigned (&goff)[ISC::AR], unsigned src_off, int wave, int tid) {
+template <int NT>
+__device__ __forceinline__ int is_dma_act(__amdgpu_buffer_rsrc_t rin, char* slot, const unsigned* goff, unsigned src_off, int wave, int tid) {
     typedef __attribute__((address_space(3))) void* lds_ptr;
+    using CC = ISCfg<NT>;
     int n = 0;
 #pragma unroll
-    for (int r = 0; r < ISC::AR; ++r) {
-        if (r * ISC::NTH + wave * 64 < ISC::APIECE) {
-            if (tid + r * ISC::NTH < ISC::APIECE)   // (the last wave of the last round is partial: the pieces behind the chunk would land in the next slot)
+    for (int r = 0; r < CC::AR; ++r) {
+        if (r * ISC::NTH + wave * 64 < CC::APIECE) {
+            if (tid + r * ISC::NTH < CC::APIECE)   // (the last wave of the last round is partial: the pieces behind the chunk would land in the next slot)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(slot + (r * ISC::NTH + wave * 64) * 16), 16, goff[r], src_off, 0, 0);
             ++n;
         }
@@ -156,9 +165,10 @@ __device__ __forceinline__ void is_dma_bias(__amdgpu_buffer_rsrc_t rb, char* dst
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)dst, 4, voff, 0, 0, 0);
 }
 
+template <int NT>
 struct ISGeo {            // one tile of the workgroup's list
     int n, oy0, ox0;
-    unsigned goff[ISC::AR];   // per-thread source offsets of the activation DMA pieces
+    unsigned goff[ISCfg<NT>::AR];   // per-thread source offsets of the activation DMA pieces
     unsigned nbo;             // lanes 0-8: byte offset of the flag word of neighbour `lane` (self where there is none)
     unsigned selfo;           // byte offset of the tile's own flag word
     unsigned f0;              // the tile's flag value at kernel start
@@ -180,11 +190,11 @@ struct ISGeo {            // one tile of the workgroup's list
 // one step's MFMA body.  a0 / a1: the accumulators of the step's one or two m-tiles (NT = 2 n-tiles each); A fragment of (tap, m-tile mi) at
 // wbuf + tap * TS + mi * MIS (+ lane * 16): conv5's granule is [tap][mi][1 KB] (TS 2048, MIS 1024), two Cout-32 convs are [conv][tap][1 KB] (TS 1024, MIS 9216).
 // B fragments: the wave's four input rows per kx, reused across ky (as conv_glds_kernel).  mid(s) runs between the fragment requests and the MFMAs of tap step s.
-template <int NU, int TS, int MIS, bool F16, class Mid>
-__device__ __forceinline__ void is_body(f32x16 (&a0)[2], f32x16 (&a1)[2], const char* abuf, const char* wbuf, const int (&baddr)[4][3], const int aoff, Mid&& mid) {
-    bf16x8 fb[2][4], fa[2][NU];
+template <int NT, int NU, int TS, int MIS, bool F16, class Mid>
+__device__ __forceinline__ void is_body(f32x16 (&a0)[NT], f32x16 (&a1)[NT], const char* abuf, const char* wbuf, const int (&baddr)[NT + 2][3], const int aoff, Mid&& mid) {
+    bf16x8 fb[2][NT + 2], fa[2][NU];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) fb[0][rr] = *(const bf16x8*)(abuf + baddr[rr][0]);
+    for (int rr = 0; rr < NT + 2; ++rr) fb[0][rr] = *(const bf16x8*)(abuf + baddr[rr][0]);
 #pragma unroll
     for (int mi = 0; mi < NU; ++mi) fa[0][mi] = *(const bf16x8*)(wbuf + aoff + mi * MIS);
 #pragma unroll
@@ -196,13 +206,13 @@ __device__ __forceinline__ void is_body(f32x16 (&a0)[2], f32x16 (&a1)[2], const 
             for (int mi = 0; mi < NU; ++mi) fa[(s + 1) & 1][mi] = *(const bf16x8*)(wbuf + aoff + (ky1 * 3 + kx1) * TS + mi * MIS);
             if (ky == 1 && kx < 2) {
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) fb[(kx + 1) & 1][rr] = *(const bf16x8*)(abuf + baddr[rr][kx + 1]);
+                for (int rr = 0; rr < NT + 2; ++rr) fb[(kx + 1) & 1][rr] = *(const bf16x8*)(abuf + baddr[rr][kx + 1]);
             }
         }
         mid(s);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             if constexpr (IS_ABL & 4) {
                 asm volatile("" ::"v"(fa[s & 1][0]), "v"(fb[kx & 1][nt + ky]));
                 if constexpr (NU == 2) asm volatile("" ::"v"(fa[s & 1][1]));
@@ -216,10 +226,10 @@ __device__ __forceinline__ void is_body(f32x16 (&a0)[2], f32x16 (&a1)[2], const 
 }
 
 
-template <bool F16, bool BWD>
+template <bool F16, bool BWD, int NT>
 __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* __restrict__ layers, const int nrdb, const int tiles_y, const int tiles_x, const int tpw,
                                                         unsigned* flags, unsigned* tickets, int* err, const int stagger) {
-    using C = ISC;
+    using C = ISCfg<NT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = tiles_y * tiles_x;
@@ -248,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
     __syncthreads();
 
     auto geo_of = [&](int slot) {
-        ISGeo q;
+        ISGeo<NT> q;
         const int idx = j + quota * slot;
         const int img = idx / T, tile = idx - img * T;
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -277,9 +287,9 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
 
     // ---- per-lane fragment addresses (the image of conv_glds_kernel; wave w: output rows 2w, 2w + 1 = input rows 2w .. 2w + 3)
     const int nn = lane & 31, kh2 = lane >> 5;
-    int baddr[4][3];
+    int baddr[NT + 2][3];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr)
+    for (int rr = 0; rr < NT + 2; ++rr)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int pp = (wave * C::NT + rr) * C::IW + nn + kx;
@@ -314,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
     // stores acknowledged: 9.7 ms per chain against 8.7 ms.  The flag then leaves up to two steps later, and what bounds this kernel is exactly that chain: epilogue stores
     // acknowledged -> flag -> the neighbours' poll -> their halo DMA; waiting for the stores at the end of the next step is the shortest form.  profiles/r06_is_chain.txt)
     // spin until they have (a group is not there where it is needed): the only place where the matrix pipe waits for a neighbour
-    auto block_until = [&](const ISGeo& q, unsigned target) {
+    auto block_until = [&](const ISGeo<NT>& q, unsigned target) {
         const unsigned long long t0 = IS_T();
         flush_pub();
         if (wave == 0 && lane < 9) {
@@ -339,14 +349,14 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
     // XCD stagger (tuning key 9): XCD k starts k * stagger * ~4 us late, so that the eight XCDs (which never wait for each other: whole images per XCD) reach
     // their store / DMA bursts at different times
     for (int i = 0; i < xcd * stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    ISGeo cur = geo_of(0);
+    ISGeo<NT> cur = geo_of(0);
     // ---- prologue: x of the first item, the weights of steps 0-2, the biases of the first item
     {
         const dasr_conv_params& p0 = layers[0];
         const __amdgpu_buffer_rsrc_t rin0 = make_rsrc((const bf16_t*)p0.in.p + (size_t)cur.n * p0.in.n_stride);
         const unsigned icb0 = (unsigned)(p0.in.cb_stride * 2);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) issued += is_dma_act(rin0, smem + c * C::ACT_SLOT, cur.goff, (unsigned)c * icb0, wave, tid);
+        for (int c = 0; c < 4; ++c) issued += is_dma_act<NT>(rin0, smem + c * C::ACT_SLOT, cur.goff, (unsigned)c * icb0, wave, tid);
         mark_x = issued;
 #pragma unroll
         for (int t = 0; t < IS_WDIST; ++t) issued += is_dma_w(make_rsrc(p0.w), smem + C::W_OFF + t * C::WGRAN, (unsigned)t * 9216u, 576, wave, tid);
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
         __builtin_amdgcn_s_waitcnt(0x0F70);   // (the one full drain of the launch: granule 0 is read by the first step)
     }
 
-    f32x16 A0[1][2], A1[1][2], A2[1][2], A3[1][2], A5[2][2];
+    f32x16 A0[1][NT], A1[1][NT], A2[1][NT], A3[1][NT], A5[2][NT];
 
     int item = 0;
     for (int r = 0; r < nrdb; ++r) {
@@ -398,8 +408,8 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                 const __amdgpu_buffer_rsrc_t rr1 = make_rsrc((const float*)p5.res1.p + (size_t)cur.n * p5.res1.n_stride);
                 const unsigned r1_cb = (unsigned)p5.res1.cb_stride;
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int oy = cur.oy0 + wave * 2 + nt, ox = cur.ox0 + nn;
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int oy = cur.oy0 + wave * NT + nt, ox = cur.ox0 + nn;
                     const bool pv = (oy < p5.Hout) & (ox < p5.Wout);
                     const unsigned pixel = (unsigned)(oy * p5.Wout + ox) * 16u;
 #pragma unroll
@@ -416,12 +426,12 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
+                    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                         for (int e = 0; e < 16; ++e) A5[mi][nt][e] = 0.f;
             }
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) A0[0][nt][e] = 0.f, A1[0][nt][e] = 0.f, A2[0][nt][e] = 0.f, A3[0][nt][e] = 0.f;
 
@@ -432,18 +442,18 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
 
             auto request_group = [&](int c0) {   // chunks c0, c0 + 1 of this item's slab
                 if constexpr (IS_BORDER) is_wait_vm(__builtin_amdgcn_readfirstlane(issued - own_mark));   // (the flag covered the border only: this tile's own interior pixels must be in memory)
-                if constexpr (!(IS_ABL & 8)) issued += is_dma_act(rin, smem + (c0 & 3) * C::ACT_SLOT, cur.goff, (unsigned)c0 * icb, wave, tid);
-                if constexpr (!(IS_ABL & 8)) issued += is_dma_act(rin, smem + ((c0 + 1) & 3) * C::ACT_SLOT, cur.goff, (unsigned)(c0 + 1) * icb, wave, tid);
+                if constexpr (!(IS_ABL & 8)) issued += is_dma_act<NT>(rin, smem + (c0 & 3) * C::ACT_SLOT, cur.goff, (unsigned)c0 * icb, wave, tid);
+                if constexpr (!(IS_ABL & 8)) issued += is_dma_act<NT>(rin, smem + ((c0 + 1) & 3) * C::ACT_SLOT, cur.goff, (unsigned)(c0 + 1) * icb, wave, tid);
                 arr_issued = true;
                 mark_act = issued;
             };
-            auto request_next_x = [&](const ISGeo& nxt) {
+            auto request_next_x = [&](const ISGeo<NT>& nxt) {
                 const dasr_conv_params& pn = layers[L0n];
                 const __amdgpu_buffer_rsrc_t rinn = make_rsrc((const bf16_t*)pn.in.p + (size_t)nxt.n * pn.in.n_stride);
                 const unsigned icbn = (unsigned)(pn.in.cb_stride * 2);
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if constexpr (!(IS_ABL & 8)) issued += is_dma_act(rinn, smem + c * C::ACT_SLOT, nxt.goff, (unsigned)c * icbn, wave, tid);
+                    if constexpr (!(IS_ABL & 8)) issued += is_dma_act<NT>(rinn, smem + c * C::ACT_SLOT, nxt.goff, (unsigned)c * icbn, wave, tid);
                 mark_x = issued;
                 next_x_issued = true;
             };
@@ -499,7 +509,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                     if (s == 0) {
                         if (poll_now && wave == 0) {
                             if constexpr (GK == 5) {
-                                const ISGeo nq = geo_of(sn);
+                                const ISGeo<NT> nq = geo_of(sn);
                                 if (lane < 9) is_dma_poll(rflags, smem + C::POLL_OFF + sn * 64, nq.nbo);
                             } else {
                                 if (lane < 9) is_dma_poll(rflags, smem + C::POLL_OFF + cur.slot * 64, cur.nbo);
@@ -519,16 +529,16 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                 };
                 const unsigned long long t0 = IS_T();
                 if constexpr (d.kind == 1) {
-                    if constexpr (d.u0 == 0) is_body<1, 1024, 0, F16>(A0[0], A0[0], abuf, wbuf, baddr, aoff, mid);
-                    else if constexpr (d.u0 == 1) is_body<1, 1024, 0, F16>(A1[0], A1[0], abuf, wbuf, baddr, aoff, mid);
-                    else if constexpr (d.u0 == 2) is_body<1, 1024, 0, F16>(A2[0], A2[0], abuf, wbuf, baddr, aoff, mid);
-                    else is_body<1, 1024, 0, F16>(A3[0], A3[0], abuf, wbuf, baddr, aoff, mid);
+                    if constexpr (d.u0 == 0) is_body<NT, 1, 1024, 0, F16>(A0[0], A0[0], abuf, wbuf, baddr, aoff, mid);
+                    else if constexpr (d.u0 == 1) is_body<NT, 1, 1024, 0, F16>(A1[0], A1[0], abuf, wbuf, baddr, aoff, mid);
+                    else if constexpr (d.u0 == 2) is_body<NT, 1, 1024, 0, F16>(A2[0], A2[0], abuf, wbuf, baddr, aoff, mid);
+                    else is_body<NT, 1, 1024, 0, F16>(A3[0], A3[0], abuf, wbuf, baddr, aoff, mid);
                 } else if constexpr (d.kind == 2) {
-                    if constexpr (d.u0 == 1) is_body<2, 1024, 9216, F16>(A1[0], A2[0], abuf, wbuf, baddr, aoff, mid);
-                    else is_body<2, 1024, 9216, F16>(A2[0], A3[0], abuf, wbuf, baddr, aoff, mid);
+                    if constexpr (d.u0 == 1) is_body<NT, 2, 1024, 9216, F16>(A1[0], A2[0], abuf, wbuf, baddr, aoff, mid);
+                    else is_body<NT, 2, 1024, 9216, F16>(A2[0], A3[0], abuf, wbuf, baddr, aoff, mid);
                     static_assert(d.kind != 2 || (d.u0 == 1 && d.u1 == 2) || (d.u0 == 2 && d.u1 == 3), "pairs of the program");
                 } else {
-                    is_body<2, 2048, 1024, F16>(A5[0], A5[1], abuf, wbuf, baddr, aoff, mid);
+                    is_body<NT, 2, 2048, 1024, F16>(A5[0], A5[1], abuf, wbuf, baddr, aoff, mid);
                 }
                 const unsigned long long t1 = IS_T();
                 // ---- end of the step: everything requested up to the end of step g - 2 has landed (the granule of step g + 1 among it); flag words / publish / group as due
@@ -582,7 +592,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
 #pragma unroll
                     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
+                        for (int nt = 0; nt < NT; ++nt) {
                             A5[mi][nt] *= c1;
                             asm volatile("" : "+v"(A5[mi][nt]));   // (here, not sunk behind the next step's DMA requests: the wait for the residual would drain them)
                         }
@@ -606,33 +616,33 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                         // BORDER FIRST (IS_BORDER): the neighbours read only the border pixels of the 16-bit planes, and the flag waits for the acknowledgement of what it covers:
                         // pass 1 stores those pixels alone (a few KB per tile), the flag's bookkeeping is taken behind it, pass 2 stores the rest (and the fp32 stream)
                         if constexpr (IS_ABL & 1) {
-                            asm volatile("" ::"v"(A5[0][0]), "v"(A5[0][1]), "v"(A5[1][0]), "v"(A5[1][1]));
+                            asm volatile("" ::"v"(A5[0][0]), "v"(A5[0][NT - 1]), "v"(A5[1][0]), "v"(A5[1][NT - 1]));
                         } else if (two && sh) {
-                            if constexpr (IS_BORDER) conv_epilogue<false, 2, 2, 1, E0 + 80 - 32, F16 ? 1 : 0, false, true, true, true, 1, C::TH>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                            if constexpr (IS_BORDER) conv_epilogue<false, 2, NT, 1, E0 + 80 - 32, F16 ? 1 : 0, false, true, true, true, 1, C::TH>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
                             pmark = issued;
-                            conv_epilogue<false, 2, 2, 1, E0 + 80, F16 ? 1 : 0, false, true, true, true, IS_BORDER ? 2 : 0, C::TH>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
-                            nlate = 24;
+                            conv_epilogue<false, 2, NT, 1, E0 + 80, F16 ? 1 : 0, false, true, true, true, IS_BORDER ? 2 : 0, C::TH>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                            nlate = 12 * NT;
                         } else if (sh) {
-                            if constexpr (IS_BORDER) conv_epilogue<false, 2, 2, 1, E0 + 64 - 32, F16 ? 1 : 0, false, true, true, true, 1, C::TH>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                            if constexpr (IS_BORDER) conv_epilogue<false, 2, NT, 1, E0 + 64 - 32, F16 ? 1 : 0, false, true, true, true, 1, C::TH>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
                             pmark = issued;
-                            conv_epilogue<false, 2, 2, 1, E0 + 64, F16 ? 1 : 0, false, true, true, true, IS_BORDER ? 2 : 0, C::TH>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
-                            nlate = 24;
+                            conv_epilogue<false, 2, NT, 1, E0 + 64, F16 ? 1 : 0, false, true, true, true, IS_BORDER ? 2 : 0, C::TH>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                            nlate = 12 * NT;
                         } else if (two) {   // (no 16-bit output: nothing a neighbour waits for)
-                            conv_epilogue<false, 2, 2, 1, E0 + 8 + 16, F16 ? 1 : 0, false, true, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                            conv_epilogue<false, 2, NT, 1, E0 + 8 + 16, F16 ? 1 : 0, false, true, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
                             pmark = issued, nlate = 0;
                         } else {
-                            conv_epilogue<false, 2, 2, 1, E0 + 8, F16 ? 1 : 0, false, true, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                            conv_epilogue<false, 2, NT, 1, E0 + 8, F16 ? 1 : 0, false, true, true, true>(p, A5, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
                             pmark = issued, nlate = 0;
                         }
                     } else {
-                        auto epi14 = [&](f32x16 (&A)[1][2]) {
+                        auto epi14 = [&](f32x16 (&A)[1][NT]) {
                             if constexpr (IS_ABL & 1) {
-                                asm volatile("" ::"v"(A[0][0]), "v"(A[0][1]));
+                                asm volatile("" ::"v"(A[0][0]), "v"(A[0][NT - 1]));
                             } else {
-                                if constexpr (IS_BORDER) conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true, true, 1, C::TH>(p, A, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                                if constexpr (IS_BORDER) conv_epilogue<false, 1, NT, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true, true, 1, C::TH>(p, A, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
                                 pmark = issued;
-                                conv_epilogue<false, 1, 2, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true, true, IS_BORDER ? 2 : 0, C::TH>(p, A, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
-                                nlate = 4;
+                                conv_epilogue<false, 1, NT, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true, true, IS_BORDER ? 2 : 0, C::TH>(p, A, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                                nlate = 2 * NT;
                             }
                         };
                         if constexpr (EU == 0) epi14(A0);
@@ -672,7 +682,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
             run(run, ISInt<0>{});
             IS_ACC(10, 1ull);
             {
-                const ISGeo nxt = geo_of(sn);
+                const ISGeo<NT> nxt = geo_of(sn);
                 if (has_next && !next_x_issued) {   // the next item's neighbours were not there in front of the conv5 epilogue: wait for them now
                     block_until(nxt, nxt.f0 + (unsigned)L0n);
                     request_next_x(nxt);
@@ -688,10 +698,10 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
 #endif
 }
 
-template <bool F16, bool BWD>
+template <bool F16, bool BWD, int NT>
 int launch_rdb_is(const dasr_conv_params* dev_layers, int nrdb, int tiles_y, int tiles_x, int tpw, unsigned* flags, unsigned* tickets, int* err, hipStream_t s, const char* name, int stagger, int grid) {
     static bool attr_set = false;
-    auto kfn = rdb_is_kernel<F16, BWD>;
+    auto kfn = rdb_is_kernel<F16, BWD, NT>;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, ISC::LDS_BYTES));
         attr_set = true;

@@ -177,6 +177,18 @@ class RRDBNetHIP:
                 return q, per_xcd // q
         return None
 
+    @staticmethod
+    def is_launch(N, h, w):
+        """(tile rows, workgroups per XCD, tiles per workgroup) of the input-stationary chained launch over N images of h x w, or None: tiles of 16 x 32 pixels, or of 8 x 32
+        where those fill more of the chip (16-row tiles leave it under 256 workgroups and 8-row tiles give more) -- mirrors dasr_rdb_chain"""
+        g16 = RRDBNetHIP.is_geometry(N, ceil_div(h, 16) * ceil_div(w, 32))
+        g8 = RRDBNetHIP.is_geometry(N, ceil_div(h, 8) * ceil_div(w, 32))
+        if g16 is None and g8 is None:
+            return None
+        if g16 is None or (g8 is not None and g16[0] < 32 and g8[0] > g16[0]):
+            return (8,) + g8
+        return (16,) + g16
+
     def chain_choice(self, N, h, w):
         """(form, k, why): how the trunk of a training plan of this shape runs.
         form 'layer', k >= 1: round 4's layer-by-layer chained launches (dasr_conv_chain).  A launch needs whole images per XCD and exactly 512 tiles: N images of T
@@ -209,7 +221,7 @@ class RRDBNetHIP:
                 return 'layer', k, ''
             why.append('layer form: %d tiles are not 512 k (k <= %d) with N / k a multiple of 8' % (ntiles, kmax))
         if self.chain_form in ('auto', 'is'):
-            if RRDBNetHIP.is_geometry(N, T) is not None and self.nf == 64:
+            if RRDBNetHIP.is_launch(N, h, w) is not None and self.nf == 64:
                 return 'is', 1, ''
             why.append('input-stationary form: needs nf 64, N %% 8 == 0 and q <= 32 workgroups per XCD with q a multiple of the %d tiles per image, q dividing the %s tiles per XCD, '
                        'at most 8 tiles per workgroup' % (T, ('%d' % (ntiles // 8)) if N % 8 == 0 else 'N x tiles / 8'))
@@ -628,7 +640,7 @@ class _Plan:
             per = N // nsub
             self.chains = []   # (the last conv5 has no 16-bit shadow to write: its own launch, over the whole batch; the input-stationary form runs it too)
             if self.chain_form == 'is':
-                ch = ConvChain(body, deps, N, tiles, net.device, err=net.chain_err, form='is')
+                ch = ConvChain(body, deps, N, ceil_div(h, 8) * ceil_div(w, 32), net.device, err=net.chain_err, form='is')   # (flag words for the finer of the two tile heights)
                 self.chains.append(ch)
                 ops.add(ch.op())
                 ops.keep.append(ch)
@@ -920,7 +932,7 @@ class _Plan:
             ops = main_ops
             self.chains_b = []   # (the last conv writes no 16-bit planes: its own launch)
             if self.chain_form == 'is':
-                ch = ConvChain(body, deps, N, tiles, net.device, err=self.chain.err, form='is')
+                ch = ConvChain(body, deps, N, ceil_div(h, 8) * ceil_div(w, 32), net.device, err=self.chain.err, form='is')
                 self.chains_b.append(ch)
                 ops.add(ch.op())
                 ops.keep.append(ch)
