@@ -540,6 +540,11 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                 } else {
                     is_body<NT, 2, 2048, 1024, F16>(A5[0], A5[1], abuf, wbuf, baddr, aoff, mid);
                 }
+                // data gradient: the LeakyReLU' mask planes of the conv this step completes are requested HERE, behind the step's last MFMA and in front of its wait + barrier
+                // (the fragment registers are dead, the weight requests of such a step are held back until after the epilogue: the loads have the queue to themselves and
+                // fly during the barrier; fetched inside the epilogue they waited in order behind the LDS-DMA in flight -- 29 k against 17 k cycles per item, r06_is_chain.txt)
+                MaskPre<NT> mpre;
+                if constexpr (BWD && EU_AFTER >= 0 && EU_AFTER < 4 && !IS_BORDER && !(IS_ABL & 1)) mask_prefetch<1, NT>(layers[L0 + EU_AFTER], mpre, tid, 0, cur.n, cur.oy0, cur.ox0);
                 const unsigned long long t1 = IS_T();
                 // ---- end of the step: everything requested up to the end of step g - 2 has landed (the granule of step g + 1 among it); flag words / publish / group as due
                 int nwait = issued - (IS_WDIST >= 3 ? mk0 : mk1);
@@ -641,7 +646,8 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                             } else {
                                 if constexpr (IS_BORDER) conv_epilogue<false, 1, NT, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true, true, 1, C::TH>(p, A, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
                                 pmark = issued;
-                                conv_epilogue<false, 1, NT, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true, true, IS_BORDER ? 2 : 0, C::TH>(p, A, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
+                                if constexpr (BWD && !IS_BORDER) conv_epilogue<false, 1, NT, 1, 68, F16 ? 1 : 0, true, true, true, true>(p, A, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0, &mpre);
+                                else conv_epilogue<false, 1, NT, 1, BWD ? 68 : 67, F16 ? 1 : 0, false, true, true, true, IS_BORDER ? 2 : 0, C::TH>(p, A, bl, 0.f, tid, 0, cur.n, cur.oy0, cur.ox0);
                                 nlate = 2 * NT;
                             }
                         };
