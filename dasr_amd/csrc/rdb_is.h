@@ -33,14 +33,14 @@
                       // SLOWER (9.9 / 10.6 ms per chain against 8.7 / 9.0): the second pass doubles the epilogue's store instructions and arithmetic -- profiles/r06_is_chain.txt
 #endif
 #ifndef IS_WDIST
-#define IS_WDIST 3   // the weights of step g + IS_WDIST are requested in step g (ring of four granules: at most 3)
+#define IS_WDIST 3   // 16-row tiles: the weights of step g + IS_WDIST are requested in step g (ring of four granules: at most 3; 2 measured the same)
 #endif
 #ifndef IS_PUB_DELAY
 #define IS_PUB_DELAY 1
 #endif
 struct ISC {   // what does not depend on the tile height
     static constexpr int NW = 8, NTH = 512, TW = 32, IW = 34;
-    static constexpr int WGRAN = 18432, NWG = 4, NSLOT = 4;
+    static constexpr int WGRAN = 18432, NSLOT = 4;
     static constexpr int LDS_BYTES = 163840;
     static constexpr int X_OFF = LDS_BYTES - 8192;           // the last 8 KB: biases, polled flag words, decision words (the same offsets for every tile height)
     static constexpr int BIAS_OFF = X_OFF;                   // [2 item parities][5 layers][64 floats]
@@ -61,7 +61,10 @@ struct ISCfg : ISC {
     static constexpr int AR = (APIECE + NTH - 1) / NTH;                // DMA rounds per chunk (the last one partial)
     static constexpr int ACT_SLOT = (APIECE * 16 + 1023) / 1024 * 1024;   // 20480 / 11264
     static constexpr int W_OFF = NSLOT * ACT_SLOT;
-    static_assert(W_OFF + NWG * WGRAN <= X_OFF, "LDS budget");
+    // ring of weight granules and how many steps ahead they are requested.  (8-row tiles have room for six granules, five steps ahead -- the same lead TIME as three steps
+    // of the 16-row tiles; measured: 2.53 / 2.59 ms per chain of the 32 x 32-crop launches against 2.43 / 2.52 ms with four / three.  Neither form waits for its weights.)
+    static constexpr int NWG = 4, WDIST = IS_WDIST;
+    static_assert(W_OFF + NWG * WGRAN <= X_OFF && WDIST < NWG && WDIST >= 2 && WDIST <= 5, "LDS budget / ring depth");
 };
 
 // the static program of one dense block on one tile: kind 1 = one Cout-32 conv u0, 2 = two Cout-32 convs u0, u1 on the same chunk, 5 = conv5; c = chunk of the slab
@@ -298,8 +301,9 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
     const int aoff = lane * 16;
 
     // ---- VMEM bookkeeping of this wave (LDS-DMA instructions only: epilogue loads / stores are not counted, which can only make a wait longer)
-    int issued = 0, mk0 = 0, mk1 = 0;
-    int g = 0;                                     // global step counter: the granule of step g lives in ring slot g & 3
+    int issued = 0;
+    int mk[8] = {0, 0, 0, 0, 0, 0, 0, 0};           // mk[k]: `issued` at the end of step g - 1 - k (g: the current step)
+    int g = 0;                                     // global step counter: the granule of step g lives in ring slot g % NWG
     bool pub_on = false;                           // a flag store is pending: value pub_val to word pub_off once every op up to pub_mark is acknowledged, at the end of step pub_due
     int pub_mark = 0, pub_due = 0, pub_late = 0;
     unsigned pub_off = 0, pub_val = 0;
@@ -358,14 +362,27 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
 #pragma unroll
         for (int c = 0; c < 4; ++c) issued += is_dma_act<NT>(rin0, smem + c * C::ACT_SLOT, cur.goff, (unsigned)c * icb0, wave, tid);
         mark_x = issued;
-#pragma unroll
-        for (int t = 0; t < IS_WDIST; ++t) issued += is_dma_w(make_rsrc(p0.w), smem + C::W_OFF + t * C::WGRAN, (unsigned)t * 9216u, 576, wave, tid);
+        auto pro = [&](auto tc) {   // the granule of step t of the first item
+            constexpr int t = decltype(tc)::value;
+            if constexpr (t < C::WDIST) {
+                constexpr ISStep e = IS_PROG[t];
+                char* dst = smem + C::W_OFF + t * C::WGRAN;
+                if constexpr (e.kind == 5) {
+                    issued += is_dma_w(make_rsrc(layers[4].w), dst, (unsigned)e.c * 18432u, 1152, wave, tid);
+                } else {
+                    issued += is_dma_w(make_rsrc(layers[e.u0].w), dst, (unsigned)e.c * 9216u, 576, wave, tid);
+                    if constexpr (e.kind == 2) issued += is_dma_w(make_rsrc(layers[e.u1].w), dst + 9216, (unsigned)e.c * 9216u, 576, wave, tid);
+                }
+            }
+        };
+        pro(ISInt<0>{}), pro(ISInt<1>{}), pro(ISInt<2>{}), pro(ISInt<3>{}), pro(ISInt<4>{}), pro(ISInt<5>{}), pro(ISInt<6>{});
         if (!BWD && wave < 5) {
             const dasr_conv_params& pb = layers[wave];
             is_dma_bias(make_rsrc(pb.bias), smem + C::BIAS_OFF + wave * 256, (pb.bias != nullptr && lane < 32 * pb.mt) ? (unsigned)lane * 4u : OOB);
             ++issued;
         }
-        mk0 = mk1 = issued;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mk[k] = issued;
         __builtin_amdgcn_s_waitcnt(0x0F70);   // (the one full drain of the launch: granule 0 is read by the first step)
     }
 
@@ -389,8 +406,12 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
             const void* wp2 = layers[L0 + 2].w;
             const void* wp3 = layers[L0 + 3].w;
             const void* wp4 = layers[L0 + 4].w;
-            const void* wpn = layers[L0n].w;
-            auto wptr = [&](int u, bool next) -> const void* { return next ? wpn : (u == 0 ? wp0 : u == 1 ? wp1 : u == 2 ? wp2 : u == 3 ? wp3 : wp4); };
+            const void* wpn0 = layers[L0n].w;       // (a step requests the granule of WDIST <= 5 steps ahead: steps 0-4 of the next item = its conv1, conv2, conv3)
+            const void* wpn1 = layers[L0n + 1].w;
+            const void* wpn2 = layers[L0n + 2].w;
+            auto wptr = [&](int u, bool next) -> const void* {
+                return next ? (u == 0 ? wpn0 : u == 1 ? wpn1 : wpn2) : (u == 0 ? wp0 : u == 1 ? wp1 : u == 2 ? wp2 : u == 3 ? wp3 : wp4);
+            };
 
             // x of this item is in LDS (requested at the end of the previous item / in the prologue)
             {
@@ -464,8 +485,8 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                 constexpr int GK = is_group_of_step(TT);            // group awaited during this step (0: none)
                 constexpr bool MUST = GK >= 1 && GK <= 4 && TT + 1 == IS_WIN1[GK];   // the group is read in the next step
                 const char* abuf = smem + (d.c & 3) * C::ACT_SLOT;
-                const char* wbuf = smem + C::W_OFF + (g & 3) * C::WGRAN;
-                char* wnext = smem + C::W_OFF + ((g + IS_WDIST) & 3) * C::WGRAN;
+                const char* wbuf = smem + C::W_OFF + (g % C::NWG) * C::WGRAN;
+                char* wnext = smem + C::W_OFF + ((g + C::WDIST) % C::NWG) * C::WGRAN;
                 if constexpr (GK != 0 && TT == IS_WIN0[GK > 0 ? GK : 1]) arr_issued = false;
                 // ---- what this step requests besides its MFMAs.  Whether a group's nine flag words have reached their target is decided by WAVE 0 ALONE (at the end of
                 // the step in which it polled, from the words its LDS-DMA brought) and handed to the other waves through a decision word in LDS across the step's
@@ -493,10 +514,10 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                 }
                 constexpr int EU_AFTER = is_epi_after(TT);
                 auto prefetch_w = [&]() {   // weights of step g + 3 (g: this step)
-                    if (g + IS_WDIST < total_steps && !(IS_ABL & 2)) {
-                        constexpr int T3 = (TT + IS_WDIST) % C::NSTEP;
+                    if (g + C::WDIST < total_steps && !(IS_ABL & 2)) {
+                        constexpr int T3 = (TT + C::WDIST) % C::NSTEP;
                         constexpr ISStep e = IS_PROG[T3];
-                        constexpr bool NX = TT + IS_WDIST >= C::NSTEP;
+                        constexpr bool NX = TT + C::WDIST >= C::NSTEP;
                         if constexpr (e.kind == 5) {
                             issued += is_dma_w(make_rsrc(wptr(4, NX)), wnext, (unsigned)e.c * 18432u, 1152, wave, tid);
                         } else {
@@ -547,7 +568,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                 if constexpr (BWD && EU_AFTER >= 0 && EU_AFTER < 4 && !IS_BORDER && !(IS_ABL & 1)) mask_prefetch<1, NT>(layers[L0 + EU_AFTER], mpre, tid, 0, cur.n, cur.oy0, cur.ox0);
                 const unsigned long long t1 = IS_T();
                 // ---- end of the step: everything requested up to the end of step g - 2 has landed (the granule of step g + 1 among it); flag words / publish / group as due
-                int nwait = issued - (IS_WDIST >= 3 ? mk0 : mk1);
+                int nwait = issued - mk[C::WDIST - 2];   // everything requested up to the end of step g + 1 - WDIST: the granule of step g + 1 among it
                 bool do_pub = false;
                 if (pub_on && g >= pub_due) do_pub = true, nwait = min(nwait, issued - pub_mark + pub_late);
                 if constexpr (MUST) {
@@ -572,7 +593,9 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                 }
                 __builtin_amdgcn_s_barrier();
                 if (do_pub) flag_store();
-                mk0 = mk1, mk1 = issued;
+#pragma unroll
+                for (int k = 7; k > 0; --k) mk[k] = mk[k - 1];
+                mk[0] = issued;
                 const unsigned long long t2 = IS_T();
                 IS_ACC(d.kind == 1 ? 0 : 1, t1 - t0);
                 IS_ACC(2, t2 - t1);
@@ -672,7 +695,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                             ++issued;
                         }
                     }
-                    mk1 = issued;   // (they count as requests of this step: the end of step g + 2 waits for them)
+                    mk[0] = issued;   // (they count as requests of this step)
                     IS_ACC(EU == 4 ? 6 : 5, IS_T() - t4);
                 }
                 ++g;
