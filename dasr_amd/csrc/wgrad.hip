@@ -828,8 +828,110 @@ struct W3L {
     static constexpr int LDS_BYTES = NBUF * W3G::BUF_BYTES;
 };
 
-template <bool F16>
-__global__ __launch_bounds__(1024, 1) void wgrad3_ld_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit_flags, float* __restrict__ ws) {
+// The k-steps of one pixel tile for one compute wave, REGISTER-WINDOW form (round 6).  The 12-wave decomposition of round 3 read 6 fragments per
+// k-step (5 X + 1 G) for 5 (th = 0) or 4 (th = 1) MFMAs: 576 KB of transposed LDS reads per tile and CU + 47 KB of LDS-DMA writes = 4 870 cycles of the
+// LDS port (128 B / clk) against 3 840 cycles of MFMA -- the kernel sat at 71 % MFMA busy because the LDS port, not the matrix pipe, bounded it
+// (profiles/r03_wgrad_ablation.txt: MFMA + fragment reads alone 1 686 us against 1 275 us MFMA-bound; profiles/r06f_pmc_mfma_busy.txt).
+// Here a wave owns taps that share a COLUMN of the 3 x 3 stencil, so that the X fragment of halo row r + dy is the same registers for every (r, dy)
+// with the same sum: th = 0: (dy 0..2, dx 0) + (dy 0..1, dx 1); th = 1: (dy 0..2, dx 2) + (2, 1).  Per k-step: ONE new fragment per column + the G
+// fragment = 3 reads for 5 / 4 MFMAs (312 KB per tile and CU).  A fragment is reloaded IN PLACE right behind the last MFMA that reads it (dy = 0) and is
+// next needed as dy = 2 (dy = 1 for the two-row column) of the following k-step: 28 fragment registers instead of 36.
+struct W3Win {
+    bf16x8 xa[3], xb[2], g[2];   // column A: halo rows r, r + 1, r + 2 (ring of three); column B: two rows (th 0) / one row, double-buffered (th 1); G row r, r + 1
+};
+template <int TH>
+__device__ __forceinline__ bf16x8 w3_win_x(const char* buf, int ibase, int R, int dx) {
+    const int o = ibase + (R * W3G::IW + dx) * 32;
+    return frag_tr(buf, o, o + 4 * 32);
+}
+__device__ __forceinline__ bf16x8 w3_win_g(const char* buf, int gbase, int r) {
+    const int o = gbase + r * W3G::PW * 32;
+    return frag_tr(buf, o, o + 4 * 32);
+}
+// the fragments k-step 0 of a tile starts from (the first tile of a workgroup; later tiles get them in place during the previous tile's last k-step)
+template <int TH>
+__device__ __forceinline__ void w3_win_prologue(const char* buf, int gbase, int ibase, W3Win& w) {
+    constexpr int DXA = TH ? 2 : 0;
+    w.g[0] = w3_win_g(buf, gbase, 0);
+    w.xa[0] = w3_win_x<TH>(buf, ibase, 0, DXA);
+    w.xb[0] = w3_win_x<TH>(buf, ibase, TH ? 2 : 0, 1);
+    w.xa[1] = w3_win_x<TH>(buf, ibase, 1, DXA);
+    if constexpr (TH == 0) w.xb[1] = w3_win_x<TH>(buf, ibase, 1, 1);
+    w.xa[2] = w3_win_x<TH>(buf, ibase, 2, DXA);
+}
+// k-steps 0 .. 6 of a tile
+template <bool F16, int TH>
+__device__ __forceinline__ void w3_win_steps(const char* buf, int gbase, int ibase, W3Win& w, f32x16 (&acc)[5], float& bsum, bool want_bias) {
+    constexpr int DXA = TH ? 2 : 0;
+#pragma unroll
+    for (int r = 0; r < W3G::PH - 1; ++r) {
+        w.g[(r + 1) & 1] = w3_win_g(buf, gbase, r + 1);
+        if constexpr (TH == 1) w.xb[(r + 1) & 1] = w3_win_x<TH>(buf, ibase, r + 3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0] = mfma16<F16>(w.g[r & 1], w.xa[r % 3], acc[0]);                       // (0, DXA)
+        __builtin_amdgcn_sched_barrier(0);
+        w.xa[r % 3] = w3_win_x<TH>(buf, ibase, r + 3, DXA);                          // -> (2, DXA) of k-step r + 1
+        __builtin_amdgcn_sched_barrier(0);
+        acc[3] = mfma16<F16>(w.g[r & 1], w.xb[r & 1], acc[3]);                       // th 0: (0, 1); th 1: (2, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (TH == 0) {
+            w.xb[r & 1] = w3_win_x<TH>(buf, ibase, r + 2, 1);                        // -> (1, 1) of k-step r + 1
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        acc[1] = mfma16<F16>(w.g[r & 1], w.xa[(r + 1) % 3], acc[1]);                 // (1, DXA)
+        if constexpr (TH == 0) {
+            acc[4] = mfma16<F16>(w.g[r & 1], w.xb[(r + 1) & 1], acc[4]);             // (1, 1)
+            if (want_bias) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum += frag_f32<F16>(w.g[r & 1], j);
+            }
+        }
+        acc[2] = mfma16<F16>(w.g[r & 1], w.xa[(r + 2) % 3], acc[2]);                 // (2, DXA)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// k-step 7 of a tile: nothing is read from the tile's own image any more; every fragment register is re-filled IN PLACE, right behind its last MFMA, with
+// what k-step 0 of the NEXT tile starts from (`nbuf`: landed -- the barrier in front of this k-step is the loaders' "tile t + 1 is in LDS"; behind the last tile
+// of the workgroup the reads fetch a stale image and nobody uses them).  So a tile starts without a burst of prologue reads behind its barrier.
+template <bool F16, int TH>
+__device__ __forceinline__ void w3_win_last(const char* nbuf, int gbase, int ibase, W3Win& w, f32x16 (&acc)[5], float& bsum, bool want_bias) {
+    constexpr int DXA = TH ? 2 : 0, r = W3G::PH - 1;
+    static_assert(r == 7, "ring indices below are those of k-step 7");
+    w.g[0] = w3_win_g(nbuf, gbase, 0);
+    if constexpr (TH == 1) w.xb[0] = w3_win_x<TH>(nbuf, ibase, 2, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[2] = mfma16<F16>(w.g[1], w.xa[0], acc[2]);                                   // (2, DXA): halo row 9
+    __builtin_amdgcn_sched_barrier(0);
+    w.xa[0] = w3_win_x<TH>(nbuf, ibase, 0, DXA);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[0] = mfma16<F16>(w.g[1], w.xa[1], acc[0]);                                   // (0, DXA): halo row 7
+    __builtin_amdgcn_sched_barrier(0);
+    w.xa[1] = w3_win_x<TH>(nbuf, ibase, 1, DXA);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[1] = mfma16<F16>(w.g[1], w.xa[2], acc[1]);                                   // (1, DXA): halo row 8
+    __builtin_amdgcn_sched_barrier(0);
+    w.xa[2] = w3_win_x<TH>(nbuf, ibase, 2, DXA);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TH == 0) {
+        acc[4] = mfma16<F16>(w.g[1], w.xb[0], acc[4]);                               // (1, 1): halo row 8
+        __builtin_amdgcn_sched_barrier(0);
+        w.xb[0] = w3_win_x<TH>(nbuf, ibase, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (want_bias) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum += frag_f32<F16>(w.g[1], j);
+        }
+        acc[3] = mfma16<F16>(w.g[1], w.xb[1], acc[3]);                               // (0, 1): halo row 7
+        __builtin_amdgcn_sched_barrier(0);
+        w.xb[1] = w3_win_x<TH>(nbuf, ibase, 1, 1);
+    } else {
+        acc[3] = mfma16<F16>(w.g[1], w.xb[1], acc[3]);                               // (2, 1): halo row 9
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool F16, bool WIN>
+__device__ __forceinline__ void wgrad3_ld_body(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit_flags, float* __restrict__ ws) {
     using C = W3G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -925,6 +1027,25 @@ __global__ __launch_bounds__(1024, 1) void wgrad3_ld_kernel(const dasr_wgrad_par
     const bool want_bias = P.want_bias && ct == 0 && th == 0;
     __syncthreads();   // tile 0 is in LDS
     int cur = 0;
+    if constexpr (WIN) {
+        // ONE barrier per tile, in front of its LAST k-step: for the loaders it is "tile t + 1 has landed, and nobody requests anything from tile t's image
+        // any more" (k-step 7 reads registers only; its in-place reloads go to tile t + 1's image).  One loop per tap set: the wave-uniform choice is made
+        // once; every wave, active or not, meets the same barriers.
+        auto run = [&](auto th_c) {
+            constexpr int TH = decltype(th_c)::value;
+            W3Win w;
+            if (active) w3_win_prologue<TH>(smem, gbase, ibase, w);
+            for (int tile = split; tile < ntiles; tile += nsplit) {
+                const char* buf = smem + cur * C::BUF_BYTES;
+                cur = cur == 2 ? 0 : cur + 1;
+                if (active) w3_win_steps<F16, TH>(buf, gbase, ibase, w, acc, bsum, want_bias);
+                __syncthreads();
+                if (active) w3_win_last<F16, TH>(smem + cur * C::BUF_BYTES, gbase, ibase, w, acc, bsum, want_bias);
+            }
+        };
+        if (th == 0) run(std::integral_constant<int, 0>{});
+        else run(std::integral_constant<int, 1>{});
+    } else
     for (int tile = split; tile < ntiles; tile += nsplit) {
         const char* buf = smem + cur * C::BUF_BYTES;
         cur = cur == 2 ? 0 : cur + 1;
@@ -962,10 +1083,11 @@ __global__ __launch_bounds__(1024, 1) void wgrad3_ld_kernel(const dasr_wgrad_par
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
             if (t < na) {
+                const int tap = WIN ? (th ? (t == 0 ? 2 : t == 1 ? 5 : t == 2 ? 8 : 7) : (t == 0 ? 0 : t == 1 ? 3 : t == 2 ? 6 : t == 3 ? 1 : 4)) : t0 + t;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
                     const int oc = (j & 3) + 8 * (j >> 2) + 4 * h;
-                    w[(size_t)(t0 + t) * 3 * 2048 + oc * 64 + cin] = acc[t][j];
+                    w[(size_t)tap * 3 * 2048 + oc * 64 + cin] = acc[t][j];
                 }
             }
         }
@@ -975,6 +1097,17 @@ __global__ __launch_bounds__(1024, 1) void wgrad3_ld_kernel(const dasr_wgrad_par
         }
     }
 }
+
+template <bool F16>
+__global__ __launch_bounds__(1024, 1) void wgrad3_ld_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit_flags, float* __restrict__ ws) {
+    wgrad3_ld_body<F16, true>(parts, nparts, nsplit_flags, ws);
+}
+#ifdef DASR_BENCH   // the round-3 compute form (six fragment reads per k-step), kept for the A/B of profiles/r06_wgrad_window.txt
+template <bool F16>
+__global__ __launch_bounds__(1024, 1) void wgrad3_ld6_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit_flags, float* __restrict__ ws) {
+    wgrad3_ld_body<F16, false>(parts, nparts, nsplit_flags, ws);
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // wgrad v4 (round 3): the same parts (one 64-channel input block x up to three 32-oc tiles x 9 taps = 54 accumulator tiles) and the same
@@ -1381,6 +1514,19 @@ int launch_wgrad3_ld(const dasr_wgrad_part* parts, int nparts, int nsplit, float
     DASR_LAUNCH_TAG(__PRETTY_FUNCTION__, kfn, dim3(nparts * (nsplit & 0xffff)), dim3(W3L::NT), W3L::LDS_BYTES, s, parts, nparts, nsplit, ws);
     return (int)hipGetLastError();
 }
+#ifdef DASR_BENCH
+template <bool F16>
+int launch_wgrad3_ld6(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws, hipStream_t s) {
+    auto kfn = wgrad3_ld6_kernel<F16>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, W3L::LDS_BYTES));
+        attr_set = true;
+    }
+    DASR_LAUNCH_TAG(__PRETTY_FUNCTION__, kfn, dim3(nparts * (nsplit & 0xffff)), dim3(W3L::NT), W3L::LDS_BYTES, s, parts, nparts, nsplit, ws);
+    return (int)hipGetLastError();
+}
+#endif
 
 int g_use_tr = -1;  // -1 unknown, 0 gather fallback, 1 transpose reads
 int g_wgrad3_ld = 1;  // 3x3 stride-1 weight gradients on 16-bit tensors: wgrad3_ld_kernel (12 compute + 4 loader waves); 0 = wgrad3_kernel
@@ -1392,6 +1538,7 @@ int g_wgrad3_ld = 1;  // 3x3 stride-1 weight gradients on 16-bit tensors: wgrad3
 int g_wgrad4 = 0;
 int g_wgrad3_stagger = 1;
 int g_wgrad3_abl = 0;   // DASR_BENCH builds: ablation bits of wgrad3_kernel (dasr_wgrad_set_mode bits 3-6); ignored by the product build
+int g_wgrad3_ld6 = 0;   // DASR_BENCH builds: wgrad3_ld6_kernel (the round-3 compute form of the loader-wave kernel) instead of wgrad3_ld_kernel (A/B)
 int g_wgrad3_glds = 0;  // LDS-DMA wgrad3: faster alone (490 vs 470 TFLOP/s) but its 101 KB of LDS keeps the other sub-batch stream off the CU: -2.5 % on the step
 
 }  // namespace
@@ -1420,6 +1567,7 @@ extern "C" int dasr_wgrad_set_mode(int use_tr) {
     g_wgrad3_glds = (use_tr & 2) ? 1 : 0;  // bit 1: LDS-DMA wgrad3 instead of the register-staged one (A/B)
     g_wgrad4 = (use_tr & 128) ? 1 : 0;     // bit 7: wgrad4_kernel instead of wgrad3_kernel (A/B)
     g_wgrad3_ld = (use_tr & 256) ? 0 : 1;  // bit 8: the register-staged 12-wave wgrad3_kernel instead of the loader-wave kernel (A/B)
+    g_wgrad3_ld6 = (use_tr & 512) ? 1 : 0; // bit 9: the loader-wave kernel with six fragment reads per k-step (round 3) instead of the register window (A/B)
 #else
     if (use_tr & ~1) return DASR_EINVAL;   // the kernel-selection bits exist in libdasr_hip_ablate.so only
 #endif
@@ -1479,6 +1627,7 @@ extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int3
             default: break;
         }
         if (tr && !g_wgrad3_ld && f32 != 1) return f32 == 2 ? launch_wgrad3<true, false, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3<true, false>(parts_dev, nparts, nsplit, ws, s);
+        if (tr && g_wgrad3_ld6 && f32 != 1) return f32 == 2 ? launch_wgrad3_ld6<true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3_ld6<false>(parts_dev, nparts, nsplit, ws, s);
 #endif
         if (!tr || f32 == 1) return DASR_EINVAL;   // gfx950 has ds_read_b64_tr_b16 (dasr_probe_tr16 confirms it); the grouped 3x3 form exists for 16-bit tensors only
         return f32 == 2 ? launch_wgrad3_ld<true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3_ld<false>(parts_dev, nparts, nsplit, ws, s);
