@@ -95,8 +95,8 @@ def main(argv=None):
         raise NotImplementedError('Generator model [{:s}] not recognized'.format(o.generator))
     if o.discriminator not in ('FSD', 'nld_s1', 'nld_s2'):
         raise NotImplementedError('Please specified conv_net of discriminator.')
-    if o.wgan or not o.highpass or o.cat_or_sum not in ('cat', 'sum') or o.norm_layer not in ('Instance', 'Batch') or (o.norm_layer == 'Batch' and o.discriminator != 'FSD'):
-        raise NotImplementedError('DSN on MI355X covers the default path: DCGAN loss, high-pass front end, wavelet bands cat, Instance norm')
+    if not o.highpass or o.cat_or_sum not in ('cat', 'sum') or o.norm_layer not in ('Instance', 'Batch'):
+        raise NotImplementedError('DSN on MI355X covers: high-pass front end, wavelet bands cat / sum, Instance or Batch norm')
     if o.checkpoint is None:
         print('Use --checkpoint to define the model parameters used')
         return None
@@ -105,7 +105,7 @@ def main(argv=None):
     for d in dirs.values():
         os.makedirs(d, exist_ok=True)
     m = DSNModel(dict(n_res_blocks=o.num_res_blocks, kernel_size=o.kernel_size, filter=o.filter, norm_layer=o.norm_layer, w_per=0.0,
-                      discriminator=o.discriminator, generator=o.generator, cat_or_sum=o.cat_or_sum))
+                      discriminator=o.discriminator, generator=o.generator, cat_or_sum=o.cat_or_sum, wgan=o.wgan))   # (--wgan: raw logit maps, model.py:104-105)
     m.load(o.checkpoint)
     print('Using model at epoch %d' % m.epoch)
     shutil.copyfile(o.checkpoint, os.path.join(out, o.name + '.tar'))

@@ -81,11 +81,13 @@ def default_init_state(spec, bn_prefixes=()):
         w = torch.empty(shape)
         init.kaiming_uniform_(w, a=math.sqrt(5))
         sd[k] = w
-        fan_in = shape[1] * shape[2] * shape[3]
-        b = torch.empty(spec[i + 1][1])
-        init.uniform_(b, -1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
-        sd[spec[i + 1][0]] = b
-        i += 2
+        i += 1
+        if i < len(spec) and spec[i][0] == k[:-len('weight')] + 'bias':   # (the BatchNorm-ed convs of the nld discriminators have none: model.py:139-142)
+            fan_in = shape[1] * shape[2] * shape[3]
+            b = torch.empty(spec[i][1])
+            init.uniform_(b, -1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
+            sd[spec[i][0]] = b
+            i += 1
     return sd
 
 
@@ -432,9 +434,11 @@ class DSNModel:
         self.d_arch = o['discriminator'].lower()
         if self.d_arch not in ('fsd', 'nld_s1', 'nld_s2'):
             raise NotImplementedError('Discriminator architecture [{:s}] not recognized'.format(o['discriminator']))
-        if o['upscale_factor'] != 4 or o['norm_layer'] not in ('Instance', 'Batch') or (self.d_arch != 'fsd' and o['norm_layer'] != 'Instance'):
-            raise NotImplementedError('DSN on MI355X: De_resnet x4 + FSD / nld_s1 / nld_s2 discriminator with Instance norm (FSD also with Batch norm)')
-        # norm_layer 'Batch' (FSD, model.py:176-189): iteration() runs BatchNorm in training mode (statistics per discriminator call = per half
+        if o['upscale_factor'] != 4:
+            raise NotImplementedError('DSN on MI355X: De_resnet x4 / DSGAN generators (--upscale_factor 4)')
+        if o['norm_layer'] not in ('Instance', 'Batch'):
+            raise NotImplementedError('Norm layer [{:s}] not recognized'.format(str(o['norm_layer'])))   # model.py:136-137,191
+        # norm_layer 'Batch' (FSD: model.py:176-189; nld_s1 / nld_s2: model.py:136-160, bias-free convs): iteration() runs BatchNorm in training mode (statistics per discriminator call = per half
         # [fake | real], as the reference's two calls); translate() / ddm_of() run it in eval mode: a conv-only copy with the running statistics
         # folded in (refreshed when the weights changed)
         self.bn = o['norm_layer'] == 'Batch'
@@ -492,7 +496,7 @@ class DSNModel:
         if self.d_arch == 'fsd':
             spec_layers = fsd_spec(nc, gk, norm='Batch' if self.bn else 'Instance')
         else:   # codes/DSN/model.py:84-89: NLayerDiscriminator(n_layers=2) with stride 1 / 2
-            spec_layers = dsn_nld_spec(nc, 1 if self.d_arch == 'nld_s1' else 2, gk)
+            spec_layers = dsn_nld_spec(nc, 1 if self.d_arch == 'nld_s1' else 2, gk, norm='Batch' if self.bn else 'Instance')
         # default nn init, G first then D (codes/DSN/train.py:124-135 under torch.manual_seed(0))
         self.netG.load_state_dict(default_init_state(self.netG.spec))
         if self.bn:
@@ -500,7 +504,8 @@ class DSNModel:
             sd = default_init_state(self.netD.spec, bn_prefixes=[L['bn'] for L in self.netD.layers if L['norm'] == 'batch'])
             sd.update({k: v.clone() for k, v in self.netD.buffers.items()})
             self.netD.load_state_dict(sd)
-            self.netD_eval = NLayerDiscriminatorHIP(nc, device=self.device, spec_layers=fsd_spec(nc, gk, norm='BatchEval'))
+            self.netD_eval = NLayerDiscriminatorHIP(nc, device=self.device, spec_layers=(
+                fsd_spec(nc, gk, norm='BatchEval') if self.d_arch == 'fsd' else dsn_nld_spec(nc, 1 if self.d_arch == 'nld_s1' else 2, gk, norm='BatchEval')))
             self._d_eval_stale = True
         else:
             self.netD = NLayerDiscriminatorHIP(nc, device=self.device, spec_layers=spec_layers)
@@ -1193,8 +1198,14 @@ class _InferPlan:
             o.f[0], o.f[1], o.t[2], o.t[3] = 0.5, 0.5, NULL_T, d.x.view()
         ops.add(o)
         ops.extend(d.fwd)
-        o = _op(_lib.OP_SIGMOID_FWD)
-        o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1] = d.logits.view(), N, 1, nh, nw, self.dout.view()
+        if m.wgan:   # --wgan (model.py:104-105): the discriminator map is the raw logit map
+            o = _op(_lib.OP_AXPBY)
+            o.t[0], o.f[0], o.t[1], o.f[1] = d.logits.view(), 1.0, NULL_T, 0.0
+            o.i[0], o.i[1], o.i[2], o.i[3] = N, 1, nh, nw
+            o.t[2], o.t[3], o.f[2], o.t[4] = self.dout.view(), NULL_T, 1.0, NULL_T
+        else:
+            o = _op(_lib.OP_SIGMOID_FWD)
+            o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.t[1] = d.logits.view(), N, 1, nh, nw, self.dout.view()
         ops.add(o)
         if m.d_arch == 'fsd':
             o = _op(_lib.OP_LOWPASS)   # count-normalised box average = spread over the receptive field / coverage count

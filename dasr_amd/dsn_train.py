@@ -88,8 +88,8 @@ def check_supported(o, have_loader=True):
         raise NotImplementedError('Discriminator architecture [{:s}] not recognized'.format(o.discriminator))
     if o.wgan and o.norm_layer != 'Instance':
         raise NotImplementedError('--wgan (gradient penalty with its second-order pass through D, train.py:231-236) is built for InstanceNorm discriminators')
-    if not o.highpass or o.cat_or_sum not in ('cat', 'sum') or o.norm_layer not in ('Instance', 'Batch') or (o.norm_layer == 'Batch' and o.discriminator.lower() != 'fsd'):
-        raise NotImplementedError('DSN on MI355X covers: high-pass front end, wavelet bands cat, Instance norm (FSD also Batch norm)')
+    if not o.highpass or o.cat_or_sum not in ('cat', 'sum') or o.norm_layer not in ('Instance', 'Batch'):
+        raise NotImplementedError('DSN on MI355X covers: high-pass front end, wavelet bands cat / sum, Instance or Batch norm')
     if o.disc_freq < 1 or o.gen_freq < 1:
         raise ValueError('--disc_freq / --gen_freq must be >= 1')
 

@@ -44,20 +44,24 @@ def nlayer_d_spec(input_nc, ndf=64, n_layers=2):
 
 
 def fold_batchnorm_fsd(sd, eps=1e-5):
-    """FSD-Batch state_dict (codes/DSN/model.py:176-189: Conv, BatchNorm2d at net.net.3 / net.net.6) -> the equivalent conv-only state_dict of
-    the network in eval() mode: BN(z) = (z - mean) / sqrt(var + eps) * gamma + beta is a per-channel affine map of the conv output, folded
-    into the conv's weight and bias (host-side, float64, once per load).  Used for inference with BN discriminators (dataset generation,
-    create_dataset_modified.py:147-164); training a BN discriminator needs cross-rank batch statistics and is not on the hot path."""
+    """State_dict of a DSN discriminator with BatchNorm2d (FSD: codes/DSN/model.py:176-189, Conv + BatchNorm2d at net.net.3 / net.net.6; nld_s1 / nld_s2:
+    model.py:136-160, bias-free Conv + BatchNorm2d at net.model.3 / net.model.6) -> the equivalent conv-only state_dict of the network in eval() mode:
+    BN(z) = (z - mean) / sqrt(var + eps) * gamma + beta is a per-channel affine map of the conv output, folded into the conv's weight and bias (host-side,
+    float64, once per load).  Used for inference with BN discriminators (dataset generation, create_dataset_modified.py:147-164)."""
+    pre = 'net.model.' if any(k.startswith('net.model.') for k in sd) else 'net.net.'
     out = {}
     for k, v in sd.items():
-        if k.split('.')[-1] in ('running_mean', 'running_var', 'num_batches_tracked') or k.startswith(('net.net.3.', 'net.net.6.')):
+        if k.split('.')[-1] in ('running_mean', 'running_var', 'num_batches_tracked') or k.startswith((pre + '3.', pre + '6.')):
             continue
         out[k] = v.clone()
-    for conv, bn in (('net.net.2.', 'net.net.3.'), ('net.net.5.', 'net.net.6.')):
+    for conv, bn in ((pre + '2.', pre + '3.'), (pre + '5.', pre + '6.')):
         s = sd[bn + 'weight'].double() / torch.sqrt(sd[bn + 'running_var'].double() + eps)
         out[conv + 'weight'] = (sd[conv + 'weight'].double() * s.view(-1, 1, 1, 1)).float()
-        out[conv + 'bias'] = ((sd[conv + 'bias'].double() - sd[bn + 'running_mean'].double()) * s + sd[bn + 'bias'].double()).float()
-    return out
+        b = sd[conv + 'bias'].double() if (conv + 'bias') in sd else torch.zeros_like(s)
+        out[conv + 'bias'] = ((b - sd[bn + 'running_mean'].double()) * s + sd[bn + 'bias'].double()).float()
+    # (the folded network has a bias on every conv: re-insert the keys in the order of its spec)
+    order = [k for i in (0, 2, 5, 8) for k in (pre + '%d.weight' % i, pre + '%d.bias' % i)]
+    return {k: out[k] for k in list(out) if k not in order} | {k: out[k] for k in order}
 
 
 def fsd_spec(input_nc, gaussian_k=None, norm='Instance'):
@@ -82,18 +86,28 @@ def fsd_spec(input_nc, gaussian_k=None, norm='Instance'):
     return spec, layers
 
 
-def dsn_nld_spec(input_nc, stride, gaussian_k=None, ndf=64):
+def dsn_nld_spec(input_nc, stride, gaussian_k=None, ndf=64, norm='Instance'):
     """DSN `--discriminator nld_s1 / nld_s2` (codes/DSN/model.py:84-89,121-170): NLayerDiscriminator(n_layers=2, kw=4, padw=1) with stride 1 or 2
-    in its first two convs; with InstanceNorm `use_bias` is True, so the normalised convs DO carry a bias (it cancels in the norm: zero gradient)"""
+    in its first two convs.  norm 'Instance': `use_bias` is True, the normalised convs DO carry a bias (it cancels in the norm: zero gradient);
+    'Batch' (model.py:139-142: `use_bias` False): bias-free convs, each followed by BatchNorm2d in training mode (BatchNormDiscriminatorHIP);
+    'BatchEval': BatchNorm in eval mode folded into those convs (fold_batchnorm_fsd) -- convs with a bias, no norm op."""
     spec = []
     if gaussian_k:
         spec.append(('filter.filter_low.filter.gaussian_filter.weight', (3, 1, gaussian_k, gaussian_k)))
     layers = []
-    for idx, cin, cout, st, norm, last in ((0, input_nc, ndf, stride, False, False), (2, ndf, 2 * ndf, stride, True, False),
-                                           (5, 2 * ndf, 4 * ndf, 1, True, False), (8, 4 * ndf, 1, 1, False, True)):
+    nrm = {'Instance': True, 'Batch': 'batch', 'BatchEval': False}[norm]
+    for idx, cin, cout, st, norm_l, last in ((0, input_nc, ndf, stride, False, False), (2, ndf, 2 * ndf, stride, nrm, False),
+                                             (5, 2 * ndf, 4 * ndf, 1, nrm, False), (8, 4 * ndf, 1, 1, False, True)):
         key = 'net.model.%d.' % idx
-        spec += [(key + 'weight', (cout, cin, 4, 4)), (key + 'bias', (cout,))]
-        layers.append(dict(key=key, cin=cin, cout=cout, stride=st, bias=True, norm=norm, last=last, kh=4, pad=1))
+        bias = norm_l != 'batch'
+        spec.append((key + 'weight', (cout, cin, 4, 4)))
+        if bias:
+            spec.append((key + 'bias', (cout,)))
+        bn = None
+        if norm_l == 'batch':
+            bn = 'net.model.%d.' % (idx + 1)
+            spec += [(bn + 'weight', (cout,)), (bn + 'bias', (cout,))]
+        layers.append(dict(key=key, cin=cin, cout=cout, stride=st, bias=bias, norm=norm_l, bn=bn, last=last, kh=4, pad=1))
     return spec, layers
 
 

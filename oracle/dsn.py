@@ -117,13 +117,16 @@ class DiscriminatorBasic(nn.Module):
 
 
 class NLayerDiscriminatorDSN(nn.Module):
-    """codes/DSN/model.py:121-170 with n_layers=2, kw=4, padw=1: `use_bias` is True under InstanceNorm; stride 1 (nld_s1) or 2 (nld_s2)"""
+    """codes/DSN/model.py:121-170 with n_layers=2, kw=4, padw=1; stride 1 (nld_s1) or 2 (nld_s2).  `use_bias` (model.py:139-142) is True under
+    InstanceNorm and False under BatchNorm: the two normalised convs carry a bias only with norm_layer 'Instance'"""
 
-    def __init__(self, input_nc, ndf=64, stride=2):
+    def __init__(self, input_nc, ndf=64, stride=2, norm='Instance'):
         super().__init__()
+        N = nn.InstanceNorm2d if norm == 'Instance' else nn.BatchNorm2d
+        ub = norm == 'Instance'
         self.model = nn.Sequential(nn.Conv2d(input_nc, ndf, 4, stride, 1), nn.LeakyReLU(0.2),
-                                   nn.Conv2d(ndf, 2 * ndf, 4, stride, 1), nn.InstanceNorm2d(2 * ndf), nn.LeakyReLU(0.2),
-                                   nn.Conv2d(2 * ndf, 4 * ndf, 4, 1, 1), nn.InstanceNorm2d(4 * ndf), nn.LeakyReLU(0.2),
+                                   nn.Conv2d(ndf, 2 * ndf, 4, stride, 1, bias=ub), N(2 * ndf), nn.LeakyReLU(0.2),
+                                   nn.Conv2d(2 * ndf, 4 * ndf, 4, 1, 1, bias=ub), N(4 * ndf), nn.LeakyReLU(0.2),
                                    nn.Conv2d(4 * ndf, 1, 4, 1, 1))
 
     def forward(self, x):
@@ -151,8 +154,7 @@ class Discriminator(nn.Module):
         if D_arch.lower() == 'fsd':
             self.net = DiscriminatorBasic(nc, norm_layer)
         elif D_arch.lower() in ('nld_s1', 'nld_s2'):
-            assert norm_layer == 'Instance'
-            self.net = NLayerDiscriminatorDSN(nc, 64, 1 if D_arch.lower() == 'nld_s1' else 2)
+            self.net = NLayerDiscriminatorDSN(nc, 64, 1 if D_arch.lower() == 'nld_s1' else 2, norm_layer)
         else:
             raise NotImplementedError('Discriminator architecture [{:s}] not recognized'.format(D_arch))
 

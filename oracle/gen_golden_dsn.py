@@ -41,6 +41,12 @@ DSN_CASES = {
     # on ONE random mix of the real and fake batch (torch.manual_seed(c['tseed']) in front of the draw), second-order pass through the discriminator
     'dsn_gau5_inst_b2_128_wgan': dict(filter='gau', k=5, norm='Instance', n=2, crop=128, wgan=True, tseed=11),
     'dsn_wavelet_inst_b2_128_wgan': dict(filter='wavelet', k=5, norm='Instance', n=2, crop=128, wgan=True, tseed=12),
+    # round 6: --norm_layer Batch with the nld discriminators (model.py:136-142: `use_bias` False, BatchNorm2d behind the 2nd / 3rd conv) and with --wgan
+    # (the gradient penalty's second-order pass goes through BatchNorm in training mode; D(sample) is a third training-mode call per iteration)
+    'dsn_gau5_nld_s1_batch_b2_128': dict(filter='gau', k=5, norm='Batch', n=2, crop=128, arch='nld_s1'),
+    'dsn_wavelet_nld_s2_batch_b3_128': dict(filter='wavelet', k=5, norm='Batch', n=3, crop=128, arch='nld_s2'),
+    'dsn_gau5_batch_b2_128_wgan': dict(filter='gau', k=5, norm='Batch', n=2, crop=128, wgan=True, tseed=13),
+    'dsn_wavelet_nld_s2_batch_b2_128_wgan': dict(filter='wavelet', k=5, norm='Batch', n=2, crop=128, arch='nld_s2', wgan=True, tseed=14),
     'dsn_gau5_inst_b2_256_lpips_rotflip': dict(filter='gau', k=5, norm='Instance', n=2, crop=256, per='LPIPS', rot_flip=True, rseed=3),
 }
 

@@ -46,7 +46,7 @@ def test_cli_flags_and_unsupported_choices():
     from dasr_amd import dsn_create_dataset as cd
     o = cd.build_parser().parse_args([])
     assert (o.generator, o.discriminator, o.kernel_size, o.filter, o.name, o.upscale_factor) == ('DeResnet', 'FSD', 5, 'gau', '0603_DSN_LRs', 4)
-    for bad in (['--generator', 'SRGAN', '--checkpoint', 'x'], ['--discriminator', 'nld_s3', '--checkpoint', 'x'], ['--wgan', '--checkpoint', 'x'],
-                ['--norm_layer', 'Batch', '--discriminator', 'nld_s1', '--checkpoint', 'x']):
+    for bad in (['--generator', 'SRGAN', '--checkpoint', 'x'], ['--discriminator', 'nld_s3', '--checkpoint', 'x'], ['--norm_layer', 'Group', '--checkpoint', 'x'],
+                ['--no_highpass', '--checkpoint', 'x']):
         with pytest.raises(NotImplementedError):
             cd.main(bad)

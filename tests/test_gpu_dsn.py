@@ -213,7 +213,8 @@ def test_deresnet_forward_backward():
                                   'dsn_wavelet_nld_s2_b2_128', 'dsn_gau5_nld_s1_b1_128', 'dsn_dsgan_gau5_inst_b2_128', 'dsn_gau5_inst_b3_128_ragan',
                                   'dsn_gau5_batch_b2_128', 'dsn_avg5_batch_b3_128_ragan', 'dsn_wavelet_sum_inst_b2_128',
                                   'dsn_gau5_inst_b2_128+fwd32', 'dsn_dsgan_gau5_inst_b2_128+fwd32', 'dsn_gau5_inst_b2_256_lpips_rotflip',
-                                  'dsn_gau5_inst_b2_128_wgan', 'dsn_wavelet_inst_b2_128_wgan'])
+                                  'dsn_gau5_inst_b2_128_wgan', 'dsn_wavelet_inst_b2_128_wgan',
+                                  'dsn_gau5_nld_s1_batch_b2_128', 'dsn_wavelet_nld_s2_batch_b3_128'])
 def test_dsn_iteration_matches_oracle_and_reference_fixture(case, golden_dir, monkeypatch, margins):
     dev = _gpu()
     case_id = case
@@ -359,22 +360,33 @@ def test_dsn_checkpoint_roundtrip(tmp_path):
 
 @pytest.mark.parametrize('filt,arch,gen', [('gau', 'FSD', 'DeResnet'), ('wavelet', 'FSD', 'DeResnet'), ('avg_pool', 'FSD', 'DeResnet'),
                                            ('gau', 'nld_s1', 'DeResnet'), ('wavelet', 'nld_s2', 'DeResnet'), ('avg_pool', 'nld_s2', 'DSGAN'),
-                                           ('gau', 'FSD', 'DSGAN')])
+                                           ('gau', 'FSD', 'DSGAN'), ('gau', 'nld_s1+Batch', 'DeResnet'), ('wavelet', 'nld_s2+Batch', 'DeResnet'),
+                                           ('gau', 'FSD+wgan', 'DeResnet'), ('avg_pool', 'nld_s2+Batch+wgan', 'DeResnet')])
 def test_dsn_translate_and_domain_distance_map(filt, arch, gen):
     """dataset-generation inference: fake LR, discriminator map and ddm against the oracle nets + the restated
-    receptive-field spreading"""
+    receptive-field spreading.  +Batch: BatchNorm discriminators in eval() mode (running statistics folded into the convs; round 6 also the nld ones,
+    whose BatchNorm-ed convs have no bias); +wgan: the map is the raw logit map (model.py:104-105)"""
     dev = _gpu()
     from dasr_amd.dsn_model import DSNModel
     from oracle import dsn, dsn_dataset
     from oracle.gen_golden_dsn import dsn_state
+    arch, *flags = arch.split('+')
+    norm, wgan = ('Batch' if 'Batch' in flags else 'Instance'), 'wgan' in flags
     G = dsn.GeneratorDSGAN() if gen == 'DSGAN' else dsn.DeResnet()
-    D = dsn.Discriminator(5, 'Instance', filt, D_arch=arch)
+    D = dsn.Discriminator(5, norm, filt, D_arch=arch, wgan=wgan)
     sdG, sdD = dsn_state(G.state_dict(), 21, 0.5), dsn_state(D.state_dict(), 22, 1.0)
+    if norm == 'Batch':   # running statistics of a trained network: not the (0, 1) of a fresh BatchNorm2d
+        for k in sdD:
+            if k.endswith('running_mean'):
+                sdD[k] = 0.05 * torch.randn(sdD[k].shape, generator=torch.Generator().manual_seed(5))
+            elif k.endswith('running_var'):
+                sdD[k] = 0.5 + torch.rand(sdD[k].shape, generator=torch.Generator().manual_seed(6))
     G.load_state_dict(sdG)
     D.load_state_dict(sdD)
-    m = DSNModel(dict(filter=filt, w_per=0.0, discriminator=arch, generator=gen), device=dev)
+    D.eval()
+    m = DSNModel(dict(filter=filt, w_per=0.0, discriminator=arch, generator=gen, norm_layer=norm, wgan=wgan), device=dev)
     m.netG.load_state_dict(sdG)
-    m.netD.load_state_dict(sdD)
+    m.load_discriminator_state(sdD)
     g = torch.Generator().manual_seed(31)
     if gen == 'DSGAN':
         img = torch.rand(1, 3, 46, 38, generator=g)     # the DSGAN Generator keeps the size
