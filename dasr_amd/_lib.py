@@ -71,6 +71,7 @@ OP_DDM_SPREAD = 43
 OP_INORM_JVP, OP_INORM_SECOND, OP_GRAD_PENALTY, OP_FILL_SCALED = 44, 45, 46, 47
 OP_CONV_CHAIN = 48
 OP_RDB_CHAIN = 49
+OP_BNORM_JVP, OP_BNORM_SECOND = 50, 51   # --wgan with BatchNorm discriminators (round 6)
 
 _SIGS = {
     'dasr_conv': [C.POINTER(ConvParams), c_vp],
@@ -135,6 +136,8 @@ _SIGS = {
     'dasr_broadcast': [c_vp, c_vp, c_i64, c_i32, c_vp],
     'dasr_rccl_destroy': [c_vp],
     'dasr_bnorm_lrelu_fwd': [Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, Tensor, c_vp, c_vp],
+    'dasr_bnorm_lrelu_jvp': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, Tensor, c_vp],
+    'dasr_bnorm_second': [Tensor, Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, Tensor, c_i32, c_vp, c_f32, c_vp],
     'dasr_bnorm_lrelu_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, Tensor, c_vp, c_vp, c_f32, c_vp],
     'dasr_bnorm_running': [c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp],
     'dasr_ragan': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, Tensor, Tensor, c_vp],
@@ -156,7 +159,7 @@ _BENCH_SIGS = {
 }
 BENCH_LIB_PATH = os.path.join(HERE, 'libdasr_bench.so')
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 _lib = None
 _bench = None
 

@@ -397,6 +397,130 @@ __global__ __launch_bounds__(256) void bnorm_lrelu_bwd_kernel(dasr_tensor x, das
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Second-order pieces of BatchNorm2d (TRAINING mode, affine) + LeakyReLU for the DSN's `--wgan` gradient penalty with `--norm_layer Batch` (round 6;
+// codes/DSN/train.py:231-236 through model.py:136-160,176-189).  Same algebra as the InstanceNorm pair above with the means taken over a GROUP of images
+// (the penalty's D(sample) is ONE call: group = N), the scale gamma behind the normalisation and the LeakyReLU' read from y = gamma xhat + beta, both
+// recomputed from the saved conv output x and the statistics (as bnorm_lrelu_bwd_kernel does):
+//   * bnorm_lrelu_jvp:  out = lrelu'(y) gamma r (t - mean t - xhat mean(xhat t))
+//   * bnorm_second:     with u = lrelu'(y) ga (ga = adjoint of the tangent output), w = gamma u:
+//       out (+)= -r^2 [ xhat (mean(w t) - mean w mean t - 3 mean(w xhat) mean(xhat t)) + mean(xhat t) (w - mean w) + mean(w xhat) (t - mean t) ]
+//       dgamma (+)= pscale * r * count * (mean(u t) - mean u mean t - mean(u xhat) mean(xhat t))      (= sum u xhat_dot: the tangent output is linear in gamma)
+//     (beta enters only through the sign of y: no term.)  One workgroup per 16-channel plane, fixed-order reductions.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bnorm_lrelu_jvp_kernel(dasr_tensor x, dasr_tensor t, int N, int C, int H, int W, int group, float slope,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ stats, dasr_tensor out) {
+    __shared__ f32x4 red[16];
+    const int cb = blockIdx.x, q = threadIdx.x & 3, pl = threadIdx.x >> 2, HW = H * W, cpad = ((C + 15) >> 4) * 16;
+    const int c0 = cb * 16 + q * 4;
+    f32x4 gm = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (c0 + j < C) { gm[j] = gamma[c0 + j]; bt[j] = beta[c0 + j]; }
+    for (int g = 0; g * group < N; ++g) {
+        const int n0 = g * group, n1 = min(N, n0 + group);
+        const float inv = 1.f / (float)((n1 - n0) * HW);
+        const float* st = stats + ((size_t)g * cpad + c0) * 3;
+        f32x4 mean, rstd;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mean[j] = st[3 * j]; rstd[j] = st[3 * j + 1]; }
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        for (int n = n0; n < n1; ++n) {
+            const float* xp = (const float*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + q * 4;
+            const float* tp = (const float*)t.p + (size_t)n * t.n_stride + (size_t)cb * t.cb_stride + q * 4;
+            for (int p = pl; p < HW; p += 64) {
+                const f32x4 xh = (*(const f32x4*)(xp + (size_t)p * 16) - mean) * rstd;
+                const f32x4 tv = *(const f32x4*)(tp + (size_t)p * 16);
+                s1 += tv;
+                s2 += tv * xh;
+            }
+        }
+        const f32x4 m1 = quad_reduce(s1, red) * inv, m2 = quad_reduce(s2, red) * inv;
+        for (int n = n0; n < n1; ++n) {
+            const float* xp = (const float*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + q * 4;
+            const float* tp = (const float*)t.p + (size_t)n * t.n_stride + (size_t)cb * t.cb_stride + q * 4;
+            float* op = (float*)out.p + (size_t)n * out.n_stride + (size_t)cb * out.cb_stride + q * 4;
+            for (int p = pl; p < HW; p += 64) {
+                const f32x4 xh = (*(const f32x4*)(xp + (size_t)p * 16) - mean) * rstd;
+                const f32x4 y = xh * gm + bt;
+                const f32x4 tv = *(const f32x4*)(tp + (size_t)p * 16);
+                f32x4 o = gm * rstd * (tv - m1 - xh * m2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = y[j] > 0.f ? o[j] : o[j] * slope;
+                *(f32x4*)(op + (size_t)p * 16) = o;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bnorm_second_kernel(dasr_tensor x, dasr_tensor t, dasr_tensor ga, int N, int C, int H, int W, int group, float slope,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ stats, dasr_tensor out, int accumulate, float* __restrict__ dgamma,
+                                                           float pscale) {
+    __shared__ f32x4 red[16];
+    const int cb = blockIdx.x, q = threadIdx.x & 3, pl = threadIdx.x >> 2, HW = H * W, cpad = ((C + 15) >> 4) * 16;
+    const int c0 = cb * 16 + q * 4;
+    f32x4 gm = {0.f, 0.f, 0.f, 0.f}, bt = {0.f, 0.f, 0.f, 0.f}, dg = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (c0 + j < C) { gm[j] = gamma[c0 + j]; bt[j] = beta[c0 + j]; }
+    for (int g = 0; g * group < N; ++g) {
+        const int n0 = g * group, n1 = min(N, n0 + group);
+        const float cnt = (float)((n1 - n0) * HW), inv = 1.f / cnt;
+        const float* st = stats + ((size_t)g * cpad + c0) * 3;
+        f32x4 mean, rstd;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mean[j] = st[3 * j]; rstd[j] = st[3 * j + 1]; }
+        f32x4 su = {0.f, 0.f, 0.f, 0.f}, sz = su, sux = su, sxz = su, suz = su;
+        for (int n = n0; n < n1; ++n) {
+            const float* xp = (const float*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + q * 4;
+            const float* tp = (const float*)t.p + (size_t)n * t.n_stride + (size_t)cb * t.cb_stride + q * 4;
+            const float* gp = (const float*)ga.p + (size_t)n * ga.n_stride + (size_t)cb * ga.cb_stride + q * 4;
+            for (int p = pl; p < HW; p += 64) {
+                const f32x4 xh = (*(const f32x4*)(xp + (size_t)p * 16) - mean) * rstd;
+                const f32x4 y = xh * gm + bt;
+                const f32x4 tv = *(const f32x4*)(tp + (size_t)p * 16);
+                f32x4 u = *(const f32x4*)(gp + (size_t)p * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) u[j] = y[j] > 0.f ? u[j] : u[j] * slope;
+                su += u;
+                sz += tv;
+                sux += u * xh;
+                sxz += xh * tv;
+                suz += u * tv;
+            }
+        }
+        const f32x4 mu = quad_reduce(su, red) * inv, mz = quad_reduce(sz, red) * inv, pu = quad_reduce(sux, red) * inv, pz = quad_reduce(sxz, red) * inv,
+                    qu = quad_reduce(suz, red) * inv;
+        dg += rstd * cnt * (qu - mu * mz - pu * pz);
+        const f32x4 mw = gm * mu, pw = gm * pu, r2 = rstd * rstd;
+        const f32x4 k0 = gm * qu - mw * mz - 3.f * pw * pz;
+        for (int n = n0; n < n1; ++n) {
+            const float* xp = (const float*)x.p + (size_t)n * x.n_stride + (size_t)cb * x.cb_stride + q * 4;
+            const float* tp = (const float*)t.p + (size_t)n * t.n_stride + (size_t)cb * t.cb_stride + q * 4;
+            const float* gp = (const float*)ga.p + (size_t)n * ga.n_stride + (size_t)cb * ga.cb_stride + q * 4;
+            float* op = (float*)out.p + (size_t)n * out.n_stride + (size_t)cb * out.cb_stride + q * 4;
+            for (int p = pl; p < HW; p += 64) {
+                const f32x4 xh = (*(const f32x4*)(xp + (size_t)p * 16) - mean) * rstd;
+                const f32x4 y = xh * gm + bt;
+                const f32x4 tv = *(const f32x4*)(tp + (size_t)p * 16);
+                f32x4 w = *(const f32x4*)(gp + (size_t)p * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = (y[j] > 0.f ? w[j] : w[j] * slope) * gm[j];
+                f32x4 o = accumulate ? *(const f32x4*)(op + (size_t)p * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+                o -= r2 * (xh * k0 + pz * (w - mw) + pw * (tv - mz));
+                *(f32x4*)(op + (size_t)p * 16) = o;
+            }
+        }
+    }
+    if (pl == 0 && dgamma) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c0 + j < C) dgamma[c0 + j] = (accumulate ? dgamma[c0 + j] : 0.f) + dg[j] * pscale;
+    }
+}
+
 // running statistics of nn.BatchNorm2d after one training-mode forward on group g (momentum 0.1, UNBIASED variance, num_batches_tracked + 1)
 __global__ void bnorm_running_kernel(const float* __restrict__ stats, int g, int C, int count, float momentum, float* __restrict__ rmean,
                                      float* __restrict__ rvar, float* __restrict__ nbt) {
@@ -1173,6 +1297,22 @@ extern "C" int dasr_bnorm_lrelu_bwd(dasr_tensor x, dasr_tensor ga, int32_t N, in
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || group <= 0 || !gamma || !beta || !stats || (dgamma != nullptr) != (dbeta != nullptr)) return DASR_EINVAL;
     DASR_LAUNCH(bnorm_lrelu_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), x, ga, N, C, H, W, group, slope, gamma, beta, stats, gx,
                 dgamma, dbeta, pscale);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_bnorm_lrelu_jvp(dasr_tensor x, dasr_tensor t, int32_t N, int32_t C, int32_t H, int32_t W, int32_t group, float slope, const float* gamma,
+                                    const float* beta, const float* stats, dasr_tensor out, void* stream) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || group <= 0 || !gamma || !beta || !stats) return DASR_EINVAL;
+    DASR_LAUNCH(bnorm_lrelu_jvp_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), x, t, N, C, H, W, group, slope, gamma, beta, stats, out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_bnorm_second(dasr_tensor x, dasr_tensor t, dasr_tensor ga, int32_t N, int32_t C, int32_t H, int32_t W, int32_t group, float slope,
+                                 const float* gamma, const float* beta, const float* stats, dasr_tensor out, int32_t accumulate, float* dgamma, float pscale,
+                                 void* stream) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || group <= 0 || !gamma || !beta || !stats) return DASR_EINVAL;
+    DASR_LAUNCH(bnorm_second_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), x, t, ga, N, C, H, W, group, slope, gamma, beta, stats, out,
+                accumulate, dgamma, pscale);
     return (int)hipGetLastError();
 }
 

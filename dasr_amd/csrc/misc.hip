@@ -838,6 +838,14 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream0) {
             case DASR_OP_INORM_SECOND:
                 rc = dasr_inorm_second(o.t[0], o.t[1], o.t[2], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], (const float*)o.p[0], o.t[3], o.i[4], stream);
                 break;
+            case DASR_OP_BNORM_JVP:
+                rc = dasr_bnorm_lrelu_jvp(o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.f[0], (const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
+                                          o.t[2], stream);
+                break;
+            case DASR_OP_BNORM_SECOND:
+                rc = dasr_bnorm_second(o.t[0], o.t[1], o.t[2], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.f[0], (const float*)o.p[0], (const float*)o.p[1],
+                                       (const float*)o.p[2], o.t[3], o.i[5], (float*)o.p[3], o.f[1], stream);
+                break;
             case DASR_OP_GRAD_PENALTY: rc = dasr_grad_penalty(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], (float*)o.p[0], (float*)o.p[1], (float*)o.p[2], o.i[4], o.i[5] > 0 ? o.i[5] : 1, stream); break;
             case DASR_OP_FILL_SCALED: rc = dasr_fill_scaled(o.t[0], o.i[0], o.i[1], o.i[2], o.i[3], (const float*)o.p[0], o.f[0], stream); break;
             case DASR_OP_CONV_CHAIN: rc = dasr_conv_chain((const dasr_conv_params*)o.p[0], (const dasr_conv_params*)o.p[1], (const int32_t*)o.p[2], o.i[0], (uint32_t*)o.p[3], (int32_t*)o.l[0], stream); break;

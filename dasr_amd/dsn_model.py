@@ -810,9 +810,9 @@ class _GradPenaltyPlan:
     def __init__(self, plan, m, N, h, w, hd, wd, acc_slot):
         from .gan_nets import _DPlan, SLOPE as D_SLOPE
         net, dev, d = m.netD, m.device, plan.d
-        if any(L['norm'] == 'batch' for L in net.layers):
-            raise NotImplementedError('--wgan with --norm_layer Batch: the second-order pass is built for InstanceNorm discriminators')
-        self.dg = dg = _DPlan(net, N, hd, wd)       # the discriminator on the N mixed images (its own activations / statistics)
+        # BatchNorm discriminators (round 6): D(sample) is ONE training-mode call on the N mixed images (train.py:234) -- one statistics group, and a third
+        # running-statistics update per discriminator step, behind those of D(real) and D(fake)
+        self.dg = dg = _DPlan(net, N, hd, wd, groups=1)       # the discriminator on the N mixed images (its own activations / statistics)
         nl = len(net.layers)
         nc = net.layers[0]['cin']
         P, pack = net.params, net.pack
@@ -834,6 +834,8 @@ class _GradPenaltyPlan:
         self.mix_op = len(ops.ops)
         ops.add(o)
         ops.extend(dg.fwd)
+        if m.bn:
+            ops.extend(dg.running_ops(0))
         lg = dg.logits
         cnt = float(N * lg.H * lg.W)
         o = _op(_lib.OP_FILL_SCALED)                  # d mean D / d D = 1 / cnt
@@ -882,9 +884,14 @@ class _GradPenaltyPlan:
                 zdot[i] = B(dg.zs[i])
                 adot[i] = B(dg.acts[i])
                 ops.add(conv_op(pack, L['fwd'], src.view(), True, L['cin_pad'], hi, wi, ho, wo, N, kh=L['kh'], stride=L['stride'], pad=L['pad'], out_f32=zdot[i].view()))
-                o = _op(_lib.OP_INORM_JVP)
-                o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3] = dg.acts[i].view(), zdot[i].view(), N, L['cout'], ho, wo
-                o.f[0], o.p[0], o.t[2] = D_SLOPE, dg.stats[i].data_ptr(), adot[i].view()
+                if L['norm'] == 'batch':
+                    o = _op(_lib.OP_BNORM_JVP)
+                    o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = dg.zs[i].view(), zdot[i].view(), N, L['cout'], ho, wo, dg.group
+                    o.f[0], o.p[0], o.p[1], o.p[2], o.t[2] = D_SLOPE, P.ptr(L['bn'] + 'weight'), P.ptr(L['bn'] + 'bias'), dg.stats[i].data_ptr(), adot[i].view()
+                else:
+                    o = _op(_lib.OP_INORM_JVP)
+                    o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3] = dg.acts[i].view(), zdot[i].view(), N, L['cout'], ho, wo
+                    o.f[0], o.p[0], o.t[2] = D_SLOPE, dg.stats[i].data_ptr(), adot[i].view()
                 ops.add(o)
             else:   # conv + lrelu: adot = lrelu'(a) * conv(tangent) (the mask multiplies the conv output in the epilogue; no bias on a tangent)
                 adot[i] = B(dg.acts[i])
@@ -920,7 +927,25 @@ class _GradPenaltyPlan:
             L = net.layers[i]
             inp_a = dg.x if i == 0 else dg.acts[i - 1]
             inp_adot = self.t0 if i == 0 else adot[i - 1]
-            if L['norm']:
+            if L['norm'] == 'batch':
+                # BatchNorm: the first-order backward on both adjoints (the primal one also gives d pen / d gamma, d beta of a = lrelu(gamma xhat + beta)), then the
+                # dependence of J on z and the tangent output's own factor gamma (dasr_bnorm_second; += on top of the primal terms when there are any)
+                g_zdot, g_z = B(dg.zs[i]), B(dg.zs[i])
+                (ho, wo) = dg.dims[i + 1]
+                gdst = (self.grad.data_ptr() + 4 * P.off(L['bn'] + 'weight'), self.grad.data_ptr() + 4 * P.off(L['bn'] + 'bias'))
+                for ga_, out_, prim in ((g_adot, g_zdot, False),) + (((g_a, g_z, True),) if g_a is not None else ()):
+                    o = _op(_lib.OP_BNORM_BWD)
+                    o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = dg.zs[i].view(), ga_.view(), N, L['cout'], ho, wo, dg.group
+                    o.f[0], o.p[0], o.p[1], o.p[2], o.t[2] = D_SLOPE, P.ptr(L['bn'] + 'weight'), P.ptr(L['bn'] + 'bias'), dg.stats[i].data_ptr(), out_.view()
+                    o.p[3], o.l[0], o.f[1] = (gdst[0] if prim else None), (gdst[1] if prim else 0), 1.0
+                    ops.add(o)
+                o = _op(_lib.OP_BNORM_SECOND)
+                o.t[0], o.t[1], o.t[2], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4] = dg.zs[i].view(), zdot[i].view(), g_adot.view(), N, L['cout'], ho, wo, dg.group
+                o.f[0], o.p[0], o.p[1], o.p[2], o.t[3] = D_SLOPE, P.ptr(L['bn'] + 'weight'), P.ptr(L['bn'] + 'bias'), dg.stats[i].data_ptr(), g_z.view()
+                o.i[5], o.p[3], o.f[1] = (1 if g_a is not None else 0), gdst[0], 1.0
+                ops.add(o)
+                mask = None
+            elif L['norm']:
                 g_zdot, g_z = B(dg.zs[i]), B(dg.zs[i])
                 for ga_, out_ in ((g_adot, g_zdot),) + (((g_a, g_z),) if g_a is not None else ()):   # J (lrelu'(a) ga): the first-order InstanceNorm backward on both adjoints
                     o = _op(_lib.OP_INORM_BWD)
@@ -1140,7 +1165,7 @@ class _DSNPlan:
             for o in ol.ops:
                 if o.op == _lib.OP_WGRAD_REDUCE:
                     o.f[0] = scale
-                elif o.op == _lib.OP_BNORM_BWD and o.p[3]:   # dgamma / dbeta of a BatchNorm discriminator
+                elif (o.op == _lib.OP_BNORM_BWD and o.p[3]) or o.op == _lib.OP_BNORM_SECOND:   # dgamma / dbeta of a BatchNorm discriminator
                     o.f[1] = scale
             ol._arr = None
 

@@ -4,7 +4,7 @@ Same flags and defaults as the reference's argparse block (train.py:24-72) and t
 DSNModel.iteration(hr, bicubic_lr, real_lr); schedulers step once per epoch (train.py:287-288); every
 `save_model_interval` epochs the `.tar` checkpoint dict of train.py:357-376 is written to
 <save_path>/checkpoints/iteration_<n>.tar and last_iteration.tar.  Accepted-but-unsupported choices fail the way the
-reference does for unknown strings (NotImplementedError): --wgan with --norm_layer Batch, --norm_layer Batch with the nld discriminators (--wgan with --ragan: round 5).  --ragan is supported, also under data parallelism (the batch means are all-reduced between the loss stages).  --per_type LPIPS (the reference
+reference does for unknown strings (NotImplementedError).  --norm_layer Batch runs with every discriminator and with --wgan (round 6; --wgan with --ragan: round 5).  --ragan is supported, also under data parallelism (the batch means are all-reduced between the loss stages).  --per_type LPIPS (the reference
 default) runs LPIPS(alex) with weights from --lpips_alexnet / --lpips_lin, --per_type VGG with --vgg_path; the pretrained files cannot be
 downloaded offline, a missing file is an error unless --allow_random_perceptual opts into a seeded random network.  Data: `--dataset aim2019 |
 ntire2020 | realsr | camerasr` read the image folders `--paths` (the reference's codes/paths.yml, train.py:82-83) names for `--artifacts`, through
@@ -86,8 +86,6 @@ def check_supported(o, have_loader=True):
         raise NotImplementedError('Generator model [{:s}] not recognized'.format(o.generator))
     if o.discriminator.lower() not in ('fsd', 'nld_s1', 'nld_s2'):
         raise NotImplementedError('Discriminator architecture [{:s}] not recognized'.format(o.discriminator))
-    if o.wgan and o.norm_layer != 'Instance':
-        raise NotImplementedError('--wgan (gradient penalty with its second-order pass through D, train.py:231-236) is built for InstanceNorm discriminators')
     if not o.highpass or o.cat_or_sum not in ('cat', 'sum') or o.norm_layer not in ('Instance', 'Batch'):
         raise NotImplementedError('DSN on MI355X covers: high-pass front end, wavelet bands cat / sum, Instance or Batch norm')
     if o.disc_freq < 1 or o.gen_freq < 1:

@@ -274,10 +274,10 @@ class _DPlan:
     """Forward on N images; data-gradient of the first `n_g` images (generator step, no weight gradients);
     full backward with weight gradients on all N images (discriminator step)."""
 
-    def __init__(self, net, N, H, W):
+    def __init__(self, net, N, H, W, groups=None):
         self.net, self.N = net, N
         dev, P, pack = net.device, net.params, net.pack
-        groups = getattr(net, 'bn_groups', 1)
+        groups = getattr(net, 'bn_groups', 1) if groups is None else groups   # (groups = 1: ONE call of the reference on all N images, e.g. the gradient penalty's D(sample))
         assert N % groups == 0
         self.group = N // groups                       # BatchNorm: images [0, group) = fake half, [group, N) = real half, own statistics each
         self.x = BTensor(N, 16, H, W, True, dev)       # D input (3 or 9 real channels)

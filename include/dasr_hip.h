@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DASR_ABI_VERSION 18
+#define DASR_ABI_VERSION 19
 #define DASR_EINVAL (-22)
 #define DASR_ECAPTURE (-16)   /* a launch needed a device allocation (the scratch row of a deterministic grid sum, first use per accumulator and stream) while its stream was being captured */
 
@@ -303,6 +303,16 @@ int dasr_bnorm_lrelu_fwd(dasr_tensor x, int32_t N, int32_t C, int32_t H, int32_t
                          const float* beta, dasr_tensor y, float* stats, void* stream);
 int dasr_bnorm_lrelu_bwd(dasr_tensor x, dasr_tensor ga, int32_t N, int32_t C, int32_t H, int32_t W, int32_t group, float slope, const float* gamma,
                          const float* beta, const float* stats, dasr_tensor gx, float* dgamma, float* dbeta, float pscale, void* stream);
+/* Second-order pieces of BatchNorm2d (training mode) + LeakyReLU for `--wgan` with `--norm_layer Batch` (ABI 19; codes/DSN/train.py:231-236 through
+ * model.py:136-160,176-189): the InstanceNorm pair above with group means, gamma behind the normalisation and lrelu' read from y = gamma xhat + beta
+ * (x = saved conv output).  dasr_bnorm_lrelu_jvp: out = lrelu'(y) gamma r (t - mean t - xhat mean(xhat t)).  dasr_bnorm_second (u = lrelu'(y) ga, w = gamma u):
+ * out (+)= -r^2 [xhat (mean(w t) - mean w mean t - 3 mean(w xhat) mean(xhat t)) + mean(xhat t) (w - mean w) + mean(w xhat) (t - mean t)];
+ * dgamma (optional; += when `accumulate`) = pscale * sum u xhat_dot -- the tangent output is linear in gamma; beta has no term. */
+int dasr_bnorm_lrelu_jvp(dasr_tensor x, dasr_tensor t, int32_t N, int32_t C, int32_t H, int32_t W, int32_t group, float slope, const float* gamma,
+                         const float* beta, const float* stats, dasr_tensor out, void* stream);
+int dasr_bnorm_second(dasr_tensor x, dasr_tensor t, dasr_tensor ga, int32_t N, int32_t C, int32_t H, int32_t W, int32_t group, float slope,
+                      const float* gamma, const float* beta, const float* stats, dasr_tensor out, int32_t accumulate, float* dgamma, float pscale,
+                      void* stream);
 int dasr_bnorm_running(const float* stats, int32_t g, int32_t C, int32_t count, float momentum, float* running_mean, float* running_var,
                        float* num_batches_tracked, void* stream);
 /* GANLoss('vanilla') = BCEWithLogitsLoss vs a constant target (loss.py:8-40): loss_acc += coef*sum(bce),
@@ -431,7 +441,10 @@ enum { DASR_OP_CONV = 1, DASR_OP_WGRAD = 2, DASR_OP_WGRAD_REDUCE = 3, DASR_OP_PA
        /* --wgan gradient penalty (round 4) */
        DASR_OP_INORM_JVP = 44, DASR_OP_INORM_SECOND = 45, DASR_OP_GRAD_PENALTY = 46, DASR_OP_FILL_SCALED = 47,
        DASR_OP_CONV_CHAIN = 48,  /* p[0] device layers, p[1] host layers, p[2] device dep_chunk, i[0] nlayers, p[3] device flags; l[0] device err word */
-       DASR_OP_RDB_CHAIN = 49    /* dasr_rdb_chain: p[0] device layers, p[1] host layers, i[0] nlayers, p[3] device flags; l[0] device err word */ };
+       DASR_OP_RDB_CHAIN = 49,   /* dasr_rdb_chain: p[0] device layers, p[1] host layers, i[0] nlayers, p[3] device flags; l[0] device err word */
+       /* --wgan with BatchNorm discriminators (round 6).  JVP: t[0] x, t[1] t, i[0..3] N C H W, i[4] group, f[0] slope, p[0] gamma, p[1] beta, p[2] stats, t[2] out.
+        * SECOND: t[0] x, t[1] t, t[2] ga, i[0..4] as above, f[0] slope, p[0..2] as above, t[3] out, i[5] accumulate, p[3] dgamma, f[1] pscale */
+       DASR_OP_BNORM_JVP = 50, DASR_OP_BNORM_SECOND = 51 };
 
 typedef struct {
     int32_t op;  int32_t i[8];  float f[4];  int64_t l[4];  void* p[4];  dasr_tensor t[5];

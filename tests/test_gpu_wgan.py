@@ -87,19 +87,67 @@ def test_instance_norm_tangent_and_second_order_adjoint():
     v = fb.t.cpu()
     assert torch.allclose(v[..., 0], torch.full_like(v[..., 0], 0.25 * o[2])) and float(v[..., 1:].abs().max()) == 0.0
 
+def test_batch_norm_tangent_and_second_order_adjoint():
+    """round 6 (--wgan with --norm_layer Batch): dasr_bnorm_lrelu_jvp / dasr_bnorm_second against torch's double backward through
+    leaky_relu(batch_norm(z, training)) -- the adjoint of z AND of gamma -- in fp64"""
+    dev = _gpu()
+    from dasr_amd import _lib
+    from dasr_amd.engine import BTensor, _stream
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(7)
+    N, C_, H, W = 3, 24, 7, 11
+    z = (torch.randn(N, C_, H, W, generator=g) * 1.5 + 0.3).double().requires_grad_(True)
+    zd = torch.randn(N, C_, H, W, generator=g).double()
+    ga = torch.randn(N, C_, H, W, generator=g).double()
+    gamma = (torch.rand(C_, generator=g) + 0.5).double().requires_grad_(True)
+    beta = (torch.randn(C_, generator=g) * 0.3).double()
+    mean = lambda t: t.mean((0, 2, 3), keepdim=True)
+    mu = mean(z)
+    r = 1.0 / torch.sqrt(mean((z - mu) ** 2) + 1e-5)
+    xh = (z - mu) * r
+    y = xh * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+    adot = torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.2)) * gamma.view(1, -1, 1, 1) * r * (zd - mean(zd) - xh * mean(xh * zd))
+    fn = lambda t: F.leaky_relu(F.batch_norm(t, None, None, gamma.detach(), beta, True, 0.1, 1e-5), 0.2)
+    _, adot_fm = torch.autograd.functional.jvp(fn, (z.detach(),), (zd,))
+    assert rel(adot.detach(), adot_fm) < 1e-12
+    want_z, want_gamma = torch.autograd.grad((adot * ga).sum(), (z, gamma))
+    zb, zdb, gab = to_blocked(z.detach().float(), dev), to_blocked(zd.float(), dev), to_blocked(ga.float(), dev)
+    ab, out = BTensor(N, C_, H, W, True, dev), BTensor(N, C_, H, W, True, dev)
+    stats = torch.zeros(32 * 3, device=dev)
+    gm, bt = gamma.detach().float().to(dev), beta.float().to(dev)
+    dgm = torch.full((C_,), 3.0, device=dev)
+    _lib.check(L.dasr_bnorm_lrelu_fwd(zb.view(), N, C_, H, W, N, 1e-5, 0.2, gm.data_ptr(), bt.data_ptr(), ab.view(), stats.data_ptr(), _stream()))
+    _lib.check(L.dasr_bnorm_lrelu_jvp(zb.view(), zdb.view(), N, C_, H, W, N, 0.2, gm.data_ptr(), bt.data_ptr(), stats.data_ptr(), out.view(), _stream()))
+    torch.cuda.synchronize()
+    assert rel(out.nchw(C_).cpu(), adot.detach()) < 1e-5
+    _lib.check(L.dasr_bnorm_second(zb.view(), zdb.view(), gab.view(), N, C_, H, W, N, 0.2, gm.data_ptr(), bt.data_ptr(), stats.data_ptr(), out.view(), 0,
+                                   dgm.data_ptr(), 0.5, _stream()))
+    torch.cuda.synchronize()
+    assert rel(out.nchw(C_).cpu(), want_z) < 2e-5
+    assert rel(dgm.cpu(), 0.5 * want_gamma) < 2e-5
+    out.t.fill_(1.0)
+    _lib.check(L.dasr_bnorm_second(zb.view(), zdb.view(), gab.view(), N, C_, H, W, N, 0.2, gm.data_ptr(), bt.data_ptr(), stats.data_ptr(), out.view(), 1,
+                                   dgm.data_ptr(), 0.5, _stream()))
+    torch.cuda.synchronize()
+    assert rel(out.nchw(C_).cpu(), want_z + 1.0) < 2e-5 and rel(dgm.cpu(), want_gamma) < 2e-5
 
-@pytest.mark.parametrize('filt,arch', [('gau', 'FSD'), ('wavelet', 'FSD'), ('avg_pool', 'nld_s2'), ('gau', 'nld_s1')])
+
+@pytest.mark.parametrize('filt,arch', [('gau', 'FSD'), ('wavelet', 'FSD'), ('avg_pool', 'nld_s2'), ('gau', 'nld_s1'),
+                                       ('gau', 'FSD+Batch'), ('wavelet', 'nld_s2+Batch'), ('avg_pool', 'nld_s1+Batch')])
 def test_gradient_penalty_value_and_weight_gradients(filt, arch, margins):
-    """the penalty and d penalty / d theta of one mixing weight against torch.autograd.grad(create_graph=True) + backward on the oracle discriminator"""
+    """the penalty and d penalty / d theta of one mixing weight against torch.autograd.grad(create_graph=True) + backward on the oracle discriminator
+    (+Batch, round 6: BatchNorm2d in training mode -- group statistics over the mixed batch, gamma / beta gradients of the penalty)"""
     dev = _gpu()
     torch.set_num_threads(8)
     from dasr_amd.dsn_model import DSNModel
     from oracle import dsn
     from oracle.gen_golden_dsn import dsn_state, dsn_batch
-    D = dsn.Discriminator(5, 'Instance', filt, D_arch=arch, wgan=True)
+    arch, *flags = arch.split('+')
+    norm = 'Batch' if 'Batch' in flags else 'Instance'
+    D = dsn.Discriminator(5, norm, filt, D_arch=arch, wgan=True)
     sdD = dsn_state(D.state_dict(), 22, 1.0)
     D.load_state_dict(sdD)
-    m = DSNModel(dict(filter=filt, kernel_size=5, discriminator=arch, w_per=0.0, wgan=True), device=dev)
+    m = DSNModel(dict(filter=filt, kernel_size=5, discriminator=arch, w_per=0.0, wgan=True, norm_layer=norm), device=dev)
     m.load_discriminator_state(sdD)
     N, crop = 2, 128
     _, fake, real = dsn_batch(dict(n=N, crop=crop))
@@ -129,13 +177,13 @@ def test_gradient_penalty_value_and_weight_gradients(filt, arch, margins):
         if wv is None or float(wv.norm()) < 1e-9:
             assert float(gv.abs().max()) < 1e-6, k
             continue
-        if k.endswith(('.2.bias', '.5.bias')):   # bias in front of an InstanceNorm: it cancels in the norm, the true gradient is 0 -- rounding noise on both sides
+        if k.endswith(('.2.bias', '.5.bias')):   # bias in front of an InstanceNorm / BatchNorm: it cancels in the norm, the true gradient is 0 -- rounding noise on both sides
             assert float(gv.abs().max()) < 1e-4 * max(float(x.abs().max()) for x in want if x is not None), k
             continue
         errs.append((rel(gv, wv), k))
     errs.sort(reverse=True)
-    margins('DSN --wgan gradient penalty (%s front end, %s): value %.6f vs %.6f, ||g|| %.5f; worst weight-gradient rel err %.2e at %s (tol 1e-2)'
-            % (filt, arch, got_pen, float(pen), float(P.gp.out3[0]), errs[0][0], errs[0][1]))
+    margins('DSN --wgan gradient penalty (%s front end, %s' % (filt, arch + ('' if norm == 'Instance' else ' with BatchNorm')) + '): value %.6f vs %.6f, ||g|| %.5f; worst weight-gradient rel err %.2e at %s (tol 1e-2)'
+            % (got_pen, float(pen), float(P.gp.out3[0]), errs[0][0], errs[0][1]))
     assert abs(got_pen - float(pen)) < 2e-4 * abs(float(pen))
     assert errs[0][0] < 1e-2, errs[:4]
 

@@ -246,7 +246,8 @@ def test_dsn_cli_flags_and_lr_rule():
     dsn_train.check_supported(dsn_train.build_parser().parse_args(['--norm_layer', 'Batch']))
     dsn_train.check_supported(dsn_train.build_parser().parse_args(['--wgan', '--ragan']))   # (round 5)
     dsn_train.check_supported(dsn_train.build_parser().parse_args(['--norm_layer', 'Batch', '--discriminator', 'nld_s1']))   # (round 6: model.py:136-160)
-    for bad in (['--generator', 'SRGAN'], ['--discriminator', 'nld_s3'], ['--wgan', '--norm_layer', 'Batch'], ['--norm_layer', 'Group']):
+    dsn_train.check_supported(dsn_train.build_parser().parse_args(['--wgan', '--norm_layer', 'Batch', '--discriminator', 'nld_s2']))       # (round 6: second-order pass through BatchNorm)
+    for bad in (['--generator', 'SRGAN'], ['--discriminator', 'nld_s3'], ['--norm_layer', 'Group']):
         with pytest.raises(NotImplementedError):
             dsn_train.check_supported(dsn_train.build_parser().parse_args(bad))
     # every flag the model acts on reaches its option dict (--disc_freq / --gen_freq were parsed, accepted and then dropped)
