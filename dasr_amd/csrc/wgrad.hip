@@ -860,21 +860,23 @@ __device__ __forceinline__ void w3_win_prologue(const char* buf, int gbase, int 
     w.xa[2] = w3_win_x<TH>(buf, ibase, 2, DXA);
 }
 // k-steps 0 .. 6 of a tile
-template <bool F16, int TH>
+// ABL (DASR_BENCH builds, WRONG results): bit 1 = no fragment reads inside the k-steps (the MFMAs reuse the first tile's fragments)
+template <bool F16, int TH, int ABL = 0>
 __device__ __forceinline__ void w3_win_steps(const char* buf, int gbase, int ibase, W3Win& w, f32x16 (&acc)[5], float& bsum, bool want_bias) {
     constexpr int DXA = TH ? 2 : 0;
+    constexpr bool RD = !(ABL & 2);
 #pragma unroll
     for (int r = 0; r < W3G::PH - 1; ++r) {
-        w.g[(r + 1) & 1] = w3_win_g(buf, gbase, r + 1);
-        if constexpr (TH == 1) w.xb[(r + 1) & 1] = w3_win_x<TH>(buf, ibase, r + 3, 1);
+        if constexpr (RD) w.g[(r + 1) & 1] = w3_win_g(buf, gbase, r + 1);
+        if constexpr (TH == 1 && RD) w.xb[(r + 1) & 1] = w3_win_x<TH>(buf, ibase, r + 3, 1);
         __builtin_amdgcn_sched_barrier(0);
         acc[0] = mfma16<F16>(w.g[r & 1], w.xa[r % 3], acc[0]);                       // (0, DXA)
         __builtin_amdgcn_sched_barrier(0);
-        w.xa[r % 3] = w3_win_x<TH>(buf, ibase, r + 3, DXA);                          // -> (2, DXA) of k-step r + 1
+        if constexpr (RD) w.xa[r % 3] = w3_win_x<TH>(buf, ibase, r + 3, DXA);        // -> (2, DXA) of k-step r + 1
         __builtin_amdgcn_sched_barrier(0);
         acc[3] = mfma16<F16>(w.g[r & 1], w.xb[r & 1], acc[3]);                       // th 0: (0, 1); th 1: (2, 1)
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (TH == 0) {
+        if constexpr (TH == 0 && RD) {
             w.xb[r & 1] = w3_win_x<TH>(buf, ibase, r + 2, 1);                        // -> (1, 1) of k-step r + 1
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -893,29 +895,30 @@ __device__ __forceinline__ void w3_win_steps(const char* buf, int gbase, int iba
 // k-step 7 of a tile: nothing is read from the tile's own image any more; every fragment register is re-filled IN PLACE, right behind its last MFMA, with
 // what k-step 0 of the NEXT tile starts from (`nbuf`: landed -- the barrier in front of this k-step is the loaders' "tile t + 1 is in LDS"; behind the last tile
 // of the workgroup the reads fetch a stale image and nobody uses them).  So a tile starts without a burst of prologue reads behind its barrier.
-template <bool F16, int TH>
+template <bool F16, int TH, int ABL = 0>
 __device__ __forceinline__ void w3_win_last(const char* nbuf, int gbase, int ibase, W3Win& w, f32x16 (&acc)[5], float& bsum, bool want_bias) {
     constexpr int DXA = TH ? 2 : 0, r = W3G::PH - 1;
+    constexpr bool RD = !(ABL & 2);
     static_assert(r == 7, "ring indices below are those of k-step 7");
-    w.g[0] = w3_win_g(nbuf, gbase, 0);
-    if constexpr (TH == 1) w.xb[0] = w3_win_x<TH>(nbuf, ibase, 2, 1);
+    if constexpr (RD) w.g[0] = w3_win_g(nbuf, gbase, 0);
+    if constexpr (TH == 1 && RD) w.xb[0] = w3_win_x<TH>(nbuf, ibase, 2, 1);
     __builtin_amdgcn_sched_barrier(0);
     acc[2] = mfma16<F16>(w.g[1], w.xa[0], acc[2]);                                   // (2, DXA): halo row 9
     __builtin_amdgcn_sched_barrier(0);
-    w.xa[0] = w3_win_x<TH>(nbuf, ibase, 0, DXA);
+    if constexpr (RD) w.xa[0] = w3_win_x<TH>(nbuf, ibase, 0, DXA);
     __builtin_amdgcn_sched_barrier(0);
     acc[0] = mfma16<F16>(w.g[1], w.xa[1], acc[0]);                                   // (0, DXA): halo row 7
     __builtin_amdgcn_sched_barrier(0);
-    w.xa[1] = w3_win_x<TH>(nbuf, ibase, 1, DXA);
+    if constexpr (RD) w.xa[1] = w3_win_x<TH>(nbuf, ibase, 1, DXA);
     __builtin_amdgcn_sched_barrier(0);
     acc[1] = mfma16<F16>(w.g[1], w.xa[2], acc[1]);                                   // (1, DXA): halo row 8
     __builtin_amdgcn_sched_barrier(0);
-    w.xa[2] = w3_win_x<TH>(nbuf, ibase, 2, DXA);
+    if constexpr (RD) w.xa[2] = w3_win_x<TH>(nbuf, ibase, 2, DXA);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (TH == 0) {
         acc[4] = mfma16<F16>(w.g[1], w.xb[0], acc[4]);                               // (1, 1): halo row 8
         __builtin_amdgcn_sched_barrier(0);
-        w.xb[0] = w3_win_x<TH>(nbuf, ibase, 0, 1);
+        if constexpr (RD) w.xb[0] = w3_win_x<TH>(nbuf, ibase, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
         if (want_bias) {
 #pragma unroll
@@ -923,14 +926,15 @@ __device__ __forceinline__ void w3_win_last(const char* nbuf, int gbase, int iba
         }
         acc[3] = mfma16<F16>(w.g[1], w.xb[1], acc[3]);                               // (0, 1): halo row 7
         __builtin_amdgcn_sched_barrier(0);
-        w.xb[1] = w3_win_x<TH>(nbuf, ibase, 1, 1);
+        if constexpr (RD) w.xb[1] = w3_win_x<TH>(nbuf, ibase, 1, 1);
     } else {
         acc[3] = mfma16<F16>(w.g[1], w.xb[1], acc[3]);                               // (2, 1): halo row 9
     }
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool F16, bool WIN>
+// ABL (DASR_BENCH builds, WRONG results, timing only): bit 0 = the loaders request nothing after the first two tiles, bit 1 = no fragment reads inside the k-steps
+template <bool F16, bool WIN, int ABL = 0>
 __device__ __forceinline__ void wgrad3_ld_body(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit_flags, float* __restrict__ ws) {
     using C = W3G;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -977,6 +981,61 @@ __device__ __forceinline__ void wgrad3_ld_body(const dasr_wgrad_part* __restrict
                 lds_dma16(T.ib, buf + C::G_BYTES + lw * C::IPLANE + sub * 1024, off);
             }
         };
+        if constexpr (ABL & 4) {
+            // (experiment, correct results) the loaders stage through REGISTERS: buffer_load_dwordx4 -> 12 x 4 registers -> ds_write_b128, two register sets =
+            // two tiles of lookahead (tile t + 1 is written to LDS during tile t, its loads were issued during tile t - 2).  Asks whether what the LDS-DMA
+            // costs next to the MFMAs (-11 % without it) is its write path into LDS or the bytes themselves.
+            u32x4 st[2][12];
+            auto load = [&](int tile, u32x4 (&r)[12]) {
+                const W3GTile T = w3g_tile(P, tile, tiles_x, tiles_y);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int oy = T.oy0 + (pos_g & 0xffff), ox = T.ox0 + (pos_g >> 16);
+                    const bool ok = (oy < P.Hout) & (ox < P.Wout) & (k < P.g_planes);
+                    const unsigned off = ok ? (unsigned)((k * (int)P.g.cb_stride + half8 + (oy * P.Wout + ox) * 16) * 2) : OOB;
+                    r[k] = __builtin_amdgcn_raw_buffer_load_b128(T.gb, off, 0, 0);
+                }
+#pragma unroll
+                for (int sub = 0; sub < 6; ++sub) {
+                    const int gy = T.oy0 - P.pad + (pos_x[sub] & 0xffff), gx = T.ox0 - P.pad + (pos_x[sub] >> 16);
+                    const bool ok = (gy >= 0) & (gy < HL) & (gx >= 0) & (gx < WL);
+                    const int sy = P.ups ? gy >> 1 : gy, sx = P.ups ? gx >> 1 : gx;
+                    const unsigned off = ok ? (unsigned)((rel_x + (sy * P.Win + sx) * 16) * 2) : OOB;
+                    r[6 + sub] = __builtin_amdgcn_raw_buffer_load_b128(T.ib, off, 0, 0);
+                }
+            };
+            auto commit = [&](int slot, const u32x4 (&r)[12]) {
+                char* b = smem + slot * C::BUF_BYTES + lane * 16;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) *(u32x4*)(b + k * C::GPLANE + lw * 1024) = r[k];
+#pragma unroll
+                for (int sub = 0; sub < 6; ++sub) *(u32x4*)(b + C::G_BYTES + lw * C::IPLANE + sub * 1024) = r[6 + sub];
+            };
+            if (split < ntiles) {
+                load(split, st[0]);
+                commit(0, st[0]);
+            }
+            if (split + nsplit < ntiles) load(split + nsplit, st[1]);
+            if (split + 2 * nsplit < ntiles) load(split + 2 * nsplit, st[0]);
+            asm volatile("s_waitcnt lgkmcnt(0)");
+            __builtin_amdgcn_s_barrier();
+            int cur = 0, tile = split;
+            auto iter = [&](auto par) {   // iteration of tile `tile`: tile + nsplit (registers of set `par`) goes to LDS, tile + 3 nsplit is requested into the same set
+                constexpr int S = decltype(par)::value;
+                const int nxt = cur == 2 ? 0 : cur + 1;
+                if (tile + nsplit < ntiles) commit(nxt, st[S]);
+                if (tile + 3 * nsplit < ntiles) load(tile + 3 * nsplit, st[S]);
+                asm volatile("s_waitcnt lgkmcnt(0)");
+                __builtin_amdgcn_s_barrier();
+                cur = nxt;
+                tile += nsplit;
+            };
+            while (tile < ntiles) {
+                iter(std::integral_constant<int, 1>{});
+                if (tile < ntiles) iter(std::integral_constant<int, 0>{});
+            }
+            return;
+        }
         // ring of three: during tile t the loaders request tile t + 2 (into the slot tile t - 1 was read from) and wait only for tile t + 1,
         // requested a whole tile earlier: the barrier that ends a tile never waits for a load in flight
         if (split < ntiles) fill(split, lds0);
@@ -990,7 +1049,7 @@ __device__ __forceinline__ void wgrad3_ld_body(const dasr_wgrad_part* __restrict
         int cur = 0;
         for (int tile = split; tile < ntiles; tile += nsplit) {
             const int slot2 = cur == 0 ? 2 : cur - 1;
-            const bool more = tile + 2 * nsplit < ntiles;
+            const bool more = tile + 2 * nsplit < ntiles && !(ABL & 1);
             if (more) {
                 fill(tile + 2 * nsplit, lds0 + slot2 * C::BUF_BYTES);
                 asm volatile("s_waitcnt vmcnt(12)");   // tile t + 1 has landed (this loader's share), tile t + 2 may fly ...
@@ -1038,9 +1097,9 @@ __device__ __forceinline__ void wgrad3_ld_body(const dasr_wgrad_part* __restrict
             for (int tile = split; tile < ntiles; tile += nsplit) {
                 const char* buf = smem + cur * C::BUF_BYTES;
                 cur = cur == 2 ? 0 : cur + 1;
-                if (active) w3_win_steps<F16, TH>(buf, gbase, ibase, w, acc, bsum, want_bias);
+                if (active) w3_win_steps<F16, TH, ABL>(buf, gbase, ibase, w, acc, bsum, want_bias);
                 __syncthreads();
-                if (active) w3_win_last<F16, TH>(smem + cur * C::BUF_BYTES, gbase, ibase, w, acc, bsum, want_bias);
+                if (active) w3_win_last<F16, TH, ABL>(smem + cur * C::BUF_BYTES, gbase, ibase, w, acc, bsum, want_bias);
             }
         };
         if (th == 0) run(std::integral_constant<int, 0>{});
@@ -1106,6 +1165,10 @@ __global__ __launch_bounds__(1024, 1) void wgrad3_ld_kernel(const dasr_wgrad_par
 template <bool F16>
 __global__ __launch_bounds__(1024, 1) void wgrad3_ld6_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit_flags, float* __restrict__ ws) {
     wgrad3_ld_body<F16, false>(parts, nparts, nsplit_flags, ws);
+}
+template <int ABL>
+__global__ __launch_bounds__(1024, 1) void wgrad3_ld_abl_kernel(const dasr_wgrad_part* __restrict__ parts, int nparts, int nsplit_flags, float* __restrict__ ws) {
+    wgrad3_ld_body<false, true, ABL>(parts, nparts, nsplit_flags, ws);
 }
 #endif
 
@@ -1515,6 +1578,17 @@ int launch_wgrad3_ld(const dasr_wgrad_part* parts, int nparts, int nsplit, float
     return (int)hipGetLastError();
 }
 #ifdef DASR_BENCH
+template <int ABL>
+int launch_wgrad3_ld_abl(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws, hipStream_t s) {
+    auto kfn = wgrad3_ld_abl_kernel<ABL>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, W3L::LDS_BYTES));
+        attr_set = true;
+    }
+    DASR_LAUNCH_TAG(__PRETTY_FUNCTION__, kfn, dim3(nparts * (nsplit & 0xffff)), dim3(W3L::NT), W3L::LDS_BYTES, s, parts, nparts, nsplit, ws);
+    return (int)hipGetLastError();
+}
 template <bool F16>
 int launch_wgrad3_ld6(const dasr_wgrad_part* parts, int nparts, int nsplit, float* ws, hipStream_t s) {
     auto kfn = wgrad3_ld6_kernel<F16>;
@@ -1538,6 +1612,7 @@ int g_wgrad3_ld = 1;  // 3x3 stride-1 weight gradients on 16-bit tensors: wgrad3
 int g_wgrad4 = 0;
 int g_wgrad3_stagger = 1;
 int g_wgrad3_abl = 0;   // DASR_BENCH builds: ablation bits of wgrad3_kernel (dasr_wgrad_set_mode bits 3-6); ignored by the product build
+int g_wgrad3_ld_abl = 0;   // DASR_BENCH builds: ablation bits of wgrad3_ld_kernel (dasr_wgrad_set_mode bits 10-11)
 int g_wgrad3_ld6 = 0;   // DASR_BENCH builds: wgrad3_ld6_kernel (the round-3 compute form of the loader-wave kernel) instead of wgrad3_ld_kernel (A/B)
 int g_wgrad3_glds = 0;  // LDS-DMA wgrad3: faster alone (490 vs 470 TFLOP/s) but its 101 KB of LDS keeps the other sub-batch stream off the CU: -2.5 % on the step
 
@@ -1567,6 +1642,7 @@ extern "C" int dasr_wgrad_set_mode(int use_tr) {
     g_wgrad3_glds = (use_tr & 2) ? 1 : 0;  // bit 1: LDS-DMA wgrad3 instead of the register-staged one (A/B)
     g_wgrad4 = (use_tr & 128) ? 1 : 0;     // bit 7: wgrad4_kernel instead of wgrad3_kernel (A/B)
     g_wgrad3_ld = (use_tr & 256) ? 0 : 1;  // bit 8: the register-staged 12-wave wgrad3_kernel instead of the loader-wave kernel (A/B)
+    g_wgrad3_ld_abl = (use_tr >> 10) & 7;  // bits 10-12 (4 = register-staged loaders, correct results); 1 / 2: wgrad3_ld_kernel without its DMA (after two tiles) / without its fragment reads (WRONG results)
     g_wgrad3_ld6 = (use_tr & 512) ? 1 : 0; // bit 9: the loader-wave kernel with six fragment reads per k-step (round 3) instead of the register window (A/B)
 #else
     if (use_tr & ~1) return DASR_EINVAL;   // the kernel-selection bits exist in libdasr_hip_ablate.so only
@@ -1627,6 +1703,12 @@ extern "C" int dasr_wgrad(const dasr_wgrad_part* parts_dev, int32_t nparts, int3
             default: break;
         }
         if (tr && !g_wgrad3_ld && f32 != 1) return f32 == 2 ? launch_wgrad3<true, false, true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3<true, false>(parts_dev, nparts, nsplit, ws, s);
+        if (tr && g_wgrad3_ld_abl && f32 == 0) switch (g_wgrad3_ld_abl) {
+            case 1: return launch_wgrad3_ld_abl<1>(parts_dev, nparts, nsplit, ws, s);
+            case 2: return launch_wgrad3_ld_abl<2>(parts_dev, nparts, nsplit, ws, s);
+            case 4: return launch_wgrad3_ld_abl<4>(parts_dev, nparts, nsplit, ws, s);
+            default: return launch_wgrad3_ld_abl<3>(parts_dev, nparts, nsplit, ws, s);
+        }
         if (tr && g_wgrad3_ld6 && f32 != 1) return f32 == 2 ? launch_wgrad3_ld6<true>(parts_dev, nparts, nsplit, ws, s) : launch_wgrad3_ld6<false>(parts_dev, nparts, nsplit, ws, s);
 #endif
         if (!tr || f32 == 1) return DASR_EINVAL;   // gfx950 has ds_read_b64_tr_b16 (dasr_probe_tr16 confirms it); the grouped 3x3 form exists for 16-bit tensors only

@@ -16,6 +16,8 @@ def main():
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--n', type=int, default=16)
     ap.add_argument('--lr', type=int, default=128)
+    ap.add_argument('--regload', action='store_true', help='the loaders stage through registers (ds_write_b128) instead of LDS-DMA: correct results, A/B')
+    ap.add_argument('--abl', action='store_true', help='ablations of the register-window kernel (WRONG results): no DMA after two tiles / no fragment reads / both')
     a = ap.parse_args()
     os.environ.setdefault('DASR_ALLOW_NONFINITE', '1')
     import torch
@@ -37,7 +39,13 @@ def main():
     L = _lib.lib()
     grads = {}
     for rnd in range(2):
-        for mode, name in ((1, 'register window (wgrad3_ld_kernel)'), (1 | 512, 'six reads per k-step (wgrad3_ld6_kernel)')):
+        cells = ((1, 'register window (wgrad3_ld_kernel)'), (1 | 512, 'six reads per k-step (wgrad3_ld6_kernel)'))
+        if a.abl:
+            cells = ((1, 'register window (wgrad3_ld_kernel)'), (1 | 1024, '  no LDS-DMA after the first two tiles'), (1 | 2048, '  no fragment reads inside the k-steps'),
+                     (1 | 3072, '  neither (MFMA + barriers)'))
+        if a.regload:
+            cells = ((1, 'register window, LDS-DMA loaders (product)'), (1 | 4096, 'register window, register-staged loaders'))
+        for mode, name in cells:
             assert L.dasr_wgrad_set_mode(mode) == 0, 'needs libdasr_hip_ablate.so (DASR_HIP_LIB)'
             for _ in range(3):
                 step()
@@ -57,18 +65,22 @@ def main():
             print('%-44s step %.2f ms | %s' % (name, ms, '  '.join(wg)), flush=True)
             if rnd == 0:   # gradients of ONE step from the same weights: reload the initial state first
                 pass
+    if a.abl:
+        L.dasr_wgrad_set_mode(1)
+        return
     # bit identity: same weights, same batch, one step under each form
     sd = {k: v.clone() for k, v in m.netG.state_dict().items()}
-    for mode in (1, 1 | 512):
+    other = (1 | 4096) if a.regload else (1 | 512)
+    for mode in (1, other):
         L.dasr_wgrad_set_mode(mode)
         m.netG.load_state_dict(sd)
         m.feed_data(data)
         m.optimize_parameters(1)
         torch.cuda.synchronize()
         grads[mode] = m.netG.params.grad.clone()
-    d = (grads[1] - grads[1 | 512]).abs().max().item()
-    print('gradients of one step, register window vs six reads: max abs diff %.3e (%s), |grad| max %.3e' % (
-        d, 'BIT-IDENTICAL' if torch.equal(grads[1], grads[1 | 512]) else 'different', grads[1].abs().max().item()))
+    d = (grads[1] - grads[other]).abs().max().item()
+    print('gradients of one step, product vs the other form: max abs diff %.3e (%s), |grad| max %.3e' % (
+        d, 'BIT-IDENTICAL' if torch.equal(grads[1], grads[other]) else 'different', grads[1].abs().max().item()))
     L.dasr_wgrad_set_mode(1)
 
 
