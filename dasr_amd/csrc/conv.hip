@@ -2230,6 +2230,7 @@ int g_tune_rot = 0;  // chunk-order rotation of the LDS-DMA dense-block conv (A/
 #ifdef DASR_BENCH
 int g_chain_form = 1;  // chained launches: 1 = conv_chain_kernel for the exact fit of 512 tiles, conv_chain2_kernel for multiples; 2 = conv_chain2_kernel always
 #endif
+int g_tune_is_th = 0;   // dasr_set_tuning key 10: force the tile height of the input-stationary chained launch (16 / 8 / 4 / 2; 0 = the rule of dasr_rdb_chain)
 int g_tune_is_stagger = 0;   // rdb_is_kernel: start offset between XCDs (units of ~4 us)
 int g_tune_rdb32 = 12, g_tune_rdb64 = 13, g_tune_stream = 0, g_tune_xcd = 1, g_tune_epi = 1;  // Cout=64: 13 = 8-wave form for launches of <= 256 four-wave workgroups (worth 1-2 % of the step under two sub-batch streams)
 
@@ -2245,6 +2246,7 @@ extern "C" int dasr_debug_set_trace(void* buf) {
 
 extern "C" int dasr_set_tuning(int32_t key, int32_t value) {
     if (key == 9 && value >= 0 && value <= 64) { g_tune_is_stagger = value; return 0; }   // rdb_is_kernel: XCD start stagger
+    if (key == 10 && (value == 0 || value == 4 || value == 8 || value == 16)) { g_tune_is_th = value; return 0; }   // rdb_is_kernel: forced tile height (experiments)
 #ifndef DASR_BENCH
     // product library: one dense-block conv kernel; the only live choice is the workgroup shape rule of the Cout = 64 launches (key 2)
     if (key == 2 && (value == 12 || value == 13)) { g_tune_rdb64 = value; return 0; }
@@ -2379,8 +2381,13 @@ extern "C" int dasr_rdb_chain(const dasr_conv_params* dev_layers, const dasr_con
     }
     // Geometry: whole images per XCD (N % 8 == 0: image n lives on XCD n % 8), q workgroups per XCD (one per CU, q <= 32), each owning tpw = (tiles per XCD) / q <= 8 tiles --
     // and every tile of an image must be worked on AT THE SAME TIME (a tile waits for its neighbours inside a dense block): the q workgroups of an XCD hold whole images,
-    // q % T == 0.  The largest such q is taken: 16 x 128^2 -> q 32, 2 tiles each.  Tiles are 16 x 32 pixels; where that fills less than the chip and tiles of 8 x 32 fill
-    // more of it, those are taken (the reference's shipped 16 crops of 32 x 32: 64 workgroups with half the work each instead of 32).
+    // q % T == 0.  The largest such q is taken: 16 x 128^2 -> q 32, 2 tiles each.  Tile heights 16 (8 waves x 2 rows), 8 (8 x 1), 4 (4 x 1) rows of 32 pixels:
+    // a chained launch is a fixed sequence of 34 steps per dense block and tile whatever the tile's height, and its steps get shorter with the tile only down to the latency
+    // of the neighbour synchronisation -- so the height is chosen by (tiles a workgroup owns) x (measured chain time of one tile at that height), see below: small images
+    // are spread over more CUs (the reference's shipped 16 crops of 32 x 32: 128 workgroups of 4-row tiles), but never at the price of more tiles per workgroup.
+    // Measured (profiles/r06_is_chain.txt): 16 x 32 x 32: 8.8 / 6.6 / 6.0 ms per SR step with 16- / 8- / 4-row tiles -- and 6.4 ms with 2-row tiles (2 waves, 256
+    // workgroups; built, bit-identical, dropped): below 4 rows the launch is bound by the latency chain store -> flag -> poll -> halo DMA between neighbouring tiles, which
+    // more workgroups do not shorten.  g_tune_is_th != 0 forces a height (experiments).
     if (p0.N & 7) return DASR_EINVAL;
     const int tiles_x = (p0.Wout + ISC::TW - 1) / ISC::TW;
     auto geometry = [&](int th, int& q_out, int& tpw_out) -> bool {   // workgroups per XCD / tiles per workgroup for tiles of th rows
@@ -2394,13 +2401,18 @@ extern "C" int dasr_rdb_chain(const dasr_conv_params* dev_layers, const dasr_con
             }
         return false;
     };
-    int q16 = 0, t16 = 0, q8 = 0, t8 = 0;
-    const bool ok16 = geometry(16, q16, t16), ok8 = geometry(8, q8, t8);
-    if (!ok16 && !ok8) return DASR_EINVAL;
-    const bool small = !ok16 || (ok8 && q16 < 32 && q8 > q16);
-    const int th = small ? 8 : 16, q = small ? q8 : q16, tpw = small ? t8 : t16, grid = 8 * q;
+    // the height that minimises (tiles per workgroup) x (time of one tile's chain at that height: 4.3 / 3.0 / 2.4 ms per 69 dense blocks for 16 / 8 / 4 rows, measured)
+    int th = 0, q = 0, tpw = 0, best = 1 << 30;
+    for (int cand = 16; cand >= 4; cand >>= 1) {
+        int qc = 0, tc = 0;
+        if (g_tune_is_th && cand != g_tune_is_th) continue;
+        if (!geometry(cand, qc, tc)) continue;
+        const int cost = tc * (cand == 16 ? 43 : cand == 8 ? 30 : 24);
+        if (cost < best) best = cost, th = cand, q = qc, tpw = tc;
+    }
+    if (!th) return DASR_EINVAL;
+    const int grid = 8 * q;
     const int tiles_y = (p0.Hout + th - 1) / th;
-    const long long ntiles = (long long)tiles_x * tiles_y * p0.N;
     {
         static int n_cu = -1;
         if (n_cu < 0) {
@@ -2412,15 +2424,17 @@ extern "C" int dasr_rdb_chain(const dasr_conv_params* dev_layers, const dasr_con
         }
         if (n_cu != 256) return DASR_EINVAL;
     }
-    // (the ticket counters sit behind the flag words of the LARGEST tile count a caller may have to provide for: N x ceil(H / 8) x ceil(W / 32))
-    unsigned* tickets = dev_flags + (long long)tiles_x * ((p0.Hout + 7) / 8) * p0.N;
-    (void)ntiles;
-    if (small) {
-        if (bwd) return launch_rdb_is<false, true, 1>(dev_layers, nlayers / 5, tiles_y, tiles_x, tpw, dev_flags, tickets, dev_err, as_stream(stream), "rdb_is_kernel<false, true, 1>", g_tune_is_stagger, grid);
-        return launch_rdb_is<false, false, 1>(dev_layers, nlayers / 5, tiles_y, tiles_x, tpw, dev_flags, tickets, dev_err, as_stream(stream), "rdb_is_kernel<false, false, 1>", g_tune_is_stagger, grid);
-    }
-    if (bwd) return launch_rdb_is<false, true, 2>(dev_layers, nlayers / 5, tiles_y, tiles_x, tpw, dev_flags, tickets, dev_err, as_stream(stream), "rdb_is_kernel<false, true, 2>", g_tune_is_stagger, grid);
-    return launch_rdb_is<false, false, 2>(dev_layers, nlayers / 5, tiles_y, tiles_x, tpw, dev_flags, tickets, dev_err, as_stream(stream), "rdb_is_kernel<false, false, 2>", g_tune_is_stagger, grid);
+    // (the ticket counters sit behind the flag words of the LARGEST tile count a caller may have to provide for: N x ceil(H / 4) x ceil(W / 32))
+    unsigned* tickets = dev_flags + (long long)tiles_x * ((p0.Hout + 3) / 4) * p0.N;
+    const int nrdb = nlayers / 5;
+    hipStream_t st = as_stream(stream);
+#define IS_GO(NTv, NWv)                                                                                                                                              \
+    return bwd ? launch_rdb_is<false, true, NTv, NWv>(dev_layers, nrdb, tiles_y, tiles_x, tpw, dev_flags, tickets, dev_err, st, "rdb_is_kernel<false, true, " #NTv ", " #NWv ">", g_tune_is_stagger, grid) \
+               : launch_rdb_is<false, false, NTv, NWv>(dev_layers, nrdb, tiles_y, tiles_x, tpw, dev_flags, tickets, dev_err, st, "rdb_is_kernel<false, false, " #NTv ", " #NWv ">", g_tune_is_stagger, grid)
+    if (th == 16) { IS_GO(2, 8); }
+    if (th == 8) { IS_GO(1, 8); }
+    IS_GO(1, 4);
+#undef IS_GO
 }
 
 extern "C" int dasr_conv(const dasr_conv_params* pp, void* stream) {

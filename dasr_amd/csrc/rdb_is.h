@@ -39,7 +39,7 @@
 #define IS_PUB_DELAY 1
 #endif
 struct ISC {   // what does not depend on the tile height
-    static constexpr int NW = 8, NTH = 512, TW = 32, IW = 34;
+    static constexpr int TW = 32, IW = 34;
     static constexpr int WGRAN = 18432, NSLOT = 4;
     static constexpr int LDS_BYTES = 163840;
     static constexpr int X_OFF = LDS_BYTES - 8192;           // the last 8 KB: biases, polled flag words, decision words (the same offsets for every tile height)
@@ -54,8 +54,13 @@ struct ISC {   // what does not depend on the tile height
 };
 // NT = output rows per wave: 2 = tiles of 16 x 32 pixels (the full-chip shapes), 1 = tiles of 8 x 32 (launches that would otherwise fill less of the chip: the reference's
 // shipped 32 x 32 crops run as 64 instead of 32 workgroups; half the MFMA work per step and workgroup)
-template <int NT_>
+// NW = waves per workgroup (round 6, last step): a chained launch is a SEQUENCE of 34 x 69 steps whose length does not shrink with the tile, and a step of the 8-row tiles
+// is bound by the LDS port, not by the matrix pipe (8 waves x 18-27 KB of fragment reads per step against 9-18 MFMAs per wave: every weight fragment feeds ONE MFMA per
+// wave).  Fewer waves per workgroup = fewer pixels per workgroup = more workgroups for the same image AND less LDS traffic per CU and step: tiles of 4 x 32 pixels (NT 1, NW 4)
+// let the reference's shipped 16 crops of 32 x 32 run as 128 workgroups (2 x 32 with two waves was built too: slower, the neighbour-sync latency chain is the bound by then).
+template <int NT_, int NW_ = 8>
 struct ISCfg : ISC {
+    static constexpr int NW = NW_, NTH = 64 * NW_;
     static constexpr int NT = NT_, TH = NW * NT, IH = TH + 2, NPIX = IH * IW;
     static constexpr int APIECE = NPIX * 2;                            // 16-byte pieces of one activation chunk (1224 / 680)
     static constexpr int AR = (APIECE + NTH - 1) / NTH;                // DMA rounds per chunk (the last one partial)
@@ -131,28 +136,28 @@ __device__ __forceinline__ void is_wait_vm(int n) {   // s_waitcnt vmcnt(min(n, 
 }
 
 // LDS-DMA helpers (free functions: see glds_dma_piece).  Every one returns the number of VMEM instructions THIS WAVE issued (wave-uniform).
+template <int NTH>
 __device__ __forceinline__ int is_dma_w(__amdgpu_buffer_rsrc_t rw, char* dst, unsigned src_off, int npieces, int wave, int tid) {
     typedef __attribute__((address_space(3))) void* lds_ptr;
     int n = 0;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        if (r * ISC::NTH + wave * 64 < npieces) {   // (whole waves: npieces is a multiple of 64)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(dst + (r * ISC::NTH + wave * 64) * 16), 16, (unsigned)(tid + r * ISC::NTH) * 16u, src_off, 0, 0);
+    for (int r = 0; r < (1152 + NTH - 1) / NTH; ++r) {   // (a granule has at most 1152 pieces)
+        if (r * NTH + wave * 64 < npieces) {   // (whole waves: npieces is a multiple of 64)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(dst + (r * NTH + wave * 64) * 16), 16, (unsigned)(tid + r * NTH) * 16u, src_off, 0, 0);
             ++n;
         }
     }
     return n;
 }
-template <int NT>
+template <class CC>
 __device__ __forceinline__ int is_dma_act(__amdgpu_buffer_rsrc_t rin, char* slot, const unsigned* goff, unsigned src_off, int wave, int tid) {
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    using CC = ISCfg<NT>;
     int n = 0;
 #pragma unroll
     for (int r = 0; r < CC::AR; ++r) {
-        if (r * ISC::NTH + wave * 64 < CC::APIECE) {
-            if (tid + r * ISC::NTH < CC::APIECE)   // (the last wave of the last round is partial: the pieces behind the chunk would land in the next slot)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(slot + (r * ISC::NTH + wave * 64) * 16), 16, goff[r], src_off, 0, 0);
+        if (r * CC::NTH + wave * 64 < CC::APIECE) {
+            if (tid + r * CC::NTH < CC::APIECE)   // (the last wave of the last round is partial: the pieces behind the chunk would land in the next slot)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(slot + (r * CC::NTH + wave * 64) * 16), 16, goff[r], src_off, 0, 0);
             ++n;
         }
     }
@@ -168,10 +173,10 @@ __device__ __forceinline__ void is_dma_bias(__amdgpu_buffer_rsrc_t rb, char* dst
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)dst, 4, voff, 0, 0, 0);
 }
 
-template <int NT>
+template <class CC>
 struct ISGeo {            // one tile of the workgroup's list
     int n, oy0, ox0;
-    unsigned goff[ISCfg<NT>::AR];   // per-thread source offsets of the activation DMA pieces
+    unsigned goff[CC::AR];   // per-thread source offsets of the activation DMA pieces
     unsigned nbo;             // lanes 0-8: byte offset of the flag word of neighbour `lane` (self where there is none)
     unsigned selfo;           // byte offset of the tile's own flag word
     unsigned f0;              // the tile's flag value at kernel start
@@ -195,33 +200,39 @@ struct ISGeo {            // one tile of the workgroup's list
 // B fragments: the wave's four input rows per kx, reused across ky (as conv_glds_kernel).  mid(s) runs between the fragment requests and the MFMAs of tap step s.
 template <int NT, int NU, int TS, int MIS, bool F16, class Mid>
 __device__ __forceinline__ void is_body(f32x16 (&a0)[NT], f32x16 (&a1)[NT], const char* abuf, const char* wbuf, const int (&baddr)[NT + 2][3], const int aoff, Mid&& mid) {
-    bf16x8 fb[2][NT + 2], fa[2][NU];
+    // PD = how many taps ahead the weight fragments are requested.  One-row tiles (NT = 1) issue one or two MFMAs per tap (32 - 64 cycles): one tap of lead does not
+    // cover the LDS round trip, and with one wave per SIMD (the 4- and 2-wave workgroups) nothing else does -- three taps of lead there (a ring of four fragment sets);
+    // the activation rows of the next kx are requested a whole kx (three taps) ahead.  Two-row tiles keep one tap (256 registers, none to spare).
+    constexpr int PD = NT == 1 ? 3 : 1, R = PD + 1;
+    bf16x8 fb[2][NT + 2], fa[R][NU];
 #pragma unroll
     for (int rr = 0; rr < NT + 2; ++rr) fb[0][rr] = *(const bf16x8*)(abuf + baddr[rr][0]);
 #pragma unroll
-    for (int mi = 0; mi < NU; ++mi) fa[0][mi] = *(const bf16x8*)(wbuf + aoff + mi * MIS);
+    for (int t = 0; t < PD; ++t)
+#pragma unroll
+        for (int mi = 0; mi < NU; ++mi) fa[t][mi] = *(const bf16x8*)(wbuf + aoff + ((t % 3) * 3 + t / 3) * TS + mi * MIS);
 #pragma unroll
     for (int s = 0; s < 9; ++s) {
         const int kx = s / 3, ky = s - kx * 3;
-        if (s + 1 < 9) {
-            const int kx1 = (s + 1) / 3, ky1 = (s + 1) - kx1 * 3;
+        if (s + PD < 9) {
+            const int kx1 = (s + PD) / 3, ky1 = (s + PD) - kx1 * 3;
 #pragma unroll
-            for (int mi = 0; mi < NU; ++mi) fa[(s + 1) & 1][mi] = *(const bf16x8*)(wbuf + aoff + (ky1 * 3 + kx1) * TS + mi * MIS);
-            if (ky == 1 && kx < 2) {
+            for (int mi = 0; mi < NU; ++mi) fa[(s + PD) % R][mi] = *(const bf16x8*)(wbuf + aoff + (ky1 * 3 + kx1) * TS + mi * MIS);
+        }
+        if (ky == (PD >= 3 ? 0 : 1) && kx < 2) {
 #pragma unroll
-                for (int rr = 0; rr < NT + 2; ++rr) fb[(kx + 1) & 1][rr] = *(const bf16x8*)(abuf + baddr[rr][kx + 1]);
-            }
+            for (int rr = 0; rr < NT + 2; ++rr) fb[(kx + 1) & 1][rr] = *(const bf16x8*)(abuf + baddr[rr][kx + 1]);
         }
         mid(s);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             if constexpr (IS_ABL & 4) {
-                asm volatile("" ::"v"(fa[s & 1][0]), "v"(fb[kx & 1][nt + ky]));
-                if constexpr (NU == 2) asm volatile("" ::"v"(fa[s & 1][1]));
+                asm volatile("" ::"v"(fa[s % R][0]), "v"(fb[kx & 1][nt + ky]));
+                if constexpr (NU == 2) asm volatile("" ::"v"(fa[s % R][1]));
             } else {
-                a0[nt] = mfma16<F16>(fa[s & 1][0], fb[kx & 1][nt + ky], a0[nt]);
-                if constexpr (NU == 2) a1[nt] = mfma16<F16>(fa[s & 1][1], fb[kx & 1][nt + ky], a1[nt]);
+                a0[nt] = mfma16<F16>(fa[s % R][0], fb[kx & 1][nt + ky], a0[nt]);
+                if constexpr (NU == 2) a1[nt] = mfma16<F16>(fa[s % R][1], fb[kx & 1][nt + ky], a1[nt]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -229,10 +240,10 @@ __device__ __forceinline__ void is_body(f32x16 (&a0)[NT], f32x16 (&a1)[NT], cons
 }
 
 
-template <bool F16, bool BWD, int NT>
-__global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* __restrict__ layers, const int nrdb, const int tiles_y, const int tiles_x, const int tpw,
+template <bool F16, bool BWD, int NT, int NW>
+__global__ __launch_bounds__(64 * NW, NW >= 8 ? 2 : 1) void rdb_is_kernel(const dasr_conv_params* __restrict__ layers, const int nrdb, const int tiles_y, const int tiles_x, const int tpw,
                                                         unsigned* flags, unsigned* tickets, int* err, const int stagger) {
-    using C = ISCfg<NT>;
+    using C = ISCfg<NT, NW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = tiles_y * tiles_x;
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
     __syncthreads();
 
     auto geo_of = [&](int slot) {
-        ISGeo<NT> q;
+        ISGeo<C> q;
         const int idx = j + quota * slot;
         const int img = idx / T, tile = idx - img * T;
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -328,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
     // stores acknowledged: 9.7 ms per chain against 8.7 ms.  The flag then leaves up to two steps later, and what bounds this kernel is exactly that chain: epilogue stores
     // acknowledged -> flag -> the neighbours' poll -> their halo DMA; waiting for the stores at the end of the next step is the shortest form.  profiles/r06_is_chain.txt)
     // spin until they have (a group is not there where it is needed): the only place where the matrix pipe waits for a neighbour
-    auto block_until = [&](const ISGeo<NT>& q, unsigned target) {
+    auto block_until = [&](const ISGeo<C>& q, unsigned target) {
         const unsigned long long t0 = IS_T();
         flush_pub();
         if (wave == 0 && lane < 9) {
@@ -353,14 +364,14 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
     // XCD stagger (tuning key 9): XCD k starts k * stagger * ~4 us late, so that the eight XCDs (which never wait for each other: whole images per XCD) reach
     // their store / DMA bursts at different times
     for (int i = 0; i < xcd * stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    ISGeo<NT> cur = geo_of(0);
+    ISGeo<C> cur = geo_of(0);
     // ---- prologue: x of the first item, the weights of steps 0-2, the biases of the first item
     {
         const dasr_conv_params& p0 = layers[0];
         const __amdgpu_buffer_rsrc_t rin0 = make_rsrc((const bf16_t*)p0.in.p + (size_t)cur.n * p0.in.n_stride);
         const unsigned icb0 = (unsigned)(p0.in.cb_stride * 2);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) issued += is_dma_act<NT>(rin0, smem + c * C::ACT_SLOT, cur.goff, (unsigned)c * icb0, wave, tid);
+        for (int c = 0; c < 4; ++c) issued += is_dma_act<C>(rin0, smem + c * C::ACT_SLOT, cur.goff, (unsigned)c * icb0, wave, tid);
         mark_x = issued;
         auto pro = [&](auto tc) {   // the granule of step t of the first item
             constexpr int t = decltype(tc)::value;
@@ -368,18 +379,23 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                 constexpr ISStep e = IS_PROG[t];
                 char* dst = smem + C::W_OFF + t * C::WGRAN;
                 if constexpr (e.kind == 5) {
-                    issued += is_dma_w(make_rsrc(layers[4].w), dst, (unsigned)e.c * 18432u, 1152, wave, tid);
+                    issued += is_dma_w<C::NTH>(make_rsrc(layers[4].w), dst, (unsigned)e.c * 18432u, 1152, wave, tid);
                 } else {
-                    issued += is_dma_w(make_rsrc(layers[e.u0].w), dst, (unsigned)e.c * 9216u, 576, wave, tid);
-                    if constexpr (e.kind == 2) issued += is_dma_w(make_rsrc(layers[e.u1].w), dst + 9216, (unsigned)e.c * 9216u, 576, wave, tid);
+                    issued += is_dma_w<C::NTH>(make_rsrc(layers[e.u0].w), dst, (unsigned)e.c * 9216u, 576, wave, tid);
+                    if constexpr (e.kind == 2) issued += is_dma_w<C::NTH>(make_rsrc(layers[e.u1].w), dst + 9216, (unsigned)e.c * 9216u, 576, wave, tid);
                 }
             }
         };
         pro(ISInt<0>{}), pro(ISInt<1>{}), pro(ISInt<2>{}), pro(ISInt<3>{}), pro(ISInt<4>{}), pro(ISInt<5>{}), pro(ISInt<6>{});
-        if (!BWD && wave < 5) {
-            const dasr_conv_params& pb = layers[wave];
-            is_dma_bias(make_rsrc(pb.bias), smem + C::BIAS_OFF + wave * 256, (pb.bias != nullptr && lane < 32 * pb.mt) ? (unsigned)lane * 4u : OOB);
-            ++issued;
+        if constexpr (!BWD) {
+#pragma unroll
+            for (int l = 0; l < 5; l += NW) {   // (layer l + wave: one wave per layer, the waves of a small workgroup take several)
+                if (l + wave < 5) {
+                    const dasr_conv_params& pb = layers[l + wave];
+                    is_dma_bias(make_rsrc(pb.bias), smem + C::BIAS_OFF + (l + wave) * 256, (pb.bias != nullptr && lane < 32 * pb.mt) ? (unsigned)lane * 4u : OOB);
+                    ++issued;
+                }
+            }
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) mk[k] = issued;
@@ -463,18 +479,18 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
 
             auto request_group = [&](int c0) {   // chunks c0, c0 + 1 of this item's slab
                 if constexpr (IS_BORDER) is_wait_vm(__builtin_amdgcn_readfirstlane(issued - own_mark));   // (the flag covered the border only: this tile's own interior pixels must be in memory)
-                if constexpr (!(IS_ABL & 8)) issued += is_dma_act<NT>(rin, smem + (c0 & 3) * C::ACT_SLOT, cur.goff, (unsigned)c0 * icb, wave, tid);
-                if constexpr (!(IS_ABL & 8)) issued += is_dma_act<NT>(rin, smem + ((c0 + 1) & 3) * C::ACT_SLOT, cur.goff, (unsigned)(c0 + 1) * icb, wave, tid);
+                if constexpr (!(IS_ABL & 8)) issued += is_dma_act<C>(rin, smem + (c0 & 3) * C::ACT_SLOT, cur.goff, (unsigned)c0 * icb, wave, tid);
+                if constexpr (!(IS_ABL & 8)) issued += is_dma_act<C>(rin, smem + ((c0 + 1) & 3) * C::ACT_SLOT, cur.goff, (unsigned)(c0 + 1) * icb, wave, tid);
                 arr_issued = true;
                 mark_act = issued;
             };
-            auto request_next_x = [&](const ISGeo<NT>& nxt) {
+            auto request_next_x = [&](const ISGeo<C>& nxt) {
                 const dasr_conv_params& pn = layers[L0n];
                 const __amdgpu_buffer_rsrc_t rinn = make_rsrc((const bf16_t*)pn.in.p + (size_t)nxt.n * pn.in.n_stride);
                 const unsigned icbn = (unsigned)(pn.in.cb_stride * 2);
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
-                    if constexpr (!(IS_ABL & 8)) issued += is_dma_act<NT>(rinn, smem + c * C::ACT_SLOT, nxt.goff, (unsigned)c * icbn, wave, tid);
+                    if constexpr (!(IS_ABL & 8)) issued += is_dma_act<C>(rinn, smem + c * C::ACT_SLOT, nxt.goff, (unsigned)c * icbn, wave, tid);
                 mark_x = issued;
                 next_x_issued = true;
             };
@@ -519,10 +535,10 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                         constexpr ISStep e = IS_PROG[T3];
                         constexpr bool NX = TT + C::WDIST >= C::NSTEP;
                         if constexpr (e.kind == 5) {
-                            issued += is_dma_w(make_rsrc(wptr(4, NX)), wnext, (unsigned)e.c * 18432u, 1152, wave, tid);
+                            issued += is_dma_w<C::NTH>(make_rsrc(wptr(4, NX)), wnext, (unsigned)e.c * 18432u, 1152, wave, tid);
                         } else {
-                            issued += is_dma_w(make_rsrc(wptr(e.u0, NX)), wnext, (unsigned)e.c * 9216u, 576, wave, tid);
-                            if constexpr (e.kind == 2) issued += is_dma_w(make_rsrc(wptr(e.u1, NX)), wnext + 9216, (unsigned)e.c * 9216u, 576, wave, tid);
+                            issued += is_dma_w<C::NTH>(make_rsrc(wptr(e.u0, NX)), wnext, (unsigned)e.c * 9216u, 576, wave, tid);
+                            if constexpr (e.kind == 2) issued += is_dma_w<C::NTH>(make_rsrc(wptr(e.u1, NX)), wnext + 9216, (unsigned)e.c * 9216u, 576, wave, tid);
                         }
                     }
                 };
@@ -530,7 +546,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                     if (s == 0) {
                         if (poll_now && wave == 0) {
                             if constexpr (GK == 5) {
-                                const ISGeo<NT> nq = geo_of(sn);
+                                const ISGeo<C> nq = geo_of(sn);
                                 if (lane < 9) is_dma_poll(rflags, smem + C::POLL_OFF + sn * 64, nq.nbo);
                             } else {
                                 if (lane < 9) is_dma_poll(rflags, smem + C::POLL_OFF + cur.slot * 64, cur.nbo);
@@ -689,10 +705,17 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
                     prefetch_w();
                     if constexpr (EU == 4) {
                         if (has_next && (rn == 0 || next_rdy)) request_next_x(geo_of(sn));
-                        if (has_next && !BWD && wave < 5) {
-                            const dasr_conv_params& pb = layers[L0n + wave];
-                            is_dma_bias(make_rsrc(pb.bias), smem + C::BIAS_OFF + (par ^ 1) * 1280 + wave * 256, (pb.bias != nullptr && lane < 32 * pb.mt) ? (unsigned)lane * 4u : OOB);
-                            ++issued;
+                        if constexpr (!BWD) {
+                            if (has_next) {
+#pragma unroll
+                                for (int l = 0; l < 5; l += NW) {
+                                    if (l + wave < 5) {
+                                        const dasr_conv_params& pb = layers[L0n + l + wave];
+                                        is_dma_bias(make_rsrc(pb.bias), smem + C::BIAS_OFF + (par ^ 1) * 1280 + (l + wave) * 256, (pb.bias != nullptr && lane < 32 * pb.mt) ? (unsigned)lane * 4u : OOB);
+                                        ++issued;
+                                    }
+                                }
+                            }
                         }
                     }
                     mk[0] = issued;   // (they count as requests of this step)
@@ -711,7 +734,7 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
             run(run, ISInt<0>{});
             IS_ACC(10, 1ull);
             {
-                const ISGeo<NT> nxt = geo_of(sn);
+                const ISGeo<C> nxt = geo_of(sn);
                 if (has_next && !next_x_issued) {   // the next item's neighbours were not there in front of the conv5 epilogue: wait for them now
                     block_until(nxt, nxt.f0 + (unsigned)L0n);
                     request_next_x(nxt);
@@ -727,14 +750,14 @@ __global__ __launch_bounds__(512, 2) void rdb_is_kernel(const dasr_conv_params* 
 #endif
 }
 
-template <bool F16, bool BWD, int NT>
+template <bool F16, bool BWD, int NT, int NW>
 int launch_rdb_is(const dasr_conv_params* dev_layers, int nrdb, int tiles_y, int tiles_x, int tpw, unsigned* flags, unsigned* tickets, int* err, hipStream_t s, const char* name, int stagger, int grid) {
     static bool attr_set = false;
-    auto kfn = rdb_is_kernel<F16, BWD, NT>;
+    auto kfn = rdb_is_kernel<F16, BWD, NT, NW>;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, ISC::LDS_BYTES));
         attr_set = true;
     }
-    DASR_LAUNCH_TAG(name, kfn, dim3((unsigned)grid), dim3(ISC::NTH), ISC::LDS_BYTES, s, dev_layers, nrdb, tiles_y, tiles_x, tpw, flags, tickets, err, stagger);
+    DASR_LAUNCH_TAG(name, kfn, dim3((unsigned)grid), dim3(64 * NW), ISC::LDS_BYTES, s, dev_layers, nrdb, tiles_y, tiles_x, tpw, flags, tickets, err, stagger);
     return (int)hipGetLastError();
 }

@@ -179,15 +179,15 @@ class RRDBNetHIP:
 
     @staticmethod
     def is_launch(N, h, w):
-        """(tile rows, workgroups per XCD, tiles per workgroup) of the input-stationary chained launch over N images of h x w, or None: tiles of 16 x 32 pixels, or of 8 x 32
-        where those fill more of the chip (16-row tiles leave it under 256 workgroups and 8-row tiles give more) -- mirrors dasr_rdb_chain"""
-        g16 = RRDBNetHIP.is_geometry(N, ceil_div(h, 16) * ceil_div(w, 32))
-        g8 = RRDBNetHIP.is_geometry(N, ceil_div(h, 8) * ceil_div(w, 32))
-        if g16 is None and g8 is None:
-            return None
-        if g16 is None or (g8 is not None and g16[0] < 32 and g8[0] > g16[0]):
-            return (8,) + g8
-        return (16,) + g16
+        """(tile rows, workgroups per XCD, tiles per workgroup) of the input-stationary chained launch over N images of h x w, or None.  Tiles of 16, 8 or 4 rows of 32
+        pixels: the height that minimises (tiles per workgroup) x (measured chain time of one tile at that height, 4.3 / 3.0 / 2.4 ms), ties to the taller --
+        mirrors dasr_rdb_chain (csrc/conv.hip)"""
+        best, cost = None, None
+        for th, c in ((16, 43), (8, 30), (4, 24)):
+            g = RRDBNetHIP.is_geometry(N, ceil_div(h, th) * ceil_div(w, 32))
+            if g is not None and (cost is None or g[1] * c < cost):
+                best, cost = (th,) + g, g[1] * c
+        return best
 
     def chain_choice(self, N, h, w):
         """(form, k, why): how the trunk of a training plan of this shape runs.
@@ -640,7 +640,7 @@ class _Plan:
             per = N // nsub
             self.chains = []   # (the last conv5 has no 16-bit shadow to write: its own launch, over the whole batch; the input-stationary form runs it too)
             if self.chain_form == 'is':
-                ch = ConvChain(body, deps, N, ceil_div(h, 8) * ceil_div(w, 32), net.device, err=net.chain_err, form='is')   # (flag words for the finer of the two tile heights)
+                ch = ConvChain(body, deps, N, ceil_div(h, 4) * ceil_div(w, 32), net.device, err=net.chain_err, form='is')   # (flag words for the finest tile height, 4 rows)
                 self.chains.append(ch)
                 ops.add(ch.op())
                 ops.keep.append(ch)
@@ -932,7 +932,7 @@ class _Plan:
             ops = main_ops
             self.chains_b = []   # (the last conv writes no 16-bit planes: its own launch)
             if self.chain_form == 'is':
-                ch = ConvChain(body, deps, N, ceil_div(h, 8) * ceil_div(w, 32), net.device, err=self.chain.err, form='is')
+                ch = ConvChain(body, deps, N, ceil_div(h, 4) * ceil_div(w, 32), net.device, err=self.chain.err, form='is')
                 self.chains_b.append(ch)
                 ops.add(ch.op())
                 ops.keep.append(ch)

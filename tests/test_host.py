@@ -435,10 +435,11 @@ def test_chain_split_rule():
     G = RRDBNetHIP.is_geometry
     assert (G(16, 32), G(8, 32), G(24, 32), G(64, 32), G(16, 2), G(32, 2), G(16, 8), G(64, 8), G(16, 16)) == ((32, 2), (32, 1), (32, 3), (32, 8), (4, 1), (8, 1), (16, 1), (32, 2), (32, 1))
     assert G(128, 32) is None and G(8, 64) is None and G(12, 32) is None
-    # ... and the tile height: 8-row tiles where 16-row tiles leave the chip under-filled and 8-row tiles fill more of it (the shipped 16 crops of 32 x 32: 64 workgroups)
+    # ... and the tile height (16 / 8 / 4 rows): tiles per workgroup x measured chain time of one tile (the shipped 16 crops of 32 x 32: 128 workgroups of 4-row tiles;
+    # 24 x 64 x 64 keeps 16-row tiles: the finer ones would give every workgroup three of them)
     Lc = RRDBNetHIP.is_launch
-    assert (Lc(16, 128, 128), Lc(8, 128, 128), Lc(16, 32, 32), Lc(32, 32, 32), Lc(16, 64, 64), Lc(8, 64, 64), Lc(16, 64, 128)) == \
-        ((16, 32, 2), (16, 32, 1), (8, 8, 1), (8, 16, 1), (8, 32, 1), (8, 16, 1), (16, 32, 1))
+    assert (Lc(16, 128, 128), Lc(8, 128, 128), Lc(16, 32, 32), Lc(32, 32, 32), Lc(16, 64, 64), Lc(8, 64, 64), Lc(16, 64, 128), Lc(8, 32, 32), Lc(24, 64, 64), Lc(16, 48, 48), Lc(32, 64, 64)) == \
+        ((16, 32, 2), (16, 32, 1), (4, 16, 1), (4, 32, 1), (8, 32, 1), (4, 32, 1), (16, 32, 1), (4, 8, 1), (16, 24, 1), (8, 24, 1), (16, 32, 1))
     assert Lc(8, 256, 128) is None and Lc(16, 192, 192) is None and Lc(12, 128, 128) is None
     assert g(NS(chain=True, _cus=256, chain_form='is', nf=32)) == 0
     # the default: the layer form where it fits, else the input-stationary form; the refusal names its clause (the decisions at batch 12 / 20 / 24 x 128^2, 16 x 192^2)
