@@ -16,6 +16,7 @@ def main():
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--more', type=int, default=2000)
     ap.add_argument('--batch', type=int, default=16, help='32: two chained launches over 16-image sub-batches per direction (RRDBNetHIP.chain_split, round 5)')
+    ap.add_argument('--lr', type=int, default=128, help='LR crop size (round 6: 32 = the shipped shape, input-stationary launches of 4-row tiles; 64: 8-row tiles at batch 16)')
     a = ap.parse_args()
     os.environ['DASR_STREAMS'] = '1'
     import torch
@@ -23,7 +24,7 @@ def main():
     from dasr_amd import options
     from dasr_amd.models import create_model
     g = torch.Generator().manual_seed(99)
-    pool = [{'LR': torch.rand(a.batch, 3, 128, 128, generator=g).cuda(), 'HR': torch.rand(a.batch, 3, 512, 512, generator=g).cuda()} for _ in range(4)]
+    pool = [{'LR': torch.rand(a.batch, 3, a.lr, a.lr, generator=g).cuda(), 'HR': torch.rand(a.batch, 3, 4 * a.lr, 4 * a.lr, generator=g).cuda()} for _ in range(4)]
     finals = []
     for chain in ('1', '0'):
         os.environ['DASR_CHAIN'] = chain
@@ -37,7 +38,7 @@ def main():
         loss = m.get_current_log()['l_pix']   # (host sync + error-word / non-finite checks)
         dt = (time.perf_counter() - t0) / a.steps * 1e3
         finals.append(m.netG.params.flat.clone())
-        print('chain %s: %d steps, %.2f ms / step, last l_pix %.6f, chained plan %s' % (chain, a.steps, dt, loss, m._out_plans[0].chain is not None))
+        print('chain %s: %d steps, %.2f ms / step, last l_pix %.6f, chained plan %s' % (chain, a.steps, dt, loss, m._out_plans[0].chain.form if m._out_plans[0].chain is not None else None))
         sys.stdout.flush()
         if chain == '1':
             keep = m
