@@ -23,7 +23,7 @@ class ConvParams(C.Structure):
                 ('alpha', c_f32), ('res1', Tensor), ('beta1', c_f32), ('res2', Tensor), ('beta2', c_f32),
                 ('out_f32', Tensor), ('out_bf16', Tensor), ('gamma', c_f32), ('xcd_remap', c_i32),
                 ('pad_x', c_i32), ('out_stride', c_i32), ('out_oy', c_i32), ('out_ox', c_i32), ('out_W', c_i32), ('slope_ptr', c_vp),
-                ('in_stride', c_i32), ('in_oy', c_i32), ('in_ox', c_i32), ('in_W', c_i32), ('in_scale', c_f32), ('out16_f16', c_i32), ('in_wrap', c_i32), ('out16_lo', c_i32), ('res1_lo', c_i32)]
+                ('in_stride', c_i32), ('in_oy', c_i32), ('in_ox', c_i32), ('in_W', c_i32), ('in_scale', c_f32), ('out16_f16', c_i32), ('in_wrap', c_i32), ('out16_lo', c_i32), ('res1_lo', c_i32), ('prelu_part', c_vp)]
 
 
 class WgradPart(C.Structure):
@@ -72,6 +72,7 @@ OP_INORM_JVP, OP_INORM_SECOND, OP_GRAD_PENALTY, OP_FILL_SCALED = 44, 45, 46, 47
 OP_CONV_CHAIN = 48
 OP_RDB_CHAIN = 49
 OP_BNORM_JVP, OP_BNORM_SECOND = 50, 51   # --wgan with BatchNorm discriminators (round 6)
+OP_PRELU_FINAL = 52
 
 _SIGS = {
     'dasr_conv': [C.POINTER(ConvParams), c_vp],
@@ -136,6 +137,7 @@ _SIGS = {
     'dasr_broadcast': [c_vp, c_vp, c_i64, c_i32, c_vp],
     'dasr_rccl_destroy': [c_vp],
     'dasr_bnorm_lrelu_fwd': [Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, Tensor, c_vp, c_vp],
+    'dasr_prelu_final': [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_f32, c_vp],
     'dasr_bnorm_lrelu_jvp': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, Tensor, c_vp],
     'dasr_bnorm_second': [Tensor, Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, Tensor, c_i32, c_vp, c_f32, c_vp],
     'dasr_bnorm_lrelu_bwd': [Tensor, Tensor, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, Tensor, c_vp, c_vp, c_f32, c_vp],
@@ -159,7 +161,7 @@ _BENCH_SIGS = {
 }
 BENCH_LIB_PATH = os.path.join(HERE, 'libdasr_bench.so')
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 _lib = None
 _bench = None
 

@@ -145,6 +145,14 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
     const int ostr = p.out_stride > 1 ? p.out_stride : 1, owid = p.out_W > 0 ? p.out_W : p.Wout;  // strided sub-grid output (stride-2 dgrad)
     constexpr int MSZ = IN_F32 ? 4 : 2;
     const float slope = (!CONST_SLOPE && p.slope_ptr) ? *p.slope_ptr : p.slope;  // PReLU: the (learned) slope lives in the parameter buffer (round 5: also in the specialised variants)
+    // dL/dslope of nn.PReLU() (ONE shared slope; codes/DSN/model.py:29,215) from the data-gradient epilogue that already holds both operands (round 6): the conv result v in
+    // front of the mask factor is dL/dh, the mask tensor is h = PReLU(z), and dL/da = sum_{h <= 0} dL/dh * z = sum v * h / a.  The 64-channel mask-only epilogue of the
+    // LDS-DMA kernel (EPI 68, MT 2: the residual blocks of the DSN generator; a 16-bit mask in the format of the 16-bit output) accumulates slope * v * h per lane and
+    // writes ONE partial per workgroup to p.prelu_part[blockIdx.x]; dasr_prelu_final sums them in a fixed order and divides by a^2 (the layout of dasr_prelu_grad's
+    // partials, whose two passes over h and dL/dz this replaces).  Run-time uniform switch: the HR-tail launches of the same instantiation pass NULL.
+    constexpr bool PACC_OK = EPI == 68 && MT == 2 && !IN_F32 && !FSC1 && !PRE && BMODE == 0;
+    const bool pacc_on = PACC_OK && p.prelu_part != nullptr;
+    float pacc = 0.f;
     const __amdgpu_buffer_rsrc_t rmask = make_rsrc((const char*)p.mask.p + (size_t)n * p.mask.n_stride * MSZ);
     const __amdgpu_buffer_rsrc_t rr1 = make_rsrc((const char*)p.res1.p + (size_t)n * p.res1.n_stride * ((G && p.res1_lo) ? 2 : 4));
     const __amdgpu_buffer_rsrc_t rr2 = make_rsrc((const float*)p.res2.p + (size_t)n * p.res2.n_stride);
@@ -349,6 +357,13 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                             // select between v and slope * v (packed multiply): 2.5 VALU ops per element instead of 3.5
                             const unsigned wd = mk[slot][g][j >> 1];
                             const short hbits = (j & 1) ? (short)(wd >> 16) : (short)(wd & 0xffffu);
+                            if constexpr (PACC_OK) {
+                                if (pacc_on) {
+                                    const unsigned short hb = (unsigned short)hbits;
+                                    const float hv = f16out ? (float)__builtin_bit_cast(f16_t, hb) : (float)__builtin_bit_cast(bf16_t, hb);
+                                    pacc += hbits > 0 ? 0.f : v[g][j] * hv;
+                                }
+                            }
                             v[g][j] = hbits > 0 ? v[g][j] : slope * v[g][j];
                         }
                     }
@@ -488,6 +503,19 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lb), rob, eo[g] != OOB ? ((cbv[g] + lo_pl) * ob_cb + eo[g]) * 2u : OOB, 0, 0);
                     }
                 }
+            }
+        }
+    }
+    if constexpr (PACC_OK) {
+        if (pacc_on) {   // one partial per workgroup, fixed order: lanes (DPP tree), then the waves in order
+            const float t = wave_sum(pacc);
+            __syncthreads();   // (every wave is done with the LDS image of the main loop)
+            if (lane == 0) ((float*)smem)[wave] = t;
+            __syncthreads();
+            if (tid == 0) {
+                float tot = 0.f;
+                for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += ((const float*)smem)[w];
+                p.prelu_part[blockIdx.x] = tot * slope;
             }
         }
     }

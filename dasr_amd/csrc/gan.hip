@@ -1201,6 +1201,21 @@ __global__ __launch_bounds__(256) void prelu_grad_final_kernel(const float* __re
     }
 }
 
+// the second stage alone, for `count` slopes at once (workgroup k: partials [k * stride, k * stride + nblocks), slope *slopes[k], result -> *dsts[k]): the partials come from the
+// data-gradient conv epilogues (dasr_conv_params::prelu_part) of the DSN generator's residual blocks -- one launch for all of them
+__global__ __launch_bounds__(256) void prelu_final_multi_kernel(const float* __restrict__ partial, int nblocks, long long stride, const float* const* __restrict__ slopes,
+                                                                float* const* __restrict__ dsts, float scale) {
+    __shared__ float red[4];
+    const float* pp = partial + (size_t)blockIdx.x * stride;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += (double)pp[i];   // fixed order per thread, fixed tree across threads: deterministic
+    const float tot = block_sum_256((float)s, red);
+    if (threadIdx.x == 0) {
+        const float a = *slopes[blockIdx.x];
+        *dsts[blockIdx.x] = scale * tot / (a * a);
+    }
+}
+
 // un-padded ("valid") depthwise k x k low-pass on C (<= 4) channels: out is (H-k+1) x (W-k+1) (FilterLow(padding=False),
 // codes/DSN/loss.py:52-56).  mode 0 forward; mode 1 adjoint (gx (+)= sum_q w * g_low[q]).
 __global__ void lowpass_valid_kernel(dasr_tensor x, const float* __restrict__ w, int k, int N, int C, int H, int W, int mode, dasr_tensor out,
@@ -1535,6 +1550,13 @@ extern "C" int dasr_prelu_grad(dasr_tensor y, dasr_tensor gx, int32_t N, int32_t
     const int nb = (int)(vec < 1024LL * 256 ? (vec + 255) / 256 : 1024);
     DASR_LAUNCH(prelu_grad_partial_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), y, gx, N, C, H, W, scratch256);
     DASR_LAUNCH(prelu_grad_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), scratch256, nb, slope, dst, scale);
+    return (int)hipGetLastError();
+}
+
+extern "C" int dasr_prelu_final(const float* partial, int32_t nblocks, int64_t stride, int32_t count, const float* const* slopes, float* const* dsts, float scale,
+                                void* stream) {
+    if (!partial || nblocks <= 0 || stride < nblocks || count <= 0 || !slopes || !dsts) return DASR_EINVAL;
+    DASR_LAUNCH(prelu_final_multi_kernel, dim3(count), dim3(256), 0, as_stream(stream), partial, nblocks, (long long)stride, slopes, dsts, scale);
     return (int)hipGetLastError();
 }
 

@@ -838,6 +838,9 @@ extern "C" int dasr_run_ops(const dasr_op* ops, int32_t n, void* stream0) {
             case DASR_OP_INORM_SECOND:
                 rc = dasr_inorm_second(o.t[0], o.t[1], o.t[2], o.i[0], o.i[1], o.i[2], o.i[3], o.f[0], (const float*)o.p[0], o.t[3], o.i[4], stream);
                 break;
+            case DASR_OP_PRELU_FINAL:
+                rc = dasr_prelu_final((const float*)o.p[0], o.i[0], o.l[0], o.i[1], (const float* const*)o.p[1], (float* const*)o.p[2], o.f[0], stream);
+                break;
             case DASR_OP_BNORM_JVP:
                 rc = dasr_bnorm_lrelu_jvp(o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.i[4], o.f[0], (const float*)o.p[0], (const float*)o.p[1], (const float*)o.p[2],
                                           o.t[2], stream);

@@ -15,7 +15,7 @@ import torch.distributed as dist
 
 # process-level switches that change what a rank COMPUTES (numerics) or how its step is scheduled: they must agree on every rank, or the
 # replicas silently diverge.  Checked by DataParallelGroup at start-up.
-RANK_CONSISTENT_ENV = ('DASR_HR_PREC', 'DASR_RDB_PREC', 'DASR_VGG_PREC', 'DASR_VGG_BWD_PREC', 'DASR_VGG_NOGRAD_PREC', 'DASR_D_PREC', 'DASR_DSN_BWD16', 'DASR_DSN_FWD16',
+RANK_CONSISTENT_ENV = ('DASR_HR_PREC', 'DASR_RDB_PREC', 'DASR_VGG_PREC', 'DASR_VGG_BWD_PREC', 'DASR_VGG_NOGRAD_PREC', 'DASR_D_PREC', 'DASR_DSN_BWD16', 'DASR_DSN_FWD16', 'DASR_DSN_PRELU_FUSED',
                        'DASR_STREAMS', 'DASR_ENQ', 'DASR_CHAIN', 'DASR_CHAIN_FORM', 'DASR_CHAIN_SPLIT', 'DASR_TUNE', 'DASR_HIP_LIB', 'DASR_RCCL_NATIVE', 'DASR_DP_BACKEND', 'DASR_ALLOW_NONFINITE')
 
 

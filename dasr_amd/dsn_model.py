@@ -308,6 +308,7 @@ class _GPlan:
                                   out_W=wi))
 
         self._prelu_ops = []
+        self._prelu_final = None
         o = _op(_lib.OP_SIGMOID_BWD)
         o.t[0], o.t[1], o.i[0], o.i[1], o.i[2], o.i[3], o.t[2] = self.fake.view(), self.g_fake.view(), N, 3, H4, W4, self.gz_out.view()
         b.add(o)
@@ -340,15 +341,26 @@ class _GPlan:
             wgrp.add_block(g16.view(), 4, inp16.view(), 4, 2, H, W, H, W, N, tiles, want_bias=True)
             wgrp.flops += 2.0 * N * H * W * 9 * 64 * 64
 
+        # PReLU-slope gradients of the residual blocks (round 6): the data-gradient conv through conv2 holds dL/dh (its result) and h (its mask) in its epilogue and leaves
+        # one partial of sum_{h <= 0} dL/dh * h per workgroup (dasr_conv_params::prelu_part); ONE dasr_prelu_final launch behind the chain finishes all nb slopes --
+        # instead of a second pass over h and dL/dz per block (dasr_prelu_grad_f16: 2 x 67 MB and two launches each at batch 8 x 256^2).  DASR_DSN_PRELU_FUSED=0: the old form.
+        fuse_prelu = b16 and nb > 0 and os.environ.get('DASR_DSN_PRELU_FUSED', '1') != '0'
+        if fuse_prelu:
+            self.prelu_nblk = N * ceil_div(H, 8) * ceil_div(W, 16)   # >= the workgroups of any tile shape of the launch; unowned entries stay zero
+            self.prelu_part = torch.zeros(nb * self.prelu_nblk, dtype=torch.float32, device=dev)
         for k in range(nb - 1, -1, -1):
             pre = 'res_blocks.%d.' % k
             if b16:
                 inv = 1.0 / self.gscale
                 gs16, g_h16 = self.g_s16[k + 1], self.g_h16[k]
                 wg16_part(pre + 'conv2.', gs16, self.h16[k])
-                b.add(conv_op(pack, pk['r%d_2_b16' % k], gs16.view(), False, 64, H, W, H, W, N, mask=self.h16[k].view(), mask_f32=0,
-                              slope_ptr=sp(pre + 'prelu.weight'), out_bf16=g_h16.view(), out16_f16=1))   # (gscale * dL/ds in, gscale * dL/dh out: no rescaling)
-                prelu_grad(pre + 'prelu.weight', self.h16[k], g_h16, H, W, f16=True)   # (dL/dh is never materialised in f32)
+                o = conv_op(pack, pk['r%d_2_b16' % k], gs16.view(), False, 64, H, W, H, W, N, mask=self.h16[k].view(), mask_f32=0,
+                            slope_ptr=sp(pre + 'prelu.weight'), out_bf16=g_h16.view(), out16_f16=1)   # (gscale * dL/ds in, gscale * dL/dh out: no rescaling)
+                if fuse_prelu:
+                    o.conv.prelu_part = self.prelu_part.data_ptr() + 4 * k * self.prelu_nblk
+                b.add(o)
+                if not fuse_prelu:
+                    prelu_grad(pre + 'prelu.weight', self.h16[k], g_h16, H, W, f16=True)   # (dL/dh is never materialised in f32)
                 wg16_part(pre + 'conv1.', g_h16, self.s16[k])
                 nxt = self.g_s[1] if gs is self.g_s[0] else self.g_s[0]
                 b.add(conv_op(pack, pk['r%d_1_b16' % k], g_h16.view(), False, 64, H, W, H, W, N, alpha=inv, res1=gs.view(), beta1=1.0,
@@ -363,6 +375,16 @@ class _GPlan:
             nxt = self.g_s[1] if gs is self.g_s[0] else self.g_s[0]
             b.add(conv_op(pack, pk['r%d_1_b' % k], self.g_h.view(), True, 64, H, W, H, W, N, res1=gs.view(), beta1=1.0, out_f32=nxt.view()))
             gs = nxt
+        if fuse_prelu:
+            keys = ['res_blocks.%d.prelu.weight' % k for k in range(nb)]
+            self.prelu_slopes = torch.tensor([sp(k_) for k_ in keys], dtype=torch.int64, device=dev)
+            self.prelu_dsts = torch.tensor([P.ptr(k_, P.grad) for k_ in keys], dtype=torch.int64, device=dev)
+            o = _op(_lib.OP_PRELU_FINAL)
+            o.p[0], o.i[0], o.l[0], o.i[1] = self.prelu_part.data_ptr(), self.prelu_nblk, self.prelu_nblk, nb
+            o.p[1], o.p[2], o.f[0] = self.prelu_slopes.data_ptr(), self.prelu_dsts.data_ptr(), 1.0 / self.gscale
+            b.add(o)
+            self._prelu_final = o
+            b.keep += [self.prelu_part, self.prelu_slopes, self.prelu_dsts]
         if wgrp is not None:   # all 2 nb residual-block weight gradients: one launch of 2 nb parts, one reduce
             wgrp.finalize(self.ws, dev)
             for op in wgrp.ops(G):
@@ -385,6 +407,8 @@ class _GPlan:
                 o.f[0] = scale
         for o in self._prelu_ops:
             o.f[0] = scale
+        if getattr(self, '_prelu_final', None) is not None:   # (the fused form: data-parallel factor x 1 / pre-scale of the 16-bit backward)
+            self._prelu_final.f[0] = scale / self.gscale
         self.bwd._arr = None
 
 

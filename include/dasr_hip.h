@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define DASR_ABI_VERSION 19
+#define DASR_ABI_VERSION 20
 #define DASR_EINVAL (-22)
 #define DASR_ECAPTURE (-16)   /* a launch needed a device allocation (the scratch row of a deterministic grid sum, first use per accumulator and stream) while its stream was being captured */
 
@@ -83,6 +83,11 @@ typedef struct {
      *   res1_lo = K' > 0: `res1` is a split 16-bit tensor (same element format as the 16-bit output), read as hi + lo.
      * LDS-DMA kernel only (16-bit input, 3x3 / stride 1 / pad 1, prec 1 or 2). */
     int32_t in_wrap, out16_lo, res1_lo;
+    /* (ABI 20) non-NULL, 64-channel mask-only data-gradient convs of the LDS-DMA kernel (16-bit input, `mask` a 16-bit tensor in the format of the 16-bit output, no other
+     * epilogue term): every workgroup also writes prelu_part[workgroup] = slope * sum over its outputs with mask <= 0 of (conv result * mask) -- the per-workgroup partials
+     * of dL/dslope of the nn.PReLU() (one shared slope, codes/DSN/model.py:29,215) whose output the mask is.  The buffer holds >= N * ceil(H/8) * ceil(W/16) floats, zero at
+     * allocation (entries no workgroup owns stay zero); dasr_prelu_final finishes the sum.  Elsewhere the field must be NULL. */
+    float* prelu_part;
 } dasr_conv_params;
 
 int dasr_conv(const dasr_conv_params* p, void* stream);
@@ -407,6 +412,10 @@ int dasr_prelu_grad(dasr_tensor y, dasr_tensor gx, int32_t N, int32_t C, int32_t
  * the caller folds 1 / pre-scale into `scale`) */
 int dasr_prelu_grad_f16(dasr_tensor y, dasr_tensor gx, int32_t N, int32_t C, int32_t H, int32_t W, const float* slope, float* scratch256,
                         float* dst, float scale, void* stream);
+/* (ABI 20) the second stage alone for `count` slopes in one launch: workgroup k sums partial[k * stride .. + nblocks) in a fixed order and writes
+ * *dsts[k] = scale * sum / (*slopes[k])^2.  The partials are those the data-gradient conv epilogues leave in dasr_conv_params::prelu_part (slope * dL/dh * h per
+ * workgroup): the DSN generator's residual blocks no longer read h and dL/dz a second time (dasr_prelu_grad_f16 did). slopes / dsts: DEVICE arrays of device pointers. */
+int dasr_prelu_final(const float* partial, int32_t nblocks, int64_t stride, int32_t count, const float* const* slopes, float* const* dsts, float scale, void* stream);
 /* un-padded low-pass of the colour loss (FilterLow(padding=False), loss.py:52-56): mode 0 forward (H-k+1 x W-k+1 out),
  * mode 1 adjoint */
 int dasr_lowpass_valid(dasr_tensor x, const float* w, int32_t k, int32_t N, int32_t C, int32_t H, int32_t W, int32_t mode,
@@ -444,7 +453,8 @@ enum { DASR_OP_CONV = 1, DASR_OP_WGRAD = 2, DASR_OP_WGRAD_REDUCE = 3, DASR_OP_PA
        DASR_OP_RDB_CHAIN = 49,   /* dasr_rdb_chain: p[0] device layers, p[1] host layers, i[0] nlayers, p[3] device flags; l[0] device err word */
        /* --wgan with BatchNorm discriminators (round 6).  JVP: t[0] x, t[1] t, i[0..3] N C H W, i[4] group, f[0] slope, p[0] gamma, p[1] beta, p[2] stats, t[2] out.
         * SECOND: t[0] x, t[1] t, t[2] ga, i[0..4] as above, f[0] slope, p[0..2] as above, t[3] out, i[5] accumulate, p[3] dgamma, f[1] pscale */
-       DASR_OP_BNORM_JVP = 50, DASR_OP_BNORM_SECOND = 51 };
+       DASR_OP_BNORM_JVP = 50, DASR_OP_BNORM_SECOND = 51,
+       DASR_OP_PRELU_FINAL = 52   /* dasr_prelu_final: p[0] partial, i[0] nblocks, l[0] stride, i[1] count, p[1] slopes, p[2] dsts, f[0] scale */ };
 
 typedef struct {
     int32_t op;  int32_t i[8];  float f[4];  int64_t l[4];  void* p[4];  dasr_tensor t[5];
