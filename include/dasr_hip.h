@@ -113,10 +113,13 @@ int dasr_conv_chain(const dasr_conv_params* dev_layers, const dasr_conv_params* 
  * alpha, one or two fp32 residuals -> fp32 stream (+ 16-bit planes of the next slab, may be absent on the last block); data gradient: LeakyReLU' mask ->
  * 16-bit planes, alpha, residuals -> fp32 (+ 16-bit)) -- bit-identical results -- but every 16-channel chunk of the slab is staged in LDS ONCE and
  * multiplied into the accumulators of every conv of the block that consumes it (12 chunks per block and tile instead of 40), one workgroup of 8 waves per
- * CU.  Geometry: tiles of 16 x 32 pixels, T per image; image n on XCD n % 8; q workgroups per XCD (the largest multiple of T that is <= 32, divides the N T / 8
- * tiles of an XCD and leaves at most 8 tiles per workgroup), i.e. a launch of 8 q <= 256 workgroups (csrc/rdb_is.h).  Constraints (DASR_EINVAL otherwise): bf16
- * storage, nlayers a multiple of 5, N a multiple of 8, T <= 32 and such a q exists (16 x 128^2: q 32, two tiles each; 8 x 128^2: q 32, one tile; 16 crops of 32 x 32: q 4).  flags / err / operational contract: as dasr_conv_chain (the
- * launch needs all 256 CUs of the device to itself: 256 workgroups with 160 KB of LDS each, all resident). */
+ * CU.  Geometry: tiles of 16, 8 or 4 rows x 32 pixels (8 waves x 2 rows, 8 x 1, 4 x 1), T per image; image n on XCD n % 8; q workgroups per XCD (the largest multiple of
+ * T that is <= 32, divides the N T / 8 tiles of an XCD and leaves at most 8 tiles per workgroup), i.e. a launch of 8 q <= 256 workgroups (csrc/rdb_is.h); the launcher takes
+ * the height that minimises (tiles per workgroup) x (measured chain time of one tile at that height).  Constraints (DASR_EINVAL otherwise): bf16 storage, nlayers a multiple
+ * of 5, N a multiple of 8, T <= 32 and such a q exists for one of the heights (16 x 128^2: 16 rows, q 32, two tiles each; 8 x 128^2: 16 rows, one tile; 16 crops of
+ * 32 x 32: 4 rows, q 16).  flags: N * ceil(H / 4) * ceil(W / 32) + 8 words, zero at allocation (sized for the finest tiles whichever height runs; the last eight: per-XCD
+ * ticket counters); err / operational contract: as dasr_conv_chain (the launch needs all 256 CUs of the device to itself: up to 256 workgroups with 160 KB of LDS each, all
+ * resident). */
 int dasr_rdb_chain(const dasr_conv_params* dev_layers, const dasr_conv_params* host_layers, int32_t nlayers, uint32_t* dev_flags, int32_t* dev_err,
                    void* stream);
 /* kernel-variant knobs for A/B runs (bench.py --sweep / --tune); defaults are the tuned choice.
