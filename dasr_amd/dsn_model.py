@@ -346,7 +346,7 @@ class _GPlan:
         # instead of a second pass over h and dL/dz per block (dasr_prelu_grad_f16: 2 x 67 MB and two launches each at batch 8 x 256^2).  DASR_DSN_PRELU_FUSED=0: the old form.
         fuse_prelu = b16 and nb > 0 and os.environ.get('DASR_DSN_PRELU_FUSED', '1') != '0'
         if fuse_prelu:
-            self.prelu_nblk = N * ceil_div(H, 8) * ceil_div(W, 16)   # >= the workgroups of any tile shape of the launch; unowned entries stay zero
+            self.prelu_nblk = N * ceil_div(H, 4) * ceil_div(W, 16)   # >= the workgroups of any tile shape a conv launch may take (16 x 32 ... 4 x 32 pixels); unowned entries stay zero
             self.prelu_part = torch.zeros(nb * self.prelu_nblk, dtype=torch.float32, device=dev)
         for k in range(nb - 1, -1, -1):
             pre = 'res_blocks.%d.' % k

@@ -85,7 +85,7 @@ typedef struct {
     int32_t in_wrap, out16_lo, res1_lo;
     /* (ABI 20) non-NULL, 64-channel mask-only data-gradient convs of the LDS-DMA kernel (16-bit input, `mask` a 16-bit tensor in the format of the 16-bit output, no other
      * epilogue term): every workgroup also writes prelu_part[workgroup] = slope * sum over its outputs with mask <= 0 of (conv result * mask) -- the per-workgroup partials
-     * of dL/dslope of the nn.PReLU() (one shared slope, codes/DSN/model.py:29,215) whose output the mask is.  The buffer holds >= N * ceil(H/8) * ceil(W/16) floats, zero at
+     * of dL/dslope of the nn.PReLU() (one shared slope, codes/DSN/model.py:29,215) whose output the mask is.  The buffer holds >= N * ceil(H/4) * ceil(W/16) floats (one per workgroup of any tile shape the launcher may choose), zero at
      * allocation (entries no workgroup owns stay zero); dasr_prelu_final finishes the sum.  Elsewhere the field must be NULL. */
     float* prelu_part;
 } dasr_conv_params;

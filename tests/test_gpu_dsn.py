@@ -209,6 +209,44 @@ def test_deresnet_forward_backward():
     print('De_resnet worst grad rel err %.2e, PReLU slopes %.2e' % (worst, slopes))
 
 
+@pytest.mark.parametrize('shape', [(2, 48, 64), (1, 40, 44), (3, 64, 32)])
+def test_prelu_slope_gradient_from_the_conv_epilogue(shape, monkeypatch, margins):
+    """round 6 (dasr_conv_params::prelu_part + dasr_prelu_final): the PReLU-slope gradients of the residual blocks taken inside the data-gradient conv's epilogue against
+    the two-pass form (dasr_prelu_grad_f16 on the stored h and dL/dz) on the same plan inputs -- every other gradient must be bit-identical (nothing else changes), the
+    slopes agree to the rounding of dL/dz to f16 that only the two-pass form sees (a slope gradient is a small difference of large sums: 5e-4 per term shows as up to
+    3e-3 of the sum; tolerance = north_star's 1e-2 for gradients); odd sizes: partial tiles contribute nothing"""
+    dev = _gpu()
+    from dasr_amd.dsn_model import DeResnetHIP
+    from oracle import dsn
+    from oracle.gen_golden_dsn import dsn_state
+    sd = dsn_state(dsn.DeResnet().state_dict(), 21, 0.5)
+    n, h, w = shape
+    g = torch.Generator().manual_seed(13)
+    x, gy = torch.rand(n, 3, h, w, generator=g), torch.randn(n, 3, h // 4, w // 4, generator=g)
+    grads = {}
+    for fused in ('1', '0'):
+        monkeypatch.setenv('DASR_DSN_PRELU_FUSED', fused)
+        G = DeResnetHIP(8, device=dev)
+        G.load_state_dict(sd)
+        p = G.plan(n, h, w)
+        assert (p._prelu_final is not None) == (fused == '1')
+        p.x_nchw.copy_(x)
+        p.fwd.run()
+        p.g_fake.t.copy_(to_blocked(gy, dev).t)
+        p.bwd.run()
+        torch.cuda.synchronize()
+        grads[fused] = {k: v.clone() for k, v in G.params.grad_dict().items()}
+    worst = 0.0
+    for k, v in grads['1'].items():
+        if k.startswith('res_blocks.') and k.endswith('prelu.weight'):
+            e = float((v - grads['0'][k]).abs() / grads['0'][k].abs().clamp_min(1e-12))
+            worst = max(worst, e)
+            assert e < 1e-2, (k, float(v), float(grads['0'][k]))
+        else:
+            assert torch.equal(v, grads['0'][k]), k
+    margins('DSN generator %d x %d x %d: PReLU-slope gradients from the conv epilogue vs the two-pass form: worst rel diff %.2e (tol 1e-2), everything else bit-identical' % (n, h, w, worst))
+
+
 @pytest.mark.parametrize('case', ['dsn_gau5_inst_b2_128', 'dsn_wavelet_inst_b2_128', 'dsn_avg5_inst_b1_160', 'dsn_gau5_inst_b1_256_lpips',
                                   'dsn_wavelet_nld_s2_b2_128', 'dsn_gau5_nld_s1_b1_128', 'dsn_dsgan_gau5_inst_b2_128', 'dsn_gau5_inst_b3_128_ragan',
                                   'dsn_gau5_batch_b2_128', 'dsn_avg5_batch_b3_128_ragan', 'dsn_wavelet_sum_inst_b2_128',
