@@ -594,6 +594,7 @@ def main():
         # LPIPS criterion): 32 tiles of 16 x 32 pixels per conv launch -- what a user who drops that JSON in gets
         sec_ship = argparse.Namespace(**vars(sec_l))
         sec_ship.lr_size, sec_ship.sec_batch, sec_ship.sec_label = 32, 16, 'shipped shape (train_DASR.json: batch_size 8, HR_size 128)'
+        sec_ship.steps, sec_ship.warmup = max(16, 2 * a.steps), 4   # (a 7-ms step: four timed steps are one host hiccup away from twice the number -- seen once, 15.1 ms, round 6)
         for fn in (lambda: bench_srn(sec, dp, True, as_secondary=True), lambda: bench_dsn(sec, dp, as_secondary=True),
                    lambda: bench_srn(sec_l, dp, True, as_secondary=True), lambda: bench_dsn(sec_l, dp, as_secondary=True),
                    lambda: bench_srn(sec_ship, dp, True, as_secondary=True)):
