@@ -121,7 +121,8 @@ __device__ __forceinline__ void st128(u32x4 v, __amdgpu_buffer_rsrc_t r, unsigne
 // BMODE / BH (rdb_is_kernel: a conv's flag waits for the acknowledgement of its stores, and the neighbours need only the tile's border): 1 = only the border pixels of the
 // BH x 32-pixel tile are computed and stored (everything else is out of range: no loads, no stores), 2 = the 16-bit output skips the border pixels (already stored by a
 // BMODE 1 call), everything else is complete.  0 = plain.
-template <bool IN_F32, int MT, int NT, int STRIDE, int EPI, int F16OUT = -1, bool PRE = false, bool FSC1 = false, bool BIAS_STAGED = false, bool CONST_SLOPE = false, int BMODE = 0, int BH = 16>
+template <bool IN_F32, int MT, int NT, int STRIDE, int EPI, int F16OUT = -1, bool PRE = false, bool FSC1 = false, bool BIAS_STAGED = false, bool CONST_SLOPE = false, int BMODE = 0, int BH = 16,
+          bool PACC = false>
 __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 (&acc)[MT][NT], char* smem, float bias_reg, int tid, int mg, int n,
                                               int oy0, int ox0, const MaskPre<NT * MT>* pre = nullptr) {
     const int lane = tid & 63, wave = tid >> 6, nn = lane & 31, kh2 = lane >> 5;
@@ -149,9 +150,11 @@ __device__ __forceinline__ void conv_epilogue(const dasr_conv_params& p, f32x16 
     // front of the mask factor is dL/dh, the mask tensor is h = PReLU(z), and dL/da = sum_{h <= 0} dL/dh * z = sum v * h / a.  The 64-channel mask-only epilogue of the
     // LDS-DMA kernel (EPI 68, MT 2: the residual blocks of the DSN generator; a 16-bit mask in the format of the 16-bit output) accumulates slope * v * h per lane and
     // writes ONE partial per workgroup to p.prelu_part[blockIdx.x]; dasr_prelu_final sums them in a fixed order and divides by a^2 (the layout of dasr_prelu_grad's
-    // partials, whose two passes over h and dL/dz this replaces).  Run-time uniform switch: the HR-tail launches of the same instantiation pass NULL.
-    constexpr bool PACC_OK = EPI == 68 && MT == 2 && !IN_F32 && !FSC1 && !PRE && BMODE == 0;
-    const bool pacc_on = PACC_OK && p.prelu_part != nullptr;
+    // partials, whose two passes over h and dL/dz this replaces).  PACC: the caller (conv_glds_kernel) instantiates the epilogue twice and takes this one when
+    // p.prelu_part is set -- the HR-tail launches of the same kernel run the plain code.
+    constexpr bool PACC_OK = PACC && EPI == 68 && MT == 2 && !IN_F32 && !FSC1 && !PRE && BMODE == 0;
+    static_assert(!PACC || PACC_OK, "the slope-gradient partials exist for the 64-channel mask-only epilogue of the LDS-DMA kernel");
+    constexpr bool pacc_on = PACC_OK;
     float pacc = 0.f;
     const __amdgpu_buffer_rsrc_t rmask = make_rsrc((const char*)p.mask.p + (size_t)n * p.mask.n_stride * MSZ);
     const __amdgpu_buffer_rsrc_t rr1 = make_rsrc((const char*)p.res1.p + (size_t)n * p.res1.n_stride * ((G && p.res1_lo) ? 2 : 4));
@@ -1361,7 +1364,12 @@ __global__ __launch_bounds__((NW + (RING >= 2 ? 1 : 0)) * 64, RING >= 2 ? 3 : (N
     }
     TRACE_STAMP(4);
     if constexpr (FLAGS) __builtin_amdgcn_s_barrier();   // the waves drift: nobody may still read fragments when the epilogue reuses LDS for the bias
-    conv_epilogue<false, MT, NT, 1, R1_PRE ? (EPI & ~8) : EPI, F16 ? 1 : 0, PRE>(p, acc, smem, bias_reg, tid, mg, n, oy0, ox0, &mpre);
+    if constexpr (EPI == 68 && MT == 2 && !PRE) {   // (the DSN generator's data-gradient convs also leave the PReLU-slope partials: dasr_conv_params::prelu_part)
+        if (p.prelu_part) conv_epilogue<false, MT, NT, 1, EPI, F16 ? 1 : 0, false, false, false, false, 0, 16, true>(p, acc, smem, bias_reg, tid, mg, n, oy0, ox0, &mpre);
+        else conv_epilogue<false, MT, NT, 1, EPI, F16 ? 1 : 0, PRE>(p, acc, smem, bias_reg, tid, mg, n, oy0, ox0, &mpre);
+    } else {
+        conv_epilogue<false, MT, NT, 1, R1_PRE ? (EPI & ~8) : EPI, F16 ? 1 : 0, PRE>(p, acc, smem, bias_reg, tid, mg, n, oy0, ox0, &mpre);
+    }
     TRACE_STAMP(6);
 #ifdef DASR_TRACE
     __builtin_amdgcn_s_waitcnt(0);
@@ -2144,7 +2152,7 @@ int launch_ring3(const dasr_conv_params& p, hipStream_t s) {
     static bool attr_set = false;
     auto kfn = conv_ring3_kernel<EPI>;
     if ((p.cin & 15) || p.kh != 3 || p.stride != 1 || p.pad != 1 || p.ups || p.in_f32 || p.prec != 1 || (p.pad_x >= 0 && p.pad_x != 1) || p.in_stride > 1 ||
-        p.cout > 32 || p.mt != 1)
+        p.cout > 32 || p.mt != 1 || p.prelu_part)
         return DASR_EINVAL;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
@@ -2167,6 +2175,7 @@ int launch_glds(const dasr_conv_params& p, hipStream_t s) {
     if ((p.cin & 15) || p.kh != 3 || p.stride != 1 || p.pad != 1 || p.in_f32 || p.prec != (F16 ? 2 : 1) || (p.pad_x >= 0 && p.pad_x != 1) || p.in_stride > 1)
         return DASR_EINVAL;
     if (p.out_bf16.p && (p.out16_f16 != 0) != F16) return DASR_EINVAL;   // the 16-bit output format of this kernel is its operand format (compile time)
+    if (p.prelu_part && !(EPI == 68 && MT == 2 && RING == 0 && ABL == 0)) return DASR_EINVAL;   // the slope-gradient partials exist in the 64-channel mask-only epilogue alone
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
@@ -2188,6 +2197,7 @@ int launch(const dasr_conv_params& p, hipStream_t s) {
     static bool attr_set = false;
     auto kfn = conv_kernel<PREC, IN_F32, MT, KH, STRIDE, NT, KS, DBUF, MODE, EPI>;
     if (p.cin % (16 * KS)) return DASR_EINVAL;
+    if (p.prelu_part) return DASR_EINVAL;   // (dasr_conv_params::prelu_part: the LDS-DMA kernel's 64-channel mask-only epilogue only -- never silently dropped)
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + 16));
         attr_set = true;
@@ -2308,7 +2318,7 @@ extern "C" int dasr_conv_chain(const dasr_conv_params* dev_layers, const dasr_co
         // one geometry for the whole chain: dense 3x3 / stride 1 / pad 1 on 16-bit tensors, every layer one m-group of its workgroup shape
         if (p.kh != 3 || p.stride != 1 || p.pad != 1 || p.in_f32 || p.prec != p0.prec || (p.cin & 15) || p.cin <= 0 || p.ups || p.in_wrap || p.out16_lo || p.res1_lo) return DASR_EINVAL;
         if (p.Hin != p0.Hin || p.Win != p0.Win || p.Hout != p0.Hin || p.Wout != p0.Win || p.N != p0.N || p.out_stride > 1 || p.in_stride > 1 || p.out_W || p.out_oy || p.out_ox) return DASR_EINVAL;
-        if (!(p.mt == 1 || p.mt == 2) || p.cout != 32 * p.mt || !p.w || !p.in.p || p.slope_ptr || p.mask_f32) return DASR_EINVAL;
+        if (!(p.mt == 1 || p.mt == 2) || p.cout != 32 * p.mt || !p.w || !p.in.p || p.slope_ptr || p.mask_f32 || p.prelu_part) return DASR_EINVAL;
         if ((p.out16_f16 != 0) != f16 || (p.prec != 1 && p.prec != 2)) return DASR_EINVAL;
         const int epi = classify_epi(p);
         // forward: conv1-4 bias + LeakyReLU -> 16-bit planes (67), conv5 bias, alpha, one / two fp32 residuals -> fp32 + 16-bit (233 / 249);
@@ -2399,7 +2409,7 @@ extern "C" int dasr_rdb_chain(const dasr_conv_params* dev_layers, const dasr_con
         const int k = i % 5;
         if (p.kh != 3 || p.stride != 1 || p.pad != 1 || p.in_f32 || p.prec != 1 || p.ups || p.in_wrap || p.out16_lo || p.res1_lo || p.out16_f16) return DASR_EINVAL;
         if (p.Hin != p0.Hin || p.Win != p0.Win || p.Hout != p0.Hin || p.Wout != p0.Win || p.N != p0.N || p.out_stride > 1 || p.in_stride > 1 || p.out_W || p.out_oy || p.out_ox) return DASR_EINVAL;
-        if (p.cin != 64 + 32 * k || p.mt != (k == 4 ? 2 : 1) || p.cout != 32 * p.mt || !p.w || !p.in.p || p.slope_ptr || p.mask_f32) return DASR_EINVAL;
+        if (p.cin != 64 + 32 * k || p.mt != (k == 4 ? 2 : 1) || p.cout != 32 * p.mt || !p.w || !p.in.p || p.slope_ptr || p.mask_f32 || p.prelu_part) return DASR_EINVAL;
         if (p.in.p != pb.in.p || p.in.n_stride != pb.in.n_stride || p.in.cb_stride != pb.in.cb_stride) return DASR_EINVAL;   // one slab per dense block
         const int epi = classify_epi(p);
         // forward: conv1-4 bias + LeakyReLU -> 16-bit planes (67), conv5 bias, alpha, one / two fp32 residuals -> fp32 (+ 16-bit) (233 / 249, 169 / 185);

@@ -115,6 +115,55 @@ def test_conv_forward_matches_torch(case):
         assert float(pad_part.abs().max()) == 0.0
 
 
+def test_prelu_slope_partials_from_the_mask_epilogue():
+    """round 6 (ABI 20): dasr_conv_params::prelu_part -- the 64-channel mask-only data-gradient conv of the LDS-DMA kernel (f16 tensors, learned slope) leaves
+    slope * sum_{h <= 0} conv * h per workgroup; dasr_prelu_final turns the partials of several such convs into dL/dslope = sum conv * h / slope.  Against fp64 torch
+    on an odd-sized image (partial tiles), and refused (DASR_EINVAL) by every launch that has no such epilogue"""
+    dev = _gpu()
+    from dasr_amd import _lib
+    from dasr_amd.engine import BTensor, OpList, conv_op, ceil_div, Op
+    L = _lib.lib()
+    N, C_, H, W = 2, 64, 21, 37
+    w, b, P, pack, ref = make_conv(C_, C_, 3, 2, 2, dev, 17)   # prec 2: f16 operands, one pass
+    g = torch.Generator().manual_seed(23)
+    f16r = lambda t: t.half().float()
+    x, h = f16r(torch.randn(N, C_, H, W, generator=g)), f16r(torch.randn(N, C_, H, W, generator=g))
+    slopes = torch.tensor([0.25, 0.1], device=dev)
+    nblk = N * ceil_div(H, 4) * ceil_div(W, 16)
+    part = torch.zeros(2 * nblk, device=dev)
+    dst = torch.zeros(2, device=dev)
+    xb, hb = BTensor(N, C_, H, W, False, dev, f16=True), BTensor(N, C_, H, W, False, dev, f16=True)
+    for bt, src in ((xb, x), (hb, h)):
+        t = src.reshape(N, C_ // 16, 16, H, W).permute(0, 1, 3, 4, 2).contiguous()
+        bt.t.copy_(t.half())
+    ob = BTensor(N, C_, H, W, False, dev, f16=True)
+    ops = OpList()
+    for k in range(2):   # two "blocks": the same conv under two slopes
+        o = conv_op(pack, ref, xb.view(), False, C_, H, W, H, W, N, mask=hb.view(), mask_f32=0, slope_ptr=slopes.data_ptr() + 4 * k, out_bf16=ob.view(), out16_f16=1)
+        o.conv.prelu_part = part.data_ptr() + 4 * k * nblk
+        ops.add(o)
+    sl = torch.tensor([slopes.data_ptr(), slopes.data_ptr() + 4], dtype=torch.int64, device=dev)
+    ds = torch.tensor([dst.data_ptr(), dst.data_ptr() + 4], dtype=torch.int64, device=dev)
+    ops.run()
+    _lib.check(L.dasr_prelu_final(part.data_ptr(), nblk, nblk, 2, sl.data_ptr(), ds.data_ptr(), 0.5, None))
+    torch.cuda.synchronize()
+    y = F.conv2d(x.double(), f16r(w).double(), None, padding=1)
+    want = 0.5 * (y * h.double())[h <= 0].sum()   # dL/da = sum_{h <= 0} dL/dh * h / a, times `scale`
+    for k, a in enumerate((0.25, 0.1)):
+        assert abs(float(dst[k]) - float(want) / a) < 2e-4 * abs(float(want) / a) + 1e-3, (k, float(dst[k]), float(want) / a)
+    # ... and nowhere else: an f32-tensor conv (register-staged kernel), a 32-channel LDS-DMA conv
+    w2, b2, P2, pack2, ref2 = make_conv(32, 64, 3, 1, 1, dev, 5)
+    xb16, o16 = BTensor(N, 64, H, W, False, dev), BTensor(N, 32, H, W, False, dev)
+    bad = conv_op(pack2, ref2, xb16.view(), False, 64, H, W, H, W, N, mask=o16.view(), mask_f32=0, out_bf16=o16.view())
+    bad.conv.prelu_part = part.data_ptr()
+    assert L.dasr_conv(C.byref(bad.conv), None) == -22
+    w3, b3, P3, pack3, ref3 = make_conv(64, 64, 3, 1, 3, dev, 6)
+    xf, of = BTensor(N, 64, H, W, True, dev), BTensor(N, 64, H, W, True, dev)
+    bad = conv_op(pack3, ref3, xf.view(), True, 64, H, W, H, W, N, mask=xf.view(), mask_f32=1, out_f32=of.view())
+    bad.conv.prelu_part = part.data_ptr()
+    assert L.dasr_conv(C.byref(bad.conv), None) == -22
+
+
 def test_product_library_has_one_dense_conv_family():
     """round 4: the A/B variants of rounds 1-3 (first-generation tilings, ring / loader / flag forms, dasr_set_tuning keys 1-6) live in
     libdasr_hip_ablate.so only; the product library accepts the defaults and the workgroup-shape rule of the Cout = 64 launches (key 2)"""
