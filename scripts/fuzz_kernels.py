@@ -175,6 +175,57 @@ def run_wgrad(c, dev, seed):
     return {'w': (rel(gd['w'], wr.grad.float()), 3e-5), 'b': (rel(gd['b'], go.double().sum((0, 2, 3)).float()), 3e-5)}
 
 
+def draw_wgrad3(rng):
+    """the GROUPED 3x3 / stride-1 weight gradient on 16-bit tensors (wgrad3_ld_kernel, register-window form of round 6): one 64-channel input block x one to three
+    32-oc tiles per part, several parts per launch, partial pixel tiles, 32-channel input blocks, nearest-x2 input, f16 / bf16"""
+    c = {'N': rng.choice([1, 2, 3]), 'cin': rng.choice([32, 64, 96, 128]), 'cout': rng.choice([32, 64, 96, 128, 160]), 'f16': rng.random() < 0.5,
+         'ups': rng.random() < 0.2}
+    c['H'], c['W'] = rng.randint(2, 40), rng.randint(2, 56)
+    return c
+
+
+def run_wgrad3(c, dev, seed):
+    from dasr_amd.engine import OpList, ParamStore, WgradGroup3, Workspace, BTensor, ceil_div
+    g = torch.Generator().manual_seed(seed)
+    N, cin, cout, H, W, ups, f16 = c['N'], c['cin'], c['cout'], c['H'], c['W'], int(c['ups']), c['f16']
+    Hi, Wi = H, W
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    rq = f16r if f16 else bf16r
+    x, go = rq(torch.randn(N, cin, Hi, Wi, generator=g)), rq(torch.randn(N, cout, Ho, Wo, generator=g))
+    P = ParamStore([('w', (cout, cin, 3, 3)), ('b', (cout,))], dev)
+    xb, gb = BTensor(N, cin, Hi, Wi, False, dev, f16=f16), BTensor(N, cout, Ho, Wo, False, dev, f16=f16)
+    for bt, src, C_ in ((xb, x, cin), (gb, go, cout)):
+        t = torch.zeros(src.shape[0], bt.planes * 16, src.shape[2], src.shape[3])
+        t[:, :C_] = src
+        bt.t.copy_(t.reshape(src.shape[0], bt.planes, 16, src.shape[2], src.shape[3]).permute(0, 1, 3, 4, 2).contiguous().to(bt.t.dtype))
+    ws = Workspace(dev)
+    grp = WgradGroup3()
+    octs = list(range(0, cout, 32))
+    for c0 in range(0, cin, 64):
+        blk = min(64, cin - c0)
+        for k0 in range(0, len(octs), 3):
+            sub = octs[k0:k0 + 3]
+            tiles = [dict(dst_w_off=P.off('w'), dst_b_off=P.off('b') if c0 == 0 else None, cout=cout, cin=cin, oc0=oc0, c0=c0, n_ctiles=min(2, ceil_div(blk, 32))) for oc0 in sub]
+            grp.add_block(gb.view(sub[0]), min(2 * len(sub), gb.planes - sub[0] // 16), xb.view(c0), ceil_div(blk, 16), ceil_div(blk, 32), Hi, Wi, Ho, Wo, N, tiles,
+                          want_bias=(c0 == 0), ups=ups)
+    grp.f16, grp.g_scale, grp.flops = f16, 1.0, 0.0
+    grp.finalize(ws, dev, target_wgs=rng_targets[seed % len(rng_targets)])
+    wl = OpList()
+    for o in grp.ops(P.grad.data_ptr()):
+        wl.add(o)
+    ws.finalize()
+    wl.run()
+    torch.cuda.synchronize()
+    xr = F.interpolate(x, scale_factor=2, mode='nearest') if ups else x
+    wr = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(xr.double(), wr, None, padding=1) * go.double()).sum().backward()
+    gd = P.grad_dict()
+    return {'w': (rel(gd['w'], wr.grad.float()), 3e-5), 'b': (rel(gd['b'], go.double().sum((0, 2, 3)).float()), 3e-5)}
+
+
+rng_targets = (256, 64, 17, 1)   # workgroup targets -> split counts from "every tile its own workgroup" down to ONE workgroup walking all tiles
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=300)
@@ -184,12 +235,13 @@ def main():
     engine.ensure_runtime_ready()
     dev = torch.device('cuda')
     rng = random.Random(a.seed)
-    fails, worst, n = 0, {}, {'conv': 0, 'wgrad': 0}
+    fails, worst, n = 0, {}, {'conv': 0, 'wgrad': 0, 'wgrad3': 0}
     for i in range(a.cases):
-        kind = 'conv' if rng.random() < 0.75 else 'wgrad'
-        c = draw_conv(rng) if kind == 'conv' else draw_wgrad(rng)
+        u = rng.random()
+        kind = 'conv' if u < 0.65 else ('wgrad' if u < 0.82 else 'wgrad3')
+        c = draw_conv(rng) if kind == 'conv' else (draw_wgrad(rng) if kind == 'wgrad' else draw_wgrad3(rng))
         try:
-            errs = (run_conv if kind == 'conv' else run_wgrad)(c, dev, 1000 + i)
+            errs = (run_conv if kind == 'conv' else (run_wgrad if kind == 'wgrad' else run_wgrad3))(c, dev, 1000 + i)
         except Exception as e:   # a refused geometry is reported like a wrong result: the drawn domain is the one the host code uses
             print('CASE %d %s %s raised %s' % (i, kind, c, repr(e)[:200]))
             fails += 1
@@ -201,7 +253,7 @@ def main():
             if not e <= tol:
                 print('CASE %d %s %s: %s error %.3e (tol %.1e)' % (i, kind, c, k, e, tol))
                 fails += 1
-    print('ran %d conv + %d weight-gradient cases, %d failures' % (n['conv'], n['wgrad'], fails))
+    print('ran %d conv + %d weight-gradient + %d grouped 3x3 weight-gradient cases, %d failures' % (n['conv'], n['wgrad'], n['wgrad3'], fails))
     for key in sorted(worst):
         print('  worst %-28s %.2e' % (' / '.join(key), worst[key]))
     sys.exit(1 if fails else 0)
